@@ -1,0 +1,438 @@
+"""ctypes binding of the C ABI in include/fd_hip.h (libfd_hip.so).
+
+This is plumbing for tests/bench only: the product is the shared library.  There is NO CPU
+fallback -- loading fails loudly when the HIP extension has not been built, and every compute call
+raises FdError when no gfx950 device is usable.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfd_hip.so")
+
+FD_OK, FD_ERR_INVALID_ARGUMENT, FD_ERR_RUNTIME, FD_ERR_LOGIC, FD_ERR_HIP, FD_ERR_CAPACITY = range(6)
+FD_LAYER_NONE, FD_LAYER_GRADBIN, FD_LAYER_LBP = 0, 1, 2
+FD_KERNEL_LINEAR, FD_KERNEL_POLY, FD_KERNEL_RBF, FD_KERNEL_HIK = 0, 1, 2, 3
+FD_DTYPE_U8, FD_DTYPE_F32 = 0, 1
+
+
+class FdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("fd_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class fd_wvm_model(C.Structure):
+    _fields_ = [("filter_w", C.c_int32), ("filter_h", C.c_int32), ("num_filters", C.c_int32), ("num_used", C.c_int32),
+                ("num_per_level", C.c_int32), ("basis_param", C.c_float), ("bias", C.c_float),
+                ("thresholds", C.POINTER(C.c_float)), ("hk_weights", C.POINTER(C.c_float)), ("pp", C.POINTER(C.c_double)),
+                ("val_off", C.POINTER(C.c_int32)), ("val", C.POINTER(C.c_double)), ("rec_off", C.POINTER(C.c_int32)),
+                ("rects", C.POINTER(C.c_uint8)), ("logistic_a", C.c_double), ("logistic_b", C.c_double)]
+
+
+class fd_svm_model(C.Structure):
+    _fields_ = [("kernel", C.c_int32), ("p0", C.c_double), ("p1", C.c_double), ("p2", C.c_double), ("num_sv", C.c_int32),
+                ("dim", C.c_int32), ("dtype", C.c_int32), ("support_vectors", C.c_void_p), ("coefficients", C.POINTER(C.c_float)),
+                ("bias", C.c_float), ("threshold", C.c_float), ("logistic_a", C.c_double), ("logistic_b", C.c_double)]
+
+
+class fd_detection(C.Structure):
+    _fields_ = [("cx", C.c_int32), ("cy", C.c_int32), ("w", C.c_int32), ("h", C.c_int32), ("layer", C.c_int32),
+                ("lx", C.c_int32), ("ly", C.c_int32), ("level", C.c_int32), ("positive", C.c_int32), ("score", C.c_float),
+                ("probability", C.c_double)]
+
+
+class fd_hog_params(C.Structure):
+    _fields_ = [("patch_w", C.c_int32), ("patch_h", C.c_int32), ("step_x", C.c_int32), ("step_y", C.c_int32),
+                ("bins", C.c_int32), ("cell_size", C.c_int32), ("block_size", C.c_int32), ("signed_and_unsigned", C.c_int32)]
+
+
+class fd_sdm_model(C.Structure):
+    _fields_ = [("num_landmarks", C.c_int32), ("num_steps", C.c_int32), ("mean", C.POINTER(C.c_float)),
+                ("R", C.POINTER(C.POINTER(C.c_float))), ("R_rows", C.POINTER(C.c_int32)), ("hog_variant", C.c_int32)]
+
+
+DET_DTYPE = np.dtype([("cx", "<i4"), ("cy", "<i4"), ("w", "<i4"), ("h", "<i4"), ("layer", "<i4"), ("lx", "<i4"),
+                      ("ly", "<i4"), ("level", "<i4"), ("positive", "<i4"), ("score", "<f4"), ("probability", "<f8")],
+                     align=True)
+assert DET_DTYPE.itemsize == C.sizeof(fd_detection)
+
+_lib = None
+
+# every symbol include/fd_hip.h declares (checked by tests/test_capi_symbols.py against the header)
+_SIGS = {
+    "fd_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "fd_ctx_destroy": (None, [C.c_void_p]),
+    "fd_last_error": (C.c_char_p, [C.c_void_p]),
+    "fd_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "fd_version": (C.c_char_p, []),
+    "fd_pyramid_create": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]),
+    "fd_pyramid_create_inc": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_void_p)]),
+    "fd_pyramid_destroy": (None, [C.c_void_p]),
+    "fd_pyramid_set_layer_filter": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "fd_pyramid_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "fd_pyramid_octave_layer_count": (C.c_int, [C.c_void_p]),
+    "fd_pyramid_incremental_scale": (C.c_double, [C.c_void_p]),
+    "fd_pyramid_layer_count": (C.c_int, [C.c_void_p]),
+    "fd_pyramid_layer_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "fd_pyramid_layer_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "fd_pyramid_window_count": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]),
+    "fd_pyramid_windows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                     C.POINTER(C.c_int64)]),
+    "fd_greyworld": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "fd_histeq64_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "fd_wvm_create": (C.c_int, [C.c_void_p, C.POINTER(fd_wvm_model), C.POINTER(C.c_void_p)]),
+    "fd_wvm_destroy": (None, [C.c_void_p]),
+    "fd_svm_create": (C.c_int, [C.c_void_p, C.POINTER(fd_svm_model), C.POINTER(C.c_void_p)]),
+    "fd_svm_destroy": (None, [C.c_void_p]),
+    "fd_svm_distance_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "fd_detect_wvm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
+    "fd_detect_five_stage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
+    "fd_overlap_elimination": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.POINTER(C.c_int)]),
+    "fd_block_nms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "fd_hog_feature_length": (C.c_int, [C.POINTER(fd_hog_params)]),
+    "fd_detect_hog_svm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(fd_hog_params), C.c_void_p, C.c_int64,
+                                    C.POINTER(C.c_int64), C.c_void_p]),
+    "fd_extract_hog": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fd_hog_params), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "fd_bench_hog_svm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(fd_hog_params), C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int64)]),
+    "fd_bench_wvm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "fd_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
+    "fd_sdm_create": (C.c_int, [C.c_void_p, C.POINTER(fd_sdm_model), C.POINTER(C.c_void_p)]),
+    "fd_sdm_destroy": (None, [C.c_void_p]),
+    "fd_sdm_descriptors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
+    "fd_sdm_fit_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                   C.c_void_p]),
+}
+
+
+def lib():
+    """Loads libfd_hip.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            f = getattr(l, name)  # AttributeError if the ABI lost a symbol
+            f.restype = res
+            f.argtypes = args
+        _lib = l
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _c(arr, dtype):
+    return np.ascontiguousarray(arr, dtype=dtype)
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        self.h = C.c_void_p()
+        rc = lib().fd_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self.h))
+        if rc != FD_OK:
+            raise FdError(rc, "fd_ctx_create failed (no usable gfx950 device?)")
+
+    def check(self, rc):
+        if rc != FD_OK:
+            raise FdError(rc, lib().fd_last_error(self.h).decode())
+
+    def synchronize(self):
+        self.check(lib().fd_ctx_synchronize(self.h))
+
+    def close(self):
+        if self.h:
+            lib().fd_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def last_kernel_ms(self):
+        name = C.c_char_p()
+        ms = C.c_float()
+        lib().fd_last_kernel_ms(self.h, C.byref(name), C.byref(ms))
+        return (name.value or b"").decode(), float(ms.value)
+
+    # ---- stand-alone filters
+    def histeq64(self, patches):
+        patches = _c(patches, np.uint8)
+        n, h, w = patches.shape
+        out = np.empty_like(patches)
+        self.check(lib().fd_histeq64_batch(self.h, _ptr(patches), n, w, h, _ptr(out)))
+        return out
+
+    def greyworld(self, bgr):
+        bgr = _c(bgr, np.uint8)
+        out = np.empty_like(bgr)
+        self.check(lib().fd_greyworld(self.h, _ptr(bgr), bgr.shape[1], bgr.shape[0], _ptr(out), 0))
+        return out
+
+
+class Pyramid:
+    def __init__(self, ctx, octave_layers=None, min_scale=0.09, max_scale=0.25, inc=None):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        if inc is not None:
+            ctx.check(lib().fd_pyramid_create_inc(ctx.h, inc, min_scale, max_scale, C.byref(self.h)))
+        else:
+            ctx.check(lib().fd_pyramid_create(ctx.h, octave_layers, min_scale, max_scale, C.byref(self.h)))
+
+    def set_layer_filter(self, kind, bins=9, signed_gradients=False, interpolate=False, grad_kernel=1, lbp_type=0):
+        self.ctx.check(lib().fd_pyramid_set_layer_filter(self.h, kind, bins, int(signed_gradients), int(interpolate), grad_kernel,
+                                                         lbp_type))
+
+    def update(self, image):
+        image = _c(image, np.uint8)
+        h, w = image.shape[:2]
+        ch = 1 if image.ndim == 2 else image.shape[2]
+        self.ctx.check(lib().fd_pyramid_update(self.h, _ptr(image), w, h, ch, 0))
+
+    def update_device(self, dev_ptr, w, h, ch):
+        self.ctx.check(lib().fd_pyramid_update(self.h, C.c_void_p(dev_ptr), w, h, ch, 1))
+
+    @property
+    def octave_layers(self):
+        return lib().fd_pyramid_octave_layer_count(self.h)
+
+    @property
+    def inc(self):
+        return lib().fd_pyramid_incremental_scale(self.h)
+
+    def layers(self):
+        out = []
+        for i in range(lib().fd_pyramid_layer_count(self.h)):
+            idx, w, h, ch = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            sc = C.c_double()
+            lib().fd_pyramid_layer_info(self.h, i, C.byref(idx), C.byref(sc), C.byref(w), C.byref(h), C.byref(ch))
+            out.append(dict(index=idx.value, scale=sc.value, w=w.value, h=h.value, ch=ch.value))
+        return out
+
+    def layer(self, i):
+        info = self.layers()[i]
+        shape = (info["h"], info["w"]) if info["ch"] == 1 else (info["h"], info["w"], info["ch"])
+        a = np.empty(shape, np.uint8)
+        self.ctx.check(lib().fd_pyramid_layer_download(self.h, i, _ptr(a)))
+        return a
+
+    def window_count(self, pw, ph, sx, sy, roi=None):
+        n = C.c_int64()
+        r = _c(roi, np.int32) if roi is not None else None
+        self.ctx.check(lib().fd_pyramid_window_count(self.h, pw, ph, sx, sy, _ptr(r), C.byref(n)))
+        return n.value
+
+    def windows(self, pw, ph, sx, sy, roi=None):
+        n = self.window_count(pw, ph, sx, sy, roi)
+        out = np.empty((n, 7), np.int32)
+        r = _c(roi, np.int32) if roi is not None else None
+        cnt = C.c_int64()
+        self.ctx.check(lib().fd_pyramid_windows(self.h, pw, ph, sx, sy, _ptr(r), _ptr(out), n, C.byref(cnt)))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().fd_pyramid_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def _wvm_struct(m, cls):
+    """m: dict of numpy arrays (featuredetection_amd.synth.make_wvm); cls: the ctypes struct type."""
+    keep = dict(thresholds=_c(m["thresholds"], np.float32), hk_weights=_c(m["hk_weights"], np.float32),
+                pp=_c(m["pp"], np.float64), val_off=_c(m["val_off"], np.int32), val=_c(m["val"], np.float64),
+                rec_off=_c(m["rec_off"], np.int32), rects=_c(m["rects"], np.uint8))
+    s = cls()
+    s.filter_w, s.filter_h = int(m["filter_w"]), int(m["filter_h"])
+    s.num_filters, s.num_used, s.num_per_level = int(m["num_filters"]), int(m["num_used"]), int(m["num_per_level"])
+    s.basis_param, s.bias = float(m["basis_param"]), float(m["bias"])
+    s.thresholds = keep["thresholds"].ctypes.data_as(C.POINTER(C.c_float))
+    s.hk_weights = keep["hk_weights"].ctypes.data_as(C.POINTER(C.c_float))
+    s.pp = keep["pp"].ctypes.data_as(C.POINTER(C.c_double))
+    s.val_off = keep["val_off"].ctypes.data_as(C.POINTER(C.c_int32))
+    s.val = keep["val"].ctypes.data_as(C.POINTER(C.c_double))
+    s.rec_off = keep["rec_off"].ctypes.data_as(C.POINTER(C.c_int32))
+    s.rects = keep["rects"].ctypes.data_as(C.POINTER(C.c_uint8))
+    s.logistic_a, s.logistic_b = float(m["logistic_a"]), float(m["logistic_b"])
+    return s, keep
+
+
+class Wvm:
+    def __init__(self, ctx, model):
+        self.ctx = ctx
+        self.model = model
+        s, keep = _wvm_struct(model, fd_wvm_model)
+        self.h = C.c_void_p()
+        ctx.check(lib().fd_wvm_create(ctx.h, C.byref(s), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().fd_wvm_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class Svm:
+    def __init__(self, ctx, model):
+        self.ctx = ctx
+        self.model = model
+        dtype = np.uint8 if model["dtype"] == FD_DTYPE_U8 else np.float32
+        sv = _c(model["sv"], dtype)
+        coeff = _c(model["coeff"], np.float32)
+        s = fd_svm_model()
+        s.kernel = int(model["kernel"])
+        s.p0, s.p1, s.p2 = float(model.get("p0", 0)), float(model.get("p1", 0)), float(model.get("p2", 0))
+        s.num_sv, s.dim = sv.shape
+        s.dtype = int(model["dtype"])
+        s.support_vectors = sv.ctypes.data
+        s.coefficients = coeff.ctypes.data_as(C.POINTER(C.c_float))
+        s.bias, s.threshold = float(model["bias"]), float(model.get("threshold", 0.0))
+        s.logistic_a, s.logistic_b = float(model.get("logistic_a", 0.00556)), float(model.get("logistic_b", -2.95))
+        self.h = C.c_void_p()
+        ctx.check(lib().fd_svm_create(ctx.h, C.byref(s), C.byref(self.h)))
+        self.dim = s.dim
+        self.np_dtype = dtype
+
+    def distance(self, feats):
+        feats = _c(feats, self.np_dtype).reshape(-1, self.dim)
+        out = np.empty(feats.shape[0], np.float64)
+        self.ctx.check(lib().fd_svm_distance_batch(self.ctx.h, self.h, _ptr(feats), feats.shape[0], _ptr(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().fd_svm_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def hog_params(pw=20, ph=20, sx=2, sy=2, bins=9, cell=5, block=2, signed_and_unsigned=False):
+    return fd_hog_params(pw, ph, sx, sy, bins, cell, block, int(signed_and_unsigned))
+
+
+def detect_wvm(ctx, pyr, wvm, sx=1, sy=1, roi=None, want_all=False, cap=1 << 20):
+    n = pyr.window_count(wvm.model["filter_w"], wvm.model["filter_h"], sx, sy, roi)
+    out = np.zeros(min(cap, max(n, 1)), DET_DTYPE)
+    lv = np.empty(n, np.int32) if want_all else None
+    sc = np.empty(n, np.float32) if want_all else None
+    cnt = C.c_int64()
+    r = _c(roi, np.int32) if roi is not None else None
+    ctx.check(lib().fd_detect_wvm(ctx.h, pyr.h, wvm.h, sx, sy, _ptr(r), _ptr(out), out.shape[0], C.byref(cnt), _ptr(lv), _ptr(sc)))
+    return out[:cnt.value], lv, sc
+
+
+def detect_five_stage(ctx, pyr, wvm, svm, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1, roi=None, cap=4096):
+    out = np.zeros(cap, DET_DTYPE)
+    cnt = C.c_int()
+    stages = np.zeros(4, np.int32)
+    r = _c(roi, np.int32) if roi is not None else None
+    ctx.check(lib().fd_detect_five_stage(ctx.h, pyr.h, wvm.h, svm.h, oe_dist, oe_ratio, sx, sy, _ptr(r), _ptr(out), cap,
+                                         C.byref(cnt), _ptr(stages)))
+    return out[:cnt.value], stages
+
+
+def overlap_elimination(dets, dist, ratio):
+    dets = _c(dets, DET_DTYPE)
+    keep = np.empty(max(len(dets), 1), np.int32)
+    cnt = C.c_int()
+    rc = lib().fd_overlap_elimination(_ptr(dets), len(dets), dist, ratio, _ptr(keep), C.byref(cnt))
+    if rc != FD_OK:
+        raise FdError(rc, "fd_overlap_elimination")
+    return keep[:cnt.value]
+
+
+def block_nms(dets, img_w, img_h, sz=35, masked=True):
+    dets = _c(dets, DET_DTYPE)
+    xy = np.empty((max(len(dets), 1), 2), np.int32)
+    cnt = C.c_int()
+    rc = lib().fd_block_nms(_ptr(dets), len(dets), img_w, img_h, sz, int(masked), _ptr(xy), len(xy), C.byref(cnt))
+    if rc != FD_OK:
+        raise FdError(rc, "fd_block_nms")
+    return xy[:cnt.value]
+
+
+def extract_hog(ctx, pyr, hp):
+    n = C.c_int64()
+    ctx.check(lib().fd_extract_hog(ctx.h, pyr.h, C.byref(hp), None, 0, C.byref(n)))
+    F = lib().fd_hog_feature_length(C.byref(hp))
+    out = np.empty((n.value, F), np.float32)
+    ctx.check(lib().fd_extract_hog(ctx.h, pyr.h, C.byref(hp), _ptr(out), n.value, C.byref(n)))
+    return out
+
+
+def detect_hog_svm(ctx, pyr, svm, hp, want_all=True, cap=1 << 20):
+    n = pyr.window_count(hp.patch_w, hp.patch_h, hp.step_x, hp.step_y)
+    out = np.zeros(min(cap, max(n, 1)), DET_DTYPE)
+    alld = np.empty(n, np.float64) if want_all else None
+    cnt = C.c_int64()
+    ctx.check(lib().fd_detect_hog_svm(ctx.h, pyr.h, svm.h, C.byref(hp), _ptr(out), out.shape[0], C.byref(cnt), _ptr(alld)))
+    return out[:cnt.value], alld
+
+
+def bench_hog_svm(ctx, pyr, svm, hp):
+    n, p = C.c_int64(), C.c_int64()
+    ctx.check(lib().fd_bench_hog_svm(ctx.h, pyr.h, svm.h, C.byref(hp), C.byref(n), C.byref(p)))
+    return n.value, p.value
+
+
+def bench_wvm(ctx, pyr, wvm, sx=1, sy=1):
+    n, p = C.c_int64(), C.c_int64()
+    ctx.check(lib().fd_bench_wvm(ctx.h, pyr.h, wvm.h, sx, sy, C.byref(n), C.byref(p)))
+    return n.value, p.value
+
+
+class Sdm:
+    def __init__(self, ctx, model):
+        self.ctx = ctx
+        self.model = model
+        L, S = int(model["L"]), int(model["S"])
+        self._mean = _c(model["mean"], np.float32)
+        self._R = [_c(r, np.float32) for r in model["R"]]
+        ptrs = (C.POINTER(C.c_float) * S)(*[r.ctypes.data_as(C.POINTER(C.c_float)) for r in self._R])
+        rows = _c([r.shape[0] for r in self._R], np.int32)
+        s = fd_sdm_model()
+        s.num_landmarks, s.num_steps = L, S
+        s.mean = self._mean.ctypes.data_as(C.POINTER(C.c_float))
+        s.R = C.cast(ptrs, C.POINTER(C.POINTER(C.c_float)))
+        s.R_rows = rows.ctypes.data_as(C.POINTER(C.c_int32))
+        s.hog_variant = int(model["variant"])
+        self.h = C.c_void_p()
+        ctx.check(lib().fd_sdm_create(ctx.h, C.byref(s), C.byref(self.h)))
+        self.L, self.S = L, S
+
+    def fit(self, gray_images, face_boxes):
+        """gray_images: [B,H,W] u8; face_boxes: [B,4] (x,y,w,h).  Returns (shapes [B,2L], status [B])."""
+        imgs = _c(gray_images, np.uint8)
+        B, H, W = imgs.shape
+        fb = _c(face_boxes, np.int32).reshape(B, 4)
+        out = np.empty((B, 2 * self.L), np.float32)
+        st = np.zeros(B, np.int32)
+        self.ctx.check(lib().fd_sdm_fit_batch(self.ctx.h, self.h, _ptr(imgs), W, H, B, _ptr(fb), 0, _ptr(out), _ptr(st)))
+        return out, st
+
+    def fit_device(self, dev_ptr, W, H, B, face_boxes):
+        fb = _c(face_boxes, np.int32).reshape(B, 4)
+        out = np.empty((B, 2 * self.L), np.float32)
+        st = np.zeros(B, np.int32)
+        self.ctx.check(lib().fd_sdm_fit_batch(self.ctx.h, self.h, C.c_void_p(dev_ptr), W, H, B, _ptr(fb), 1, _ptr(out), _ptr(st)))
+        return out, st
+
+    def close(self):
+        if self.h:
+            lib().fd_sdm_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def sdm_descriptors(ctx, gray, px, py, wsh, variant=1, num_cells=3, cell_size=10, num_bins=9):
+    gray = _c(gray, np.uint8)
+    px, py = _c(px, np.float32), _c(py, np.float32)
+    n = len(px)
+    ln = C.c_int()
+    ctx.check(lib().fd_sdm_descriptors(ctx.h, _ptr(gray), gray.shape[1], gray.shape[0], _ptr(px), _ptr(py), n, wsh, variant, num_cells,
+                                       cell_size, num_bins, None, C.byref(ln)))
+    out = np.empty((n, ln.value), np.float32)
+    ctx.check(lib().fd_sdm_descriptors(ctx.h, _ptr(gray), gray.shape[1], gray.shape[0], _ptr(px), _ptr(py), n, wsh, variant, num_cells,
+                                       cell_size, num_bins, _ptr(out), C.byref(ln)))
+    return out

@@ -1,0 +1,72 @@
+// featuredetection_amd/csrc/ctx.hip -- context management of libfd_hip.so
+#include "fd_internal.hpp"
+#include <cstring>
+
+extern "C" {
+
+const char* fd_version(void) { return "fd_hip 0.1 (gfx950)"; }
+
+int fd_ctx_create(int device_id, void* hip_stream, fd_ctx** out) {
+    if (!out) return FD_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    fd_ctx* ctx = new fd_ctx();
+    int rc = fd_guard(ctx, [&] {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0) FD_THROW(FD_ERR_HIP, "no HIP device available (%s); this library has no CPU fallback", hipGetErrorString(e));
+        if (device_id < 0 || device_id >= n) FD_THROW(FD_ERR_INVALID_ARGUMENT, "device %d out of range (0..%d)", device_id, n - 1);
+        HIP_CHECK(hipSetDevice(device_id));
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            FD_THROW(FD_ERR_HIP, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+        ctx->device = device_id;
+        ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (hip_stream) {
+            ctx->stream = (hipStream_t)hip_stream;
+            ctx->own_stream = false;
+        } else {
+            HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+            ctx->own_stream = true;
+        }
+        HIP_CHECK(hipEventCreate(&ctx->ev0));
+        HIP_CHECK(hipEventCreate(&ctx->ev1));
+    });
+    if (rc != FD_OK) {
+        // keep the message reachable for the caller through a static buffer
+        static thread_local std::string last;
+        last = ctx->error;
+        fprintf(stderr, "fd_ctx_create: %s\n", last.c_str());
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return FD_OK;
+}
+
+void fd_ctx_destroy(fd_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* fd_last_error(const fd_ctx* ctx) { return ctx ? ctx->error.c_str() : "NULL context"; }
+
+int fd_ctx_synchronize(fd_ctx* ctx) {
+    return fd_guard(ctx, [&] {
+        if (!ctx) FD_THROW(FD_ERR_INVALID_ARGUMENT, "NULL context");
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int fd_last_kernel_ms(fd_ctx* ctx, const char** kernel_name, float* ms) {
+    if (!ctx) return FD_ERR_INVALID_ARGUMENT;
+    if (kernel_name) *kernel_name = ctx->last_kernel;
+    if (ms) *ms = ctx->last_kernel_ms;
+    return FD_OK;
+}
+
+}  // extern "C"

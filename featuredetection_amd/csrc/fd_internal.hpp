@@ -1,0 +1,148 @@
+// featuredetection_amd/csrc/fd_internal.hpp -- internal declarations of libfd_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cmath>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include "../../include/fd_hip.h"
+
+struct fd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string error;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // brackets the dominant kernel of fd_bench_* calls
+    const char* last_kernel = "";
+    float last_kernel_ms = 0.f;
+    int num_cus = 256;
+};
+
+struct FdError {
+    int code;
+    std::string msg;
+};
+
+#define FD_THROW(code, ...)                               \
+    do {                                                  \
+        char _b[512];                                     \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);            \
+        throw FdError{code, std::string(_b)};             \
+    } while (0)
+
+#define HIP_CHECK(expr)                                                                       \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) FD_THROW(FD_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+// Runs body, converts exceptions into status codes + ctx->error (no exceptions cross the C ABI).
+template <class F>
+static inline int fd_guard(fd_ctx* ctx, F&& body) {
+    try {
+        body();
+        return FD_OK;
+    } catch (const FdError& e) {
+        if (ctx) ctx->error = e.msg;
+        return e.code;
+    } catch (const std::exception& e) {
+        if (ctx) ctx->error = e.what();
+        return FD_ERR_RUNTIME;
+    } catch (...) {
+        if (ctx) ctx->error = "unknown error";
+        return FD_ERR_RUNTIME;
+    }
+}
+
+// Simple owning device buffer that only grows (reused across calls: no hipMalloc in steady state).
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    void reserve(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) HIP_CHECK(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        HIP_CHECK(hipMalloc(&p, want));
+        cap = want;
+    }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+// Pinned host staging buffer
+struct HostBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    ~HostBuf() { if (p) (void)hipHostFree(p); }
+    void reserve(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) HIP_CHECK(hipHostFree(p));
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+    }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+static inline int fd_cvRound(double v) { return (int)std::lrint(v); }  // cvRound: half-to-even
+
+// ---------------- pyramid ----------------
+struct LayerDesc {          // device-visible layer descriptor
+    int32_t w, h;           // layer size (pixels)
+    int32_t ch;             // channels of the filtered layer
+    int32_t pad;
+    uint32_t gray_off;      // byte offset of the gray layer in the arena
+    uint32_t filt_off;      // byte offset of the filtered layer (== gray_off when no layer filter)
+};
+
+struct HostLayer {
+    int index;
+    double scale;
+    int w, h, ch;
+    uint32_t gray_off, filt_off;
+    bool kept;
+    int chain, depth;       // first-octave slot i and pyrDown depth j
+};
+
+struct WindowLayer {        // per kept layer, for the window enumeration of one (patch, step, roi)
+    int32_t layer;          // position in the kept-layer list
+    int32_t bx, by;         // first window origin
+    int32_t nx, ny;         // number of window positions
+    int32_t ow, oh;         // original (image) patch size
+    int64_t first;          // index of the first window of this layer
+};
+
+struct fd_pyramid {
+    fd_ctx* ctx;
+    size_t octl;
+    double inc, minS, maxS;
+    int filter_kind = FD_LAYER_NONE, bins = 9, signed_gradients = 0, interpolate = 0, grad_kernel = 1, lbp_type = 0;
+    int img_w = 0, img_h = 0;
+    std::vector<HostLayer> all;      // every computed layer (kept or only a pyrDown source)
+    std::vector<int> kept;           // indices into all, sorted by layer index
+    DevBuf arena;                    // gray full-res + all layers + filtered layers
+    DevBuf input;                    // staging for host images
+    DevBuf lut;                      // gradient binning LUT (65536 * 2|4 bytes)
+    DevBuf layer_table;              // LayerDesc per kept layer
+    std::vector<LayerDesc> h_layer_table;
+    uint32_t gray_full_off = 0;
+    size_t arena_bytes = 0;
+    uint64_t version = 0;            // bumped by every update
+};
+
+void fd_enumerate_layers(const fd_pyramid* p, int pw, int ph, int sx, int sy, const int* roi,
+                         std::vector<WindowLayer>& out, int64_t& total);
+
+// ---------------- host-side detection logic (hostalgo.cpp) ----------------
+void fd_host_overlap_elimination(const fd_detection* in, int n, float dist, float ratio, std::vector<int>& keep);
+void fd_host_block_nms_sparse(const std::vector<fd_detection>& pos, int imgW, int imgH, int sz, bool masked,
+                              std::vector<int>& maxima_xy /* pairs x,y in row-major order */);

@@ -1,0 +1,116 @@
+// featuredetection_amd/csrc/hostalgo.cpp -- host-side stage glue of the detection path: the greedy,
+// order-dependent steps that the reference runs on a handful of survivors per image
+// (OverlapElimination, block non-maxima suppression).  They stay on the host: n is tens to a few
+// thousand records and the algorithms are sequential by definition (sort + greedy erase).
+#include "fd_internal.hpp"
+#include <algorithm>
+#include <map>
+
+// detection::OverlapElimination::eliminate (OverlapElimination.cpp:44-105).  std::sort on the
+// probability only (boost::indirect_iterator + std::greater<ClassifiedPatch>), then greedy erase.
+// Implemented with a "removed" flag instead of vector::erase (same result, O(n^2) compares).
+void fd_host_overlap_elimination(const fd_detection* in, int n, float distIn, float ratioIn, std::vector<int>& keep) {
+    keep.clear();
+    if (n <= 0) return;
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return in[a].probability > in[b].probability; });
+    const float dist = distIn;
+    const float ratio = ((ratioIn > 0.0f) && (ratioIn <= 1.0f)) ? ratioIn : 0.0f;
+    std::vector<char> removed(n, 0);
+    for (int a = 0; a < n; ++a) {
+        if (removed[a]) continue;
+        const fd_detection& A = in[order[a]];
+        keep.push_back(order[a]);
+        for (int b = a + 1; b < n; ++b) {
+            if (removed[b]) continue;
+            const fd_detection& P = in[order[b]];
+            float d = dist <= 1.0 ? dist * std::max(A.w, P.w) : dist;
+            if ((std::abs(A.cx - P.cx) < d) && (std::abs(A.cy - P.cy) < d) &&
+                (((float)std::min(A.w, P.w) / (float)std::max(A.w, P.w)) > ratio))
+                removed[b] = 1;
+        }
+    }
+}
+
+// nonMaximaSuppression (FiveStageSlidingWindowDetector.cpp:143-184) evaluated on the sparse set of
+// non-zero map entries instead of a dense H x W probability map.  Equivalent because (a) blocks
+// without a (masked) entry can never produce a maximum (candidate value 0 is never > neighbour
+// maximum >= 0), and (b) cv::minMaxLoc returns the first row-major maximum, which the ordered
+// std::map reproduces.  masked: only entries with value > 0.3 take part (mask = map > 0.3f, :286).
+void fd_host_block_nms_sparse(const std::vector<fd_detection>& pos, int imgW, int imgH, int sz, bool masked,
+                              std::vector<int>& maxima_xy) {
+    maxima_xy.clear();
+    // probabilityMap(py, px) = max probability at that pixel (:277-284), as float
+    std::map<std::pair<int, int>, float> map;  // key (y, x): row-major order
+    for (const fd_detection& d : pos) {
+        if (d.cx < 0 || d.cy < 0 || d.cx >= imgW || d.cy >= imgH) continue;  // (reference: out-of-range Mat::at, UB)
+        auto key = std::make_pair(d.cy, d.cx);
+        auto it = map.find(key);
+        float cur = it == map.end() ? 0.f : it->second;
+        if (cur < d.probability) map[key] = (float)d.probability;
+    }
+    struct Pt { int x, y; float v; };
+    std::vector<Pt> pts;
+    for (auto& kv : map) {
+        if (masked && !(kv.second > 0.3f)) continue;
+        pts.push_back(Pt{kv.first.second, kv.first.first, kv.second});
+    }
+    // group by block, keeping row-major order inside each block
+    std::map<std::pair<int, int>, std::vector<int>> blocks;  // (block row, block col)
+    for (size_t i = 0; i < pts.size(); ++i) blocks[{pts[i].y / (sz + 1), pts[i].x / (sz + 1)}].push_back((int)i);
+    std::vector<Pt> accepted;
+    for (auto& kv : blocks) {
+        const int m = kv.first.first * (sz + 1), n = kv.first.second * (sz + 1);
+        // candidate: first maximum of the block (pts are in row-major order already)
+        int best = -1;
+        for (int i : kv.second)
+            if (best < 0 || pts[i].v > pts[best].v) best = i;
+        const Pt c = pts[best];
+        if (!masked && !(c.v > 0.f)) continue;
+        const double vcmax = c.v;
+        // neighbourhood (2sz+1)^2 around the candidate, minus the candidate's own block
+        const int y0 = std::max(c.y - sz, 0), y1 = std::min(c.y + sz + 1, imgH);
+        const int x0 = std::max(c.x - sz, 0), x1 = std::min(c.x + sz + 1, imgW);
+        const int by0 = m, by1 = std::min(m + sz + 1, imgH), bx0 = n, bx1 = std::min(n + sz + 1, imgW);
+        double vnmax = 0;  // all-zero mask => 0; unmasked => zeros of the map
+        bool any = false;
+        for (const Pt& q : pts) {
+            if (q.y < y0 || q.y >= y1 || q.x < x0 || q.x >= x1) continue;
+            if (q.y >= by0 && q.y < by1 && q.x >= bx0 && q.x < bx1) continue;
+            if (!any || q.v > vnmax) { vnmax = q.v; any = true; }
+        }
+        if (!masked && any && vnmax < 0) vnmax = 0;
+        if (!masked) {
+            // unmasked: zeros of the map inside the neighbourhood also count (value 0) whenever the
+            // neighbourhood has at least one pixel outside the block
+            bool outside = (y0 < by0) || (y1 > by1) || (x0 < bx0) || (x1 > bx1);
+            if (!any) vnmax = 0;
+            else if (outside && vnmax < 0) vnmax = 0;
+        }
+        if (vcmax > vnmax) accepted.push_back(c);
+    }
+    std::sort(accepted.begin(), accepted.end(), [](const Pt& a, const Pt& b) { return a.y != b.y ? a.y < b.y : a.x < b.x; });
+    for (const Pt& a : accepted) { maxima_xy.push_back(a.x); maxima_xy.push_back(a.y); }
+}
+
+extern "C" int fd_overlap_elimination(const fd_detection* in, int n, float dist, float ratio, int32_t* keep_idx, int* count) {
+    if (!count || (n > 0 && (!in || !keep_idx))) return FD_ERR_INVALID_ARGUMENT;
+    std::vector<int> keep;
+    fd_host_overlap_elimination(in, n, dist, ratio, keep);
+    for (size_t i = 0; i < keep.size(); ++i) keep_idx[i] = keep[i];
+    *count = (int)keep.size();
+    return FD_OK;
+}
+
+extern "C" int fd_block_nms(const fd_detection* in, int n, int image_w, int image_h, int sz, int masked, int32_t* maxima_xy,
+                            int cap_pairs, int* count) {
+    if (!count || n < 0 || (n > 0 && !in) || image_w < 1 || image_h < 1 || sz < 0) return FD_ERR_INVALID_ARGUMENT;
+    std::vector<fd_detection> v(in, in + n);
+    std::vector<int> xy;
+    fd_host_block_nms_sparse(v, image_w, image_h, sz, masked != 0, xy);
+    *count = (int)(xy.size() / 2);
+    if (*count > cap_pairs) return FD_ERR_CAPACITY;
+    for (size_t i = 0; i < xy.size(); ++i) maxima_xy[i] = xy[i];
+    return FD_OK;
+}

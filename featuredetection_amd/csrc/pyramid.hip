@@ -1,0 +1,640 @@
+// featuredetection_amd/csrc/pyramid.hip -- image pyramid on the GPU (gfx950).
+//
+// Restates imageprocessing::ImagePyramid (ImagePyramid.cpp:67-92,116-128,170-198) with the
+// GrayscaleFilter image filter and optional layer filters.  All arithmetic is the integer-exact
+// OpenCV 2.4 fixed-point arithmetic (cvtColor, resize INTER_LINEAR, pyrDown, Sobel), so layers are
+// bit-identical to the CPU path.  Layout in HBM: ONE arena per pyramid holding the full-resolution
+// gray image, every computed layer (kept or only a pyrDown source) and the filtered kept layers,
+// each 256-byte aligned, rows densely packed.  The whole pyramid of a 640x480 frame is ~1.6 MB and
+// stays L2/MALL resident for the scoring kernels that follow.
+//
+// HBM-bound stage: algorithmic bytes = 3WH (BGR read) + WH (gray write) + per layer (src read +
+// dst write); see DESIGN.md.  One launch covers all chains of a pyramid depth (blockIdx.y = chain).
+#include "fd_internal.hpp"
+#include <algorithm>
+#include <cstring>
+
+namespace {
+
+constexpr int MAXJ = 16;
+
+struct ResizeJob {
+    int dw, dh;
+    uint32_t dst_off;
+    double scale_x, scale_y;
+};
+struct ResizeJobs {
+    int n;
+    ResizeJob j[MAXJ];
+};
+struct DownJob {
+    int sw, sh;
+    uint32_t src_off, dst_off;
+};
+struct DownJobs {
+    int n;
+    DownJob j[MAXJ];
+};
+struct FilterJob {
+    int w, h;
+    uint32_t src_off, dst_off;
+};
+struct FilterJobs {
+    int n;
+    FilterJob j[MAXJ];
+};
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) {
+        if (p < 0) p = -p;
+        else p = 2 * len - 2 - p;
+    }
+    return p;
+}
+
+// cv::cvtColor(BGR2GRAY), 8U: (B*1868 + G*9617 + R*4899 + 8192) >> 14
+__global__ void k_bgr2gray(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ gray, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int stride = gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        int b = bgr[3 * (size_t)i], g = bgr[3 * (size_t)i + 1], r = bgr[3 * (size_t)i + 2];
+        gray[i] = (uint8_t)((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14);
+    }
+}
+
+// cv::resize INTER_LINEAR 8UC1 -> all first-octave layers from the full-resolution gray image
+__global__ void k_resize_linear(const uint8_t* __restrict__ arena, uint8_t* __restrict__ out, uint32_t src_off, int sw,
+                                int sh, ResizeJobs jobs) {
+    const ResizeJob jb = jobs.j[blockIdx.y];
+    const int npix = jb.dw * jb.dh;
+    const uint8_t* src = arena + src_off;
+    uint8_t* dst = out + jb.dst_off;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        int dy = i / jb.dw, dx = i - dy * jb.dw;
+        float fx = (float)((dx + 0.5) * jb.scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        int a0 = __float2int_rn((1.f - fx) * 2048), a1 = __float2int_rn(fx * 2048);
+        float fy = (float)((dy + 0.5) * jb.scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        int b0 = __float2int_rn((1.f - fy) * 2048), b1 = __float2int_rn(fy * 2048);
+        int y0 = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);
+        int y1 = sy + 1 < 0 ? 0 : (sy + 1 >= sh ? sh - 1 : sy + 1);
+        int sx1 = sx + 1 < sw ? sx + 1 : sx;
+        const uint8_t* S0 = src + (size_t)y0 * sw;
+        const uint8_t* S1 = src + (size_t)y1 * sw;
+        int r0 = S0[sx] * a0 + S0[sx1] * a1;
+        int r1 = S1[sx] * a0 + S1[sx1] * a1;
+        dst[i] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
+// cv::pyrDown 8UC1: separable [1 4 6 4 1], (sum + 128) >> 8, BORDER_REFLECT_101
+__global__ void k_pyrdown(uint8_t* __restrict__ arena, DownJobs jobs) {
+    const DownJob jb = jobs.j[blockIdx.y];
+    const int dw = (jb.sw + 1) / 2, dh = (jb.sh + 1) / 2;
+    const uint8_t* src = arena + jb.src_off;
+    uint8_t* dst = arena + jb.dst_off;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dw * dh; i += gridDim.x * blockDim.x) {
+        int y = i / dw, x = i - y * dw;
+        int xs[5], ys[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            xs[k] = reflect101(2 * x - 2 + k, jb.sw);
+            ys[k] = reflect101(2 * y - 2 + k, jb.sh);
+        }
+        int rows[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const uint8_t* S = src + (size_t)ys[k] * jb.sw;
+            rows[k] = S[xs[2]] * 6 + (S[xs[1]] + S[xs[3]]) * 4 + S[xs[0]] + S[xs[4]];
+        }
+        int v = rows[2] * 6 + (rows[1] + rows[3]) * 4 + rows[0] + rows[4];
+        dst[i] = (uint8_t)((v + 128) >> 8);
+    }
+}
+
+// GradientFilter (Sobel ksize 1 or 3, scale 1/2 or 1/8, delta 127, 8U saturate + cvRound) fused
+// with the GradientBinningFilter 64K-entry look-up (index = gx | gy << 8).
+template <int E>  // bytes per LUT entry: 2 (one bin + weight) or 4 (two bins + weights)
+__global__ void k_gradbin(uint8_t* __restrict__ arena, const uint8_t* __restrict__ lut, int ksize, FilterJobs jobs) {
+    const FilterJob jb = jobs.j[blockIdx.y];
+    const uint8_t* src = arena + jb.src_off;
+    uint8_t* dst = arena + jb.dst_off;
+    const int w = jb.w, h = jb.h;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < w * h; i += gridDim.x * blockDim.x) {
+        int y = i / w, x = i - y * w;
+        int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+        int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
+        const uint8_t *S0 = src + (size_t)ym * w, *S1 = src + (size_t)y * w, *S2 = src + (size_t)yp * w;
+        int gx, gy;
+        float scale;
+        if (ksize == 1) {
+            gx = S1[xp] - S1[xm];
+            gy = S2[x] - S0[x];
+            scale = 0.5f;
+        } else {
+            gx = (S0[xp] - S0[xm]) + 2 * (S1[xp] - S1[xm]) + (S2[xp] - S2[xm]);
+            gy = (S2[xm] - S0[xm]) + 2 * (S2[x] - S0[x]) + (S2[xp] - S0[xp]);
+            scale = 0.125f;
+        }
+        // exact in float; cvRound = round-half-even; saturate to 0..255
+        int vx = __float2int_rn(127.f + scale * gx), vy = __float2int_rn(127.f + scale * gy);
+        vx = min(255, max(0, vx));
+        vy = min(255, max(0, vy));
+        uint32_t idx = (uint32_t)vx | ((uint32_t)vy << 8);
+        if (E == 2) {
+            *(uint16_t*)(dst + 2 * (size_t)i) = *(const uint16_t*)(lut + 2 * (size_t)idx);
+        } else {
+            *(uint32_t*)(dst + 4 * (size_t)i) = *(const uint32_t*)(lut + 4 * (size_t)idx);
+        }
+    }
+}
+
+// LbpFilter 3x3 codes with BORDER_REPLICATE (LbpFilter.hpp:88-180), optional uniform map
+__global__ void k_lbp(uint8_t* __restrict__ arena, int type, FilterJobs jobs) {
+    const FilterJob jb = jobs.j[blockIdx.y];
+    const uint8_t* src = arena + jb.src_off;
+    uint8_t* dst = arena + jb.dst_off;
+    const int w = jb.w, h = jb.h;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < w * h; i += gridDim.x * blockDim.x) {
+        int y = i / w, x = i - y * w;
+        int xm = max(x - 1, 0), xp = min(x + 1, w - 1), ym = max(y - 1, 0), yp = min(y + 1, h - 1);
+        const uint8_t *P = src + (size_t)ym * w, *C = src + (size_t)y * w, *N = src + (size_t)yp * w;
+        int c = C[x];
+        int code = 0;
+        if (type == FD_LBP8 || type == FD_LBP8_UNIFORM) {
+            code |= (P[xm] > c) << 7;
+            code |= (P[x] > c) << 6;
+            code |= (P[xp] > c) << 5;
+            code |= (C[xp] > c) << 4;
+            code |= (N[xp] > c) << 3;
+            code |= (N[x] > c) << 2;
+            code |= (N[xm] > c) << 1;
+            code |= (C[xm] > c) << 0;
+            if (type == FD_LBP8_UNIFORM) {
+                // LbpFilter.cpp:20-44: uniform patterns (<= 2 circular transitions) get indices 1..58 in
+                // increasing code order, all others 0.  index = 1 + #uniform codes below this one.
+                int rot = ((code << 1) | (code >> 7)) & 0xff;  // bit pos compared with bit pos-1 (pos 0 with 7)
+                int transitions = __popc((code ^ rot) & 0xff);
+                if (transitions > 2) code = 0;
+                else {
+                    int cnt = 0;
+                    for (int q = 0; q < code; ++q) {
+                        int rq = ((q << 1) | (q >> 7)) & 0xff;
+                        cnt += __popc((q ^ rq) & 0xff) <= 2;
+                    }
+                    code = 1 + cnt;
+                }
+            }
+        } else if (type == FD_LBP4) {
+            code |= (P[x] > c) << 3;
+            code |= (C[xp] > c) << 2;
+            code |= (N[x] > c) << 1;
+            code |= (C[xm] > c) << 0;
+        } else {
+            code |= (P[xm] > c) << 3;
+            code |= (P[xp] > c) << 2;
+            code |= (N[xp] > c) << 1;
+            code |= (N[xm] > c) << 0;
+        }
+        dst[i] = (uint8_t)code;
+    }
+}
+
+// GreyWorldNormalizationFilter.cpp:20-71 -- pass 1: per-channel sum and max
+__global__ void k_greyworld_stats(const uint8_t* __restrict__ bgr, int n, unsigned long long* sums, unsigned int* maxs) {
+    unsigned long long s[3] = {0, 0, 0};
+    unsigned int m[3] = {0, 0, 0};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        for (int c = 0; c < 3; ++c) {
+            unsigned int v = bgr[3 * (size_t)i + c];
+            s[c] += v;
+            m[c] = max(m[c], v);
+        }
+    for (int c = 0; c < 3; ++c) {
+        for (int o = 32; o > 0; o >>= 1) {
+            s[c] += __shfl_down(s[c], o, 64);
+            m[c] = max(m[c], (unsigned int)__shfl_down((int)m[c], o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&sums[c], s[c]);
+            atomicMax(&maxs[c], m[c]);
+        }
+    }
+}
+__global__ void k_greyworld_apply(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ dst, int n, double s0, double s1,
+                                  double s2) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double sc[3] = {s0, s1, s2};
+        for (int c = 0; c < 3; ++c) {
+            int v = __double2int_rn(sc[c] * (double)bgr[3 * (size_t)i + c]);
+            dst[3 * (size_t)i + c] = (uint8_t)min(255, max(0, v));
+        }
+    }
+}
+
+inline uint32_t align256(size_t v) { return (uint32_t)((v + 255) & ~(size_t)255); }
+
+// GradientBinningFilter.cpp:18-60 -- built on the host with libm, exactly like the reference ctor
+void build_gradient_lut(int bins, bool signedGradients, bool interpolate, std::vector<uint8_t>& lut) {
+    const double PI = 3.1415926535897932384626433832795;
+    const int E = interpolate ? 4 : 2;
+    lut.resize((size_t)65536 * E);
+    for (int x = 0; x < 256; ++x) {
+        double gradientX = ((double)x - 127) / 255;
+        for (int y = 0; y < 256; ++y) {
+            double gradientY = ((double)y - 127) / 255;
+            double direction = std::atan2(gradientY, gradientX);
+            double magnitude = std::sqrt(gradientX * gradientX + gradientY * gradientY);
+            double bin;
+            if (signedGradients) {
+                direction += PI;
+                bin = direction * bins / (2 * PI);
+            } else {
+                if (direction < 0) direction += PI;
+                bin = direction * bins / PI;
+            }
+            auto sat = [](double v) { int r = fd_cvRound(v); return (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r)); };
+            size_t index = (size_t)x | ((size_t)y << 8);
+            if (!interpolate) {
+                lut[2 * index] = (uint8_t)((uint8_t)std::round(bin) % (unsigned)bins);
+                lut[2 * index + 1] = sat(255 * magnitude);
+            } else {
+                uint8_t w1 = sat(255 * magnitude * (bin - std::floor(bin)));
+                lut[4 * index] = (uint8_t)((uint8_t)std::floor(bin) % (unsigned)bins);
+                lut[4 * index + 1] = sat(255 * magnitude - w1);
+                lut[4 * index + 2] = (uint8_t)((uint8_t)std::ceil(bin) % (unsigned)bins);
+                lut[4 * index + 3] = w1;
+            }
+        }
+    }
+}
+
+void build_layout(fd_pyramid* p, int W, int H) {
+    p->img_w = W;
+    p->img_h = H;
+    p->all.clear();
+    p->kept.clear();
+    size_t off = 0;
+    p->gray_full_off = 0;
+    off = align256((size_t)W * H);
+    const int fch = p->filter_kind == FD_LAYER_GRADBIN ? (p->interpolate ? 4 : 2) : 1;
+    for (size_t i = 0; i < p->octl; ++i) {
+        double scaleFactor = std::pow(p->inc, (double)i);
+        int w = fd_cvRound(W * scaleFactor), h = fd_cvRound(H * scaleFactor);
+        if (w < 1 || h < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "ImagePyramid: layer %zu would be empty", i);
+        int depth = 0;
+        HostLayer L{(int)i, scaleFactor, w, h, 1, (uint32_t)off, 0, scaleFactor <= p->maxS && scaleFactor >= p->minS, (int)i, depth};
+        off = align256(off + (size_t)w * h);
+        p->all.push_back(L);
+        int pw = w, ph = h;
+        scaleFactor *= 0.5;
+        for (size_t j = 1; scaleFactor >= p->minS && pw > 1; ++j, scaleFactor *= 0.5) {
+            int dw = (pw + 1) / 2, dh = (ph + 1) / 2;
+            HostLayer D{(int)(i + j * p->octl), scaleFactor, dw, dh, 1, (uint32_t)off, 0, scaleFactor <= p->maxS, (int)i, (int)j};
+            off = align256(off + (size_t)dw * dh);
+            p->all.push_back(D);
+            pw = dw;
+            ph = dh;
+        }
+    }
+    for (size_t k = 0; k < p->all.size(); ++k) {
+        HostLayer& L = p->all[k];
+        if (!L.kept) continue;
+        L.ch = fch;
+        if (p->filter_kind == FD_LAYER_NONE) L.filt_off = L.gray_off;
+        else {
+            L.filt_off = (uint32_t)off;
+            off = align256(off + (size_t)L.w * L.h * fch);
+        }
+        p->kept.push_back((int)k);
+    }
+    if (off > 0xfffffff0ull) FD_THROW(FD_ERR_INVALID_ARGUMENT, "ImagePyramid: pyramid exceeds 4 GB arena");
+    std::sort(p->kept.begin(), p->kept.end(), [&](int a, int b) { return p->all[a].index < p->all[b].index; });
+    p->arena_bytes = off + 256;
+    p->arena.reserve(p->arena_bytes);
+    p->h_layer_table.clear();
+    for (int k : p->kept) {
+        const HostLayer& L = p->all[k];
+        p->h_layer_table.push_back(LayerDesc{L.w, L.h, L.ch, 0, L.gray_off, L.filt_off});
+    }
+    p->layer_table.reserve(sizeof(LayerDesc) * std::max<size_t>(1, p->h_layer_table.size()));
+    if (!p->h_layer_table.empty())
+        HIP_CHECK(hipMemcpyAsync(p->layer_table.p, p->h_layer_table.data(), sizeof(LayerDesc) * p->h_layer_table.size(),
+                                 hipMemcpyHostToDevice, p->ctx->stream));
+}
+
+int grid_for(int npix) { return std::max(1, std::min(1024, (npix + 255) / 256)); }
+
+void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, int is_device) {
+    if (!image) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_update: image is NULL");
+    if (W < 1 || H < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_update: empty image");
+    if (ch != 1 && ch != 3) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_update: image must have 1 or 3 channels");
+    hipStream_t st = p->ctx->stream;
+    if (W != p->img_w || H != p->img_h || p->all.empty()) build_layout(p, W, H);
+    uint8_t* arena = p->arena.as<uint8_t>();
+    const size_t npix = (size_t)W * H;
+    const uint8_t* dimg = image;
+    if (!is_device) {
+        p->input.reserve(npix * ch);
+        HIP_CHECK(hipMemcpyAsync(p->input.p, image, npix * ch, hipMemcpyHostToDevice, st));
+        dimg = p->input.as<uint8_t>();
+    }
+    if (ch == 3) {
+        hipLaunchKernelGGL(k_bgr2gray, dim3(grid_for((int)npix)), dim3(256), 0, st, dimg, arena + p->gray_full_off, (int)npix);
+    } else {
+        HIP_CHECK(hipMemcpyAsync(arena + p->gray_full_off, dimg, npix, hipMemcpyDeviceToDevice, st));
+    }
+    // depth 0: resize from the full-resolution gray image
+    int maxDepth = 0;
+    for (const HostLayer& L : p->all) maxDepth = std::max(maxDepth, L.depth);
+    {
+        ResizeJobs jobs;
+        jobs.n = 0;
+        int maxpix = 0;
+        auto flush = [&]() {
+            if (!jobs.n) return;
+            hipLaunchKernelGGL(k_resize_linear, dim3(grid_for(maxpix), jobs.n), dim3(256), 0, st, arena, arena, p->gray_full_off, W, H, jobs);
+            jobs.n = 0;
+            maxpix = 0;
+        };
+        for (const HostLayer& L : p->all) {
+            if (L.depth != 0) continue;
+            ResizeJob& j = jobs.j[jobs.n++];
+            j.dw = L.w; j.dh = L.h; j.dst_off = L.gray_off;
+            j.scale_x = 1. / ((double)L.w / W);
+            j.scale_y = 1. / ((double)L.h / H);
+            maxpix = std::max(maxpix, L.w * L.h);
+            if (jobs.n == MAXJ) flush();
+        }
+        flush();
+    }
+    for (int d = 1; d <= maxDepth; ++d) {
+        DownJobs jobs;
+        jobs.n = 0;
+        int maxpix = 0;
+        auto flush = [&]() {
+            if (!jobs.n) return;
+            hipLaunchKernelGGL(k_pyrdown, dim3(grid_for(maxpix), jobs.n), dim3(256), 0, st, arena, jobs);
+            jobs.n = 0;
+            maxpix = 0;
+        };
+        for (size_t k = 0; k < p->all.size(); ++k) {
+            const HostLayer& L = p->all[k];
+            if (L.depth != d) continue;
+            const HostLayer& S = p->all[k - 1];  // previous entry of the same chain
+            DownJob& j = jobs.j[jobs.n++];
+            j.sw = S.w; j.sh = S.h; j.src_off = S.gray_off; j.dst_off = L.gray_off;
+            maxpix = std::max(maxpix, L.w * L.h);
+            if (jobs.n == MAXJ) flush();
+        }
+        flush();
+    }
+    if (p->filter_kind != FD_LAYER_NONE) {
+        FilterJobs jobs;
+        jobs.n = 0;
+        int maxpix = 0;
+        auto flush = [&]() {
+            if (!jobs.n) return;
+            dim3 g(grid_for(maxpix), jobs.n);
+            if (p->filter_kind == FD_LAYER_GRADBIN) {
+                if (p->interpolate)
+                    hipLaunchKernelGGL(k_gradbin<4>, g, dim3(256), 0, st, arena, p->lut.as<uint8_t>(), p->grad_kernel, jobs);
+                else
+                    hipLaunchKernelGGL(k_gradbin<2>, g, dim3(256), 0, st, arena, p->lut.as<uint8_t>(), p->grad_kernel, jobs);
+            } else {
+                hipLaunchKernelGGL(k_lbp, g, dim3(256), 0, st, arena, p->lbp_type, jobs);
+            }
+            jobs.n = 0;
+            maxpix = 0;
+        };
+        for (int k : p->kept) {
+            const HostLayer& L = p->all[k];
+            FilterJob& j = jobs.j[jobs.n++];
+            j.w = L.w; j.h = L.h; j.src_off = L.gray_off; j.dst_off = L.filt_off;
+            maxpix = std::max(maxpix, L.w * L.h);
+            if (jobs.n == MAXJ) flush();
+        }
+        flush();
+    }
+    HIP_CHECK(hipGetLastError());
+    p->version++;
+}
+
+}  // namespace
+
+// DirectPyramidFeatureExtractor::extract(stepX, stepY, roi) window grid, :75-123
+void fd_enumerate_layers(const fd_pyramid* p, int pw, int ph, int sx, int sy, const int* roiIn,
+                         std::vector<WindowLayer>& out, int64_t& total) {
+    if (sx < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "DirectPyramidFeatureExtractor: stepX has to be greater than zero");
+    if (sy < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "DirectPyramidFeatureExtractor: stepY has to be greater than zero");
+    if (pw < 1 || ph < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "DirectPyramidFeatureExtractor: empty patch size");
+    int rx = 0, ry = 0, rw = 0, rh = 0;
+    if (roiIn) { rx = roiIn[0]; ry = roiIn[1]; rw = roiIn[2]; rh = roiIn[3]; }
+    if (rx == 0 && ry == 0 && rw == 0 && rh == 0) {
+        rw = p->img_w;
+        rh = p->img_h;
+    } else {
+        int nx = std::max(0, rx), ny = std::max(0, ry);
+        rw = std::min(p->img_w, rw + nx) - nx;
+        rh = std::min(p->img_h, rh + ny) - ny;
+        rx = nx;
+        ry = ny;
+    }
+    out.clear();
+    total = 0;
+    for (size_t li = 0; li < p->kept.size(); ++li) {
+        const HostLayer& L = p->all[p->kept[li]];
+        auto scaled = [&](int v) { return fd_cvRound(v * L.scale); };     // ImagePyramidLayer.hpp:65-67
+        auto original = [&](int v) { return fd_cvRound(v / L.scale); };   // :98-100
+        WindowLayer wl;
+        wl.layer = (int)li;
+        wl.ow = original(pw);
+        wl.oh = original(ph);
+        wl.bx = scaled(rx);
+        wl.by = scaled(ry);
+        int ex = scaled(rx + rw), ey = scaled(ry + rh);
+        // positions x = bx + k*sx with x + pw < ex  (strict)
+        long spanx = (long)ex - pw - wl.bx, spany = (long)ey - ph - wl.by;
+        wl.nx = spanx > 0 ? (int)((spanx - 1) / sx + 1) : 0;
+        wl.ny = spany > 0 ? (int)((spany - 1) / sy + 1) : 0;
+        // windows must lie inside the layer (cv::Mat(image, bounds) would assert otherwise)
+        if (wl.nx > 0 && wl.ny > 0) {
+            if (wl.bx < 0 || wl.by < 0 || wl.bx + (wl.nx - 1) * sx + pw > L.w || wl.by + (wl.ny - 1) * sy + ph > L.h)
+                FD_THROW(FD_ERR_RUNTIME, "DirectPyramidFeatureExtractor: window outside of pyramid layer %d", L.index);
+        } else {
+            wl.nx = wl.ny = 0;
+        }
+        wl.first = total;
+        total += (int64_t)wl.nx * wl.ny;
+        out.push_back(wl);
+    }
+}
+
+extern "C" {
+
+int fd_pyramid_create(fd_ctx* ctx, int octl, double minS, double maxS, fd_pyramid** out) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !out) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_create: NULL argument");
+        if (octl <= 0) FD_THROW(FD_ERR_INVALID_ARGUMENT, "the number of layers per octave must be greater than zero");
+        if (minS <= 0) FD_THROW(FD_ERR_INVALID_ARGUMENT, "the minimum scale factor must be greater than zero");
+        if (maxS > 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "the maximum scale factor must not exceed one");
+        fd_pyramid* p = new fd_pyramid();
+        p->ctx = ctx;
+        p->octl = (size_t)octl;
+        p->inc = std::pow(0.5, 1. / octl);
+        p->minS = minS;
+        p->maxS = maxS;
+        *out = p;
+    });
+}
+
+int fd_pyramid_create_inc(fd_ctx* ctx, double inc, double minS, double maxS, fd_pyramid** out) {
+    return fd_guard(ctx, [&] {
+        if (inc <= 0 || inc >= 1)
+            FD_THROW(FD_ERR_INVALID_ARGUMENT, "the incremental scale factor must be greater than zero and smaller than one");
+    }) ?: fd_pyramid_create(ctx, (int)std::round(std::log(0.5) / std::log(inc)), minS, maxS, out);
+}
+
+void fd_pyramid_destroy(fd_pyramid* p) { delete p; }
+
+int fd_pyramid_set_layer_filter(fd_pyramid* p, int kind, int bins, int signed_gradients, int interpolate, int grad_kernel,
+                                int lbp_type) {
+    return fd_guard(p ? p->ctx : nullptr, [&] {
+        if (!p) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_set_layer_filter: NULL pyramid");
+        if (kind == FD_LAYER_GRADBIN) {
+            if (grad_kernel != 1 && grad_kernel != 3)
+                FD_THROW(FD_ERR_INVALID_ARGUMENT, "GradientFilter: the kernel size must be 1 or 3 on this backend");
+            if (bins < 1 || bins > 255) FD_THROW(FD_ERR_INVALID_ARGUMENT, "GradientBinningFilter: bins must be in 1..255");
+            std::vector<uint8_t> lut;
+            build_gradient_lut(bins, signed_gradients != 0, interpolate != 0, lut);
+            p->lut.reserve(lut.size());
+            HIP_CHECK(hipMemcpyAsync(p->lut.p, lut.data(), lut.size(), hipMemcpyHostToDevice, p->ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+        } else if (kind == FD_LAYER_LBP) {
+            if (lbp_type < 0 || lbp_type > 3) FD_THROW(FD_ERR_INVALID_ARGUMENT, "LbpFilter: invalid type");
+        } else if (kind != FD_LAYER_NONE) {
+            FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_set_layer_filter: unknown kind %d", kind);
+        }
+        p->filter_kind = kind;
+        p->bins = bins;
+        p->signed_gradients = signed_gradients;
+        p->interpolate = interpolate;
+        p->grad_kernel = grad_kernel;
+        p->lbp_type = lbp_type;
+        p->all.clear();  // force a new layout
+        p->img_w = p->img_h = 0;
+    });
+}
+
+int fd_pyramid_update(fd_pyramid* p, const uint8_t* image, int w, int h, int ch, int is_device) {
+    return fd_guard(p ? p->ctx : nullptr, [&] {
+        if (!p) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_update: NULL pyramid");
+        HIP_CHECK(hipSetDevice(p->ctx->device));
+        pyramid_update(p, image, w, h, ch, is_device);
+    });
+}
+
+int fd_pyramid_octave_layer_count(const fd_pyramid* p) { return p ? (int)p->octl : 0; }
+double fd_pyramid_incremental_scale(const fd_pyramid* p) { return p ? p->inc : 0.0; }
+int fd_pyramid_layer_count(const fd_pyramid* p) { return p ? (int)p->kept.size() : 0; }
+
+int fd_pyramid_layer_info(const fd_pyramid* p, int i, int* index, double* scale, int* w, int* h, int* ch) {
+    if (!p || i < 0 || i >= (int)p->kept.size()) return FD_ERR_INVALID_ARGUMENT;
+    const HostLayer& L = p->all[p->kept[i]];
+    if (index) *index = L.index;
+    if (scale) *scale = L.scale;
+    if (w) *w = L.w;
+    if (h) *h = L.h;
+    if (ch) *ch = L.ch;
+    return FD_OK;
+}
+
+int fd_pyramid_layer_download(fd_pyramid* p, int i, uint8_t* host_dst) {
+    return fd_guard(p ? p->ctx : nullptr, [&] {
+        if (!p || !host_dst || i < 0 || i >= (int)p->kept.size()) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_layer_download: bad argument");
+        const HostLayer& L = p->all[p->kept[i]];
+        HIP_CHECK(hipMemcpyAsync(host_dst, p->arena.as<uint8_t>() + L.filt_off, (size_t)L.w * L.h * L.ch, hipMemcpyDeviceToHost, p->ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    });
+}
+
+int fd_pyramid_window_count(const fd_pyramid* p, int pw, int ph, int sx, int sy, const int* roi, int64_t* count) {
+    return fd_guard(p ? p->ctx : nullptr, [&] {
+        if (!p || !count) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_window_count: NULL argument");
+        std::vector<WindowLayer> wl;
+        fd_enumerate_layers(p, pw, ph, sx, sy, roi, wl, *count);
+    });
+}
+
+int fd_pyramid_windows(const fd_pyramid* p, int pw, int ph, int sx, int sy, const int* roi, int32_t* out, int64_t cap,
+                       int64_t* count) {
+    return fd_guard(p ? p->ctx : nullptr, [&] {
+        if (!p || !count) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_windows: NULL argument");
+        std::vector<WindowLayer> wl;
+        int64_t total;
+        fd_enumerate_layers(p, pw, ph, sx, sy, roi, wl, total);
+        *count = total;
+        if (!out) return;
+        int64_t n = 0;
+        for (const WindowLayer& w : wl) {
+            const HostLayer& L = p->all[p->kept[w.layer]];
+            for (int iy = 0; iy < w.ny; ++iy)
+                for (int ix = 0; ix < w.nx; ++ix, ++n) {
+                    if (n >= cap) continue;
+                    int x = w.bx + ix * sx, y = w.by + iy * sy;
+                    int32_t* o = out + 7 * n;
+                    o[0] = w.layer; o[1] = x; o[2] = y;
+                    o[3] = fd_cvRound(x / L.scale) + w.ow / 2;
+                    o[4] = fd_cvRound(y / L.scale) + w.oh / 2;
+                    o[5] = w.ow; o[6] = w.oh;
+                }
+        }
+        if (total > cap) FD_THROW(FD_ERR_CAPACITY, "fd_pyramid_windows: %lld windows, capacity %lld", (long long)total, (long long)cap);
+    });
+}
+
+int fd_greyworld(fd_ctx* ctx, const uint8_t* bgr, int w, int h, uint8_t* dst, int is_device) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !bgr || !dst || w < 1 || h < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_greyworld: bad argument");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const int n = w * h;
+        DevBuf in, out, stats;
+        const uint8_t* din = bgr;
+        uint8_t* dout = dst;
+        if (!is_device) {
+            in.reserve((size_t)n * 3);
+            out.reserve((size_t)n * 3);
+            HIP_CHECK(hipMemcpyAsync(in.p, bgr, (size_t)n * 3, hipMemcpyHostToDevice, ctx->stream));
+            din = in.as<uint8_t>();
+            dout = out.as<uint8_t>();
+        }
+        stats.reserve(64);
+        HIP_CHECK(hipMemsetAsync(stats.p, 0, 64, ctx->stream));
+        unsigned long long* sums = stats.as<unsigned long long>();
+        unsigned int* maxs = (unsigned int*)(sums + 3);
+        hipLaunchKernelGGL(k_greyworld_stats, dim3(grid_for(n)), dim3(256), 0, ctx->stream, din, n, sums, maxs);
+        unsigned long long hs[4];
+        HIP_CHECK(hipMemcpyAsync(hs, stats.p, 40, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        unsigned int hm[3];
+        std::memcpy(hm, (char*)hs + 24, 12);
+        // scalar part exactly as GreyWorldNormalizationFilter.cpp:45-60 (double, host)
+        double mean[3], maxNew[3], scale[3];
+        for (int c = 0; c < 3; ++c) { mean[c] = (double)hs[c] / n; maxNew[c] = (uint8_t)hm[c] / mean[c]; }
+        double mx = maxNew[0];
+        if (maxNew[1] > mx) mx = maxNew[1];
+        if (maxNew[2] > mx) mx = maxNew[2];
+        for (int c = 0; c < 3; ++c) scale[c] = 255.0 / (mean[c] * mx);
+        hipLaunchKernelGGL(k_greyworld_apply, dim3(grid_for(n)), dim3(256), 0, ctx->stream, din, dout, n, scale[0], scale[1], scale[2]);
+        if (!is_device) HIP_CHECK(hipMemcpyAsync(dst, dout, (size_t)n * 3, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,503 @@
+// featuredetection_amd/csrc/sdm.hip -- supervised descent landmark fitting on the GPU.
+//
+// superviseddescent::SdmLandmarkModelFitting::optimize (SdmLandmarkModel.hpp:199-256) for a batch of
+// faces: per cascade step
+//   k_sdm_prepare      dynamic face size, window half size (:212-229), integer patch origins and the
+//                      zero-border quirk of DescriptorExtractor.hpp:156-178,
+//   k_sdm_descriptors  one wavefront per (face, landmark): crop -> fp32 bilinear resize to 30x30
+//                      (cv::resize semantics) -> VLFeat HOG (hog.c:596-721,858-1063).  Lane e owns one
+//                      (cell, orientation) accumulator and walks the pixels in the reference's scan
+//                      order, so descriptors are bit-identical to hog.c,
+//   k_sdm_regress      delta = F * R[0:-1] + R[-1] (:241) as a batch x regressor contraction on the f64
+//                      MFMA pipe (v_mfma_f64_16x16x4_f64): fp32 inputs are exact in f64 and the sum is
+//                      rounded to fp32 once, like OpenCV's gemm (double accumulator), which keeps the
+//                      next step's cvRound(landmark) decisions identical to the CPU path,
+//   k_sdm_update       shape += delta * d (:243).
+// MFMA-bound stage: 2*B*F*2L flop per step; HBM: R (F+1)*2L*4 B + descriptors.
+#include "fd_internal.hpp"
+#include <algorithm>
+#include <cstring>
+#include <memory>
+
+namespace {
+
+constexpr int SDM_IMG = 48;          // max working image side in LDS
+constexpr int SDM_MAX_CELLS = 12;    // per dimension
+constexpr int SDM_MAX_ORI = 16;
+
+struct DescParams {
+    int32_t W, H;              // gray image size
+    int32_t L;                 // landmarks per face
+    int32_t adaptive;          // 1: resize patch to 30x30, cell 10, 9 orientations
+    int32_t cellSize, nori, variant;
+    int32_t iw, ih;            // working image size (30x30 when adaptive, side x side otherwise)
+    int32_t hogW, hogH, dim, len;
+    int64_t image_stride;      // bytes between consecutive face images
+    int32_t ldsPerWave;        // bytes of LDS one wavefront needs (host-computed)
+    float oX[SDM_MAX_ORI], oY[SDM_MAX_ORI];  // hog.c:195-204, computed on the host with libm like the reference
+};
+
+struct DescLds {   // per-wave views carved out of dynamic LDS
+    float* img;
+    float* grad;
+    unsigned char* ori;
+    float *wx1, *wx2;
+    int* binx;
+    float *hog, *norm, *feat;
+};
+__host__ __device__ inline int align16i(int v) { return (v + 15) & ~15; }
+__host__ __device__ inline int desc_lds_bytes(int iw, int ih, int ncell, int nori, int dim) {
+    const int m = iw > ih ? iw : ih;
+    return 2 * align16i(iw * ih * 4) + align16i(iw * ih) + 3 * align16i(m * 4) + align16i(ncell * nori * 2 * 4) + align16i(ncell * 4) +
+           align16i(ncell * dim * 4);
+}
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// per (face, landmark): integer patch origin in image coordinates (may be negative: zero border),
+// side length, validity.  origin[.] = {ox, oy, side, valid}
+__global__ void k_sdm_prepare(const float* __restrict__ shapes, int B, int L, int W, int H, int adaptive, int fixedHalf,
+                              int maxSide, double stepFactor, int32_t* __restrict__ origin, float* __restrict__ dist_out,
+                              int32_t* __restrict__ status) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= B) return;
+    const float* s = shapes + (size_t)f * 2 * L;
+    int pwh = fixedHalf;
+    float dist = 0.f;
+    if (adaptive) {
+        // SdmLandmarkModel.hpp:212-229
+        const float a1x = (s[8] + s[9]) / 2.0f, a1y = (s[8 + L] + s[9 + L]) / 2.0f;
+        const float a2x = (s[11] + s[12]) / 2.0f, a2y = (s[11 + L] + s[12 + L]) / 2.0f;
+        const double dx = (double)(a1x - a2x), dy = (double)(a1y - a2y);
+        dist = (float)sqrt(dx * dx + dy * dy);
+        const float windowSize = dist / 2.0f;
+        float windowSizeHalf = windowSize / 2;
+        windowSizeHalf = (float)round((double)windowSizeHalf * stepFactor);
+        const int wi = (int)windowSizeHalf;
+        pwh = wi + 3 - (wi % 3);
+    }
+    dist_out[f] = dist;
+    const int side = 2 * pwh;
+    for (int i = 0; i < L; ++i) {
+        const int x = __float2int_rn(s[i]), y = __float2int_rn(s[i + L]);
+        int ox = x - pwh, oy = y - pwh, valid = 1;
+        if (x - pwh < 0 || y - pwh < 0 || x + pwh >= W || y + pwh >= H) {
+            const int bl = (x - pwh) < 0 ? abs(x - pwh) : 0;
+            const int bt = (y - pwh) < 0 ? abs(y - pwh) : 0;
+            const int br = (x + pwh) >= W ? abs(W - (x + pwh)) : 0;
+            const int bb = (y + pwh) >= H ? abs(H - (y + pwh)) : 0;
+            const int rx = (x - pwh) + bl, ry = (y - pwh) + br;  // reference quirk: y uses borderRight (:171)
+            const int EW = W + bl + br, EH = H + bt + bb;
+            if (rx < 0 || ry < 0 || rx + side > EW || ry + side > EH) valid = 0;  // cv::Mat roi assertion
+            ox = rx - bl;
+            oy = ry - bt;
+        }
+        if (side < 4 || side > maxSide) valid = 0;
+        int32_t* o = origin + 4 * ((size_t)f * L + i);
+        o[0] = ox; o[1] = oy; o[2] = side; o[3] = valid;
+        if (!valid) status[f] = 1;
+    }
+}
+
+__device__ __forceinline__ float src_px(const uint8_t* __restrict__ img, int W, int H, int x, int y) {
+    return (x >= 0 && y >= 0 && x < W && y < H) ? (float)img[(size_t)y * W + x] : 0.f;
+}
+
+// one wavefront per (face, landmark)
+__global__ __launch_bounds__(128) void k_sdm_descriptors(const uint8_t* __restrict__ images, const int32_t* __restrict__ origin,
+                                                         DescParams p, int64_t nitems, float* __restrict__ out, int64_t out_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int iw = p.iw, ih = p.ih, cs = p.cellSize, nori = p.nori;
+    const int hogW = p.hogW, hogH = p.hogH;
+    const int ncell = hogW * hogH;
+    DescLds S;
+    {
+        unsigned char* b = smem + (size_t)wave * p.ldsPerWave;
+        const int m = iw > ih ? iw : ih;
+        S.img = (float*)b; b += align16i(iw * ih * 4);
+        S.grad = (float*)b; b += align16i(iw * ih * 4);
+        S.ori = b; b += align16i(iw * ih);
+        S.wx1 = (float*)b; b += align16i(m * 4);
+        S.wx2 = (float*)b; b += align16i(m * 4);
+        S.binx = (int*)b; b += align16i(m * 4);
+        S.hog = (float*)b; b += align16i(ncell * nori * 2 * 4);
+        S.norm = (float*)b; b += align16i(ncell * 4);
+        S.feat = (float*)b;
+    }
+    for (int64_t item = (int64_t)blockIdx.x * 2 + wave; item < nitems; item += (int64_t)gridDim.x * 2) {
+        const int64_t face = item / p.L;
+        const int lm = (int)(item - face * p.L);
+        const int32_t* org = origin + 4 * item;
+        const int ox = org[0], oy = org[1], side = org[2], valid = org[3];
+        float* dst = out + face * out_stride + (size_t)lm * p.len;
+        if (!valid) {
+            for (int i = lane; i < p.len; i += 64) dst[i] = 0.f;
+            continue;
+        }
+        const uint8_t* img = images + face * p.image_stride;
+        // ---- working image: crop (+ fp32 bilinear resize to 30x30 when adaptive)
+        if (p.adaptive && side != iw) {
+            const double scale = 1. / ((double)iw / side);  // cv::resize: scale = 1/inv_scale
+            for (int i = lane; i < iw * ih; i += 64) {
+                const int dy = i / iw, dx = i - dy * iw;
+                float fx = (float)((dx + 0.5) * scale - 0.5);
+                int sx = (int)floorf(fx);
+                fx -= sx;
+                if (sx < 0) { fx = 0; sx = 0; }
+                if (sx >= side - 1) { fx = 0; sx = side - 1; }
+                float fy = (float)((dy + 0.5) * scale - 0.5);
+                int sy = (int)floorf(fy);
+                fy -= sy;
+                const int y0 = sy < 0 ? 0 : (sy >= side ? side - 1 : sy);
+                const int y1 = sy + 1 < 0 ? 0 : (sy + 1 >= side ? side - 1 : sy + 1);
+                const int sx1 = sx + 1 < side ? sx + 1 : sx;
+                const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+                const float r0 = src_px(img, p.W, p.H, ox + sx, oy + y0) * a0 + src_px(img, p.W, p.H, ox + sx1, oy + y0) * a1;
+                const float r1 = src_px(img, p.W, p.H, ox + sx, oy + y1) * a0 + src_px(img, p.W, p.H, ox + sx1, oy + y1) * a1;
+                S.img[i] = r0 * b0 + r1 * b1;
+            }
+        } else {
+            for (int i = lane; i < iw * ih; i += 64) {
+                const int dy = i / iw, dx = i - dy * iw;
+                S.img[i] = src_px(img, p.W, p.H, ox + dx, oy + dy);
+            }
+        }
+        // column/row interpolation tables: hx = (x + 0.5) / cellSize - 0.5 (hog.c:697-704); rows use the same table
+        for (int x = lane; x < max(iw, ih); x += 64) {
+            const float hx = (float)((x + 0.5) / cs - 0.5);
+            int b = (int)hx;
+            if (!(hx >= 0 || (float)b == hx)) b -= 1;  // vl_floor_f
+            const float w2 = hx - b;
+            const float w1 = (float)(1.0 - (double)w2);
+            S.binx[x] = b; S.wx1[x] = w1; S.wx2[x] = w2;
+        }
+        for (int i = lane; i < ncell * nori * 2; i += 64) S.hog[i] = 0.f;
+        wave_sync();
+        // ---- gradient magnitude and hard orientation assignment per interior pixel (hog.c:612-665)
+        for (int i = lane; i < iw * ih; i += 64) {
+            const int y = i / iw, x = i - y * iw;
+            if (x < 1 || y < 1 || x >= iw - 1 || y >= ih - 1) continue;
+            const float* it = S.img + i;
+            float gradx = *(it + 1) - *(it - 1);
+            float grady = *(it + iw) - *(it - iw);
+            float grad2 = gradx * gradx + grady * grady;
+            if (!(grad2 > 0.f)) { gradx = 0.f; grady = 0.f; grad2 = 0.f; }
+            const float grad = sqrtf(grad2);
+            const double den = (double)grad > 1e-10 ? (double)grad : 1e-10;
+            gradx = (float)((double)gradx / den);
+            grady = (float)((double)grady / den);
+            float w0 = 0.f;
+            int b0 = -1;
+            for (int k = 0; k < nori; ++k) {
+                float score = gradx * p.oX[k] + grady * p.oY[k];
+                int bin = k;
+                if (score < 0) { score = -score; bin += nori; }
+                if (score > w0) { b0 = bin; w0 = score; }
+            }
+            S.grad[i] = grad;
+            S.ori[i] = (unsigned char)(b0 < 0 ? 255 : b0);
+        }
+        wave_sync();
+        // ---- spatial voting: lane e = (orientation, cell); sequential fp32 adds in pixel scan order
+        for (int e = lane; e < ncell * nori * 2; e += 64) {
+            const int o = e / ncell, c = e - o * ncell;
+            const int cy = c / hogW, cx = c - cy * hogW;
+            float acc = 0.f;
+            for (int y = 1; y < ih - 1; ++y) {
+                const int by = S.binx[y];
+                if (by != cy && by + 1 != cy) continue;
+                const float wy = by == cy ? S.wx1[y] : S.wx2[y];
+                for (int x = 1; x < iw - 1; ++x) {
+                    const int bx = S.binx[x];
+                    if (bx != cx && bx + 1 != cx) continue;
+                    if ((int)S.ori[y * iw + x] != o) continue;
+                    const float wx = bx == cx ? S.wx1[x] : S.wx2[x];
+                    acc = acc + S.grad[y * iw + x] * wx * wy;
+                }
+            }
+            S.hog[e] = acc;  // layout hog[x + y*hogW + o*hogStride] == e
+        }
+        wave_sync();
+        // ---- undirected squared norms (hog.c:878-893)
+        for (int c = lane; c < ncell; c += 64) {
+            float nrm = 0.f;
+            for (int k = 0; k < nori; ++k) {
+                const float h = S.hog[c + k * ncell] + S.hog[c + (k + nori) * ncell];
+                nrm = nrm + h * h;
+            }
+            S.norm[c] = nrm;
+        }
+        wave_sync();
+        // ---- block normalisation and feature assembly (hog.c:925-1060); one cell per lane
+        const int dim = p.dim;
+        for (int c = lane; c < ncell; c += 64) {
+            const int y = c / hogW, x = c - y * hogW;
+            const int xm = max(x - 1, 0), xp = min(x + 1, hogW - 1), ym = max(y - 1, 0), yp = min(y + 1, hogH - 1);
+            const double n1 = S.norm[xm + ym * hogW], n2 = S.norm[x + ym * hogW], n3 = S.norm[xp + ym * hogW];
+            const double n4 = S.norm[xm + y * hogW], n5 = S.norm[x + y * hogW], n6 = S.norm[xp + y * hogW];
+            const double n7 = S.norm[xm + yp * hogW], n8 = S.norm[x + yp * hogW], n9 = S.norm[xp + yp * hogW];
+            const double f1 = 1.0 / sqrt(n1 + n2 + n4 + n5 + 1e-4);
+            const double f2 = 1.0 / sqrt(n2 + n3 + n5 + n6 + 1e-4);
+            const double f3 = 1.0 / sqrt(n4 + n5 + n7 + n8 + 1e-4);
+            const double f4 = 1.0 / sqrt(n5 + n6 + n8 + n9 + 1e-4);
+            double t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+            for (int k = 0; k < nori; ++k) {
+                const double ha = S.hog[c + k * ncell], hb = S.hog[c + (k + nori) * ncell];
+                double ha1 = f1 * ha, ha2 = f2 * ha, ha3 = f3 * ha, ha4 = f4 * ha;
+                double hb1 = f1 * hb, hb2 = f2 * hb, hb3 = f3 * hb, hb4 = f4 * hb;
+                double hc1 = ha1 + hb1, hc2 = ha2 + hb2, hc3 = ha3 + hb3, hc4 = ha4 + hb4;
+                ha1 = fmin(0.2, ha1); ha2 = fmin(0.2, ha2); ha3 = fmin(0.2, ha3); ha4 = fmin(0.2, ha4);
+                hb1 = fmin(0.2, hb1); hb2 = fmin(0.2, hb2); hb3 = fmin(0.2, hb3); hb4 = fmin(0.2, hb4);
+                hc1 = fmin(0.2, hc1); hc2 = fmin(0.2, hc2); hc3 = fmin(0.2, hc3); hc4 = fmin(0.2, hc4);
+                t1 = t1 + hc1; t2 = t2 + hc2; t3 = t3 + hc3; t4 = t4 + hc4;
+                if (p.variant == 1) {
+                    S.feat[c + k * ncell] = (float)(0.5 * (ha1 + ha2 + ha3 + ha4));
+                    S.feat[c + (k + nori) * ncell] = (float)(0.5 * (hb1 + hb2 + hb3 + hb4));
+                    S.feat[c + (k + 2 * nori) * ncell] = (float)(0.5 * (hc1 + hc2 + hc3 + hc4));
+                } else {
+                    S.feat[c + k * ncell] = (float)hc1;
+                    S.feat[c + (k + nori) * ncell] = (float)hc2;
+                    S.feat[c + (k + 2 * nori) * ncell] = (float)hc3;
+                    S.feat[c + (k + 3 * nori) * ncell] = (float)hc4;
+                }
+            }
+            if (p.variant == 1) {
+                const float q = 1.0f / sqrtf(18.0f);
+                S.feat[c + (3 * nori + 0) * ncell] = (float)((double)q * t1);
+                S.feat[c + (3 * nori + 1) * ncell] = (float)((double)q * t2);
+                S.feat[c + (3 * nori + 2) * ncell] = (float)((double)q * t3);
+                S.feat[c + (3 * nori + 3) * ncell] = (float)((double)q * t4);
+            }
+        }
+        wave_sync();
+        // ---- per-plane transpose and stack (DescriptorExtractor.hpp:198-205): out[j][c][r] = feat[j][r][c]
+        for (int i = lane; i < dim * ncell; i += 64) {
+            const int j = i / ncell, rem = i - j * ncell;
+            const int cc = rem / hogH, r = rem - cc * hogH;
+            dst[i] = S.feat[j * ncell + r * hogW + cc];
+        }
+        wave_sync();
+    }
+}
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int RG_KCHUNK = 256;
+
+// delta partial sums: one wavefront per (16-face tile, 16-output tile, K chunk) on the f64 MFMA pipe
+__global__ __launch_bounds__(64) void k_sdm_regress(const float* __restrict__ D, int B, int F, const float* __restrict__ R, int N,
+                                                    double* __restrict__ partial, int nchunks) {
+    const int lane = threadIdx.x;
+    const int mt = blockIdx.x, nt = blockIdx.y, ch = blockIdx.z;
+    const int i = mt * 16 + (lane & 15), j = nt * 16 + (lane & 15), kq = lane >> 4;
+    const int k0 = ch * RG_KCHUNK, k1 = min(F, k0 + RG_KCHUNK);
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    const bool iok = i < B, jok = j < N;
+    for (int k = k0; k < k1; k += 4) {
+        const int kk = k + kq;
+        const double a = (iok && kk < k1) ? (double)D[(size_t)i * F + kk] : 0.0;
+        const double b = (jok && kk < k1) ? (double)R[(size_t)kk * N + j] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = mt * 16 + (lane >> 4) + 4 * r;
+        if (row < B && jok) partial[((size_t)ch * B + row) * N + j] = acc[r];
+    }
+}
+
+// shape += (float)(sum of partials + bias row) * dist   (SdmLandmarkModel.hpp:241-243)
+__global__ void k_sdm_update(float* __restrict__ shapes, const double* __restrict__ partial, int nchunks, const float* __restrict__ biasRow,
+                             const float* __restrict__ dist, int B, int N) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * N) return;
+    const int f = idx / N, j = idx - f * N;
+    double acc = 0.0;
+    for (int c = 0; c < nchunks; ++c) acc = acc + partial[((size_t)c * B + f) * N + j];
+    acc = acc + (double)biasRow[j];
+    const float delta = (float)acc;
+    const float t = delta * dist[f];
+    shapes[idx] = shapes[idx] + t;
+}
+
+}  // namespace
+
+struct fd_sdm {
+    fd_ctx* ctx;
+    int L, S, variant;
+    std::vector<float> mean;
+    std::vector<int> Rrows;
+    std::vector<std::unique_ptr<DevBuf>> R;
+    DevBuf images, shapes, origin, dist, status, desc, partial;
+};
+
+namespace {
+
+void fill_desc_params(DescParams& p, int W, int H, int L, bool adaptive, int variant, int numCells, int cellSize, int numBins,
+                      int side) {
+    std::memset(&p, 0, sizeof(p));
+    p.W = W; p.H = H; p.L = L;
+    p.adaptive = adaptive ? 1 : 0;
+    p.variant = variant;
+    if (adaptive) { p.cellSize = 10; p.nori = 9; p.iw = p.ih = 30; }
+    else { p.cellSize = cellSize; p.nori = numBins; p.iw = p.ih = side; }
+    (void)numCells;
+    if (p.cellSize < 1 || p.nori < 1 || p.nori > SDM_MAX_ORI) FD_THROW(FD_ERR_INVALID_ARGUMENT, "VlHog: unsupported cellSize/numBins");
+    if (p.iw < 4 || p.iw > SDM_IMG) FD_THROW(FD_ERR_INVALID_ARGUMENT, "VlHog: patch side %d outside 4..%d", p.iw, SDM_IMG);
+    p.hogW = (p.iw + p.cellSize / 2) / p.cellSize;
+    p.hogH = (p.ih + p.cellSize / 2) / p.cellSize;
+    if (p.hogW < 1 || p.hogH < 1 || p.hogW > SDM_MAX_CELLS || p.hogH > SDM_MAX_CELLS)
+        FD_THROW(FD_ERR_INVALID_ARGUMENT, "VlHog: %dx%d cells unsupported", p.hogW, p.hogH);
+    p.dim = variant == 1 ? 3 * p.nori + 4 : 4 * p.nori;
+    p.len = p.hogW * p.hogH * p.dim;
+    for (int o = 0; o < p.nori; ++o) {
+        double angle = o * 3.141592653589793 / p.nori;
+        p.oX[o] = (float)std::cos(angle);
+        p.oY[o] = (float)std::sin(angle);
+    }
+    p.ldsPerWave = desc_lds_bytes(p.iw, p.ih, p.hogW * p.hogH, p.nori, p.dim);
+    if (2 * p.ldsPerWave > 64 * 1024) FD_THROW(FD_ERR_INVALID_ARGUMENT, "VlHog: patch too large for the LDS budget");
+}
+
+}  // namespace
+
+extern "C" {
+
+int fd_sdm_create(fd_ctx* ctx, const fd_sdm_model* md, fd_sdm** out) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !md || !out || !md->mean || !md->R || !md->R_rows) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_sdm_create: NULL argument");
+        if (md->num_landmarks < 13) FD_THROW(FD_ERR_INVALID_ARGUMENT, "SdmLandmarkModelFitting needs landmarks 8,9,11,12 (SdmLandmarkModel.hpp:212-216)");
+        if (md->num_steps < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "SdmLandmarkModel: no cascade steps");
+        if (md->hog_variant != 0 && md->hog_variant != 1)
+            FD_THROW(FD_ERR_LOGIC, "descriptorType does not match 'vlhog-dt' or 'vlhog-uoctti'");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        std::unique_ptr<fd_sdm> m(new fd_sdm());
+        m->ctx = ctx;
+        m->L = md->num_landmarks;
+        m->S = md->num_steps;
+        m->variant = md->hog_variant;
+        m->mean.assign(md->mean, md->mean + 2 * m->L);
+        const int dim = m->variant == 1 ? 31 : 36;
+        for (int s = 0; s < m->S; ++s) {
+            if (md->R_rows[s] != m->L * 9 * dim + 1)
+                FD_THROW(FD_ERR_INVALID_ARGUMENT, "regressor %d has %d rows, expected %d (adaptive 3x3x%d descriptor per landmark + bias)",
+                         s, md->R_rows[s], m->L * 9 * dim + 1, dim);
+            m->Rrows.push_back(md->R_rows[s]);
+            std::unique_ptr<DevBuf> b(new DevBuf());
+            const size_t bytes = sizeof(float) * (size_t)md->R_rows[s] * 2 * m->L;
+            b->reserve(bytes);
+            HIP_CHECK(hipMemcpy(b->p, md->R[s], bytes, hipMemcpyHostToDevice));
+            m->R.push_back(std::move(b));
+        }
+        *out = m.release();
+    });
+}
+
+void fd_sdm_destroy(fd_sdm* m) { delete m; }
+
+int fd_sdm_descriptors(fd_ctx* ctx, const uint8_t* gray, int W, int H, const float* px, const float* py, int n, int wsh,
+                       int variant, int numCells, int cellSize, int numBins, float* out, int* len) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !gray || !px || !py || n < 0 || W < 1 || H < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_sdm_descriptors: bad argument");
+        if (variant != 0 && variant != 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_sdm_descriptors: unknown HOG variant");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const bool adaptive = wsh > 0;
+        const int pwh = adaptive ? wsh : numCells * (cellSize / 2);
+        DescParams p;
+        fill_desc_params(p, W, H, n, adaptive, variant, numCells, cellSize, numBins, 2 * pwh);
+        p.image_stride = 0;
+        if (len) *len = p.len;
+        if (!out || n == 0) return;
+        hipStream_t st = ctx->stream;
+        DevBuf dimg, dshape, dorigin, ddist, dstatus, ddesc;
+        dimg.reserve((size_t)W * H);
+        dshape.reserve(sizeof(float) * 2 * (size_t)n);
+        dorigin.reserve(sizeof(int32_t) * 4 * (size_t)n);
+        ddist.reserve(16);
+        dstatus.reserve(16);
+        ddesc.reserve(sizeof(float) * (size_t)n * p.len);
+        HIP_CHECK(hipMemcpyAsync(dimg.p, gray, (size_t)W * H, hipMemcpyHostToDevice, st));
+        std::vector<float> shape(2 * (size_t)n);
+        for (int i = 0; i < n; ++i) { shape[i] = px[i]; shape[i + n] = py[i]; }
+        HIP_CHECK(hipMemcpyAsync(dshape.p, shape.data(), sizeof(float) * shape.size(), hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemsetAsync(dstatus.p, 0, 4, st));
+        // one "face" with n landmarks and a fixed half window
+        hipLaunchKernelGGL(k_sdm_prepare, dim3(1), dim3(64), 0, st, dshape.as<float>(), 1, n, W, H, 0, pwh, adaptive ? (1 << 20) : SDM_IMG, 1.0, dorigin.as<int32_t>(),
+                           ddist.as<float>(), dstatus.as<int32_t>());
+        hipLaunchKernelGGL(k_sdm_descriptors, dim3((n + 1) / 2), dim3(128), 2 * p.ldsPerWave, st, dimg.as<uint8_t>(), dorigin.as<int32_t>(), p, (int64_t)n,
+                           ddesc.as<float>(), (int64_t)n * p.len);
+        HIP_CHECK(hipGetLastError());
+        int32_t status = 0;
+        HIP_CHECK(hipMemcpyAsync(out, ddesc.p, sizeof(float) * (size_t)n * p.len, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(&status, dstatus.p, 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (status) FD_THROW(FD_ERR_RUNTIME, "VlHogDescriptorExtractor: patch window leaves the zero-extended image (cv::Mat roi assertion in the reference)");
+    });
+}
+
+int fd_sdm_fit_batch(fd_ctx* ctx, const fd_sdm* m_, const uint8_t* gray_images, int W, int H, int batch, const int32_t* face_boxes,
+                     int images_on_device, float* shapes_out, int32_t* status_out) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !m_ || !gray_images || !face_boxes || !shapes_out || batch < 0 || W < 1 || H < 1)
+            FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_sdm_fit_batch: bad argument");
+        if (batch == 0) return;
+        fd_sdm* m = const_cast<fd_sdm*>(m_);
+        HIP_CHECK(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        const int L = m->L, N = 2 * L, B = batch;
+        const uint8_t* dimg = gray_images;
+        if (!images_on_device) {
+            m->images.reserve((size_t)W * H * B);
+            HIP_CHECK(hipMemcpyAsync(m->images.p, gray_images, (size_t)W * H * B, hipMemcpyHostToDevice, st));
+            dimg = m->images.as<uint8_t>();
+        }
+        // alignRigid (SdmLandmarkModel.hpp:156-192) on the host, exactly as the cv::MatExpr evaluates it:
+        // x * float(w) + float(0.5 * w + bx)
+        std::vector<float> shapes((size_t)B * N);
+        for (int f = 0; f < B; ++f) {
+            const int32_t* fb = face_boxes + 4 * f;
+            const float ax = (float)(double)fb[2], bx = (float)(0.5 * fb[2] + fb[0]);
+            const float ay = (float)(double)fb[3], by = (float)(0.5 * fb[3] + fb[1]);
+            for (int i = 0; i < L; ++i) {
+                shapes[(size_t)f * N + i] = m->mean[i] * ax + bx;
+                shapes[(size_t)f * N + i + L] = m->mean[i + L] * ay + by;
+            }
+        }
+        DescParams p;
+        fill_desc_params(p, W, H, L, true, m->variant, 3, 10, 9, 30);
+        p.image_stride = (int64_t)W * H;
+        const int F = L * p.len;
+        const int nchunks = (F + RG_KCHUNK - 1) / RG_KCHUNK;
+        m->shapes.reserve(sizeof(float) * shapes.size());
+        m->origin.reserve(sizeof(int32_t) * 4 * (size_t)B * L);
+        m->dist.reserve(sizeof(float) * B);
+        m->status.reserve(sizeof(int32_t) * B);
+        m->desc.reserve(sizeof(float) * (size_t)B * F);
+        m->partial.reserve(sizeof(double) * (size_t)nchunks * B * N);
+        HIP_CHECK(hipMemcpyAsync(m->shapes.p, shapes.data(), sizeof(float) * shapes.size(), hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemsetAsync(m->status.p, 0, sizeof(int32_t) * B, st));
+        const int64_t nitems = (int64_t)B * L;
+        for (int step = 0; step < m->S; ++step) {
+            const double stepFactor = 1 / (1 + std::exp((double)((step + 1) - m->S)));  // :226, double on the host
+            hipLaunchKernelGGL(k_sdm_prepare, dim3((B + 63) / 64), dim3(64), 0, st, m->shapes.as<float>(), B, L, W, H, 1, 0, 1 << 20, stepFactor,
+                               m->origin.as<int32_t>(), m->dist.as<float>(), m->status.as<int32_t>());
+            const int grid = (int)std::min<int64_t>((nitems + 1) / 2, (int64_t)ctx->num_cus * 16);
+            hipLaunchKernelGGL(k_sdm_descriptors, dim3(grid), dim3(128), 2 * p.ldsPerWave, st, dimg, m->origin.as<int32_t>(), p, nitems, m->desc.as<float>(), (int64_t)F);
+            const float* R = m->R[step]->as<float>();
+            hipLaunchKernelGGL(k_sdm_regress, dim3((B + 15) / 16, (N + 15) / 16, nchunks), dim3(64), 0, st, m->desc.as<float>(), B, F, R, N,
+                               m->partial.as<double>(), nchunks);
+            hipLaunchKernelGGL(k_sdm_update, dim3((B * N + 255) / 256), dim3(256), 0, st, m->shapes.as<float>(), m->partial.as<double>(), nchunks,
+                               R + (size_t)F * N, m->dist.as<float>(), B, N);
+        }
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(shapes_out, m->shapes.p, sizeof(float) * shapes.size(), hipMemcpyDeviceToHost, st));
+        if (status_out) HIP_CHECK(hipMemcpyAsync(status_out, m->status.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+    });
+}
+
+}  // extern "C"

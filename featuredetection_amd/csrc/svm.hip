@@ -1,0 +1,388 @@
+// featuredetection_amd/csrc/svm.hip -- kernel SVM scoring (SvmClassifier.cpp:55-60 with
+// RbfKernel.hpp:32-108, HistogramIntersectionKernel.hpp:28-93, LinearKernel.hpp:27-29,
+// PolynomialKernel.hpp:35-37,73-81).
+//
+// Two paths:
+//  * k_svm_generic: one workgroup per feature vector, one wavefront per support vector, all four
+//    kernels, u8 (exact integer SSD / min-sum / dot via v_dot4) or f32 features.  Used for the
+//    second cascade stage (a few hundred survivors per image) and for fd_svm_distance_batch.
+//  * k_svm_rbf_mfma: the dense stage of config 2 -- N patches x 1024 support vectors x 324 dims
+//    as a patch x support-vector contraction on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32), with
+//    the RBF epilogue exp(-gamma (|x|^2 + |s|^2 - 2 x.s)) * coeff fused and the sum over support
+//    vectors kept in registers; nothing but the 8-byte result per patch goes back to HBM.
+//    Both operands are stored "fragment-major" in HBM (see FragLayout below) so that a wave's
+//    operand fetch is one fully coalesced 1 KiB access: A (64 patches) is staged once per
+//    workgroup in LDS, B (support vectors, L2-resident) streams straight into registers.
+// MFMA-bound: 2*d*n_sv flop per patch; peak 157.3 TFLOP/s dense f32 MFMA.
+#include "fd_internal.hpp"
+#include <algorithm>
+#include <cstring>
+#include <memory>
+
+// ---- fragment-major operand layout --------------------------------------------------------------
+// A matrix [rows][K] (K padded to a multiple of 8 with zeros, rows padded to a multiple of 32) is
+// stored as tiles of 32 rows; within a tile, for each group q of 8 consecutive k there are 64
+// float4 slots: slot (h*32 + r) holds row r, k = 8q + 4h .. 8q + 4h + 3.  Lane l of a wave reads
+// slot l: that is exactly its operand for four consecutive v_mfma_f32_32x32x2_f32 issues (lanes
+// 0-31 supply k = 8q+t, lanes 32-63 supply k = 8q+4+t, t = 0..3).
+static inline size_t frag_index(int64_t row, int k, int KP) {
+    const int64_t tile = row >> 5;
+    const int r = (int)(row & 31), q = k >> 3, h = (k >> 2) & 1, t = k & 3;
+    return (size_t)tile * 32 * KP + (size_t)q * 256 + (size_t)(h * 32 + r) * 4 + t;
+}
+
+struct SvmDev {
+    int32_t kernel, nsv, dim, dtype;
+    int32_t dpad;            // generic path: row stride in elements (u8: multiple of 4, f32: == dim)
+    double p0, p1;
+    int32_t degree;
+    float bias;
+    const void* sv;          // [nsv][dpad]
+    const float* coeff;      // [nsv]
+    const uint32_t* ss_u32;  // u8 rbf: sum of squares per SV
+    // MFMA path (f32 RBF)
+    int32_t KP;              // padded feature length (multiple of 8)
+    int32_t nsv_pad;         // multiple of 256
+    const float* svFrag;     // fragment-major [nsv_pad][KP]
+    const float* ss_f32;     // [nsv_pad]
+    const float* coeffPad;   // [nsv_pad], zero padded
+};
+
+struct fd_svm {
+    fd_ctx* ctx;
+    SvmDev dev;
+    float threshold;
+    double logisticA, logisticB;
+    DevBuf sv, coeff, ss, svFrag, ssF, coeffPad;
+    DevBuf feat, dist, idx;  // scratch for batch calls
+};
+
+namespace {
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ double powi(double base, int exponent) {  // PolynomialKernel.hpp:73-81
+    double tmp = base, ret = 1.0;
+    for (int t = exponent; t > 0; t /= 2) {
+        if (t % 2 == 1) ret *= tmp;
+        tmp = tmp * tmp;
+    }
+    return ret;
+}
+
+// One workgroup (256 threads) per feature vector; wave w handles support vectors w, w+4, ...
+// features: [n][dpad] (u8 or f32), optionally gathered through idx (slot indices).
+__global__ __launch_bounds__(256) void k_svm_generic(SvmDev m, const void* __restrict__ features, const uint32_t* __restrict__ idx,
+                                                     int64_t feat_stride_bytes, double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t item = blockIdx.x;
+    const int64_t slot = idx ? (int64_t)idx[item] : item;
+    const unsigned char* x = (const unsigned char*)features + slot * feat_stride_bytes;
+    const int nbytes = m.dtype == FD_DTYPE_U8 ? m.dpad : m.dim * 4;
+    for (int i = threadIdx.x; i < nbytes; i += 256) smem[i] = i < (m.dtype == FD_DTYPE_U8 ? m.dim : nbytes) ? x[i] : 0;
+    __syncthreads();
+    double acc = 0.0;
+    if (m.dtype == FD_DTYPE_U8) {
+        const uint32_t* xs = (const uint32_t*)smem;
+        const int nd = m.dpad >> 2;
+        int xxp = 0;
+        for (int i = lane; i < nd; i += 64) xxp = __builtin_amdgcn_udot4(xs[i], xs[i], xxp, false);
+        const int xx = __builtin_amdgcn_readfirstlane(wave_sum_i(xxp));
+        for (int s = wave; s < m.nsv; s += 4) {
+            const uint32_t* sv = (const uint32_t*)((const unsigned char*)m.sv + (size_t)s * m.dpad);
+            int part = 0;
+            if (m.kernel == FD_KERNEL_HIK) {
+                for (int i = lane; i < nd; i += 64) {
+                    uint32_t a = xs[i], b = sv[i];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) part += min((a >> (8 * q)) & 255u, (b >> (8 * q)) & 255u);
+                }
+            } else {
+                for (int i = lane; i < nd; i += 64) part = __builtin_amdgcn_udot4(xs[i], sv[i], part, false);
+            }
+            const int tot = wave_sum_i(part);
+            if (lane == 0) {
+                double kv;
+                if (m.kernel == FD_KERNEL_RBF) {
+                    const int ssd = xx + (int)m.ss_u32[s] - 2 * tot;  // exact integer SSD (RbfKernel.hpp:78-88)
+                    kv = exp(-m.p0 * (double)ssd);
+                } else if (m.kernel == FD_KERNEL_HIK) {
+                    kv = (double)tot;
+                } else if (m.kernel == FD_KERNEL_LINEAR) {
+                    kv = (double)tot;
+                } else {
+                    kv = powi(m.p0 * (double)tot + m.p1, m.degree);
+                }
+                acc += (double)m.coeff[s] * kv;
+            }
+        }
+    } else {
+        const float* xs = (const float*)smem;
+        for (int s = wave; s < m.nsv; s += 4) {
+            const float* sv = (const float*)m.sv + (size_t)s * m.dim;
+            double kv;
+            if (m.kernel == FD_KERNEL_RBF) {
+                float part = 0.f;
+                for (int i = lane; i < m.dim; i += 64) { float df = xs[i] - sv[i]; part += df * df; }
+                kv = exp(-m.p0 * (double)wave_sum_f(part));
+            } else if (m.kernel == FD_KERNEL_HIK) {
+                float part = 0.f;
+                for (int i = lane; i < m.dim; i += 64) part += fminf(xs[i], sv[i]);
+                kv = (double)wave_sum_f(part);
+            } else {
+                double part = 0.0;
+                for (int i = lane; i < m.dim; i += 64) part += (double)xs[i] * (double)sv[i];
+                part = wave_sum_d(part);
+                kv = m.kernel == FD_KERNEL_LINEAR ? part : powi(m.p0 * part + m.p1, m.degree);
+            }
+            if (lane == 0) acc += (double)m.coeff[s] * kv;
+        }
+    }
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[item] = -(double)m.bias + ((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+// ---- dense RBF stage on the f32 MFMA pipe --------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RB_THREADS = 512;   // 8 waves: 2 per SIMD (one can run its exp epilogue while the other issues MFMAs)
+constexpr int RB_BM = 64;         // patches per workgroup (2 row tiles), A resident in LDS
+constexpr int RB_DEPTH = 4;       // B prefetch ring (q-groups in flight per wave)
+
+// xFrag: fragment-major features [npad][KP]; xx: |x|^2 per patch; out: hyperplane distance per patch
+__global__ __launch_bounds__(RB_THREADS, 2) void k_svm_rbf_mfma(const float* __restrict__ xFrag, const float* __restrict__ xx,
+                                                                 SvmDev m, float negGamma, int64_t npatches,
+                                                                 double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int KP = m.KP, Q = KP >> 3;
+    float* ldsA = lds;                       // 2 tiles * Q * 256 floats
+    float* ldsXX = lds + (size_t)2 * Q * 256;  // 64 floats
+    double* ldsRed = (double*)(ldsXX + 64);  // 8 waves * 64 rows
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * RB_BM;
+
+    // stage A: the two 32-row tiles of this workgroup are contiguous in HBM (2*Q KiB)
+    {
+        const f32x4* src = (const f32x4*)(xFrag + (size_t)(row0 >> 5) * 32 * KP);
+        f32x4* dst = (f32x4*)ldsA;
+        const int n4 = 2 * Q * 64;
+        for (int i = threadIdx.x; i < n4; i += RB_THREADS) dst[i] = src[i];
+        if (threadIdx.x < 64) ldsXX[threadIdx.x] = xx[row0 + threadIdx.x];
+    }
+    __syncthreads();
+
+    double rs0[16], rs1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { rs0[r] = 0.0; rs1[r] = 0.0; }
+
+    const int ntilesB = m.nsv_pad >> 5;
+    for (int nt = wave; nt < ntilesB; nt += 8) {
+        const f32x4* bsrc = (const f32x4*)(m.svFrag + (size_t)nt * 32 * KP) + lane;
+        f32x16 acc0 = {0}, acc1 = {0};
+        f32x4 ring[RB_DEPTH];
+#pragma unroll
+        for (int i = 0; i < RB_DEPTH; ++i) ring[i] = i < Q ? bsrc[(size_t)i * 64] : f32x4{0, 0, 0, 0};
+        const f32x4* a0p = (const f32x4*)ldsA + lane;
+        const f32x4* a1p = a0p + (size_t)Q * 64;
+        for (int q0 = 0; q0 < Q; q0 += RB_DEPTH) {
+#pragma unroll
+            for (int i = 0; i < RB_DEPTH; ++i) {
+                const int q = q0 + i;
+                if (q < Q) {
+                    const f32x4 b = ring[i];
+                    if (q + RB_DEPTH < Q) ring[i] = bsrc[(size_t)(q + RB_DEPTH) * 64];
+                    const f32x4 a0 = a0p[(size_t)q * 64];
+                    const f32x4 a1 = a1p[(size_t)q * 64];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b[t], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b[t], acc1, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // epilogue: C/D layout col = lane & 31 (support vector), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (patch)
+        const int j = nt * 32 + (lane & 31);
+        const float ssj = m.ss_f32[j];
+        const double cj = (double)m.coeffPad[j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float d0 = (ldsXX[row] + ssj) - 2.f * acc0[r];
+            const float d1 = (ldsXX[32 + row] + ssj) - 2.f * acc1[r];
+            rs0[r] += cj * (double)expf(negGamma * fmaxf(d0, 0.f));
+            rs1[r] += cj * (double)expf(negGamma * fmaxf(d1, 0.f));
+        }
+    }
+    // reduce over the 32 support-vector columns held by lanes with equal (lane >> 5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        double a = rs0[r], b = rs1[r];
+        for (int o = 16; o > 0; o >>= 1) {
+            a += __shfl_xor(a, o, 64);
+            b += __shfl_xor(b, o, 64);
+        }
+        if ((lane & 31) == 0) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            ldsRed[wave * 64 + row] = a;
+            ldsRed[wave * 64 + 32 + row] = b;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += ldsRed[w * 64 + threadIdx.x];
+        const int64_t row = row0 + threadIdx.x;
+        if (row < npatches) out[row] = -(double)m.bias + s;
+    }
+}
+
+}  // namespace
+
+// ---- host side ---------------------------------------------------------------------------------
+bool fd_svm_has_mfma_path(const fd_svm* m) { return m->dev.svFrag != nullptr; }
+int fd_svm_KP(const fd_svm* m) { return m->dev.KP; }
+float fd_svm_threshold(const fd_svm* m) { return m->threshold; }
+int fd_svm_dim(const fd_svm* m) { return m->dev.dim; }
+bool fd_svm_is_u8(const fd_svm* m) { return m->dev.dtype == FD_DTYPE_U8; }
+double fd_svm_probability(const fd_svm* m, double d) {  // ProbabilisticSvmClassifier.cpp:54-58 (host, libm)
+    double fABp = m->logisticA + m->logisticB * d;
+    return fABp >= 0 ? std::exp(-fABp) / (1.0 + std::exp(-fABp)) : 1.0 / (1.0 + std::exp(fABp));
+}
+
+size_t fd_svm_rbf_lds_bytes(int KP) { return (size_t)2 * (KP / 8) * 256 * 4 + 64 * 4 + 8 * 64 * 8; }
+
+// dense MFMA scoring of npatches feature vectors already on the device in fragment-major layout
+void fd_svm_rbf_mfma_launch(fd_ctx* ctx, const fd_svm* m, const float* xFrag, const float* xx, int64_t npatches, double* out) {
+    if (!m->dev.svFrag) FD_THROW(FD_ERR_INVALID_ARGUMENT, "SVM has no MFMA path (needs an RBF kernel on f32 vectors)");
+    const size_t ldsBytes = fd_svm_rbf_lds_bytes(m->dev.KP);
+    if (ldsBytes > 160 * 1024) FD_THROW(FD_ERR_INVALID_ARGUMENT, "feature length %d too large for the MFMA SVM kernel", m->dev.dim);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_svm_rbf_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int64_t blocks = (npatches + RB_BM - 1) / RB_BM;
+    hipLaunchKernelGGL(k_svm_rbf_mfma, dim3((unsigned)blocks), dim3(RB_THREADS), ldsBytes, ctx->stream, xFrag, xx, m->dev,
+                       (float)(-m->dev.p0), npatches, out);
+    HIP_CHECK(hipGetLastError());
+}
+
+// generic scoring of n device-resident feature vectors (optionally gathered by slot index)
+void fd_svm_generic_launch(fd_ctx* ctx, const fd_svm* m, const void* dfeat, const uint32_t* didx, int64_t stride_bytes,
+                           int64_t n, double* dout) {
+    if (n <= 0) return;
+    const size_t ldsBytes = m->dev.dtype == FD_DTYPE_U8 ? (size_t)m->dev.dpad : (size_t)m->dev.dim * 4;
+    if (ldsBytes > 64 * 1024) FD_THROW(FD_ERR_INVALID_ARGUMENT, "feature vector too long (%d)", m->dev.dim);
+    hipLaunchKernelGGL(k_svm_generic, dim3((unsigned)n), dim3(256), ldsBytes, ctx->stream, m->dev, dfeat, didx, stride_bytes, dout);
+    HIP_CHECK(hipGetLastError());
+}
+
+extern "C" {
+
+int fd_svm_create(fd_ctx* ctx, const fd_svm_model* md, fd_svm** out) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !md || !out) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_svm_create: NULL argument");
+        if (md->kernel < 0 || md->kernel > 3) FD_THROW(FD_ERR_RUNTIME, "SvmClassifier: Invalid kernel type: %d", md->kernel);
+        if (md->dtype != FD_DTYPE_U8 && md->dtype != FD_DTYPE_F32)
+            FD_THROW(FD_ERR_INVALID_ARGUMENT, "SvmClassifier: support vectors must be u8 or f32");
+        if (md->num_sv < 1 || md->dim < 1 || !md->support_vectors || !md->coefficients)
+            FD_THROW(FD_ERR_INVALID_ARGUMENT, "SvmClassifier: empty model");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        std::unique_ptr<fd_svm> m(new fd_svm());
+        m->ctx = ctx;
+        SvmDev& d = m->dev;
+        std::memset(&d, 0, sizeof(d));
+        d.kernel = md->kernel; d.nsv = md->num_sv; d.dim = md->dim; d.dtype = md->dtype;
+        d.p0 = md->p0; d.p1 = md->p1; d.degree = (int)md->p2; d.bias = md->bias;
+        m->threshold = md->threshold;
+        m->logisticA = md->logistic_a;
+        m->logisticB = md->logistic_b;
+        auto up = [&](DevBuf& b, const void* src, size_t bytes) {
+            b.reserve(std::max<size_t>(bytes, 16));
+            HIP_CHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+        };
+        up(m->coeff, md->coefficients, sizeof(float) * d.nsv);
+        d.coeff = m->coeff.as<float>();
+        if (d.dtype == FD_DTYPE_U8) {
+            d.dpad = (d.dim + 3) & ~3;
+            std::vector<uint8_t> sv((size_t)d.nsv * d.dpad, 0);
+            std::vector<uint32_t> ss(d.nsv, 0);
+            const uint8_t* src = (const uint8_t*)md->support_vectors;
+            for (int s = 0; s < d.nsv; ++s)
+                for (int k = 0; k < d.dim; ++k) {
+                    uint8_t v = src[(size_t)s * d.dim + k];
+                    sv[(size_t)s * d.dpad + k] = v;
+                    ss[s] += (uint32_t)v * v;
+                }
+            up(m->sv, sv.data(), sv.size());
+            up(m->ss, ss.data(), sizeof(uint32_t) * ss.size());
+            d.sv = m->sv.p;
+            d.ss_u32 = m->ss.as<uint32_t>();
+        } else {
+            d.dpad = d.dim;
+            up(m->sv, md->support_vectors, sizeof(float) * (size_t)d.nsv * d.dim);
+            d.sv = m->sv.p;
+            if (d.kernel == FD_KERNEL_RBF) {
+                d.KP = (d.dim + 7) & ~7;
+                d.nsv_pad = (d.nsv + 255) & ~255;
+                std::vector<float> frag((size_t)d.nsv_pad * d.KP, 0.f), ss(d.nsv_pad, 0.f), cp(d.nsv_pad, 0.f);
+                const float* src = (const float*)md->support_vectors;
+                for (int s = 0; s < d.nsv; ++s) {
+                    double acc = 0;
+                    for (int k = 0; k < d.dim; ++k) {
+                        float v = src[(size_t)s * d.dim + k];
+                        frag[frag_index(s, k, d.KP)] = v;
+                        acc += (double)v * v;
+                    }
+                    ss[s] = (float)acc;
+                    cp[s] = md->coefficients[s];
+                }
+                up(m->svFrag, frag.data(), sizeof(float) * frag.size());
+                up(m->ssF, ss.data(), sizeof(float) * ss.size());
+                up(m->coeffPad, cp.data(), sizeof(float) * cp.size());
+                d.svFrag = m->svFrag.as<float>();
+                d.ss_f32 = m->ssF.as<float>();
+                d.coeffPad = m->coeffPad.as<float>();
+            }
+        }
+        *out = m.release();
+    });
+}
+
+void fd_svm_destroy(fd_svm* m) { delete m; }
+
+int fd_svm_distance_batch(fd_ctx* ctx, const fd_svm* m_, const void* features, int64_t n, double* out_distance) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !m_ || (n > 0 && (!features || !out_distance))) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_svm_distance_batch: NULL argument");
+        if (n <= 0) return;
+        fd_svm* m = const_cast<fd_svm*>(m_);
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const size_t es = m->dev.dtype == FD_DTYPE_U8 ? 1 : 4;
+        const size_t stride = (size_t)m->dev.dim * es;
+        m->feat.reserve(stride * (size_t)n + 16);
+        m->dist.reserve(sizeof(double) * (size_t)n);
+        HIP_CHECK(hipMemcpyAsync(m->feat.p, features, stride * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        fd_svm_generic_launch(ctx, m, m->feat.p, nullptr, (int64_t)stride, n, m->dist.as<double>());
+        HIP_CHECK(hipMemcpyAsync(out_distance, m->dist.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+}  // extern "C"

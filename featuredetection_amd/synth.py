@@ -1,0 +1,205 @@
+"""Seeded synthetic frames and classifier models.
+
+The reference ships no WVM/SVM model files (they are Matlab .mat files on the author's disk,
+ffpDetectApp/FaceFrontal.cfg:7-16), so models are synthesised here in the unit conventions of the
+reference loaders (0..255 grey values, gamma / 65025 etc.).  Pure numpy; used by tests, bench.py
+and __graft_entry__.smoke().  Nothing here depends on oracle/.
+"""
+import numpy as np
+
+# ffpDetectApp/*.cfg: name -> (incrementalScaleFactor, minScale, maxScale, patch w, patch h, nPerLevel, levels)
+DETECTOR_CFGS = {
+    "FaceFrontal": (0.92, 0.05, 0.16, 20, 20, 14, 20),
+    "FaceLeftProfile": (0.9, 0.09, 0.25, 20, 20, 14, 7),
+    "FaceRightProfile": (0.9, 0.09, 0.25, 20, 20, 14, 7),
+    "LeftEarCenter": (0.9, 0.5, 0.7, 16, 24, 20, 10),
+    "RightEarCenter": (0.9, 0.5, 0.7, 16, 24, 20, 10),
+    "LeftEyeCenter": (0.9, 0.5, 0.7, 32, 16, 20, 8),
+    "RightEyeCenter": (0.85, 0.5, 0.7, 32, 16, 20, 8),
+    "LeftEyeOuterCorner": (0.9, 0.5, 0.7, 24, 24, 20, 11),
+    "RightEyeOuterCorner": (0.9, 0.5, 0.7, 24, 24, 20, 11),
+    "LeftLipCorner": (0.9, 0.5, 0.7, 24, 24, 30, 8),
+    "RightLipCorner": (0.9, 0.5, 0.7, 24, 24, 30, 8),
+    "LeftNoseCorner": (0.9, 0.5, 0.7, 24, 24, 30, 8),
+    "RightNoseCorner": (0.9, 0.5, 0.7, 24, 24, 30, 8),
+    "CenterLipUpperOuter": (0.9, 0.5, 0.7, 24, 24, 30, 8),
+    "NoseTip": (0.9, 0.5, 0.7, 32, 24, 30, 7),
+}
+
+
+def _blur(a, sigma):
+    """separable Gaussian blur, reflect border (numpy only)"""
+    r = int(3 * sigma + 0.5)
+    k = np.exp(-0.5 * (np.arange(-r, r + 1) / sigma) ** 2)
+    k /= k.sum()
+    p = np.pad(a, ((r, r), (0, 0)), mode="reflect")
+    a = sum(k[i] * p[i:i + a.shape[0]] for i in range(2 * r + 1))
+    p = np.pad(a, ((0, 0), (r, r)), mode="reflect")
+    return sum(k[i] * p[:, i:i + a.shape[1]] for i in range(2 * r + 1))
+
+
+def make_frame(width=640, height=480, seed=20260927, channels=3):
+    """Smooth noise base + 3 pasted high-contrast blobs (SURVEY.md 8(d) config 1 recipe)."""
+    rng = np.random.default_rng(seed)
+    planes = []
+    for _ in range(channels):
+        base = _blur(rng.random((height, width)), 8.0)
+        base = (base - base.min()) / max(base.max() - base.min(), 1e-12)
+        fine = rng.random((height, width))
+        planes.append(0.8 * base + 0.2 * fine)
+    img = np.stack(planes, axis=-1)
+    for _ in range(3):
+        s = int(rng.integers(64, 161))
+        s = min(s, height - 2, width - 2)
+        y0 = int(rng.integers(0, height - s))
+        x0 = int(rng.integers(0, width - s))
+        yy, xx = np.mgrid[0:s, 0:s]
+        blob = 0.5 + 0.5 * np.sin(yy / s * rng.uniform(4, 12)) * np.cos(xx / s * rng.uniform(4, 12))
+        img[y0:y0 + s, x0:x0 + s, :] = 0.15 * img[y0:y0 + s, x0:x0 + s, :] + 0.85 * blob[..., None]
+    out = np.clip(np.rint(img * 255), 0, 255).astype(np.uint8)
+    return out if channels == 3 else out[..., 0]
+
+
+def histeq64_np(patches):
+    """Vectorised HistEq64 used only for threshold calibration / SV synthesis (not a parity reference)."""
+    p = np.asarray(patches, np.uint8)
+    n = p.shape[0]
+    flat = p.reshape(n, -1)
+    d = flat.shape[1]
+    bins = flat >> 2
+    hist = np.zeros((n, 64), np.float32)
+    np.add.at(hist, (np.repeat(np.arange(n), d), bins.ravel()), 1.0)
+    pdf = hist * np.float32(255.0 / d)
+    cdf = np.cumsum(pdf, axis=1, dtype=np.float32)
+    lut = np.floor(cdf.astype(np.float64) + 0.5).astype(np.uint8)
+    return np.take_along_axis(lut, bins.astype(np.int64), axis=1).reshape(p.shape)
+
+
+def random_patches(frame_gray, pw, ph, n, rng):
+    H, W = frame_gray.shape
+    ys = rng.integers(0, H - ph, n)
+    xs = rng.integers(0, W - pw, n)
+    return np.stack([frame_gray[y:y + ph, x:x + pw] for y, x in zip(ys, xs)])
+
+
+def make_wvm(seed, fw=20, fh=20, n_per=14, n_levels=20, r=0.04, calib_patches=None, pass_rate=0.65, min_survivors=32,
+             cntval=6, rect_range=(2, 8)):
+    """Synthetic wavelet reduced vector machine in the layout of fd_wvm_model / orc_wvm_desc.
+
+    Structure follows the cfg-implied one (n_per x n_levels filters); thresholds are calibrated so that
+    ~pass_rate of the surviving calibration patches pass each filter while at least min_survivors
+    remain, after that every survivor passes (mimics a cascade)."""
+    rng = np.random.default_rng(seed)
+    F = n_per * n_levels
+    d = fw * fh
+    val_off = np.arange(F + 1, dtype=np.int32) * cntval
+    val = rng.uniform(0, 255, F * cntval)
+    rec_off = [0]
+    rects = []
+    for k in range(F):
+        for v in range(cntval):
+            nrec = 0 if v == 0 else int(rng.integers(rect_range[0], rect_range[1] + 1))
+            for _ in range(nrec):
+                x1 = int(rng.integers(0, fw)); x2 = int(rng.integers(x1, min(fw, x1 + max(2, fw // 2))))
+                y1 = int(rng.integers(0, fh)); y2 = int(rng.integers(y1, min(fh, y1 + max(2, fh // 2))))
+                rects.append((x1, y1, x2, y2))
+            rec_off.append(len(rects))
+    rects = np.asarray(rects, np.uint8).reshape(-1, 4)
+    rec_off = np.asarray(rec_off, np.int32)
+    # later approximation levels hold residuals: small values around zero (cumulative vector stays in range)
+    for k in range(n_per, F):
+        v0 = val_off[k]
+        val[v0:v0 + cntval] = (val[v0:v0 + cntval] - 127.5) / (2.0 ** (k // n_per))
+    # dense residual images r_k and cumulative approximated vectors P_k
+    dense = np.zeros((F, fh, fw), np.float64)
+    for k in range(F):
+        v0 = val_off[k]
+        dense[k] += val[v0]
+        for v in range(1, cntval):
+            for i in range(rec_off[v0 + v], rec_off[v0 + v + 1]):
+                x1, y1, x2, y2 = rects[i]
+                dense[k, y1:y2 + 1, x1:x2 + 1] += val[v0 + v] - val[v0]
+    P = np.zeros_like(dense)
+    for k in range(F):
+        P[k] = dense[k] + (P[k - n_per] if k >= n_per else 0)
+    pp = (P.reshape(F, -1) ** 2).sum(1)
+    basis = np.float32(r / 65025.0)
+    hk = np.zeros((F, F), np.float32)
+    for k in range(F):
+        hk[k, :k + 1] = rng.normal(0, 1.0 / np.sqrt(k + 1), k + 1).astype(np.float32)
+    bias = np.float32(0.0)
+    thresholds = np.full(F, -1e30, np.float32)
+    if calib_patches is not None and len(calib_patches):
+        X = histeq64_np(calib_patches).reshape(len(calib_patches), -1).astype(np.float64)
+        sxx = (X ** 2).sum(1)
+        xp = X @ P.reshape(F, -1).T
+        norm = sxx[:, None] - 2 * xp + pp[None, :]
+        K = np.exp(-float(basis) * norm)
+        res = K @ hk.astype(np.float64).T - float(bias)  # res[:, k] = sum_{p<=k} w[k][p] K[p]
+        alive = np.ones(len(X), bool)
+        for k in range(F):
+            vals = res[alive, k]
+            if vals.size >= min_survivors:
+                thr = np.quantile(vals, 1.0 - pass_rate)
+            else:
+                thr = (vals.min() - 1.0) if vals.size else -1e30
+            thresholds[k] = np.float32(thr)
+            alive &= res[:, k] >= thresholds[k]
+    return dict(filter_w=fw, filter_h=fh, num_filters=F, num_used=F, num_per_level=n_per, basis_param=float(basis),
+                bias=float(bias), thresholds=thresholds, hk_weights=hk, pp=pp.astype(np.float64), val_off=val_off,
+                val=val.astype(np.float64), rec_off=rec_off, rects=rects, logistic_a=0.00556, logistic_b=-2.95)
+
+
+def make_svm_u8(seed, patches_eq, nsv=1024, r=0.04, positive_fraction=0.3, calib=None):
+    """RBF SVM on u8 HistEq64 patches (second cascade stage): SVs = equalised random patches,
+    gamma = r/65025 (SvmClassifier.cpp:264), bias chosen so that ~positive_fraction of calib is positive."""
+    rng = np.random.default_rng(seed)
+    sv = np.asarray(patches_eq[:nsv], np.uint8).reshape(nsv, -1)
+    coeff = rng.normal(0, 1, nsv).astype(np.float32)
+    gamma = float(np.float32(r / 65025.0))
+    bias = 0.0
+    if calib is not None and len(calib):
+        X = np.asarray(calib, np.uint8).reshape(len(calib), -1).astype(np.float64)
+        S = sv.astype(np.float64)
+        d2 = (X ** 2).sum(1)[:, None] + (S ** 2).sum(1)[None, :] - 2 * X @ S.T
+        dist = np.exp(-gamma * d2) @ coeff.astype(np.float64)
+        bias = float(np.quantile(dist, 1.0 - positive_fraction))
+    return dict(kernel=2, p0=gamma, p1=0.0, p2=0.0, dtype=0, sv=sv, coeff=coeff, bias=np.float32(bias), threshold=0.0,
+                logistic_a=0.00556, logistic_b=-2.95)
+
+
+def make_svm_f32(seed, feats, nsv=1024, gamma=0.5, positive_fraction=0.01, kernel=2):
+    """SVM on f32 feature vectors (config 2: HOG-324): SVs drawn from real feature vectors of a second
+    frame, coefficients ~N(0,1), bias such that ~positive_fraction of `feats` is positive."""
+    rng = np.random.default_rng(seed)
+    feats = np.asarray(feats, np.float32)
+    idx = rng.choice(len(feats), nsv, replace=len(feats) < nsv)
+    sv = feats[idx].copy()
+    coeff = rng.normal(0, 1, nsv).astype(np.float32)
+    sub = feats[rng.choice(len(feats), min(len(feats), 4096), replace=False)].astype(np.float64)
+    S = sv.astype(np.float64)
+    if kernel == 2:
+        d2 = (sub ** 2).sum(1)[:, None] + (S ** 2).sum(1)[None, :] - 2 * sub @ S.T
+        dist = np.exp(-gamma * np.maximum(d2, 0)) @ coeff.astype(np.float64)
+    elif kernel == 3:
+        dist = np.minimum(sub[:, None, :], S[None, :, :]).sum(-1) @ coeff.astype(np.float64)
+    else:
+        dist = (sub @ S.T) @ coeff.astype(np.float64)
+    bias = float(np.quantile(dist, 1.0 - positive_fraction))
+    return dict(kernel=kernel, p0=gamma, p1=0.0, p2=0.0, dtype=1, sv=sv, coeff=coeff, bias=np.float32(bias), threshold=0.0,
+                logistic_a=0.00556, logistic_b=-2.95)
+
+
+def make_sdm(seed, L=68, S=4, feat_per_landmark=279, sigma=1e-3):
+    """SDM model: mean shape = L points on a 0.6-scale template in
+    [-0.5,0.5]^2, R_s ~ N(0, sigma^2) of shape (L*279 + 1) x 2L."""
+    rng = np.random.default_rng(seed)
+    ang = np.linspace(0, 2 * np.pi, L, endpoint=False)
+    rad = 0.3 * (0.6 + 0.4 * rng.random(L))
+    mean = np.concatenate([rad * np.cos(ang), rad * np.sin(ang)]).astype(np.float32)
+    # landmarks 8,9 (eyes) above 11,12 (mouth) so that the anchor distance is well defined
+    mean[8], mean[9], mean[8 + L], mean[9 + L] = -0.12, 0.12, -0.12, -0.12
+    mean[11], mean[12], mean[11 + L], mean[12 + L] = -0.1, 0.1, 0.18, 0.18
+    F = L * feat_per_landmark
+    R = [rng.normal(0, sigma, (F + 1, 2 * L)).astype(np.float32) for _ in range(S)]
+    return dict(L=L, S=S, mean=mean, R=R, variant=1)

@@ -1,0 +1,206 @@
+/* include/fd_hip.h -- C ABI of the MI355X-native FeatureDetection hot path (libfd_hip.so).
+ *
+ * The reference (elador/FeatureDetection) has no FFI/plugin layer: its extension points are the
+ * C++ abstract classes wired by shared_ptr in each app's main().  The drop-in boundary is therefore
+ *   C++ subclass of the reference interface (host/ in this repo)  ->  this C ABI  ->  HIP kernels.
+ * Every entry point names the reference interface (file:line) whose work it performs.
+ *
+ * Conventions: opaque handles, int status (0 = FD_OK), caller-owned buffers, no exceptions across
+ * the ABI, one HIP stream per context (thread-compatible, not thread-safe -- like the reference,
+ * whose const methods mutate scratch buffers, WvmClassifier.hpp:129-130).  Pointers named dev_* are
+ * device (HBM) pointers, everything else is host memory.  The library has NO CPU fallback: every
+ * compute entry point fails with FD_ERR_HIP when no gfx950 device is usable.
+ */
+#ifndef FD_HIP_H_
+#define FD_HIP_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    FD_OK = 0,
+    FD_ERR_INVALID_ARGUMENT = 1, /* std::invalid_argument in the reference */
+    FD_ERR_RUNTIME = 2,          /* std::runtime_error */
+    FD_ERR_LOGIC = 3,            /* std::logic_error */
+    FD_ERR_HIP = 4,              /* HIP runtime failure / no device */
+    FD_ERR_CAPACITY = 5          /* caller buffer too small; required count is still reported */
+};
+
+typedef struct fd_ctx fd_ctx;
+typedef struct fd_pyramid fd_pyramid;
+typedef struct fd_wvm fd_wvm;
+typedef struct fd_svm fd_svm;
+typedef struct fd_sdm fd_sdm;
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* hip_stream: an existing hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream),
+ * or NULL to create a private stream. */
+int fd_ctx_create(int device_id, void* hip_stream, fd_ctx** out);
+void fd_ctx_destroy(fd_ctx* ctx);
+const char* fd_last_error(const fd_ctx* ctx); /* valid until the next failing call on ctx */
+int fd_ctx_synchronize(fd_ctx* ctx);
+const char* fd_version(void);
+
+/* ---- image pyramid: imageprocessing::ImagePyramid (ImagePyramid.cpp:67-92 ctors, :116-128 update,
+ *      :170-198 createLayers) with the GrayscaleFilter image filter (GrayscaleFilter.cpp:18-24) ---- */
+int fd_pyramid_create(fd_ctx* ctx, int octave_layer_count, double min_scale, double max_scale, fd_pyramid** out);
+int fd_pyramid_create_inc(fd_ctx* ctx, double incremental_scale, double min_scale, double max_scale, fd_pyramid** out);
+void fd_pyramid_destroy(fd_pyramid* p);
+/* Layer filters (ImagePyramid::addLayerFilter, ImagePyramid.cpp:112-114):
+ *  FD_LAYER_NONE       gray layers (u8, 1 channel)
+ *  FD_LAYER_GRADBIN    GradientFilter(grad_kernel, blur=0) -> GradientBinningFilter(bins, signed, interpolate)
+ *                      (GradientFilter.cpp:38-59, GradientBinningFilter.cpp:18-93); 2 or 4 channels
+ *  FD_LAYER_LBP        LbpFilter(lbp_type) (LbpFilter.cpp:56-85); 1 channel */
+enum { FD_LAYER_NONE = 0, FD_LAYER_GRADBIN = 1, FD_LAYER_LBP = 2 };
+enum { FD_LBP8 = 0, FD_LBP8_UNIFORM = 1, FD_LBP4 = 2, FD_LBP4_ROTATED = 3 };
+int fd_pyramid_set_layer_filter(fd_pyramid* p, int kind, int bins, int signed_gradients, int interpolate,
+                                int grad_kernel, int lbp_type);
+/* channels 1 (gray) or 3 (BGR, interleaved).  is_device != 0: image already resident in HBM. */
+int fd_pyramid_update(fd_pyramid* p, const uint8_t* image, int width, int height, int channels, int is_device);
+int fd_pyramid_octave_layer_count(const fd_pyramid* p);
+double fd_pyramid_incremental_scale(const fd_pyramid* p);
+int fd_pyramid_layer_count(const fd_pyramid* p);
+/* ImagePyramidLayer.hpp:34-35: index, theoretical scale, size; channels of the filtered layer */
+int fd_pyramid_layer_info(const fd_pyramid* p, int i, int* index, double* scale, int* width, int* height, int* channels);
+/* copy the (filtered) layer i to host: width*height*channels bytes */
+int fd_pyramid_layer_download(fd_pyramid* p, int i, uint8_t* host_dst);
+/* Window enumeration of DirectPyramidFeatureExtractor::extract(stepX, stepY, roi) (:75-123).
+ * roi = {x,y,w,h} or NULL (whole image).  rows of out: {layerPos, lx, ly, cx, cy, ow, oh}. */
+int fd_pyramid_window_count(const fd_pyramid* p, int patch_w, int patch_h, int step_x, int step_y,
+                            const int* roi, int64_t* count);
+int fd_pyramid_windows(const fd_pyramid* p, int patch_w, int patch_h, int step_x, int step_y, const int* roi,
+                       int32_t* out, int64_t cap, int64_t* count);
+
+/* Stand-alone image filters (ImageFilter::applyTo): GreyWorldNormalizationFilter.cpp:20-71 */
+int fd_greyworld(fd_ctx* ctx, const uint8_t* bgr, int width, int height, uint8_t* dst, int is_device);
+/* HistEq64Filter::applyTo (HistEq64Filter.cpp:32-125) on n contiguous patches of w*h bytes (host buffers) */
+int fd_histeq64_batch(fd_ctx* ctx, const uint8_t* patches, int64_t n, int w, int h, uint8_t* dst);
+
+/* ---- classification::WvmClassifier / ProbabilisticWvmClassifier --------------------------------
+ * Field meaning as in WvmClassifier.hpp / the Matlab loader WvmClassifier.cpp:352-769 (values already
+ * converted to the 0..255 domain as the loader does). */
+typedef struct {
+    int32_t filter_w, filter_h;  /* filter_size_x/y */
+    int32_t num_filters;         /* numLinFilters */
+    int32_t num_used;            /* numUsedFilters (0 or > num_filters => num_filters, :151-158) */
+    int32_t num_per_level;       /* numFiltersPerLevel */
+    float basis_param;           /* basisParam */
+    float bias;                  /* lin_thresholds[i] == bias for all i (:567-570) */
+    const float* thresholds;     /* hierarchicalThresholds[num_filters] (limitReliabilityFilter already added) */
+    const float* hk_weights;     /* [num_filters][num_filters] row-major; hk_weights[k][p], p <= k */
+    const double* pp;            /* app_rsv_convol[num_filters] */
+    const int32_t* val_off;      /* [num_filters+1]; grey values of filter k are val[val_off[k]..val_off[k+1]) */
+    const double* val;           /* area[k]->val[v] */
+    const int32_t* rec_off;      /* [val_off[num_filters]+1]; rects of (k,v) */
+    const uint8_t* rects;        /* {x1,y1,x2,y2} inclusive patch coordinates, 4 bytes per rect */
+    double logistic_a, logistic_b; /* ProbabilisticWvmClassifier.hpp:36 */
+} fd_wvm_model;
+int fd_wvm_create(fd_ctx* ctx, const fd_wvm_model* model, fd_wvm** out);
+void fd_wvm_destroy(fd_wvm* m);
+
+/* ---- classification::SvmClassifier / ProbabilisticSvmClassifier with Kernel{Linear,Polynomial,Rbf,HIK} */
+enum { FD_KERNEL_LINEAR = 0, FD_KERNEL_POLY = 1, FD_KERNEL_RBF = 2, FD_KERNEL_HIK = 3 };
+enum { FD_DTYPE_U8 = 0, FD_DTYPE_F32 = 1 };
+typedef struct {
+    int32_t kernel;       /* FD_KERNEL_* */
+    double p0, p1, p2;    /* rbf: gamma; poly: alpha, constant, degree */
+    int32_t num_sv, dim;
+    int32_t dtype;        /* FD_DTYPE_* of the support vectors (and of the feature vectors) */
+    const void* support_vectors; /* [num_sv][dim] */
+    const float* coefficients;   /* [num_sv] */
+    float bias, threshold;       /* VectorMachineClassifier.hpp */
+    double logistic_a, logistic_b;
+} fd_svm_model;
+int fd_svm_create(fd_ctx* ctx, const fd_svm_model* model, fd_svm** out);
+void fd_svm_destroy(fd_svm* m);
+/* SvmClassifier::computeHyperplaneDistance (SvmClassifier.cpp:55-60) for n feature vectors (host buffers).
+ * Backs the per-Mat BinaryClassifier::classify / ProbabilisticClassifier::getProbability. */
+int fd_svm_distance_batch(fd_ctx* ctx, const fd_svm* m, const void* features, int64_t n, double* out_distance);
+
+/* ---- detection ------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t cx, cy, w, h;   /* imageprocessing::Patch centre and size in the original image (Patch.hpp:64-65) */
+    int32_t layer, lx, ly;  /* layer position (pyramid order) and top-left corner inside the layer */
+    int32_t level;          /* WVM: last evaluated filter (WvmClassifier.cpp:149); else -1 */
+    int32_t positive;       /* ClassifiedPatch::isPositive */
+    float score;            /* WVM fout / (float) SVM hyperplane distance */
+    double probability;     /* ClassifiedPatch::getProbability */
+} fd_detection;
+
+/* detection::SlidingWindowDetector::detect (SlidingWindowDetector.cpp:40-98) with
+ * DirectPyramidFeatureExtractor + HistEq64Filter patch filter + ProbabilisticWvmClassifier
+ * (ffpDetectApp.cpp:407-417).  Positives are returned in extraction order.
+ * all_level/all_score (host, may be NULL) receive every window's (lastLevel, fout). */
+int fd_detect_wvm(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm, int step_x, int step_y, const int* roi,
+                  fd_detection* out, int64_t cap, int64_t* count, int32_t* all_level, float* all_score);
+
+/* detection::FiveStageSlidingWindowDetector::detect(image) (:187-320, roi == NULL) and
+ * detect(image, roi) (:331-380): WVM -> OverlapElimination(dist, ratio) -> SVM classify ->
+ * positives -> [block NMS, no-roi variant only] -> sort.  stage_counts[4] (may be NULL) =
+ * {WVM positives, after OE, SVM positives, final}. */
+int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm, const fd_svm* svm, float oe_dist,
+                         float oe_ratio, int step_x, int step_y, const int* roi, fd_detection* out, int cap,
+                         int* count, int32_t* stage_counts);
+
+/* detection::OverlapElimination::eliminate (OverlapElimination.cpp:44-105); host-side, deterministic */
+int fd_overlap_elimination(const fd_detection* in, int n, float dist, float ratio, int32_t* keep_idx, int* count);
+/* nonMaximaSuppression (FiveStageSlidingWindowDetector.cpp:143-184) applied to the probability map that
+ * :276-285 builds from the detections (max probability per centre pixel; masked != 0: only entries > 0.3).
+ * maxima_xy receives (x, y) pairs in row-major order (cv::findNonZero order); host-side. */
+int fd_block_nms(const fd_detection* in, int n, int image_w, int image_h, int sz, int masked, int32_t* maxima_xy,
+                 int cap_pairs, int* count);
+
+/* Single-stage SlidingWindowDetector with the HOG feature chain of benchmarkApp
+ * (BenchmarkRunner.cpp:118-126,235-242): pyramid layer filter FD_LAYER_GRADBIN, patch filter
+ * HogFilter(bins, cell, block, interpolate=false, signedAndUnsigned) (HogFilter.cpp:58-122) and a
+ * ProbabilisticSvmClassifier on the f32 feature vectors.
+ * all_distance (host, may be NULL): every window's hyperplane distance, extraction order. */
+typedef struct {
+    int32_t patch_w, patch_h, step_x, step_y;
+    int32_t bins, cell_size, block_size, signed_and_unsigned;
+} fd_hog_params;
+int fd_hog_feature_length(const fd_hog_params* hp);
+int fd_detect_hog_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_hog_params* hp, fd_detection* out,
+                      int64_t cap, int64_t* count, double* all_distance);
+/* FeatureExtractor::extract for every window: n_windows x feature_length floats to host (tests) */
+int fd_extract_hog(fd_ctx* ctx, fd_pyramid* p, const fd_hog_params* hp, float* features, int64_t cap_windows,
+                   int64_t* count);
+
+/* Throughput entry points used by bench.py: everything stays on the device, no host copies of
+ * per-window data; *count = enumerated windows, *positives = classifier positives. */
+int fd_bench_hog_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_hog_params* hp, int64_t* count,
+                     int64_t* positives);
+int fd_bench_wvm(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm, int step_x, int step_y, int64_t* count,
+                 int64_t* positives);
+/* hipEvent-timed duration (ms) of the dominant kernel of the last fd_bench_* call on this context */
+int fd_last_kernel_ms(fd_ctx* ctx, const char** kernel_name, float* ms);
+
+/* ---- supervised descent: superviseddescent::SdmLandmarkModel / SdmLandmarkModelFitting ---------- */
+typedef struct {
+    int32_t num_landmarks;      /* L */
+    int32_t num_steps;          /* S (numCascadeSteps) */
+    const float* mean;          /* 2L: x0..xL-1, y0..yL-1 (SdmLandmarkModel.cpp:53-56) */
+    const float* const* R;      /* per step: (feature_dim+1) x 2L row-major regressor (last row = bias) */
+    const int32_t* R_rows;      /* per step: feature_dim + 1 */
+    int32_t hog_variant;        /* 0 DalalTriggs, 1 UoCTTI (VlHogDescriptorExtractor::VlHogType) */
+} fd_sdm_model;
+int fd_sdm_create(fd_ctx* ctx, const fd_sdm_model* model, fd_sdm** out);
+void fd_sdm_destroy(fd_sdm* m);
+/* VlHogDescriptorExtractor::getDescriptors (DescriptorExtractor.hpp:106-219), adaptive parameters
+ * (window_size_half > 0: 30x30 patch, 3x3 cells of 10, 9 bins) or fixed (num_cells, cell_size, num_bins).
+ * gray: host image; out: n x len floats; *len receives the descriptor length. */
+int fd_sdm_descriptors(fd_ctx* ctx, const uint8_t* gray, int width, int height, const float* px, const float* py,
+                       int n, int window_size_half, int variant, int num_cells, int cell_size, int num_bins,
+                       float* out, int* len);
+/* SdmLandmarkModelFitting::alignRigid + optimize (SdmLandmarkModel.hpp:156-192,199-256) for a batch of
+ * B gray images of identical size (contiguous, host or device) and one face box {x,y,w,h} each.
+ * shapes_out: B x 2L floats.  status_out (may be NULL): per face 0 ok / 1 window left the image
+ * (the reference would throw). */
+int fd_sdm_fit_batch(fd_ctx* ctx, const fd_sdm* m, const uint8_t* gray_images, int width, int height, int batch,
+                     const int32_t* face_boxes, int images_on_device, float* shapes_out, int32_t* status_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FD_HIP_H_ */

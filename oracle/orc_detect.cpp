@@ -1,0 +1,238 @@
+// oracle/orc_detect.cpp -- TEST INFRASTRUCTURE ONLY (see orc_common.h).
+// libDetection: SlidingWindowDetector, OverlapElimination, FiveStageSlidingWindowDetector.
+#include "orc_common.h"
+#include "orc_internal.h"
+#include "oracle.h"
+#include <cstring>
+#include <memory>
+
+namespace orc {
+
+// OverlapElimination.cpp:44-105.  The reference sorts shared_ptrs through boost::indirect_iterator
+// with std::greater<ClassifiedPatch> (probability only), i.e. a plain std::sort on the same sequence.
+static std::vector<int> overlap_elimination(const std::vector<orc_det>& in, float distIn, float ratioIn) {
+    std::vector<int> cand(in.size());
+    for (size_t i = 0; i < in.size(); ++i) cand[i] = (int)i;
+    if (cand.empty()) return cand;
+    float dist = distIn;
+    float ratio = ((ratioIn > 0.0f) && (ratioIn <= 1.0f)) ? ratioIn : 0.0f;
+    float d;
+    std::sort(cand.begin(), cand.end(), [&](int a, int b) { return in[a].prob > in[b].prob; });
+    for (auto accepted = cand.begin(); accepted != cand.end(); accepted++) {
+        for (auto proband = accepted + 1; proband != cand.end();) {
+            const orc_det &A = in[*accepted], &P = in[*proband];
+            if (dist <= 1.0) d = dist * std::max(A.w, P.w);
+            else d = dist;
+            if ((std::abs(A.cx - P.cx) < d) && (std::abs(A.cy - P.cy) < d) &&
+                (((float)std::min(A.w, P.w) / (float)std::max(A.w, P.w)) > ratio))
+                proband = cand.erase(proband);
+            else
+                proband++;
+        }
+    }
+    return cand;
+}
+
+// cv::minMaxLoc(src(rows,cols), NULL, &maxVal, NULL, &maxLoc, mask) on a CV_32F sub-matrix
+// (OpenCV 2.4 minMaxIdx: strict '>' so the first row-major maximum wins; an all-zero mask yields
+// maxVal = 0 and location (-1,-1)).
+static void maxloc(const float* src, int W, int r0, int r1, int c0, int c1, const uchar* mask, int maskStride,
+                   double& maxVal, int& mx, int& my) {
+    float best = -3.402823466e+38F;
+    size_t idx = 0, k = 1;
+    for (int r = r0; r < r1; ++r)
+        for (int c = c0; c < c1; ++c, ++k) {
+            if (mask && !mask[(size_t)(r - r0) * maskStride + (c - c0)]) continue;
+            float v = src[(size_t)r * W + c];
+            if (v > best) { best = v; idx = k; }
+        }
+    if (idx == 0) { maxVal = 0; mx = -1; my = -1; }
+    else { maxVal = best; size_t o = idx - 1; int cols = c1 - c0; my = (int)(o / cols); mx = (int)(o % cols); }
+}
+
+// nonMaximaSuppression, FiveStageSlidingWindowDetector.cpp:143-184
+static void block_nms(const float* src, int M, int N, int sz, const uchar* mask, uchar* dst) {
+    const bool masked = mask != nullptr;
+    std::memset(dst, 0, (size_t)M * N);
+    std::vector<uchar> bm;
+    for (int m = 0; m < M; m += sz + 1)
+        for (int n = 0; n < N; n += sz + 1) {
+            int ic0 = m, ic1 = std::min(m + sz + 1, M), jc0 = n, jc1 = std::min(n + sz + 1, N);
+            double vcmax, vnmax;
+            int ix, iy;
+            // candidate: maximum inside the block (mask restricted to the block)
+            std::vector<uchar> cm;
+            if (masked) {
+                cm.resize((size_t)(ic1 - ic0) * (jc1 - jc0));
+                for (int r = ic0; r < ic1; ++r)
+                    for (int c = jc0; c < jc1; ++c) cm[(size_t)(r - ic0) * (jc1 - jc0) + (c - jc0)] = mask[(size_t)r * N + c];
+            }
+            maxloc(src, N, ic0, ic1, jc0, jc1, masked ? cm.data() : nullptr, jc1 - jc0, vcmax, ix, iy);
+            int ccx = ix + jc0, ccy = iy + ic0;
+            int in0 = std::max(ccy - sz, 0), in1 = std::min(ccy + sz + 1, M);
+            int jn0 = std::max(ccx - sz, 0), jn1 = std::min(ccx + sz + 1, N);
+            int ih = in1 - in0, jw = jn1 - jn0;
+            if (ih <= 0 || jw <= 0) continue;  // cannot happen for sz >= 0 inside the image
+            bm.assign((size_t)ih * jw, 255);
+            int iis0 = ic0 - in0, iis1 = std::min(ic0 - in0 + sz + 1, ih);
+            int jis0 = jc0 - jn0, jis1 = std::min(jc0 - jn0 + sz + 1, jw);
+            for (int r = iis0; r < iis1; ++r)
+                for (int c = jis0; c < jis1; ++c) bm[(size_t)r * jw + c] = 0;
+            if (masked)  // mask(in,jn).mul(blockmask): non-zero iff both non-zero
+                for (int r = 0; r < ih; ++r)
+                    for (int c = 0; c < jw; ++c)
+                        if (!mask[(size_t)(r + in0) * N + (c + jn0)]) bm[(size_t)r * jw + c] = 0;
+            maxloc(src, N, in0, in1, jn0, jn1, bm.data(), jw, vnmax, ix, iy);
+            if (vcmax > vnmax) dst[(size_t)ccy * N + ccx] = 255;
+        }
+}
+
+static orc_det make_det(const Window& w) {
+    orc_det d;
+    std::memset(&d, 0, sizeof(d));
+    d.cx = w.cx; d.cy = w.cy; d.w = w.ow; d.h = w.oh; d.layer = w.layer; d.lx = w.lx; d.ly = w.ly;
+    d.level = -1; d.positive = 0; d.fout = 0; d.prob = 0.5;
+    return d;
+}
+
+struct Scored {
+    orc_det det;
+    std::vector<uchar> data;  // HistEq64'd patch (Patch::data)
+};
+
+// SlidingWindowDetector.cpp:53-78 / :87-98 with DirectPyramidFeatureExtractor + HistEq64Filter + PWVM
+static void sliding_wvm(const Pyramid& p, const Wvm& m, int stepX, int stepY, const int* roi,
+                        std::vector<Scored>& positives, int32_t* all_level, float* all_fout) {
+    std::vector<Window> wins;
+    enumerate_windows(p, m.fw, m.fh, stepX, stepY, roi, wins);
+    std::vector<uchar> eq((size_t)m.fw * m.fh);
+    for (size_t i = 0; i < wins.size(); ++i) {
+        const Window& w = wins[i];
+        const ImgU8& img = p.layers[w.layer].img;
+        histeq64(img.d.data() + (size_t)w.ly * img.w + w.lx, m.fw, m.fh, img.w, eq.data());
+        int level; float fout;
+        m.eval(eq.data(), level, fout);
+        if (all_level) all_level[i] = level;
+        if (all_fout) all_fout[i] = fout;
+        if (m.classify(level, fout)) {
+            Scored s;
+            s.det = make_det(w);
+            s.det.level = level; s.det.fout = fout; s.det.positive = 1; s.det.prob = m.probability(fout);
+            s.data = eq;
+            positives.push_back(std::move(s));
+        }
+    }
+}
+
+// FiveStageSlidingWindowDetector.cpp:187-320 (roi == nullptr) and :331-380 (roi != nullptr)
+static std::vector<orc_det> five_stage(const Pyramid& p, int imgW, int imgH, const Wvm& wvm, const Svm& svm,
+                                       float oeDist, float oeRatio, int stepX, int stepY, const int* roi,
+                                       int32_t* counts) {
+    std::vector<Scored> cls;
+    sliding_wvm(p, wvm, stepX, stepY, roi, cls, nullptr, nullptr);
+    if (counts) counts[0] = (int)cls.size();
+    // OE
+    std::vector<orc_det> dets(cls.size());
+    for (size_t i = 0; i < cls.size(); ++i) dets[i] = cls[i].det;
+    std::vector<int> keep = overlap_elimination(dets, oeDist, oeRatio);
+    if (counts) counts[1] = (int)keep.size();
+    // SVM stage: classify() only -> ClassifiedPatch(patch, bool) => probability 0.5 (ClassifiedPatch.hpp:29-30)
+    std::vector<orc_det> svmPos;
+    for (int k : keep) {
+        double dist = svm.distance(cls[k].data.data());
+        if (svm.classify(dist)) {
+            orc_det d = cls[k].det;
+            d.fout = (float)dist; d.positive = 1; d.prob = 0.5;
+            svmPos.push_back(d);
+        }
+    }
+    if (counts) counts[2] = (int)svmPos.size();
+    if (!roi) {
+        std::vector<float> map((size_t)imgW * imgH, 0.f);
+        for (const auto& d : svmPos)
+            if (map[(size_t)d.cy * imgW + d.cx] < d.prob) map[(size_t)d.cy * imgW + d.cx] = (float)d.prob;
+        std::vector<uchar> mask((size_t)imgW * imgH), maxima((size_t)imgW * imgH);
+        for (size_t i = 0; i < map.size(); ++i) mask[i] = map[i] > 0.3f ? 255 : 0;
+        block_nms(map.data(), imgH, imgW, 35, mask.data(), maxima.data());
+        size_t nz = 0;
+        for (uchar v : maxima) nz += v != 0;
+        if (nz == 0) {
+            block_nms(map.data(), imgH, imgW, 35, nullptr, maxima.data());
+            for (uchar v : maxima) nz += v != 0;
+            if (nz == 0) { if (counts) counts[3] = (int)svmPos.size(); return svmPos; }
+        }
+        std::sort(svmPos.begin(), svmPos.end(), [](const orc_det& a, const orc_det& b) { return a.prob > b.prob; });
+        std::vector<orc_det> res;
+        for (int y = 0; y < imgH; ++y)  // cv::findNonZero: row-major order
+            for (int x = 0; x < imgW; ++x) {
+                if (!maxima[(size_t)y * imgW + x]) continue;
+                auto it = std::find_if(svmPos.begin(), svmPos.end(), [&](const orc_det& a) { return a.cx == x && a.cy == y; });
+                if (it != svmPos.end()) res.push_back(*it);  // (the reference dereferences end() here: UB)
+            }
+        svmPos = res;
+    }
+    std::sort(svmPos.begin(), svmPos.end(), [](const orc_det& a, const orc_det& b) { return a.prob > b.prob; });
+    if (counts) counts[3] = (int)svmPos.size();
+    return svmPos;
+}
+
+}  // namespace orc
+
+using namespace orc;
+extern "C" {
+int orc_overlap_elimination(int n, const orc_det* in, float dist, float ratio, int32_t* idx_out) {
+    std::vector<orc_det> v(in, in + n);
+    std::vector<int> k = overlap_elimination(v, dist, ratio);
+    for (size_t i = 0; i < k.size(); ++i) idx_out[i] = k[i];
+    return (int)k.size();
+}
+void orc_block_nms(const float* map, int H, int W, int sz, const uint8_t* mask, uint8_t* dst) { block_nms(map, H, W, sz, mask, dst); }
+
+int64_t orc_sliding_wvm(const orc_pyramid* p, const orc_wvm* m, int stepX, int stepY, const int* roi, orc_det* out,
+                        int64_t cap, int32_t* all_level, float* all_fout) {
+    std::vector<Scored> pos;
+    sliding_wvm(*(const Pyramid*)p, *(const Wvm*)m, stepX, stepY, roi, pos, all_level, all_fout);
+    for (int64_t i = 0; i < (int64_t)pos.size() && i < cap; ++i) out[i] = pos[i].det;
+    return (int64_t)pos.size();
+}
+
+int orc_five_stage(const orc_pyramid* p, int imgW, int imgH, const orc_wvm* wvm, const orc_svm* svm, float oeDist,
+                   float oeRatio, int stepX, int stepY, const int* roi, orc_det* out, int cap, int32_t* counts) {
+    std::vector<orc_det> r = five_stage(*(const Pyramid*)p, imgW, imgH, *(const Wvm*)wvm, *(const Svm*)svm, oeDist,
+                                        oeRatio, stepX, stepY, roi, counts);
+    for (int i = 0; i < (int)r.size() && i < cap; ++i) out[i] = r[i];
+    return (int)r.size();
+}
+
+int64_t orc_sliding_hog_svm(const orc_pyramid* p_, const orc_svm* svm_, int pw, int ph, int stepX, int stepY, int bins,
+                            int cell, int block, int interpolate, int signedAndUnsigned, orc_det* out, int64_t cap,
+                            double* all_dist, float* feat_out, int64_t feat_cap_windows) {
+    const Pyramid& p = *(const Pyramid*)p_;
+    const Svm* svm = (const Svm*)svm_;
+    std::vector<Window> wins;
+    enumerate_windows(p, pw, ph, stepX, stepY, nullptr, wins);
+    std::vector<float> feat;
+    int64_t npos = 0;
+    for (size_t i = 0; i < wins.size(); ++i) {
+        const Window& w = wins[i];
+        const ImgU8& img = p.layers[w.layer].img;
+        const uchar* src = img.d.data() + ((size_t)w.ly * img.w + w.lx) * img.ch;
+        hog_filter(src, pw, ph, img.ch, img.w * img.ch, bins, cell, cell, block, block, interpolate != 0,
+                   signedAndUnsigned != 0, feat);
+        if (feat_out && (int64_t)i < feat_cap_windows)
+            std::memcpy(feat_out + i * feat.size(), feat.data(), sizeof(float) * feat.size());
+        if (!svm) continue;
+        double dist = svm->distance(feat.data());
+        if (all_dist) all_dist[i] = dist;
+        if (svm->classify(dist)) {
+            if (npos < cap && out) {
+                orc_det d = make_det(w);
+                d.fout = (float)dist; d.positive = 1; d.prob = svm->probability(dist);
+                out[npos] = d;
+            }
+            ++npos;
+        }
+    }
+    return svm ? npos : (int64_t)wins.size();
+}
+}

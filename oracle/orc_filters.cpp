@@ -1,0 +1,429 @@
+// oracle/orc_filters.cpp -- TEST INFRASTRUCTURE ONLY (see orc_common.h).
+// Patch / layer filters of libImageProcessing that sit on the hot path.
+#include "orc_common.h"
+#include "orc_internal.h"
+#include "oracle.h"
+#include <array>
+#include <complex>
+#include <cstring>
+
+namespace orc {
+
+// HistEq64Filter.cpp:32-125
+void histeq64(const uchar* src, int w, int h, int stride, uchar* dst) {
+    float stretchFactor = 255.0f / (float)(w * h);
+    float pdf_bins[64];
+    for (int i = 0; i < 64; i++) pdf_bins[i] = 0.0f;
+    for (int z = 0; z < h; z++) {
+        const uchar* o = src + (size_t)z * stride;
+        for (int i = 0; i < w; i++) pdf_bins[o[i] >> 2] = pdf_bins[o[i] >> 2] + 1;
+    }
+    for (int i = 0; i < 64; i++)
+        if (pdf_bins[i] != 0) pdf_bins[i] = pdf_bins[i] * stretchFactor;
+    float cdf_BINS[64];
+    cdf_BINS[0] = pdf_bins[0];
+    for (unsigned int i = 1; i < 64; i++) cdf_BINS[i] = cdf_BINS[i - 1] + pdf_bins[i];
+    float LUTeq[256];
+    for (int i = 0; i < 256; i++) LUTeq[i] = cdf_BINS[i >> 2];
+    for (int z = 0; z < h; z++) {
+        const uchar* o = src + (size_t)z * stride;
+        uchar* f = dst + (size_t)z * w;
+        for (int i = 0; i < w; i++) f[i] = (uchar)std::floor(LUTeq[o[i]] + 0.5);
+    }
+}
+
+// GradientBinningFilter.cpp:18-60.  lut index = gx | gy<<8 (little-endian union), entry 2 or 4 bytes.
+static void gradient_binning_lut(int bins, bool signedGradients, bool interpolate, uchar* lut) {
+    const double PI = 3.1415926535897932384626433832795;  // CV_PI
+    for (int x = 0; x < 256; ++x) {
+        double gradientX = ((double)x - 127) / 255;
+        for (int y = 0; y < 256; ++y) {
+            double gradientY = ((double)y - 127) / 255;
+            double direction = std::atan2(gradientY, gradientX);
+            double magnitude = std::sqrt(gradientX * gradientX + gradientY * gradientY);
+            double bin;
+            if (signedGradients) {
+                direction += PI;
+                bin = direction * bins / (2 * PI);
+            } else {
+                if (direction < 0) direction += PI;
+                bin = direction * bins / PI;
+            }
+            size_t index = (size_t)x | ((size_t)y << 8);
+            if (!interpolate) {
+                lut[2 * index] = (uchar)((uchar)std::round(bin) % (unsigned)bins);
+                lut[2 * index + 1] = sat_u8(255 * magnitude);
+            } else {
+                uchar b0 = (uchar)((uchar)std::floor(bin) % (unsigned)bins);
+                uchar b1 = (uchar)((uchar)std::ceil(bin) % (unsigned)bins);
+                uchar w1 = sat_u8(255 * magnitude * (bin - std::floor(bin)));
+                uchar w0 = sat_u8(255 * magnitude - w1);
+                lut[4 * index] = b0;
+                lut[4 * index + 1] = w0;
+                lut[4 * index + 2] = b1;
+                lut[4 * index + 3] = w1;
+            }
+        }
+    }
+}
+
+// GradientBinningFilter.cpp:66-93
+void gradient_binning(const uchar* grad2, int n, int bins, int signedGradients, int interpolate, uchar* dst) {
+    const int e = interpolate ? 4 : 2;
+    std::vector<uchar> lut((size_t)65536 * e);
+    gradient_binning_lut(bins, signedGradients != 0, interpolate != 0, lut.data());
+    for (int i = 0; i < n; ++i) {
+        size_t index = (size_t)grad2[2 * i] | ((size_t)grad2[2 * i + 1] << 8);
+        std::memcpy(dst + (size_t)e * i, lut.data() + e * index, e);
+    }
+}
+
+// LbpFilter.cpp:20-44 (uniform map), :56-85, LbpFilter.hpp:88-180 (3x3 kernels, BORDER_REPLICATE)
+void lbp(const uchar* src, int w, int h, int type, uchar* dst) {
+    std::array<uchar, 256> map{};
+    if (type == 1) {
+        int nonUniformIndex = 0, emptyIndex = 1;
+        for (unsigned i = 0; i < 256; ++i) {
+            uchar code = (uchar)i;
+            int transitions = 0, previousBit = (code >> 7) & 1;
+            for (int pos = 0; pos < 8; ++pos) {
+                int currentBit = (code >> pos) & 1;
+                if (previousBit != currentBit) { transitions++; previousBit = currentBit; }
+            }
+            map[i] = (uchar)(transitions <= 2 ? emptyIndex++ : nonUniformIndex);
+        }
+    }
+    auto at = [&](int y, int x) {
+        y = y < 0 ? 0 : (y >= h ? h - 1 : y);
+        x = x < 0 ? 0 : (x >= w ? w - 1 : x);
+        return src[(size_t)y * w + x];
+    };
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            uchar c = at(y, x), code = 0;
+            if (type == 0 || type == 1) {
+                code |= (at(y - 1, x - 1) > c) << 7;
+                code |= (at(y - 1, x) > c) << 6;
+                code |= (at(y - 1, x + 1) > c) << 5;
+                code |= (at(y, x + 1) > c) << 4;
+                code |= (at(y + 1, x + 1) > c) << 3;
+                code |= (at(y + 1, x) > c) << 2;
+                code |= (at(y + 1, x - 1) > c) << 1;
+                code |= (at(y, x - 1) > c) << 0;
+                if (type == 1) code = map[code];
+            } else if (type == 2) {
+                code |= (at(y - 1, x) > c) << 3;
+                code |= (at(y, x + 1) > c) << 2;
+                code |= (at(y + 1, x) > c) << 1;
+                code |= (at(y, x - 1) > c) << 0;
+            } else {
+                code |= (at(y - 1, x - 1) > c) << 3;
+                code |= (at(y - 1, x + 1) > c) << 2;
+                code |= (at(y + 1, x + 1) > c) << 1;
+                code |= (at(y + 1, x - 1) > c) << 0;
+            }
+            dst[(size_t)y * w + x] = code;
+        }
+}
+
+// GreyWorldNormalizationFilter.cpp:20-71 (continuous input)
+static void greyworld(const uchar* bgr, int w, int h, uchar* dst) {
+    const int n = w * h;
+    double sum[3] = {0, 0, 0};
+    uchar mx[3] = {0, 0, 0};
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) {
+            sum[c] += bgr[3 * i + c];
+            if (bgr[3 * i + c] > mx[c]) mx[c] = bgr[3 * i + c];
+        }
+    double mean[3], maxNew[3];
+    for (int c = 0; c < 3; ++c) { mean[c] = sum[c] / n; maxNew[c] = mx[c] / mean[c]; }
+    double max = maxNew[0];
+    if (maxNew[1] > max) max = maxNew[1];
+    if (maxNew[2] > max) max = maxNew[2];
+    double scale[3];
+    for (int c = 0; c < 3; ++c) scale[c] = 255.0 / (mean[c] * max);
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) dst[3 * i + c] = sat_u8(cvRound(scale[c] * bgr[3 * i + c]));
+}
+
+// "whi" chain, ffpDetectApp.cpp:449-454: WhiteningFilter (WhiteningFilter.cpp:20-81) ->
+// HistogramEqualizationFilter -> ConversionFilter(CV_32F, 1/127.5, -1) -> UnitNormFilter(L2).
+// The DFTs are evaluated naively in double (cv::dft results are tolerance-compared only).
+static void whi(const uchar* src, int w, int h, int stride, float alpha, float cutoff, float* dst) {
+    const int n = w * h;
+    const double PI2 = 6.283185307179586476925286766559;
+    std::vector<std::complex<double>> F((size_t)n), T((size_t)n);
+    // forward DFT with DFT_SCALE
+    for (int v = 0; v < h; ++v)
+        for (int x = 0; x < w; ++x) {  // row transform along x -> T[v][u]
+            std::complex<double> s = 0;
+            for (int k = 0; k < w; ++k)
+                s += (double)src[(size_t)v * stride + k] * std::polar(1.0, -PI2 * x * k / w);
+            T[(size_t)v * w + x] = s;
+        }
+    for (int u = 0; u < w; ++u)
+        for (int y = 0; y < h; ++y) {
+            std::complex<double> s = 0;
+            for (int k = 0; k < h; ++k) s += T[(size_t)k * w + u] * std::polar(1.0, -PI2 * y * k / h);
+            F[(size_t)y * w + u] = std::complex<double>((float)(s.real() / n), (float)(s.imag() / n));
+        }
+    // filter (WhiteningFilter.cpp:62-81), float arithmetic
+    for (int row = 0; row < h; ++row)
+        for (int col = 0; col < w; ++col) {
+            int shiftedRow = (row + h / 2) % h, shiftedCol = (col + w / 2) % w;
+            float fx = -0.5f + shiftedCol * (2 * 0.5f) / (w - 1);
+            float fy = -0.5f + shiftedRow * (2 * 0.5f) / (h - 1);
+            float rho = std::sqrt(fx * fx + fy * fy);
+            float f = std::pow(rho, alpha);
+            if (cutoff > 0) f *= std::exp(-std::pow(rho / cutoff, 4));
+            F[(size_t)row * w + col] *= (double)f;
+        }
+    // inverse DFT, DFT_REAL_OUTPUT: only the half-spectrum (cols 0..w/2) is consumed, the rest is
+    // implied by conjugate symmetry (OpenCV packs the complex input into CCS form).
+    std::vector<std::complex<double>> G((size_t)n);
+    for (int r = 0; r < h; ++r)
+        for (int c = 0; c < w; ++c) {
+            int rr = (h - r) % h, cc = (w - c) % w;
+            bool own = c < cc || (c == cc && r <= rr);
+            G[(size_t)r * w + c] = own ? F[(size_t)r * w + c] : std::conj(F[(size_t)rr * w + cc]);
+        }
+    std::vector<uchar> u8((size_t)n), eq((size_t)n);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            std::complex<double> s = 0;
+            for (int v = 0; v < h; ++v)
+                for (int u = 0; u < w; ++u)
+                    s += G[(size_t)v * w + u] * std::polar(1.0, PI2 * ((double)x * u / w + (double)y * v / h));
+            float val = (float)s.real();
+            u8[(size_t)y * w + x] = sat_u8((double)(val * 1.0f + 127.0f));
+        }
+    equalize_hist(u8.data(), w, h, w, eq.data());
+    const float a = (float)(1.0 / 127.5), b = -1.0f;
+    double norm2 = 0;
+    for (int i = 0; i < n; ++i) {
+        dst[i] = eq[i] * a + b;
+        norm2 += (double)dst[i] * dst[i];
+    }
+    double norm = std::sqrt(norm2);
+    const float eps = 1e-4f;
+    float inv = (float)(1.0 / (norm + eps));
+    for (int i = 0; i < n; ++i) dst[i] = dst[i] * inv;
+}
+
+// ---------------------------------------------------------------------------------------
+// HistogramFilter::createCellHistograms, HistogramFilter.cpp:23-197 (+createCache :199-220)
+// ---------------------------------------------------------------------------------------
+struct CacheEntry { int index1, index2; float weight1, weight2; };
+static void createCache(std::vector<CacheEntry>& cache, unsigned size, int count) {
+    cache.clear();
+    for (unsigned m = 0; m < size; ++m) {
+        CacheEntry e;
+        double realIndex = (double)count * ((double)m + 0.5) / (double)size - 0.5;
+        e.index1 = (int)std::floor(realIndex);
+        e.index2 = e.index1 + 1;
+        e.weight2 = (float)(realIndex - e.index1);
+        e.weight1 = 1.f - e.weight2;
+        if (e.index1 < 0) { e.index1 = e.index2; e.weight1 = 0; }
+        else if (e.index2 >= count) { e.index2 = e.index1; e.weight2 = 0; }
+        cache.push_back(e);
+    }
+}
+
+static void createCellHistograms(const uchar* img, int w, int h, int ch, int strideBytes, std::vector<float>& hist,
+                                 int binCount, int rowCount, int columnCount, bool interpolate) {
+    if (ch != 1 && ch != 2 && ch != 4) throw std::runtime_error("HistogramFilter: image must have one, two or four channels");
+    hist.assign((size_t)rowCount * columnCount * binCount, 0.f);
+    const float factor = 1.f / 255.f;
+    auto H = [&](int r, int c) { return hist.data() + ((size_t)r * columnCount + c) * binCount; };
+    if (interpolate) {
+        std::vector<CacheEntry> rowCache, colCache;
+        createCache(rowCache, h, rowCount);
+        createCache(colCache, w, columnCount);
+        for (int y = 0; y < h; ++y) {
+            const uchar* row = img + (size_t)y * strideBytes;
+            int r0 = rowCache[y].index1, r1 = rowCache[y].index2;
+            float rw1 = rowCache[y].weight2, rw0 = rowCache[y].weight1;
+            for (int x = 0; x < w; ++x) {
+                int c0 = colCache[x].index1, c1 = colCache[x].index2;
+                float cw1 = colCache[x].weight2, cw0 = colCache[x].weight1;
+                const uchar* px = row + (size_t)x * ch;
+                int nb = ch == 4 ? 2 : 1;
+                uchar b[2];
+                float wt[2];
+                b[0] = px[0];
+                wt[0] = ch == 1 ? 1.f : factor * px[1];
+                if (ch == 4) { b[1] = px[2]; wt[1] = factor * px[3]; }
+                auto add = [&](int r, int c, float wr, float wc) {
+                    float* hv = H(r, c);
+                    for (int k = 0; k < nb; ++k) {
+                        if (ch == 1) hv[b[k]] += wr * wc;
+                        else hv[b[k]] += wt[k] * wr * wc;
+                    }
+                };
+                if (r0 >= 0 && c0 >= 0) add(r0, c0, rw0, cw0);
+                if (r0 >= 0 && c1 < columnCount) add(r0, c1, rw0, cw1);
+                if (r1 < rowCount && c0 >= 0) add(r1, c0, rw1, cw0);
+                if (r1 < rowCount && c1 < columnCount) add(r1, c1, rw1, cw1);
+            }
+        }
+    } else {
+        float* hv = hist.data();
+        for (int cr = 0; cr < rowCount; ++cr)
+            for (int cc = 0; cc < columnCount; ++cc) {
+                int startRow = (cr * h) / rowCount, startCol = (cc * w) / columnCount;
+                int endRow = ((cr + 1) * h) / rowCount, endCol = ((cc + 1) * w) / columnCount;
+                for (int y = startRow; y < endRow; ++y) {
+                    const uchar* row = img + (size_t)y * strideBytes;
+                    for (int x = startCol; x < endCol; ++x) {
+                        const uchar* px = row + (size_t)x * ch;
+                        if (ch == 1) hv[px[0]]++;
+                        else if (ch == 2) hv[px[0]] += factor * px[1];
+                        else { hv[px[0]] += factor * px[1]; hv[px[2]] += factor * px[3]; }
+                    }
+                }
+                hv += binCount;
+            }
+    }
+}
+
+// HogFilter.cpp:58-122
+int hog_filter(const uchar* img, int w, int h, int ch, int strideBytes, int binCount, int cellW, int cellH,
+               int blockW, int blockH, bool interpolate, bool signedAndUnsigned, std::vector<float>& out) {
+    const float eps = 1e-4f;
+    int cellRowCount = cvRound((double)h / (double)cellH);
+    int cellColumnCount = cvRound((double)w / (double)cellW);
+    std::vector<float> cells;
+    createCellHistograms(img, w, h, ch, strideBytes, cells, binCount, cellRowCount, cellColumnCount, interpolate);
+    int binHalfCount = binCount / 2;
+    std::vector<float> energies((size_t)cellRowCount * cellColumnCount);
+    for (int ci = 0; ci < cellRowCount * cellColumnCount; ++ci) {
+        const float* hv = cells.data() + (size_t)ci * binCount;
+        float energy = 0;
+        if (signedAndUnsigned) {
+            for (int b = 0; b < binHalfCount; ++b) {
+                float u = hv[b] + hv[binHalfCount + b];
+                energy += u * u;
+            }
+        } else {
+            for (int b = 0; b < binCount; ++b) energy += hv[b] * hv[b];
+        }
+        energies[ci] = energy;
+    }
+    int blockHistogramSize = signedAndUnsigned ? blockW * blockH * (binCount + binHalfCount) : blockW * blockH * binCount;
+    int blockRowCount = cellRowCount - blockH + 1, blockColumnCount = cellColumnCount - blockW + 1;
+    if (blockRowCount < 0) blockRowCount = 0;
+    if (blockColumnCount < 0) blockColumnCount = 0;
+    out.assign((size_t)blockRowCount * blockColumnCount * blockHistogramSize, 0.f);
+    float* o = out.data();
+    for (int br = 0; br < blockRowCount; ++br)
+        for (int bc = 0; bc < blockColumnCount; ++bc) {
+            float energy = 0;
+            for (int cr = br; cr < br + blockH; ++cr)
+                for (int cc = bc; cc < bc + blockW; ++cc) energy += energies[(size_t)cr * cellColumnCount + cc];
+            float normalizer = 1.f / std::sqrt(energy + eps);
+            for (int cr = br; cr < br + blockH; ++cr)
+                for (int cc = bc; cc < bc + blockW; ++cc) {
+                    const float* hv = cells.data() + ((size_t)cr * cellColumnCount + cc) * binCount;
+                    for (int b = 0; b < binCount; ++b) o[b] = normalizer * hv[b];
+                    o += binCount;
+                    if (signedAndUnsigned) {
+                        for (int b = 0; b < binHalfCount; ++b) o[b] = normalizer * (hv[b] + hv[binHalfCount + b]);
+                        o += binHalfCount;
+                    }
+                }
+        }
+    return (int)out.size();
+}
+
+// HistogramFilter.cpp:222-251
+static void normalizeL2(float* v, int n) {
+    const float eps = 1e-4f;
+    double s = 0;
+    for (int i = 0; i < n; ++i) s += (double)v[i] * v[i];
+    float norm = (float)std::sqrt(s);
+    float inv = (float)(1.0 / (double)(norm + eps));
+    for (int i = 0; i < n; ++i) v[i] = v[i] * inv;
+}
+static void normalizeL1(float* v, int n) {
+    const float eps = 1e-4f;
+    double s = 0;
+    for (int i = 0; i < n; ++i) s += std::fabs((double)v[i]);
+    float norm = (float)s;
+    float inv = (float)(1.0 / (double)(norm + eps));
+    for (int i = 0; i < n; ++i) v[i] = v[i] * inv;
+}
+static void normalizeHist(float* v, int n, int normalization) {
+    switch (normalization) {
+        case 1: normalizeL2(v, n); break;
+        case 2:
+            normalizeL2(v, n);
+            for (int i = 0; i < n; ++i) v[i] = std::min(v[i], (float)0.2);
+            normalizeL2(v, n);
+            break;
+        case 3: normalizeL1(v, n); break;
+        case 4:
+            normalizeL1(v, n);
+            for (int i = 0; i < n; ++i) v[i] = std::sqrt(v[i]);
+            break;
+        default: break;
+    }
+}
+
+// SpatialHistogramFilter.cpp:56-94
+static int spatial_histogram(const uchar* img, int w, int h, int ch, int strideBytes, int binCount, int cellW, int cellH,
+                             int blockW, int blockH, bool interpolate, bool concatenate, int normalization,
+                             std::vector<float>& out) {
+    int cellRowCount = cvRound((double)h / (double)cellH);
+    int cellColumnCount = cvRound((double)w / (double)cellW);
+    if (blockW == 1 && blockH == 1) {
+        createCellHistograms(img, w, h, ch, strideBytes, out, binCount, cellRowCount, cellColumnCount, interpolate);
+        normalizeHist(out.data(), (int)out.size(), normalization);
+        return (int)out.size();
+    }
+    std::vector<float> cells;
+    createCellHistograms(img, w, h, ch, strideBytes, cells, binCount, cellRowCount, cellColumnCount, interpolate);
+    int blockHistogramSize = concatenate ? blockW * blockH * binCount : binCount;
+    int blockRowCount = cellRowCount - blockH + 1, blockColumnCount = cellColumnCount - blockW + 1;
+    out.assign((size_t)blockRowCount * blockColumnCount * blockHistogramSize, 0.f);
+    float* o = out.data();
+    for (int br = 0; br < blockRowCount; ++br)
+        for (int bc = 0; bc < blockColumnCount; ++bc) {
+            float* blockStart = o;
+            for (int cr = br; cr < br + blockH; ++cr)
+                for (int cc = bc; cc < bc + blockW; ++cc) {
+                    const float* hv = cells.data() + ((size_t)cr * cellColumnCount + cc) * binCount;
+                    for (int b = 0; b < binCount; ++b) o[b] += hv[b];
+                    if (concatenate) o += binCount;
+                }
+            if (!concatenate) o += binCount;
+            normalizeHist(blockStart, blockHistogramSize, normalization);
+        }
+    return (int)out.size();
+}
+
+}  // namespace orc
+
+using namespace orc;
+extern "C" {
+void orc_histeq64(const uint8_t* s, int w, int h, int stride, uint8_t* d) { histeq64(s, w, h, stride, d); }
+void orc_gradient_binning_lut(int bins, int sg, int interp, uint8_t* lut) { gradient_binning_lut(bins, sg != 0, interp != 0, lut); }
+void orc_gradient_binning(const uint8_t* g, int n, int bins, int sg, int interp, uint8_t* d) { gradient_binning(g, n, bins, sg, interp, d); }
+void orc_lbp(const uint8_t* s, int w, int h, int type, uint8_t* d) { lbp(s, w, h, type, d); }
+void orc_greyworld(const uint8_t* s, int w, int h, uint8_t* d) { greyworld(s, w, h, d); }
+void orc_whi(const uint8_t* s, int w, int h, int stride, float alpha, float cutoff, float* d) { whi(s, w, h, stride, alpha, cutoff, d); }
+int orc_hog_filter(const uint8_t* img, int w, int h, int ch, int stride, int bins, int cw, int chh, int bw, int bh,
+                   int interp, int sau, float* out) {
+    std::vector<float> v;
+    int n = hog_filter(img, w, h, ch, stride, bins, cw, chh, bw, bh, interp != 0, sau != 0, v);
+    if (out) std::memcpy(out, v.data(), sizeof(float) * v.size());
+    return n;
+}
+int orc_spatial_histogram(const uint8_t* img, int w, int h, int ch, int stride, int bins, int cw, int chh, int bw, int bh,
+                          int interp, int concat, int normalization, float* out) {
+    std::vector<float> v;
+    int n = spatial_histogram(img, w, h, ch, stride, bins, cw, chh, bw, bh, interp != 0, concat != 0, normalization, v);
+    if (out) std::memcpy(out, v.data(), sizeof(float) * v.size());
+    return n;
+}
+}

@@ -1,0 +1,389 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so) and of the compiled reference translation
+units (oracle/_ref/libfdref.so).  TEST INFRASTRUCTURE ONLY: imported by tests/, bench.py's
+cpu_baseline leg and __graft_entry__.smoke() -- never by the product."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+_ref = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE], stdout=subprocess.DEVNULL)
+
+
+class orc_wvm_desc(C.Structure):
+    _fields_ = [("filter_w", C.c_int32), ("filter_h", C.c_int32), ("num_filters", C.c_int32), ("num_used", C.c_int32),
+                ("num_per_level", C.c_int32), ("basis_param", C.c_float), ("bias", C.c_float),
+                ("thresholds", C.POINTER(C.c_float)), ("hk_weights", C.POINTER(C.c_float)), ("pp", C.POINTER(C.c_double)),
+                ("val_off", C.POINTER(C.c_int32)), ("val", C.POINTER(C.c_double)), ("rec_off", C.POINTER(C.c_int32)),
+                ("rects", C.POINTER(C.c_uint8)), ("logistic_a", C.c_double), ("logistic_b", C.c_double)]
+
+
+DET_DTYPE = np.dtype([("cx", "<i4"), ("cy", "<i4"), ("w", "<i4"), ("h", "<i4"), ("layer", "<i4"), ("lx", "<i4"),
+                      ("ly", "<i4"), ("level", "<i4"), ("positive", "<i4"), ("fout", "<f4"), ("prob", "<f8")], align=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        l = C.CDLL(path)
+        l.orc_pyramid_create.restype = C.c_void_p
+        l.orc_pyramid_create.argtypes = [C.c_int, C.c_double, C.c_double]
+        l.orc_pyramid_create_inc.restype = C.c_void_p
+        l.orc_pyramid_create_inc.argtypes = [C.c_double, C.c_double, C.c_double]
+        l.orc_pyramid_destroy.argtypes = [C.c_void_p]
+        l.orc_pyramid_set_layer_filter.argtypes = [C.c_void_p] + [C.c_int] * 7
+        l.orc_pyramid_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        l.orc_pyramid_octave_layers.argtypes = [C.c_void_p]
+        l.orc_pyramid_inc_scale.restype = C.c_double
+        l.orc_pyramid_inc_scale.argtypes = [C.c_void_p]
+        l.orc_pyramid_num_layers.argtypes = [C.c_void_p]
+        l.orc_pyramid_layer_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                             C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        l.orc_pyramid_layer_data.restype = C.c_void_p
+        l.orc_pyramid_layer_data.argtypes = [C.c_void_p, C.c_int]
+        l.orc_extract_windows.restype = C.c_int64
+        l.orc_extract_windows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
+        l.orc_wvm_create.restype = C.c_void_p
+        l.orc_wvm_create.argtypes = [C.POINTER(orc_wvm_desc)]
+        l.orc_wvm_destroy.argtypes = [C.c_void_p]
+        l.orc_wvm_eval.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float)]
+        l.orc_wvm_classify.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        l.orc_wvm_probability.restype = C.c_double
+        l.orc_wvm_probability.argtypes = [C.c_void_p, C.c_double]
+        l.orc_svm_create.restype = C.c_void_p
+        l.orc_svm_create.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_float, C.c_float, C.c_double, C.c_double]
+        l.orc_svm_destroy.argtypes = [C.c_void_p]
+        l.orc_svm_distance.restype = C.c_double
+        l.orc_svm_distance.argtypes = [C.c_void_p, C.c_void_p]
+        l.orc_svm_probability.restype = C.c_double
+        l.orc_svm_probability.argtypes = [C.c_void_p, C.c_double]
+        l.orc_svm_classify.argtypes = [C.c_void_p, C.c_double]
+        l.orc_svm_distance_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        l.orc_overlap_elimination.argtypes = [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        l.orc_block_nms.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        l.orc_sliding_wvm.restype = C.c_int64
+        l.orc_sliding_wvm.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                      C.c_void_p]
+        l.orc_five_stage.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        l.orc_sliding_hog_svm.restype = C.c_int64
+        l.orc_sliding_hog_svm.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                                                                   C.c_int64]
+        l.orc_hog_filter.argtypes = [C.c_void_p] + [C.c_int] * 11 + [C.c_void_p]
+        l.orc_spatial_histogram.argtypes = [C.c_void_p] + [C.c_int] * 12 + [C.c_void_p]
+        l.orc_vlhog.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int),
+                                C.POINTER(C.c_int)]
+        l.orc_sdm_descriptors.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_void_p]
+        l.orc_sdm_align_rigid.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        l.orc_sdm_optimize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        l.orc_whi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
+        _lib = l
+    return _lib
+
+
+def ref():
+    """The reference's own hog.c / IImg.cpp / svm.cpp compiled from /root/reference (oracle/_ref)."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(_HERE, "_ref", "libfdref.so")
+        if not os.path.exists(path):
+            if os.path.isdir("/root/reference"):
+                build()
+            if not os.path.exists(path):
+                return None
+        r = C.CDLL(path)
+        r.ref_iimg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        r.ref_svm_decision.restype = C.c_double
+        r.ref_svm_decision.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_double, C.c_void_p]
+        r.vl_hog_new.restype = C.c_void_p
+        r.vl_hog_new.argtypes = [C.c_int, C.c_ulonglong, C.c_int]
+        r.vl_hog_delete.argtypes = [C.c_void_p]
+        r.vl_hog_put_image.argtypes = [C.c_void_p, C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_ulonglong, C.c_ulonglong]
+        r.vl_hog_extract.argtypes = [C.c_void_p, C.c_void_p]
+        r.vl_hog_get_width.restype = C.c_ulonglong
+        r.vl_hog_get_width.argtypes = [C.c_void_p]
+        r.vl_hog_get_height.restype = C.c_ulonglong
+        r.vl_hog_get_height.argtypes = [C.c_void_p]
+        r.vl_hog_get_dimension.restype = C.c_ulonglong
+        r.vl_hog_get_dimension.argtypes = [C.c_void_p]
+        _ref = r
+    return _ref
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+# ---- image primitives -------------------------------------------------------------------------
+def bgr2gray(img):
+    img = _c(img, np.uint8)
+    out = np.empty(img.shape[:2], np.uint8)
+    lib().orc_bgr2gray(_p(img), img.shape[1], img.shape[0], _p(out))
+    return out
+
+
+def resize_linear_u8(img, dw, dh):
+    img = _c(img, np.uint8)
+    out = np.empty((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_p(img), img.shape[1], img.shape[0], _p(out), dw, dh)
+    return out
+
+
+def pyrdown(img):
+    img = _c(img, np.uint8)
+    out = np.empty(((img.shape[0] + 1) // 2, (img.shape[1] + 1) // 2), np.uint8)
+    lib().orc_pyrdown_u8(_p(img), img.shape[1], img.shape[0], _p(out))
+    return out
+
+
+def histeq64(patch):
+    patch = _c(patch, np.uint8)
+    out = np.empty_like(patch)
+    lib().orc_histeq64(_p(patch), patch.shape[1], patch.shape[0], patch.shape[1], _p(out))
+    return out
+
+
+def greyworld(bgr):
+    bgr = _c(bgr, np.uint8)
+    out = np.empty_like(bgr)
+    lib().orc_greyworld(_p(bgr), bgr.shape[1], bgr.shape[0], _p(out))
+    return out
+
+
+def iimg(patch, sqr):
+    patch = _c(patch, np.uint8)
+    out = np.empty(patch.shape, np.float32)
+    lib().orc_iimg(_p(patch), patch.shape[1], patch.shape[0], int(sqr), _p(out))
+    return out
+
+
+def hog_filter(binimg, bins, cell, block, interpolate=False, signed_and_unsigned=False):
+    binimg = _c(binimg, np.uint8)
+    h, w = binimg.shape[:2]
+    ch = 1 if binimg.ndim == 2 else binimg.shape[2]
+    n = lib().orc_hog_filter(_p(binimg), w, h, ch, w * ch, bins, cell, cell, block, block, int(interpolate),
+                             int(signed_and_unsigned), None)
+    out = np.empty(n, np.float32)
+    lib().orc_hog_filter(_p(binimg), w, h, ch, w * ch, bins, cell, cell, block, block, int(interpolate),
+                         int(signed_and_unsigned), _p(out))
+    return out
+
+
+class Pyramid:
+    def __init__(self, octave_layers=None, min_scale=0.09, max_scale=0.25, inc=None):
+        if inc is not None:
+            self.h = lib().orc_pyramid_create_inc(inc, min_scale, max_scale)
+        else:
+            self.h = lib().orc_pyramid_create(octave_layers, min_scale, max_scale)
+        if not self.h:
+            raise ValueError("invalid pyramid parameters")
+
+    def set_layer_filter(self, kind, bins=9, signed_gradients=False, interpolate=False, grad_kernel=1, blur_kernel=0, lbp_type=0):
+        lib().orc_pyramid_set_layer_filter(self.h, kind, bins, int(signed_gradients), int(interpolate), grad_kernel, blur_kernel,
+                                           lbp_type)
+
+    def update(self, image):
+        image = _c(image, np.uint8)
+        self.img_h, self.img_w = image.shape[:2]
+        lib().orc_pyramid_update(self.h, _p(image), image.shape[1], image.shape[0], 1 if image.ndim == 2 else image.shape[2])
+
+    @property
+    def octave_layers(self):
+        return lib().orc_pyramid_octave_layers(self.h)
+
+    @property
+    def inc(self):
+        return lib().orc_pyramid_inc_scale(self.h)
+
+    def layers(self):
+        out = []
+        for i in range(lib().orc_pyramid_num_layers(self.h)):
+            idx, w, h, ch = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            sc = C.c_double()
+            lib().orc_pyramid_layer_info(self.h, i, C.byref(idx), C.byref(sc), C.byref(w), C.byref(h), C.byref(ch))
+            out.append(dict(index=idx.value, scale=sc.value, w=w.value, h=h.value, ch=ch.value))
+        return out
+
+    def layer(self, i):
+        info = self.layers()[i]
+        n = info["h"] * info["w"] * info["ch"]
+        buf = (C.c_uint8 * n).from_address(lib().orc_pyramid_layer_data(self.h, i))
+        a = np.frombuffer(buf, np.uint8).copy()
+        return a.reshape((info["h"], info["w"]) if info["ch"] == 1 else (info["h"], info["w"], info["ch"]))
+
+    def windows(self, pw, ph, sx, sy, roi=None):
+        r = _c(roi, np.int32) if roi is not None else None
+        n = lib().orc_extract_windows(self.h, pw, ph, sx, sy, _p(r), None, 0)
+        out = np.empty((n, 7), np.int32)
+        lib().orc_extract_windows(self.h, pw, ph, sx, sy, _p(r), _p(out), n)
+        return out
+
+    def close(self):
+        if self.h:
+            lib().orc_pyramid_destroy(self.h)
+            self.h = None
+
+
+class Wvm:
+    def __init__(self, m):
+        self.keep = dict(thresholds=_c(m["thresholds"], np.float32), hk_weights=_c(m["hk_weights"], np.float32),
+                         pp=_c(m["pp"], np.float64), val_off=_c(m["val_off"], np.int32), val=_c(m["val"], np.float64),
+                         rec_off=_c(m["rec_off"], np.int32), rects=_c(m["rects"], np.uint8))
+        k = self.keep
+        s = orc_wvm_desc()
+        s.filter_w, s.filter_h = int(m["filter_w"]), int(m["filter_h"])
+        s.num_filters, s.num_used, s.num_per_level = int(m["num_filters"]), int(m["num_used"]), int(m["num_per_level"])
+        s.basis_param, s.bias = float(m["basis_param"]), float(m["bias"])
+        s.thresholds = k["thresholds"].ctypes.data_as(C.POINTER(C.c_float))
+        s.hk_weights = k["hk_weights"].ctypes.data_as(C.POINTER(C.c_float))
+        s.pp = k["pp"].ctypes.data_as(C.POINTER(C.c_double))
+        s.val_off = k["val_off"].ctypes.data_as(C.POINTER(C.c_int32))
+        s.val = k["val"].ctypes.data_as(C.POINTER(C.c_double))
+        s.rec_off = k["rec_off"].ctypes.data_as(C.POINTER(C.c_int32))
+        s.rects = k["rects"].ctypes.data_as(C.POINTER(C.c_uint8))
+        s.logistic_a, s.logistic_b = float(m["logistic_a"]), float(m["logistic_b"])
+        self.h = lib().orc_wvm_create(C.byref(s))
+        self.model = m
+
+    def eval(self, patch):
+        patch = _c(patch, np.uint8)
+        lv, f = C.c_int32(), C.c_float()
+        lib().orc_wvm_eval(self.h, _p(patch), C.byref(lv), C.byref(f))
+        return lv.value, f.value
+
+    def probability(self, fout):
+        return lib().orc_wvm_probability(self.h, float(fout))
+
+
+class Svm:
+    def __init__(self, m):
+        dt = np.uint8 if m["dtype"] == 0 else np.float32
+        self.sv = _c(m["sv"], dt)
+        self.coeff = _c(m["coeff"], np.float32)
+        self.dt = dt
+        self.dim = self.sv.shape[1]
+        self.h = lib().orc_svm_create(int(m["kernel"]), float(m.get("p0", 0)), float(m.get("p1", 0)), float(m.get("p2", 0)),
+                                      self.sv.shape[0], self.dim, int(m["dtype"]), _p(self.sv), _p(self.coeff),
+                                      float(m["bias"]), float(m.get("threshold", 0.0)), float(m.get("logistic_a", 0.00556)),
+                                      float(m.get("logistic_b", -2.95)))
+
+    def distance(self, feats):
+        feats = _c(feats, self.dt).reshape(-1, self.dim)
+        out = np.empty(feats.shape[0], np.float64)
+        lib().orc_svm_distance_batch(self.h, _p(feats), feats.shape[0], _p(out))
+        return out
+
+    def probability(self, d):
+        return lib().orc_svm_probability(self.h, float(d))
+
+
+def sliding_wvm(pyr, wvm, sx=1, sy=1, roi=None, want_all=True):
+    wins = pyr.windows(wvm.model["filter_w"], wvm.model["filter_h"], sx, sy, roi)
+    n = len(wins)
+    lv = np.empty(n, np.int32) if want_all else None
+    fo = np.empty(n, np.float32) if want_all else None
+    out = np.zeros(max(n, 1), DET_DTYPE)
+    r = _c(roi, np.int32) if roi is not None else None
+    cnt = lib().orc_sliding_wvm(pyr.h, wvm.h, sx, sy, _p(r), _p(out), len(out), _p(lv), _p(fo))
+    return out[:cnt], lv, fo
+
+
+def five_stage(pyr, wvm, svm, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1, roi=None, cap=4096):
+    out = np.zeros(cap, DET_DTYPE)
+    stages = np.zeros(4, np.int32)
+    r = _c(roi, np.int32) if roi is not None else None
+    n = lib().orc_five_stage(pyr.h, pyr.img_w, pyr.img_h, wvm.h, svm.h, oe_dist, oe_ratio, sx, sy, _p(r), _p(out), cap, _p(stages))
+    return out[:n], stages
+
+
+def overlap_elimination(dets, dist, ratio):
+    dets = _c(dets, DET_DTYPE)
+    idx = np.empty(max(len(dets), 1), np.int32)
+    n = lib().orc_overlap_elimination(len(dets), _p(dets), dist, ratio, _p(idx))
+    return idx[:n]
+
+
+def block_nms(pmap, sz, mask=None):
+    pmap = _c(pmap, np.float32)
+    m = _c(mask, np.uint8) if mask is not None else None
+    out = np.empty(pmap.shape, np.uint8)
+    lib().orc_block_nms(_p(pmap), pmap.shape[0], pmap.shape[1], sz, _p(m), _p(out))
+    return out
+
+
+def sliding_hog_svm(pyr, svm, pw, ph, sx, sy, bins, cell, block, interpolate=False, sau=False, want_feats=0):
+    wins = pyr.windows(pw, ph, sx, sy)
+    n = len(wins)
+    dist = np.empty(n, np.float64)
+    out = np.zeros(max(n, 1), DET_DTYPE)
+    feats = None
+    if want_feats:
+        F = len(hog_filter(np.zeros((ph, pw, 2), np.uint8), bins, cell, block, interpolate, sau))
+        feats = np.empty((min(n, want_feats), F), np.float32)
+    cnt = lib().orc_sliding_hog_svm(pyr.h, svm.h if svm else None, pw, ph, sx, sy, bins, cell, block, int(interpolate), int(sau),
+                                    _p(out), len(out), _p(dist) if svm else None, _p(feats), len(feats) if feats is not None else 0)
+    return (out[:cnt] if svm else None), (dist if svm else None), feats
+
+
+def vlhog(img, cell, nori, variant):
+    img = _c(img, np.float32)
+    hw, hh = C.c_int(), C.c_int()
+    d = lib().orc_vlhog(_p(img), img.shape[1], img.shape[0], cell, nori, variant, None, C.byref(hw), C.byref(hh))
+    out = np.empty(hw.value * hh.value * d, np.float32)
+    lib().orc_vlhog(_p(img), img.shape[1], img.shape[0], cell, nori, variant, _p(out), C.byref(hw), C.byref(hh))
+    return out.reshape(d, hh.value, hw.value)
+
+
+def ref_vlhog(img, cell, nori, variant):
+    r = ref()
+    img = _c(img, np.float32)
+    h = r.vl_hog_new(variant, nori, 0)
+    r.vl_hog_put_image(h, _p(img), img.shape[1], img.shape[0], 1, cell)
+    ww, hh, dd = r.vl_hog_get_width(h), r.vl_hog_get_height(h), r.vl_hog_get_dimension(h)
+    out = np.empty(ww * hh * dd, np.float32)
+    r.vl_hog_extract(h, _p(out))
+    r.vl_hog_delete(h)
+    return out.reshape(dd, hh, ww)
+
+
+def sdm_descriptors(gray, px, py, wsh, variant=1, num_cells=3, cell_size=10, num_bins=9):
+    gray = _c(gray, np.uint8)
+    px, py = _c(px, np.float32), _c(py, np.float32)
+    n = len(px)
+    ln = lib().orc_sdm_descriptors(_p(gray), gray.shape[1], gray.shape[0], _p(px), _p(py), n, wsh, variant, num_cells, cell_size,
+                                   num_bins, None)
+    if ln < 0:
+        return None
+    out = np.empty((n, ln), np.float32)
+    lib().orc_sdm_descriptors(_p(gray), gray.shape[1], gray.shape[0], _p(px), _p(py), n, wsh, variant, num_cells, cell_size,
+                              num_bins, _p(out))
+    return out
+
+
+def sdm_fit(gray, model, face_box):
+    """alignRigid + optimize for one face; returns (status, shape[2L])"""
+    gray = _c(gray, np.uint8)
+    L, S = model["L"], model["S"]
+    shape = _c(model["mean"], np.float32).copy()
+    fb = _c(face_box, np.int32)
+    lib().orc_sdm_align_rigid(_p(shape), L, _p(fb))
+    Rs = [_c(r, np.float32) for r in model["R"]]
+    ptrs = (C.c_void_p * S)(*[r.ctypes.data for r in Rs])
+    rows = _c([r.shape[0] for r in Rs], np.int32)
+    st = lib().orc_sdm_optimize(_p(gray), gray.shape[1], gray.shape[0], _p(shape), L, S, ptrs, _p(rows), int(model["variant"]))
+    return st, shape

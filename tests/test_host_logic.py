@@ -1,0 +1,75 @@
+"""Host-side logic of the product library that needs no GPU: OverlapElimination and block NMS through
+the C ABI against the oracle, the exported symbol table against include/fd_hip.h, and the loud
+failure when no device is present."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _random_dets(oracle, capi, rng, n, w=640, h=480, tie=False):
+    o = np.zeros(n, oracle.DET_DTYPE)
+    o["cx"] = rng.integers(0, w, n)
+    o["cy"] = rng.integers(0, h, n)
+    o["w"] = rng.choice([120, 135, 147, 160, 200], n)
+    o["h"] = o["w"]
+    o["prob"] = 0.5 if tie else rng.random(n)
+    c = np.zeros(n, capi.DET_DTYPE)
+    for f in ("cx", "cy", "w", "h"):
+        c[f] = o[f]
+    c["probability"] = o["prob"]
+    return o, c
+
+
+def test_symbols_match_header(capi):
+    hdr = open(os.path.join(ROOT, "include", "fd_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(fd_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) > 30
+    lib = capi.lib()
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, "symbols declared in include/fd_hip.h but not exported: %s" % missing
+    assert set(capi._SIGS) == names
+
+
+@pytest.mark.parametrize("dist,ratio", [(5.0, 0.0), (0.5, 0.0), (20.0, 0.8), (1.0, 1.5)])
+def test_overlap_elimination_matches_oracle(oracle, capi, dist, ratio):
+    rng = np.random.default_rng(int(dist * 10 + ratio * 100))
+    for n in (0, 1, 2, 17, 300):
+        o, c = _random_dets(oracle, capi, rng, n, w=200, h=150)
+        assert np.array_equal(oracle.overlap_elimination(o, dist, ratio), capi.overlap_elimination(c, dist, ratio))
+
+
+def test_overlap_elimination_ties(oracle, capi):
+    rng = np.random.default_rng(9)
+    o, c = _random_dets(oracle, capi, rng, 200, w=120, h=90, tie=True)
+    assert np.array_equal(oracle.overlap_elimination(o, 5.0, 0.0), capi.overlap_elimination(c, 5.0, 0.0))
+
+
+@pytest.mark.parametrize("masked", [True, False])
+def test_block_nms_matches_dense_oracle(oracle, capi, masked):
+    rng = np.random.default_rng(4)
+    for n, tie in ((0, False), (1, False), (40, False), (40, True), (400, False), (400, True)):
+        W, H = 320, 240
+        o, c = _random_dets(oracle, capi, rng, n, w=W, h=H, tie=tie)
+        pmap = np.zeros((H, W), np.float32)
+        for d in o:
+            if pmap[d["cy"], d["cx"]] < d["prob"]:
+                pmap[d["cy"], d["cx"]] = d["prob"]
+        mask = ((pmap > np.float32(0.3)) * 255).astype(np.uint8) if masked else None
+        dense = oracle.block_nms(pmap, 35, mask)
+        ys, xs = np.nonzero(dense)
+        got = capi.block_nms(c, W, H, 35, masked)
+        assert np.array_equal(got, np.stack([xs, ys], 1).astype(np.int32).reshape(-1, 2)), (n, tie)
+
+
+def test_no_silent_cpu_fallback(capi):
+    """On a box without a GPU every compute entry point must fail loudly (FD_ERR_HIP)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.FdError):
+        capi.Context(0)

@@ -1,0 +1,128 @@
+"""Oracle pinned against (a) outputs of the reference's own translation units (tests/golden/ref_*.npz,
+generated from /root/reference by tests/golden/make_golden.py) and (b) its own committed regression
+vectors.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_vlhog_matches_reference_hog_c(oracle):
+    g = np.load(os.path.join(G, "ref_vlhog.npz"))
+    for i in range(int(g["n"])):
+        cell, nori, var = [int(v) for v in g["par%d" % i]]
+        out = oracle.vlhog(g["img%d" % i], cell, nori, var)
+        assert out.shape == g["out%d" % i].shape
+        assert np.array_equal(out, g["out%d" % i]), "case %d differs from hog.c" % i  # bit-exact
+
+
+def test_iimg_matches_reference_iimg_cpp(oracle):
+    g = np.load(os.path.join(G, "ref_iimg.npz"))
+    for i in range(int(g["n"])):
+        for sqr in (0, 1):
+            assert np.array_equal(oracle.iimg(g["patch%d" % i], sqr), g["out%d_%d" % (i, sqr)])
+
+
+def test_svm_kernels_match_reference_libsvm(oracle):
+    """libsvm computes everything in fp64; the reference kernels use fp32 SSD/min-sum for float
+    inputs, so compare to 1e-5 relative (tolerance stated here)."""
+    g = np.load(os.path.join(G, "ref_libsvm.npz"))
+    sv, x, coef, rho = g["sv"].astype(np.float32), g["x"].astype(np.float32), g["coef"].astype(np.float32), float(g["rho"])
+    for name, kern in (("linear", 0), ("poly", 1), ("rbf", 2), ("hik", 3)):
+        kt, deg, gamma, c0 = g["par_" + name]
+        m = dict(kernel=kern, dtype=1, sv=sv, coeff=coef, bias=np.float32(rho), threshold=0.0)
+        if kern == 1:
+            m.update(p0=gamma, p1=c0, p2=deg)   # libsvm poly: (gamma*u'v + coef0)^degree
+        elif kern == 2:
+            m.update(p0=gamma)
+        d = oracle.Svm(m).distance(x)
+        ref = g["dec_" + name]
+        # rho/coef were rounded to f32 for the reference classes: compare with matching tolerance
+        assert np.allclose(d, ref, rtol=2e-5, atol=2e-5 * np.abs(coef).sum()), (name, d, ref)
+
+
+def test_oracle_live_reference_units(oracle):
+    """When oracle/_ref is present (build container, or shipped prebuilt), cross-check on fresh random
+    inputs, beyond the committed vectors."""
+    if oracle.ref() is None:
+        pytest.skip("oracle/_ref/libfdref.so not available")
+    rng = np.random.default_rng(123)
+    for _ in range(5):
+        img = rng.uniform(0, 255, (30, 30)).astype(np.float32)
+        assert np.array_equal(oracle.vlhog(img, 10, 9, 1), oracle.ref_vlhog(img, 10, 9, 1))
+        img = rng.uniform(0, 255, (27, 33)).astype(np.float32)
+        assert np.array_equal(oracle.vlhog(img, 4, 6, 0), oracle.ref_vlhog(img, 4, 6, 0))
+
+
+def test_cascade_regression_vectors(oracle):
+    g = np.load(os.path.join(G, "orc_cascade_160x120.npz"))
+    wvm = {k[5:]: g[k] for k in g.files if k.startswith("wvm__")}
+    svm = {k[5:]: g[k] for k in g.files if k.startswith("svm__")}
+    pyr = oracle.Pyramid(octave_layers=4, min_scale=0.4, max_scale=1.0)
+    pyr.update(g["frame"])
+    sizes = np.array([[l["index"], l["w"], l["h"]] for l in pyr.layers()], np.int32)
+    assert np.array_equal(sizes, g["layer_sizes"])
+    sums = np.array([int(pyr.layer(i).astype(np.int64).sum()) for i in range(len(sizes))], np.int64)
+    assert np.array_equal(sums, g["layer_sums"])
+    assert np.array_equal(pyr.layer(len(sizes) - 1), g["last_layer"])
+    w, s = oracle.Wvm(wvm), oracle.Svm(svm)
+    pos, lv, fo = oracle.sliding_wvm(pyr, w)
+    assert np.array_equal(lv, g["wvm_level"])
+    assert np.array_equal(fo, g["wvm_fout"])
+    dets, stages = oracle.five_stage(pyr, w, s)
+    assert np.array_equal(stages, g["stages"])
+    for f in ("cx", "cy", "w", "h", "layer", "lx", "ly"):
+        assert np.array_equal(dets[f], g["five"][f])
+    pyr2 = oracle.Pyramid(octave_layers=3, min_scale=0.3, max_scale=1.0)
+    pyr2.set_layer_filter(1, bins=9)
+    pyr2.update(g["frame"])
+    _, _, feats = oracle.sliding_hog_svm(pyr2, None, 20, 20, 2, 2, 9, 5, 2, want_feats=10 ** 9)
+    assert len(feats) == int(g["hog_n"])
+    assert np.array_equal(feats[:64], g["hog_feat_head"])
+
+
+def test_pyramid_structure_matches_survey_appendix_d(oracle, frame640):
+    """ffpDetectApp/FaceFrontal.cfg parameters (float-typed as ffpDetectApp.cpp:407 reads them):
+    13 layers 96x72 .. 34x26 and 16,185 windows at step 1."""
+    p = oracle.Pyramid(inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))
+    p.update(frame640)
+    L = p.layers()
+    assert p.octave_layers == 8
+    assert [(l["index"], l["w"], l["h"]) for l in L][:3] == [(22, 96, 72), (23, 88, 66), (24, 80, 60)]
+    assert (L[-1]["index"], L[-1]["w"], L[-1]["h"]) == (34, 34, 26)
+    assert len(p.windows(20, 20, 1, 1)) == 16185
+    assert len(p.windows(20, 20, 2, 2)) == 4161
+
+
+def test_histeq64_properties(oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        p = rng.integers(0, 256, (20, 20), dtype=np.uint8)
+        e = oracle.histeq64(p)
+        assert e.max() in (254, 255)
+        order = np.argsort(p.ravel() >> 2, kind="stable")
+        assert np.all(np.diff(e.ravel()[order].astype(int)) >= 0)  # monotone in the input bin
+    flat = np.full((20, 20), 77, np.uint8)
+    assert np.all(oracle.histeq64(flat) == 255)
+
+
+def test_wvm_invariants(oracle, small_models):
+    wvm, _ = small_models
+    w = oracle.Wvm(wvm)
+    rng = np.random.default_rng(2)
+    for _ in range(50):
+        patch = rng.integers(0, 256, (20, 20), dtype=np.uint8)
+        lv, fo = w.eval(patch)
+        assert 0 <= lv < wvm["num_filters"]
+        if lv + 1 < wvm["num_filters"]:
+            assert fo < wvm["thresholds"][lv]  # early exit means the threshold was missed
+
+
+def test_empty_and_tiny_inputs(oracle):
+    p = oracle.Pyramid(octave_layers=2, min_scale=0.5, max_scale=1.0)
+    p.update(np.zeros((10, 10), np.uint8))  # smaller than the patch: no windows
+    assert len(p.windows(20, 20, 1, 1)) == 0
+    assert len(oracle.overlap_elimination(np.zeros(0, oracle.DET_DTYPE), 5.0, 0.0)) == 0
+    assert oracle.block_nms(np.zeros((40, 50), np.float32), 35).sum() == 0
