@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json metric: Mpatches/s (extract + classify) on a 640x480 pyramid.
+
+Default workload (N=1): BASELINE config 2 -- 640x480 frame, ImagePyramid(octaveLayerCount=5, 1/16..1),
+20x20 windows at stride 2 (278,142 windows/frame), HOG-324 features + RBF SVM with 1024 support
+vectors.  One step = one frame through pyramid build + HOG extraction + SVM scoring; frames are
+resident in HBM before the timed region.  --workload wvm / sdm time the cascade and SDM paths.
+
+Prints ONE JSON line (rank 0).  Multi-GPU: one process per GPU (torch.distributed, RCCL), frames
+sharded across ranks (weak scaling), ONE gather of detection records every --gather-every steps."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense f32 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline_hog_svm(frame2, model, seconds_hint=20):
+    """Oracle ("port" of the reference CPU path, single thread like the reference) on a bounded sample:
+    a 224x168 crop of the same frame recipe, same pyramid/window/HOG/SVM parameters."""
+    from oracle import pyoracle as O
+    from featuredetection_amd import synth
+    crop = synth.make_frame(224, 168, seed=20260927)
+    p = O.Pyramid(octave_layers=5, min_scale=1 / 16, max_scale=1.0)
+    p.set_layer_filter(1, bins=9)
+    s = O.Svm(model)
+    t0 = time.perf_counter()
+    p.update(crop)
+    _, dist, _ = O.sliding_hog_svm(p, s, 20, 20, 2, 2, 9, 5, 2)
+    dt = time.perf_counter() - t0
+    return dict(value=len(dist) / dt / 1e6, unit="Mpatches/s", cores=1, kind="port",
+                sample="224x168 crop, %d windows, %.1f s, oracle -O2 single thread (pyramid+HOG+RBF-SVM 1024 SV)" % (len(dist), dt))
+
+
+def cpu_baseline_wvm(frame, wvm, svm):
+    from oracle import pyoracle as O
+    p = O.Pyramid(inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))
+    w, s = O.Wvm(wvm), O.Svm(svm)
+    t0 = time.perf_counter()
+    n = 0
+    reps = 0
+    while time.perf_counter() - t0 < 10:
+        p.update(frame)
+        O.five_stage(p, w, s)
+        n += 16185
+        reps += 1
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt / 1e6, unit="Mpatches/s", cores=1, kind="port",
+                sample="%d x 640x480 FaceFrontal five-stage cascade (16,185 windows each), %.1f s, oracle -O2 single thread" % (reps, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="hog_svm", choices=["hog_svm", "wvm", "sdm"])
+    ap.add_argument("--gather-every", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from featuredetection_amd import capi, synth, parallel
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = capi.Context(local_rank, stream)
+
+    NFRAMES = 4  # distinct frames per rank, cycled
+    out = {}
+    if args.workload == "hog_svm":
+        W, H = 640, 480
+        frames = [synth.make_frame(W, H, seed=20260927 + 1000 * rank + i) for i in range(NFRAMES)]
+        dframes = [torch.from_numpy(f).to(dev) for f in frames]
+        pyr = capi.Pyramid(ctx, octave_layers=5, min_scale=1 / 16, max_scale=1.0)
+        pyr.set_layer_filter(capi.FD_LAYER_GRADBIN, bins=9)
+        hp = capi.hog_params(20, 20, 2, 2, 9, 5, 2, False)
+        # model: SVs drawn from the HOG features of a second seeded frame (same on every rank)
+        pyr.update(synth.make_frame(W, H, seed=4242))
+        feats2 = capi.extract_hog(ctx, pyr, hp)
+        model = synth.make_svm_f32(20260927, feats2, nsv=1024, gamma=0.5, positive_fraction=0.01)
+        svm = capi.Svm(ctx, model)
+        del feats2
+
+        def step(i):
+            f = dframes[i % NFRAMES]
+            pyr.update_device(f.data_ptr(), W, H, 3)
+            return capi.bench_hog_svm(ctx, pyr, svm, hp)
+
+        units_name = "windows"
+        config = dict(workload="config2: 640x480 BGR frame, ImagePyramid(octl=5, 1/16..1) 21 layers, 20x20 windows stride 2, "
+                               "GradientFilter+GradientBinning(9) layers, HogFilter(9,cell 5,block 2)=324 f32, RBF-SVM 1024 SV gamma 0.5",
+                      frames_per_step=1, parallelism="image-shard dp%d" % world)
+        dtype = "f32"
+    elif args.workload == "wvm":
+        W, H = 640, 480
+        frames = [synth.make_frame(W, H, seed=20260927 + 1000 * rank + i) for i in range(NFRAMES)]
+        dframes = [torch.from_numpy(f).to(dev) for f in frames]
+        from oracle import pyoracle as O  # only to build the calibration patches identically to tests
+        gray = O.bgr2gray(frames[0])
+        calib = synth.random_patches(gray[::4, ::4].copy(), 20, 20, 8000, np.random.default_rng(1))
+        wvm_m = synth.make_wvm(7, calib_patches=calib)
+        eq = synth.histeq64_np(synth.random_patches(gray[::4, ::4].copy(), 20, 20, 1400, np.random.default_rng(2)))
+        svm_m = synth.make_svm_u8(3, eq, nsv=1024, calib=eq[1024:])
+        pyr = capi.Pyramid(ctx, inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))
+        wvm, svm = capi.Wvm(ctx, wvm_m), capi.Svm(ctx, svm_m)
+
+        def step(i):
+            f = dframes[i % NFRAMES]
+            pyr.update_device(f.data_ptr(), W, H, 3)
+            dets, st = capi.detect_five_stage(ctx, pyr, wvm, svm)
+            return 16185, len(dets)
+
+        units_name = "windows"
+        config = dict(workload="config1 on GPU: 640x480, FaceFrontal.cfg pyramid (13 layers), 20x20 step 1, WVM 280 filters -> OE -> "
+                               "RBF-SVM 1024 SV -> NMS", frames_per_step=1, parallelism="image-shard dp%d" % world)
+        dtype = "u8/f32/f64"
+    else:
+        B, W, H = 256, 256, 256
+        imgs = np.stack([synth.make_frame(W, H, seed=9000 + 1000 * rank + i, channels=1) for i in range(16)])
+        imgs = np.concatenate([imgs] * (B // 16))
+        dimgs = torch.from_numpy(imgs).to(dev)
+        model = synth.make_sdm(9, L=68, S=4)
+        sdm = capi.Sdm(ctx, model)
+        boxes = np.array([[48, 48, 160, 160]] * B, np.int32)
+
+        def step(i):
+            sdm.fit_device(dimgs.data_ptr(), W, H, B, boxes)
+            return B * 4, 0
+
+        units_name = "sdm_iters"
+        config = dict(workload="config4: 256 gray 256x256 crops, 68 landmarks, 4 cascade steps, adaptive VlHog 3x3x31 + regressor 18973x136",
+                      frames_per_step=B, parallelism="face-shard dp%d" % world)
+        dtype = "f32/f64"
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    kernel_ms = []
+    recs_cap = 4096
+    barrier()
+    t0 = time.perf_counter()
+    units = 0
+    pending = []
+    for i in range(args.steps):
+        n, npos = step(i)
+        units += n
+        pending.append((i, npos))
+        if args.workload != "sdm":
+            kernel_ms.append(ctx.last_kernel_ms()[1])
+        if world > 1 and ((i + 1) % args.gather_every == 0 or i + 1 == args.steps):
+            local = np.array([[rank * 1e6 + s, 0, 0, 0, 0, 0, 0, p] for s, p in pending], np.float64)
+            parallel.gather_records(local, recs_cap, device=dev)
+            pending = []
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    uu = torch.tensor([float(units)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(uu, op=dist.ReduceOp.SUM)
+    dt, total_units = float(tt.item()), float(uu.item())
+
+    if rank == 0:
+        value = total_units / dt / 1e6
+        res = dict(metric="Mpatches/s (extract+HOG+RBF-SVM), 640x480 pyramid" if args.workload == "hog_svm" else
+                   ("Mpatches/s (extract+WVM+SVM cascade), 640x480 pyramid" if args.workload == "wvm" else "SDM iters/s (x1e6)"),
+                   value=value, unit="Mpatches/s" if args.workload != "sdm" else "M SDM iters/s", n_gpus=world, steps=args.steps,
+                   warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype=dtype, data="synthetic", config=config)
+        if args.workload == "hog_svm":
+            kms = float(np.mean(kernel_ms))
+            nwin = units / args.steps
+            flops = 2.0 * 324 * 1024 * nwin
+            ach = flops / (kms * 1e-3) / 1e12
+            res["roofline"] = dict(bound="mfma", kernel="k_svm_rbf_mfma", achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                                   frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=None, kernel_ms=kms,
+                                   algorithmic="2*324*1024 flop/window x %d windows/launch" % nwin)
+            if not args.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline_hog_svm(None, model)
+        elif args.workload == "wvm":
+            kms = float(np.mean(kernel_ms))
+            layer_bytes = 38751
+            bytes_per_launch = layer_bytes + 16185 * 16
+            ach = bytes_per_launch / (kms * 1e-3) / 1e9
+            res["roofline"] = dict(bound="hbm", kernel="k_wvm_cascade", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
+                                   traffic=None, kernel_ms=kms, algorithmic="38,751 layer bytes + 16 B record x 16,185 windows per launch")
+            if not args.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline_wvm(frames[0], wvm_m, svm_m)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -619,7 +619,8 @@ int fd_greyworld(fd_ctx* ctx, const uint8_t* bgr, int w, int h, uint8_t* dst, in
         unsigned long long* sums = stats.as<unsigned long long>();
         unsigned int* maxs = (unsigned int*)(sums + 3);
         hipLaunchKernelGGL(k_greyworld_stats, dim3(grid_for(n)), dim3(256), 0, ctx->stream, din, n, sums, maxs);
-        unsigned long long hs[4];
+        HIP_CHECK(hipGetLastError());
+        unsigned long long hs[5] = {0, 0, 0, 0, 0};
         HIP_CHECK(hipMemcpyAsync(hs, stats.p, 40, hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         unsigned int hm[3];
@@ -632,6 +633,7 @@ int fd_greyworld(fd_ctx* ctx, const uint8_t* bgr, int w, int h, uint8_t* dst, in
         if (maxNew[2] > mx) mx = maxNew[2];
         for (int c = 0; c < 3; ++c) scale[c] = 255.0 / (mean[c] * mx);
         hipLaunchKernelGGL(k_greyworld_apply, dim3(grid_for(n)), dim3(256), 0, ctx->stream, din, dout, n, scale[0], scale[1], scale[2]);
+        HIP_CHECK(hipGetLastError());
         if (!is_device) HIP_CHECK(hipMemcpyAsync(dst, dout, (size_t)n * 3, hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
     });

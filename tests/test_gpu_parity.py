@@ -1,0 +1,324 @@
+"""GPU parity tests: the HIP path through the C ABI against the CPU oracle on identical seeded inputs.
+Bit-exact for integer/byte/index work (pyramid layers, window enumeration, HistEq64, WVM level and
+fp32 filter output, HOG features, detections); stated tolerances for the fp paths that reorder sums."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FF = dict(inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))  # FaceFrontal.cfg
+
+
+def _pyr_pair(oracle, capi, ctx, frame, **kw):
+    po = oracle.Pyramid(**kw)
+    po.update(frame)
+    pg = capi.Pyramid(ctx, **kw)
+    pg.update(frame)
+    return po, pg
+
+
+def _same_geometry(g, o):
+    for f in ("cx", "cy", "w", "h", "layer", "lx", "ly"):
+        assert np.array_equal(g[f], o[f]), f
+
+
+def test_native_library_loaded(capi, ctx):
+    assert b"gfx950" in capi.lib().fd_version()
+    maps = open("/proc/self/maps").read()
+    assert "libfd_hip.so" in maps
+
+
+@pytest.mark.parametrize("size,kw", [((640, 480), FF), ((640, 480), dict(octave_layers=5, min_scale=1 / 16, max_scale=1.0)),
+                                      ((321, 243), dict(octave_layers=3, min_scale=0.1, max_scale=0.8)),
+                                      ((1920, 1080), dict(inc=float(np.float32(0.9)), min_scale=float(np.float32(0.09)),
+                                                          max_scale=float(np.float32(0.25))))])
+def test_pyramid_layers_bit_exact(oracle, capi, ctx, synth, size, kw):
+    frame = synth.make_frame(size[0], size[1], seed=size[0])
+    po, pg = _pyr_pair(oracle, capi, ctx, frame, **kw)
+    assert pg.octave_layers == po.octave_layers and pg.inc == po.inc
+    lo, lg = po.layers(), pg.layers()
+    assert lo == lg
+    for i in range(len(lo)):
+        assert np.array_equal(pg.layer(i), po.layer(i)), "layer %d" % i
+    # gray input must give the same pyramid as its BGR source converted by the oracle
+    gray = oracle.bgr2gray(frame)
+    pg.update(gray)
+    assert np.array_equal(pg.layer(len(lg) - 1), po.layer(len(lo) - 1))
+    pg.close()
+
+
+@pytest.mark.parametrize("roi", [None, (100, 80, 300, 200), (-20, -10, 200, 100), (500, 400, 400, 400)])
+def test_window_enumeration(oracle, capi, ctx, frame640, roi):
+    po, pg = _pyr_pair(oracle, capi, ctx, frame640, **FF)
+    for (pw, ph, sx, sy) in ((20, 20, 1, 1), (20, 20, 2, 2), (32, 16, 3, 1)):
+        assert np.array_equal(pg.windows(pw, ph, sx, sy, roi), po.windows(pw, ph, sx, sy, roi))
+    pg.close()
+
+
+def test_layer_filters_bit_exact(oracle, capi, ctx, frame640):
+    kw = dict(octave_layers=3, min_scale=0.2, max_scale=1.0)
+    for filt in (dict(kind=1, bins=9), dict(kind=1, bins=8, signed_gradients=True), dict(kind=1, bins=9, interpolate=True),
+                 dict(kind=1, bins=9, grad_kernel=3), dict(kind=2, lbp_type=0), dict(kind=2, lbp_type=1), dict(kind=2, lbp_type=2),
+                 dict(kind=2, lbp_type=3)):
+        po = oracle.Pyramid(**kw)
+        po.set_layer_filter(**filt)
+        po.update(frame640)
+        pg = capi.Pyramid(ctx, **kw)
+        pg.set_layer_filter(**filt)
+        pg.update(frame640)
+        assert pg.layers() == po.layers()
+        for i in range(len(po.layers())):
+            assert np.array_equal(pg.layer(i), po.layer(i)), (filt, i)
+        pg.close()
+
+
+def test_histeq64_bit_exact_including_half_ties(oracle, ctx):
+    rng = np.random.default_rng(3)
+    patches = rng.integers(0, 256, (512, 20, 20), dtype=np.uint8)
+    # exact .5 ties: cumulative counts of 40, 120, 200, ... pixels (255/400 * k = m + 0.5)
+    t = np.zeros((20, 20), np.uint8).ravel()
+    t[:40] = 8; t[40:120] = 100; t[120:200] = 160; t[200:] = 250
+    patches[0] = t.reshape(20, 20)
+    patches[1] = 255
+    patches[2] = 0
+    out = ctx.histeq64(patches)
+    for i in range(len(patches)):
+        assert np.array_equal(out[i], oracle.histeq64(patches[i])), i
+    for (w, h) in ((32, 16), (16, 24), (24, 24), (32, 24)):
+        p = rng.integers(0, 256, (64, h, w), dtype=np.uint8)
+        o = ctx.histeq64(p)
+        for i in range(len(p)):
+            assert np.array_equal(o[i], oracle.histeq64(p[i])), (w, h, i)
+
+
+def test_greyworld_bit_exact(oracle, ctx, frame640):
+    assert np.array_equal(ctx.greyworld(frame640), oracle.greyworld(frame640))
+
+
+def test_wvm_all_windows_bit_exact(oracle, capi, ctx, frame640, small_models):
+    """Every window's (last level, fp32 filter output) must equal the CPU cascade exactly."""
+    wvm, _ = small_models
+    po, pg = _pyr_pair(oracle, capi, ctx, frame640, **FF)
+    wo = oracle.Wvm(wvm)
+    wg = capi.Wvm(ctx, wvm)
+    for step in (1, 2):
+        pos_o, lv_o, fo_o = oracle.sliding_wvm(po, wo, step, step)
+        pos_g, lv_g, fo_g = capi.detect_wvm(ctx, pg, wg, step, step, want_all=True)
+        assert len(lv_g) == len(lv_o) == (16185 if step == 1 else 4161)
+        assert np.array_equal(lv_g, lv_o)
+        assert np.array_equal(fo_g, fo_o)
+        assert len(pos_g) == len(pos_o)
+        _same_geometry(pos_g, pos_o)
+        assert np.array_equal(pos_g["score"], pos_o["fout"])
+        assert np.array_equal(pos_g["probability"], pos_o["prob"])
+    wg.close(); pg.close()
+
+
+def test_wvm_full_size_model_and_other_patch_shapes(oracle, capi, ctx, synth, frame640):
+    gray = oracle.bgr2gray(frame640)
+    rng = np.random.default_rng(8)
+    for (name, n_levels) in (("FaceFrontal", 20), ("LeftEyeCenter", 3), ("NoseTip", 2), ("LeftEarCenter", 2)):
+        inc, mn, mx, pw, ph, nper, _ = synth.DETECTOR_CFGS[name]
+        calib = synth.random_patches(gray[::2, ::2].copy(), pw, ph, 3000, rng)
+        wvm = synth.make_wvm(31, fw=pw, fh=ph, n_per=nper, n_levels=n_levels, calib_patches=calib, min_survivors=48)
+        kw = dict(inc=float(np.float32(inc)), min_scale=float(np.float32(mn)), max_scale=float(np.float32(mx)))
+        small = frame640[:240, :320] if name != "FaceFrontal" else frame640
+        po, pg = _pyr_pair(oracle, capi, ctx, small, **kw)
+        wo, wg = oracle.Wvm(wvm), capi.Wvm(ctx, wvm)
+        step = 1 if name == "FaceFrontal" else 3
+        pos_o, lv_o, fo_o = oracle.sliding_wvm(po, wo, step, step)
+        pos_g, lv_g, fo_g = capi.detect_wvm(ctx, pg, wg, step, step, want_all=True)
+        assert len(lv_o) > 0
+        assert np.array_equal(lv_g, lv_o), name
+        assert np.array_equal(fo_g, fo_o), name
+        _same_geometry(pos_g, pos_o)
+        wg.close(); pg.close()
+
+
+@pytest.mark.parametrize("kernel,dtype", [(2, 0), (3, 0), (0, 0), (1, 0), (2, 1), (3, 1), (0, 1), (1, 1)])
+def test_svm_distance_batch(oracle, capi, ctx, kernel, dtype):
+    rng = np.random.default_rng(kernel * 2 + dtype)
+    nsv, dim, n = 200, 400, 64
+    if dtype == 0:
+        sv = rng.integers(0, 256, (nsv, dim), dtype=np.uint8)
+        x = rng.integers(0, 256, (n, dim), dtype=np.uint8)
+        p0 = {2: 0.04 / 65025.0, 1: 1.0 / 65025.0}.get(kernel, 0.0)
+    else:
+        sv = rng.random((nsv, dim)).astype(np.float32) * 0.2
+        x = rng.random((n, dim)).astype(np.float32) * 0.2
+        p0 = {2: 0.5, 1: 0.3}.get(kernel, 0.0)
+    m = dict(kernel=kernel, p0=p0, p1=0.7, p2=3, dtype=dtype, sv=sv, coeff=rng.normal(0, 1, nsv).astype(np.float32),
+             bias=np.float32(0.25), threshold=0.0)
+    do = oracle.Svm(m).distance(x)
+    sg = capi.Svm(ctx, m)
+    dg = sg.distance(x)
+    # integer kernels are exact per term; only the order of the fp64 sum over support vectors differs.
+    # f32 RBF/HIK reorder an fp32 sum inside each kernel value -> 1e-4 relative to the term scale.
+    scale = np.abs(m["coeff"]).sum() * (np.abs(do).max() / max(np.abs(m["coeff"]).sum(), 1e-30) if kernel in (0, 1, 3) else 1.0)
+    tol = 1e-12 if (dtype == 0) else 1e-5
+    assert np.all(np.abs(dg - do) <= 1e-4 * np.abs(do) + tol * max(scale, 1.0)), (np.abs(dg - do).max(), scale)
+    if dtype == 0 and kernel in (2, 3):
+        assert np.allclose(dg, do, rtol=1e-12, atol=1e-12 * scale)
+    sg.close()
+
+
+def test_five_stage_cascade_identical_detections(oracle, capi, ctx, frame640, small_models):
+    wvm, svm = small_models
+    po, pg = _pyr_pair(oracle, capi, ctx, frame640, **FF)
+    wo, so = oracle.Wvm(wvm), oracle.Svm(svm)
+    wg, sg = capi.Wvm(ctx, wvm), capi.Svm(ctx, svm)
+    for roi in (None, (120, 60, 360, 300)):
+        do, sto = oracle.five_stage(po, wo, so, 5.0, 0.0, 1, 1, roi)
+        dg, stg = capi.detect_five_stage(ctx, pg, wg, sg, 5.0, 0.0, 1, 1, roi)
+        assert np.array_equal(stg, sto), (stg, sto)
+        assert sto[0] > 10 and sto[2] > 0, "test model produces no detections: %s" % sto
+        _same_geometry(dg, do)
+        assert np.array_equal(dg["probability"], do["prob"])
+        assert np.allclose(dg["score"], do["fout"], rtol=1e-6, atol=1e-6)
+    # relative OE distance and ratio
+    do, sto = oracle.five_stage(po, wo, so, 0.5, 0.7, 2, 2, None)
+    dg, stg = capi.detect_five_stage(ctx, pg, wg, sg, 0.5, 0.7, 2, 2, None)
+    assert np.array_equal(stg, sto)
+    _same_geometry(dg, do)
+    wg.close(); sg.close(); pg.close()
+
+
+def test_golden_cascade_fixture(capi, ctx):
+    """Committed oracle vectors (tests/golden): the GPU path must reproduce them on the GPU box,
+    where neither the reference nor (necessarily) the oracle build is available."""
+    g = np.load(os.path.join(G, "orc_cascade_160x120.npz"))
+    wvm = {k[5:]: g[k] for k in g.files if k.startswith("wvm__")}
+    svm = {k[5:]: g[k] for k in g.files if k.startswith("svm__")}
+    svm["dtype"] = int(svm["dtype"]); svm["kernel"] = int(svm["kernel"])
+    pg = capi.Pyramid(ctx, octave_layers=4, min_scale=0.4, max_scale=1.0)
+    pg.update(g["frame"])
+    sizes = np.array([[l["index"], l["w"], l["h"]] for l in pg.layers()], np.int32)
+    assert np.array_equal(sizes, g["layer_sizes"])
+    assert np.array_equal(pg.layer(len(sizes) - 1), g["last_layer"])
+    wg, sg = capi.Wvm(ctx, wvm), capi.Svm(ctx, svm)
+    pos, lv, fo = capi.detect_wvm(ctx, pg, wg, 1, 1, want_all=True)
+    assert np.array_equal(lv, g["wvm_level"])
+    assert np.array_equal(fo, g["wvm_fout"])
+    dets, stages = capi.detect_five_stage(ctx, pg, wg, sg)
+    assert np.array_equal(stages, g["stages"])
+    for f in ("cx", "cy", "w", "h", "layer", "lx", "ly"):
+        assert np.array_equal(dets[f], g["five"][f])
+    pg2 = capi.Pyramid(ctx, octave_layers=3, min_scale=0.3, max_scale=1.0)
+    pg2.set_layer_filter(1, bins=9)
+    pg2.update(g["frame"])
+    feats = capi.extract_hog(ctx, pg2, capi.hog_params())
+    assert len(feats) == int(g["hog_n"])
+    assert np.array_equal(feats[:64], g["hog_feat_head"])
+    wg.close(); sg.close(); pg.close(); pg2.close()
+
+
+@pytest.mark.parametrize("hp", [dict(), dict(signed_and_unsigned=True, bins=8), dict(cell=4, block=1), dict(pw=32, ph=16, cell=8, block=2),
+                                dict(sx=1, sy=3, cell=10, block=1)])
+def test_hog_features_bit_exact(oracle, capi, ctx, frame640, hp):
+    kw = dict(octave_layers=2, min_scale=0.25, max_scale=0.6)
+    p = dict(pw=20, ph=20, sx=2, sy=2, bins=9, cell=5, block=2, signed_and_unsigned=False)
+    p.update(hp)
+    po = oracle.Pyramid(**kw)
+    po.set_layer_filter(1, bins=p["bins"], signed_gradients=p["signed_and_unsigned"])
+    po.update(frame640)
+    pg = capi.Pyramid(ctx, **kw)
+    pg.set_layer_filter(1, bins=p["bins"], signed_gradients=p["signed_and_unsigned"])
+    pg.update(frame640)
+    _, _, fo = oracle.sliding_hog_svm(po, None, p["pw"], p["ph"], p["sx"], p["sy"], p["bins"], p["cell"], p["block"], False,
+                                      p["signed_and_unsigned"], want_feats=10 ** 9)
+    fg = capi.extract_hog(ctx, pg, capi.hog_params(**p))
+    assert fg.shape == fo.shape and len(fo) > 1000
+    assert np.array_equal(fg, fo)
+    pg.close()
+
+
+def test_hog_rbf_svm_detector_config2(oracle, capi, ctx, synth):
+    """BASELINE config 2 shape on a reduced frame: HOG-324 + RBF SVM (MFMA path).  Scores within
+    1e-4 relative (of the natural scale sum|coeff_i| K_i), positives identical away from the threshold."""
+    frame = synth.make_frame(320, 240, seed=11)
+    frame2 = synth.make_frame(320, 240, seed=12)
+    kw = dict(octave_layers=5, min_scale=1 / 16, max_scale=1.0)
+    po = oracle.Pyramid(**kw)
+    po.set_layer_filter(1, bins=9)
+    po.update(frame2)
+    _, _, feats2 = oracle.sliding_hog_svm(po, None, 20, 20, 2, 2, 9, 5, 2, want_feats=10 ** 9)
+    m = synth.make_svm_f32(5, feats2, nsv=300, gamma=0.5, positive_fraction=0.02)   # 300: exercises SV padding to 512
+    po.update(frame)
+    so = oracle.Svm(m)
+    dets_o, dist_o, _ = oracle.sliding_hog_svm(po, so, 20, 20, 2, 2, 9, 5, 2)
+    pg = capi.Pyramid(ctx, **kw)
+    pg.set_layer_filter(1, bins=9)
+    pg.update(frame)
+    sg = capi.Svm(ctx, m)
+    dets_g, dist_g = capi.detect_hog_svm(ctx, pg, sg, capi.hog_params())
+    assert len(dist_g) == len(dist_o) and len(dist_o) % 64 != 0
+    err = np.abs(dist_g - dist_o)
+    scale = np.abs(m["coeff"]).sum()
+    assert err.max() <= 1e-4 * max(1.0, np.abs(dist_o).max()), err.max()
+    assert err.max() <= 1e-5 * scale
+    safe = np.abs(dist_o - m["threshold"]) > 1e-4
+    pos_o = np.nonzero((dist_o >= m["threshold"]))[0]
+    pos_g = np.nonzero((dist_g >= m["threshold"]))[0]
+    assert np.array_equal(pos_o[safe[pos_o]], pos_g[safe[pos_g]])
+    assert len(pos_o) > 0
+    if np.array_equal(pos_o, pos_g):
+        _same_geometry(dets_g, dets_o)
+        assert np.allclose(dets_g["probability"], dets_o["prob"], rtol=1e-4)
+    sg.close(); pg.close()
+
+
+def test_sdm_descriptors_bit_exact(oracle, capi, ctx, synth):
+    gray = synth.make_frame(256, 256, seed=21, channels=1)
+    rng = np.random.default_rng(1)
+    px = rng.uniform(40, 216, 40).astype(np.float32)
+    py = rng.uniform(40, 216, 40).astype(np.float32)
+    # points whose window crosses the left/top border use the zero-extended image (where the quirk allows)
+    px[:4] = [3.2, 8.5, 5.5, 200.4]
+    py[:4] = [100.0, 120.5, 60.5, 150.0]
+    for wsh in (12, 15, 21, 33):
+        do = oracle.sdm_descriptors(gray, px, py, wsh)
+        assert do is not None
+        dg = capi.sdm_descriptors(ctx, gray, px, py, wsh)
+        assert dg.shape == do.shape == (40, 279)
+        assert np.array_equal(dg, do), wsh
+    do = oracle.sdm_descriptors(gray, px[4:], py[4:], 0, variant=0, num_cells=3, cell_size=8, num_bins=4)
+    dg = capi.sdm_descriptors(ctx, gray, px[4:], py[4:], 0, variant=0, num_cells=3, cell_size=8, num_bins=4)
+    assert np.array_equal(dg, do)
+
+
+def test_sdm_fit_batch(oracle, capi, ctx, synth):
+    """68 landmarks, 4 cascade steps (BASELINE config 4 shape, reduced batch).  Landmarks within 1e-4 relative."""
+    model = synth.make_sdm(9, L=68, S=4)
+    B = 6
+    imgs = np.stack([synth.make_frame(256, 256, seed=100 + i, channels=1) for i in range(B)])
+    boxes = np.array([[48, 48, 160, 160]] * B, np.int32)
+    boxes[1] = [40, 56, 150, 170]
+    sg = capi.Sdm(ctx, model)
+    shapes, status = sg.fit(imgs, boxes)
+    for i in range(B):
+        st, ref = oracle.sdm_fit(imgs[i], model, boxes[i])
+        assert st == 0 and status[i] == 0
+        assert np.allclose(shapes[i], ref, rtol=1e-4, atol=1e-4), np.abs(shapes[i] - ref).max()
+    # R = 0 returns the rigidly aligned mean (SURVEY.md App. C invariant)
+    zero = dict(model)
+    zero["R"] = [np.zeros_like(r) for r in model["R"]]
+    s0, _ = capi.Sdm(ctx, zero).fit(imgs[:1], boxes[:1])
+    _, r0 = oracle.sdm_fit(imgs[0], zero, boxes[0])
+    assert np.array_equal(s0[0], r0)
+    sg.close()
+
+
+def test_errors_are_reported_not_swallowed(capi, ctx):
+    with pytest.raises(capi.FdError) as e:
+        capi.Pyramid(ctx, octave_layers=0, min_scale=0.1, max_scale=1.0)
+    assert e.value.code == capi.FD_ERR_INVALID_ARGUMENT
+    with pytest.raises(capi.FdError):
+        capi.Pyramid(ctx, octave_layers=3, min_scale=0.1, max_scale=1.5)
+    p = capi.Pyramid(ctx, octave_layers=3, min_scale=0.5, max_scale=1.0)
+    with pytest.raises(capi.FdError):
+        p.window_count(20, 20, 0, 1)  # stepX has to be greater than zero
+    p.update(np.zeros((8, 8), np.uint8))
+    assert p.window_count(20, 20, 1, 1) == 0  # image smaller than the patch: no windows, no error
+    p.close()
