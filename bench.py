@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="hog_svm", choices=["hog_svm", "wvm", "sdm"])
     ap.add_argument("--gather-every", type=int, default=8)
+    ap.add_argument("--size", default="640x480", help="frame size WxH for the hog_svm / wvm workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -84,8 +85,9 @@ def main():
 
     NFRAMES = 4  # distinct frames per rank, cycled
     out = {}
+    FW, FH = [int(v) for v in args.size.split("x")]
     if args.workload == "hog_svm":
-        W, H = 640, 480
+        W, H = FW, FH
         frames = [synth.make_frame(W, H, seed=20260927 + 1000 * rank + i) for i in range(NFRAMES)]
         dframes = [torch.from_numpy(f).to(dev) for f in frames]
         pyr = capi.Pyramid(ctx, octave_layers=5, min_scale=1 / 16, max_scale=1.0)
@@ -98,10 +100,11 @@ def main():
         svm = capi.Svm(ctx, model)
         del feats2
 
-        def step(i):
+        def step(i, sync=False):
+            # asynchronous: pyramid + HOG + SVM + positive selection are only enqueued; detections stay in HBM
             f = dframes[i % NFRAMES]
             pyr.update_device(f.data_ptr(), W, H, 3)
-            return capi.bench_hog_svm(ctx, pyr, svm, hp)
+            return capi.bench_hog_svm(ctx, pyr, svm, hp, sync=sync)
 
         units_name = "windows"
         config = dict(workload="config2: 640x480 BGR frame, ImagePyramid(octl=5, 1/16..1) 21 layers, 20x20 windows stride 2, "
@@ -109,7 +112,7 @@ def main():
                       frames_per_step=1, parallelism="image-shard dp%d" % world)
         dtype = "f32"
     elif args.workload == "wvm":
-        W, H = 640, 480
+        W, H = FW, FH
         frames = [synth.make_frame(W, H, seed=20260927 + 1000 * rank + i) for i in range(NFRAMES)]
         dframes = [torch.from_numpy(f).to(dev) for f in frames]
         from oracle import pyoracle as O  # only to build the calibration patches identically to tests
@@ -120,16 +123,20 @@ def main():
         svm_m = synth.make_svm_u8(3, eq, nsv=1024, calib=eq[1024:])
         pyr = capi.Pyramid(ctx, inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))
         wvm, svm = capi.Wvm(ctx, wvm_m), capi.Svm(ctx, svm_m)
+        pyr.update(frames[0])
+        nwin_wvm = pyr.window_count(20, 20, 1, 1)
+        layer_bytes = sum(l["w"] * l["h"] for l in pyr.layers())
 
-        def step(i):
+        def step(i, sync=True):
             f = dframes[i % NFRAMES]
             pyr.update_device(f.data_ptr(), W, H, 3)
             dets, st = capi.detect_five_stage(ctx, pyr, wvm, svm)
-            return 16185, len(dets)
+            return nwin_wvm, len(dets)
 
         units_name = "windows"
-        config = dict(workload="config1 on GPU: 640x480, FaceFrontal.cfg pyramid (13 layers), 20x20 step 1, WVM 280 filters -> OE -> "
-                               "RBF-SVM 1024 SV -> NMS", frames_per_step=1, parallelism="image-shard dp%d" % world)
+        config = dict(workload="FaceFrontal.cfg five-stage cascade on a %dx%d frame: %d-layer pyramid, 20x20 windows step 1 (%d windows), "
+                               "WVM 280 filters -> OE -> RBF-SVM 1024 SV -> NMS" % (W, H, len(pyr.layers()), nwin_wvm),
+                      frames_per_step=1, parallelism="image-shard dp%d" % world)
         dtype = "u8/f32/f64"
     else:
         B, W, H = 256, 256, 256
@@ -140,7 +147,7 @@ def main():
         sdm = capi.Sdm(ctx, model)
         boxes = np.array([[48, 48, 160, 160]] * B, np.int32)
 
-        def step(i):
+        def step(i, sync=True):
             sdm.fit_device(dimgs.data_ptr(), W, H, B, boxes)
             return B * 4, 0
 
@@ -165,8 +172,8 @@ def main():
     for i in range(args.steps):
         n, npos = step(i)
         units += n
-        pending.append((i, npos))
-        if args.workload != "sdm":
+        pending.append((i, npos or 0))
+        if args.workload == "wvm":
             kernel_ms.append(ctx.last_kernel_ms()[1])
         if world > 1 and ((i + 1) % args.gather_every == 0 or i + 1 == args.steps):
             local = np.array([[rank * 1e6 + s, 0, 0, 0, 0, 0, 0, p] for s, p in pending], np.float64)
@@ -181,6 +188,11 @@ def main():
         dist.all_reduce(uu, op=dist.ReduceOp.SUM)
     dt, total_units = float(tt.item()), float(uu.item())
 
+    if args.workload == "hog_svm":
+        # dominant-kernel duration: hipEvents on the launch stream, synchronous steps outside the timed region
+        for i in range(min(10, max(3, args.steps))):
+            step(i, sync=True)
+            kernel_ms.append(ctx.last_kernel_ms()[1])
     if rank == 0:
         value = total_units / dt / 1e6
         res = dict(metric="Mpatches/s (extract+HOG+RBF-SVM), 640x480 pyramid" if args.workload == "hog_svm" else
@@ -200,13 +212,12 @@ def main():
                 res["cpu_baseline"] = cpu_baseline_hog_svm(None, model)
         elif args.workload == "wvm":
             kms = float(np.mean(kernel_ms))
-            layer_bytes = 38751
-            bytes_per_launch = layer_bytes + 16185 * 16
+            bytes_per_launch = layer_bytes + nwin_wvm * 16
             ach = bytes_per_launch / (kms * 1e-3) / 1e9
             res["roofline"] = dict(bound="hbm", kernel="k_wvm_cascade", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
-                                   traffic=None, kernel_ms=kms, algorithmic="38,751 layer bytes + 16 B record x 16,185 windows per launch")
+                                   traffic=None, kernel_ms=kms, algorithmic="%d layer bytes + 16 B record x %d windows per launch" % (layer_bytes, nwin_wvm))
             if not args.no_cpu_baseline:
-                res["cpu_baseline"] = cpu_baseline_wvm(frames[0], wvm_m, svm_m)
+                res["cpu_baseline"] = cpu_baseline_wvm(synth.make_frame(640, 480, seed=20260927), wvm_m, svm_m)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

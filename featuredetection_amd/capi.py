@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfd_hip.so")
+LIB_PATH = os.environ.get("FD_HIP_LIB", os.path.join(_HERE, "libfd_hip.so"))
 
 FD_OK, FD_ERR_INVALID_ARGUMENT, FD_ERR_RUNTIME, FD_ERR_LOGIC, FD_ERR_HIP, FD_ERR_CAPACITY = range(6)
 FD_LAYER_NONE, FD_LAYER_GRADBIN, FD_LAYER_LBP = 0, 1, 2
@@ -371,10 +371,11 @@ def detect_hog_svm(ctx, pyr, svm, hp, want_all=True, cap=1 << 20):
     return out[:cnt.value], alld
 
 
-def bench_hog_svm(ctx, pyr, svm, hp):
+def bench_hog_svm(ctx, pyr, svm, hp, sync=True):
+    """sync=False: enqueue only (no read-back, no host synchronisation); positives is then None."""
     n, p = C.c_int64(), C.c_int64()
-    ctx.check(lib().fd_bench_hog_svm(ctx.h, pyr.h, svm.h, C.byref(hp), C.byref(n), C.byref(p)))
-    return n.value, p.value
+    ctx.check(lib().fd_bench_hog_svm(ctx.h, pyr.h, svm.h, C.byref(hp), C.byref(n), C.byref(p) if sync else None))
+    return n.value, (p.value if sync else None)
 
 
 def bench_wvm(ctx, pyr, wvm, sx=1, sy=1):

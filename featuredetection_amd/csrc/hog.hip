@@ -47,21 +47,18 @@ void fd_svm_generic_launch(fd_ctx* ctx, const fd_svm* m, const void* dfeat, cons
 
 namespace {
 
-constexpr int HOG_MAX_PIX = 32 * 32;
 constexpr int HOG_MAX_HIST = 1024;   // cells * bins
 constexpr int HOG_MAX_CELLS = 64;
 constexpr int HOG_MAX_BLOCKS = 64;
 
-struct __attribute__((aligned(16))) HogLds {
-    unsigned short px[HOG_MAX_PIX];   // bin | weight << 8
-    float hist[HOG_MAX_HIST];
-    float energy[HOG_MAX_CELLS];
-    float norm[HOG_MAX_BLOCKS];
-};
-
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+
+// fp32 add executed by the LDS unit (ds_add_f32, no return value): fire-and-forget, in program order per wave
+__device__ __forceinline__ void lds_fadd(float* p, float v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
 __device__ __forceinline__ size_t frag_index_dev(int64_t row, int k, int KP) {
@@ -70,96 +67,142 @@ __device__ __forceinline__ size_t frag_index_dev(int64_t row, int k, int KP) {
     return (size_t)tile * 32 * KP + (size_t)q * 256 + (size_t)(h * 32 + r) * 4 + t;
 }
 
+// Tables built once on the host per HOG parameter set (no per-element integer divisions in the kernel):
+//  cTab[c]  cell rectangle startRow | endRow<<8 | startCol<<16 | endCol<<24 (HistogramFilter.cpp:134-137)
+//  oTab[o]  (o = output element): cell | bin<<8 | block<<16 | (1<<30 if the element is the "unsigned"
+//           sum hv[bin] + hv[bin + bins/2]) | (1<<31 if o is padding and must be zero)
+struct HogTables {
+    const uint32_t* cTab;
+    const uint32_t* oTab;
+};
+
+// A wavefront works on WPW = 64 / cells windows at once: lane = (window, cell).  Each lane walks its
+// cell's pixels (straight from the L1/L2-resident layer) in the reference's row-major order and
+// accumulates into its private histogram column in LDS (hist[bin][lane]); per-address order is the
+// program order, so the fp32 sums are bit-identical to the CPU loop.  Block vectors are written as
+// float4 (one fragment slot = 4 consecutive feature elements) directly into the fragment-major
+// tile of the MFMA SVM kernel; the WPW windows of a pass fill WPW*16 contiguous bytes per slot.
+// Only ~3 KB of LDS per wave, so occupancy (and with it latency hiding) is register-bound.
 template <bool FRAG>
-__global__ __launch_bounds__(128) void k_hog_features(const uint8_t* __restrict__ arena, HogWinTable wt, HogDev hp,
-                                                      float* __restrict__ feat, float* __restrict__ xx) {
-    __shared__ HogLds lds[2];
+__global__ __launch_bounds__(256) void k_hog_tile(const uint8_t* __restrict__ arena, HogWinTable wt, HogDev hp, HogTables tab,
+                                                  int64_t npad, float* __restrict__ feat, float* __restrict__ xx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    HogLds& L = lds[wave];
-    const int pw = hp.pw, ph = hp.ph, B = hp.bins;
-    const int ncells = hp.rows * hp.cols, nhist = ncells * B, nblocks = hp.brows * hp.bcols;
+    const int B = hp.bins;
+    const int C = hp.rows * hp.cols, nblocks = hp.brows * hp.bcols;
+    const int WPW = 64 / C;                       // windows per wavefront pass
+    const int LPW = 64 / WPW;                     // lanes per window in the output stage
+    const int KP = hp.KP, F = hp.F;
+    uint32_t* cTab = (uint32_t*)smem;                             // 64
+    uint32_t* oTab = cTab + 64;                                   // KP
+    unsigned char* wbase = (unsigned char*)(oTab + ((KP + 3) & ~3));
+    const int perWave = (B * 64 + 64 + 64 + 64) * 4;
+    float* hist = (float*)(wbase + (size_t)wave * perWave);       // [B][64]
+    float* energy = hist + B * 64;                                // [64]  (window, cell)
+    float* norm = energy + 64;                                    // [64]  (window, block)
+    float* part = norm + 64;                                      // [64]  partial |x|^2 per lane
+    for (int i = threadIdx.x; i < C; i += 256) cTab[i] = tab.cTab[i];
+    for (int i = threadIdx.x; i < KP; i += 256) oTab[i] = tab.oTab[i];
+    __syncthreads();
     const float factor = 1.f / 255.f;
     const float eps = 1e-4f;
-    const int64_t nwaves = (int64_t)gridDim.x * 2;
-    for (int64_t wid = (int64_t)blockIdx.x * 2 + wave; wid < wt.total; wid += nwaves) {
-        int li;
-        {
-            bool le = lane < wt.n && wt.l[lane < wt.n ? lane : 0].first <= wid;
-            li = __popcll(__ballot(le)) - 1;
-        }
-        li = __builtin_amdgcn_readfirstlane(li);
-        const HogWinLayer wl = wt.l[li];
-        const int local = (int)(wid - wl.first);
-        const int iy = local / wl.nx, ix = local - iy * wl.nx;
-        const int lx = wl.bx + ix * wt.sx, ly = wl.by + iy * wt.sy;
-        const unsigned short* src = (const unsigned short*)(arena + wl.off) + (size_t)ly * wl.lw + lx;
-        // stage the window's (bin, weight) pixels: two rows per wave instruction
-        {
-            const int half = lane >> 5, col = lane & 31;
-            for (int r = half; r < ph; r += 2)
-                if (col < pw) L.px[r * pw + col] = src[(size_t)r * wl.lw + col];
-        }
-        wave_sync();
-        // cell histograms: lane e = (cell, bin); sequential fp32 adds in row-major pixel order
-        for (int e = lane; e < nhist; e += 64) {
-            const int cell = e / B, bin = e - cell * B;
-            const int cr = cell / hp.cols, cc = cell - cr * hp.cols;
-            const int startRow = (cr * ph) / hp.rows, endRow = ((cr + 1) * ph) / hp.rows;
-            const int startCol = (cc * pw) / hp.cols, endCol = ((cc + 1) * pw) / hp.cols;
-            float h = 0.f;
-            for (int y = startRow; y < endRow; ++y)
-                for (int x = startCol; x < endCol; ++x) {
-                    const unsigned int v = L.px[y * pw + x];
-                    const float wgt = factor * (float)(v >> 8);
-                    if ((int)(v & 255u) == bin) h = h + wgt;
+    const int lw_ = lane / C, lc = lane - lw_ * C;          // this lane's window slot and cell
+    const bool laneUsed = lw_ < WPW;
+    const int nw_ = lane / nblocks, nb_ = lane - nw_ * nblocks;   // (window, block) role for the normalisers
+    const int ow = lane / LPW, ol = lane - ow * LPW;        // (window, sub-lane) role for the output stage
+    const uint32_t crect = cTab[laneUsed ? lc : 0];
+    const int cr0 = crect & 255, cr1 = (crect >> 8) & 255, cc0 = (crect >> 16) & 255, cc1 = crect >> 24;
+    const int npass = (32 + WPW - 1) / WPW;
+    const int64_t ntiles = (npad + 31) >> 5;
+    // work item = (tile, pass); consecutive waves take consecutive passes of the same tile
+    const int64_t nitems = ntiles * npass;
+    for (int64_t item = (int64_t)blockIdx.x * 4 + wave; item < nitems; item += (int64_t)gridDim.x * 4) {
+        const int64_t tileId = item / npass;
+        const int pass = (int)(item - tileId * npass);
+        const int r0 = pass * WPW;
+        const int r = r0 + lw_;                       // tile row of this lane's window
+        const int64_t wid = tileId * 32 + r;
+        const bool valid = laneUsed && r < 32 && wid < wt.total;
+        for (int b = 0; b < B; ++b) hist[b * 64 + lane] = 0.f;
+        if (valid) {
+            // window geometry per lane (windows of one pass may straddle rows / layers)
+            int li = 0;
+            for (int l = 1; l < wt.n; ++l) li = wt.l[l].first <= wid ? l : li;
+            const HogWinLayer wl = wt.l[li];
+            const int local = (int)(wid - wl.first);
+            const int iy = local / wl.nx, ix = local - iy * wl.nx;
+            const unsigned short* src = (const unsigned short*)(arena + wl.off) + (size_t)(wl.by + iy * wt.sy) * wl.lw + (wl.bx + ix * wt.sx);
+            // cell histograms (HistogramFilter.cpp:150-163)
+            for (int y = cr0; y < cr1; ++y) {
+                const unsigned short* rowp = src + (size_t)y * wl.lw;
+                for (int x = cc0; x < cc1; ++x) {
+                    const unsigned int v = rowp[x];
+                    float* hp_ = &hist[(v & 255u) * 64 + lane];
+                    *hp_ = *hp_ + factor * (float)(v >> 8);
                 }
-            L.hist[e] = h;
+            }
         }
         wave_sync();
-        // cell energies (HogFilter.cpp:102-122)
-        for (int c = lane; c < ncells; c += 64) {
-            const float* hv = L.hist + c * B;
-            float energy = 0.f;
+        // ---- cell energies (HogFilter.cpp:102-122)
+        {
+            float en = 0.f;
             if (hp.sau) {
                 const int hb = B / 2;
-                for (int b = 0; b < hb; ++b) { const float uw = hv[b] + hv[hb + b]; energy = energy + uw * uw; }
+                for (int b = 0; b < hb; ++b) { const float uw = hist[b * 64 + lane] + hist[(hb + b) * 64 + lane]; en = en + uw * uw; }
             } else {
-                for (int b = 0; b < B; ++b) energy = energy + hv[b] * hv[b];
+                for (int b = 0; b < B; ++b) { const float hv = hist[b * 64 + lane]; en = en + hv * hv; }
             }
-            L.energy[c] = energy;
+            energy[lane] = en;
         }
         wave_sync();
-        // block normalisers (HogFilter.cpp:78-84)
-        for (int bl = lane; bl < nblocks; bl += 64) {
-            const int br = bl / hp.bcols, bc = bl - br * hp.bcols;
-            float energy = 0.f;
+        // ---- block normalisers (HogFilter.cpp:78-84): lane = (window, block)
+        if (nw_ < WPW) {
+            const int br = nb_ / hp.bcols, bc = nb_ - br * hp.bcols;
+            float en = 0.f;
             for (int cr = br; cr < br + hp.block; ++cr)
-                for (int cc = bc; cc < bc + hp.block; ++cc) energy = energy + L.energy[cr * hp.cols + cc];
-            L.norm[bl] = 1.f / sqrtf(energy + eps);
+                for (int cc = bc; cc < bc + hp.block; ++cc) en = en + energy[nw_ * C + cr * hp.cols + cc];
+            norm[lane] = 1.f / sqrtf(en + eps);
         }
         wave_sync();
-        // block vectors (HogFilter.cpp:85-97): one output element per lane
-        const int hb = B / 2;
-        const int perCell = hp.sau ? B + hb : B;
+        // ---- block vectors (HogFilter.cpp:85-97): lane = (window, sub-lane); 4 consecutive elements per store
         float sq = 0.f;
-        for (int o = lane; o < hp.KP; o += 64) {
-            float val = 0.f;
-            if (o < hp.F) {
-                const int bl = o / hp.perBlock, w = o - bl * hp.perBlock;
-                const int ci = w / perCell, b = w - ci * perCell;
-                const int br = bl / hp.bcols, bc = bl - br * hp.bcols;
-                const int cr = br + ci / hp.block, cc = bc + (ci - (ci / hp.block) * hp.block);
-                const float* hv = L.hist + (cr * hp.cols + cc) * B;
-                const float nrm = L.norm[bl];
-                val = b < B ? nrm * hv[b] : nrm * (hv[b - B] + hv[hb + b - B]);
+        const int rr = r0 + ow;
+        if (ow < WPW && rr < 32) {
+            const bool wvalid = tileId * 32 + rr < wt.total;
+            for (int s4 = ol; s4 < KP / 4; s4 += LPW) {
+                float vals[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t t = oTab[4 * s4 + k];
+                    float val = 0.f;
+                    if (wvalid && !(t >> 31)) {
+                        const int cell = t & 255, bin = (t >> 8) & 255, bl = (t >> 16) & 255;
+                        const float nrm = norm[ow * nblocks + bl];
+                        const float h0 = hist[bin * 64 + ow * C + cell];
+                        val = (t >> 30) & 1 ? nrm * (h0 + hist[(bin + B / 2) * 64 + ow * C + cell]) : nrm * h0;
+                    }
+                    vals[k] = val;
+                    sq += val * val;
+                }
+                if (FRAG) {
+                    float4 o4 = make_float4(vals[0], vals[1], vals[2], vals[3]);
+                    *(float4*)(feat + (size_t)tileId * 32 * KP + (size_t)(s4 >> 1) * 256 + ((s4 & 1) * 32 + rr) * 4) = o4;
+                } else if (wvalid) {
+                    float* d = feat + (size_t)(tileId * 32 + rr) * F + 4 * s4;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (4 * s4 + k < F) d[k] = vals[k];
+                }
             }
-            sq += val * val;
-            if (FRAG) feat[frag_index_dev(wid, o, hp.KP)] = val;
-            else if (o < hp.F) feat[(size_t)wid * hp.F + o] = val;
         }
         if (FRAG) {
-            for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
-            if (lane == 0) xx[wid] = sq;
+            part[lane] = sq;
+            wave_sync();
+            if (ol == 0 && ow < WPW && rr < 32 && tileId * 32 + rr < npad) {
+                float tot = 0.f;
+                for (int k = 0; k < LPW; ++k) tot += part[ow * LPW + k];
+                xx[tileId * 32 + rr] = tot;
+            }
         }
         wave_sync();
     }
@@ -182,7 +225,10 @@ __global__ void k_select_positives(const double* __restrict__ dist, int64_t n, f
 }
 
 struct HogScratch {
-    DevBuf feat, xx, dist, pos, counter;
+    DevBuf feat, xx, dist, pos, counter, tables;
+    HostBuf hcount;       // pinned read-back slot
+    HogDev tabFor;        // parameters the tables were built for
+    bool tabValid = false;
 };
 HogScratch& scratch(fd_ctx* ctx) {
     static thread_local std::vector<std::pair<fd_ctx*, std::unique_ptr<HogScratch>>> tab;
@@ -211,10 +257,68 @@ HogDev make_hogdev(const fd_hog_params* hp, int KPwant) {
     if (d.rows < 1 || d.cols < 1 || d.brows < 1 || d.bcols < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "HogFilter: patch smaller than one block");
     d.perBlock = d.block * d.block * (d.sau ? d.bins + d.bins / 2 : d.bins);
     d.F = d.brows * d.bcols * d.perBlock;
-    if (d.rows * d.cols > HOG_MAX_CELLS || d.rows * d.cols * d.bins > HOG_MAX_HIST || d.brows * d.bcols > HOG_MAX_BLOCKS)
+    if (d.rows * d.cols > HOG_MAX_CELLS || d.rows * d.cols * d.bins > HOG_MAX_HIST || d.brows * d.bcols > HOG_MAX_BLOCKS ||
+        d.bins > 64 || d.pw > 255 || d.ph > 255)
         FD_THROW(FD_ERR_INVALID_ARGUMENT, "HogFilter: too many cells/bins for this backend");
     d.KP = KPwant > 0 ? KPwant : ((d.F + 7) & ~7);
     return d;
+}
+
+// host-built index tables of k_hog_tile (HistogramFilter.cpp:134-137 cell bounds, HogFilter.cpp:85-97 output order)
+HogTables hog_tables(fd_ctx* ctx, HogScratch& S, const HogDev& d) {
+    const int C = d.rows * d.cols;
+    if (!S.tabValid || std::memcmp(&S.tabFor, &d, sizeof(HogDev)) != 0) {
+        std::vector<uint32_t> t((size_t)64 + d.KP, 0u);
+        for (int c = 0; c < C; ++c) {
+            const int cr = c / d.cols, cc = c % d.cols;
+            const uint32_t sr = (cr * d.ph) / d.rows, er = ((cr + 1) * d.ph) / d.rows;
+            const uint32_t sc = (cc * d.pw) / d.cols, ec = ((cc + 1) * d.pw) / d.cols;
+            t[c] = sr | (er << 8) | (sc << 16) | (ec << 24);
+        }
+        const int hb = d.bins / 2, perCell = d.sau ? d.bins + hb : d.bins;
+        for (int o = 0; o < d.KP; ++o) {
+            uint32_t v = 1u << 31;
+            if (o < d.F) {
+                const int bl = o / d.perBlock, w = o % d.perBlock, ci = w / perCell, b = w % perCell;
+                const int br = bl / d.bcols, bc = bl % d.bcols;
+                const int cell = (br + ci / d.block) * d.cols + (bc + ci % d.block);
+                v = b < d.bins ? (uint32_t)cell | ((uint32_t)b << 8) | ((uint32_t)bl << 16)
+                               : (uint32_t)cell | ((uint32_t)(b - d.bins) << 8) | ((uint32_t)bl << 16) | (1u << 30);
+            }
+            t[64 + o] = v;
+        }
+        S.tables.reserve(sizeof(uint32_t) * t.size());
+        HIP_CHECK(hipMemcpyAsync(S.tables.p, t.data(), sizeof(uint32_t) * t.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));  // t is a stack-lifetime host buffer
+        S.tabFor = d;
+        S.tabValid = true;
+    }
+    HogTables tb;
+    tb.cTab = S.tables.as<uint32_t>();
+    tb.oTab = tb.cTab + 64;
+    return tb;
+}
+
+size_t hog_lds_bytes(const HogDev& d, bool /*frag*/) {
+    const size_t perWave = ((size_t)d.bins * 64 + 64 + 64 + 64) * 4;
+    return (64 + (((size_t)d.KP + 3) & ~(size_t)3)) * 4 + 4 * perWave;
+}
+
+template <bool FRAG>
+void launch_hog(fd_ctx* ctx, const fd_pyramid* p, const HogWinTable& wt, const HogDev& hd, HogScratch& S, int64_t npad, float* feat, float* xx) {
+    const HogTables tb = hog_tables(ctx, S, hd);
+    const size_t lds = hog_lds_bytes(hd, FRAG);
+    if (lds > 160 * 1024) FD_THROW(FD_ERR_INVALID_ARGUMENT, "HOG feature vector too long for the LDS tile (%d floats)", hd.F);
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[FRAG]) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_hog_tile<FRAG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[FRAG] = true;
+    }
+    const int C = hd.rows * hd.cols, WPW = 64 / C, npass = (32 + WPW - 1) / WPW;
+    const int64_t nitems = ((npad + 31) / 32) * npass;
+    const int grid = (int)std::min<int64_t>((nitems + 3) / 4, (int64_t)ctx->num_cus * 16);
+    hipLaunchKernelGGL(k_hog_tile<FRAG>, dim3(grid), dim3(256), lds, ctx->stream, p->arena.as<uint8_t>(), wt, hd, tb, npad, feat, xx);
+    HIP_CHECK(hipGetLastError());
 }
 
 void build_table(const fd_pyramid* p, const fd_hog_params* hp, HogWinTable& wt, std::vector<WindowLayer>& wls) {
@@ -268,14 +372,7 @@ int64_t run_hog_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_hog_
     S.feat.reserve(sizeof(float) * (size_t)Npad * hd.KP);
     S.xx.reserve(sizeof(float) * (size_t)Npad);
     S.dist.reserve(sizeof(double) * (size_t)Npad);
-    if (Npad > N) {  // zero the partially used last tile pair (rows N..Npad-1 live in the last 2 tiles)
-        const int64_t firstTile = N >> 5;
-        HIP_CHECK(hipMemsetAsync(S.feat.as<float>() + (size_t)firstTile * 32 * hd.KP, 0, sizeof(float) * (size_t)(Npad / 32 - firstTile) * 32 * hd.KP, st));
-        HIP_CHECK(hipMemsetAsync(S.xx.as<float>() + N, 0, sizeof(float) * (size_t)(Npad - N), st));
-    }
-    const int grid = (int)std::min<int64_t>((N + 1) / 2, (int64_t)ctx->num_cus * 16);
-    hipLaunchKernelGGL(k_hog_features<true>, dim3(grid), dim3(128), 0, st, p->arena.as<uint8_t>(), wt, hd, S.feat.as<float>(), S.xx.as<float>());
-    HIP_CHECK(hipGetLastError());
+    launch_hog<true>(ctx, p, wt, hd, S, Npad, S.feat.as<float>(), S.xx.as<float>());
     if (time_kernel) HIP_CHECK(hipEventRecord(ctx->ev0, st));
     fd_svm_rbf_mfma_launch(ctx, svm, S.feat.as<float>(), S.xx.as<float>(), N, S.dist.as<double>());
     if (time_kernel) HIP_CHECK(hipEventRecord(ctx->ev1, st));
@@ -304,9 +401,7 @@ int fd_extract_hog(fd_ctx* ctx, fd_pyramid* p, const fd_hog_params* hp, float* f
         HogScratch& S = scratch(ctx);
         const size_t bytes = sizeof(float) * (size_t)wt.total * hd.F;
         S.feat.reserve(bytes);
-        const int grid = (int)std::min<int64_t>((wt.total + 1) / 2, (int64_t)ctx->num_cus * 16);
-        hipLaunchKernelGGL(k_hog_features<false>, dim3(grid), dim3(128), 0, ctx->stream, p->arena.as<uint8_t>(), wt, hd, S.feat.as<float>(), (float*)nullptr);
-        HIP_CHECK(hipGetLastError());
+        launch_hog<false>(ctx, p, wt, hd, S, wt.total, S.feat.as<float>(), nullptr);
         HIP_CHECK(hipMemcpyAsync(features, S.feat.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
     });
@@ -358,24 +453,29 @@ int fd_bench_hog_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_hog
         if (!ctx || !p || !svm || !hp) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_bench_hog_svm: NULL argument");
         HogScratch& S = scratch(ctx);
         std::vector<WindowLayer> wls;
-        const int64_t N = run_hog_svm(ctx, p, svm, hp, wls, S, true);
+        // positives == NULL: fully asynchronous (nothing is read back, no host synchronisation; the
+        // caller brackets many calls with fd_ctx_synchronize).  Otherwise the call is synchronous and
+        // also records the hipEvent-timed duration of the dominant kernel.
+        const bool sync = positives != nullptr;
+        const int64_t N = run_hog_svm(ctx, p, svm, hp, wls, S, sync);
         if (count) *count = N;
-        unsigned int cnt = 0;
-        if (N) {
-            hipStream_t st = ctx->stream;
-            const unsigned int pcap = (unsigned int)std::min<int64_t>(N, 1 << 22);
-            S.pos.reserve(sizeof(HogPos) * (size_t)pcap);
-            S.counter.reserve(256);
-            HIP_CHECK(hipMemsetAsync(S.counter.p, 0, 4, st));
-            hipLaunchKernelGGL(k_select_positives, dim3((unsigned)std::min<int64_t>((N + 255) / 256, 2048)), dim3(256), 0, st,
-                               S.dist.as<double>(), N, fd_svm_threshold(svm), S.pos.as<HogPos>(), S.counter.as<unsigned int>(), pcap);
-            HIP_CHECK(hipGetLastError());
-            HIP_CHECK(hipMemcpyAsync(&cnt, S.counter.p, 4, hipMemcpyDeviceToHost, st));
+        if (!N) { if (positives) *positives = 0; return; }
+        hipStream_t st = ctx->stream;
+        const unsigned int pcap = (unsigned int)std::min<int64_t>(N, 1 << 22);
+        S.pos.reserve(sizeof(HogPos) * (size_t)pcap);
+        S.counter.reserve(256);
+        S.hcount.reserve(64);
+        HIP_CHECK(hipMemsetAsync(S.counter.p, 0, 4, st));
+        hipLaunchKernelGGL(k_select_positives, dim3((unsigned)std::min<int64_t>((N + 255) / 256, 2048)), dim3(256), 0, st,
+                           S.dist.as<double>(), N, fd_svm_threshold(svm), S.pos.as<HogPos>(), S.counter.as<unsigned int>(), pcap);
+        HIP_CHECK(hipGetLastError());
+        if (sync) {
+            HIP_CHECK(hipMemcpyAsync(S.hcount.p, S.counter.p, 4, hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
             HIP_CHECK(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev0, ctx->ev1));
             ctx->last_kernel = "k_svm_rbf_mfma";
+            *positives = *S.hcount.as<unsigned int>();
         }
-        if (positives) *positives = cnt;
     });
 }
 

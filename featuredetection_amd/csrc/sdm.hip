@@ -44,12 +44,15 @@ struct DescLds {   // per-wave views carved out of dynamic LDS
     float *wx1, *wx2;
     int* binx;
     float *hog, *norm, *feat;
+    unsigned long long* masks;    // [2*nori][ih]: bit x set iff pixel (y, x) voted for that orientation
+    unsigned long long* colmask;  // [hogW]: columns x contributing to cell column cx
+    int* yrange;                  // [hogH][2]: first/last+1 row contributing to cell row cy
 };
 __host__ __device__ inline int align16i(int v) { return (v + 15) & ~15; }
 __host__ __device__ inline int desc_lds_bytes(int iw, int ih, int ncell, int nori, int dim) {
     const int m = iw > ih ? iw : ih;
     return 2 * align16i(iw * ih * 4) + align16i(iw * ih) + 3 * align16i(m * 4) + align16i(ncell * nori * 2 * 4) + align16i(ncell * 4) +
-           align16i(ncell * dim * 4);
+           align16i(ncell * dim * 4) + align16i(2 * nori * ih * 8) + align16i(m * 8) + align16i(m * 2 * 4);
 }
 
 __device__ __forceinline__ void wave_sync() {
@@ -126,7 +129,10 @@ __global__ __launch_bounds__(128) void k_sdm_descriptors(const uint8_t* __restri
         S.binx = (int*)b; b += align16i(m * 4);
         S.hog = (float*)b; b += align16i(ncell * nori * 2 * 4);
         S.norm = (float*)b; b += align16i(ncell * 4);
-        S.feat = (float*)b;
+        S.feat = (float*)b; b += align16i(ncell * p.dim * 4);
+        S.masks = (unsigned long long*)b; b += align16i(2 * nori * ih * 8);
+        S.colmask = (unsigned long long*)b; b += align16i(m * 8);
+        S.yrange = (int*)b;
     }
     for (int64_t item = (int64_t)blockIdx.x * 2 + wave; item < nitems; item += (int64_t)gridDim.x * 2) {
         const int64_t face = item / p.L;
@@ -176,7 +182,22 @@ __global__ __launch_bounds__(128) void k_sdm_descriptors(const uint8_t* __restri
             S.binx[x] = b; S.wx1[x] = w1; S.wx2[x] = w2;
         }
         for (int i = lane; i < ncell * nori * 2; i += 64) S.hog[i] = 0.f;
+        for (int i = lane; i < 2 * nori * ih; i += 64) S.masks[i] = 0ull;
         wave_sync();
+        // per cell column: bit mask of the interior columns that vote into it; per cell row: row range
+        for (int c = lane; c < hogW; c += 64) {
+            unsigned long long mk = 0ull;
+            for (int x = 1; x < iw - 1; ++x)
+                if (S.binx[x] == c || S.binx[x] + 1 == c) mk |= 1ull << x;
+            S.colmask[c] = mk;
+        }
+        for (int c = lane; c < hogH; c += 64) {
+            int lo = ih, hi = 0;
+            for (int y = 1; y < ih - 1; ++y)
+                if (S.binx[y] == c || S.binx[y] + 1 == c) { lo = min(lo, y); hi = max(hi, y + 1); }
+            S.yrange[2 * c] = lo;
+            S.yrange[2 * c + 1] = hi;
+        }
         // ---- gradient magnitude and hard orientation assignment per interior pixel (hog.c:612-665)
         for (int i = lane; i < iw * ih; i += 64) {
             const int y = i / iw, x = i - y * iw;
@@ -200,22 +221,25 @@ __global__ __launch_bounds__(128) void k_sdm_descriptors(const uint8_t* __restri
             }
             S.grad[i] = grad;
             S.ori[i] = (unsigned char)(b0 < 0 ? 255 : b0);
+            if (b0 >= 0) atomicOr(&S.masks[b0 * ih + y], 1ull << x);
         }
         wave_sync();
-        // ---- spatial voting: lane e = (orientation, cell); sequential fp32 adds in pixel scan order
+        // ---- spatial voting: lane e = (orientation, cell) walks ITS contributing pixels (orientation bit
+        // masks) in the reference's scan order (y outer, x inner) with sequential fp32 adds
         for (int e = lane; e < ncell * nori * 2; e += 64) {
             const int o = e / ncell, c = e - o * ncell;
             const int cy = c / hogW, cx = c - cy * hogW;
+            const unsigned long long cm = S.colmask[cx];
+            const int ylo = S.yrange[2 * cy], yhi = S.yrange[2 * cy + 1];
             float acc = 0.f;
-            for (int y = 1; y < ih - 1; ++y) {
-                const int by = S.binx[y];
-                if (by != cy && by + 1 != cy) continue;
-                const float wy = by == cy ? S.wx1[y] : S.wx2[y];
-                for (int x = 1; x < iw - 1; ++x) {
-                    const int bx = S.binx[x];
-                    if (bx != cx && bx + 1 != cx) continue;
-                    if ((int)S.ori[y * iw + x] != o) continue;
-                    const float wx = bx == cx ? S.wx1[x] : S.wx2[x];
+            for (int y = ylo; y < yhi; ++y) {
+                unsigned long long mk = S.masks[o * ih + y] & cm;
+                if (!mk) continue;
+                const float wy = S.binx[y] == cy ? S.wx1[y] : S.wx2[y];
+                while (mk) {
+                    const int x = __ffsll((long long)mk) - 1;
+                    mk &= mk - 1;
+                    const float wx = S.binx[x] == cx ? S.wx1[x] : S.wx2[x];
                     acc = acc + S.grad[y * iw + x] * wx * wy;
                 }
             }

@@ -543,7 +543,7 @@ int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const f
             FD_THROW(FD_ERR_INVALID_ARGUMENT, "second classifier must work on the %d-byte HistEq64 patch", m->dev.d);
         // stage 1: WVM over all windows (SlidingWindowDetector::detect), positives in extraction order
         WvmRun run;
-        fd_wvm_run(ctx, p, m, sx, sy, roi, false, run, false);
+        fd_wvm_run(ctx, p, m, sx, sy, roi, false, run, true);
         std::vector<fd_detection> wvmPos;
         fd_wvm_positives_to_detections(p, m, run, sx, sy, wvmPos);
         if (stage_counts) stage_counts[0] = (int)wvmPos.size();
