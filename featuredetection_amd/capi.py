@@ -85,6 +85,7 @@ _SIGS = {
     "fd_histeq64_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "fd_wvm_create": (C.c_int, [C.c_void_p, C.POINTER(fd_wvm_model), C.POINTER(C.c_void_p)]),
     "fd_wvm_destroy": (None, [C.c_void_p]),
+    "fd_wvm_eval_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "fd_svm_create": (C.c_int, [C.c_void_p, C.POINTER(fd_svm_model), C.POINTER(C.c_void_p)]),
     "fd_svm_destroy": (None, [C.c_void_p]),
     "fd_svm_distance_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -108,6 +109,7 @@ _SIGS = {
                                      C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     "fd_sdm_fit_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                    C.c_void_p]),
+    "fd_sdm_optimize_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }
 
 
@@ -273,6 +275,16 @@ class Wvm:
         if self.h:
             lib().fd_wvm_destroy(self.h)
             self.h = C.c_void_p()
+
+
+def wvm_eval(ctx, wvm, patches_eq):
+    """WvmClassifier::computeHyperplaneDistance on already equalised patches [n, h, w] u8"""
+    patches_eq = _c(patches_eq, np.uint8)
+    n = patches_eq.shape[0]
+    lv = np.empty(n, np.int32)
+    sc = np.empty(n, np.float32)
+    ctx.check(lib().fd_wvm_eval_batch(ctx.h, wvm.h, _ptr(patches_eq), n, _ptr(lv), _ptr(sc)))
+    return lv, sc
 
 
 class Svm:

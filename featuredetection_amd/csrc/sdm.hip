@@ -463,6 +463,49 @@ int fd_sdm_descriptors(fd_ctx* ctx, const uint8_t* gray, int W, int H, const flo
     });
 }
 
+static void sdm_optimize(fd_ctx* ctx, fd_sdm* m, const uint8_t* gray_images, int W, int H, int B, int images_on_device,
+                         std::vector<float>& shapes, int32_t* status_out) {
+    HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int L = m->L, N = 2 * L;
+    const uint8_t* dimg = gray_images;
+    if (!images_on_device) {
+        m->images.reserve((size_t)W * H * B);
+        HIP_CHECK(hipMemcpyAsync(m->images.p, gray_images, (size_t)W * H * B, hipMemcpyHostToDevice, st));
+        dimg = m->images.as<uint8_t>();
+    }
+    DescParams p;
+    fill_desc_params(p, W, H, L, true, m->variant, 3, 10, 9, 30);
+    p.image_stride = (int64_t)W * H;
+    const int F = L * p.len;
+    const int nchunks = (F + RG_KCHUNK - 1) / RG_KCHUNK;
+    m->shapes.reserve(sizeof(float) * shapes.size());
+    m->origin.reserve(sizeof(int32_t) * 4 * (size_t)B * L);
+    m->dist.reserve(sizeof(float) * B);
+    m->status.reserve(sizeof(int32_t) * B);
+    m->desc.reserve(sizeof(float) * (size_t)B * F);
+    m->partial.reserve(sizeof(double) * (size_t)nchunks * B * N);
+    HIP_CHECK(hipMemcpyAsync(m->shapes.p, shapes.data(), sizeof(float) * shapes.size(), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemsetAsync(m->status.p, 0, sizeof(int32_t) * B, st));
+    const int64_t nitems = (int64_t)B * L;
+    for (int step = 0; step < m->S; ++step) {
+        const double stepFactor = 1 / (1 + std::exp((double)((step + 1) - m->S)));  // :226, double on the host
+        hipLaunchKernelGGL(k_sdm_prepare, dim3((B + 63) / 64), dim3(64), 0, st, m->shapes.as<float>(), B, L, W, H, 1, 0, 1 << 20, stepFactor,
+                           m->origin.as<int32_t>(), m->dist.as<float>(), m->status.as<int32_t>());
+        const int grid = (int)std::min<int64_t>((nitems + 1) / 2, (int64_t)ctx->num_cus * 16);
+        hipLaunchKernelGGL(k_sdm_descriptors, dim3(grid), dim3(128), 2 * p.ldsPerWave, st, dimg, m->origin.as<int32_t>(), p, nitems, m->desc.as<float>(), (int64_t)F);
+        const float* R = m->R[step]->as<float>();
+        hipLaunchKernelGGL(k_sdm_regress, dim3((B + 15) / 16, (N + 15) / 16, nchunks), dim3(64), 0, st, m->desc.as<float>(), B, F, R, N,
+                           m->partial.as<double>(), nchunks);
+        hipLaunchKernelGGL(k_sdm_update, dim3((B * N + 255) / 256), dim3(256), 0, st, m->shapes.as<float>(), m->partial.as<double>(), nchunks,
+                           R + (size_t)F * N, m->dist.as<float>(), B, N);
+    }
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(shapes.data(), m->shapes.p, sizeof(float) * shapes.size(), hipMemcpyDeviceToHost, st));
+    if (status_out) HIP_CHECK(hipMemcpyAsync(status_out, m->status.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+}
+
 int fd_sdm_fit_batch(fd_ctx* ctx, const fd_sdm* m_, const uint8_t* gray_images, int W, int H, int batch, const int32_t* face_boxes,
                      int images_on_device, float* shapes_out, int32_t* status_out) {
     return fd_guard(ctx, [&] {
@@ -470,15 +513,7 @@ int fd_sdm_fit_batch(fd_ctx* ctx, const fd_sdm* m_, const uint8_t* gray_images, 
             FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_sdm_fit_batch: bad argument");
         if (batch == 0) return;
         fd_sdm* m = const_cast<fd_sdm*>(m_);
-        HIP_CHECK(hipSetDevice(ctx->device));
-        hipStream_t st = ctx->stream;
         const int L = m->L, N = 2 * L, B = batch;
-        const uint8_t* dimg = gray_images;
-        if (!images_on_device) {
-            m->images.reserve((size_t)W * H * B);
-            HIP_CHECK(hipMemcpyAsync(m->images.p, gray_images, (size_t)W * H * B, hipMemcpyHostToDevice, st));
-            dimg = m->images.as<uint8_t>();
-        }
         // alignRigid (SdmLandmarkModel.hpp:156-192) on the host, exactly as the cv::MatExpr evaluates it:
         // x * float(w) + float(0.5 * w + bx)
         std::vector<float> shapes((size_t)B * N);
@@ -491,36 +526,21 @@ int fd_sdm_fit_batch(fd_ctx* ctx, const fd_sdm* m_, const uint8_t* gray_images, 
                 shapes[(size_t)f * N + i + L] = m->mean[i + L] * ay + by;
             }
         }
-        DescParams p;
-        fill_desc_params(p, W, H, L, true, m->variant, 3, 10, 9, 30);
-        p.image_stride = (int64_t)W * H;
-        const int F = L * p.len;
-        const int nchunks = (F + RG_KCHUNK - 1) / RG_KCHUNK;
-        m->shapes.reserve(sizeof(float) * shapes.size());
-        m->origin.reserve(sizeof(int32_t) * 4 * (size_t)B * L);
-        m->dist.reserve(sizeof(float) * B);
-        m->status.reserve(sizeof(int32_t) * B);
-        m->desc.reserve(sizeof(float) * (size_t)B * F);
-        m->partial.reserve(sizeof(double) * (size_t)nchunks * B * N);
-        HIP_CHECK(hipMemcpyAsync(m->shapes.p, shapes.data(), sizeof(float) * shapes.size(), hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemsetAsync(m->status.p, 0, sizeof(int32_t) * B, st));
-        const int64_t nitems = (int64_t)B * L;
-        for (int step = 0; step < m->S; ++step) {
-            const double stepFactor = 1 / (1 + std::exp((double)((step + 1) - m->S)));  // :226, double on the host
-            hipLaunchKernelGGL(k_sdm_prepare, dim3((B + 63) / 64), dim3(64), 0, st, m->shapes.as<float>(), B, L, W, H, 1, 0, 1 << 20, stepFactor,
-                               m->origin.as<int32_t>(), m->dist.as<float>(), m->status.as<int32_t>());
-            const int grid = (int)std::min<int64_t>((nitems + 1) / 2, (int64_t)ctx->num_cus * 16);
-            hipLaunchKernelGGL(k_sdm_descriptors, dim3(grid), dim3(128), 2 * p.ldsPerWave, st, dimg, m->origin.as<int32_t>(), p, nitems, m->desc.as<float>(), (int64_t)F);
-            const float* R = m->R[step]->as<float>();
-            hipLaunchKernelGGL(k_sdm_regress, dim3((B + 15) / 16, (N + 15) / 16, nchunks), dim3(64), 0, st, m->desc.as<float>(), B, F, R, N,
-                               m->partial.as<double>(), nchunks);
-            hipLaunchKernelGGL(k_sdm_update, dim3((B * N + 255) / 256), dim3(256), 0, st, m->shapes.as<float>(), m->partial.as<double>(), nchunks,
-                               R + (size_t)F * N, m->dist.as<float>(), B, N);
-        }
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipMemcpyAsync(shapes_out, m->shapes.p, sizeof(float) * shapes.size(), hipMemcpyDeviceToHost, st));
-        if (status_out) HIP_CHECK(hipMemcpyAsync(status_out, m->status.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
+        sdm_optimize(ctx, m, gray_images, W, H, B, images_on_device, shapes, status_out);
+        std::memcpy(shapes_out, shapes.data(), sizeof(float) * shapes.size());
+    });
+}
+
+int fd_sdm_optimize_batch(fd_ctx* ctx, const fd_sdm* m_, const uint8_t* gray_images, int W, int H, int batch, int images_on_device,
+                          float* shapes_inout, int32_t* status_out) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !m_ || !gray_images || !shapes_inout || batch < 0 || W < 1 || H < 1)
+            FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_sdm_optimize_batch: bad argument");
+        if (batch == 0) return;
+        fd_sdm* m = const_cast<fd_sdm*>(m_);
+        std::vector<float> shapes(shapes_inout, shapes_inout + (size_t)batch * 2 * m->L);
+        sdm_optimize(ctx, m, gray_images, W, H, batch, images_on_device, shapes, status_out);
+        std::memcpy(shapes_inout, shapes.data(), sizeof(float) * shapes.size());
     });
 }
 

@@ -276,6 +276,117 @@ __global__ __launch_bounds__(RB_THREADS, 2) void k_svm_rbf_mfma(const float* __r
     }
 }
 
+
+// ---- support-vector-stationary variant (feature length <= 8*SVQ) -----------------------------------
+// Each wavefront keeps ONE 32-SV fragment tile entirely in registers (Q float4 = up to 168 VGPRs) for
+// the whole kernel and streams 32-patch tiles through a double-buffered LDS image filled by
+// global_load_lds (LDS-DMA, no VGPR round trip).  C[i = SV][j = patch]: a lane's 16 accumulators are
+// 16 support vectors of ONE patch, so the sum over support vectors is in-register; only one
+// lane<->lane+32 exchange and an 8-wave LDS reduction remain.  Workgroup = 8 waves = 256 support
+// vectors; blockIdx.y selects the 256-SV group, each group writes its own partial sum (no atomics).
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+template <int Q>   // exact number of 8-wide k groups (KP / 8): keeps the K loop free of branches
+__global__ __launch_bounds__(512, 2) void k_svm_rbf_mfma_svs(const float* __restrict__ xFrag, const float* __restrict__ xx, SvmDev m,
+                                                             float negGamma, int64_t ntiles, double* __restrict__ partial,
+                                                             int64_t npadRows) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int KP = Q * 8;
+    constexpr int tileFloats = Q * 256;
+    float* const buf0 = lds;
+    float* const buf1 = lds + tileFloats;
+    float* red = lds + 2 * tileFloats;           // [2][8][32]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nt = blockIdx.y * 8 + wave;        // this wave's support-vector tile
+    // stationary operand: Q float4 per lane
+    f32x4 sv[Q];
+    {
+        const f32x4* src = (const f32x4*)(m.svFrag + (size_t)nt * 32 * KP) + lane;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) sv[q] = src[(size_t)q * 64];
+    }
+    // epilogue constants of this wave's 32 support vectors live in LDS (keeps the VGPR budget for the
+    // stationary operand): svc[wave][0..31] = |s|^2, svc[wave][32..63] = coefficient
+    float* svc = red + 2 * 8 * 32 * 2 + wave * 64;
+    svc[lane] = lane < 32 ? m.ss_f32[nt * 32 + lane] : m.coeffPad[nt * 32 + lane - 32];
+    auto issue_tile = [&](int64_t tile, float* dst) {
+        // LDS-DMA, 1 KiB per wave instruction; wave w moves q-groups w, w+8, ...  Issued through inline asm so
+        // that the compiler does not see a pending LDS write (it would wait vmcnt(0) before every ds_read of
+        // the tile being computed); completion is awaited explicitly (vmcnt(0) + barrier) before the buffer
+        // is read.  Recipe: cdna_hip_programming.md section 5.7 (M0 = wave-uniform LDS destination).
+        const char* g = (const char*)(xFrag + (size_t)tile * 32 * KP) + (size_t)lane * 16;
+        for (int q = wave; q < Q; q += 8) {
+            const unsigned ldsDst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void_t*)(dst + q * 256));
+            const char* gsrc = g + (size_t)q * 1024;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gsrc), "s"(ldsDst) : "memory");
+        }
+    };
+    int cur = 0;
+    int64_t tile = blockIdx.x;
+    float xxj = tile < ntiles ? xx[tile * 32 + (lane & 31)] : 0.f;
+    if (tile < ntiles) issue_tile(tile, buf0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int64_t next = tile + gridDim.x;
+        // |x|^2 of the NEXT tile is fetched one iteration ahead, before the LDS-DMA is queued, so that no
+        // compiler-inserted vmcnt wait for it can land behind the DMA inside this iteration's compute
+        const float xxn = next < ntiles ? xx[next * 32 + (lane & 31)] : 0.f;
+        if (next < ntiles) issue_tile(next, cur ? buf0 : buf1);
+        const f32x4* ap = (const f32x4*)(cur ? buf1 : buf0) + lane;
+        f32x16 acc = {0};
+        f32x4 p = ap[0];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const f32x4 pn = ap[(size_t)(q + 1 < Q ? q + 1 : q) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[q][0], p[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[q][1], p[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[q][2], p[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[q][3], p[3], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            p = pn;
+        }
+        // epilogue: column = patch (lane & 31)
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);   // support vector of accumulator r
+            const float d2 = (xxj + svc[row]) - 2.f * acc[r];
+            s += (double)svc[32 + row] * (double)__expf(negGamma * fmaxf(d2, 0.f));
+        }
+        s += __shfl_xor(s, 32, 64);
+        float* rd = red + cur * 512;
+        // double stored as two floats slots: keep fp64 through the LDS reduction
+        if (lane < 32) ((double*)rd)[wave * 32 + lane] = s;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile has landed in LDS
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const double* rdd = (const double*)rd;
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) t += rdd[w * 32 + threadIdx.x];
+            partial[(size_t)blockIdx.y * npadRows + tile * 32 + threadIdx.x] = t;
+        }
+        xxj = xxn;
+        cur ^= 1;
+    }
+}
+
+// out[i] = -bias + sum over SV groups
+__global__ void k_sum_partials(const double* __restrict__ partial, int ngroups, int64_t npadRows, int64_t n, float bias,
+                               double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int g = 0; g < ngroups; ++g) s += partial[(size_t)g * npadRows + i];
+        out[i] = -(double)bias + s;
+    }
+}
+
 }  // namespace
 
 // ---- host side ---------------------------------------------------------------------------------
@@ -292,9 +403,38 @@ double fd_svm_probability(const fd_svm* m, double d) {  // ProbabilisticSvmClass
 size_t fd_svm_rbf_lds_bytes(int KP) { return (size_t)2 * (KP / 8) * 256 * 4 + 64 * 4 + 8 * 64 * 8; }
 
 // dense MFMA scoring of npatches feature vectors already on the device in fragment-major layout
+// (rows padded to a multiple of 64, pad rows zero).  partial: scratch for the SV-stationary kernel.
 void fd_svm_rbf_mfma_launch(fd_ctx* ctx, const fd_svm* m, const float* xFrag, const float* xx, int64_t npatches, double* out) {
     if (!m->dev.svFrag) FD_THROW(FD_ERR_INVALID_ARGUMENT, "SVM has no MFMA path (needs an RBF kernel on f32 vectors)");
-    const size_t ldsBytes = fd_svm_rbf_lds_bytes(m->dev.KP);
+    const int KP = m->dev.KP;
+    static int variant = -1;
+    if (variant < 0) { const char* e = getenv("FD_SVM_KERNEL"); variant = e ? atoi(e) : 2; }
+    if (variant == 2 && (KP == 328 || KP == 336)) {   // instantiated sizes (HOG-324 -> 328); others use the A-resident kernel
+        fd_svm* mm = const_cast<fd_svm*>(m);
+        const int64_t ntiles = (npatches + 31) / 32;
+        const int64_t npadRows = ((npatches + 63) / 64) * 64;
+        const int ngroups = m->dev.nsv_pad / 256;
+        mm->dist.reserve(sizeof(double) * (size_t)ngroups * npadRows);
+        const size_t ldsBytes = (size_t)2 * (KP / 8) * 256 * 4 + 2 * 8 * 32 * 8 + 8 * 64 * 4;
+        static bool attr2 = false;
+        if (!attr2) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)k_svm_rbf_mfma_svs<41>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_CHECK(hipFuncSetAttribute((const void*)k_svm_rbf_mfma_svs<42>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr2 = true;
+        }
+        const int gx = (int)std::min<int64_t>(ntiles, std::max(1, ctx->num_cus / ngroups));
+        if (KP == 328)
+            hipLaunchKernelGGL(k_svm_rbf_mfma_svs<41>, dim3(gx, ngroups), dim3(512), ldsBytes, ctx->stream, xFrag, xx, m->dev,
+                               (float)(-m->dev.p0), ntiles, mm->dist.as<double>(), npadRows);
+        else
+            hipLaunchKernelGGL(k_svm_rbf_mfma_svs<42>, dim3(gx, ngroups), dim3(512), ldsBytes, ctx->stream, xFrag, xx, m->dev,
+                               (float)(-m->dev.p0), ntiles, mm->dist.as<double>(), npadRows);
+        hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)std::min<int64_t>((npatches + 255) / 256, 2048)), dim3(256), 0, ctx->stream,
+                           mm->dist.as<double>(), ngroups, npadRows, npatches, m->dev.bias, out);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
+    const size_t ldsBytes = fd_svm_rbf_lds_bytes(KP);
     if (ldsBytes > 160 * 1024) FD_THROW(FD_ERR_INVALID_ARGUMENT, "feature length %d too large for the MFMA SVM kernel", m->dev.dim);
     static bool attr_set = false;
     if (!attr_set) {

@@ -43,7 +43,7 @@ struct WinLayerDev {
 struct WinTable {
     int32_t n;
     int32_t sx, sy;
-    int32_t pad;
+    int32_t raw;   // != 0: arena holds `total` contiguous, already equalised patches (fd_wvm_eval_batch)
     int64_t total;
     WinLayerDev l[WVM_MAX_LAYERS];
 };
@@ -114,24 +114,32 @@ __global__ __launch_bounds__(256) void k_wvm_cascade(const uint8_t* __restrict__
 
     for (int64_t wid = (int64_t)blockIdx.x * 4 + wave; wid < wt.total; wid += nwaves) {
         // ---- window id -> (layer, x, y): count layers whose first window <= wid
-        int li;
-        {
-            bool le = lane < wt.n && wt.l[lane < wt.n ? lane : 0].first <= wid;
-            li = __popcll(__ballot(le)) - 1;
+        const uint8_t* src;
+        int srcStride;
+        if (wt.raw) {
+            src = arena + (size_t)wid * d;
+            srcStride = pw;
+        } else {
+            int li;
+            {
+                bool le = lane < wt.n && wt.l[lane < wt.n ? lane : 0].first <= wid;
+                li = __popcll(__ballot(le)) - 1;
+            }
+            li = __builtin_amdgcn_readfirstlane(li);
+            const WinLayerDev wl = wt.l[li];
+            const int local = (int)(wid - wl.first);
+            const int iy = local / wl.nx, ix = local - iy * wl.nx;
+            const int lx = wl.bx + ix * wt.sx, ly = wl.by + iy * wt.sy;
+            src = arena + wl.off + (size_t)ly * wl.lw + lx;
+            srcStride = wl.lw;
         }
-        li = __builtin_amdgcn_readfirstlane(li);
-        const WinLayerDev wl = wt.l[li];
-        const int local = (int)(wid - wl.first);
-        const int iy = local / wl.nx, ix = local - iy * wl.nx;
-        const int lx = wl.bx + ix * wt.sx, ly = wl.by + iy * wt.sy;
-        const uint8_t* src = arena + wl.off + (size_t)ly * wl.lw + lx;
 
         // ---- 1. load the window: lanes 0-31 -> even rows, 32-63 -> odd rows
         unsigned int px[WVM_MAX_DIM / 2];
 #pragma unroll
         for (int j = 0; j < WVM_MAX_DIM / 2; ++j) {
             int r = half + 2 * j;
-            px[j] = (r < ph && col < pw) ? src[(size_t)r * wl.lw + col] : 0u;
+            px[j] = (r < ph && col < pw) ? src[(size_t)r * srcStride + col] : 0u;
         }
         // ---- 2. HistEq64: histogram (lane == bin)
         L.hist[lane] = 0;
@@ -152,12 +160,12 @@ __global__ __launch_bounds__(256) void k_wvm_cascade(const uint8_t* __restrict__
         }
         L.lut[lane] = (unsigned int)(unsigned char)floor((double)mycdf + 0.5);
         wave_sync();
-        // ---- 3. equalised patch -> LDS, integral image
+        // ---- 3. equalised patch -> LDS, integral image (raw mode: the input already is the equalised patch)
 #pragma unroll
         for (int j = 0; j < WVM_MAX_DIM / 2; ++j) {
             int r = half + 2 * j;
             if (r < ph && col < pw) {
-                px[j] = L.lut[px[j] >> 2];
+                if (!wt.raw) px[j] = L.lut[px[j] >> 2];
                 L.ii[r * pw + col] = px[j];
             }
         }
@@ -520,6 +528,37 @@ int fd_detect_wvm(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, int sx, int sy
         for (size_t i = 0; i < dets.size() && (int64_t)i < cap && out; ++i) out[i] = dets[i];
         if ((int64_t)dets.size() > cap && out)
             FD_THROW(FD_ERR_CAPACITY, "fd_detect_wvm: %zu positives, capacity %lld", dets.size(), (long long)cap);
+    });
+}
+
+int fd_wvm_eval_batch(fd_ctx* ctx, const fd_wvm* wvm_, const uint8_t* patches, int64_t n, int32_t* out_level, float* out_score) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !wvm_ || (n > 0 && !patches) || n < 0) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_wvm_eval_batch: bad argument");
+        if (n == 0) return;
+        fd_wvm* m = const_cast<fd_wvm*>(wvm_);
+        HIP_CHECK(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        const size_t bytes = (size_t)n * m->dev.d;
+        DevBuf in;
+        in.reserve(bytes);
+        m->all_level.reserve(sizeof(int32_t) * (size_t)n);
+        m->all_fout.reserve(sizeof(float) * (size_t)n);
+        m->pos.reserve(sizeof(PosRec) * 16);
+        m->pos_patches.reserve((size_t)m->dev.d * 16);
+        m->counter.reserve(256);
+        HIP_CHECK(hipMemcpyAsync(in.p, patches, bytes, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemsetAsync(m->counter.p, 0, 4, st));
+        WinTable wt;
+        std::memset(&wt, 0, sizeof(wt));
+        wt.raw = 1;
+        wt.total = n;
+        const int grid = (int)std::min<int64_t>((n + 3) / 4, (int64_t)ctx->num_cus * 8);
+        hipLaunchKernelGGL(k_wvm_cascade, dim3(grid), dim3(256), 0, st, in.as<uint8_t>(), wt, m->dev, m->all_level.as<int32_t>(),
+                           m->all_fout.as<float>(), m->pos.as<PosRec>(), m->pos_patches.as<uint8_t>(), m->counter.as<unsigned int>(), 0u);
+        HIP_CHECK(hipGetLastError());
+        if (out_level) HIP_CHECK(hipMemcpyAsync(out_level, m->all_level.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+        if (out_score) HIP_CHECK(hipMemcpyAsync(out_score, m->all_fout.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
     });
 }
 

@@ -1,0 +1,32 @@
+// sdm_fit_app -- the two calls every SDM caller of the reference makes (detect-landmarks.cpp:272-276,
+// sdmTracking.cpp:362,371): alignRigid + optimize, on the reference-shaped classes of this backend.
+// usage: sdm_fit_app <model.txt> <image.pgm> <x> <y> <w> <h>   -> prints the 2L landmark coordinates
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include "superviseddescent/superviseddescent_all.hpp"
+
+using namespace superviseddescent;
+
+int main(int argc, char** argv) {
+    if (argc < 7) { std::fprintf(stderr, "usage: %s model.txt image.pgm x y w h\n", argv[0]); return 2; }
+    try {
+        SdmLandmarkModel lmModel = SdmLandmarkModel::load(argv[1]);
+        SdmLandmarkModelFitting modelFitter(lmModel);
+        std::ifstream f(argv[2], std::ios::binary);
+        std::string magic; int w, h, maxv;
+        f >> magic >> w >> h >> maxv; f.get();
+        if (magic != "P5" || maxv != 255) throw std::runtime_error("need a binary PGM");
+        cv::Mat imgGray(h, w, CV_8UC1);
+        f.read((char*)imgGray.data, (size_t)w * h);
+        cv::Rect faceBox(std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), std::atoi(argv[6]));
+        cv::Mat modelShape = lmModel.getMeanShape();
+        modelShape = modelFitter.alignRigid(modelShape, faceBox);
+        modelShape = modelFitter.optimize(modelShape, imgGray);
+        for (int i = 0; i < modelShape.rows; ++i) std::printf("%.9g\n", modelShape.at<float>(i, 0));
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

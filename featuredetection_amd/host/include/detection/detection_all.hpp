@@ -1,0 +1,90 @@
+// detection/*.hpp of the reference on top of the C ABI (include/fd_hip.h).
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+#include "classification/classification_all.hpp"
+#include "imageprocessing/imageprocessing_all.hpp"
+
+namespace detection {
+
+// ClassifiedPatch.hpp:19-97
+class ClassifiedPatch {
+public:
+    ClassifiedPatch(std::shared_ptr<imageprocessing::Patch> patch, bool positive, double probability = 0.5)
+        : patch(patch), positive(positive), probability(probability) {}
+    ClassifiedPatch(std::shared_ptr<imageprocessing::Patch> patch, std::pair<bool, double> result)
+        : patch(patch), positive(result.first), probability(result.second) {}
+    std::shared_ptr<imageprocessing::Patch> getPatch() { return patch; }
+    const std::shared_ptr<imageprocessing::Patch> getPatch() const { return patch; }
+    bool isPositive() const { return positive; }
+    double getProbability() const { return probability; }
+    bool operator<(const ClassifiedPatch& other) const { return probability < other.probability; }
+    bool operator>(const ClassifiedPatch& other) const { return probability > other.probability; }
+private:
+    std::shared_ptr<imageprocessing::Patch> patch;
+    bool positive;
+    double probability;
+};
+
+// Detector.hpp:43-81
+class Detector {
+public:
+    virtual ~Detector() {}
+    virtual std::vector<std::shared_ptr<ClassifiedPatch>> detect(const cv::Mat& image) = 0;
+    virtual std::vector<std::shared_ptr<ClassifiedPatch>> detect(const cv::Mat& image, const cv::Rect& roi) = 0;
+    virtual std::vector<std::shared_ptr<ClassifiedPatch>> detect(std::shared_ptr<imageprocessing::VersionedImage> image) = 0;
+    std::string landmark;
+};
+
+// OverlapElimination.hpp:45-55 / OverlapElimination.cpp:44-105
+class OverlapElimination {
+public:
+    explicit OverlapElimination(float dist = 5.0f, float ratio = 0.0f) : dist(dist), ratio(ratio) {}
+    std::vector<std::shared_ptr<ClassifiedPatch>> eliminate(std::vector<std::shared_ptr<ClassifiedPatch>>& classifiedPatches);
+    float getDist() const { return dist; }
+    float getRatio() const { return ratio; }
+private:
+    float dist, ratio;
+};
+
+// SlidingWindowDetector.hpp:41-93 / SlidingWindowDetector.cpp:40-98
+class SlidingWindowDetector : public Detector {
+public:
+    explicit SlidingWindowDetector(std::shared_ptr<classification::ProbabilisticClassifier> classifier,
+                                   std::shared_ptr<imageprocessing::PyramidFeatureExtractor> featureExtractor, int stepSizeX = 1,
+                                   int stepSizeY = 1);
+    std::vector<std::shared_ptr<ClassifiedPatch>> detect(const cv::Mat& image) override;
+    std::vector<std::shared_ptr<ClassifiedPatch>> detect(const cv::Mat& image, const cv::Rect& roi) override;
+    std::vector<std::shared_ptr<ClassifiedPatch>> detect(std::shared_ptr<imageprocessing::VersionedImage> image) override;
+    const std::shared_ptr<imageprocessing::PyramidFeatureExtractor> getPyramidFeatureExtractor() const { return featureExtractor; }
+    std::shared_ptr<classification::ProbabilisticClassifier> getClassifier() const { return classifier; }
+    int getStepSizeX() const { return stepSizeX; }
+    int getStepSizeY() const { return stepSizeY; }
+private:
+    std::vector<std::shared_ptr<ClassifiedPatch>> detect(const cv::Rect* roi) const;
+    std::shared_ptr<classification::ProbabilisticClassifier> classifier;
+    std::shared_ptr<imageprocessing::PyramidFeatureExtractor> featureExtractor;
+    int stepSizeX, stepSizeY;
+};
+
+// FiveStageSlidingWindowDetector.hpp:36 / FiveStageSlidingWindowDetector.cpp:187-380
+class FiveStageSlidingWindowDetector : public Detector {
+public:
+    FiveStageSlidingWindowDetector(std::shared_ptr<SlidingWindowDetector> slidingWindowDetector,
+                                   std::shared_ptr<OverlapElimination> overlapElimination,
+                                   std::shared_ptr<classification::ProbabilisticClassifier> strongClassifier);
+    std::vector<std::shared_ptr<ClassifiedPatch>> detect(const cv::Mat& image) override;
+    std::vector<std::shared_ptr<ClassifiedPatch>> detect(const cv::Mat& image, const cv::Rect& roi) override;
+    std::vector<std::shared_ptr<ClassifiedPatch>> detect(std::shared_ptr<imageprocessing::VersionedImage> image) override;
+    const std::shared_ptr<imageprocessing::PyramidFeatureExtractor> getPyramidFeatureExtractor() const {
+        return slidingWindowDetector->getPyramidFeatureExtractor();
+    }
+private:
+    std::vector<std::shared_ptr<ClassifiedPatch>> run(const cv::Mat& image, const cv::Rect* roi);
+    std::shared_ptr<SlidingWindowDetector> slidingWindowDetector;
+    std::shared_ptr<OverlapElimination> overlapElimination;
+    std::shared_ptr<classification::ProbabilisticClassifier> strongClassifier;
+};
+
+}  // namespace detection

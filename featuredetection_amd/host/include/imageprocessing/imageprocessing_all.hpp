@@ -1,0 +1,269 @@
+// imageprocessing/*.hpp of the reference, re-implemented on top of the C ABI (include/fd_hip.h).
+// Class names, namespaces, constructor and method signatures follow the reference headers cited per
+// class; the work is done by the HIP kernels behind fd_hip.h.  Filters that the GPU path fuses into a
+// kernel (GradientFilter, GradientBinningFilter, HogFilter, LbpFilter as layer filter, HistEq64Filter as
+// patch filter) are recognised by type when they are added to a pyramid / extractor.
+#pragma once
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+#include "fdcompat/cv.hpp"
+#include "fdcompat/runtime.hpp"
+
+namespace imageprocessing {
+
+// Version.hpp:18-46 -- (instance id, counter) pair used to avoid rebuilding pyramids
+class Version {
+public:
+    Version() : instance(-1), counter(0) {}
+    static Version fresh() { Version v; v.instance = nextInstance()++; return v; }
+    bool operator==(const Version& o) const { return instance == o.instance && counter == o.counter; }
+    bool operator!=(const Version& o) const { return !(*this == o); }
+    Version& operator++() { ++counter; return *this; }
+private:
+    static int& nextInstance() { static int n = 0; return n; }
+    int instance, counter;
+};
+
+// VersionedImage.hpp:19-67
+class VersionedImage {
+public:
+    VersionedImage() : data(), version(Version::fresh()) {}
+    explicit VersionedImage(const cv::Mat& d) : data(d), version(Version::fresh()) {}
+    cv::Mat& getData() { return data; }
+    const cv::Mat& getData() const { return data; }
+    void setData(const cv::Mat& d) { data = d; ++version; }
+    Version getVersion() const { return version; }
+private:
+    cv::Mat data;
+    Version version;
+};
+
+// ImageFilter.hpp:18-57
+class ImageFilter {
+public:
+    virtual ~ImageFilter() {}
+    cv::Mat applyTo(const cv::Mat& image) const { cv::Mat filtered; return applyTo(image, filtered); }
+    virtual cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const = 0;
+    virtual void applyInPlace(cv::Mat& image) const { image = applyTo(image); }
+};
+
+// ChainedFilter.cpp:36-50
+class ChainedFilter : public ImageFilter {
+public:
+    using ImageFilter::applyTo;
+    void add(std::shared_ptr<ImageFilter> filter) { filters.push_back(filter); }
+    const std::vector<std::shared_ptr<ImageFilter>>& getFilters() const { return filters; }
+    cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override {
+        if (filters.empty()) { image.copyTo(filtered); return filtered; }
+        filtered = image;
+        for (const auto& f : filters) { cv::Mat tmp; f->applyTo(filtered, tmp); filtered = tmp; }
+        return filtered;
+    }
+private:
+    std::vector<std::shared_ptr<ImageFilter>> filters;
+};
+
+// GrayscaleFilter.cpp:18-24 (image filter of the pyramid: fused into fd_pyramid_update)
+class GrayscaleFilter : public ImageFilter {
+public:
+    using ImageFilter::applyTo;
+    cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;
+};
+
+// HistEq64Filter.cpp:32-125 (patch filter: fused into the WVM kernel; stand-alone via fd_histeq64_batch)
+class HistEq64Filter : public ImageFilter {
+public:
+    using ImageFilter::applyTo;
+    cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;
+};
+
+// GreyWorldNormalizationFilter.cpp:20-71
+class GreyWorldNormalizationFilter : public ImageFilter {
+public:
+    using ImageFilter::applyTo;
+    cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;
+};
+
+// GradientFilter.cpp:16-59 (layer filter only on this backend)
+class GradientFilter : public ImageFilter {
+public:
+    using ImageFilter::applyTo;
+    explicit GradientFilter(int kernelSize, int blurKernelSize = 0);
+    cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;
+    int kernelSize, blurKernelSize;
+};
+
+// GradientBinningFilter.cpp:18-93 (layer filter only on this backend)
+class GradientBinningFilter : public ImageFilter {
+public:
+    using ImageFilter::applyTo;
+    explicit GradientBinningFilter(unsigned int bins, bool signedGradients = false, bool interpolate = false);
+    cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;
+    unsigned int getBinCount() const { return bins; }
+    unsigned int bins;
+    bool signedGradients, interpolate;
+};
+
+// LbpFilter.hpp (layer filter only on this backend)
+class LbpFilter : public ImageFilter {
+public:
+    using ImageFilter::applyTo;
+    enum class Type { LBP8, LBP8_UNIFORM, LBP4, LBP4_ROTATED };
+    explicit LbpFilter(Type type = Type::LBP8) : type(type) {}
+    cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;
+    unsigned int getBinCount() const;
+    Type type;
+};
+
+// HogFilter.cpp:16-57 (patch filter: fused into k_hog_tile)
+class HogFilter : public ImageFilter {
+public:
+    using ImageFilter::applyTo;
+    explicit HogFilter(int binCount, int cellSize = 5, int blockSize = 2, bool interpolate = false, bool signedAndUnsigned = false);
+    cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;
+    int binCount, cellSize, blockSize;
+    bool interpolate, signedAndUnsigned;
+};
+
+// ImagePyramidLayer.hpp:34-163
+class ImagePyramidLayer {
+public:
+    ImagePyramidLayer(int index, double scale, double scaleX, double scaleY, const cv::Mat& image)
+        : index(index), scale(scale), scaleX(scaleX), scaleY(scaleY), image(image) {}
+    int getScaled(int value) const { return cv::cvRound(value * scale); }
+    int getOriginal(int value) const { return cv::cvRound(value / scale); }
+    cv::Size getSize() const { return cv::Size(image.cols, image.rows); }
+    int getIndex() const { return index; }
+    double getScaleFactor() const { return scale; }
+    const cv::Mat& getScaledImage() const { return image; }
+private:
+    int index;
+    double scale, scaleX, scaleY;
+    cv::Mat image;
+};
+
+// ImagePyramid.hpp / ImagePyramid.cpp:67-92,116-128,148-198,300-328 -- backed by fd_pyramid
+class ImagePyramid {
+public:
+    ImagePyramid(size_t octaveLayerCount, double minScaleFactor, double maxScaleFactor = 1);
+    ImagePyramid(double incrementalScaleFactor, double minScaleFactor, double maxScaleFactor = 1);
+    ~ImagePyramid();
+    ImagePyramid(const ImagePyramid&) = delete;
+    ImagePyramid& operator=(const ImagePyramid&) = delete;
+    void addImageFilter(const std::shared_ptr<ImageFilter>& filter);   // GrayscaleFilter
+    void addLayerFilter(const std::shared_ptr<ImageFilter>& filter);   // GradientFilter, GradientBinningFilter, LbpFilter
+    void update(const cv::Mat& image);
+    void update(const std::shared_ptr<VersionedImage>& image);
+    const std::vector<std::shared_ptr<ImagePyramidLayer>>& getLayers() const;  // downloads the layers on first use
+    const std::shared_ptr<ImagePyramidLayer> getLayer(int index) const;
+    double getMinScaleFactor() const { return minScaleFactor; }
+    double getMaxScaleFactor() const { return maxScaleFactor; }
+    double getIncrementalScaleFactor() const;
+    cv::Size getImageSize() const { return imageSize; }
+    std::vector<std::pair<int, double>> getLayerScales() const;
+    std::vector<cv::Size> getLayerSizes() const;
+    fd_pyramid* native() const { return handle; }
+private:
+    void applyLayerFilterConfig();
+    fd_pyramid* handle;
+    double minScaleFactor, maxScaleFactor;
+    cv::Size imageSize;
+    Version version;
+    std::shared_ptr<GradientFilter> gradient;
+    std::shared_ptr<GradientBinningFilter> binning;
+    std::shared_ptr<LbpFilter> lbp;
+    mutable std::vector<std::shared_ptr<ImagePyramidLayer>> layers;
+    mutable bool layersValid;
+};
+
+// Patch.hpp:28-243
+class Patch {
+public:
+    Patch() : center(0, 0), size(0, 0), data() {}
+    Patch(int x, int y, int width, int height, const cv::Mat& data) : center(x, y), size(width, height), data(data) {}
+    Patch(const Patch& other) : center(other.center), size(other.size), data(other.data.clone()) {}
+    bool operator==(const Patch& o) const {
+        return center.x == o.center.x && center.y == o.center.y && size.width == o.size.width && size.height == o.size.height;
+    }
+    cv::Rect getBounds() const { return cv::Rect(center.x - size.width / 2, center.y - size.height / 2, size.width, size.height); }
+    int getX() const { return center.x; }
+    int getY() const { return center.y; }
+    int getWidth() const { return size.width; }
+    int getHeight() const { return size.height; }
+    cv::Mat& getData() { return data; }
+    const cv::Mat& getData() const { return data; }
+private:
+    cv::Point center;
+    cv::Size size;
+    cv::Mat data;
+};
+
+// FeatureExtractor.hpp:22-55
+class FeatureExtractor {
+public:
+    virtual ~FeatureExtractor() {}
+    void update(const cv::Mat& image) { update(std::make_shared<VersionedImage>(image)); }
+    virtual void update(std::shared_ptr<VersionedImage> image) = 0;
+    virtual std::shared_ptr<Patch> extract(int x, int y, int width, int height) const = 0;
+};
+
+// PyramidFeatureExtractor.hpp:21-119
+class PyramidFeatureExtractor : public FeatureExtractor {
+public:
+    using FeatureExtractor::update;
+    using FeatureExtractor::extract;
+    virtual std::vector<std::shared_ptr<Patch>> extract(int stepX, int stepY, cv::Rect roi = cv::Rect(), int firstLayer = -1,
+                                                        int lastLayer = -1, int stepLayer = 1) const = 0;
+    virtual std::shared_ptr<Patch> extract(int layer, int x, int y) const = 0;
+    virtual int getLayerIndex(int width, int height) const = 0;
+    virtual double getMinScaleFactor() const = 0;
+    virtual double getMaxScaleFactor() const = 0;
+    virtual double getIncrementalScaleFactor() const = 0;
+    virtual cv::Size getPatchSize() const = 0;
+    virtual cv::Size getImageSize() const = 0;
+    virtual std::vector<std::pair<int, double>> getLayerScales() const = 0;
+    virtual std::vector<cv::Size> getLayerSizes() const = 0;
+    virtual std::vector<cv::Size> getPatchSizes() const = 0;
+};
+
+// DirectPyramidFeatureExtractor.hpp / .cpp:27-229
+class DirectPyramidFeatureExtractor : public PyramidFeatureExtractor {
+public:
+    using PyramidFeatureExtractor::update;
+    using PyramidFeatureExtractor::extract;
+    DirectPyramidFeatureExtractor(std::shared_ptr<ImagePyramid> pyramid, int width, int height);
+    void addImageFilter(std::shared_ptr<ImageFilter> filter) { pyramid->addImageFilter(filter); }
+    void addLayerFilter(std::shared_ptr<ImageFilter> filter) { pyramid->addLayerFilter(filter); }
+    void addPatchFilter(std::shared_ptr<ImageFilter> filter);          // HistEq64Filter or HogFilter
+    void update(std::shared_ptr<VersionedImage> image) override { pyramid->update(image); }
+    std::shared_ptr<Patch> extract(int x, int y, int width, int height) const override;
+    std::vector<std::shared_ptr<Patch>> extract(int stepX, int stepY, cv::Rect roi = cv::Rect(), int firstLayer = -1, int lastLayer = -1,
+                                                int stepLayer = 1) const override;
+    std::shared_ptr<Patch> extract(int layer, int x, int y) const override;
+    int getLayerIndex(int width, int height) const override;
+    double getMinScaleFactor() const override { return pyramid->getMinScaleFactor(); }
+    double getMaxScaleFactor() const override { return pyramid->getMaxScaleFactor(); }
+    double getIncrementalScaleFactor() const override { return pyramid->getIncrementalScaleFactor(); }
+    cv::Size getPatchSize() const override { return cv::Size(patchWidth, patchHeight); }
+    cv::Size getImageSize() const override { return pyramid->getImageSize(); }
+    std::vector<std::pair<int, double>> getLayerScales() const override { return pyramid->getLayerScales(); }
+    std::vector<cv::Size> getLayerSizes() const override { return pyramid->getLayerSizes(); }
+    std::vector<cv::Size> getPatchSizes() const override;
+    std::shared_ptr<ImagePyramid> getPyramid() { return pyramid; }
+    const std::shared_ptr<ImagePyramid> getPyramid() const { return pyramid; }
+    int getPatchWidth() const { return patchWidth; }
+    int getPatchHeight() const { return patchHeight; }
+    // which fused GPU path the patch filter chain maps to
+    bool hasHistEq64() const { return (bool)histeq; }
+    std::shared_ptr<HogFilter> getHogFilter() const { return hog; }
+private:
+    std::shared_ptr<Patch> extractFromLayer(const ImagePyramidLayer& layer, cv::Rect bounds) const;
+    std::shared_ptr<ImagePyramid> pyramid;
+    int patchWidth, patchHeight;
+    std::shared_ptr<HistEq64Filter> histeq;
+    std::shared_ptr<HogFilter> hog;
+};
+
+}  // namespace imageprocessing

@@ -1,0 +1,857 @@
+// featuredetection_amd/host/src/fd_host.cpp -- implementation of the reference-shaped C++ classes
+// (host/include/{imageprocessing,classification,detection,superviseddescent}) on top of the C ABI.
+// Everything numerical is delegated to libfd_hip.so; this file is object plumbing only.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <iomanip>
+#include <sstream>
+#include "detection/detection_all.hpp"
+#include "superviseddescent/superviseddescent_all.hpp"
+
+using cv::Mat;
+using cv::uchar;
+using std::make_shared;
+using std::shared_ptr;
+using std::string;
+using std::vector;
+
+namespace fdhost {
+fd_ctx* context() {
+    static fd_ctx* ctx = nullptr;
+    if (!ctx) {
+        const char* dev = std::getenv("FD_DEVICE");
+        int rc = fd_ctx_create(dev ? std::atoi(dev) : 0, nullptr, &ctx);
+        if (rc != FD_OK || !ctx) throw std::runtime_error("fd_ctx_create failed: no usable gfx950 device (this backend has no CPU fallback)");
+    }
+    return ctx;
+}
+}  // namespace fdhost
+using fdhost::check;
+using fdhost::context;
+
+static Mat contiguous(const Mat& m) { return m.isContinuous() ? m : m.clone(); }
+
+// =================================================================================================
+namespace imageprocessing {
+
+Mat GrayscaleFilter::applyTo(const Mat& image, Mat& filtered) const {
+    if (image.channels() == 1) { image.copyTo(filtered); return filtered; }
+    // a one-layer pyramid at scale 1 is exactly the grayscale image (resize to the same size is a copy)
+    fd_pyramid* p = nullptr;
+    check(fd_pyramid_create(context(), 1, 1.0, 1.0, &p));
+    Mat src = contiguous(image);
+    int rc = fd_pyramid_update(p, src.data, src.cols, src.rows, src.channels(), 0);
+    if (rc == FD_OK) {
+        filtered.create(src.rows, src.cols, CV_8UC1);
+        rc = fd_pyramid_layer_download(p, 0, filtered.data);
+    }
+    fd_pyramid_destroy(p);
+    check(rc);
+    return filtered;
+}
+
+Mat HistEq64Filter::applyTo(const Mat& image, Mat& filtered) const {
+    if (image.type() != CV_8UC1) throw std::invalid_argument("HistEq64Filter: the image must be of type CV_8UC1");
+    Mat src = contiguous(image);
+    Mat dst(src.rows, src.cols, CV_8UC1);
+    check(fd_histeq64_batch(context(), src.data, 1, src.cols, src.rows, dst.data));
+    filtered = dst;
+    return filtered;
+}
+
+Mat GreyWorldNormalizationFilter::applyTo(const Mat& image, Mat& filtered) const {
+    if (image.type() != CV_8UC3) throw std::invalid_argument("GreyWorldNormalizationFilter: The image type must be CV_8UC3");
+    Mat src = contiguous(image);
+    Mat dst(src.rows, src.cols, CV_8UC3);
+    check(fd_greyworld(context(), src.data, src.cols, src.rows, dst.data, 0));
+    filtered = dst;
+    return filtered;
+}
+
+GradientFilter::GradientFilter(int kernelSize, int blurKernelSize) : kernelSize(kernelSize), blurKernelSize(blurKernelSize) {
+    if (kernelSize != 1 && kernelSize != 3)
+        throw std::invalid_argument("GradientFilter: the kernel size must be 1 or 3 on this backend (reference: 1, 3, 5, 7 or CV_SCHARR)");
+    if (blurKernelSize != 0) throw std::invalid_argument("GradientFilter: blurring is not available on this backend");
+}
+static Mat fused_only(const char* what) {
+    throw std::logic_error(string(what) + " is fused into the pyramid / feature kernels of this backend: add it as a layer or patch filter");
+}
+Mat GradientFilter::applyTo(const Mat&, Mat&) const { return fused_only("GradientFilter"); }
+GradientBinningFilter::GradientBinningFilter(unsigned int bins, bool signedGradients, bool interpolate)
+    : bins(bins), signedGradients(signedGradients), interpolate(interpolate) {}
+Mat GradientBinningFilter::applyTo(const Mat&, Mat&) const { return fused_only("GradientBinningFilter"); }
+Mat LbpFilter::applyTo(const Mat&, Mat&) const { return fused_only("LbpFilter"); }
+unsigned int LbpFilter::getBinCount() const {
+    switch (type) {
+        case Type::LBP8: return 256;
+        case Type::LBP8_UNIFORM: return 59;
+        default: return 16;
+    }
+}
+HogFilter::HogFilter(int binCount, int cellSize, int blockSize, bool interpolate, bool signedAndUnsigned)
+    : binCount(binCount), cellSize(cellSize), blockSize(blockSize), interpolate(interpolate), signedAndUnsigned(signedAndUnsigned) {
+    if (binCount <= 0) throw std::invalid_argument("HogFilter: binCount must be greater than zero");
+    if (cellSize <= 0) throw std::invalid_argument("HogFilter: cellSize must be greater than zero");
+    if (blockSize <= 0) throw std::invalid_argument("HogFilter: blockSize must be greater than zero");
+    if (signedAndUnsigned && binCount % 2 != 0)
+        throw std::invalid_argument("HogFilter: the bin size must be even for signed and unsigned gradients to be combined");
+    if (interpolate) throw std::invalid_argument("HogFilter: cell interpolation is not available on this backend");
+}
+Mat HogFilter::applyTo(const Mat&, Mat&) const { return fused_only("HogFilter"); }
+
+// ---- ImagePyramid -------------------------------------------------------------------------------
+ImagePyramid::ImagePyramid(size_t octaveLayerCount, double minS, double maxS)
+    : handle(nullptr), minScaleFactor(minS), maxScaleFactor(maxS), layersValid(false) {
+    check(fd_pyramid_create(context(), (int)octaveLayerCount, minS, maxS, &handle));
+}
+ImagePyramid::ImagePyramid(double inc, double minS, double maxS) : handle(nullptr), minScaleFactor(minS), maxScaleFactor(maxS), layersValid(false) {
+    check(fd_pyramid_create_inc(context(), inc, minS, maxS, &handle));
+}
+ImagePyramid::~ImagePyramid() { fd_pyramid_destroy(handle); }
+double ImagePyramid::getIncrementalScaleFactor() const { return fd_pyramid_incremental_scale(handle); }
+
+void ImagePyramid::addImageFilter(const shared_ptr<ImageFilter>& filter) {
+    if (!std::dynamic_pointer_cast<GrayscaleFilter>(filter))
+        throw std::logic_error("ImagePyramid: only GrayscaleFilter is supported as image filter on this backend");
+}
+void ImagePyramid::addLayerFilter(const shared_ptr<ImageFilter>& filter) {
+    if (auto g = std::dynamic_pointer_cast<GradientFilter>(filter)) gradient = g;
+    else if (auto b = std::dynamic_pointer_cast<GradientBinningFilter>(filter)) binning = b;
+    else if (auto l = std::dynamic_pointer_cast<LbpFilter>(filter)) lbp = l;
+    else throw std::logic_error("ImagePyramid: unsupported layer filter (GradientFilter, GradientBinningFilter, LbpFilter are available)");
+    applyLayerFilterConfig();
+}
+void ImagePyramid::applyLayerFilterConfig() {
+    if (gradient && binning)
+        check(fd_pyramid_set_layer_filter(handle, FD_LAYER_GRADBIN, (int)binning->bins, binning->signedGradients, binning->interpolate,
+                                          gradient->kernelSize, 0));
+    else if (lbp)
+        check(fd_pyramid_set_layer_filter(handle, FD_LAYER_LBP, 0, 0, 0, 1, (int)lbp->type));
+    version = Version();
+}
+void ImagePyramid::update(const Mat& image) { update(make_shared<VersionedImage>(image)); }
+void ImagePyramid::update(const shared_ptr<VersionedImage>& image) {
+    if ((gradient != nullptr) != (binning != nullptr))
+        throw std::logic_error("ImagePyramid: GradientFilter and GradientBinningFilter have to be added together");
+    if (version == image->getVersion()) return;   // ImagePyramid.cpp:150
+    Mat src = contiguous(image->getData());
+    check(fd_pyramid_update(handle, src.data, src.cols, src.rows, src.channels(), 0));
+    imageSize = cv::Size(src.cols, src.rows);
+    version = image->getVersion();
+    layersValid = false;
+}
+const vector<shared_ptr<ImagePyramidLayer>>& ImagePyramid::getLayers() const {
+    if (!layersValid) {
+        layers.clear();
+        const int n = fd_pyramid_layer_count(handle);
+        for (int i = 0; i < n; ++i) {
+            int index, w, h, ch;
+            double scale;
+            check(fd_pyramid_layer_info(handle, i, &index, &scale, &w, &h, &ch));
+            Mat img(h, w, CV_MAKETYPE(CV_8U, ch));
+            check(fd_pyramid_layer_download(handle, i, img.data));
+            layers.push_back(make_shared<ImagePyramidLayer>(index, scale, (double)w / imageSize.width, (double)h / imageSize.height, img));
+        }
+        layersValid = true;
+    }
+    return layers;
+}
+const shared_ptr<ImagePyramidLayer> ImagePyramid::getLayer(int index) const {
+    const auto& ls = getLayers();
+    if (ls.empty()) return shared_ptr<ImagePyramidLayer>();
+    int real = index - ls.front()->getIndex();
+    if (real < 0 || real >= (int)ls.size()) return shared_ptr<ImagePyramidLayer>();
+    return ls[real];
+}
+vector<std::pair<int, double>> ImagePyramid::getLayerScales() const {
+    vector<std::pair<int, double>> out;
+    for (int i = 0; i < fd_pyramid_layer_count(handle); ++i) {
+        int index, w, h, ch; double scale;
+        fd_pyramid_layer_info(handle, i, &index, &scale, &w, &h, &ch);
+        out.emplace_back(index, scale);
+    }
+    return out;
+}
+vector<cv::Size> ImagePyramid::getLayerSizes() const {
+    vector<cv::Size> out;
+    for (int i = 0; i < fd_pyramid_layer_count(handle); ++i) {
+        int index, w, h, ch; double scale;
+        fd_pyramid_layer_info(handle, i, &index, &scale, &w, &h, &ch);
+        out.push_back(cv::Size(w, h));
+    }
+    return out;
+}
+
+// ---- DirectPyramidFeatureExtractor ----------------------------------------------------------------
+DirectPyramidFeatureExtractor::DirectPyramidFeatureExtractor(shared_ptr<ImagePyramid> pyramid, int width, int height)
+    : pyramid(pyramid), patchWidth(width), patchHeight(height) {}
+void DirectPyramidFeatureExtractor::addPatchFilter(shared_ptr<ImageFilter> filter) {
+    if (auto h = std::dynamic_pointer_cast<HistEq64Filter>(filter)) histeq = h;
+    else if (auto g = std::dynamic_pointer_cast<HogFilter>(filter)) hog = g;
+    else throw std::logic_error("DirectPyramidFeatureExtractor: unsupported patch filter (HistEq64Filter, HogFilter are available)");
+}
+vector<cv::Size> DirectPyramidFeatureExtractor::getPatchSizes() const {
+    vector<cv::Size> sizes;
+    for (const auto& sc : pyramid->getLayerScales())
+        sizes.push_back(cv::Size(cv::cvRound(patchWidth / sc.second), cv::cvRound(patchHeight / sc.second)));
+    return sizes;
+}
+int DirectPyramidFeatureExtractor::getLayerIndex(int width, int) const {
+    double scaleFactor = (double)patchWidth / (double)width;
+    int idx = (int)std::round(std::log(scaleFactor) / std::log(pyramid->getIncrementalScaleFactor()));
+    return pyramid->getLayer(idx) ? idx : -1;
+}
+shared_ptr<Patch> DirectPyramidFeatureExtractor::extractFromLayer(const ImagePyramidLayer& layer, cv::Rect b) const {
+    const Mat& image = layer.getScaledImage();
+    if (b.x < 0 || b.y < 0 || b.x + b.width > image.cols || b.y + b.height > image.rows) return shared_ptr<Patch>();
+    int ow = layer.getOriginal(b.width), oh = layer.getOriginal(b.height);
+    int ox = layer.getOriginal(b.x) + ow / 2, oy = layer.getOriginal(b.y) + oh / 2;
+    Mat data = Mat(image, b).clone();
+    if (histeq) data = histeq->applyTo(data);
+    if (hog) throw std::logic_error("DirectPyramidFeatureExtractor: single-patch extraction with a HogFilter is not available; use extract(stepX, stepY)");
+    return make_shared<Patch>(ox, oy, ow, oh, data);
+}
+shared_ptr<Patch> DirectPyramidFeatureExtractor::extract(int x, int y, int width, int height) const {
+    int idx = getLayerIndex(width, height);
+    auto layer = idx < 0 ? shared_ptr<ImagePyramidLayer>() : pyramid->getLayer(idx);
+    if (!layer) return shared_ptr<Patch>();
+    return extractFromLayer(*layer, cv::Rect(layer->getScaled(x - width / 2), layer->getScaled(y - height / 2), patchWidth, patchHeight));
+}
+shared_ptr<Patch> DirectPyramidFeatureExtractor::extract(int layerIndex, int x, int y) const {
+    auto layer = pyramid->getLayer(layerIndex);
+    if (!layer) return shared_ptr<Patch>();
+    return extractFromLayer(*layer, cv::Rect(x - patchWidth / 2, y - patchHeight / 2, patchWidth, patchHeight));
+}
+vector<shared_ptr<Patch>> DirectPyramidFeatureExtractor::extract(int stepX, int stepY, cv::Rect roi, int firstLayer, int lastLayer,
+                                                                 int stepLayer) const {
+    if (firstLayer != -1 || lastLayer != -1 || stepLayer != 1)
+        throw std::logic_error("DirectPyramidFeatureExtractor: layer sub-ranges are not available on this backend");
+    int r[4] = {roi.x, roi.y, roi.width, roi.height};
+    int64_t n = 0;
+    check(fd_pyramid_window_count(pyramid->native(), patchWidth, patchHeight, stepX, stepY, r, &n));
+    vector<int32_t> wins((size_t)n * 7);
+    if (n) check(fd_pyramid_windows(pyramid->native(), patchWidth, patchHeight, stepX, stepY, r, wins.data(), n, &n));
+    vector<shared_ptr<Patch>> patches;
+    patches.reserve((size_t)n);
+    if (hog) {
+        if (roi.area() != 0) throw std::logic_error("DirectPyramidFeatureExtractor: HOG extraction works on the whole image only");
+        fd_hog_params hp = {patchWidth, patchHeight, stepX, stepY, hog->binCount, hog->cellSize, hog->blockSize, hog->signedAndUnsigned};
+        const int F = fd_hog_feature_length(&hp);
+        Mat all((int)n, F, CV_32FC1);
+        int64_t cnt = 0;
+        if (n) check(fd_extract_hog(context(), pyramid->native(), &hp, all.ptr<float>(0), n, &cnt));
+        for (int64_t i = 0; i < n; ++i) {
+            const int32_t* w = &wins[7 * i];
+            patches.push_back(make_shared<Patch>(w[3], w[4], w[5], w[6], Mat(all, cv::Rect(0, (int)i, F, 1))));
+        }
+        return patches;
+    }
+    const auto& layers = pyramid->getLayers();
+    const int d = patchWidth * patchHeight;
+    Mat raw((int)std::max<int64_t>(n, 1), d, CV_8UC1), eq;
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t* w = &wins[7 * i];
+        const Mat& img = layers[w[0]]->getScaledImage();
+        for (int y = 0; y < patchHeight; ++y) std::memcpy(raw.ptr<uchar>((int)i) + y * patchWidth, img.ptr<uchar>(w[2] + y) + w[1], patchWidth);
+    }
+    if (histeq && n) {
+        eq.create((int)n, d, CV_8UC1);
+        check(fd_histeq64_batch(context(), raw.data, n, patchWidth, patchHeight, eq.data));
+    } else {
+        eq = raw;
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t* w = &wins[7 * i];
+        Mat data(patchHeight, patchWidth, CV_8UC1);
+        std::memcpy(data.data, eq.ptr<uchar>((int)i), d);
+        patches.push_back(make_shared<Patch>(w[3], w[4], w[5], w[6], data));
+    }
+    return patches;
+}
+
+}  // namespace imageprocessing
+
+// =================================================================================================
+namespace classification {
+
+double Kernel::compute(const Mat& lhs, const Mat& rhs) const {
+    if (!lhs.isContinuous() || !rhs.isContinuous()) throw std::invalid_argument("Kernel: arguments have to be continuous");
+    if (lhs.flags != rhs.flags) throw std::invalid_argument("Kernel: arguments have to have the same type");
+    if (lhs.total() * lhs.channels() != rhs.total() * rhs.channels()) throw std::invalid_argument("Kernel: arguments have to have the same length");
+    if (lhs.depth() != CV_8U && lhs.depth() != CV_32F) throw std::invalid_argument("Kernel: arguments have to be of depth CV_8U or CV_32F on this backend");
+    fd_svm_model m;
+    std::memset(&m, 0, sizeof(m));
+    m.kernel = abiKernel();
+    abiParams(m.p0, m.p1, m.p2);
+    m.num_sv = 1;
+    m.dim = (int)(rhs.total() * rhs.channels());
+    m.dtype = rhs.depth() == CV_8U ? FD_DTYPE_U8 : FD_DTYPE_F32;
+    m.support_vectors = rhs.data;
+    const float one = 1.f;
+    m.coefficients = &one;
+    fd_svm* h = nullptr;
+    check(fd_svm_create(context(), &m, &h));
+    double out = 0;
+    int rc = fd_svm_distance_batch(context(), h, lhs.data, 1, &out);
+    fd_svm_destroy(h);
+    check(rc);
+    return out;
+}
+
+SvmClassifier::SvmClassifier(shared_ptr<Kernel> kernel) : VectorMachineClassifier(kernel), handle(nullptr), dirty(true) {}
+SvmClassifier::~SvmClassifier() { fd_svm_destroy(handle); }
+void SvmClassifier::setSvmParameters(vector<Mat> sv, vector<float> coeff, double b) {
+    supportVectors = sv;
+    coefficients = coeff;
+    bias = (float)b;
+    dirty = true;
+}
+const fd_svm* SvmClassifier::native(double la, double lb) const {
+    if (dirty || !handle) {
+        fd_svm_destroy(handle);
+        handle = nullptr;
+        if (supportVectors.empty() || supportVectors.size() != coefficients.size())
+            throw std::runtime_error("SvmClassifier: no support vectors / coefficient count mismatch");
+        const Mat& first = supportVectors.front();
+        const int dim = (int)(first.total() * first.channels());
+        const int depth = first.depth();
+        if (depth != CV_8U && depth != CV_32F) throw std::runtime_error("SvmClassifier: support vectors must be CV_8U or CV_32F on this backend");
+        const size_t es = depth == CV_8U ? 1 : 4;
+        vector<unsigned char> flat(supportVectors.size() * dim * es);
+        for (size_t i = 0; i < supportVectors.size(); ++i) {
+            Mat s = contiguous(supportVectors[i]);
+            if ((int)(s.total() * s.channels()) != dim || s.depth() != depth) throw std::runtime_error("SvmClassifier: inconsistent support vectors");
+            std::memcpy(flat.data() + i * dim * es, s.data, dim * es);
+        }
+        fd_svm_model m;
+        std::memset(&m, 0, sizeof(m));
+        m.kernel = kernel->abiKernel();
+        kernel->abiParams(m.p0, m.p1, m.p2);
+        m.num_sv = (int)supportVectors.size();
+        m.dim = dim;
+        m.dtype = depth == CV_8U ? FD_DTYPE_U8 : FD_DTYPE_F32;
+        m.support_vectors = flat.data();
+        m.coefficients = coefficients.data();
+        m.bias = bias;
+        m.threshold = threshold;
+        m.logistic_a = la;
+        m.logistic_b = lb;
+        check(fd_svm_create(context(), &m, &handle));
+        dirty = false;
+    }
+    return handle;
+}
+double SvmClassifier::computeHyperplaneDistance(const Mat& featureVector) const {
+    Mat x = contiguous(featureVector);
+    double out = 0;
+    check(fd_svm_distance_batch(context(), native(), x.data, 1, &out));
+    return out;
+}
+bool SvmClassifier::classify(const Mat& featureVector) const { return classify(computeHyperplaneDistance(featureVector)); }
+std::pair<bool, double> SvmClassifier::getConfidence(const Mat& featureVector) const {
+    double d = computeHyperplaneDistance(featureVector);
+    return classify(d) ? std::make_pair(true, d) : std::make_pair(false, -d);
+}
+void SvmClassifier::store(std::ofstream& file) {   // SvmClassifier.cpp:68-107
+    if (!file) throw std::runtime_error("SvmClassifier: Cannot write into stream");
+    file << "Kernel ";
+    if (dynamic_cast<LinearKernel*>(kernel.get())) file << "Linear\n";
+    else if (auto* k = dynamic_cast<PolynomialKernel*>(kernel.get())) file << "Polynomial " << k->getDegree() << ' ' << k->getConstant() << ' ' << k->getAlpha() << '\n';
+    else if (auto* k = dynamic_cast<RbfKernel*>(kernel.get())) file << "RBF " << std::setprecision(17) << k->getGamma() << '\n';
+    else if (dynamic_cast<HistogramIntersectionKernel*>(kernel.get())) file << "HIK\n";
+    else throw std::runtime_error("SvmClassifier: cannot write kernel parameters (unknown kernel type)");
+    file << std::setprecision(9) << "Bias " << getBias() << '\n';
+    file << "Coefficients " << coefficients.size() << '\n';
+    for (float c : coefficients) file << c << '\n';
+    const Mat& v = supportVectors.front();
+    file << "SupportVectors " << supportVectors.size() << ' ' << v.rows << ' ' << v.cols << ' ' << v.channels() << ' ' << v.depth() << '\n';
+    for (const Mat& s : supportVectors) {
+        const size_t n = s.total() * s.channels();
+        Mat c = contiguous(s);
+        for (size_t i = 0; i < n; ++i) {
+            if (v.depth() == CV_8U) file << (int)c.ptr<uchar>(0)[i] << ' ';
+            else file << c.ptr<float>(0)[i] << ' ';
+        }
+        file << '\n';
+    }
+}
+shared_ptr<SvmClassifier> SvmClassifier::load(std::ifstream& file) {   // SvmClassifier.cpp:109-159
+    if (!file) throw std::runtime_error("SvmClassifier: Cannot read from stream");
+    string tmp, kernelType;
+    file >> tmp >> kernelType;
+    shared_ptr<Kernel> kernel;
+    if (kernelType == "Linear") kernel.reset(new LinearKernel());
+    else if (kernelType == "Polynomial") { int degree; double constant, scale; file >> degree >> constant >> scale; kernel.reset(new PolynomialKernel(scale, constant, degree)); }
+    else if (kernelType == "RBF") { double gamma; file >> gamma; kernel.reset(new RbfKernel(gamma)); }
+    else if (kernelType == "HIK") kernel.reset(new HistogramIntersectionKernel());
+    else throw std::runtime_error("SvmClassifier: Invalid kernel type: " + kernelType);
+    auto svm = make_shared<SvmClassifier>(kernel);
+    file >> tmp >> svm->bias;
+    size_t count;
+    file >> tmp >> count;
+    svm->coefficients.resize(count);
+    for (size_t i = 0; i < count; ++i) file >> svm->coefficients[i];
+    int rows, cols, channels, depth;
+    file >> tmp >> count >> rows >> cols >> channels >> depth;
+    if (depth != CV_8U && depth != CV_32F)
+        throw std::runtime_error("SvmClassifier: cannot load support vectors of depth other than CV_8U or CV_32F on this backend");
+    for (size_t i = 0; i < count; ++i) {
+        Mat v(rows, cols, CV_MAKETYPE(depth, channels));
+        const size_t n = (size_t)rows * cols * channels;
+        for (size_t k = 0; k < n; ++k) {
+            if (depth == CV_8U) { int t; file >> t; v.ptr<uchar>(0)[k] = (uchar)t; }
+            else file >> v.ptr<float>(0)[k];
+        }
+        svm->supportVectors.push_back(v);
+    }
+    if (!file) throw std::runtime_error("SvmClassifier: Invalid classifier file");
+    svm->dirty = true;
+    return svm;
+}
+
+std::pair<bool, double> ProbabilisticSvmClassifier::getProbability(const Mat& featureVector) const {
+    return getProbability(svm->computeHyperplaneDistance(featureVector));
+}
+std::pair<bool, double> ProbabilisticSvmClassifier::getProbability(double d) const {   // ProbabilisticSvmClassifier.cpp:54-58
+    double fABp = logisticA + logisticB * d;
+    double p = fABp >= 0 ? std::exp(-fABp) / (1.0 + std::exp(-fABp)) : 1.0 / (1.0 + std::exp(fABp));
+    return std::make_pair(svm->classify(d), p);
+}
+void ProbabilisticSvmClassifier::store(std::ofstream& file) {
+    svm->store(file);
+    file << std::setprecision(17) << "Logistic " << logisticA << ' ' << logisticB << '\n';
+}
+shared_ptr<ProbabilisticSvmClassifier> ProbabilisticSvmClassifier::load(std::ifstream& file) {
+    auto svm = SvmClassifier::load(file);
+    string tmp;
+    double a, b;
+    file >> tmp >> a >> b;
+    return make_shared<ProbabilisticSvmClassifier>(svm, a, b);
+}
+shared_ptr<ProbabilisticSvmClassifier> ProbabilisticSvmClassifier::load(const boost::property_tree::ptree& subtree) {
+    string classifierFile = subtree.get<string>("classifierFile");
+    if (classifierFile.size() > 4 && classifierFile.substr(classifierFile.size() - 4) == ".mat")
+        throw std::runtime_error("ProbabilisticSvmClassifier: Cannot load a Matlab classifier (the reference needs libmat; this backend reads the text format of SvmClassifier::store)");
+    std::ifstream f(classifierFile.c_str());
+    if (!f.is_open()) throw std::runtime_error("SvmClassifier: Invalid classifier file");
+    auto psvm = load(f);
+    double la = subtree.get("logisticA", 0.0), lb = subtree.get("logisticB", 0.0);
+    if (la != 0.0 && lb != 0.0) psvm->setLogisticParameters(la, lb);
+    psvm->getSvm()->setThreshold(subtree.get("threshold", 0.0f));
+    return psvm;
+}
+
+// ---- WVM ------------------------------------------------------------------------------------------
+WvmClassifier::WvmClassifier() : VectorMachineClassifier(nullptr), limitReliabilityFilter(0.f), handle(nullptr), dirty(true) {}
+WvmClassifier::~WvmClassifier() { fd_wvm_destroy(handle); }
+void WvmClassifier::setModel(const Model& m) {
+    model = m;
+    bias = m.bias;
+    setNumUsedFilters(m.num_used);
+    setLimitReliabilityFilter(limitReliabilityFilter);
+}
+void WvmClassifier::setNumUsedFilters(int var) {   // WvmClassifier.cpp:151-158
+    model.num_used = (var > model.num_filters || var == 0) ? model.num_filters : var;
+    dirty = true;
+}
+void WvmClassifier::setLimitReliabilityFilter(float var) {   // WvmClassifier.cpp:165-181
+    limitReliabilityFilter = var;
+    hierarchicalThresholds = model.thresholdsFromFile;
+    if (var != 0.0f)
+        for (float& t : hierarchicalThresholds) t = t + limitReliabilityFilter;
+    dirty = true;
+}
+const fd_wvm* WvmClassifier::native(double la, double lb) const {
+    if (dirty || !handle) {
+        fd_wvm_destroy(handle);
+        handle = nullptr;
+        fd_wvm_model m;
+        std::memset(&m, 0, sizeof(m));
+        m.filter_w = model.filter_w; m.filter_h = model.filter_h; m.num_filters = model.num_filters; m.num_used = model.num_used;
+        m.num_per_level = model.num_per_level; m.basis_param = model.basis_param; m.bias = model.bias;
+        m.thresholds = hierarchicalThresholds.data(); m.hk_weights = model.hk_weights.data(); m.pp = model.pp.data();
+        m.val_off = model.val_off.data(); m.val = model.val.data(); m.rec_off = model.rec_off.data(); m.rects = model.rects.data();
+        m.logistic_a = la; m.logistic_b = lb;
+        check(fd_wvm_create(context(), &m, &handle));
+        dirty = false;
+    }
+    return handle;
+}
+std::pair<int, double> WvmClassifier::computeHyperplaneDistance(const Mat& featureVector) const {
+    if (featureVector.depth() != CV_8U || (int)(featureVector.total() * featureVector.channels()) != model.filter_w * model.filter_h)
+        throw std::invalid_argument("WvmClassifier: feature vector must be a CV_8U patch of the filter size");
+    Mat x = contiguous(featureVector);
+    int32_t level = 0;
+    float fout = 0;
+    check(fd_wvm_eval_batch(context(), native(), x.data, 1, &level, &fout));
+    return std::make_pair((int)level, (double)fout);
+}
+bool WvmClassifier::classify(std::pair<int, double> lad) const {   // WvmClassifier.cpp:91-98
+    return lad.first + 1 == model.num_filters && lad.second >= hierarchicalThresholds[lad.first];
+}
+bool WvmClassifier::classify(const Mat& featureVector) const { return classify(computeHyperplaneDistance(featureVector)); }
+std::pair<bool, double> WvmClassifier::getConfidence(const Mat& featureVector) const {
+    auto lad = computeHyperplaneDistance(featureVector);
+    return classify(lad) ? std::make_pair(true, lad.second) : std::make_pair(false, -lad.second);
+}
+// Binary model file "FDWVM1": int32 header {fw, fh, F, used, nper, nval, nrect}, float basis, float bias,
+// then thresholds[F] f32, hk[F*F] f32, pp[F] f64, val_off[F+1] i32, val[nval] f64, rec_off[nval+1] i32, rects[4*nrect] u8
+shared_ptr<WvmClassifier> WvmClassifier::loadFromFile(const string& filename) {
+    std::ifstream f(filename.c_str(), std::ios::binary);
+    if (!f.is_open()) throw std::invalid_argument("WvmClassifier: Could not open the provided classifier filename: " + filename);
+    char magic[8];
+    f.read(magic, 8);
+    if (std::memcmp(magic, "FDWVM1\0\0", 8) != 0) throw std::runtime_error("WvmClassifier: not a FDWVM1 model file: " + filename);
+    int32_t hdr[7];
+    f.read((char*)hdr, sizeof(hdr));
+    Model m;
+    m.filter_w = hdr[0]; m.filter_h = hdr[1]; m.num_filters = hdr[2]; m.num_used = hdr[3]; m.num_per_level = hdr[4];
+    const int nval = hdr[5], nrect = hdr[6], F = m.num_filters;
+    if (F < 1 || nval < F || nrect < 0) throw std::runtime_error("WvmClassifier: corrupt model header");
+    f.read((char*)&m.basis_param, 4);
+    f.read((char*)&m.bias, 4);
+    m.thresholdsFromFile.resize(F); m.hk_weights.resize((size_t)F * F); m.pp.resize(F); m.val_off.resize(F + 1); m.val.resize(nval);
+    m.rec_off.resize(nval + 1); m.rects.resize((size_t)4 * nrect);
+    f.read((char*)m.thresholdsFromFile.data(), 4 * F);
+    f.read((char*)m.hk_weights.data(), 4 * (size_t)F * F);
+    f.read((char*)m.pp.data(), 8 * F);
+    f.read((char*)m.val_off.data(), 4 * (F + 1));
+    f.read((char*)m.val.data(), 8 * nval);
+    f.read((char*)m.rec_off.data(), 4 * (nval + 1));
+    f.read((char*)m.rects.data(), 4 * (size_t)nrect);
+    if (!f) throw std::runtime_error("WvmClassifier: truncated model file: " + filename);
+    auto wvm = make_shared<WvmClassifier>();
+    wvm->setModel(m);
+    return wvm;
+}
+
+std::pair<bool, double> ProbabilisticWvmClassifier::getProbability(const Mat& featureVector) const {
+    return getProbability(wvm->computeHyperplaneDistance(featureVector));
+}
+std::pair<bool, double> ProbabilisticWvmClassifier::getProbability(std::pair<int, double> lad) const {   // ProbabilisticWvmClassifier.cpp:52
+    double probability = 1.0f / (1.0f + std::exp(logisticA + logisticB * lad.second));
+    return std::make_pair(wvm->classify(lad), probability);
+}
+shared_ptr<ProbabilisticWvmClassifier> ProbabilisticWvmClassifier::load(const boost::property_tree::ptree& subtree) {
+    auto wvm = WvmClassifier::loadFromFile(subtree.get<string>("classifierFile"));
+    auto pwvm = make_shared<ProbabilisticWvmClassifier>(wvm, subtree.get("logisticA", 0.00556), subtree.get("logisticB", -2.95));
+    pwvm->getWvm()->setLimitReliabilityFilter(subtree.get("threshold", 0.0f));
+    return pwvm;
+}
+
+}  // namespace classification
+
+// =================================================================================================
+namespace detection {
+using classification::ProbabilisticSvmClassifier;
+using classification::ProbabilisticWvmClassifier;
+using imageprocessing::DirectPyramidFeatureExtractor;
+using imageprocessing::Patch;
+
+static shared_ptr<ClassifiedPatch> to_patch(const fd_detection& d) {
+    return make_shared<ClassifiedPatch>(make_shared<Patch>(d.cx, d.cy, d.w, d.h, Mat()), d.positive != 0, d.probability);
+}
+static fd_detection from_patch(const ClassifiedPatch& p) {
+    fd_detection d;
+    std::memset(&d, 0, sizeof(d));
+    d.cx = p.getPatch()->getX(); d.cy = p.getPatch()->getY(); d.w = p.getPatch()->getWidth(); d.h = p.getPatch()->getHeight();
+    d.positive = p.isPositive(); d.probability = p.getProbability();
+    return d;
+}
+
+vector<shared_ptr<ClassifiedPatch>> OverlapElimination::eliminate(vector<shared_ptr<ClassifiedPatch>>& classifiedPatches) {
+    vector<shared_ptr<ClassifiedPatch>> out;
+    if (classifiedPatches.empty()) return out;
+    vector<fd_detection> dets;
+    for (const auto& p : classifiedPatches) dets.push_back(from_patch(*p));
+    vector<int32_t> keep(dets.size());
+    int n = 0;
+    if (fd_overlap_elimination(dets.data(), (int)dets.size(), dist, ratio, keep.data(), &n) != FD_OK)
+        throw std::runtime_error("OverlapElimination: invalid arguments");
+    for (int i = 0; i < n; ++i) out.push_back(classifiedPatches[keep[i]]);
+    return out;
+}
+
+SlidingWindowDetector::SlidingWindowDetector(shared_ptr<classification::ProbabilisticClassifier> classifier,
+                                             shared_ptr<imageprocessing::PyramidFeatureExtractor> featureExtractor, int sx, int sy)
+    : classifier(classifier), featureExtractor(featureExtractor), stepSizeX(sx), stepSizeY(sy) {}
+
+vector<shared_ptr<ClassifiedPatch>> SlidingWindowDetector::detect(const cv::Rect* roi) const {
+    vector<shared_ptr<ClassifiedPatch>> out;
+    auto direct = std::dynamic_pointer_cast<DirectPyramidFeatureExtractor>(featureExtractor);
+    auto pwvm = std::dynamic_pointer_cast<ProbabilisticWvmClassifier>(classifier);
+    auto psvm = std::dynamic_pointer_cast<ProbabilisticSvmClassifier>(classifier);
+    int r[4] = {0, 0, 0, 0};
+    if (roi) { r[0] = roi->x; r[1] = roi->y; r[2] = roi->width; r[3] = roi->height; }
+    if (direct && pwvm && direct->hasHistEq64()) {   // fused extract + HistEq64 + WVM cascade
+        const fd_wvm* w = pwvm->getWvm()->native(pwvm->getLogisticA(), pwvm->getLogisticB());
+        int64_t cnt = 0, cap = 1 << 16;
+        vector<fd_detection> dets((size_t)cap);
+        int rc = fd_detect_wvm(context(), direct->getPyramid()->native(), w, stepSizeX, stepSizeY, roi ? r : nullptr, dets.data(), cap, &cnt, nullptr, nullptr);
+        if (rc == FD_ERR_CAPACITY) {
+            dets.resize((size_t)cnt);
+            rc = fd_detect_wvm(context(), direct->getPyramid()->native(), w, stepSizeX, stepSizeY, roi ? r : nullptr, dets.data(), cnt, &cnt, nullptr, nullptr);
+        }
+        check(rc);
+        for (int64_t i = 0; i < cnt; ++i) out.push_back(to_patch(dets[i]));
+        return out;
+    }
+    if (direct && psvm && direct->getHogFilter() && !roi) {   // fused HOG + MFMA RBF-SVM
+        auto hog = direct->getHogFilter();
+        fd_hog_params hp = {direct->getPatchWidth(), direct->getPatchHeight(), stepSizeX, stepSizeY, hog->binCount, hog->cellSize, hog->blockSize,
+                            hog->signedAndUnsigned};
+        const fd_svm* s = psvm->getSvm()->native(psvm->getLogisticA(), psvm->getLogisticB());
+        int64_t cnt = 0, cap = 1 << 16;
+        vector<fd_detection> dets((size_t)cap);
+        int rc = fd_detect_hog_svm(context(), direct->getPyramid()->native(), s, &hp, dets.data(), cap, &cnt, nullptr);
+        if (rc == FD_ERR_CAPACITY) {
+            dets.resize((size_t)cnt);
+            rc = fd_detect_hog_svm(context(), direct->getPyramid()->native(), s, &hp, dets.data(), cnt, &cnt, nullptr);
+        }
+        check(rc);
+        for (int64_t i = 0; i < cnt; ++i) out.push_back(to_patch(dets[i]));
+        return out;
+    }
+    // generic composition (SlidingWindowDetector.cpp:87-98): extract all, classify each through the per-Mat interface
+    auto patches = roi ? featureExtractor->extract(stepSizeX, stepSizeY, *roi) : featureExtractor->extract(stepSizeX, stepSizeY);
+    for (auto& p : patches) {
+        auto res = classifier->getProbability(p->getData());
+        if (res.first) out.push_back(make_shared<ClassifiedPatch>(p, res));
+    }
+    return out;
+}
+vector<shared_ptr<ClassifiedPatch>> SlidingWindowDetector::detect(const Mat& image) {
+    featureExtractor->update(image);
+    return detect((const cv::Rect*)nullptr);
+}
+vector<shared_ptr<ClassifiedPatch>> SlidingWindowDetector::detect(const Mat& image, const cv::Rect& roi) {
+    featureExtractor->update(image);
+    return detect(&roi);
+}
+vector<shared_ptr<ClassifiedPatch>> SlidingWindowDetector::detect(shared_ptr<imageprocessing::VersionedImage> image) {
+    featureExtractor->update(image);
+    return detect((const cv::Rect*)nullptr);
+}
+
+FiveStageSlidingWindowDetector::FiveStageSlidingWindowDetector(shared_ptr<SlidingWindowDetector> swd, shared_ptr<OverlapElimination> oe,
+                                                               shared_ptr<classification::ProbabilisticClassifier> strong)
+    : slidingWindowDetector(swd), overlapElimination(oe), strongClassifier(strong) {}
+
+vector<shared_ptr<ClassifiedPatch>> FiveStageSlidingWindowDetector::run(const Mat& image, const cv::Rect* roi) {
+    auto direct = std::dynamic_pointer_cast<DirectPyramidFeatureExtractor>(slidingWindowDetector->getPyramidFeatureExtractor());
+    auto pwvm = std::dynamic_pointer_cast<ProbabilisticWvmClassifier>(slidingWindowDetector->getClassifier());
+    auto psvm = std::dynamic_pointer_cast<ProbabilisticSvmClassifier>(strongClassifier);
+    if (!direct || !pwvm || !psvm || !direct->hasHistEq64())
+        throw std::logic_error("FiveStageSlidingWindowDetector: this backend needs DirectPyramidFeatureExtractor + HistEq64Filter, a "
+                               "ProbabilisticWvmClassifier first stage and a ProbabilisticSvmClassifier second stage (ffpDetectApp.cpp:398-419)");
+    direct->update(image);
+    int r[4] = {0, 0, 0, 0};
+    if (roi) { r[0] = roi->x; r[1] = roi->y; r[2] = roi->width; r[3] = roi->height; }
+    int cnt = 0, cap = 4096;
+    vector<fd_detection> dets((size_t)cap);
+    int rc = fd_detect_five_stage(context(), direct->getPyramid()->native(), pwvm->getWvm()->native(pwvm->getLogisticA(), pwvm->getLogisticB()),
+                                  psvm->getSvm()->native(psvm->getLogisticA(), psvm->getLogisticB()), overlapElimination->getDist(),
+                                  overlapElimination->getRatio(), slidingWindowDetector->getStepSizeX(), slidingWindowDetector->getStepSizeY(),
+                                  roi ? r : nullptr, dets.data(), cap, &cnt, nullptr);
+    if (rc == FD_ERR_CAPACITY) {
+        dets.resize((size_t)cnt);
+        rc = fd_detect_five_stage(context(), direct->getPyramid()->native(), pwvm->getWvm()->native(), psvm->getSvm()->native(),
+                                  overlapElimination->getDist(), overlapElimination->getRatio(), slidingWindowDetector->getStepSizeX(),
+                                  slidingWindowDetector->getStepSizeY(), roi ? r : nullptr, dets.data(), cnt, &cnt, nullptr);
+    }
+    check(rc);
+    vector<shared_ptr<ClassifiedPatch>> out;
+    for (int i = 0; i < cnt; ++i) out.push_back(to_patch(dets[i]));
+    return out;
+}
+vector<shared_ptr<ClassifiedPatch>> FiveStageSlidingWindowDetector::detect(const Mat& image) { return run(image, nullptr); }
+vector<shared_ptr<ClassifiedPatch>> FiveStageSlidingWindowDetector::detect(const Mat& image, const cv::Rect& roi) { return run(image, &roi); }
+vector<shared_ptr<ClassifiedPatch>> FiveStageSlidingWindowDetector::detect(shared_ptr<imageprocessing::VersionedImage>) {
+    // FiveStageSlidingWindowDetector.cpp:324-329: "not yet implemented for a VersionedImage", returns empty
+    return vector<shared_ptr<ClassifiedPatch>>();
+}
+
+}  // namespace detection
+
+// =================================================================================================
+namespace superviseddescent {
+
+Mat VlHogDescriptorExtractor::getDescriptors(const Mat image, vector<cv::Point2f> locations, int windowSizeHalf) {
+    if (image.channels() != 1 || image.depth() != CV_8U)
+        throw std::invalid_argument("VlHogDescriptorExtractor: this backend expects the CV_8UC1 (gray) image the callers pass (detect-landmarks.cpp:245)");
+    Mat img = contiguous(image);
+    const int n = (int)locations.size();
+    vector<float> px(n), py(n);
+    for (int i = 0; i < n; ++i) { px[i] = locations[i].x; py[i] = locations[i].y; }
+    const int variant = hogType == VlHogType::Uoctti ? 1 : 0;
+    int len = 0;
+    check(fd_sdm_descriptors(context(), img.data, img.cols, img.rows, px.data(), py.data(), n, windowSizeHalf, variant, numCells, cellSize, numBins, nullptr, &len));
+    Mat out(n, len, CV_32FC1);
+    if (n) check(fd_sdm_descriptors(context(), img.data, img.cols, img.rows, px.data(), py.data(), n, windowSizeHalf, variant, numCells, cellSize, numBins,
+                                    out.ptr<float>(0), &len));
+    return out;
+}
+string VlHogDescriptorExtractor::getParameterString() const {
+    std::ostringstream s;
+    s << "numCells " << numCells << " cellSize " << cellSize << " numBins " << numBins;
+    return s.str();
+}
+
+SdmLandmarkModel::SdmLandmarkModel(Mat mean, vector<string> ids, vector<Mat> regs, vector<shared_ptr<DescriptorExtractor>> ex, vector<string> types)
+    : meanLandmarks(mean), landmarkIdentifier(ids), regressorData(regs), descriptorExtractors(ex), descriptorTypes(types) {}
+Mat SdmLandmarkModel::getMeanShape() const {   // SdmLandmarkModel.cpp:53-56: clone().t()
+    const int n = meanLandmarks.cols;
+    Mat col(n, 1, CV_32FC1);
+    for (int i = 0; i < n; ++i) col.at<float>(i, 0) = meanLandmarks.at<float>(0, i);
+    return col;
+}
+vector<cv::Point2f> SdmLandmarkModel::getMeanAsPoints() const {
+    vector<cv::Point2f> pts;
+    const int L = getNumLandmarks();
+    for (int i = 0; i < L; ++i) pts.push_back(cv::Point2f(meanLandmarks.at<float>(0, i), meanLandmarks.at<float>(0, i + L)));
+    return pts;
+}
+cv::Point2f SdmLandmarkModel::getLandmarkAsPoint(string id, Mat inst) const {
+    auto it = std::find(landmarkIdentifier.begin(), landmarkIdentifier.end(), id);
+    if (it == landmarkIdentifier.end()) throw std::invalid_argument("SdmLandmarkModel: unknown landmark " + id);
+    const int index = (int)(it - landmarkIdentifier.begin()), L = getNumLandmarks();
+    if (inst.empty()) return cv::Point2f(meanLandmarks.at<float>(0, index), meanLandmarks.at<float>(0, index + L));
+    return cv::Point2f(inst.at<float>(index), inst.at<float>(index + L));
+}
+void SdmLandmarkModel::save(string filename, string comment) {   // SdmLandmarkModel.cpp:98-128
+    std::ofstream file(filename.c_str());
+    file << "# " << comment << std::endl;
+    file << "numLandmarks " << getNumLandmarks() << std::endl;
+    for (const auto& id : landmarkIdentifier) file << id << std::endl;
+    file << std::setprecision(9);
+    for (int i = 0; i < 2 * getNumLandmarks(); ++i) file << meanLandmarks.at<float>(0, i) << std::endl;
+    file << "numCascadeSteps " << getNumCascadeSteps() << std::endl;
+    for (int s = 0; s < getNumCascadeSteps(); ++s) {
+        const Mat& R = regressorData[s];
+        file << "cascadeStep " << s << " rows " << R.rows << " cols " << R.cols << std::endl;
+        file << "descriptorType " << descriptorTypes[s] << std::endl;
+        file << "descriptorPostprocessing none" << std::endl;
+        file << "descriptorParameters " << descriptorExtractors[s]->getParameterString() << std::endl;
+        for (int r = 0; r < R.rows; ++r) {
+            for (int c = 0; c < R.cols; ++c) file << R.at<float>(r, c) << " ";
+            file << std::endl;
+        }
+    }
+}
+static vector<string> split_ws(const string& line) {
+    vector<string> out;
+    std::istringstream ss(line);
+    string t;
+    while (std::getline(ss, t, ' ')) out.push_back(t);
+    return out;
+}
+static void chomp(string& s) { while (!s.empty() && s.back() == '\r') s.pop_back(); }
+SdmLandmarkModel SdmLandmarkModel::load(string filename) {   // SdmLandmarkModel.cpp:130-233
+    SdmLandmarkModel model;
+    std::ifstream file(filename.c_str());
+    if (!file.is_open()) throw std::runtime_error("Given SDM model file could not be opened: " + filename);
+    string line;
+    std::getline(file, line);   // description
+    std::getline(file, line); chomp(line);
+    const int L = std::stoi(split_ws(line).at(1));
+    for (int i = 0; i < L; ++i) { std::getline(file, line); chomp(line); model.landmarkIdentifier.push_back(line); }
+    model.meanLandmarks = Mat(1, 2 * L, CV_32FC1);
+    for (int i = 0; i < 2 * L; ++i) { std::getline(file, line); chomp(line); model.meanLandmarks.at<float>(0, i) = std::stof(line); }
+    std::getline(file, line); chomp(line);
+    const int S = std::stoi(split_ws(line).at(1));
+    for (int s = 0; s < S; ++s) {
+        std::getline(file, line); chomp(line);
+        auto hdr = split_ws(line);
+        const int rows = std::stoi(hdr.at(3)), cols = std::stoi(hdr.at(5));
+        std::getline(file, line); chomp(line);
+        const string type = split_ws(line).at(1);
+        std::getline(file, line);   // descriptorPostprocessing
+        std::getline(file, line); chomp(line);
+        auto par = split_ws(line);
+        if (type == "vlhog-dt") {
+            if (par.size() != 7) throw std::logic_error("descriptorParameters must contain numCells, cellSize and numBins.");
+            model.descriptorExtractors.push_back(make_shared<VlHogDescriptorExtractor>(VlHogDescriptorExtractor::VlHogType::DalalTriggs, std::stoi(par[2]),
+                                                                                       std::stoi(par[4]), std::stoi(par[6])));
+        } else if (type == "vlhog-uoctti") {
+            if (par.size() <= 2) model.descriptorExtractors.push_back(make_shared<VlHogDescriptorExtractor>(VlHogDescriptorExtractor::VlHogType::Uoctti));
+            else if (par.size() == 7)
+                model.descriptorExtractors.push_back(make_shared<VlHogDescriptorExtractor>(VlHogDescriptorExtractor::VlHogType::Uoctti, std::stoi(par[2]),
+                                                                                           std::stoi(par[4]), std::stoi(par[6])));
+            else throw std::logic_error("descriptorParameters must either be empty (=face-size adaptive parameters) or contain numCells, cellSize and numBins.");
+        } else {
+            throw std::logic_error("descriptorType does not match 'vlhog-dt' or 'vlhog-uoctti' (OpenCVSift is not available on this backend).");
+        }
+        model.descriptorTypes.push_back(type);
+        Mat R(rows, cols, CV_32FC1);
+        for (int r = 0; r < rows; ++r) {
+            std::getline(file, line);
+            std::istringstream ss(line);
+            for (int c = 0; c < cols; ++c) ss >> R.at<float>(r, c);
+        }
+        model.regressorData.push_back(R);
+    }
+    return model;
+}
+
+SdmLandmarkModelFitting::SdmLandmarkModelFitting(SdmLandmarkModel m) : model(m), handle(nullptr) {
+    const int L = model.getNumLandmarks(), S = model.getNumCascadeSteps();
+    if (S == 0) return;
+    Mat mean = model.getMeanShape();
+    vector<float> meanv(2 * L);
+    for (int i = 0; i < 2 * L; ++i) meanv[i] = mean.at<float>(i, 0);
+    vector<Mat> regs;
+    vector<const float*> R;
+    vector<int32_t> rows;
+    for (int s = 0; s < S; ++s) { regs.push_back(contiguous(model.getRegressorData(s))); R.push_back(regs.back().ptr<float>(0)); rows.push_back(regs.back().rows); }
+    auto vl = std::dynamic_pointer_cast<VlHogDescriptorExtractor>(model.getDescriptorExtractor(0));
+    if (!vl) throw std::logic_error("SdmLandmarkModelFitting: only VlHog descriptors are available on this backend");
+    fd_sdm_model md;
+    md.num_landmarks = L; md.num_steps = S; md.mean = meanv.data(); md.R = R.data(); md.R_rows = rows.data();
+    md.hog_variant = vl->getType() == VlHogDescriptorExtractor::VlHogType::Uoctti ? 1 : 0;
+    check(fd_sdm_create(context(), &md, &handle));
+}
+SdmLandmarkModelFitting::~SdmLandmarkModelFitting() { fd_sdm_destroy(handle); }
+Mat SdmLandmarkModelFitting::alignRigid(Mat modelShape, cv::Rect faceBox) const {   // SdmLandmarkModel.hpp:156-192
+    if (modelShape.cols != 1) throw std::runtime_error("The supplied model shape does not have one column (i.e. it doesn't seem to be a column-vector).");
+    const int L = modelShape.rows / 2;
+    // cv::MatExpr "(x + 0.5f) * w + bx" evaluates as x * float(w) + float(0.5 * w + bx) (convertTo with alpha/beta)
+    const float ax = (float)(double)faceBox.width, bx = (float)(0.5 * faceBox.width + faceBox.x);
+    const float ay = (float)(double)faceBox.height, by = (float)(0.5 * faceBox.height + faceBox.y);
+    for (int i = 0; i < L; ++i) {
+        modelShape.at<float>(i, 0) = modelShape.at<float>(i, 0) * ax + bx;
+        modelShape.at<float>(i + L, 0) = modelShape.at<float>(i + L, 0) * ay + by;
+    }
+    return modelShape;
+}
+vector<Mat> SdmLandmarkModelFitting::optimize(const vector<Mat>& shapes, const vector<Mat>& images) {
+    if (!handle) throw std::logic_error("SdmLandmarkModelFitting: model has no cascade steps");
+    const int B = (int)images.size(), L = model.getNumLandmarks();
+    if (B == 0 || (int)shapes.size() != B) throw std::invalid_argument("SdmLandmarkModelFitting: need one shape per image");
+    const int W = images[0].cols, H = images[0].rows;
+    vector<unsigned char> stack((size_t)B * W * H);
+    vector<float> sh((size_t)B * 2 * L);
+    for (int b = 0; b < B; ++b) {
+        if (images[b].cols != W || images[b].rows != H || images[b].type() != CV_8UC1)
+            throw std::invalid_argument("SdmLandmarkModelFitting: images of a batch must be CV_8UC1 and of equal size");
+        Mat im = contiguous(images[b]);
+        std::memcpy(stack.data() + (size_t)b * W * H, im.data, (size_t)W * H);
+        for (int i = 0; i < 2 * L; ++i) sh[(size_t)b * 2 * L + i] = shapes[b].at<float>(i, 0);
+    }
+    vector<int32_t> status(B);
+    check(fd_sdm_optimize_batch(context(), handle, stack.data(), W, H, B, 0, sh.data(), status.data()));
+    vector<Mat> out;
+    for (int b = 0; b < B; ++b) {
+        if (status[b]) throw std::runtime_error("VlHogDescriptorExtractor: patch window leaves the zero-extended image (cv::Mat roi assertion in the reference)");
+        Mat s(2 * L, 1, CV_32FC1);
+        for (int i = 0; i < 2 * L; ++i) s.at<float>(i, 0) = sh[(size_t)b * 2 * L + i];
+        out.push_back(s);
+    }
+    return out;
+}
+Mat SdmLandmarkModelFitting::optimize(Mat modelShape, Mat image) {
+    return optimize(vector<Mat>{modelShape}, vector<Mat>{image})[0];
+}
+
+}  // namespace superviseddescent

@@ -203,3 +203,75 @@ def make_sdm(seed, L=68, S=4, feat_per_landmark=279, sigma=1e-3):
     F = L * feat_per_landmark
     R = [rng.normal(0, sigma, (F + 1, 2 * L)).astype(np.float32) for _ in range(S)]
     return dict(L=L, S=S, mean=mean, R=R, variant=1)
+
+
+# ---- model / image files read by the C++ host layer (featuredetection_amd/host) -----------------------
+def save_wvm(path, m):
+    """Binary FDWVM1 file (WvmClassifier::loadFromFile): the reference's Matlab .mat models are absent."""
+    import struct
+    F = int(m["num_filters"])
+    val = np.ascontiguousarray(m["val"], np.float64)
+    rects = np.ascontiguousarray(m["rects"], np.uint8).reshape(-1, 4)
+    with open(path, "wb") as f:
+        f.write(b"FDWVM1\0\0")
+        f.write(struct.pack("<7i", int(m["filter_w"]), int(m["filter_h"]), F, int(m["num_used"]), int(m["num_per_level"]), len(val), len(rects)))
+        f.write(struct.pack("<2f", float(m["basis_param"]), float(m["bias"])))
+        f.write(np.ascontiguousarray(m["thresholds"], np.float32).tobytes())
+        f.write(np.ascontiguousarray(m["hk_weights"], np.float32).tobytes())
+        f.write(np.ascontiguousarray(m["pp"], np.float64).tobytes())
+        f.write(np.ascontiguousarray(m["val_off"], np.int32).tobytes())
+        f.write(val.tobytes())
+        f.write(np.ascontiguousarray(m["rec_off"], np.int32).tobytes())
+        f.write(rects.tobytes())
+
+
+def save_svm_text(path, m, rows=None, cols=None):
+    """Text format of SvmClassifier::store + 'Logistic a b' (SvmClassifier.cpp:68-107, ProbabilisticSvmClassifier.cpp:65-68)."""
+    sv = np.asarray(m["sv"])
+    n, d = sv.shape
+    rows = rows or 1
+    cols = cols or d // rows
+    depth = 0 if sv.dtype == np.uint8 else 5
+    kname = {0: "Linear", 1: "Polynomial %d %.17g %.17g" % (int(m.get("p2", 2)), m.get("p1", 0.0), m.get("p0", 1.0)),
+             2: "RBF %.17g" % m.get("p0", 0.0), 3: "HIK"}[int(m["kernel"])]
+    with open(path, "w") as f:
+        f.write("Kernel %s\n" % kname)
+        f.write("Bias %.9g\n" % float(m["bias"]))
+        f.write("Coefficients %d\n" % n)
+        for c in np.asarray(m["coeff"], np.float32):
+            f.write("%.9g\n" % c)
+        f.write("SupportVectors %d %d %d 1 %d\n" % (n, rows, cols, depth))
+        for s in sv:
+            f.write(" ".join(("%d" % v) if depth == 0 else ("%.9g" % v) for v in s) + "\n")
+        f.write("Logistic %.17g %.17g\n" % (m.get("logistic_a", 0.00556), m.get("logistic_b", -2.95)))
+
+
+def save_pnm(path, img):
+    img = np.ascontiguousarray(img, np.uint8)
+    with open(path, "wb") as f:
+        if img.ndim == 2:
+            f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+            f.write(img.tobytes())
+        else:  # BGR in memory -> RGB in the file
+            f.write(b"P6\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+            f.write(img[..., ::-1].tobytes())
+
+
+def save_sdm_text(path, m):
+    """Text format of SdmLandmarkModel::save (SdmLandmarkModel.cpp:98-128), adaptive vlhog-uoctti descriptors."""
+    L = int(m["L"])
+    with open(path, "w") as f:
+        f.write("# synthetic SDM model\n")
+        f.write("numLandmarks %d\n" % L)
+        for i in range(L):
+            f.write("lm%d\n" % i)
+        for v in np.asarray(m["mean"], np.float32):
+            f.write("%.9g\n" % v)
+        f.write("numCascadeSteps %d\n" % int(m["S"]))
+        for s, R in enumerate(m["R"]):
+            f.write("cascadeStep %d rows %d cols %d\n" % (s, R.shape[0], R.shape[1]))
+            f.write("descriptorType vlhog-uoctti\n")
+            f.write("descriptorPostprocessing none\n")
+            f.write("descriptorParameters \n")
+            for row in np.asarray(R, np.float32):
+                f.write(" ".join("%.9g" % v for v in row) + " \n")

@@ -98,6 +98,10 @@ typedef struct {
 } fd_wvm_model;
 int fd_wvm_create(fd_ctx* ctx, const fd_wvm_model* model, fd_wvm** out);
 void fd_wvm_destroy(fd_wvm* m);
+/* WvmClassifier::computeHyperplaneDistance (WvmClassifier.cpp:100-149) for n feature vectors (already
+ * HistEq64-filtered filter_w x filter_h u8 patches, contiguous, host buffers): (lastLevel, fout) each.
+ * Backs the per-Mat BinaryClassifier::classify / ProbabilisticClassifier::getProbability. */
+int fd_wvm_eval_batch(fd_ctx* ctx, const fd_wvm* m, const uint8_t* patches, int64_t n, int32_t* out_level, float* out_score);
 
 /* ---- classification::SvmClassifier / ProbabilisticSvmClassifier with Kernel{Linear,Polynomial,Rbf,HIK} */
 enum { FD_KERNEL_LINEAR = 0, FD_KERNEL_POLY = 1, FD_KERNEL_RBF = 2, FD_KERNEL_HIK = 3 };
@@ -199,6 +203,10 @@ int fd_sdm_descriptors(fd_ctx* ctx, const uint8_t* gray, int width, int height, 
  * (the reference would throw). */
 int fd_sdm_fit_batch(fd_ctx* ctx, const fd_sdm* m, const uint8_t* gray_images, int width, int height, int batch,
                      const int32_t* face_boxes, int images_on_device, float* shapes_out, int32_t* status_out);
+/* SdmLandmarkModelFitting::optimize only (SdmLandmarkModel.hpp:199-256): shapes_inout holds the B initial
+ * shapes (2L floats each: x0..xL-1, y0..yL-1) and receives the optimised ones. */
+int fd_sdm_optimize_batch(fd_ctx* ctx, const fd_sdm* m, const uint8_t* gray_images, int width, int height, int batch,
+                          int images_on_device, float* shapes_inout, int32_t* status_out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,82 @@
+"""N>1 path on CPU: two gloo ranks shard a batch of images (rank r takes images r, r+2, ...), run a
+CPU stand-in for the per-image detector (the oracle) and exchange ONE gather of detection records.
+The gathered, ordered record list must equal the single-process result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _detect_image(i):
+    """deterministic fake detector: image id -> structured detections"""
+    from featuredetection_amd import capi
+    rng = np.random.default_rng(1000 + i)
+    n = int(rng.integers(0, 6))
+    d = np.zeros(n, capi.DET_DTYPE)
+    d["cx"], d["cy"] = rng.integers(0, 640, n), rng.integers(0, 480, n)
+    d["w"] = d["h"] = rng.integers(80, 200, n)
+    d["score"], d["probability"] = rng.random(n), rng.random(n)
+    return d
+
+
+def _worker(rank, world, port, nimages, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from featuredetection_amd import parallel
+    mine = parallel.shard_indices(nimages, rank, world)
+    recs = [parallel.pack_records(np.full(len(d), i), np.zeros(len(d)), d) for i in mine for d in [_detect_image(i)]]
+    local = np.concatenate(recs) if recs else np.zeros((0, parallel.RECORD_FIELDS))
+    allr, trunc = parallel.gather_records(local, cap=256)
+    if rank == 0:
+        q.put((allr, trunc))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_and_gather_world2():
+    from featuredetection_amd import parallel
+    nimages, world = 11, 2
+    assert parallel.shard_indices(nimages, 0, 2) == [0, 2, 4, 6, 8, 10]
+    assert parallel.shard_indices(nimages, 1, 2) == [1, 3, 5, 7, 9]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nimages, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    allr, trunc = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert not trunc
+    ref = [parallel.pack_records(np.full(len(d), i), np.zeros(len(d)), d) for i in range(nimages) for d in [_detect_image(i)]]
+    ref = np.concatenate(ref)
+    assert allr.shape == ref.shape
+    assert np.array_equal(allr, ref)   # ordered by image id, original order inside an image
+
+
+def test_gather_single_process_and_truncation():
+    from featuredetection_amd import parallel
+    d = _detect_image(3)
+    local = parallel.pack_records(np.full(len(d), 3), np.zeros(len(d)), d)
+    allr, trunc = parallel.gather_records(local, cap=64)
+    assert np.array_equal(allr, local) and not trunc
+    big = np.zeros((10, parallel.RECORD_FIELDS))
+    allr, trunc = parallel.gather_records(big, cap=4)
+    assert trunc and len(allr) == 4

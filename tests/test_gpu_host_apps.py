@@ -1,0 +1,89 @@
+"""The reference-shaped C++ host layer (featuredetection_amd/host) driven through its example apps:
+ffp_detect_app mirrors ffpDetectApp's object graph (config 1 plumbing), sdm_fit_app the two SDM calls.
+Their printed results must equal the oracle's."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "featuredetection_amd")
+
+
+def _run(args):
+    env = dict(os.environ, LD_LIBRARY_PATH=PKG + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run(args, capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    return r.stdout
+
+
+def test_ffp_detect_app_matches_oracle(tmp_path, oracle, synth, frame640, small_models):
+    app = os.path.join(PKG, "ffp_detect_app")
+    if not os.path.exists(app):
+        pytest.fail("host apps not built (make -C featuredetection_amd/host)")
+    wvm, svm = small_models
+    synth.save_wvm(str(tmp_path / "face.fdwvm"), wvm)
+    synth.save_svm_text(str(tmp_path / "face.svm.txt"), svm, rows=20, cols=20)
+    synth.save_pnm(str(tmp_path / "frame.ppm"), frame640)
+    cfg = """detectors
+{
+    FaceFrontal
+    {
+        landmark "face"
+        type fiveStageCascade ; same keys as ffpDetectApp/FaceFrontal.cfg
+        firstClassifier pwvm
+        {
+            classifierFile %s
+        }
+        secondClassifier psvm
+        {
+            classifierFile %s
+        }
+        pyramid
+        {
+            minScaleFactor 0.05
+            maxScaleFactor 0.16
+            incrementalScaleFactor 0.92
+            patch
+            {
+                width 20
+                height 20
+            }
+        }
+        overlapElimination
+        {
+            dist 5.0
+            ratio 0.0
+        }
+    }
+}
+""" % (tmp_path / "face.fdwvm", tmp_path / "face.svm.txt")
+    (tmp_path / "face.cfg").write_text(cfg)
+    out = _run([app, str(tmp_path / "face.cfg"), str(tmp_path / "frame.ppm")])
+    got = [l.split() for l in out.strip().splitlines()]
+    po = oracle.Pyramid(inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))
+    po.update(frame640)
+    dets, stages = oracle.five_stage(po, oracle.Wvm(wvm), oracle.Svm(svm), 5.0, 0.0, 1, 1, None)
+    assert len(got) == len(dets) > 0
+    for g, d in zip(got, dets):
+        assert g[0] == "FaceFrontal" and g[1] == "face"
+        # Patch::getBounds (Patch.hpp:28-35)
+        assert [int(v) for v in g[2:6]] == [d["cx"] - d["w"] // 2, d["cy"] - d["h"] // 2, d["w"], d["h"]]
+        assert float(g[6]) == d["prob"]
+
+
+def test_sdm_fit_app_matches_oracle(tmp_path, oracle, synth):
+    app = os.path.join(PKG, "sdm_fit_app")
+    if not os.path.exists(app):
+        pytest.fail("host apps not built (make -C featuredetection_amd/host)")
+    model = synth.make_sdm(4, L=20, S=3)
+    # the text file stores 9 significant digits: reload what the app will read
+    synth.save_sdm_text(str(tmp_path / "sdm.txt"), model)
+    gray = synth.make_frame(200, 180, seed=55, channels=1)
+    synth.save_pnm(str(tmp_path / "face.pgm"), gray)
+    out = _run([app, str(tmp_path / "sdm.txt"), str(tmp_path / "face.pgm"), "30", "25", "120", "130"])
+    got = np.array([float(v) for v in out.split()], np.float32)
+    st, ref = oracle.sdm_fit(gray, model, [30, 25, 120, 130])
+    assert st == 0 and got.shape == ref.shape
+    assert np.allclose(got, ref, rtol=1e-4, atol=1e-4), np.abs(got - ref).max()

@@ -137,6 +137,19 @@ def test_wvm_full_size_model_and_other_patch_shapes(oracle, capi, ctx, synth, fr
         wg.close(); pg.close()
 
 
+def test_wvm_eval_batch_per_patch_api(oracle, capi, ctx, small_models):
+    """fd_wvm_eval_batch backs the per-Mat classify()/getProbability() of the reference interface"""
+    wvm, _ = small_models
+    rng = np.random.default_rng(17)
+    patches = np.stack([oracle.histeq64(rng.integers(0, 256, (20, 20), dtype=np.uint8)) for _ in range(300)])
+    wo, wg = oracle.Wvm(wvm), capi.Wvm(ctx, wvm)
+    lv, sc = capi.wvm_eval(ctx, wg, patches)
+    for i in range(len(patches)):
+        l, f = wo.eval(patches[i])
+        assert (l, np.float32(f)) == (lv[i], sc[i]), i
+    wg.close()
+
+
 @pytest.mark.parametrize("kernel,dtype", [(2, 0), (3, 0), (0, 0), (1, 0), (2, 1), (3, 1), (0, 1), (1, 1)])
 def test_svm_distance_batch(oracle, capi, ctx, kernel, dtype):
     rng = np.random.default_rng(kernel * 2 + dtype)
