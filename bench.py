@@ -116,7 +116,7 @@ def main():
         frames = [synth.make_frame(W, H, seed=20260927 + 1000 * rank + i) for i in range(NFRAMES)]
         dframes = [torch.from_numpy(f).to(dev) for f in frames]
         from oracle import pyoracle as O  # only to build the calibration patches identically to tests
-        gray = O.bgr2gray(frames[0])
+        gray = O.bgr2gray(synth.make_frame(640, 480, seed=20260927))   # models calibrated on the config-1 frame, whatever --size is
         calib = synth.random_patches(gray[::4, ::4].copy(), 20, 20, 8000, np.random.default_rng(1))
         wvm_m = synth.make_wvm(7, calib_patches=calib)
         eq = synth.histeq64_np(synth.random_patches(gray[::4, ::4].copy(), 20, 20, 1400, np.random.default_rng(2)))

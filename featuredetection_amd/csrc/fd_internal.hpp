@@ -9,6 +9,11 @@
 #include <stdexcept>
 #include "../../include/fd_hip.h"
 
+struct FdPinned {   // pinned host scratch (allocated lazily): pageable async copies cost ~1 ms each on this stack
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
 struct fd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -18,6 +23,7 @@ struct fd_ctx {
     const char* last_kernel = "";
     float last_kernel_ms = 0.f;
     int num_cus = 256;
+    FdPinned pinned;
 };
 
 struct FdError {
@@ -92,6 +98,19 @@ struct HostBuf {
     }
     template <class T> T* as() const { return (T*)p; }
 };
+
+// pinned scratch of the context, at least `bytes` large
+static inline void* fd_pinned(fd_ctx* ctx, size_t bytes) {
+    if (bytes > ctx->pinned.cap) {
+        if (ctx->pinned.p) HIP_CHECK(hipHostFree(ctx->pinned.p));
+        ctx->pinned.p = nullptr;
+        ctx->pinned.cap = 0;
+        size_t want = bytes + bytes / 2 + 4096;
+        HIP_CHECK(hipHostMalloc(&ctx->pinned.p, want, hipHostMallocDefault));
+        ctx->pinned.cap = want;
+    }
+    return ctx->pinned.p;
+}
 
 static inline int fd_cvRound(double v) { return (int)std::lrint(v); }  // cvRound: half-to-even
 

@@ -424,10 +424,11 @@ int fd_detect_hog_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_ho
         hipLaunchKernelGGL(k_select_positives, dim3((unsigned)std::min<int64_t>((N + 255) / 256, 2048)), dim3(256), 0, st,
                            S.dist.as<double>(), N, fd_svm_threshold(svm), S.pos.as<HogPos>(), S.counter.as<unsigned int>(), pcap);
         HIP_CHECK(hipGetLastError());
-        unsigned int cnt = 0;
-        HIP_CHECK(hipMemcpyAsync(&cnt, S.counter.p, 4, hipMemcpyDeviceToHost, st));
+        unsigned int* hcnt = (unsigned int*)fd_pinned(ctx, 64);
+        HIP_CHECK(hipMemcpyAsync(hcnt, S.counter.p, 4, hipMemcpyDeviceToHost, st));
         if (all_distance) HIP_CHECK(hipMemcpyAsync(all_distance, S.dist.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
+        const unsigned int cnt = *hcnt;
         if (cnt > pcap) FD_THROW(FD_ERR_CAPACITY, "fd_detect_hog_svm: %u positives exceed the device buffer", cnt);
         std::vector<HogPos> raw(cnt);
         if (cnt) HIP_CHECK(hipMemcpy(raw.data(), S.pos.p, sizeof(HogPos) * cnt, hipMemcpyDeviceToHost));

@@ -7,8 +7,11 @@
 #include <map>
 
 // detection::OverlapElimination::eliminate (OverlapElimination.cpp:44-105).  std::sort on the
-// probability only (boost::indirect_iterator + std::greater<ClassifiedPatch>), then greedy erase.
-// Implemented with a "removed" flag instead of vector::erase (same result, O(n^2) compares).
+// probability only (boost::indirect_iterator + std::greater<ClassifiedPatch>), then the greedy erase:
+// an element survives iff no earlier *surviving* element (in sorted order) overlaps it.  The reference
+// is O(n^2) with vector::erase; here survivors are bucketed in a uniform grid whose cell is at least
+// the largest possible distance threshold, so only the 3x3 neighbouring cells are examined.  The
+// result (content and order) is identical for any n.
 void fd_host_overlap_elimination(const fd_detection* in, int n, float distIn, float ratioIn, std::vector<int>& keep) {
     keep.clear();
     if (n <= 0) return;
@@ -17,18 +20,33 @@ void fd_host_overlap_elimination(const fd_detection* in, int n, float distIn, fl
     std::sort(order.begin(), order.end(), [&](int a, int b) { return in[a].probability > in[b].probability; });
     const float dist = distIn;
     const float ratio = ((ratioIn > 0.0f) && (ratioIn <= 1.0f)) ? ratioIn : 0.0f;
-    std::vector<char> removed(n, 0);
-    for (int a = 0; a < n; ++a) {
-        if (removed[a]) continue;
-        const fd_detection& A = in[order[a]];
-        keep.push_back(order[a]);
-        for (int b = a + 1; b < n; ++b) {
-            if (removed[b]) continue;
-            const fd_detection& P = in[order[b]];
-            float d = dist <= 1.0 ? dist * std::max(A.w, P.w) : dist;
-            if ((std::abs(A.cx - P.cx) < d) && (std::abs(A.cy - P.cy) < d) &&
-                (((float)std::min(A.w, P.w) / (float)std::max(A.w, P.w)) > ratio))
-                removed[b] = 1;
+    int maxw = 1;
+    for (int i = 0; i < n; ++i) maxw = std::max(maxw, in[i].w);
+    const float dmax = dist <= 1.0 ? dist * maxw : dist;
+    const int cell = std::max(1, (int)std::ceil(dmax > 0 ? dmax : 1.f));
+    auto cellOf = [&](int v) { return v >= 0 ? v / cell : -((-v + cell - 1) / cell); };
+    std::map<std::pair<int, int>, std::vector<int>> grid;   // accepted elements per cell
+    for (int bi = 0; bi < n; ++bi) {
+        const fd_detection& P = in[order[bi]];
+        const int gx = cellOf(P.cx), gy = cellOf(P.cy);
+        bool removed = false;
+        for (int dy = -1; dy <= 1 && !removed; ++dy)
+            for (int dx = -1; dx <= 1 && !removed; ++dx) {
+                auto it = grid.find({gy + dy, gx + dx});
+                if (it == grid.end()) continue;
+                for (int ai : it->second) {
+                    const fd_detection& A = in[ai];
+                    float d = dist <= 1.0 ? dist * std::max(A.w, P.w) : dist;
+                    if ((std::abs(A.cx - P.cx) < d) && (std::abs(A.cy - P.cy) < d) &&
+                        (((float)std::min(A.w, P.w) / (float)std::max(A.w, P.w)) > ratio)) {
+                        removed = true;
+                        break;
+                    }
+                }
+            }
+        if (!removed) {
+            keep.push_back(order[bi]);
+            grid[{gy, gx}].push_back(order[bi]);
         }
     }
 }

@@ -32,7 +32,7 @@ void fd_svm_generic_launch(fd_ctx* ctx, const fd_svm* m, const void* dfeat, cons
 constexpr int WVM_MAX_LAYERS = 64;
 constexpr int WVM_MAX_DIM = 32;      // patch width/height limit of this kernel
 constexpr int WVM_MAX_VALS = 16;     // grey values per filter
-constexpr int WVM_PJ = 8;            // up to 512 filters
+constexpr int WVM_PJ = 5;            // up to 320 filters (largest cfg-implied WVM: 280)
 
 struct WinLayerDev {
     int32_t bx, by, nx, ny;
@@ -46,6 +46,15 @@ struct WinTable {
     int32_t raw;   // != 0: arena holds `total` contiguous, already equalised patches (fd_wvm_eval_batch)
     int64_t total;
     WinLayerDev l[WVM_MAX_LAYERS];
+};
+
+// Per-level header, fetched with one scalar load
+struct WvmLevelHdr {
+    int32_t nrects, cntval;
+    float thr;
+    int32_t pad;
+    double pp;
+    double pad2;
 };
 
 struct WvmDev {
@@ -62,6 +71,8 @@ struct WvmDev {
     const int32_t* rectBegin;  // [numFilters + 1]
     const uint32_t* rects;     // x1 | y1 << 8 | x2 << 16 | y2 << 24
     const uint8_t* rectV;      // grey-value index v (>= 1) of each rect
+    const uint4* lvlRec;       // [numFilters][64]: lane l -> {rect l, v tag of rect l, val[l] (double bits)}
+    const struct WvmLevelHdr* lvlHdr;   // [numFilters]
 };
 
 struct PosRec {
@@ -73,7 +84,7 @@ struct PosRec {
 struct fd_wvm {
     fd_ctx* ctx;
     WvmDev dev;
-    DevBuf thresholds, wT, pp, valOff, val, rectBegin, rects, rectV;
+    DevBuf thresholds, wT, pp, valOff, val, rectBegin, rects, rectV, lvlRec, lvlHdr;
     double logisticA, logisticB;
     std::vector<float> h_thresholds;
     // scratch reused across calls
@@ -133,6 +144,13 @@ __global__ __launch_bounds__(256) void k_wvm_cascade(const uint8_t* __restrict__
             src = arena + wl.off + (size_t)ly * wl.lw + lx;
             srcStride = wl.lw;
         }
+
+        // ---- 0. level-0 model data: requested now, consumed after the fixed part (latency hidden)
+        uint4 lv = m.lvlRec[lane];
+        WvmLevelHdr hd = m.lvlHdr[0];
+        float wr[WVM_PJ];
+#pragma unroll
+        for (int j = 0; j < WVM_PJ; ++j) wr[j] = (lane + 64 * j) < m.numUsed ? m.wT[lane + 64 * j] : 0.f;
 
         // ---- 1. load the window: lanes 0-31 -> even rows, 32-63 -> odd rows
         unsigned int px[WVM_MAX_DIM / 2];
@@ -201,43 +219,65 @@ __global__ __launch_bounds__(256) void k_wvm_cascade(const uint8_t* __restrict__
         float u = 0.f;  // lane n holds u_kernel_eval[n]
         int level = 0;
         float fout = 0.f;
+        float thr = 0.f;
         for (int k = 0;; ++k) {
             const int n = k % m.numPer;
+            // software pipeline: the (packed) model data of level k+1 is requested before level k is
+            // evaluated; an early exit simply drops it.  One 16-byte load per lane + one scalar header.
+            const int kn = min(k + 1, m.numUsed - 1);
+            const uint4 lvN = m.lvlRec[(size_t)kn * 64 + lane];
+            const WvmLevelHdr hdN = m.lvlHdr[kn];
+            float wrN[WVM_PJ];
+#pragma unroll
+            for (int j = 0; j < WVM_PJ; ++j) wrN[j] = (lane + 64 * j) < m.numUsed ? m.wT[(size_t)kn * m.numFilters + lane + 64 * j] : 0.f;
+
             if (lane < WVM_MAX_VALS) L.sv[lane] = 0;
             wave_sync();
-            const int rb = m.rectBegin[k], re = m.rectBegin[k + 1];
-            for (int r = rb + lane; r < re; r += 64) {
-                const unsigned int rc = m.rects[r];
+            if (lane < hd.nrects) {   // first 64 rects of the level come from the prefetched record
+                const unsigned int rc = lv.x;
                 const int x1 = rc & 255, y1 = (rc >> 8) & 255, x2 = (rc >> 16) & 255, y2 = rc >> 24;
                 int s = (int)L.ii[y2 * pw + x2];
                 if (x1 > 0) s -= (int)L.ii[y2 * pw + x1 - 1];
                 if (y1 > 0) s -= (int)L.ii[(y1 - 1) * pw + x2];
                 if (x1 > 0 && y1 > 0) s += (int)L.ii[(y1 - 1) * pw + x1 - 1];
-                atomicAdd(&L.sv[m.rectV[r]], s);
+                atomicAdd(&L.sv[lv.y], s);
+            }
+            if (hd.nrects > 64) {     // rare: remaining rects straight from the flat arrays
+                const int rb = m.rectBegin[k];
+                for (int r = rb + 64 + lane; r < rb + hd.nrects; r += 64) {
+                    const unsigned int rc = m.rects[r];
+                    const int x1 = rc & 255, y1 = (rc >> 8) & 255, x2 = (rc >> 16) & 255, y2 = rc >> 24;
+                    int s = (int)L.ii[y2 * pw + x2];
+                    if (x1 > 0) s -= (int)L.ii[y2 * pw + x1 - 1];
+                    if (y1 > 0) s -= (int)L.ii[(y1 - 1) * pw + x2];
+                    if (x1 > 0 && y1 > 0) s += (int)L.ii[(y1 - 1) * pw + x1 - 1];
+                    atomicAdd(&L.sv[m.rectV[r]], s);
+                }
             }
             wave_sync();
-            const int v0 = m.valOff[k], cntval = m.valOff[k + 1] - v0;
+            const int cntval = hd.cntval;
             double sum_xp = 0.0;
             int sumv0 = sx_total;
             for (int v = 1; v < cntval; ++v) {
                 const int s = L.sv[v];
                 sumv0 -= s;
-                sum_xp = sum_xp + (double)s * m.val[v0 + v];
+                const double valv = __hiloint2double(__builtin_amdgcn_readlane((int)lv.w, v), __builtin_amdgcn_readlane((int)lv.z, v));
+                sum_xp = sum_xp + (double)s * valv;
             }
-            sum_xp = sum_xp + (double)sumv0 * m.val[v0];
+            const double val0 = __hiloint2double(__builtin_amdgcn_readlane((int)lv.w, 0), __builtin_amdgcn_readlane((int)lv.z, 0));
+            sum_xp = sum_xp + (double)sumv0 * val0;
             sum_xp = sum_xp + (double)readlane_f(u, n);
             const float unew = (float)sum_xp;
             u = (lane == n) ? unew : u;
             double norm = (double)sxx;
             norm = norm - 2 * sum_xp;
-            norm = norm + m.pp[k];
+            norm = norm + hd.pp;
             const float Kk = (float)exp((double)m.negBasis * norm);
-            const float* wrow = m.wT + (size_t)k * m.numFilters;
 #pragma unroll
             for (int j = 0; j < WVM_PJ; ++j) {
                 const int mm = lane + 64 * j;
                 if (mm >= k && mm < m.numUsed) {
-                    const float t = wrow[mm] * Kk;
+                    const float t = wr[j] * Kk;
                     P[j] = P[j] + t;
                 }
             }
@@ -247,10 +287,15 @@ __global__ __launch_bounds__(256) void k_wvm_cascade(const uint8_t* __restrict__
                 if ((k >> 6) == j) res = readlane_f(P[j], k & 63);
             fout = res;
             level = k;
-            if (!(fout >= m.thresholds[k] && k + 1 < m.numUsed)) break;
+            thr = hd.thr;
+            if (!(fout >= thr && k + 1 < m.numUsed)) break;
+            lv = lvN;
+            hd = hdN;
+#pragma unroll
+            for (int j = 0; j < WVM_PJ; ++j) wr[j] = wrN[j];
         }
         // ---- 5. results
-        const bool positive = (level + 1 == m.numFilters) && (fout >= m.thresholds[level]);
+        const bool positive = (level + 1 == m.numFilters) && (fout >= thr);
         if (lane == 0) {
             if (all_level) all_level[wid] = level;
             if (all_fout) all_fout[wid] = fout;
@@ -385,9 +430,10 @@ void fd_wvm_run(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, int sx, int sy, const int
                        m->pos.as<PosRec>(), m->pos_patches.as<uint8_t>(), m->counter.as<unsigned int>(), (unsigned int)m->pos_cap);
     if (time_kernel) HIP_CHECK(hipEventRecord(ctx->ev1, st));
     HIP_CHECK(hipGetLastError());
-    unsigned int cnt = 0;
-    HIP_CHECK(hipMemcpyAsync(&cnt, m->counter.p, 4, hipMemcpyDeviceToHost, st));
+    unsigned int* hcnt = (unsigned int*)fd_pinned(ctx, 64);
+    HIP_CHECK(hipMemcpyAsync(hcnt, m->counter.p, 4, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
+    const unsigned int cnt = *hcnt;
     if (time_kernel) {
         HIP_CHECK(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev0, ctx->ev1));
         ctx->last_kernel = "k_wvm_cascade";
@@ -395,8 +441,10 @@ void fd_wvm_run(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, int sx, int sy, const int
     if ((int64_t)cnt > m->pos_cap)
         FD_THROW(FD_ERR_CAPACITY, "WVM produced %u positives, device buffer holds %lld (set FD_WVM_POS_CAP)", cnt, (long long)m->pos_cap);
     if (cnt) {
-        std::vector<PosRec> raw(cnt);
-        HIP_CHECK(hipMemcpy(raw.data(), m->pos.p, sizeof(PosRec) * cnt, hipMemcpyDeviceToHost));
+        PosRec* hraw = (PosRec*)fd_pinned(ctx, sizeof(PosRec) * (size_t)cnt);
+        HIP_CHECK(hipMemcpyAsync(hraw, m->pos.p, sizeof(PosRec) * cnt, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        std::vector<PosRec> raw(hraw, hraw + cnt);
         std::vector<uint32_t> order(cnt);
         for (uint32_t i = 0; i < cnt; ++i) order[i] = i;
         auto widof = [&](uint32_t i) { return ((uint64_t)raw[i].wid_hi << 32) | raw[i].wid_lo; };
@@ -490,6 +538,23 @@ int fd_wvm_create(fd_ctx* ctx, const fd_wvm_model* md, fd_wvm** out) {
         up(m->rectBegin, rectBegin.data(), sizeof(int32_t) * (F + 1));
         up(m->rects, rects.data(), sizeof(uint32_t) * rects.size());
         up(m->rectV, rectV.data(), rectV.size());
+        {   // packed per-level records for the software-pipelined cascade
+            std::vector<uint32_t> rec((size_t)F * 64 * 4, 0u);
+            std::vector<WvmLevelHdr> hdr(F);
+            for (int k = 0; k < F; ++k) {
+                const int v0 = md->val_off[k], cntval = md->val_off[k + 1] - v0;
+                const int nrects = rectBegin[k + 1] - rectBegin[k];
+                std::memset(&hdr[k], 0, sizeof(WvmLevelHdr));
+                hdr[k].nrects = nrects; hdr[k].cntval = cntval; hdr[k].thr = md->thresholds[k]; hdr[k].pp = md->pp[k];
+                for (int l = 0; l < 64; ++l) {
+                    uint32_t* r4 = &rec[((size_t)k * 64 + l) * 4];
+                    if (l < nrects) { r4[0] = rects[rectBegin[k] + l]; r4[1] = rectV[rectBegin[k] + l]; }
+                    if (l < cntval) { uint64_t bits; std::memcpy(&bits, &md->val[v0 + l], 8); r4[2] = (uint32_t)bits; r4[3] = (uint32_t)(bits >> 32); }
+                }
+            }
+            up(m->lvlRec, rec.data(), sizeof(uint32_t) * rec.size());
+            up(m->lvlHdr, hdr.data(), sizeof(WvmLevelHdr) * hdr.size());
+        }
         WvmDev& d = m->dev;
         d.fw = md->filter_w; d.fh = md->filter_h; d.d = md->filter_w * md->filter_h;
         d.numFilters = F;
@@ -501,6 +566,7 @@ int fd_wvm_create(fd_ctx* ctx, const fd_wvm_model* md, fd_wvm** out) {
         d.thresholds = m->thresholds.as<float>(); d.wT = m->wT.as<float>(); d.pp = m->pp.as<double>();
         d.valOff = m->valOff.as<int32_t>(); d.val = m->val.as<double>(); d.rectBegin = m->rectBegin.as<int32_t>();
         d.rects = m->rects.as<uint32_t>(); d.rectV = m->rectV.as<uint8_t>();
+        d.lvlRec = m->lvlRec.as<uint4>(); d.lvlHdr = m->lvlHdr.as<WvmLevelHdr>();
         m->logisticA = md->logistic_a;
         m->logisticB = md->logistic_b;
         m->h_thresholds.assign(md->thresholds, md->thresholds + F);
@@ -598,11 +664,15 @@ int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const f
             DevBuf& idx = m->all_level;  // reuse scratch (not used by this call)
             idx.reserve(sizeof(uint32_t) * slots.size());
             m->all_fout.reserve(sizeof(double) * slots.size());
-            HIP_CHECK(hipMemcpyAsync(idx.p, slots.data(), sizeof(uint32_t) * slots.size(), hipMemcpyHostToDevice, ctx->stream));
+            // pinned staging: [slots (u32) | distances (f64)]
+            const size_t distOff = (sizeof(uint32_t) * slots.size() + 15) & ~(size_t)15;
+            char* pin = (char*)fd_pinned(ctx, distOff + sizeof(double) * slots.size());
+            std::memcpy(pin, slots.data(), sizeof(uint32_t) * slots.size());
+            HIP_CHECK(hipMemcpyAsync(idx.p, pin, sizeof(uint32_t) * slots.size(), hipMemcpyHostToDevice, ctx->stream));
             fd_svm_generic_launch(ctx, svm, m->pos_patches.p, idx.as<uint32_t>(), (int64_t)m->dev.d, (int64_t)slots.size(), m->all_fout.as<double>());
-            std::vector<double> dist(slots.size());
-            HIP_CHECK(hipMemcpyAsync(dist.data(), m->all_fout.p, sizeof(double) * slots.size(), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipMemcpyAsync(pin + distOff, m->all_fout.p, sizeof(double) * slots.size(), hipMemcpyDeviceToHost, ctx->stream));
             HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            const double* dist = (const double*)(pin + distOff);
             for (size_t i = 0; i < keep.size(); ++i) {
                 if (dist[i] >= (double)fd_svm_threshold(svm)) {  // strongClassifier->classify(): bool only
                     fd_detection d = wvmPos[keep[i]];
