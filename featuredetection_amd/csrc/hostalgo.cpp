@@ -9,7 +9,7 @@
 // detection::OverlapElimination::eliminate (OverlapElimination.cpp:44-105).  std::sort on the
 // probability only (boost::indirect_iterator + std::greater<ClassifiedPatch>), then the greedy erase:
 // an element survives iff no earlier *surviving* element (in sorted order) overlaps it.  The reference
-// is O(n^2) with vector::erase; here survivors are bucketed in a uniform grid whose cell is at least
+// is O(n^2) with vector::erase; here survivors are bucketed in a (hashed) uniform grid whose cell is at least
 // the largest possible distance threshold, so only the 3x3 neighbouring cells are examined.  The
 // result (content and order) is identical for any n.
 void fd_host_overlap_elimination(const fd_detection* in, int n, float distIn, float ratioIn, std::vector<int>& keep) {
@@ -25,16 +25,30 @@ void fd_host_overlap_elimination(const fd_detection* in, int n, float distIn, fl
     const float dmax = dist <= 1.0 ? dist * maxw : dist;
     const int cell = std::max(1, (int)std::ceil(dmax > 0 ? dmax : 1.f));
     auto cellOf = [&](int v) { return v >= 0 ? v / cell : -((-v + cell - 1) / cell); };
-    std::map<std::pair<int, int>, std::vector<int>> grid;   // accepted elements per cell
+    // accepted elements per cell: open-addressed table (key = cell, value = head of a singly linked list)
+    size_t cap = 16;
+    while (cap < (size_t)n * 4) cap <<= 1;
+    std::vector<uint64_t> keys(cap, ~0ull);
+    std::vector<int> head(cap, -1), next(n, -1);
+    auto slotOf = [&](int gy, int gx, bool insert) -> int64_t {
+        const uint64_t key = ((uint64_t)(uint32_t)gy << 32) | (uint32_t)gx;
+        size_t h = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
+        while (keys[h] != ~0ull && keys[h] != key) h = (h + 1) & (cap - 1);
+        if (keys[h] == key) return (int64_t)h;
+        if (!insert) return -1;
+        keys[h] = key;
+        return (int64_t)h;
+    };
+    keep.reserve(n);
     for (int bi = 0; bi < n; ++bi) {
         const fd_detection& P = in[order[bi]];
         const int gx = cellOf(P.cx), gy = cellOf(P.cy);
         bool removed = false;
         for (int dy = -1; dy <= 1 && !removed; ++dy)
             for (int dx = -1; dx <= 1 && !removed; ++dx) {
-                auto it = grid.find({gy + dy, gx + dx});
-                if (it == grid.end()) continue;
-                for (int ai : it->second) {
+                const int64_t h = slotOf(gy + dy, gx + dx, false);
+                if (h < 0) continue;
+                for (int ai = head[h]; ai >= 0; ai = next[ai]) {
                     const fd_detection& A = in[ai];
                     float d = dist <= 1.0 ? dist * std::max(A.w, P.w) : dist;
                     if ((std::abs(A.cx - P.cx) < d) && (std::abs(A.cy - P.cy) < d) &&
@@ -46,7 +60,9 @@ void fd_host_overlap_elimination(const fd_detection* in, int n, float distIn, fl
             }
         if (!removed) {
             keep.push_back(order[bi]);
-            grid[{gy, gx}].push_back(order[bi]);
+            const int64_t h = slotOf(gy, gx, true);
+            next[order[bi]] = head[h];
+            head[h] = order[bi];
         }
     }
 }

@@ -40,6 +40,10 @@ struct SvmDev {
     const void* sv;          // [nsv][dpad]
     const float* coeff;      // [nsv]
     const uint32_t* ss_u32;  // u8 rbf: sum of squares per SV
+    int32_t nsvp;            // u8: nsv padded to a multiple of 64
+    const uint32_t* svT;     // u8: [dpad/4][nsvp], word i of support vector s at svT[i*nsvp + s]
+    const float* coeffP;     // u8: [nsvp], zero padded
+    const uint32_t* ssP;     // u8: [nsvp]
     // MFMA path (f32 RBF)
     int32_t KP;              // padded feature length (multiple of 8)
     int32_t nsv_pad;         // multiple of 256
@@ -53,7 +57,7 @@ struct fd_svm {
     SvmDev dev;
     float threshold;
     double logisticA, logisticB;
-    DevBuf sv, coeff, ss, svFrag, ssF, coeffPad;
+    DevBuf sv, coeff, ss, svFrag, ssF, coeffPad, svT, coeffP, ssP;
     DevBuf feat, dist, idx;  // scratch for batch calls
 };
 
@@ -154,6 +158,90 @@ __global__ __launch_bounds__(256) void k_svm_generic(SvmDev m, const void* __res
     if (lane == 0) red[wave] = acc;
     __syncthreads();
     if (threadIdx.x == 0) out[item] = -(double)m.bias + ((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+
+// u8 features (the HistEq64 patches of the second cascade stage): lane == support vector.  The
+// support vectors are stored word-transposed so that a wave's fetch of word i of 64 consecutive
+// vectors is one coalesced 256-byte access; every lane finishes its own kernel value (exp in fp64),
+// so the transcendental runs 64-wide instead of on one lane per support vector.  Integer SSD /
+// min-sum / dot stay exact (RbfKernel.hpp:78-88, HistogramIntersectionKernel.hpp:60-72).
+constexpr int SU_PB = 2;   // feature vectors per workgroup (each fetched support-vector word is used SU_PB times)
+template <bool HIK>
+__global__ __launch_bounds__(256) void k_svm_u8_lanes(SvmDev m, const void* __restrict__ features, const uint32_t* __restrict__ idx,
+                                                      int64_t feat_stride_bytes, int64_t n, double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double red[SU_PB][4];
+    __shared__ int xxs[SU_PB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nd = m.dpad >> 2;
+    const int64_t item0 = (int64_t)blockIdx.x * SU_PB;
+#pragma unroll
+    for (int p = 0; p < SU_PB; ++p) {
+        const int64_t item = item0 + p;
+        const bool valid = item < n;
+        const int64_t slot = valid ? (idx ? (int64_t)idx[item] : item) : 0;
+        const unsigned char* x = (const unsigned char*)features + slot * feat_stride_bytes;
+        for (int i = threadIdx.x; i < m.dpad; i += 256) smem[p * m.dpad + i] = (valid && i < m.dim) ? x[i] : 0;
+    }
+    __syncthreads();
+    const uint32_t* xs = (const uint32_t*)smem;
+    if (wave < SU_PB) {
+        int xxp = 0;
+        for (int i = lane; i < nd; i += 64) xxp = __builtin_amdgcn_udot4(xs[wave * nd + i], xs[wave * nd + i], xxp, false);
+        xxp = wave_sum_i(xxp);
+        if (lane == 0) xxs[wave] = xxp;
+    }
+    __syncthreads();
+    double acc[SU_PB];
+#pragma unroll
+    for (int p = 0; p < SU_PB; ++p) acc[p] = 0.0;
+    for (int s0 = wave * 64; s0 < m.nsvp; s0 += 256) {
+        const int s = s0 + lane;
+        const uint32_t* colp = m.svT + s;
+        int dot[SU_PB];
+#pragma unroll
+        for (int p = 0; p < SU_PB; ++p) dot[p] = 0;
+#pragma unroll 4
+        for (int i = 0; i < nd; ++i) {
+            const uint32_t b = colp[(size_t)i * m.nsvp];
+#pragma unroll
+            for (int p = 0; p < SU_PB; ++p) {
+                const uint32_t a = xs[p * nd + i];
+                if (HIK) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dot[p] += (int)min((a >> (8 * q)) & 255u, (b >> (8 * q)) & 255u);
+                } else {
+                    dot[p] = __builtin_amdgcn_udot4(a, b, dot[p], false);
+                }
+            }
+        }
+        const double cf = (double)m.coeffP[s];
+        const int ssv = (int)m.ssP[s];
+#pragma unroll
+        for (int p = 0; p < SU_PB; ++p) {
+            double kv;
+            if (m.kernel == FD_KERNEL_RBF) {
+                const int ssd = xxs[p] + ssv - 2 * dot[p];
+                kv = exp(-m.p0 * (double)ssd);
+            } else if (m.kernel == FD_KERNEL_POLY) {
+                kv = powi(m.p0 * (double)dot[p] + m.p1, m.degree);
+            } else {
+                kv = (double)dot[p];
+            }
+            acc[p] += cf * kv;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < SU_PB; ++p) {
+        const double v = wave_sum_d(acc[p]);
+        if (lane == 0) red[p][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < SU_PB && item0 + threadIdx.x < n) {
+        const int p = threadIdx.x;
+        out[item0 + p] = -(double)m.bias + ((red[p][0] + red[p][1]) + (red[p][2] + red[p][3]));
+    }
 }
 
 // ---- dense RBF stage on the f32 MFMA pipe --------------------------------------------------------
@@ -451,6 +539,17 @@ void fd_svm_rbf_mfma_launch(fd_ctx* ctx, const fd_svm* m, const float* xFrag, co
 void fd_svm_generic_launch(fd_ctx* ctx, const fd_svm* m, const void* dfeat, const uint32_t* didx, int64_t stride_bytes,
                            int64_t n, double* dout) {
     if (n <= 0) return;
+    if (m->dev.dtype == FD_DTYPE_U8) {
+        const size_t lb = (size_t)SU_PB * m->dev.dpad;
+        if (lb > 64 * 1024) FD_THROW(FD_ERR_INVALID_ARGUMENT, "feature vector too long (%d)", m->dev.dim);
+        const unsigned grid = (unsigned)((n + SU_PB - 1) / SU_PB);
+        if (m->dev.kernel == FD_KERNEL_HIK)
+            hipLaunchKernelGGL(k_svm_u8_lanes<true>, dim3(grid), dim3(256), lb, ctx->stream, m->dev, dfeat, didx, stride_bytes, n, dout);
+        else
+            hipLaunchKernelGGL(k_svm_u8_lanes<false>, dim3(grid), dim3(256), lb, ctx->stream, m->dev, dfeat, didx, stride_bytes, n, dout);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     const size_t ldsBytes = m->dev.dtype == FD_DTYPE_U8 ? (size_t)m->dev.dpad : (size_t)m->dev.dim * 4;
     if (ldsBytes > 64 * 1024) FD_THROW(FD_ERR_INVALID_ARGUMENT, "feature vector too long (%d)", m->dev.dim);
     hipLaunchKernelGGL(k_svm_generic, dim3((unsigned)n), dim3(256), ldsBytes, ctx->stream, m->dev, dfeat, didx, stride_bytes, dout);
@@ -498,6 +597,25 @@ int fd_svm_create(fd_ctx* ctx, const fd_svm_model* md, fd_svm** out) {
             up(m->ss, ss.data(), sizeof(uint32_t) * ss.size());
             d.sv = m->sv.p;
             d.ss_u32 = m->ss.as<uint32_t>();
+            {   // word-transposed copy for the lane == support-vector kernel
+                d.nsvp = (d.nsv + 63) & ~63;
+                const int nd = d.dpad >> 2;
+                std::vector<uint32_t> svT((size_t)nd * d.nsvp, 0u), ssP(d.nsvp, 0u);
+                std::vector<float> cP(d.nsvp, 0.f);
+                for (int sI = 0; sI < d.nsv; ++sI) {
+                    for (int i = 0; i < nd; ++i) {
+                        uint32_t wv;
+                        std::memcpy(&wv, &sv[(size_t)sI * d.dpad + 4 * i], 4);
+                        svT[(size_t)i * d.nsvp + sI] = wv;
+                    }
+                    ssP[sI] = ss[sI];
+                    cP[sI] = md->coefficients[sI];
+                }
+                up(m->svT, svT.data(), sizeof(uint32_t) * svT.size());
+                up(m->ssP, ssP.data(), sizeof(uint32_t) * ssP.size());
+                up(m->coeffP, cP.data(), sizeof(float) * cP.size());
+                d.svT = m->svT.as<uint32_t>(); d.ssP = m->ssP.as<uint32_t>(); d.coeffP = m->coeffP.as<float>();
+            }
         } else {
             d.dpad = d.dim;
             up(m->sv, md->support_vectors, sizeof(float) * (size_t)d.nsv * d.dim);

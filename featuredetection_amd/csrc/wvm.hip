@@ -17,6 +17,7 @@
 // Roofline: nominally HBM (compulsory bytes/window = layer bytes / windows + 12 B record), in
 // practice VALU/LDS bound; both figures are reported by bench.py --workload wvm.
 #include "fd_internal.hpp"
+#include <chrono>
 #include <algorithm>
 #include <cstring>
 #include <memory>
@@ -38,6 +39,8 @@ struct WinLayerDev {
     int32_t bx, by, nx, ny;
     int32_t lw;
     uint32_t off;
+    uint32_t magic;   // min(floor(2^32 / nx), 2^32 - 1): mulhi(local, magic) is local / nx or one less
+    uint32_t pad;
     int64_t first;
 };
 struct WinTable {
@@ -103,136 +106,189 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-// LDS per wave (bytes): hist 256 + lut 256 + sv 64 + ii 4096 = 4672
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142;
+
+// Inclusive prefix sum inside each 32-lane half of the wave (integer, so the order is free):
+// Hillis-Steele inside the 16-lane DPP rows, then lane 15 of rows 0/2 is added to rows 1/3.
+__device__ __forceinline__ int scan_half(int s) {
+    s += __builtin_amdgcn_update_dpp(0, s, DPP_ROW_SHR1, 0xf, 0xf, true);
+    s += __builtin_amdgcn_update_dpp(0, s, DPP_ROW_SHR2, 0xf, 0xf, true);
+    s += __builtin_amdgcn_update_dpp(0, s, DPP_ROW_SHR4, 0xf, 0xf, true);
+    s += __builtin_amdgcn_update_dpp(0, s, DPP_ROW_SHR8, 0xf, 0xf, true);
+    s += __builtin_amdgcn_update_dpp(0, s, DPP_ROW_BCAST15, 0xa, 0xf, false);
+    return s;
+}
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+// LDS per wave: hist 256 + sv 64 + kernel-value history 1280 + integral image (1600 for 20x20, else 4096)
+template <int PW_, int PH_>
 struct __attribute__((aligned(16))) WaveLds {
     unsigned int hist[64];
-    unsigned int lut[64];
     int sv[WVM_MAX_VALS];
-    unsigned int ii[WVM_MAX_DIM * WVM_MAX_DIM];
+    float kh[64 * WVM_PJ];
+    unsigned int ii[PW_ ? PW_ * PH_ : WVM_MAX_DIM * WVM_MAX_DIM];
 };
 
+// One wave per window.  PW_/PH_ != 0: patch size known at compile time (the 20x20 detectors of the
+// reference configs); 0: sizes from the model, up to 32x32.  RAW: the input is `total` contiguous,
+// already equalised patches (fd_wvm_eval_batch).
+//
+// Lane layout of the patch: lanes 0-31 = columns of the top rows [0, rh), lanes 32-63 = columns of the
+// bottom rows [rh, ph); register j of a lane = row r0 + j.  HistEq64, the integral image and the sum of
+// squares run on registers + DPP; only the histogram, the finished integral image and the per-level
+// grey-value sums go through LDS.
+template <int PW_, int PH_, bool RAW>
 __global__ __launch_bounds__(256) void k_wvm_cascade(const uint8_t* __restrict__ arena, WinTable wt, WvmDev m,
                                                       int32_t* __restrict__ all_level, float* __restrict__ all_fout,
                                                       PosRec* __restrict__ pos, uint8_t* __restrict__ pos_patches,
                                                       unsigned int* __restrict__ pos_count, unsigned int pos_cap) {
-    __shared__ WaveLds lds[4];
+    __shared__ WaveLds<PW_, PH_> lds[4];
+    constexpr int RHMAX = PW_ ? (PH_ + 1) / 2 : WVM_MAX_DIM / 2;
+    constexpr bool ALLROWS = PW_ && (PH_ % 2 == 0);   // every (half, j) is a real row
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    WaveLds& L = lds[wave];
-    const int pw = m.fw, ph = m.fh, d = m.d;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    WaveLds<PW_, PH_>& L = lds[wave];
+    const int pw = PW_ ? PW_ : m.fw, ph = PW_ ? PH_ : m.fh, d = pw * ph;
+    const int rh = PW_ ? RHMAX : (ph + 1) / 2;
     const int half = lane >> 5, col = lane & 31;
+    const bool colok = col < pw;
+    const int r0 = half * rh;
     const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int F = m.numFilters;
+    auto rowok = [&](int j) { return ALLROWS ? true : (j < rh && r0 + j < ph); };
+
+    // layer cursor: window ids only grow, so the layer index only moves forward (all scalar)
+    int li = 0;
+    int64_t nextFirst = (!RAW && wt.n > 1) ? wt.l[1].first : INT64_MAX;
+    if (lane < WVM_MAX_VALS) L.sv[lane] = 0;
+    wave_sync();
 
     for (int64_t wid = (int64_t)blockIdx.x * 4 + wave; wid < wt.total; wid += nwaves) {
-        // ---- window id -> (layer, x, y): count layers whose first window <= wid
         const uint8_t* src;
         int srcStride;
-        if (wt.raw) {
+        if (RAW) {
             src = arena + (size_t)wid * d;
             srcStride = pw;
         } else {
-            int li;
-            {
-                bool le = lane < wt.n && wt.l[lane < wt.n ? lane : 0].first <= wid;
-                li = __popcll(__ballot(le)) - 1;
+            while (wid >= nextFirst) {
+                ++li;
+                nextFirst = (li + 1 < wt.n) ? wt.l[li + 1].first : INT64_MAX;
             }
-            li = __builtin_amdgcn_readfirstlane(li);
-            const WinLayerDev wl = wt.l[li];
-            const int local = (int)(wid - wl.first);
-            const int iy = local / wl.nx, ix = local - iy * wl.nx;
-            const int lx = wl.bx + ix * wt.sx, ly = wl.by + iy * wt.sy;
+            const WinLayerDev& wl = wt.l[li];
+            const unsigned int local = (unsigned int)(wid - wl.first);
+            unsigned int iy = __umulhi(local, wl.magic);   // floor(local / nx) or one less
+            unsigned int ix = local - iy * (unsigned int)wl.nx;
+            if (ix >= (unsigned int)wl.nx) { ix -= wl.nx; ++iy; }
+            const int lx = wl.bx + (int)ix * wt.sx, ly = wl.by + (int)iy * wt.sy;
             src = arena + wl.off + (size_t)ly * wl.lw + lx;
             srcStride = wl.lw;
         }
 
-        // ---- 0. level-0 model data: requested now, consumed after the fixed part (latency hidden)
+        // ---- 0. level-0 model data: requested now, consumed after the fixed part
         uint4 lv = m.lvlRec[lane];
         WvmLevelHdr hd = m.lvlHdr[0];
-        float wr[WVM_PJ];
-#pragma unroll
-        for (int j = 0; j < WVM_PJ; ++j) wr[j] = (lane + 64 * j) < m.numUsed ? m.wT[lane + 64 * j] : 0.f;
+        float w = m.wT[lane];
 
-        // ---- 1. load the window: lanes 0-31 -> even rows, 32-63 -> odd rows
-        unsigned int px[WVM_MAX_DIM / 2];
+        // ---- 1. load the window (columns beyond the patch read column 0 and are masked later)
+        unsigned int px[RHMAX];
+        {
+            const uint8_t* sp = src + (size_t)r0 * srcStride + (colok ? col : 0);
 #pragma unroll
-        for (int j = 0; j < WVM_MAX_DIM / 2; ++j) {
-            int r = half + 2 * j;
-            px[j] = (r < ph && col < pw) ? src[(size_t)r * srcStride + col] : 0u;
+            for (int j = 0; j < RHMAX; ++j) px[j] = rowok(j) ? sp[(size_t)j * srcStride] : 0u;
         }
-        // ---- 2. HistEq64: histogram (lane == bin)
-        L.hist[lane] = 0;
-        wave_sync();
+        if (!RAW) {
+            // ---- 2. HistEq64 (HistEq64Filter.cpp:32-125): histogram with lane == bin
+            L.hist[lane] = 0;
+            wave_sync();
+            if (colok) {
 #pragma unroll
-        for (int j = 0; j < WVM_MAX_DIM / 2; ++j) {
-            int r = half + 2 * j;
-            if (r < ph && col < pw) atomicAdd(&L.hist[px[j] >> 2], 1u);
-        }
-        wave_sync();
-        const float pdf = (float)L.hist[lane] * m.stretch;
-        float c = readlane_f(pdf, 0);
-        float mycdf = c;
-#pragma unroll
-        for (int b = 1; b < 64; ++b) {
-            c = c + readlane_f(pdf, b);
-            mycdf = (lane == b) ? c : mycdf;
-        }
-        L.lut[lane] = (unsigned int)(unsigned char)floor((double)mycdf + 0.5);
-        wave_sync();
-        // ---- 3. equalised patch -> LDS, integral image (raw mode: the input already is the equalised patch)
-#pragma unroll
-        for (int j = 0; j < WVM_MAX_DIM / 2; ++j) {
-            int r = half + 2 * j;
-            if (r < ph && col < pw) {
-                if (!wt.raw) px[j] = L.lut[px[j] >> 2];
-                L.ii[r * pw + col] = px[j];
+                for (int j = 0; j < RHMAX; ++j)
+                    if (rowok(j)) atomicAdd(&L.hist[px[j] >> 2], 1u);
             }
-        }
-        wave_sync();
-        int rowsq = 0;
-        if (lane < ph) {
-            unsigned int s = 0;
-            for (int x = 0; x < pw; ++x) {
-                unsigned int e = L.ii[lane * pw + x];
-                s += e;
-                rowsq += (int)(e * e);
-                L.ii[lane * pw + x] = s;
+            wave_sync();
+            const float pdf = (float)L.hist[lane] * m.stretch;
+            // sequential fp32 cdf: x_t[l] = x_{t-1}[l-1] + pdf[l]; lane l holds cdf[l] from step l on
+            float x = pdf;
+#pragma unroll
+            for (int t = 1; t < 64; ++t) {
+                const float sh = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), DPP_WAVE_SHR1, 0xf, 0xf, true));
+                x = sh + pdf;
             }
-        }
-        wave_sync();
-        if (lane < pw) {
-            unsigned int s = L.ii[lane];
-            for (int y = 1; y < ph; ++y) {
-                s += L.ii[y * pw + lane];
-                L.ii[y * pw + lane] = s;
+            const int lutv = (int)(unsigned int)(unsigned char)floor((double)x + 0.5);
+            // ---- 3. equalise through the crossbar (lane b holds lut[b])
+#pragma unroll
+            for (int j = 0; j < RHMAX; ++j) {
+                const unsigned int e = (unsigned int)__builtin_amdgcn_ds_bpermute((int)(px[j] & 0xfcu), lutv);
+                px[j] = (colok && rowok(j)) ? e : 0u;
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < RHMAX; ++j) px[j] = (colok && rowok(j)) ? px[j] : 0u;
+        }
+        // ---- integral image (IImg.cpp:22-47): row prefix sums by DPP, column sums in registers
+        float sxx;
+        {
+            int s[RHMAX];
+            int qTop[RHMAX], qBot[RHMAX];
+#pragma unroll
+            for (int j = 0; j < RHMAX; ++j) {
+                s[j] = scan_half((int)px[j]);
+                const int q = scan_half((int)(px[j] * px[j]));
+                qTop[j] = __builtin_amdgcn_readlane(q, 31);
+                qBot[j] = __builtin_amdgcn_readlane(q, 63);
+            }
+#pragma unroll
+            for (int j = 1; j < RHMAX; ++j) s[j] += s[j - 1];
+            // column totals of the top half go to the bottom half
+            int topTotal = s[0];
+#pragma unroll
+            for (int j = 1; j < RHMAX; ++j)
+                if (j < rh) topTotal = s[j];
+            topTotal = __builtin_amdgcn_ds_bpermute(col << 2, topTotal);
+            if (half == 0) topTotal = 0;
+            if (colok) {
+#pragma unroll
+                for (int j = 0; j < RHMAX; ++j)
+                    if (rowok(j)) L.ii[(r0 + j) * pw + col] = (unsigned int)(s[j] + topTotal);
+            }
+            // sum of squares: last column, fp32, row by row (IImg.cpp:33-47)
+            sxx = (float)qTop[0];
+#pragma unroll
+            for (int j = 1; j < RHMAX; ++j)
+                if (j < rh) sxx = sxx + (float)qTop[j];
+#pragma unroll
+            for (int j = 0; j < RHMAX; ++j)
+                if (j < rh && rh + j < ph) sxx = sxx + (float)qBot[j];
         }
         wave_sync();
-        // sum of squares: IImg.cpp:33-47 -- last column, fp32, row by row
-        float sxx = (float)__builtin_amdgcn_readlane(rowsq, 0);
-        for (int y = 1; y < ph; ++y) sxx = sxx + (float)__builtin_amdgcn_readlane(rowsq, y);
         const int sx_total = (int)L.ii[(ph - 1) * pw + (pw - 1)];
 
-        // ---- 4. cascade
-        float P[WVM_PJ];
-#pragma unroll
-        for (int j = 0; j < WVM_PJ; ++j) P[j] = m.negBias;
+        // ---- 4. cascade (WvmClassifier.cpp:100-149, linEvalWvmHisteq64 :190-350)
+        // Pb: lane l holds the running fp32 sum of level 64*b + l (b = block of the current level), in
+        // the reference's summation order; blocks are caught up from the kernel-value history when entered.
+        float Pb = m.negBias;
         float u = 0.f;  // lane n holds u_kernel_eval[n]
-        int level = 0;
+        int level = 0, n = 0;
         float fout = 0.f;
         float thr = 0.f;
         for (int k = 0;; ++k) {
-            const int n = k % m.numPer;
             // software pipeline: the (packed) model data of level k+1 is requested before level k is
-            // evaluated; an early exit simply drops it.  One 16-byte load per lane + one scalar header.
+            // evaluated; an early exit simply drops it.
             const int kn = min(k + 1, m.numUsed - 1);
             const uint4 lvN = m.lvlRec[(size_t)kn * 64 + lane];
             const WvmLevelHdr hdN = m.lvlHdr[kn];
-            float wrN[WVM_PJ];
-#pragma unroll
-            for (int j = 0; j < WVM_PJ; ++j) wrN[j] = (lane + 64 * j) < m.numUsed ? m.wT[(size_t)kn * m.numFilters + lane + 64 * j] : 0.f;
+            const float wN = m.wT[(size_t)kn * F + (kn & ~63) + lane];
 
-            if (lane < WVM_MAX_VALS) L.sv[lane] = 0;
-            wave_sync();
+            if (k > 0 && (k & 63) == 0) {   // entering block b: replay levels 0..k-1 for its lanes
+                Pb = m.negBias;
+                for (int kk = 0; kk < k; ++kk) {
+                    const float t = m.wT[(size_t)kk * F + k + lane] * L.kh[kk];
+                    Pb = Pb + t;
+                }
+            }
             if (lane < hd.nrects) {   // first 64 rects of the level come from the prefetched record
                 const unsigned int rc = lv.x;
                 const int x1 = rc & 255, y1 = (rc >> 8) & 255, x2 = (rc >> 16) & 255, y2 = rc >> 24;
@@ -255,17 +311,22 @@ __global__ __launch_bounds__(256) void k_wvm_cascade(const uint8_t* __restrict__
                 }
             }
             wave_sync();
+            int svr = 0;
+            if (lane < WVM_MAX_VALS) {   // lane v takes the sum of grey value v and clears it for the next level
+                svr = L.sv[lane];
+                L.sv[lane] = 0;
+            }
+            const double valL = __hiloint2double((int)lv.w, (int)lv.z);
+            const double prod = (double)svr * valL;
             const int cntval = hd.cntval;
             double sum_xp = 0.0;
             int sumv0 = sx_total;
             for (int v = 1; v < cntval; ++v) {
-                const int s = L.sv[v];
-                sumv0 -= s;
-                const double valv = __hiloint2double(__builtin_amdgcn_readlane((int)lv.w, v), __builtin_amdgcn_readlane((int)lv.z, v));
-                sum_xp = sum_xp + (double)s * valv;
+                sumv0 -= __builtin_amdgcn_readlane(svr, v);
+                sum_xp = sum_xp + readlane_d(prod, v);
             }
-            const double val0 = __hiloint2double(__builtin_amdgcn_readlane((int)lv.w, 0), __builtin_amdgcn_readlane((int)lv.z, 0));
-            sum_xp = sum_xp + (double)sumv0 * val0;
+            const double t0 = (double)sumv0 * readlane_d(valL, 0);
+            sum_xp = sum_xp + t0;
             sum_xp = sum_xp + (double)readlane_f(u, n);
             const float unew = (float)sum_xp;
             u = (lane == n) ? unew : u;
@@ -273,26 +334,19 @@ __global__ __launch_bounds__(256) void k_wvm_cascade(const uint8_t* __restrict__
             norm = norm - 2 * sum_xp;
             norm = norm + hd.pp;
             const float Kk = (float)exp((double)m.negBasis * norm);
-#pragma unroll
-            for (int j = 0; j < WVM_PJ; ++j) {
-                const int mm = lane + 64 * j;
-                if (mm >= k && mm < m.numUsed) {
-                    const float t = wr[j] * Kk;
-                    P[j] = P[j] + t;
-                }
+            if (m.numUsed > 64 && lane == 0) L.kh[k] = Kk;
+            {
+                const float t = w * Kk;   // weights above the diagonal are stored as 0
+                Pb = Pb + t;
             }
-            float res = 0.f;
-#pragma unroll
-            for (int j = 0; j < WVM_PJ; ++j)
-                if ((k >> 6) == j) res = readlane_f(P[j], k & 63);
-            fout = res;
+            fout = readlane_f(Pb, k & 63);
             level = k;
             thr = hd.thr;
             if (!(fout >= thr && k + 1 < m.numUsed)) break;
             lv = lvN;
             hd = hdN;
-#pragma unroll
-            for (int j = 0; j < WVM_PJ; ++j) wr[j] = wrN[j];
+            w = wN;
+            if (++n == m.numPer) n = 0;
         }
         // ---- 5. results
         const bool positive = (level + 1 == m.numFilters) && (fout >= thr);
@@ -307,10 +361,10 @@ __global__ __launch_bounds__(256) void k_wvm_cascade(const uint8_t* __restrict__
             if (slot < pos_cap) {
                 if (lane == 0) pos[slot] = PosRec{(uint32_t)wid, (uint32_t)(wid >> 32), level, fout};
                 uint8_t* dst = pos_patches + (size_t)slot * d;
+                if (colok) {
 #pragma unroll
-                for (int j = 0; j < WVM_MAX_DIM / 2; ++j) {
-                    int r = half + 2 * j;
-                    if (r < ph && col < pw) dst[r * pw + col] = (uint8_t)px[j];
+                    for (int j = 0; j < RHMAX; ++j)
+                        if (rowok(j)) dst[(r0 + j) * pw + col] = (uint8_t)px[j];
                 }
             }
         }
@@ -346,6 +400,17 @@ __global__ __launch_bounds__(256) void k_histeq64(const uint8_t* __restrict__ in
     }
 }
 
+template <bool RAW>
+void launch_cascade(hipStream_t st, int grid, const WvmDev& dev, const uint8_t* arena, const WinTable& wt, int32_t* all_level,
+                    float* all_fout, PosRec* pos, uint8_t* pos_patches, unsigned int* counter, unsigned int pos_cap) {
+    if (dev.fw == 20 && dev.fh == 20)
+        hipLaunchKernelGGL((k_wvm_cascade<20, 20, RAW>), dim3(grid), dim3(256), 0, st, arena, wt, dev, all_level, all_fout, pos,
+                           pos_patches, counter, pos_cap);
+    else
+        hipLaunchKernelGGL((k_wvm_cascade<0, 0, RAW>), dim3(grid), dim3(256), 0, st, arena, wt, dev, all_level, all_fout, pos,
+                           pos_patches, counter, pos_cap);
+}
+
 }  // namespace
 
 // ---- host side ---------------------------------------------------------------------------------
@@ -366,6 +431,7 @@ void fd_wvm_build_table(const fd_pyramid* p, int pw, int ph, int sx, int sy, con
         const HostLayer& L = p->all[p->kept[w.layer]];
         WinLayerDev& dl = wt.l[wt.n++];
         dl.bx = w.bx; dl.by = w.by; dl.nx = w.nx; dl.ny = w.ny; dl.lw = L.w; dl.off = L.gray_off; dl.first = w.first;
+        dl.magic = (uint32_t)std::min<uint64_t>((1ull << 32) / (uint64_t)w.nx, 0xffffffffull);
     }
 }
 
@@ -418,22 +484,24 @@ void fd_wvm_run(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, int sx, int sy, const int
         const char* e = getenv("FD_WVM_POS_CAP");
         if (e && atoll(e) > 0) m->pos_cap = atoll(e);
     }
-    m->pos.reserve(sizeof(PosRec) * (size_t)m->pos_cap);
+    // pos buffer: record 0 is the header (positive counter), records 1.. are the positives, so that the
+    // counter and the first records come back in a single read
+    m->pos.reserve(sizeof(PosRec) * ((size_t)m->pos_cap + 1));
     m->pos_patches.reserve((size_t)m->dev.d * (size_t)m->pos_cap);
-    m->counter.reserve(256);
-    HIP_CHECK(hipMemsetAsync(m->counter.p, 0, 4, st));
+    HIP_CHECK(hipMemsetAsync(m->pos.p, 0, sizeof(PosRec), st));
     const int64_t blocks_needed = (wt.total + 3) / 4;
     const int grid = (int)std::min<int64_t>(blocks_needed, (int64_t)ctx->num_cus * 8);
     if (time_kernel) HIP_CHECK(hipEventRecord(ctx->ev0, st));
-    hipLaunchKernelGGL(k_wvm_cascade, dim3(grid), dim3(256), 0, st, p->arena.as<uint8_t>(), wt, m->dev,
-                       want_all ? m->all_level.as<int32_t>() : nullptr, want_all ? m->all_fout.as<float>() : nullptr,
-                       m->pos.as<PosRec>(), m->pos_patches.as<uint8_t>(), m->counter.as<unsigned int>(), (unsigned int)m->pos_cap);
+    launch_cascade<false>(st, grid, m->dev, p->arena.as<uint8_t>(), wt, want_all ? m->all_level.as<int32_t>() : nullptr,
+                          want_all ? m->all_fout.as<float>() : nullptr, m->pos.as<PosRec>() + 1, m->pos_patches.as<uint8_t>(),
+                          m->pos.as<unsigned int>(), (unsigned int)m->pos_cap);
     if (time_kernel) HIP_CHECK(hipEventRecord(ctx->ev1, st));
     HIP_CHECK(hipGetLastError());
-    unsigned int* hcnt = (unsigned int*)fd_pinned(ctx, 64);
-    HIP_CHECK(hipMemcpyAsync(hcnt, m->counter.p, 4, hipMemcpyDeviceToHost, st));
+    const size_t firstChunk = (size_t)std::min<int64_t>(m->pos_cap, 2048);
+    PosRec* hraw = (PosRec*)fd_pinned(ctx, sizeof(PosRec) * ((size_t)m->pos_cap + 1));
+    HIP_CHECK(hipMemcpyAsync(hraw, m->pos.p, sizeof(PosRec) * (firstChunk + 1), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    const unsigned int cnt = *hcnt;
+    const unsigned int cnt = hraw[0].wid_lo;
     if (time_kernel) {
         HIP_CHECK(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev0, ctx->ev1));
         ctx->last_kernel = "k_wvm_cascade";
@@ -441,10 +509,12 @@ void fd_wvm_run(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, int sx, int sy, const int
     if ((int64_t)cnt > m->pos_cap)
         FD_THROW(FD_ERR_CAPACITY, "WVM produced %u positives, device buffer holds %lld (set FD_WVM_POS_CAP)", cnt, (long long)m->pos_cap);
     if (cnt) {
-        PosRec* hraw = (PosRec*)fd_pinned(ctx, sizeof(PosRec) * (size_t)cnt);
-        HIP_CHECK(hipMemcpyAsync(hraw, m->pos.p, sizeof(PosRec) * cnt, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        std::vector<PosRec> raw(hraw, hraw + cnt);
+        if (cnt > firstChunk) {
+            HIP_CHECK(hipMemcpyAsync(hraw + 1 + firstChunk, m->pos.as<PosRec>() + 1 + firstChunk, sizeof(PosRec) * (cnt - firstChunk),
+                                     hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
+        const PosRec* raw = hraw + 1;
         std::vector<uint32_t> order(cnt);
         for (uint32_t i = 0; i < cnt; ++i) order[i] = i;
         auto widof = [&](uint32_t i) { return ((uint64_t)raw[i].wid_hi << 32) | raw[i].wid_lo; };
@@ -497,7 +567,7 @@ int fd_wvm_create(fd_ctx* ctx, const fd_wvm_model* md, fd_wvm** out) {
         std::unique_ptr<fd_wvm> guard(m);
         m->ctx = ctx;
         const int nval = md->val_off[F];
-        std::vector<float> wT((size_t)F * F, 0.f);
+        std::vector<float> wT((size_t)F * F + 64, 0.f);   // +64: a block of lanes may read past the last row
         for (int k = 0; k < F; ++k)
             for (int pidx = 0; pidx <= k; ++pidx) wT[(size_t)pidx * F + k] = md->hk_weights[(size_t)k * F + pidx];
         std::vector<int32_t> rectBegin(F + 1);
@@ -619,8 +689,8 @@ int fd_wvm_eval_batch(fd_ctx* ctx, const fd_wvm* wvm_, const uint8_t* patches, i
         wt.raw = 1;
         wt.total = n;
         const int grid = (int)std::min<int64_t>((n + 3) / 4, (int64_t)ctx->num_cus * 8);
-        hipLaunchKernelGGL(k_wvm_cascade, dim3(grid), dim3(256), 0, st, in.as<uint8_t>(), wt, m->dev, m->all_level.as<int32_t>(),
-                           m->all_fout.as<float>(), m->pos.as<PosRec>(), m->pos_patches.as<uint8_t>(), m->counter.as<unsigned int>(), 0u);
+        launch_cascade<true>(st, grid, m->dev, in.as<uint8_t>(), wt, m->all_level.as<int32_t>(), m->all_fout.as<float>(),
+                             m->pos.as<PosRec>(), m->pos_patches.as<uint8_t>(), m->counter.as<unsigned int>(), 0u);
         HIP_CHECK(hipGetLastError());
         if (out_level) HIP_CHECK(hipMemcpyAsync(out_level, m->all_level.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
         if (out_score) HIP_CHECK(hipMemcpyAsync(out_score, m->all_fout.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
@@ -647,15 +717,27 @@ int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const f
         if (fd_svm_dim(svm) != m->dev.d || !fd_svm_is_u8(svm))
             FD_THROW(FD_ERR_INVALID_ARGUMENT, "second classifier must work on the %d-byte HistEq64 patch", m->dev.d);
         // stage 1: WVM over all windows (SlidingWindowDetector::detect), positives in extraction order
+        static const bool trace = getenv("FD_TRACE") != nullptr;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto t0 = now();
+        auto lap = [&](const char* what) {
+            if (!trace) return;
+            auto t1 = now();
+            fprintf(stderr, "[fd five-stage] %-12s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t1 - t0).count());
+            t0 = t1;
+        };
         WvmRun run;
         fd_wvm_run(ctx, p, m, sx, sy, roi, false, run, true);
+        lap("wvm");
         std::vector<fd_detection> wvmPos;
         fd_wvm_positives_to_detections(p, m, run, sx, sy, wvmPos);
         if (stage_counts) stage_counts[0] = (int)wvmPos.size();
+        lap("to_dets");
         // stage 2: overlap elimination
         std::vector<int> keep;
         fd_host_overlap_elimination(wvmPos.data(), (int)wvmPos.size(), oe_dist, oe_ratio, keep);
         if (stage_counts) stage_counts[1] = (int)keep.size();
+        lap("oe");
         // stage 3: SVM on the survivors' HistEq64 patches (still resident in HBM, gathered by slot)
         std::vector<fd_detection> svmPos;
         if (!keep.empty()) {
@@ -684,6 +766,7 @@ int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const f
             }
         }
         if (stage_counts) stage_counts[2] = (int)svmPos.size();
+        lap("svm");
         auto byProb = [](const fd_detection& a, const fd_detection& b) { return a.probability > b.probability; };
         bool sortAtEnd = true;
         if (!roi) {
@@ -705,6 +788,7 @@ int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const f
         }
         if (sortAtEnd) std::sort(svmPos.begin(), svmPos.end(), byProb);
         if (stage_counts) stage_counts[3] = (int)svmPos.size();
+        lap("nms");
         *count = (int)svmPos.size();
         for (size_t i = 0; i < svmPos.size() && (int)i < cap && out; ++i) out[i] = svmPos[i];
         if (out && (int)svmPos.size() > cap) FD_THROW(FD_ERR_CAPACITY, "fd_detect_five_stage: %zu detections, capacity %d", svmPos.size(), cap);
