@@ -33,6 +33,7 @@ void fd_svm_generic_launch(fd_ctx* ctx, const fd_svm* m, const void* dfeat, cons
 constexpr int WVM_MAX_LAYERS = 64;
 constexpr int WVM_MAX_DIM = 32;      // patch width/height limit of this kernel
 constexpr int WVM_MAX_VALS = 16;     // grey values per filter
+constexpr int WVM_LCAP = 16;         // filters evaluated by the one-wave-per-window stage; survivors go to k_wvm_deep
 constexpr int WVM_PJ = 5;            // up to 320 filters (largest cfg-implied WVM: 280)
 
 struct WinLayerDev {
@@ -91,7 +92,7 @@ struct fd_wvm {
     double logisticA, logisticB;
     std::vector<float> h_thresholds;
     // scratch reused across calls
-    DevBuf all_level, all_fout, pos, pos_patches, counter;
+    DevBuf all_level, all_fout, pos, pos_patches, counter, deep_q;
     HostBuf h_pos;
     int64_t pos_cap = 0;
 };
@@ -123,252 +124,397 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 
-// LDS per wave: hist 256 + sv 64 + kernel-value history 1280 + integral image (1600 for 20x20, else 4096)
+// PW_/PH_ != 0: patch size known at compile time (the 20x20 detectors of the reference configs);
+// 0: sizes from the model, up to 32x32.
+//
+// Lane layout of a patch inside one wave: lanes 0-31 = columns of the top rows [0, rh), lanes 32-63 =
+// columns of the bottom rows [rh, ph); register j of a lane = row r0 + j.
+template <int PW_, int PH_>
+struct Geo {
+    static constexpr int RHMAX = PW_ ? (PH_ + 1) / 2 : WVM_MAX_DIM / 2;
+    static constexpr bool ALLROWS = PW_ && (PH_ % 2 == 0);   // every (half, j) is a real row
+    static constexpr int IISZ = PW_ ? PW_ * PH_ : WVM_MAX_DIM * WVM_MAX_DIM;
+    int pw, ph, d, rh, half, col, r0;
+    bool colok;
+    __device__ __forceinline__ Geo(const WvmDev& m, int lane) {
+        pw = PW_ ? PW_ : m.fw;
+        ph = PW_ ? PH_ : m.fh;
+        d = pw * ph;
+        rh = PW_ ? RHMAX : (ph + 1) / 2;
+        half = lane >> 5;
+        col = lane & 31;
+        r0 = half * rh;
+        colok = col < pw;
+    }
+    __device__ __forceinline__ bool rowok(int j) const { return ALLROWS ? true : (j < rh && r0 + j < ph); }
+};
+
+// window id -> first pixel of the window in the arena (DirectPyramidFeatureExtractor.cpp:75-123 order:
+// layers, then rows, then columns).  RAW: `total` contiguous, already equalised patches.
+template <bool RAW>
+__device__ __forceinline__ const uint8_t* wvm_locate(const uint8_t* arena, const WinTable& wt, const int64_t* sFirst, int64_t wid,
+                                                     int lane, int pw, int d, int& stride) {
+    if (RAW) {
+        stride = pw;
+        return arena + (size_t)wid * d;
+    }
+    const int li = __builtin_amdgcn_readfirstlane(__popcll(__ballot(sFirst[lane] <= wid)) - 1);
+    const WinLayerDev& wl = wt.l[li];
+    const unsigned int local = (unsigned int)(wid - wl.first);
+    unsigned int iy = __umulhi(local, wl.magic);   // floor(local / nx) or one less
+    unsigned int ix = local - iy * (unsigned int)wl.nx;
+    if (ix >= (unsigned int)wl.nx) { ix -= wl.nx; ++iy; }
+    const int lx = wl.bx + (int)ix * wt.sx, ly = wl.by + (int)iy * wt.sy;
+    stride = wl.lw;
+    return arena + wl.off + (size_t)ly * wl.lw + lx;
+}
+
+// Fixed part of one window, executed by one wave: HistEq64 (HistEq64Filter.cpp:32-125), integral image
+// and sum of squares (IImg.cpp:22-47).  Everything runs on registers + DPP; only the histogram and the
+// finished integral image go through LDS.  On return px[] holds the equalised patch, ii the integral
+// image (visible to this wave).
+template <int PW_, int PH_, bool RAW>
+__device__ __forceinline__ void wvm_prepare(const Geo<PW_, PH_>& g, const uint8_t* src, int srcStride, float stretch, int lane,
+                                            unsigned int* hist, unsigned int* ii,
+                                            unsigned int (&px)[Geo<PW_, PH_>::RHMAX], float& sxx, int& sx_total) {
+    constexpr int RHMAX = Geo<PW_, PH_>::RHMAX;
+    {   // columns beyond the patch read column 0 and are masked later
+        const uint8_t* sp = src + (size_t)g.r0 * srcStride + (g.colok ? g.col : 0);
+#pragma unroll
+        for (int j = 0; j < RHMAX; ++j) px[j] = g.rowok(j) ? sp[(size_t)j * srcStride] : 0u;
+    }
+    if (!RAW) {
+        hist[lane] = 0;   // lane == bin
+        wave_sync();
+        if (g.colok) {
+#pragma unroll
+            for (int j = 0; j < RHMAX; ++j)
+                if (g.rowok(j)) atomicAdd(&hist[px[j] >> 2], 1u);
+        }
+        wave_sync();
+        const float pdf = (float)hist[lane] * stretch;
+        // sequential fp32 cdf: x_t[l] = x_{t-1}[l-1] + pdf[l]; lane l holds cdf[l] from step l on
+        float x = pdf;
+#pragma unroll
+        for (int t = 1; t < 64; ++t) {
+            const float sh = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), DPP_WAVE_SHR1, 0xf, 0xf, true));
+            x = sh + pdf;
+        }
+        const int lutv = (int)(unsigned int)(unsigned char)floor((double)x + 0.5);
+        // equalise through the crossbar (lane b holds lut[b])
+#pragma unroll
+        for (int j = 0; j < RHMAX; ++j) {
+            const unsigned int e = (unsigned int)__builtin_amdgcn_ds_bpermute((int)(px[j] & 0xfcu), lutv);
+            px[j] = (g.colok && g.rowok(j)) ? e : 0u;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < RHMAX; ++j) px[j] = (g.colok && g.rowok(j)) ? px[j] : 0u;
+    }
+    // integral image: row prefix sums by DPP, column sums in registers
+    int s[RHMAX];
+    int qTop[RHMAX], qBot[RHMAX];
+#pragma unroll
+    for (int j = 0; j < RHMAX; ++j) {
+        s[j] = scan_half((int)px[j]);
+        const int q = scan_half((int)(px[j] * px[j]));
+        qTop[j] = __builtin_amdgcn_readlane(q, 31);
+        qBot[j] = __builtin_amdgcn_readlane(q, 63);
+    }
+#pragma unroll
+    for (int j = 1; j < RHMAX; ++j) s[j] += s[j - 1];
+    int topTotal = s[0];   // column totals of the top half go to the bottom half
+#pragma unroll
+    for (int j = 1; j < RHMAX; ++j)
+        if (j < g.rh) topTotal = s[j];
+    topTotal = __builtin_amdgcn_ds_bpermute(g.col << 2, topTotal);
+    if (g.half == 0) topTotal = 0;
+    if (g.colok) {
+#pragma unroll
+        for (int j = 0; j < RHMAX; ++j)
+            if (g.rowok(j)) ii[(g.r0 + j) * g.pw + g.col] = (unsigned int)(s[j] + topTotal);
+    }
+    // sum of squares: last column, fp32, row by row (IImg.cpp:33-47)
+    sxx = (float)qTop[0];
+#pragma unroll
+    for (int j = 1; j < RHMAX; ++j)
+        if (j < g.rh) sxx = sxx + (float)qTop[j];
+#pragma unroll
+    for (int j = 0; j < RHMAX; ++j)
+        if (j < g.rh && g.rh + j < g.ph) sxx = sxx + (float)qBot[j];
+    wave_sync();
+    sx_total = (int)ii[(g.ph - 1) * g.pw + (g.pw - 1)];
+}
+
+// Kernel value of one filter (WvmClassifier.cpp:190-350, linEvalWvmHisteq64): rect sums of the level
+// from the integral image (lane == rect), grey-value sums through sv (must be all zero on entry, is
+// all zero on return), then the scalar fp64 chain of the reference.  lv = packed level record of this
+// lane, hd = level header.  u_n = u_kernel_eval[n] of the level; unew = its new value.
+__device__ __forceinline__ float wvm_level_K(const WvmDev& m, const unsigned int* ii, int* sv, int pw, int lane, int k,
+                                             const uint4& lv, const WvmLevelHdr& hd, int sx_total, float sxx, float u_n,
+                                             float& unew) {
+    if (lane < hd.nrects) {   // first 64 rects of the level come from the record
+        const unsigned int rc = lv.x;
+        const int x1 = rc & 255, y1 = (rc >> 8) & 255, x2 = (rc >> 16) & 255, y2 = rc >> 24;
+        int s = (int)ii[y2 * pw + x2];
+        if (x1 > 0) s -= (int)ii[y2 * pw + x1 - 1];
+        if (y1 > 0) s -= (int)ii[(y1 - 1) * pw + x2];
+        if (x1 > 0 && y1 > 0) s += (int)ii[(y1 - 1) * pw + x1 - 1];
+        atomicAdd(&sv[lv.y], s);
+    }
+    if (hd.nrects > 64) {     // rare: remaining rects straight from the flat arrays
+        const int rb = m.rectBegin[k];
+        for (int r = rb + 64 + lane; r < rb + hd.nrects; r += 64) {
+            const unsigned int rc = m.rects[r];
+            const int x1 = rc & 255, y1 = (rc >> 8) & 255, x2 = (rc >> 16) & 255, y2 = rc >> 24;
+            int s = (int)ii[y2 * pw + x2];
+            if (x1 > 0) s -= (int)ii[y2 * pw + x1 - 1];
+            if (y1 > 0) s -= (int)ii[(y1 - 1) * pw + x2];
+            if (x1 > 0 && y1 > 0) s += (int)ii[(y1 - 1) * pw + x1 - 1];
+            atomicAdd(&sv[m.rectV[r]], s);
+        }
+    }
+    wave_sync();
+    int svr = 0;
+    if (lane < WVM_MAX_VALS) {   // lane v takes the sum of grey value v and clears it for the next level
+        svr = sv[lane];
+        sv[lane] = 0;
+    }
+    const double valL = __hiloint2double((int)lv.w, (int)lv.z);
+    const double prod = (double)svr * valL;
+    const int cntval = hd.cntval;
+    double sum_xp = 0.0;
+    int sumv0 = sx_total;
+    for (int v = 1; v < cntval; ++v) {
+        sumv0 -= __builtin_amdgcn_readlane(svr, v);
+        sum_xp = sum_xp + readlane_d(prod, v);
+    }
+    const double t0 = (double)sumv0 * readlane_d(valL, 0);
+    sum_xp = sum_xp + t0;
+    sum_xp = sum_xp + (double)u_n;
+    unew = (float)sum_xp;
+    double norm = (double)sxx;
+    norm = norm - 2 * sum_xp;
+    norm = norm + hd.pp;
+    return (float)exp((double)m.negBasis * norm);
+}
+
+struct CascadeOut {
+    int32_t* all_level;
+    float* all_fout;
+    PosRec* pos;
+    uint8_t* pos_patches;
+    unsigned int* pos_count;
+    unsigned int pos_cap;
+    int64_t* deep_q;           // windows that survive the first WVM_LCAP levels (finished by k_wvm_deep)
+    unsigned int* deep_count;
+};
+
+template <int PW_, int PH_>
+__device__ __forceinline__ void wvm_emit(const Geo<PW_, PH_>& g, const WvmDev& m, const CascadeOut& o, int64_t wid, int lane,
+                                         int level, float fout, float thr, const unsigned int (&px)[Geo<PW_, PH_>::RHMAX]) {
+    const bool positive = (level + 1 == m.numFilters) && (fout >= thr);
+    if (lane == 0) {
+        if (o.all_level) o.all_level[wid] = level;
+        if (o.all_fout) o.all_fout[wid] = fout;
+    }
+    if (positive) {
+        unsigned int slot = 0;
+        if (lane == 0) slot = atomicAdd(o.pos_count, 1u);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (slot < o.pos_cap) {
+            if (lane == 0) o.pos[slot] = PosRec{(uint32_t)wid, (uint32_t)(wid >> 32), level, fout};
+            uint8_t* dst = o.pos_patches + (size_t)slot * g.d;
+            if (g.colok) {
+#pragma unroll
+                for (int j = 0; j < Geo<PW_, PH_>::RHMAX; ++j)
+                    if (g.rowok(j)) dst[(g.r0 + j) * g.pw + g.col] = (uint8_t)px[j];
+            }
+        }
+    }
+}
+
+// ---- stage A: one wave per window, first WVM_LCAP levels -----------------------------------------
+// Most windows leave the cascade here; the cost of the few that do not is two orders
+// of magnitude higher, so they are queued for k_wvm_deep instead of stalling their wave.
 template <int PW_, int PH_>
 struct __attribute__((aligned(16))) WaveLds {
     unsigned int hist[64];
     int sv[WVM_MAX_VALS];
-    float kh[64 * WVM_PJ];
-    unsigned int ii[PW_ ? PW_ * PH_ : WVM_MAX_DIM * WVM_MAX_DIM];
+    unsigned int ii[Geo<PW_, PH_>::IISZ];
 };
 
-// One wave per window.  PW_/PH_ != 0: patch size known at compile time (the 20x20 detectors of the
-// reference configs); 0: sizes from the model, up to 32x32.  RAW: the input is `total` contiguous,
-// already equalised patches (fd_wvm_eval_batch).
-//
-// Lane layout of the patch: lanes 0-31 = columns of the top rows [0, rh), lanes 32-63 = columns of the
-// bottom rows [rh, ph); register j of a lane = row r0 + j.  HistEq64, the integral image and the sum of
-// squares run on registers + DPP; only the histogram, the finished integral image and the per-level
-// grey-value sums go through LDS.
 template <int PW_, int PH_, bool RAW>
-__global__ __launch_bounds__(256) void k_wvm_cascade(const uint8_t* __restrict__ arena, WinTable wt, WvmDev m,
-                                                      int32_t* __restrict__ all_level, float* __restrict__ all_fout,
-                                                      PosRec* __restrict__ pos, uint8_t* __restrict__ pos_patches,
-                                                      unsigned int* __restrict__ pos_count, unsigned int pos_cap) {
+__global__ __launch_bounds__(256) void k_wvm_cascade(const uint8_t* __restrict__ arena, WinTable wt, WvmDev m, CascadeOut o) {
     __shared__ WaveLds<PW_, PH_> lds[4];
-    constexpr int RHMAX = PW_ ? (PH_ + 1) / 2 : WVM_MAX_DIM / 2;
-    constexpr bool ALLROWS = PW_ && (PH_ % 2 == 0);   // every (half, j) is a real row
+    __shared__ int64_t sFirst[WVM_MAX_LAYERS];
+    constexpr int RHMAX = Geo<PW_, PH_>::RHMAX;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveLds<PW_, PH_>& L = lds[wave];
-    const int pw = PW_ ? PW_ : m.fw, ph = PW_ ? PH_ : m.fh, d = pw * ph;
-    const int rh = PW_ ? RHMAX : (ph + 1) / 2;
-    const int half = lane >> 5, col = lane & 31;
-    const bool colok = col < pw;
-    const int r0 = half * rh;
+    const Geo<PW_, PH_> g(m, lane);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const int F = m.numFilters;
-    auto rowok = [&](int j) { return ALLROWS ? true : (j < rh && r0 + j < ph); };
+    const int nA = min(m.numUsed, WVM_LCAP);
 
-    // layer cursor: window ids only grow, so the layer index only moves forward (all scalar)
-    int li = 0;
-    int64_t nextFirst = (!RAW && wt.n > 1) ? wt.l[1].first : INT64_MAX;
+    if (!RAW) {
+        if (threadIdx.x < WVM_MAX_LAYERS) sFirst[threadIdx.x] = (int)threadIdx.x < wt.n ? wt.l[threadIdx.x].first : INT64_MAX;
+        __syncthreads();
+    }
     if (lane < WVM_MAX_VALS) L.sv[lane] = 0;
     wave_sync();
 
     for (int64_t wid = (int64_t)blockIdx.x * 4 + wave; wid < wt.total; wid += nwaves) {
-        const uint8_t* src;
         int srcStride;
-        if (RAW) {
-            src = arena + (size_t)wid * d;
-            srcStride = pw;
-        } else {
-            while (wid >= nextFirst) {
-                ++li;
-                nextFirst = (li + 1 < wt.n) ? wt.l[li + 1].first : INT64_MAX;
-            }
-            const WinLayerDev& wl = wt.l[li];
-            const unsigned int local = (unsigned int)(wid - wl.first);
-            unsigned int iy = __umulhi(local, wl.magic);   // floor(local / nx) or one less
-            unsigned int ix = local - iy * (unsigned int)wl.nx;
-            if (ix >= (unsigned int)wl.nx) { ix -= wl.nx; ++iy; }
-            const int lx = wl.bx + (int)ix * wt.sx, ly = wl.by + (int)iy * wt.sy;
-            src = arena + wl.off + (size_t)ly * wl.lw + lx;
-            srcStride = wl.lw;
-        }
-
-        // ---- 0. level-0 model data: requested now, consumed after the fixed part
+        const uint8_t* src = wvm_locate<RAW>(arena, wt, sFirst, wid, lane, g.pw, g.d, srcStride);
+        // level-0 model data: requested now, consumed after the fixed part
         uint4 lv = m.lvlRec[lane];
         WvmLevelHdr hd = m.lvlHdr[0];
         float w = m.wT[lane];
-
-        // ---- 1. load the window (columns beyond the patch read column 0 and are masked later)
         unsigned int px[RHMAX];
-        {
-            const uint8_t* sp = src + (size_t)r0 * srcStride + (colok ? col : 0);
-#pragma unroll
-            for (int j = 0; j < RHMAX; ++j) px[j] = rowok(j) ? sp[(size_t)j * srcStride] : 0u;
-        }
-        if (!RAW) {
-            // ---- 2. HistEq64 (HistEq64Filter.cpp:32-125): histogram with lane == bin
-            L.hist[lane] = 0;
-            wave_sync();
-            if (colok) {
-#pragma unroll
-                for (int j = 0; j < RHMAX; ++j)
-                    if (rowok(j)) atomicAdd(&L.hist[px[j] >> 2], 1u);
-            }
-            wave_sync();
-            const float pdf = (float)L.hist[lane] * m.stretch;
-            // sequential fp32 cdf: x_t[l] = x_{t-1}[l-1] + pdf[l]; lane l holds cdf[l] from step l on
-            float x = pdf;
-#pragma unroll
-            for (int t = 1; t < 64; ++t) {
-                const float sh = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), DPP_WAVE_SHR1, 0xf, 0xf, true));
-                x = sh + pdf;
-            }
-            const int lutv = (int)(unsigned int)(unsigned char)floor((double)x + 0.5);
-            // ---- 3. equalise through the crossbar (lane b holds lut[b])
-#pragma unroll
-            for (int j = 0; j < RHMAX; ++j) {
-                const unsigned int e = (unsigned int)__builtin_amdgcn_ds_bpermute((int)(px[j] & 0xfcu), lutv);
-                px[j] = (colok && rowok(j)) ? e : 0u;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < RHMAX; ++j) px[j] = (colok && rowok(j)) ? px[j] : 0u;
-        }
-        // ---- integral image (IImg.cpp:22-47): row prefix sums by DPP, column sums in registers
         float sxx;
-        {
-            int s[RHMAX];
-            int qTop[RHMAX], qBot[RHMAX];
-#pragma unroll
-            for (int j = 0; j < RHMAX; ++j) {
-                s[j] = scan_half((int)px[j]);
-                const int q = scan_half((int)(px[j] * px[j]));
-                qTop[j] = __builtin_amdgcn_readlane(q, 31);
-                qBot[j] = __builtin_amdgcn_readlane(q, 63);
-            }
-#pragma unroll
-            for (int j = 1; j < RHMAX; ++j) s[j] += s[j - 1];
-            // column totals of the top half go to the bottom half
-            int topTotal = s[0];
-#pragma unroll
-            for (int j = 1; j < RHMAX; ++j)
-                if (j < rh) topTotal = s[j];
-            topTotal = __builtin_amdgcn_ds_bpermute(col << 2, topTotal);
-            if (half == 0) topTotal = 0;
-            if (colok) {
-#pragma unroll
-                for (int j = 0; j < RHMAX; ++j)
-                    if (rowok(j)) L.ii[(r0 + j) * pw + col] = (unsigned int)(s[j] + topTotal);
-            }
-            // sum of squares: last column, fp32, row by row (IImg.cpp:33-47)
-            sxx = (float)qTop[0];
-#pragma unroll
-            for (int j = 1; j < RHMAX; ++j)
-                if (j < rh) sxx = sxx + (float)qTop[j];
-#pragma unroll
-            for (int j = 0; j < RHMAX; ++j)
-                if (j < rh && rh + j < ph) sxx = sxx + (float)qBot[j];
-        }
-        wave_sync();
-        const int sx_total = (int)L.ii[(ph - 1) * pw + (pw - 1)];
+        int sx_total;
+        wvm_prepare<PW_, PH_, RAW>(g, src, srcStride, m.stretch, lane, L.hist, L.ii, px, sxx, sx_total);
 
-        // ---- 4. cascade (WvmClassifier.cpp:100-149, linEvalWvmHisteq64 :190-350)
-        // Pb: lane l holds the running fp32 sum of level 64*b + l (b = block of the current level), in
-        // the reference's summation order; blocks are caught up from the kernel-value history when entered.
+        // cascade (WvmClassifier.cpp:100-149).  Pb: lane l holds the running fp32 sum of level l in the
+        // reference's summation order (weights above the diagonal are stored as 0).
         float Pb = m.negBias;
         float u = 0.f;  // lane n holds u_kernel_eval[n]
-        int level = 0, n = 0;
-        float fout = 0.f;
-        float thr = 0.f;
+        int n = 0;
+        bool deep = false;
+        int level;
+        float fout, thr;
         for (int k = 0;; ++k) {
             // software pipeline: the (packed) model data of level k+1 is requested before level k is
             // evaluated; an early exit simply drops it.
-            const int kn = min(k + 1, m.numUsed - 1);
+            const int kn = min(k + 1, nA - 1);
             const uint4 lvN = m.lvlRec[(size_t)kn * 64 + lane];
             const WvmLevelHdr hdN = m.lvlHdr[kn];
-            const float wN = m.wT[(size_t)kn * F + (kn & ~63) + lane];
-
-            if (k > 0 && (k & 63) == 0) {   // entering block b: replay levels 0..k-1 for its lanes
-                Pb = m.negBias;
-                for (int kk = 0; kk < k; ++kk) {
-                    const float t = m.wT[(size_t)kk * F + k + lane] * L.kh[kk];
-                    Pb = Pb + t;
-                }
-            }
-            if (lane < hd.nrects) {   // first 64 rects of the level come from the prefetched record
-                const unsigned int rc = lv.x;
-                const int x1 = rc & 255, y1 = (rc >> 8) & 255, x2 = (rc >> 16) & 255, y2 = rc >> 24;
-                int s = (int)L.ii[y2 * pw + x2];
-                if (x1 > 0) s -= (int)L.ii[y2 * pw + x1 - 1];
-                if (y1 > 0) s -= (int)L.ii[(y1 - 1) * pw + x2];
-                if (x1 > 0 && y1 > 0) s += (int)L.ii[(y1 - 1) * pw + x1 - 1];
-                atomicAdd(&L.sv[lv.y], s);
-            }
-            if (hd.nrects > 64) {     // rare: remaining rects straight from the flat arrays
-                const int rb = m.rectBegin[k];
-                for (int r = rb + 64 + lane; r < rb + hd.nrects; r += 64) {
-                    const unsigned int rc = m.rects[r];
-                    const int x1 = rc & 255, y1 = (rc >> 8) & 255, x2 = (rc >> 16) & 255, y2 = rc >> 24;
-                    int s = (int)L.ii[y2 * pw + x2];
-                    if (x1 > 0) s -= (int)L.ii[y2 * pw + x1 - 1];
-                    if (y1 > 0) s -= (int)L.ii[(y1 - 1) * pw + x2];
-                    if (x1 > 0 && y1 > 0) s += (int)L.ii[(y1 - 1) * pw + x1 - 1];
-                    atomicAdd(&L.sv[m.rectV[r]], s);
-                }
-            }
-            wave_sync();
-            int svr = 0;
-            if (lane < WVM_MAX_VALS) {   // lane v takes the sum of grey value v and clears it for the next level
-                svr = L.sv[lane];
-                L.sv[lane] = 0;
-            }
-            const double valL = __hiloint2double((int)lv.w, (int)lv.z);
-            const double prod = (double)svr * valL;
-            const int cntval = hd.cntval;
-            double sum_xp = 0.0;
-            int sumv0 = sx_total;
-            for (int v = 1; v < cntval; ++v) {
-                sumv0 -= __builtin_amdgcn_readlane(svr, v);
-                sum_xp = sum_xp + readlane_d(prod, v);
-            }
-            const double t0 = (double)sumv0 * readlane_d(valL, 0);
-            sum_xp = sum_xp + t0;
-            sum_xp = sum_xp + (double)readlane_f(u, n);
-            const float unew = (float)sum_xp;
+            const float wN = m.wT[(size_t)kn * F + lane];
+            float unew;
+            const float Kk = wvm_level_K(m, L.ii, L.sv, g.pw, lane, k, lv, hd, sx_total, sxx, readlane_f(u, n), unew);
             u = (lane == n) ? unew : u;
-            double norm = (double)sxx;
-            norm = norm - 2 * sum_xp;
-            norm = norm + hd.pp;
-            const float Kk = (float)exp((double)m.negBasis * norm);
-            if (m.numUsed > 64 && lane == 0) L.kh[k] = Kk;
             {
-                const float t = w * Kk;   // weights above the diagonal are stored as 0
+                const float t = w * Kk;
                 Pb = Pb + t;
             }
-            fout = readlane_f(Pb, k & 63);
+            fout = readlane_f(Pb, k);
             level = k;
             thr = hd.thr;
             if (!(fout >= thr && k + 1 < m.numUsed)) break;
+            if (k + 1 == nA) { deep = true; break; }
             lv = lvN;
             hd = hdN;
             w = wN;
             if (++n == m.numPer) n = 0;
         }
-        // ---- 5. results
-        const bool positive = (level + 1 == m.numFilters) && (fout >= thr);
-        if (lane == 0) {
-            if (all_level) all_level[wid] = level;
-            if (all_fout) all_fout[wid] = fout;
-        }
-        if (positive) {
-            unsigned int slot = 0;
-            if (lane == 0) slot = atomicAdd(pos_count, 1u);
-            slot = __builtin_amdgcn_readfirstlane(slot);
-            if (slot < pos_cap) {
-                if (lane == 0) pos[slot] = PosRec{(uint32_t)wid, (uint32_t)(wid >> 32), level, fout};
-                uint8_t* dst = pos_patches + (size_t)slot * d;
-                if (colok) {
-#pragma unroll
-                    for (int j = 0; j < RHMAX; ++j)
-                        if (rowok(j)) dst[(r0 + j) * pw + col] = (uint8_t)px[j];
-                }
-            }
+        if (deep) {
+            if (lane == 0) o.deep_q[atomicAdd(o.deep_count, 1u)] = wid;
+        } else {
+            wvm_emit<PW_, PH_>(g, m, o, wid, lane, level, fout, thr, px);
         }
         wave_sync();
+    }
+}
+
+// ---- stage B: one workgroup per surviving window ---------------------------------------------------
+// The kernel values K_k of different filters are independent of each other except through
+// u_kernel_eval[k % numPer] (written numPer filters earlier), so the four waves evaluate disjoint
+// residue classes n = k % numPer concurrently (wave j: n = j, j+4, ...), keeping their u values in
+// registers.  After every chunk of whole "generations" (numPer filters each, at most 64 filters) one
+// wave forms the hierarchical sums of the chunk's filters lane-parallel -- lane == filter, each lane
+// adding its terms in the reference order -- and the first failed threshold ends the window.
+template <int PW_, int PH_, bool RAW>
+__global__ __launch_bounds__(256) void k_wvm_deep(const uint8_t* __restrict__ arena, WinTable wt, WvmDev m, CascadeOut o) {
+    constexpr int RHMAX = Geo<PW_, PH_>::RHMAX;
+    __shared__ unsigned int ii[Geo<PW_, PH_>::IISZ];
+    __shared__ unsigned int hist[4][64];
+    __shared__ int sv[4][WVM_MAX_VALS];
+    __shared__ float kh[64 * WVM_PJ];
+    __shared__ int64_t sFirst[WVM_MAX_LAYERS];
+    __shared__ int sExit[2];   // exit level (or -1), fout bits
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const Geo<PW_, PH_> g(m, lane);
+    const int F = m.numFilters, NU = m.numUsed, NP = m.numPer;
+    const int gensPerChunk = max(1, 64 / NP);
+    const int chunk = gensPerChunk * NP;
+
+    if (!RAW && threadIdx.x < WVM_MAX_LAYERS) sFirst[threadIdx.x] = (int)threadIdx.x < wt.n ? wt.l[threadIdx.x].first : INT64_MAX;
+    if (lane < WVM_MAX_VALS) sv[wave][lane] = 0;
+    __syncthreads();
+    const unsigned int ndeep = *o.deep_count;
+
+    for (unsigned int q = blockIdx.x; q < ndeep; q += gridDim.x) {
+        const int64_t wid = o.deep_q[q];
+        int srcStride;
+        const uint8_t* src = wvm_locate<RAW>(arena, wt, sFirst, wid, lane, g.pw, g.d, srcStride);
+        unsigned int px[RHMAX];
+        float sxx;
+        int sx_total;
+        // every wave prepares the window (identical values; they all write the one integral image)
+        wvm_prepare<PW_, PH_, RAW>(g, src, srcStride, m.stretch, lane, hist[wave], ii, px, sxx, sx_total);
+        __syncthreads();
+
+        float u = 0.f;   // lane n holds u_kernel_eval[n] (only this wave's classes are used)
+        int level = NU - 1;
+        float fout = 0.f;
+        for (int c0 = 0; c0 < NU; c0 += chunk) {
+            const int c1 = min(c0 + chunk, NU);
+            // ---- kernel values of this wave's filters in [c0, c1): generation-major, classes wave, wave+4, ...
+            {
+                int k = c0 + wave;          // c0 is a multiple of NP
+                int n = wave, gbase = c0;
+                if (n >= NP) k = c1;
+                uint4 lv;
+                WvmLevelHdr hd;
+                if (k < c1) { lv = m.lvlRec[(size_t)k * 64 + lane]; hd = m.lvlHdr[k]; }
+                while (k < c1) {
+                    int n2 = n + 4, gb2 = gbase;
+                    if (n2 >= NP) { n2 = wave; gb2 += NP; }
+                    const int k2 = gb2 + n2;
+                    const int kp = k2 < c1 ? k2 : k;
+                    const uint4 lvN = m.lvlRec[(size_t)kp * 64 + lane];
+                    const WvmLevelHdr hdN = m.lvlHdr[kp];
+                    float unew;
+                    const float Kk = wvm_level_K(m, ii, sv[wave], g.pw, lane, k, lv, hd, sx_total, sxx, readlane_f(u, n), unew);
+                    u = (lane == n) ? unew : u;
+                    if (lane == 0) kh[k] = Kk;
+                    k = k2; n = n2; gbase = gb2;
+                    lv = lvN;
+                    hd = hdN;
+                }
+            }
+            __syncthreads();
+            // ---- hierarchical sums of the chunk: lane == filter c0 + lane
+            if (wave == 0) {
+                const int mm = c0 + lane;
+                float P = m.negBias;
+                const float* wp = m.wT + mm;
+#pragma unroll 8
+                for (int i = 0; i < c1; ++i) {
+                    const float t = wp[(size_t)i * F] * kh[i];
+                    P = P + t;
+                }
+                const float thrm = mm < c1 ? m.thresholds[mm] : 0.f;
+                const bool fail = mm < c1 && !(P >= thrm && mm + 1 < NU);
+                const unsigned long long fm = __ballot(fail);
+                if (lane == 0) sExit[0] = -1;
+                if (fm) {
+                    const int e = __builtin_ctzll(fm);
+                    if (lane == e) { sExit[0] = c0 + e; sExit[1] = __float_as_int(P); }
+                }
+            }
+            __syncthreads();
+            const int ex = sExit[0];
+            if (ex >= 0) {
+                level = ex;
+                fout = __int_as_float(sExit[1]);
+                break;
+            }
+        }
+        if (wave == 0) wvm_emit<PW_, PH_>(g, m, o, wid, lane, level, fout, m.thresholds[level], px);
+        __syncthreads();
     }
 }
 
@@ -400,15 +546,20 @@ __global__ __launch_bounds__(256) void k_histeq64(const uint8_t* __restrict__ in
     }
 }
 
+// Launches stage A over all windows and stage B over its survivors (same stream, no host round trip:
+// stage B is a persistent grid that reads the survivor count from device memory).
 template <bool RAW>
-void launch_cascade(hipStream_t st, int grid, const WvmDev& dev, const uint8_t* arena, const WinTable& wt, int32_t* all_level,
-                    float* all_fout, PosRec* pos, uint8_t* pos_patches, unsigned int* counter, unsigned int pos_cap) {
-    if (dev.fw == 20 && dev.fh == 20)
-        hipLaunchKernelGGL((k_wvm_cascade<20, 20, RAW>), dim3(grid), dim3(256), 0, st, arena, wt, dev, all_level, all_fout, pos,
-                           pos_patches, counter, pos_cap);
-    else
-        hipLaunchKernelGGL((k_wvm_cascade<0, 0, RAW>), dim3(grid), dim3(256), 0, st, arena, wt, dev, all_level, all_fout, pos,
-                           pos_patches, counter, pos_cap);
+void launch_cascade(fd_ctx* ctx, hipStream_t st, int64_t total, const WvmDev& dev, const uint8_t* arena, const WinTable& wt,
+                    const CascadeOut& o) {
+    const int gridA = (int)std::min<int64_t>((total + 3) / 4, (int64_t)ctx->num_cus * 8);
+    const int gridB = (int)std::min<int64_t>(total, (int64_t)ctx->num_cus * 4);
+    if (dev.fw == 20 && dev.fh == 20) {
+        hipLaunchKernelGGL((k_wvm_cascade<20, 20, RAW>), dim3(gridA), dim3(256), 0, st, arena, wt, dev, o);
+        if (dev.numUsed > WVM_LCAP) hipLaunchKernelGGL((k_wvm_deep<20, 20, RAW>), dim3(gridB), dim3(256), 0, st, arena, wt, dev, o);
+    } else {
+        hipLaunchKernelGGL((k_wvm_cascade<0, 0, RAW>), dim3(gridA), dim3(256), 0, st, arena, wt, dev, o);
+        if (dev.numUsed > WVM_LCAP) hipLaunchKernelGGL((k_wvm_deep<0, 0, RAW>), dim3(gridB), dim3(256), 0, st, arena, wt, dev, o);
+    }
 }
 
 }  // namespace
@@ -489,12 +640,18 @@ void fd_wvm_run(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, int sx, int sy, const int
     m->pos.reserve(sizeof(PosRec) * ((size_t)m->pos_cap + 1));
     m->pos_patches.reserve((size_t)m->dev.d * (size_t)m->pos_cap);
     HIP_CHECK(hipMemsetAsync(m->pos.p, 0, sizeof(PosRec), st));
-    const int64_t blocks_needed = (wt.total + 3) / 4;
-    const int grid = (int)std::min<int64_t>(blocks_needed, (int64_t)ctx->num_cus * 8);
+    m->deep_q.reserve(sizeof(int64_t) * (size_t)wt.total);
+    CascadeOut o;
+    o.all_level = want_all ? m->all_level.as<int32_t>() : nullptr;
+    o.all_fout = want_all ? m->all_fout.as<float>() : nullptr;
+    o.pos = m->pos.as<PosRec>() + 1;
+    o.pos_patches = m->pos_patches.as<uint8_t>();
+    o.pos_count = m->pos.as<unsigned int>();        // header word 0
+    o.pos_cap = (unsigned int)m->pos_cap;
+    o.deep_q = m->deep_q.as<int64_t>();
+    o.deep_count = m->pos.as<unsigned int>() + 1;   // header word 1
     if (time_kernel) HIP_CHECK(hipEventRecord(ctx->ev0, st));
-    launch_cascade<false>(st, grid, m->dev, p->arena.as<uint8_t>(), wt, want_all ? m->all_level.as<int32_t>() : nullptr,
-                          want_all ? m->all_fout.as<float>() : nullptr, m->pos.as<PosRec>() + 1, m->pos_patches.as<uint8_t>(),
-                          m->pos.as<unsigned int>(), (unsigned int)m->pos_cap);
+    launch_cascade<false>(ctx, st, wt.total, m->dev, p->arena.as<uint8_t>(), wt, o);
     if (time_kernel) HIP_CHECK(hipEventRecord(ctx->ev1, st));
     HIP_CHECK(hipGetLastError());
     const size_t firstChunk = (size_t)std::min<int64_t>(m->pos_cap, 2048);
@@ -682,15 +839,23 @@ int fd_wvm_eval_batch(fd_ctx* ctx, const fd_wvm* wvm_, const uint8_t* patches, i
         m->pos.reserve(sizeof(PosRec) * 16);
         m->pos_patches.reserve((size_t)m->dev.d * 16);
         m->counter.reserve(256);
+        m->deep_q.reserve(sizeof(int64_t) * (size_t)n);
         HIP_CHECK(hipMemcpyAsync(in.p, patches, bytes, hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemsetAsync(m->counter.p, 0, 4, st));
+        HIP_CHECK(hipMemsetAsync(m->counter.p, 0, 8, st));
         WinTable wt;
         std::memset(&wt, 0, sizeof(wt));
         wt.raw = 1;
         wt.total = n;
-        const int grid = (int)std::min<int64_t>((n + 3) / 4, (int64_t)ctx->num_cus * 8);
-        launch_cascade<true>(st, grid, m->dev, in.as<uint8_t>(), wt, m->all_level.as<int32_t>(), m->all_fout.as<float>(),
-                             m->pos.as<PosRec>(), m->pos_patches.as<uint8_t>(), m->counter.as<unsigned int>(), 0u);
+        CascadeOut o;
+        o.all_level = m->all_level.as<int32_t>();
+        o.all_fout = m->all_fout.as<float>();
+        o.pos = m->pos.as<PosRec>();
+        o.pos_patches = m->pos_patches.as<uint8_t>();
+        o.pos_count = m->counter.as<unsigned int>();
+        o.pos_cap = 0u;   // positives are not collected here
+        o.deep_q = m->deep_q.as<int64_t>();
+        o.deep_count = m->counter.as<unsigned int>() + 1;
+        launch_cascade<true>(ctx, st, n, m->dev, in.as<uint8_t>(), wt, o);
         HIP_CHECK(hipGetLastError());
         if (out_level) HIP_CHECK(hipMemcpyAsync(out_level, m->all_level.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
         if (out_score) HIP_CHECK(hipMemcpyAsync(out_score, m->all_fout.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));

@@ -10,6 +10,8 @@ d = [torch.from_numpy(f).cuda() for f in frames]
 gray = O.bgr2gray(synth.make_frame(640, 480, seed=20260927))
 calib = synth.random_patches(gray[::4, ::4].copy(), 20, 20, 8000, np.random.default_rng(1))
 wvm_m = synth.make_wvm(7, calib_patches=calib)
+import os
+if os.environ.get("NUM_USED"): wvm_m["num_used"] = int(os.environ["NUM_USED"])
 eq = synth.histeq64_np(synth.random_patches(gray[::4, ::4].copy(), 20, 20, 1400, np.random.default_rng(2)))
 svm_m = synth.make_svm_u8(3, eq, nsv=1024, calib=eq[1024:])
 pyr = capi.Pyramid(ctx, inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))
