@@ -61,6 +61,19 @@ assert DET_DTYPE.itemsize == C.sizeof(fd_detection)
 _lib = None
 
 # every symbol include/fd_hip.h declares (checked by tests/test_capi_symbols.py against the header)
+class fd_hist_params(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("patch_w", "patch_h", "step_x", "step_y", "kind", "bins", "cell_size", "block_size",
+                                         "levels", "interpolate", "signed_and_unsigned", "concatenate", "normalization", "cell_h",
+                                         "block_h")]
+
+
+class fd_whi_params(C.Structure):
+    _fields_ = [("patch_w", C.c_int32), ("patch_h", C.c_int32), ("step_x", C.c_int32), ("step_y", C.c_int32), ("alpha", C.c_float),
+                ("cutoff", C.c_float)]
+
+
+HIST_HOG, HIST_SPATIAL, HIST_PYRAMID_HOG, HIST_SPATIAL_PYRAMID = 0, 1, 2, 3
+
 _SIGS = {
     "fd_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "fd_ctx_destroy": (None, [C.c_void_p]),
@@ -97,6 +110,15 @@ _SIGS = {
     "fd_block_nms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "fd_hog_feature_length": (C.c_int, [C.POINTER(fd_hog_params)]),
     "fd_detect_hog_svm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(fd_hog_params), C.c_void_p, C.c_int64,
+                                    C.POINTER(C.c_int64), C.c_void_p]),
+    "fd_hist_feature_length": (C.c_int, [C.POINTER(fd_hist_params), C.c_int]),
+    "fd_extract_hist": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fd_hist_params), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "fd_detect_hist_svm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(fd_hist_params), C.c_void_p, C.c_int64,
+                                     C.POINTER(C.c_int64), C.c_void_p]),
+    "fd_whi_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "fd_equalize_hist_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "fd_extract_whi": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fd_whi_params), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "fd_detect_whi_svm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(fd_whi_params), C.c_void_p, C.c_int64,
                                     C.POINTER(C.c_int64), C.c_void_p]),
     "fd_extract_hog": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fd_hog_params), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "fd_bench_hog_svm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(fd_hog_params), C.POINTER(C.c_int64),
@@ -372,6 +394,71 @@ def extract_hog(ctx, pyr, hp):
     out = np.empty((n.value, F), np.float32)
     ctx.check(lib().fd_extract_hog(ctx.h, pyr.h, C.byref(hp), _ptr(out), n.value, C.byref(n)))
     return out
+
+
+def hist_params(kind, pw=20, ph=20, sx=2, sy=2, bins=9, cell=5, block=1, levels=2, interpolate=False, signed_and_unsigned=False,
+                concatenate=False, normalization=1, cell_h=0, block_h=0):
+    return fd_hist_params(pw, ph, sx, sy, kind, bins, cell, block, levels, int(interpolate), int(signed_and_unsigned),
+                          int(concatenate), int(normalization), cell_h, block_h)
+
+
+def extract_hist(ctx, pyr, hp):
+    """features of every window: (n_windows, feature_length) float32"""
+    n = C.c_int64()
+    ctx.check(lib().fd_extract_hist(ctx.h, pyr.h, C.byref(hp), None, 0, C.byref(n)))
+    ch = pyr.layers()[0]["ch"]
+    F = lib().fd_hist_feature_length(C.byref(hp), ch)
+    if F < 0:
+        raise ValueError("invalid histogram parameters")
+    out = np.empty((n.value, F), np.float32)
+    ctx.check(lib().fd_extract_hist(ctx.h, pyr.h, C.byref(hp), _ptr(out), n.value, C.byref(n)))
+    return out
+
+
+def detect_hist_svm(ctx, pyr, svm, hp, want_all=True, cap=1 << 20):
+    n = pyr.window_count(hp.patch_w, hp.patch_h, hp.step_x, hp.step_y)
+    out = np.zeros(min(cap, max(n, 1)), DET_DTYPE)
+    alld = np.empty(n, np.float64) if want_all else None
+    cnt = C.c_int64()
+    ctx.check(lib().fd_detect_hist_svm(ctx.h, pyr.h, svm.h, C.byref(hp), _ptr(out), out.shape[0], C.byref(cnt), _ptr(alld)))
+    return out[:cnt.value], alld
+
+
+def whi_batch(ctx, patches, alpha=1.0, cutoff=0.390625):
+    patches = _c(patches, np.uint8)
+    n, h, w = patches.shape
+    out = np.empty((n, h, w), np.float32)
+    ctx.check(lib().fd_whi_batch(ctx.h, _ptr(patches), n, w, h, alpha, cutoff, _ptr(out)))
+    return out
+
+
+def equalize_hist_batch(ctx, patches):
+    patches = _c(patches, np.uint8)
+    n, h, w = patches.shape
+    out = np.empty_like(patches)
+    ctx.check(lib().fd_equalize_hist_batch(ctx.h, _ptr(patches), n, w, h, _ptr(out)))
+    return out
+
+
+def whi_params(pw=20, ph=20, sx=2, sy=2, alpha=1.0, cutoff=0.390625):
+    return fd_whi_params(pw, ph, sx, sy, alpha, cutoff)
+
+
+def extract_whi(ctx, pyr, wp):
+    n = C.c_int64()
+    ctx.check(lib().fd_extract_whi(ctx.h, pyr.h, C.byref(wp), None, 0, C.byref(n)))
+    out = np.empty((n.value, wp.patch_w * wp.patch_h), np.float32)
+    ctx.check(lib().fd_extract_whi(ctx.h, pyr.h, C.byref(wp), _ptr(out), n.value, C.byref(n)))
+    return out
+
+
+def detect_whi_svm(ctx, pyr, svm, wp, want_all=True, cap=1 << 20):
+    n = pyr.window_count(wp.patch_w, wp.patch_h, wp.step_x, wp.step_y)
+    out = np.zeros(min(cap, max(n, 1)), DET_DTYPE)
+    alld = np.empty(n, np.float64) if want_all else None
+    cnt = C.c_int64()
+    ctx.check(lib().fd_detect_whi_svm(ctx.h, pyr.h, svm.h, C.byref(wp), _ptr(out), out.shape[0], C.byref(cnt), _ptr(alld)))
+    return out[:cnt.value], alld
 
 
 def detect_hog_svm(ctx, pyr, svm, hp, want_all=True, cap=1 << 20):

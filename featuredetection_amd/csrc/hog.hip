@@ -41,6 +41,8 @@ struct fd_svm;
 bool fd_svm_has_mfma_path(const fd_svm* m);
 int fd_svm_KP(const fd_svm* m);
 float fd_svm_threshold(const fd_svm* m);
+int fd_svm_dim(const fd_svm* m);
+bool fd_svm_is_u8(const fd_svm* m);
 double fd_svm_probability(const fd_svm* m, double d);
 void fd_svm_rbf_mfma_launch(fd_ctx* ctx, const fd_svm* m, const float* xFrag, const float* xx, int64_t npatches, double* out);
 void fd_svm_generic_launch(fd_ctx* ctx, const fd_svm* m, const void* dfeat, const uint32_t* didx, int64_t stride_bytes, int64_t n, double* dout);
@@ -225,7 +227,7 @@ __global__ void k_select_positives(const double* __restrict__ dist, int64_t n, f
 }
 
 struct HogScratch {
-    DevBuf feat, xx, dist, pos, counter, tables;
+    DevBuf feat, xx, dist, pos, counter, tables, histTables;
     HostBuf hcount;       // pinned read-back slot
     HogDev tabFor;        // parameters the tables were built for
     bool tabValid = false;
@@ -321,10 +323,12 @@ void launch_hog(fd_ctx* ctx, const fd_pyramid* p, const HogWinTable& wt, const H
     HIP_CHECK(hipGetLastError());
 }
 
-void build_table(const fd_pyramid* p, const fd_hog_params* hp, HogWinTable& wt, std::vector<WindowLayer>& wls) {
-    if (p->filter_kind != FD_LAYER_GRADBIN || p->interpolate)
-        FD_THROW(FD_ERR_INVALID_ARGUMENT, "HOG extraction needs a pyramid with the FD_LAYER_GRADBIN layer filter (no bin interpolation)");
-    if (p->bins != hp->bins) FD_THROW(FD_ERR_INVALID_ARGUMENT, "HogFilter bins (%d) differ from the layer filter bins (%d)", hp->bins, p->bins);
+void build_table(const fd_pyramid* p, const fd_hog_params* hp, HogWinTable& wt, std::vector<WindowLayer>& wls, bool any_bin_image = false) {
+    if (!any_bin_image) {
+        if (p->filter_kind != FD_LAYER_GRADBIN || p->interpolate)
+            FD_THROW(FD_ERR_INVALID_ARGUMENT, "HOG extraction needs a pyramid with the FD_LAYER_GRADBIN layer filter (no bin interpolation)");
+        if (p->bins != hp->bins) FD_THROW(FD_ERR_INVALID_ARGUMENT, "HogFilter bins (%d) differ from the layer filter bins (%d)", hp->bins, p->bins);
+    }
     if (p->all.empty()) FD_THROW(FD_ERR_RUNTIME, "pyramid has not been updated with an image");
     int64_t total;
     fd_enumerate_layers(p, hp->patch_w, hp->patch_h, hp->step_x, hp->step_y, nullptr, wls, total);
@@ -477,6 +481,529 @@ int fd_bench_hog_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_hog
             ctx->last_kernel = "k_svm_rbf_mfma";
             *positives = *S.hcount.as<unsigned int>();
         }
+    });
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+// Generic histogram features: every HistogramFilter subclass of the reference on top of
+// HistogramFilter::createCellHistograms (HistogramFilter.cpp:23-197, both the interpolating and the
+// non-interpolating path, 1/2/4-channel bin images):
+//   FD_HIST_HOG              HogFilter.cpp:58-122
+//   FD_HIST_SPATIAL          SpatialHistogramFilter.cpp:56-94 (block 1x1 and general blocks)
+//   FD_HIST_PYRAMID_HOG      PyramidHogFilter.cpp:33-113
+//   FD_HIST_SPATIAL_PYRAMID  SpatialPyramidHistogramFilter.cpp:37-81
+// One wavefront per window.  The patch of the filtered layer is staged in LDS; lane == cell walks the
+// pixels that contribute to its cell in the reference's scan order and accumulates into its private
+// histogram row, so every fp32 accumulator sees its addends in the reference order.  The block /
+// pyramid / normalisation stage runs with lane == block (or histogram) in the reference's loop order.
+// The k_hog_tile kernel above is the tuned special case (HOG, no interpolation, <= 64 cells) of this.
+struct HistDev {
+    int32_t kind, pw, ph, ch, bins, interpolate, sau, concatenate, normalization;
+    int32_t rows, cols;        // finest cell grid
+    int32_t blockW, blockH, brows, bcols;
+    int32_t maxLevel, histCount;
+    int32_t realBins;          // bins (+ bins/2 with signedAndUnsigned)
+    int32_t F;                 // feature length
+    int32_t cellsOff;          // float offset of the cell histograms inside the LDS vector area
+    int32_t ldsFloats;         // floats in the vector area
+    int32_t patchBytes;        // pw*ph*ch rounded up to 16
+};
+struct HistCache { int32_t i1, i2; float w1, w2; };   // HistogramFilter.cpp:199-220
+struct HistTables {
+    const HistCache* rowCache;   // [ph]
+    const HistCache* colCache;   // [pw]
+    const int32_t* rowRange;     // [rows] lo | hi << 16 (pixel rows contributing to a cell row)
+    const int32_t* colRange;     // [cols]
+};
+
+namespace {
+
+__device__ __forceinline__ double wave_sum_dd(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// HistogramFilter::normalize (HistogramFilter.cpp:222-251) of v[0..n) by ONE lane (sequential, like the reference)
+__device__ __forceinline__ void hist_normalize_seq(float* v, int n, int normalization) {
+    const float eps = 1e-4f;
+    auto l2 = [&]() {
+        double s = 0;
+        for (int i = 0; i < n; ++i) s += (double)v[i] * v[i];
+        const float norm = (float)sqrt(s);
+        const float inv = (float)(1.0 / (double)(norm + eps));
+        for (int i = 0; i < n; ++i) v[i] = v[i] * inv;
+    };
+    auto l1 = [&]() {
+        double s = 0;
+        for (int i = 0; i < n; ++i) s += fabs((double)v[i]);
+        const float norm = (float)s;
+        const float inv = (float)(1.0 / (double)(norm + eps));
+        for (int i = 0; i < n; ++i) v[i] = v[i] * inv;
+    };
+    if (normalization == 1) l2();
+    else if (normalization == 2) { l2(); for (int i = 0; i < n; ++i) v[i] = fminf(v[i], 0.2f); l2(); }
+    else if (normalization == 3) l1();
+    else if (normalization == 4) { l1(); for (int i = 0; i < n; ++i) v[i] = sqrtf(v[i]); }
+}
+
+// the same by the whole wave on a long vector (block 1x1 of SpatialHistogramFilter: one normalisation of
+// the concatenated cell histograms); the fp64 partial sums are combined in a different order than the
+// sequential loop, which the fp32 result tolerates (compared at 1e-6 relative in the tests)
+__device__ __forceinline__ void hist_normalize_wave(float* v, int n, int normalization, int lane) {
+    const float eps = 1e-4f;
+    auto l2 = [&]() {
+        double s = 0;
+        for (int i = lane; i < n; i += 64) s += (double)v[i] * v[i];
+        s = wave_sum_dd(s);
+        const float norm = (float)sqrt(s);
+        const float inv = (float)(1.0 / (double)(norm + eps));
+        for (int i = lane; i < n; i += 64) v[i] = v[i] * inv;
+        wave_sync();
+    };
+    auto l1 = [&]() {
+        double s = 0;
+        for (int i = lane; i < n; i += 64) s += fabs((double)v[i]);
+        s = wave_sum_dd(s);
+        const float norm = (float)s;
+        const float inv = (float)(1.0 / (double)(norm + eps));
+        for (int i = lane; i < n; i += 64) v[i] = v[i] * inv;
+        wave_sync();
+    };
+    if (normalization == 1) l2();
+    else if (normalization == 2) {
+        l2();
+        for (int i = lane; i < n; i += 64) v[i] = fminf(v[i], 0.2f);
+        wave_sync();
+        l2();
+    } else if (normalization == 3) l1();
+    else if (normalization == 4) {
+        l1();
+        for (int i = lane; i < n; i += 64) v[i] = sqrtf(v[i]);
+        wave_sync();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_hist_features(const uint8_t* __restrict__ arena, HogWinTable wt, HistDev hd, HistTables tab,
+                                                      float* __restrict__ feat) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int pw = hd.pw, ph = hd.ph, ch = hd.ch, B = hd.bins;
+    const int R = hd.rows, Cc = hd.cols, ncells = R * Cc;
+    unsigned char* patch = smem;                                           // [ph][pw][ch]
+    HistCache* rowCache = (HistCache*)(smem + hd.patchBytes);               // [ph]
+    HistCache* colCache = rowCache + ph;                                    // [pw]
+    int32_t* rowRange = (int32_t*)(colCache + pw);                          // [R]
+    int32_t* colRange = rowRange + R;                                       // [Cc]
+    float* vec = (float*)(((size_t)(colRange + Cc) + 15) & ~(size_t)15);    // [ldsFloats]: output vector (+ raw cells, scratch)
+    float* cells = vec + hd.cellsOff;                                       // [ncells][B]
+    if (hd.interpolate) {
+        for (int i = lane; i < ph; i += 64) rowCache[i] = tab.rowCache[i];
+        for (int i = lane; i < pw; i += 64) colCache[i] = tab.colCache[i];
+        for (int i = lane; i < R; i += 64) rowRange[i] = tab.rowRange[i];
+        for (int i = lane; i < Cc; i += 64) colRange[i] = tab.colRange[i];
+    }
+    const float factor = 1.f / 255.f;
+    const float eps = 1e-4f;
+    const int rowBytes = pw * ch;
+
+    for (int64_t wid = blockIdx.x; wid < wt.total; wid += gridDim.x) {
+        // ---- window -> layer position (DirectPyramidFeatureExtractor.cpp:75-123 order)
+        int li = 0;
+        for (int l = 1; l < wt.n; ++l) li = wt.l[l].first <= wid ? l : li;
+        const HogWinLayer& wl = wt.l[li];
+        const int local = (int)(wid - wl.first);
+        const int iy = local / wl.nx, ix = local - iy * wl.nx;
+        const uint8_t* src = arena + wl.off + ((size_t)(wl.by + iy * wt.sy) * wl.lw + (wl.bx + ix * wt.sx)) * ch;
+        const size_t srcStride = (size_t)wl.lw * ch;
+        for (int i = lane; i < ph * rowBytes; i += 64) {
+            const int y = i / rowBytes, xb = i - y * rowBytes;
+            patch[i] = src[(size_t)y * srcStride + xb];
+        }
+        for (int i = lane; i < hd.ldsFloats; i += 64) vec[i] = 0.f;
+        wave_sync();
+
+        // ---- cell histograms: lane == cell
+        for (int c = lane; c < ncells; c += 64) {
+            const int cr = c / Cc, cc = c - cr * Cc;
+            float* hv = cells + (size_t)c * B;
+            if (!hd.interpolate) {   // HistogramFilter.cpp:130-163
+                const int sr = (cr * ph) / R, er = ((cr + 1) * ph) / R;
+                const int sc = (cc * pw) / Cc, ec = ((cc + 1) * pw) / Cc;
+                for (int y = sr; y < er; ++y)
+                    for (int x = sc; x < ec; ++x) {
+                        const unsigned char* px = patch + (y * pw + x) * ch;
+                        if (ch == 1) {
+                            if (px[0] < B) hv[px[0]] = hv[px[0]] + 1.f;
+                        } else {
+                            if (px[0] < B) hv[px[0]] = hv[px[0]] + factor * (float)px[1];
+                            if (ch == 4 && px[2] < B) hv[px[2]] = hv[px[2]] + factor * (float)px[3];
+                        }
+                    }
+            } else {                 // HistogramFilter.cpp:36-128: bilinear cell interpolation
+                const int ylo = rowRange[cr] & 0xffff, yhi = rowRange[cr] >> 16;
+                const int xlo = colRange[cc] & 0xffff, xhi = colRange[cc] >> 16;
+                for (int y = ylo; y <= yhi; ++y) {
+                    const HistCache rc = rowCache[y];
+                    for (int x = xlo; x <= xhi; ++x) {
+                        const HistCache kc = colCache[x];
+                        const unsigned char* px = patch + (y * pw + x) * ch;
+                        const float wt0 = ch == 1 ? 1.f : factor * (float)px[1];
+                        const float wt1 = ch == 4 ? factor * (float)px[3] : 0.f;
+                        // the four (row, column) neighbours in the reference's order; only mine are added
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int rr = (q & 2) ? rc.i2 : rc.i1, qc = (q & 1) ? kc.i2 : kc.i1;
+                            if (rr != cr || qc != cc) continue;
+                            const float wr = (q & 2) ? rc.w2 : rc.w1, wc = (q & 1) ? kc.w2 : kc.w1;
+                            if (ch == 1) {
+                                if (px[0] < B) hv[px[0]] = hv[px[0]] + wr * wc;
+                            } else {
+                                if (px[0] < B) hv[px[0]] = hv[px[0]] + wt0 * wr * wc;
+                                if (ch == 4 && px[2] < B) hv[px[2]] = hv[px[2]] + wt1 * wr * wc;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        wave_sync();
+
+        // ---- feature vector
+        float* out = vec;
+        if (hd.kind == FD_HIST_HOG) {
+            // scratch behind the cells: energies [ncells], then normalisers [nblocks]
+            float* energy = cells + (size_t)ncells * B;
+            float* nrm = energy + ncells;
+            const int hb = B / 2, nblocks = hd.brows * hd.bcols;
+            for (int c = lane; c < ncells; c += 64) {   // HogFilter.cpp:102-122
+                const float* hv = cells + (size_t)c * B;
+                float en = 0.f;
+                if (hd.sau) for (int b = 0; b < hb; ++b) { const float u = hv[b] + hv[hb + b]; en = en + u * u; }
+                else for (int b = 0; b < B; ++b) en = en + hv[b] * hv[b];
+                energy[c] = en;
+            }
+            wave_sync();
+            const int perCell = hd.realBins, perBlock = hd.blockW * hd.blockH * perCell;
+            for (int bl = lane; bl < nblocks; bl += 64) {   // HogFilter.cpp:69-100
+                const int br = bl / hd.bcols, bc = bl - br * hd.bcols;
+                float en = 0.f;
+                for (int r2 = br; r2 < br + hd.blockH; ++r2)
+                    for (int c2 = bc; c2 < bc + hd.blockW; ++c2) en = en + energy[r2 * Cc + c2];
+                nrm[bl] = 1.f / sqrtf(en + eps);
+            }
+            wave_sync();
+            for (int o = lane; o < hd.F; o += 64) {
+                const int bl = o / perBlock, w = o - bl * perBlock, ci = w / perCell, b = w - ci * perCell;
+                const int br = bl / hd.bcols, bc = bl - br * hd.bcols;
+                const float* hv = cells + (size_t)((br + ci / hd.blockW) * Cc + (bc + ci % hd.blockW)) * B;
+                out[o] = b < B ? nrm[bl] * hv[b] : nrm[bl] * (hv[b - B] + hv[b - B + hb]);
+            }
+            wave_sync();
+        } else if (hd.kind == FD_HIST_SPATIAL) {
+            if (hd.blockW == 1 && hd.blockH == 1) {   // SpatialHistogramFilter.cpp:60-63: cells are the vector
+                hist_normalize_wave(out, hd.F, hd.normalization, lane);
+            } else {               // :64-92
+                const int nblocks = hd.brows * hd.bcols;
+                const int bhs = hd.concatenate ? hd.blockW * hd.blockH * B : B;
+                for (int bl = lane; bl < nblocks; bl += 64) {
+                    const int br = bl / hd.bcols, bc = bl - br * hd.bcols;
+                    float* o = out + (size_t)bl * bhs;
+                    for (int r2 = br; r2 < br + hd.blockH; ++r2)
+                        for (int c2 = bc; c2 < bc + hd.blockW; ++c2) {
+                            const float* hv = cells + (size_t)(r2 * Cc + c2) * B;
+                            for (int b = 0; b < B; ++b) o[b] = o[b] + hv[b];
+                            if (hd.concatenate) o += B;
+                        }
+                    hist_normalize_seq(out + (size_t)bl * bhs, bhs, hd.normalization);
+                }
+                wave_sync();
+            }
+        } else {   // pyramid kinds
+            const int RB = hd.realBins, hb = B / 2;
+            const int finest = 1 << (2 * hd.maxLevel);
+            float* level = out + (size_t)(hd.histCount - finest) * RB;
+            if (hd.kind == FD_HIST_PYRAMID_HOG) {   // copyCellHistograms, PyramidHogFilter.cpp:57-74
+                for (int i = lane; i < finest * RB; i += 64) {
+                    const int c = i / RB, b = i - c * RB;
+                    const float* hv = cells + (size_t)c * B;
+                    level[i] = b < B ? hv[b] : hv[b - B] + hv[b - B + hb];
+                }
+                wave_sync();
+            }   // FD_HIST_SPATIAL_PYRAMID: the cells were accumulated in place (cellsOff)
+            for (int lv = hd.maxLevel - 1; lv >= 0; --lv) {   // combineHistograms: children in row-major order
+                const int bcnt = 1 << lv, ccnt = bcnt << 1;
+                float* parent = level - (size_t)(bcnt * bcnt) * RB;
+                for (int i = lane; i < bcnt * bcnt * RB; i += 64) {
+                    const int bl = i / RB, b = i - bl * RB;
+                    const int br = bl / bcnt, bc = bl - br * bcnt;
+                    float s = 0.f;
+                    for (int r2 = 2 * br; r2 < 2 * br + 2; ++r2)
+                        for (int c2 = 2 * bc; c2 < 2 * bc + 2; ++c2) s = s + level[(size_t)(r2 * ccnt + c2) * RB + b];
+                    parent[i] = s;
+                }
+                wave_sync();
+                level = parent;
+            }
+            for (int hgi = lane; hgi < hd.histCount; hgi += 64) {
+                float* hv = out + (size_t)hgi * RB;
+                if (hd.kind == FD_HIST_PYRAMID_HOG) {   // normalizeHistograms, PyramidHogFilter.cpp:94-113
+                    float en = 0.f;
+                    if (hd.sau) for (int b = B; b < RB; ++b) en = en + hv[b] * hv[b];
+                    else for (int b = 0; b < B; ++b) en = en + hv[b] * hv[b];
+                    const float normalizer = 1.f / sqrtf(en + eps);
+                    for (int b = 0; b < RB; ++b) hv[b] = normalizer * hv[b];
+                } else {
+                    hist_normalize_seq(hv, RB, hd.normalization);
+                }
+            }
+            wave_sync();
+        }
+        for (int i = lane; i < hd.F; i += 64) feat[(size_t)wid * hd.F + i] = out[i];
+        wave_sync();
+    }
+}
+
+HistDev make_histdev(const fd_hist_params* hp, int ch) {
+    if (!hp) FD_THROW(FD_ERR_INVALID_ARGUMENT, "NULL histogram parameters");
+    if (hp->bins <= 0 || hp->bins > 256) FD_THROW(FD_ERR_INVALID_ARGUMENT, "HistogramFilter: binCount must be within 1..256");
+    if (hp->patch_w < 1 || hp->patch_h < 1 || hp->patch_w > 64 || hp->patch_h > 64)
+        FD_THROW(FD_ERR_INVALID_ARGUMENT, "patch size must be within 1..64 on this backend");
+    HistDev d;
+    std::memset(&d, 0, sizeof(d));
+    d.kind = hp->kind; d.pw = hp->patch_w; d.ph = hp->patch_h; d.ch = ch; d.bins = hp->bins;
+    d.interpolate = hp->interpolate ? 1 : 0;
+    d.sau = hp->signed_and_unsigned ? 1 : 0;
+    d.concatenate = hp->concatenate ? 1 : 0;
+    d.normalization = hp->normalization;
+    d.realBins = d.bins;
+    if (d.kind == FD_HIST_HOG || d.kind == FD_HIST_SPATIAL) {
+        const char* who = d.kind == FD_HIST_HOG ? "HogFilter" : "SpatialHistogramFilter";
+        if (hp->cell_size <= 0) FD_THROW(FD_ERR_INVALID_ARGUMENT, "%s: cellSize must be greater than zero", who);
+        if (hp->block_size <= 0) FD_THROW(FD_ERR_INVALID_ARGUMENT, "%s: blockSize must be greater than zero", who);
+        if (hp->cell_h < 0 || hp->block_h < 0) FD_THROW(FD_ERR_INVALID_ARGUMENT, "%s: negative cell/block height", who);
+        const int cellH = hp->cell_h > 0 ? hp->cell_h : hp->cell_size;
+        d.rows = fd_cvRound((double)d.ph / (double)cellH);
+        d.cols = fd_cvRound((double)d.pw / (double)hp->cell_size);
+        d.blockW = hp->block_size;
+        d.blockH = hp->block_h > 0 ? hp->block_h : hp->block_size;
+        d.brows = d.rows - d.blockH + 1;
+        d.bcols = d.cols - d.blockW + 1;
+        if (d.rows < 1 || d.cols < 1 || d.brows < 1 || d.bcols < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "%s: patch smaller than one block", who);
+        if (d.kind == FD_HIST_HOG) {
+            if (d.sau && d.bins % 2 != 0)
+                FD_THROW(FD_ERR_INVALID_ARGUMENT, "HogFilter: the bin size must be even for signed and unsigned gradients to be combined");
+            d.realBins = d.sau ? d.bins + d.bins / 2 : d.bins;
+            d.F = d.brows * d.bcols * d.blockW * d.blockH * d.realBins;
+            d.cellsOff = (d.F + 3) & ~3;   // raw cells (+ energies, normalisers) behind the output vector
+            d.ldsFloats = d.cellsOff + d.rows * d.cols * d.bins + d.rows * d.cols + d.brows * d.bcols;
+        } else {
+            d.sau = 0;
+            if (d.normalization < 0 || d.normalization > 4) FD_THROW(FD_ERR_INVALID_ARGUMENT, "SpatialHistogramFilter: invalid normalization");
+            if (d.blockW == 1 && d.blockH == 1) {
+                d.F = d.rows * d.cols * d.bins;
+                d.cellsOff = 0;
+                d.ldsFloats = d.F;
+            } else {
+                d.F = d.brows * d.bcols * (d.concatenate ? d.blockW * d.blockH * d.bins : d.bins);
+                d.cellsOff = (d.F + 3) & ~3;
+                d.ldsFloats = d.cellsOff + d.rows * d.cols * d.bins;
+            }
+        }
+    } else if (d.kind == FD_HIST_PYRAMID_HOG || d.kind == FD_HIST_SPATIAL_PYRAMID) {
+        const char* who = d.kind == FD_HIST_PYRAMID_HOG ? "PyramidHogFilter" : "SpatialPyramidHistogramFilter";
+        if (hp->levels <= 0 || hp->levels > 5) FD_THROW(FD_ERR_INVALID_ARGUMENT, "%s: levelCount must be within 1..5", who);
+        d.maxLevel = hp->levels - 1;
+        for (int l = 0; l < hp->levels; ++l) d.histCount += 1 << (2 * l);
+        d.rows = d.cols = 1 << d.maxLevel;
+        d.blockW = d.blockH = 1; d.brows = d.rows; d.bcols = d.cols;
+        if (d.kind == FD_HIST_PYRAMID_HOG) {
+            if (d.sau && d.bins % 2 != 0)
+                FD_THROW(FD_ERR_INVALID_ARGUMENT, "PyramidHogFilter: the bin size must be even for signed and unsigned gradients to be combined");
+            d.realBins = d.sau ? d.bins + d.bins / 2 : d.bins;
+            d.F = d.histCount * d.realBins;
+            d.cellsOff = (d.F + 3) & ~3;
+            d.ldsFloats = d.cellsOff + d.rows * d.cols * d.bins;
+        } else {
+            d.sau = 0;
+            if (d.normalization < 0 || d.normalization > 4) FD_THROW(FD_ERR_INVALID_ARGUMENT, "SpatialPyramidHistogramFilter: invalid normalization");
+            d.F = d.histCount * d.bins;
+            d.cellsOff = (d.histCount - d.rows * d.cols) * d.bins;   // finest level accumulates in place
+            d.ldsFloats = d.F;
+        }
+    } else {
+        FD_THROW(FD_ERR_INVALID_ARGUMENT, "invalid histogram feature kind %d", d.kind);
+    }
+    d.patchBytes = (d.pw * d.ph * d.ch + 15) & ~15;
+    return d;
+}
+
+size_t hist_lds_bytes(const HistDev& d) {
+    return (size_t)d.patchBytes + sizeof(HistCache) * (size_t)(d.pw + d.ph) + sizeof(int32_t) * (size_t)(d.rows + d.cols) + 16 +
+           sizeof(float) * (size_t)d.ldsFloats;
+}
+
+// HistogramFilter::createCache (HistogramFilter.cpp:199-220) + the pixel range each cell row/column receives
+void hist_tables(fd_ctx* ctx, HogScratch& S, const HistDev& d, HistTables& tb) {
+    std::vector<unsigned char> blob;
+    auto cache = [](int size, int count, std::vector<HistCache>& c, std::vector<int32_t>& range) {
+        c.resize(size);
+        std::vector<int> lo(count, 1 << 20), hi(count, -1);
+        for (int m = 0; m < size; ++m) {
+            HistCache e;
+            const double realIndex = (double)count * ((double)m + 0.5) / (double)size - 0.5;
+            e.i1 = (int)std::floor(realIndex);
+            e.i2 = e.i1 + 1;
+            e.w2 = (float)(realIndex - e.i1);
+            e.w1 = 1.f - e.w2;
+            if (e.i1 < 0) { e.i1 = e.i2; e.w1 = 0; }
+            else if (e.i2 >= count) { e.i2 = e.i1; e.w2 = 0; }
+            c[m] = e;
+            for (int idx : {e.i1, e.i2}) { lo[idx] = std::min(lo[idx], m); hi[idx] = std::max(hi[idx], m); }
+        }
+        range.resize(count);
+        for (int i = 0; i < count; ++i) range[i] = hi[i] < 0 ? (1 | (0 << 16)) : (lo[i] | (hi[i] << 16));   // empty: lo > hi
+    };
+    std::vector<HistCache> rc, cc;
+    std::vector<int32_t> rr, cr;
+    cache(d.ph, d.rows, rc, rr);
+    cache(d.pw, d.cols, cc, cr);
+    const size_t o1 = sizeof(HistCache) * rc.size(), o2 = o1 + sizeof(HistCache) * cc.size(), o3 = o2 + 4 * rr.size();
+    blob.resize(o3 + 4 * cr.size());
+    std::memcpy(blob.data(), rc.data(), o1);
+    std::memcpy(blob.data() + o1, cc.data(), o2 - o1);
+    std::memcpy(blob.data() + o2, rr.data(), o3 - o2);
+    std::memcpy(blob.data() + o3, cr.data(), 4 * cr.size());
+    S.histTables.reserve(blob.size());
+    HIP_CHECK(hipMemcpyAsync(S.histTables.p, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    tb.rowCache = (const HistCache*)S.histTables.p;
+    tb.colCache = (const HistCache*)((const char*)S.histTables.p + o1);
+    tb.rowRange = (const int32_t*)((const char*)S.histTables.p + o2);
+    tb.colRange = (const int32_t*)((const char*)S.histTables.p + o3);
+}
+
+// features of every window, plain [N][F] layout, into S.feat; returns N
+int64_t run_hist_features(fd_ctx* ctx, fd_pyramid* p, const fd_hist_params* hp, std::vector<WindowLayer>& wls, HogScratch& S, HistDev& hd) {
+    if (!hp) FD_THROW(FD_ERR_INVALID_ARGUMENT, "NULL histogram parameters");
+    if (p->filter_kind != FD_LAYER_GRADBIN && p->filter_kind != FD_LAYER_LBP)
+        FD_THROW(FD_ERR_INVALID_ARGUMENT, "histogram features need a pyramid whose layers are bin images (FD_LAYER_GRADBIN or FD_LAYER_LBP)");
+    if (p->all.empty()) FD_THROW(FD_ERR_RUNTIME, "pyramid has not been updated with an image");
+    const int ch = p->all[p->kept[0]].ch;
+    if ((hp->kind == FD_HIST_HOG || hp->kind == FD_HIST_PYRAMID_HOG) && ch == 1)
+        FD_THROW(FD_ERR_INVALID_ARGUMENT, "HOG features need a gradient bin image (FD_LAYER_GRADBIN)");
+    if (p->filter_kind == FD_LAYER_GRADBIN && p->bins != hp->bins)
+        FD_THROW(FD_ERR_INVALID_ARGUMENT, "histogram bins (%d) differ from the layer filter bins (%d)", hp->bins, p->bins);
+    hd = make_histdev(hp, ch);
+    fd_hog_params g;
+    std::memset(&g, 0, sizeof(g));
+    g.patch_w = hp->patch_w; g.patch_h = hp->patch_h; g.step_x = hp->step_x; g.step_y = hp->step_y; g.bins = hp->bins;
+    HogWinTable wt;
+    build_table(p, &g, wt, wls, /*any_bin_image=*/true);
+    const int64_t N = wt.total;
+    if (N == 0) return 0;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t lds = hist_lds_bytes(hd);
+    if (lds > 160 * 1024) FD_THROW(FD_ERR_INVALID_ARGUMENT, "histogram feature vector too long for the LDS (%d floats)", hd.F);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_hist_features, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    HistTables tb;
+    hist_tables(ctx, S, hd, tb);
+    S.feat.reserve(sizeof(float) * (size_t)N * hd.F);
+    const int grid = (int)std::min<int64_t>(N, (int64_t)ctx->num_cus * 32);
+    hipLaunchKernelGGL(k_hist_features, dim3(grid), dim3(64), lds, ctx->stream, p->arena.as<uint8_t>(), wt, hd, tb, S.feat.as<float>());
+    HIP_CHECK(hipGetLastError());
+    return N;
+}
+
+}  // namespace
+
+// classifier positives (distance >= threshold, SvmClassifier.cpp:44-46) of N scored windows -> detection
+// records in extraction order, with the logistic probability (ProbabilisticSvmClassifier.cpp:50-58)
+void fd_svm_positives_to_detections(fd_ctx* ctx, const fd_pyramid* p, const fd_svm* svm, const std::vector<WindowLayer>& wls, int sx, int sy,
+                                    const double* ddist, int64_t N, fd_detection* out, int64_t cap, int64_t* count, double* all_distance) {
+    HogScratch& S = scratch(ctx);
+    hipStream_t st = ctx->stream;
+    const unsigned int pcap = (unsigned int)std::min<int64_t>(N, 1 << 22);
+    S.pos.reserve(sizeof(HogPos) * (size_t)pcap);
+    S.counter.reserve(256);
+    HIP_CHECK(hipMemsetAsync(S.counter.p, 0, 4, st));
+    hipLaunchKernelGGL(k_select_positives, dim3((unsigned)std::min<int64_t>((N + 255) / 256, 2048)), dim3(256), 0, st, ddist, N,
+                       fd_svm_threshold(svm), S.pos.as<HogPos>(), S.counter.as<unsigned int>(), pcap);
+    HIP_CHECK(hipGetLastError());
+    unsigned int* hcnt = (unsigned int*)fd_pinned(ctx, 64);
+    HIP_CHECK(hipMemcpyAsync(hcnt, S.counter.p, 4, hipMemcpyDeviceToHost, st));
+    if (all_distance) HIP_CHECK(hipMemcpyAsync(all_distance, ddist, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    const unsigned int cnt = *hcnt;
+    if (cnt > pcap) FD_THROW(FD_ERR_CAPACITY, "%u positives exceed the device buffer", cnt);
+    std::vector<HogPos> raw(cnt);
+    if (cnt) HIP_CHECK(hipMemcpy(raw.data(), S.pos.p, sizeof(HogPos) * cnt, hipMemcpyDeviceToHost));
+    auto widof = [](const HogPos& r) { return ((uint64_t)r.wid_hi << 32) | r.wid_lo; };
+    std::sort(raw.begin(), raw.end(), [&](const HogPos& a, const HogPos& b) { return widof(a) < widof(b); });
+    *count = cnt;
+    for (unsigned int i = 0; i < cnt && out && (int64_t)i < cap; ++i) {
+        fd_detection d;
+        std::memset(&d, 0, sizeof(d));
+        window_geometry(p, wls, sx, sy, (int64_t)widof(raw[i]), d);
+        d.level = -1;
+        d.positive = 1;
+        d.score = (float)raw[i].dist;
+        d.probability = fd_svm_probability(svm, raw[i].dist);
+        out[i] = d;
+    }
+    if (out && (int64_t)cnt > cap) FD_THROW(FD_ERR_CAPACITY, "%u positives, capacity %lld", cnt, (long long)cap);
+}
+
+extern "C" {
+
+int fd_hist_feature_length(const fd_hist_params* hp, int channels) {
+    try { return make_histdev(hp, channels).F; } catch (...) { return -1; }
+}
+
+int fd_extract_hist(fd_ctx* ctx, fd_pyramid* p, const fd_hist_params* hp, float* features, int64_t cap_windows, int64_t* count) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !p || !hp || !count) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_extract_hist: NULL argument");
+        HogScratch& S = scratch(ctx);
+        std::vector<WindowLayer> wls;
+        HistDev hd;
+        if (!features) {   // count only
+            int64_t total;
+            fd_enumerate_layers(p, hp->patch_w, hp->patch_h, hp->step_x, hp->step_y, nullptr, wls, total);
+            *count = total;
+            return;
+        }
+        const int64_t N = run_hist_features(ctx, p, hp, wls, S, hd);
+        *count = N;
+        if (N == 0) return;
+        if (N > cap_windows) FD_THROW(FD_ERR_CAPACITY, "fd_extract_hist: %lld windows, capacity %lld", (long long)N, (long long)cap_windows);
+        HIP_CHECK(hipMemcpyAsync(features, S.feat.p, sizeof(float) * (size_t)N * hd.F, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+// SlidingWindowDetector::detect (SlidingWindowDetector.cpp:87-98) with a histogram patch filter and a
+// ProbabilisticSvmClassifier on f32 feature vectors (any kernel; BenchmarkRunner.cpp:185-263 wiring)
+int fd_detect_hist_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_hist_params* hp, fd_detection* out, int64_t cap,
+                       int64_t* count, double* all_distance) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !p || !svm || !hp || !count) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_hist_svm: NULL argument");
+        HogScratch& S = scratch(ctx);
+        std::vector<WindowLayer> wls;
+        HistDev hd;
+        const int64_t N = run_hist_features(ctx, p, hp, wls, S, hd);
+        *count = 0;
+        if (N == 0) return;
+        if (fd_svm_dim(svm) != hd.F || fd_svm_is_u8(svm))
+            FD_THROW(FD_ERR_INVALID_ARGUMENT, "SVM must work on f32 vectors of length %d", hd.F);
+        hipStream_t st = ctx->stream;
+        S.dist.reserve(sizeof(double) * (size_t)N);
+        fd_svm_generic_launch(ctx, svm, S.feat.p, nullptr, (int64_t)hd.F * 4, N, S.dist.as<double>());
+        fd_svm_positives_to_detections(ctx, p, svm, wls, hp->step_x, hp->step_y, S.dist.as<double>(), N, out, cap, count, all_distance);
     });
 }
 

@@ -1,0 +1,418 @@
+// featuredetection_amd/csrc/whi.hip -- the "whi" patch filter chain of ffpDetectApp.cpp:449-454:
+//   WhiteningFilter (WhiteningFilter.cpp:20-81) -> HistogramEqualizationFilter (cv::equalizeHist) ->
+//   ConversionFilter(CV_32F, 1/127.5, -1) -> UnitNormFilter(NORM_L2) (UnitNormFilter.cpp, eps 1e-4)
+// and the stand-alone HistogramEqualizationFilter ("histeq" feature space, :446-448).
+//
+// One wavefront per patch.  The two DFTs of the whitening filter are evaluated as separable plain
+// DFTs in fp64 (row pass, column pass; patch sizes are 16..32, so a pass is a 20-term sum per
+// output), every lane owning complete output sums in the k order of oracle/orc_filters.cpp whi(): the
+// whitened u8 image and the equalised image are bit-identical to the CPU restatement; only the final
+// L2 norm is reduced across lanes.  All intermediates live in LDS (32 bytes per pixel); HBM traffic
+// is the patch read (L2 hits for overlapping windows) and the 4*w*h-byte feature write.
+#include "fd_internal.hpp"
+#include <algorithm>
+#include <complex>
+#include <cstring>
+#include <memory>
+
+struct fd_svm;
+float fd_svm_threshold(const fd_svm* m);
+int fd_svm_dim(const fd_svm* m);
+bool fd_svm_is_u8(const fd_svm* m);
+void fd_svm_generic_launch(fd_ctx* ctx, const fd_svm* m, const void* dfeat, const uint32_t* didx, int64_t stride_bytes, int64_t n, double* dout);
+void fd_svm_positives_to_detections(fd_ctx* ctx, const fd_pyramid* p, const fd_svm* svm, const std::vector<WindowLayer>& wls, int sx, int sy,
+                                    const double* ddist, int64_t N, fd_detection* out, int64_t cap, int64_t* count, double* all_distance);
+
+constexpr int WHI_MAX_LAYERS = 64;
+constexpr int WHI_MAX_DIM = 32;
+
+struct WhiWinLayer {
+    int32_t bx, by, nx, ny;
+    int32_t lw;
+    uint32_t off;
+    int64_t first;
+};
+struct WhiWinTable {
+    int32_t n, sx, sy, raw;   // raw != 0: `total` contiguous w x h patches
+    int64_t total;
+    WhiWinLayer l[WHI_MAX_LAYERS];
+};
+struct WhiDev {
+    int32_t w, h;
+    const double* twRow;   // [w][w] (re, im) = polar(1, -2 pi x k / w)
+    const double* twCol;   // [h][h]
+    const float* filt;     // [h][w]  WhiteningFilter.cpp:62-81
+};
+
+namespace {
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ unsigned char sat_u8_d(double v) {   // saturate_cast<uchar>(double): cvRound, clamp
+    const int i = (int)rint(v);
+    return (unsigned char)(i < 0 ? 0 : (i > 255 ? 255 : i));
+}
+
+// cv::equalizeHist of the n-pixel image `px` (LDS) by one wave; hist/lut: 256 ints each (LDS)
+__device__ __forceinline__ void equalize_hist_wave(const unsigned char* px, unsigned char* out, int n, int* hist, int* lut, int lane) {
+    for (int i = lane; i < 256; i += 64) hist[i] = 0;
+    wave_sync();
+    for (int i = lane; i < n; i += 64) atomicAdd(&hist[px[i]], 1);
+    wave_sync();
+    // lane l owns bins 4l..4l+3
+    int c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c[k] = hist[4 * lane + k];
+    const int mine = c[0] + c[1] + c[2] + c[3];
+    const unsigned long long nz = __ballot(mine != 0);
+    const int l0 = __builtin_ctzll(nz);                        // lane holding the first non-empty bin
+    int i0 = 0;
+    if (lane == l0) i0 = c[0] ? 0 : (c[1] ? 1 : (c[2] ? 2 : 3));
+    i0 = 4 * l0 + __builtin_amdgcn_readlane(i0, l0);
+    const int h0 = hist[i0];
+    if (h0 == n) {
+        for (int i = lane; i < n; i += 64) out[i] = (unsigned char)i0;
+        wave_sync();
+        return;
+    }
+    const float scale = (256 - 1.f) / (float)(n - h0);
+    // inclusive prefix over lanes of the per-lane totals (integer: order-free)
+    int incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    int run = incl - mine;   // sum of all bins before 4*lane
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int bin = 4 * lane + k;
+        run += c[k];
+        // lut[i0] = 0; lut[i] = saturate(sum_{j in (i0, i]} hist[j] * scale)
+        lut[bin] = bin <= i0 ? 0 : (int)sat_u8_d((double)((float)(run - h0) * scale));
+    }
+    wave_sync();
+    for (int i = lane; i < n; i += 64) out[i] = (unsigned char)lut[px[i]];
+    wave_sync();
+}
+
+__device__ __forceinline__ const uint8_t* locate(const uint8_t* arena, const WhiWinTable& wt, int64_t wid, int w, int h, int& stride) {
+    if (wt.raw) {
+        stride = w;
+        return arena + (size_t)wid * w * h;
+    }
+    int li = 0;
+    for (int l = 1; l < wt.n; ++l) li = wt.l[l].first <= wid ? l : li;
+    const WhiWinLayer& wl = wt.l[li];
+    const int local = (int)(wid - wl.first);
+    const int iy = local / wl.nx, ix = local - iy * wl.nx;
+    stride = wl.lw;
+    return arena + wl.off + (size_t)(wl.by + iy * wt.sy) * wl.lw + (wl.bx + ix * wt.sx);
+}
+
+// EQ_ONLY: HistogramEqualizationFilter alone, u8 output
+template <bool EQ_ONLY>
+__global__ __launch_bounds__(64) void k_whi(const uint8_t* __restrict__ arena, WhiWinTable wt, WhiDev d, float* __restrict__ feat,
+                                            uint8_t* __restrict__ eqOut) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int w = d.w, h = d.h, n = w * h;
+    double* Are = (double*)smem;          // T, later U
+    double* Aim = Are + n;
+    double* Bre = Aim + n;                // filtered spectrum
+    double* Bim = Bre + n;
+    int* hist = (int*)(Bim + n);
+    int* lut = hist + 256;
+    unsigned char* px = (unsigned char*)(lut + 256);   // [n] input patch, later the whitened u8 image
+    unsigned char* eq = px + ((n + 15) & ~15);         // [n]
+    for (int64_t wid = blockIdx.x; wid < wt.total; wid += gridDim.x) {
+        int stride;
+        const uint8_t* src = locate(arena, wt, wid, w, h, stride);
+        for (int i = lane; i < n; i += 64) {
+            const int y = i / w, x = i - y * w;
+            px[i] = src[(size_t)y * stride + x];
+        }
+        wave_sync();
+        if (!EQ_ONLY) {
+            // forward DFT (DFT_SCALE | DFT_COMPLEX_OUTPUT): rows
+            for (int o = lane; o < n; o += 64) {
+                const int v = o / w, x = o - v * w;
+                const double* tw = d.twRow + (size_t)x * w * 2;
+                double sr = 0, si = 0;
+                for (int k = 0; k < w; ++k) {
+                    const double p = (double)px[v * w + k];
+                    sr = sr + p * tw[2 * k];
+                    si = si + p * tw[2 * k + 1];
+                }
+                Are[o] = sr;
+                Aim[o] = si;
+            }
+            wave_sync();
+            // columns, 1/n, float spectrum, whitening filter in float (WhiteningFilter.cpp:38-45)
+            for (int o = lane; o < n; o += 64) {
+                const int y = o / w, u = o - y * w;
+                const double* tw = d.twCol + (size_t)y * h * 2;
+                double sr = 0, si = 0;
+                for (int k = 0; k < h; ++k) {
+                    const double ar = Are[k * w + u], ai = Aim[k * w + u];
+                    const double br = tw[2 * k], bi = tw[2 * k + 1];
+                    sr = sr + (ar * br - ai * bi);
+                    si = si + (ar * bi + ai * br);
+                }
+                const float f = d.filt[o];
+                Bre[o] = (double)((float)(sr / n) * f);
+                Bim[o] = (double)((float)(si / n) * f);
+            }
+            wave_sync();
+            // inverse DFT (DFT_INVERSE | DFT_REAL_OUTPUT): rows over the conjugate-symmetric completion of the half spectrum
+            for (int o = lane; o < n; o += 64) {
+                const int v = o / w, x = o - v * w;
+                const double* tw = d.twRow + (size_t)x * w * 2;
+                const int rr = (h - v) % h;
+                double sr = 0, si = 0;
+                for (int u = 0; u < w; ++u) {
+                    const int cc = (w - u) % w;
+                    const bool own = u < cc || (u == cc && v <= rr);
+                    const double gr = own ? Bre[v * w + u] : Bre[rr * w + cc];
+                    const double gi = own ? Bim[v * w + u] : -Bim[rr * w + cc];
+                    const double br = tw[2 * u], bi = -tw[2 * u + 1];
+                    sr = sr + (gr * br - gi * bi);
+                    si = si + (gr * bi + gi * br);
+                }
+                Are[o] = sr;
+                Aim[o] = si;
+            }
+            wave_sync();
+            // columns (real part), convertTo(CV_8U, 1, 127)
+            for (int o = lane; o < n; o += 64) {
+                const int y = o / w, x = o - y * w;
+                const double* tw = d.twCol + (size_t)y * h * 2;
+                double sr = 0;
+                for (int v = 0; v < h; ++v) {
+                    const double br = tw[2 * v], bi = -tw[2 * v + 1];
+                    sr = sr + (Are[v * w + x] * br - Aim[v * w + x] * bi);
+                }
+                const float val = (float)sr;
+                px[o] = sat_u8_d((double)(val * 1.0f + 127.0f));
+            }
+            wave_sync();
+        }
+        equalize_hist_wave(px, eq, n, hist, lut, lane);
+        if (EQ_ONLY) {
+            for (int i = lane; i < n; i += 64) eqOut[(size_t)wid * n + i] = eq[i];
+        } else {
+            const float a = (float)(1.0 / 127.5), b = -1.0f;
+            double part = 0;
+            for (int i = lane; i < n; i += 64) {
+                const float v = (float)eq[i] * a + b;
+                part += (double)v * v;
+            }
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+            const double norm = sqrt(part);
+            const float eps = 1e-4f;
+            const float inv = (float)(1.0 / (norm + eps));
+            for (int i = lane; i < n; i += 64) {
+                const float v = (float)eq[i] * a + b;
+                feat[(size_t)wid * n + i] = v * inv;
+            }
+        }
+        wave_sync();
+    }
+}
+
+struct WhiScratch {
+    DevBuf tables, in, feat, dist;
+    int w = 0, h = 0;
+    float alpha = 0, cutoff = 0;
+    bool valid = false;
+    WhiDev dev;
+};
+WhiScratch& scratch(fd_ctx* ctx) {
+    static thread_local std::vector<std::pair<fd_ctx*, std::unique_ptr<WhiScratch>>> tab;
+    for (auto& kv : tab)
+        if (kv.first == ctx) return *kv.second;
+    tab.emplace_back(ctx, std::unique_ptr<WhiScratch>(new WhiScratch()));
+    return *tab.back().second;
+}
+
+// twiddles + whitening filter (same expressions as oracle/orc_filters.cpp whi_tables: both sides evaluate
+// std::polar / powf / expf with the host libm)
+const WhiDev& tables(fd_ctx* ctx, WhiScratch& S, int w, int h, float alpha, float cutoff) {
+    if (w < 2 || h < 2 || w > WHI_MAX_DIM || h > WHI_MAX_DIM) FD_THROW(FD_ERR_INVALID_ARGUMENT, "patch size must be within 2..%d", WHI_MAX_DIM);
+    if (S.valid && S.w == w && S.h == h && S.alpha == alpha && S.cutoff == cutoff) return S.dev;
+    const double PI2 = 6.283185307179586476925286766559;
+    std::vector<double> twRow((size_t)w * w * 2), twCol((size_t)h * h * 2);
+    std::vector<float> filt((size_t)w * h);
+    for (int x = 0; x < w; ++x)
+        for (int k = 0; k < w; ++k) {
+            std::complex<double> t = std::polar(1.0, -PI2 * x * k / w);
+            twRow[((size_t)x * w + k) * 2] = t.real();
+            twRow[((size_t)x * w + k) * 2 + 1] = t.imag();
+        }
+    for (int y = 0; y < h; ++y)
+        for (int k = 0; k < h; ++k) {
+            std::complex<double> t = std::polar(1.0, -PI2 * y * k / h);
+            twCol[((size_t)y * h + k) * 2] = t.real();
+            twCol[((size_t)y * h + k) * 2 + 1] = t.imag();
+        }
+    for (int row = 0; row < h; ++row)
+        for (int col = 0; col < w; ++col) {
+            int shiftedRow = (row + h / 2) % h, shiftedCol = (col + w / 2) % w;
+            float fx = -0.5f + shiftedCol * (2 * 0.5f) / (w - 1);
+            float fy = -0.5f + shiftedRow * (2 * 0.5f) / (h - 1);
+            float rho = std::sqrt(fx * fx + fy * fy);
+            float f = std::pow(rho, alpha);
+            if (cutoff > 0) f *= std::exp(-std::pow(rho / cutoff, 4));
+            filt[(size_t)row * w + col] = f;
+        }
+    const size_t b0 = sizeof(double) * twRow.size(), b1 = sizeof(double) * twCol.size(), b2 = sizeof(float) * filt.size();
+    S.tables.reserve(b0 + b1 + b2);
+    HIP_CHECK(hipMemcpy(S.tables.p, twRow.data(), b0, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy((char*)S.tables.p + b0, twCol.data(), b1, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy((char*)S.tables.p + b0 + b1, filt.data(), b2, hipMemcpyHostToDevice));
+    S.dev.w = w; S.dev.h = h;
+    S.dev.twRow = (const double*)S.tables.p;
+    S.dev.twCol = (const double*)((char*)S.tables.p + b0);
+    S.dev.filt = (const float*)((char*)S.tables.p + b0 + b1);
+    S.w = w; S.h = h; S.alpha = alpha; S.cutoff = cutoff; S.valid = true;
+    return S.dev;
+}
+
+size_t lds_bytes(int w, int h) {
+    const size_t n = (size_t)w * h;
+    return 4 * n * sizeof(double) + 512 * sizeof(int) + 2 * ((n + 15) & ~(size_t)15);
+}
+
+template <bool EQ_ONLY>
+void launch(fd_ctx* ctx, const uint8_t* arena, const WhiWinTable& wt, const WhiDev& d, float* feat, uint8_t* eqOut) {
+    const size_t lds = lds_bytes(d.w, d.h);
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[EQ_ONLY]) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_whi<EQ_ONLY>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr_set[EQ_ONLY] = true;
+    }
+    const int grid = (int)std::min<int64_t>(wt.total, (int64_t)ctx->num_cus * 16);
+    hipLaunchKernelGGL(k_whi<EQ_ONLY>, dim3(grid), dim3(64), lds, ctx->stream, arena, wt, d, feat, eqOut);
+    HIP_CHECK(hipGetLastError());
+}
+
+void build_table(const fd_pyramid* p, const fd_whi_params* wp, WhiWinTable& wt, std::vector<WindowLayer>& wls) {
+    if (p->filter_kind != FD_LAYER_NONE) FD_THROW(FD_ERR_INVALID_ARGUMENT, "the whi chain needs a gray pyramid (no layer filter)");
+    if (p->all.empty()) FD_THROW(FD_ERR_RUNTIME, "pyramid has not been updated with an image");
+    int64_t total;
+    fd_enumerate_layers(p, wp->patch_w, wp->patch_h, wp->step_x, wp->step_y, nullptr, wls, total);
+    if (wls.size() > (size_t)WHI_MAX_LAYERS) FD_THROW(FD_ERR_INVALID_ARGUMENT, "too many pyramid layers (%zu)", wls.size());
+    std::memset(&wt, 0, sizeof(wt));
+    wt.sx = wp->step_x; wt.sy = wp->step_y; wt.total = total;
+    for (const WindowLayer& w : wls) {
+        if (w.nx == 0 || w.ny == 0) continue;
+        const HostLayer& L = p->all[p->kept[w.layer]];
+        WhiWinLayer& dl = wt.l[wt.n++];
+        dl.bx = w.bx; dl.by = w.by; dl.nx = w.nx; dl.ny = w.ny; dl.lw = L.w; dl.off = L.gray_off; dl.first = w.first;
+    }
+}
+
+// whi features of every window into S.feat ([N][w*h] floats); returns N
+int64_t run_whi(fd_ctx* ctx, fd_pyramid* p, const fd_whi_params* wp, std::vector<WindowLayer>& wls, WhiScratch& S) {
+    if (p->ctx != ctx) FD_THROW(FD_ERR_INVALID_ARGUMENT, "objects belong to different contexts");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    const WhiDev& d = tables(ctx, S, wp->patch_w, wp->patch_h, wp->alpha, wp->cutoff);
+    WhiWinTable wt;
+    build_table(p, wp, wt, wls);
+    if (wt.total == 0) return 0;
+    S.feat.reserve(sizeof(float) * (size_t)wt.total * d.w * d.h);
+    launch<false>(ctx, p->arena.as<uint8_t>(), wt, d, S.feat.as<float>(), nullptr);
+    return wt.total;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fd_whi_batch(fd_ctx* ctx, const uint8_t* patches, int64_t n, int w, int h, float alpha, float cutoff, float* dst) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || n < 0 || (n > 0 && (!patches || !dst))) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_whi_batch: bad argument");
+        if (n == 0) return;
+        HIP_CHECK(hipSetDevice(ctx->device));
+        WhiScratch& S = scratch(ctx);
+        const WhiDev& d = tables(ctx, S, w, h, alpha, cutoff);
+        const size_t bytes = (size_t)n * w * h;
+        S.in.reserve(bytes);
+        S.feat.reserve(bytes * sizeof(float));
+        HIP_CHECK(hipMemcpyAsync(S.in.p, patches, bytes, hipMemcpyHostToDevice, ctx->stream));
+        WhiWinTable wt;
+        std::memset(&wt, 0, sizeof(wt));
+        wt.raw = 1;
+        wt.total = n;
+        launch<false>(ctx, S.in.as<uint8_t>(), wt, d, S.feat.as<float>(), nullptr);
+        HIP_CHECK(hipMemcpyAsync(dst, S.feat.p, bytes * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int fd_equalize_hist_batch(fd_ctx* ctx, const uint8_t* patches, int64_t n, int w, int h, uint8_t* dst) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || n < 0 || (n > 0 && (!patches || !dst))) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_equalize_hist_batch: bad argument");
+        if (n == 0) return;
+        if (w < 1 || h < 1 || w > WHI_MAX_DIM || h > WHI_MAX_DIM) FD_THROW(FD_ERR_INVALID_ARGUMENT, "patch size must be within 1..%d", WHI_MAX_DIM);
+        HIP_CHECK(hipSetDevice(ctx->device));
+        WhiScratch& S = scratch(ctx);
+        const size_t bytes = (size_t)n * w * h;
+        S.in.reserve(bytes);
+        S.feat.reserve(bytes);
+        HIP_CHECK(hipMemcpyAsync(S.in.p, patches, bytes, hipMemcpyHostToDevice, ctx->stream));
+        WhiWinTable wt;
+        std::memset(&wt, 0, sizeof(wt));
+        wt.raw = 1;
+        wt.total = n;
+        WhiDev d;
+        std::memset(&d, 0, sizeof(d));
+        d.w = w; d.h = h;
+        launch<true>(ctx, S.in.as<uint8_t>(), wt, d, nullptr, S.feat.as<uint8_t>());
+        HIP_CHECK(hipMemcpyAsync(dst, S.feat.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int fd_extract_whi(fd_ctx* ctx, fd_pyramid* p, const fd_whi_params* wp, float* features, int64_t cap_windows, int64_t* count) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !p || !wp || !count) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_extract_whi: NULL argument");
+        std::vector<WindowLayer> wls;
+        if (!features) {
+            int64_t total;
+            fd_enumerate_layers(p, wp->patch_w, wp->patch_h, wp->step_x, wp->step_y, nullptr, wls, total);
+            *count = total;
+            return;
+        }
+        WhiScratch& S = scratch(ctx);
+        const int64_t N = run_whi(ctx, p, wp, wls, S);
+        *count = N;
+        if (N == 0) return;
+        if (N > cap_windows) FD_THROW(FD_ERR_CAPACITY, "fd_extract_whi: %lld windows, capacity %lld", (long long)N, (long long)cap_windows);
+        HIP_CHECK(hipMemcpyAsync(features, S.feat.p, sizeof(float) * (size_t)N * wp->patch_w * wp->patch_h, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+// SlidingWindowDetector::detect with the whi feature space and a ProbabilisticSvmClassifier on the f32
+// vectors (ffpDetectApp.cpp:446-500: featurespace "whi", classifier "psvm")
+int fd_detect_whi_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_whi_params* wp, fd_detection* out, int64_t cap,
+                      int64_t* count, double* all_distance) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !p || !svm || !wp || !count) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_whi_svm: NULL argument");
+        if (fd_svm_dim(svm) != wp->patch_w * wp->patch_h || fd_svm_is_u8(svm))
+            FD_THROW(FD_ERR_INVALID_ARGUMENT, "SVM must work on f32 vectors of length %d", wp->patch_w * wp->patch_h);
+        WhiScratch& S = scratch(ctx);
+        std::vector<WindowLayer> wls;
+        const int64_t N = run_whi(ctx, p, wp, wls, S);
+        *count = 0;
+        if (N == 0) return;
+        const int dlen = wp->patch_w * wp->patch_h;
+        S.dist.reserve(sizeof(double) * (size_t)N);
+        fd_svm_generic_launch(ctx, svm, S.feat.p, nullptr, (int64_t)dlen * 4, N, S.dist.as<double>());
+        fd_svm_positives_to_detections(ctx, p, svm, wls, wp->step_x, wp->step_y, S.dist.as<double>(), N, out, cap, count, all_distance);
+    });
+}
+
+}  // extern "C"

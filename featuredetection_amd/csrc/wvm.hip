@@ -552,7 +552,16 @@ template <bool RAW>
 void launch_cascade(fd_ctx* ctx, hipStream_t st, int64_t total, const WvmDev& dev, const uint8_t* arena, const WinTable& wt,
                     const CascadeOut& o) {
     const int gridA = (int)std::min<int64_t>((total + 3) / 4, (int64_t)ctx->num_cus * 8);
-    const int gridB = (int)std::min<int64_t>(total, (int64_t)ctx->num_cus * 4);
+    // stage B is persistent: as many workgroups as fit on the device at once
+    static int perCuB20 = 0, perCuB0 = 0;
+    int& perCu = (dev.fw == 20 && dev.fh == 20) ? perCuB20 : perCuB0;
+    if (perCu == 0) {
+        hipError_t e = (dev.fw == 20 && dev.fh == 20)
+            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wvm_deep<20, 20, false>, 256, 0)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wvm_deep<0, 0, false>, 256, 0);
+        if (e != hipSuccess || perCu < 1) perCu = 2;
+    }
+    const int gridB = (int)std::min<int64_t>(total, (int64_t)ctx->num_cus * perCu);
     if (dev.fw == 20 && dev.fh == 20) {
         hipLaunchKernelGGL((k_wvm_cascade<20, 20, RAW>), dim3(gridA), dim3(256), 0, st, arena, wt, dev, o);
         if (dev.numUsed > WVM_LCAP) hipLaunchKernelGGL((k_wvm_deep<20, 20, RAW>), dim3(gridB), dim3(256), 0, st, arena, wt, dev, o);

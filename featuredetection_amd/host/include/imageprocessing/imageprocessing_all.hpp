@@ -117,14 +117,58 @@ public:
     Type type;
 };
 
-// HogFilter.cpp:16-57 (patch filter: fused into k_hog_tile)
-class HogFilter : public ImageFilter {
+// HistogramFilter.hpp:24-33 -- base of the histogram patch filters.  On this backend they run fused on the
+// pyramid's bin-image layers (k_hog_tile / k_hist_features); applyTo(Mat) throws std::logic_error.
+class HistogramFilter : public ImageFilter {
+public:
+    enum class Normalization { NONE, L2NORM, L2HYS, L1NORM, L1SQRT };
+    explicit HistogramFilter(Normalization normalization) : normalization(normalization) {}
+    Normalization normalization;
+};
+
+// HogFilter.hpp / HogFilter.cpp:16-57
+class HogFilter : public HistogramFilter {
 public:
     using ImageFilter::applyTo;
     explicit HogFilter(int binCount, int cellSize = 5, int blockSize = 2, bool interpolate = false, bool signedAndUnsigned = false);
+    HogFilter(int binCount, int cellWidth, int cellHeight, int blockWidth, int blockHeight, bool interpolate = false,
+              bool signedAndUnsigned = false);
     cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;
-    int binCount, cellSize, blockSize;
+    int binCount, cellWidth, cellHeight, blockWidth, blockHeight;
     bool interpolate, signedAndUnsigned;
+};
+
+// SpatialHistogramFilter.hpp:38-54 / SpatialHistogramFilter.cpp:16-54
+class SpatialHistogramFilter : public HistogramFilter {
+public:
+    using ImageFilter::applyTo;
+    SpatialHistogramFilter(int binCount, int cellSize, int blockSize, bool interpolate, bool concatenate = false,
+                           Normalization normalization = Normalization::NONE);
+    SpatialHistogramFilter(int binCount, int cellWidth, int cellHeight, int blockWidth, int blockHeight, bool interpolate,
+                           bool concatenate = false, Normalization normalization = Normalization::NONE);
+    cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;
+    int binCount, cellWidth, cellHeight, blockWidth, blockHeight;
+    bool interpolate, concatenate;
+};
+
+// PyramidHogFilter.hpp:35 / PyramidHogFilter.cpp:15-31
+class PyramidHogFilter : public HistogramFilter {
+public:
+    using ImageFilter::applyTo;
+    PyramidHogFilter(int binCount, int levelCount, bool interpolate = false, bool signedAndUnsigned = false);
+    cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;
+    int binCount, levelCount;
+    bool interpolate, signedAndUnsigned;
+};
+
+// SpatialPyramidHistogramFilter.hpp:36 / SpatialPyramidHistogramFilter.cpp:21-35
+class SpatialPyramidHistogramFilter : public HistogramFilter {
+public:
+    using ImageFilter::applyTo;
+    SpatialPyramidHistogramFilter(int binCount, int levelCount, bool interpolate = false, Normalization normalization = Normalization::NONE);
+    cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;
+    int binCount, levelCount;
+    bool interpolate;
 };
 
 // ImagePyramidLayer.hpp:34-163
@@ -236,7 +280,7 @@ public:
     DirectPyramidFeatureExtractor(std::shared_ptr<ImagePyramid> pyramid, int width, int height);
     void addImageFilter(std::shared_ptr<ImageFilter> filter) { pyramid->addImageFilter(filter); }
     void addLayerFilter(std::shared_ptr<ImageFilter> filter) { pyramid->addLayerFilter(filter); }
-    void addPatchFilter(std::shared_ptr<ImageFilter> filter);          // HistEq64Filter or HogFilter
+    void addPatchFilter(std::shared_ptr<ImageFilter> filter);          // HistEq64Filter or one HistogramFilter
     void update(std::shared_ptr<VersionedImage> image) override { pyramid->update(image); }
     std::shared_ptr<Patch> extract(int x, int y, int width, int height) const override;
     std::vector<std::shared_ptr<Patch>> extract(int stepX, int stepY, cv::Rect roi = cv::Rect(), int firstLayer = -1, int lastLayer = -1,
@@ -257,13 +301,15 @@ public:
     int getPatchHeight() const { return patchHeight; }
     // which fused GPU path the patch filter chain maps to
     bool hasHistEq64() const { return (bool)histeq; }
-    std::shared_ptr<HogFilter> getHogFilter() const { return hog; }
+    std::shared_ptr<HogFilter> getHogFilter() const { return hog; }   // non-interpolating square HogFilter: k_hog_tile path
+    std::shared_ptr<HistogramFilter> getHistogramFilter() const { return hist; }
 private:
     std::shared_ptr<Patch> extractFromLayer(const ImagePyramidLayer& layer, cv::Rect bounds) const;
     std::shared_ptr<ImagePyramid> pyramid;
     int patchWidth, patchHeight;
     std::shared_ptr<HistEq64Filter> histeq;
     std::shared_ptr<HogFilter> hog;
+    std::shared_ptr<HistogramFilter> hist;
 };
 
 }  // namespace imageprocessing

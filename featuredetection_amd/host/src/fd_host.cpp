@@ -91,13 +91,68 @@ unsigned int LbpFilter::getBinCount() const {
     }
 }
 HogFilter::HogFilter(int binCount, int cellSize, int blockSize, bool interpolate, bool signedAndUnsigned)
-    : binCount(binCount), cellSize(cellSize), blockSize(blockSize), interpolate(interpolate), signedAndUnsigned(signedAndUnsigned) {
+    : HogFilter(binCount, cellSize, cellSize, blockSize, blockSize, interpolate, signedAndUnsigned) {}
+HogFilter::HogFilter(int binCount, int cellWidth, int cellHeight, int blockWidth, int blockHeight, bool interpolate, bool signedAndUnsigned)
+    : HistogramFilter(Normalization::L2NORM), binCount(binCount), cellWidth(cellWidth), cellHeight(cellHeight), blockWidth(blockWidth),
+      blockHeight(blockHeight), interpolate(interpolate), signedAndUnsigned(signedAndUnsigned) {
     if (binCount <= 0) throw std::invalid_argument("HogFilter: binCount must be greater than zero");
-    if (cellSize <= 0) throw std::invalid_argument("HogFilter: cellSize must be greater than zero");
-    if (blockSize <= 0) throw std::invalid_argument("HogFilter: blockSize must be greater than zero");
+    if (cellWidth <= 0) throw std::invalid_argument("HogFilter: cellWidth must be greater than zero");
+    if (cellHeight <= 0) throw std::invalid_argument("HogFilter: cellHeight must be greater than zero");
+    if (blockWidth <= 0) throw std::invalid_argument("HogFilter: blockWidth must be greater than zero");
+    if (blockHeight <= 0) throw std::invalid_argument("HogFilter: blockHeight must be greater than zero");
     if (signedAndUnsigned && binCount % 2 != 0)
         throw std::invalid_argument("HogFilter: the bin size must be even for signed and unsigned gradients to be combined");
-    if (interpolate) throw std::invalid_argument("HogFilter: cell interpolation is not available on this backend");
+}
+SpatialHistogramFilter::SpatialHistogramFilter(int binCount, int cellSize, int blockSize, bool interpolate, bool concatenate, Normalization normalization)
+    : SpatialHistogramFilter(binCount, cellSize, cellSize, blockSize, blockSize, interpolate, concatenate, normalization) {}
+SpatialHistogramFilter::SpatialHistogramFilter(int binCount, int cellWidth, int cellHeight, int blockWidth, int blockHeight, bool interpolate,
+                                               bool concatenate, Normalization normalization)
+    : HistogramFilter(normalization), binCount(binCount), cellWidth(cellWidth), cellHeight(cellHeight), blockWidth(blockWidth),
+      blockHeight(blockHeight), interpolate(interpolate), concatenate(concatenate) {
+    if (binCount <= 0) throw std::invalid_argument("SpatialHistogramFilter: binCount must be greater than zero");
+    if (cellWidth <= 0) throw std::invalid_argument("SpatialHistogramFilter: cellWidth must be greater than zero");
+    if (cellHeight <= 0) throw std::invalid_argument("SpatialHistogramFilter: cellHeight must be greater than zero");
+    if (blockWidth <= 0) throw std::invalid_argument("SpatialHistogramFilter: blockWidth must be greater than zero");
+    if (blockHeight <= 0) throw std::invalid_argument("SpatialHistogramFilter: blockHeight must be greater than zero");
+}
+Mat SpatialHistogramFilter::applyTo(const Mat&, Mat&) const { return fused_only("SpatialHistogramFilter"); }
+PyramidHogFilter::PyramidHogFilter(int binCount, int levelCount, bool interpolate, bool signedAndUnsigned)
+    : HistogramFilter(Normalization::L2NORM), binCount(binCount), levelCount(levelCount), interpolate(interpolate),
+      signedAndUnsigned(signedAndUnsigned) {
+    if (binCount <= 0) throw std::invalid_argument("PyramidHogFilter: binCount must be greater than zero");
+    if (levelCount <= 0) throw std::invalid_argument("PyramidHogFilter: levelCount must be greater than zero");
+    if (signedAndUnsigned && binCount % 2 != 0)
+        throw std::invalid_argument("PyramidHogFilter: the bin size must be even for signed and unsigned gradients to be combined");
+}
+Mat PyramidHogFilter::applyTo(const Mat&, Mat&) const { return fused_only("PyramidHogFilter"); }
+SpatialPyramidHistogramFilter::SpatialPyramidHistogramFilter(int binCount, int levelCount, bool interpolate, Normalization normalization)
+    : HistogramFilter(normalization), binCount(binCount), levelCount(levelCount), interpolate(interpolate) {
+    if (binCount <= 0) throw std::invalid_argument("SpatialPyramidHistogramFilter: binCount must be greater than zero");
+    if (levelCount <= 0) throw std::invalid_argument("SpatialPyramidHistogramFilter: levelCount must be greater than zero");
+}
+Mat SpatialPyramidHistogramFilter::applyTo(const Mat&, Mat&) const { return fused_only("SpatialPyramidHistogramFilter"); }
+
+// parameters of the fused histogram kernels for a patch filter
+static fd_hist_params hist_params_of(const HistogramFilter& f, int pw, int ph, int stepX, int stepY) {
+    fd_hist_params hp;
+    std::memset(&hp, 0, sizeof(hp));
+    hp.patch_w = pw; hp.patch_h = ph; hp.step_x = stepX; hp.step_y = stepY;
+    hp.normalization = (int)f.normalization;
+    if (auto h = dynamic_cast<const HogFilter*>(&f)) {
+        hp.kind = FD_HIST_HOG; hp.bins = h->binCount; hp.cell_size = h->cellWidth; hp.cell_h = h->cellHeight;
+        hp.block_size = h->blockWidth; hp.block_h = h->blockHeight; hp.interpolate = h->interpolate; hp.signed_and_unsigned = h->signedAndUnsigned;
+    } else if (auto s = dynamic_cast<const SpatialHistogramFilter*>(&f)) {
+        hp.kind = FD_HIST_SPATIAL; hp.bins = s->binCount; hp.cell_size = s->cellWidth; hp.cell_h = s->cellHeight;
+        hp.block_size = s->blockWidth; hp.block_h = s->blockHeight; hp.interpolate = s->interpolate; hp.concatenate = s->concatenate;
+    } else if (auto q = dynamic_cast<const PyramidHogFilter*>(&f)) {
+        hp.kind = FD_HIST_PYRAMID_HOG; hp.bins = q->binCount; hp.levels = q->levelCount; hp.interpolate = q->interpolate;
+        hp.signed_and_unsigned = q->signedAndUnsigned;
+    } else if (auto y = dynamic_cast<const SpatialPyramidHistogramFilter*>(&f)) {
+        hp.kind = FD_HIST_SPATIAL_PYRAMID; hp.bins = y->binCount; hp.levels = y->levelCount; hp.interpolate = y->interpolate;
+    } else {
+        throw std::logic_error("unsupported HistogramFilter subclass");
+    }
+    return hp;
 }
 Mat HogFilter::applyTo(const Mat&, Mat&) const { return fused_only("HogFilter"); }
 
@@ -189,8 +244,12 @@ DirectPyramidFeatureExtractor::DirectPyramidFeatureExtractor(shared_ptr<ImagePyr
     : pyramid(pyramid), patchWidth(width), patchHeight(height) {}
 void DirectPyramidFeatureExtractor::addPatchFilter(shared_ptr<ImageFilter> filter) {
     if (auto h = std::dynamic_pointer_cast<HistEq64Filter>(filter)) histeq = h;
-    else if (auto g = std::dynamic_pointer_cast<HogFilter>(filter)) hog = g;
-    else throw std::logic_error("DirectPyramidFeatureExtractor: unsupported patch filter (HistEq64Filter, HogFilter are available)");
+    else if (auto hf = std::dynamic_pointer_cast<HistogramFilter>(filter)) {
+        hist = hf;
+        auto g = std::dynamic_pointer_cast<HogFilter>(filter);
+        // the tuned k_hog_tile path covers the square, non-interpolating HogFilter; everything else runs k_hist_features
+        hog = (g && !g->interpolate && g->cellWidth == g->cellHeight && g->blockWidth == g->blockHeight) ? g : nullptr;
+    } else throw std::logic_error("DirectPyramidFeatureExtractor: unsupported patch filter (HistEq64Filter and the HistogramFilter family are available)");
 }
 vector<cv::Size> DirectPyramidFeatureExtractor::getPatchSizes() const {
     vector<cv::Size> sizes;
@@ -210,7 +269,7 @@ shared_ptr<Patch> DirectPyramidFeatureExtractor::extractFromLayer(const ImagePyr
     int ox = layer.getOriginal(b.x) + ow / 2, oy = layer.getOriginal(b.y) + oh / 2;
     Mat data = Mat(image, b).clone();
     if (histeq) data = histeq->applyTo(data);
-    if (hog) throw std::logic_error("DirectPyramidFeatureExtractor: single-patch extraction with a HogFilter is not available; use extract(stepX, stepY)");
+    if (hist) throw std::logic_error("DirectPyramidFeatureExtractor: single-patch extraction with a histogram filter is not available; use extract(stepX, stepY)");
     return make_shared<Patch>(ox, oy, ow, oh, data);
 }
 shared_ptr<Patch> DirectPyramidFeatureExtractor::extract(int x, int y, int width, int height) const {
@@ -237,11 +296,27 @@ vector<shared_ptr<Patch>> DirectPyramidFeatureExtractor::extract(int stepX, int 
     patches.reserve((size_t)n);
     if (hog) {
         if (roi.area() != 0) throw std::logic_error("DirectPyramidFeatureExtractor: HOG extraction works on the whole image only");
-        fd_hog_params hp = {patchWidth, patchHeight, stepX, stepY, hog->binCount, hog->cellSize, hog->blockSize, hog->signedAndUnsigned};
+        fd_hog_params hp = {patchWidth, patchHeight, stepX, stepY, hog->binCount, hog->cellWidth, hog->blockWidth, hog->signedAndUnsigned};
         const int F = fd_hog_feature_length(&hp);
         Mat all((int)n, F, CV_32FC1);
         int64_t cnt = 0;
         if (n) check(fd_extract_hog(context(), pyramid->native(), &hp, all.ptr<float>(0), n, &cnt));
+        for (int64_t i = 0; i < n; ++i) {
+            const int32_t* w = &wins[7 * i];
+            patches.push_back(make_shared<Patch>(w[3], w[4], w[5], w[6], Mat(all, cv::Rect(0, (int)i, F, 1))));
+        }
+        return patches;
+    }
+    if (hist) {
+        if (roi.area() != 0) throw std::logic_error("DirectPyramidFeatureExtractor: histogram feature extraction works on the whole image only");
+        fd_hist_params hp = hist_params_of(*hist, patchWidth, patchHeight, stepX, stepY);
+        int index, lw, lh, ch = 1; double scale;
+        if (fd_pyramid_layer_count(pyramid->native()) > 0) fd_pyramid_layer_info(pyramid->native(), 0, &index, &scale, &lw, &lh, &ch);
+        const int F = fd_hist_feature_length(&hp, ch);
+        if (F < 0) throw std::invalid_argument("DirectPyramidFeatureExtractor: invalid histogram filter parameters for this patch size");
+        Mat all((int)std::max<int64_t>(n, 1), F, CV_32FC1);
+        int64_t cnt = 0;
+        if (n) check(fd_extract_hist(context(), pyramid->native(), &hp, all.ptr<float>(0), n, &cnt));
         for (int64_t i = 0; i < n; ++i) {
             const int32_t* w = &wins[7 * i];
             patches.push_back(make_shared<Patch>(w[3], w[4], w[5], w[6], Mat(all, cv::Rect(0, (int)i, F, 1))));
@@ -598,9 +673,11 @@ vector<shared_ptr<ClassifiedPatch>> SlidingWindowDetector::detect(const cv::Rect
         for (int64_t i = 0; i < cnt; ++i) out.push_back(to_patch(dets[i]));
         return out;
     }
-    if (direct && psvm && direct->getHogFilter() && !roi) {   // fused HOG + MFMA RBF-SVM
+    const bool f32sv = psvm && !psvm->getSvm()->getSupportVectors().empty() && psvm->getSvm()->getSupportVectors()[0].depth() == CV_32F;
+    if (direct && psvm && direct->getHogFilter() && !roi && f32sv &&
+        std::dynamic_pointer_cast<classification::RbfKernel>(psvm->getSvm()->getKernel())) {   // fused HOG + MFMA RBF-SVM
         auto hog = direct->getHogFilter();
-        fd_hog_params hp = {direct->getPatchWidth(), direct->getPatchHeight(), stepSizeX, stepSizeY, hog->binCount, hog->cellSize, hog->blockSize,
+        fd_hog_params hp = {direct->getPatchWidth(), direct->getPatchHeight(), stepSizeX, stepSizeY, hog->binCount, hog->cellWidth, hog->blockWidth,
                             hog->signedAndUnsigned};
         const fd_svm* s = psvm->getSvm()->native(psvm->getLogisticA(), psvm->getLogisticB());
         int64_t cnt = 0, cap = 1 << 16;
@@ -609,6 +686,20 @@ vector<shared_ptr<ClassifiedPatch>> SlidingWindowDetector::detect(const cv::Rect
         if (rc == FD_ERR_CAPACITY) {
             dets.resize((size_t)cnt);
             rc = fd_detect_hog_svm(context(), direct->getPyramid()->native(), s, &hp, dets.data(), cnt, &cnt, nullptr);
+        }
+        check(rc);
+        for (int64_t i = 0; i < cnt; ++i) out.push_back(to_patch(dets[i]));
+        return out;
+    }
+    if (direct && psvm && direct->getHistogramFilter() && !roi && f32sv) {   // fused histogram features + SVM (any kernel)
+        fd_hist_params hp = hist_params_of(*direct->getHistogramFilter(), direct->getPatchWidth(), direct->getPatchHeight(), stepSizeX, stepSizeY);
+        const fd_svm* s = psvm->getSvm()->native(psvm->getLogisticA(), psvm->getLogisticB());
+        int64_t cnt = 0, cap = 1 << 16;
+        vector<fd_detection> dets((size_t)cap);
+        int rc = fd_detect_hist_svm(context(), direct->getPyramid()->native(), s, &hp, dets.data(), cap, &cnt, nullptr);
+        if (rc == FD_ERR_CAPACITY) {
+            dets.resize((size_t)cnt);
+            rc = fd_detect_hist_svm(context(), direct->getPyramid()->native(), s, &hp, dets.data(), cnt, &cnt, nullptr);
         }
         check(rc);
         for (int64_t i = 0; i < cnt; ++i) out.push_back(to_patch(dets[i]));

@@ -171,6 +171,53 @@ int fd_detect_hog_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_ho
 int fd_extract_hog(fd_ctx* ctx, fd_pyramid* p, const fd_hog_params* hp, float* features, int64_t cap_windows,
                    int64_t* count);
 
+/* Generic histogram patch filters on the pyramid's bin-image layers (FD_LAYER_GRADBIN: 2 or 4 channels,
+ * FD_LAYER_LBP: 1 channel), all built on HistogramFilter::createCellHistograms (HistogramFilter.cpp:23-197,
+ * interpolating and non-interpolating):
+ *  FD_HIST_HOG             HogFilter(bins, cell_size, block_size, interpolate, signed_and_unsigned)  HogFilter.cpp:58-122
+ *  FD_HIST_SPATIAL         SpatialHistogramFilter(bins, cell_size, block_size, interpolate, concatenate, normalization)
+ *                          SpatialHistogramFilter.cpp:56-94
+ *  FD_HIST_PYRAMID_HOG     PyramidHogFilter(bins, levels, interpolate, signed_and_unsigned)  PyramidHogFilter.cpp:33-113
+ *  FD_HIST_SPATIAL_PYRAMID SpatialPyramidHistogramFilter(bins, levels, interpolate, normalization)
+ *                          SpatialPyramidHistogramFilter.cpp:37-81
+ * normalization (HistogramFilter::Normalization): 0 none, 1 L2NORM, 2 L2HYS, 3 L1NORM, 4 L1SQRT. */
+enum { FD_HIST_HOG = 0, FD_HIST_SPATIAL = 1, FD_HIST_PYRAMID_HOG = 2, FD_HIST_SPATIAL_PYRAMID = 3 };
+typedef struct {
+    int32_t patch_w, patch_h, step_x, step_y;
+    int32_t kind, bins;
+    int32_t cell_size, block_size;   /* FD_HIST_HOG, FD_HIST_SPATIAL: cell width / block width (cells) */
+    int32_t levels;                  /* pyramid kinds: levelCount */
+    int32_t interpolate, signed_and_unsigned, concatenate, normalization;
+    int32_t cell_h, block_h;         /* cell height / block height; 0 = same as cell_size / block_size */
+} fd_hist_params;
+/* feature length for a bin image with `channels` channels; -1 on invalid parameters */
+int fd_hist_feature_length(const fd_hist_params* hp, int channels);
+/* FeatureExtractor::extract for every window: n_windows x feature_length floats to host.
+ * features == NULL: only *count is set. */
+int fd_extract_hist(fd_ctx* ctx, fd_pyramid* p, const fd_hist_params* hp, float* features, int64_t cap_windows,
+                    int64_t* count);
+/* SlidingWindowDetector::detect with the histogram patch filter + ProbabilisticSvmClassifier on the f32
+ * vectors (any kernel; wiring of BenchmarkRunner.cpp:185-263) */
+int fd_detect_hist_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_hist_params* hp, fd_detection* out,
+                       int64_t cap, int64_t* count, double* all_distance);
+
+/* The "whi" feature space of ffpDetectApp.cpp:449-454 on gray pyramid windows: WhiteningFilter(alpha, cutoff)
+ * (WhiteningFilter.cpp:20-81) -> HistogramEqualizationFilter (cv::equalizeHist) -> ConversionFilter(CV_32F,
+ * 1/127.5, -1) -> UnitNormFilter(NORM_L2).  Reference defaults: alpha 1, cutoff 0.390625 (WhiteningFilter.hpp:31). */
+typedef struct {
+    int32_t patch_w, patch_h, step_x, step_y;
+    float alpha, cutoff;
+} fd_whi_params;
+/* the chain on n contiguous w x h u8 patches (host) -> n*w*h floats (host) */
+int fd_whi_batch(fd_ctx* ctx, const uint8_t* patches, int64_t n, int w, int h, float alpha, float cutoff, float* dst);
+/* HistogramEqualizationFilter::applyTo ("histeq" feature space, ffpDetectApp.cpp:446-448) on n patches */
+int fd_equalize_hist_batch(fd_ctx* ctx, const uint8_t* patches, int64_t n, int w, int h, uint8_t* dst);
+/* every window of the pyramid: n_windows x (patch_w*patch_h) floats to host; features == NULL: count only */
+int fd_extract_whi(fd_ctx* ctx, fd_pyramid* p, const fd_whi_params* wp, float* features, int64_t cap_windows, int64_t* count);
+/* SlidingWindowDetector::detect with the whi feature space + ProbabilisticSvmClassifier (any kernel, f32 vectors) */
+int fd_detect_whi_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_whi_params* wp, fd_detection* out, int64_t cap,
+                      int64_t* count, double* all_distance);
+
 /* Throughput entry points used by bench.py: everything stays on the device, no host copies of
  * per-window data; *count = enumerated windows, *positives = classifier positives. */
 int fd_bench_hog_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_hog_params* hp, int64_t* count,

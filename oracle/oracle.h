@@ -32,6 +32,13 @@ int orc_spatial_histogram(const uint8_t* img, int w, int h, int ch, int stride_b
                           int cellW, int cellH, int blockW, int blockH, int interpolate,
                           int concatenate, int normalization, float* out);
 
+/* PyramidHogFilter.cpp:33-113 */
+int orc_pyramid_hog(const uint8_t* img, int w, int h, int ch, int stride_bytes, int bins, int levels,
+                    int interpolate, int signedAndUnsigned, float* out);
+/* SpatialPyramidHistogramFilter.cpp:37-81 */
+int orc_spatial_pyramid_histogram(const uint8_t* img, int w, int h, int ch, int stride_bytes, int bins, int levels,
+                                  int interpolate, int normalization, float* out);
+
 /* ---------------- pyramid + window enumeration ---------------- */
 typedef struct orc_pyramid orc_pyramid;
 orc_pyramid* orc_pyramid_create(int octaveLayerCount, double minScale, double maxScale); /* ImagePyramid.cpp:67-77 */

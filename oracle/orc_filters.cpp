@@ -149,26 +149,29 @@ static void greyworld(const uchar* bgr, int w, int h, uchar* dst) {
 
 // "whi" chain, ffpDetectApp.cpp:449-454: WhiteningFilter (WhiteningFilter.cpp:20-81) ->
 // HistogramEqualizationFilter -> ConversionFilter(CV_32F, 1/127.5, -1) -> UnitNormFilter(L2).
-// The DFTs are evaluated naively in double (cv::dft results are tolerance-compared only).
-static void whi(const uchar* src, int w, int h, int stride, float alpha, float cutoff, float* dst) {
-    const int n = w * h;
+// cv::dft is not available here and its butterfly order is not part of the reference's
+// source, so the transforms are restated as plain separable DFTs in double with explicit complex
+// arithmetic (row pass, then column pass; twiddles from std::polar).  Against OpenCV this agrees to
+// float rounding of the whitened image (a rounding flip of a u8 pixel is possible where the value
+// lies within ~1e-5 of .5); tests/test_oracle_golden.py pins it against numpy's FFT.
+void whi_tables(int w, int h, float alpha, float cutoff, std::vector<double>& twRow, std::vector<double>& twCol,
+                std::vector<float>& filt) {
     const double PI2 = 6.283185307179586476925286766559;
-    std::vector<std::complex<double>> F((size_t)n), T((size_t)n);
-    // forward DFT with DFT_SCALE
-    for (int v = 0; v < h; ++v)
-        for (int x = 0; x < w; ++x) {  // row transform along x -> T[v][u]
-            std::complex<double> s = 0;
-            for (int k = 0; k < w; ++k)
-                s += (double)src[(size_t)v * stride + k] * std::polar(1.0, -PI2 * x * k / w);
-            T[(size_t)v * w + x] = s;
+    twRow.resize((size_t)w * w * 2);
+    twCol.resize((size_t)h * h * 2);
+    for (int x = 0; x < w; ++x)
+        for (int k = 0; k < w; ++k) {
+            std::complex<double> t = std::polar(1.0, -PI2 * x * k / w);
+            twRow[((size_t)x * w + k) * 2] = t.real();
+            twRow[((size_t)x * w + k) * 2 + 1] = t.imag();
         }
-    for (int u = 0; u < w; ++u)
-        for (int y = 0; y < h; ++y) {
-            std::complex<double> s = 0;
-            for (int k = 0; k < h; ++k) s += T[(size_t)k * w + u] * std::polar(1.0, -PI2 * y * k / h);
-            F[(size_t)y * w + u] = std::complex<double>((float)(s.real() / n), (float)(s.imag() / n));
+    for (int y = 0; y < h; ++y)
+        for (int k = 0; k < h; ++k) {
+            std::complex<double> t = std::polar(1.0, -PI2 * y * k / h);
+            twCol[((size_t)y * h + k) * 2] = t.real();
+            twCol[((size_t)y * h + k) * 2 + 1] = t.imag();
         }
-    // filter (WhiteningFilter.cpp:62-81), float arithmetic
+    filt.resize((size_t)w * h);   // WhiteningFilter.cpp:62-81, float arithmetic
     for (int row = 0; row < h; ++row)
         for (int col = 0; col < w; ++col) {
             int shiftedRow = (row + h / 2) % h, shiftedCol = (col + w / 2) % w;
@@ -177,25 +180,69 @@ static void whi(const uchar* src, int w, int h, int stride, float alpha, float c
             float rho = std::sqrt(fx * fx + fy * fy);
             float f = std::pow(rho, alpha);
             if (cutoff > 0) f *= std::exp(-std::pow(rho / cutoff, 4));
-            F[(size_t)row * w + col] *= (double)f;
+            filt[(size_t)row * w + col] = f;
         }
-    // inverse DFT, DFT_REAL_OUTPUT: only the half-spectrum (cols 0..w/2) is consumed, the rest is
-    // implied by conjugate symmetry (OpenCV packs the complex input into CCS form).
-    std::vector<std::complex<double>> G((size_t)n);
-    for (int r = 0; r < h; ++r)
-        for (int c = 0; c < w; ++c) {
-            int rr = (h - r) % h, cc = (w - c) % w;
-            bool own = c < cc || (c == cc && r <= rr);
-            G[(size_t)r * w + c] = own ? F[(size_t)r * w + c] : std::conj(F[(size_t)rr * w + cc]);
+}
+
+static void whi(const uchar* src, int w, int h, int stride, float alpha, float cutoff, float* dst) {
+    const int n = w * h;
+    std::vector<double> twRow, twCol;
+    std::vector<float> filt;
+    whi_tables(w, h, alpha, cutoff, twRow, twCol, filt);
+    std::vector<double> Tre((size_t)n), Tim((size_t)n), Fre((size_t)n), Fim((size_t)n);
+    // forward DFT with DFT_SCALE: rows (real input), then columns
+    for (int v = 0; v < h; ++v)
+        for (int x = 0; x < w; ++x) {
+            double sr = 0, si = 0;
+            for (int k = 0; k < w; ++k) {
+                const double p = (double)src[(size_t)v * stride + k];
+                sr = sr + p * twRow[((size_t)x * w + k) * 2];
+                si = si + p * twRow[((size_t)x * w + k) * 2 + 1];
+            }
+            Tre[(size_t)v * w + x] = sr;
+            Tim[(size_t)v * w + x] = si;
+        }
+    for (int y = 0; y < h; ++y)
+        for (int u = 0; u < w; ++u) {
+            double sr = 0, si = 0;
+            for (int k = 0; k < h; ++k) {
+                const double ar = Tre[(size_t)k * w + u], ai = Tim[(size_t)k * w + u];
+                const double br = twCol[((size_t)y * h + k) * 2], bi = twCol[((size_t)y * h + k) * 2 + 1];
+                sr = sr + (ar * br - ai * bi);
+                si = si + (ar * bi + ai * br);
+            }
+            // the spectrum is a CV_32FC2 Mat; the whitening filter multiplies it in float (WhiteningFilter.cpp:38-45)
+            const float f = filt[(size_t)y * w + u];
+            Fre[(size_t)y * w + u] = (double)((float)(sr / n) * f);
+            Fim[(size_t)y * w + u] = (double)((float)(si / n) * f);
+        }
+    // inverse DFT, DFT_REAL_OUTPUT: only the half-spectrum is consumed, the rest is implied by conjugate
+    // symmetry (OpenCV packs the complex input into CCS form).  Rows, then columns (real part only).
+    std::vector<double> Ure((size_t)n), Uim((size_t)n);
+    for (int v = 0; v < h; ++v)
+        for (int x = 0; x < w; ++x) {
+            double sr = 0, si = 0;
+            for (int u = 0; u < w; ++u) {
+                const int rr = (h - v) % h, cc = (w - u) % w;
+                const bool own = u < cc || (u == cc && v <= rr);
+                const double gr = own ? Fre[(size_t)v * w + u] : Fre[(size_t)rr * w + cc];
+                const double gi = own ? Fim[(size_t)v * w + u] : -Fim[(size_t)rr * w + cc];
+                const double br = twRow[((size_t)x * w + u) * 2], bi = -twRow[((size_t)x * w + u) * 2 + 1];   // conjugate twiddle
+                sr = sr + (gr * br - gi * bi);
+                si = si + (gr * bi + gi * br);
+            }
+            Ure[(size_t)v * w + x] = sr;
+            Uim[(size_t)v * w + x] = si;
         }
     std::vector<uchar> u8((size_t)n), eq((size_t)n);
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) {
-            std::complex<double> s = 0;
-            for (int v = 0; v < h; ++v)
-                for (int u = 0; u < w; ++u)
-                    s += G[(size_t)v * w + u] * std::polar(1.0, PI2 * ((double)x * u / w + (double)y * v / h));
-            float val = (float)s.real();
+            double sr = 0;
+            for (int v = 0; v < h; ++v) {
+                const double br = twCol[((size_t)y * h + v) * 2], bi = -twCol[((size_t)y * h + v) * 2 + 1];
+                sr = sr + (Ure[(size_t)v * w + x] * br - Uim[(size_t)v * w + x] * bi);
+            }
+            const float val = (float)sr;
             u8[(size_t)y * w + x] = sat_u8((double)(val * 1.0f + 127.0f));
         }
     equalize_hist(u8.data(), w, h, w, eq.data());
@@ -402,6 +449,88 @@ static int spatial_histogram(const uchar* img, int w, int h, int ch, int strideB
     return (int)out.size();
 }
 
+// PyramidHogFilter.cpp:33-113 / SpatialPyramidHistogramFilter.cpp:37-81: cell histograms on the finest
+// 2^L x 2^L grid, every coarser level = sum of its 2x2 children (row-major child order, accumulated
+// into zeros), all levels concatenated coarse -> fine, each histogram normalised on its own.
+static void combine_levels(float* base, int histogramCount, int maxLevel, int binCount) {
+    float* cellValues = base + (size_t)(histogramCount - (1 << (2 * maxLevel))) * binCount;
+    for (int level = maxLevel - 1; level >= 0; --level) {
+        float* blockValues = cellValues - (size_t)(1 << (2 * level)) * binCount;
+        int blockCount = 1 << level, cellCount = blockCount << 1;
+        float* bv = blockValues;
+        for (int br = 0; br < blockCount; ++br)
+            for (int bc = 0; bc < blockCount; ++bc) {
+                for (int cr = 2 * br; cr < 2 * (br + 1); ++cr)
+                    for (int cc = 2 * bc; cc < 2 * (bc + 1); ++cc) {
+                        const float* cv = cellValues + (size_t)(cr * cellCount + cc) * binCount;
+                        for (int b = 0; b < binCount; ++b) bv[b] += cv[b];
+                    }
+                bv += binCount;
+            }
+        cellValues = blockValues;
+    }
+}
+
+static int pyramid_hog(const uchar* img, int w, int h, int ch, int strideBytes, int binCount, int levelCount, bool interpolate,
+                       bool signedAndUnsigned, std::vector<float>& out) {
+    if (binCount <= 0) throw std::invalid_argument("PyramidHogFilter: binCount must be greater than zero");
+    if (levelCount <= 0) throw std::invalid_argument("PyramidHogFilter: levelCount must be greater than zero");
+    if (signedAndUnsigned && binCount % 2 != 0)
+        throw std::invalid_argument("PyramidHogFilter: the bin size must be even for signed and unsigned gradients to be combined");
+    const float eps = 1e-4f;
+    int maxLevel = levelCount - 1, histogramCount = 0;
+    for (int level = 0; level < levelCount; ++level) histogramCount += 1 << (2 * level);
+    int binHalfCount = binCount / 2;
+    int realBinCount = signedAndUnsigned ? 3 * binCount / 2 : binCount;
+    out.assign((size_t)histogramCount * realBinCount, 0.f);
+    int gridCount = 1 << maxLevel;
+    std::vector<float> cells;
+    createCellHistograms(img, w, h, ch, strideBytes, cells, binCount, gridCount, gridCount, interpolate);
+    {   // copyCellHistograms :57-74
+        const float* sv = cells.data();
+        float* dv = out.data() + (size_t)(histogramCount - gridCount * gridCount) * realBinCount;
+        for (int i = 0; i < gridCount * gridCount; ++i) {
+            for (int b = 0; b < binCount; ++b) dv[b] = sv[b];
+            dv += binCount;
+            if (signedAndUnsigned) {
+                for (int b = 0; b < binHalfCount; ++b) dv[b] = sv[b] + sv[binHalfCount + b];
+                dv += binHalfCount;
+            }
+            sv += binCount;
+        }
+    }
+    combine_levels(out.data(), histogramCount, maxLevel, realBinCount);
+    float* hv = out.data();   // normalizeHistograms :94-113
+    for (int i = 0; i < histogramCount; ++i) {
+        float energy = 0;
+        if (signedAndUnsigned) {
+            for (int b = binCount; b < realBinCount; ++b) energy += hv[b] * hv[b];
+        } else {
+            for (int b = 0; b < binCount; ++b) energy += hv[b] * hv[b];
+        }
+        float normalizer = 1.f / std::sqrt(energy + eps);
+        for (int b = 0; b < realBinCount; ++b) hv[b] = normalizer * hv[b];
+        hv += realBinCount;
+    }
+    return (int)out.size();
+}
+
+static int spatial_pyramid_histogram(const uchar* img, int w, int h, int ch, int strideBytes, int binCount, int levelCount,
+                                     bool interpolate, int normalization, std::vector<float>& out) {
+    if (binCount <= 0) throw std::invalid_argument("SpatialPyramidHistogramFilter: binCount must be greater than zero");
+    if (levelCount <= 0) throw std::invalid_argument("SpatialPyramidHistogramFilter: levelCount must be greater than zero");
+    int maxLevel = levelCount - 1, histogramCount = 0;
+    for (int level = 0; level < levelCount; ++level) histogramCount += 1 << (2 * level);
+    out.assign((size_t)histogramCount * binCount, 0.f);
+    int gridCount = 1 << maxLevel;
+    std::vector<float> cells;
+    createCellHistograms(img, w, h, ch, strideBytes, cells, binCount, gridCount, gridCount, interpolate);
+    std::copy(cells.begin(), cells.end(), out.begin() + (size_t)(histogramCount - gridCount * gridCount) * binCount);
+    combine_levels(out.data(), histogramCount, maxLevel, binCount);
+    for (int i = 0; i < histogramCount; ++i) normalizeHist(out.data() + (size_t)i * binCount, binCount, normalization);
+    return (int)out.size();
+}
+
 }  // namespace orc
 
 using namespace orc;
@@ -423,6 +552,19 @@ int orc_spatial_histogram(const uint8_t* img, int w, int h, int ch, int stride, 
                           int interp, int concat, int normalization, float* out) {
     std::vector<float> v;
     int n = spatial_histogram(img, w, h, ch, stride, bins, cw, chh, bw, bh, interp != 0, concat != 0, normalization, v);
+    if (out) std::memcpy(out, v.data(), sizeof(float) * v.size());
+    return n;
+}
+int orc_pyramid_hog(const uint8_t* img, int w, int h, int ch, int stride, int bins, int levels, int interpolate, int sau, float* out) {
+    std::vector<float> v;
+    int n = pyramid_hog(img, w, h, ch, stride, bins, levels, interpolate != 0, sau != 0, v);
+    if (out) std::memcpy(out, v.data(), sizeof(float) * v.size());
+    return n;
+}
+int orc_spatial_pyramid_histogram(const uint8_t* img, int w, int h, int ch, int stride, int bins, int levels, int interpolate,
+                                  int normalization, float* out) {
+    std::vector<float> v;
+    int n = spatial_pyramid_histogram(img, w, h, ch, stride, bins, levels, interpolate != 0, normalization, v);
     if (out) std::memcpy(out, v.data(), sizeof(float) * v.size());
     return n;
 }

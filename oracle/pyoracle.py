@@ -80,12 +80,15 @@ def lib():
                                                                                    C.c_int64]
         l.orc_hog_filter.argtypes = [C.c_void_p] + [C.c_int] * 11 + [C.c_void_p]
         l.orc_spatial_histogram.argtypes = [C.c_void_p] + [C.c_int] * 12 + [C.c_void_p]
+        l.orc_pyramid_hog.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]
+        l.orc_spatial_pyramid_histogram.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]
         l.orc_vlhog.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int),
                                 C.POINTER(C.c_int)]
         l.orc_sdm_descriptors.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_void_p]
         l.orc_sdm_align_rigid.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         l.orc_sdm_optimize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        l.orc_equalize_hist.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         l.orc_whi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
         _lib = l
     return _lib
@@ -158,6 +161,23 @@ def histeq64(patch):
     return out
 
 
+def equalize_hist(patch):
+    """cv::equalizeHist (HistogramEqualizationFilter)"""
+    patch = _c(patch, np.uint8)
+    out = np.empty_like(patch)
+    lib().orc_equalize_hist(_p(patch), patch.shape[1], patch.shape[0], patch.shape[1], _p(out))
+    return out
+
+
+def whi(patch, alpha=1.0, cutoff=0.390625):
+    """WhiteningFilter -> HistogramEqualizationFilter -> ConversionFilter(CV_32F, 1/127.5, -1) -> UnitNormFilter(L2)
+    (ffpDetectApp.cpp:449-454); returns h x w float32"""
+    patch = _c(patch, np.uint8)
+    out = np.empty(patch.shape, np.float32)
+    lib().orc_whi(_p(patch), patch.shape[1], patch.shape[0], patch.shape[1], alpha, cutoff, _p(out))
+    return out
+
+
 def greyworld(bgr):
     bgr = _c(bgr, np.uint8)
     out = np.empty_like(bgr)
@@ -172,16 +192,42 @@ def iimg(patch, sqr):
     return out
 
 
-def hog_filter(binimg, bins, cell, block, interpolate=False, signed_and_unsigned=False):
+def hog_filter(binimg, bins, cell, block, interpolate=False, signed_and_unsigned=False, cell_h=0, block_h=0):
     binimg = _c(binimg, np.uint8)
     h, w = binimg.shape[:2]
     ch = 1 if binimg.ndim == 2 else binimg.shape[2]
-    n = lib().orc_hog_filter(_p(binimg), w, h, ch, w * ch, bins, cell, cell, block, block, int(interpolate),
+    n = lib().orc_hog_filter(_p(binimg), w, h, ch, w * ch, bins, cell, cell_h or cell, block, block_h or block, int(interpolate),
                              int(signed_and_unsigned), None)
     out = np.empty(n, np.float32)
-    lib().orc_hog_filter(_p(binimg), w, h, ch, w * ch, bins, cell, cell, block, block, int(interpolate),
+    lib().orc_hog_filter(_p(binimg), w, h, ch, w * ch, bins, cell, cell_h or cell, block, block_h or block, int(interpolate),
                          int(signed_and_unsigned), _p(out))
     return out
+
+
+def _two_pass(fn, binimg, *args):
+    binimg = _c(binimg, np.uint8)
+    h, w = binimg.shape[:2]
+    ch = 1 if binimg.ndim == 2 else binimg.shape[2]
+    n = fn(_p(binimg), w, h, ch, w * ch, *args, None)
+    out = np.empty(n, np.float32)
+    fn(_p(binimg), w, h, ch, w * ch, *args, _p(out))
+    return out
+
+
+def spatial_histogram(binimg, bins, cell, block, interpolate=False, concatenate=False, normalization=1, cell_h=0, block_h=0):
+    """SpatialHistogramFilter.cpp:56-94; normalization 0 none, 1 L2, 2 L2HYS, 3 L1, 4 L1SQRT"""
+    return _two_pass(lib().orc_spatial_histogram, binimg, bins, cell, cell_h or cell, block, block_h or block, int(interpolate),
+                     int(concatenate), int(normalization))
+
+
+def pyramid_hog(binimg, bins, levels, interpolate=False, signed_and_unsigned=False):
+    """PyramidHogFilter.cpp:33-113"""
+    return _two_pass(lib().orc_pyramid_hog, binimg, bins, levels, int(interpolate), int(signed_and_unsigned))
+
+
+def spatial_pyramid_histogram(binimg, bins, levels, interpolate=False, normalization=1):
+    """SpatialPyramidHistogramFilter.cpp:37-81"""
+    return _two_pass(lib().orc_spatial_pyramid_histogram, binimg, bins, levels, int(interpolate), int(normalization))
 
 
 class Pyramid:

@@ -247,6 +247,156 @@ def test_hog_features_bit_exact(oracle, capi, ctx, frame640, hp):
     pg.close()
 
 
+def _oracle_hist_features(oracle, po, hp, fn):
+    """fn(bin-image patch) for every window of the oracle pyramid, in extraction order"""
+    layers = [po.layer(i) for i in range(len(po.layers()))]
+    feats = []
+    for lp, lx, ly, *_ in po.windows(hp.patch_w, hp.patch_h, hp.step_x, hp.step_y):
+        feats.append(fn(np.ascontiguousarray(layers[lp][ly:ly + hp.patch_h, lx:lx + hp.patch_w])))
+    return np.stack(feats)
+
+
+HIST_CASES = [
+    # (layer filter kwargs, hist params, oracle function name, oracle kwargs, exact?)
+    (dict(kind=1, bins=9), dict(kind=0, bins=9, cell=5, block=2, interpolate=True), "hog_filter",
+     dict(bins=9, cell=5, block=2, interpolate=True), True),
+    (dict(kind=1, bins=8, signed_gradients=True, interpolate=True), dict(kind=0, bins=8, cell=5, block=2, interpolate=True, signed_and_unsigned=True),
+     "hog_filter", dict(bins=8, cell=5, block=2, interpolate=True, signed_and_unsigned=True), True),
+    (dict(kind=1, bins=9), dict(kind=0, bins=9, cell=4, block=3), "hog_filter", dict(bins=9, cell=4, block=3), True),
+    (dict(kind=2, lbp_type=1), dict(kind=1, bins=59, cell=5, block=1, normalization=2), "spatial_histogram",
+     dict(bins=59, cell=5, block=1, normalization=2), False),
+    (dict(kind=2, lbp_type=0), dict(kind=1, bins=256, cell=10, block=1, interpolate=True, normalization=1), "spatial_histogram",
+     dict(bins=256, cell=10, block=1, interpolate=True, normalization=1), False),
+    (dict(kind=2, lbp_type=2), dict(kind=1, bins=16, cell=5, block=2, concatenate=True, normalization=4), "spatial_histogram",
+     dict(bins=16, cell=5, block=2, concatenate=True, normalization=4), True),
+    (dict(kind=1, bins=9), dict(kind=1, bins=9, cell=5, block=2, concatenate=False, normalization=3, interpolate=True), "spatial_histogram",
+     dict(bins=9, cell=5, block=2, concatenate=False, normalization=3, interpolate=True), True),
+    (dict(kind=1, bins=9), dict(kind=1, bins=9, cell=5, block=1, normalization=0), "spatial_histogram",
+     dict(bins=9, cell=5, block=1, normalization=0), True),
+    (dict(kind=1, bins=8, signed_gradients=True), dict(kind=2, bins=8, levels=3, signed_and_unsigned=True), "pyramid_hog",
+     dict(bins=8, levels=3, signed_and_unsigned=True), True),
+    (dict(kind=1, bins=9, interpolate=True), dict(kind=2, bins=9, levels=2, interpolate=True), "pyramid_hog",
+     dict(bins=9, levels=2, interpolate=True), True),
+    (dict(kind=2, lbp_type=1), dict(kind=3, bins=59, levels=3, normalization=1), "spatial_pyramid_histogram",
+     dict(bins=59, levels=3, normalization=1), True),
+    (dict(kind=1, bins=9), dict(kind=3, bins=9, levels=2, interpolate=True, normalization=2), "spatial_pyramid_histogram",
+     dict(bins=9, levels=2, interpolate=True, normalization=2), True),
+    # non-square cells and blocks (cellWidth 5, cellHeight 4, blockWidth 2, blockHeight 3)
+    (dict(kind=1, bins=9), dict(kind=0, bins=9, cell=5, cell_h=4, block=2, block_h=3), "hog_filter",
+     dict(bins=9, cell=5, cell_h=4, block=2, block_h=3), True),
+    (dict(kind=2, lbp_type=3), dict(kind=1, bins=16, cell=4, cell_h=10, block=3, block_h=1, concatenate=True, normalization=1, interpolate=True),
+     "spatial_histogram", dict(bins=16, cell=4, cell_h=10, block=3, block_h=1, concatenate=True, normalization=1, interpolate=True), True),
+]
+
+
+@pytest.mark.parametrize("case", range(len(HIST_CASES)))
+def test_histogram_filters_match_oracle(oracle, capi, ctx, frame640, case):
+    """HogFilter (interpolating), SpatialHistogramFilter, PyramidHogFilter, SpatialPyramidHistogramFilter on every
+    window.  Bit-exact where the reference order is reproduced; the whole-vector normalisation of the block-1x1
+    SpatialHistogramFilter reduces in fp64 across lanes and is compared at 1e-6 relative."""
+    lf, hpk, fname, okw, exact = HIST_CASES[case]
+    kw = dict(octave_layers=2, min_scale=0.2, max_scale=0.4)
+    small = np.ascontiguousarray(frame640[:240, :320])
+    po = oracle.Pyramid(**kw)
+    po.set_layer_filter(**lf)
+    po.update(small)
+    pg = capi.Pyramid(ctx, **kw)
+    pg.set_layer_filter(**lf)
+    pg.update(small)
+    hp = capi.hist_params(pw=20, ph=20, sx=3, sy=3, **hpk)
+    fo = _oracle_hist_features(oracle, po, hp, lambda patch: getattr(oracle, fname)(patch, **okw))
+    fg = capi.extract_hist(ctx, pg, hp)
+    assert fg.shape == fo.shape and len(fo) > 300
+    if exact:
+        assert np.array_equal(fg, fo)
+    else:
+        assert np.allclose(fg, fo, rtol=1e-6, atol=1e-9)
+    pg.close(); po.close()
+
+
+def test_lbp_hik_svm_detector(oracle, capi, ctx, synth, frame640):
+    """LBP(uniform) layers + SpatialHistogramFilter + histogram-intersection SVM (the LBP chain of
+    BenchmarkRunner.cpp:185-201): distances within 1e-4 relative, positives identical away from the threshold."""
+    kw = dict(octave_layers=2, min_scale=0.2, max_scale=0.4)
+    small = np.ascontiguousarray(frame640[:240, :320])
+    po = oracle.Pyramid(**kw)
+    po.set_layer_filter(kind=2, lbp_type=1)
+    po.update(small)
+    pg = capi.Pyramid(ctx, **kw)
+    pg.set_layer_filter(kind=2, lbp_type=1)
+    pg.update(small)
+    hp = capi.hist_params(kind=1, pw=20, ph=20, sx=3, sy=3, bins=59, cell=5, block=1, normalization=1)
+    fo = _oracle_hist_features(oracle, po, hp, lambda patch: oracle.spatial_histogram(patch, bins=59, cell=5, block=1, normalization=1))
+    rng = np.random.default_rng(5)
+    nsv = 96
+    sv = fo[rng.choice(len(fo), nsv, replace=False)].copy()
+    coeff = rng.normal(0, 1, nsv).astype(np.float32)
+    m = dict(kernel=3, dtype=1, sv=sv, coeff=coeff, bias=np.float32(0.0), p0=0.0, p1=0.0, p2=0.0, threshold=0.0, logistic_a=0.0,
+             logistic_b=-1.0)
+    so = oracle.Svm(m)
+    do = so.distance(fo)
+    m["threshold"] = float(np.float32(np.quantile(do, 0.97)))
+    sg = capi.Svm(ctx, m)
+    dets, dg = capi.detect_hist_svm(ctx, pg, sg, hp)
+    scale = np.abs(coeff).sum() * fo.sum(1).max()
+    assert np.max(np.abs(dg - do)) <= 1e-4 * scale
+    margin = 1e-4 * scale
+    sure = np.abs(do - float(m["threshold"])) > margin
+    pos_o = do >= float(m["threshold"])
+    wins = po.windows(20, 20, 3, 3)
+    got = {(int(d["layer"]), int(d["lx"]), int(d["ly"])) for d in dets}
+    for i in np.nonzero(sure)[0]:
+        key = (int(wins[i][0]), int(wins[i][1]), int(wins[i][2]))
+        assert (key in got) == bool(pos_o[i])
+    sg.close(); pg.close(); po.close()
+
+
+def test_whi_chain_and_histeq(oracle, capi, ctx, frame640):
+    """WhiteningFilter -> HistogramEqualizationFilter -> ConversionFilter -> UnitNormFilter per patch and per
+    pyramid window.  The kernel evaluates the oracle's DFT sums in the same order (whitened + equalised u8 image
+    bit-identical); the L2 norm is reduced across lanes, hence 1e-6 relative on the final floats."""
+    gray = oracle.bgr2gray(frame640)
+    rng = np.random.default_rng(4)
+    for (h, w) in ((20, 20), (24, 24), (16, 32), (15, 21)):
+        patches = np.stack([gray[y:y + h, x:x + w] for y, x in zip(rng.integers(0, 400, 40), rng.integers(0, 560, 40))])
+        patches[0] = 77   # constant patch: equalizeHist early-out
+        eq_g = capi.equalize_hist_batch(ctx, patches)
+        eq_o = np.stack([oracle.equalize_hist(p_) for p_ in patches])
+        assert np.array_equal(eq_g, eq_o)
+        for alpha, cutoff in ((1.0, 0.390625), (0.5, 0.0)):
+            wg = capi.whi_batch(ctx, patches, alpha, cutoff)
+            wo = np.stack([oracle.whi(p_, alpha, cutoff) for p_ in patches])
+            assert np.allclose(wg, wo, rtol=1e-6, atol=1e-9)
+    kw = dict(octave_layers=2, min_scale=0.2, max_scale=0.4)
+    small = np.ascontiguousarray(frame640[:240, :320])
+    po = oracle.Pyramid(**kw); po.update(small)
+    pg = capi.Pyramid(ctx, **kw); pg.update(small)
+    wp = capi.whi_params(20, 20, 3, 3)
+    layers = [po.layer(i) for i in range(len(po.layers()))]
+    fo = np.stack([oracle.whi(np.ascontiguousarray(layers[lp][ly:ly + 20, lx:lx + 20])).ravel() for lp, lx, ly, *_ in po.windows(20, 20, 3, 3)])
+    fg = capi.extract_whi(ctx, pg, wp)
+    assert fg.shape == fo.shape and len(fo) > 300
+    assert np.allclose(fg, fo, rtol=1e-6, atol=1e-9)
+    # whi + RBF SVM detector (ffpDetectApp.cpp featurespace "whi", classifier "psvm")
+    nsv = 64
+    sv = fo[rng.choice(len(fo), nsv, replace=False)].copy()
+    coeff = rng.normal(0, 1, nsv).astype(np.float32)
+    m = dict(kernel=2, dtype=1, sv=sv, coeff=coeff, bias=np.float32(0.1), p0=2.0, p1=0.0, p2=0.0, threshold=0.0, logistic_a=0.0, logistic_b=-1.0)
+    so = oracle.Svm(m)
+    do = so.distance(fo)
+    m["threshold"] = float(np.float32(np.quantile(do, 0.95)))
+    sg = capi.Svm(ctx, m)
+    dets, dg = capi.detect_whi_svm(ctx, pg, sg, wp)
+    scale = np.abs(coeff).sum()
+    assert np.max(np.abs(dg - do)) <= 1e-4 * scale
+    sure = np.abs(do - m["threshold"]) > 1e-4 * scale
+    wins = po.windows(20, 20, 3, 3)
+    got = {(int(d["layer"]), int(d["lx"]), int(d["ly"])) for d in dets}
+    for i in np.nonzero(sure)[0]:
+        assert ((int(wins[i][0]), int(wins[i][1]), int(wins[i][2])) in got) == bool(do[i] >= m["threshold"])
+    sg.close(); pg.close(); po.close()
+
+
 def test_hog_rbf_svm_detector_config2(oracle, capi, ctx, synth):
     """BASELINE config 2 shape on a reduced frame: HOG-324 + RBF SVM (MFMA path).  Scores within
     1e-4 relative (of the natural scale sum|coeff_i| K_i), positives identical away from the threshold."""

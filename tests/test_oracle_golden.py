@@ -126,3 +126,78 @@ def test_empty_and_tiny_inputs(oracle):
     assert len(p.windows(20, 20, 1, 1)) == 0
     assert len(oracle.overlap_elimination(np.zeros(0, oracle.DET_DTYPE), 5.0, 0.0)) == 0
     assert oracle.block_nms(np.zeros((40, 50), np.float32), 35).sum() == 0
+
+
+def test_pyramid_histogram_filters_structure(oracle):
+    """PyramidHogFilter / SpatialPyramidHistogramFilter restatements against first principles: without
+    normalisation the level-l histograms are the sums of their children and the root is the histogram of
+    the whole patch; PyramidHog normalises each histogram by 1/sqrt(energy + 1e-4)."""
+    rng = np.random.default_rng(3)
+    img = np.stack([rng.integers(0, 9, (24, 24)), rng.integers(0, 256, (24, 24))], -1).astype(np.uint8)
+    v = oracle.spatial_pyramid_histogram(img, bins=9, levels=3, interpolate=False, normalization=0).reshape(21, 9)
+    whole = np.zeros(9, np.float64)
+    for b, w in img.reshape(-1, 2):
+        whole[b] += np.float32(1.0 / 255.0) * np.float32(w)
+    assert np.allclose(v[0], whole, rtol=1e-5)
+    lvl1, lvl2 = v[1:5].reshape(2, 2, 9), v[5:21].reshape(4, 4, 9)
+    for r in range(2):
+        for c in range(2):
+            kids = lvl2[2 * r:2 * r + 2, 2 * c:2 * c + 2].reshape(4, 9)
+            assert np.array_equal(lvl1[r, c], ((kids[0] + kids[1]) + kids[2]) + kids[3])
+    assert np.array_equal(v[0], ((v[1] + v[2]) + v[3]) + v[4])
+    # finest level == cell histograms of the spatial filter on the same grid (cell = 24/4 = 6)
+    cells = oracle.spatial_histogram(img, bins=9, cell=6, block=1, normalization=0).reshape(16, 9)
+    assert np.array_equal(lvl2.reshape(16, 9), cells)
+    ph = oracle.pyramid_hog(img, bins=9, levels=3).reshape(21, 9)
+    expect = v / np.sqrt((v.astype(np.float32) ** 2).sum(1, dtype=np.float32) + np.float32(1e-4))[:, None]
+    assert np.allclose(ph, expect, rtol=2e-6)
+    # signed + unsigned: 3/2 * bins values per histogram, energy over the unsigned half
+    img8 = img.copy(); img8[..., 0] %= 8
+    ps = oracle.pyramid_hog(img8, bins=8, levels=2, signed_and_unsigned=True).reshape(5, 12)
+    raw = oracle.spatial_pyramid_histogram(img8, bins=8, levels=2, normalization=0).reshape(5, 8)
+    un = raw[:, :4] + raw[:, 4:]
+    nrm = 1.0 / np.sqrt((un ** 2).sum(1) + 1e-4)
+    assert np.allclose(ps[:, :8], raw * nrm[:, None], rtol=2e-6) and np.allclose(ps[:, 8:], un * nrm[:, None], rtol=2e-6)
+
+
+def _whi_numpy(x, alpha=1.0, cutoff=0.390625):
+    """The "whi" chain through numpy's FFT (independent of the oracle's DFT loops)."""
+    h, w = x.shape
+    n = w * h
+    F = (np.fft.fft2(x.astype(np.float64)) / n).astype(np.complex64)
+    rows, cols = (np.arange(h) + h // 2) % h, (np.arange(w) + w // 2) % w
+    fx = (np.float32(-0.5) + cols.astype(np.float32) * np.float32(1.0) / np.float32(w - 1)).astype(np.float32)
+    fy = (np.float32(-0.5) + rows.astype(np.float32) * np.float32(1.0) / np.float32(h - 1)).astype(np.float32)
+    rho = np.sqrt(fx[None, :] ** 2 + fy[:, None] ** 2, dtype=np.float32)
+    f = np.power(rho, np.float32(alpha), dtype=np.float32)
+    if cutoff > 0:
+        f = f * np.exp(-np.power(rho / np.float32(cutoff), 4, dtype=np.float32), dtype=np.float32)
+    G = (F.real * f).astype(np.float32) + 1j * (F.imag * f).astype(np.float32)
+    # DFT_REAL_OUTPUT consumes the half spectrum only: rebuild the other half by conjugate symmetry
+    full = np.empty((h, w), np.complex128)
+    for r in range(h):
+        for c in range(w):
+            rr, cc = (h - r) % h, (w - c) % w
+            own = c < cc or (c == cc and r <= rr)
+            full[r, c] = G[r, c] if own else np.conj(G[rr, cc])
+    val = (np.fft.ifft2(full).real * n).astype(np.float32)
+    u8 = np.clip(np.rint(val.astype(np.float64) + 127.0), 0, 255).astype(np.uint8)
+    return u8
+
+
+def test_whi_chain_against_numpy_fft(oracle):
+    rng = np.random.default_rng(9)
+    flips = total = 0
+    for (h, w) in ((20, 20), (24, 24), (16, 32), (15, 21)):
+        for _ in range(6):
+            x = rng.integers(0, 256, (h, w)).astype(np.uint8)
+            x[: h // 2] //= 2
+            u8 = _whi_numpy(x)
+            eq = oracle.equalize_hist(u8)
+            v = eq.astype(np.float32) * np.float32(1.0 / 127.5) + np.float32(-1.0)
+            expect = v * np.float32(1.0 / (np.sqrt((v.astype(np.float64) ** 2).sum()) + np.float32(1e-4)))
+            got = oracle.whi(x)
+            bad = ~np.isclose(got, expect, rtol=1e-5, atol=1e-7)
+            flips += int(bad.sum()); total += bad.size
+    # a whitened value within float rounding of .5 may round the other way; anything systematic would show up everywhere
+    assert flips <= total // 500
