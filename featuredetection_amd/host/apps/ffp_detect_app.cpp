@@ -61,9 +61,25 @@ int main(int argc, char** argv) {
                 featureExtractor->addPatchFilter(make_shared<HistEq64Filter>());
                 auto swd = make_shared<SlidingWindowDetector>(firstClassifier, featureExtractor);
                 det = make_shared<FiveStageSlidingWindowDetector>(swd, oe, secondClassifier);
-            } else if (type == "single") {
-                featureExtractor->addPatchFilter(make_shared<HistEq64Filter>());   // feature space hq64 (ffpDetectApp.cpp:455-457)
-                auto classifier = ProbabilisticWvmClassifier::load(node.get_child("classifier"));
+            } else if (type == "single") {   // ffpDetectApp.cpp:427-500
+                const string featurespace = node.get<string>("feature", "hq64");
+                if (featurespace == "histeq") {
+                    featureExtractor->addPatchFilter(make_shared<HistogramEqualizationFilter>());
+                } else if (featurespace == "whi") {
+                    featureExtractor->addPatchFilter(make_shared<WhiteningFilter>());
+                    featureExtractor->addPatchFilter(make_shared<HistogramEqualizationFilter>());
+                    featureExtractor->addPatchFilter(make_shared<ConversionFilter>(CV_32F, 1.0 / 127.5, -1.0));
+                    featureExtractor->addPatchFilter(make_shared<UnitNormFilter>(cv::NORM_L2));
+                } else if (featurespace == "hq64") {
+                    featureExtractor->addPatchFilter(make_shared<HistEq64Filter>());
+                } else if (featurespace != "gray") {
+                    throw std::invalid_argument("unknown feature space " + featurespace);
+                }
+                const ptree& classifierNode = node.get_child("classifier");
+                const string classifierType = classifierNode.get_value<string>();
+                shared_ptr<ProbabilisticClassifier> classifier;
+                if (classifierType == "psvm") classifier = ProbabilisticSvmClassifier::load(classifierNode);
+                else classifier = ProbabilisticWvmClassifier::load(classifierNode);   // "pwvm" (prvm: SURVEY 8(f), not on this backend)
                 det = make_shared<SlidingWindowDetector>(classifier, featureExtractor);
             } else {
                 throw std::invalid_argument("unknown detector type " + type);

@@ -26,6 +26,7 @@
 #define CV_32FC1 CV_MAKETYPE(CV_32F, 1)
 
 namespace cv {
+enum { NORM_INF = 1, NORM_L1 = 2, NORM_L2 = 4 };
 
 typedef unsigned char uchar;
 

@@ -1,0 +1,3 @@
+// ConversionFilter.hpp of the reference -- see imageprocessing_all.hpp
+#pragma once
+#include "imageprocessing/imageprocessing_all.hpp"

@@ -79,6 +79,41 @@ public:
     cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;
 };
 
+// The "whi" patch filter chain of ffpDetectApp.cpp:449-454.  Added in this order to a DirectPyramidFeatureExtractor
+// the four filters run as one fused kernel (fd_extract_whi / fd_detect_whi_svm); stand-alone only the
+// HistogramEqualizationFilter has a per-Mat form (fd_equalize_hist_batch).
+// WhiteningFilter.hpp:31 / WhiteningFilter.cpp:18-81
+class WhiteningFilter : public ImageFilter {
+public:
+    using ImageFilter::applyTo;
+    explicit WhiteningFilter(float alpha = 1, float cutoffFrequency = 0.390625f) : alpha(alpha), cutoffFrequency(cutoffFrequency) {}
+    cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;
+    float alpha, cutoffFrequency;
+};
+// HistogramEqualizationFilter.cpp (cv::equalizeHist)
+class HistogramEqualizationFilter : public ImageFilter {
+public:
+    using ImageFilter::applyTo;
+    cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;
+};
+// ConversionFilter.hpp: convertTo(type, alpha, beta)
+class ConversionFilter : public ImageFilter {
+public:
+    using ImageFilter::applyTo;
+    explicit ConversionFilter(int type, double alpha = 1, double beta = 0) : type(type), alpha(alpha), beta(beta) {}
+    cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;
+    int type;
+    double alpha, beta;
+};
+// UnitNormFilter.hpp / UnitNormFilter.cpp (eps 1e-4)
+class UnitNormFilter : public ImageFilter {
+public:
+    using ImageFilter::applyTo;
+    explicit UnitNormFilter(int normType = cv::NORM_L2) : normType(normType) {}
+    cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;
+    int normType;
+};
+
 // GreyWorldNormalizationFilter.cpp:20-71
 class GreyWorldNormalizationFilter : public ImageFilter {
 public:
@@ -303,6 +338,8 @@ public:
     bool hasHistEq64() const { return (bool)histeq; }
     std::shared_ptr<HogFilter> getHogFilter() const { return hog; }   // non-interpolating square HogFilter: k_hog_tile path
     std::shared_ptr<HistogramFilter> getHistogramFilter() const { return hist; }
+    // complete whi chain (WhiteningFilter, HistogramEqualizationFilter, ConversionFilter(CV_32F, 1/127.5, -1), UnitNormFilter(L2))
+    std::shared_ptr<WhiteningFilter> getWhiChain() const { return whiStage == 4 ? whitening : nullptr; }
 private:
     std::shared_ptr<Patch> extractFromLayer(const ImagePyramidLayer& layer, cv::Rect bounds) const;
     std::shared_ptr<ImagePyramid> pyramid;
@@ -310,6 +347,9 @@ private:
     std::shared_ptr<HistEq64Filter> histeq;
     std::shared_ptr<HogFilter> hog;
     std::shared_ptr<HistogramFilter> hist;
+    std::shared_ptr<WhiteningFilter> whitening;
+    std::shared_ptr<HistogramEqualizationFilter> equalization;
+    int whiStage = 0;   // number of whi chain filters added so far (in order)
 };
 
 }  // namespace imageprocessing

@@ -90,6 +90,16 @@ unsigned int LbpFilter::getBinCount() const {
         default: return 16;
     }
 }
+Mat WhiteningFilter::applyTo(const Mat&, Mat&) const { return fused_only("WhiteningFilter"); }
+Mat ConversionFilter::applyTo(const Mat&, Mat&) const { return fused_only("ConversionFilter"); }
+Mat UnitNormFilter::applyTo(const Mat&, Mat&) const { return fused_only("UnitNormFilter"); }
+Mat HistogramEqualizationFilter::applyTo(const Mat& image, Mat& filtered) const {
+    if (image.type() != CV_8UC1) throw std::invalid_argument("HistogramEqualizationFilter: the image must be of type CV_8UC1");
+    Mat src = image.isContinuous() ? image : image.clone();
+    filtered.create(src.rows, src.cols, CV_8UC1);
+    check(fd_equalize_hist_batch(context(), src.ptr<uchar>(0), 1, src.cols, src.rows, filtered.ptr<uchar>(0)));
+    return filtered;
+}
 HogFilter::HogFilter(int binCount, int cellSize, int blockSize, bool interpolate, bool signedAndUnsigned)
     : HogFilter(binCount, cellSize, cellSize, blockSize, blockSize, interpolate, signedAndUnsigned) {}
 HogFilter::HogFilter(int binCount, int cellWidth, int cellHeight, int blockWidth, int blockHeight, bool interpolate, bool signedAndUnsigned)
@@ -244,7 +254,22 @@ DirectPyramidFeatureExtractor::DirectPyramidFeatureExtractor(shared_ptr<ImagePyr
     : pyramid(pyramid), patchWidth(width), patchHeight(height) {}
 void DirectPyramidFeatureExtractor::addPatchFilter(shared_ptr<ImageFilter> filter) {
     if (auto h = std::dynamic_pointer_cast<HistEq64Filter>(filter)) histeq = h;
-    else if (auto hf = std::dynamic_pointer_cast<HistogramFilter>(filter)) {
+    else if (auto wf = std::dynamic_pointer_cast<WhiteningFilter>(filter)) {
+        if (whiStage != 0) throw std::logic_error("DirectPyramidFeatureExtractor: WhiteningFilter must be the first filter of the whi chain");
+        whitening = wf; whiStage = 1;
+    } else if (auto ef = std::dynamic_pointer_cast<HistogramEqualizationFilter>(filter)) {
+        if (whiStage != 0 && whiStage != 1) throw std::logic_error("DirectPyramidFeatureExtractor: unsupported patch filter order");
+        equalization = ef;
+        if (whiStage == 1) whiStage = 2;
+    } else if (auto cf = std::dynamic_pointer_cast<ConversionFilter>(filter)) {
+        if (whiStage != 2 || cf->type != CV_32F || cf->alpha != 1.0 / 127.5 || cf->beta != -1.0)
+            throw std::logic_error("DirectPyramidFeatureExtractor: ConversionFilter is available as ConversionFilter(CV_32F, 1.0/127.5, -1.0) inside the whi chain only");
+        whiStage = 3;
+    } else if (auto uf = std::dynamic_pointer_cast<UnitNormFilter>(filter)) {
+        if (whiStage != 3 || uf->normType != cv::NORM_L2)
+            throw std::logic_error("DirectPyramidFeatureExtractor: UnitNormFilter is available as UnitNormFilter(cv::NORM_L2) at the end of the whi chain only");
+        whiStage = 4;
+    } else if (auto hf = std::dynamic_pointer_cast<HistogramFilter>(filter)) {
         hist = hf;
         auto g = std::dynamic_pointer_cast<HogFilter>(filter);
         // the tuned k_hog_tile path covers the square, non-interpolating HogFilter; everything else runs k_hist_features
@@ -307,6 +332,22 @@ vector<shared_ptr<Patch>> DirectPyramidFeatureExtractor::extract(int stepX, int 
         }
         return patches;
     }
+    if (whiStage != 0 && whiStage != 4) throw std::logic_error("DirectPyramidFeatureExtractor: incomplete whi filter chain");
+    if (whiStage == 4) {
+        if (roi.area() != 0) throw std::logic_error("DirectPyramidFeatureExtractor: whi extraction works on the whole image only");
+        fd_whi_params wp = {patchWidth, patchHeight, stepX, stepY, whitening->alpha, whitening->cutoffFrequency};
+        const int F = patchWidth * patchHeight;
+        Mat all((int)std::max<int64_t>(n, 1), F, CV_32FC1);
+        int64_t cnt = 0;
+        if (n) check(fd_extract_whi(context(), pyramid->native(), &wp, all.ptr<float>(0), n, &cnt));
+        for (int64_t i = 0; i < n; ++i) {
+            const int32_t* w = &wins[7 * i];
+            Mat data(patchHeight, patchWidth, CV_32FC1);
+            std::memcpy(data.data, all.ptr<float>((int)i), sizeof(float) * (size_t)F);
+            patches.push_back(make_shared<Patch>(w[3], w[4], w[5], w[6], data));
+        }
+        return patches;
+    }
     if (hist) {
         if (roi.area() != 0) throw std::logic_error("DirectPyramidFeatureExtractor: histogram feature extraction works on the whole image only");
         fd_hist_params hp = hist_params_of(*hist, patchWidth, patchHeight, stepX, stepY);
@@ -334,6 +375,9 @@ vector<shared_ptr<Patch>> DirectPyramidFeatureExtractor::extract(int stepX, int 
     if (histeq && n) {
         eq.create((int)n, d, CV_8UC1);
         check(fd_histeq64_batch(context(), raw.data, n, patchWidth, patchHeight, eq.data));
+    } else if (equalization && n) {   // feature space "histeq" (ffpDetectApp.cpp:446-448)
+        eq.create((int)n, d, CV_8UC1);
+        check(fd_equalize_hist_batch(context(), raw.data, n, patchWidth, patchHeight, eq.data));
     } else {
         eq = raw;
     }
@@ -686,6 +730,21 @@ vector<shared_ptr<ClassifiedPatch>> SlidingWindowDetector::detect(const cv::Rect
         if (rc == FD_ERR_CAPACITY) {
             dets.resize((size_t)cnt);
             rc = fd_detect_hog_svm(context(), direct->getPyramid()->native(), s, &hp, dets.data(), cnt, &cnt, nullptr);
+        }
+        check(rc);
+        for (int64_t i = 0; i < cnt; ++i) out.push_back(to_patch(dets[i]));
+        return out;
+    }
+    if (direct && psvm && direct->getWhiChain() && !roi && f32sv) {   // fused whi chain + SVM (ffpDetectApp.cpp:449-454, "psvm")
+        auto wf = direct->getWhiChain();
+        fd_whi_params wp = {direct->getPatchWidth(), direct->getPatchHeight(), stepSizeX, stepSizeY, wf->alpha, wf->cutoffFrequency};
+        const fd_svm* s = psvm->getSvm()->native(psvm->getLogisticA(), psvm->getLogisticB());
+        int64_t cnt = 0, cap = 1 << 16;
+        vector<fd_detection> dets((size_t)cap);
+        int rc = fd_detect_whi_svm(context(), direct->getPyramid()->native(), s, &wp, dets.data(), cap, &cnt, nullptr);
+        if (rc == FD_ERR_CAPACITY) {
+            dets.resize((size_t)cnt);
+            rc = fd_detect_whi_svm(context(), direct->getPyramid()->native(), s, &wp, dets.data(), cnt, &cnt, nullptr);
         }
         check(rc);
         for (int64_t i = 0; i < cnt; ++i) out.push_back(to_patch(dets[i]));

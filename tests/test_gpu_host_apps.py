@@ -73,6 +73,79 @@ def test_ffp_detect_app_matches_oracle(tmp_path, oracle, synth, frame640, small_
         assert float(g[6]) == d["prob"]
 
 
+
+SINGLE_CFG = """detectors
+{
+    Face
+    {
+        landmark "face"
+        type single
+        feature %s
+        classifier psvm
+        {
+            classifierFile %s
+            threshold %s
+        }
+        pyramid
+        {
+            minScaleFactor 0.2
+            maxScaleFactor 0.4
+            incrementalScaleFactor 0.7071
+            patch
+            {
+                width 20
+                height 20
+            }
+        }
+    }
+}
+"""
+
+
+@pytest.mark.parametrize("feature", ["whi", "histeq", "gray"])
+def test_ffp_detect_app_single_detector_feature_spaces(tmp_path, oracle, synth, frame640, feature):
+    """type "single" of ffpDetectApp.cpp:427-500: feature spaces whi / histeq / gray with a ProbabilisticSvmClassifier,
+    through the C++ mirror classes (WhiteningFilter ... UnitNormFilter, HistogramEqualizationFilter)."""
+    app = os.path.join(PKG, "ffp_detect_app")
+    if not os.path.exists(app):
+        pytest.fail("host apps not built (make -C featuredetection_amd/host)")
+    small = np.ascontiguousarray(frame640[:240, :320])
+    inc = float(np.float32(0.7071))
+    po = oracle.Pyramid(inc=inc, min_scale=float(np.float32(0.2)), max_scale=float(np.float32(0.4)))
+    po.update(small)
+    layers = [po.layer(i) for i in range(len(po.layers()))]
+    wins = po.windows(20, 20, 1, 1)
+    pat = np.stack([np.ascontiguousarray(layers[lp][ly:ly + 20, lx:lx + 20]) for lp, lx, ly, *_ in wins])
+    rng = np.random.default_rng(8)
+    if feature == "whi":
+        feats = np.stack([oracle.whi(p_).ravel() for p_ in pat])
+        sv = feats[rng.choice(len(feats), 48, replace=False)].copy()
+        m = dict(kernel=2, dtype=1, sv=sv, p0=2.0)
+    else:
+        feats = (np.stack([oracle.equalize_hist(p_) for p_ in pat]) if feature == "histeq" else pat).reshape(len(pat), -1)
+        sv = feats[rng.choice(len(feats), 48, replace=False)].copy()
+        m = dict(kernel=2, dtype=0, sv=sv, p0=2e-6)
+    m.update(coeff=rng.normal(0, 1, 48).astype(np.float32), bias=np.float32(0.05), p1=0.0, p2=0.0, threshold=0.0, logistic_a=0.3, logistic_b=-1.7)
+    so = oracle.Svm(m)
+    do = so.distance(feats)
+    order = np.sort(do)
+    # threshold in the widest gap of the upper tail, so that no distance sits within rounding of it
+    tail = order[-60:]
+    k = int(np.argmax(np.diff(tail)))
+    m["threshold"] = float(np.float32(0.5 * (tail[k] + tail[k + 1])))
+    so = oracle.Svm(m)
+    synth.save_svm_text(str(tmp_path / "c.svm.txt"), m, rows=20, cols=20)
+    synth.save_pnm(str(tmp_path / "frame.ppm"), small)
+    (tmp_path / "c.cfg").write_text(SINGLE_CFG % (feature, tmp_path / "c.svm.txt", repr(m["threshold"])))
+    out = _run([app, str(tmp_path / "c.cfg"), str(tmp_path / "frame.ppm")])
+    got = [l.split() for l in out.strip().splitlines()]
+    pos = np.nonzero(do >= m["threshold"])[0]
+    assert len(got) == len(pos) > 0
+    for g, i in zip(got, pos):
+        lp, lx, ly, cx, cy, ow, oh = [int(v) for v in wins[i]]
+        assert [int(v) for v in g[2:6]] == [cx - ow // 2, cy - oh // 2, ow, oh]
+        assert abs(float(g[6]) - so.probability(do[i])) <= 1e-6
+
 def test_sdm_fit_app_matches_oracle(tmp_path, oracle, synth):
     app = os.path.join(PKG, "sdm_fit_app")
     if not os.path.exists(app):
