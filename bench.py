@@ -57,6 +57,19 @@ def cpu_baseline_wvm(frame, wvm, svm):
                 sample="%d x 640x480 FaceFrontal five-stage cascade (16,185 windows each), %.1f s, oracle -O2 single thread" % (reps, dt))
 
 
+def pmc_traffic(workload, kernel_substr):
+    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json,
+    produced by tools/pmc_traffic.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        rec = json.load(open(path)).get(workload)
+        if rec and kernel_substr in rec["kernel"]:
+            return float(rec["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,6 +176,10 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    # a full Python gc pass over torch's object graph costs ~75 ms and would land on a random step
+    import gc
+    gc.collect()
+    gc.disable()
     kernel_ms = []
     recs_cap = 4096
     barrier()
@@ -181,6 +198,7 @@ def main():
             pending = []
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     uu = torch.tensor([float(units)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -196,7 +214,7 @@ def main():
     if rank == 0:
         value = total_units / dt / 1e6
         res = dict(metric="Mpatches/s (extract+HOG+RBF-SVM), 640x480 pyramid" if args.workload == "hog_svm" else
-                   ("Mpatches/s (extract+WVM+SVM cascade), 640x480 pyramid" if args.workload == "wvm" else "SDM iters/s (x1e6)"),
+                   ("Mpatches/s (extract+WVM+SVM cascade), %dx%d pyramid" % (FW, FH) if args.workload == "wvm" else "SDM iters/s (x1e6)"),
                    value=value, unit="Mpatches/s" if args.workload != "sdm" else "M SDM iters/s", n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype=dtype, data="synthetic", config=config)
@@ -206,7 +224,8 @@ def main():
             flops = 2.0 * 324 * 1024 * nwin
             ach = flops / (kms * 1e-3) / 1e12
             res["roofline"] = dict(bound="mfma", kernel="k_svm_rbf_mfma", achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                                   frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=None, kernel_ms=kms,
+                                   frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=pmc_traffic("hog_svm", "k_svm_rbf_mfma") if (W, H) == (640, 480) else None,
+                                   kernel_ms=kms,
                                    algorithmic="2*324*1024 flop/window x %d windows/launch" % nwin)
             if not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline_hog_svm(None, model)
@@ -215,7 +234,8 @@ def main():
             bytes_per_launch = layer_bytes + nwin_wvm * 16
             ach = bytes_per_launch / (kms * 1e-3) / 1e9
             res["roofline"] = dict(bound="hbm", kernel="k_wvm_cascade", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
-                                   traffic=None, kernel_ms=kms, algorithmic="%d layer bytes + 16 B record x %d windows per launch" % (layer_bytes, nwin_wvm))
+                                   traffic=pmc_traffic("wvm", "k_wvm_cascade") if (W, H) == (640, 480) else None, kernel_ms=kms,
+                                   algorithmic="%d layer bytes + 16 B record x %d windows per launch" % (layer_bytes, nwin_wvm))
             if not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline_wvm(synth.make_frame(640, 480, seed=20260927), wvm_m, svm_m)
         print(json.dumps(res))
