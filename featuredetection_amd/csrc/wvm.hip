@@ -548,27 +548,32 @@ __global__ __launch_bounds__(256) void k_histeq64(const uint8_t* __restrict__ in
 
 // Launches stage A over all windows and stage B over its survivors (same stream, no host round trip:
 // stage B is a persistent grid that reads the survivor count from device memory).
+template <int PW_, int PH_, bool RAW>
+void launch_sized(fd_ctx* ctx, hipStream_t st, int64_t total, const WvmDev& dev, const uint8_t* arena, const WinTable& wt,
+                  const CascadeOut& o) {
+    const int gridA = (int)std::min<int64_t>((total + 3) / 4, (int64_t)ctx->num_cus * 8);
+    hipLaunchKernelGGL((k_wvm_cascade<PW_, PH_, RAW>), dim3(gridA), dim3(256), 0, st, arena, wt, dev, o);
+    if (dev.numUsed <= WVM_LCAP) return;
+    static int perCu = 0;   // stage B is persistent: as many workgroups as fit on the device at once
+    if (perCu == 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wvm_deep<PW_, PH_, RAW>, 256, 0) != hipSuccess || perCu < 1) perCu = 2;
+    }
+    const int gridB = (int)std::min<int64_t>(total, (int64_t)ctx->num_cus * perCu);
+    hipLaunchKernelGGL((k_wvm_deep<PW_, PH_, RAW>), dim3(gridB), dim3(256), 0, st, arena, wt, dev, o);
+}
+
+// patch sizes with compile-time geometry: the detectors of ffpDetectApp/*.cfg (20x20 faces, 24x24 lip / nose / eye
+// corners, 16x24 ears, 32x16 eyes, 32x24 nose tip); anything else up to 32x32 takes the run-time-sized instance
+#define FD_WVM_SIZES(X) X(20, 20) X(24, 24) X(16, 24) X(32, 16) X(32, 24)
+
 template <bool RAW>
 void launch_cascade(fd_ctx* ctx, hipStream_t st, int64_t total, const WvmDev& dev, const uint8_t* arena, const WinTable& wt,
                     const CascadeOut& o) {
-    const int gridA = (int)std::min<int64_t>((total + 3) / 4, (int64_t)ctx->num_cus * 8);
-    // stage B is persistent: as many workgroups as fit on the device at once
-    static int perCuB20 = 0, perCuB0 = 0;
-    int& perCu = (dev.fw == 20 && dev.fh == 20) ? perCuB20 : perCuB0;
-    if (perCu == 0) {
-        hipError_t e = (dev.fw == 20 && dev.fh == 20)
-            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wvm_deep<20, 20, false>, 256, 0)
-            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wvm_deep<0, 0, false>, 256, 0);
-        if (e != hipSuccess || perCu < 1) perCu = 2;
-    }
-    const int gridB = (int)std::min<int64_t>(total, (int64_t)ctx->num_cus * perCu);
-    if (dev.fw == 20 && dev.fh == 20) {
-        hipLaunchKernelGGL((k_wvm_cascade<20, 20, RAW>), dim3(gridA), dim3(256), 0, st, arena, wt, dev, o);
-        if (dev.numUsed > WVM_LCAP) hipLaunchKernelGGL((k_wvm_deep<20, 20, RAW>), dim3(gridB), dim3(256), 0, st, arena, wt, dev, o);
-    } else {
-        hipLaunchKernelGGL((k_wvm_cascade<0, 0, RAW>), dim3(gridA), dim3(256), 0, st, arena, wt, dev, o);
-        if (dev.numUsed > WVM_LCAP) hipLaunchKernelGGL((k_wvm_deep<0, 0, RAW>), dim3(gridB), dim3(256), 0, st, arena, wt, dev, o);
-    }
+#define FD_WVM_CASE(W, H) \
+    if (dev.fw == W && dev.fh == H) return launch_sized<W, H, RAW>(ctx, st, total, dev, arena, wt, o);
+    FD_WVM_SIZES(FD_WVM_CASE)
+#undef FD_WVM_CASE
+    launch_sized<0, 0, RAW>(ctx, st, total, dev, arena, wt, o);
 }
 
 }  // namespace
