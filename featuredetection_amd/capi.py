@@ -72,6 +72,19 @@ class fd_whi_params(C.Structure):
                 ("cutoff", C.c_float)]
 
 
+class fd_rvm_model(C.Structure):
+    _fields_ = [("kernel", C.c_int32), ("p0", C.c_double), ("p1", C.c_double), ("p2", C.c_double), ("num_filters", C.c_int32),
+                ("num_used", C.c_int32), ("filter_w", C.c_int32), ("filter_h", C.c_int32), ("support_vectors", C.c_void_p),
+                ("coefficients", C.c_void_p), ("thresholds", C.c_void_p), ("bias", C.c_float), ("logistic_a", C.c_double),
+                ("logistic_b", C.c_double)]
+
+
+class fd_rvm_detect_params(C.Structure):
+    _fields_ = [("feature_space", C.c_int32), ("conv_scale", C.c_float), ("conv_shift", C.c_float), ("step_x", C.c_int32),
+                ("step_y", C.c_int32)]
+
+
+FEATURE_GRAY, FEATURE_HQ64, FEATURE_HISTEQ = 0, 1, 2
 HIST_HOG, HIST_SPATIAL, HIST_PYRAMID_HOG, HIST_SPATIAL_PYRAMID = 0, 1, 2, 3
 
 _SIGS = {
@@ -120,6 +133,11 @@ _SIGS = {
     "fd_extract_whi": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fd_whi_params), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "fd_detect_whi_svm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(fd_whi_params), C.c_void_p, C.c_int64,
                                     C.POINTER(C.c_int64), C.c_void_p]),
+    "fd_rvm_create": (C.c_int, [C.c_void_p, C.POINTER(fd_rvm_model), C.POINTER(C.c_void_p)]),
+    "fd_rvm_destroy": (None, [C.c_void_p]),
+    "fd_rvm_eval_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "fd_detect_rvm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(fd_rvm_detect_params), C.c_void_p, C.c_void_p, C.c_int64,
+                                C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
     "fd_extract_hog": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fd_hog_params), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "fd_bench_hog_svm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(fd_hog_params), C.POINTER(C.c_int64),
                                    C.POINTER(C.c_int64)]),
@@ -422,6 +440,47 @@ def detect_hist_svm(ctx, pyr, svm, hp, want_all=True, cap=1 << 20):
     cnt = C.c_int64()
     ctx.check(lib().fd_detect_hist_svm(ctx.h, pyr.h, svm.h, C.byref(hp), _ptr(out), out.shape[0], C.byref(cnt), _ptr(alld)))
     return out[:cnt.value], alld
+
+
+class Rvm:
+    """fd_rvm handle; m: dict as synth.make_rvm"""
+    def __init__(self, ctx, m):
+        self.ctx, self.model = ctx, m
+        self._sv = _c(m["sv"], np.float32)
+        self._coeff = _c(m["coeff"], np.float32)
+        self._thr = _c(m["thresholds"], np.float32)
+        s = fd_rvm_model()
+        s.kernel = int(m["kernel"]); s.p0 = float(m.get("p0", 0)); s.p1 = float(m.get("p1", 0)); s.p2 = float(m.get("p2", 0))
+        s.num_filters = self._sv.shape[0]; s.num_used = int(m.get("num_used", 0))
+        s.filter_w, s.filter_h = int(m["filter_w"]), int(m["filter_h"])
+        s.support_vectors = self._sv.ctypes.data; s.coefficients = self._coeff.ctypes.data; s.thresholds = self._thr.ctypes.data
+        s.bias = float(m["bias"]); s.logistic_a = float(m.get("logistic_a", 0.0)); s.logistic_b = float(m.get("logistic_b", -1.0))
+        self.h = C.c_void_p()
+        ctx.check(lib().fd_rvm_create(ctx.h, C.byref(s), C.byref(self.h)))
+
+    def eval(self, feats):
+        feats = _c(feats, np.float32).reshape(len(feats), -1)
+        lv = np.empty(len(feats), np.int32)
+        d = np.empty(len(feats), np.float64)
+        self.ctx.check(lib().fd_rvm_eval_batch(self.ctx.h, self.h, _ptr(feats), len(feats), _ptr(lv), _ptr(d)))
+        return lv, d
+
+    def close(self):
+        if self.h:
+            lib().fd_rvm_destroy(self.h)
+            self.h = None
+
+
+def detect_rvm(ctx, pyr, rvm, feature_space=FEATURE_HQ64, conv_scale=1.0, conv_shift=0.0, sx=1, sy=1, roi=None, want_all=True, cap=1 << 20):
+    n = pyr.window_count(rvm.model["filter_w"], rvm.model["filter_h"], sx, sy, roi)
+    out = np.zeros(min(cap, max(n, 1)), DET_DTYPE)
+    lv = np.empty(n, np.int32) if want_all else None
+    dd = np.empty(n, np.float64) if want_all else None
+    cnt = C.c_int64()
+    dp = fd_rvm_detect_params(feature_space, conv_scale, conv_shift, sx, sy)
+    r = _c(roi, np.int32) if roi is not None else None
+    ctx.check(lib().fd_detect_rvm(ctx.h, pyr.h, rvm.h, C.byref(dp), _ptr(r), _ptr(out), out.shape[0], C.byref(cnt), _ptr(lv), _ptr(dd)))
+    return out[:cnt.value], lv, dd
 
 
 def whi_batch(ctx, patches, alpha=1.0, cutoff=0.390625):

@@ -1000,7 +1000,6 @@ int fd_detect_hist_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_h
         if (N == 0) return;
         if (fd_svm_dim(svm) != hd.F || fd_svm_is_u8(svm))
             FD_THROW(FD_ERR_INVALID_ARGUMENT, "SVM must work on f32 vectors of length %d", hd.F);
-        hipStream_t st = ctx->stream;
         S.dist.reserve(sizeof(double) * (size_t)N);
         fd_svm_generic_launch(ctx, svm, S.feat.p, nullptr, (int64_t)hd.F * 4, N, S.dist.as<double>());
         fd_svm_positives_to_detections(ctx, p, svm, wls, hp->step_x, hp->step_y, S.dist.as<double>(), N, out, cap, count, all_distance);

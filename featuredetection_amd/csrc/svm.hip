@@ -370,8 +370,12 @@ __global__ __launch_bounds__(RB_THREADS, 2) void k_svm_rbf_mfma(const float* __r
 // the whole kernel and streams 32-patch tiles through a double-buffered LDS image filled by
 // global_load_lds (LDS-DMA, no VGPR round trip).  C[i = SV][j = patch]: a lane's 16 accumulators are
 // 16 support vectors of ONE patch, so the sum over support vectors is in-register; only one
-// lane<->lane+32 exchange and an 8-wave LDS reduction remain.  Workgroup = 8 waves = 256 support
-// vectors; blockIdx.y selects the 256-SV group, each group writes its own partial sum (no atomics).
+// lane<->lane+32 exchange remains.  Every wave writes its own fp64 partial sum per patch (256 B per
+// tile, coalesced; k_sum_partials adds the 8 * ngroups partials): an 8-wave LDS reduction behind the
+// per-tile barrier cost 9 % of the kernel (1.55 -> 1.41 ms).  Workgroup = 8 waves = 256 support
+// vectors; blockIdx.y selects the 256-SV group.  Running the two waves of a SIMD half a tile out of
+// phase (deferred epilogue) was measured to change nothing: the matrix pipe is already 95 % busy at
+// the ~2.1 GHz the part sustains under this load (PMC: SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE).
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(512, 2) void k_svm_rbf_mfma_svs(const float* __rest
     constexpr int tileFloats = Q * 256;
     float* const buf0 = lds;
     float* const buf1 = lds + tileFloats;
-    float* red = lds + 2 * tileFloats;           // [2][8][32]
+    float* red = lds + 2 * tileFloats;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nt = blockIdx.y * 8 + wave;        // this wave's support-vector tile
     // stationary operand: Q float4 per lane
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void k_svm_rbf_mfma_svs(const float* __rest
     }
     // epilogue constants of this wave's 32 support vectors live in LDS (keeps the VGPR budget for the
     // stationary operand): svc[wave][0..31] = |s|^2, svc[wave][32..63] = coefficient
-    float* svc = red + 2 * 8 * 32 * 2 + wave * 64;
+    float* svc = red + wave * 64;
     svc[lane] = lane < 32 ? m.ss_f32[nt * 32 + lane] : m.coeffPad[nt * 32 + lane - 32];
     auto issue_tile = [&](int64_t tile, float* dst) {
         // LDS-DMA, 1 KiB per wave instruction; wave w moves q-groups w, w+8, ...  Issued through inline asm so
@@ -412,6 +416,20 @@ __global__ __launch_bounds__(512, 2) void k_svm_rbf_mfma_svs(const float* __rest
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(gsrc), "s"(ldsDst) : "memory");
         }
+    };
+    // epilogue of one tile: RBF values of this wave's 32 support vectors for the 32 patches, summed over the support
+    // vectors in fp64 and written as this wave's partial sum (k_sum_partials adds the 8 * ngroups partials)
+    double* const myPartial = partial + ((size_t)blockIdx.y * 8 + wave) * npadRows;
+    auto epilogue = [&](const f32x16& a, float xxv, int64_t t) {
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);   // support vector of accumulator r
+            const float d2 = (xxv + svc[row]) - 2.f * a[r];
+            s += (double)svc[32 + row] * (double)__expf(negGamma * fmaxf(d2, 0.f));
+        }
+        s += __shfl_xor(s, 32, 64);
+        if (lane < 32) myPartial[t * 32 + lane] = s;
     };
     int cur = 0;
     int64_t tile = blockIdx.x;
@@ -439,27 +457,9 @@ __global__ __launch_bounds__(512, 2) void k_svm_rbf_mfma_svs(const float* __rest
             __builtin_amdgcn_sched_barrier(0);
             p = pn;
         }
-        // epilogue: column = patch (lane & 31)
-        double s = 0.0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);   // support vector of accumulator r
-            const float d2 = (xxj + svc[row]) - 2.f * acc[r];
-            s += (double)svc[32 + row] * (double)__expf(negGamma * fmaxf(d2, 0.f));
-        }
-        s += __shfl_xor(s, 32, 64);
-        float* rd = red + cur * 512;
-        // double stored as two floats slots: keep fp64 through the LDS reduction
-        if (lane < 32) ((double*)rd)[wave * 32 + lane] = s;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile has landed in LDS
+        epilogue(acc, xxj, tile);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile has landed in LDS (and the partial sums are out)
         __syncthreads();
-        if (threadIdx.x < 32) {
-            const double* rdd = (const double*)rd;
-            double t = 0.0;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) t += rdd[w * 32 + threadIdx.x];
-            partial[(size_t)blockIdx.y * npadRows + tile * 32 + threadIdx.x] = t;
-        }
         xxj = xxn;
         cur ^= 1;
     }
@@ -502,8 +502,8 @@ void fd_svm_rbf_mfma_launch(fd_ctx* ctx, const fd_svm* m, const float* xFrag, co
         const int64_t ntiles = (npatches + 31) / 32;
         const int64_t npadRows = ((npatches + 63) / 64) * 64;
         const int ngroups = m->dev.nsv_pad / 256;
-        mm->dist.reserve(sizeof(double) * (size_t)ngroups * npadRows);
-        const size_t ldsBytes = (size_t)2 * (KP / 8) * 256 * 4 + 2 * 8 * 32 * 8 + 8 * 64 * 4;
+        mm->dist.reserve(sizeof(double) * (size_t)ngroups * 8 * npadRows);
+        const size_t ldsBytes = (size_t)2 * (KP / 8) * 256 * 4 + 8 * 64 * 4;
         static bool attr2 = false;
         if (!attr2) {
             HIP_CHECK(hipFuncSetAttribute((const void*)k_svm_rbf_mfma_svs<41>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -518,7 +518,7 @@ void fd_svm_rbf_mfma_launch(fd_ctx* ctx, const fd_svm* m, const float* xFrag, co
             hipLaunchKernelGGL(k_svm_rbf_mfma_svs<42>, dim3(gx, ngroups), dim3(512), ldsBytes, ctx->stream, xFrag, xx, m->dev,
                                (float)(-m->dev.p0), ntiles, mm->dist.as<double>(), npadRows);
         hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)std::min<int64_t>((npatches + 255) / 256, 2048)), dim3(256), 0, ctx->stream,
-                           mm->dist.as<double>(), ngroups, npadRows, npatches, m->dev.bias, out);
+                           mm->dist.as<double>(), ngroups * 8, npadRows, npatches, m->dev.bias, out);
         HIP_CHECK(hipGetLastError());
         return;
     }

@@ -10,6 +10,7 @@
 // L2 norm is reduced across lanes.  All intermediates live in LDS (32 bytes per pixel); HBM traffic
 // is the patch read (L2 hits for overlapping windows) and the 4*w*h-byte feature write.
 #include "fd_internal.hpp"
+#include "fd_device.hpp"
 #include <algorithm>
 #include <complex>
 #include <cstring>
@@ -46,56 +47,7 @@ struct WhiDev {
 
 namespace {
 
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-__device__ __forceinline__ unsigned char sat_u8_d(double v) {   // saturate_cast<uchar>(double): cvRound, clamp
-    const int i = (int)rint(v);
-    return (unsigned char)(i < 0 ? 0 : (i > 255 ? 255 : i));
-}
-
-// cv::equalizeHist of the n-pixel image `px` (LDS) by one wave; hist/lut: 256 ints each (LDS)
-__device__ __forceinline__ void equalize_hist_wave(const unsigned char* px, unsigned char* out, int n, int* hist, int* lut, int lane) {
-    for (int i = lane; i < 256; i += 64) hist[i] = 0;
-    wave_sync();
-    for (int i = lane; i < n; i += 64) atomicAdd(&hist[px[i]], 1);
-    wave_sync();
-    // lane l owns bins 4l..4l+3
-    int c[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) c[k] = hist[4 * lane + k];
-    const int mine = c[0] + c[1] + c[2] + c[3];
-    const unsigned long long nz = __ballot(mine != 0);
-    const int l0 = __builtin_ctzll(nz);                        // lane holding the first non-empty bin
-    int i0 = 0;
-    if (lane == l0) i0 = c[0] ? 0 : (c[1] ? 1 : (c[2] ? 2 : 3));
-    i0 = 4 * l0 + __builtin_amdgcn_readlane(i0, l0);
-    const int h0 = hist[i0];
-    if (h0 == n) {
-        for (int i = lane; i < n; i += 64) out[i] = (unsigned char)i0;
-        wave_sync();
-        return;
-    }
-    const float scale = (256 - 1.f) / (float)(n - h0);
-    // inclusive prefix over lanes of the per-lane totals (integer: order-free)
-    int incl = mine;
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-    }
-    int run = incl - mine;   // sum of all bins before 4*lane
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int bin = 4 * lane + k;
-        run += c[k];
-        // lut[i0] = 0; lut[i] = saturate(sum_{j in (i0, i]} hist[j] * scale)
-        lut[bin] = bin <= i0 ? 0 : (int)sat_u8_d((double)((float)(run - h0) * scale));
-    }
-    wave_sync();
-    for (int i = lane; i < n; i += 64) out[i] = (unsigned char)lut[px[i]];
-    wave_sync();
-}
+using namespace fd_dev;
 
 __device__ __forceinline__ const uint8_t* locate(const uint8_t* arena, const WhiWinTable& wt, int64_t wid, int w, int h, int& stride) {
     if (wt.raw) {

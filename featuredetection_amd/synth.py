@@ -225,6 +225,58 @@ def save_wvm(path, m):
         f.write(rects.tobytes())
 
 
+def make_rvm(seed, feats, fw, fh, n_filters=24, kernel=2, gamma=None, pass_rate=0.6, min_survivors=24):
+    """Synthetic cascaded reduced-vector machine (RvmClassifier): reduced set vectors = smoothed training vectors,
+    lower-triangular coefficients, thresholds calibrated on `feats` (f32 [n][fw*fh], already in the classifier's
+    feature space) so that ~pass_rate of the survivors pass each level while at least min_survivors remain.
+    The calibration follows the reference's cached evaluation (d_k = d_{k-1} + c[k][k] K_k)."""
+    rng = np.random.default_rng(seed)
+    feats = np.ascontiguousarray(feats, np.float32).reshape(len(feats), -1)
+    d = fw * fh
+    assert feats.shape[1] == d
+    idx = rng.choice(len(feats), n_filters, replace=len(feats) < n_filters)
+    sv = (0.85 * feats[idx] + 0.15 * feats.mean(0, keepdims=True)).astype(np.float32)
+    if gamma is None:
+        d2 = ((feats[:200, None, :].astype(np.float64) - sv[None, :8].astype(np.float64)) ** 2).sum(-1)
+        gamma = float(np.float32(1.0 / np.median(d2)))
+    coeff = np.zeros(n_filters * (n_filters + 1) // 2, np.float32)
+    for k in range(n_filters):
+        coeff[k * (k + 1) // 2: k * (k + 1) // 2 + k + 1] = rng.normal(0, 1, k + 1).astype(np.float32)
+    bias = np.float32(0.1)
+    X = feats.astype(np.float64)
+    if kernel == 2:
+        ssd = np.stack([((feats - sv[k]) ** 2).sum(1, dtype=np.float32) for k in range(n_filters)], 1)   # ~fp32 like the reference
+        K = np.exp(-gamma * ssd.astype(np.float64))
+        p0, p1, p2 = gamma, 0.0, 0.0
+    elif kernel == 1:
+        p0, p1, p2 = 1.0 / (d * 255.0 * 255.0), 0.5, 2.0
+        K = (p0 * (X @ sv.astype(np.float64).T) + p1) ** 2
+    elif kernel == 3:
+        K = np.minimum(X[:, None, :], sv[None].astype(np.float64)).sum(-1)
+        coeff /= np.float32(K.mean())
+        p0 = p1 = p2 = 0.0
+    else:
+        K = X @ sv.astype(np.float64).T
+        coeff /= np.float32(np.abs(K).mean())
+        p0 = p1 = p2 = 0.0
+    thr = np.full(n_filters, -1e30, np.float32)
+    alive = np.ones(len(feats), bool)
+    dist = np.full(len(feats), -float(bias))
+    for k in range(n_filters):
+        dist = dist + float(coeff[k * (k + 1) // 2 + k]) * K[:, k]
+        vals = dist[alive]
+        if alive.sum() * pass_rate >= min_survivors:
+            t = np.quantile(vals, 1.0 - pass_rate)
+            # keep the threshold away from any sample (fp64 exp differs by an ulp between libm and the device)
+            gaps = np.sort(vals)
+            j = np.searchsorted(gaps, t)
+            j = min(max(j, 1), len(gaps) - 1)
+            thr[k] = np.float32(0.5 * (gaps[j - 1] + gaps[j]))
+            alive &= dist >= thr[k]
+    return dict(kernel=kernel, p0=p0, p1=p1, p2=p2, filter_w=fw, filter_h=fh, sv=sv, coeff=coeff, thresholds=thr, bias=bias, num_used=0,
+                logistic_a=0.2, logistic_b=-1.5)
+
+
 def save_svm_text(path, m, rows=None, cols=None):
     """Text format of SvmClassifier::store + 'Logistic a b' (SvmClassifier.cpp:68-107, ProbabilisticSvmClassifier.cpp:65-68)."""
     sv = np.asarray(m["sv"])

@@ -218,6 +218,39 @@ int fd_extract_whi(fd_ctx* ctx, fd_pyramid* p, const fd_whi_params* wp, float* f
 int fd_detect_whi_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_whi_params* wp, fd_detection* out, int64_t cap,
                       int64_t* count, double* all_distance);
 
+/* ---- classification::RvmClassifier / ProbabilisticRvmClassifier -----------------
+ * Cascaded reduced-vector machine (RvmClassifier.cpp:75-126): level k evaluates kernel(x, rsv_k) on the whole
+ * vector; through the reference's cached path the running distance is d_0 = -bias + c[0][0] K_0,
+ * d_k = d_{k-1} + c[k][k] K_k; a vector leaves at the first level with d_k < thresholds[k]; positive iff the last
+ * used level is passed.  Probability = 1/(1+exp(a + b d)) for every vector (ProbabilisticRvmClassifier.cpp:62). */
+typedef struct fd_rvm fd_rvm;
+typedef struct {
+    int32_t kernel;                 /* FD_KERNEL_* (the reference's loader builds RBF or polynomial, RvmClassifier.cpp:196-204) */
+    double p0, p1, p2;              /* like fd_svm_model */
+    int32_t num_filters, num_used;  /* num_used: setNumFiltersToUse (0 or > num_filters: all) */
+    int32_t filter_w, filter_h;     /* reduced set vectors are filter_h x filter_w f32 images */
+    const float* support_vectors;   /* [num_filters][filter_w*filter_h] */
+    const float* coefficients;      /* lower triangle, coefficients[k][i] (i <= k) at k(k+1)/2 + i */
+    const float* thresholds;        /* [num_filters] hierarchicalThresholds */
+    float bias;
+    double logistic_a, logistic_b;
+} fd_rvm_model;
+int fd_rvm_create(fd_ctx* ctx, const fd_rvm_model* model, fd_rvm** out);
+void fd_rvm_destroy(fd_rvm* m);
+/* computeHyperplaneDistance (RvmClassifier.cpp:75-85) of n f32 vectors (host): last level and distance */
+int fd_rvm_eval_batch(fd_ctx* ctx, const fd_rvm* rvm, const float* features, int64_t n, int32_t* out_level, double* out_distance);
+/* u8 patch feature spaces of ffpDetectApp.cpp:446-461 */
+enum { FD_FEATURE_GRAY = 0, FD_FEATURE_HQ64 = 1, FD_FEATURE_HISTEQ = 2 };
+typedef struct {
+    int32_t feature_space;          /* FD_FEATURE_* */
+    float conv_scale, conv_shift;   /* ConversionFilter(CV_32F, scale, shift): x = float(u8) * scale + shift */
+    int32_t step_x, step_y;
+} fd_rvm_detect_params;
+/* SlidingWindowDetector::detect (SlidingWindowDetector.cpp:87-98) with a ProbabilisticRvmClassifier ("prvm",
+ * ffpDetectApp.cpp:484).  all_level / all_distance (may be NULL): per window in extraction order. */
+int fd_detect_rvm(fd_ctx* ctx, fd_pyramid* p, const fd_rvm* rvm, const fd_rvm_detect_params* dp, const int* roi, fd_detection* out,
+                  int64_t cap, int64_t* count, int32_t* all_level, double* all_distance);
+
 /* Throughput entry points used by bench.py: everything stays on the device, no host copies of
  * per-window data; *count = enumerated windows, *positives = classifier positives. */
 int fd_bench_hog_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_hog_params* hp, int64_t* count,

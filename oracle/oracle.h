@@ -97,6 +97,16 @@ int orc_svm_classify(const orc_svm* m, double dist);                            
 double orc_svm_probability(const orc_svm* m, double dist);                         /* ProbabilisticSvmClassifier.cpp:54-58 */
 void orc_svm_distance_batch(const orc_svm* m, const void* x, int64_t n, double* out);
 
+/* RvmClassifier (RvmClassifier.cpp:75-126) on f32 feature vectors; coeffPacked: coefficients[k][i] at k(k+1)/2 + i */
+typedef struct orc_rvm orc_rvm;
+orc_rvm* orc_rvm_create(int kernel, double p0, double p1, double p2, int numFilters, int numUse, int dim, const float* sv,
+                        const float* coeffPacked, const float* thresholds, float bias, double logisticA, double logisticB);
+void orc_rvm_destroy(orc_rvm* m);
+void orc_rvm_eval(const orc_rvm* m, const float* x, int32_t* lastLevel, double* distance);   /* computeHyperplaneDistance :75-85 */
+void orc_rvm_eval_batch(const orc_rvm* m, const float* x, int64_t n, int32_t* lastLevel, double* distance);
+int orc_rvm_classify(const orc_rvm* m, int lastLevel, double distance);                      /* :68-73 */
+double orc_rvm_probability(const orc_rvm* m, double distance);                               /* ProbabilisticRvmClassifier.cpp:62 */
+
 /* ---------------- detection ---------------- */
 typedef struct {
     int32_t cx, cy, w, h;     /* Patch centre/size in the original image (Patch.hpp) */

@@ -138,6 +138,35 @@ double Svm::distance(const void* x) const {
     return distance;
 }
 
+// RvmClassifier::computeHyperplaneDistance (RvmClassifier.cpp:75-85) through computeHyperplaneDistanceCached
+// (:94-112).  Note the quirk of the cached path, kept here: filterEvalCache is constructed with numFiltersToUse
+// elements (:78), level 0 clears it and computes -bias + c[0][0] K_0, and from then on `size == filterLevel`
+// holds, so level k only adds c[k][k] K_k to the level k-1 value (the off-diagonal coefficients c[k][i], i < k,
+// are never used unless numFiltersToUse == 1).
+void Rvm::eval(const float* x, int& lastLevel, double& distanceOut) const {
+    int filterLevel = -1;
+    double hyperplaneDistance = 0;
+    std::vector<double> cache((size_t)numUse);
+    do {
+        ++filterLevel;
+        if (cache.size() == (size_t)filterLevel && filterLevel != 0) {
+            double distance = cache[filterLevel - 1];
+            distance += coeff[(size_t)filterLevel * (filterLevel + 1) / 2 + filterLevel] * store.kernelValue(x, filterLevel);
+            cache.push_back(distance);
+            hyperplaneDistance = distance;
+        } else {
+            cache.clear();
+            double distance = -bias;
+            for (int i = 0; i <= filterLevel; ++i)
+                distance += coeff[(size_t)filterLevel * (filterLevel + 1) / 2 + i] * store.kernelValue(x, i);
+            cache.push_back(distance);
+            hyperplaneDistance = distance;
+        }
+    } while (hyperplaneDistance >= thresholds[filterLevel] && filterLevel + 1 < numUse);
+    lastLevel = filterLevel;
+    distanceOut = hyperplaneDistance;
+}
+
 }  // namespace orc
 
 using namespace orc;
@@ -188,4 +217,33 @@ void orc_svm_distance_batch(const orc_svm* m_, const void* x, int64_t n, double*
     size_t es = m->dtype == 0 ? 1 : 4;
     for (int64_t i = 0; i < n; ++i) out[i] = m->distance((const char*)x + (size_t)i * m->dim * es);
 }
+orc_rvm* orc_rvm_create(int kernel, double p0, double p1, double p2, int numFilters, int numUse, int dim, const float* sv,
+                        const float* coeffPacked, const float* thresholds, float bias, double la, double lb) {
+    Rvm* m = new Rvm();
+    m->store.kernel = kernel; m->store.p0 = p0; m->store.p1 = p1; m->store.p2 = p2;
+    m->store.nsv = numFilters; m->store.dim = dim; m->store.dtype = 1;
+    m->store.svF32.assign(sv, sv + (size_t)numFilters * dim);
+    m->coeff.assign(coeffPacked, coeffPacked + (size_t)numFilters * (numFilters + 1) / 2);
+    m->thresholds.assign(thresholds, thresholds + numFilters);
+    m->numFilters = numFilters;
+    m->numUse = (numUse == 0 || numUse > numFilters) ? numFilters : numUse;   // setNumFiltersToUse, RvmClassifier.cpp:119-126
+    m->bias = bias; m->logisticA = la; m->logisticB = lb;
+    return (orc_rvm*)m;
+}
+void orc_rvm_destroy(orc_rvm* m) { delete (Rvm*)m; }
+void orc_rvm_eval(const orc_rvm* m, const float* x, int32_t* lastLevel, double* distance) {
+    int l; double d;
+    ((const Rvm*)m)->eval(x, l, d);
+    *lastLevel = l; *distance = d;
+}
+void orc_rvm_eval_batch(const orc_rvm* m_, const float* x, int64_t n, int32_t* lastLevel, double* distance) {
+    const Rvm* m = (const Rvm*)m_;
+    for (int64_t i = 0; i < n; ++i) {
+        int l; double d;
+        m->eval(x + (size_t)i * m->store.dim, l, d);
+        lastLevel[i] = l; distance[i] = d;
+    }
+}
+int orc_rvm_classify(const orc_rvm* m, int lastLevel, double d) { return ((const Rvm*)m)->classify(lastLevel, d); }
+double orc_rvm_probability(const orc_rvm* m, double d) { return ((const Rvm*)m)->probability(d); }
 }

@@ -67,4 +67,17 @@ struct Svm {
     }
 };
 
+// RvmClassifier (RvmClassifier.cpp:75-110) + ProbabilisticRvmClassifier (ProbabilisticRvmClassifier.cpp:52-64)
+struct Rvm {
+    Svm store;                    // kernel + reduced set vectors (f32), reuses Svm::kernelValue
+    std::vector<float> coeff;     // packed lower triangle: coefficients[k][i] at k(k+1)/2 + i
+    std::vector<float> thresholds;
+    int numFilters, numUse;
+    float bias;
+    double logisticA, logisticB;
+    void eval(const float* x, int& lastLevel, double& distance) const;
+    bool classify(int lastLevel, double d) const { return lastLevel + 1 == numUse && d >= thresholds[lastLevel]; }
+    double probability(double d) const { return 1.0f / (1.0f + std::exp(logisticA + logisticB * d)); }
+};
+
 }  // namespace orc

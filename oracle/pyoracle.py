@@ -338,6 +338,47 @@ class Svm:
         return lib().orc_svm_probability(self.h, float(d))
 
 
+class Rvm:
+    """RvmClassifier / ProbabilisticRvmClassifier (RvmClassifier.cpp:75-126); model dict as featuredetection_amd.synth.make_rvm"""
+    def __init__(self, m):
+        self.model = m
+        self.sv = _c(m["sv"], np.float32)
+        self.coeff = _c(m["coeff"], np.float32)
+        self.thr = _c(m["thresholds"], np.float32)
+        F, self.dim = self.sv.shape
+        assert self.coeff.size == F * (F + 1) // 2
+        l = lib()
+        l.orc_rvm_create.restype = C.c_void_p
+        l.orc_rvm_create.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_float, C.c_double, C.c_double]
+        l.orc_rvm_eval_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        l.orc_rvm_probability.restype = C.c_double
+        l.orc_rvm_probability.argtypes = [C.c_void_p, C.c_double]
+        l.orc_rvm_classify.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        l.orc_rvm_destroy.argtypes = [C.c_void_p]
+        self.h = l.orc_rvm_create(int(m["kernel"]), float(m.get("p0", 0)), float(m.get("p1", 0)), float(m.get("p2", 0)), F,
+                                  int(m.get("num_used", 0)), self.dim, _p(self.sv), _p(self.coeff), _p(self.thr), float(m["bias"]),
+                                  float(m.get("logistic_a", 0.0)), float(m.get("logistic_b", -1.0)))
+
+    def eval(self, feats):
+        feats = _c(feats, np.float32).reshape(-1, self.dim)
+        lv = np.empty(len(feats), np.int32)
+        d = np.empty(len(feats), np.float64)
+        lib().orc_rvm_eval_batch(self.h, _p(feats), len(feats), _p(lv), _p(d))
+        return lv, d
+
+    def classify(self, level, d):
+        return bool(lib().orc_rvm_classify(self.h, int(level), float(d)))
+
+    def probability(self, d):
+        return lib().orc_rvm_probability(self.h, float(d))
+
+    def close(self):
+        if self.h:
+            lib().orc_rvm_destroy(self.h)
+            self.h = None
+
+
 def sliding_wvm(pyr, wvm, sx=1, sy=1, roi=None, want_all=True):
     wins = pyr.windows(wvm.model["filter_w"], wvm.model["filter_h"], sx, sy, roi)
     n = len(wins)

@@ -401,6 +401,59 @@ def test_whi_chain_and_histeq(oracle, capi, ctx, frame640):
     sg.close(); pg.close(); po.close()
 
 
+@pytest.mark.parametrize("kernel", [2, 1, 3, 0])
+def test_rvm_eval_batch_matches_oracle(oracle, capi, ctx, synth, kernel):
+    """fd_rvm_eval_batch (per-Mat API of RvmClassifier): last level identical, fp64 distance to the last bits
+    (the device exp may differ from libm by an ulp of fp64)."""
+    rng = np.random.default_rng(31 + kernel)
+    feats = (rng.integers(0, 256, (3000, 20 * 20)).astype(np.float32)) * np.float32(1.0 / 255.0)
+    feats += (rng.random(feats.shape) * 0.01).astype(np.float32)
+    m = synth.make_rvm(7 + kernel, feats[:1500], 20, 20, n_filters=40, kernel=kernel)
+    ro, rg = oracle.Rvm(m), capi.Rvm(ctx, m)
+    lo, do = ro.eval(feats)
+    lg, dg = rg.eval(feats)
+    assert np.array_equal(lg, lo)
+    assert np.allclose(dg, do, rtol=1e-12, atol=1e-300)
+    assert (lo == 39).sum() > 0 and (lo < 3).sum() > len(feats) // 3
+    m2 = dict(m, num_used=5)
+    lo2, _ = oracle.Rvm(m2).eval(feats)
+    r2 = capi.Rvm(ctx, m2)
+    lg2, _ = r2.eval(feats)
+    assert np.array_equal(lg2, lo2) and lo2.max() == 4
+    rg.close(); r2.close(); ro.close()
+
+
+@pytest.mark.parametrize("space,scale,shift,pw,ph", [(1, 1.0, 0.0, 20, 20), (0, 1.0 / 255.0, 0.0, 24, 24), (2, 0.5, -3.0, 16, 24), (1, 1.0, 0.0, 19, 21)])
+def test_rvm_sliding_window_detector(oracle, capi, ctx, synth, frame640, space, scale, shift, pw, ph):
+    """SlidingWindowDetector + ProbabilisticRvmClassifier ("prvm") on the gray / hq64 / histeq feature spaces followed by
+    ConversionFilter(CV_32F, scale, shift): every window's last level identical, distances to 1e-12, same detections."""
+    kw = dict(octave_layers=2, min_scale=0.2, max_scale=0.4)
+    small = np.ascontiguousarray(frame640[:240, :320])
+    po = oracle.Pyramid(**kw); po.update(small)
+    pg = capi.Pyramid(ctx, **kw); pg.update(small)
+    layers = [po.layer(i) for i in range(len(po.layers()))]
+    wins = po.windows(pw, ph, 2, 2)
+    pat = np.stack([np.ascontiguousarray(layers[lp][ly:ly + ph, lx:lx + pw]) for lp, lx, ly, *_ in wins])
+    if space == 1:
+        pat = np.stack([oracle.histeq64(p_) for p_ in pat])
+    elif space == 2:
+        pat = np.stack([oracle.equalize_hist(p_) for p_ in pat])
+    feats = pat.reshape(len(pat), -1).astype(np.float32) * np.float32(scale) + np.float32(shift)
+    m = synth.make_rvm(3, feats[::3], pw, ph, n_filters=30, kernel=2)
+    ro, rg = oracle.Rvm(m), capi.Rvm(ctx, m)
+    lo, do = ro.eval(feats)
+    dets, lg, dg = capi.detect_rvm(ctx, pg, rg, feature_space=space, conv_scale=scale, conv_shift=shift, sx=2, sy=2)
+    assert len(lg) == len(lo) > 1000
+    assert np.array_equal(lg, lo)
+    assert np.allclose(dg, do, rtol=1e-12, atol=1e-300)
+    pos = np.nonzero((lo == 29) & (do >= m["thresholds"][29]))[0]
+    assert len(dets) == len(pos) > 0
+    for dt, i in zip(dets, pos):
+        assert (int(dt["layer"]), int(dt["lx"]), int(dt["ly"]), int(dt["cx"]), int(dt["cy"]), int(dt["w"]), int(dt["h"])) == tuple(int(v) for v in wins[i])
+        assert abs(dt["probability"] - ro.probability(do[i])) <= 1e-12
+    rg.close(); pg.close(); po.close(); ro.close()
+
+
 def test_hog_rbf_svm_detector_config2(oracle, capi, ctx, synth):
     """BASELINE config 2 shape on a reduced frame: HOG-324 + RBF SVM (MFMA path).  Scores within
     1e-4 relative (of the natural scale sum|coeff_i| K_i), positives identical away from the threshold."""

@@ -201,3 +201,38 @@ def test_whi_chain_against_numpy_fft(oracle):
             flips += int(bad.sum()); total += bad.size
     # a whitened value within float rounding of .5 may round the other way; anything systematic would show up everywhere
     assert flips <= total // 500
+
+
+def test_rvm_cascade_restatement(oracle, synth):
+    """RvmClassifier through the cached evaluation path (RvmClassifier.cpp:94-112): d_0 = -bias + c00 K_0,
+    d_k = d_{k-1} + c_kk K_k (the off-diagonal coefficients are never used), against a direct numpy restatement;
+    kernels via the SVM oracle (itself pinned against libsvm)."""
+    rng = np.random.default_rng(21)
+    feats = (rng.integers(0, 256, (400, 16 * 12)).astype(np.float32)) * np.float32(0.5)
+    for kernel in (2, 1, 3, 0):
+        m = synth.make_rvm(5 + kernel, feats, 16, 12, n_filters=10, kernel=kernel)
+        r = oracle.Rvm(m)
+        lv, d = r.eval(feats)
+        # kernel values from the (libsvm-pinned) SVM oracle: one "SVM" per reduced set vector with coefficient 1, bias 0
+        K = np.empty((len(feats), 10))
+        for k in range(10):
+            s = oracle.Svm(dict(kernel=kernel, dtype=1, sv=m["sv"][k:k + 1], coeff=np.ones(1, np.float32), bias=np.float32(0), p0=m["p0"], p1=m["p1"],
+                                p2=m["p2"], threshold=0.0))
+            K[:, k] = s.distance(feats)
+        for i in range(len(feats)):
+            dist, k = -float(m["bias"]), -1
+            while True:
+                k += 1
+                dist = dist + float(m["coeff"][k * (k + 1) // 2 + k]) * K[i, k]
+                if not (dist >= float(m["thresholds"][k]) and k + 1 < 10):
+                    break
+            assert lv[i] == k and d[i] == dist
+        assert 0 < (lv == 9).sum() < len(feats)      # the calibrated cascade lets some vectors through and rejects most
+        assert r.classify(9, float(m["thresholds"][9]) + 1) and not r.classify(8, 1e9)
+        assert r.probability(0.3) == 1.0 / (1.0 + np.exp(m["logistic_a"] + m["logistic_b"] * 0.3))
+        r.close()
+    # setNumFiltersToUse (RvmClassifier.cpp:119-126)
+    m = synth.make_rvm(1, feats, 16, 12, n_filters=6)
+    m["num_used"] = 3
+    lv, _ = oracle.Rvm(m).eval(feats)
+    assert lv.max() == 2
