@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <fstream>
 #include <iostream>
+#include <sstream>
 #include <unordered_map>
 #include "detection/detection_all.hpp"
 
@@ -75,11 +76,24 @@ int main(int argc, char** argv) {
                 } else if (featurespace != "gray") {
                     throw std::invalid_argument("unknown feature space " + featurespace);
                 }
+                if (node.count("patchFilter")) {   // ffpDetectApp.cpp:462-476
+                    for (const auto& filterNode : node.get_child("patchFilter")) {
+                        if (filterNode.first == "conversionFilter") {
+                            std::stringstream ss(filterNode.second.get_value<string>());
+                            int type; double scaling;
+                            ss >> type >> scaling;
+                            featureExtractor->addPatchFilter(make_shared<ConversionFilter>(type, scaling));
+                        } else {
+                            throw std::invalid_argument("unknown patch filter " + filterNode.first);   // reshapingFilter: a no-op for contiguous patches
+                        }
+                    }
+                }
                 const ptree& classifierNode = node.get_child("classifier");
                 const string classifierType = classifierNode.get_value<string>();
                 shared_ptr<ProbabilisticClassifier> classifier;
                 if (classifierType == "psvm") classifier = ProbabilisticSvmClassifier::load(classifierNode);
-                else classifier = ProbabilisticWvmClassifier::load(classifierNode);   // "pwvm" (prvm: SURVEY 8(f), not on this backend)
+                else if (classifierType == "prvm") classifier = ProbabilisticRvmClassifier::load(classifierNode);
+                else classifier = ProbabilisticWvmClassifier::load(classifierNode);   // "pwvm"
                 det = make_shared<SlidingWindowDetector>(classifier, featureExtractor);
             } else {
                 throw std::invalid_argument("unknown detector type " + type);

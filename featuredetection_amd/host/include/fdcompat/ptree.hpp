@@ -28,6 +28,11 @@ public:
     const_iterator begin() const { return children.begin(); }
     const_iterator end() const { return children.end(); }
     bool empty() const { return children.empty(); }
+    size_t count(const std::string& key) const {
+        size_t n = 0;
+        for (const auto& c : children) n += c.first == key;
+        return n;
+    }
 
     const ptree* find(const std::string& path) const {
         const ptree* cur = this;

@@ -340,6 +340,10 @@ public:
     std::shared_ptr<HistogramFilter> getHistogramFilter() const { return hist; }
     // complete whi chain (WhiteningFilter, HistogramEqualizationFilter, ConversionFilter(CV_32F, 1/127.5, -1), UnitNormFilter(L2))
     std::shared_ptr<WhiteningFilter> getWhiChain() const { return whiStage == 4 ? whitening : nullptr; }
+    // u8 feature space (0 gray, 1 hq64 = HistEq64Filter, 2 histeq = HistogramEqualizationFilter) followed by a
+    // ConversionFilter(CV_32F, scale, shift): the input of a ProbabilisticRvmClassifier (fd_detect_rvm)
+    std::shared_ptr<ConversionFilter> getConversion() const { return whiStage == 0 ? conversion : nullptr; }
+    int getU8FeatureSpace() const { return histeq ? 1 : (equalization ? 2 : 0); }
 private:
     std::shared_ptr<Patch> extractFromLayer(const ImagePyramidLayer& layer, cv::Rect bounds) const;
     std::shared_ptr<ImagePyramid> pyramid;
@@ -349,6 +353,7 @@ private:
     std::shared_ptr<HistogramFilter> hist;
     std::shared_ptr<WhiteningFilter> whitening;
     std::shared_ptr<HistogramEqualizationFilter> equalization;
+    std::shared_ptr<ConversionFilter> conversion;
     int whiStage = 0;   // number of whi chain filters added so far (in order)
 };
 

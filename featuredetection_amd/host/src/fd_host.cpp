@@ -262,8 +262,13 @@ void DirectPyramidFeatureExtractor::addPatchFilter(shared_ptr<ImageFilter> filte
         equalization = ef;
         if (whiStage == 1) whiStage = 2;
     } else if (auto cf = std::dynamic_pointer_cast<ConversionFilter>(filter)) {
+        if (whiStage == 0 && !hist && cf->type == CV_32F) {   // u8 feature space -> f32 (input of an RVM / f32 SVM)
+            conversion = cf;
+            return;
+        }
         if (whiStage != 2 || cf->type != CV_32F || cf->alpha != 1.0 / 127.5 || cf->beta != -1.0)
-            throw std::logic_error("DirectPyramidFeatureExtractor: ConversionFilter is available as ConversionFilter(CV_32F, 1.0/127.5, -1.0) inside the whi chain only");
+            throw std::logic_error("DirectPyramidFeatureExtractor: ConversionFilter is available as ConversionFilter(CV_32F, alpha, beta) after a u8 "
+                                   "feature space, or as ConversionFilter(CV_32F, 1.0/127.5, -1.0) inside the whi chain");
         whiStage = 3;
     } else if (auto uf = std::dynamic_pointer_cast<UnitNormFilter>(filter)) {
         if (whiStage != 3 || uf->normType != cv::NORM_L2)
@@ -383,6 +388,15 @@ vector<shared_ptr<Patch>> DirectPyramidFeatureExtractor::extract(int stepX, int 
     }
     for (int64_t i = 0; i < n; ++i) {
         const int32_t* w = &wins[7 * i];
+        if (conversion) {   // cv::Mat::convertTo(CV_32F, alpha, beta): float(u8) * float(alpha) + float(beta)
+            Mat data(patchHeight, patchWidth, CV_32FC1);
+            const uchar* srcp = eq.ptr<uchar>((int)i);
+            float* dstp = data.ptr<float>(0);
+            const float a = (float)conversion->alpha, b = (float)conversion->beta;
+            for (int k = 0; k < d; ++k) dstp[k] = (float)srcp[k] * a + b;
+            patches.push_back(make_shared<Patch>(w[3], w[4], w[5], w[6], data));
+            continue;
+        }
         Mat data(patchHeight, patchWidth, CV_8UC1);
         std::memcpy(data.data, eq.ptr<uchar>((int)i), d);
         patches.push_back(make_shared<Patch>(w[3], w[4], w[5], w[6], data));
@@ -646,6 +660,97 @@ shared_ptr<WvmClassifier> WvmClassifier::loadFromFile(const string& filename) {
     return wvm;
 }
 
+// ---- RVM ------------------------------------------------------------------------------------------
+RvmClassifier::RvmClassifier(shared_ptr<Kernel> kernel, bool) : VectorMachineClassifier(kernel) {}
+RvmClassifier::~RvmClassifier() { fd_rvm_destroy(handle); }
+void RvmClassifier::setNumFiltersToUse(unsigned int numFilters) {   // RvmClassifier.cpp:119-126
+    numFiltersToUse = (numFilters == 0 || numFilters > (unsigned int)model.num_filters) ? (unsigned int)model.num_filters : numFilters;
+    dirty = true;
+}
+const fd_rvm* RvmClassifier::native(double la, double lb) const {
+    if (dirty || !handle || la != builtA || lb != builtB) {
+        fd_rvm_destroy(handle);
+        handle = nullptr;
+        fd_rvm_model m;
+        std::memset(&m, 0, sizeof(m));
+        m.kernel = model.kernel; m.p0 = model.p0; m.p1 = model.p1; m.p2 = model.p2;
+        m.num_filters = model.num_filters; m.num_used = (int)numFiltersToUse; m.filter_w = model.filter_w; m.filter_h = model.filter_h;
+        m.support_vectors = model.support_vectors.data(); m.coefficients = model.coefficients.data(); m.thresholds = model.thresholds.data();
+        m.bias = model.bias; m.logistic_a = la; m.logistic_b = lb;
+        check(fd_rvm_create(context(), &m, &handle));
+        dirty = false; builtA = la; builtB = lb;
+    }
+    return handle;
+}
+std::pair<int, double> RvmClassifier::computeHyperplaneDistance(const Mat& featureVector) const {
+    if (featureVector.depth() != CV_32F || (int)(featureVector.total() * featureVector.channels()) != model.filter_w * model.filter_h)
+        throw std::invalid_argument("RbfKernel: arguments have to have the same type");   // Kernel::compute contract (RbfKernel.hpp:35-38)
+    Mat x = contiguous(featureVector);
+    int32_t level = 0;
+    double dist = 0;
+    check(fd_rvm_eval_batch(context(), native(), x.ptr<float>(0), 1, &level, &dist));
+    return std::make_pair((int)level, dist);
+}
+bool RvmClassifier::classify(std::pair<int, double> lad) const {   // RvmClassifier.cpp:66-73
+    return lad.first + 1 == (int)numFiltersToUse && lad.second >= model.thresholds[lad.first];
+}
+bool RvmClassifier::classify(const Mat& featureVector) const { return classify(computeHyperplaneDistance(featureVector)); }
+std::pair<bool, double> RvmClassifier::getConfidence(std::pair<int, double> lad) const {
+    return classify(lad) ? std::make_pair(true, lad.second) : std::make_pair(false, -lad.second);
+}
+std::pair<bool, double> RvmClassifier::getConfidence(const Mat& featureVector) const { return getConfidence(computeHyperplaneDistance(featureVector)); }
+shared_ptr<RvmClassifier> RvmClassifier::loadFromFile(const string& filename) {
+    std::ifstream f(filename.c_str(), std::ios::binary);
+    if (!f.is_open()) throw std::invalid_argument("RvmClassifier: Could not open the provided classifier filename: " + filename);
+    char magic[8];
+    f.read(magic, 8);
+    if (std::memcmp(magic, "FDRVM1\0\0", 8) != 0) throw std::runtime_error("RvmClassifier: not a FDRVM1 model file: " + filename);
+    int32_t hdr[5];
+    double prm[3];
+    Model m;
+    f.read((char*)hdr, sizeof(hdr));
+    f.read((char*)prm, sizeof(prm));
+    f.read((char*)&m.bias, 4);
+    m.kernel = hdr[0]; m.filter_w = hdr[1]; m.filter_h = hdr[2]; m.num_filters = hdr[3];
+    m.p0 = prm[0]; m.p1 = prm[1]; m.p2 = prm[2];
+    const int F = m.num_filters, dim = m.filter_w * m.filter_h;
+    if (F < 1 || dim < 1 || m.kernel < 0 || m.kernel > 3) throw std::runtime_error("RvmClassifier: corrupt model header");
+    m.support_vectors.resize((size_t)F * dim); m.coefficients.resize((size_t)F * (F + 1) / 2); m.thresholds.resize(F);
+    f.read((char*)m.support_vectors.data(), 4 * m.support_vectors.size());
+    f.read((char*)m.coefficients.data(), 4 * m.coefficients.size());
+    f.read((char*)m.thresholds.data(), 4 * (size_t)F);
+    if (!f) throw std::runtime_error("RvmClassifier: truncated model file: " + filename);
+    shared_ptr<Kernel> kernel;
+    if (m.kernel == FD_KERNEL_RBF) kernel = make_shared<RbfKernel>(m.p0);
+    else if (m.kernel == FD_KERNEL_POLY) kernel = make_shared<PolynomialKernel>(m.p0, m.p1, (int)m.p2);
+    else if (m.kernel == FD_KERNEL_HIK) kernel = make_shared<HistogramIntersectionKernel>();
+    else kernel = make_shared<LinearKernel>();
+    auto rvm = make_shared<RvmClassifier>(kernel);
+    rvm->model = m;
+    rvm->bias = m.bias;
+    rvm->setNumFiltersToUse((unsigned int)hdr[4]);
+    return rvm;
+}
+shared_ptr<RvmClassifier> RvmClassifier::load(const boost::property_tree::ptree& subtree) {
+    string classifierFile = subtree.get<string>("classifierFile");
+    if (classifierFile.size() > 4 && classifierFile.substr(classifierFile.size() - 4) == ".mat")
+        throw std::runtime_error("RvmClassifier: Cannot load a Matlab classifier (the reference needs libmat; this backend reads the FDRVM1 format)");
+    return loadFromFile(classifierFile);
+}
+std::pair<bool, double> ProbabilisticRvmClassifier::getProbability(const Mat& featureVector) const {
+    return getProbability(rvm->computeHyperplaneDistance(featureVector));
+}
+std::pair<bool, double> ProbabilisticRvmClassifier::getProbability(std::pair<int, double> lad) const {   // ProbabilisticRvmClassifier.cpp:62
+    double probability = 1.0f / (1.0f + std::exp(logisticA + logisticB * lad.second));
+    return std::make_pair(rvm->classify(lad), probability);
+}
+shared_ptr<ProbabilisticRvmClassifier> ProbabilisticRvmClassifier::load(const boost::property_tree::ptree& subtree) {
+    auto rvm = RvmClassifier::load(subtree);
+    auto prvm = make_shared<ProbabilisticRvmClassifier>(rvm, subtree.get("logisticA", 0.00556), subtree.get("logisticB", -2.95));
+    if (int nf = subtree.get("numFiltersToUse", 0)) rvm->setNumFiltersToUse((unsigned int)nf);
+    return prvm;
+}
+
 std::pair<bool, double> ProbabilisticWvmClassifier::getProbability(const Mat& featureVector) const {
     return getProbability(wvm->computeHyperplaneDistance(featureVector));
 }
@@ -730,6 +835,22 @@ vector<shared_ptr<ClassifiedPatch>> SlidingWindowDetector::detect(const cv::Rect
         if (rc == FD_ERR_CAPACITY) {
             dets.resize((size_t)cnt);
             rc = fd_detect_hog_svm(context(), direct->getPyramid()->native(), s, &hp, dets.data(), cnt, &cnt, nullptr);
+        }
+        check(rc);
+        for (int64_t i = 0; i < cnt; ++i) out.push_back(to_patch(dets[i]));
+        return out;
+    }
+    auto prvm = std::dynamic_pointer_cast<classification::ProbabilisticRvmClassifier>(classifier);
+    if (direct && prvm && direct->getConversion() && !direct->getHistogramFilter() && !direct->getWhiChain()) {   // fused RVM cascade ("prvm")
+        auto cf = direct->getConversion();
+        fd_rvm_detect_params dp = {direct->getU8FeatureSpace(), (float)cf->alpha, (float)cf->beta, stepSizeX, stepSizeY};
+        const fd_rvm* rv = prvm->getRvm()->native(prvm->getLogisticA(), prvm->getLogisticB());
+        int64_t cnt = 0, cap = 1 << 16;
+        vector<fd_detection> dets((size_t)cap);
+        int rc = fd_detect_rvm(context(), direct->getPyramid()->native(), rv, &dp, roi ? r : nullptr, dets.data(), cap, &cnt, nullptr, nullptr);
+        if (rc == FD_ERR_CAPACITY) {
+            dets.resize((size_t)cnt);
+            rc = fd_detect_rvm(context(), direct->getPyramid()->native(), rv, &dp, roi ? r : nullptr, dets.data(), cnt, &cnt, nullptr, nullptr);
         }
         check(rc);
         for (int64_t i = 0; i < cnt; ++i) out.push_back(to_patch(dets[i]));

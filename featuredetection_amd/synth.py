@@ -277,6 +277,20 @@ def make_rvm(seed, feats, fw, fh, n_filters=24, kernel=2, gamma=None, pass_rate=
                 logistic_a=0.2, logistic_b=-1.5)
 
 
+def save_rvm(path, m):
+    """Binary FDRVM1 file (RvmClassifier::loadFromFile of the host layer): the reference's Matlab .mat models are absent."""
+    import struct
+    sv = np.ascontiguousarray(m["sv"], np.float32)
+    with open(path, "wb") as f:
+        f.write(b"FDRVM1\0\0")
+        f.write(struct.pack("<5i", int(m["kernel"]), int(m["filter_w"]), int(m["filter_h"]), sv.shape[0], int(m.get("num_used", 0))))
+        f.write(struct.pack("<3d", float(m.get("p0", 0)), float(m.get("p1", 0)), float(m.get("p2", 0))))
+        f.write(struct.pack("<f", float(m["bias"])))
+        f.write(sv.tobytes())
+        f.write(np.ascontiguousarray(m["coeff"], np.float32).tobytes())
+        f.write(np.ascontiguousarray(m["thresholds"], np.float32).tobytes())
+
+
 def save_svm_text(path, m, rows=None, cols=None):
     """Text format of SvmClassifier::store + 'Logistic a b' (SvmClassifier.cpp:68-107, ProbabilisticSvmClassifier.cpp:65-68)."""
     sv = np.asarray(m["sv"])

@@ -160,3 +160,65 @@ def test_sdm_fit_app_matches_oracle(tmp_path, oracle, synth):
     st, ref = oracle.sdm_fit(gray, model, [30, 25, 120, 130])
     assert st == 0 and got.shape == ref.shape
     assert np.allclose(got, ref, rtol=1e-4, atol=1e-4), np.abs(got - ref).max()
+
+
+def test_ffp_detect_app_prvm_single_detector(tmp_path, oracle, synth, frame640):
+    """type "single" with classifier "prvm" (ffpDetectApp.cpp:427-500): hq64 feature space + conversionFilter patch
+    filter + ProbabilisticRvmClassifier, through the C++ mirror classes and fd_detect_rvm."""
+    app = os.path.join(PKG, "ffp_detect_app")
+    if not os.path.exists(app):
+        pytest.fail("host apps not built (make -C featuredetection_amd/host)")
+    small = np.ascontiguousarray(frame640[:240, :320])
+    po = oracle.Pyramid(inc=float(np.float32(0.7071)), min_scale=float(np.float32(0.2)), max_scale=float(np.float32(0.4)))
+    po.update(small)
+    layers = [po.layer(i) for i in range(len(po.layers()))]
+    wins = po.windows(20, 20, 1, 1)
+    pat = np.stack([oracle.histeq64(np.ascontiguousarray(layers[lp][ly:ly + 20, lx:lx + 20])) for lp, lx, ly, *_ in wins])
+    scale = 0.25
+    feats = pat.reshape(len(pat), -1).astype(np.float32) * np.float32(scale)
+    m = synth.make_rvm(12, feats[::4], 20, 20, n_filters=20, kernel=2)
+    m["logistic_a"], m["logistic_b"] = 0.4, -2.0
+    synth.save_rvm(str(tmp_path / "c.fdrvm"), m)
+    synth.save_pnm(str(tmp_path / "frame.ppm"), small)
+    cfg = """detectors
+{
+    Face
+    {
+        landmark "face"
+        type single
+        feature hq64
+        patchFilter
+        {
+            conversionFilter "5 0.25"
+        }
+        classifier prvm
+        {
+            classifierFile %s
+            logisticA 0.4
+            logisticB -2.0
+        }
+        pyramid
+        {
+            minScaleFactor 0.2
+            maxScaleFactor 0.4
+            incrementalScaleFactor 0.7071
+            patch
+            {
+                width 20
+                height 20
+            }
+        }
+    }
+}
+""" % (tmp_path / "c.fdrvm")
+    (tmp_path / "c.cfg").write_text(cfg)
+    out = _run([app, str(tmp_path / "c.cfg"), str(tmp_path / "frame.ppm")])
+    got = [l.split() for l in out.strip().splitlines()]
+    ro = oracle.Rvm(m)
+    lv, dd = ro.eval(feats)
+    pos = np.nonzero((lv == 19) & (dd >= m["thresholds"][19]))[0]
+    assert len(got) == len(pos) > 0
+    for g, i in zip(got, pos):
+        lp, lx, ly, cx, cy, ow, oh = [int(v) for v in wins[i]]
+        assert [int(v) for v in g[2:6]] == [cx - ow // 2, cy - oh // 2, ow, oh]
+        assert abs(float(g[6]) - ro.probability(dd[i])) <= 1e-9
