@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="hog_svm", choices=["hog_svm", "wvm", "sdm"])
+    ap.add_argument("--workload", default="hog_svm", choices=["hog_svm", "wvm", "ffp15", "sdm"])
     ap.add_argument("--gather-every", type=int, default=8)
     ap.add_argument("--size", default="640x480", help="frame size WxH for the hog_svm / wvm workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -151,6 +151,41 @@ def main():
                                "WVM 280 filters -> OE -> RBF-SVM 1024 SV -> NMS" % (W, H, len(pyr.layers()), nwin_wvm),
                       frames_per_step=1, parallelism="image-shard dp%d" % world)
         dtype = "u8/f32/f64"
+    elif args.workload == "ffp15":
+        # BASELINE config 2/4 shape: all 15 detectors of ffpDetectApp/*.cfg full-frame (32.1 M windows
+        # per 1080p frame).  Detectors with identical pyramid parameters share one pyramid (identical layers).
+        W, H = (FW, FH) if args.size != "640x480" else (1920, 1080)
+        frames = [synth.make_frame(W, H, seed=20260927 + 1000 * rank + i) for i in range(2)]
+        dframes = [torch.from_numpy(f).to(dev) for f in frames]
+        from oracle import pyoracle as O  # calibration patches only
+        gray = O.bgr2gray(synth.make_frame(640, 480, seed=20260927))
+        pyrs, dets = {}, []
+        for di, (name, (inc, mn, mx, pw, ph, nper, nlev)) in enumerate(sorted(synth.DETECTOR_CFGS.items())):
+            key = (inc, mn, mx)
+            if key not in pyrs:
+                pyrs[key] = capi.Pyramid(ctx, inc=float(np.float32(inc)), min_scale=float(np.float32(mn)), max_scale=float(np.float32(mx)))
+            src = gray[::4, ::4] if mx < 0.3 else gray[::2, ::2]
+            calib = synth.random_patches(src.copy(), pw, ph, 6000, np.random.default_rng(100 + di))
+            wm = synth.make_wvm(50 + di, fw=pw, fh=ph, n_per=nper, n_levels=nlev, calib_patches=calib, min_survivors=24)
+            eq = synth.histeq64_np(synth.random_patches(src.copy(), pw, ph, 700, np.random.default_rng(200 + di)))
+            sm = synth.make_svm_u8(300 + di, eq, nsv=512, calib=eq[512:])
+            dets.append((name, pyrs[key], capi.Wvm(ctx, wm), capi.Svm(ctx, sm), pw, ph))
+        for pr in pyrs.values():
+            pr.update(frames[0])
+        nwin_all = sum(pr.window_count(pw, ph, 1, 1) for _, pr, _, _, pw, ph in dets)
+
+        def step(i, sync=True):
+            f = dframes[i % 2]
+            for pr in pyrs.values():
+                pr.update_device(f.data_ptr(), W, H, 3)
+            res = capi.detect_five_stage_batch(ctx, [(pr, wv, sv_) for _, pr, wv, sv_, _, _ in dets], cap=1 << 16)
+            return nwin_all, sum(len(d_) for d_, _ in res)
+
+        units_name = "windows"
+        config = dict(workload="config 3: the 15 detectors of ffpDetectApp/*.cfg (five-stage WVM -> OE -> SVM -> NMS each), full %dx%d frame, "
+                               "step 1: %d windows per frame; %d shared pyramids" % (W, H, nwin_all, len(pyrs)),
+                      frames_per_step=1, parallelism="image-shard dp%d" % world)
+        dtype = "u8/f32/f64"
     else:
         B, W, H = 256, 256, 256
         imgs = np.stack([synth.make_frame(W, H, seed=9000 + 1000 * rank + i, channels=1) for i in range(16)])
@@ -214,7 +249,7 @@ def main():
     if rank == 0:
         value = total_units / dt / 1e6
         res = dict(metric="Mpatches/s (extract+HOG+RBF-SVM), 640x480 pyramid" if args.workload == "hog_svm" else
-                   ("Mpatches/s (extract+WVM+SVM cascade), %dx%d pyramid" % (FW, FH) if args.workload == "wvm" else "SDM iters/s (x1e6)"),
+                   ("Mpatches/s (extract+WVM+SVM cascade), %dx%d pyramid" % (W, H) if args.workload in ("wvm", "ffp15") else "SDM iters/s (x1e6)"),
                    value=value, unit="Mpatches/s" if args.workload != "sdm" else "M SDM iters/s", n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype=dtype, data="synthetic", config=config)

@@ -72,6 +72,12 @@ class fd_whi_params(C.Structure):
                 ("cutoff", C.c_float)]
 
 
+class fd_five_stage_job(C.Structure):
+    _fields_ = [("pyramid", C.c_void_p), ("wvm", C.c_void_p), ("svm", C.c_void_p), ("oe_dist", C.c_float), ("oe_ratio", C.c_float),
+                ("step_x", C.c_int32), ("step_y", C.c_int32), ("roi", C.c_void_p), ("out", C.c_void_p), ("cap", C.c_int32),
+                ("count", C.c_int32), ("stage_counts", C.c_int32 * 4), ("status", C.c_int32)]
+
+
 class fd_rvm_model(C.Structure):
     _fields_ = [("kernel", C.c_int32), ("p0", C.c_double), ("p1", C.c_double), ("p2", C.c_double), ("num_filters", C.c_int32),
                 ("num_used", C.c_int32), ("filter_w", C.c_int32), ("filter_h", C.c_int32), ("support_vectors", C.c_void_p),
@@ -133,6 +139,7 @@ _SIGS = {
     "fd_extract_whi": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fd_whi_params), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "fd_detect_whi_svm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(fd_whi_params), C.c_void_p, C.c_int64,
                                     C.POINTER(C.c_int64), C.c_void_p]),
+    "fd_detect_five_stage_batch": (C.c_int, [C.c_void_p, C.POINTER(fd_five_stage_job), C.c_int]),
     "fd_rvm_create": (C.c_int, [C.c_void_p, C.POINTER(fd_rvm_model), C.POINTER(C.c_void_p)]),
     "fd_rvm_destroy": (None, [C.c_void_p]),
     "fd_rvm_eval_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -383,6 +390,19 @@ def detect_five_stage(ctx, pyr, wvm, svm, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1,
     ctx.check(lib().fd_detect_five_stage(ctx.h, pyr.h, wvm.h, svm.h, oe_dist, oe_ratio, sx, sy, _ptr(r), _ptr(out), cap,
                                          C.byref(cnt), _ptr(stages)))
     return out[:cnt.value], stages
+
+
+def detect_five_stage_batch(ctx, detectors, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1, cap=4096):
+    """detectors: list of (pyramid, wvm, svm); returns [(detections, stage_counts)] in the same order"""
+    n = len(detectors)
+    jobs = (fd_five_stage_job * n)()
+    outs = [np.zeros(cap, DET_DTYPE) for _ in range(n)]
+    for j, (pyr, wvm, svm), o in zip(jobs, detectors, outs):
+        j.pyramid, j.wvm, j.svm = pyr.h, wvm.h, svm.h
+        j.oe_dist, j.oe_ratio, j.step_x, j.step_y, j.roi = oe_dist, oe_ratio, sx, sy, None
+        j.out, j.cap = o.ctypes.data, cap
+    ctx.check(lib().fd_detect_five_stage_batch(ctx.h, jobs, n))
+    return [(o[:j.count], np.array(list(j.stage_counts), np.int32)) for j, o in zip(jobs, outs)]
 
 
 def overlap_elimination(dets, dist, ratio):

@@ -24,6 +24,7 @@ struct fd_ctx {
     float last_kernel_ms = 0.f;
     int num_cus = 256;
     FdPinned pinned;
+    hipStream_t aux = nullptr;   // second stream (created on first use): small follow-up work that must not queue behind ctx->stream
 };
 
 struct FdError {
@@ -110,6 +111,11 @@ static inline void* fd_pinned(fd_ctx* ctx, size_t bytes) {
         ctx->pinned.cap = want;
     }
     return ctx->pinned.p;
+}
+
+static inline hipStream_t fd_aux_stream(fd_ctx* ctx) {
+    if (!ctx->aux) HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+    return ctx->aux;
 }
 
 static inline int fd_cvRound(double v) { return (int)std::lrint(v); }  // cvRound: half-to-even

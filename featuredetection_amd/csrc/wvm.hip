@@ -33,6 +33,7 @@ void fd_svm_generic_launch(fd_ctx* ctx, const fd_svm* m, const void* dfeat, cons
 constexpr int WVM_MAX_LAYERS = 64;
 constexpr int WVM_MAX_DIM = 32;      // patch width/height limit of this kernel
 constexpr int WVM_MAX_VALS = 16;     // grey values per filter
+constexpr int WVM_FIRST_CHUNK = 4096;  // positives fetched together with the counter
 constexpr int WVM_LCAP = 16;         // filters evaluated by the one-wave-per-window stage; survivors go to k_wvm_deep
 constexpr int WVM_PJ = 5;            // up to 320 filters (largest cfg-implied WVM: 280)
 
@@ -95,6 +96,8 @@ struct fd_wvm {
     DevBuf all_level, all_fout, pos, pos_patches, counter, deep_q;
     HostBuf h_pos;
     int64_t pos_cap = 0;
+    hipEvent_t done = nullptr;   // recorded after the cascade kernels + first read-back of a run
+    ~fd_wvm() { if (done) (void)hipEventDestroy(done); }
 };
 
 namespace {
@@ -345,7 +348,7 @@ struct __attribute__((aligned(16))) WaveLds {
 };
 
 template <int PW_, int PH_, bool RAW>
-__global__ __launch_bounds__(256) void k_wvm_cascade(const uint8_t* __restrict__ arena, WinTable wt, WvmDev m, CascadeOut o) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_wvm_cascade(const uint8_t* __restrict__ arena, WinTable wt, WvmDev m, CascadeOut o) {
     __shared__ WaveLds<PW_, PH_> lds[4];
     __shared__ int64_t sFirst[WVM_MAX_LAYERS];
     constexpr int RHMAX = Geo<PW_, PH_>::RHMAX;
@@ -551,10 +554,17 @@ __global__ __launch_bounds__(256) void k_histeq64(const uint8_t* __restrict__ in
 template <int PW_, int PH_, bool RAW>
 void launch_sized(fd_ctx* ctx, hipStream_t st, int64_t total, const WvmDev& dev, const uint8_t* arena, const WinTable& wt,
                   const CascadeOut& o) {
-    const int gridA = (int)std::min<int64_t>((total + 3) / 4, (int64_t)ctx->num_cus * 8);
+    // both stages are persistent grids: exactly as many workgroups as fit on the device at once (a partial second
+    // round of workgroups would run at a fraction of the occupancy)
+    static int perCuA = 0;
+    if (perCuA == 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuA, k_wvm_cascade<PW_, PH_, RAW>, 256, 0) != hipSuccess || perCuA < 1) perCuA = 4;
+        if (const char* e = getenv("FD_WVM_GRID_PER_CU")) if (atoi(e) > 0) perCuA = atoi(e);
+    }
+    const int gridA = (int)std::min<int64_t>((total + 3) / 4, (int64_t)ctx->num_cus * perCuA * 2);   // two full rounds
     hipLaunchKernelGGL((k_wvm_cascade<PW_, PH_, RAW>), dim3(gridA), dim3(256), 0, st, arena, wt, dev, o);
     if (dev.numUsed <= WVM_LCAP) return;
-    static int perCu = 0;   // stage B is persistent: as many workgroups as fit on the device at once
+    static int perCu = 0;
     if (perCu == 0) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wvm_deep<PW_, PH_, RAW>, 256, 0) != hipSuccess || perCu < 1) perCu = 2;
     }
@@ -624,10 +634,12 @@ struct WvmRun {
     int64_t total = 0;
     std::vector<PosRec> pos;       // sorted by window id (= extraction order)
     std::vector<uint32_t> slots;   // device slot of each sorted positive (index into pos_patches)
+    bool timed = false;
 };
 
-void fd_wvm_run(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, int sx, int sy, const int* roi, bool want_all, WvmRun& run,
-                bool time_kernel) {
+// Asynchronous half of a WVM run: enumerates the windows, launches both cascade stages on the context's stream,
+// queues the read-back of the counter + first positives into the model's own pinned buffer and records m->done.
+void fd_wvm_launch(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, int sx, int sy, const int* roi, bool want_all, WvmRun& run, bool time_kernel) {
     if (p->ctx != ctx || m->ctx != ctx) FD_THROW(FD_ERR_INVALID_ARGUMENT, "objects belong to different contexts");
     if (p->filter_kind != FD_LAYER_NONE)
         FD_THROW(FD_ERR_INVALID_ARGUMENT, "WVM detection needs a gray pyramid (no layer filter)");
@@ -638,6 +650,7 @@ void fd_wvm_run(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, int sx, int sy, const int
     run.total = wt.total;
     run.pos.clear();
     run.slots.clear();
+    run.timed = time_kernel;
     if (wt.total == 0) return;
     hipStream_t st = ctx->stream;
     if (want_all) {
@@ -653,6 +666,8 @@ void fd_wvm_run(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, int sx, int sy, const int
     // counter and the first records come back in a single read
     m->pos.reserve(sizeof(PosRec) * ((size_t)m->pos_cap + 1));
     m->pos_patches.reserve((size_t)m->dev.d * (size_t)m->pos_cap);
+    m->h_pos.reserve(sizeof(PosRec) * ((size_t)m->pos_cap + 1));
+    if (!m->done) HIP_CHECK(hipEventCreateWithFlags(&m->done, hipEventDisableTiming));
     HIP_CHECK(hipMemsetAsync(m->pos.p, 0, sizeof(PosRec), st));
     m->deep_q.reserve(sizeof(int64_t) * (size_t)wt.total);
     CascadeOut o;
@@ -668,22 +683,30 @@ void fd_wvm_run(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, int sx, int sy, const int
     launch_cascade<false>(ctx, st, wt.total, m->dev, p->arena.as<uint8_t>(), wt, o);
     if (time_kernel) HIP_CHECK(hipEventRecord(ctx->ev1, st));
     HIP_CHECK(hipGetLastError());
-    const size_t firstChunk = (size_t)std::min<int64_t>(m->pos_cap, 2048);
-    PosRec* hraw = (PosRec*)fd_pinned(ctx, sizeof(PosRec) * ((size_t)m->pos_cap + 1));
-    HIP_CHECK(hipMemcpyAsync(hraw, m->pos.p, sizeof(PosRec) * (firstChunk + 1), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
+    const size_t firstChunk = (size_t)std::min<int64_t>(m->pos_cap, WVM_FIRST_CHUNK);
+    HIP_CHECK(hipMemcpyAsync(m->h_pos.p, m->pos.p, sizeof(PosRec) * (firstChunk + 1), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipEventRecord(m->done, st));
+}
+
+// Synchronous half: waits for m->done, fetches the remaining positives and sorts them into extraction order.
+void fd_wvm_finish(fd_ctx* ctx, fd_wvm* m, WvmRun& run) {
+    if (run.total == 0) return;
+    HIP_CHECK(hipEventSynchronize(m->done));
+    PosRec* hraw = m->h_pos.as<PosRec>();
     const unsigned int cnt = hraw[0].wid_lo;
-    if (time_kernel) {
+    if (run.timed) {
         HIP_CHECK(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev0, ctx->ev1));
         ctx->last_kernel = "k_wvm_cascade";
     }
     if ((int64_t)cnt > m->pos_cap)
         FD_THROW(FD_ERR_CAPACITY, "WVM produced %u positives, device buffer holds %lld (set FD_WVM_POS_CAP)", cnt, (long long)m->pos_cap);
     if (cnt) {
-        if (cnt > firstChunk) {
+        const size_t firstChunk = (size_t)std::min<int64_t>(m->pos_cap, WVM_FIRST_CHUNK);
+        if (cnt > firstChunk) {   // on the auxiliary stream: the main stream may already hold the next detectors' kernels
+            hipStream_t ax = fd_aux_stream(ctx);
             HIP_CHECK(hipMemcpyAsync(hraw + 1 + firstChunk, m->pos.as<PosRec>() + 1 + firstChunk, sizeof(PosRec) * (cnt - firstChunk),
-                                     hipMemcpyDeviceToHost, st));
-            HIP_CHECK(hipStreamSynchronize(st));
+                                     hipMemcpyDeviceToHost, ax));
+            HIP_CHECK(hipStreamSynchronize(ax));
         }
         const PosRec* raw = hraw + 1;
         std::vector<uint32_t> order(cnt);
@@ -694,6 +717,12 @@ void fd_wvm_run(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, int sx, int sy, const int
         run.slots.resize(cnt);
         for (uint32_t i = 0; i < cnt; ++i) { run.pos[i] = raw[order[i]]; run.slots[i] = order[i]; }
     }
+}
+
+void fd_wvm_run(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, int sx, int sy, const int* roi, bool want_all, WvmRun& run,
+                bool time_kernel) {
+    fd_wvm_launch(ctx, p, m, sx, sy, roi, want_all, run, time_kernel);
+    fd_wvm_finish(ctx, m, run);
 }
 
 // ProbabilisticWvmClassifier.cpp:52 -- evaluated on the host with libm, like the reference
@@ -887,90 +916,144 @@ int fd_bench_wvm(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, int sx, int sy,
     });
 }
 
+// Stages 2-5 of FiveStageSlidingWindowDetector::detect (FiveStageSlidingWindowDetector.cpp:200-320 / :340-380) on a
+// finished WVM run.  GPU work (the SVM on the survivors) goes to the stream `st`.
+static void five_stage_tail(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, const fd_svm* svm, const WvmRun& run, float oe_dist, float oe_ratio,
+                            int sx, int sy, const int* roi, hipStream_t st, fd_detection* out, int cap, int* count, int32_t* stage_counts) {
+    static const bool trace = getenv("FD_TRACE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t0 = now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        auto t1 = now();
+        fprintf(stderr, "[fd five-stage] %-12s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t1 - t0).count());
+        t0 = t1;
+    };
+    struct StreamSwap {   // fd_svm_generic_launch works on ctx->stream
+        fd_ctx* c;
+        hipStream_t keep;
+        StreamSwap(fd_ctx* c_, hipStream_t s_) : c(c_), keep(c_->stream) { c->stream = s_; }
+        ~StreamSwap() { c->stream = keep; }
+    } swap(ctx, st);
+    std::vector<fd_detection> wvmPos;
+    fd_wvm_positives_to_detections(p, m, run, sx, sy, wvmPos);
+    if (stage_counts) stage_counts[0] = (int)wvmPos.size();
+    lap("to_dets");
+    // stage 2: overlap elimination
+    std::vector<int> keep;
+    fd_host_overlap_elimination(wvmPos.data(), (int)wvmPos.size(), oe_dist, oe_ratio, keep);
+    if (stage_counts) stage_counts[1] = (int)keep.size();
+    lap("oe");
+    // stage 3: SVM on the survivors' HistEq64 patches (still resident in HBM, gathered by slot)
+    std::vector<fd_detection> svmPos;
+    if (!keep.empty()) {
+        std::vector<uint32_t> slots(keep.size());
+        for (size_t i = 0; i < keep.size(); ++i) slots[i] = run.slots[keep[i]];
+        DevBuf& idx = m->all_level;  // reuse scratch (not used by this call)
+        idx.reserve(sizeof(uint32_t) * slots.size());
+        m->all_fout.reserve(sizeof(double) * slots.size());
+        // pinned staging: [slots (u32) | distances (f64)]
+        const size_t distOff = (sizeof(uint32_t) * slots.size() + 15) & ~(size_t)15;
+        char* pin = (char*)fd_pinned(ctx, distOff + sizeof(double) * slots.size());
+        std::memcpy(pin, slots.data(), sizeof(uint32_t) * slots.size());
+        HIP_CHECK(hipMemcpyAsync(idx.p, pin, sizeof(uint32_t) * slots.size(), hipMemcpyHostToDevice, st));
+        fd_svm_generic_launch(ctx, svm, m->pos_patches.p, idx.as<uint32_t>(), (int64_t)m->dev.d, (int64_t)slots.size(), m->all_fout.as<double>());
+        HIP_CHECK(hipMemcpyAsync(pin + distOff, m->all_fout.p, sizeof(double) * slots.size(), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        const double* dist = (const double*)(pin + distOff);
+        for (size_t i = 0; i < keep.size(); ++i) {
+            if (dist[i] >= (double)fd_svm_threshold(svm)) {  // strongClassifier->classify(): bool only
+                fd_detection d = wvmPos[keep[i]];
+                d.score = (float)dist[i];
+                d.positive = 1;
+                d.probability = 0.5;  // ClassifiedPatch(patch, bool) default probability (ClassifiedPatch.hpp:29-30)
+                svmPos.push_back(d);
+            }
+        }
+    }
+    if (stage_counts) stage_counts[2] = (int)svmPos.size();
+    lap("svm");
+    auto byProb = [](const fd_detection& a, const fd_detection& b) { return a.probability > b.probability; };
+    bool sortAtEnd = true;
+    if (!roi) {
+        std::vector<int> maxima;
+        fd_host_block_nms_sparse(svmPos, p->img_w, p->img_h, 35, true, maxima);
+        if (maxima.empty()) fd_host_block_nms_sparse(svmPos, p->img_w, p->img_h, 35, false, maxima);
+        if (maxima.empty()) {
+            sortAtEnd = false;  // "return svmPatchesPositive; // Should be empty." (:292-294), unsorted
+        } else {
+            std::sort(svmPos.begin(), svmPos.end(), byProb);
+            std::vector<fd_detection> res;
+            for (size_t i = 0; i + 1 < maxima.size(); i += 2) {
+                const int x = maxima[i], y = maxima[i + 1];
+                auto it = std::find_if(svmPos.begin(), svmPos.end(), [&](const fd_detection& a) { return a.cx == x && a.cy == y; });
+                if (it != svmPos.end()) res.push_back(*it);
+            }
+            svmPos.swap(res);
+        }
+    }
+    if (sortAtEnd) std::sort(svmPos.begin(), svmPos.end(), byProb);
+    if (stage_counts) stage_counts[3] = (int)svmPos.size();
+    lap("nms");
+    *count = (int)svmPos.size();
+    for (size_t i = 0; i < svmPos.size() && (int)i < cap && out; ++i) out[i] = svmPos[i];
+    if (out && (int)svmPos.size() > cap) FD_THROW(FD_ERR_CAPACITY, "five-stage: %zu detections, capacity %d", svmPos.size(), cap);
+}
+
+static void five_stage_check(const fd_wvm* m, const fd_svm* svm) {
+    if (fd_svm_dim(svm) != m->dev.d || !fd_svm_is_u8(svm))
+        FD_THROW(FD_ERR_INVALID_ARGUMENT, "second classifier must work on the %d-byte HistEq64 patch", m->dev.d);
+}
+
 // detection::FiveStageSlidingWindowDetector::detect, FiveStageSlidingWindowDetector.cpp:187-320 / :331-380
 int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const fd_svm* svm, float oe_dist, float oe_ratio,
                          int sx, int sy, const int* roi, fd_detection* out, int cap, int* count, int32_t* stage_counts) {
     return fd_guard(ctx, [&] {
         if (!ctx || !p || !wvm_ || !svm || !count) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage: NULL argument");
         fd_wvm* m = const_cast<fd_wvm*>(wvm_);
-        if (fd_svm_dim(svm) != m->dev.d || !fd_svm_is_u8(svm))
-            FD_THROW(FD_ERR_INVALID_ARGUMENT, "second classifier must work on the %d-byte HistEq64 patch", m->dev.d);
+        five_stage_check(m, svm);
         // stage 1: WVM over all windows (SlidingWindowDetector::detect), positives in extraction order
-        static const bool trace = getenv("FD_TRACE") != nullptr;
-        auto now = [] { return std::chrono::steady_clock::now(); };
-        auto t0 = now();
-        auto lap = [&](const char* what) {
-            if (!trace) return;
-            auto t1 = now();
-            fprintf(stderr, "[fd five-stage] %-12s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t1 - t0).count());
-            t0 = t1;
-        };
         WvmRun run;
         fd_wvm_run(ctx, p, m, sx, sy, roi, false, run, true);
-        lap("wvm");
-        std::vector<fd_detection> wvmPos;
-        fd_wvm_positives_to_detections(p, m, run, sx, sy, wvmPos);
-        if (stage_counts) stage_counts[0] = (int)wvmPos.size();
-        lap("to_dets");
-        // stage 2: overlap elimination
-        std::vector<int> keep;
-        fd_host_overlap_elimination(wvmPos.data(), (int)wvmPos.size(), oe_dist, oe_ratio, keep);
-        if (stage_counts) stage_counts[1] = (int)keep.size();
-        lap("oe");
-        // stage 3: SVM on the survivors' HistEq64 patches (still resident in HBM, gathered by slot)
-        std::vector<fd_detection> svmPos;
-        if (!keep.empty()) {
-            std::vector<uint32_t> slots(keep.size());
-            for (size_t i = 0; i < keep.size(); ++i) slots[i] = run.slots[keep[i]];
-            DevBuf& idx = m->all_level;  // reuse scratch (not used by this call)
-            idx.reserve(sizeof(uint32_t) * slots.size());
-            m->all_fout.reserve(sizeof(double) * slots.size());
-            // pinned staging: [slots (u32) | distances (f64)]
-            const size_t distOff = (sizeof(uint32_t) * slots.size() + 15) & ~(size_t)15;
-            char* pin = (char*)fd_pinned(ctx, distOff + sizeof(double) * slots.size());
-            std::memcpy(pin, slots.data(), sizeof(uint32_t) * slots.size());
-            HIP_CHECK(hipMemcpyAsync(idx.p, pin, sizeof(uint32_t) * slots.size(), hipMemcpyHostToDevice, ctx->stream));
-            fd_svm_generic_launch(ctx, svm, m->pos_patches.p, idx.as<uint32_t>(), (int64_t)m->dev.d, (int64_t)slots.size(), m->all_fout.as<double>());
-            HIP_CHECK(hipMemcpyAsync(pin + distOff, m->all_fout.p, sizeof(double) * slots.size(), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            const double* dist = (const double*)(pin + distOff);
-            for (size_t i = 0; i < keep.size(); ++i) {
-                if (dist[i] >= (double)fd_svm_threshold(svm)) {  // strongClassifier->classify(): bool only
-                    fd_detection d = wvmPos[keep[i]];
-                    d.score = (float)dist[i];
-                    d.positive = 1;
-                    d.probability = 0.5;  // ClassifiedPatch(patch, bool) default probability (ClassifiedPatch.hpp:29-30)
-                    svmPos.push_back(d);
-                }
+        five_stage_tail(ctx, p, m, svm, run, oe_dist, oe_ratio, sx, sy, roi, ctx->stream, out, cap, count, stage_counts);
+    });
+}
+
+// Several five-stage detectors on (possibly shared) pyramids, as ffpDetectApp.cpp:557-600 loops over its detectors.  All
+// WVM stages are queued first on the context's stream; while the GPU works through them the host finishes the
+// detectors one by one (read-back, overlap elimination, the small SVM stage on an auxiliary stream, NMS).
+int fd_detect_five_stage_batch(fd_ctx* ctx, fd_five_stage_job* jobs, int n) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || n < 0 || (n > 0 && !jobs)) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_batch: bad argument");
+        std::vector<WvmRun> runs((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            fd_five_stage_job& j = jobs[i];
+            j.count = 0;
+            j.status = FD_OK;
+            if (!j.pyramid || !j.wvm || !j.svm) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_batch: NULL handle in job %d", i);
+            for (int k = 0; k < i; ++k)
+                if (jobs[k].wvm == j.wvm) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_batch: jobs %d and %d share a WVM handle", k, i);
+            five_stage_check(j.wvm, j.svm);
+        }
+        for (int i = 0; i < n; ++i)
+            fd_wvm_launch(ctx, jobs[i].pyramid, const_cast<fd_wvm*>(jobs[i].wvm), jobs[i].step_x, jobs[i].step_y, jobs[i].roi, false, runs[i], false);
+        hipStream_t ax = fd_aux_stream(ctx);
+        int firstError = FD_OK;
+        for (int i = 0; i < n; ++i) {
+            fd_five_stage_job& j = jobs[i];
+            fd_wvm* m = const_cast<fd_wvm*>(j.wvm);
+            try {
+                fd_wvm_finish(ctx, m, runs[i]);
+                int cnt = 0;
+                five_stage_tail(ctx, j.pyramid, m, j.svm, runs[i], j.oe_dist, j.oe_ratio, j.step_x, j.step_y, j.roi, ax, j.out, j.cap, &cnt,
+                                j.stage_counts);
+                j.count = cnt;
+            } catch (const FdError& e) {   // the remaining jobs are still collected; the first failure is reported
+                j.status = e.code;
+                if (firstError == FD_OK) { firstError = e.code; ctx->error = e.msg; }
             }
         }
-        if (stage_counts) stage_counts[2] = (int)svmPos.size();
-        lap("svm");
-        auto byProb = [](const fd_detection& a, const fd_detection& b) { return a.probability > b.probability; };
-        bool sortAtEnd = true;
-        if (!roi) {
-            std::vector<int> maxima;
-            fd_host_block_nms_sparse(svmPos, p->img_w, p->img_h, 35, true, maxima);
-            if (maxima.empty()) fd_host_block_nms_sparse(svmPos, p->img_w, p->img_h, 35, false, maxima);
-            if (maxima.empty()) {
-                sortAtEnd = false;  // "return svmPatchesPositive; // Should be empty." (:292-294), unsorted
-            } else {
-                std::sort(svmPos.begin(), svmPos.end(), byProb);
-                std::vector<fd_detection> res;
-                for (size_t i = 0; i + 1 < maxima.size(); i += 2) {
-                    const int x = maxima[i], y = maxima[i + 1];
-                    auto it = std::find_if(svmPos.begin(), svmPos.end(), [&](const fd_detection& a) { return a.cx == x && a.cy == y; });
-                    if (it != svmPos.end()) res.push_back(*it);
-                }
-                svmPos.swap(res);
-            }
-        }
-        if (sortAtEnd) std::sort(svmPos.begin(), svmPos.end(), byProb);
-        if (stage_counts) stage_counts[3] = (int)svmPos.size();
-        lap("nms");
-        *count = (int)svmPos.size();
-        for (size_t i = 0; i < svmPos.size() && (int)i < cap && out; ++i) out[i] = svmPos[i];
-        if (out && (int)svmPos.size() > cap) FD_THROW(FD_ERR_CAPACITY, "fd_detect_five_stage: %zu detections, capacity %d", svmPos.size(), cap);
+        if (firstError != FD_OK) throw FdError{firstError, ctx->error};
     });
 }
 

@@ -146,6 +146,23 @@ int fd_detect_wvm(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm, int step_x, int
 int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm, const fd_svm* svm, float oe_dist,
                          float oe_ratio, int step_x, int step_y, const int* roi, fd_detection* out, int cap,
                          int* count, int32_t* stage_counts);
+/* Several five-stage detectors in one call (the detector loop of ffpDetectApp.cpp:557-600; BASELINE config 3).  All WVM
+ * stages are queued first; the host-side stages of detector i overlap the GPU work of detectors i+1...  Two jobs may
+ * share a pyramid (identical layers) but not a WVM handle.  Per job: count / stage_counts / status are outputs. */
+typedef struct {
+    fd_pyramid* pyramid;
+    const fd_wvm* wvm;
+    const fd_svm* svm;
+    float oe_dist, oe_ratio;
+    int32_t step_x, step_y;
+    const int* roi;             /* {x,y,w,h} or NULL */
+    fd_detection* out;
+    int32_t cap;
+    int32_t count;              /* out */
+    int32_t stage_counts[4];    /* out */
+    int32_t status;             /* out: FD_OK or the job's error code */
+} fd_five_stage_job;
+int fd_detect_five_stage_batch(fd_ctx* ctx, fd_five_stage_job* jobs, int n);
 
 /* detection::OverlapElimination::eliminate (OverlapElimination.cpp:44-105); host-side, deterministic */
 int fd_overlap_elimination(const fd_detection* in, int n, float dist, float ratio, int32_t* keep_idx, int* count);

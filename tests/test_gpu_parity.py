@@ -454,6 +454,30 @@ def test_rvm_sliding_window_detector(oracle, capi, ctx, synth, frame640, space, 
     rg.close(); pg.close(); po.close(); ro.close()
 
 
+def test_five_stage_batch_equals_single_calls(oracle, capi, ctx, synth, frame640, small_models):
+    """fd_detect_five_stage_batch (all WVM stages queued first, host stages overlapped) returns exactly what the
+    individual fd_detect_five_stage calls return; two detectors share a pyramid."""
+    wvm, svm = small_models
+    gray = oracle.bgr2gray(frame640)
+    rng = np.random.default_rng(5)
+    calib = synth.random_patches(gray[::2, ::2].copy(), 24, 24, 3000, rng)
+    wvm2 = synth.make_wvm(77, fw=24, fh=24, n_per=10, n_levels=3, calib_patches=calib, min_survivors=48)
+    eq = synth.histeq64_np(synth.random_patches(gray[::2, ::2].copy(), 24, 24, 400, rng))
+    svm2 = synth.make_svm_u8(78, eq, nsv=256, calib=eq[256:])
+    pA = capi.Pyramid(ctx, **FF); pA.update(frame640)
+    pB = capi.Pyramid(ctx, inc=0.9, min_scale=0.3, max_scale=0.5); pB.update(frame640)
+    dets = [(pA, capi.Wvm(ctx, wvm), capi.Svm(ctx, svm)), (pB, capi.Wvm(ctx, wvm2), capi.Svm(ctx, svm2)), (pB, capi.Wvm(ctx, wvm), capi.Svm(ctx, svm))]
+    single = [capi.detect_five_stage(ctx, p_, w_, s_) for p_, w_, s_ in dets]
+    batch = capi.detect_five_stage_batch(ctx, dets)
+    assert sum(len(d) for d, _ in single) > 0
+    for (d1, st1), (d2, st2) in zip(single, batch):
+        assert np.array_equal(st1, st2)
+        assert d1.tobytes() == d2.tobytes()
+    for p_, w_, s_ in dets:
+        w_.close(); s_.close()
+    pA.close(); pB.close()
+
+
 def test_hog_rbf_svm_detector_config2(oracle, capi, ctx, synth):
     """BASELINE config 2 shape on a reduced frame: HOG-324 + RBF SVM (MFMA path).  Scores within
     1e-4 relative (of the natural scale sum|coeff_i| K_i), positives identical away from the threshold."""
