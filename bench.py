@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="hog_svm", choices=["hog_svm", "wvm", "ffp15", "sdm"])
+    ap.add_argument("--workload", default="hog_svm", choices=["hog_svm", "wvm", "ffp15", "rvm", "sdm"])
     ap.add_argument("--gather-every", type=int, default=8)
     ap.add_argument("--size", default="640x480", help="frame size WxH for the hog_svm / wvm workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -149,6 +149,32 @@ def main():
         units_name = "windows"
         config = dict(workload="FaceFrontal.cfg five-stage cascade on a %dx%d frame: %d-layer pyramid, 20x20 windows step 1 (%d windows), "
                                "WVM 280 filters -> OE -> RBF-SVM 1024 SV -> NMS" % (W, H, len(pyr.layers()), nwin_wvm),
+                      frames_per_step=1, parallelism="image-shard dp%d" % world)
+        dtype = "u8/f32/f64"
+    elif args.workload == "rvm":
+        # SlidingWindowDetector + ProbabilisticRvmClassifier ("prvm"), hq64 feature space + ConversionFilter
+        W, H = FW, FH
+        frames = [synth.make_frame(W, H, seed=20260927 + 1000 * rank + i) for i in range(NFRAMES)]
+        dframes = [torch.from_numpy(f).to(dev) for f in frames]
+        from oracle import pyoracle as O  # calibration patches only
+        gray = O.bgr2gray(synth.make_frame(640, 480, seed=20260927))
+        calib = synth.histeq64_np(synth.random_patches(gray[::4, ::4].copy(), 20, 20, 6000, np.random.default_rng(1)))
+        feats = calib.reshape(len(calib), -1).astype(np.float32) * np.float32(1.0 / 255.0)
+        rvm_m = synth.make_rvm(9, feats, 20, 20, n_filters=100, kernel=2, pass_rate=0.5)
+        pyr = capi.Pyramid(ctx, inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))
+        rvm = capi.Rvm(ctx, rvm_m)
+        pyr.update(frames[0])
+        nwin_rvm = pyr.window_count(20, 20, 1, 1)
+
+        def step(i, sync=True):
+            f = dframes[i % NFRAMES]
+            pyr.update_device(f.data_ptr(), W, H, 3)
+            d_, _, _ = capi.detect_rvm(ctx, pyr, rvm, feature_space=capi.FEATURE_HQ64, conv_scale=1.0 / 255.0, want_all=False)
+            return nwin_rvm, len(d_)
+
+        units_name = "windows"
+        config = dict(workload="prvm single detector: FaceFrontal pyramid on a %dx%d frame, 20x20 windows step 1 (%d windows), hq64 + "
+                               "ConversionFilter(CV_32F, 1/255), RBF RVM with 100 reduced set vectors" % (W, H, nwin_rvm),
                       frames_per_step=1, parallelism="image-shard dp%d" % world)
         dtype = "u8/f32/f64"
     elif args.workload == "ffp15":
@@ -249,7 +275,8 @@ def main():
     if rank == 0:
         value = total_units / dt / 1e6
         res = dict(metric="Mpatches/s (extract+HOG+RBF-SVM), 640x480 pyramid" if args.workload == "hog_svm" else
-                   ("Mpatches/s (extract+WVM+SVM cascade), %dx%d pyramid" % (W, H) if args.workload in ("wvm", "ffp15") else "SDM iters/s (x1e6)"),
+                   ("Mpatches/s (extract+WVM+SVM cascade), %dx%d pyramid" % (W, H) if args.workload in ("wvm", "ffp15") else
+                    ("Mpatches/s (extract+HistEq64+RVM cascade), %dx%d pyramid" % (W, H) if args.workload == "rvm" else "SDM iters/s (x1e6)")),
                    value=value, unit="Mpatches/s" if args.workload != "sdm" else "M SDM iters/s", n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype=dtype, data="synthetic", config=config)

@@ -23,6 +23,7 @@
 void fd_window_to_detection(const fd_pyramid* p, const std::vector<WindowLayer>& wls, int sx, int sy, int64_t wid, fd_detection& d);
 
 constexpr int RVM_MAX_LAYERS = 64;
+constexpr int RVM_DEEP_FROM = 16;    // levels from here on are evaluated 64 at a time per surviving window
 constexpr int RVM_MAX_DIM = 32;       // patch width/height limit of the window feature kernel
 
 struct RvmWinLayer {
@@ -43,6 +44,7 @@ struct RvmDev {
     int32_t degree;
     float bias;
     const float* sv;      // [numFilters][dim]
+    const float* svT;     // [dim][numFilters]: element i of every reduced set vector (lane == level reads are coalesced)
     const float* diag;    // [numFilters]: coefficients[k][k]
     const float* thr;     // [numFilters]
 };
@@ -58,7 +60,7 @@ struct fd_rvm {
     int filter_w, filter_h;
     double logisticA, logisticB;
     std::vector<float> h_thr;
-    DevBuf sv, diag, thr;
+    DevBuf sv, svT, diag, thr;
     DevBuf feats, q0, q1, counters, level, dist, pos;   // scratch reused across calls
 };
 
@@ -117,7 +119,28 @@ __device__ __forceinline__ double rvm_kernel_value(const RvmDev& m, const void* 
     if (m.kernel == FD_KERNEL_RBF) {
         float sum = 0.f;
         int i = 0;
-        if (U8IN && (dim & 3) == 0) {
+        if (U8IN && (dim & 15) == 0) {
+            // 16 pixels per 128-bit load, the next chunk in flight while the current one is consumed; the fp32
+            // chain itself stays in element order
+            const uint4* xw = (const uint4*)xv;   // rows are 16-byte aligned when dim % 16 == 0
+            const float4* sw = (const float4*)s;
+            uint4 cur = xw[0];
+            for (; i + 16 <= dim; i += 16) {
+                const uint4 nxt = xw[(i + 16 < dim ? i + 16 : i) >> 4];
+                const unsigned int w[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float4 sv4 = sw[(i >> 2) + c];
+                    const float sa[4] = {sv4.x, sv4.y, sv4.z, sv4.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float diff = ((float)((w[c] >> (8 * q)) & 255u) * scale + shift) - sa[q];
+                        sum = sum + diff * diff;
+                    }
+                }
+                cur = nxt;
+            }
+        } else if (U8IN && (dim & 3) == 0) {
             const unsigned int* xw = (const unsigned int*)xv;   // rows are 4-byte aligned when dim % 4 == 0
             for (; i + 4 <= dim; i += 4) {
                 const unsigned int w4 = xw[i >> 2];
@@ -197,9 +220,85 @@ __global__ __launch_bounds__(256) void k_rvm_pass(RvmDev m, const void* __restri
     }
 }
 
+// Deep part of the cascade: the few windows that survive the first levels run dozens more, and a lane == window
+// mapping would leave them on a handful of wavefronts, each bound by its 400-step fp32 chains.  The kernel values of
+// different levels are independent, so here a wavefront takes ONE window and evaluates 64 levels at once (lane ==
+// level; the patch is wave-uniform, the reduced set vectors are read transposed), then forms the running distance
+// in level order and stops at the first missed threshold.
+template <bool U8IN>
+__global__ __launch_bounds__(256) void k_rvm_deep(RvmDev m, const void* __restrict__ feats, int64_t rowBytes, float scale, float shift,
+                                                  const RvmRec* __restrict__ inq, const unsigned int* __restrict__ in_count, int k0,
+                                                  int32_t* __restrict__ all_level, double* __restrict__ all_dist,
+                                                  RvmRec* __restrict__ pos, unsigned int* __restrict__ pos_count, unsigned int pos_cap) {
+    __shared__ float xs[4][RVM_MAX_DIM * RVM_MAX_DIM];   // the window's vector, converted once
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t n = (int64_t)*in_count;
+    const int dim = m.dim, F = m.numFilters;
+    float* x = xs[wave];
+    for (int64_t item = (int64_t)blockIdx.x * 4 + wave; item < n; item += (int64_t)gridDim.x * 4) {
+        const int64_t wid = (int64_t)(((uint64_t)inq[item].wid_hi << 32) | inq[item].wid_lo);
+        double d = inq[item].d;
+        const char* row = (const char*)feats + (size_t)wid * rowBytes;
+        for (int i = lane; i < dim; i += 64)
+            x[i] = U8IN ? (float)((const unsigned char*)row)[i] * scale + shift : ((const float*)row)[i];
+        wave_sync();
+        int level = -1;
+        for (int kb = k0; kb < m.numUse && level < 0; kb += 64) {
+            const int k = kb + lane;
+            const bool valid = k < m.numUse;
+            const float* st = m.svT + (valid ? k : kb);
+            double K;
+            if (m.kernel == FD_KERNEL_RBF) {
+                float sum = 0.f;
+                for (int i = 0; i < dim; ++i) {
+                    const float diff = x[i] - st[(size_t)i * F];
+                    sum = sum + diff * diff;
+                }
+                K = exp(-m.p0 * (double)sum);
+            } else if (m.kernel == FD_KERNEL_HIK) {
+                float sum = 0.f;
+                for (int i = 0; i < dim; ++i) sum = sum + fminf(x[i], st[(size_t)i * F]);
+                K = (double)sum;
+            } else {
+                double dot = 0.0;
+                for (int i = 0; i < dim; ++i) dot = dot + (double)x[i] * (double)st[(size_t)i * F];
+                K = m.kernel == FD_KERNEL_LINEAR ? dot : powi_d(m.p0 * dot + m.p1, m.degree);
+            }
+            const double term = valid ? (double)m.diag[k] * K : 0.0;
+            // running distance in level order (RvmClassifier.cpp:94-112); lane j keeps d_{kb+j}
+            double mine = 0.0;
+            const int cnt = min(64, m.numUse - kb);
+            for (int j = 0; j < cnt; ++j) {
+                const double t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(term), j),
+                                                  __builtin_amdgcn_readlane(__double2loint(term), j));
+                d = (kb + j == 0) ? (-(double)m.bias) + t : d + t;
+                mine = (lane == j) ? d : mine;
+            }
+            const float thr = valid ? m.thr[k] : 0.f;
+            const bool leaves = valid && !(mine >= (double)thr && k + 1 < m.numUse);
+            const unsigned long long lm = __ballot(leaves);
+            if (lm) {
+                const int e = __builtin_ctzll(lm);
+                level = kb + e;
+                if (lane == e) {
+                    if (all_level) all_level[wid] = level;
+                    if (all_dist) all_dist[wid] = mine;
+                    if (level + 1 == m.numUse && mine >= (double)thr) {
+                        const unsigned int slot = atomicAdd(pos_count, 1u);
+                        if (slot < pos_cap) pos[slot] = RvmRec{(uint32_t)wid, (uint32_t)(wid >> 32), mine};
+                    }
+                }
+            }
+            // (d now holds the distance after the last level of the block: the entry value of the next one)
+        }
+        wave_sync();
+    }
+}
+
 // level ranges of the passes: short at the start (most windows leave early), longer later
 int pass_bounds(int numUse, int* b) {
-    static const int cuts[] = {2, 6, 16, 48, 128, 512, 1 << 30};
+    static const int cuts[] = {2, 6, RVM_DEEP_FROM};   // the rest runs lane == level (k_rvm_deep)
     int np = 0, k = 0;
     b[0] = 0;
     for (int c : cuts) {
@@ -236,6 +335,15 @@ void run_cascade(fd_ctx* ctx, fd_rvm* m, const void* dfeats, int64_t rowBytes, f
                            want_all ? m->dist.as<double>() : nullptr, m->pos.as<RvmRec>(), cnt, pos_cap);
         HIP_CHECK(hipGetLastError());
     }
+    if (m->dev.numUse > b[np]) {
+        if (m->dev.dim > RVM_MAX_DIM * RVM_MAX_DIM) FD_THROW(FD_ERR_INVALID_ARGUMENT, "RvmClassifier: vectors longer than %d are not supported", RVM_MAX_DIM * RVM_MAX_DIM);
+        const RvmRec* inq = np % 2 ? m->q0.as<RvmRec>() : m->q1.as<RvmRec>();
+        const int grid = (int)std::min<int64_t>((n + 3) / 4, (int64_t)ctx->num_cus * 8);
+        hipLaunchKernelGGL(k_rvm_deep<U8IN>, dim3(grid), dim3(256), 0, st, m->dev, dfeats, rowBytes, scale, shift, inq, cnt + np, b[np],
+                           want_all ? m->level.as<int32_t>() : nullptr, want_all ? m->dist.as<double>() : nullptr, m->pos.as<RvmRec>(), cnt,
+                           pos_cap);
+        HIP_CHECK(hipGetLastError());
+    }
 }
 
 }  // namespace
@@ -264,9 +372,15 @@ int fd_rvm_create(fd_ctx* ctx, const fd_rvm_model* md, fd_rvm** out) {
             HIP_CHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
         };
         up(m->sv, md->support_vectors, sizeof(float) * (size_t)F * dim);
+        {
+            std::vector<float> svT((size_t)F * dim);
+            for (int k = 0; k < F; ++k)
+                for (int i = 0; i < dim; ++i) svT[(size_t)i * F + k] = md->support_vectors[(size_t)k * dim + i];
+            up(m->svT, svT.data(), sizeof(float) * svT.size());
+        }
         up(m->diag, diag.data(), sizeof(float) * F);
         up(m->thr, md->thresholds, sizeof(float) * F);
-        d.sv = m->sv.as<float>(); d.diag = m->diag.as<float>(); d.thr = m->thr.as<float>();
+        d.sv = m->sv.as<float>(); d.svT = m->svT.as<float>(); d.diag = m->diag.as<float>(); d.thr = m->thr.as<float>();
         m->filter_w = md->filter_w; m->filter_h = md->filter_h;
         m->logisticA = md->logistic_a; m->logisticB = md->logistic_b;
         m->h_thr.assign(md->thresholds, md->thresholds + F);
