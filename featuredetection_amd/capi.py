@@ -139,6 +139,7 @@ _SIGS = {
     "fd_extract_whi": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fd_whi_params), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "fd_detect_whi_svm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(fd_whi_params), C.c_void_p, C.c_int64,
                                     C.POINTER(C.c_int64), C.c_void_p]),
+    "fd_wvm_svm_evaluate_samples": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fd_detect_five_stage_batch": (C.c_int, [C.c_void_p, C.POINTER(fd_five_stage_job), C.c_int]),
     "fd_rvm_create": (C.c_int, [C.c_void_p, C.POINTER(fd_rvm_model), C.POINTER(C.c_void_p)]),
     "fd_rvm_destroy": (None, [C.c_void_p]),
@@ -403,6 +404,15 @@ def detect_five_stage_batch(ctx, detectors, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=
         j.out, j.cap = o.ctypes.data, cap
     ctx.check(lib().fd_detect_five_stage_batch(ctx.h, jobs, n))
     return [(o[:j.count], np.array(list(j.stage_counts), np.int32)) for j, o in zip(jobs, outs)]
+
+
+def wvm_svm_evaluate(ctx, pyr, wvm, svm, samples):
+    """condensation::WvmSvmModel::evaluate: samples (n, 4) {x, y, width, height} -> (target bool[n], weight f64[n])"""
+    samples = _c(samples, np.int32).reshape(-1, 4)
+    target = np.zeros(len(samples), np.uint8)
+    weight = np.zeros(len(samples), np.float64)
+    ctx.check(lib().fd_wvm_svm_evaluate_samples(ctx.h, pyr.h, wvm.h, svm.h, len(samples), _ptr(samples), _ptr(target), _ptr(weight)))
+    return target.astype(bool), weight
 
 
 def overlap_elimination(dets, dist, ratio):

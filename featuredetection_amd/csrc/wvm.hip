@@ -28,6 +28,7 @@ struct fd_svm;
 int fd_svm_dim(const fd_svm* m);
 bool fd_svm_is_u8(const fd_svm* m);
 float fd_svm_threshold(const fd_svm* m);
+double fd_svm_probability(const fd_svm* m, double d);
 void fd_svm_generic_launch(fd_ctx* ctx, const fd_svm* m, const void* dfeat, const uint32_t* didx, int64_t stride_bytes, int64_t n, double* dout);
 
 constexpr int WVM_MAX_LAYERS = 64;
@@ -50,6 +51,7 @@ struct WinTable {
     int32_t sx, sy;
     int32_t raw;   // != 0: arena holds `total` contiguous, already equalised patches (fd_wvm_eval_batch)
     int64_t total;
+    const int32_t* list;   // != NULL: `total` explicit windows {layer position, lx, ly}; l[i] then describes kept layer i
     WinLayerDev l[WVM_MAX_LAYERS];
 };
 
@@ -93,7 +95,7 @@ struct fd_wvm {
     double logisticA, logisticB;
     std::vector<float> h_thresholds;
     // scratch reused across calls
-    DevBuf all_level, all_fout, pos, pos_patches, counter, deep_q;
+    DevBuf all_level, all_fout, pos, pos_patches, counter, deep_q, list;
     HostBuf h_pos;
     int64_t pos_cap = 0;
     hipEvent_t done = nullptr;   // recorded after the cascade kernels + first read-back of a run
@@ -160,6 +162,12 @@ __device__ __forceinline__ const uint8_t* wvm_locate(const uint8_t* arena, const
     if (RAW) {
         stride = pw;
         return arena + (size_t)wid * d;
+    }
+    if (wt.list) {   // explicit window list (single-patch extraction of sampled positions)
+        const int32_t* e = wt.list + 3 * wid;
+        const WinLayerDev& wl = wt.l[e[0]];
+        stride = wl.lw;
+        return arena + wl.off + (size_t)e[2] * wl.lw + e[1];
     }
     const int li = __builtin_amdgcn_readfirstlane(__popcll(__ballot(sFirst[lane] <= wid)) - 1);
     const WinLayerDev& wl = wt.l[li];
@@ -639,6 +647,8 @@ struct WvmRun {
 
 // Asynchronous half of a WVM run: enumerates the windows, launches both cascade stages on the context's stream,
 // queues the read-back of the counter + first positives into the model's own pinned buffer and records m->done.
+static void wvm_launch_table(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, const WinTable& wt, bool want_all, WvmRun& run, bool time_kernel);
+
 void fd_wvm_launch(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, int sx, int sy, const int* roi, bool want_all, WvmRun& run, bool time_kernel) {
     if (p->ctx != ctx || m->ctx != ctx) FD_THROW(FD_ERR_INVALID_ARGUMENT, "objects belong to different contexts");
     if (p->filter_kind != FD_LAYER_NONE)
@@ -647,6 +657,10 @@ void fd_wvm_launch(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, int sx, int sy, const 
     HIP_CHECK(hipSetDevice(ctx->device));
     WinTable wt;
     fd_wvm_build_table(p, m->dev.fw, m->dev.fh, sx, sy, roi, wt, run.wls);
+    wvm_launch_table(ctx, p, m, wt, want_all, run, time_kernel);
+}
+
+static void wvm_launch_table(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, const WinTable& wt, bool want_all, WvmRun& run, bool time_kernel) {
     run.total = wt.total;
     run.pos.clear();
     run.slots.clear();
@@ -1054,6 +1068,99 @@ int fd_detect_five_stage_batch(fd_ctx* ctx, fd_five_stage_job* jobs, int n) {
             }
         }
         if (firstError != FD_OK) throw FdError{firstError, ctx->error};
+    });
+}
+
+// condensation::WvmSvmModel::evaluate(image, samples) (WvmSvmModel.cpp:69-118) on top of a DirectPyramidFeatureExtractor
+// + HistEq64Filter: every sample {x, y, width, height} maps to one pyramid window (DirectPyramidFeatureExtractor::extract
+// (x, y, width, height), :67-73,134-153); all windows run through the WVM cascade in one launch (explicit window list);
+// the (at most 8) most probable WVM positives are re-scored by the SVM.  The reference's patch cache is keyed by
+// shared_ptr identity and never hits (oracle/orc_detect.cpp), so every sample is scored on its own.
+int fd_wvm_svm_evaluate_samples(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const fd_svm* svm, int n, const int32_t* xywh,
+                                uint8_t* target, double* weight) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !p || !wvm_ || !svm || n < 0 || (n > 0 && (!xywh || !target || !weight)))
+            FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_wvm_svm_evaluate_samples: bad argument");
+        fd_wvm* m = const_cast<fd_wvm*>(wvm_);
+        five_stage_check(m, svm);
+        if (p->ctx != ctx || m->ctx != ctx) FD_THROW(FD_ERR_INVALID_ARGUMENT, "objects belong to different contexts");
+        if (p->filter_kind != FD_LAYER_NONE) FD_THROW(FD_ERR_INVALID_ARGUMENT, "WVM evaluation needs a gray pyramid (no layer filter)");
+        if (p->all.empty()) FD_THROW(FD_ERR_RUNTIME, "pyramid has not been updated with an image");
+        if (p->kept.size() > (size_t)WVM_MAX_LAYERS) FD_THROW(FD_ERR_INVALID_ARGUMENT, "pyramid has %zu layers, this backend supports %d", p->kept.size(), WVM_MAX_LAYERS);
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const int pw = m->dev.fw, ph = m->dev.fh;
+        // sample -> window (ImagePyramid::getLayer(double) :307-310, getLayer(int) by index, extract bounds check)
+        std::vector<int32_t> list;
+        std::vector<int> sampleOf;
+        const int firstIndex = p->kept.empty() ? 0 : p->all[p->kept[0]].index;
+        for (int i = 0; i < n; ++i) {
+            target[i] = 0;
+            weight[i] = 0;
+            const int x = xywh[4 * i], y = xywh[4 * i + 1], width = xywh[4 * i + 2], height = xywh[4 * i + 3];
+            if (width <= 0 || p->kept.empty()) continue;
+            const double power = std::log((double)pw / (double)width) / std::log(p->inc);
+            const long index = std::lround(power);   // std::round, then the int cast of the reference
+            const long realIndex = index - firstIndex;
+            if (realIndex < 0 || realIndex >= (long)p->kept.size()) continue;
+            const HostLayer& L = p->all[p->kept[realIndex]];
+            const int bx = fd_cvRound((x - width / 2) * L.scale), by = fd_cvRound((y - height / 2) * L.scale);
+            if (bx < 0 || by < 0 || bx + pw > L.w || by + ph > L.h) continue;
+            list.push_back((int32_t)realIndex); list.push_back(bx); list.push_back(by);
+            sampleOf.push_back(i);
+        }
+        const int64_t nv = (int64_t)sampleOf.size();
+        if (nv == 0) return;
+        hipStream_t st = ctx->stream;
+        m->list.reserve(sizeof(int32_t) * list.size());
+        int32_t* pin = (int32_t*)fd_pinned(ctx, sizeof(int32_t) * list.size());
+        std::memcpy(pin, list.data(), sizeof(int32_t) * list.size());
+        HIP_CHECK(hipMemcpyAsync(m->list.p, pin, sizeof(int32_t) * list.size(), hipMemcpyHostToDevice, st));
+        WinTable wt;
+        std::memset(&wt, 0, sizeof(wt));
+        wt.n = (int32_t)p->kept.size();
+        wt.sx = wt.sy = 1;
+        wt.total = nv;
+        wt.list = m->list.as<int32_t>();
+        for (size_t i = 0; i < p->kept.size(); ++i) {
+            const HostLayer& L = p->all[p->kept[i]];
+            wt.l[i].lw = L.w; wt.l[i].off = L.gray_off; wt.l[i].nx = 1; wt.l[i].ny = 1; wt.l[i].magic = 0xffffffffu; wt.l[i].first = INT64_MAX;
+        }
+        WvmRun run;
+        wvm_launch_table(ctx, p, m, wt, true, run, false);
+        fd_wvm_finish(ctx, m, run);
+        std::vector<float> fout((size_t)nv);
+        HIP_CHECK(hipMemcpy(fout.data(), m->all_fout.p, sizeof(float) * (size_t)nv, hipMemcpyDeviceToHost));
+        std::vector<double> prob((size_t)nv);
+        for (int64_t k = 0; k < nv; ++k) {
+            prob[k] = wvm_probability(m, (double)fout[k]);
+            weight[sampleOf[k]] = 0.5 * prob[k];
+        }
+        struct Remaining { int64_t item; double prob; uint32_t slot; };
+        std::vector<Remaining> remaining;
+        for (size_t i = 0; i < run.pos.size(); ++i) {   // WVM positives in sample order
+            const int64_t item = (int64_t)(((uint64_t)run.pos[i].wid_hi << 32) | run.pos[i].wid_lo);
+            remaining.push_back(Remaining{item, prob[item], run.slots[i]});
+        }
+        if (remaining.empty()) return;
+        if (remaining.size() > 8) {   // sort(indirect, greater<ClassifiedPatch>()) + resize(8), WvmSvmModel.cpp:100-103
+            std::sort(remaining.begin(), remaining.end(), [](const Remaining& a, const Remaining& b) { return a.prob > b.prob; });
+            remaining.resize(8);
+        }
+        uint32_t slots[8];
+        double dist[8];
+        for (size_t i = 0; i < remaining.size(); ++i) slots[i] = remaining[i].slot;
+        DevBuf& idx = m->all_level;   // scratch
+        idx.reserve(64);
+        m->all_fout.reserve(sizeof(double) * 8 + sizeof(float) * (size_t)nv);
+        HIP_CHECK(hipMemcpy(idx.p, slots, sizeof(uint32_t) * remaining.size(), hipMemcpyHostToDevice));
+        fd_svm_generic_launch(ctx, svm, m->pos_patches.p, idx.as<uint32_t>(), (int64_t)m->dev.d, (int64_t)remaining.size(), m->all_fout.as<double>());
+        HIP_CHECK(hipStreamSynchronize(st));
+        HIP_CHECK(hipMemcpy(dist, m->all_fout.p, sizeof(double) * remaining.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < remaining.size(); ++i) {
+            const int sidx = sampleOf[remaining[i].item];
+            target[sidx] = dist[i] >= (double)fd_svm_threshold(svm) ? 1 : 0;
+            weight[sidx] = 2 * weight[sidx] * fd_svm_probability(svm, dist[i]);
+        }
     });
 }
 

@@ -1126,3 +1126,58 @@ Mat SdmLandmarkModelFitting::optimize(Mat modelShape, Mat image) {
 }
 
 }  // namespace superviseddescent
+
+// =================================================================================================
+#include "condensation/condensation_all.hpp"
+namespace condensation {
+
+double Sample::aspectRatio = 1;
+
+WvmSvmModel::WvmSvmModel(shared_ptr<imageprocessing::FeatureExtractor> featureExtractor, shared_ptr<classification::ProbabilisticWvmClassifier> wvm,
+                         shared_ptr<classification::ProbabilisticSvmClassifier> svm)
+    : featureExtractor(featureExtractor), wvm(wvm), svm(svm) {}
+void WvmSvmModel::update(shared_ptr<imageprocessing::VersionedImage> image) { featureExtractor->update(image); }
+static imageprocessing::DirectPyramidFeatureExtractor* fused_extractor(const shared_ptr<imageprocessing::FeatureExtractor>& fe) {
+    auto* d = dynamic_cast<imageprocessing::DirectPyramidFeatureExtractor*>(fe.get());
+    if (!d || !d->hasHistEq64())
+        throw std::logic_error("WvmSvmModel: this backend needs a DirectPyramidFeatureExtractor with a HistEq64Filter patch filter");
+    return d;
+}
+void WvmSvmModel::evaluate(Sample& sample) const {   // WvmSvmModel.cpp:44-67 (single sample: no top-8 selection)
+    auto patch = featureExtractor->extract(sample.getX(), sample.getY(), sample.getWidth(), sample.getHeight());
+    if (!patch) {
+        sample.setTarget(false);
+        sample.setWeight(0);
+        return;
+    }
+    auto wvmResult = wvm->getProbability(patch->getData());
+    if (wvmResult.first) {
+        auto svmResult = svm->getProbability(patch->getData());
+        sample.setTarget(svmResult.first);
+        sample.setWeight(wvmResult.second * svmResult.second);
+    } else {
+        sample.setTarget(false);
+        sample.setWeight(0.5 * wvmResult.second);
+    }
+}
+void WvmSvmModel::evaluate(shared_ptr<imageprocessing::VersionedImage> image, vector<shared_ptr<Sample>>& samples) {   // :69-118
+    update(image);
+    auto* direct = fused_extractor(featureExtractor);
+    const int n = (int)samples.size();
+    if (n == 0) return;
+    vector<int32_t> xywh((size_t)4 * n);
+    for (int i = 0; i < n; ++i) {
+        xywh[4 * i] = samples[i]->getX(); xywh[4 * i + 1] = samples[i]->getY();
+        xywh[4 * i + 2] = samples[i]->getWidth(); xywh[4 * i + 3] = samples[i]->getHeight();
+    }
+    vector<uint8_t> target((size_t)n);
+    vector<double> weight((size_t)n);
+    check(fd_wvm_svm_evaluate_samples(context(), direct->getPyramid()->native(), wvm->getWvm()->native(wvm->getLogisticA(), wvm->getLogisticB()),
+                                      svm->getSvm()->native(svm->getLogisticA(), svm->getLogisticB()), n, xywh.data(), target.data(), weight.data()));
+    for (int i = 0; i < n; ++i) {
+        samples[i]->setTarget(target[i] != 0);
+        samples[i]->setWeight(weight[i]);
+    }
+}
+
+}  // namespace condensation

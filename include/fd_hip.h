@@ -146,6 +146,14 @@ int fd_detect_wvm(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm, int step_x, int
 int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm, const fd_svm* svm, float oe_dist,
                          float oe_ratio, int step_x, int step_y, const int* roi, fd_detection* out, int cap,
                          int* count, int32_t* stage_counts);
+/* condensation::WvmSvmModel::evaluate(image, samples) (WvmSvmModel.cpp:69-118): the particle-filter
+ * measurement model of the tracking apps on an updated gray pyramid.  xywh: n samples {x, y, width, height} (Sample::getX/
+ * getY/getWidth/getHeight).  Every sample maps to one window (DirectPyramidFeatureExtractor::extract(x, y, width, height)),
+ * weight = 0.5 p_wvm; the (at most 8) most probable WVM positives are re-scored: target = SVM decision, weight = p_wvm p_svm;
+ * samples without a patch get weight 0. */
+int fd_wvm_svm_evaluate_samples(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm, const fd_svm* svm, int n, const int32_t* xywh,
+                                uint8_t* target, double* weight);
+
 /* Several five-stage detectors in one call (the detector loop of ffpDetectApp.cpp:557-600; BASELINE config 3).  All WVM
  * stages are queued first; the host-side stages of detector i overlap the GPU work of detectors i+1...  Two jobs may
  * share a pyramid (identical layers) but not a WVM handle.  Per job: count / stage_counts / status are outputs. */

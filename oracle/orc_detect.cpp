@@ -124,6 +124,63 @@ static void sliding_wvm(const Pyramid& p, const Wvm& m, int stepX, int stepY, co
     }
 }
 
+// DirectPyramidFeatureExtractor::extract(x, y, width, height) (DirectPyramidFeatureExtractor.cpp:67-73,134-153) with
+// ImagePyramid::getLayer(double scaleFactor) / getLayer(int index) (ImagePyramid.cpp:300-310): the window of the
+// sample, or false when there is no such layer / the patch leaves the layer.
+static bool extract_single(const Pyramid& p, int pw, int ph, int x, int y, int width, int height, Window& w) {
+    if (p.layers.empty()) return false;
+    const double scaleFactor = (double)pw / (double)width;
+    const double power = std::log(scaleFactor) / std::log(p.incScale);
+    const int index = (int)std::round(power);
+    const int realIndex = index - p.layers.front().index;   // layers are sorted by index, consecutive
+    if (realIndex < 0 || realIndex >= (int)p.layers.size()) return false;
+    const Layer& L = p.layers[realIndex];
+    const int bx = cvRound((x - width / 2) * L.scale), by = cvRound((y - height / 2) * L.scale);
+    if (bx < 0 || by < 0 || bx + pw > L.img.w || by + ph > L.img.h) return false;
+    w.layer = realIndex; w.lx = bx; w.ly = by;
+    w.ow = cvRound(pw / L.scale); w.oh = cvRound(ph / L.scale);
+    w.cx = cvRound(bx / L.scale) + w.ow / 2;
+    w.cy = cvRound(by / L.scale) + w.oh / 2;
+    return true;
+}
+
+// condensation::WvmSvmModel::evaluate(image, samples) (WvmSvmModel.cpp:69-118) with a DirectPyramidFeatureExtractor +
+// HistEq64Filter.  The cache map is keyed by shared_ptr<Patch> with the default (pointer) hash and equality
+// (WvmSvmModel.hpp:61) and extract() makes a new Patch per call, so the cache never hits: every sample is scored.
+static void wvm_svm_evaluate(const Pyramid& p, const Wvm& wvm, const Svm& svm, int n, const int32_t* xywh, uint8_t* target, double* weight) {
+    struct Remaining { int sample; double prob; std::vector<uchar> data; };
+    std::vector<Remaining> remaining;
+    std::vector<uchar> eq((size_t)wvm.fw * wvm.fh);
+    for (int i = 0; i < n; ++i) {
+        target[i] = 0;
+        Window w;
+        if (!extract_single(p, wvm.fw, wvm.fh, xywh[4 * i], xywh[4 * i + 1], xywh[4 * i + 2], xywh[4 * i + 3], w)) {
+            weight[i] = 0;
+            continue;
+        }
+        const ImgU8& img = p.layers[w.layer].img;
+        histeq64(img.d.data() + (size_t)w.ly * img.w + w.lx, wvm.fw, wvm.fh, img.w, eq.data());
+        int level; float fout;
+        wvm.eval(eq.data(), level, fout);
+        const double prob = wvm.probability(fout);
+        if (wvm.classify(level, fout)) remaining.push_back(Remaining{i, prob, eq});
+        weight[i] = 0.5 * prob;
+    }
+    if (!remaining.empty()) {
+        if (remaining.size() > 8) {
+            // sort(make_indirect_iterator(...), greater<ClassifiedPatch>()): probability descending, unstable;
+            // restated with the same std::sort on the same sequence of keys
+            std::sort(remaining.begin(), remaining.end(), [](const Remaining& a, const Remaining& b) { return a.prob > b.prob; });
+            remaining.resize(8);
+        }
+        for (const Remaining& r : remaining) {
+            const double dist = svm.distance(r.data.data());
+            target[r.sample] = svm.classify(dist) ? 1 : 0;
+            weight[r.sample] = 2 * weight[r.sample] * svm.probability(dist);
+        }
+    }
+}
+
 // FiveStageSlidingWindowDetector.cpp:187-320 (roi == nullptr) and :331-380 (roi != nullptr)
 static std::vector<orc_det> five_stage(const Pyramid& p, int imgW, int imgH, const Wvm& wvm, const Svm& svm,
                                        float oeDist, float oeRatio, int stepX, int stepY, const int* roi,
@@ -194,6 +251,17 @@ int64_t orc_sliding_wvm(const orc_pyramid* p, const orc_wvm* m, int stepX, int s
     sliding_wvm(*(const Pyramid*)p, *(const Wvm*)m, stepX, stepY, roi, pos, all_level, all_fout);
     for (int64_t i = 0; i < (int64_t)pos.size() && i < cap; ++i) out[i] = pos[i].det;
     return (int64_t)pos.size();
+}
+
+int orc_extract_single(const orc_pyramid* p, int pw, int ph, int x, int y, int width, int height, int32_t* out7) {
+    Window w;
+    if (!extract_single(*(const Pyramid*)p, pw, ph, x, y, width, height, w)) return 0;
+    out7[0] = w.layer; out7[1] = w.lx; out7[2] = w.ly; out7[3] = w.cx; out7[4] = w.cy; out7[5] = w.ow; out7[6] = w.oh;
+    return 1;
+}
+void orc_wvm_svm_evaluate(const orc_pyramid* p, const orc_wvm* wvm, const orc_svm* svm, int n, const int32_t* xywh, uint8_t* target,
+                          double* weight) {
+    wvm_svm_evaluate(*(const Pyramid*)p, *(const Wvm*)wvm, *(const Svm*)svm, n, xywh, target, weight);
 }
 
 int orc_five_stage(const orc_pyramid* p, int imgW, int imgH, const orc_wvm* wvm, const orc_svm* svm, float oeDist,

@@ -338,6 +338,24 @@ class Svm:
         return lib().orc_svm_probability(self.h, float(d))
 
 
+def extract_single(pyr, pw, ph, x, y, width, height):
+    """DirectPyramidFeatureExtractor::extract(x, y, width, height): (layerPos, lx, ly, cx, cy, ow, oh) or None"""
+    out = np.zeros(7, np.int32)
+    lib().orc_extract_single.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
+    ok = lib().orc_extract_single(pyr.h, pw, ph, int(x), int(y), int(width), int(height), _p(out))
+    return tuple(int(v) for v in out) if ok else None
+
+
+def wvm_svm_evaluate(pyr, wvm, svm, samples):
+    """condensation::WvmSvmModel::evaluate(image, samples) (WvmSvmModel.cpp:69-118); samples: (n, 4) {x, y, width, height}"""
+    samples = _c(samples, np.int32).reshape(-1, 4)
+    target = np.zeros(len(samples), np.uint8)
+    weight = np.zeros(len(samples), np.float64)
+    lib().orc_wvm_svm_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib().orc_wvm_svm_evaluate(pyr.h, wvm.h, svm.h, len(samples), _p(samples), _p(target), _p(weight))
+    return target.astype(bool), weight
+
+
 class Rvm:
     """RvmClassifier / ProbabilisticRvmClassifier (RvmClassifier.cpp:75-126); model dict as featuredetection_amd.synth.make_rvm"""
     def __init__(self, m):

@@ -222,3 +222,57 @@ def test_ffp_detect_app_prvm_single_detector(tmp_path, oracle, synth, frame640):
         lp, lx, ly, cx, cy, ow, oh = [int(v) for v in wins[i]]
         assert [int(v) for v in g[2:6]] == [cx - ow // 2, cy - oh // 2, ow, oh]
         assert abs(float(g[6]) - ro.probability(dd[i])) <= 1e-9
+
+
+def test_condensation_eval_app_matches_oracle(tmp_path, oracle, synth, frame640, small_models):
+    """condensation::WvmSvmModel (C++ mirror) through condensation_eval_app vs the oracle's restatement of WvmSvmModel.cpp:69-118."""
+    app = os.path.join(PKG, "condensation_eval_app")
+    if not os.path.exists(app):
+        pytest.fail("host apps not built (make -C featuredetection_amd/host)")
+    wvm, svm = small_models
+    synth.save_wvm(str(tmp_path / "face.fdwvm"), wvm)
+    synth.save_svm_text(str(tmp_path / "face.svm.txt"), svm, rows=20, cols=20)
+    synth.save_pnm(str(tmp_path / "frame.ppm"), frame640)
+    cfg = """detectors
+{
+    FaceFrontal
+    {
+        firstClassifier pwvm
+        {
+            classifierFile %s
+        }
+        secondClassifier psvm
+        {
+            classifierFile %s
+            threshold %s
+        }
+        pyramid
+        {
+            minScaleFactor 0.05
+            maxScaleFactor 0.16
+            incrementalScaleFactor 0.92
+            patch
+            {
+                width 20
+                height 20
+            }
+        }
+    }
+}
+""" % (tmp_path / "face.fdwvm", tmp_path / "face.svm.txt", repr(float(svm["threshold"])))
+    (tmp_path / "face.cfg").write_text(cfg)
+    po = oracle.Pyramid(inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))
+    po.update(frame640)
+    wo, so = oracle.Wvm(wvm), oracle.Svm(svm)
+    pos, _, _ = oracle.sliding_wvm(po, wo, 1, 1)
+    rng = np.random.default_rng(3)
+    size = rng.integers(100, 440, 400)
+    samples = np.stack([rng.integers(0, 640, 400), rng.integers(0, 480, 400), size], 1)
+    samples = np.concatenate([samples, np.array([[d["cx"], d["cy"], d["w"]] for d in pos[:20]])]).astype(np.int32)
+    (tmp_path / "samples.txt").write_text("".join("%d %d %d\n" % tuple(r) for r in samples))
+    out = _run([app, str(tmp_path / "face.cfg"), str(tmp_path / "frame.ppm"), str(tmp_path / "samples.txt")])
+    got = np.array([[float(v) for v in l.split()] for l in out.strip().splitlines()])
+    to, wt = oracle.wvm_svm_evaluate(po, wo, so, np.concatenate([samples, samples[:, 2:3]], 1))   # Sample::aspectRatio = 1
+    assert len(got) == len(samples)
+    assert np.array_equal(got[:, 0].astype(bool), to) and (wt > 0).sum() > 20
+    assert np.allclose(got[:, 1], wt, rtol=1e-12, atol=0)

@@ -478,6 +478,37 @@ def test_five_stage_batch_equals_single_calls(oracle, capi, ctx, synth, frame640
     pA.close(); pB.close()
 
 
+def test_condensation_wvm_svm_model(oracle, capi, ctx, frame640, small_models):
+    """condensation::WvmSvmModel::evaluate (particle-filter measurement model): samples -> single-patch windows
+    (DirectPyramidFeatureExtractor::extract(x, y, w, h)) -> WVM for all, SVM for the 8 most probable positives."""
+    wvm, svm = small_models
+    po, pg = _pyr_pair(oracle, capi, ctx, frame640, **FF)
+    wo, so = oracle.Wvm(wvm), oracle.Svm(svm)
+    wg, sg = capi.Wvm(ctx, wvm), capi.Svm(ctx, svm)
+    rng = np.random.default_rng(12)
+    n = 3000
+    size = rng.integers(90, 460, n)                       # FaceFrontal layers cover patch widths of about 125..400 px
+    samples = np.stack([rng.integers(-20, 660, n), rng.integers(-20, 500, n), size, size], 1).astype(np.int32)
+    # dense cluster around WVM positives so that more than 8 samples survive the cascade
+    pos, _, _ = oracle.sliding_wvm(po, wo, 1, 1)
+    assert len(pos) > 8
+    extra = np.array([[d["cx"], d["cy"], d["w"], d["h"]] for d in pos[:40]], np.int32)
+    samples = np.concatenate([samples, extra, extra[:5]])
+    to, wo_ = oracle.wvm_svm_evaluate(po, wo, so, samples)
+    tg, wg_ = capi.wvm_svm_evaluate(ctx, pg, wg, sg, samples)
+    assert np.array_equal(tg, to)
+    assert np.allclose(wg_, wo_, rtol=1e-12, atol=0)
+    valid = np.array([oracle.extract_single(po, 20, 20, *s_) is not None for s_ in samples])
+    assert 100 < valid.sum() < len(samples) and np.all(wo_[~valid] == 0) and np.all(wo_[valid] > 0)
+    assert 1 <= to.sum() <= 8
+    # empty / all-invalid inputs
+    t0, w0 = capi.wvm_svm_evaluate(ctx, pg, wg, sg, np.zeros((0, 4), np.int32))
+    assert len(t0) == 0
+    t1, w1 = capi.wvm_svm_evaluate(ctx, pg, wg, sg, np.array([[5, 5, 3000, 3000], [100, 100, 0, 0]], np.int32))
+    assert not t1.any() and np.all(w1 == 0)
+    wg.close(); sg.close(); pg.close()
+
+
 def test_hog_rbf_svm_detector_config2(oracle, capi, ctx, synth):
     """BASELINE config 2 shape on a reduced frame: HOG-324 + RBF SVM (MFMA path).  Scores within
     1e-4 relative (of the natural scale sum|coeff_i| K_i), positives identical away from the threshold."""
