@@ -428,6 +428,217 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     }
 }
 
+// ---- stage A, two windows per wavefront -------------------------------------------------------------
+// Lanes 0-31 hold the columns of window 2p, lanes 32-63 of window 2p+1 (adjacent in extraction order), one register
+// per patch row.  Per wave-instruction count is that of the one-window kernel, but it serves two windows wherever the
+// work was wave-uniform before: the level evaluation (rect lookups use 32 lanes per window, the scalar fp64 chain runs
+// once per half), the sum-of-squares chain, window decode and the model prefetch; the two fp32 cdf chains interleave.
+// The two windows run the cascade in lockstep (same level k); a half that has left simply idles.
+// Requires a compile-time patch size with PW <= 32 and numPer <= 32.
+template <int PW_, int PH_>
+struct __attribute__((aligned(16))) PairLds {
+    unsigned int hist[2][64];   // histograms, then the two LUTs
+    int sv[2][WVM_MAX_VALS];
+    float u[2][32];             // u_kernel_eval of each window
+    unsigned int ii[2][PW_ * PH_];
+};
+
+template <int PW_, int PH_, bool RAW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_wvm_cascade2(const uint8_t* __restrict__ arena, WinTable wt, WvmDev m,
+                                                                                                  CascadeOut o) {
+    static_assert(PW_ > 0 && PW_ <= 32, "two-window layout needs a compile-time width <= 32");
+    __shared__ PairLds<PW_, PH_> lds[4];
+    __shared__ int64_t sFirst[WVM_MAX_LAYERS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    PairLds<PW_, PH_>& L = lds[wave];
+    const int half = lane >> 5, c = lane & 31;
+    const bool colok = c < PW_;
+    constexpr int d = PW_ * PH_;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int F = m.numFilters;
+    const int nA = min(m.numUsed, WVM_LCAP);
+    const int halfBase = lane & 32;
+
+    if (!RAW) {
+        if (threadIdx.x < WVM_MAX_LAYERS) sFirst[threadIdx.x] = (int)threadIdx.x < wt.n ? wt.l[threadIdx.x].first : INT64_MAX;
+        __syncthreads();
+    }
+    if (c < WVM_MAX_VALS) L.sv[half][c] = 0;
+    wave_sync();
+
+    const int64_t npairs = (wt.total + 1) >> 1;
+    for (int64_t pair = (int64_t)blockIdx.x * 4 + wave; pair < npairs; pair += nwaves) {
+        const int64_t wid0 = 2 * pair, wid1 = wid0 + 1;
+        const bool has1 = wid1 < wt.total;
+        const int64_t myWid = half ? wid1 : wid0;
+        const bool valid = half ? has1 : true;
+        int stride0, stride1;
+        const uint8_t* src0 = wvm_locate<RAW>(arena, wt, sFirst, wid0, lane, PW_, d, stride0);
+        const uint8_t* src1 = src0;
+        stride1 = stride0;
+        if (has1) src1 = wvm_locate<RAW>(arena, wt, sFirst, wid1, lane, PW_, d, stride1);
+        const uint8_t* src = half ? src1 : src0;
+        const int stride = half ? stride1 : stride0;
+
+        // level-0 model data: requested now, consumed after the fixed part
+        uint4 lv = m.lvlRec[c];
+        WvmLevelHdr hd = m.lvlHdr[0];
+        float w = m.wT[c];
+
+        // ---- 1. load the two windows (columns beyond the patch read column 0 and are masked later)
+        unsigned int px[PH_];
+        {
+            const uint8_t* sp = src + (colok ? c : 0);
+#pragma unroll
+            for (int r = 0; r < PH_; ++r) px[r] = sp[(size_t)r * stride];
+        }
+        if (!RAW) {
+            // ---- 2. HistEq64 of both windows: histograms by LDS atomics, the two fp32 cdf chains interleaved
+            L.hist[0][lane] = 0;
+            L.hist[1][lane] = 0;
+            wave_sync();
+            if (colok) {
+#pragma unroll
+                for (int r = 0; r < PH_; ++r) atomicAdd(&L.hist[half][px[r] >> 2], 1u);
+            }
+            wave_sync();
+            const float pdfA = (float)L.hist[0][lane] * m.stretch, pdfB = (float)L.hist[1][lane] * m.stretch;
+            float xA = pdfA, xB = pdfB;
+#pragma unroll
+            for (int t = 1; t < 64; ++t) {
+                const float sa = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(xA), DPP_WAVE_SHR1, 0xf, 0xf, true));
+                const float sb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(xB), DPP_WAVE_SHR1, 0xf, 0xf, true));
+                xA = sa + pdfA;
+                xB = sb + pdfB;
+            }
+            wave_sync();
+            L.hist[0][lane] = (unsigned int)(unsigned char)floor((double)xA + 0.5);
+            L.hist[1][lane] = (unsigned int)(unsigned char)floor((double)xB + 0.5);
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < PH_; ++r) {
+                const unsigned int e = L.hist[half][px[r] >> 2];
+                px[r] = colok ? e : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < PH_; ++r) px[r] = colok ? px[r] : 0u;
+        }
+        // ---- 3. integral images (row prefix by DPP inside each half, running column sum) and the sum of squares:
+        // lanes 31 / 63 see the row totals and run the fp32 chain of IImg.cpp:33-47 for their window
+        int colsum = 0;
+        float sxxc = 0.f;
+#pragma unroll
+        for (int r = 0; r < PH_; ++r) {
+            colsum += scan_half((int)px[r]);
+            if (colok) L.ii[half][r * PW_ + c] = (unsigned int)colsum;
+            const float qf = (float)scan_half((int)(px[r] * px[r]));
+            sxxc = r == 0 ? qf : sxxc + qf;
+        }
+        const float sxx = __int_as_float(__builtin_amdgcn_ds_bpermute((lane | 31) << 2, __float_as_int(sxxc)));
+        const int sx_total = __builtin_amdgcn_ds_bpermute((halfBase + PW_ - 1) << 2, colsum);
+        L.u[half][c] = 0.f;
+        wave_sync();
+
+        // ---- 4. first levels of the cascade, both windows in lockstep
+        const unsigned int* ii = L.ii[half];
+        int* sv = L.sv[half];
+        float Pb = m.negBias;   // lane c of each half: running sum of level c (c < 32)
+        bool alive = valid, deep = false;
+        int level = 0, n = 0;
+        float fout = 0.f, thr = 0.f;
+        for (int k = 0;; ++k) {
+            const int kn = min(k + 1, nA - 1);
+            const uint4 lvN = m.lvlRec[(size_t)kn * 64 + c];
+            const WvmLevelHdr hdN = m.lvlHdr[kn];
+            const float wN = m.wT[(size_t)kn * F + c];
+            // rect sums: 32 rects per pass and window
+            for (int rb = 0; rb < hd.nrects; rb += 32) {
+                unsigned int rc, vt;
+                if (rb == 0) { rc = lv.x; vt = lv.y; }
+                else if (rb < 64) { const uint4 t = m.lvlRec[(size_t)k * 64 + rb + c]; rc = t.x; vt = t.y; }
+                else { const int ri = m.rectBegin[k] + min(rb + c, hd.nrects - 1); rc = m.rects[ri]; vt = m.rectV[ri]; }
+                if (alive && rb + c < hd.nrects) {
+                    const int x1 = rc & 255, y1 = (rc >> 8) & 255, x2 = (rc >> 16) & 255, y2 = rc >> 24;
+                    int s = (int)ii[y2 * PW_ + x2];
+                    if (x1 > 0) s -= (int)ii[y2 * PW_ + x1 - 1];
+                    if (y1 > 0) s -= (int)ii[(y1 - 1) * PW_ + x2];
+                    if (x1 > 0 && y1 > 0) s += (int)ii[(y1 - 1) * PW_ + x1 - 1];
+                    atomicAdd(&sv[vt], s);
+                }
+            }
+            wave_sync();
+            // the reference's scalar chain (WvmClassifier.cpp:308-346), once per half
+            const double valL = __hiloint2double((int)lv.w, (int)lv.z);
+            double sum_xp = 0.0;
+            int sumv0 = sx_total;
+            for (int v = 1; v < hd.cntval; ++v) {
+                const int s = sv[v];
+                sumv0 -= s;
+                const double prod = (double)s * readlane_d(valL, v);
+                sum_xp = sum_xp + prod;
+            }
+            const double t0 = (double)sumv0 * readlane_d(valL, 0);
+            sum_xp = sum_xp + t0;
+            sum_xp = sum_xp + (double)L.u[half][n];
+            const float unew = (float)sum_xp;
+            wave_sync();
+            if (c < WVM_MAX_VALS) sv[c] = 0;
+            if (c == 0) L.u[half][n] = unew;
+            double norm = (double)sxx;
+            norm = norm - 2 * sum_xp;
+            norm = norm + hd.pp;
+            const float Kk = (float)exp((double)m.negBasis * norm);
+            {
+                const float t = w * Kk;   // weights above the diagonal are stored as 0
+                Pb = Pb + t;
+            }
+            const float fk = __int_as_float(__builtin_amdgcn_ds_bpermute((halfBase + k) << 2, __float_as_int(Pb)));
+            if (alive) {
+                if (!(fk >= hd.thr && k + 1 < m.numUsed)) {   // leaves the cascade here
+                    level = k; fout = fk; thr = hd.thr;
+                    alive = false;
+                } else if (k + 1 == nA) {                     // survives stage A: finished by k_wvm_deep
+                    deep = true;
+                    alive = false;
+                }
+            }
+            if (!__any(alive)) break;
+            lv = lvN;
+            hd = hdN;
+            w = wN;
+            if (++n == m.numPer) n = 0;
+        }
+        // ---- 5. results, per half
+        if (valid) {
+            if (deep) {
+                if (c == 0) o.deep_q[atomicAdd(o.deep_count, 1u)] = myWid;
+            } else {
+                const bool positive = (level + 1 == m.numFilters) && (fout >= thr);
+                if (c == 0) {
+                    if (o.all_level) o.all_level[myWid] = level;
+                    if (o.all_fout) o.all_fout[myWid] = fout;
+                }
+                if (positive) {
+                    unsigned int slot = 0;
+                    if (c == 0) slot = atomicAdd(o.pos_count, 1u);
+                    slot = (unsigned int)__builtin_amdgcn_ds_bpermute(halfBase << 2, (int)slot);
+                    if (slot < o.pos_cap) {
+                        if (c == 0) o.pos[slot] = PosRec{(uint32_t)myWid, (uint32_t)(myWid >> 32), level, fout};
+                        uint8_t* dst = o.pos_patches + (size_t)slot * d;
+                        if (colok) {
+#pragma unroll
+                            for (int r = 0; r < PH_; ++r) dst[r * PW_ + c] = (uint8_t)px[r];
+                        }
+                    }
+                }
+            }
+        }
+        wave_sync();
+    }
+}
+
 // ---- stage B: one workgroup per surviving window ---------------------------------------------------
 // The kernel values K_k of different filters are independent of each other except through
 // u_kernel_eval[k % numPer] (written numPer filters earlier), so the four waves evaluate disjoint
@@ -569,8 +780,21 @@ void launch_sized(fd_ctx* ctx, hipStream_t st, int64_t total, const WvmDev& dev,
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuA, k_wvm_cascade<PW_, PH_, RAW>, 256, 0) != hipSuccess || perCuA < 1) perCuA = 4;
         if (const char* e = getenv("FD_WVM_GRID_PER_CU")) if (atoi(e) > 0) perCuA = atoi(e);
     }
+    static const bool single = getenv("FD_WVM_SINGLE") != nullptr;
+    bool launched = false;
+    if constexpr (PW_ > 0 && PW_ <= 32) {
+        if (dev.numPer <= 32 && !single) {   // two windows per wavefront
+            static int perCu2 = 0;
+            if (perCu2 == 0) {
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu2, k_wvm_cascade2<PW_, PH_, RAW>, 256, 0) != hipSuccess || perCu2 < 1) perCu2 = 4;
+            }
+            const int grid2 = (int)std::min<int64_t>((total + 7) / 8, (int64_t)ctx->num_cus * perCu2 * 2);
+            hipLaunchKernelGGL((k_wvm_cascade2<PW_, PH_, RAW>), dim3(grid2), dim3(256), 0, st, arena, wt, dev, o);
+            launched = true;
+        }
+    }
     const int gridA = (int)std::min<int64_t>((total + 3) / 4, (int64_t)ctx->num_cus * perCuA * 2);   // two full rounds
-    hipLaunchKernelGGL((k_wvm_cascade<PW_, PH_, RAW>), dim3(gridA), dim3(256), 0, st, arena, wt, dev, o);
+    if (!launched) hipLaunchKernelGGL((k_wvm_cascade<PW_, PH_, RAW>), dim3(gridA), dim3(256), 0, st, arena, wt, dev, o);
     if (dev.numUsed <= WVM_LCAP) return;
     static int perCu = 0;
     if (perCu == 0) {
