@@ -444,7 +444,7 @@ struct __attribute__((aligned(16))) PairLds {
 };
 
 template <int PW_, int PH_, bool RAW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_wvm_cascade2(const uint8_t* __restrict__ arena, WinTable wt, WvmDev m,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_wvm_cascade2(const uint8_t* __restrict__ arena, WinTable wt, WvmDev m,
                                                                                                   CascadeOut o) {
     static_assert(PW_ > 0 && PW_ <= 32, "two-window layout needs a compile-time width <= 32");
     __shared__ PairLds<PW_, PH_> lds[4];
