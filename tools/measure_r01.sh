@@ -12,6 +12,9 @@ for wl in hog_svm wvm sdm; do
 done
 $B --workload wvm --size 1920x1080 --no-cpu-baseline > $O/bench_wvm_1080p.json 2> $O/bench_wvm_1080p.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_wvm_1080p -- $B --workload wvm --size 1920x1080 --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+timeout 200 $B --workload ffp15 --steps 5 --warmup 2 > $O/bench_ffp15.json 2> $O/bench_ffp15.err
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ffp15 -- $B --workload ffp15 --steps 3 --warmup 1 > /dev/null 2>&1
+timeout 200 $B --workload rvm --size 1920x1080 --no-cpu-baseline > $O/bench_rvm_1080p.json 2> $O/bench_rvm_1080p.err
 for wl in hog_svm wvm; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$wl -- $B --workload $wl --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$wl -- $B --workload $wl --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
