@@ -43,6 +43,24 @@ def test_overlap_elimination_matches_oracle(oracle, capi, dist, ratio):
         assert np.array_equal(oracle.overlap_elimination(o, dist, ratio), capi.overlap_elimination(c, dist, ratio))
 
 
+def test_overlap_elimination_large_clustered(oracle, capi):
+    """The hashed-grid implementation against the reference-shaped O(n^2) loop at the sizes config 3 produces
+    (thousands of WVM positives, clustered, also with negative coordinates)."""
+    rng = np.random.default_rng(77)
+    n = 6000
+    centres = rng.integers(-40, 1900, (60, 2))
+    pick = rng.integers(0, 60, n)
+    o, c = _random_dets(oracle, capi, rng, n, w=1920, h=1080)
+    o["cx"] = centres[pick, 0] + rng.integers(-15, 16, n)
+    o["cy"] = centres[pick, 1] + rng.integers(-15, 16, n)
+    o["prob"] = np.round(rng.random(n), 3)   # many equal probabilities
+    for f in ("cx", "cy"):
+        c[f] = o[f]
+    c["probability"] = o["prob"]
+    for dist, ratio in ((5.0, 0.0), (0.05, 0.7), (12.5, 0.0)):
+        assert np.array_equal(oracle.overlap_elimination(o, dist, ratio), capi.overlap_elimination(c, dist, ratio))
+
+
 def test_overlap_elimination_ties(oracle, capi):
     rng = np.random.default_rng(9)
     o, c = _random_dets(oracle, capi, rng, 200, w=120, h=90, tie=True)
