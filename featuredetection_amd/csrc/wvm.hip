@@ -646,15 +646,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 // registers.  After every chunk of whole "generations" (numPer filters each, at most 64 filters) one
 // wave forms the hierarchical sums of the chunk's filters lane-parallel -- lane == filter, each lane
 // adding its terms in the reference order -- and the first failed threshold ends the window.
-template <int PW_, int PH_, bool RAW>
-__global__ __launch_bounds__(256) void k_wvm_deep(const uint8_t* __restrict__ arena, WinTable wt, WvmDev m, CascadeOut o) {
+template <int PW_, int PH_, bool RAW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_wvm_deep(const uint8_t* __restrict__ arena, WinTable wt, WvmDev m, CascadeOut o) {
     constexpr int RHMAX = Geo<PW_, PH_>::RHMAX;
+    constexpr int MAXOWN = (WVM_PJ + NW - 1) / NW;   // 64-level blocks owned by one wave (block j belongs to wave j % NW)
     __shared__ unsigned int ii[Geo<PW_, PH_>::IISZ];
-    __shared__ unsigned int hist[4][64];
-    __shared__ int sv[4][WVM_MAX_VALS];
+    __shared__ unsigned int hist[NW][64];
+    __shared__ int sv[NW][WVM_MAX_VALS];
     __shared__ float kh[64 * WVM_PJ];
     __shared__ int64_t sFirst[WVM_MAX_LAYERS];
-    __shared__ int sExit[2];   // exit level (or -1), fout bits
+    __shared__ unsigned long long sExit;   // (first failed level << 32 | fp32 bits of its sum), minimum over the candidates
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const Geo<PW_, PH_> g(m, lane);
@@ -676,14 +677,20 @@ __global__ __launch_bounds__(256) void k_wvm_deep(const uint8_t* __restrict__ ar
         int sx_total;
         // every wave prepares the window (identical values; they all write the one integral image)
         wvm_prepare<PW_, PH_, RAW>(g, src, srcStride, m.stretch, lane, hist[wave], ii, px, sxx, sx_total);
+        if (threadIdx.x == 0) sExit = ~0ull;
         __syncthreads();
 
         float u = 0.f;   // lane n holds u_kernel_eval[n] (only this wave's classes are used)
+        // running hierarchical sums of the levels this wave owns (lane == level inside the block), in reference order:
+        // every chunk appends its kernel values to ALL later levels, so no level ever has to catch up
+        float Pacc[MAXOWN];
+#pragma unroll
+        for (int ow = 0; ow < MAXOWN; ++ow) Pacc[ow] = m.negBias;
         int level = NU - 1;
         float fout = 0.f;
         for (int c0 = 0; c0 < NU; c0 += chunk) {
             const int c1 = min(c0 + chunk, NU);
-            // ---- kernel values of this wave's filters in [c0, c1): generation-major, classes wave, wave+4, ...
+            // ---- kernel values of this wave's filters in [c0, c1): generation-major, classes wave, wave+NW, ...
             {
                 int k = c0 + wave;          // c0 is a multiple of NP
                 int n = wave, gbase = c0;
@@ -692,7 +699,7 @@ __global__ __launch_bounds__(256) void k_wvm_deep(const uint8_t* __restrict__ ar
                 WvmLevelHdr hd;
                 if (k < c1) { lv = m.lvlRec[(size_t)k * 64 + lane]; hd = m.lvlHdr[k]; }
                 while (k < c1) {
-                    int n2 = n + 4, gb2 = gbase;
+                    int n2 = n + NW, gb2 = gbase;
                     if (n2 >= NP) { n2 = wave; gb2 += NP; }
                     const int k2 = gb2 + n2;
                     const int kp = k2 < c1 ? k2 : k;
@@ -708,30 +715,35 @@ __global__ __launch_bounds__(256) void k_wvm_deep(const uint8_t* __restrict__ ar
                 }
             }
             __syncthreads();
-            // ---- hierarchical sums of the chunk: lane == filter c0 + lane
-            if (wave == 0) {
-                const int mm = c0 + lane;
-                float P = m.negBias;
+            // ---- hierarchical sums: add the chunk's terms to every owned level >= c0; check the levels inside the chunk
+#pragma unroll
+            for (int ow = 0; ow < MAXOWN; ++ow) {
+                const int blk = wave + ow * NW;
+                if (blk * 64 >= NU || blk * 64 + 63 < c0) continue;   // nothing owned here / already decided
+                const int mm = blk * 64 + lane;
                 const float* wp = m.wT + mm;
+                float P = Pacc[ow];
+                const float* wq = wp + (size_t)c0 * F;
 #pragma unroll 8
-                for (int i = 0; i < c1; ++i) {
-                    const float t = wp[(size_t)i * F] * kh[i];
+                for (int i = c0; i < c1; ++i, wq += F) {
+                    const float t = *wq * kh[i];
                     P = P + t;
                 }
-                const float thrm = mm < c1 ? m.thresholds[mm] : 0.f;
-                const bool fail = mm < c1 && !(P >= thrm && mm + 1 < NU);
+                Pacc[ow] = P;
+                const bool mine = mm >= c0 && mm < c1;
+                const float thrm = mine ? m.thresholds[mm] : 0.f;
+                const bool fail = mine && !(P >= thrm && mm + 1 < NU);
                 const unsigned long long fm = __ballot(fail);
-                if (lane == 0) sExit[0] = -1;
                 if (fm) {
                     const int e = __builtin_ctzll(fm);
-                    if (lane == e) { sExit[0] = c0 + e; sExit[1] = __float_as_int(P); }
+                    if (lane == e) atomicMin(&sExit, ((unsigned long long)(unsigned int)mm << 32) | (unsigned int)__float_as_int(P));
                 }
             }
             __syncthreads();
-            const int ex = sExit[0];
-            if (ex >= 0) {
-                level = ex;
-                fout = __int_as_float(sExit[1]);
+            const unsigned long long ex = sExit;
+            if (ex != ~0ull) {
+                level = (int)(ex >> 32);
+                fout = __int_as_float((int)(unsigned int)ex);
                 break;
             }
         }
@@ -796,12 +808,22 @@ void launch_sized(fd_ctx* ctx, hipStream_t st, int64_t total, const WvmDev& dev,
     const int gridA = (int)std::min<int64_t>((total + 3) / 4, (int64_t)ctx->num_cus * perCuA * 2);   // two full rounds
     if (!launched) hipLaunchKernelGGL((k_wvm_cascade<PW_, PH_, RAW>), dim3(gridA), dim3(256), 0, st, arena, wt, dev, o);
     if (dev.numUsed <= WVM_LCAP) return;
-    static int perCu = 0;
-    if (perCu == 0) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wvm_deep<PW_, PH_, RAW>, 256, 0) != hipSuccess || perCu < 1) perCu = 2;
+    // 8 waves per survivor: half the latency of 4 on small frames (45 vs 72 us at 640x480) and no worse in the
+    // throughput-bound cases (config 3: 48 vs 63 ms per frame); FD_WVM_DEEP_WAVES=4 selects the narrow variant
+    static int perCu4 = 0, perCu8 = 0;
+    if (perCu4 == 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu4, k_wvm_deep<PW_, PH_, RAW, 4>, 256, 0) != hipSuccess || perCu4 < 1) perCu4 = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu8, k_wvm_deep<PW_, PH_, RAW, 8>, 512, 0) != hipSuccess || perCu8 < 1) perCu8 = 1;
     }
-    const int gridB = (int)std::min<int64_t>(total, (int64_t)ctx->num_cus * perCu);
-    hipLaunchKernelGGL((k_wvm_deep<PW_, PH_, RAW>), dim3(gridB), dim3(256), 0, st, arena, wt, dev, o);
+    static const char* nwEnv = getenv("FD_WVM_DEEP_WAVES");
+    const bool wide = nwEnv ? atoi(nwEnv) != 4 : true;
+    if (wide) {
+        const int gridB = (int)std::min<int64_t>(total, (int64_t)ctx->num_cus * perCu8);
+        hipLaunchKernelGGL((k_wvm_deep<PW_, PH_, RAW, 8>), dim3(gridB), dim3(512), 0, st, arena, wt, dev, o);
+    } else {
+        const int gridB = (int)std::min<int64_t>(total, (int64_t)ctx->num_cus * perCu4);
+        hipLaunchKernelGGL((k_wvm_deep<PW_, PH_, RAW, 4>), dim3(gridB), dim3(256), 0, st, arena, wt, dev, o);
+    }
 }
 
 // patch sizes with compile-time geometry: the detectors of ffpDetectApp/*.cfg (20x20 faces, 24x24 lip / nose / eye
