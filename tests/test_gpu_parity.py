@@ -122,8 +122,9 @@ def test_wvm_full_size_model_and_other_patch_shapes(oracle, capi, ctx, synth, fr
     cfgs = dict(synth.DETECTOR_CFGS)
     cfgs["odd19x21"] = (0.9, 0.5, 0.7, 19, 21, 9, 4)   # run-time-sized kernel instance, odd height
     cfgs["tiny7x5"] = (0.9, 0.5, 0.7, 7, 5, 3, 4)
+    cfgs["nper40"] = (0.9, 0.5, 0.7, 20, 20, 40, 1)   # numPer > 32: one-window stage A kernel with compile-time geometry
     for (name, n_levels) in (("FaceFrontal", 20), ("LeftEyeCenter", 3), ("NoseTip", 2), ("LeftEarCenter", 2), ("LeftLipCorner", 2),
-                             ("odd19x21", 4), ("tiny7x5", 8)):
+                             ("odd19x21", 4), ("tiny7x5", 8), ("nper40", 2)):
         inc, mn, mx, pw, ph, nper, _ = cfgs[name]
         calib = synth.random_patches(gray[::2, ::2].copy(), pw, ph, 3000, rng)
         wvm = synth.make_wvm(31, fw=pw, fh=ph, n_per=nper, n_levels=n_levels, calib_patches=calib, min_survivors=48)
