@@ -148,13 +148,12 @@ def main():
         layer_bytes = sum(l["w"] * l["h"] for l in pyr.layers())
 
         def step(i, sync=True):
-            for j in range(NB):
-                f = dframes[(i * NB + j) % NFRAMES]
-                pyrs[j].update_device(f.data_ptr(), W, H, 3)
             if NB == 1:
+                pyrs[0].update_device(dframes[i % NFRAMES].data_ptr(), W, H, 3)
                 dets, st = capi.detect_five_stage(ctx, pyrs[0], wvms[0], svm)
                 return nwin_wvm, len(dets)
-            res = capi.detect_five_stage_batch(ctx, [(pyrs[j], wvms[j], svm) for j in range(NB)])
+            fr = [(dframes[(i * NB + j) % NFRAMES].data_ptr(), W, H, 3) for j in range(NB)]
+            res = capi.detect_five_stage_batch(ctx, [(pyrs[j], wvms[j], svm) for j in range(NB)], device_frames=fr)
             return nwin_wvm * NB, sum(len(d_) for d_, _ in res)
 
         units_name = "windows"

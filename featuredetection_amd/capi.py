@@ -75,7 +75,8 @@ class fd_whi_params(C.Structure):
 class fd_five_stage_job(C.Structure):
     _fields_ = [("pyramid", C.c_void_p), ("wvm", C.c_void_p), ("svm", C.c_void_p), ("oe_dist", C.c_float), ("oe_ratio", C.c_float),
                 ("step_x", C.c_int32), ("step_y", C.c_int32), ("roi", C.c_void_p), ("out", C.c_void_p), ("cap", C.c_int32),
-                ("count", C.c_int32), ("stage_counts", C.c_int32 * 4), ("status", C.c_int32)]
+                ("count", C.c_int32), ("stage_counts", C.c_int32 * 4), ("status", C.c_int32), ("image", C.c_void_p), ("image_w", C.c_int32),
+                ("image_h", C.c_int32), ("image_channels", C.c_int32), ("image_is_device", C.c_int32)]
 
 
 class fd_rvm_model(C.Structure):
@@ -393,8 +394,9 @@ def detect_five_stage(ctx, pyr, wvm, svm, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1,
     return out[:cnt.value], stages
 
 
-def detect_five_stage_batch(ctx, detectors, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1, cap=4096):
-    """detectors: list of (pyramid, wvm, svm); returns [(detections, stage_counts)] in the same order"""
+def detect_five_stage_batch(ctx, detectors, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1, cap=4096, device_frames=None):
+    """detectors: list of (pyramid, wvm, svm); returns [(detections, stage_counts)] in the same order.
+    device_frames: optional list of (device pointer, w, h, channels) per detector: the pyramid is updated inside the call"""
     n = len(detectors)
     jobs = (fd_five_stage_job * n)()
     outs = [np.zeros(cap, DET_DTYPE) for _ in range(n)]
@@ -402,6 +404,9 @@ def detect_five_stage_batch(ctx, detectors, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=
         j.pyramid, j.wvm, j.svm = pyr.h, wvm.h, svm.h
         j.oe_dist, j.oe_ratio, j.step_x, j.step_y, j.roi = oe_dist, oe_ratio, sx, sy, None
         j.out, j.cap = o.ctypes.data, cap
+    if device_frames is not None:
+        for j, (ptr, w, h, ch) in zip(jobs, device_frames):
+            j.image, j.image_w, j.image_h, j.image_channels, j.image_is_device = ptr, w, h, ch, 1
     ctx.check(lib().fd_detect_five_stage_batch(ctx.h, jobs, n))
     return [(o[:j.count], np.array(list(j.stage_counts), np.int32)) for j, o in zip(jobs, outs)]
 

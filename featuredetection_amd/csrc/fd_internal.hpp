@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <string>
 #include <vector>
@@ -25,6 +26,7 @@ struct fd_ctx {
     int num_cus = 256;
     FdPinned pinned;
     hipStream_t aux = nullptr;   // second stream (created on first use): small follow-up work that must not queue behind ctx->stream
+    hipStream_t pool[4] = {nullptr, nullptr, nullptr, nullptr};   // batch jobs are spread over these (created on first use)
 };
 
 struct FdError {
@@ -117,6 +119,19 @@ static inline hipStream_t fd_aux_stream(fd_ctx* ctx) {
     if (!ctx->aux) HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
     return ctx->aux;
 }
+
+static inline hipStream_t fd_pool_stream(fd_ctx* ctx, int i) {
+    static const int nstreams = [] { const char* e = getenv("FD_BATCH_STREAMS"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+    hipStream_t& s = ctx->pool[i % nstreams];
+    if (!s) HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return s;
+}
+struct FdStreamSwap {   // temporarily redirects everything that launches on ctx->stream
+    fd_ctx* c;
+    hipStream_t keep;
+    FdStreamSwap(fd_ctx* c_, hipStream_t s_) : c(c_), keep(c_->stream) { c->stream = s_; }
+    ~FdStreamSwap() { c->stream = keep; }
+};
 
 static inline int fd_cvRound(double v) { return (int)std::lrint(v); }  // cvRound: half-to-even
 

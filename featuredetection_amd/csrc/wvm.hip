@@ -1189,12 +1189,7 @@ static void five_stage_tail(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, const fd_svm*
         fprintf(stderr, "[fd five-stage] %-12s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t1 - t0).count());
         t0 = t1;
     };
-    struct StreamSwap {   // fd_svm_generic_launch works on ctx->stream
-        fd_ctx* c;
-        hipStream_t keep;
-        StreamSwap(fd_ctx* c_, hipStream_t s_) : c(c_), keep(c_->stream) { c->stream = s_; }
-        ~StreamSwap() { c->stream = keep; }
-    } swap(ctx, st);
+    FdStreamSwap swap(ctx, st);   // fd_svm_generic_launch works on ctx->stream
     std::vector<fd_detection> wvmPos;
     fd_wvm_positives_to_detections(p, m, run, sx, sy, wvmPos);
     if (stage_counts) stage_counts[0] = (int)wvmPos.size();
@@ -1295,9 +1290,19 @@ int fd_detect_five_stage_batch(fd_ctx* ctx, fd_five_stage_job* jobs, int n) {
                 if (jobs[k].wvm == j.wvm) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_batch: jobs %d and %d share a WVM handle", k, i);
             five_stage_check(j.wvm, j.svm);
         }
-        for (int i = 0; i < n; ++i)
-            fd_wvm_launch(ctx, jobs[i].pyramid, const_cast<fd_wvm*>(jobs[i].wvm), jobs[i].step_x, jobs[i].step_y, jobs[i].roi, false, runs[i], false);
-        hipStream_t ax = fd_aux_stream(ctx);
+        // jobs are spread over a few streams so that the small kernels of different jobs (pyramid levels, the deep
+        // cascade stage, the SVM stage) overlap each other; a job's optional frame upload / pyramid update runs on its stream
+        for (int i = 0; i < n; ++i) {
+            FdStreamSwap sw(ctx, fd_pool_stream(ctx, i));
+            fd_five_stage_job& j = jobs[i];
+            if (j.image) {
+                for (int k = 0; k < i; ++k)
+                    if (jobs[k].pyramid == j.pyramid) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_batch: jobs %d and %d update the same pyramid", k, i);
+                const int rc = fd_pyramid_update(j.pyramid, j.image, j.image_w, j.image_h, j.image_channels, j.image_is_device);
+                if (rc != FD_OK) throw FdError{rc, ctx->error};
+            }
+            fd_wvm_launch(ctx, j.pyramid, const_cast<fd_wvm*>(j.wvm), j.step_x, j.step_y, j.roi, false, runs[i], false);
+        }
         int firstError = FD_OK;
         for (int i = 0; i < n; ++i) {
             fd_five_stage_job& j = jobs[i];
@@ -1305,8 +1310,8 @@ int fd_detect_five_stage_batch(fd_ctx* ctx, fd_five_stage_job* jobs, int n) {
             try {
                 fd_wvm_finish(ctx, m, runs[i]);
                 int cnt = 0;
-                five_stage_tail(ctx, j.pyramid, m, j.svm, runs[i], j.oe_dist, j.oe_ratio, j.step_x, j.step_y, j.roi, ax, j.out, j.cap, &cnt,
-                                j.stage_counts);
+                five_stage_tail(ctx, j.pyramid, m, j.svm, runs[i], j.oe_dist, j.oe_ratio, j.step_x, j.step_y, j.roi, fd_pool_stream(ctx, i), j.out,
+                                j.cap, &cnt, j.stage_counts);
                 j.count = cnt;
             } catch (const FdError& e) {   // the remaining jobs are still collected; the first failure is reported
                 j.status = e.code;

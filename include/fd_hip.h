@@ -155,8 +155,9 @@ int fd_wvm_svm_evaluate_samples(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm, c
                                 uint8_t* target, double* weight);
 
 /* Several five-stage detectors in one call (the detector loop of ffpDetectApp.cpp:557-600; BASELINE config 3).  All WVM
- * stages are queued first; the host-side stages of detector i overlap the GPU work of detectors i+1...  Two jobs may
- * share a pyramid (identical layers) but not a WVM handle.  Per job: count / stage_counts / status are outputs. */
+ * stages are queued first (spread over a few internal streams, so that the small kernels of different jobs overlap);
+ * the host-side stages of detector i overlap the GPU work of detectors i+1...  Two jobs may share a pyramid
+ * (identical layers) but not a WVM handle.  Per job: count / stage_counts / status are outputs. */
 typedef struct {
     fd_pyramid* pyramid;
     const fd_wvm* wvm;
@@ -169,6 +170,10 @@ typedef struct {
     int32_t count;              /* out */
     int32_t stage_counts[4];    /* out */
     int32_t status;             /* out: FD_OK or the job's error code */
+    /* optional: update the job's pyramid with this frame first (fd_pyramid_update arguments), on the job's stream;
+     * NULL: the pyramid has been updated by the caller.  A pyramid may be updated by one job of a batch only. */
+    const uint8_t* image;
+    int32_t image_w, image_h, image_channels, image_is_device;
 } fd_five_stage_job;
 int fd_detect_five_stage_batch(fd_ctx* ctx, fd_five_stage_job* jobs, int n);
 
