@@ -72,6 +72,9 @@ class fd_whi_params(C.Structure):
                 ("cutoff", C.c_float)]
 
 
+BOX_DTYPE = np.dtype([("score", np.float32), ("x", np.int32), ("y", np.int32), ("w", np.int32), ("h", np.int32)])
+
+
 class fd_five_stage_job(C.Structure):
     _fields_ = [("pyramid", C.c_void_p), ("wvm", C.c_void_p), ("svm", C.c_void_p), ("oe_dist", C.c_float), ("oe_ratio", C.c_float),
                 ("step_x", C.c_int32), ("step_y", C.c_int32), ("roi", C.c_void_p), ("out", C.c_void_p), ("cap", C.c_int32),
@@ -140,6 +143,7 @@ _SIGS = {
     "fd_extract_whi": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fd_whi_params), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "fd_detect_whi_svm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(fd_whi_params), C.c_void_p, C.c_int64,
                                     C.POINTER(C.c_int64), C.c_void_p]),
+    "fd_nms_iou": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     "fd_wvm_svm_evaluate_samples": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fd_detect_five_stage_batch": (C.c_int, [C.c_void_p, C.POINTER(fd_five_stage_job), C.c_int]),
     "fd_rvm_create": (C.c_int, [C.c_void_p, C.POINTER(fd_rvm_model), C.POINTER(C.c_void_p)]),
@@ -409,6 +413,17 @@ def detect_five_stage_batch(ctx, detectors, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=
             j.image, j.image_w, j.image_h, j.image_channels, j.image_is_device = ptr, w, h, ch, 1
     ctx.check(lib().fd_detect_five_stage_batch(ctx.h, jobs, n))
     return [(o[:j.count], np.array(list(j.stage_counts), np.int32)) for j, o in zip(jobs, outs)]
+
+
+def nms_iou(boxes, overlap_threshold, maximum_type=0):
+    """NonMaximumSuppression::eliminateRedundantDetections on a BOX_DTYPE array (host only)"""
+    boxes = _c(boxes, BOX_DTYPE)
+    out = np.zeros(max(len(boxes), 1), BOX_DTYPE)
+    cnt = C.c_int()
+    rc = lib().fd_nms_iou(_ptr(boxes), len(boxes), overlap_threshold, maximum_type, _ptr(out), C.byref(cnt))
+    if rc != 0:
+        raise RuntimeError("fd_nms_iou failed: %d" % rc)
+    return out[:cnt.value]
 
 
 def wvm_svm_evaluate(ctx, pyr, wvm, svm, samples):

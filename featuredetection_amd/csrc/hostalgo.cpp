@@ -148,3 +148,50 @@ extern "C" int fd_block_nms(const fd_detection* in, int n, int image_w, int imag
     for (size_t i = 0; i < xy.size(); ++i) maxima_xy[i] = xy[i];
     return FD_OK;
 }
+
+// detection::NonMaximumSuppression::eliminateRedundantDetections (NonMaximumSuppression.cpp:27-118): candidates sorted by
+// ascending score (std::sort, unstable like the reference), then clusters are peeled off from the back: the best remaining
+// detection takes every candidate whose IoU with it exceeds the threshold (std::stable_partition keeps the order of the
+// rest), and each cluster (best first) is reduced to its maximum / average / score-weighted average.
+extern "C" int fd_nms_iou(const fd_box* in, int n, double overlap_threshold, int maximum_type, fd_box* out, int* count) {
+    if (!count || n < 0 || (n > 0 && (!in || !out)) || maximum_type < 0 || maximum_type > 2) return FD_ERR_INVALID_ARGUMENT;
+    std::vector<fd_box> candidates(in, in + n);
+    if (overlap_threshold == 1.0) {   // :28-29
+        for (int i = 0; i < n; ++i) out[i] = in[i];
+        *count = n;
+        return FD_OK;
+    }
+    std::sort(candidates.begin(), candidates.end(), [](const fd_box& a, const fd_box& b) { return a.score < b.score; });
+    auto overlap = [](const fd_box& a, const fd_box& b) {   // computeOverlap :58-62 with cv::Rect operator& and area()
+        const int x = std::max(a.x, b.x), y = std::max(a.y, b.y);
+        const int w = std::min(a.x + a.w, b.x + b.w) - x, h = std::min(a.y + a.h, b.y + b.h) - y;
+        const double intersectionArea = (w <= 0 || h <= 0) ? 0 : w * h;
+        const double unionArea = a.w * a.h + b.w * b.h - intersectionArea;
+        return intersectionArea / unionArea;
+    };
+    int nout = 0;
+    while (!candidates.empty()) {
+        const fd_box detection = candidates.back();
+        auto firstOverlapping = std::stable_partition(candidates.begin(), candidates.end(),
+                                                      [&](const fd_box& c) { return overlap(detection, c) <= overlap_threshold; });
+        std::vector<fd_box> cluster(firstOverlapping, candidates.end());
+        std::reverse(cluster.begin(), cluster.end());
+        candidates.erase(firstOverlapping, candidates.end());
+        if (cluster.empty()) return FD_ERR_RUNTIME;   // overlap threshold > 1: nothing overlaps, not even the box itself; the reference loops forever
+        fd_box r = cluster.front();
+        if (maximum_type != 0) {
+            double weightSum = 0, xSum = 0, ySum = 0, wSum = 0, hSum = 0;
+            for (const fd_box& e : cluster) {
+                const double weight = maximum_type == 2 ? (double)e.score : 1.0;
+                weightSum += weight;
+                xSum += weight * e.x; ySum += weight * e.y; wSum += weight * e.w; hSum += weight * e.h;
+            }
+            if (maximum_type == 1) weightSum = (double)cluster.size();
+            r.x = (int)std::round(xSum / weightSum); r.y = (int)std::round(ySum / weightSum);
+            r.w = (int)std::round(wSum / weightSum); r.h = (int)std::round(hSum / weightSum);
+        }
+        out[nout++] = r;
+    }
+    *count = nout;
+    return FD_OK;
+}

@@ -201,6 +201,15 @@ int fd_detect_hog_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_ho
 int fd_extract_hog(fd_ctx* ctx, fd_pyramid* p, const fd_hog_params* hp, float* features, int64_t cap_windows,
                    int64_t* count);
 
+/* detection::NonMaximumSuppression::eliminateRedundantDetections (NonMaximumSuppression.cpp:27-118):
+ * IoU clustering around the best remaining detection; maximum_type 0 MAX_SCORE, 1 AVERAGE, 2 WEIGHTED_AVERAGE.  Host only.
+ * out: room for n boxes.  FD_ERR_RUNTIME for an overlap threshold > 1 (the reference does not terminate). */
+typedef struct {
+    float score;
+    int32_t x, y, w, h;   /* cv::Rect bounds */
+} fd_box;
+int fd_nms_iou(const fd_box* in, int n, double overlap_threshold, int maximum_type, fd_box* out, int* count);
+
 /* Generic histogram patch filters on the pyramid's bin-image layers (FD_LAYER_GRADBIN: 2 or 4 channels,
  * FD_LAYER_LBP: 1 channel), all built on HistogramFilter::createCellHistograms (HistogramFilter.cpp:23-197,
  * interpolating and non-interpolating):

@@ -127,6 +127,8 @@ int64_t orc_sliding_wvm(const orc_pyramid* p, const orc_wvm* m, int stepX, int s
                         orc_det* out, int64_t cap, int32_t* all_level, float* all_fout);
 /* FiveStageSlidingWindowDetector.cpp:187-320 (roi==NULL) / :331-380 (roi!=NULL).
  * stage_counts[4] = {wvm positives, after OE, svm positives, final}. */
+/* NonMaximumSuppression::eliminateRedundantDetections (NonMaximumSuppression.cpp:27-118); returns the number of detections (-1: overlap threshold > 1) */
+int orc_nms_iou(int n, const float* score, const int32_t* xywh, double overlapThreshold, int maximumType, float* outScore, int32_t* outXywh);
 /* DirectPyramidFeatureExtractor::extract(x, y, width, height) (:67-73,134-153): 1 + {layerPos, lx, ly, cx, cy, ow, oh} or 0 */
 int orc_extract_single(const orc_pyramid* p, int pw, int ph, int x, int y, int width, int height, int32_t* out7);
 /* condensation::WvmSvmModel::evaluate(image, samples) (WvmSvmModel.cpp:69-118): samples {x, y, width, height} */

@@ -253,6 +253,64 @@ int64_t orc_sliding_wvm(const orc_pyramid* p, const orc_wvm* m, int stepX, int s
     return (int64_t)pos.size();
 }
 
+// NonMaximumSuppression.cpp:27-118
+int orc_nms_iou(int n, const float* score, const int32_t* xywh, double overlapThreshold, int maximumType, float* outScore, int32_t* outXywh) {
+    struct Det { float score; int x, y, w, h; };
+    std::vector<Det> candidates;
+    for (int i = 0; i < n; ++i) candidates.push_back(Det{score[i], xywh[4 * i], xywh[4 * i + 1], xywh[4 * i + 2], xywh[4 * i + 3]});
+    std::vector<Det> finalDetections;
+    if (overlapThreshold == 1.0) {
+        finalDetections = candidates;
+    } else {
+        std::sort(candidates.begin(), candidates.end(), [](const Det& a, const Det& b) { return a.score < b.score; });   // sortByScore :35-39
+        auto computeOverlap = [](const Det& a, const Det& b) {   // :58-62
+            int x1 = std::max(a.x, b.x), y1 = std::max(a.y, b.y);
+            int x2 = std::min(a.x + a.w, b.x + b.w), y2 = std::min(a.y + a.h, b.y + b.h);
+            double intersectionArea = (x2 - x1 <= 0 || y2 - y1 <= 0) ? 0 : (x2 - x1) * (y2 - y1);
+            double unionArea = a.w * a.h + b.w * b.h - intersectionArea;
+            return intersectionArea / unionArea;
+        };
+        std::vector<std::vector<Det>> clusters;
+        while (!candidates.empty()) {   // cluster :41-46, extractOverlappingDetections :48-57
+            Det detection = candidates.back();
+            std::vector<Det> overlappingDetections;
+            auto firstOverlapping = std::stable_partition(candidates.begin(), candidates.end(), [&](const Det& candidate) {
+                return computeOverlap(detection, candidate) <= overlapThreshold;
+            });
+            std::move(firstOverlapping, candidates.end(), std::back_inserter(overlappingDetections));
+            std::reverse(overlappingDetections.begin(), overlappingDetections.end());
+            candidates.erase(firstOverlapping, candidates.end());
+            if (overlappingDetections.empty()) return -1;   // overlap threshold > 1: endless loop in the reference
+            clusters.push_back(overlappingDetections);
+        }
+        for (const std::vector<Det>& cluster : clusters) {   // getMaximum :72-118
+            Det r = cluster.front();
+            if (maximumType == 1) {
+                double xSum = 0, ySum = 0, wSum = 0, hSum = 0;
+                for (const Det& e : cluster) { xSum += e.x; ySum += e.y; wSum += e.w; hSum += e.h; }
+                r.x = (int)std::round(xSum / cluster.size()); r.y = (int)std::round(ySum / cluster.size());
+                r.w = (int)std::round(wSum / cluster.size()); r.h = (int)std::round(hSum / cluster.size());
+            } else if (maximumType == 2) {
+                double weightSum = 0, xSum = 0, ySum = 0, wSum = 0, hSum = 0;
+                for (const Det& e : cluster) {
+                    double weight = e.score;
+                    weightSum += weight;
+                    xSum += weight * e.x; ySum += weight * e.y; wSum += weight * e.w; hSum += weight * e.h;
+                }
+                r.x = (int)std::round(xSum / weightSum); r.y = (int)std::round(ySum / weightSum);
+                r.w = (int)std::round(wSum / weightSum); r.h = (int)std::round(hSum / weightSum);
+            }
+            finalDetections.push_back(r);
+        }
+    }
+    for (size_t i = 0; i < finalDetections.size(); ++i) {
+        outScore[i] = finalDetections[i].score;
+        outXywh[4 * i] = finalDetections[i].x; outXywh[4 * i + 1] = finalDetections[i].y;
+        outXywh[4 * i + 2] = finalDetections[i].w; outXywh[4 * i + 3] = finalDetections[i].h;
+    }
+    return (int)finalDetections.size();
+}
+
 int orc_extract_single(const orc_pyramid* p, int pw, int ph, int x, int y, int width, int height, int32_t* out7) {
     Window w;
     if (!extract_single(*(const Pyramid*)p, pw, ph, x, y, width, height, w)) return 0;

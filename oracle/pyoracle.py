@@ -338,6 +338,18 @@ class Svm:
         return lib().orc_svm_probability(self.h, float(d))
 
 
+def nms_iou(score, xywh, overlap_threshold, maximum_type=0):
+    """NonMaximumSuppression::eliminateRedundantDetections; returns (score[m], xywh[m, 4])"""
+    score = _c(score, np.float32)
+    xywh = _c(xywh, np.int32).reshape(-1, 4)
+    os_, ob = np.empty(len(score), np.float32), np.empty((len(score), 4), np.int32)
+    lib().orc_nms_iou.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+    m = lib().orc_nms_iou(len(score), _p(score), _p(xywh), float(overlap_threshold), int(maximum_type), _p(os_), _p(ob))
+    if m < 0:
+        raise ValueError("overlap threshold > 1")
+    return os_[:m], ob[:m]
+
+
 def extract_single(pyr, pw, ph, x, y, width, height):
     """DirectPyramidFeatureExtractor::extract(x, y, width, height): (layerPos, lx, ly, cx, cy, ow, oh) or None"""
     out = np.zeros(7, np.int32)

@@ -61,6 +61,32 @@ def test_overlap_elimination_large_clustered(oracle, capi):
         assert np.array_equal(oracle.overlap_elimination(o, dist, ratio), capi.overlap_elimination(c, dist, ratio))
 
 
+@pytest.mark.parametrize("mtype", [0, 1, 2])
+def test_iou_nms_matches_oracle(oracle, capi, mtype):
+    """detection::NonMaximumSuppression (IoU clustering) through the C ABI against the oracle, plus the defining property
+    for MAX_SCORE: the kept boxes are the cluster heads and no two of them overlap more than the threshold allows at the
+    time they were picked."""
+    rng = np.random.default_rng(40 + mtype)
+    for n, thr in ((0, 0.3), (1, 0.3), (50, 0.3), (400, 0.5), (400, 0.0), (30, 1.0)):
+        b = np.zeros(n, capi.BOX_DTYPE)
+        centres = rng.integers(0, 500, (max(n // 8, 1), 2))
+        pick = rng.integers(0, len(centres), n)
+        b["x"] = centres[pick, 0] + rng.integers(-12, 13, n)
+        b["y"] = centres[pick, 1] + rng.integers(-12, 13, n)
+        b["w"] = rng.integers(20, 80, n)
+        b["h"] = rng.integers(20, 80, n)
+        b["score"] = np.round(rng.random(n) + 0.1, 2).astype(np.float32)   # ties included
+        got = capi.nms_iou(b, thr, mtype)
+        so, bo = oracle.nms_iou(b["score"], np.stack([b["x"], b["y"], b["w"], b["h"]], 1) if n else np.zeros((0, 4), np.int32), thr, mtype)
+        assert len(got) == len(so)
+        assert np.array_equal(got["score"], so)
+        assert np.array_equal(np.stack([got["x"], got["y"], got["w"], got["h"]], 1) if len(got) else np.zeros((0, 4), np.int32), bo)
+        if mtype == 0 and thr < 1.0 and n:
+            assert np.all(np.diff(got["score"]) <= 0)   # cluster heads come out best first
+    with pytest.raises(RuntimeError):
+        capi.nms_iou(np.array([(1.0, 0, 0, 10, 10)], capi.BOX_DTYPE), 1.5)
+
+
 def test_overlap_elimination_ties(oracle, capi):
     rng = np.random.default_rng(9)
     o, c = _random_dets(oracle, capi, rng, 200, w=120, h=90, tie=True)
