@@ -510,6 +510,89 @@ def test_condensation_wvm_svm_model(oracle, capi, ctx, frame640, small_models):
     wg.close(); sg.close(); pg.close()
 
 
+def test_full_size_properties_config2_and_config3(oracle, capi, ctx, synth):
+    """BASELINE full sizes, where the oracle is too slow to score every window: size-independent properties.
+    Config 2 (640x480, 278,142 windows): window count, positives == {distance >= threshold} in extraction order, probability =
+    logistic(distance), a second run is identical, and a strided sample of windows is checked against the oracle features + SVM.
+    Config 3 shape (1080p): per-detector window counts add up to SURVEY App. D's 32,113,402; the FaceFrontal five-stage result is
+    reproducible, stage counts are non-increasing, all boxes lie in the frame and the batch entry point agrees."""
+    frame = synth.make_frame(640, 480, seed=31)
+    kw = dict(octave_layers=5, min_scale=1 / 16, max_scale=1.0)
+    pg = capi.Pyramid(ctx, **kw)
+    pg.set_layer_filter(1, bins=9)
+    pg.update(synth.make_frame(640, 480, seed=32))
+    hp = capi.hog_params(20, 20, 2, 2, 9, 5, 2, False)
+    feats2 = capi.extract_hog(ctx, pg, hp)
+    assert len(feats2) == 278142
+    m = synth.make_svm_f32(6, feats2, nsv=1024, gamma=0.5, positive_fraction=0.01)
+    sg = capi.Svm(ctx, m)
+    pg.update(frame)
+    dets, dist = capi.detect_hog_svm(ctx, pg, sg, hp)
+    assert len(dist) == 278142
+    pos = np.nonzero(dist >= float(np.float32(m["threshold"])))[0]
+    assert len(dets) == len(pos) > 100
+    wins = pg.windows(20, 20, 2, 2)
+    assert np.array_equal(np.stack([dets["layer"], dets["lx"], dets["ly"]], 1), wins[pos][:, :3])
+    so = oracle.Svm(m)
+    assert np.allclose(dets["probability"], [so.probability(d) for d in dist[pos]], rtol=1e-12)
+    dets2, dist2 = capi.detect_hog_svm(ctx, pg, sg, hp)
+    assert np.array_equal(dist2, dist) and dets2.tobytes() == dets.tobytes()
+    # strided sample against the oracle (features bit-exact, distances 1e-4 of the natural scale)
+    po = oracle.Pyramid(**kw)
+    po.set_layer_filter(1, bins=9)
+    po.update(frame)
+    layers = [po.layer(i) for i in range(len(po.layers()))]
+    fg = capi.extract_hog(ctx, pg, hp)
+    idx = np.arange(0, 278142, 997)
+    fo = np.stack([oracle.hog_filter(np.ascontiguousarray(layers[wins[i][0]][wins[i][2]:wins[i][2] + 20, wins[i][1]:wins[i][1] + 20]), 9, 5, 2) for i in idx])
+    assert np.array_equal(fg[idx], fo)
+    do = so.distance(fo)
+    assert np.max(np.abs(dist[idx] - do)) <= 1e-4 * np.abs(m["coeff"]).sum()
+    sg.close(); pg.close(); po.close()
+
+    # config 3 shape
+    total = 0
+    pyrs = {}
+    for name, (inc, mn, mx, pw, ph, nper, nlev) in synth.DETECTOR_CFGS.items():
+        key = (inc, mn, mx)
+        if key not in pyrs:
+            pyrs[key] = capi.Pyramid(ctx, inc=float(np.float32(inc)), min_scale=float(np.float32(mn)), max_scale=float(np.float32(mx)))
+            pyrs[key].update(np.zeros((1080, 1920), np.uint8))
+        total += pyrs[key].window_count(pw, ph, 1, 1)
+    assert total == 32113402
+    for p_ in pyrs.values():
+        p_.close()
+    gray = oracle.bgr2gray(synth.make_frame(640, 480, seed=20260927))
+    calib = synth.random_patches(gray[::4, ::4].copy(), 20, 20, 8000, np.random.default_rng(1))
+    wvm_m = synth.make_wvm(7, calib_patches=calib)
+    eq = synth.histeq64_np(synth.random_patches(gray[::4, ::4].copy(), 20, 20, 1400, np.random.default_rng(2)))
+    svm_m = synth.make_svm_u8(3, eq, nsv=1024, calib=eq[1024:])
+    big = synth.make_frame(1920, 1080, seed=20260927)
+    pA, pB = capi.Pyramid(ctx, **FF), capi.Pyramid(ctx, **FF)
+    pA.update(big); pB.update(big)
+    assert pA.window_count(20, 20, 1, 1) == 190616
+    wA, wB, sv_ = capi.Wvm(ctx, wvm_m), capi.Wvm(ctx, wvm_m), capi.Svm(ctx, svm_m)
+    d1, st1 = capi.detect_five_stage(ctx, pA, wA, sv_)
+    d2, st2 = capi.detect_five_stage(ctx, pA, wA, sv_)
+    assert d1.tobytes() == d2.tobytes() and np.array_equal(st1, st2)
+    assert st1[0] >= st1[1] >= st1[2] >= st1[3] == len(d1) > 0
+    assert np.all(d1["cx"] >= 0) and np.all(d1["cx"] < 1920) and np.all(d1["cy"] >= 0) and np.all(d1["cy"] < 1080)
+    assert np.all(np.diff(d1["probability"]) <= 0)          # sorted by probability (FiveStageSlidingWindowDetector.cpp:316)
+    (b1, bs1), (b2, bs2) = capi.detect_five_stage_batch(ctx, [(pA, wA, sv_), (pB, wB, sv_)])
+    assert b1.tobytes() == d1.tobytes() and b2.tobytes() == d1.tobytes() and np.array_equal(bs1, st1) and np.array_equal(bs2, st1)
+    # the WVM stage on a strided sample of the 190,616 windows against the oracle
+    posw, lv, fo_ = capi.detect_wvm(ctx, pA, wA, 1, 1, want_all=True)
+    po = oracle.Pyramid(**FF); po.update(big)
+    wo = oracle.Wvm(wvm_m)
+    layers = [po.layer(i) for i in range(len(po.layers()))]
+    wins = po.windows(20, 20, 1, 1)
+    for i in list(range(0, 190616, 1499)) + [int(d["level"]) * 0 + k for k, d in enumerate(posw[:0])]:
+        lp, lx, ly = wins[i][:3]
+        l_, f_ = wo.eval(oracle.histeq64(np.ascontiguousarray(layers[lp][ly:ly + 20, lx:lx + 20])))
+        assert (l_, np.float32(f_)) == (lv[i], fo_[i]), i
+    wA.close(); wB.close(); sv_.close(); pA.close(); pB.close(); po.close()
+
+
 def test_hog_rbf_svm_detector_config2(oracle, capi, ctx, synth):
     """BASELINE config 2 shape on a reduced frame: HOG-324 + RBF SVM (MFMA path).  Scores within
     1e-4 relative (of the natural scale sum|coeff_i| K_i), positives identical away from the threshold."""
