@@ -75,6 +75,11 @@ class fd_whi_params(C.Structure):
 BOX_DTYPE = np.dtype([("score", np.float32), ("x", np.int32), ("y", np.int32), ("w", np.int32), ("h", np.int32)])
 
 
+class fd_fhog_params(C.Structure):
+    _fields_ = [("cell_size", C.c_int32), ("unsigned_bins", C.c_int32), ("interpolate_bins", C.c_int32), ("interpolate_cells", C.c_int32),
+                ("alpha", C.c_float)]
+
+
 class fd_five_stage_job(C.Structure):
     _fields_ = [("pyramid", C.c_void_p), ("wvm", C.c_void_p), ("svm", C.c_void_p), ("oe_dist", C.c_float), ("oe_ratio", C.c_float),
                 ("step_x", C.c_int32), ("step_y", C.c_int32), ("roi", C.c_void_p), ("out", C.c_void_p), ("cap", C.c_int32),
@@ -143,6 +148,9 @@ _SIGS = {
     "fd_extract_whi": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fd_whi_params), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "fd_detect_whi_svm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(fd_whi_params), C.c_void_p, C.c_int64,
                                     C.POINTER(C.c_int64), C.c_void_p]),
+    "fd_fhog_size": (C.c_int, [C.POINTER(fd_fhog_params), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "fd_fhog_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(fd_fhog_params), C.c_void_p]),
+    "fd_pyramid_fhog_layer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(fd_fhog_params), C.c_void_p]),
     "fd_nms_iou": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     "fd_wvm_svm_evaluate_samples": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fd_detect_five_stage_batch": (C.c_int, [C.c_void_p, C.POINTER(fd_five_stage_job), C.c_int]),
@@ -413,6 +421,23 @@ def detect_five_stage_batch(ctx, detectors, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=
             j.image, j.image_w, j.image_h, j.image_channels, j.image_is_device = ptr, w, h, ch, 1
     ctx.check(lib().fd_detect_five_stage_batch(ctx.h, jobs, n))
     return [(o[:j.count], np.array(list(j.stage_counts), np.int32)) for j, o in zip(jobs, outs)]
+
+
+def fhog(ctx, gray=None, pyramid=None, layer=0, cell_size=8, unsigned_bins=9, interpolate_bins=False, interpolate_cells=True, alpha=0.2):
+    """FhogFilter::applyTo on a host gray image or on a layer of a gray pyramid: (rows, cols, 3 * unsigned_bins + 4) float32"""
+    fp = fd_fhog_params(cell_size, unsigned_bins, int(interpolate_bins), int(interpolate_cells), alpha)
+    if gray is not None:
+        gray = _c(gray, np.uint8)
+        h, w = gray.shape
+    else:
+        info = pyramid.layers()[layer]
+        h, w = info["h"], info["w"]
+    out = np.zeros((h // cell_size, w // cell_size, 3 * unsigned_bins + 4), np.float32)
+    if gray is not None:
+        ctx.check(lib().fd_fhog_image(ctx.h, _ptr(gray), w, h, C.byref(fp), _ptr(out)))
+    else:
+        ctx.check(lib().fd_pyramid_fhog_layer(ctx.h, pyramid.h, layer, C.byref(fp), _ptr(out)))
+    return out
 
 
 def nms_iou(boxes, overlap_threshold, maximum_type=0):

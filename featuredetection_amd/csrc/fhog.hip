@@ -1,0 +1,283 @@
+// featuredetection_amd/csrc/fhog.hip -- imageprocessing::filtering::FhogFilter (FhogFilter.cpp:20-132,
+// FhogFilter.hpp:120-207) + FhogAggregationFilter::computeDescriptors (FhogAggregationFilter.cpp:38-168) on gray
+// images / gray pyramid layers: the cell descriptors (2B signed + B unsigned orientation features + 4 energy features)
+// the AggregatedFeaturesDetector family convolves its linear SVM over.  SURVEY.md 8(f) row 2, second piece.
+//
+// k_fhog_hist: lane == cell.  A lane walks the pixels that contribute to its cell in the reference's row-major scan
+// order (with bilinear cell interpolation a pixel feeds up to four cells, so a cell sees a 2c x 2c neighbourhood) and
+// accumulates into its private 2B-bin histogram in LDS, so every fp32 accumulator receives its addends in the
+// reference order.  The per-pixel (bin, weight) pair comes from the same 511 x 511 gradient look-up table the
+// reference builds (host libm atan2 / sqrt: FhogFilter.cpp:35-57), uploaded once per parameter set.
+// k_fhog_desc: lane == cell: the four neighbourhood normalisers, truncation at alpha, the 0.5 / 0.2357 factors.
+// HBM-bound in principle (w*h bytes in, rows*cols*(3B+4)*4 bytes out); the table look-ups are L2 hits.
+#include "fd_internal.hpp"
+#include "fd_device.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+struct FhogLut {   // one entry per (dy, dx) gradient code
+    uint8_t index1, index2;
+    uint16_t pad;
+    float weight1, weight2;
+};
+struct FhogCoeffDev { int32_t index1, index2; float weight1, weight2; };
+
+struct FhogDev {
+    int32_t w, h, stride;        // image
+    int32_t rows, cols, cell, ubins, sbins, D;
+    int32_t interpBins, interpCells;
+    float alpha;
+    const FhogLut* lut;          // [512 * 512], index dy * 512 + dx
+    const FhogCoeffDev* rowCoeff; // [rows * cell]
+    const FhogCoeffDev* colCoeff; // [cols * cell]
+};
+
+namespace {
+
+using namespace fd_dev;
+
+constexpr int FHOG_MAX_SBINS = 36;
+
+__global__ __launch_bounds__(64) void k_fhog_hist(const uint8_t* __restrict__ img, FhogDev d, float* __restrict__ desc, float* __restrict__ energies) {
+    __shared__ float hist[FHOG_MAX_SBINS][64];
+    const int lane = threadIdx.x;
+    const int ncells = d.rows * d.cols;
+    const int cellId = blockIdx.x * 64 + lane;
+    const bool valid = cellId < ncells;
+    const int r = valid ? cellId / d.cols : 0, c = valid ? cellId - r * d.cols : 0;
+    for (int b = 0; b < d.sbins; ++b) hist[b][lane] = 0.f;
+    if (valid) {
+        // pixel range feeding this cell: non-interpolated [r*cell, (r+1)*cell); interpolated: every pixel whose index1 or index2 is r
+        const int cs = d.cell;
+        const int H = d.rows * cs, W = d.cols * cs;
+        int y0, y1, x0, x1;
+        if (d.interpCells) {
+            y0 = max(r * cs - (cs + 1) / 2 - 1, 0); y1 = min((r + 1) * cs + (cs + 1) / 2 + 1, H);
+            x0 = max(c * cs - (cs + 1) / 2 - 1, 0); x1 = min((c + 1) * cs + (cs + 1) / 2 + 1, W);
+        } else {
+            y0 = r * cs; y1 = y0 + cs; x0 = c * cs; x1 = x0 + cs;
+        }
+        for (int y = y0; y < y1; ++y) {
+            const FhogCoeffDev rc = d.rowCoeff[y];
+            const bool r1 = rc.index1 == r, r2 = d.interpCells && rc.index2 == r;
+            if (!r1 && !r2) continue;
+            const int py = max(y - 1, 0), ny = min(y + 1, d.h - 1);
+            const uint8_t* rowp = img + (size_t)y * d.stride;
+            const uint8_t* up = img + (size_t)py * d.stride;
+            const uint8_t* dn = img + (size_t)ny * d.stride;
+            for (int x = x0; x < x1; ++x) {
+                const FhogCoeffDev cc = d.colCoeff[x];
+                const bool c1 = cc.index1 == c, c2 = d.interpCells && cc.index2 == c;
+                if (!c1 && !c2) continue;
+                const int px = max(x - 1, 0), nx = min(x + 1, d.w - 1);
+                const int dx = (int)rowp[nx] - (int)rowp[px] + 256;
+                const int dy = (int)dn[x] - (int)up[x] + 256;
+                const FhogLut e = d.lut[dy * 512 + dx];
+                // the (up to four) adds this cell receives from the pixel, in the order h11, h12, h21, h22 of
+                // FhogFilter.hpp:173-205 (a role applies when the corresponding row / column index is this cell)
+#pragma unroll
+                for (int role = 0; role < 4; ++role) {
+                    const bool rowHit = (role & 2) ? r2 : r1, colHit = (role & 1) ? c2 : c1;
+                    if (!rowHit || !colHit) continue;
+                    if (d.interpCells) {
+                        const float wr = (role & 2) ? rc.weight2 : rc.weight1, wc = (role & 1) ? cc.weight2 : cc.weight1;
+                        hist[e.index1][lane] = hist[e.index1][lane] + e.weight1 * wr * wc;
+                        if (d.interpBins) hist[e.index2][lane] = hist[e.index2][lane] + e.weight2 * wr * wc;
+                    } else {
+                        hist[e.index1][lane] = hist[e.index1][lane] + e.weight1;
+                        if (d.interpBins) hist[e.index2][lane] = hist[e.index2][lane] + e.weight2;
+                    }
+                }
+            }
+        }
+        float* out = desc + (size_t)cellId * d.D;
+        float energy = 0.f;   // computeGradientEnergy, FhogAggregationFilter.cpp:53-61
+        for (int b = 0; b < d.ubins; ++b) {
+            const float u = hist[b][lane] + hist[b + d.ubins][lane];
+            energy = energy + u * u;
+        }
+        for (int b = 0; b < d.sbins; ++b) out[b] = hist[b][lane];
+        energies[cellId] = energy;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_fhog_desc(FhogDev d, const float* __restrict__ energies, float* __restrict__ desc) {
+    const int cellId = blockIdx.x * 64 + threadIdx.x;
+    if (cellId >= d.rows * d.cols) return;
+    const int r = cellId / d.cols, c = cellId - r * d.cols;
+    const int pr = max(r - 1, 0), nr = min(r + 1, d.rows - 1), pc = max(c - 1, 0), nc = min(c + 1, d.cols - 1);
+    auto E = [&](int rr, int cc) { return energies[rr * d.cols + cc]; };
+    const float eps = 1e-4f;
+    float n[4];   // computeNormalizers, FhogAggregationFilter.cpp:77-99
+    n[0] = 1.f / sqrtf(E(pr, pc) + E(pr, c) + E(r, pc) + E(r, c) + eps);
+    n[1] = 1.f / sqrtf(E(pr, c) + E(pr, nc) + E(r, c) + E(r, nc) + eps);
+    n[2] = 1.f / sqrtf(E(r, pc) + E(r, c) + E(nr, pc) + E(nr, c) + eps);
+    n[3] = 1.f / sqrtf(E(r, c) + E(r, nc) + E(nr, c) + E(nr, nc) + eps);
+    float* p = desc + (size_t)cellId * d.D;
+    float energy[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < d.ubins; ++b) {   // computeDescriptor, :101-148 (0.5 and 0.2357 are double literals)
+        const float v = p[b] + p[b + d.ubins];
+        const float s = fminf(d.alpha, n[0] * v) + fminf(d.alpha, n[1] * v) + fminf(d.alpha, n[2] * v) + fminf(d.alpha, n[3] * v);
+        p[d.sbins + b] = (float)(0.5 * (double)s);
+    }
+    for (int b = 0; b < d.sbins; ++b) {
+        const float v = p[b];
+        const float v0 = fminf(d.alpha, n[0] * v), v1 = fminf(d.alpha, n[1] * v), v2 = fminf(d.alpha, n[2] * v), v3 = fminf(d.alpha, n[3] * v);
+        p[b] = (float)(0.5 * (double)(v0 + v1 + v2 + v3));
+        energy[0] = energy[0] + v0; energy[1] = energy[1] + v1; energy[2] = energy[2] + v2; energy[3] = energy[3] + v3;
+    }
+    for (int i = 0; i < 4; ++i) p[d.sbins + d.ubins + i] = (float)(0.2357 * (double)energy[i]);
+}
+
+struct FhogScratch {
+    DevBuf lut, coeff, img, desc, energies;
+    fd_fhog_params lutFor;
+    bool lutValid = false;
+};
+FhogScratch& scratch(fd_ctx* ctx) {
+    static thread_local std::vector<std::pair<fd_ctx*, std::unique_ptr<FhogScratch>>> tab;
+    for (auto& kv : tab)
+        if (kv.first == ctx) return *kv.second;
+    tab.emplace_back(ctx, std::unique_ptr<FhogScratch>(new FhogScratch()));
+    return *tab.back().second;
+}
+
+// gradient look-up table of FhogFilter::createGradientLut (FhogFilter.cpp:35-57), host libm like the reference
+void build_lut(fd_ctx* ctx, FhogScratch& S, const fd_fhog_params& fp) {
+    if (S.lutValid && S.lutFor.unsigned_bins == fp.unsigned_bins && S.lutFor.interpolate_bins == fp.interpolate_bins) return;
+    const int signedBinCount = 2 * fp.unsigned_bins;
+    const float TWO_PI = (float)(2 * M_PI);
+    const float value2bin = signedBinCount / TWO_PI;
+    std::vector<FhogLut> lut((size_t)512 * 512);
+    std::memset(lut.data(), 0, sizeof(FhogLut) * lut.size());
+    for (int gradientCodeX = 1; gradientCodeX < 512; ++gradientCodeX) {
+        const float gradientX = (gradientCodeX - 256) / (255.0f * 2.0f);
+        for (int gradientCodeY = 1; gradientCodeY < 512; ++gradientCodeY) {
+            const float gradientY = (gradientCodeY - 256) / (255.0f * 2.0f);
+            const float magnitude = std::sqrt(gradientX * gradientX + gradientY * gradientY);
+            float orientation = std::atan2(gradientY, gradientX);
+            if (orientation < 0) orientation += TWO_PI;
+            FhogLut e;
+            std::memset(&e, 0, sizeof(e));
+            if (fp.interpolate_bins) {
+                const float bin = orientation * value2bin;
+                int i1 = (int)bin, i2 = i1 + 1;
+                if (i2 == signedBinCount) i2 = 0;
+                e.index1 = (uint8_t)i1; e.index2 = (uint8_t)i2;
+                e.weight2 = magnitude * (bin - i1);
+                e.weight1 = magnitude - e.weight2;
+            } else {
+                int bin = (int)(orientation * value2bin + 0.5f);
+                if (bin == signedBinCount) bin = 0;
+                e.index1 = (uint8_t)bin; e.weight1 = magnitude;
+            }
+            lut[(size_t)gradientCodeY * 512 + gradientCodeX] = e;
+        }
+    }
+    S.lut.reserve(sizeof(FhogLut) * lut.size());
+    HIP_CHECK(hipMemcpy(S.lut.p, lut.data(), sizeof(FhogLut) * lut.size(), hipMemcpyHostToDevice));
+    S.lutFor = fp;
+    S.lutValid = true;
+}
+
+std::vector<FhogCoeffDev> interp_coefficients(int sizeInPixels, int sizeInCells, int cellSize, bool interpolateCells) {   // FhogFilter.cpp:74-98
+    std::vector<FhogCoeffDev> c((size_t)sizeInPixels);
+    for (int pixel = 0; pixel < sizeInPixels; ++pixel) {
+        if (interpolateCells) {
+            const float realCellIndex = (pixel + 0.5f) / cellSize - 0.5f;
+            int index1 = (int)std::floor(realCellIndex);
+            int index2 = index1 + 1;
+            float weight2 = realCellIndex - index1;
+            float weight1 = index2 - realCellIndex;
+            if (index1 < 0) { index1 = index2; weight1 = 0; }
+            else if (index2 >= sizeInCells) { index2 = index1; weight2 = 0; }
+            c[pixel] = FhogCoeffDev{index1, index2, weight1, weight2};
+        } else {
+            c[pixel] = FhogCoeffDev{pixel / cellSize, -1, 1.f, 0.f};
+        }
+    }
+    return c;
+}
+
+// descriptors of the gray image at dimg (device, row stride `stride`) into S.desc; returns rows / cols
+void run_fhog(fd_ctx* ctx, FhogScratch& S, const uint8_t* dimg, int w, int h, int stride, const fd_fhog_params& fp, int& rows, int& cols) {
+    if (fp.cell_size < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "FhogFilter: cellSize must be bigger than zero");
+    if (fp.unsigned_bins < 1 || 2 * fp.unsigned_bins > FHOG_MAX_SBINS)
+        FD_THROW(FD_ERR_INVALID_ARGUMENT, "FhogFilter: unsignedBinCount must be bigger than zero, but was: %d (this backend: <= %d)", fp.unsigned_bins,
+                 FHOG_MAX_SBINS / 2);
+    if (!(fp.alpha > 0)) FD_THROW(FD_ERR_INVALID_ARGUMENT, "FhogAggregationFilter: alpha must be bigger than zero, but was: %g", (double)fp.alpha);
+    rows = h / fp.cell_size;
+    cols = w / fp.cell_size;
+    if (rows == 0 || cols == 0) return;
+    build_lut(ctx, S, fp);
+    std::vector<FhogCoeffDev> rc = interp_coefficients(rows * fp.cell_size, rows, fp.cell_size, fp.interpolate_cells != 0);
+    std::vector<FhogCoeffDev> cc = interp_coefficients(cols * fp.cell_size, cols, fp.cell_size, fp.interpolate_cells != 0);
+    S.coeff.reserve(sizeof(FhogCoeffDev) * (rc.size() + cc.size()));
+    FhogCoeffDev* pin = (FhogCoeffDev*)fd_pinned(ctx, sizeof(FhogCoeffDev) * (rc.size() + cc.size()));
+    std::memcpy(pin, rc.data(), sizeof(FhogCoeffDev) * rc.size());
+    std::memcpy(pin + rc.size(), cc.data(), sizeof(FhogCoeffDev) * cc.size());
+    HIP_CHECK(hipMemcpyAsync(S.coeff.p, pin, sizeof(FhogCoeffDev) * (rc.size() + cc.size()), hipMemcpyHostToDevice, ctx->stream));
+    FhogDev d;
+    std::memset(&d, 0, sizeof(d));
+    d.w = w; d.h = h; d.stride = stride; d.rows = rows; d.cols = cols; d.cell = fp.cell_size; d.ubins = fp.unsigned_bins;
+    d.sbins = 2 * fp.unsigned_bins; d.D = 3 * fp.unsigned_bins + 4; d.interpBins = fp.interpolate_bins != 0; d.interpCells = fp.interpolate_cells != 0;
+    d.alpha = fp.alpha;
+    d.lut = S.lut.as<FhogLut>();
+    d.rowCoeff = S.coeff.as<FhogCoeffDev>();
+    d.colCoeff = d.rowCoeff + rc.size();
+    const int ncells = rows * cols;
+    S.desc.reserve(sizeof(float) * (size_t)ncells * d.D);
+    S.energies.reserve(sizeof(float) * (size_t)ncells);
+    const int grid = (ncells + 63) / 64;
+    hipLaunchKernelGGL(k_fhog_hist, dim3(grid), dim3(64), 0, ctx->stream, dimg, d, S.desc.as<float>(), S.energies.as<float>());
+    hipLaunchKernelGGL(k_fhog_desc, dim3(grid), dim3(64), 0, ctx->stream, d, S.energies.as<float>(), S.desc.as<float>());
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace
+
+extern "C" {
+
+int fd_fhog_size(const fd_fhog_params* fp, int width, int height, int* rows, int* cols, int* channels) {
+    if (!fp || fp->cell_size < 1 || fp->unsigned_bins < 1) return FD_ERR_INVALID_ARGUMENT;
+    if (rows) *rows = height / fp->cell_size;
+    if (cols) *cols = width / fp->cell_size;
+    if (channels) *channels = 3 * fp->unsigned_bins + 4;
+    return FD_OK;
+}
+
+int fd_fhog_image(fd_ctx* ctx, const uint8_t* gray, int width, int height, const fd_fhog_params* fp, float* out) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !gray || !fp || !out || width < 1 || height < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_fhog_image: bad argument");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        FhogScratch& S = scratch(ctx);
+        S.img.reserve((size_t)width * height);
+        HIP_CHECK(hipMemcpyAsync(S.img.p, gray, (size_t)width * height, hipMemcpyHostToDevice, ctx->stream));
+        int rows, cols;
+        run_fhog(ctx, S, S.img.as<uint8_t>(), width, height, width, *fp, rows, cols);
+        if (rows && cols)
+            HIP_CHECK(hipMemcpyAsync(out, S.desc.p, sizeof(float) * (size_t)rows * cols * (3 * fp->unsigned_bins + 4), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int fd_pyramid_fhog_layer(fd_ctx* ctx, fd_pyramid* p, int layer, const fd_fhog_params* fp, float* out) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !p || !fp || !out) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_fhog_layer: NULL argument");
+        if (p->ctx != ctx) FD_THROW(FD_ERR_INVALID_ARGUMENT, "objects belong to different contexts");
+        if (p->filter_kind != FD_LAYER_NONE) FD_THROW(FD_ERR_INVALID_ARGUMENT, "FhogFilter needs a gray pyramid (no layer filter)");
+        if (layer < 0 || layer >= (int)p->kept.size()) FD_THROW(FD_ERR_INVALID_ARGUMENT, "no such pyramid layer: %d", layer);
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const HostLayer& L = p->all[p->kept[layer]];
+        FhogScratch& S = scratch(ctx);
+        int rows, cols;
+        run_fhog(ctx, S, p->arena.as<uint8_t>() + L.gray_off, L.w, L.h, L.w, *fp, rows, cols);
+        if (rows && cols)
+            HIP_CHECK(hipMemcpyAsync(out, S.desc.p, sizeof(float) * (size_t)rows * cols * (3 * fp->unsigned_bins + 4), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+}  // extern "C"

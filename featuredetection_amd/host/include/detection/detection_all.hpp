@@ -48,6 +48,24 @@ private:
     float dist, ratio;
 };
 
+// NonMaximumSuppression.hpp:20-117 / NonMaximumSuppression.cpp:27-118 (IoU clustering of the AggregatedFeaturesDetector family)
+struct Detection {
+    float score;
+    cv::Rect bounds;
+};
+class NonMaximumSuppression {
+public:
+    enum class MaximumType { MAX_SCORE, AVERAGE, WEIGHTED_AVERAGE };
+    explicit NonMaximumSuppression(double overlapThreshold, MaximumType maximumType = MaximumType::MAX_SCORE)
+        : overlapThreshold(overlapThreshold), maximumType(maximumType) {}
+    std::vector<Detection> eliminateRedundantDetections(std::vector<Detection> candidates) const;
+    double getOverlapThreshold() const { return overlapThreshold; }
+    MaximumType getMaximumType() const { return maximumType; }
+private:
+    double overlapThreshold;
+    MaximumType maximumType;
+};
+
 // SlidingWindowDetector.hpp:41-93 / SlidingWindowDetector.cpp:40-98
 class SlidingWindowDetector : public Detector {
 public:

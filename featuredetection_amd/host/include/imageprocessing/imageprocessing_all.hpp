@@ -357,4 +357,17 @@ private:
     int whiStage = 0;   // number of whi chain filters added so far (in order)
 };
 
+// filtering/FhogFilter.hpp:55-56 / FhogFilter.cpp:20-72 (the cell descriptors of the AggregatedFeaturesDetector family)
+namespace filtering {
+class FhogFilter : public ImageFilter {
+public:
+    using ImageFilter::applyTo;
+    explicit FhogFilter(int cellSize = 8, int unsignedBinCount = 9, bool interpolateBins = false, bool interpolateCells = true, float alpha = 0.2f);
+    cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;   // CV_8UC1 -> rows x cols x (3B+4) CV_32F (stored as rows x cols*(3B+4))
+    int cellSize, unsignedBinCount;
+    bool interpolateBins, interpolateCells;
+    float alpha;
+};
+}  // namespace filtering
+
 }  // namespace imageprocessing

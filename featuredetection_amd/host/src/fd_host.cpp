@@ -249,6 +249,24 @@ vector<cv::Size> ImagePyramid::getLayerSizes() const {
     return out;
 }
 
+namespace filtering {
+FhogFilter::FhogFilter(int cellSize, int unsignedBinCount, bool interpolateBins, bool interpolateCells, float alpha)
+    : cellSize(cellSize), unsignedBinCount(unsignedBinCount), interpolateBins(interpolateBins), interpolateCells(interpolateCells), alpha(alpha) {
+    if (unsignedBinCount < 1) throw std::invalid_argument("FhogFilter: unsignedBinCount must be bigger than zero, but was: " + std::to_string(unsignedBinCount));
+    if (alpha <= 0) throw std::invalid_argument("FhogAggregationFilter: alpha must be bigger than zero, but was: " + std::to_string(alpha));
+}
+Mat FhogFilter::applyTo(const Mat& image, Mat& descriptors) const {
+    if (image.type() != CV_8UC1)
+        throw std::invalid_argument("FhogFilter: the image type must be CV_8UC1 on this backend, but was " + std::to_string(image.type()));
+    Mat src = image.isContinuous() ? image : image.clone();
+    fd_fhog_params fp = {cellSize, unsignedBinCount, interpolateBins, interpolateCells, alpha};
+    const int rows = src.rows / cellSize, cols = src.cols / cellSize, D = 3 * unsignedBinCount + 4;
+    descriptors.create(rows, cols * D, CV_32FC1);   // the compat Mat has no CV_32FC(n) with n > 4: channels are interleaved in the row
+    if (rows > 0 && cols > 0) check(fd_fhog_image(context(), src.ptr<uchar>(0), src.cols, src.rows, &fp, descriptors.ptr<float>(0)));
+    return descriptors;
+}
+}  // namespace filtering
+
 // ---- DirectPyramidFeatureExtractor ----------------------------------------------------------------
 DirectPyramidFeatureExtractor::DirectPyramidFeatureExtractor(shared_ptr<ImagePyramid> pyramid, int width, int height)
     : pyramid(pyramid), patchWidth(width), patchHeight(height) {}
@@ -796,6 +814,19 @@ vector<shared_ptr<ClassifiedPatch>> OverlapElimination::eliminate(vector<shared_
         throw std::runtime_error("OverlapElimination: invalid arguments");
     for (int i = 0; i < n; ++i) out.push_back(classifiedPatches[keep[i]]);
     return out;
+}
+
+vector<Detection> NonMaximumSuppression::eliminateRedundantDetections(vector<Detection> candidates) const {
+    vector<fd_box> in(candidates.size()), out(candidates.size());
+    for (size_t i = 0; i < candidates.size(); ++i)
+        in[i] = fd_box{candidates[i].score, candidates[i].bounds.x, candidates[i].bounds.y, candidates[i].bounds.width, candidates[i].bounds.height};
+    int n = 0;
+    const int rc = fd_nms_iou(in.data(), (int)in.size(), overlapThreshold, (int)maximumType, out.data(), &n);
+    if (rc == FD_ERR_RUNTIME) throw std::runtime_error("NonMaximumSuppression: the overlap threshold must not exceed one");
+    if (rc != FD_OK) throw std::invalid_argument("NonMaximumSuppression: invalid arguments");
+    vector<Detection> res;
+    for (int i = 0; i < n; ++i) res.push_back(Detection{out[i].score, cv::Rect(out[i].x, out[i].y, out[i].w, out[i].h)});
+    return res;
 }
 
 SlidingWindowDetector::SlidingWindowDetector(shared_ptr<classification::ProbabilisticClassifier> classifier,

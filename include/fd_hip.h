@@ -210,6 +210,20 @@ typedef struct {
 } fd_box;
 int fd_nms_iou(const fd_box* in, int n, double overlap_threshold, int maximum_type, fd_box* out, int* count);
 
+/* imageprocessing::filtering::FhogFilter(cellSize, unsignedBinCount, interpolateBins, interpolateCells, alpha)
+ * (FhogFilter.cpp:20-132, FhogFilter.hpp:120-207; descriptors by FhogAggregationFilter.cpp:38-168) on CV_8UC1 images:
+ * rows = height / cell_size, cols = width / cell_size cells of 3 * unsigned_bins + 4 floats (2B signed, B unsigned
+ * orientation features, 4 energy features).  Reference defaults: 8, 9, false, true, 0.2 (FhogFilter.hpp:55-56). */
+typedef struct {
+    int32_t cell_size, unsigned_bins, interpolate_bins, interpolate_cells;
+    float alpha;
+} fd_fhog_params;
+int fd_fhog_size(const fd_fhog_params* fp, int width, int height, int* rows, int* cols, int* channels);
+/* gray: host image (width * height bytes); out: rows * cols * channels floats (host) */
+int fd_fhog_image(fd_ctx* ctx, const uint8_t* gray, int width, int height, const fd_fhog_params* fp, float* out);
+/* the same on kept layer `layer` of an updated gray pyramid (the layer filter of AggregatedFeaturesExtractor's feature pyramid) */
+int fd_pyramid_fhog_layer(fd_ctx* ctx, fd_pyramid* p, int layer, const fd_fhog_params* fp, float* out);
+
 /* Generic histogram patch filters on the pyramid's bin-image layers (FD_LAYER_GRADBIN: 2 or 4 channels,
  * FD_LAYER_LBP: 1 channel), all built on HistogramFilter::createCellHistograms (HistogramFilter.cpp:23-197,
  * interpolating and non-interpolating):

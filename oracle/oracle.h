@@ -39,6 +39,11 @@ int orc_pyramid_hog(const uint8_t* img, int w, int h, int ch, int stride_bytes, 
 int orc_spatial_pyramid_histogram(const uint8_t* img, int w, int h, int ch, int stride_bytes, int bins, int levels,
                                   int interpolate, int normalization, float* out);
 
+/* filtering::FhogFilter::applyTo on a CV_8UC1 image (FhogFilter.cpp:59-72 + FhogAggregationFilter.cpp:38-168):
+ * rows = h / cellSize, cols = w / cellSize cells of 3 * unsignedBinCount + 4 floats; returns the number of floats */
+int orc_fhog(const uint8_t* img, int w, int h, int stride, int cellSize, int unsignedBinCount, int interpolateBins,
+             int interpolateCells, float alpha, float* out, int* rows, int* cols);
+
 /* ---------------- pyramid + window enumeration ---------------- */
 typedef struct orc_pyramid orc_pyramid;
 orc_pyramid* orc_pyramid_create(int octaveLayerCount, double minScale, double maxScale); /* ImagePyramid.cpp:67-77 */

@@ -531,6 +531,147 @@ static int spatial_pyramid_histogram(const uchar* img, int w, int h, int ch, int
     return (int)out.size();
 }
 
+// ---------------------------------------------------------------------------------------
+// imageprocessing::filtering::FhogFilter (FhogFilter.cpp:20-132, FhogFilter.hpp:120-207) on a CV_8UC1 image +
+// FhogAggregationFilter::computeDescriptors (FhogAggregationFilter.cpp:38-168).  SURVEY.md 8(f) row 2.
+// Output: rows x cols cells (image size / cellSize, integer division) x (3 * unsignedBinCount + 4) floats.
+// ---------------------------------------------------------------------------------------
+struct FhogCoeff { int index1, index2; float weight1, weight2; };
+
+static std::vector<FhogCoeff> fhog_interp_coefficients(int sizeInPixels, int sizeInCells, int cellSize, bool interpolateCells) {
+    std::vector<FhogCoeff> c((size_t)sizeInPixels);
+    if (interpolateCells) {
+        for (int pixel = 0; pixel < sizeInPixels; ++pixel) {   // FhogFilter.cpp:76-91
+            float realCellIndex = (pixel + 0.5f) / cellSize - 0.5f;
+            int index1 = (int)std::floor(realCellIndex);
+            int index2 = index1 + 1;
+            float weight2 = realCellIndex - index1;
+            float weight1 = index2 - realCellIndex;
+            if (index1 < 0) { index1 = index2; weight1 = 0; }
+            else if (index2 >= sizeInCells) { index2 = index1; weight2 = 0; }
+            c[pixel] = FhogCoeff{index1, index2, weight1, weight2};
+        }
+    } else {
+        for (int pixel = 0; pixel < sizeInPixels; ++pixel) c[pixel] = FhogCoeff{pixel / cellSize, -1, 1, 0};
+    }
+    return c;
+}
+
+// one entry of the 512 x 512 gradient look-up table (FhogFilter.cpp:35-57): dx, dy in [1, 511] are gradient + 256
+static FhogCoeff fhog_lut_entry(int gradientCodeX, int gradientCodeY, int signedBinCount, bool interpolateBins, float& magnitude) {
+    const float TWO_PI = (float)(2 * M_PI);                    // GradientOrientationFilter.hpp:57
+    const float value2bin = signedBinCount / TWO_PI;           // FhogFilter.cpp:27
+    float gradientX = (gradientCodeX - 256) / (255.0f * 2.0f);
+    float gradientY = (gradientCodeY - 256) / (255.0f * 2.0f);
+    magnitude = std::sqrt(gradientX * gradientX + gradientY * gradientY);   // GradientMagnitudeFilter.cpp:80-86
+    float orientation = std::atan2(gradientY, gradientX);      // GradientOrientationFilter.cpp:137-144 (full range)
+    if (orientation < 0) orientation += TWO_PI;
+    FhogCoeff bins;
+    if (interpolateBins) {                                     // computeInterpolatedBins :111-121
+        const float bin = orientation * value2bin;
+        bins.index1 = (int)bin;
+        bins.index2 = bins.index1 + 1;
+        if (bins.index2 == signedBinCount) bins.index2 = 0;
+        bins.weight2 = magnitude * (bin - bins.index1);
+        bins.weight1 = magnitude - bins.weight2;
+    } else {                                                   // computeBin :103-108
+        int bin = (int)(orientation * value2bin + 0.5f);
+        if (bin == signedBinCount) bin = 0;
+        bins.index1 = bin; bins.index2 = 0; bins.weight1 = magnitude; bins.weight2 = 0;
+    }
+    return bins;
+}
+
+int fhog_filter(const uchar* img, int w, int h, int stride, int cellSize, int unsignedBinCount, bool interpolateBins, bool interpolateCells,
+                float alpha, std::vector<float>& out, int& rowsOut, int& colsOut) {
+    if (unsignedBinCount < 1) throw std::invalid_argument("FhogFilter: unsignedBinCount must be bigger than zero");
+    if (alpha <= 0) throw std::invalid_argument("FhogAggregationFilter: alpha must be bigger than zero");
+    const int signedBinCount = 2 * unsignedBinCount;
+    const int rows = h / cellSize, cols = w / cellSize;
+    const int D = signedBinCount + unsignedBinCount + 4;
+    rowsOut = rows; colsOut = cols;
+    out.assign((size_t)rows * cols * D, 0.f);
+    if (rows == 0 || cols == 0) return 0;
+    // computeSignedHistograms<true> (FhogFilter.hpp:120-131): pixels of the cell-covered region in row-major order
+    std::vector<FhogCoeff> rowCoeff = fhog_interp_coefficients(rows * cellSize, rows, cellSize, interpolateCells);
+    std::vector<FhogCoeff> colCoeff = fhog_interp_coefficients(cols * cellSize, cols, cellSize, interpolateCells);
+    auto H = [&](int r, int c) { return out.data() + ((size_t)r * cols + c) * D; };
+    for (int imageRow = 0; imageRow < (int)rowCoeff.size(); ++imageRow)
+        for (int imageCol = 0; imageCol < (int)colCoeff.size(); ++imageCol) {
+            int prevRow = std::max(imageRow - 1, 0), nextRow = std::min(imageRow + 1, h - 1);
+            int prevCol = std::max(imageCol - 1, 0), nextCol = std::min(imageCol + 1, w - 1);
+            int dx = img[(size_t)imageRow * stride + nextCol] - img[(size_t)imageRow * stride + prevCol] + 256;
+            int dy = img[(size_t)nextRow * stride + imageCol] - img[(size_t)prevRow * stride + imageCol] + 256;
+            float magnitude;
+            FhogCoeff b = fhog_lut_entry(dx, dy, signedBinCount, interpolateBins, magnitude);
+            const FhogCoeff& rc = rowCoeff[imageRow];
+            const FhogCoeff& cc = colCoeff[imageCol];
+            if (interpolateCells) {   // addToSignedHistograms :173-205
+                float* h11 = H(rc.index1, cc.index1); float* h12 = H(rc.index1, cc.index2);
+                float* h21 = H(rc.index2, cc.index1); float* h22 = H(rc.index2, cc.index2);
+                if (interpolateBins) {
+                    h11[b.index1] += b.weight1 * rc.weight1 * cc.weight1;
+                    h11[b.index2] += b.weight2 * rc.weight1 * cc.weight1;
+                    h12[b.index1] += b.weight1 * rc.weight1 * cc.weight2;
+                    h12[b.index2] += b.weight2 * rc.weight1 * cc.weight2;
+                    h21[b.index1] += b.weight1 * rc.weight2 * cc.weight1;
+                    h21[b.index2] += b.weight2 * rc.weight2 * cc.weight1;
+                    h22[b.index1] += b.weight1 * rc.weight2 * cc.weight2;
+                    h22[b.index2] += b.weight2 * rc.weight2 * cc.weight2;
+                } else {
+                    h11[b.index1] += b.weight1 * rc.weight1 * cc.weight1;
+                    h12[b.index1] += b.weight1 * rc.weight1 * cc.weight2;
+                    h21[b.index1] += b.weight1 * rc.weight2 * cc.weight1;
+                    h22[b.index1] += b.weight1 * rc.weight2 * cc.weight2;
+                }
+            } else {
+                float* hh = H(rc.index1, cc.index1);
+                if (interpolateBins) { hh[b.index1] += b.weight1; hh[b.index2] += b.weight2; }
+                else hh[b.index1] += b.weight1;
+            }
+        }
+    // FhogAggregationFilter::computeDescriptors, in place on the same buffer (FhogFilter.cpp:70)
+    const float eps = 1e-4f;
+    std::vector<float> energies((size_t)rows * cols);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) {   // computeGradientEnergy :53-61
+            const float* sh = H(r, c);
+            float energy = 0;
+            for (int bin = 0; bin < unsignedBinCount; ++bin) {
+                float u = sh[bin] + sh[bin + unsignedBinCount];
+                energy += u * u;
+            }
+            energies[(size_t)r * cols + c] = energy;
+        }
+    auto E = [&](int r, int c) { return energies[(size_t)r * cols + c]; };
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) {
+            int pr = std::max(r - 1, 0), nr = std::min(r + 1, rows - 1), pc = std::max(c - 1, 0), nc = std::min(c + 1, cols - 1);
+            float n[4] = {   // computeNormalizers :77-99
+                1.f / std::sqrt(E(pr, pc) + E(pr, c) + E(r, pc) + E(r, c) + eps),
+                1.f / std::sqrt(E(pr, c) + E(pr, nc) + E(r, c) + E(r, nc) + eps),
+                1.f / std::sqrt(E(r, pc) + E(r, c) + E(nr, pc) + E(nr, c) + eps),
+                1.f / std::sqrt(E(r, c) + E(r, nc) + E(nr, c) + E(nr, nc) + eps)};
+            float* d = H(r, c);
+            float energy[4] = {0, 0, 0, 0};
+            auto normalized = [&](float value, float* v4) { for (int i = 0; i < 4; ++i) v4[i] = std::min(alpha, n[i] * value); };
+            for (int bin = 0; bin < unsignedBinCount; ++bin) {   // computeDescriptor :101-148
+                float v4[4];
+                normalized(d[bin] + d[bin + unsignedBinCount], v4);
+                d[signedBinCount + bin] = 0.5 * (v4[0] + v4[1] + v4[2] + v4[3]);
+            }
+            for (int bin = 0; bin < signedBinCount; ++bin) {
+                float v4[4];
+                normalized(d[bin], v4);
+                d[bin] = 0.5 * (v4[0] + v4[1] + v4[2] + v4[3]);
+                for (int i = 0; i < 4; ++i) energy[i] += v4[i];
+            }
+            for (int i = 0; i < 4; ++i) d[signedBinCount + unsignedBinCount + i] = 0.2357 * energy[i];
+        }
+    return (int)out.size();
+}
+
+
 }  // namespace orc
 
 using namespace orc;
@@ -565,6 +706,16 @@ int orc_spatial_pyramid_histogram(const uint8_t* img, int w, int h, int ch, int 
                                   int normalization, float* out) {
     std::vector<float> v;
     int n = spatial_pyramid_histogram(img, w, h, ch, stride, bins, levels, interpolate != 0, normalization, v);
+    if (out) std::memcpy(out, v.data(), sizeof(float) * v.size());
+    return n;
+}
+int orc_fhog(const uint8_t* img, int w, int h, int stride, int cellSize, int unsignedBinCount, int interpolateBins, int interpolateCells,
+             float alpha, float* out, int* rows, int* cols) {
+    std::vector<float> v;
+    int r, c;
+    int n = fhog_filter(img, w, h, stride, cellSize, unsignedBinCount, interpolateBins != 0, interpolateCells != 0, alpha, v, r, c);
+    if (rows) *rows = r;
+    if (cols) *cols = c;
     if (out) std::memcpy(out, v.data(), sizeof(float) * v.size());
     return n;
 }

@@ -220,6 +220,18 @@ def spatial_histogram(binimg, bins, cell, block, interpolate=False, concatenate=
                      int(concatenate), int(normalization))
 
 
+def fhog(gray, cell_size=8, unsigned_bins=9, interpolate_bins=False, interpolate_cells=True, alpha=0.2):
+    """filtering::FhogFilter::applyTo on a gray image: (rows, cols, 3 * unsigned_bins + 4) float32"""
+    gray = _c(gray, np.uint8)
+    h, w = gray.shape
+    rows, cols = h // cell_size, w // cell_size
+    out = np.zeros((rows, cols, 3 * unsigned_bins + 4), np.float32)
+    lib().orc_fhog.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                               C.c_void_p]
+    lib().orc_fhog(_p(gray), w, h, w, cell_size, unsigned_bins, int(interpolate_bins), int(interpolate_cells), alpha, _p(out), None, None)
+    return out
+
+
 def pyramid_hog(binimg, bins, levels, interpolate=False, signed_and_unsigned=False):
     """PyramidHogFilter.cpp:33-113"""
     return _two_pass(lib().orc_pyramid_hog, binimg, bins, levels, int(interpolate), int(signed_and_unsigned))

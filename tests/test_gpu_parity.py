@@ -593,6 +593,26 @@ def test_full_size_properties_config2_and_config3(oracle, capi, ctx, synth):
     wA.close(); wB.close(); sv_.close(); pA.close(); pB.close(); po.close()
 
 
+@pytest.mark.parametrize("cell,ub,ib,ic", [(8, 9, False, True), (8, 9, True, True), (4, 9, False, False), (6, 6, True, False), (5, 18, False, True)])
+def test_fhog_filter_bit_exact(oracle, capi, ctx, frame640, cell, ub, ib, ic):
+    """filtering::FhogFilter on gray images and pyramid layers: descriptors bit-identical to the oracle (lane == cell walks its
+    pixels in the reference's scan order; the gradient LUT is built with the host libm on both sides)."""
+    gray = oracle.bgr2gray(frame640)
+    for img in (gray, np.ascontiguousarray(gray[:97, :131]), np.ascontiguousarray(gray[:cell, :cell * 3]), np.ascontiguousarray(gray[:5, :300])):
+        fo = oracle.fhog(img, cell, ub, ib, ic, 0.2)
+        fg = capi.fhog(ctx, gray=img, cell_size=cell, unsigned_bins=ub, interpolate_bins=ib, interpolate_cells=ic, alpha=0.2)
+        assert fg.shape == fo.shape
+        assert np.array_equal(fg, fo)
+    kw = dict(octave_layers=3, min_scale=0.2, max_scale=1.0)
+    po = oracle.Pyramid(**kw); po.update(frame640)
+    pg = capi.Pyramid(ctx, **kw); pg.update(frame640)
+    for li in (0, len(po.layers()) - 1):
+        fo = oracle.fhog(po.layer(li), cell, ub, ib, ic, 0.35)
+        fg = capi.fhog(ctx, pyramid=pg, layer=li, cell_size=cell, unsigned_bins=ub, interpolate_bins=ib, interpolate_cells=ic, alpha=0.35)
+        assert fo.size > 0 and np.array_equal(fg, fo)
+    pg.close(); po.close()
+
+
 def test_hog_rbf_svm_detector_config2(oracle, capi, ctx, synth):
     """BASELINE config 2 shape on a reduced frame: HOG-324 + RBF SVM (MFMA path).  Scores within
     1e-4 relative (of the natural scale sum|coeff_i| K_i), positives identical away from the threshold."""

@@ -236,3 +236,58 @@ def test_rvm_cascade_restatement(oracle, synth):
     m["num_used"] = 3
     lv, _ = oracle.Rvm(m).eval(feats)
     assert lv.max() == 2
+
+
+def test_fhog_against_numpy_restatement(oracle):
+    """FhogFilter + FhogAggregationFilter restatement against an independent vectorised numpy version (float64 accumulation,
+    so 1e-5): default parameters (cell 8, 9 unsigned bins, hard bin assignment, bilinear cell interpolation, alpha 0.2)."""
+    rng = np.random.default_rng(6)
+    img = rng.integers(0, 256, (67, 90)).astype(np.uint8)
+    img[20:40, 30:70] //= 3
+    cs, ub = 8, 9
+    sb = 2 * ub
+    rows, cols = img.shape[0] // cs, img.shape[1] // cs
+    I = img.astype(np.float64)
+    H, W = rows * cs, cols * cs
+    ys, xs = np.arange(H), np.arange(W)
+    dx = ((I[:H][:, np.minimum(xs + 1, img.shape[1] - 1)] - I[:H][:, np.maximum(xs - 1, 0)]).astype(np.float32) / np.float32(510))
+    dy = ((I[np.minimum(ys + 1, img.shape[0] - 1)][:, :W] - I[np.maximum(ys - 1, 0)][:, :W]).astype(np.float32) / np.float32(510))
+    mag = np.sqrt(dx * dx + dy * dy, dtype=np.float32).astype(np.float64)
+    # orientation and hard bin assignment in float32 like the reference: with 18 bins the axis-aligned gradients sit exactly
+    # on .5 boundaries, so the bin of a purely vertical gradient is decided by float rounding
+    ori = np.arctan2(dy, dx)
+    ori[ori < 0] += np.float32(2 * np.pi)
+    b = (ori * np.float32(sb / np.float32(2 * np.pi)) + np.float32(0.5)).astype(int) % sb
+    hist = np.zeros((rows, cols, sb))
+    def coeff(n, cnt):
+        real = (np.arange(n) + 0.5) / cs - 0.5
+        i1 = np.floor(real).astype(int); i2 = i1 + 1
+        w2 = real - i1; w1 = i2 - real
+        lo, hi = i1 < 0, i2 >= cnt
+        i1[lo] = i2[lo]; w1[lo] = 0
+        i2[hi] = i1[hi]; w2[hi] = 0
+        return i1, i2, w1, w2
+    r1, r2, rw1, rw2 = coeff(H, rows)
+    c1, c2, cw1, cw2 = coeff(W, cols)
+    for (ri, rw) in ((r1, rw1), (r2, rw2)):
+        for (ci, cw) in ((c1, cw1), (c2, cw2)):
+            np.add.at(hist, (ri[:, None].repeat(W, 1), ci[None, :].repeat(H, 0), b), mag * rw[:, None] * cw[None, :])
+    u = hist[..., :ub] + hist[..., ub:]
+    E = (u ** 2).sum(-1)
+    Ep = np.pad(E, 1, mode="edge")
+    def blk(dr, dc):
+        return Ep[dr:dr + rows, dc:dc + cols] + Ep[dr:dr + rows, dc + 1:dc + 1 + cols] + Ep[dr + 1:dr + 1 + rows, dc:dc + cols] + Ep[dr + 1:dr + 1 + rows, dc + 1:dc + 1 + cols]
+    n = [1.0 / np.sqrt(blk(dr, dc) + 1e-4) for dr in (0, 1) for dc in (0, 1)]
+    out = np.zeros((rows, cols, 3 * ub + 4))
+    for k in range(4):
+        vs = np.minimum(0.2, hist * n[k][..., None])
+        out[..., :sb] += 0.5 * vs
+        out[..., sb:sb + ub] += 0.5 * np.minimum(0.2, u * n[k][..., None])
+        out[..., sb + ub + k] = 0.2357 * vs.sum(-1)
+    got = oracle.fhog(img)
+    assert got.shape == out.shape
+    assert np.allclose(got, out, rtol=2e-4, atol=2e-5)
+    for args in ((8, 9, False, False), (4, 6, False, True)):   # other cell sizes / bin counts, shape + range sanity
+        f = oracle.fhog(img, *args)
+        assert f.shape == (img.shape[0] // args[0], img.shape[1] // args[0], 3 * args[1] + 4)
+        assert f.min() >= 0 and f[..., :3 * args[1]].max() <= 0.4 + 1e-6
