@@ -80,6 +80,12 @@ class fd_fhog_params(C.Structure):
                 ("alpha", C.c_float)]
 
 
+class fd_aggregated_params(C.Structure):
+    _fields_ = [("fhog", fd_fhog_params), ("window_w", C.c_int32), ("window_h", C.c_int32), ("octave_layer_count", C.c_int32),
+                ("min_window_width", C.c_int32), ("width_scale", C.c_float), ("height_scale", C.c_float), ("svm_weights", C.c_void_p),
+                ("svm_bias", C.c_float), ("score_threshold", C.c_float), ("nms_overlap_threshold", C.c_double), ("nms_maximum_type", C.c_int32)]
+
+
 class fd_five_stage_job(C.Structure):
     _fields_ = [("pyramid", C.c_void_p), ("wvm", C.c_void_p), ("svm", C.c_void_p), ("oe_dist", C.c_float), ("oe_ratio", C.c_float),
                 ("step_x", C.c_int32), ("step_y", C.c_int32), ("roi", C.c_void_p), ("out", C.c_void_p), ("cap", C.c_int32),
@@ -151,6 +157,10 @@ _SIGS = {
     "fd_fhog_size": (C.c_int, [C.POINTER(fd_fhog_params), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "fd_fhog_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(fd_fhog_params), C.c_void_p]),
     "fd_pyramid_fhog_layer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(fd_fhog_params), C.c_void_p]),
+    "fd_aggregated_create": (C.c_int, [C.c_void_p, C.POINTER(fd_aggregated_params), C.POINTER(C.c_void_p)]),
+    "fd_aggregated_destroy": (None, [C.c_void_p]),
+    "fd_aggregated_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                       C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "fd_nms_iou": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     "fd_wvm_svm_evaluate_samples": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fd_detect_five_stage_batch": (C.c_int, [C.c_void_p, C.POINTER(fd_five_stage_job), C.c_int]),
@@ -438,6 +448,37 @@ def fhog(ctx, gray=None, pyramid=None, layer=0, cell_size=8, unsigned_bins=9, in
     else:
         ctx.check(lib().fd_pyramid_fhog_layer(ctx.h, pyramid.h, layer, C.byref(fp), _ptr(out)))
     return out
+
+
+class Aggregated:
+    """fd_aggregated handle: AggregatedFeaturesDetector with GrayscaleFilter + FhogFilter; weights (window_h, window_w, 3B+4)"""
+    def __init__(self, ctx, weights, bias, threshold, cell_size=8, unsigned_bins=9, interpolate_bins=False, interpolate_cells=True, alpha=0.2,
+                 octave_layers=5, min_window_width=0, width_scale=1.0, height_scale=1.0, nms_overlap=0.3, nms_type=0):
+        self.ctx = ctx
+        self._w = _c(weights, np.float32)
+        wh, ww, d = self._w.shape
+        assert d == 3 * unsigned_bins + 4
+        prm = fd_aggregated_params(fd_fhog_params(cell_size, unsigned_bins, int(interpolate_bins), int(interpolate_cells), alpha), ww, wh,
+                                   octave_layers, min_window_width, width_scale, height_scale, self._w.ctypes.data, bias, threshold,
+                                   nms_overlap, nms_type)
+        self.h = C.c_void_p()
+        ctx.check(lib().fd_aggregated_create(ctx.h, C.byref(prm), C.byref(self.h)))
+
+    def detect(self, image, cap=1 << 16):
+        """(final detections, candidates) as BOX_DTYPE arrays"""
+        image = _c(image, np.uint8)
+        h, w = image.shape[:2]
+        ch = 1 if image.ndim == 2 else image.shape[2]
+        out, cand = np.zeros(cap, BOX_DTYPE), np.zeros(1 << 20, BOX_DTYPE)
+        n, nc = C.c_int(), C.c_int()
+        self.ctx.check(lib().fd_aggregated_detect(self.ctx.h, self.h, _ptr(image), w, h, ch, 0, _ptr(out), cap, C.byref(n), _ptr(cand), len(cand),
+                                                  C.byref(nc)))
+        return out[:n.value], cand[:nc.value]
+
+    def close(self):
+        if self.h:
+            lib().fd_aggregated_destroy(self.h)
+            self.h = None
 
 
 def nms_iou(boxes, overlap_threshold, maximum_type=0):

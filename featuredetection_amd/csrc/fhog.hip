@@ -17,6 +17,16 @@
 #include <cstring>
 #include <memory>
 
+struct fd_aggregated {
+    fd_ctx* ctx;
+    fd_aggregated_params prm;
+    std::vector<float> weights;
+    DevBuf dweights, scores;
+    fd_pyramid* pyr = nullptr;
+    int pyrW = 0, pyrH = 0;
+    ~fd_aggregated() { if (pyr) fd_pyramid_destroy(pyr); }
+};
+
 struct FhogLut {   // one entry per (dy, dx) gradient code
     uint8_t index1, index2;
     uint16_t pad;
@@ -236,6 +246,29 @@ void run_fhog(fd_ctx* ctx, FhogScratch& S, const uint8_t* dimg, int w, int h, in
     HIP_CHECK(hipGetLastError());
 }
 
+
+// ConvolutionFilter(CV_32F) of AggregatedFeaturesDetector (ConvolutionFilter.cpp:27-43 with anchor (0, 0), delta = -bias):
+// score(y, x) = delta + sum over channels c of [sum over the kernel window, row-major, of K[ky][kx][c] * F[y+ky][x+kx][c]];
+// lane == window position, the nesting and the fp32 accumulation order of the per-channel cv::filter2D + channel sum.
+__global__ __launch_bounds__(256) void k_fhog_score(const float* __restrict__ F, int rows, int cols, int D, const float* __restrict__ K, int kh, int kw,
+                                                    float delta, float* __restrict__ scores) {
+    const int vw = cols - kw + 1, vh = rows - kh + 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= vw * vh) return;
+    const int y = i / vw, x = i - y * vw;
+    float score = delta;
+    for (int c = 0; c < D; ++c) {
+        float sacc = 0.f;
+        for (int ky = 0; ky < kh; ++ky) {
+            const float* frow = F + ((size_t)(y + ky) * cols + x) * D + c;
+            const float* krow = K + (size_t)ky * kw * D + c;
+            for (int kx = 0; kx < kw; ++kx) sacc = sacc + krow[(size_t)kx * D] * frow[(size_t)kx * D];
+        }
+        score = score + sacc;
+    }
+    scores[i] = score;
+}
+
 }  // namespace
 
 extern "C" {
@@ -277,6 +310,119 @@ int fd_pyramid_fhog_layer(fd_ctx* ctx, fd_pyramid* p, int layer, const fd_fhog_p
         if (rows && cols)
             HIP_CHECK(hipMemcpyAsync(out, S.desc.p, sizeof(float) * (size_t)rows * cols * (3 * fp->unsigned_bins + 4), hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int fd_aggregated_create(fd_ctx* ctx, const fd_aggregated_params* prm, fd_aggregated** out) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !prm || !out || !prm->svm_weights) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_aggregated_create: NULL argument");
+        if (prm->window_w < 1 || prm->window_h < 1 || prm->octave_layer_count < 1)
+            FD_THROW(FD_ERR_INVALID_ARGUMENT, "AggregatedFeaturesDetector: window size and octave layer count must be positive");
+        if (prm->fhog.cell_size < 1 || prm->fhog.unsigned_bins < 1 || 2 * prm->fhog.unsigned_bins > FHOG_MAX_SBINS || !(prm->fhog.alpha > 0))
+            FD_THROW(FD_ERR_INVALID_ARGUMENT, "AggregatedFeaturesDetector: invalid FhogFilter parameters");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        std::unique_ptr<fd_aggregated> a(new fd_aggregated());
+        a->ctx = ctx;
+        a->prm = *prm;
+        const size_t nw = (size_t)prm->window_w * prm->window_h * (3 * prm->fhog.unsigned_bins + 4);
+        a->weights.assign(prm->svm_weights, prm->svm_weights + nw);
+        a->prm.svm_weights = nullptr;
+        a->dweights.reserve(sizeof(float) * nw);
+        HIP_CHECK(hipMemcpy(a->dweights.p, a->weights.data(), sizeof(float) * nw, hipMemcpyHostToDevice));
+        *out = a.release();
+    });
+}
+
+void fd_aggregated_destroy(fd_aggregated* a) { delete a; }
+
+int fd_aggregated_detect(fd_ctx* ctx, fd_aggregated* a, const uint8_t* image, int width, int height, int channels, int is_device, fd_box* out,
+                         int cap, int* count, fd_box* candidates, int cand_cap, int* cand_count) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !a || !image || !count) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_aggregated_detect: NULL argument");
+        if (a->ctx != ctx) FD_THROW(FD_ERR_INVALID_ARGUMENT, "objects belong to different contexts");
+        const fd_aggregated_params& P = a->prm;
+        HIP_CHECK(hipSetDevice(ctx->device));
+        // feature pyramid limits (AggregatedFeaturesExtractor.cpp:30-31,47-52,58-77), recomputed when the image size changes
+        if (!a->pyr || a->pyrW != width || a->pyrH != height) {
+            if (a->pyr) { fd_pyramid_destroy(a->pyr); a->pyr = nullptr; }
+            const int patchWpx = P.window_w * P.fhog.cell_size, patchHpx = P.window_h * P.fhog.cell_size;
+            const double inc = std::pow(0.5, 1. / P.octave_layer_count);
+            double maxScale = 1.0;
+            if (P.min_window_width > patchWpx) {
+                const double m = (double)patchWpx / P.min_window_width;
+                const int minLayerIndex = (int)std::ceil(std::log(m) / std::log(inc));
+                maxScale = std::pow(inc, minLayerIndex);
+            }
+            const double aspectRatio = (double)patchHpx / (double)patchWpx, imageAspectRatio = (double)height / (double)width;
+            const int maxWidth = aspectRatio > imageAspectRatio ? (int)(height / aspectRatio) : width;
+            const double m = (double)patchWpx / maxWidth;
+            const int maxLayerIndex = (int)(std::log(m) / std::log(inc));
+            const double minScale = std::pow(inc, maxLayerIndex);
+            const int rc = fd_pyramid_create(ctx, P.octave_layer_count, minScale, maxScale, &a->pyr);
+            if (rc != FD_OK) throw FdError{rc, ctx->error};
+            a->pyrW = width; a->pyrH = height;
+        }
+        {
+            const int rc = fd_pyramid_update(a->pyr, image, width, height, channels, is_device);
+            if (rc != FD_OK) throw FdError{rc, ctx->error};
+        }
+        fd_pyramid* p = a->pyr;
+        if (p->kept.size() < 2)   // ImagePyramid::estimateLambdas (ImagePyramid.cpp:240-242) of the score pyramid
+            FD_THROW(FD_ERR_RUNTIME, "ImagePyramid: at least two pyramid layers are needed to estimate the lambdas");
+        FhogScratch& S = scratch(ctx);
+        const int D = 3 * P.fhog.unsigned_bins + 4;
+        // score maps of all layers, one after the other on the stream
+        std::vector<size_t> off(p->kept.size() + 1, 0);
+        std::vector<int> vw(p->kept.size()), vh(p->kept.size());
+        for (size_t li = 0; li < p->kept.size(); ++li) {
+            const HostLayer& L = p->all[p->kept[li]];
+            const int rows = L.h / P.fhog.cell_size, cols = L.w / P.fhog.cell_size;
+            vh[li] = std::max(rows - P.window_h + 1, 0);
+            vw[li] = std::max(cols - P.window_w + 1, 0);
+            off[li + 1] = off[li] + (size_t)vw[li] * vh[li];
+        }
+        a->scores.reserve(sizeof(float) * std::max<size_t>(off.back(), 1));
+        for (size_t li = 0; li < p->kept.size(); ++li) {
+            if (!vw[li] || !vh[li]) continue;
+            const HostLayer& L = p->all[p->kept[li]];
+            int rows, cols;
+            run_fhog(ctx, S, p->arena.as<uint8_t>() + L.gray_off, L.w, L.h, L.w, P.fhog, rows, cols);
+            const int npos = vw[li] * vh[li];
+            hipLaunchKernelGGL(k_fhog_score, dim3((npos + 255) / 256), dim3(256), 0, ctx->stream, S.desc.as<float>(), rows, cols, D,
+                               a->dweights.as<float>(), P.window_h, P.window_w, -P.svm_bias, a->scores.as<float>() + off[li]);
+            HIP_CHECK(hipGetLastError());
+            // run_fhog stages its interpolation tables through the context's pinned scratch: keep the host from overwriting it
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        }
+        std::vector<float> hs(off.back());
+        if (!hs.empty()) HIP_CHECK(hipMemcpy(hs.data(), a->scores.p, sizeof(float) * hs.size(), hipMemcpyDeviceToHost));
+        // getPositiveWindows (AggregatedFeaturesDetector.cpp:87-106): layer, row, column order
+        std::vector<fd_box> cand;
+        for (size_t li = 0; li < p->kept.size(); ++li) {
+            const HostLayer& L = p->all[p->kept[li]];
+            const double scaleX = (double)L.w / (double)width, scaleY = (double)L.h / (double)height;   // ImagePyramid.cpp:178-179,187-188
+            for (int y = 0; y < vh[li]; ++y)
+                for (int x = 0; x < vw[li]; ++x) {
+                    const float score = hs[off[li] + (size_t)y * vw[li] + x];
+                    if (!(score > P.score_threshold)) continue;
+                    const int cs = P.fhog.cell_size;
+                    const int bx = (int)std::round((x * cs) / scaleX), by = (int)std::round((y * cs) / scaleY);
+                    const int bw = (int)std::round((P.window_w * cs) / scaleX), bh = (int)std::round((P.window_h * cs) / scaleY);
+                    const int cx = bx + bw / 2, cy = by + bh / 2;                                // Patch::computeCenter
+                    const int rw = (int)(P.width_scale * bw), rh = (int)(P.height_scale * bh);  // rescaleWindow :108-112
+                    cand.push_back(fd_box{score, cx - rw / 2, cy - rh / 2, rw, rh});
+                }
+        }
+        if (cand_count) *cand_count = (int)cand.size();
+        if (candidates)
+            for (size_t i = 0; i < cand.size() && (int)i < cand_cap; ++i) candidates[i] = cand[i];
+        std::vector<fd_box> fin(cand.size());
+        int nfin = 0;
+        const int rc = fd_nms_iou(cand.data(), (int)cand.size(), P.nms_overlap_threshold, P.nms_maximum_type, fin.data(), &nfin);
+        if (rc != FD_OK) FD_THROW(rc, "NonMaximumSuppression failed (overlap threshold %g, maximum type %d)", P.nms_overlap_threshold, P.nms_maximum_type);
+        *count = nfin;
+        for (int i = 0; i < nfin && i < cap && out; ++i) out[i] = fin[i];
+        if (out && nfin > cap) FD_THROW(FD_ERR_CAPACITY, "fd_aggregated_detect: %d detections, capacity %d", nfin, cap);
     });
 }
 

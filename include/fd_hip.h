@@ -224,6 +224,28 @@ int fd_fhog_image(fd_ctx* ctx, const uint8_t* gray, int width, int height, const
 /* the same on kept layer `layer` of an updated gray pyramid (the layer filter of AggregatedFeaturesExtractor's feature pyramid) */
 int fd_pyramid_fhog_layer(fd_ctx* ctx, fd_pyramid* p, int layer, const fd_fhog_params* fp, float* out);
 
+/* detection::AggregatedFeaturesDetector (AggregatedFeaturesDetector.cpp:37-128) with imageFilter = GrayscaleFilter,
+ * layerFilter = FhogFilter on an extraction::AggregatedFeaturesExtractor (AggregatedFeaturesExtractor.cpp:34-130): a linear
+ * SVM convolved over the FHOG cell pyramid (ConvolutionFilter.cpp:27-43), windows with score > threshold, bounds through
+ * the layers' actual x / y scales, rescaleWindow, NonMaximumSuppression.  SURVEY.md 8(f) row 2. */
+typedef struct fd_aggregated fd_aggregated;
+typedef struct {
+    fd_fhog_params fhog;              /* layer filter; fhog.cell_size is the detector's cellSize */
+    int32_t window_w, window_h;       /* windowSize in cells */
+    int32_t octave_layer_count;
+    int32_t min_window_width;         /* minWindowWidth in pixels (0: none) */
+    float width_scale, height_scale;  /* rescaleWindow */
+    const float* svm_weights;         /* the linear SVM's support vector, [window_h][window_w][3 * unsigned_bins + 4] */
+    float svm_bias, score_threshold;  /* delta = -bias; getThreshold() */
+    double nms_overlap_threshold;
+    int32_t nms_maximum_type;         /* 0 MAX_SCORE, 1 AVERAGE, 2 WEIGHTED_AVERAGE */
+} fd_aggregated_params;
+int fd_aggregated_create(fd_ctx* ctx, const fd_aggregated_params* prm, fd_aggregated** out);
+void fd_aggregated_destroy(fd_aggregated* a);
+/* detectWithScores(image): final detections in out; candidates (before NMS, layer / row / column order) optionally */
+int fd_aggregated_detect(fd_ctx* ctx, fd_aggregated* a, const uint8_t* image, int width, int height, int channels, int is_device,
+                         fd_box* out, int cap, int* count, fd_box* candidates, int cand_cap, int* cand_count);
+
 /* Generic histogram patch filters on the pyramid's bin-image layers (FD_LAYER_GRADBIN: 2 or 4 channels,
  * FD_LAYER_LBP: 1 channel), all built on HistogramFilter::createCellHistograms (HistogramFilter.cpp:23-197,
  * interpolating and non-interpolating):

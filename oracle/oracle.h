@@ -132,6 +132,13 @@ int64_t orc_sliding_wvm(const orc_pyramid* p, const orc_wvm* m, int stepX, int s
                         orc_det* out, int64_t cap, int32_t* all_level, float* all_fout);
 /* FiveStageSlidingWindowDetector.cpp:187-320 (roi==NULL) / :331-380 (roi!=NULL).
  * stage_counts[4] = {wvm positives, after OE, svm positives, final}. */
+/* AggregatedFeaturesDetector::getPositiveWindows (AggregatedFeaturesDetector.cpp:87-106) for GrayscaleFilter + FhogFilter on
+ * an AggregatedFeaturesExtractor: candidate windows (score, rescaled bounds) before NMS, in layer / row / column order.
+ * Returns their number (may exceed cap), -1 when the feature pyramid has fewer than two layers (the reference throws). */
+int orc_aggregated_candidates(const uint8_t* img, int w, int h, int ch, int cellSize, int unsignedBinCount, int interpolateBins,
+                              int interpolateCells, float alpha, int windowW, int windowH, int octaveLayerCount, int minWindowWidth,
+                              float widthScale, float heightScale, const float* svmWeights, float svmBias, float scoreThreshold,
+                              float* outScore, int32_t* outXywh, int cap);
 /* NonMaximumSuppression::eliminateRedundantDetections (NonMaximumSuppression.cpp:27-118); returns the number of detections (-1: overlap threshold > 1) */
 int orc_nms_iou(int n, const float* score, const int32_t* xywh, double overlapThreshold, int maximumType, float* outScore, int32_t* outXywh);
 /* DirectPyramidFeatureExtractor::extract(x, y, width, height) (:67-73,134-153): 1 + {layerPos, lx, ly, cx, cy, ow, oh} or 0 */

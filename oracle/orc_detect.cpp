@@ -253,6 +253,72 @@ int64_t orc_sliding_wvm(const orc_pyramid* p, const orc_wvm* m, int stepX, int s
     return (int64_t)pos.size();
 }
 
+// detection::AggregatedFeaturesDetector (AggregatedFeaturesDetector.cpp:37-128) with a GrayscaleFilter image filter and a
+// FhogFilter layer filter on an AggregatedFeaturesExtractor (AggregatedFeaturesExtractor.cpp:34-86): feature pyramid
+// ImagePyramid(octaveLayerCount, 0.5, 1) whose minimum / maximum scale factors follow the image and the minimum window
+// width, score pyramid = ConvolutionFilter(CV_32F) of the linear SVM's support vector with anchor (0, 0) and delta = -bias
+// (ConvolutionFilter.cpp:27-43: per channel cv::filter2D, summed channel by channel onto delta), windows with
+// score > threshold in layer / row / column order, bounds through the layer's actual x / y scale, rescaleWindow.
+// Returns the candidates (before NonMaximumSuppression).
+int orc_aggregated_candidates(const uint8_t* img, int w, int h, int ch, int cellSize, int unsignedBinCount, int interpolateBins,
+                              int interpolateCells, float alpha, int windowW, int windowH, int octaveLayerCount, int minWindowWidth,
+                              float widthScale, float heightScale, const float* svmWeights, float svmBias, float scoreThreshold,
+                              float* outScore, int32_t* outXywh, int cap) {
+    const int D = 3 * unsignedBinCount + 4;
+    const int patchWpx = windowW * cellSize, patchHpx = windowH * cellSize;
+    const double inc = std::pow(0.5, 1. / octaveLayerCount);   // ImagePyramid.cpp:67-78
+    double maxScale = 1.0;
+    if (minWindowWidth > patchWpx) {   // AggregatedFeaturesExtractor.cpp:30-31,47-52
+        double m = (double)patchWpx / minWindowWidth;
+        int minLayerIndex = (int)std::ceil(std::log(m) / std::log(inc));
+        maxScale = std::pow(inc, minLayerIndex);
+    }
+    double minScale;
+    {   // getMinScaleFactor / getMaxWidth :64-77
+        double aspectRatio = (double)patchHpx / (double)patchWpx;
+        double imageAspectRatio = (double)h / (double)w;
+        int maxWidth = aspectRatio > imageAspectRatio ? (int)(h / aspectRatio) : w;
+        double m = (double)patchWpx / maxWidth;
+        int maxLayerIndex = (int)(std::log(m) / std::log(inc));
+        minScale = std::pow(inc, maxLayerIndex);
+    }
+    Pyramid pyr((size_t)octaveLayerCount, minScale, maxScale);
+    pyr.update(img, w, h, ch);
+    if (pyr.layers.size() < 2) return -1;   // ImagePyramid::estimateLambdas (ImagePyramid.cpp:240-242) throws
+    int n = 0;
+    for (const Layer& L : pyr.layers) {
+        std::vector<float> F;
+        int rows, cols;
+        fhog_filter(L.img.d.data(), L.img.w, L.img.h, L.img.w, cellSize, unsignedBinCount, interpolateBins != 0, interpolateCells != 0, alpha, F,
+                    rows, cols);
+        int validHeight = rows - windowH + 1, validWidth = cols - windowW + 1;   // AggregatedFeaturesDetector.cpp:91-92
+        for (int y = 0; y < validHeight; ++y)
+            for (int x = 0; x < validWidth; ++x) {
+                float score = -svmBias;   // filtered = delta; filtered += filter2D(channel_i, kernel_i)
+                for (int c = 0; c < D; ++c) {
+                    float s = 0;
+                    for (int ky = 0; ky < windowH; ++ky)
+                        for (int kx = 0; kx < windowW; ++kx)
+                            s += svmWeights[((size_t)ky * windowW + kx) * D + c] * F[((size_t)(y + ky) * cols + (x + kx)) * D + c];
+                    score += s;
+                }
+                if (score > scoreThreshold) {
+                    // computeBoundsInImagePixels (AggregatedFeaturesExtractor.cpp:123-130), rescaleWindow (:108-112)
+                    int bx = (int)std::round((x * cellSize) / L.scaleX), by = (int)std::round((y * cellSize) / L.scaleY);
+                    int bw = (int)std::round((windowW * cellSize) / L.scaleX), bh = (int)std::round((windowH * cellSize) / L.scaleY);
+                    int cx = bx + bw / 2, cy = by + bh / 2;
+                    int rw = (int)(widthScale * bw), rh = (int)(heightScale * bh);
+                    if (n < cap) {
+                        outScore[n] = score;
+                        outXywh[4 * n] = cx - rw / 2; outXywh[4 * n + 1] = cy - rh / 2; outXywh[4 * n + 2] = rw; outXywh[4 * n + 3] = rh;
+                    }
+                    ++n;
+                }
+            }
+    }
+    return n;
+}
+
 // NonMaximumSuppression.cpp:27-118
 int orc_nms_iou(int n, const float* score, const int32_t* xywh, double overlapThreshold, int maximumType, float* outScore, int32_t* outXywh) {
     struct Det { float score; int x, y, w, h; };

@@ -350,6 +350,28 @@ class Svm:
         return lib().orc_svm_probability(self.h, float(d))
 
 
+def aggregated_candidates(img, weights, bias, threshold, cell_size=8, unsigned_bins=9, interpolate_bins=False, interpolate_cells=True, alpha=0.2,
+                          octave_layers=5, min_window_width=0, width_scale=1.0, height_scale=1.0):
+    """AggregatedFeaturesDetector::getPositiveWindows (GrayscaleFilter + FhogFilter): weights (window_h, window_w, 3B+4);
+    returns (score[n], xywh[n, 4]) in layer / row / column order, or None when the pyramid has fewer than two layers"""
+    img = _c(img, np.uint8)
+    h, w = img.shape[:2]
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    weights = _c(weights, np.float32)
+    wh, ww, _ = weights.shape
+    cap = 1 << 20
+    sc, bx = np.empty(cap, np.float32), np.empty((cap, 4), np.int32)
+    f = lib().orc_aggregated_candidates
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
+                  C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int]
+    n = f(_p(img), w, h, ch, cell_size, unsigned_bins, int(interpolate_bins), int(interpolate_cells), alpha, ww, wh, octave_layers,
+          min_window_width, width_scale, height_scale, _p(weights), bias, threshold, _p(sc), _p(bx), cap)
+    if n < 0:
+        return None
+    assert n <= cap
+    return sc[:n].copy(), bx[:n].copy()
+
+
 def nms_iou(score, xywh, overlap_threshold, maximum_type=0):
     """NonMaximumSuppression::eliminateRedundantDetections; returns (score[m], xywh[m, 4])"""
     score = _c(score, np.float32)

@@ -613,6 +613,38 @@ def test_fhog_filter_bit_exact(oracle, capi, ctx, frame640, cell, ub, ib, ic):
     pg.close(); po.close()
 
 
+@pytest.mark.parametrize("cfg", [dict(size=(320, 240), win=(6, 6), cell=8, octl=5, ib=False, ic=True, minw=0, ws=1.0, hs=1.0, ch=3, nms=(0.3, 0)),
+                                 dict(size=(400, 300), win=(5, 7), cell=6, octl=3, ib=True, ic=True, minw=80, ws=0.8, hs=1.1, ch=1, nms=(0.5, 2)),
+                                 dict(size=(251, 333), win=(8, 4), cell=4, octl=4, ib=False, ic=False, minw=0, ws=1.0, hs=1.0, ch=3, nms=(0.4, 1))])
+def test_aggregated_features_detector(oracle, capi, ctx, synth, cfg):
+    """detection::AggregatedFeaturesDetector (GrayscaleFilter + FhogFilter feature pyramid, linear SVM as ConvolutionFilter, score
+    threshold, window bounds, rescaleWindow, IoU NMS): candidates (scores included) and final detections identical to the oracle."""
+    W, H = cfg["size"]
+    frame = synth.make_frame(W, H, seed=77)
+    img = frame if cfg["ch"] == 3 else oracle.bgr2gray(frame)
+    ww, wh = cfg["win"]
+    rng = np.random.default_rng(5)
+    weights = rng.normal(0, 0.05, (wh, ww, 31)).astype(np.float32)
+    # threshold: a high quantile of the scores of the full-resolution layer, so that a few hundred windows are positive
+    sc0, _ = oracle.aggregated_candidates(img, weights, 0.1, -1e30, cell_size=cfg["cell"], interpolate_bins=cfg["ib"], interpolate_cells=cfg["ic"],
+                                          octave_layers=cfg["octl"], min_window_width=cfg["minw"])
+    thr = float(np.float32(np.quantile(sc0, 0.9)))
+    kw = dict(cell_size=cfg["cell"], interpolate_bins=cfg["ib"], interpolate_cells=cfg["ic"], octave_layers=cfg["octl"], min_window_width=cfg["minw"],
+              width_scale=cfg["ws"], height_scale=cfg["hs"])
+    so, bo = oracle.aggregated_candidates(img, weights, 0.1, thr, **kw)
+    det = capi.Aggregated(ctx, weights, 0.1, thr, nms_overlap=cfg["nms"][0], nms_type=cfg["nms"][1], **kw)
+    fin, cand = det.detect(img)
+    assert len(cand) == len(so) > 5
+    assert np.array_equal(cand["score"], so)
+    assert np.array_equal(np.stack([cand["x"], cand["y"], cand["w"], cand["h"]], 1), bo)
+    fs, fb = oracle.nms_iou(so, bo, cfg["nms"][0], cfg["nms"][1])
+    assert len(fin) == len(fs) > 0
+    assert np.array_equal(fin["score"], fs) and np.array_equal(np.stack([fin["x"], fin["y"], fin["w"], fin["h"]], 1), fb)
+    fin2, _ = det.detect(img)   # second frame of the same size reuses the pyramid
+    assert fin2.tobytes() == fin.tobytes()
+    det.close()
+
+
 def test_hog_rbf_svm_detector_config2(oracle, capi, ctx, synth):
     """BASELINE config 2 shape on a reduced frame: HOG-324 + RBF SVM (MFMA path).  Scores within
     1e-4 relative (of the natural scale sum|coeff_i| K_i), positives identical away from the threshold."""
