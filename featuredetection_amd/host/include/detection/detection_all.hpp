@@ -66,6 +66,28 @@ private:
     MaximumType maximumType;
 };
 
+// AggregatedFeaturesDetector.hpp:40-110 / AggregatedFeaturesDetector.cpp:37-128 (SimpleDetector interface: bounding boxes).
+// On this backend the image filter must be a GrayscaleFilter and the layer filter a filtering::FhogFilter; the SVM must
+// use a LinearKernel and hold one support vector of windowSize.height x (windowSize.width * channels) floats.
+class AggregatedFeaturesDetector {
+public:
+    AggregatedFeaturesDetector(std::shared_ptr<imageprocessing::ImageFilter> imageFilter, std::shared_ptr<imageprocessing::ImageFilter> layerFilter,
+                               int cellSize, cv::Size windowSize, int octaveLayerCount, std::shared_ptr<classification::SvmClassifier> svm,
+                               std::shared_ptr<NonMaximumSuppression> nonMaximumSuppression, float widthScale = 1.0f, float heightScale = 1.0f,
+                               int minWindowWidth = 0);
+    ~AggregatedFeaturesDetector();
+    std::vector<cv::Rect> detect(std::shared_ptr<imageprocessing::VersionedImage> image);
+    std::vector<std::pair<cv::Rect, float>> detectWithScores(std::shared_ptr<imageprocessing::VersionedImage> image);
+    std::vector<cv::Rect> detect(const cv::Mat& image) { return detect(std::make_shared<imageprocessing::VersionedImage>(image)); }
+    std::vector<std::pair<cv::Rect, float>> detectWithScores(const cv::Mat& image) {
+        return detectWithScores(std::make_shared<imageprocessing::VersionedImage>(image));
+    }
+    float getScoreThreshold() const { return scoreThreshold; }
+private:
+    fd_aggregated* handle = nullptr;
+    float scoreThreshold;
+};
+
 // SlidingWindowDetector.hpp:41-93 / SlidingWindowDetector.cpp:40-98
 class SlidingWindowDetector : public Detector {
 public:

@@ -829,6 +829,54 @@ vector<Detection> NonMaximumSuppression::eliminateRedundantDetections(vector<Det
     return res;
 }
 
+AggregatedFeaturesDetector::AggregatedFeaturesDetector(shared_ptr<imageprocessing::ImageFilter> imageFilter, shared_ptr<imageprocessing::ImageFilter> layerFilter,
+                                                       int cellSize, cv::Size windowSize, int octaveLayerCount,
+                                                       shared_ptr<classification::SvmClassifier> svm, shared_ptr<NonMaximumSuppression> nms,
+                                                       float widthScale, float heightScale, int minWindowWidth)
+    : scoreThreshold(svm->getThreshold()) {
+    if (!dynamic_cast<classification::LinearKernel*>(svm->getKernel().get()))
+        throw std::invalid_argument("AggregatedFeaturesDetector: the SVM must use a LinearKernel");
+    auto fhog = std::dynamic_pointer_cast<imageprocessing::filtering::FhogFilter>(layerFilter);
+    if (!std::dynamic_pointer_cast<imageprocessing::GrayscaleFilter>(imageFilter) || !fhog)
+        throw std::logic_error("AggregatedFeaturesDetector: this backend needs a GrayscaleFilter image filter and a filtering::FhogFilter layer filter");
+    if (fhog->cellSize != cellSize) throw std::invalid_argument("AggregatedFeaturesDetector: cellSize differs from the FhogFilter's");
+    const int D = 3 * fhog->unsignedBinCount + 4;
+    if (svm->getSupportVectors().size() != 1) throw std::invalid_argument("AggregatedFeaturesDetector: a linear SVM with one support vector is needed");
+    Mat sv = contiguous(svm->getSupportVectors()[0]);
+    if (sv.depth() != CV_32F || (int)(sv.total() * sv.channels()) != windowSize.width * windowSize.height * D)
+        throw std::invalid_argument("AggregatedFeaturesDetector: the support vector must hold windowSize x (3 * unsignedBinCount + 4) floats");
+    fd_aggregated_params prm;
+    std::memset(&prm, 0, sizeof(prm));
+    prm.fhog = fd_fhog_params{fhog->cellSize, fhog->unsignedBinCount, fhog->interpolateBins, fhog->interpolateCells, fhog->alpha};
+    prm.window_w = windowSize.width; prm.window_h = windowSize.height; prm.octave_layer_count = octaveLayerCount;
+    prm.min_window_width = minWindowWidth; prm.width_scale = widthScale; prm.height_scale = heightScale;
+    // SvmClassifier: distance = -bias + coefficient * <sv, x>; the reference convolves the raw support vector (coefficients are 1)
+    prm.svm_weights = sv.ptr<float>(0);
+    prm.svm_bias = svm->getBias(); prm.score_threshold = svm->getThreshold();
+    prm.nms_overlap_threshold = nms->getOverlapThreshold(); prm.nms_maximum_type = (int)nms->getMaximumType();
+    check(fd_aggregated_create(context(), &prm, &handle));
+}
+AggregatedFeaturesDetector::~AggregatedFeaturesDetector() { fd_aggregated_destroy(handle); }
+vector<std::pair<cv::Rect, float>> AggregatedFeaturesDetector::detectWithScores(shared_ptr<imageprocessing::VersionedImage> image) {
+    Mat img = contiguous(image->getData());
+    vector<fd_box> out(1 << 14);
+    int n = 0;
+    int rc = fd_aggregated_detect(context(), handle, img.data, img.cols, img.rows, img.channels(), 0, out.data(), (int)out.size(), &n, nullptr, 0, nullptr);
+    if (rc == FD_ERR_CAPACITY) {
+        out.resize((size_t)n);
+        rc = fd_aggregated_detect(context(), handle, img.data, img.cols, img.rows, img.channels(), 0, out.data(), n, &n, nullptr, 0, nullptr);
+    }
+    check(rc);
+    vector<std::pair<cv::Rect, float>> res;
+    for (int i = 0; i < n; ++i) res.emplace_back(cv::Rect(out[i].x, out[i].y, out[i].w, out[i].h), out[i].score);
+    return res;
+}
+vector<cv::Rect> AggregatedFeaturesDetector::detect(shared_ptr<imageprocessing::VersionedImage> image) {
+    vector<cv::Rect> res;
+    for (const auto& d : detectWithScores(image)) res.push_back(d.first);
+    return res;
+}
+
 SlidingWindowDetector::SlidingWindowDetector(shared_ptr<classification::ProbabilisticClassifier> classifier,
                                              shared_ptr<imageprocessing::PyramidFeatureExtractor> featureExtractor, int sx, int sy)
     : classifier(classifier), featureExtractor(featureExtractor), stepSizeX(sx), stepSizeY(sy) {}
