@@ -1,9 +1,11 @@
 // sdm_fit_app -- the two calls every SDM caller of the reference makes (detect-landmarks.cpp:272-276,
 // sdmTracking.cpp:362,371): alignRigid + optimize, on the reference-shaped classes of this backend.
-// usage: sdm_fit_app <model.txt> <image.pgm> <x> <y> <w> <h>   -> prints the 2L landmark coordinates
+// usage: sdm_fit_app <model.txt> <image.pgm> <x> <y> <w> <h> [landmarks.txt]   -> prints the 2L landmark coordinates;
+// with a seventh argument the landmarks also go through imageio::SimpleModelLandmarkSink ("name x y" per line)
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include "imageio/imageio_all.hpp"
 #include "superviseddescent/superviseddescent_all.hpp"
 
 using namespace superviseddescent;
@@ -24,6 +26,13 @@ int main(int argc, char** argv) {
         modelShape = modelFitter.alignRigid(modelShape, faceBox);
         modelShape = modelFitter.optimize(modelShape, imgGray);
         for (int i = 0; i < modelShape.rows; ++i) std::printf("%.9g\n", modelShape.at<float>(i, 0));
+        if (argc > 7) {   // like the landmark output of the reference's detect-landmarks app
+            imageio::LandmarkCollection lms;
+            const int L = modelShape.rows / 2;
+            for (int i = 0; i < L; ++i)
+                lms.insert(std::make_shared<imageio::ModelLandmark>(std::to_string(i), modelShape.at<float>(i, 0), modelShape.at<float>(i + L, 0)));
+            imageio::SimpleModelLandmarkSink().add(lms, argv[7]);
+        }
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 1;

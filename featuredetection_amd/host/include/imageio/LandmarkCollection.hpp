@@ -1,0 +1,3 @@
+// LandmarkCollection.hpp of the reference -- see imageio_all.hpp
+#pragma once
+#include "imageio/imageio_all.hpp"

@@ -1,0 +1,3 @@
+// SimpleModelLandmarkSink.hpp of the reference -- see imageio_all.hpp
+#pragma once
+#include "imageio/imageio_all.hpp"

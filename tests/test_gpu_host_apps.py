@@ -155,11 +155,16 @@ def test_sdm_fit_app_matches_oracle(tmp_path, oracle, synth):
     synth.save_sdm_text(str(tmp_path / "sdm.txt"), model)
     gray = synth.make_frame(200, 180, seed=55, channels=1)
     synth.save_pnm(str(tmp_path / "face.pgm"), gray)
-    out = _run([app, str(tmp_path / "sdm.txt"), str(tmp_path / "face.pgm"), "30", "25", "120", "130"])
+    out = _run([app, str(tmp_path / "sdm.txt"), str(tmp_path / "face.pgm"), "30", "25", "120", "130", str(tmp_path / "lms.txt")])
     got = np.array([float(v) for v in out.split()], np.float32)
     st, ref = oracle.sdm_fit(gray, model, [30, 25, 120, 130])
     assert st == 0 and got.shape == ref.shape
     assert np.allclose(got, ref, rtol=1e-4, atol=1e-4), np.abs(got - ref).max()
+    # imageio::SimpleModelLandmarkSink: "name x y" per landmark (SimpleModelLandmarkSink.cpp:29-31)
+    lines = [l.split() for l in (tmp_path / "lms.txt").read_text().strip().splitlines()]
+    assert [l[0] for l in lines] == [str(i) for i in range(20)]
+    xy = np.array([[float(l[1]), float(l[2])] for l in lines], np.float32)
+    assert np.allclose(xy[:, 0], got[:20], rtol=1e-5) and np.allclose(xy[:, 1], got[20:], rtol=1e-5)
 
 
 def test_ffp_detect_app_prvm_single_detector(tmp_path, oracle, synth, frame640):
