@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="hog_svm", choices=["hog_svm", "wvm", "ffp15", "rvm", "sdm"])
+    ap.add_argument("--workload", default="hog_svm", choices=["hog_svm", "wvm", "ffp15", "rvm", "aggregated", "sdm"])
     ap.add_argument("--gather-every", type=int, default=8)
     ap.add_argument("--size", default="640x480", help="frame size WxH for the hog_svm / wvm workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -187,6 +187,36 @@ def main():
                                "ConversionFilter(CV_32F, 1/255), RBF RVM with 100 reduced set vectors" % (W, H, nwin_rvm),
                       frames_per_step=1, parallelism="image-shard dp%d" % world)
         dtype = "u8/f32/f64"
+    elif args.workload == "aggregated":
+        # AggregatedFeaturesDetector (GrayscaleFilter + FhogFilter(8, 9), 10x10-cell window, 5 layers per octave)
+        W, H = (FW, FH) if args.size != "640x480" else (1920, 1080)
+        frames = [synth.make_frame(W, H, seed=20260927 + 1000 * rank + i) for i in range(2)]
+        wts = np.random.default_rng(3).normal(0, 0.05, (10, 10, 31)).astype(np.float32)
+        det = capi.Aggregated(ctx, wts, 0.1, 1.5, octave_layers=5, nms_overlap=0.3)
+        _, cand0 = det.detect(frames[0])
+        # windows = valid score positions over all layers (the unit of this detector)
+        from oracle import pyoracle as O  # only to count the positions with the same pyramid rules
+        nwin_agg = len(O.aggregated_candidates(frames[0], wts, 0.1, -1e30, octave_layers=5)[0]) if (W * H) <= 640 * 480 else None
+        if nwin_agg is None:
+            inc = 0.5 ** (1 / 5)
+            k, nwin_agg = 0, 0
+            while True:
+                sc = inc ** k
+                lw, lh = int(round(W * sc)), int(round(H * sc))
+                if lw // 8 < 10 or lh // 8 < 10:
+                    break
+                nwin_agg += (lw // 8 - 9) * (lh // 8 - 9)
+                k += 1
+
+        def step(i, sync=True):
+            fin, _ = det.detect(frames[i % 2])
+            return nwin_agg, len(fin)
+
+        units_name = "windows"
+        config = dict(workload="AggregatedFeaturesDetector: %dx%d BGR frame, FhogFilter(8, 9 bins, cell interpolation), 10x10-cell linear SVM, "
+                               "5 layers per octave, ~%d window positions, IoU NMS 0.3 (host image upload included)" % (W, H, nwin_agg),
+                      frames_per_step=1, parallelism="image-shard dp%d" % world)
+        dtype = "u8/f32"
     elif args.workload == "ffp15":
         # BASELINE config 2/4 shape: all 15 detectors of ffpDetectApp/*.cfg full-frame (32.1 M windows
         # per 1080p frame).  Detectors with identical pyramid parameters share one pyramid (identical layers).
@@ -290,7 +320,8 @@ def main():
         value = total_units / dt / 1e6
         res = dict(metric="Mpatches/s (extract+HOG+RBF-SVM), 640x480 pyramid" if args.workload == "hog_svm" else
                    ("Mpatches/s (extract+WVM+SVM cascade), %dx%d pyramid" % (W, H) if args.workload in ("wvm", "ffp15") else
-                    ("Mpatches/s (extract+HistEq64+RVM cascade), %dx%d pyramid" % (W, H) if args.workload == "rvm" else "SDM iters/s (x1e6)")),
+                    ("Mpatches/s (extract+HistEq64+RVM cascade), %dx%d pyramid" % (W, H) if args.workload == "rvm" else
+                     ("Mwindows/s (FHOG pyramid + linear SVM convolution + NMS), %dx%d" % (W, H) if args.workload == "aggregated" else "SDM iters/s (x1e6)"))),
                    value=value, unit="Mpatches/s" if args.workload != "sdm" else "M SDM iters/s", n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype=dtype, data="synthetic", config=config)

@@ -3,10 +3,10 @@
 // images / gray pyramid layers: the cell descriptors (2B signed + B unsigned orientation features + 4 energy features)
 // the AggregatedFeaturesDetector family convolves its linear SVM over.  SURVEY.md 8(f) row 2, second piece.
 //
-// k_fhog_hist: lane == cell.  A lane walks the pixels that contribute to its cell in the reference's row-major scan
-// order (with bilinear cell interpolation a pixel feeds up to four cells, so a cell sees a 2c x 2c neighbourhood) and
-// accumulates into its private 2B-bin histogram in LDS, so every fp32 accumulator receives its addends in the
-// reference order.  The per-pixel (bin, weight) pair comes from the same 511 x 511 gradient look-up table the
+// k_fhog_hist: thread == (cell, signed bin), i.e. one thread per fp32 accumulator of the reference.  A thread walks the
+// pixels that contribute to its cell in the reference's row-major scan order (with bilinear cell interpolation a pixel
+// feeds up to four cells, so a cell sees a 2c x 2c neighbourhood) and adds the contributions that carry its bin, so
+// every accumulator receives its addends in the reference order, with 2B x more threads than cells to fill the chip.  The per-pixel (bin, weight) pair comes from the same 511 x 511 gradient look-up table the
 // reference builds (host libm atan2 / sqrt: FhogFilter.cpp:35-57), uploaded once per parameter set.
 // k_fhog_desc: lane == cell: the four neighbourhood normalisers, truncation at alpha, the 0.5 / 0.2357 factors.
 // HBM-bound in principle (w*h bytes in, rows*cols*(3B+4)*4 bytes out); the table look-ups are L2 hits.
@@ -17,16 +17,6 @@
 #include <cstring>
 #include <memory>
 
-struct fd_aggregated {
-    fd_ctx* ctx;
-    fd_aggregated_params prm;
-    std::vector<float> weights;
-    DevBuf dweights, scores;
-    fd_pyramid* pyr = nullptr;
-    int pyrW = 0, pyrH = 0;
-    ~fd_aggregated() { if (pyr) fd_pyramid_destroy(pyr); }
-};
-
 struct FhogLut {   // one entry per (dy, dx) gradient code
     uint8_t index1, index2;
     uint16_t pad;
@@ -34,14 +24,36 @@ struct FhogLut {   // one entry per (dy, dx) gradient code
 };
 struct FhogCoeffDev { int32_t index1, index2; float weight1, weight2; };
 
-struct FhogDev {
-    int32_t w, h, stride;        // image
-    int32_t rows, cols, cell, ubins, sbins, D;
-    int32_t interpBins, interpCells;
+struct FhogParamsDev {
+    int32_t cell, ubins, sbins, D, interpBins, interpCells;
     float alpha;
-    const FhogLut* lut;          // [512 * 512], index dy * 512 + dx
-    const FhogCoeffDev* rowCoeff; // [rows * cell]
-    const FhogCoeffDev* colCoeff; // [cols * cell]
+    const FhogLut* lut;            // [512 * 512], index dy * 512 + dx
+    const FhogCoeffDev* coeff;     // all layers: rows of layer 0, columns of layer 0, rows of layer 1, ...
+};
+struct FhogLayerDev {              // one gray image / pyramid layer of a launch
+    const uint8_t* img;
+    int32_t w, h, stride;
+    int32_t rows, cols;            // cells
+    int32_t cellBase, coeffBase;   // first cell / first coefficient of the layer in the launch-wide arrays
+    int32_t vw, vh, posBase;       // window positions of the score map (aggregated detector only)
+    int32_t cellBlockBase;         // first 64-cell block of the layer
+    int32_t posBlockBase;          // first 8-position block of the layer
+};
+
+struct FhogLayoutTotals { int cells = 0, coeffs = 0, cellBlocks = 0, positions = 0, posBlocks = 0; };
+
+struct fd_aggregated {
+    fd_ctx* ctx;
+    fd_aggregated_params prm;
+    std::vector<float> weights;
+    DevBuf dweights, scores;
+    fd_pyramid* pyr = nullptr;
+    int pyrW = 0, pyrH = 0;
+    std::vector<FhogLayerDev> layerTable;   // of the current pyramid geometry
+    FhogLayoutTotals layout;
+    DevBuf dlayers;
+    void* arenaAt = nullptr;
+    ~fd_aggregated() { if (pyr) fd_pyramid_destroy(pyr); }
 };
 
 namespace {
@@ -49,19 +61,59 @@ namespace {
 using namespace fd_dev;
 
 constexpr int FHOG_MAX_SBINS = 36;
+constexpr int FHOG_CH = 6;         // pixels whose loads are in flight together in k_fhog_hist
 
-__global__ __launch_bounds__(64) void k_fhog_hist(const uint8_t* __restrict__ img, FhogDev d, float* __restrict__ desc, float* __restrict__ energies) {
+__device__ __forceinline__ int layer_of_block(const FhogLayerDev* __restrict__ layers, int nLayers, int block, bool cells) {
+    int l = 0;
+    for (int i = 1; i < nLayers; ++i)
+        if (block >= (cells ? layers[i].cellBlockBase : layers[i].posBlockBase)) l = i;
+    return l;
+}
+
+// createInterpolationCoefficients (FhogFilter.cpp:74-98), one thread per pixel row / column of every layer.
+// fp32 add / divide / floor are correctly rounded on the device (no fast-math), so the table equals the host's.
+__global__ __launch_bounds__(256) void k_fhog_coeff(const FhogLayerDev* __restrict__ layers, int nLayers, int total, FhogParamsDev d,
+                                                    FhogCoeffDev* __restrict__ coeff) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int l = 0;
+    for (int k = 1; k < nLayers; ++k)
+        if (i >= layers[k].coeffBase) l = k;
+    const FhogLayerDev L = layers[l];
+    const int j = i - L.coeffBase, rowPixels = L.rows * d.cell;
+    const int pixel = j < rowPixels ? j : j - rowPixels;
+    const int sizeInCells = j < rowPixels ? L.rows : L.cols;
+    FhogCoeffDev c;
+    if (d.interpCells) {
+        const float realCellIndex = (pixel + 0.5f) / d.cell - 0.5f;
+        int index1 = (int)floorf(realCellIndex);
+        int index2 = index1 + 1;
+        float weight2 = realCellIndex - index1;
+        float weight1 = index2 - realCellIndex;
+        if (index1 < 0) { index1 = index2; weight1 = 0; }
+        else if (index2 >= sizeInCells) { index2 = index1; weight2 = 0; }
+        c = FhogCoeffDev{index1, index2, weight1, weight2};
+    } else {
+        c = FhogCoeffDev{pixel / d.cell, -1, 1.f, 0.f};
+    }
+    coeff[i] = c;
+}
+
+__global__ __launch_bounds__(64) void k_fhog_hist(const FhogLayerDev* __restrict__ layers, int nLayers, FhogParamsDev d, float* __restrict__ desc,
+                                                  float* __restrict__ energies) {
     __shared__ float hist[FHOG_MAX_SBINS][64];
+    const FhogLayerDev L = layers[layer_of_block(layers, nLayers, blockIdx.x, true)];
     const int lane = threadIdx.x;
-    const int ncells = d.rows * d.cols;
-    const int cellId = blockIdx.x * 64 + lane;
-    const bool valid = cellId < ncells;
-    const int r = valid ? cellId / d.cols : 0, c = valid ? cellId - r * d.cols : 0;
+    const int cellId = (blockIdx.x - L.cellBlockBase) * 64 + lane;
+    const bool valid = cellId < L.rows * L.cols;
+    const int r = valid ? cellId / L.cols : 0, c = valid ? cellId - r * L.cols : 0;
     for (int b = 0; b < d.sbins; ++b) hist[b][lane] = 0.f;
     if (valid) {
+        const FhogCoeffDev* __restrict__ rowCoeff = d.coeff + L.coeffBase;
+        const FhogCoeffDev* __restrict__ colCoeff = rowCoeff + L.rows * d.cell;
         // pixel range feeding this cell: non-interpolated [r*cell, (r+1)*cell); interpolated: every pixel whose index1 or index2 is r
         const int cs = d.cell;
-        const int H = d.rows * cs, W = d.cols * cs;
+        const int H = L.rows * cs, W = L.cols * cs;
         int y0, y1, x0, x1;
         if (d.interpCells) {
             y0 = max(r * cs - (cs + 1) / 2 - 1, 0); y1 = min((r + 1) * cs + (cs + 1) / 2 + 1, H);
@@ -70,62 +122,80 @@ __global__ __launch_bounds__(64) void k_fhog_hist(const uint8_t* __restrict__ im
             y0 = r * cs; y1 = y0 + cs; x0 = c * cs; x1 = x0 + cs;
         }
         for (int y = y0; y < y1; ++y) {
-            const FhogCoeffDev rc = d.rowCoeff[y];
+            const FhogCoeffDev rc = rowCoeff[y];
             const bool r1 = rc.index1 == r, r2 = d.interpCells && rc.index2 == r;
             if (!r1 && !r2) continue;
-            const int py = max(y - 1, 0), ny = min(y + 1, d.h - 1);
-            const uint8_t* rowp = img + (size_t)y * d.stride;
-            const uint8_t* up = img + (size_t)py * d.stride;
-            const uint8_t* dn = img + (size_t)ny * d.stride;
-            for (int x = x0; x < x1; ++x) {
-                const FhogCoeffDev cc = d.colCoeff[x];
-                const bool c1 = cc.index1 == c, c2 = d.interpCells && cc.index2 == c;
-                if (!c1 && !c2) continue;
-                const int px = max(x - 1, 0), nx = min(x + 1, d.w - 1);
-                const int dx = (int)rowp[nx] - (int)rowp[px] + 256;
-                const int dy = (int)dn[x] - (int)up[x] + 256;
-                const FhogLut e = d.lut[dy * 512 + dx];
-                // the (up to four) adds this cell receives from the pixel, in the order h11, h12, h21, h22 of
-                // FhogFilter.hpp:173-205 (a role applies when the corresponding row / column index is this cell)
+            const int py = max(y - 1, 0), ny = min(y + 1, L.h - 1);
+            const uint8_t* rowp = L.img + (size_t)y * L.stride;
+            const uint8_t* up = L.img + (size_t)py * L.stride;
+            const uint8_t* dn = L.img + (size_t)ny * L.stride;
+            for (int xb = x0; xb < x1; xb += FHOG_CH) {
+                // the loads of FHOG_CH pixels are issued together (column coefficients, the four neighbours, then the table
+                // entries), the adds below run in scan order
+                FhogCoeffDev cc[FHOG_CH];
+                FhogLut e[FHOG_CH];
+                int code[FHOG_CH];
 #pragma unroll
-                for (int role = 0; role < 4; ++role) {
-                    const bool rowHit = (role & 2) ? r2 : r1, colHit = (role & 1) ? c2 : c1;
-                    if (!rowHit || !colHit) continue;
-                    if (d.interpCells) {
-                        const float wr = (role & 2) ? rc.weight2 : rc.weight1, wc = (role & 1) ? cc.weight2 : cc.weight1;
-                        hist[e.index1][lane] = hist[e.index1][lane] + e.weight1 * wr * wc;
-                        if (d.interpBins) hist[e.index2][lane] = hist[e.index2][lane] + e.weight2 * wr * wc;
-                    } else {
-                        hist[e.index1][lane] = hist[e.index1][lane] + e.weight1;
-                        if (d.interpBins) hist[e.index2][lane] = hist[e.index2][lane] + e.weight2;
+                for (int j = 0; j < FHOG_CH; ++j) {
+                    const int x = min(xb + j, x1 - 1);
+                    cc[j] = colCoeff[x];
+                    const int px = max(x - 1, 0), nx = min(x + 1, L.w - 1);
+                    const int dx = (int)rowp[nx] - (int)rowp[px] + 256;
+                    const int dy = (int)dn[x] - (int)up[x] + 256;
+                    code[j] = dy * 512 + dx;
+                }
+#pragma unroll
+                for (int j = 0; j < FHOG_CH; ++j) e[j] = d.lut[code[j]];
+#pragma unroll
+                for (int j = 0; j < FHOG_CH; ++j) {
+                    if (xb + j >= x1) continue;
+                    const bool c1 = cc[j].index1 == c, c2 = d.interpCells && cc[j].index2 == c;
+                    if (!c1 && !c2) continue;
+                    // the (up to four) adds this cell receives from the pixel, in the order h11, h12, h21, h22 of
+                    // FhogFilter.hpp:173-205 (a role applies when the corresponding row / column index is this cell)
+#pragma unroll
+                    for (int role = 0; role < 4; ++role) {
+                        const bool rowHit = (role & 2) ? r2 : r1, colHit = (role & 1) ? c2 : c1;
+                        if (!rowHit || !colHit) continue;
+                        if (d.interpCells) {
+                            const float wr = (role & 2) ? rc.weight2 : rc.weight1, wc = (role & 1) ? cc[j].weight2 : cc[j].weight1;
+                            hist[e[j].index1][lane] = hist[e[j].index1][lane] + e[j].weight1 * wr * wc;
+                            if (d.interpBins) hist[e[j].index2][lane] = hist[e[j].index2][lane] + e[j].weight2 * wr * wc;
+                        } else {
+                            hist[e[j].index1][lane] = hist[e[j].index1][lane] + e[j].weight1;
+                            if (d.interpBins) hist[e[j].index2][lane] = hist[e[j].index2][lane] + e[j].weight2;
+                        }
                     }
                 }
             }
         }
-        float* out = desc + (size_t)cellId * d.D;
+        float* out = desc + (size_t)(L.cellBase + cellId) * d.D;
         float energy = 0.f;   // computeGradientEnergy, FhogAggregationFilter.cpp:53-61
         for (int b = 0; b < d.ubins; ++b) {
             const float u = hist[b][lane] + hist[b + d.ubins][lane];
             energy = energy + u * u;
         }
         for (int b = 0; b < d.sbins; ++b) out[b] = hist[b][lane];
-        energies[cellId] = energy;
+        energies[L.cellBase + cellId] = energy;
     }
 }
 
-__global__ __launch_bounds__(64) void k_fhog_desc(FhogDev d, const float* __restrict__ energies, float* __restrict__ desc) {
-    const int cellId = blockIdx.x * 64 + threadIdx.x;
-    if (cellId >= d.rows * d.cols) return;
-    const int r = cellId / d.cols, c = cellId - r * d.cols;
-    const int pr = max(r - 1, 0), nr = min(r + 1, d.rows - 1), pc = max(c - 1, 0), nc = min(c + 1, d.cols - 1);
-    auto E = [&](int rr, int cc) { return energies[rr * d.cols + cc]; };
+__global__ __launch_bounds__(64) void k_fhog_desc(const FhogLayerDev* __restrict__ layers, int nLayers, FhogParamsDev d,
+                                                  const float* __restrict__ energiesAll, float* __restrict__ descAll) {
+    const FhogLayerDev L = layers[layer_of_block(layers, nLayers, blockIdx.x, true)];
+    const int cellId = (blockIdx.x - L.cellBlockBase) * 64 + threadIdx.x;
+    if (cellId >= L.rows * L.cols) return;
+    const float* energies = energiesAll + L.cellBase;
+    const int r = cellId / L.cols, c = cellId - r * L.cols;
+    const int pr = max(r - 1, 0), nr = min(r + 1, L.rows - 1), pc = max(c - 1, 0), nc = min(c + 1, L.cols - 1);
+    auto E = [&](int rr, int cc) { return energies[rr * L.cols + cc]; };
     const float eps = 1e-4f;
     float n[4];   // computeNormalizers, FhogAggregationFilter.cpp:77-99
     n[0] = 1.f / sqrtf(E(pr, pc) + E(pr, c) + E(r, pc) + E(r, c) + eps);
     n[1] = 1.f / sqrtf(E(pr, c) + E(pr, nc) + E(r, c) + E(r, nc) + eps);
     n[2] = 1.f / sqrtf(E(r, pc) + E(r, c) + E(nr, pc) + E(nr, c) + eps);
     n[3] = 1.f / sqrtf(E(r, c) + E(r, nc) + E(nr, c) + E(nr, nc) + eps);
-    float* p = desc + (size_t)cellId * d.D;
+    float* p = descAll + (size_t)(L.cellBase + cellId) * d.D;
     float energy[4] = {0.f, 0.f, 0.f, 0.f};
     for (int b = 0; b < d.ubins; ++b) {   // computeDescriptor, :101-148 (0.5 and 0.2357 are double literals)
         const float v = p[b] + p[b + d.ubins];
@@ -142,7 +212,7 @@ __global__ __launch_bounds__(64) void k_fhog_desc(FhogDev d, const float* __rest
 }
 
 struct FhogScratch {
-    DevBuf lut, coeff, img, desc, energies;
+    DevBuf lut, coeff, img, desc, energies, layers;
     fd_fhog_params lutFor;
     bool lutValid = false;
 };
@@ -192,81 +262,114 @@ void build_lut(fd_ctx* ctx, FhogScratch& S, const fd_fhog_params& fp) {
     S.lutValid = true;
 }
 
-std::vector<FhogCoeffDev> interp_coefficients(int sizeInPixels, int sizeInCells, int cellSize, bool interpolateCells) {   // FhogFilter.cpp:74-98
-    std::vector<FhogCoeffDev> c((size_t)sizeInPixels);
-    for (int pixel = 0; pixel < sizeInPixels; ++pixel) {
-        if (interpolateCells) {
-            const float realCellIndex = (pixel + 0.5f) / cellSize - 0.5f;
-            int index1 = (int)std::floor(realCellIndex);
-            int index2 = index1 + 1;
-            float weight2 = realCellIndex - index1;
-            float weight1 = index2 - realCellIndex;
-            if (index1 < 0) { index1 = index2; weight1 = 0; }
-            else if (index2 >= sizeInCells) { index2 = index1; weight2 = 0; }
-            c[pixel] = FhogCoeffDev{index1, index2, weight1, weight2};
-        } else {
-            c[pixel] = FhogCoeffDev{pixel / cellSize, -1, 1.f, 0.f};
-        }
-    }
-    return c;
-}
-
-// descriptors of the gray image at dimg (device, row stride `stride`) into S.desc; returns rows / cols
-void run_fhog(fd_ctx* ctx, FhogScratch& S, const uint8_t* dimg, int w, int h, int stride, const fd_fhog_params& fp, int& rows, int& cols) {
+void check_fhog_params(const fd_fhog_params& fp) {
     if (fp.cell_size < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "FhogFilter: cellSize must be bigger than zero");
     if (fp.unsigned_bins < 1 || 2 * fp.unsigned_bins > FHOG_MAX_SBINS)
         FD_THROW(FD_ERR_INVALID_ARGUMENT, "FhogFilter: unsignedBinCount must be bigger than zero, but was: %d (this backend: <= %d)", fp.unsigned_bins,
                  FHOG_MAX_SBINS / 2);
     if (!(fp.alpha > 0)) FD_THROW(FD_ERR_INVALID_ARGUMENT, "FhogAggregationFilter: alpha must be bigger than zero, but was: %g", (double)fp.alpha);
-    rows = h / fp.cell_size;
-    cols = w / fp.cell_size;
-    if (rows == 0 || cols == 0) return;
-    build_lut(ctx, S, fp);
-    std::vector<FhogCoeffDev> rc = interp_coefficients(rows * fp.cell_size, rows, fp.cell_size, fp.interpolate_cells != 0);
-    std::vector<FhogCoeffDev> cc = interp_coefficients(cols * fp.cell_size, cols, fp.cell_size, fp.interpolate_cells != 0);
-    S.coeff.reserve(sizeof(FhogCoeffDev) * (rc.size() + cc.size()));
-    FhogCoeffDev* pin = (FhogCoeffDev*)fd_pinned(ctx, sizeof(FhogCoeffDev) * (rc.size() + cc.size()));
-    std::memcpy(pin, rc.data(), sizeof(FhogCoeffDev) * rc.size());
-    std::memcpy(pin + rc.size(), cc.data(), sizeof(FhogCoeffDev) * cc.size());
-    HIP_CHECK(hipMemcpyAsync(S.coeff.p, pin, sizeof(FhogCoeffDev) * (rc.size() + cc.size()), hipMemcpyHostToDevice, ctx->stream));
-    FhogDev d;
-    std::memset(&d, 0, sizeof(d));
-    d.w = w; d.h = h; d.stride = stride; d.rows = rows; d.cols = cols; d.cell = fp.cell_size; d.ubins = fp.unsigned_bins;
-    d.sbins = 2 * fp.unsigned_bins; d.D = 3 * fp.unsigned_bins + 4; d.interpBins = fp.interpolate_bins != 0; d.interpCells = fp.interpolate_cells != 0;
-    d.alpha = fp.alpha;
-    d.lut = S.lut.as<FhogLut>();
-    d.rowCoeff = S.coeff.as<FhogCoeffDev>();
-    d.colCoeff = d.rowCoeff + rc.size();
-    const int ncells = rows * cols;
-    S.desc.reserve(sizeof(float) * (size_t)ncells * d.D);
-    S.energies.reserve(sizeof(float) * (size_t)ncells);
-    const int grid = (ncells + 63) / 64;
-    hipLaunchKernelGGL(k_fhog_hist, dim3(grid), dim3(64), 0, ctx->stream, dimg, d, S.desc.as<float>(), S.energies.as<float>());
-    hipLaunchKernelGGL(k_fhog_desc, dim3(grid), dim3(64), 0, ctx->stream, d, S.energies.as<float>(), S.desc.as<float>());
-    HIP_CHECK(hipGetLastError());
 }
 
+// fills the launch-wide offsets of a layer list (img, w, h, stride, vw, vh set by the caller); returns total cells
+using FhogLayout = FhogLayoutTotals;
+FhogLayout layout_layers(std::vector<FhogLayerDev>& layers, const fd_fhog_params& fp) {
+    FhogLayout t;
+    for (FhogLayerDev& L : layers) {
+        L.rows = L.h / fp.cell_size;
+        L.cols = L.w / fp.cell_size;
+        L.cellBase = t.cells; L.coeffBase = t.coeffs; L.cellBlockBase = t.cellBlocks; L.posBase = t.positions; L.posBlockBase = t.posBlocks;
+        t.cells += L.rows * L.cols;
+        t.coeffs += (L.rows + L.cols) * fp.cell_size;
+        t.cellBlocks += (L.rows * L.cols + 63) / 64;
+        t.positions += L.vw * L.vh;
+        t.posBlocks += (L.vw * L.vh + 7) / 8;
+    }
+    return t;
+}
+
+// descriptors of every layer of the table at dlayers (device copy of `layers`, laid out by layout_layers) into S.desc
+FhogParamsDev run_fhog(fd_ctx* ctx, FhogScratch& S, const FhogLayerDev* dlayers, int nLayers, const FhogLayout& t, const fd_fhog_params& fp) {
+    check_fhog_params(fp);
+    build_lut(ctx, S, fp);
+    FhogParamsDev d;
+    std::memset(&d, 0, sizeof(d));
+    d.cell = fp.cell_size; d.ubins = fp.unsigned_bins; d.sbins = 2 * fp.unsigned_bins; d.D = 3 * fp.unsigned_bins + 4;
+    d.interpBins = fp.interpolate_bins != 0; d.interpCells = fp.interpolate_cells != 0; d.alpha = fp.alpha;
+    if (t.cells == 0) return d;
+    S.coeff.reserve(sizeof(FhogCoeffDev) * (size_t)t.coeffs);
+    S.desc.reserve(sizeof(float) * (size_t)t.cells * d.D);
+    S.energies.reserve(sizeof(float) * (size_t)t.cells);
+    d.lut = S.lut.as<FhogLut>();
+    d.coeff = S.coeff.as<FhogCoeffDev>();
+    hipLaunchKernelGGL(k_fhog_coeff, dim3((t.coeffs + 255) / 256), dim3(256), 0, ctx->stream, dlayers, nLayers, t.coeffs, d, S.coeff.as<FhogCoeffDev>());
+    hipLaunchKernelGGL(k_fhog_hist, dim3(t.cellBlocks), dim3(64), 0, ctx->stream, dlayers, nLayers, d, S.desc.as<float>(), S.energies.as<float>());
+    hipLaunchKernelGGL(k_fhog_desc, dim3(t.cellBlocks), dim3(64), 0, ctx->stream, dlayers, nLayers, d, S.energies.as<float>(), S.desc.as<float>());
+    HIP_CHECK(hipGetLastError());
+    return d;
+}
+
+// one gray image already on the device
+void run_fhog_single(fd_ctx* ctx, FhogScratch& S, const uint8_t* dimg, int w, int h, int stride, const fd_fhog_params& fp, int& rows, int& cols) {
+    check_fhog_params(fp);
+    std::vector<FhogLayerDev> layers(1);
+    std::memset(&layers[0], 0, sizeof(FhogLayerDev));
+    layers[0].img = dimg; layers[0].w = w; layers[0].h = h; layers[0].stride = stride;
+    const FhogLayout t = layout_layers(layers, fp);
+    rows = layers[0].rows; cols = layers[0].cols;
+    if (rows == 0 || cols == 0) return;
+    S.layers.reserve(sizeof(FhogLayerDev));
+    HIP_CHECK(hipMemcpyAsync(S.layers.p, layers.data(), sizeof(FhogLayerDev), hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));   // `layers` is pageable host memory
+    run_fhog(ctx, S, S.layers.as<FhogLayerDev>(), 1, t, fp);
+}
 
 // ConvolutionFilter(CV_32F) of AggregatedFeaturesDetector (ConvolutionFilter.cpp:27-43 with anchor (0, 0), delta = -bias):
-// score(y, x) = delta + sum over channels c of [sum over the kernel window, row-major, of K[ky][kx][c] * F[y+ky][x+kx][c]];
-// lane == window position, the nesting and the fp32 accumulation order of the per-channel cv::filter2D + channel sum.
-__global__ __launch_bounds__(256) void k_fhog_score(const float* __restrict__ F, int rows, int cols, int D, const float* __restrict__ K, int kh, int kw,
-                                                    float delta, float* __restrict__ scores) {
-    const int vw = cols - kw + 1, vh = rows - kh + 1;
+// score(y, x) = delta + sum over channels c of [sum over the kernel window, row-major, of K[ky][kx][c] * F[y+ky][x+kx][c]]:
+// the nesting and the fp32 accumulation order of the per-channel cv::filter2D + channel sum.  All layers in one launch,
+// 8 window positions per block, 32 lanes per position, lane == channel (D <= 32: coalesced reads of a cell's descriptor);
+// each lane runs its channel's filter2D sum in kernel row-major order, then the channel sums are added in channel order.
+__global__ __launch_bounds__(256) void k_fhog_score(const FhogLayerDev* __restrict__ layers, int nLayers, const float* __restrict__ descAll, int D,
+                                                    const float* __restrict__ K, int kh, int kw, float delta, float* __restrict__ scores) {
+    const FhogLayerDev L = layers[layer_of_block(layers, nLayers, blockIdx.x, false)];
+    const int lane = threadIdx.x & 31;
+    const int pos = (blockIdx.x - L.posBlockBase) * 8 + (threadIdx.x >> 5);
+    const bool valid = pos < L.vw * L.vh;
+    const int y = valid ? pos / L.vw : 0, x = valid ? pos - y * L.vw : 0;
+    const float* F = descAll + (size_t)L.cellBase * D;
+    float sacc = 0.f;
+    if (valid && lane < D) {
+        for (int ky = 0; ky < kh; ++ky) {
+            const float* frow = F + ((size_t)(y + ky) * L.cols + x) * D + lane;
+            const float* krow = K + (size_t)ky * kw * D + lane;
+#pragma unroll 5
+            for (int kx = 0; kx < kw; ++kx) sacc = sacc + krow[(size_t)kx * D] * frow[(size_t)kx * D];
+        }
+    }
+    float score = delta;
+    const int base = threadIdx.x & 32;   // first lane of this position inside the wave
+    for (int c = 0; c < D; ++c) score = score + __shfl(sacc, base + c, 64);
+    if (valid && lane == 0) scores[L.posBase + pos] = score;
+}
+
+// descriptors wider than 32 channels (more than 9 unsigned bins): one lane per position, one block row per layer
+__global__ __launch_bounds__(256) void k_fhog_score_wide(const FhogLayerDev* __restrict__ layers, const float* __restrict__ descAll, int D,
+                                                         const float* __restrict__ K, int kh, int kw, float delta, float* __restrict__ scores) {
+    const FhogLayerDev L = layers[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= vw * vh) return;
-    const int y = i / vw, x = i - y * vw;
+    if (i >= L.vw * L.vh) return;
+    const int y = i / L.vw, x = i - y * L.vw;
+    const float* F = descAll + (size_t)L.cellBase * D;
     float score = delta;
     for (int c = 0; c < D; ++c) {
         float sacc = 0.f;
         for (int ky = 0; ky < kh; ++ky) {
-            const float* frow = F + ((size_t)(y + ky) * cols + x) * D + c;
+            const float* frow = F + ((size_t)(y + ky) * L.cols + x) * D + c;
             const float* krow = K + (size_t)ky * kw * D + c;
             for (int kx = 0; kx < kw; ++kx) sacc = sacc + krow[(size_t)kx * D] * frow[(size_t)kx * D];
         }
         score = score + sacc;
     }
-    scores[i] = score;
+    scores[L.posBase + i] = score;
 }
 
 }  // namespace
@@ -289,7 +392,7 @@ int fd_fhog_image(fd_ctx* ctx, const uint8_t* gray, int width, int height, const
         S.img.reserve((size_t)width * height);
         HIP_CHECK(hipMemcpyAsync(S.img.p, gray, (size_t)width * height, hipMemcpyHostToDevice, ctx->stream));
         int rows, cols;
-        run_fhog(ctx, S, S.img.as<uint8_t>(), width, height, width, *fp, rows, cols);
+        run_fhog_single(ctx, S, S.img.as<uint8_t>(), width, height, width, *fp, rows, cols);
         if (rows && cols)
             HIP_CHECK(hipMemcpyAsync(out, S.desc.p, sizeof(float) * (size_t)rows * cols * (3 * fp->unsigned_bins + 4), hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -306,7 +409,7 @@ int fd_pyramid_fhog_layer(fd_ctx* ctx, fd_pyramid* p, int layer, const fd_fhog_p
         const HostLayer& L = p->all[p->kept[layer]];
         FhogScratch& S = scratch(ctx);
         int rows, cols;
-        run_fhog(ctx, S, p->arena.as<uint8_t>() + L.gray_off, L.w, L.h, L.w, *fp, rows, cols);
+        run_fhog_single(ctx, S, p->arena.as<uint8_t>() + L.gray_off, L.w, L.h, L.w, *fp, rows, cols);
         if (rows && cols)
             HIP_CHECK(hipMemcpyAsync(out, S.desc.p, sizeof(float) * (size_t)rows * cols * (3 * fp->unsigned_bins + 4), hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -345,6 +448,7 @@ int fd_aggregated_detect(fd_ctx* ctx, fd_aggregated* a, const uint8_t* image, in
         // feature pyramid limits (AggregatedFeaturesExtractor.cpp:30-31,47-52,58-77), recomputed when the image size changes
         if (!a->pyr || a->pyrW != width || a->pyrH != height) {
             if (a->pyr) { fd_pyramid_destroy(a->pyr); a->pyr = nullptr; }
+            a->layerTable.clear();
             const int patchWpx = P.window_w * P.fhog.cell_size, patchHpx = P.window_h * P.fhog.cell_size;
             const double inc = std::pow(0.5, 1. / P.octave_layer_count);
             double maxScale = 1.0;
@@ -371,31 +475,49 @@ int fd_aggregated_detect(fd_ctx* ctx, fd_aggregated* a, const uint8_t* image, in
             FD_THROW(FD_ERR_RUNTIME, "ImagePyramid: at least two pyramid layers are needed to estimate the lambdas");
         FhogScratch& S = scratch(ctx);
         const int D = 3 * P.fhog.unsigned_bins + 4;
-        // score maps of all layers, one after the other on the stream
+        // layer table of this pyramid geometry (rebuilt with the pyramid): descriptors and score maps of all layers run as
+        // single launches over the table
+        if (a->layerTable.empty() || a->arenaAt != p->arena.p) {
+            a->layerTable.resize(p->kept.size());
+            for (size_t li = 0; li < p->kept.size(); ++li) {
+                const HostLayer& L = p->all[p->kept[li]];
+                FhogLayerDev& T = a->layerTable[li];
+                std::memset(&T, 0, sizeof(T));
+                T.img = p->arena.as<uint8_t>() + L.gray_off; T.w = L.w; T.h = L.h; T.stride = L.w;
+                T.vh = std::max(L.h / P.fhog.cell_size - P.window_h + 1, 0);
+                T.vw = std::max(L.w / P.fhog.cell_size - P.window_w + 1, 0);
+                if (T.vw == 0 || T.vh == 0) T.vw = T.vh = 0;
+            }
+            a->layout = layout_layers(a->layerTable, P.fhog);
+            a->dlayers.reserve(sizeof(FhogLayerDev) * a->layerTable.size());
+            HIP_CHECK(hipMemcpy(a->dlayers.p, a->layerTable.data(), sizeof(FhogLayerDev) * a->layerTable.size(), hipMemcpyHostToDevice));
+            a->arenaAt = p->arena.p;
+        }
+        const int nLayers = (int)a->layerTable.size();
         std::vector<size_t> off(p->kept.size() + 1, 0);
         std::vector<int> vw(p->kept.size()), vh(p->kept.size());
         for (size_t li = 0; li < p->kept.size(); ++li) {
-            const HostLayer& L = p->all[p->kept[li]];
-            const int rows = L.h / P.fhog.cell_size, cols = L.w / P.fhog.cell_size;
-            vh[li] = std::max(rows - P.window_h + 1, 0);
-            vw[li] = std::max(cols - P.window_w + 1, 0);
-            off[li + 1] = off[li] + (size_t)vw[li] * vh[li];
+            vw[li] = a->layerTable[li].vw; vh[li] = a->layerTable[li].vh;
+            off[li] = (size_t)a->layerTable[li].posBase;
         }
+        off[p->kept.size()] = (size_t)a->layout.positions;
         a->scores.reserve(sizeof(float) * std::max<size_t>(off.back(), 1));
-        for (size_t li = 0; li < p->kept.size(); ++li) {
-            if (!vw[li] || !vh[li]) continue;
-            const HostLayer& L = p->all[p->kept[li]];
-            int rows, cols;
-            run_fhog(ctx, S, p->arena.as<uint8_t>() + L.gray_off, L.w, L.h, L.w, P.fhog, rows, cols);
-            const int npos = vw[li] * vh[li];
-            hipLaunchKernelGGL(k_fhog_score, dim3((npos + 255) / 256), dim3(256), 0, ctx->stream, S.desc.as<float>(), rows, cols, D,
-                               a->dweights.as<float>(), P.window_h, P.window_w, -P.svm_bias, a->scores.as<float>() + off[li]);
+        run_fhog(ctx, S, a->dlayers.as<FhogLayerDev>(), nLayers, a->layout, P.fhog);
+        if (a->layout.positions > 0) {
+            if (D <= 32) {
+                hipLaunchKernelGGL(k_fhog_score, dim3(a->layout.posBlocks), dim3(256), 0, ctx->stream, a->dlayers.as<FhogLayerDev>(), nLayers,
+                                   S.desc.as<float>(), D, a->dweights.as<float>(), P.window_h, P.window_w, -P.svm_bias, a->scores.as<float>());
+            } else {
+                int maxPos = 0;
+                for (const FhogLayerDev& T : a->layerTable) maxPos = std::max(maxPos, T.vw * T.vh);
+                hipLaunchKernelGGL(k_fhog_score_wide, dim3((maxPos + 255) / 256, nLayers), dim3(256), 0, ctx->stream, a->dlayers.as<FhogLayerDev>(),
+                                   S.desc.as<float>(), D, a->dweights.as<float>(), P.window_h, P.window_w, -P.svm_bias, a->scores.as<float>());
+            }
             HIP_CHECK(hipGetLastError());
-            // run_fhog stages its interpolation tables through the context's pinned scratch: keep the host from overwriting it
-            HIP_CHECK(hipStreamSynchronize(ctx->stream));
         }
         std::vector<float> hs(off.back());
-        if (!hs.empty()) HIP_CHECK(hipMemcpy(hs.data(), a->scores.p, sizeof(float) * hs.size(), hipMemcpyDeviceToHost));
+        if (!hs.empty()) HIP_CHECK(hipMemcpyAsync(hs.data(), a->scores.p, sizeof(float) * hs.size(), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
         // getPositiveWindows (AggregatedFeaturesDetector.cpp:87-106): layer, row, column order
         std::vector<fd_box> cand;
         for (size_t li = 0; li < p->kept.size(); ++li) {
