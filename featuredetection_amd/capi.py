@@ -464,16 +464,24 @@ class Aggregated:
         self.h = C.c_void_p()
         ctx.check(lib().fd_aggregated_create(ctx.h, C.byref(prm), C.byref(self.h)))
 
-    def detect(self, image, cap=1 << 16):
-        """(final detections, candidates) as BOX_DTYPE arrays"""
+    def detect(self, image, cap=1 << 16, candidates=True):
+        """(final detections, candidates) as BOX_DTYPE arrays (candidates None when not asked for)"""
         image = _c(image, np.uint8)
         h, w = image.shape[:2]
         ch = 1 if image.ndim == 2 else image.shape[2]
-        out, cand = np.zeros(cap, BOX_DTYPE), np.zeros(1 << 20, BOX_DTYPE)
+        return self._detect(_ptr(image), w, h, ch, 0, cap, candidates)
+
+    def detect_device(self, ptr, w, h, ch, cap=1 << 16, candidates=False):
+        """same on a frame that already lives in HBM (ptr: device address of h x w x ch bytes)"""
+        return self._detect(C.c_void_p(ptr), w, h, ch, 1, cap, candidates)
+
+    def _detect(self, iptr, w, h, ch, is_device, cap, candidates):
+        out = np.zeros(cap, BOX_DTYPE)
+        cand = np.zeros(1 << 20, BOX_DTYPE) if candidates else None
         n, nc = C.c_int(), C.c_int()
-        self.ctx.check(lib().fd_aggregated_detect(self.ctx.h, self.h, _ptr(image), w, h, ch, 0, _ptr(out), cap, C.byref(n), _ptr(cand), len(cand),
-                                                  C.byref(nc)))
-        return out[:n.value], cand[:nc.value]
+        self.ctx.check(lib().fd_aggregated_detect(self.ctx.h, self.h, iptr, w, h, ch, is_device, _ptr(out), cap, C.byref(n),
+                                                  _ptr(cand) if candidates else None, len(cand) if candidates else 0, C.byref(nc)))
+        return out[:n.value], (cand[:nc.value] if candidates else None)
 
     def close(self):
         if self.h:

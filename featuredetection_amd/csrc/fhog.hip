@@ -3,13 +3,13 @@
 // images / gray pyramid layers: the cell descriptors (2B signed + B unsigned orientation features + 4 energy features)
 // the AggregatedFeaturesDetector family convolves its linear SVM over.  SURVEY.md 8(f) row 2, second piece.
 //
-// k_fhog_hist: thread == (cell, signed bin), i.e. one thread per fp32 accumulator of the reference.  A thread walks the
-// pixels that contribute to its cell in the reference's row-major scan order (with bilinear cell interpolation a pixel
-// feeds up to four cells, so a cell sees a 2c x 2c neighbourhood) and adds the contributions that carry its bin, so
-// every accumulator receives its addends in the reference order, with 2B x more threads than cells to fill the chip.  The per-pixel (bin, weight) pair comes from the same 511 x 511 gradient look-up table the
-// reference builds (host libm atan2 / sqrt: FhogFilter.cpp:35-57), uploaded once per parameter set.
-// k_fhog_desc: lane == cell: the four neighbourhood normalisers, truncation at alpha, the 0.5 / 0.2357 factors.
-// HBM-bound in principle (w*h bytes in, rows*cols*(3B+4)*4 bytes out); the table look-ups are L2 hits.
+// All layers of a launch (one image, or every layer of a pyramid) go through the kernels together over a device layer table:
+// k_fhog_coeff (bilinear cell-interpolation tables), k_fhog_grad (per-pixel (bin, weight) entries from the same 511 x 511
+// gradient look-up table the reference builds with host libm atan2 / sqrt: FhogFilter.cpp:35-57), k_fhog_hist (lane == cell:
+// a lane walks the pixels that contribute to its cell in the reference's row-major scan order -- with bilinear cell
+// interpolation a pixel feeds up to four cells, so a cell sees a 2c x 2c neighbourhood -- and accumulates into its private
+// 2B-bin histogram in LDS, so every fp32 accumulator receives its addends in the reference order), k_fhog_desc (the four
+// neighbourhood normalisers, truncation at alpha, the 0.5 / 0.2357 factors) and, for the detector, k_fhog_score.
 #include "fd_internal.hpp"
 #include "fd_device.hpp"
 #include <algorithm>
@@ -37,10 +37,11 @@ struct FhogLayerDev {              // one gray image / pyramid layer of a launch
     int32_t cellBase, coeffBase;   // first cell / first coefficient of the layer in the launch-wide arrays
     int32_t vw, vh, posBase;       // window positions of the score map (aggregated detector only)
     int32_t cellBlockBase;         // first 64-cell block of the layer
+    int32_t pixBase, pixBlockBase; // first covered pixel (rows*cell x cols*cell per layer) / first 256-pixel block
     int32_t posBlockBase;          // first 8-position block of the layer
 };
 
-struct FhogLayoutTotals { int cells = 0, coeffs = 0, cellBlocks = 0, positions = 0, posBlocks = 0; };
+struct FhogLayoutTotals { int cells = 0, coeffs = 0, cellBlocks = 0, positions = 0, posBlocks = 0, pixels = 0, pixBlocks = 0; };
 
 struct fd_aggregated {
     fd_ctx* ctx;
@@ -70,6 +71,30 @@ __device__ __forceinline__ int layer_of_block(const FhogLayerDev* __restrict__ l
     return l;
 }
 
+// (bin, weight) entries of every pixel the cells cover: the gradient of FhogFilter.hpp:120-160 (central differences,
+// replicated border) as a code into the reference's look-up table, so that k_fhog_hist reads each entry from a dense map
+// instead of chasing the table once per neighbouring cell.  The map is stored phase-major, entry (y, x) at
+// [(y * cell + x % cell) * cols + x / cell]: in k_fhog_hist lane == cell, so the 64 lanes of a wavefront, which look at the
+// same in-cell offset of consecutive cells, read consecutive entries (a lane-per-cell walk over a row-major map touches 64
+// cache lines per load and is bound by the L1 tag rate).  Thread order == storage order: coalesced writes.
+__global__ __launch_bounds__(256) void k_fhog_grad(const FhogLayerDev* __restrict__ layers, int nLayers, FhogParamsDev d, FhogLut* __restrict__ grad) {
+    int l = 0;
+    for (int i = 1; i < nLayers; ++i)
+        if ((int)blockIdx.x >= layers[i].pixBlockBase) l = i;
+    const FhogLayerDev L = layers[l];
+    const int W = L.cols * d.cell, H = L.rows * d.cell;
+    const int i = (blockIdx.x - L.pixBlockBase) * 256 + threadIdx.x;
+    if (i >= W * H) return;
+    const int y = i / W, rem = i - y * W;
+    const int o = rem / L.cols, cx = rem - o * L.cols;
+    const int x = cx * d.cell + o;
+    const int py = max(y - 1, 0), ny = min(y + 1, L.h - 1), px = max(x - 1, 0), nx = min(x + 1, L.w - 1);
+    const uint8_t* rowp = L.img + (size_t)y * L.stride;
+    const int dx = (int)rowp[nx] - (int)rowp[px] + 256;
+    const int dy = (int)L.img[(size_t)ny * L.stride + x] - (int)L.img[(size_t)py * L.stride + x] + 256;
+    grad[(size_t)L.pixBase + i] = d.lut[dy * 512 + dx];
+}
+
 // createInterpolationCoefficients (FhogFilter.cpp:74-98), one thread per pixel row / column of every layer.
 // fp32 add / divide / floor are correctly rounded on the device (no fast-math), so the table equals the host's.
 __global__ __launch_bounds__(256) void k_fhog_coeff(const FhogLayerDev* __restrict__ layers, int nLayers, int total, FhogParamsDev d,
@@ -96,11 +121,12 @@ __global__ __launch_bounds__(256) void k_fhog_coeff(const FhogLayerDev* __restri
     } else {
         c = FhogCoeffDev{pixel / d.cell, -1, 1.f, 0.f};
     }
-    coeff[i] = c;
+    // rows in pixel order; columns phase-major ([x % cell][x / cell]) like the gradient map
+    coeff[j < rowPixels ? i : L.coeffBase + rowPixels + (pixel % d.cell) * L.cols + pixel / d.cell] = c;
 }
 
-__global__ __launch_bounds__(64) void k_fhog_hist(const FhogLayerDev* __restrict__ layers, int nLayers, FhogParamsDev d, float* __restrict__ desc,
-                                                  float* __restrict__ energies) {
+__global__ __launch_bounds__(64) void k_fhog_hist(const FhogLayerDev* __restrict__ layers, int nLayers, FhogParamsDev d,
+                                                  const FhogLut* __restrict__ gradAll, float* __restrict__ rawHist, float* __restrict__ energies) {
     __shared__ float hist[FHOG_MAX_SBINS][64];
     const FhogLayerDev L = layers[layer_of_block(layers, nLayers, blockIdx.x, true)];
     const int lane = threadIdx.x;
@@ -111,80 +137,84 @@ __global__ __launch_bounds__(64) void k_fhog_hist(const FhogLayerDev* __restrict
     if (valid) {
         const FhogCoeffDev* __restrict__ rowCoeff = d.coeff + L.coeffBase;
         const FhogCoeffDev* __restrict__ colCoeff = rowCoeff + L.rows * d.cell;
-        // pixel range feeding this cell: non-interpolated [r*cell, (r+1)*cell); interpolated: every pixel whose index1 or index2 is r
+        // pixel box feeding this cell: non-interpolated [r*cell, (r+1)*cell); interpolated: every pixel whose index1 or index2
+        // is r lies within `off` pixels around it
         const int cs = d.cell;
-        const int H = L.rows * cs, W = L.cols * cs;
-        int y0, y1, x0, x1;
-        if (d.interpCells) {
-            y0 = max(r * cs - (cs + 1) / 2 - 1, 0); y1 = min((r + 1) * cs + (cs + 1) / 2 + 1, H);
-            x0 = max(c * cs - (cs + 1) / 2 - 1, 0); x1 = min((c + 1) * cs + (cs + 1) / 2 + 1, W);
-        } else {
-            y0 = r * cs; y1 = y0 + cs; x0 = c * cs; x1 = x0 + cs;
-        }
-        for (int y = y0; y < y1; ++y) {
+        const int H = L.rows * cs;
+        const int off = d.interpCells ? (cs + 1) / 2 + 1 : 0, box = cs + 2 * off;
+        // A pixel reaches a cell through at most one row role and one column role with a non-zero weight: where index1 ==
+        // index2 (clamped borders, FhogFilter.cpp:88-95) one of the two weights is exactly 0, and the reference's add of
+        // e.weight * 0 * w = +0 leaves the (non-negative) accumulator unchanged.  So the effective weight of a row / column is
+        // (index1 hit ? weight1 : 0) + (index2 hit ? weight2 : 0) -- exact, one addend is 0 -- and every pixel costs one
+        // read-modify-write per bin, in scan order.
+        const FhogLut* __restrict__ gbase = gradAll + (size_t)L.pixBase;
+        for (int ii = 0; ii < box; ++ii) {
+            const int y = r * cs - off + ii;
+            if (y < 0 || y >= H) continue;
             const FhogCoeffDev rc = rowCoeff[y];
             const bool r1 = rc.index1 == r, r2 = d.interpCells && rc.index2 == r;
             if (!r1 && !r2) continue;
-            const int py = max(y - 1, 0), ny = min(y + 1, L.h - 1);
-            const uint8_t* rowp = L.img + (size_t)y * L.stride;
-            const uint8_t* up = L.img + (size_t)py * L.stride;
-            const uint8_t* dn = L.img + (size_t)ny * L.stride;
-            for (int xb = x0; xb < x1; xb += FHOG_CH) {
-                // the loads of FHOG_CH pixels are issued together (column coefficients, the four neighbours, then the table
-                // entries), the adds below run in scan order
+            const float wr = (r1 ? rc.weight1 : 0.f) + (r2 ? rc.weight2 : 0.f);
+            const size_t yrow = (size_t)y * cs;
+            for (int jb = 0; jb < box; jb += FHOG_CH) {
                 FhogCoeffDev cc[FHOG_CH];
                 FhogLut e[FHOG_CH];
-                int code[FHOG_CH];
+                bool in[FHOG_CH];
 #pragma unroll
-                for (int j = 0; j < FHOG_CH; ++j) {
-                    const int x = min(xb + j, x1 - 1);
-                    cc[j] = colCoeff[x];
-                    const int px = max(x - 1, 0), nx = min(x + 1, L.w - 1);
-                    const int dx = (int)rowp[nx] - (int)rowp[px] + 256;
-                    const int dy = (int)dn[x] - (int)up[x] + 256;
-                    code[j] = dy * 512 + dx;
+                for (int j = 0; j < FHOG_CH; ++j) {   // the loads of FHOG_CH pixels are issued together
+                    // x = c*cs - off + jb + j = (c + q - 2) * cs + o with wave-uniform q, o
+                    const int t = 2 * cs - off + jb + j, q = t / cs, o = t - q * cs;
+                    const int cx = c + q - 2;
+                    in[j] = jb + j < box && cx >= 0 && cx < L.cols;
+                    const int cxs = in[j] ? cx : c;
+                    cc[j] = colCoeff[o * L.cols + cxs];
+                    e[j] = gbase[(yrow + o) * L.cols + cxs];
                 }
 #pragma unroll
-                for (int j = 0; j < FHOG_CH; ++j) e[j] = d.lut[code[j]];
-#pragma unroll
                 for (int j = 0; j < FHOG_CH; ++j) {
-                    if (xb + j >= x1) continue;
                     const bool c1 = cc[j].index1 == c, c2 = d.interpCells && cc[j].index2 == c;
-                    if (!c1 && !c2) continue;
-                    // the (up to four) adds this cell receives from the pixel, in the order h11, h12, h21, h22 of
-                    // FhogFilter.hpp:173-205 (a role applies when the corresponding row / column index is this cell)
-#pragma unroll
-                    for (int role = 0; role < 4; ++role) {
-                        const bool rowHit = (role & 2) ? r2 : r1, colHit = (role & 1) ? c2 : c1;
-                        if (!rowHit || !colHit) continue;
-                        if (d.interpCells) {
-                            const float wr = (role & 2) ? rc.weight2 : rc.weight1, wc = (role & 1) ? cc[j].weight2 : cc[j].weight1;
-                            hist[e[j].index1][lane] = hist[e[j].index1][lane] + e[j].weight1 * wr * wc;
-                            if (d.interpBins) hist[e[j].index2][lane] = hist[e[j].index2][lane] + e[j].weight2 * wr * wc;
-                        } else {
-                            hist[e[j].index1][lane] = hist[e[j].index1][lane] + e[j].weight1;
-                            if (d.interpBins) hist[e[j].index2][lane] = hist[e[j].index2][lane] + e[j].weight2;
-                        }
+                    if (!in[j] || (!c1 && !c2)) continue;
+                    if (d.interpCells) {
+                        const float wc = (c1 ? cc[j].weight1 : 0.f) + (c2 ? cc[j].weight2 : 0.f);
+                        hist[e[j].index1][lane] = hist[e[j].index1][lane] + e[j].weight1 * wr * wc;
+                        if (d.interpBins) hist[e[j].index2][lane] = hist[e[j].index2][lane] + e[j].weight2 * wr * wc;
+                    } else {
+                        hist[e[j].index1][lane] = hist[e[j].index1][lane] + e[j].weight1;
+                        if (d.interpBins) hist[e[j].index2][lane] = hist[e[j].index2][lane] + e[j].weight2;
                     }
                 }
             }
         }
-        float* out = desc + (size_t)(L.cellBase + cellId) * d.D;
         float energy = 0.f;   // computeGradientEnergy, FhogAggregationFilter.cpp:53-61
         for (int b = 0; b < d.ubins; ++b) {
             const float u = hist[b][lane] + hist[b + d.ubins][lane];
             energy = energy + u * u;
         }
-        for (int b = 0; b < d.sbins; ++b) out[b] = hist[b][lane];
         energies[L.cellBase + cellId] = energy;
+    }
+    // raw histograms [cell][2B] of the block's 64 consecutive cells, written as one contiguous run
+    wave_sync();
+    const int cellsHere = min(64, L.rows * L.cols - (blockIdx.x - L.cellBlockBase) * 64);
+    float* out = rawHist + ((size_t)L.cellBase + (size_t)(blockIdx.x - L.cellBlockBase) * 64) * d.sbins;
+    for (int i = lane; i < cellsHere * d.sbins; i += 64) {
+        const int cl = i / d.sbins, b = i - cl * d.sbins;
+        out[i] = hist[b][cl];
     }
 }
 
-__global__ __launch_bounds__(64) void k_fhog_desc(const FhogLayerDev* __restrict__ layers, int nLayers, FhogParamsDev d,
-                                                  const float* __restrict__ energiesAll, float* __restrict__ descAll) {
-    const FhogLayerDev L = layers[layer_of_block(layers, nLayers, blockIdx.x, true)];
-    const int cellId = (blockIdx.x - L.cellBlockBase) * 64 + threadIdx.x;
-    if (cellId >= L.rows * L.cols) return;
+// FhogAggregationFilter::computeDescriptors (:63-148) from the raw histograms: LPC (32 or 64) lanes per cell, lane == output
+// feature, so that the [cell][2B] reads and the [cell][3B+4] writes are contiguous; every lane derives the cell's four
+// normalisers itself (16 cached energy reads).
+template <int LPC>
+__global__ __launch_bounds__(256) void k_fhog_desc(const FhogLayerDev* __restrict__ layers, int nLayers, int totalCells, FhogParamsDev d,
+                                                   const float* __restrict__ energiesAll, const float* __restrict__ rawHist, float* __restrict__ descAll) {
+    const int g = (blockIdx.x * 256 + threadIdx.x) / LPC, f = threadIdx.x & (LPC - 1);
+    if (g >= totalCells || f >= d.D) return;
+    int l = 0;
+    for (int i = 1; i < nLayers; ++i)
+        if (g >= layers[i].cellBase) l = i;
+    const FhogLayerDev L = layers[l];
+    const int cellId = g - L.cellBase;
     const float* energies = energiesAll + L.cellBase;
     const int r = cellId / L.cols, c = cellId - r * L.cols;
     const int pr = max(r - 1, 0), nr = min(r + 1, L.rows - 1), pc = max(c - 1, 0), nc = min(c + 1, L.cols - 1);
@@ -195,24 +225,28 @@ __global__ __launch_bounds__(64) void k_fhog_desc(const FhogLayerDev* __restrict
     n[1] = 1.f / sqrtf(E(pr, c) + E(pr, nc) + E(r, c) + E(r, nc) + eps);
     n[2] = 1.f / sqrtf(E(r, pc) + E(r, c) + E(nr, pc) + E(nr, c) + eps);
     n[3] = 1.f / sqrtf(E(r, c) + E(r, nc) + E(nr, c) + E(nr, nc) + eps);
-    float* p = descAll + (size_t)(L.cellBase + cellId) * d.D;
-    float energy[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int b = 0; b < d.ubins; ++b) {   // computeDescriptor, :101-148 (0.5 and 0.2357 are double literals)
-        const float v = p[b] + p[b + d.ubins];
-        const float s = fminf(d.alpha, n[0] * v) + fminf(d.alpha, n[1] * v) + fminf(d.alpha, n[2] * v) + fminf(d.alpha, n[3] * v);
-        p[d.sbins + b] = (float)(0.5 * (double)s);
-    }
-    for (int b = 0; b < d.sbins; ++b) {
-        const float v = p[b];
+    const float* h = rawHist + (size_t)g * d.sbins;
+    float out;   // computeDescriptor, :101-148 (0.5 and 0.2357 are double literals)
+    if (f < d.sbins) {
+        const float v = h[f];
         const float v0 = fminf(d.alpha, n[0] * v), v1 = fminf(d.alpha, n[1] * v), v2 = fminf(d.alpha, n[2] * v), v3 = fminf(d.alpha, n[3] * v);
-        p[b] = (float)(0.5 * (double)(v0 + v1 + v2 + v3));
-        energy[0] = energy[0] + v0; energy[1] = energy[1] + v1; energy[2] = energy[2] + v2; energy[3] = energy[3] + v3;
+        out = (float)(0.5 * (double)(v0 + v1 + v2 + v3));
+    } else if (f < d.sbins + d.ubins) {
+        const int b = f - d.sbins;
+        const float v = h[b] + h[b + d.ubins];
+        const float s = fminf(d.alpha, n[0] * v) + fminf(d.alpha, n[1] * v) + fminf(d.alpha, n[2] * v) + fminf(d.alpha, n[3] * v);
+        out = (float)(0.5 * (double)s);
+    } else {
+        const float ni = n[f - d.sbins - d.ubins];
+        float energy = 0.f;
+        for (int b = 0; b < d.sbins; ++b) energy = energy + fminf(d.alpha, ni * h[b]);
+        out = (float)(0.2357 * (double)energy);
     }
-    for (int i = 0; i < 4; ++i) p[d.sbins + d.ubins + i] = (float)(0.2357 * (double)energy[i]);
+    descAll[(size_t)g * d.D + f] = out;
 }
 
 struct FhogScratch {
-    DevBuf lut, coeff, img, desc, energies, layers;
+    DevBuf lut, coeff, img, desc, energies, layers, grad, hist;
     fd_fhog_params lutFor;
     bool lutValid = false;
 };
@@ -278,11 +312,16 @@ FhogLayout layout_layers(std::vector<FhogLayerDev>& layers, const fd_fhog_params
         L.rows = L.h / fp.cell_size;
         L.cols = L.w / fp.cell_size;
         L.cellBase = t.cells; L.coeffBase = t.coeffs; L.cellBlockBase = t.cellBlocks; L.posBase = t.positions; L.posBlockBase = t.posBlocks;
+        L.pixBase = t.pixels; L.pixBlockBase = t.pixBlocks;
+        const int64_t npix = (int64_t)L.rows * L.cols * fp.cell_size * fp.cell_size;
+        if (t.pixels + npix > (int64_t)0x7fffff00) FD_THROW(FD_ERR_INVALID_ARGUMENT, "FhogFilter: the layers of one launch exceed 2^31 pixels");
+        t.pixels += (int)npix;
+        t.pixBlocks += (int)((npix + 255) / 256);
         t.cells += L.rows * L.cols;
         t.coeffs += (L.rows + L.cols) * fp.cell_size;
         t.cellBlocks += (L.rows * L.cols + 63) / 64;
         t.positions += L.vw * L.vh;
-        t.posBlocks += (L.vw * L.vh + 7) / 8;
+        t.posBlocks += (((L.vw + 3) / 4) * L.vh + 7) / 8;   // k_fhog_score: 8 groups of FHOG_SP = 4 positions per block
     }
     return t;
 }
@@ -299,11 +338,20 @@ FhogParamsDev run_fhog(fd_ctx* ctx, FhogScratch& S, const FhogLayerDev* dlayers,
     S.coeff.reserve(sizeof(FhogCoeffDev) * (size_t)t.coeffs);
     S.desc.reserve(sizeof(float) * (size_t)t.cells * d.D);
     S.energies.reserve(sizeof(float) * (size_t)t.cells);
+    S.grad.reserve(sizeof(FhogLut) * (size_t)t.pixels);
+    S.hist.reserve(sizeof(float) * (size_t)t.cells * d.sbins);
     d.lut = S.lut.as<FhogLut>();
     d.coeff = S.coeff.as<FhogCoeffDev>();
     hipLaunchKernelGGL(k_fhog_coeff, dim3((t.coeffs + 255) / 256), dim3(256), 0, ctx->stream, dlayers, nLayers, t.coeffs, d, S.coeff.as<FhogCoeffDev>());
-    hipLaunchKernelGGL(k_fhog_hist, dim3(t.cellBlocks), dim3(64), 0, ctx->stream, dlayers, nLayers, d, S.desc.as<float>(), S.energies.as<float>());
-    hipLaunchKernelGGL(k_fhog_desc, dim3(t.cellBlocks), dim3(64), 0, ctx->stream, dlayers, nLayers, d, S.energies.as<float>(), S.desc.as<float>());
+    hipLaunchKernelGGL(k_fhog_grad, dim3(t.pixBlocks), dim3(256), 0, ctx->stream, dlayers, nLayers, d, S.grad.as<FhogLut>());
+    hipLaunchKernelGGL(k_fhog_hist, dim3(t.cellBlocks), dim3(64), 0, ctx->stream, dlayers, nLayers, d, S.grad.as<FhogLut>(), S.hist.as<float>(),
+                       S.energies.as<float>());
+    if (d.D <= 32)
+        hipLaunchKernelGGL(k_fhog_desc<32>, dim3((unsigned)(((int64_t)t.cells * 32 + 255) / 256)), dim3(256), 0, ctx->stream, dlayers, nLayers, t.cells, d,
+                           S.energies.as<float>(), S.hist.as<float>(), S.desc.as<float>());
+    else
+        hipLaunchKernelGGL(k_fhog_desc<64>, dim3((unsigned)(((int64_t)t.cells * 64 + 255) / 256)), dim3(256), 0, ctx->stream, dlayers, nLayers, t.cells, d,
+                           S.energies.as<float>(), S.hist.as<float>(), S.desc.as<float>());
     HIP_CHECK(hipGetLastError());
     return d;
 }
@@ -325,30 +373,52 @@ void run_fhog_single(fd_ctx* ctx, FhogScratch& S, const uint8_t* dimg, int w, in
 
 // ConvolutionFilter(CV_32F) of AggregatedFeaturesDetector (ConvolutionFilter.cpp:27-43 with anchor (0, 0), delta = -bias):
 // score(y, x) = delta + sum over channels c of [sum over the kernel window, row-major, of K[ky][kx][c] * F[y+ky][x+kx][c]]:
-// the nesting and the fp32 accumulation order of the per-channel cv::filter2D + channel sum.  All layers in one launch,
-// 8 window positions per block, 32 lanes per position, lane == channel (D <= 32: coalesced reads of a cell's descriptor);
-// each lane runs its channel's filter2D sum in kernel row-major order, then the channel sums are added in channel order.
+// the nesting and the fp32 accumulation order of the per-channel cv::filter2D + channel sum.  All layers in one launch;
+// a group of 32 lanes (lane == channel, D <= 32: coalesced reads of a cell's descriptor) owns FHOG_SP horizontally adjacent
+// window positions and slides a register window over the descriptor row, so a kernel column costs one K and one F load for
+// FHOG_SP multiply-adds; every position's per-channel sum still runs in kernel row-major order.  The channel sums are then
+// added in channel order onto delta by one lane per position.
+constexpr int FHOG_SP = 4;
 __global__ __launch_bounds__(256) void k_fhog_score(const FhogLayerDev* __restrict__ layers, int nLayers, const float* __restrict__ descAll, int D,
                                                     const float* __restrict__ K, int kh, int kw, float delta, float* __restrict__ scores) {
+    __shared__ float part[8][FHOG_SP][33];
     const FhogLayerDev L = layers[layer_of_block(layers, nLayers, blockIdx.x, false)];
-    const int lane = threadIdx.x & 31;
-    const int pos = (blockIdx.x - L.posBlockBase) * 8 + (threadIdx.x >> 5);
-    const bool valid = pos < L.vw * L.vh;
-    const int y = valid ? pos / L.vw : 0, x = valid ? pos - y * L.vw : 0;
+    const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int gpr = (L.vw + FHOG_SP - 1) / FHOG_SP;   // groups per score row
+    const int g = (blockIdx.x - L.posBlockBase) * 8 + grp;
+    const bool valid = g < gpr * L.vh;
+    const int y = valid ? g / gpr : 0, x0 = valid ? (g - y * gpr) * FHOG_SP : 0;
     const float* F = descAll + (size_t)L.cellBase * D;
-    float sacc = 0.f;
+    float sacc[FHOG_SP];
+#pragma unroll
+    for (int p = 0; p < FHOG_SP; ++p) sacc[p] = 0.f;
     if (valid && lane < D) {
+        const int lastCol = L.cols - 1;
         for (int ky = 0; ky < kh; ++ky) {
-            const float* frow = F + ((size_t)(y + ky) * L.cols + x) * D + lane;
+            const float* frow = F + (size_t)(y + ky) * L.cols * D + lane;
             const float* krow = K + (size_t)ky * kw * D + lane;
-#pragma unroll 5
-            for (int kx = 0; kx < kw; ++kx) sacc = sacc + krow[(size_t)kx * D] * frow[(size_t)kx * D];
+            float w[FHOG_SP];
+#pragma unroll
+            for (int p = 0; p < FHOG_SP; ++p) w[p] = frow[(size_t)min(x0 + p, lastCol) * D];
+            for (int kx = 0; kx < kw; ++kx) {
+                const float k = krow[(size_t)kx * D];
+                const float nxt = frow[(size_t)min(x0 + kx + FHOG_SP, lastCol) * D];
+#pragma unroll
+                for (int p = 0; p < FHOG_SP; ++p) sacc[p] = sacc[p] + k * w[p];
+#pragma unroll
+                for (int p = 0; p + 1 < FHOG_SP; ++p) w[p] = w[p + 1];
+                w[FHOG_SP - 1] = nxt;
+            }
         }
     }
-    float score = delta;
-    const int base = threadIdx.x & 32;   // first lane of this position inside the wave
-    for (int c = 0; c < D; ++c) score = score + __shfl(sacc, base + c, 64);
-    if (valid && lane == 0) scores[L.posBase + pos] = score;
+#pragma unroll
+    for (int p = 0; p < FHOG_SP; ++p) part[grp][p][lane] = sacc[p];
+    __syncthreads();
+    if (valid && lane < FHOG_SP && x0 + lane < L.vw) {
+        float score = delta;
+        for (int c = 0; c < D; ++c) score = score + part[grp][lane][c];
+        scores[L.posBase + y * L.vw + x0 + lane] = score;
+    }
 }
 
 // descriptors wider than 32 channels (more than 9 unsigned bins): one lane per position, one block row per layer

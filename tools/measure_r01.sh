@@ -7,17 +7,20 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py"
 for wl in hog_svm wvm sdm; do
-  $B --workload $wl > $O/bench_$wl.json 2> $O/bench_$wl.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$wl -- $B --workload $wl --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+  timeout 240 $B --workload $wl > $O/bench_$wl.json 2> $O/bench_$wl.err
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$wl -- $B --workload $wl --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
 done
-$B --workload wvm --size 1920x1080 --no-cpu-baseline > $O/bench_wvm_1080p.json 2> $O/bench_wvm_1080p.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_wvm_1080p -- $B --workload wvm --size 1920x1080 --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+timeout 200 $B --workload wvm --size 1920x1080 --no-cpu-baseline > $O/bench_wvm_1080p.json 2> $O/bench_wvm_1080p.err
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_wvm_1080p -- $B --workload wvm --size 1920x1080 --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
 timeout 200 $B --workload ffp15 --steps 5 --warmup 2 > $O/bench_ffp15.json 2> $O/bench_ffp15.err
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ffp15 -- $B --workload ffp15 --steps 3 --warmup 1 > /dev/null 2>&1
 timeout 200 $B --workload rvm --size 1920x1080 --no-cpu-baseline > $O/bench_rvm_1080p.json 2> $O/bench_rvm_1080p.err
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_rvm_1080p -- $B --workload rvm --size 1920x1080 --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+timeout 200 $B --workload aggregated --steps 20 --warmup 3 > $O/bench_aggregated.json 2> $O/bench_aggregated.err
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_aggregated -- $B --workload aggregated --steps 10 --warmup 3 > /dev/null 2>&1
 for wl in hog_svm wvm; do
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$wl -- $B --workload $wl --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$wl -- $B --workload $wl --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$wl -- $B --workload $wl --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$wl -- $B --workload $wl --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 done
 python $R/tools/pmc_traffic.py $O/pmc_fetch_hog_svm $O/pmc_write_hog_svm k_svm_rbf_mfma hog_svm $O/r01_pmc_traffic.json
 python $R/tools/pmc_traffic.py $O/pmc_fetch_wvm $O/pmc_write_wvm k_wvm_cascade wvm $O/r01_pmc_traffic.json
