@@ -548,7 +548,10 @@ def extract_hist(ctx, pyr, hp):
     """features of every window: (n_windows, feature_length) float32"""
     n = C.c_int64()
     ctx.check(lib().fd_extract_hist(ctx.h, pyr.h, C.byref(hp), None, 0, C.byref(n)))
-    ch = pyr.layers()[0]["ch"]
+    layers = pyr.layers()
+    if not layers:   # no pyramid layer inside [min scale, max scale]: no windows
+        return np.empty((0, 0), np.float32)
+    ch = layers[0]["ch"]
     F = lib().fd_hist_feature_length(C.byref(hp), ch)
     if F < 0:
         raise ValueError("invalid histogram parameters")

@@ -1,0 +1,316 @@
+#!/usr/bin/env python
+"""Seeded differential fuzzing of the HIP path (through the C ABI) against the CPU oracle on randomised geometry:
+frame sizes, pyramid parameters, patch sizes, strides, ROIs, model shapes, histogram / FHOG parameters.
+Test infrastructure (uses oracle/); run on the GPU box:  python tools/fuzz_parity.py --cases 60 --seed 1
+Prints one line per case and a summary; exit code 1 on any mismatch."""
+import argparse
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from featuredetection_amd import capi, synth  # noqa: E402
+from oracle import pyoracle as O  # noqa: E402
+
+
+def rand_pyr_kw(rng, small=False):
+    if rng.random() < 0.5:
+        inc = float(np.float32(rng.choice([0.92, 0.9, 0.85, 0.8])))
+        mn = float(np.float32(rng.uniform(0.08, 0.3)))
+        mx = float(np.float32(min(1.0, mn * rng.uniform(1.2, 3.0))))
+        return dict(inc=inc, min_scale=mn, max_scale=mx)
+    octl = int(rng.integers(1, 6))
+    mn = float(rng.uniform(0.1, 0.4))
+    return dict(octave_layers=octl, min_scale=mn, max_scale=float(min(1.0, mn * rng.uniform(1.5, 3.5))))
+
+
+def rand_frame(rng, channels=3):
+    w, h = int(rng.integers(97, 420)), int(rng.integers(81, 330))
+    f = synth.make_frame(w, h, seed=int(rng.integers(1 << 30)))
+    if channels == 1:
+        return O.bgr2gray(f)
+    return f
+
+
+def rand_roi(rng, w, h):
+    if rng.random() < 0.4:
+        return None
+    x, y = int(rng.integers(-30, w - 10)), int(rng.integers(-30, h - 10))
+    return (x, y, int(rng.integers(30, w + 40)), int(rng.integers(30, h + 40)))
+
+
+def same_geometry(g, o):
+    for f in ("cx", "cy", "w", "h", "layer", "lx", "ly"):
+        if not np.array_equal(g[f], o[f]):
+            return "geometry field %s differs" % f
+    return None
+
+
+def case_pyramid(rng, ctx):
+    frame = rand_frame(rng, channels=int(rng.choice([1, 3])))
+    kw = rand_pyr_kw(rng)
+    po = O.Pyramid(**kw); po.update(frame)
+    pg = capi.Pyramid(ctx, **kw); pg.update(frame)
+    try:
+        lo, lg = po.layers(), pg.layers()
+        if lo != lg:
+            return "layer tables differ: %s vs %s" % (lo, lg)
+        STATS['layers'] += len(lo)
+        for i in range(len(lo)):
+            if not np.array_equal(pg.layer(i), po.layer(i)):
+                return "layer %d pixels differ (%s, frame %s)" % (i, kw, frame.shape)
+        pw, ph = int(rng.integers(5, 33)), int(rng.integers(5, 33))
+        sx, sy = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+        roi = rand_roi(rng, frame.shape[1], frame.shape[0])
+        if not np.array_equal(pg.windows(pw, ph, sx, sy, roi), po.windows(pw, ph, sx, sy, roi)):
+            return "window enumeration differs (%dx%d step %d,%d roi %s)" % (pw, ph, sx, sy, roi)
+    finally:
+        pg.close(); po.close()
+    return None
+
+
+STATS = dict(layers=0, windows=0, detections=0, features=0, cells=0, candidates=0)
+
+SIZES = [(20, 20), (24, 24), (16, 24), (32, 16), (32, 24), (19, 21), (7, 5), (12, 30), (31, 9)]
+
+
+def case_cascade(rng, ctx):
+    frame = rand_frame(rng)
+    gray = O.bgr2gray(frame)
+    pw, ph = SIZES[int(rng.integers(len(SIZES)))]
+    kw = rand_pyr_kw(rng)
+    nper = int(rng.choice([1, 3, 6, 10, 20, 33]))
+    nlev = int(rng.integers(1, 5)) if nper < 20 else int(rng.integers(1, 3))
+    src = np.ascontiguousarray(gray[::2, ::2])
+    if src.shape[0] <= ph + 2 or src.shape[1] <= pw + 2:
+        src = gray
+    calib = synth.random_patches(src, pw, ph, 1500, rng)
+    wvm = synth.make_wvm(int(rng.integers(1 << 20)), fw=pw, fh=ph, n_per=nper, n_levels=nlev, calib_patches=calib,
+                         min_survivors=int(rng.integers(8, 64)))
+    eq = synth.histeq64_np(synth.random_patches(src, pw, ph, 260, rng))
+    svm = synth.make_svm_u8(int(rng.integers(1 << 20)), eq, nsv=int(rng.choice([17, 64, 100])), calib=eq[100:], positive_fraction=0.4)
+    po = O.Pyramid(**kw); po.update(frame)
+    pg = capi.Pyramid(ctx, **kw); pg.update(frame)
+    wo, so = O.Wvm(wvm), O.Svm(svm)
+    wg, sg = capi.Wvm(ctx, wvm), capi.Svm(ctx, svm)
+    desc = "%dx%d nper %d lev %d pyr %s frame %s" % (pw, ph, nper, nlev, kw, frame.shape)
+    try:
+        sx, sy = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        pos_o, lv_o, fo_o = O.sliding_wvm(po, wo, sx, sy)
+        pos_g, lv_g, fo_g = capi.detect_wvm(ctx, pg, wg, sx, sy, want_all=True)
+        if len(lv_o) != len(lv_g):
+            return "window count %d vs %d (%s)" % (len(lv_g), len(lv_o), desc)
+        if len(lv_o) == 0:
+            return None
+        STATS['windows'] += len(lv_o)
+        if not np.array_equal(lv_g, lv_o):
+            return "cascade levels differ at %d windows (%s)" % (int((lv_g != lv_o).sum()), desc)
+        if not np.array_equal(fo_g, fo_o):
+            return "fp32 filter outputs differ at %d windows (%s)" % (int((fo_g != fo_o).sum()), desc)
+        e = same_geometry(pos_g, pos_o)
+        if e:
+            return e + " (" + desc + ")"
+        roi = rand_roi(rng, frame.shape[1], frame.shape[0])
+        dist, ratio = (5.0, 0.0) if rng.random() < 0.5 else (float(rng.uniform(0.2, 0.9)), float(rng.uniform(0.3, 0.9)))
+        do, sto = O.five_stage(po, wo, so, dist, ratio, sx, sy, roi)
+        dg, stg = capi.detect_five_stage(ctx, pg, wg, sg, dist, ratio, sx, sy, roi)
+        STATS['detections'] += len(do)
+        if not np.array_equal(stg, sto):
+            return "stage counts %s vs %s (roi %s, %s)" % (stg, sto, roi, desc)
+        e = same_geometry(dg, do)
+        if e:
+            return "five-stage " + e + " (" + desc + ")"
+        if not np.array_equal(dg["probability"], do["prob"]):
+            # SVM distances agree to 1e-4 relative; probabilities follow
+            if not np.allclose(dg["probability"], do["prob"], rtol=1e-4, atol=1e-7):
+                return "five-stage probabilities differ (%s)" % desc
+    finally:
+        wg.close(); sg.close(); pg.close(); po.close()
+    return None
+
+
+def case_hist(rng, ctx):
+    frame = rand_frame(rng)
+    kw = rand_pyr_kw(rng)
+    kind = int(rng.integers(0, 4))
+    lbp = rng.random() < 0.35 and kind in (1, 3)
+    interp = bool(rng.random() < 0.5)
+    if lbp:
+        lt = int(rng.integers(0, 4))
+        bins = {0: 256, 1: 59, 2: 16, 3: 16}[lt]
+        lf = dict(kind=2, lbp_type=lt)
+        sau = False
+    else:
+        bins = int(rng.integers(4, 13))
+        sau = bool(rng.random() < 0.3) and kind in (0, 2)
+        if sau:
+            bins = 2 * (bins // 2) or 2
+        lf = dict(kind=1, bins=bins, signed_gradients=sau, interpolate=bool(rng.random() < 0.5))
+    if kind in (0, 1):
+        cell, cell_h = int(rng.integers(3, 9)), int(rng.integers(3, 9))
+        block, block_h = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        nx, ny = int(rng.integers(block, block + 3)), int(rng.integers(block_h, block_h + 3))
+        pw, ph = cell * nx, cell_h * ny
+        hpk = dict(kind=kind, bins=bins, cell=cell, cell_h=cell_h, block=block, block_h=block_h, interpolate=interp)
+        okw = dict(bins=bins, cell=cell, cell_h=cell_h, block=block, block_h=block_h, interpolate=interp)
+        if kind == 0:
+            hpk["signed_and_unsigned"] = sau; okw["signed_and_unsigned"] = sau
+            fname = "hog_filter"
+        else:
+            norm = int(rng.integers(0, 5))
+            conc = bool(rng.random() < 0.5)
+            hpk.update(normalization=norm, concatenate=conc); okw.update(normalization=norm, concatenate=conc)
+            fname = "spatial_histogram"
+    else:
+        levels = int(rng.integers(1, 4))
+        pw = ph = int(rng.choice([16, 20, 24, 32]))
+        hpk = dict(kind=kind, bins=bins, levels=levels, interpolate=interp)
+        okw = dict(bins=bins, levels=levels, interpolate=interp)
+        if kind == 2:
+            hpk["signed_and_unsigned"] = sau; okw["signed_and_unsigned"] = sau
+            fname = "pyramid_hog"
+        else:
+            norm = int(rng.integers(0, 5))
+            hpk["normalization"] = norm; okw["normalization"] = norm
+            fname = "spatial_pyramid_histogram"
+    if pw > 64 or ph > 64:
+        return None
+    desc = "%s %s layer %s patch %dx%d pyr %s" % (fname, hpk, lf, pw, ph, kw)
+    po = O.Pyramid(**kw); po.set_layer_filter(**lf); po.update(frame)
+    pg = capi.Pyramid(ctx, **kw); pg.set_layer_filter(**lf); pg.update(frame)
+    try:
+        sx, sy = int(rng.integers(2, 6)), int(rng.integers(2, 6))
+        try:
+            hp = capi.hist_params(pw=pw, ph=ph, sx=sx, sy=sy, **hpk)
+            fg = capi.extract_hist(ctx, pg, hp)
+        except capi.FdError as e:   # unsupported / invalid combination: the oracle must reject it too, or it is a limit of the backend
+            return "skip:" + str(e)[:80]
+        layers = [po.layer(i) for i in range(len(po.layers()))]
+        wins = po.windows(pw, ph, sx, sy)
+        if len(wins) == 0:
+            return None if len(fg) == 0 else "features for no windows"
+        if len(fg) == 0:
+            return "no features for %d windows (%s)" % (len(wins), desc)
+        fo = np.stack([getattr(O, fname)(np.ascontiguousarray(layers[lp][ly:ly + ph, lx:lx + pw]), **okw) for lp, lx, ly, *_ in wins])
+        STATS['features'] += int(fo.size)
+        if fg.shape != fo.shape:
+            return "shape %s vs %s (%s)" % (fg.shape, fo.shape, desc)
+        if not np.array_equal(fg, fo):
+            if not np.allclose(fg, fo, rtol=1e-6, atol=1e-9):
+                return "features differ, max abs %g (%s)" % (float(np.abs(fg - fo).max()), desc)
+            return "note:tolerance-equal only"
+    finally:
+        pg.close(); po.close()
+    return None
+
+
+def case_fhog(rng, ctx):
+    gray = rand_frame(rng, channels=1)
+    cell = int(rng.integers(2, 11))
+    ub = int(rng.integers(2, 19))
+    ib, ic = bool(rng.random() < 0.5), bool(rng.random() < 0.5)
+    alpha = float(rng.choice([0.2, 0.1, 0.5]))
+    fo = O.fhog(gray, cell, ub, ib, ic, alpha)
+    fg = capi.fhog(ctx, gray, cell_size=cell, unsigned_bins=ub, interpolate_bins=ib, interpolate_cells=ic, alpha=alpha)
+    STATS['cells'] += int(fo.shape[0] * fo.shape[1])
+    if fo.shape != fg.shape:
+        return "fhog shape %s vs %s" % (fg.shape, fo.shape)
+    if not np.array_equal(fo, fg):
+        return "fhog differs at %d values (cell %d bins %d ib %s ic %s, image %s)" % (int((fo != fg).sum()), cell, ub, ib, ic, gray.shape)
+    return None
+
+
+def case_aggregated(rng, ctx):
+    ch = int(rng.choice([1, 3]))
+    frame = rand_frame(rng, channels=ch)
+    cell = int(rng.choice([4, 6, 8]))
+    ww, wh = int(rng.integers(3, 8)), int(rng.integers(3, 8))
+    ib, ic = bool(rng.random() < 0.5), bool(rng.random() < 0.7)
+    wts = np.random.default_rng(int(rng.integers(1 << 30))).normal(0, 0.1, (wh, ww, 31)).astype(np.float32)
+    octl = int(rng.integers(2, 7))
+    minw = int(rng.choice([0, ww * cell * 2]))
+    wsc, hsc = float(rng.choice([1.0, 0.8])), float(rng.choice([1.0, 1.2]))
+    nms, mtype = float(rng.choice([0.3, 0.5])), int(rng.integers(0, 2))
+    bias = 0.05
+    okw = dict(cell_size=cell, interpolate_bins=ib, interpolate_cells=ic, octave_layers=octl, min_window_width=minw, width_scale=wsc, height_scale=hsc)
+    r = O.aggregated_candidates(frame, wts, bias, -1e30, **okw)
+    if r is None:   # fewer than two layers: the backend must refuse too
+        try:
+            det = capi.Aggregated(ctx, wts, bias, 0.0, nms_overlap=nms, nms_type=mtype, **okw)
+            try:
+                det.detect(frame)
+            finally:
+                det.close()
+        except capi.FdError:
+            return None
+        return "oracle rejects the pyramid but the backend accepts"
+    so, co = r
+    if len(so) == 0:
+        return None
+    thr = float(np.quantile(so, 0.97))
+    det = capi.Aggregated(ctx, wts, bias, thr, nms_overlap=nms, nms_type=mtype, **okw)
+    try:
+        fin, cand = det.detect(frame)
+        so2, co2 = O.aggregated_candidates(frame, wts, bias, thr, **okw)
+        STATS['candidates'] += len(so2)
+        if len(cand) != len(so2):
+            return "candidates %d vs %d" % (len(cand), len(so2))
+        gb = np.stack([cand["x"], cand["y"], cand["w"], cand["h"]], 1) if len(cand) else np.zeros((0, 4), np.int32)
+        if not np.array_equal(gb, np.asarray(co2).reshape(-1, 4)) or not np.array_equal(cand["score"], so2):
+            return "candidate boxes / scores differ"
+        fs, fb = O.nms_iou(so2, co2, nms, mtype)
+        fgb = np.stack([fin["x"], fin["y"], fin["w"], fin["h"]], 1) if len(fin) else np.zeros((0, 4), np.int32)
+        if len(fs) != len(fin) or not np.array_equal(fin["score"], fs) or not np.array_equal(fgb, np.asarray(fb).reshape(-1, 4)):
+            return "final detections differ (%d vs %d)" % (len(fin), len(fs))
+    finally:
+        det.close()
+    return None
+
+
+CASES = dict(pyramid=case_pyramid, cascade=case_cascade, hist=case_hist, fhog=case_fhog, aggregated=case_aggregated)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--kinds", default=",".join(CASES))
+    ap.add_argument("--seconds", type=float, default=240.0, help="stop starting new cases after this long")
+    args = ap.parse_args()
+    ctx = capi.Context(0)
+    kinds = args.kinds.split(",")
+    bad, skipped, notes = [], 0, 0
+    t0 = time.time()
+    for i in range(args.cases):
+        if time.time() - t0 > args.seconds:
+            print("time limit after %d cases" % i)
+            break
+        kind = kinds[i % len(kinds)]
+        rng = np.random.default_rng([args.seed, i])
+        try:
+            r = CASES[kind](rng, ctx)
+        except Exception:
+            r = "EXCEPTION " + traceback.format_exc().strip().splitlines()[-1][:200]
+        if r is None:
+            status = "ok"
+        elif r.startswith("skip:"):
+            status = r; skipped += 1
+        elif r.startswith("note:"):
+            status = r; notes += 1
+        else:
+            status = "MISMATCH " + r
+            bad.append((i, kind, r))
+        print("case %3d %-10s %s" % (i, kind, status), flush=True)
+    print("fuzz summary: %d mismatches, %d skipped, %d tolerance-only, seed %d; compared %s" % (len(bad), skipped, notes, args.seed, STATS))
+    for b in bad:
+        print("  ", b)
+    ctx.close()
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
