@@ -271,7 +271,173 @@ def case_aggregated(rng, ctx):
     return None
 
 
-CASES = dict(pyramid=case_pyramid, cascade=case_cascade, hist=case_hist, fhog=case_fhog, aggregated=case_aggregated)
+def case_svm(rng, ctx):
+    kernel, dtype = int(rng.integers(0, 4)), int(rng.integers(0, 2))
+    nsv, dim, n = int(rng.integers(1, 700)), int(rng.integers(1, 1100)), int(rng.integers(1, 300))
+    if dtype == 0:
+        sv = rng.integers(0, 256, (nsv, dim), dtype=np.uint8)
+        x = rng.integers(0, 256, (n, dim), dtype=np.uint8)
+        p0 = {2: 0.04 / 65025.0 * 400 / dim, 1: 1.0 / 65025.0}.get(kernel, 0.0)
+    else:
+        sv = rng.random((nsv, dim)).astype(np.float32) * 0.2
+        x = rng.random((n, dim)).astype(np.float32) * 0.2
+        p0 = {2: 0.5, 1: 0.3}.get(kernel, 0.0)
+    m = dict(kernel=kernel, p0=p0, p1=0.7, p2=int(rng.integers(1, 4)), dtype=dtype, sv=sv, coeff=rng.normal(0, 1, nsv).astype(np.float32),
+             bias=np.float32(0.25), threshold=0.0)
+    do = O.Svm(m).distance(x)
+    sg = capi.Svm(ctx, m)
+    try:
+        dg = sg.distance(x)
+    finally:
+        sg.close()
+    STATS['features'] += n * nsv
+    scale = np.abs(m["coeff"]).sum() * (np.abs(do).max() / max(np.abs(m["coeff"]).sum(), 1e-30) if kernel in (0, 1, 3) else 1.0)
+    tol = 1e-12 if dtype == 0 else 1e-5
+    if not np.all(np.abs(dg - do) <= 1e-4 * np.abs(do) + tol * max(scale, 1.0)):
+        return "svm distances differ: max %g (kernel %d dtype %d nsv %d dim %d n %d)" % (float(np.abs(dg - do).max()), kernel, dtype, nsv, dim, n)
+    return None
+
+
+def case_hog_svm(rng, ctx):
+    """config-2 path (HOG features in the fragment layout + MFMA RBF SVM) on random geometry"""
+    frame, frame2 = rand_frame(rng), rand_frame(rng)
+    kw = rand_pyr_kw(rng)
+    cell, block = int(rng.integers(3, 7)), int(rng.integers(1, 3))
+    ncell = int(rng.integers(block, 5))
+    pw = ph = cell * ncell
+    bins = int(rng.integers(4, 10))
+    sx, sy = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    po = O.Pyramid(**kw); po.set_layer_filter(1, bins=bins); po.update(frame2)
+    pg = capi.Pyramid(ctx, **kw); pg.set_layer_filter(1, bins=bins)
+    try:
+        _, _, feats2 = O.sliding_hog_svm(po, None, pw, ph, sx, sy, bins, cell, block, want_feats=10 ** 9)
+        if feats2 is None or len(feats2) < 40:
+            return None
+        nsv = int(rng.choice([33, 64, 150, 300]))
+        m = synth.make_svm_f32(int(rng.integers(1 << 20)), feats2, nsv=min(nsv, len(feats2)), gamma=float(rng.choice([0.5, 2.0])), positive_fraction=0.05)
+        po.update(frame)
+        so = O.Svm(m)
+        dets_o, dist_o, feats = O.sliding_hog_svm(po, so, pw, ph, sx, sy, bins, cell, block, want_feats=10 ** 9)
+        pg.update(frame)
+        hp = capi.hog_params(pw=pw, ph=ph, sx=sx, sy=sy, bins=bins, cell=cell, block=block, signed_and_unsigned=False)
+        fg = capi.extract_hog(ctx, pg, hp)
+        if len(dist_o) == 0:
+            return None if len(fg) == 0 else "features without windows"
+        STATS['windows'] += len(dist_o)
+        if fg.shape != feats.shape or not np.array_equal(fg, feats):
+            return "HOG features differ (cell %d block %d bins %d patch %d)" % (cell, block, bins, pw)
+        sg = capi.Svm(ctx, m)
+        try:
+            dets_g, dist_g = capi.detect_hog_svm(ctx, pg, sg, hp)
+        finally:
+            sg.close()
+        err = np.abs(dist_g - dist_o)
+        scale = np.abs(m["coeff"]).sum()
+        if err.max() > 1e-5 * scale or err.max() > 1e-4 * max(1.0, np.abs(dist_o).max()):
+            return "HOG+SVM distances differ: %g (scale %g, F %d, nsv %d)" % (float(err.max()), float(scale), feats.shape[1], len(m["coeff"]))
+        safe = np.abs(dist_o - m["threshold"]) > 1e-4
+        pos_o, pos_g = np.nonzero(dist_o >= m["threshold"])[0], np.nonzero(dist_g >= m["threshold"])[0]
+        if not np.array_equal(pos_o[safe[pos_o]], pos_g[safe[pos_g]]):
+            return "positives differ away from the threshold"
+        if np.array_equal(pos_o, pos_g):
+            e = same_geometry(dets_g, dets_o)
+            if e:
+                return "HOG+SVM " + e
+    finally:
+        pg.close(); po.close()
+    return None
+
+
+def case_rvm(rng, ctx):
+    frame = rand_frame(rng)
+    kw = rand_pyr_kw(rng)
+    space = int(rng.integers(0, 3))
+    scale, shift = [(1.0, 0.0), (1.0 / 255.0, 0.0), (0.5, -3.0)][int(rng.integers(0, 3))]
+    pw, ph = SIZES[int(rng.integers(len(SIZES)))]
+    sx, sy = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    po = O.Pyramid(**kw); po.update(frame)
+    pg = capi.Pyramid(ctx, **kw); pg.update(frame)
+    try:
+        layers = [po.layer(i) for i in range(len(po.layers()))]
+        wins = po.windows(pw, ph, sx, sy)
+        if len(wins) < 60:
+            return None
+        pat = np.stack([np.ascontiguousarray(layers[lp][ly:ly + ph, lx:lx + pw]) for lp, lx, ly, *_ in wins])
+        if space == 1:
+            pat = np.stack([O.histeq64(p_) for p_ in pat])
+        elif space == 2:
+            pat = np.stack([O.equalize_hist(p_) for p_ in pat])
+        feats = pat.reshape(len(pat), -1).astype(np.float32) * np.float32(scale) + np.float32(shift)
+        nf = int(rng.integers(1, 45))
+        m = synth.make_rvm(int(rng.integers(1 << 20)), feats[::3], pw, ph, n_filters=nf, kernel=int(rng.choice([2, 2, 1, 3, 0])))
+        ro, rg = O.Rvm(m), capi.Rvm(ctx, m)
+        try:
+            lo, do = ro.eval(feats)
+            dets, lg, dg = capi.detect_rvm(ctx, pg, rg, feature_space=space, conv_scale=scale, conv_shift=shift, sx=sx, sy=sy)
+            STATS['windows'] += len(lo)
+            if len(lg) != len(lo) or not np.array_equal(lg, lo):
+                return "RVM levels differ (%dx%d space %d filters %d)" % (pw, ph, space, nf)
+            # fp64 chain with the device exp (an ulp off libm now and then): 1e-12 relative to the size of the terms
+            atol = 1e-12 * float(np.abs(do).max())
+            if not np.allclose(dg, do, rtol=1e-12, atol=atol):
+                bad = np.nonzero(~np.isclose(dg, do, rtol=1e-12, atol=atol))[0]
+                return "RVM distances differ at %d of %d windows, e.g. %r vs %r at level %d (%dx%d space %d scale %g shift %g filters %d kernel %d)" % (
+                    len(bad), len(do), float(dg[bad[0]]), float(do[bad[0]]), int(lo[bad[0]]), pw, ph, space, scale, shift, nf, m["kernel"])
+            pos = np.nonzero((lo == nf - 1) & (do >= m["thresholds"][nf - 1]))[0]
+            if len(dets) != len(pos):
+                return "RVM detections %d vs %d" % (len(dets), len(pos))
+        finally:
+            rg.close(); ro.close()
+    finally:
+        pg.close(); po.close()
+    return None
+
+
+def case_whi(rng, ctx):
+    gray = rand_frame(rng, channels=1)
+    h, w = int(rng.integers(8, 33)), int(rng.integers(8, 33))
+    n = 24
+    ys, xs = rng.integers(0, gray.shape[0] - h, n), rng.integers(0, gray.shape[1] - w, n)
+    patches = np.stack([gray[y:y + h, x:x + w] for y, x in zip(ys, xs)])
+    patches[0] = int(rng.integers(0, 256))
+    try:
+        eq_g = capi.equalize_hist_batch(ctx, patches)
+    except capi.FdError as e:
+        return "skip:" + str(e)[:80]
+    eq_o = np.stack([O.equalize_hist(p_) for p_ in patches])
+    STATS['features'] += int(patches.size)
+    if not np.array_equal(eq_g, eq_o):
+        return "equalizeHist differs (%dx%d)" % (w, h)
+    alpha, cutoff = float(rng.choice([1.0, 0.5, 2.0])), float(rng.choice([0.390625, 0.0, 0.25]))
+    wg = capi.whi_batch(ctx, patches, alpha, cutoff)
+    wo = np.stack([O.whi(p_, alpha, cutoff) for p_ in patches])
+    if not np.allclose(wg, wo, rtol=1e-6, atol=1e-9):
+        return "whi chain differs: %g (%dx%d alpha %g cutoff %g)" % (float(np.abs(wg - wo).max()), w, h, alpha, cutoff)
+    return None
+
+
+def case_sdm(rng, ctx):
+    gray = synth.make_frame(256, 256, seed=int(rng.integers(1 << 30)), channels=1)
+    npts = int(rng.integers(1, 80))
+    px = rng.uniform(2, 254, npts).astype(np.float32)
+    py = rng.uniform(2, 254, npts).astype(np.float32)
+    wsh = int(rng.integers(6, 40))
+    do = O.sdm_descriptors(gray, px, py, wsh)
+    if do is None:   # a window leaves the image where the reference throws
+        try:
+            capi.sdm_descriptors(ctx, gray, px, py, wsh)
+        except capi.FdError:
+            return None
+        return "oracle rejects the points but the backend accepts (wsh %d)" % wsh
+    dg = capi.sdm_descriptors(ctx, gray, px, py, wsh)
+    STATS['features'] += int(do.size)
+    if dg.shape != do.shape or not np.array_equal(dg, do):
+        return "SDM descriptors differ (wsh %d, %d points)" % (wsh, npts)
+    return None
+
+
+CASES = dict(pyramid=case_pyramid, cascade=case_cascade, hist=case_hist, fhog=case_fhog, aggregated=case_aggregated, svm=case_svm,
+             hog_svm=case_hog_svm, rvm=case_rvm, whi=case_whi, sdm=case_sdm)
 
 
 def main():
@@ -280,6 +446,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--kinds", default=",".join(CASES))
     ap.add_argument("--seconds", type=float, default=240.0, help="stop starting new cases after this long")
+    ap.add_argument("--only", type=int, default=-1, help="run just this case index")
     args = ap.parse_args()
     ctx = capi.Context(0)
     kinds = args.kinds.split(",")
@@ -289,6 +456,8 @@ def main():
         if time.time() - t0 > args.seconds:
             print("time limit after %d cases" % i)
             break
+        if args.only >= 0 and i != args.only:
+            continue
         kind = kinds[i % len(kinds)]
         rng = np.random.default_rng([args.seed, i])
         try:
