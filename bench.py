@@ -14,6 +14,10 @@ import os
 import sys
 import time
 
+# torch initialises the HIP runtime before libfd_hip.so is loaded: same default as the library's load-time constructor
+# (eight hardware queues, so that the stream pool of the batch entry points does not share queues)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

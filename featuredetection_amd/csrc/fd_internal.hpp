@@ -26,7 +26,7 @@ struct fd_ctx {
     int num_cus = 256;
     FdPinned pinned;
     hipStream_t aux = nullptr;   // second stream (created on first use): small follow-up work that must not queue behind ctx->stream
-    hipStream_t pool[4] = {nullptr, nullptr, nullptr, nullptr};   // batch jobs are spread over these (created on first use)
+    hipStream_t pool[8] = {};   // batch jobs are spread over these (created on first use)
 };
 
 struct FdError {
@@ -121,7 +121,7 @@ static inline hipStream_t fd_aux_stream(fd_ctx* ctx) {
 }
 
 static inline hipStream_t fd_pool_stream(fd_ctx* ctx, int i) {
-    static const int nstreams = [] { const char* e = getenv("FD_BATCH_STREAMS"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+    static const int nstreams = [] { const char* e = getenv("FD_BATCH_STREAMS"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
     hipStream_t& s = ctx->pool[i % nstreams];
     if (!s) HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     return s;
