@@ -38,21 +38,31 @@ struct DescParams {
 };
 
 struct DescLds {   // per-wave views carved out of dynamic LDS
-    float* img;
+    float* img;                   // working image; SMALL: the gradient magnitudes overwrite it, later the features
     float* grad;
-    unsigned char* ori;
     float *wx1, *wx2;
     int* binx;
     float *hog, *norm, *feat;
     unsigned long long* masks;    // [2*nori][ih]: bit x set iff pixel (y, x) voted for that orientation
+    double *fac, *hc;             // block factors [ncell][4], clamped undirected terms [ncell*nori][4] (reuse the mask region)
     unsigned long long* colmask;  // [hogW]: columns x contributing to cell column cx
     int* yrange;                  // [hogH][2]: first/last+1 row contributing to cell row cy
 };
+constexpr int SDM_SMALL_ITERS = 16;   // working images of up to 64 * 16 pixels keep their gradients in registers for one sync
 __host__ __device__ inline int align16i(int v) { return (v + 15) & ~15; }
+__host__ __device__ inline bool desc_small(int iw, int ih) { return iw * ih <= 64 * SDM_SMALL_ITERS; }
+__host__ __device__ inline int desc_region_img(int iw, int ih, int ncell, int dim) {
+    const int a = align16i(iw * ih * 4), b = align16i(ncell * dim * 4);
+    return a > b ? a : b;
+}
+__host__ __device__ inline int desc_region_masks(int ih, int ncell, int nori) {
+    const int a = align16i(2 * nori * ih * 8), b = align16i(ncell * 4 * 8) + align16i(ncell * nori * 4 * 8);
+    return a > b ? a : b;   // (also holds the six resize tables of ih entries: 24 * ih <= 16 * nori * ih)
+}
 __host__ __device__ inline int desc_lds_bytes(int iw, int ih, int ncell, int nori, int dim) {
     const int m = iw > ih ? iw : ih;
-    return 2 * align16i(iw * ih * 4) + align16i(iw * ih) + 3 * align16i(m * 4) + align16i(ncell * nori * 2 * 4) + align16i(ncell * 4) +
-           align16i(ncell * dim * 4) + align16i(2 * nori * ih * 8) + align16i(m * 8) + align16i(m * 2 * 4);
+    return desc_region_img(iw, ih, ncell, dim) + (desc_small(iw, ih) ? 0 : align16i(iw * ih * 4)) + 3 * align16i(m * 4) +
+           align16i(ncell * nori * 2 * 4) + align16i(ncell * 4) + desc_region_masks(ih, ncell, nori) + align16i(m * 8) + align16i(m * 2 * 4);
 }
 
 __device__ __forceinline__ void wave_sync() {
@@ -65,8 +75,10 @@ __device__ __forceinline__ void wave_sync() {
 __global__ void k_sdm_prepare(const float* __restrict__ shapes, int B, int L, int W, int H, int adaptive, int fixedHalf,
                               int maxSide, double stepFactor, int32_t* __restrict__ origin, float* __restrict__ dist_out,
                               int32_t* __restrict__ status) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= B) return;
+    // one thread per (face, landmark); every thread of a face derives the face's window half size itself
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * L) return;
+    const int f = t / L, i = t - f * L;
     const float* s = shapes + (size_t)f * 2 * L;
     int pwh = fixedHalf;
     float dist = 0.f;
@@ -82,58 +94,90 @@ __global__ void k_sdm_prepare(const float* __restrict__ shapes, int B, int L, in
         const int wi = (int)windowSizeHalf;
         pwh = wi + 3 - (wi % 3);
     }
-    dist_out[f] = dist;
+    if (i == 0) dist_out[f] = dist;
     const int side = 2 * pwh;
-    for (int i = 0; i < L; ++i) {
-        const int x = __float2int_rn(s[i]), y = __float2int_rn(s[i + L]);
-        int ox = x - pwh, oy = y - pwh, valid = 1;
-        if (x - pwh < 0 || y - pwh < 0 || x + pwh >= W || y + pwh >= H) {
-            const int bl = (x - pwh) < 0 ? abs(x - pwh) : 0;
-            const int bt = (y - pwh) < 0 ? abs(y - pwh) : 0;
-            const int br = (x + pwh) >= W ? abs(W - (x + pwh)) : 0;
-            const int bb = (y + pwh) >= H ? abs(H - (y + pwh)) : 0;
-            const int rx = (x - pwh) + bl, ry = (y - pwh) + br;  // reference quirk: y uses borderRight (:171)
-            const int EW = W + bl + br, EH = H + bt + bb;
-            if (rx < 0 || ry < 0 || rx + side > EW || ry + side > EH) valid = 0;  // cv::Mat roi assertion
-            ox = rx - bl;
-            oy = ry - bt;
-        }
-        if (side < 4 || side > maxSide) valid = 0;
-        int32_t* o = origin + 4 * ((size_t)f * L + i);
-        o[0] = ox; o[1] = oy; o[2] = side; o[3] = valid;
-        if (!valid) status[f] = 1;
+    const int x = __float2int_rn(s[i]), y = __float2int_rn(s[i + L]);
+    int ox = x - pwh, oy = y - pwh, valid = 1;
+    if (x - pwh < 0 || y - pwh < 0 || x + pwh >= W || y + pwh >= H) {
+        const int bl = (x - pwh) < 0 ? abs(x - pwh) : 0;
+        const int bt = (y - pwh) < 0 ? abs(y - pwh) : 0;
+        const int br = (x + pwh) >= W ? abs(W - (x + pwh)) : 0;
+        const int bb = (y + pwh) >= H ? abs(H - (y + pwh)) : 0;
+        const int rx = (x - pwh) + bl, ry = (y - pwh) + br;  // reference quirk: y uses borderRight (:171)
+        const int EW = W + bl + br, EH = H + bt + bb;
+        if (rx < 0 || ry < 0 || rx + side > EW || ry + side > EH) valid = 0;  // cv::Mat roi assertion
+        ox = rx - bl;
+        oy = ry - bt;
     }
+    if (side < 4 || side > maxSide) valid = 0;
+    int32_t* o = origin + 4 * (size_t)t;
+    o[0] = ox; o[1] = oy; o[2] = side; o[3] = valid;
+    if (!valid) status[f] = 1;
 }
 
 __device__ __forceinline__ float src_px(const uint8_t* __restrict__ img, int W, int H, int x, int y) {
     return (x >= 0 && y >= 0 && x < W && y < H) ? (float)img[(size_t)y * W + x] : 0.f;
 }
 
-// one wavefront per (face, landmark)
-__global__ __launch_bounds__(128) void k_sdm_descriptors(const uint8_t* __restrict__ images, const int32_t* __restrict__ origin,
+// one wavefront per (face, landmark).  LDS per wave is what bounds the occupancy of this latency-bound kernel, so regions
+// are reused: the gradient magnitudes overwrite the working image (SMALL: they wait in registers until every lane has read
+// its neighbours), the features overwrite it once the votes are in, the block factors reuse the orientation masks.
+template <bool SMALL>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_sdm_descriptors(const uint8_t* __restrict__ images, const int32_t* __restrict__ origin,
                                                          DescParams p, int64_t nitems, float* __restrict__ out, int64_t out_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int iw = p.iw, ih = p.ih, cs = p.cellSize, nori = p.nori;
     const int hogW = p.hogW, hogH = p.hogH;
     const int ncell = hogW * hogH;
+    const int npix = iw * ih;
+    const int m_ = iw > ih ? iw : ih;
+    // i / iw for 0 <= i < 4096, iw <= 64 (exhaustively checked): three VALU instead of an integer division
+    const float invW = 1.0f / (float)iw;
+    auto divw = [&](int i) { return (int)(((float)i + 0.5f) * invW); };
     DescLds S;
     {
         unsigned char* b = smem + (size_t)wave * p.ldsPerWave;
         const int m = iw > ih ? iw : ih;
-        S.img = (float*)b; b += align16i(iw * ih * 4);
-        S.grad = (float*)b; b += align16i(iw * ih * 4);
-        S.ori = b; b += align16i(iw * ih);
+        S.img = (float*)b; S.feat = (float*)b; b += desc_region_img(iw, ih, ncell, p.dim);
+        if (SMALL) S.grad = S.img;
+        else { S.grad = (float*)b; b += align16i(npix * 4); }
         S.wx1 = (float*)b; b += align16i(m * 4);
         S.wx2 = (float*)b; b += align16i(m * 4);
         S.binx = (int*)b; b += align16i(m * 4);
         S.hog = (float*)b; b += align16i(ncell * nori * 2 * 4);
         S.norm = (float*)b; b += align16i(ncell * 4);
-        S.feat = (float*)b; b += align16i(ncell * p.dim * 4);
-        S.masks = (unsigned long long*)b; b += align16i(2 * nori * ih * 8);
+        S.masks = (unsigned long long*)b; S.fac = (double*)b; S.hc = (double*)(b + align16i(ncell * 4 * 8));
+        b += desc_region_masks(ih, ncell, nori);
         S.colmask = (unsigned long long*)b; b += align16i(m * 8);
         S.yrange = (int*)b;
     }
+    // ---- per-wave tables that only depend on the geometry.  Column/row interpolation: hx = (x + 0.5) / cellSize - 0.5
+    // (hog.c:697-704); rows use the same table
+    for (int x = lane; x < max(iw, ih); x += 64) {
+        const float hx = (float)((x + 0.5) / cs - 0.5);
+        int b = (int)hx;
+        if (!(hx >= 0 || (float)b == hx)) b -= 1;  // vl_floor_f
+        const float w2 = hx - b;
+        const float w1 = (float)(1.0 - (double)w2);
+        S.binx[x] = b; S.wx1[x] = w1; S.wx2[x] = w2;
+    }
+    wave_sync();
+    // per cell column: bit mask of the interior columns that vote into it; per cell row: row range
+    for (int c = lane; c < hogW; c += 64) {
+        unsigned long long mk = 0ull;
+        for (int x = 1; x < iw - 1; ++x)
+            if (S.binx[x] == c || S.binx[x] + 1 == c) mk |= 1ull << x;
+        S.colmask[c] = mk;
+    }
+    for (int c = lane; c < hogH; c += 64) {
+        int lo = ih, hi = 0;
+        for (int y = 1; y < ih - 1; ++y)
+            if (S.binx[y] == c || S.binx[y] + 1 == c) { lo = min(lo, y); hi = max(hi, y + 1); }
+        S.yrange[2 * c] = lo;
+        S.yrange[2 * c + 1] = hi;
+    }
+    wave_sync();
     for (int64_t item = (int64_t)blockIdx.x * 2 + wave; item < nitems; item += (int64_t)gridDim.x * 2) {
         const int64_t face = item / p.L;
         const int lm = (int)(item - face * p.L);
@@ -147,70 +191,67 @@ __global__ __launch_bounds__(128) void k_sdm_descriptors(const uint8_t* __restri
         const uint8_t* img = images + face * p.image_stride;
         // ---- working image: crop (+ fp32 bilinear resize to 30x30 when adaptive)
         if (p.adaptive && side != iw) {
+            // cv::resize coordinates per destination column / row (the orientation-mask region is free until the gradients)
+            int* rsx = (int*)S.masks;
+            int* rsx1 = rsx + m_;
+            int* ry0 = rsx1 + m_;
+            int* ry1 = ry0 + m_;
+            float* rfx = (float*)(ry1 + m_);
+            float* rfy = rfx + m_;
             const double scale = 1. / ((double)iw / side);  // cv::resize: scale = 1/inv_scale
-            for (int i = lane; i < iw * ih; i += 64) {
-                const int dy = i / iw, dx = i - dy * iw;
-                float fx = (float)((dx + 0.5) * scale - 0.5);
+            for (int d = lane; d < m_; d += 64) {
+                float fx = (float)((d + 0.5) * scale - 0.5);
                 int sx = (int)floorf(fx);
                 fx -= sx;
+                float fy = fx;
+                const int sy = sx;
                 if (sx < 0) { fx = 0; sx = 0; }
                 if (sx >= side - 1) { fx = 0; sx = side - 1; }
-                float fy = (float)((dy + 0.5) * scale - 0.5);
-                int sy = (int)floorf(fy);
-                fy -= sy;
-                const int y0 = sy < 0 ? 0 : (sy >= side ? side - 1 : sy);
-                const int y1 = sy + 1 < 0 ? 0 : (sy + 1 >= side ? side - 1 : sy + 1);
-                const int sx1 = sx + 1 < side ? sx + 1 : sx;
+                rsx[d] = sx; rsx1[d] = sx + 1 < side ? sx + 1 : sx; rfx[d] = fx;
+                ry0[d] = sy < 0 ? 0 : (sy >= side ? side - 1 : sy);
+                ry1[d] = sy + 1 < 0 ? 0 : (sy + 1 >= side ? side - 1 : sy + 1);
+                rfy[d] = fy;
+            }
+            wave_sync();
+            for (int i = lane; i < npix; i += 64) {
+                const int dy = divw(i), dx = i - dy * iw;
+                const float fx = rfx[dx], fy = rfy[dy];
+                const int sx = rsx[dx], sx1 = rsx1[dx], y0 = ry0[dy], y1 = ry1[dy];
                 const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
                 const float r0 = src_px(img, p.W, p.H, ox + sx, oy + y0) * a0 + src_px(img, p.W, p.H, ox + sx1, oy + y0) * a1;
                 const float r1 = src_px(img, p.W, p.H, ox + sx, oy + y1) * a0 + src_px(img, p.W, p.H, ox + sx1, oy + y1) * a1;
                 S.img[i] = r0 * b0 + r1 * b1;
             }
+            wave_sync();
         } else {
-            for (int i = lane; i < iw * ih; i += 64) {
-                const int dy = i / iw, dx = i - dy * iw;
+            for (int i = lane; i < npix; i += 64) {
+                const int dy = divw(i), dx = i - dy * iw;
                 S.img[i] = src_px(img, p.W, p.H, ox + dx, oy + dy);
             }
-        }
-        // column/row interpolation tables: hx = (x + 0.5) / cellSize - 0.5 (hog.c:697-704); rows use the same table
-        for (int x = lane; x < max(iw, ih); x += 64) {
-            const float hx = (float)((x + 0.5) / cs - 0.5);
-            int b = (int)hx;
-            if (!(hx >= 0 || (float)b == hx)) b -= 1;  // vl_floor_f
-            const float w2 = hx - b;
-            const float w1 = (float)(1.0 - (double)w2);
-            S.binx[x] = b; S.wx1[x] = w1; S.wx2[x] = w2;
         }
         for (int i = lane; i < ncell * nori * 2; i += 64) S.hog[i] = 0.f;
         for (int i = lane; i < 2 * nori * ih; i += 64) S.masks[i] = 0ull;
         wave_sync();
-        // per cell column: bit mask of the interior columns that vote into it; per cell row: row range
-        for (int c = lane; c < hogW; c += 64) {
-            unsigned long long mk = 0ull;
-            for (int x = 1; x < iw - 1; ++x)
-                if (S.binx[x] == c || S.binx[x] + 1 == c) mk |= 1ull << x;
-            S.colmask[c] = mk;
-        }
-        for (int c = lane; c < hogH; c += 64) {
-            int lo = ih, hi = 0;
-            for (int y = 1; y < ih - 1; ++y)
-                if (S.binx[y] == c || S.binx[y] + 1 == c) { lo = min(lo, y); hi = max(hi, y + 1); }
-            S.yrange[2 * c] = lo;
-            S.yrange[2 * c + 1] = hi;
-        }
         // ---- gradient magnitude and hard orientation assignment per interior pixel (hog.c:612-665)
-        for (int i = lane; i < iw * ih; i += 64) {
-            const int y = i / iw, x = i - y * iw;
-            if (x < 1 || y < 1 || x >= iw - 1 || y >= ih - 1) continue;
+        auto gradient = [&](int i, float& gout) -> int {   // returns the orientation bin or -1, -2 for border pixels
+            const int y = divw(i), x = i - y * iw;
+            if (x < 1 || y < 1 || x >= iw - 1 || y >= ih - 1) return -2;
             const float* it = S.img + i;
             float gradx = *(it + 1) - *(it - 1);
             float grady = *(it + iw) - *(it - iw);
             float grad2 = gradx * gradx + grady * grady;
             if (!(grad2 > 0.f)) { gradx = 0.f; grady = 0.f; grad2 = 0.f; }
             const float grad = sqrtf(grad2);
-            const double den = (double)grad > 1e-10 ? (double)grad : 1e-10;
-            gradx = (float)((double)gradx / den);
-            grady = (float)((double)grady / den);
+            if ((double)grad > 1e-10) {
+                // (float)((double)a / (double)b) == a / b for fp32 a, b: rounding the fp64 quotient (53 >= 2 * 24 + 2 bits) to
+                // fp32 cannot double-round, and the device's fp32 division is correctly rounded
+                gradx = gradx / grad;
+                grady = grady / grad;
+            } else {
+                asm volatile("" ::: "memory");   // a real branch: the fp64 divisions must not be if-converted into every pixel
+                gradx = (float)((double)gradx / 1e-10);
+                grady = (float)((double)grady / 1e-10);
+            }
             float w0 = 0.f;
             int b0 = -1;
             for (int k = 0; k < nori; ++k) {
@@ -219,9 +260,37 @@ __global__ __launch_bounds__(128) void k_sdm_descriptors(const uint8_t* __restri
                 if (score < 0) { score = -score; bin += nori; }
                 if (score > w0) { b0 = bin; w0 = score; }
             }
-            S.grad[i] = grad;
-            S.ori[i] = (unsigned char)(b0 < 0 ? 255 : b0);
-            if (b0 >= 0) atomicOr(&S.masks[b0 * ih + y], 1ull << x);
+            gout = grad;
+            return b0;
+        };
+        if (SMALL) {
+            float gr[SDM_SMALL_ITERS];
+            int ob[SDM_SMALL_ITERS];
+#pragma unroll
+            for (int t = 0; t < SDM_SMALL_ITERS; ++t) {
+                const int i = lane + 64 * t;
+                gr[t] = 0.f;
+                ob[t] = i < npix ? gradient(i, gr[t]) : -2;
+                __builtin_amdgcn_sched_barrier(0);   // keep the unrolled iterations apart: 16 x (loads + temporaries) otherwise cost 235 VGPRs
+            }
+            wave_sync();   // every lane has read its neighbours: the magnitudes may overwrite the image
+#pragma unroll
+            for (int t = 0; t < SDM_SMALL_ITERS; ++t) {
+                const int i = lane + 64 * t;
+                if (ob[t] > -2) {
+                    S.grad[i] = gr[t];
+                    if (ob[t] >= 0) { const int y = divw(i); atomicOr(&S.masks[ob[t] * ih + y], 1ull << (i - y * iw)); }
+                }
+            }
+        } else {
+            for (int i = lane; i < npix; i += 64) {
+                float g = 0.f;
+                const int b0 = gradient(i, g);
+                if (b0 > -2) {
+                    S.grad[i] = g;
+                    if (b0 >= 0) { const int y = divw(i); atomicOr(&S.masks[b0 * ih + y], 1ull << (i - y * iw)); }
+                }
+            }
         }
         wave_sync();
         // ---- spatial voting: lane e = (orientation, cell) walks ITS contributing pixels (orientation bit
@@ -256,45 +325,50 @@ __global__ __launch_bounds__(128) void k_sdm_descriptors(const uint8_t* __restri
             S.norm[c] = nrm;
         }
         wave_sync();
-        // ---- block normalisation and feature assembly (hog.c:925-1060); one cell per lane
+        // ---- block normalisation and feature assembly (hog.c:925-1060).  Lane (cell, q): block factor f_q of the cell;
+        // lane (cell, k): the clamped terms of orientation k; lane cell: the four texture sums in orientation order.
         const int dim = p.dim;
-        for (int c = lane; c < ncell; c += 64) {
+        for (int j = lane; j < ncell * 4; j += 64) {
+            const int c = j >> 2, q = j & 3;
             const int y = c / hogW, x = c - y * hogW;
             const int xm = max(x - 1, 0), xp = min(x + 1, hogW - 1), ym = max(y - 1, 0), yp = min(y + 1, hogH - 1);
-            const double n1 = S.norm[xm + ym * hogW], n2 = S.norm[x + ym * hogW], n3 = S.norm[xp + ym * hogW];
-            const double n4 = S.norm[xm + y * hogW], n5 = S.norm[x + y * hogW], n6 = S.norm[xp + y * hogW];
-            const double n7 = S.norm[xm + yp * hogW], n8 = S.norm[x + yp * hogW], n9 = S.norm[xp + yp * hogW];
-            const double f1 = 1.0 / sqrt(n1 + n2 + n4 + n5 + 1e-4);
-            const double f2 = 1.0 / sqrt(n2 + n3 + n5 + n6 + 1e-4);
-            const double f3 = 1.0 / sqrt(n4 + n5 + n7 + n8 + 1e-4);
-            const double f4 = 1.0 / sqrt(n5 + n6 + n8 + n9 + 1e-4);
-            double t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-            for (int k = 0; k < nori; ++k) {
-                const double ha = S.hog[c + k * ncell], hb = S.hog[c + (k + nori) * ncell];
-                double ha1 = f1 * ha, ha2 = f2 * ha, ha3 = f3 * ha, ha4 = f4 * ha;
-                double hb1 = f1 * hb, hb2 = f2 * hb, hb3 = f3 * hb, hb4 = f4 * hb;
-                double hc1 = ha1 + hb1, hc2 = ha2 + hb2, hc3 = ha3 + hb3, hc4 = ha4 + hb4;
-                ha1 = fmin(0.2, ha1); ha2 = fmin(0.2, ha2); ha3 = fmin(0.2, ha3); ha4 = fmin(0.2, ha4);
-                hb1 = fmin(0.2, hb1); hb2 = fmin(0.2, hb2); hb3 = fmin(0.2, hb3); hb4 = fmin(0.2, hb4);
-                hc1 = fmin(0.2, hc1); hc2 = fmin(0.2, hc2); hc3 = fmin(0.2, hc3); hc4 = fmin(0.2, hc4);
-                t1 = t1 + hc1; t2 = t2 + hc2; t3 = t3 + hc3; t4 = t4 + hc4;
-                if (p.variant == 1) {
-                    S.feat[c + k * ncell] = (float)(0.5 * (ha1 + ha2 + ha3 + ha4));
-                    S.feat[c + (k + nori) * ncell] = (float)(0.5 * (hb1 + hb2 + hb3 + hb4));
-                    S.feat[c + (k + 2 * nori) * ncell] = (float)(0.5 * (hc1 + hc2 + hc3 + hc4));
-                } else {
-                    S.feat[c + k * ncell] = (float)hc1;
-                    S.feat[c + (k + nori) * ncell] = (float)hc2;
-                    S.feat[c + (k + 2 * nori) * ncell] = (float)hc3;
-                    S.feat[c + (k + 3 * nori) * ncell] = (float)hc4;
-                }
-            }
+            // f1 = n1+n2+n4+n5, f2 = n2+n3+n5+n6, f3 = n4+n5+n7+n8, f4 = n5+n6+n8+n9 over the 3x3 neighbourhood n1..n9
+            const int xa = (q & 1) ? x : xm, xb = (q & 1) ? xp : x, ya = (q & 2) ? y : ym, yb = (q & 2) ? yp : y;
+            const double na = S.norm[xa + ya * hogW], nb = S.norm[xb + ya * hogW], nc = S.norm[xa + yb * hogW], nd = S.norm[xb + yb * hogW];
+            S.fac[j] = 1.0 / sqrt(na + nb + nc + nd + 1e-4);
+        }
+        wave_sync();
+        for (int j = lane; j < ncell * nori; j += 64) {
+            const int k = j / ncell, c = j - k * ncell;
+            const double f1 = S.fac[4 * c], f2 = S.fac[4 * c + 1], f3 = S.fac[4 * c + 2], f4 = S.fac[4 * c + 3];
+            const double ha = S.hog[c + k * ncell], hb = S.hog[c + (k + nori) * ncell];
+            double ha1 = f1 * ha, ha2 = f2 * ha, ha3 = f3 * ha, ha4 = f4 * ha;
+            double hb1 = f1 * hb, hb2 = f2 * hb, hb3 = f3 * hb, hb4 = f4 * hb;
+            double hc1 = ha1 + hb1, hc2 = ha2 + hb2, hc3 = ha3 + hb3, hc4 = ha4 + hb4;
+            ha1 = fmin(0.2, ha1); ha2 = fmin(0.2, ha2); ha3 = fmin(0.2, ha3); ha4 = fmin(0.2, ha4);
+            hb1 = fmin(0.2, hb1); hb2 = fmin(0.2, hb2); hb3 = fmin(0.2, hb3); hb4 = fmin(0.2, hb4);
+            hc1 = fmin(0.2, hc1); hc2 = fmin(0.2, hc2); hc3 = fmin(0.2, hc3); hc4 = fmin(0.2, hc4);
+            double* hcp = S.hc + 4 * (size_t)(c * nori + k);
+            hcp[0] = hc1; hcp[1] = hc2; hcp[2] = hc3; hcp[3] = hc4;
             if (p.variant == 1) {
+                S.feat[c + k * ncell] = (float)(0.5 * (ha1 + ha2 + ha3 + ha4));
+                S.feat[c + (k + nori) * ncell] = (float)(0.5 * (hb1 + hb2 + hb3 + hb4));
+                S.feat[c + (k + 2 * nori) * ncell] = (float)(0.5 * (hc1 + hc2 + hc3 + hc4));
+            } else {
+                S.feat[c + k * ncell] = (float)hc1;
+                S.feat[c + (k + nori) * ncell] = (float)hc2;
+                S.feat[c + (k + 2 * nori) * ncell] = (float)hc3;
+                S.feat[c + (k + 3 * nori) * ncell] = (float)hc4;
+            }
+        }
+        wave_sync();
+        if (p.variant == 1) {
+            for (int j = lane; j < ncell * 4; j += 64) {
+                const int c = j >> 2, q4 = j & 3;
+                double t = 0;
+                for (int k = 0; k < nori; ++k) t = t + S.hc[4 * (size_t)(c * nori + k) + q4];
                 const float q = 1.0f / sqrtf(18.0f);
-                S.feat[c + (3 * nori + 0) * ncell] = (float)((double)q * t1);
-                S.feat[c + (3 * nori + 1) * ncell] = (float)((double)q * t2);
-                S.feat[c + (3 * nori + 2) * ncell] = (float)((double)q * t3);
-                S.feat[c + (3 * nori + 3) * ncell] = (float)((double)q * t4);
+                S.feat[c + (3 * nori + q4) * ncell] = (float)((double)q * t);
             }
         }
         wave_sync();
@@ -387,6 +461,24 @@ void fill_desc_params(DescParams& p, int W, int H, int L, bool adaptive, int var
     if (2 * p.ldsPerWave > 64 * 1024) FD_THROW(FD_ERR_INVALID_ARGUMENT, "VlHog: patch too large for the LDS budget");
 }
 
+// resident workgroups per CU of the descriptor kernel (LDS-bound): the persistent grid is sized to them so that the per-wave
+// geometry tables are built once per resident wave
+int descriptor_blocks_per_cu(const DescParams& p) {
+    int nb = 0;
+    const hipError_t e = desc_small(p.iw, p.ih)
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sdm_descriptors<true>, 128, (size_t)2 * p.ldsPerWave)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sdm_descriptors<false>, 128, (size_t)2 * p.ldsPerWave);
+    return e == hipSuccess && nb > 0 ? nb : 4;
+}
+
+void launch_descriptors(dim3 grid, hipStream_t st, const uint8_t* dimg, const int32_t* origin, const DescParams& p, int64_t nitems, float* out,
+                        int64_t out_stride) {
+    if (desc_small(p.iw, p.ih))
+        hipLaunchKernelGGL(k_sdm_descriptors<true>, grid, dim3(128), 2 * p.ldsPerWave, st, dimg, origin, p, nitems, out, out_stride);
+    else
+        hipLaunchKernelGGL(k_sdm_descriptors<false>, grid, dim3(128), 2 * p.ldsPerWave, st, dimg, origin, p, nitems, out, out_stride);
+}
+
 }  // namespace
 
 extern "C" {
@@ -450,10 +542,9 @@ int fd_sdm_descriptors(fd_ctx* ctx, const uint8_t* gray, int W, int H, const flo
         HIP_CHECK(hipMemcpyAsync(dshape.p, shape.data(), sizeof(float) * shape.size(), hipMemcpyHostToDevice, st));
         HIP_CHECK(hipMemsetAsync(dstatus.p, 0, 4, st));
         // one "face" with n landmarks and a fixed half window
-        hipLaunchKernelGGL(k_sdm_prepare, dim3(1), dim3(64), 0, st, dshape.as<float>(), 1, n, W, H, 0, pwh, adaptive ? (1 << 20) : SDM_IMG, 1.0, dorigin.as<int32_t>(),
+        hipLaunchKernelGGL(k_sdm_prepare, dim3((n + 63) / 64), dim3(64), 0, st, dshape.as<float>(), 1, n, W, H, 0, pwh, adaptive ? (1 << 20) : SDM_IMG, 1.0, dorigin.as<int32_t>(),
                            ddist.as<float>(), dstatus.as<int32_t>());
-        hipLaunchKernelGGL(k_sdm_descriptors, dim3((n + 1) / 2), dim3(128), 2 * p.ldsPerWave, st, dimg.as<uint8_t>(), dorigin.as<int32_t>(), p, (int64_t)n,
-                           ddesc.as<float>(), (int64_t)n * p.len);
+        launch_descriptors(dim3((n + 1) / 2), st, dimg.as<uint8_t>(), dorigin.as<int32_t>(), p, (int64_t)n, ddesc.as<float>(), (int64_t)n * p.len);
         HIP_CHECK(hipGetLastError());
         int32_t status = 0;
         HIP_CHECK(hipMemcpyAsync(out, ddesc.p, sizeof(float) * (size_t)n * p.len, hipMemcpyDeviceToHost, st));
@@ -490,10 +581,10 @@ static void sdm_optimize(fd_ctx* ctx, fd_sdm* m, const uint8_t* gray_images, int
     const int64_t nitems = (int64_t)B * L;
     for (int step = 0; step < m->S; ++step) {
         const double stepFactor = 1 / (1 + std::exp((double)((step + 1) - m->S)));  // :226, double on the host
-        hipLaunchKernelGGL(k_sdm_prepare, dim3((B + 63) / 64), dim3(64), 0, st, m->shapes.as<float>(), B, L, W, H, 1, 0, 1 << 20, stepFactor,
+        hipLaunchKernelGGL(k_sdm_prepare, dim3((B * L + 255) / 256), dim3(256), 0, st, m->shapes.as<float>(), B, L, W, H, 1, 0, 1 << 20, stepFactor,
                            m->origin.as<int32_t>(), m->dist.as<float>(), m->status.as<int32_t>());
-        const int grid = (int)std::min<int64_t>((nitems + 1) / 2, (int64_t)ctx->num_cus * 16);
-        hipLaunchKernelGGL(k_sdm_descriptors, dim3(grid), dim3(128), 2 * p.ldsPerWave, st, dimg, m->origin.as<int32_t>(), p, nitems, m->desc.as<float>(), (int64_t)F);
+        const int grid = (int)std::min<int64_t>((nitems + 1) / 2, (int64_t)ctx->num_cus * descriptor_blocks_per_cu(p));
+        launch_descriptors(dim3(grid), st, dimg, m->origin.as<int32_t>(), p, nitems, m->desc.as<float>(), (int64_t)F);
         const float* R = m->R[step]->as<float>();
         hipLaunchKernelGGL(k_sdm_regress, dim3((B + 15) / 16, (N + 15) / 16, nchunks), dim3(64), 0, st, m->desc.as<float>(), B, F, R, N,
                            m->partial.as<double>(), nchunks);
