@@ -385,27 +385,44 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int RG_KCHUNK = 256;
 
-// delta partial sums: one wavefront per (16-face tile, 16-output tile, K chunk) on the f64 MFMA pipe
+// delta partial sums: one wavefront per (16-face tile, RG_NT 16-output tiles, K chunk) on the f64 MFMA pipe; the descriptor
+// fragment is loaded once for the RG_NT independent accumulator chains
+constexpr int RG_NT = 3;
 __global__ __launch_bounds__(64) void k_sdm_regress(const float* __restrict__ D, int B, int F, const float* __restrict__ R, int N,
                                                     double* __restrict__ partial, int nchunks) {
     const int lane = threadIdx.x;
-    const int mt = blockIdx.x, nt = blockIdx.y, ch = blockIdx.z;
-    const int i = mt * 16 + (lane & 15), j = nt * 16 + (lane & 15), kq = lane >> 4;
+    const int mt = blockIdx.x, ng = blockIdx.y, ch = blockIdx.z;
+    const int i = mt * 16 + (lane & 15), kq = lane >> 4;
     const int k0 = ch * RG_KCHUNK, k1 = min(F, k0 + RG_KCHUNK);
-    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-    const bool iok = i < B, jok = j < N;
+    f64x4 acc[RG_NT];
+    int j[RG_NT];
+    bool jok[RG_NT];
+#pragma unroll
+    for (int t = 0; t < RG_NT; ++t) {
+        acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+        j[t] = (ng * RG_NT + t) * 16 + (lane & 15);
+        jok[t] = j[t] < N;
+    }
+    const bool iok = i < B;
+    const float* __restrict__ drow = D + (size_t)(iok ? i : 0) * F;
     for (int k = k0; k < k1; k += 4) {
         const int kk = k + kq;
-        const double a = (iok && kk < k1) ? (double)D[(size_t)i * F + kk] : 0.0;
-        const double b = (jok && kk < k1) ? (double)R[(size_t)kk * N + j] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        const bool kok = kk < k1;
+        const double a = (iok && kok) ? (double)drow[kk] : 0.0;
+        double b[RG_NT];
+#pragma unroll
+        for (int t = 0; t < RG_NT; ++t) b[t] = (jok[t] && kok) ? (double)R[(size_t)kk * N + j[t]] : 0.0;
+#pragma unroll
+        for (int t = 0; t < RG_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[t], acc[t], 0, 0, 0);
     }
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = mt * 16 + (lane >> 4) + 4 * r;
-        if (row < B && jok) partial[((size_t)ch * B + row) * N + j] = acc[r];
-    }
+    for (int t = 0; t < RG_NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = mt * 16 + (lane >> 4) + 4 * r;
+            if (row < B && jok[t]) partial[((size_t)ch * B + row) * N + j[t]] = acc[t][r];
+        }
 }
 
 // shape += (float)(sum of partials + bias row) * dist   (SdmLandmarkModel.hpp:241-243)
@@ -586,7 +603,7 @@ static void sdm_optimize(fd_ctx* ctx, fd_sdm* m, const uint8_t* gray_images, int
         const int grid = (int)std::min<int64_t>((nitems + 1) / 2, (int64_t)ctx->num_cus * descriptor_blocks_per_cu(p));
         launch_descriptors(dim3(grid), st, dimg, m->origin.as<int32_t>(), p, nitems, m->desc.as<float>(), (int64_t)F);
         const float* R = m->R[step]->as<float>();
-        hipLaunchKernelGGL(k_sdm_regress, dim3((B + 15) / 16, (N + 15) / 16, nchunks), dim3(64), 0, st, m->desc.as<float>(), B, F, R, N,
+        hipLaunchKernelGGL(k_sdm_regress, dim3((B + 15) / 16, ((N + 15) / 16 + RG_NT - 1) / RG_NT, nchunks), dim3(64), 0, st, m->desc.as<float>(), B, F, R, N,
                            m->partial.as<double>(), nchunks);
         hipLaunchKernelGGL(k_sdm_update, dim3((B * N + 255) / 256), dim3(256), 0, st, m->shapes.as<float>(), m->partial.as<double>(), nchunks,
                            R + (size_t)F * N, m->dist.as<float>(), B, N);
