@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--gather-every", type=int, default=8)
     ap.add_argument("--size", default="640x480", help="frame size WxH for the hog_svm / wvm workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="hog_svm workload: frames in flight (one context + stream each); the pyramid / HOG kernels of one frame "
+                         "overlap the MFMA SVM kernel of the previous one")
     ap.add_argument("--frames-per-step", type=int, default=4,
                     help="wvm workload: frames per step; their WVM stages are queued together (fd_detect_five_stage_batch), "
                          "so the host stages of one frame overlap the kernels of the next")
@@ -119,17 +122,25 @@ def main():
         model = synth.make_svm_f32(20260927, feats2, nsv=1024, gamma=0.5, positive_fraction=0.01)
         svm = capi.Svm(ctx, model)
         del feats2
+        # frames in flight: slot 0 is the context above; further slots have their own context (stream, scratch), pyramid and model copy
+        slots = [(ctx, pyr, svm)]
+        for _ in range(1, max(1, args.inflight)):
+            c2 = capi.Context(local_rank)
+            p2 = capi.Pyramid(c2, octave_layers=5, min_scale=1 / 16, max_scale=1.0)
+            p2.set_layer_filter(capi.FD_LAYER_GRADBIN, bins=9)
+            slots.append((c2, p2, capi.Svm(c2, model)))
 
         def step(i, sync=False):
             # asynchronous: pyramid + HOG + SVM + positive selection are only enqueued; detections stay in HBM
             f = dframes[i % NFRAMES]
-            pyr.update_device(f.data_ptr(), W, H, 3)
-            return capi.bench_hog_svm(ctx, pyr, svm, hp, sync=sync)
+            c_, p_, s_ = slots[0] if sync else slots[i % len(slots)]
+            p_.update_device(f.data_ptr(), W, H, 3)
+            return capi.bench_hog_svm(c_, p_, s_, hp, sync=sync)
 
         units_name = "windows"
         config = dict(workload="config2: 640x480 BGR frame, ImagePyramid(octl=5, 1/16..1) 21 layers, 20x20 windows stride 2, "
                                "GradientFilter+GradientBinning(9) layers, HogFilter(9,cell 5,block 2)=324 f32, RBF-SVM 1024 SV gamma 0.5",
-                      frames_per_step=1, parallelism="image-shard dp%d" % world)
+                      frames_per_step=1, frames_in_flight=len(slots), parallelism="image-shard dp%d" % world)
         dtype = "f32"
     elif args.workload == "wvm":
         W, H = FW, FH
@@ -279,6 +290,9 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
+        if args.workload == "hog_svm":
+            for c_, _, _ in slots[1:]:
+                c_.synchronize()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
