@@ -156,6 +156,7 @@ _SIGS = {
                                     C.POINTER(C.c_int64), C.c_void_p]),
     "fd_fhog_size": (C.c_int, [C.POINTER(fd_fhog_params), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "fd_fhog_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(fd_fhog_params), C.c_void_p]),
+    "fd_fhog_image_channels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(fd_fhog_params), C.c_void_p]),
     "fd_pyramid_fhog_layer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(fd_fhog_params), C.c_void_p]),
     "fd_aggregated_create": (C.c_int, [C.c_void_p, C.POINTER(fd_aggregated_params), C.POINTER(C.c_void_p)]),
     "fd_aggregated_destroy": (None, [C.c_void_p]),
@@ -434,17 +435,22 @@ def detect_five_stage_batch(ctx, detectors, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=
 
 
 def fhog(ctx, gray=None, pyramid=None, layer=0, cell_size=8, unsigned_bins=9, interpolate_bins=False, interpolate_cells=True, alpha=0.2):
-    """FhogFilter::applyTo on a host gray image or on a layer of a gray pyramid: (rows, cols, 3 * unsigned_bins + 4) float32"""
+    """FhogFilter::applyTo on a host gray (h, w) / BGR (h, w, 3) image or on a layer of a gray pyramid:
+    (rows, cols, 3 * unsigned_bins + 4) float32"""
     fp = fd_fhog_params(cell_size, unsigned_bins, int(interpolate_bins), int(interpolate_cells), alpha)
     if gray is not None:
         gray = _c(gray, np.uint8)
-        h, w = gray.shape
+        h, w = gray.shape[:2]
     else:
         info = pyramid.layers()[layer]
         h, w = info["h"], info["w"]
     out = np.zeros((h // cell_size, w // cell_size, 3 * unsigned_bins + 4), np.float32)
     if gray is not None:
-        ctx.check(lib().fd_fhog_image(ctx.h, _ptr(gray), w, h, C.byref(fp), _ptr(out)))
+        ch = 1 if gray.ndim == 2 else gray.shape[2]
+        if ch == 1:
+            ctx.check(lib().fd_fhog_image(ctx.h, _ptr(gray), w, h, C.byref(fp), _ptr(out)))
+        else:
+            ctx.check(lib().fd_fhog_image_channels(ctx.h, _ptr(gray), w, h, ch, C.byref(fp), _ptr(out)))
     else:
         ctx.check(lib().fd_pyramid_fhog_layer(ctx.h, pyramid.h, layer, C.byref(fp), _ptr(out)))
     return out

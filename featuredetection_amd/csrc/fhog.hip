@@ -17,22 +17,27 @@
 #include <cstring>
 #include <memory>
 
-struct FhogLut {   // one entry per (dy, dx) gradient code
+struct FhogLut {   // (bin, weight) of a gradient: what k_fhog_hist consumes per pixel
     uint8_t index1, index2;
     uint16_t pad;
     float weight1, weight2;
+};
+struct FhogLutEntry {   // one entry per (dy, dx) gradient code (FhogFilter.hpp:108-111: bins + magnitude)
+    FhogLut bins;
+    float magnitude;
 };
 struct FhogCoeffDev { int32_t index1, index2; float weight1, weight2; };
 
 struct FhogParamsDev {
     int32_t cell, ubins, sbins, D, interpBins, interpCells;
     float alpha;
-    const FhogLut* lut;            // [512 * 512], index dy * 512 + dx
+    const FhogLutEntry* lut;       // [512 * 512], index dy * 512 + dx
     const FhogCoeffDev* coeff;     // all layers: rows of layer 0, columns of layer 0, rows of layer 1, ...
 };
 struct FhogLayerDev {              // one gray image / pyramid layer of a launch
     const uint8_t* img;
-    int32_t w, h, stride;
+    int32_t w, h, stride;          // stride in bytes
+    int32_t channels;              // 1 or 3 (interleaved)
     int32_t rows, cols;            // cells
     int32_t cellBase, coeffBase;   // first cell / first coefficient of the layer in the launch-wide arrays
     int32_t vw, vh, posBase;       // window positions of the score map (aggregated detector only)
@@ -90,9 +95,23 @@ __global__ __launch_bounds__(256) void k_fhog_grad(const FhogLayerDev* __restric
     const int x = cx * d.cell + o;
     const int py = max(y - 1, 0), ny = min(y + 1, L.h - 1), px = max(x - 1, 0), nx = min(x + 1, L.w - 1);
     const uint8_t* rowp = L.img + (size_t)y * L.stride;
-    const int dx = (int)rowp[nx] - (int)rowp[px] + 256;
-    const int dy = (int)L.img[(size_t)ny * L.stride + x] - (int)L.img[(size_t)py * L.stride + x] + 256;
-    grad[(size_t)L.pixBase + i] = d.lut[dy * 512 + dx];
+    FhogLut e;
+    if (L.channels == 1) {
+        const int dx = (int)rowp[nx] - (int)rowp[px] + 256;
+        const int dy = (int)L.img[(size_t)ny * L.stride + x] - (int)L.img[(size_t)py * L.stride + x] + 256;
+        e = d.lut[dy * 512 + dx].bins;
+    } else {   // getBinCoefficients<false> (FhogFilter.hpp:144-172): the channel with the largest gradient magnitude
+        const uint8_t* up = L.img + (size_t)py * L.stride + 3 * x;
+        const uint8_t* dn = L.img + (size_t)ny * L.stride + 3 * x;
+        const uint8_t* lf = rowp + 3 * px;
+        const uint8_t* rt = rowp + 3 * nx;
+        const FhogLutEntry e1 = d.lut[((int)dn[0] - (int)up[0] + 256) * 512 + ((int)rt[0] - (int)lf[0] + 256)];
+        const FhogLutEntry e2 = d.lut[((int)dn[1] - (int)up[1] + 256) * 512 + ((int)rt[1] - (int)lf[1] + 256)];
+        const FhogLutEntry e3 = d.lut[((int)dn[2] - (int)up[2] + 256) * 512 + ((int)rt[2] - (int)lf[2] + 256)];
+        if (e1.magnitude > e2.magnitude) e = e1.magnitude > e3.magnitude ? e1.bins : e3.bins;
+        else e = e2.magnitude > e3.magnitude ? e2.bins : e3.bins;
+    }
+    grad[(size_t)L.pixBase + i] = e;
 }
 
 // createInterpolationCoefficients (FhogFilter.cpp:74-98), one thread per pixel row / column of every layer.
@@ -264,8 +283,8 @@ void build_lut(fd_ctx* ctx, FhogScratch& S, const fd_fhog_params& fp) {
     const int signedBinCount = 2 * fp.unsigned_bins;
     const float TWO_PI = (float)(2 * M_PI);
     const float value2bin = signedBinCount / TWO_PI;
-    std::vector<FhogLut> lut((size_t)512 * 512);
-    std::memset(lut.data(), 0, sizeof(FhogLut) * lut.size());
+    std::vector<FhogLutEntry> lut((size_t)512 * 512);
+    std::memset(lut.data(), 0, sizeof(FhogLutEntry) * lut.size());
     for (int gradientCodeX = 1; gradientCodeX < 512; ++gradientCodeX) {
         const float gradientX = (gradientCodeX - 256) / (255.0f * 2.0f);
         for (int gradientCodeY = 1; gradientCodeY < 512; ++gradientCodeY) {
@@ -287,11 +306,11 @@ void build_lut(fd_ctx* ctx, FhogScratch& S, const fd_fhog_params& fp) {
                 if (bin == signedBinCount) bin = 0;
                 e.index1 = (uint8_t)bin; e.weight1 = magnitude;
             }
-            lut[(size_t)gradientCodeY * 512 + gradientCodeX] = e;
+            lut[(size_t)gradientCodeY * 512 + gradientCodeX] = FhogLutEntry{e, magnitude};
         }
     }
-    S.lut.reserve(sizeof(FhogLut) * lut.size());
-    HIP_CHECK(hipMemcpy(S.lut.p, lut.data(), sizeof(FhogLut) * lut.size(), hipMemcpyHostToDevice));
+    S.lut.reserve(sizeof(FhogLutEntry) * lut.size());
+    HIP_CHECK(hipMemcpy(S.lut.p, lut.data(), sizeof(FhogLutEntry) * lut.size(), hipMemcpyHostToDevice));
     S.lutFor = fp;
     S.lutValid = true;
 }
@@ -340,7 +359,7 @@ FhogParamsDev run_fhog(fd_ctx* ctx, FhogScratch& S, const FhogLayerDev* dlayers,
     S.energies.reserve(sizeof(float) * (size_t)t.cells);
     S.grad.reserve(sizeof(FhogLut) * (size_t)t.pixels);
     S.hist.reserve(sizeof(float) * (size_t)t.cells * d.sbins);
-    d.lut = S.lut.as<FhogLut>();
+    d.lut = S.lut.as<FhogLutEntry>();
     d.coeff = S.coeff.as<FhogCoeffDev>();
     hipLaunchKernelGGL(k_fhog_coeff, dim3((t.coeffs + 255) / 256), dim3(256), 0, ctx->stream, dlayers, nLayers, t.coeffs, d, S.coeff.as<FhogCoeffDev>());
     hipLaunchKernelGGL(k_fhog_grad, dim3(t.pixBlocks), dim3(256), 0, ctx->stream, dlayers, nLayers, d, S.grad.as<FhogLut>());
@@ -357,11 +376,12 @@ FhogParamsDev run_fhog(fd_ctx* ctx, FhogScratch& S, const FhogLayerDev* dlayers,
 }
 
 // one gray image already on the device
-void run_fhog_single(fd_ctx* ctx, FhogScratch& S, const uint8_t* dimg, int w, int h, int stride, const fd_fhog_params& fp, int& rows, int& cols) {
+void run_fhog_single(fd_ctx* ctx, FhogScratch& S, const uint8_t* dimg, int w, int h, int stride, const fd_fhog_params& fp, int& rows, int& cols,
+                     int channels = 1) {
     check_fhog_params(fp);
     std::vector<FhogLayerDev> layers(1);
     std::memset(&layers[0], 0, sizeof(FhogLayerDev));
-    layers[0].img = dimg; layers[0].w = w; layers[0].h = h; layers[0].stride = stride;
+    layers[0].img = dimg; layers[0].w = w; layers[0].h = h; layers[0].stride = stride; layers[0].channels = channels;
     const FhogLayout t = layout_layers(layers, fp);
     rows = layers[0].rows; cols = layers[0].cols;
     if (rows == 0 || cols == 0) return;
@@ -455,14 +475,20 @@ int fd_fhog_size(const fd_fhog_params* fp, int width, int height, int* rows, int
 }
 
 int fd_fhog_image(fd_ctx* ctx, const uint8_t* gray, int width, int height, const fd_fhog_params* fp, float* out) {
+    return fd_fhog_image_channels(ctx, gray, width, height, 1, fp, out);
+}
+
+int fd_fhog_image_channels(fd_ctx* ctx, const uint8_t* image, int width, int height, int channels, const fd_fhog_params* fp, float* out) {
     return fd_guard(ctx, [&] {
-        if (!ctx || !gray || !fp || !out || width < 1 || height < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_fhog_image: bad argument");
+        if (!ctx || !image || !fp || !out || width < 1 || height < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_fhog_image: bad argument");
+        if (channels != 1 && channels != 3) FD_THROW(FD_ERR_INVALID_ARGUMENT, "FhogFilter: the image type must be CV_8UC1 or CV_8UC3 (%d channels)", channels);
         HIP_CHECK(hipSetDevice(ctx->device));
         FhogScratch& S = scratch(ctx);
-        S.img.reserve((size_t)width * height);
-        HIP_CHECK(hipMemcpyAsync(S.img.p, gray, (size_t)width * height, hipMemcpyHostToDevice, ctx->stream));
+        const size_t bytes = (size_t)width * height * channels;
+        S.img.reserve(bytes);
+        HIP_CHECK(hipMemcpyAsync(S.img.p, image, bytes, hipMemcpyHostToDevice, ctx->stream));
         int rows, cols;
-        run_fhog_single(ctx, S, S.img.as<uint8_t>(), width, height, width, *fp, rows, cols);
+        run_fhog_single(ctx, S, S.img.as<uint8_t>(), width, height, width * channels, *fp, rows, cols, channels);
         if (rows && cols)
             HIP_CHECK(hipMemcpyAsync(out, S.desc.p, sizeof(float) * (size_t)rows * cols * (3 * fp->unsigned_bins + 4), hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -553,7 +579,7 @@ int fd_aggregated_detect(fd_ctx* ctx, fd_aggregated* a, const uint8_t* image, in
                 const HostLayer& L = p->all[p->kept[li]];
                 FhogLayerDev& T = a->layerTable[li];
                 std::memset(&T, 0, sizeof(T));
-                T.img = p->arena.as<uint8_t>() + L.gray_off; T.w = L.w; T.h = L.h; T.stride = L.w;
+                T.img = p->arena.as<uint8_t>() + L.gray_off; T.w = L.w; T.h = L.h; T.stride = L.w; T.channels = 1;
                 T.vh = std::max(L.h / P.fhog.cell_size - P.window_h + 1, 0);
                 T.vw = std::max(L.w / P.fhog.cell_size - P.window_w + 1, 0);
                 if (T.vw == 0 || T.vh == 0) T.vw = T.vh = 0;

@@ -256,13 +256,14 @@ FhogFilter::FhogFilter(int cellSize, int unsignedBinCount, bool interpolateBins,
     if (alpha <= 0) throw std::invalid_argument("FhogAggregationFilter: alpha must be bigger than zero, but was: " + std::to_string(alpha));
 }
 Mat FhogFilter::applyTo(const Mat& image, Mat& descriptors) const {
-    if (image.type() != CV_8UC1)
-        throw std::invalid_argument("FhogFilter: the image type must be CV_8UC1 on this backend, but was " + std::to_string(image.type()));
+    if (image.type() != CV_8UC1 && image.type() != CV_8UC3)
+        throw std::invalid_argument("FhogFilter: the image type must be CV_8UC1 or CV_8UC3, but was " + std::to_string(image.type()));
     Mat src = image.isContinuous() ? image : image.clone();
     fd_fhog_params fp = {cellSize, unsignedBinCount, interpolateBins, interpolateCells, alpha};
     const int rows = src.rows / cellSize, cols = src.cols / cellSize, D = 3 * unsignedBinCount + 4;
     descriptors.create(rows, cols * D, CV_32FC1);   // the compat Mat has no CV_32FC(n) with n > 4: channels are interleaved in the row
-    if (rows > 0 && cols > 0) check(fd_fhog_image(context(), src.ptr<uchar>(0), src.cols, src.rows, &fp, descriptors.ptr<float>(0)));
+    if (rows > 0 && cols > 0)
+        check(fd_fhog_image_channels(context(), src.ptr<uchar>(0), src.cols, src.rows, src.channels(), &fp, descriptors.ptr<float>(0)));
     return descriptors;
 }
 }  // namespace filtering

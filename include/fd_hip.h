@@ -221,6 +221,9 @@ typedef struct {
 int fd_fhog_size(const fd_fhog_params* fp, int width, int height, int* rows, int* cols, int* channels);
 /* gray: host image (width * height bytes); out: rows * cols * channels floats (host) */
 int fd_fhog_image(fd_ctx* ctx, const uint8_t* gray, int width, int height, const fd_fhog_params* fp, float* out);
+/* the same for CV_8UC1 (channels 1) or CV_8UC3 (channels 3) host images: with three channels every pixel votes with the channel
+ * of the largest gradient magnitude (getBinCoefficients<false>, FhogFilter.hpp:144-172); image: width * height * channels bytes */
+int fd_fhog_image_channels(fd_ctx* ctx, const uint8_t* image, int width, int height, int channels, const fd_fhog_params* fp, float* out);
 /* the same on kept layer `layer` of an updated gray pyramid (the layer filter of AggregatedFeaturesExtractor's feature pyramid) */
 int fd_pyramid_fhog_layer(fd_ctx* ctx, fd_pyramid* p, int layer, const fd_fhog_params* fp, float* out);
 

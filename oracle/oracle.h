@@ -43,6 +43,10 @@ int orc_spatial_pyramid_histogram(const uint8_t* img, int w, int h, int ch, int 
  * rows = h / cellSize, cols = w / cellSize cells of 3 * unsignedBinCount + 4 floats; returns the number of floats */
 int orc_fhog(const uint8_t* img, int w, int h, int stride, int cellSize, int unsignedBinCount, int interpolateBins,
              int interpolateCells, float alpha, float* out, int* rows, int* cols);
+/* the same on a CV_8UC1 (channels 1) or CV_8UC3 (channels 3: per pixel the channel with the largest gradient magnitude,
+   FhogFilter.hpp:144-172) image; stride in bytes */
+int orc_fhog_channels(const uint8_t* img, int w, int h, int channels, int stride, int cellSize, int unsignedBinCount, int interpolateBins,
+                      int interpolateCells, float alpha, float* out, int* rows, int* cols);
 
 /* ---------------- pyramid + window enumeration ---------------- */
 typedef struct orc_pyramid orc_pyramid;

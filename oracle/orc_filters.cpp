@@ -583,7 +583,8 @@ static FhogCoeff fhog_lut_entry(int gradientCodeX, int gradientCodeY, int signed
 }
 
 int fhog_filter(const uchar* img, int w, int h, int stride, int cellSize, int unsignedBinCount, bool interpolateBins, bool interpolateCells,
-                float alpha, std::vector<float>& out, int& rowsOut, int& colsOut) {
+                float alpha, std::vector<float>& out, int& rowsOut, int& colsOut, int channels) {
+    if (channels != 1 && channels != 3) throw std::invalid_argument("FhogFilter: the image type must be CV_8UC1 or CV_8UC3");
     if (unsignedBinCount < 1) throw std::invalid_argument("FhogFilter: unsignedBinCount must be bigger than zero");
     if (alpha <= 0) throw std::invalid_argument("FhogAggregationFilter: alpha must be bigger than zero");
     const int signedBinCount = 2 * unsignedBinCount;
@@ -600,10 +601,24 @@ int fhog_filter(const uchar* img, int w, int h, int stride, int cellSize, int un
         for (int imageCol = 0; imageCol < (int)colCoeff.size(); ++imageCol) {
             int prevRow = std::max(imageRow - 1, 0), nextRow = std::min(imageRow + 1, h - 1);
             int prevCol = std::max(imageCol - 1, 0), nextCol = std::min(imageCol + 1, w - 1);
-            int dx = img[(size_t)imageRow * stride + nextCol] - img[(size_t)imageRow * stride + prevCol] + 256;
-            int dy = img[(size_t)nextRow * stride + imageCol] - img[(size_t)prevRow * stride + imageCol] + 256;
-            float magnitude;
-            FhogCoeff b = fhog_lut_entry(dx, dy, signedBinCount, interpolateBins, magnitude);
+            FhogCoeff b;
+            if (channels == 1) {   // getBinCoefficients<true> :133-142
+                int dx = img[(size_t)imageRow * stride + nextCol] - img[(size_t)imageRow * stride + prevCol] + 256;
+                int dy = img[(size_t)nextRow * stride + imageCol] - img[(size_t)prevRow * stride + imageCol] + 256;
+                float magnitude;
+                b = fhog_lut_entry(dx, dy, signedBinCount, interpolateBins, magnitude);
+            } else {               // getBinCoefficients<false> :144-172: the channel with the largest gradient magnitude
+                const uchar* up = img + (size_t)prevRow * stride + 3 * imageCol;
+                const uchar* down = img + (size_t)nextRow * stride + 3 * imageCol;
+                const uchar* left = img + (size_t)imageRow * stride + 3 * prevCol;
+                const uchar* right = img + (size_t)imageRow * stride + 3 * nextCol;
+                float m1, m2, m3;
+                const FhogCoeff b1 = fhog_lut_entry(right[0] - left[0] + 256, down[0] - up[0] + 256, signedBinCount, interpolateBins, m1);
+                const FhogCoeff b2 = fhog_lut_entry(right[1] - left[1] + 256, down[1] - up[1] + 256, signedBinCount, interpolateBins, m2);
+                const FhogCoeff b3 = fhog_lut_entry(right[2] - left[2] + 256, down[2] - up[2] + 256, signedBinCount, interpolateBins, m3);
+                if (m1 > m2) b = m1 > m3 ? b1 : b3;
+                else b = m2 > m3 ? b2 : b3;
+            }
             const FhogCoeff& rc = rowCoeff[imageRow];
             const FhogCoeff& cc = colCoeff[imageCol];
             if (interpolateCells) {   // addToSignedHistograms :173-205
@@ -711,9 +726,13 @@ int orc_spatial_pyramid_histogram(const uint8_t* img, int w, int h, int ch, int 
 }
 int orc_fhog(const uint8_t* img, int w, int h, int stride, int cellSize, int unsignedBinCount, int interpolateBins, int interpolateCells,
              float alpha, float* out, int* rows, int* cols) {
+    return orc_fhog_channels(img, w, h, 1, stride, cellSize, unsignedBinCount, interpolateBins, interpolateCells, alpha, out, rows, cols);
+}
+int orc_fhog_channels(const uint8_t* img, int w, int h, int channels, int stride, int cellSize, int unsignedBinCount, int interpolateBins,
+                      int interpolateCells, float alpha, float* out, int* rows, int* cols) {
     std::vector<float> v;
     int r, c;
-    int n = fhog_filter(img, w, h, stride, cellSize, unsignedBinCount, interpolateBins != 0, interpolateCells != 0, alpha, v, r, c);
+    int n = fhog_filter(img, w, h, stride, cellSize, unsignedBinCount, interpolateBins != 0, interpolateCells != 0, alpha, v, r, c, channels);
     if (rows) *rows = r;
     if (cols) *cols = c;
     if (out) std::memcpy(out, v.data(), sizeof(float) * v.size());

@@ -69,7 +69,7 @@ struct Svm {
 
 // filtering::FhogFilter on a gray image (orc_filters.cpp)
 int fhog_filter(const uchar* img, int w, int h, int stride, int cellSize, int unsignedBinCount, bool interpolateBins, bool interpolateCells,
-                float alpha, std::vector<float>& out, int& rowsOut, int& colsOut);
+                float alpha, std::vector<float>& out, int& rowsOut, int& colsOut, int channels = 1);
 
 // RvmClassifier (RvmClassifier.cpp:75-110) + ProbabilisticRvmClassifier (ProbabilisticRvmClassifier.cpp:52-64)
 struct Rvm {

@@ -220,15 +220,17 @@ def spatial_histogram(binimg, bins, cell, block, interpolate=False, concatenate=
                      int(concatenate), int(normalization))
 
 
-def fhog(gray, cell_size=8, unsigned_bins=9, interpolate_bins=False, interpolate_cells=True, alpha=0.2):
-    """filtering::FhogFilter::applyTo on a gray image: (rows, cols, 3 * unsigned_bins + 4) float32"""
-    gray = _c(gray, np.uint8)
-    h, w = gray.shape
+def fhog(img, cell_size=8, unsigned_bins=9, interpolate_bins=False, interpolate_cells=True, alpha=0.2):
+    """filtering::FhogFilter::applyTo on a gray (h, w) or BGR (h, w, 3) image: (rows, cols, 3 * unsigned_bins + 4) float32"""
+    img = _c(img, np.uint8)
+    h, w = img.shape[:2]
+    ch = 1 if img.ndim == 2 else img.shape[2]
     rows, cols = h // cell_size, w // cell_size
     out = np.zeros((rows, cols, 3 * unsigned_bins + 4), np.float32)
-    lib().orc_fhog.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
-                               C.c_void_p]
-    lib().orc_fhog(_p(gray), w, h, w, cell_size, unsigned_bins, int(interpolate_bins), int(interpolate_cells), alpha, _p(out), None, None)
+    lib().orc_fhog_channels.restype = C.c_int
+    lib().orc_fhog_channels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]
+    lib().orc_fhog_channels(_p(img), w, h, ch, w * ch, cell_size, unsigned_bins, int(interpolate_bins), int(interpolate_cells), alpha, _p(out), None, None)
     return out
 
 

@@ -595,10 +595,11 @@ def test_full_size_properties_config2_and_config3(oracle, capi, ctx, synth):
 
 @pytest.mark.parametrize("cell,ub,ib,ic", [(8, 9, False, True), (8, 9, True, True), (4, 9, False, False), (6, 6, True, False), (5, 18, False, True)])
 def test_fhog_filter_bit_exact(oracle, capi, ctx, frame640, cell, ub, ib, ic):
-    """filtering::FhogFilter on gray images and pyramid layers: descriptors bit-identical to the oracle (lane == cell walks its
-    pixels in the reference's scan order; the gradient LUT is built with the host libm on both sides)."""
+    """filtering::FhogFilter on gray (CV_8UC1) and BGR (CV_8UC3) images and on pyramid layers: descriptors bit-identical to the
+    oracle (lane == cell walks its pixels in the reference's scan order; the gradient LUT is built with the host libm on both sides)."""
     gray = oracle.bgr2gray(frame640)
-    for img in (gray, np.ascontiguousarray(gray[:97, :131]), np.ascontiguousarray(gray[:cell, :cell * 3]), np.ascontiguousarray(gray[:5, :300])):
+    for img in (gray, np.ascontiguousarray(gray[:97, :131]), np.ascontiguousarray(gray[:cell, :cell * 3]), np.ascontiguousarray(gray[:5, :300]),
+                frame640, np.ascontiguousarray(frame640[:97, :131]), np.ascontiguousarray(frame640[:cell, :cell * 3])):
         fo = oracle.fhog(img, cell, ub, ib, ic, 0.2)
         fg = capi.fhog(ctx, gray=img, cell_size=cell, unsigned_bins=ub, interpolate_bins=ib, interpolate_cells=ic, alpha=0.2)
         assert fg.shape == fo.shape

@@ -238,27 +238,37 @@ def test_rvm_cascade_restatement(oracle, synth):
     assert lv.max() == 2
 
 
-def test_fhog_against_numpy_restatement(oracle):
-    """FhogFilter + FhogAggregationFilter restatement against an independent vectorised numpy version (float64 accumulation,
-    so 1e-5): default parameters (cell 8, 9 unsigned bins, hard bin assignment, bilinear cell interpolation, alpha 0.2)."""
-    rng = np.random.default_rng(6)
-    img = rng.integers(0, 256, (67, 90)).astype(np.uint8)
-    img[20:40, 30:70] //= 3
-    cs, ub = 8, 9
+def _np_fhog(img, cs=8, ub=9):
+    """independent vectorised FHOG (float64 accumulation) of a gray (h, w) or BGR (h, w, 3) image: hard bin assignment,
+    bilinear cell interpolation, alpha 0.2; for BGR the channel with the largest gradient magnitude per pixel"""
     sb = 2 * ub
     rows, cols = img.shape[0] // cs, img.shape[1] // cs
-    I = img.astype(np.float64)
     H, W = rows * cs, cols * cs
     ys, xs = np.arange(H), np.arange(W)
-    dx = ((I[:H][:, np.minimum(xs + 1, img.shape[1] - 1)] - I[:H][:, np.maximum(xs - 1, 0)]).astype(np.float32) / np.float32(510))
-    dy = ((I[np.minimum(ys + 1, img.shape[0] - 1)][:, :W] - I[np.maximum(ys - 1, 0)][:, :W]).astype(np.float32) / np.float32(510))
-    mag = np.sqrt(dx * dx + dy * dy, dtype=np.float32).astype(np.float64)
+
+    def grads(I):
+        I = I.astype(np.float64)
+        dx = ((I[:H][:, np.minimum(xs + 1, img.shape[1] - 1)] - I[:H][:, np.maximum(xs - 1, 0)]).astype(np.float32) / np.float32(510))
+        dy = ((I[np.minimum(ys + 1, img.shape[0] - 1)][:, :W] - I[np.maximum(ys - 1, 0)][:, :W]).astype(np.float32) / np.float32(510))
+        return dx, dy, np.sqrt(dx * dx + dy * dy, dtype=np.float32)
+
+    if img.ndim == 2:
+        dx, dy, magf = grads(img)
+    else:
+        g = [grads(img[..., c]) for c in range(3)]
+        m1, m2, m3 = g[0][2], g[1][2], g[2][2]
+        pick = np.where(m1 > m2, np.where(m1 > m3, 0, 2), np.where(m2 > m3, 1, 2))   # FhogFilter.hpp:161-171
+        dx = np.choose(pick, [g[0][0], g[1][0], g[2][0]])
+        dy = np.choose(pick, [g[0][1], g[1][1], g[2][1]])
+        magf = np.choose(pick, [m1, m2, m3])
+    mag = magf.astype(np.float64)
     # orientation and hard bin assignment in float32 like the reference: with 18 bins the axis-aligned gradients sit exactly
     # on .5 boundaries, so the bin of a purely vertical gradient is decided by float rounding
     ori = np.arctan2(dy, dx)
     ori[ori < 0] += np.float32(2 * np.pi)
     b = (ori * np.float32(sb / np.float32(2 * np.pi)) + np.float32(0.5)).astype(int) % sb
     hist = np.zeros((rows, cols, sb))
+
     def coeff(n, cnt):
         real = (np.arange(n) + 0.5) / cs - 0.5
         i1 = np.floor(real).astype(int); i2 = i1 + 1
@@ -275,6 +285,7 @@ def test_fhog_against_numpy_restatement(oracle):
     u = hist[..., :ub] + hist[..., ub:]
     E = (u ** 2).sum(-1)
     Ep = np.pad(E, 1, mode="edge")
+
     def blk(dr, dc):
         return Ep[dr:dr + rows, dc:dc + cols] + Ep[dr:dr + rows, dc + 1:dc + 1 + cols] + Ep[dr + 1:dr + 1 + rows, dc:dc + cols] + Ep[dr + 1:dr + 1 + rows, dc + 1:dc + 1 + cols]
     n = [1.0 / np.sqrt(blk(dr, dc) + 1e-4) for dr in (0, 1) for dc in (0, 1)]
@@ -284,9 +295,27 @@ def test_fhog_against_numpy_restatement(oracle):
         out[..., :sb] += 0.5 * vs
         out[..., sb:sb + ub] += 0.5 * np.minimum(0.2, u * n[k][..., None])
         out[..., sb + ub + k] = 0.2357 * vs.sum(-1)
+    return out
+
+
+def test_fhog_against_numpy_restatement(oracle):
+    """FhogFilter + FhogAggregationFilter restatement against an independent vectorised numpy version (float64 accumulation,
+    so 1e-5): default parameters (cell 8, 9 unsigned bins, hard bin assignment, bilinear cell interpolation, alpha 0.2), on a
+    CV_8UC1 and on a CV_8UC3 image (per pixel the channel with the largest gradient magnitude)."""
+    rng = np.random.default_rng(6)
+    img = rng.integers(0, 256, (67, 90)).astype(np.uint8)
+    img[20:40, 30:70] //= 3
+    out = _np_fhog(img)
     got = oracle.fhog(img)
     assert got.shape == out.shape
     assert np.allclose(got, out, rtol=2e-4, atol=2e-5)
+    bgr = rng.integers(0, 256, (67, 90, 3)).astype(np.uint8)
+    bgr[10:30, 20:60, 1] //= 4
+    bgr[..., 2] = (bgr[..., 2].astype(int) * 3 // 4).astype(np.uint8)
+    gotc = oracle.fhog(bgr)
+    assert np.allclose(gotc, _np_fhog(bgr), rtol=2e-4, atol=2e-5)
+    assert not np.allclose(gotc, oracle.fhog(bgr[..., 0].copy()), atol=1e-3)
+    assert np.array_equal(oracle.fhog(np.repeat(img[:, :, None], 3, 2)), got)   # equal channels: ties fall through to channel 3
     for args in ((8, 9, False, False), (4, 6, False, True)):   # other cell sizes / bin counts, shape + range sanity
         f = oracle.fhog(img, *args)
         assert f.shape == (img.shape[0] // args[0], img.shape[1] // args[0], 3 * args[1] + 4)

@@ -209,7 +209,7 @@ def case_hist(rng, ctx):
 
 
 def case_fhog(rng, ctx):
-    gray = rand_frame(rng, channels=1)
+    gray = rand_frame(rng, channels=int(rng.choice([1, 3])))   # CV_8UC1 or CV_8UC3
     cell = int(rng.integers(2, 11))
     ub = int(rng.integers(2, 19))
     ib, ic = bool(rng.random() < 0.5), bool(rng.random() < 0.5)
