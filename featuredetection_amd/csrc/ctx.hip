@@ -55,6 +55,8 @@ int fd_ctx_create(int device_id, void* hip_stream, fd_ctx** out) {
 void fd_ctx_destroy(fd_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    ctx->scratch.clear();   // device buffers of the per-context scratch objects
     if (ctx->pinned.p) (void)hipHostFree(ctx->pinned.p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

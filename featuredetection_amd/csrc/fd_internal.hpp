@@ -5,7 +5,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
+#include <map>
+#include <memory>
 #include <string>
+#include <typeindex>
+#include <typeinfo>
 #include <vector>
 #include <stdexcept>
 #include "../../include/fd_hip.h"
@@ -27,7 +31,18 @@ struct fd_ctx {
     FdPinned pinned;
     hipStream_t aux = nullptr;   // second stream (created on first use): small follow-up work that must not queue behind ctx->stream
     hipStream_t pool[8] = {};   // batch jobs are spread over these (created on first use)
+    // per-context device scratch of the translation units (fd_scratch<T>): owned by the context, freed with it
+    std::map<std::type_index, std::shared_ptr<void>> scratch;
 };
+
+// the context's scratch object of type T (one per context and type, created on first use); contexts are not shared between
+// host threads, so no locking
+template <class T>
+static inline T& fd_scratch(fd_ctx* ctx) {
+    std::shared_ptr<void>& slot = ctx->scratch[std::type_index(typeid(T))];
+    if (!slot) slot = std::shared_ptr<void>(new T(), [](void* p) { delete static_cast<T*>(p); });
+    return *static_cast<T*>(slot.get());
+}
 
 struct FdError {
     int code;

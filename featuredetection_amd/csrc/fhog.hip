@@ -269,13 +269,7 @@ struct FhogScratch {
     fd_fhog_params lutFor;
     bool lutValid = false;
 };
-FhogScratch& scratch(fd_ctx* ctx) {
-    static thread_local std::vector<std::pair<fd_ctx*, std::unique_ptr<FhogScratch>>> tab;
-    for (auto& kv : tab)
-        if (kv.first == ctx) return *kv.second;
-    tab.emplace_back(ctx, std::unique_ptr<FhogScratch>(new FhogScratch()));
-    return *tab.back().second;
-}
+FhogScratch& scratch(fd_ctx* ctx) { return fd_scratch<FhogScratch>(ctx); }
 
 // gradient look-up table of FhogFilter::createGradientLut (FhogFilter.cpp:35-57), host libm like the reference
 void build_lut(fd_ctx* ctx, FhogScratch& S, const fd_fhog_params& fp) {

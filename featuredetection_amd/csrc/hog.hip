@@ -232,13 +232,7 @@ struct HogScratch {
     HogDev tabFor;        // parameters the tables were built for
     bool tabValid = false;
 };
-HogScratch& scratch(fd_ctx* ctx) {
-    static thread_local std::vector<std::pair<fd_ctx*, std::unique_ptr<HogScratch>>> tab;
-    for (auto& kv : tab)
-        if (kv.first == ctx) return *kv.second;
-    tab.emplace_back(ctx, std::unique_ptr<HogScratch>(new HogScratch()));
-    return *tab.back().second;
-}
+HogScratch& scratch(fd_ctx* ctx) { return fd_scratch<HogScratch>(ctx); }
 
 HogDev make_hogdev(const fd_hog_params* hp, int KPwant) {
     if (!hp) FD_THROW(FD_ERR_INVALID_ARGUMENT, "NULL hog parameters");

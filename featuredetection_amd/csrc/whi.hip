@@ -180,13 +180,7 @@ struct WhiScratch {
     bool valid = false;
     WhiDev dev;
 };
-WhiScratch& scratch(fd_ctx* ctx) {
-    static thread_local std::vector<std::pair<fd_ctx*, std::unique_ptr<WhiScratch>>> tab;
-    for (auto& kv : tab)
-        if (kv.first == ctx) return *kv.second;
-    tab.emplace_back(ctx, std::unique_ptr<WhiScratch>(new WhiScratch()));
-    return *tab.back().second;
-}
+WhiScratch& scratch(fd_ctx* ctx) { return fd_scratch<WhiScratch>(ctx); }
 
 // twiddles + whitening filter (same expressions as oracle/orc_filters.cpp whi_tables: both sides evaluate
 // std::polar / powf / expf with the host libm)
