@@ -141,6 +141,14 @@ static inline hipStream_t fd_pool_stream(fd_ctx* ctx, int i) {
     if (!s) HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     return s;
 }
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): `done` is the caller's static per-kernel bit mask
+static inline void fd_allow_lds(fd_ctx* ctx, const void* kernel, int bytes, uint64_t& done) {
+    const uint64_t bit = 1ull << (ctx->device & 63);
+    if (done & bit) return;
+    HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done |= bit;
+}
+
 struct FdStreamSwap {   // temporarily redirects everything that launches on ctx->stream
     fd_ctx* c;
     hipStream_t keep;

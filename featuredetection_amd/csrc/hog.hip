@@ -305,11 +305,8 @@ void launch_hog(fd_ctx* ctx, const fd_pyramid* p, const HogWinTable& wt, const H
     const HogTables tb = hog_tables(ctx, S, hd);
     const size_t lds = hog_lds_bytes(hd, FRAG);
     if (lds > 160 * 1024) FD_THROW(FD_ERR_INVALID_ARGUMENT, "HOG feature vector too long for the LDS tile (%d floats)", hd.F);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[FRAG]) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_hog_tile<FRAG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[FRAG] = true;
-    }
+    static uint64_t lds_allowed = 0;   // per instantiation
+    fd_allow_lds(ctx, (const void*)k_hog_tile<FRAG>, 160 * 1024, lds_allowed);
     const int C = hd.rows * hd.cols, WPW = 64 / C, npass = (32 + WPW - 1) / WPW;
     const int64_t nitems = ((npad + 31) / 32) * npass;
     const int grid = (int)std::min<int64_t>((nitems + 3) / 4, (int64_t)ctx->num_cus * 16);
@@ -900,11 +897,8 @@ int64_t run_hist_features(fd_ctx* ctx, fd_pyramid* p, const fd_hist_params* hp, 
     HIP_CHECK(hipSetDevice(ctx->device));
     const size_t lds = hist_lds_bytes(hd);
     if (lds > 160 * 1024) FD_THROW(FD_ERR_INVALID_ARGUMENT, "histogram feature vector too long for the LDS (%d floats)", hd.F);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_hist_features, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static uint64_t lds_allowed = 0;
+    fd_allow_lds(ctx, (const void*)k_hist_features, 160 * 1024, lds_allowed);
     HistTables tb;
     hist_tables(ctx, S, hd, tb);
     S.feat.reserve(sizeof(float) * (size_t)N * hd.F);

@@ -504,12 +504,9 @@ void fd_svm_rbf_mfma_launch(fd_ctx* ctx, const fd_svm* m, const float* xFrag, co
         const int ngroups = m->dev.nsv_pad / 256;
         mm->dist.reserve(sizeof(double) * (size_t)ngroups * 8 * npadRows);
         const size_t ldsBytes = (size_t)2 * (KP / 8) * 256 * 4 + 8 * 64 * 4;
-        static bool attr2 = false;
-        if (!attr2) {
-            HIP_CHECK(hipFuncSetAttribute((const void*)k_svm_rbf_mfma_svs<41>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            HIP_CHECK(hipFuncSetAttribute((const void*)k_svm_rbf_mfma_svs<42>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr2 = true;
-        }
+        static uint64_t lds41 = 0, lds42 = 0;
+        fd_allow_lds(ctx, (const void*)k_svm_rbf_mfma_svs<41>, 160 * 1024, lds41);
+        fd_allow_lds(ctx, (const void*)k_svm_rbf_mfma_svs<42>, 160 * 1024, lds42);
         const int gx = (int)std::min<int64_t>(ntiles, std::max(1, ctx->num_cus / ngroups));
         if (KP == 328)
             hipLaunchKernelGGL(k_svm_rbf_mfma_svs<41>, dim3(gx, ngroups), dim3(512), ldsBytes, ctx->stream, xFrag, xx, m->dev,
@@ -524,11 +521,8 @@ void fd_svm_rbf_mfma_launch(fd_ctx* ctx, const fd_svm* m, const float* xFrag, co
     }
     const size_t ldsBytes = fd_svm_rbf_lds_bytes(KP);
     if (ldsBytes > 160 * 1024) FD_THROW(FD_ERR_INVALID_ARGUMENT, "feature length %d too large for the MFMA SVM kernel", m->dev.dim);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_svm_rbf_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static uint64_t lds_allowed = 0;
+    fd_allow_lds(ctx, (const void*)k_svm_rbf_mfma, 160 * 1024, lds_allowed);
     const int64_t blocks = (npatches + RB_BM - 1) / RB_BM;
     hipLaunchKernelGGL(k_svm_rbf_mfma, dim3((unsigned)blocks), dim3(RB_THREADS), ldsBytes, ctx->stream, xFrag, xx, m->dev,
                        (float)(-m->dev.p0), npatches, out);

@@ -233,11 +233,8 @@ size_t lds_bytes(int w, int h) {
 template <bool EQ_ONLY>
 void launch(fd_ctx* ctx, const uint8_t* arena, const WhiWinTable& wt, const WhiDev& d, float* feat, uint8_t* eqOut) {
     const size_t lds = lds_bytes(d.w, d.h);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[EQ_ONLY]) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_whi<EQ_ONLY>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        attr_set[EQ_ONLY] = true;
-    }
+    static uint64_t lds_allowed = 0;   // per instantiation
+    fd_allow_lds(ctx, (const void*)k_whi<EQ_ONLY>, 64 * 1024, lds_allowed);
     const int grid = (int)std::min<int64_t>(wt.total, (int64_t)ctx->num_cus * 16);
     hipLaunchKernelGGL(k_whi<EQ_ONLY>, dim3(grid), dim3(64), lds, ctx->stream, arena, wt, d, feat, eqOut);
     HIP_CHECK(hipGetLastError());
