@@ -444,7 +444,8 @@ def fhog(ctx, gray=None, pyramid=None, layer=0, cell_size=8, unsigned_bins=9, in
     else:
         info = pyramid.layers()[layer]
         h, w = info["h"], info["w"]
-    out = np.zeros((h // cell_size, w // cell_size, 3 * unsigned_bins + 4), np.float32)
+    cs = max(cell_size, 1)   # invalid parameters are reported by the library
+    out = np.zeros((h // cs, w // cs, max(3 * unsigned_bins + 4, 0)), np.float32)
     if gray is not None:
         ch = 1 if gray.ndim == 2 else gray.shape[2]
         if ch == 1:
@@ -502,7 +503,7 @@ def nms_iou(boxes, overlap_threshold, maximum_type=0):
     cnt = C.c_int()
     rc = lib().fd_nms_iou(_ptr(boxes), len(boxes), overlap_threshold, maximum_type, _ptr(out), C.byref(cnt))
     if rc != 0:
-        raise RuntimeError("fd_nms_iou failed: %d" % rc)
+        raise FdError(rc, "fd_nms_iou: invalid arguments (overlap threshold %g, maximum type %d)" % (overlap_threshold, maximum_type))
     return out[:cnt.value]
 
 

@@ -734,3 +734,37 @@ def test_errors_are_reported_not_swallowed(capi, ctx):
     p.update(np.zeros((8, 8), np.uint8))
     assert p.window_count(20, 20, 1, 1) == 0  # image smaller than the patch: no windows, no error
     p.close()
+
+
+def test_error_paths_of_the_later_entry_points(capi, ctx, synth):
+    """invalid arguments of the FHOG / aggregated / NMS / RVM / histogram entry points come back as status codes + messages"""
+    gray = np.zeros((40, 40), np.uint8)
+    with pytest.raises(capi.FdError) as e:
+        capi.fhog(ctx, gray=np.zeros((40, 40, 2), np.uint8))   # neither CV_8UC1 nor CV_8UC3
+    assert e.value.code == capi.FD_ERR_INVALID_ARGUMENT and "CV_8UC" in str(e.value)
+    with pytest.raises(capi.FdError):
+        capi.fhog(ctx, gray=gray, cell_size=0)
+    with pytest.raises(capi.FdError):
+        capi.fhog(ctx, gray=gray, unsigned_bins=0)
+    with pytest.raises(capi.FdError):
+        capi.fhog(ctx, gray=gray, unsigned_bins=19)    # more than 36 signed bins: backend limit, reported
+    with pytest.raises(capi.FdError):
+        capi.fhog(ctx, gray=gray, alpha=0.0)
+    assert capi.fhog(ctx, gray=np.zeros((5, 40), np.uint8)).shape == (0, 5, 31)   # image lower than a cell: empty descriptor map
+    wts = np.zeros((4, 4, 31), np.float32)
+    with pytest.raises(capi.FdError):
+        capi.Aggregated(ctx, wts, 0.0, 0.0, octave_layers=0)
+    det = capi.Aggregated(ctx, wts, 0.0, 0.0, cell_size=8)
+    with pytest.raises(capi.FdError):
+        det.detect(np.zeros((33, 33, 3), np.uint8))   # one pyramid layer only: the score pyramid cannot estimate its lambdas
+    det.close()
+    boxes = np.zeros(3, capi.BOX_DTYPE)
+    boxes["w"] = boxes["h"] = 10
+    with pytest.raises(capi.FdError):
+        capi.nms_iou(boxes, 1.5)   # overlap threshold above 1: no cluster ever forms, the reference would spin
+    pg = capi.Pyramid(ctx, octave_layers=2, min_scale=0.5, max_scale=1.0)
+    pg.set_layer_filter(1, bins=9)
+    pg.update(synth.make_frame(96, 80, seed=1))
+    with pytest.raises((capi.FdError, ValueError)):
+        capi.extract_hist(ctx, pg, capi.hist_params(kind=0, pw=20, ph=20, bins=9, cell=5, block=9))   # block larger than the cell grid
+    pg.close()
