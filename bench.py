@@ -29,10 +29,10 @@ PEAK_HBM_GBS = 8000.0
 
 def cpu_baseline_hog_svm(frame2, model, seconds_hint=20):
     """Oracle ("port" of the reference CPU path, single thread like the reference) on a bounded sample:
-    a 224x168 crop of the same frame recipe, same pyramid/window/HOG/SVM parameters."""
+    a 416x312 frame of the same recipe (about 12 s of CPU work), same pyramid/window/HOG/SVM parameters."""
     from oracle import pyoracle as O
     from featuredetection_amd import synth
-    crop = synth.make_frame(224, 168, seed=20260927)
+    crop = synth.make_frame(416, 312, seed=20260927)
     p = O.Pyramid(octave_layers=5, min_scale=1 / 16, max_scale=1.0)
     p.set_layer_filter(1, bins=9)
     s = O.Svm(model)
@@ -41,7 +41,7 @@ def cpu_baseline_hog_svm(frame2, model, seconds_hint=20):
     _, dist, _ = O.sliding_hog_svm(p, s, 20, 20, 2, 2, 9, 5, 2)
     dt = time.perf_counter() - t0
     return dict(value=len(dist) / dt / 1e6, unit="Mpatches/s", cores=1, kind="port",
-                sample="224x168 crop, %d windows, %.1f s, oracle -O2 single thread (pyramid+HOG+RBF-SVM 1024 SV)" % (len(dist), dt))
+                sample="416x312 frame, %d windows, %.1f s, oracle -O2 single thread (pyramid+HOG+RBF-SVM 1024 SV)" % (len(dist), dt))
 
 
 def cpu_baseline_wvm(frame, wvm, svm):
