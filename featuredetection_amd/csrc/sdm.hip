@@ -405,15 +405,27 @@ __global__ __launch_bounds__(64) void k_sdm_regress(const float* __restrict__ D,
     }
     const bool iok = i < B;
     const float* __restrict__ drow = D + (size_t)(iok ? i : 0) * F;
-    for (int k = k0; k < k1; k += 4) {
-        const int kk = k + kq;
-        const bool kok = kk < k1;
-        const double a = (iok && kok) ? (double)drow[kk] : 0.0;
-        double b[RG_NT];
+    // RG_U k-steps per iteration: their loads are issued together, then the dependent MFMA chains run
+    constexpr int RG_U = 4;
+    for (int k = k0; k < k1; k += 4 * RG_U) {
+        float a[RG_U], b[RG_U][RG_NT];
 #pragma unroll
-        for (int t = 0; t < RG_NT; ++t) b[t] = (jok[t] && kok) ? (double)R[(size_t)kk * N + j[t]] : 0.0;
+        for (int u = 0; u < RG_U; ++u) {
+            const int kk = k + 4 * u + kq;
+            const bool kok = kk < k1;
+            const int kc = kok ? kk : k0;   // in-range address for the masked lanes
+            a[u] = drow[kc];
+            a[u] = (iok && kok) ? a[u] : 0.f;
 #pragma unroll
-        for (int t = 0; t < RG_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[t], acc[t], 0, 0, 0);
+            for (int t = 0; t < RG_NT; ++t) {
+                const float v = R[(size_t)kc * N + (jok[t] ? j[t] : 0)];
+                b[u][t] = (jok[t] && kok) ? v : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RG_U; ++u)
+#pragma unroll
+            for (int t = 0; t < RG_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a[u], (double)b[u][t], acc[t], 0, 0, 0);
     }
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
