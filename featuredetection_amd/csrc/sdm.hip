@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cstring>
 #include <memory>
+#include <type_traits>
 
 namespace {
 
@@ -43,26 +44,29 @@ struct DescLds {   // per-wave views carved out of dynamic LDS
     float *wx1, *wx2;
     int* binx;
     float *hog, *norm, *feat;
-    unsigned long long* masks;    // [2*nori][ih]: bit x set iff pixel (y, x) voted for that orientation
+    void* masks;                  // [2*nori][ih] words (32 bits SMALL, else 64): bit x set iff pixel (y, x) voted for that orientation
+    float* wsel;                  // [max(hogW, hogH)][m]: interpolation weight of column / row p towards cell column / row c
     double *fac, *hc;             // block factors [ncell][4], clamped undirected terms [ncell*nori][4] (reuse the mask region)
     unsigned long long* colmask;  // [hogW]: columns x contributing to cell column cx
     int* yrange;                  // [hogH][2]: first/last+1 row contributing to cell row cy
 };
 constexpr int SDM_SMALL_ITERS = 16;   // working images of up to 64 * 16 pixels keep their gradients in registers for one sync
 __host__ __device__ inline int align16i(int v) { return (v + 15) & ~15; }
-__host__ __device__ inline bool desc_small(int iw, int ih) { return iw * ih <= 64 * SDM_SMALL_ITERS; }
+__host__ __device__ inline bool desc_small(int iw, int ih) { return iw * ih <= 64 * SDM_SMALL_ITERS && iw <= 32; }
 __host__ __device__ inline int desc_region_img(int iw, int ih, int ncell, int dim) {
     const int a = align16i(iw * ih * 4), b = align16i(ncell * dim * 4);
     return a > b ? a : b;
 }
-__host__ __device__ inline int desc_region_masks(int ih, int ncell, int nori) {
-    const int a = align16i(2 * nori * ih * 8), b = align16i(ncell * 4 * 8) + align16i(ncell * nori * 4 * 8);
-    return a > b ? a : b;   // (also holds the six resize tables of ih entries: 24 * ih <= 16 * nori * ih)
+__host__ __device__ inline int desc_region_masks(int iw, int ih, int ncell, int nori) {
+    const int a = align16i(2 * nori * ih * (desc_small(iw, ih) ? 4 : 8)), b = align16i(ncell * 4 * 8) + align16i(ncell * nori * 4 * 8);
+    const int c = align16i(6 * (iw > ih ? iw : ih) * 4);   // the six resize tables
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
-__host__ __device__ inline int desc_lds_bytes(int iw, int ih, int ncell, int nori, int dim) {
+__host__ __device__ inline int desc_lds_bytes(int iw, int ih, int ncell, int nori, int dim, int hogMax) {
     const int m = iw > ih ? iw : ih;
     return desc_region_img(iw, ih, ncell, dim) + (desc_small(iw, ih) ? 0 : align16i(iw * ih * 4)) + 3 * align16i(m * 4) +
-           align16i(ncell * nori * 2 * 4) + align16i(ncell * 4) + desc_region_masks(ih, ncell, nori) + align16i(m * 8) + align16i(m * 2 * 4);
+           align16i(ncell * nori * 2 * 4) + align16i(ncell * 4) + desc_region_masks(iw, ih, ncell, nori) + align16i(m * 8) + align16i(m * 2 * 4) +
+           align16i(hogMax * m * 4);
 }
 
 __device__ __forceinline__ void wave_sync() {
@@ -132,6 +136,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const int ncell = hogW * hogH;
     const int npix = iw * ih;
     const int m_ = iw > ih ? iw : ih;
+    using mask_t = typename std::conditional<SMALL, unsigned int, unsigned long long>::type;   // SMALL: iw <= 32
     // i / iw for 0 <= i < 4096, iw <= 64 (exhaustively checked): three VALU instead of an integer division
     const float invW = 1.0f / (float)iw;
     auto divw = [&](int i) { return (int)(((float)i + 0.5f) * invW); };
@@ -147,11 +152,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         S.binx = (int*)b; b += align16i(m * 4);
         S.hog = (float*)b; b += align16i(ncell * nori * 2 * 4);
         S.norm = (float*)b; b += align16i(ncell * 4);
-        S.masks = (unsigned long long*)b; S.fac = (double*)b; S.hc = (double*)(b + align16i(ncell * 4 * 8));
-        b += desc_region_masks(ih, ncell, nori);
+        S.masks = (void*)b; S.fac = (double*)b; S.hc = (double*)(b + align16i(ncell * 4 * 8));
+        b += desc_region_masks(iw, ih, ncell, nori);
         S.colmask = (unsigned long long*)b; b += align16i(m * 8);
-        S.yrange = (int*)b;
+        S.yrange = (int*)b; b += align16i(m * 2 * 4);
+        S.wsel = (float*)b;
     }
+    mask_t* const masks = (mask_t*)S.masks;
+    const int hogMax = hogW > hogH ? hogW : hogH;
     // ---- per-wave tables that only depend on the geometry.  Column/row interpolation: hx = (x + 0.5) / cellSize - 0.5
     // (hog.c:697-704); rows use the same table
     for (int x = lane; x < max(iw, ih); x += 64) {
@@ -163,6 +171,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         S.binx[x] = b; S.wx1[x] = w1; S.wx2[x] = w2;
     }
     wave_sync();
+    for (int i = lane; i < hogMax * m_; i += 64) {   // weight of pixel column / row p towards cell column / row c
+        const int c = i / m_, p_ = i - c * m_;
+        S.wsel[i] = S.binx[p_] == c ? S.wx1[p_] : S.wx2[p_];
+    }
     // per cell column: bit mask of the interior columns that vote into it; per cell row: row range
     for (int c = lane; c < hogW; c += 64) {
         unsigned long long mk = 0ull;
@@ -230,7 +242,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             }
         }
         for (int i = lane; i < ncell * nori * 2; i += 64) S.hog[i] = 0.f;
-        for (int i = lane; i < 2 * nori * ih; i += 64) S.masks[i] = 0ull;
+        for (int i = lane; i < 2 * nori * ih; i += 64) masks[i] = (mask_t)0;
         wave_sync();
         // ---- gradient magnitude and hard orientation assignment per interior pixel (hog.c:612-665)
         auto gradient = [&](int i, float& gout) -> int {   // returns the orientation bin or -1, -2 for border pixels
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 const int i = lane + 64 * t;
                 if (ob[t] > -2) {
                     S.grad[i] = gr[t];
-                    if (ob[t] >= 0) { const int y = divw(i); atomicOr(&S.masks[ob[t] * ih + y], 1ull << (i - y * iw)); }
+                    if (ob[t] >= 0) { const int y = divw(i); atomicOr(&masks[ob[t] * ih + y], (mask_t)1 << (i - y * iw)); }
                 }
             }
         } else {
@@ -288,7 +300,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 const int b0 = gradient(i, g);
                 if (b0 > -2) {
                     S.grad[i] = g;
-                    if (b0 >= 0) { const int y = divw(i); atomicOr(&S.masks[b0 * ih + y], 1ull << (i - y * iw)); }
+                    if (b0 >= 0) { const int y = divw(i); atomicOr(&masks[b0 * ih + y], (mask_t)1 << (i - y * iw)); }
                 }
             }
         }
@@ -298,18 +310,20 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         for (int e = lane; e < ncell * nori * 2; e += 64) {
             const int o = e / ncell, c = e - o * ncell;
             const int cy = c / hogW, cx = c - cy * hogW;
-            const unsigned long long cm = S.colmask[cx];
+            const mask_t cm = (mask_t)S.colmask[cx];
             const int ylo = S.yrange[2 * cy], yhi = S.yrange[2 * cy + 1];
+            const float* __restrict__ wxs = S.wsel + cx * m_;
+            const float* __restrict__ wys = S.wsel + cy * m_;
             float acc = 0.f;
             for (int y = ylo; y < yhi; ++y) {
-                unsigned long long mk = S.masks[o * ih + y] & cm;
+                mask_t mk = masks[o * ih + y] & cm;
                 if (!mk) continue;
-                const float wy = S.binx[y] == cy ? S.wx1[y] : S.wx2[y];
+                const float wy = wys[y];
+                const float* __restrict__ grow = S.grad + y * iw;
                 while (mk) {
-                    const int x = __ffsll((long long)mk) - 1;
+                    const int x = (SMALL ? __ffs((int)mk) : __ffsll((long long)mk)) - 1;
                     mk &= mk - 1;
-                    const float wx = S.binx[x] == cx ? S.wx1[x] : S.wx2[x];
-                    acc = acc + S.grad[y * iw + x] * wx * wy;
+                    acc = acc + grow[x] * wxs[x] * wy;
                 }
             }
             S.hog[e] = acc;  // layout hog[x + y*hogW + o*hogStride] == e
@@ -486,7 +500,7 @@ void fill_desc_params(DescParams& p, int W, int H, int L, bool adaptive, int var
         p.oX[o] = (float)std::cos(angle);
         p.oY[o] = (float)std::sin(angle);
     }
-    p.ldsPerWave = desc_lds_bytes(p.iw, p.ih, p.hogW * p.hogH, p.nori, p.dim);
+    p.ldsPerWave = desc_lds_bytes(p.iw, p.ih, p.hogW * p.hogH, p.nori, p.dim, p.hogW > p.hogH ? p.hogW : p.hogH);
     if (2 * p.ldsPerWave > 64 * 1024) FD_THROW(FD_ERR_INVALID_ARGUMENT, "VlHog: patch too large for the LDS budget");
 }
 
