@@ -639,6 +639,238 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
 }
 
+// ---- stage A, four windows per wavefront -----------------------------------------------------------
+// Phase timing of the pair kernel: HistEq64 26 %, integral images 13 %, the filter loop 60 %, and the filter loop is bound by
+// instruction issue: the wave-uniform part of a filter (the fp64 grey-value chain, exp, thresholds, prefetch, control:
+// ~190 of ~250 instructions) runs once per instruction for only two windows.  Here a wavefront owns four consecutive
+// windows: the fixed part runs twice in the pair layout above (lanes 0-31 / 32-63 = the two windows of a pair, lane ==
+// column) and leaves four integral images in LDS; in the filter loop the rect sums still run in the pair layout (lane ==
+// rect, 32 rects per pass, once per pair, the level record loaded once), but everything wave-uniform runs in a quarter
+// layout: lanes 16q..16q+15 belong to window q, lane r of a quarter holds the running sum of cascade level r
+// (WVM_LCAP == 16).  Only used for cascades that continue in k_wvm_deep (numUsed > WVM_LCAP), so no window can turn
+// positive here and the equalised patches need not be kept.
+template <int PW_, int PH_>
+struct __attribute__((aligned(16))) QuadLds {
+    unsigned int hist[2][64];   // histograms of the current pair, then its two LUTs
+    int sv[4][WVM_MAX_VALS];
+    float u[4][32];             // u_kernel_eval of each window
+    unsigned int ii[4][PW_ * PH_];
+};
+
+constexpr int WVM_QUAD_WAVES = 2;   // wavefronts per workgroup (LDS granularity: 24x24 -> 7 workgroups per CU)
+
+template <int PW_, int PH_, bool RAW>
+__global__ __launch_bounds__(64 * WVM_QUAD_WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_wvm_cascade4(const uint8_t* __restrict__ arena,
+                                                                                                                   WinTable wt, WvmDev m, CascadeOut o) {
+    static_assert(PW_ > 0 && PW_ <= 32, "pair layout needs a compile-time width <= 32");
+    static_assert(WVM_LCAP == 16, "quarter layout: one lane per cascade level of stage A");
+    __shared__ QuadLds<PW_, PH_> lds[WVM_QUAD_WAVES];
+    __shared__ int64_t sFirst[WVM_MAX_LAYERS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    QuadLds<PW_, PH_>& L = lds[wave];
+    const int half = lane >> 5, c = lane & 31;   // pair layout
+    const int q = lane >> 4, r = lane & 15;      // quarter layout
+    const bool colok = c < PW_;
+    constexpr int d = PW_ * PH_;
+    const int64_t nwaves = (int64_t)gridDim.x * WVM_QUAD_WAVES;
+    const int F = m.numFilters;
+    const int nA = min(m.numUsed, WVM_LCAP);
+    const int halfBase = lane & 32, quarterBase = lane & 48;
+
+    if (!RAW) {
+        if (threadIdx.x < WVM_MAX_LAYERS) sFirst[threadIdx.x] = (int)threadIdx.x < wt.n ? wt.l[threadIdx.x].first : INT64_MAX;
+        __syncthreads();
+    }
+    L.sv[q][r] = 0;
+    wave_sync();
+
+    const int64_t nquads = (wt.total + 3) >> 2;
+    for (int64_t quad = (int64_t)blockIdx.x * WVM_QUAD_WAVES + wave; quad < nquads; quad += nwaves) {
+        // level-0 model data: requested now, consumed after the fixed part
+        uint4 lv = m.lvlRec[c];
+        WvmLevelHdr hd = m.lvlHdr[0];
+        float w = m.wT[r];
+
+        float sxxP0 = 0.f, sxxP1 = 0.f;
+        int sxtP0 = 0, sxtP1 = 0;
+#pragma unroll 1
+        for (int p = 0; p < 2; ++p) {
+            // ---- fixed part of the pair (windows 4*quad + 2p, + 2p + 1), as in k_wvm_cascade2
+            const int64_t wid0 = 4 * quad + 2 * p, wid1 = wid0 + 1;
+            const bool has0 = wid0 < wt.total, has1 = wid1 < wt.total;
+            int stride0, stride1;
+            const uint8_t* src0 = wvm_locate<RAW>(arena, wt, sFirst, has0 ? wid0 : 4 * quad, lane, PW_, d, stride0);
+            const uint8_t* src1 = src0;
+            stride1 = stride0;
+            if (has1) src1 = wvm_locate<RAW>(arena, wt, sFirst, wid1, lane, PW_, d, stride1);
+            const uint8_t* src = half ? src1 : src0;
+            const int stride = half ? stride1 : stride0;
+            unsigned int px[PH_];
+            {
+                const uint8_t* sp = src + (colok ? c : 0);
+#pragma unroll
+                for (int rr = 0; rr < PH_; ++rr) px[rr] = sp[(size_t)rr * stride];
+            }
+            if (!RAW) {
+                L.hist[0][lane] = 0;
+                L.hist[1][lane] = 0;
+                wave_sync();
+                if (colok) {
+#pragma unroll
+                    for (int rr = 0; rr < PH_; ++rr) atomicAdd(&L.hist[half][px[rr] >> 2], 1u);
+                }
+                wave_sync();
+                const float pdfA = (float)L.hist[0][lane] * m.stretch, pdfB = (float)L.hist[1][lane] * m.stretch;
+                float xA = pdfA, xB = pdfB;
+#pragma unroll
+                for (int t = 1; t < 64; ++t) {
+                    const float sa = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(xA), DPP_WAVE_SHR1, 0xf, 0xf, true));
+                    const float sb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(xB), DPP_WAVE_SHR1, 0xf, 0xf, true));
+                    xA = sa + pdfA;
+                    xB = sb + pdfB;
+                }
+                wave_sync();
+                L.hist[0][lane] = (unsigned int)(unsigned char)floor((double)xA + 0.5);
+                L.hist[1][lane] = (unsigned int)(unsigned char)floor((double)xB + 0.5);
+                wave_sync();
+#pragma unroll
+                for (int rr = 0; rr < PH_; ++rr) {
+                    const unsigned int e = L.hist[half][px[rr] >> 2];
+                    px[rr] = colok ? e : 0u;
+                }
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < PH_; ++rr) px[rr] = colok ? px[rr] : 0u;
+            }
+            int colsum = 0;
+            float sxxc = 0.f;
+            unsigned int* iiw = L.ii[2 * p + half];
+#pragma unroll
+            for (int rr = 0; rr < PH_; ++rr) {
+                colsum += scan_half((int)px[rr]);
+                if (colok) iiw[rr * PW_ + c] = (unsigned int)colsum;
+                const float qf = (float)scan_half((int)(px[rr] * px[rr]));
+                sxxc = rr == 0 ? qf : sxxc + qf;
+            }
+            const float sxxH = __int_as_float(__builtin_amdgcn_ds_bpermute((lane | 31) << 2, __float_as_int(sxxc)));
+            const int sxtH = __builtin_amdgcn_ds_bpermute((halfBase + PW_ - 1) << 2, colsum);
+            if (p == 0) { sxxP0 = sxxH; sxtP0 = sxtH; }
+            else { sxxP1 = sxxH; sxtP1 = sxtH; }
+            wave_sync();
+        }
+        // ---- quarter layout: window q of the quad comes from half q & 1 of pair q >> 1
+        const int64_t myWid = 4 * quad + q;
+        const bool valid = myWid < wt.total;
+        float sxx;
+        int sx_total;
+        {
+            const float a0 = readlane_f(sxxP0, 0), a1 = readlane_f(sxxP0, 32), a2 = readlane_f(sxxP1, 0), a3 = readlane_f(sxxP1, 32);
+            const int b0 = __builtin_amdgcn_readlane(sxtP0, 0), b1 = __builtin_amdgcn_readlane(sxtP0, 32);
+            const int b2 = __builtin_amdgcn_readlane(sxtP1, 0), b3 = __builtin_amdgcn_readlane(sxtP1, 32);
+            sxx = q == 0 ? a0 : (q == 1 ? a1 : (q == 2 ? a2 : a3));
+            sx_total = q == 0 ? b0 : (q == 1 ? b1 : (q == 2 ? b2 : b3));
+        }
+        L.u[q][r] = 0.f;
+        L.u[q][r + 16] = 0.f;
+        wave_sync();
+
+        // ---- first levels of the cascade, the four windows in lockstep
+        float Pb = m.negBias;   // lane r of each quarter: running sum of level r
+        bool alive = valid, deep = false;
+        int level = 0, n = 0;
+        float fout = 0.f, thr = 0.f;
+        for (int k = 0;; ++k) {
+            const int kn = min(k + 1, nA - 1);
+            const uint4 lvN = m.lvlRec[(size_t)kn * 64 + c];
+            const WvmLevelHdr hdN = m.lvlHdr[kn];
+            const float wN = m.wT[(size_t)kn * F + r];
+            // rect sums in the pair layout: 32 rects per pass, the rect record loaded once for both pairs
+            const unsigned long long aliveBits = __ballot(alive);
+            const bool aliveP0 = (aliveBits >> (16 * half)) & 1, aliveP1 = (aliveBits >> (32 + 16 * half)) & 1;
+            for (int rb = 0; rb < hd.nrects; rb += 32) {
+                unsigned int rc, vt;
+                if (rb == 0) { rc = lv.x; vt = lv.y; }
+                else if (rb < 64) { const uint4 t = m.lvlRec[(size_t)k * 64 + rb + c]; rc = t.x; vt = t.y; }
+                else { const int ri = m.rectBegin[k] + min(rb + c, hd.nrects - 1); rc = m.rects[ri]; vt = m.rectV[ri]; }
+                if (rb + c < hd.nrects) {
+                    const int x1 = rc & 255, y1 = (rc >> 8) & 255, x2 = (rc >> 16) & 255, y2 = rc >> 24;
+                    const int i22 = y2 * PW_ + x2, i21 = y2 * PW_ + x1 - 1, i12 = (y1 - 1) * PW_ + x2, i11 = (y1 - 1) * PW_ + x1 - 1;
+                    if (aliveP0) {
+                        const unsigned int* ii = L.ii[half];
+                        int s = (int)ii[i22];
+                        if (x1 > 0) s -= (int)ii[i21];
+                        if (y1 > 0) s -= (int)ii[i12];
+                        if (x1 > 0 && y1 > 0) s += (int)ii[i11];
+                        atomicAdd(&L.sv[half][vt], s);
+                    }
+                    if (aliveP1) {
+                        const unsigned int* ii = L.ii[2 + half];
+                        int s = (int)ii[i22];
+                        if (x1 > 0) s -= (int)ii[i21];
+                        if (y1 > 0) s -= (int)ii[i12];
+                        if (x1 > 0 && y1 > 0) s += (int)ii[i11];
+                        atomicAdd(&L.sv[2 + half][vt], s);
+                    }
+                }
+            }
+            wave_sync();
+            // the reference's scalar chain (WvmClassifier.cpp:308-346), once per quarter
+            const int* sv = L.sv[q];
+            const double valL = __hiloint2double((int)lv.w, (int)lv.z);
+            double sum_xp = 0.0;
+            int sumv0 = sx_total;
+            for (int v = 1; v < hd.cntval; ++v) {
+                const int s = sv[v];
+                sumv0 -= s;
+                const double prod = (double)s * readlane_d(valL, v);
+                sum_xp = sum_xp + prod;
+            }
+            const double t0 = (double)sumv0 * readlane_d(valL, 0);
+            sum_xp = sum_xp + t0;
+            sum_xp = sum_xp + (double)L.u[q][n];
+            const float unew = (float)sum_xp;
+            wave_sync();
+            L.sv[q][r] = 0;
+            if (r == 0) L.u[q][n] = unew;
+            double norm = (double)sxx;
+            norm = norm - 2 * sum_xp;
+            norm = norm + hd.pp;
+            const float Kk = (float)exp((double)m.negBasis * norm);
+            {
+                const float t = w * Kk;   // weights above the diagonal are stored as 0
+                Pb = Pb + t;
+            }
+            const float fk = __int_as_float(__builtin_amdgcn_ds_bpermute((quarterBase + k) << 2, __float_as_int(Pb)));
+            if (alive) {
+                if (!(fk >= hd.thr && k + 1 < m.numUsed)) {   // leaves the cascade here
+                    level = k; fout = fk; thr = hd.thr;
+                    alive = false;
+                } else if (k + 1 == nA) {                     // survives stage A: finished by k_wvm_deep
+                    deep = true;
+                    alive = false;
+                }
+            }
+            if (!__any(alive)) break;
+            lv = lvN;
+            hd = hdN;
+            w = wN;
+            if (++n == m.numPer) n = 0;
+        }
+        // ---- results, per quarter
+        if (valid && r == 0) {
+            if (deep) {
+                o.deep_q[atomicAdd(o.deep_count, 1u)] = myWid;
+            } else {
+                if (o.all_level) o.all_level[myWid] = level;
+                if (o.all_fout) o.all_fout[myWid] = fout;
+            }
+        }
+        (void)thr;
+        wave_sync();
+    }
+}
+
 // ---- stage B: one workgroup per surviving window ---------------------------------------------------
 // The kernel values K_k of different filters are independent of each other except through
 // u_kernel_eval[k % numPer] (written numPer filters earlier), so the four waves evaluate disjoint
@@ -795,7 +1027,20 @@ void launch_sized(fd_ctx* ctx, hipStream_t st, int64_t total, const WvmDev& dev,
     static const bool single = getenv("FD_WVM_SINGLE") != nullptr;
     bool launched = false;
     if constexpr (PW_ > 0 && PW_ <= 32) {
-        if (dev.numPer <= 32 && !single) {   // two windows per wavefront
+        static const bool pairOnly = getenv("FD_WVM_PAIR") != nullptr;
+        // four windows per wavefront where four integral images leave enough LDS for the occupancy of the fixed part (measured per
+        // kernel, pair -> quad: 20x20 -12 %, 16x24 -12 %, 24x24 -3 %, 32x16 0 %, 32x24 +19 %)
+        constexpr bool quadFits = PW_ * PH_ <= 576 && PW_ <= 24;
+        if (quadFits && dev.numPer <= 32 && !single && !pairOnly && dev.numUsed > WVM_LCAP) {
+            static int perCu4q = 0;
+            if (perCu4q == 0) {
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu4q, k_wvm_cascade4<PW_, PH_, RAW>, 64 * WVM_QUAD_WAVES, 0) != hipSuccess || perCu4q < 1)
+                    perCu4q = 4;
+            }
+            const int grid4 = (int)std::min<int64_t>((total + 4 * WVM_QUAD_WAVES - 1) / (4 * WVM_QUAD_WAVES), (int64_t)ctx->num_cus * perCu4q * 2);
+            hipLaunchKernelGGL((k_wvm_cascade4<PW_, PH_, RAW>), dim3(grid4), dim3(64 * WVM_QUAD_WAVES), 0, st, arena, wt, dev, o);
+            launched = true;
+        } else if (dev.numPer <= 32 && !single) {   // two windows per wavefront
             static int perCu2 = 0;
             if (perCu2 == 0) {
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu2, k_wvm_cascade2<PW_, PH_, RAW>, 256, 0) != hipSuccess || perCu2 < 1) perCu2 = 4;
