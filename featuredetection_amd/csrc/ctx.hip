@@ -61,6 +61,7 @@ void fd_ctx_destroy(fd_ctx* ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
+    if (ctx->tail) (void)hipStreamDestroy(ctx->tail);
     for (hipStream_t ps : ctx->pool) if (ps) (void)hipStreamDestroy(ps);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -31,6 +31,7 @@ struct fd_ctx {
     FdPinned pinned;
     hipStream_t aux = nullptr;   // second stream (created on first use): small follow-up work that must not queue behind ctx->stream
     hipStream_t pool[8] = {};   // batch jobs are spread over these (created on first use)
+    hipStream_t tail = nullptr; // high-priority stream of the batch entry points' follow-up kernels (created on first use)
     // per-context device scratch of the translation units (fd_scratch<T>): owned by the context, freed with it
     std::map<std::type_index, std::shared_ptr<void>> scratch;
 };
@@ -133,6 +134,18 @@ static inline void* fd_pinned(fd_ctx* ctx, size_t bytes) {
 static inline hipStream_t fd_aux_stream(fd_ctx* ctx) {
     if (!ctx->aux) HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
     return ctx->aux;
+}
+
+// Stream of the small follow-up kernels of the batch entry points (the SVM stage and read-backs of a detector whose cascade has
+// finished): highest priority and never behind the cascades still queued on the pool streams, so that the host can finish the
+// detectors one by one while the GPU works through the remaining cascades.
+static inline hipStream_t fd_tail_stream(fd_ctx* ctx) {
+    if (!ctx->tail) {
+        int least = 0, greatest = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_CHECK(hipStreamCreateWithPriority(&ctx->tail, hipStreamNonBlocking, greatest));
+    }
+    return ctx->tail;
 }
 
 static inline hipStream_t fd_pool_stream(fd_ctx* ctx, int i) {

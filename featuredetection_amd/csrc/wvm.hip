@@ -99,7 +99,9 @@ struct fd_wvm {
     HostBuf h_pos;
     int64_t pos_cap = 0;
     hipEvent_t done = nullptr;   // recorded after the cascade kernels + first read-back of a run
-    ~fd_wvm() { if (done) (void)hipEventDestroy(done); }
+    HostBuf h_tail;              // pinned staging of the SVM stage of a five-stage run: [slots | distances]
+    hipEvent_t tailDone = nullptr;   // recorded after the SVM stage + its read-back
+    ~fd_wvm() { if (done) (void)hipEventDestroy(done); if (tailDone) (void)hipEventDestroy(tailDone); }
 };
 
 namespace {
@@ -1422,82 +1424,124 @@ int fd_bench_wvm(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, int sx, int sy,
 }
 
 // Stages 2-5 of FiveStageSlidingWindowDetector::detect (FiveStageSlidingWindowDetector.cpp:200-320 / :340-380) on a
-// finished WVM run.  GPU work (the SVM on the survivors) goes to the stream `st`.
-static void five_stage_tail(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, const fd_svm* svm, const WvmRun& run, float oe_dist, float oe_ratio,
-                            int sx, int sy, const int* roi, hipStream_t st, fd_detection* out, int cap, int* count, int32_t* stage_counts) {
-    static const bool trace = getenv("FD_TRACE") != nullptr;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto t0 = now();
-    auto lap = [&](const char* what) {
+// finished WVM run, in two halves so that a batch can keep the host busy while the GPU is: begin() does the host stages up to
+// overlap elimination and queues the SVM on the survivors + its read-back on the stream `st` (event m->tailDone); end() waits
+// for that event and finishes with the block NMS.
+struct FiveStageTail {
+    fd_ctx* ctx = nullptr;
+    fd_pyramid* p = nullptr;
+    fd_wvm* m = nullptr;
+    const fd_svm* svm = nullptr;
+    const int* roi = nullptr;
+    fd_detection* out = nullptr;
+    int cap = 0;
+    int* count = nullptr;
+    int32_t* stage_counts = nullptr;
+    std::vector<fd_detection> wvmPos;
+    std::vector<int> keep;
+    size_t distOff = 0;
+    bool pending = false, finished = false;
+    std::chrono::steady_clock::time_point t0;
+
+    void lap(const char* what) {
+        static const bool trace = getenv("FD_TRACE") != nullptr;
         if (!trace) return;
-        auto t1 = now();
+        auto t1 = std::chrono::steady_clock::now();
         fprintf(stderr, "[fd five-stage] %-12s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t1 - t0).count());
         t0 = t1;
-    };
-    FdStreamSwap swap(ctx, st);   // fd_svm_generic_launch works on ctx->stream
-    std::vector<fd_detection> wvmPos;
-    fd_wvm_positives_to_detections(p, m, run, sx, sy, wvmPos);
-    if (stage_counts) stage_counts[0] = (int)wvmPos.size();
-    lap("to_dets");
-    // stage 2: overlap elimination
-    std::vector<int> keep;
-    fd_host_overlap_elimination(wvmPos.data(), (int)wvmPos.size(), oe_dist, oe_ratio, keep);
-    if (stage_counts) stage_counts[1] = (int)keep.size();
-    lap("oe");
-    // stage 3: SVM on the survivors' HistEq64 patches (still resident in HBM, gathered by slot)
-    std::vector<fd_detection> svmPos;
-    if (!keep.empty()) {
-        std::vector<uint32_t> slots(keep.size());
-        for (size_t i = 0; i < keep.size(); ++i) slots[i] = run.slots[keep[i]];
-        DevBuf& idx = m->all_level;  // reuse scratch (not used by this call)
-        idx.reserve(sizeof(uint32_t) * slots.size());
-        m->all_fout.reserve(sizeof(double) * slots.size());
-        // pinned staging: [slots (u32) | distances (f64)]
-        const size_t distOff = (sizeof(uint32_t) * slots.size() + 15) & ~(size_t)15;
-        char* pin = (char*)fd_pinned(ctx, distOff + sizeof(double) * slots.size());
-        std::memcpy(pin, slots.data(), sizeof(uint32_t) * slots.size());
-        HIP_CHECK(hipMemcpyAsync(idx.p, pin, sizeof(uint32_t) * slots.size(), hipMemcpyHostToDevice, st));
-        fd_svm_generic_launch(ctx, svm, m->pos_patches.p, idx.as<uint32_t>(), (int64_t)m->dev.d, (int64_t)slots.size(), m->all_fout.as<double>());
-        HIP_CHECK(hipMemcpyAsync(pin + distOff, m->all_fout.p, sizeof(double) * slots.size(), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        const double* dist = (const double*)(pin + distOff);
-        for (size_t i = 0; i < keep.size(); ++i) {
-            if (dist[i] >= (double)fd_svm_threshold(svm)) {  // strongClassifier->classify(): bool only
-                fd_detection d = wvmPos[keep[i]];
-                d.score = (float)dist[i];
-                d.positive = 1;
-                d.probability = 0.5;  // ClassifiedPatch(patch, bool) default probability (ClassifiedPatch.hpp:29-30)
-                svmPos.push_back(d);
+    }
+
+    void begin(fd_ctx* ctx_, fd_pyramid* p_, fd_wvm* m_, const fd_svm* svm_, const WvmRun& run, float oe_dist, float oe_ratio, int sx, int sy,
+               const int* roi_, hipStream_t st, fd_detection* out_, int cap_, int* count_, int32_t* stage_counts_) {
+        ctx = ctx_; p = p_; m = m_; svm = svm_; roi = roi_; out = out_; cap = cap_; count = count_; stage_counts = stage_counts_;
+        t0 = std::chrono::steady_clock::now();
+        FdStreamSwap swap(ctx, st);   // fd_svm_generic_launch works on ctx->stream
+        fd_wvm_positives_to_detections(p, m, run, sx, sy, wvmPos);
+        if (stage_counts) stage_counts[0] = (int)wvmPos.size();
+        lap("to_dets");
+        // stage 2: overlap elimination
+        fd_host_overlap_elimination(wvmPos.data(), (int)wvmPos.size(), oe_dist, oe_ratio, keep);
+        if (stage_counts) stage_counts[1] = (int)keep.size();
+        lap("oe");
+        // stage 3: SVM on the survivors' HistEq64 patches (still resident in HBM, gathered by slot)
+        if (!keep.empty()) {
+            std::vector<uint32_t> slots(keep.size());
+            for (size_t i = 0; i < keep.size(); ++i) slots[i] = run.slots[keep[i]];
+            DevBuf& idx = m->all_level;  // reuse scratch (not used by this call)
+            idx.reserve(sizeof(uint32_t) * slots.size());
+            m->all_fout.reserve(sizeof(double) * slots.size());
+            // pinned staging of this detector: [slots (u32) | distances (f64)]
+            distOff = (sizeof(uint32_t) * slots.size() + 15) & ~(size_t)15;
+            m->h_tail.reserve(distOff + sizeof(double) * slots.size());
+            char* pin = m->h_tail.as<char>();
+            std::memcpy(pin, slots.data(), sizeof(uint32_t) * slots.size());
+            HIP_CHECK(hipMemcpyAsync(idx.p, pin, sizeof(uint32_t) * slots.size(), hipMemcpyHostToDevice, st));
+            fd_svm_generic_launch(ctx, svm, m->pos_patches.p, idx.as<uint32_t>(), (int64_t)m->dev.d, (int64_t)slots.size(), m->all_fout.as<double>());
+            HIP_CHECK(hipMemcpyAsync(pin + distOff, m->all_fout.p, sizeof(double) * slots.size(), hipMemcpyDeviceToHost, st));
+            if (!m->tailDone) HIP_CHECK(hipEventCreateWithFlags(&m->tailDone, hipEventDisableTiming));
+            HIP_CHECK(hipEventRecord(m->tailDone, st));
+            pending = true;
+        }
+        lap("svm launch");
+    }
+
+    // true when end() would not block
+    bool ready() const { return !pending || hipEventQuery(m->tailDone) == hipSuccess; }
+
+    void end() {
+        if (finished) return;
+        finished = true;
+        t0 = std::chrono::steady_clock::now();
+        std::vector<fd_detection> svmPos;
+        if (pending) {
+            HIP_CHECK(hipEventSynchronize(m->tailDone));
+            pending = false;
+            const double* dist = (const double*)(m->h_tail.as<char>() + distOff);
+            for (size_t i = 0; i < keep.size(); ++i) {
+                if (dist[i] >= (double)fd_svm_threshold(svm)) {  // strongClassifier->classify(): bool only
+                    fd_detection d = wvmPos[keep[i]];
+                    d.score = (float)dist[i];
+                    d.positive = 1;
+                    d.probability = 0.5;  // ClassifiedPatch(patch, bool) default probability (ClassifiedPatch.hpp:29-30)
+                    svmPos.push_back(d);
+                }
             }
         }
-    }
-    if (stage_counts) stage_counts[2] = (int)svmPos.size();
-    lap("svm");
-    auto byProb = [](const fd_detection& a, const fd_detection& b) { return a.probability > b.probability; };
-    bool sortAtEnd = true;
-    if (!roi) {
-        std::vector<int> maxima;
-        fd_host_block_nms_sparse(svmPos, p->img_w, p->img_h, 35, true, maxima);
-        if (maxima.empty()) fd_host_block_nms_sparse(svmPos, p->img_w, p->img_h, 35, false, maxima);
-        if (maxima.empty()) {
-            sortAtEnd = false;  // "return svmPatchesPositive; // Should be empty." (:292-294), unsorted
-        } else {
-            std::sort(svmPos.begin(), svmPos.end(), byProb);
-            std::vector<fd_detection> res;
-            for (size_t i = 0; i + 1 < maxima.size(); i += 2) {
-                const int x = maxima[i], y = maxima[i + 1];
-                auto it = std::find_if(svmPos.begin(), svmPos.end(), [&](const fd_detection& a) { return a.cx == x && a.cy == y; });
-                if (it != svmPos.end()) res.push_back(*it);
+        if (stage_counts) stage_counts[2] = (int)svmPos.size();
+        lap("svm wait");
+        auto byProb = [](const fd_detection& a, const fd_detection& b) { return a.probability > b.probability; };
+        bool sortAtEnd = true;
+        if (!roi) {
+            std::vector<int> maxima;
+            fd_host_block_nms_sparse(svmPos, p->img_w, p->img_h, 35, true, maxima);
+            if (maxima.empty()) fd_host_block_nms_sparse(svmPos, p->img_w, p->img_h, 35, false, maxima);
+            if (maxima.empty()) {
+                sortAtEnd = false;  // "return svmPatchesPositive; // Should be empty." (:292-294), unsorted
+            } else {
+                std::sort(svmPos.begin(), svmPos.end(), byProb);
+                std::vector<fd_detection> res;
+                for (size_t i = 0; i + 1 < maxima.size(); i += 2) {
+                    const int x = maxima[i], y = maxima[i + 1];
+                    auto it = std::find_if(svmPos.begin(), svmPos.end(), [&](const fd_detection& a) { return a.cx == x && a.cy == y; });
+                    if (it != svmPos.end()) res.push_back(*it);
+                }
+                svmPos.swap(res);
             }
-            svmPos.swap(res);
         }
+        if (sortAtEnd) std::sort(svmPos.begin(), svmPos.end(), byProb);
+        if (stage_counts) stage_counts[3] = (int)svmPos.size();
+        lap("nms");
+        *count = (int)svmPos.size();
+        for (size_t i = 0; i < svmPos.size() && (int)i < cap && out; ++i) out[i] = svmPos[i];
+        if (out && (int)svmPos.size() > cap) FD_THROW(FD_ERR_CAPACITY, "five-stage: %zu detections, capacity %d", svmPos.size(), cap);
     }
-    if (sortAtEnd) std::sort(svmPos.begin(), svmPos.end(), byProb);
-    if (stage_counts) stage_counts[3] = (int)svmPos.size();
-    lap("nms");
-    *count = (int)svmPos.size();
-    for (size_t i = 0; i < svmPos.size() && (int)i < cap && out; ++i) out[i] = svmPos[i];
-    if (out && (int)svmPos.size() > cap) FD_THROW(FD_ERR_CAPACITY, "five-stage: %zu detections, capacity %d", svmPos.size(), cap);
+};
+
+static void five_stage_tail(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, const fd_svm* svm, const WvmRun& run, float oe_dist, float oe_ratio,
+                            int sx, int sy, const int* roi, hipStream_t st, fd_detection* out, int cap, int* count, int32_t* stage_counts) {
+    FiveStageTail t;
+    t.begin(ctx, p, m, svm, run, oe_dist, oe_ratio, sx, sy, roi, st, out, cap, count, stage_counts);
+    t.end();
 }
 
 static void five_stage_check(const fd_wvm* m, const fd_svm* svm) {
@@ -1548,21 +1592,39 @@ int fd_detect_five_stage_batch(fd_ctx* ctx, fd_five_stage_job* jobs, int n) {
             }
             fd_wvm_launch(ctx, j.pyramid, const_cast<fd_wvm*>(j.wvm), j.step_x, j.step_y, j.roi, false, runs[i], false);
         }
+        // The host then finishes the detectors one by one: as soon as a cascade is done, its positives are read back and
+        // thinned out by the overlap elimination while the GPU works on the later cascades; the SVM stage of the survivors is
+        // only queued (high-priority stream), and its NMS runs whenever the result has arrived, at the latest after the loop.
         int firstError = FD_OK;
+        std::vector<FiveStageTail> tails((size_t)n);
+        std::vector<int> counts((size_t)n, 0);
+        auto fail = [&](int i, const FdError& e) {   // the remaining jobs are still collected; the first failure is reported
+            jobs[i].status = e.code;
+            if (firstError == FD_OK) { firstError = e.code; ctx->error = e.msg; }
+        };
+        auto finish = [&](int i) {
+            try {
+                tails[i].end();
+                jobs[i].count = counts[i];
+            } catch (const FdError& e) { fail(i, e); }
+        };
+        static const bool tailOnPool = getenv("FD_TAIL_ON_POOL") != nullptr;
         for (int i = 0; i < n; ++i) {
             fd_five_stage_job& j = jobs[i];
             fd_wvm* m = const_cast<fd_wvm*>(j.wvm);
             try {
                 fd_wvm_finish(ctx, m, runs[i]);
-                int cnt = 0;
-                five_stage_tail(ctx, j.pyramid, m, j.svm, runs[i], j.oe_dist, j.oe_ratio, j.step_x, j.step_y, j.roi, fd_pool_stream(ctx, i), j.out,
-                                j.cap, &cnt, j.stage_counts);
-                j.count = cnt;
-            } catch (const FdError& e) {   // the remaining jobs are still collected; the first failure is reported
-                j.status = e.code;
-                if (firstError == FD_OK) { firstError = e.code; ctx->error = e.msg; }
+                tails[i].begin(ctx, j.pyramid, m, j.svm, runs[i], j.oe_dist, j.oe_ratio, j.step_x, j.step_y, j.roi,
+                               tailOnPool ? fd_pool_stream(ctx, i) : fd_tail_stream(ctx), j.out, j.cap, &counts[i], j.stage_counts);
+            } catch (const FdError& e) {
+                tails[i].finished = true;
+                fail(i, e);
             }
+            for (int k = 0; k < i; ++k)
+                if (!tails[k].finished && tails[k].ready()) finish(k);
         }
+        for (int i = 0; i < n; ++i)
+            if (!tails[i].finished) finish(i);
         if (firstError != FD_OK) throw FdError{firstError, ctx->error};
     });
 }
