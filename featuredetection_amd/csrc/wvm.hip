@@ -986,6 +986,172 @@ __global__ __launch_bounds__(64 * NW) void k_wvm_deep(const uint8_t* __restrict_
     }
 }
 
+// ---- stage B, four filters per wavefront -----------------------------------------------------------
+// Same decomposition as k_wvm_deep (one workgroup per surviving window, waves on disjoint residue classes n = k % numPer,
+// block-owned hierarchical sums), but a wavefront evaluates four filters of the window at once in the quarter layout of
+// k_wvm_cascade4: lanes 16q..16q+15 work on the filter of class n = 4 * (wave + round * NW) + q -- lane == rect (16 per pass)
+// for the rect sums, then the wave-uniform part of the evaluation (fp64 grey-value chain, exp) once per instruction for
+// four filters; val[v] / the grey-value sums reach the lanes of their quarter by DPP row broadcasts.  With numPer <= 16 a
+// whole generation of filters is in flight at once in four waves, so the serial chain of a surviving window is one filter
+// evaluation per generation.
+#define FD_ROW_BCAST_I(x, V) __builtin_amdgcn_update_dpp(0, (x), 0x150 + (V), 0xf, 0xf, false)   /* row_newbcast:V */
+template <int V>
+__device__ __forceinline__ double row_bcast_d(double v) {
+    const int lo = FD_ROW_BCAST_I(__double2loint(v), V), hi = FD_ROW_BCAST_I(__double2hiint(v), V);
+    return __hiloint2double(hi, lo);
+}
+
+template <int PW_, int PH_, bool RAW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_wvm_deep4(const uint8_t* __restrict__ arena, WinTable wt, WvmDev m, CascadeOut o) {
+    constexpr int RHMAX = Geo<PW_, PH_>::RHMAX;
+    constexpr int MAXOWN = (WVM_PJ + NW - 1) / NW;   // 64-level blocks owned by one wave (block j belongs to wave j % NW)
+    constexpr int MAXR = (32 + 4 * NW - 1) / (4 * NW);   // rounds of 4 * NW classes (numPer <= 32)
+    __shared__ unsigned int ii[Geo<PW_, PH_>::IISZ];
+    __shared__ unsigned int hist[NW][64];
+    __shared__ int sv[NW][4][WVM_MAX_VALS];
+    __shared__ float kh[64 * WVM_PJ];
+    __shared__ int64_t sFirst[WVM_MAX_LAYERS];
+    __shared__ unsigned long long sExit;   // (first failed level << 32 | fp32 bits of its sum), minimum over the candidates
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4, r = lane & 15;
+    const Geo<PW_, PH_> g(m, lane);
+    const int F = m.numFilters, NU = m.numUsed, NP = m.numPer;
+    const int gensPerChunk = max(1, 64 / NP);
+    const int chunk = gensPerChunk * NP;
+    const int pw = g.pw;
+
+    if (!RAW && threadIdx.x < WVM_MAX_LAYERS) sFirst[threadIdx.x] = (int)threadIdx.x < wt.n ? wt.l[threadIdx.x].first : INT64_MAX;
+    sv[wave][q][r] = 0;
+    __syncthreads();
+    const unsigned int ndeep = *o.deep_count;
+
+    for (unsigned int qi = blockIdx.x; qi < ndeep; qi += gridDim.x) {
+        const int64_t wid = o.deep_q[qi];
+        int srcStride;
+        const uint8_t* src = wvm_locate<RAW>(arena, wt, sFirst, wid, lane, g.pw, g.d, srcStride);
+        unsigned int px[RHMAX];
+        float sxx;
+        int sx_total;
+        // every wave prepares the window (identical values; they all write the one integral image)
+        wvm_prepare<PW_, PH_, RAW>(g, src, srcStride, m.stretch, lane, hist[wave], ii, px, sxx, sx_total);
+        if (threadIdx.x == 0) sExit = ~0ull;
+        __syncthreads();
+
+        float u[MAXR];   // u_kernel_eval of this quarter's class in each round
+#pragma unroll
+        for (int rd = 0; rd < MAXR; ++rd) u[rd] = 0.f;
+        float Pacc[MAXOWN];
+#pragma unroll
+        for (int ow = 0; ow < MAXOWN; ++ow) Pacc[ow] = m.negBias;
+        int level = NU - 1;
+        float fout = 0.f;
+        int* svq = sv[wave][q];
+        for (int c0 = 0; c0 < NU; c0 += chunk) {
+            const int c1 = min(c0 + chunk, NU);
+            // ---- kernel values of this wave's filters in [c0, c1): generation by generation, four classes per round
+            for (int gbase = c0; gbase < c1; gbase += NP) {
+#pragma unroll
+                for (int rd = 0; rd < MAXR; ++rd) {
+                    const int nFirst = 4 * (wave + rd * NW);
+                    if (nFirst >= NP || gbase + nFirst >= c1) break;   // wave-uniform
+                    const int n = nFirst + q;
+                    const int k = gbase + n;
+                    const bool active = n < NP && k < c1;
+                    const int kc = active ? k : gbase + nFirst;   // in-range model record for idle quarters
+                    const uint4 lv = m.lvlRec[(size_t)kc * 64 + r];
+                    const WvmLevelHdr hd = m.lvlHdr[kc];
+                    const int nr = active ? hd.nrects : 0;
+                    // rect sums: lane == rect of this quarter's filter, 16 per pass
+                    for (int rb = 0; __any(rb < nr); rb += 16) {
+                        unsigned int rc, vt;
+                        if (rb == 0) { rc = lv.x; vt = lv.y; }
+                        else if (rb < 64) { const uint4 t = m.lvlRec[(size_t)kc * 64 + rb + r]; rc = t.x; vt = t.y; }
+                        else { const int ri = m.rectBegin[kc] + min(rb + r, max(nr, 1) - 1); rc = m.rects[ri]; vt = m.rectV[ri]; }
+                        if (rb + r < nr) {
+                            const int x1 = rc & 255, y1 = (rc >> 8) & 255, x2 = (rc >> 16) & 255, y2 = rc >> 24;
+                            int sm = (int)ii[y2 * pw + x2];
+                            if (x1 > 0) sm -= (int)ii[y2 * pw + x1 - 1];
+                            if (y1 > 0) sm -= (int)ii[(y1 - 1) * pw + x2];
+                            if (x1 > 0 && y1 > 0) sm += (int)ii[(y1 - 1) * pw + x1 - 1];
+                            atomicAdd(&svq[vt], sm);
+                        }
+                    }
+                    wave_sync();
+                    // lane v of the quarter takes the sum of grey value v (and clears it), its product with val[v]; the chain of
+                    // the reference (WvmClassifier.cpp:308-346) then runs in value order on row broadcasts
+                    const int svr = svq[r];
+                    svq[r] = 0;
+                    const double valL = __hiloint2double((int)lv.w, (int)lv.z);
+                    const double prod = (double)svr * valL;
+                    const int cntval = hd.cntval;
+                    const int maxCnt = __builtin_amdgcn_readfirstlane(max(max(__builtin_amdgcn_readlane(cntval, 0), __builtin_amdgcn_readlane(cntval, 16)),
+                                                                        max(__builtin_amdgcn_readlane(cntval, 32), __builtin_amdgcn_readlane(cntval, 48))));
+                    double sum_xp = 0.0;
+                    int sumv0 = sx_total;
+#define FD_CHAIN_STEP(V)                                                      \
+    if ((V) < maxCnt) {                                                       \
+        const int s_ = FD_ROW_BCAST_I(svr, V);                                \
+        const double p_ = row_bcast_d<V>(prod);                               \
+        if ((V) < cntval) { sumv0 -= s_; sum_xp = sum_xp + p_; }              \
+    }
+                    FD_CHAIN_STEP(1) FD_CHAIN_STEP(2) FD_CHAIN_STEP(3) FD_CHAIN_STEP(4) FD_CHAIN_STEP(5)
+                    FD_CHAIN_STEP(6) FD_CHAIN_STEP(7) FD_CHAIN_STEP(8) FD_CHAIN_STEP(9) FD_CHAIN_STEP(10)
+                    FD_CHAIN_STEP(11) FD_CHAIN_STEP(12) FD_CHAIN_STEP(13) FD_CHAIN_STEP(14) FD_CHAIN_STEP(15)
+#undef FD_CHAIN_STEP
+                    const double t0 = (double)sumv0 * row_bcast_d<0>(valL);
+                    sum_xp = sum_xp + t0;
+                    sum_xp = sum_xp + (double)u[rd];
+                    const float unew = (float)sum_xp;
+                    double norm = (double)sxx;
+                    norm = norm - 2 * sum_xp;
+                    norm = norm + hd.pp;
+                    const float Kk = (float)exp((double)m.negBasis * norm);
+                    if (active) {
+                        u[rd] = unew;
+                        if (r == 0) kh[k] = Kk;
+                    }
+                    wave_sync();
+                }
+            }
+            __syncthreads();
+            // ---- hierarchical sums: add the chunk's terms to every owned level >= c0; check the levels inside the chunk
+#pragma unroll
+            for (int ow = 0; ow < MAXOWN; ++ow) {
+                const int blk = wave + ow * NW;
+                if (blk * 64 >= NU || blk * 64 + 63 < c0) continue;   // nothing owned here / already decided
+                const int mm = blk * 64 + lane;
+                const float* wp = m.wT + mm;
+                float P = Pacc[ow];
+                const float* wq = wp + (size_t)c0 * F;
+#pragma unroll 8
+                for (int i = c0; i < c1; ++i, wq += F) {
+                    const float t = *wq * kh[i];
+                    P = P + t;
+                }
+                Pacc[ow] = P;
+                const bool mine = mm >= c0 && mm < c1;
+                const float thrm = mine ? m.thresholds[mm] : 0.f;
+                const bool fail = mine && !(P >= thrm && mm + 1 < NU);
+                const unsigned long long fm = __ballot(fail);
+                if (fm) {
+                    const int e = __builtin_ctzll(fm);
+                    if (lane == e) atomicMin(&sExit, ((unsigned long long)(unsigned int)mm << 32) | (unsigned int)__float_as_int(P));
+                }
+            }
+            __syncthreads();
+            const unsigned long long ex = sExit;
+            if (ex != ~0ull) {
+                level = (int)(ex >> 32);
+                fout = __int_as_float((int)(unsigned int)ex);
+                break;
+            }
+        }
+        if (wave == 0) wvm_emit<PW_, PH_>(g, m, o, wid, lane, level, fout, m.thresholds[level], px);
+        __syncthreads();
+    }
+}
+
 // HistEq64 only (fd_histeq64_batch): same steps 1-3 on contiguous patches
 __global__ __launch_bounds__(256) void k_histeq64(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int64_t n, int pw,
                                                   int ph, float stretch) {
@@ -1063,6 +1229,14 @@ void launch_sized(fd_ctx* ctx, hipStream_t st, int64_t total, const WvmDev& dev,
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu8, k_wvm_deep<PW_, PH_, RAW, 8>, 512, 0) != hipSuccess || perCu8 < 1) perCu8 = 1;
     }
     static const char* nwEnv = getenv("FD_WVM_DEEP_WAVES");
+    static const bool deepOld = getenv("FD_WVM_DEEP_OLD") != nullptr;
+    if (dev.numPer <= 32 && !deepOld) {   // four filters per wavefront, four waves per surviving window
+        static int perCuQ = 0;
+        if (perCuQ == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuQ, k_wvm_deep4<PW_, PH_, RAW, 4>, 256, 0) != hipSuccess || perCuQ < 1)) perCuQ = 2;
+        const int gridB = (int)std::min<int64_t>(total, (int64_t)ctx->num_cus * perCuQ);
+        hipLaunchKernelGGL((k_wvm_deep4<PW_, PH_, RAW, 4>), dim3(gridB), dim3(256), 0, st, arena, wt, dev, o);
+        return;
+    }
     const bool wide = nwEnv ? atoi(nwEnv) != 4 : true;
     if (wide) {
         const int gridB = (int)std::min<int64_t>(total, (int64_t)ctx->num_cus * perCu8);
