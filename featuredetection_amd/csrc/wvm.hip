@@ -641,6 +641,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
 }
 
+// DPP broadcast of lane V of every row of 16 lanes (a quarter of the wavefront) to the lanes of that row
+// (v_mov_b32_dpp row_newbcast).  The empty asm keeps the compiler from folding the DPP control into the consuming VALU
+// instruction: a folded `v_subrev_u32_dpp ... row_newbcast` returned wrong values on gfx950 (every window of a test frame
+// left the cascade two levels early), the plain move is fine.
+template <int V>
+__device__ __forceinline__ int row_bcast_i(int x) {
+    int y = __builtin_amdgcn_update_dpp(0, x, 0x150 + V, 0xf, 0xf, false);   // row_newbcast:V
+    asm volatile("" : "+v"(y));
+    return y;
+}
+#define FD_ROW_BCAST_I(x, V) row_bcast_i<V>(x)
+template <int V>
+__device__ __forceinline__ double row_bcast_d(double v) {
+    const int lo = row_bcast_i<V>(__double2loint(v)), hi = row_bcast_i<V>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 // ---- stage A, four windows per wavefront -----------------------------------------------------------
 // Phase timing of the pair kernel: HistEq64 26 %, integral images 13 %, the filter loop 60 %, and the filter loop is bound by
 // instruction issue: the wave-uniform part of a filter (the fp64 grey-value chain, exp, thresholds, prefetch, control:
@@ -691,6 +708,7 @@ __global__ __launch_bounds__(64 * WVM_QUAD_WAVES) __attribute__((amdgpu_waves_pe
     for (int64_t quad = (int64_t)blockIdx.x * WVM_QUAD_WAVES + wave; quad < nquads; quad += nwaves) {
         // level-0 model data: requested now, consumed after the fixed part
         uint4 lv = m.lvlRec[c];
+        uint4 lq = m.lvlRec[r];          // quarter layout: lane r holds val[r] of the level (z, w)
         WvmLevelHdr hd = m.lvlHdr[0];
         float w = m.wT[r];
 
@@ -785,6 +803,7 @@ __global__ __launch_bounds__(64 * WVM_QUAD_WAVES) __attribute__((amdgpu_waves_pe
         for (int k = 0;; ++k) {
             const int kn = min(k + 1, nA - 1);
             const uint4 lvN = m.lvlRec[(size_t)kn * 64 + c];
+            const uint4 lqN = m.lvlRec[(size_t)kn * 64 + r];
             const WvmLevelHdr hdN = m.lvlHdr[kn];
             const float wN = m.wT[(size_t)kn * F + r];
             // rect sums in the pair layout: 32 rects per pass, the rect record loaded once for both pairs
@@ -817,23 +836,29 @@ __global__ __launch_bounds__(64 * WVM_QUAD_WAVES) __attribute__((amdgpu_waves_pe
                 }
             }
             wave_sync();
-            // the reference's scalar chain (WvmClassifier.cpp:308-346), once per quarter
-            const int* sv = L.sv[q];
-            const double valL = __hiloint2double((int)lv.w, (int)lv.z);
+            // the reference's scalar chain (WvmClassifier.cpp:308-346), once per quarter: lane v of the quarter takes the sum of
+            // grey value v (and clears it) and its product with val[v]; the chain runs in value order on row broadcasts
+            const int svr = L.sv[q][r];
+            L.sv[q][r] = 0;
+            const double valL = __hiloint2double((int)lq.w, (int)lq.z);
+            const double prod = (double)svr * valL;
+            const int cntval = hd.cntval;
             double sum_xp = 0.0;
             int sumv0 = sx_total;
-            for (int v = 1; v < hd.cntval; ++v) {
-                const int s = sv[v];
-                sumv0 -= s;
-                const double prod = (double)s * readlane_d(valL, v);
-                sum_xp = sum_xp + prod;
-            }
-            const double t0 = (double)sumv0 * readlane_d(valL, 0);
+#define FD_CHAIN_STEP(V)                                                      \
+    if ((V) < cntval) {                                                       \
+        sumv0 -= FD_ROW_BCAST_I(svr, V);                                      \
+        sum_xp = sum_xp + row_bcast_d<V>(prod);                               \
+    }
+            FD_CHAIN_STEP(1) FD_CHAIN_STEP(2) FD_CHAIN_STEP(3) FD_CHAIN_STEP(4) FD_CHAIN_STEP(5)
+            FD_CHAIN_STEP(6) FD_CHAIN_STEP(7) FD_CHAIN_STEP(8) FD_CHAIN_STEP(9) FD_CHAIN_STEP(10)
+            FD_CHAIN_STEP(11) FD_CHAIN_STEP(12) FD_CHAIN_STEP(13) FD_CHAIN_STEP(14) FD_CHAIN_STEP(15)
+#undef FD_CHAIN_STEP
+            const double t0 = (double)sumv0 * row_bcast_d<0>(valL);
             sum_xp = sum_xp + t0;
             sum_xp = sum_xp + (double)L.u[q][n];
             const float unew = (float)sum_xp;
             wave_sync();
-            L.sv[q][r] = 0;
             if (r == 0) L.u[q][n] = unew;
             double norm = (double)sxx;
             norm = norm - 2 * sum_xp;
@@ -855,6 +880,7 @@ __global__ __launch_bounds__(64 * WVM_QUAD_WAVES) __attribute__((amdgpu_waves_pe
             }
             if (!__any(alive)) break;
             lv = lvN;
+            lq = lqN;
             hd = hdN;
             w = wN;
             if (++n == m.numPer) n = 0;
@@ -994,13 +1020,6 @@ __global__ __launch_bounds__(64 * NW) void k_wvm_deep(const uint8_t* __restrict_
 // four filters; val[v] / the grey-value sums reach the lanes of their quarter by DPP row broadcasts.  With numPer <= 16 a
 // whole generation of filters is in flight at once in four waves, so the serial chain of a surviving window is one filter
 // evaluation per generation.
-#define FD_ROW_BCAST_I(x, V) __builtin_amdgcn_update_dpp(0, (x), 0x150 + (V), 0xf, 0xf, false)   /* row_newbcast:V */
-template <int V>
-__device__ __forceinline__ double row_bcast_d(double v) {
-    const int lo = FD_ROW_BCAST_I(__double2loint(v), V), hi = FD_ROW_BCAST_I(__double2hiint(v), V);
-    return __hiloint2double(hi, lo);
-}
-
 template <int PW_, int PH_, bool RAW, int NW>
 __global__ __launch_bounds__(64 * NW) void k_wvm_deep4(const uint8_t* __restrict__ arena, WinTable wt, WvmDev m, CascadeOut o) {
     constexpr int RHMAX = Geo<PW_, PH_>::RHMAX;
