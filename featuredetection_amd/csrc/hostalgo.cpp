@@ -15,9 +15,14 @@
 void fd_host_overlap_elimination(const fd_detection* in, int n, float distIn, float ratioIn, std::vector<int>& keep) {
     keep.clear();
     if (n <= 0) return;
+    // descending probability.  Sorting (probability, index) pairs makes the same comparisons with the same outcomes as sorting the
+    // indices through the detections, so std::sort produces the same permutation (ties included) without chasing 48-byte records
+    struct Key { double p; int i; };
+    std::vector<Key> keyed(n);
+    for (int i = 0; i < n; ++i) keyed[i] = Key{in[i].probability, i};
+    std::sort(keyed.begin(), keyed.end(), [](const Key& a, const Key& b) { return a.p > b.p; });
     std::vector<int> order(n);
-    for (int i = 0; i < n; ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return in[a].probability > in[b].probability; });
+    for (int i = 0; i < n; ++i) order[i] = keyed[i].i;
     const float dist = distIn;
     const float ratio = ((ratioIn > 0.0f) && (ratioIn <= 1.0f)) ? ratioIn : 0.0f;
     int maxw = 1;
@@ -25,11 +30,42 @@ void fd_host_overlap_elimination(const fd_detection* in, int n, float distIn, fl
     const float dmax = dist <= 1.0 ? dist * maxw : dist;
     const int cell = std::max(1, (int)std::ceil(dmax > 0 ? dmax : 1.f));
     auto cellOf = [&](int v) { return v >= 0 ? v / cell : -((-v + cell - 1) / cell); };
-    // accepted elements per cell: open-addressed table (key = cell, value = head of a singly linked list)
+    std::vector<int> next(n, -1);
+    auto overlaps = [&](const fd_detection& A, const fd_detection& P) {
+        const float d = dist <= 1.0 ? dist * std::max(A.w, P.w) : dist;
+        return (std::abs(A.cx - P.cx) < d) && (std::abs(A.cy - P.cy) < d) && (((float)std::min(A.w, P.w) / (float)std::max(A.w, P.w)) > ratio);
+    };
+    keep.reserve(n);
+    // accepted elements per grid cell (singly linked lists).  The centres of a frame's detections span a small range, so the
+    // grid is a dense array (with a one-cell border); an open-addressed hash table takes over for pathological extents.
+    int gx0 = INT32_MAX, gx1 = INT32_MIN, gy0 = INT32_MAX, gy1 = INT32_MIN;
+    for (int i = 0; i < n; ++i) {
+        const int gx = cellOf(in[i].cx), gy = cellOf(in[i].cy);
+        gx0 = std::min(gx0, gx); gx1 = std::max(gx1, gx); gy0 = std::min(gy0, gy); gy1 = std::max(gy1, gy);
+    }
+    const int64_t gw = (int64_t)gx1 - gx0 + 3, gh = (int64_t)gy1 - gy0 + 3;
+    if (gw * gh <= (int64_t)1 << 22) {
+        std::vector<int> head((size_t)(gw * gh), -1);
+        for (int bi = 0; bi < n; ++bi) {
+            const fd_detection& P = in[order[bi]];
+            const int64_t base = (int64_t)(cellOf(P.cy) - gy0 + 1) * gw + (cellOf(P.cx) - gx0 + 1);
+            bool removed = false;
+            for (int dy = -1; dy <= 1 && !removed; ++dy)
+                for (int dx = -1; dx <= 1 && !removed; ++dx)
+                    for (int ai = head[(size_t)(base + dy * gw + dx)]; ai >= 0; ai = next[ai])
+                        if (overlaps(in[ai], P)) { removed = true; break; }
+            if (!removed) {
+                keep.push_back(order[bi]);
+                next[order[bi]] = head[(size_t)base];
+                head[(size_t)base] = order[bi];
+            }
+        }
+        return;
+    }
     size_t cap = 16;
     while (cap < (size_t)n * 4) cap <<= 1;
     std::vector<uint64_t> keys(cap, ~0ull);
-    std::vector<int> head(cap, -1), next(n, -1);
+    std::vector<int> head(cap, -1);
     auto slotOf = [&](int gy, int gx, bool insert) -> int64_t {
         const uint64_t key = ((uint64_t)(uint32_t)gy << 32) | (uint32_t)gx;
         size_t h = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
@@ -39,7 +75,6 @@ void fd_host_overlap_elimination(const fd_detection* in, int n, float distIn, fl
         keys[h] = key;
         return (int64_t)h;
     };
-    keep.reserve(n);
     for (int bi = 0; bi < n; ++bi) {
         const fd_detection& P = in[order[bi]];
         const int gx = cellOf(P.cx), gy = cellOf(P.cy);
@@ -48,15 +83,8 @@ void fd_host_overlap_elimination(const fd_detection* in, int n, float distIn, fl
             for (int dx = -1; dx <= 1 && !removed; ++dx) {
                 const int64_t h = slotOf(gy + dy, gx + dx, false);
                 if (h < 0) continue;
-                for (int ai = head[h]; ai >= 0; ai = next[ai]) {
-                    const fd_detection& A = in[ai];
-                    float d = dist <= 1.0 ? dist * std::max(A.w, P.w) : dist;
-                    if ((std::abs(A.cx - P.cx) < d) && (std::abs(A.cy - P.cy) < d) &&
-                        (((float)std::min(A.w, P.w) / (float)std::max(A.w, P.w)) > ratio)) {
-                        removed = true;
-                        break;
-                    }
-                }
+                for (int ai = head[h]; ai >= 0; ai = next[ai])
+                    if (overlaps(in[ai], P)) { removed = true; break; }
             }
         if (!removed) {
             keep.push_back(order[bi]);
@@ -75,31 +103,55 @@ void fd_host_overlap_elimination(const fd_detection* in, int n, float distIn, fl
 void fd_host_block_nms_sparse(const std::vector<fd_detection>& pos, int imgW, int imgH, int sz, bool masked,
                               std::vector<int>& maxima_xy) {
     maxima_xy.clear();
-    // probabilityMap(py, px) = max probability at that pixel (:277-284), as float
-    std::map<std::pair<int, int>, float> map;  // key (y, x): row-major order
+    // probabilityMap(py, px) = max probability at that pixel (:277-284), as float: the reference's running
+    // "if (map(y, x) < p) map(y, x) = p" ends at (float)(largest p) whatever the order (float rounding is monotonic), and pixels
+    // whose probabilities are all <= 0 keep the map's 0.  Sorted vectors instead of node-based maps.
+    struct Pt { int x, y; float v; };
+    std::vector<Pt> all;
+    all.reserve(pos.size());
     for (const fd_detection& d : pos) {
         if (d.cx < 0 || d.cy < 0 || d.cx >= imgW || d.cy >= imgH) continue;  // (reference: out-of-range Mat::at, UB)
-        auto key = std::make_pair(d.cy, d.cx);
-        auto it = map.find(key);
-        float cur = it == map.end() ? 0.f : it->second;
-        if (cur < d.probability) map[key] = (float)d.probability;
+        if (!(0.f < d.probability)) continue;
+        all.push_back(Pt{d.cx, d.cy, (float)d.probability});
     }
-    struct Pt { int x, y; float v; };
-    std::vector<Pt> pts;
-    for (auto& kv : map) {
-        if (masked && !(kv.second > 0.3f)) continue;
-        pts.push_back(Pt{kv.first.second, kv.first.first, kv.second});
+    std::sort(all.begin(), all.end(), [](const Pt& a, const Pt& b) { return a.y != b.y ? a.y < b.y : (a.x != b.x ? a.x < b.x : a.v > b.v); });
+    std::vector<Pt> pts;   // row-major order, one entry per pixel (its maximum)
+    pts.reserve(all.size());
+    for (size_t i = 0; i < all.size(); ++i) {
+        if (i > 0 && all[i].x == all[i - 1].x && all[i].y == all[i - 1].y) continue;
+        if (masked && !(all[i].v > 0.3f)) continue;
+        pts.push_back(all[i]);
     }
-    // group by block, keeping row-major order inside each block
-    std::map<std::pair<int, int>, std::vector<int>> blocks;  // (block row, block col)
-    for (size_t i = 0; i < pts.size(); ++i) blocks[{pts[i].y / (sz + 1), pts[i].x / (sz + 1)}].push_back((int)i);
+    // group by block, keeping row-major order inside each block: indices sorted (stably) by block id
+    const int bs = sz + 1;
+    const int64_t bcols = (int64_t)imgW / bs + 2;
+    auto blockId = [&](const Pt& q) { return (int64_t)(q.y / bs) * bcols + q.x / bs; };
+    std::vector<int> byBlock(pts.size());
+    for (size_t i = 0; i < pts.size(); ++i) byBlock[i] = (int)i;
+    std::stable_sort(byBlock.begin(), byBlock.end(), [&](int a, int b) { return blockId(pts[a]) < blockId(pts[b]); });
+    struct Blk { int64_t id; int begin, end; };
+    std::vector<Blk> blocks;
+    for (size_t i = 0; i < byBlock.size();) {
+        size_t j = i;
+        const int64_t id = blockId(pts[byBlock[i]]);
+        while (j < byBlock.size() && blockId(pts[byBlock[j]]) == id) ++j;
+        blocks.push_back(Blk{id, (int)i, (int)j});
+        i = j;
+    }
+    auto findBlock = [&](int64_t id) -> const Blk* {
+        auto it = std::lower_bound(blocks.begin(), blocks.end(), id, [](const Blk& b, int64_t v) { return b.id < v; });
+        return it != blocks.end() && it->id == id ? &*it : nullptr;
+    };
     std::vector<Pt> accepted;
-    for (auto& kv : blocks) {
-        const int m = kv.first.first * (sz + 1), n = kv.first.second * (sz + 1);
-        // candidate: first maximum of the block (pts are in row-major order already)
+    for (const Blk& blk : blocks) {
+        const int brow = (int)(blk.id / bcols), bcol = (int)(blk.id % bcols);
+        const int m = brow * bs, n = bcol * bs;
+        // candidate: first maximum of the block (row-major order inside the block)
         int best = -1;
-        for (int i : kv.second)
+        for (int t = blk.begin; t < blk.end; ++t) {
+            const int i = byBlock[t];
             if (best < 0 || pts[i].v > pts[best].v) best = i;
+        }
         const Pt c = pts[best];
         if (!masked && !(c.v > 0.f)) continue;
         const double vcmax = c.v;
@@ -109,12 +161,19 @@ void fd_host_block_nms_sparse(const std::vector<fd_detection>& pos, int imgW, in
         const int by0 = m, by1 = std::min(m + sz + 1, imgH), bx0 = n, bx1 = std::min(n + sz + 1, imgW);
         double vnmax = 0;  // all-zero mask => 0; unmasked => zeros of the map
         bool any = false;
-        for (const Pt& q : pts) {
-            if (q.y < y0 || q.y >= y1 || q.x < x0 || q.x >= x1) continue;
-            if (q.y >= by0 && q.y < by1 && q.x >= bx0 && q.x < bx1) continue;
-            if (!any || q.v > vnmax) { vnmax = q.v; any = true; }
-        }
-        if (!masked && any && vnmax < 0) vnmax = 0;
+        // the neighbourhood reaches at most one block in every direction: only the points of those blocks are looked at
+        // (a maximum, so the visiting order does not matter)
+        for (int br = brow - 1; br <= brow + 1; ++br)
+            for (int bc = bcol - 1; bc <= bcol + 1; ++bc) {
+                if (br < 0 || bc < 0 || (br == brow && bc == bcol)) continue;
+                const Blk* nb = findBlock((int64_t)br * bcols + bc);
+                if (!nb) continue;
+                for (int t = nb->begin; t < nb->end; ++t) {
+                    const Pt& q = pts[byBlock[t]];
+                    if (q.y < y0 || q.y >= y1 || q.x < x0 || q.x >= x1) continue;
+                    if (!any || q.v > vnmax) { vnmax = q.v; any = true; }
+                }
+            }
         if (!masked) {
             // unmasked: zeros of the map inside the neighbourhood also count (value 0) whenever the
             // neighbourhood has at least one pixel outside the block
