@@ -1409,13 +1409,13 @@ void fd_wvm_finish(fd_ctx* ctx, fd_wvm* m, WvmRun& run) {
             HIP_CHECK(hipStreamSynchronize(ax));
         }
         const PosRec* raw = hraw + 1;
-        std::vector<uint32_t> order(cnt);
-        for (uint32_t i = 0; i < cnt; ++i) order[i] = i;
-        auto widof = [&](uint32_t i) { return ((uint64_t)raw[i].wid_hi << 32) | raw[i].wid_lo; };
-        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return widof(a) < widof(b); });
+        // extraction order = ascending window id (ids are unique): sort compact (id, slot) keys, not the records
+        std::vector<std::pair<uint64_t, uint32_t>> order(cnt);
+        for (uint32_t i = 0; i < cnt; ++i) order[i] = {((uint64_t)raw[i].wid_hi << 32) | raw[i].wid_lo, i};
+        std::sort(order.begin(), order.end());
         run.pos.resize(cnt);
         run.slots.resize(cnt);
-        for (uint32_t i = 0; i < cnt; ++i) { run.pos[i] = raw[order[i]]; run.slots[i] = order[i]; }
+        for (uint32_t i = 0; i < cnt; ++i) { run.pos[i] = raw[order[i].second]; run.slots[i] = order[i].second; }
     }
 }
 
