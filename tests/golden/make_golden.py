@@ -86,8 +86,53 @@ def main():
     for k, v in svmm.items():
         g["svm__" + k] = np.asarray(v)
     np.savez_compressed(os.path.join(OUT, "orc_cascade_160x120.npz"), **g)
+    next_rows()
     print("golden fixtures written to", OUT)
 
 
+def next_rows():
+    """orc_next_rows_128x96.npz: oracle regression vectors of the SURVEY 8(f) rows (FHOG on gray / BGR images, the aggregated
+    detector, the cascaded RVM, the whitening chain, one HistogramFilter variant) on a 128x96 frame."""
+    frame = synth.make_frame(128, 96, seed=91)
+    gray = O.bgr2gray(frame)
+    g = dict(frame=frame, gray=gray)
+    g["fhog_gray"] = O.fhog(gray, 8, 9, False, True, 0.2)
+    g["fhog_bgr"] = O.fhog(frame, 8, 9, False, True, 0.2)
+    g["fhog_gray_c4_b6_ib"] = O.fhog(gray, 4, 6, True, False, 0.2)
+    wts = np.random.default_rng(5).normal(0, 0.1, (4, 5, 31)).astype(np.float32)
+    so, co = O.aggregated_candidates(frame, wts, 0.05, -1e30, cell_size=8, octave_layers=4)
+    thr = float(np.float32(np.quantile(so, 0.9)))
+    sc, cc = O.aggregated_candidates(frame, wts, 0.05, thr, cell_size=8, octave_layers=4)
+    fs, fb = O.nms_iou(sc, cc, 0.3, 0)
+    g.update(agg_weights=wts, agg_threshold=np.float32(thr), agg_cand_scores=sc, agg_cand_boxes=np.asarray(cc, np.int32).reshape(-1, 4),
+             agg_final_scores=fs, agg_final_boxes=np.asarray(fb, np.int32).reshape(-1, 4))
+    # cascaded RVM on HistEq64 windows of a small pyramid
+    kw = dict(octave_layers=2, min_scale=0.4, max_scale=0.8)
+    pyr = O.Pyramid(**kw)
+    pyr.update(frame)
+    layers = [pyr.layer(i) for i in range(len(pyr.layers()))]
+    wins = pyr.windows(20, 20, 2, 2)
+    pat = np.stack([O.histeq64(np.ascontiguousarray(layers[lp][ly:ly + 20, lx:lx + 20])) for lp, lx, ly, *_ in wins])
+    feats = pat.reshape(len(pat), -1).astype(np.float32)
+    rvm = synth.make_rvm(13, feats[::3], 20, 20, n_filters=12, kernel=2)
+    lo, do = O.Rvm(rvm).eval(feats)
+    g.update(rvm_level=lo, rvm_dist=do)
+    for k, v in rvm.items():
+        g["rvm__" + k] = np.asarray(v)
+    # whitening chain and equalizeHist on a few patches
+    pp = np.stack([gray[y:y + 20, x:x + 20] for y, x in ((0, 0), (10, 30), (40, 77), (76, 108))])
+    g.update(whi_patches=pp, whi_out=np.stack([O.whi(q, 1.0, 0.390625) for q in pp]), eqhist_out=np.stack([O.equalize_hist(q) for q in pp]))
+    # interpolating HogFilter with signed + unsigned bins on the bin image of the last pyramid layer
+    pyr2 = O.Pyramid(**kw)
+    pyr2.set_layer_filter(kind=1, bins=8, signed_gradients=True, interpolate=True)
+    pyr2.update(frame)
+    L = pyr2.layer(len(pyr2.layers()) - 1)
+    g["hist_hog_interp"] = np.stack([O.hog_filter(np.ascontiguousarray(L[y:y + 20, x:x + 20]), 8, 5, 2, True, True) for y, x in ((0, 0), (7, 11), (15, 20))])
+    np.savez_compressed(os.path.join(OUT, "orc_next_rows_128x96.npz"), **g)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "next_rows":
+        next_rows()
+    else:
+        main()

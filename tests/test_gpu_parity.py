@@ -768,3 +768,36 @@ def test_error_paths_of_the_later_entry_points(capi, ctx, synth):
     with pytest.raises((capi.FdError, ValueError)):
         capi.extract_hist(ctx, pg, capi.hist_params(kind=0, pw=20, ph=20, bins=9, cell=5, block=9))   # block larger than the cell grid
     pg.close()
+
+
+def test_golden_next_rows_fixture(capi, ctx):
+    """Committed oracle vectors of the SURVEY 8(f) rows (tests/golden/orc_next_rows_128x96.npz): FHOG on gray / BGR images and the
+    aggregated detector bit-exact, RVM levels exact and distances to 1e-12, whitening chain to 1e-6, equalizeHist exact."""
+    g = np.load(os.path.join(G, "orc_next_rows_128x96.npz"))
+    frame = g["frame"]
+    pg = capi.Pyramid(ctx, octave_layers=2, min_scale=0.4, max_scale=0.8)
+    pg.update(frame)
+    gray = g["gray"]
+    assert np.array_equal(capi.fhog(ctx, gray=gray), g["fhog_gray"])
+    assert np.array_equal(capi.fhog(ctx, gray=frame), g["fhog_bgr"])
+    assert np.array_equal(capi.fhog(ctx, gray=gray, cell_size=4, unsigned_bins=6, interpolate_bins=True, interpolate_cells=False), g["fhog_gray_c4_b6_ib"])
+    det = capi.Aggregated(ctx, g["agg_weights"], 0.05, float(g["agg_threshold"]), cell_size=8, octave_layers=4, nms_overlap=0.3, nms_type=0)
+    fin, cand = det.detect(frame)
+    assert np.array_equal(cand["score"], g["agg_cand_scores"])
+    assert np.array_equal(np.stack([cand["x"], cand["y"], cand["w"], cand["h"]], 1), g["agg_cand_boxes"])
+    assert np.array_equal(fin["score"], g["agg_final_scores"])
+    assert np.array_equal(np.stack([fin["x"], fin["y"], fin["w"], fin["h"]], 1), g["agg_final_boxes"])
+    det.close()
+    m = {k[5:]: g[k] for k in g.files if k.startswith("rvm__")}
+    for k in ("kernel", "filter_w", "filter_h", "num_used"):
+        m[k] = int(m[k])
+    for k in ("p0", "p1", "p2", "logistic_a", "logistic_b", "bias"):
+        m[k] = float(m[k])
+    rg = capi.Rvm(ctx, m)
+    dets, lg, dg = capi.detect_rvm(ctx, pg, rg, feature_space=1, conv_scale=1.0, conv_shift=0.0, sx=2, sy=2)
+    assert np.array_equal(lg, g["rvm_level"])
+    assert np.allclose(dg, g["rvm_dist"], rtol=1e-12, atol=1e-12 * float(np.abs(g["rvm_dist"]).max()))
+    rg.close()
+    assert np.array_equal(capi.equalize_hist_batch(ctx, g["whi_patches"]), g["eqhist_out"])
+    assert np.allclose(capi.whi_batch(ctx, g["whi_patches"], 1.0, 0.390625), g["whi_out"], rtol=1e-6, atol=1e-9)
+    pg.close()

@@ -320,3 +320,36 @@ def test_fhog_against_numpy_restatement(oracle):
         f = oracle.fhog(img, *args)
         assert f.shape == (img.shape[0] // args[0], img.shape[1] // args[0], 3 * args[1] + 4)
         assert f.min() >= 0 and f[..., :3 * args[1]].max() <= 0.4 + 1e-6
+
+
+def _rvm_from_fixture(g):
+    m = {k[5:]: g[k] for k in g.files if k.startswith("rvm__")}
+    for k in ("kernel", "filter_w", "filter_h", "num_used"):
+        m[k] = int(m[k])
+    for k in ("p0", "p1", "p2", "logistic_a", "logistic_b", "bias"):
+        m[k] = float(m[k])
+    return m
+
+
+def test_next_rows_regression_vectors(oracle):
+    """tests/golden/orc_next_rows_128x96.npz (FHOG on gray / BGR images, aggregated detector, cascaded RVM, whitening chain,
+    interpolating HogFilter): the oracle must keep reproducing its committed outputs."""
+    g = np.load(os.path.join(G, "orc_next_rows_128x96.npz"))
+    frame = g["frame"]
+    gray = oracle.bgr2gray(frame)
+    assert np.array_equal(gray, g["gray"])
+    assert np.array_equal(oracle.fhog(gray, 8, 9, False, True, 0.2), g["fhog_gray"])
+    assert np.array_equal(oracle.fhog(frame, 8, 9, False, True, 0.2), g["fhog_bgr"])
+    assert np.array_equal(oracle.fhog(gray, 4, 6, True, False, 0.2), g["fhog_gray_c4_b6_ib"])
+    sc, cc = oracle.aggregated_candidates(frame, g["agg_weights"], 0.05, float(g["agg_threshold"]), cell_size=8, octave_layers=4)
+    assert np.array_equal(sc, g["agg_cand_scores"]) and np.array_equal(np.asarray(cc).reshape(-1, 4), g["agg_cand_boxes"])
+    fs, fb = oracle.nms_iou(sc, cc, 0.3, 0)
+    assert np.array_equal(fs, g["agg_final_scores"]) and np.array_equal(np.asarray(fb).reshape(-1, 4), g["agg_final_boxes"])
+    pyr = oracle.Pyramid(octave_layers=2, min_scale=0.4, max_scale=0.8)
+    pyr.update(frame)
+    layers = [pyr.layer(i) for i in range(len(pyr.layers()))]
+    pat = np.stack([oracle.histeq64(np.ascontiguousarray(layers[lp][ly:ly + 20, lx:lx + 20])) for lp, lx, ly, *_ in pyr.windows(20, 20, 2, 2)])
+    lo, do = oracle.Rvm(_rvm_from_fixture(g)).eval(pat.reshape(len(pat), -1).astype(np.float32))
+    assert np.array_equal(lo, g["rvm_level"]) and np.array_equal(do, g["rvm_dist"])
+    assert np.array_equal(np.stack([oracle.whi(q, 1.0, 0.390625) for q in g["whi_patches"]]), g["whi_out"])
+    assert np.array_equal(np.stack([oracle.equalize_hist(q) for q in g["whi_patches"]]), g["eqhist_out"])
