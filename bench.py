@@ -83,9 +83,11 @@ def main():
     ap.add_argument("--gather-every", type=int, default=8)
     ap.add_argument("--size", default="640x480", help="frame size WxH for the hog_svm / wvm workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=1,
-                    help="hog_svm workload: frames in flight (one context + stream each); the pyramid / HOG kernels of one frame "
-                         "overlap the MFMA SVM kernel of the previous one")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="frames in flight (0 = the workload's default).  hog_svm (default 1): one context + stream per frame, the "
+                         "pyramid / HOG kernels of one frame overlap the MFMA SVM kernel of the previous one.  ffp15 (default 1): one "
+                         "set of pyramids and detector handles per frame, the cascades of frame i+1 are queued "
+                         "(fd_five_stage_batch_begin) before the host stages of frame i run (fd_five_stage_batch_end)")
     ap.add_argument("--frames-per-step", type=int, default=4,
                     help="wvm workload: frames per step; their WVM stages are queued together (fd_detect_five_stage_batch), "
                          "so the host stages of one frame overlap the kernels of the next")
@@ -124,7 +126,7 @@ def main():
         del feats2
         # frames in flight: slot 0 is the context above; further slots have their own context (stream, scratch), pyramid and model copy
         slots = [(ctx, pyr, svm)]
-        for _ in range(1, max(1, args.inflight)):
+        for _ in range(1, max(1, args.inflight or 1)):
             c2 = capi.Context(local_rank)
             p2 = capi.Pyramid(c2, octave_layers=5, min_scale=1 / 16, max_scale=1.0)
             p2.set_layer_filter(capi.FD_LAYER_GRADBIN, bins=9)
@@ -242,32 +244,53 @@ def main():
         dframes = [torch.from_numpy(f).to(dev) for f in frames]
         from oracle import pyoracle as O  # calibration patches only
         gray = O.bgr2gray(synth.make_frame(640, 480, seed=20260927))
-        pyrs, dets = {}, []
+        nfly = max(1, args.inflight or 1)
+        models = []
         for di, (name, (inc, mn, mx, pw, ph, nper, nlev)) in enumerate(sorted(synth.DETECTOR_CFGS.items())):
-            key = (inc, mn, mx)
-            if key not in pyrs:
-                pyrs[key] = capi.Pyramid(ctx, inc=float(np.float32(inc)), min_scale=float(np.float32(mn)), max_scale=float(np.float32(mx)))
             src = gray[::4, ::4] if mx < 0.3 else gray[::2, ::2]
             calib = synth.random_patches(src.copy(), pw, ph, 6000, np.random.default_rng(100 + di))
             wm = synth.make_wvm(50 + di, fw=pw, fh=ph, n_per=nper, n_levels=nlev, calib_patches=calib, min_survivors=24)
             eq = synth.histeq64_np(synth.random_patches(src.copy(), pw, ph, 700, np.random.default_rng(200 + di)))
             sm = synth.make_svm_u8(300 + di, eq, nsv=512, calib=eq[512:])
-            dets.append((name, pyrs[key], capi.Wvm(ctx, wm), capi.Svm(ctx, sm), pw, ph))
-        for pr in pyrs.values():
-            pr.update(frames[0])
+            models.append((name, (inc, mn, mx), wm, sm, pw, ph))
+        # one set of pyramids + detector handles per frame in flight (a handle's scratch belongs to one run at a time)
+        sets = []
+        for _ in range(nfly):
+            pyrs, dets = {}, []
+            for name, key, wm, sm, pw, ph in models:
+                if key not in pyrs:
+                    pyrs[key] = capi.Pyramid(ctx, inc=float(np.float32(key[0])), min_scale=float(np.float32(key[1])), max_scale=float(np.float32(key[2])))
+                dets.append((name, pyrs[key], capi.Wvm(ctx, wm), capi.Svm(ctx, sm), pw, ph))
+            for pr in pyrs.values():
+                pr.update(frames[0])
+            sets.append((pyrs, dets))
+        pyrs, dets = sets[0]
         nwin_all = sum(pr.window_count(pw, ph, 1, 1) for _, pr, _, _, pw, ph in dets)
+        flying = []
+
+        def collect(batch):
+            return sum(len(d_) for d_, _ in batch.end())
 
         def step(i, sync=True):
+            # frame i: pyramids + all cascades are queued; then the host stages of the oldest frame in flight are collected
+            prs, dts = sets[i % nfly]
             f = dframes[i % 2]
-            for pr in pyrs.values():
+            for pr in prs.values():
                 pr.update_device(f.data_ptr(), W, H, 3)
-            res = capi.detect_five_stage_batch(ctx, [(pr, wv, sv_) for _, pr, wv, sv_, _, _ in dets], cap=1 << 16)
-            return nwin_all, sum(len(d_) for d_, _ in res)
+            flying.append(capi.FiveStageBatch(ctx, [(pr, wv, sv_) for _, pr, wv, sv_, _, _ in dts], cap=1 << 16))
+            npos = 0
+            while len(flying) >= nfly:
+                npos += collect(flying.pop(0))
+            return nwin_all, npos
+
+        def flush():
+            while flying:
+                collect(flying.pop(0))
 
         units_name = "windows"
         config = dict(workload="config 3: the 15 detectors of ffpDetectApp/*.cfg (five-stage WVM -> OE -> SVM -> NMS each), full %dx%d frame, "
                                "step 1: %d windows per frame; %d shared pyramids" % (W, H, nwin_all, len(pyrs)),
-                      frames_per_step=1, parallelism="image-shard dp%d" % world)
+                      frames_per_step=1, frames_in_flight=nfly, parallelism="image-shard dp%d" % world)
         dtype = "u8/f32/f64"
     else:
         B, W, H = 256, 256, 256
@@ -288,6 +311,8 @@ def main():
         dtype = "f32/f64"
 
     def barrier():
+        if args.workload == "ffp15":
+            flush()   # frames still in flight are collected inside the timed region
         if world > 1:
             dist.barrier()
         if args.workload == "hog_svm":
@@ -302,6 +327,8 @@ def main():
     while time.perf_counter() - tpre < 0.25:
         step(i)
         i += 1
+        if args.workload == "ffp15":
+            flush()
         torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)

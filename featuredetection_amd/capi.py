@@ -164,6 +164,8 @@ _SIGS = {
                                        C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "fd_nms_iou": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     "fd_wvm_svm_evaluate_samples": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fd_five_stage_batch_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "fd_five_stage_batch_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fd_detect_five_stage_batch": (C.c_int, [C.c_void_p, C.POINTER(fd_five_stage_job), C.c_int]),
     "fd_rvm_create": (C.c_int, [C.c_void_p, C.POINTER(fd_rvm_model), C.POINTER(C.c_void_p)]),
     "fd_rvm_destroy": (None, [C.c_void_p]),
@@ -417,9 +419,7 @@ def detect_five_stage(ctx, pyr, wvm, svm, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1,
     return out[:cnt.value], stages
 
 
-def detect_five_stage_batch(ctx, detectors, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1, cap=4096, device_frames=None):
-    """detectors: list of (pyramid, wvm, svm); returns [(detections, stage_counts)] in the same order.
-    device_frames: optional list of (device pointer, w, h, channels) per detector: the pyramid is updated inside the call"""
+def _five_stage_jobs(detectors, oe_dist, oe_ratio, sx, sy, cap, device_frames):
     n = len(detectors)
     jobs = (fd_five_stage_job * n)()
     outs = [np.zeros(cap, DET_DTYPE) for _ in range(n)]
@@ -430,8 +430,34 @@ def detect_five_stage_batch(ctx, detectors, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=
     if device_frames is not None:
         for j, (ptr, w, h, ch) in zip(jobs, device_frames):
             j.image, j.image_w, j.image_h, j.image_channels, j.image_is_device = ptr, w, h, ch, 1
-    ctx.check(lib().fd_detect_five_stage_batch(ctx.h, jobs, n))
+    return jobs, outs
+
+
+def _five_stage_results(jobs, outs):
     return [(o[:j.count], np.array(list(j.stage_counts), np.int32)) for j, o in zip(jobs, outs)]
+
+
+def detect_five_stage_batch(ctx, detectors, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1, cap=4096, device_frames=None):
+    """detectors: list of (pyramid, wvm, svm); returns [(detections, stage_counts)] in the same order.
+    device_frames: optional list of (device pointer, w, h, channels) per detector: the pyramid is updated inside the call"""
+    jobs, outs = _five_stage_jobs(detectors, oe_dist, oe_ratio, sx, sy, cap, device_frames)
+    ctx.check(lib().fd_detect_five_stage_batch(ctx.h, jobs, len(detectors)))
+    return _five_stage_results(jobs, outs)
+
+
+class FiveStageBatch:
+    """fd_five_stage_batch_begin / _end: begin queues the pyramid updates and cascades of all detectors and returns;
+    end() runs the host stages and returns [(detections, stage_counts)].  Batches in flight must use different handles."""
+    def __init__(self, ctx, detectors, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1, cap=4096, device_frames=None):
+        self.ctx = ctx
+        self.jobs, self.outs = _five_stage_jobs(detectors, oe_dist, oe_ratio, sx, sy, cap, device_frames)
+        self.ticket = C.c_void_p()
+        ctx.check(lib().fd_five_stage_batch_begin(ctx.h, self.jobs, len(detectors), C.byref(self.ticket)))
+
+    def end(self):
+        t, self.ticket = self.ticket, None
+        self.ctx.check(lib().fd_five_stage_batch_end(self.ctx.h, t))
+        return _five_stage_results(self.jobs, self.outs)
 
 
 def fhog(ctx, gray=None, pyramid=None, layer=0, cell_size=8, unsigned_bins=9, interpolate_bins=False, interpolate_cells=True, alpha=0.2):

@@ -1218,21 +1218,29 @@ void launch_sized(fd_ctx* ctx, hipStream_t st, int64_t total, const WvmDev& dev,
         // four windows per wavefront where four integral images leave enough LDS for the occupancy of the fixed part (measured per
         // kernel, pair -> quad: 20x20 -12 %, 16x24 -12 %, 24x24 -3 %, 32x16 0 %, 32x24 +19 %)
         constexpr bool quadFits = PW_ * PH_ <= 576 && PW_ <= 24;
-        if (quadFits && dev.numPer <= 32 && !single && !pairOnly && dev.numUsed > WVM_LCAP) {
+        bool quadLaunched = false;
+        if constexpr (quadFits) {
+          if (dev.numPer <= 32 && !single && !pairOnly && dev.numUsed > WVM_LCAP) {
             static int perCu4q = 0;
             if (perCu4q == 0) {
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu4q, k_wvm_cascade4<PW_, PH_, RAW>, 64 * WVM_QUAD_WAVES, 0) != hipSuccess || perCu4q < 1)
                     perCu4q = 4;
             }
-            const int grid4 = (int)std::min<int64_t>((total + 4 * WVM_QUAD_WAVES - 1) / (4 * WVM_QUAD_WAVES), (int64_t)ctx->num_cus * perCu4q * 2);
+            // rounds of resident workgroups: 2 = (almost) persistent; more rounds retire workgroups more often, which lets the
+            // high-priority follow-up kernels of other detectors / frames in between (FD_WVM_ROUNDS)
+            static const int rounds = [] { const char* e = getenv("FD_WVM_ROUNDS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
+            const int grid4 = (int)std::min<int64_t>((total + 4 * WVM_QUAD_WAVES - 1) / (4 * WVM_QUAD_WAVES), (int64_t)ctx->num_cus * perCu4q * rounds);
             hipLaunchKernelGGL((k_wvm_cascade4<PW_, PH_, RAW>), dim3(grid4), dim3(64 * WVM_QUAD_WAVES), 0, st, arena, wt, dev, o);
-            launched = true;
-        } else if (dev.numPer <= 32 && !single) {   // two windows per wavefront
+            launched = quadLaunched = true;
+          }
+        }
+        if (!quadLaunched && dev.numPer <= 32 && !single) {   // two windows per wavefront
             static int perCu2 = 0;
             if (perCu2 == 0) {
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu2, k_wvm_cascade2<PW_, PH_, RAW>, 256, 0) != hipSuccess || perCu2 < 1) perCu2 = 4;
             }
-            const int grid2 = (int)std::min<int64_t>((total + 7) / 8, (int64_t)ctx->num_cus * perCu2 * 2);
+            static const int rounds2 = [] { const char* e = getenv("FD_WVM_ROUNDS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
+            const int grid2 = (int)std::min<int64_t>((total + 7) / 8, (int64_t)ctx->num_cus * perCu2 * rounds2);
             hipLaunchKernelGGL((k_wvm_cascade2<PW_, PH_, RAW>), dim3(grid2), dim3(256), 0, st, arena, wt, dev, o);
             launched = true;
         }
@@ -1756,69 +1764,105 @@ int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const f
     });
 }
 
+struct fd_five_stage_batch {
+    fd_five_stage_job* jobs = nullptr;
+    int n = 0;
+    std::vector<WvmRun> runs;
+};
+
+static void five_stage_batch_begin(fd_ctx* ctx, fd_five_stage_job* jobs, int n, fd_five_stage_batch& b) {
+    if (!ctx || n < 0 || (n > 0 && !jobs)) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_batch: bad argument");
+    b.jobs = jobs;
+    b.n = n;
+    b.runs.assign((size_t)n, WvmRun());
+    for (int i = 0; i < n; ++i) {
+        fd_five_stage_job& j = jobs[i];
+        j.count = 0;
+        j.status = FD_OK;
+        if (!j.pyramid || !j.wvm || !j.svm) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_batch: NULL handle in job %d", i);
+        for (int k = 0; k < i; ++k)
+            if (jobs[k].wvm == j.wvm) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_batch: jobs %d and %d share a WVM handle", k, i);
+        five_stage_check(j.wvm, j.svm);
+    }
+    // jobs are spread over a few streams so that the small kernels of different jobs (pyramid levels, the deep
+    // cascade stage, the SVM stage) overlap each other; a job's optional frame upload / pyramid update runs on its stream
+    for (int i = 0; i < n; ++i) {
+        FdStreamSwap sw(ctx, fd_pool_stream(ctx, i));
+        fd_five_stage_job& j = jobs[i];
+        if (j.image) {
+            for (int k = 0; k < i; ++k)
+                if (jobs[k].pyramid == j.pyramid) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_batch: jobs %d and %d update the same pyramid", k, i);
+            const int rc = fd_pyramid_update(j.pyramid, j.image, j.image_w, j.image_h, j.image_channels, j.image_is_device);
+            if (rc != FD_OK) throw FdError{rc, ctx->error};
+        }
+        fd_wvm_launch(ctx, j.pyramid, const_cast<fd_wvm*>(j.wvm), j.step_x, j.step_y, j.roi, false, b.runs[i], false);
+    }
+}
+
+static void five_stage_batch_end(fd_ctx* ctx, fd_five_stage_batch& b) {
+    fd_five_stage_job* jobs = b.jobs;
+    const int n = b.n;
+    // The host takes the detectors one by one: as soon as a cascade is done, its positives are read back and
+    // thinned out by the overlap elimination while the GPU works on the later cascades; the SVM stage of the survivors is
+    // only queued (high-priority stream), and its NMS runs whenever the result has arrived, at the latest after the loop.
+    int firstError = FD_OK;
+    std::vector<FiveStageTail> tails((size_t)n);
+    std::vector<int> counts((size_t)n, 0);
+    auto fail = [&](int i, const FdError& e) {   // the remaining jobs are still collected; the first failure is reported
+        jobs[i].status = e.code;
+        if (firstError == FD_OK) { firstError = e.code; ctx->error = e.msg; }
+    };
+    auto finish = [&](int i) {
+        try {
+            tails[i].end();
+            jobs[i].count = counts[i];
+        } catch (const FdError& e) { fail(i, e); }
+    };
+    static const bool tailOnPool = getenv("FD_TAIL_ON_POOL") != nullptr;
+    for (int i = 0; i < n; ++i) {
+        fd_five_stage_job& j = jobs[i];
+        fd_wvm* m = const_cast<fd_wvm*>(j.wvm);
+        try {
+            fd_wvm_finish(ctx, m, b.runs[i]);
+            tails[i].begin(ctx, j.pyramid, m, j.svm, b.runs[i], j.oe_dist, j.oe_ratio, j.step_x, j.step_y, j.roi,
+                           tailOnPool ? fd_pool_stream(ctx, i) : fd_tail_stream(ctx), j.out, j.cap, &counts[i], j.stage_counts);
+        } catch (const FdError& e) {
+            tails[i].finished = true;
+            fail(i, e);
+        }
+        for (int k = 0; k < i; ++k)
+            if (!tails[k].finished && tails[k].ready()) finish(k);
+    }
+    for (int i = 0; i < n; ++i)
+        if (!tails[i].finished) finish(i);
+    if (firstError != FD_OK) throw FdError{firstError, ctx->error};
+}
+
 // Several five-stage detectors on (possibly shared) pyramids, as ffpDetectApp.cpp:557-600 loops over its detectors.  All
-// WVM stages are queued first on the context's stream; while the GPU works through them the host finishes the
-// detectors one by one (read-back, overlap elimination, the small SVM stage on an auxiliary stream, NMS).
+// cascades are queued first (begin); while the GPU works through them the host finishes the detectors one by one (end).
 int fd_detect_five_stage_batch(fd_ctx* ctx, fd_five_stage_job* jobs, int n) {
     return fd_guard(ctx, [&] {
-        if (!ctx || n < 0 || (n > 0 && !jobs)) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_batch: bad argument");
-        std::vector<WvmRun> runs((size_t)n);
-        for (int i = 0; i < n; ++i) {
-            fd_five_stage_job& j = jobs[i];
-            j.count = 0;
-            j.status = FD_OK;
-            if (!j.pyramid || !j.wvm || !j.svm) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_batch: NULL handle in job %d", i);
-            for (int k = 0; k < i; ++k)
-                if (jobs[k].wvm == j.wvm) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_batch: jobs %d and %d share a WVM handle", k, i);
-            five_stage_check(j.wvm, j.svm);
-        }
-        // jobs are spread over a few streams so that the small kernels of different jobs (pyramid levels, the deep
-        // cascade stage, the SVM stage) overlap each other; a job's optional frame upload / pyramid update runs on its stream
-        for (int i = 0; i < n; ++i) {
-            FdStreamSwap sw(ctx, fd_pool_stream(ctx, i));
-            fd_five_stage_job& j = jobs[i];
-            if (j.image) {
-                for (int k = 0; k < i; ++k)
-                    if (jobs[k].pyramid == j.pyramid) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_batch: jobs %d and %d update the same pyramid", k, i);
-                const int rc = fd_pyramid_update(j.pyramid, j.image, j.image_w, j.image_h, j.image_channels, j.image_is_device);
-                if (rc != FD_OK) throw FdError{rc, ctx->error};
-            }
-            fd_wvm_launch(ctx, j.pyramid, const_cast<fd_wvm*>(j.wvm), j.step_x, j.step_y, j.roi, false, runs[i], false);
-        }
-        // The host then finishes the detectors one by one: as soon as a cascade is done, its positives are read back and
-        // thinned out by the overlap elimination while the GPU works on the later cascades; the SVM stage of the survivors is
-        // only queued (high-priority stream), and its NMS runs whenever the result has arrived, at the latest after the loop.
-        int firstError = FD_OK;
-        std::vector<FiveStageTail> tails((size_t)n);
-        std::vector<int> counts((size_t)n, 0);
-        auto fail = [&](int i, const FdError& e) {   // the remaining jobs are still collected; the first failure is reported
-            jobs[i].status = e.code;
-            if (firstError == FD_OK) { firstError = e.code; ctx->error = e.msg; }
-        };
-        auto finish = [&](int i) {
-            try {
-                tails[i].end();
-                jobs[i].count = counts[i];
-            } catch (const FdError& e) { fail(i, e); }
-        };
-        static const bool tailOnPool = getenv("FD_TAIL_ON_POOL") != nullptr;
-        for (int i = 0; i < n; ++i) {
-            fd_five_stage_job& j = jobs[i];
-            fd_wvm* m = const_cast<fd_wvm*>(j.wvm);
-            try {
-                fd_wvm_finish(ctx, m, runs[i]);
-                tails[i].begin(ctx, j.pyramid, m, j.svm, runs[i], j.oe_dist, j.oe_ratio, j.step_x, j.step_y, j.roi,
-                               tailOnPool ? fd_pool_stream(ctx, i) : fd_tail_stream(ctx), j.out, j.cap, &counts[i], j.stage_counts);
-            } catch (const FdError& e) {
-                tails[i].finished = true;
-                fail(i, e);
-            }
-            for (int k = 0; k < i; ++k)
-                if (!tails[k].finished && tails[k].ready()) finish(k);
-        }
-        for (int i = 0; i < n; ++i)
-            if (!tails[i].finished) finish(i);
-        if (firstError != FD_OK) throw FdError{firstError, ctx->error};
+        fd_five_stage_batch b;
+        five_stage_batch_begin(ctx, jobs, n, b);
+        five_stage_batch_end(ctx, b);
+    });
+}
+
+int fd_five_stage_batch_begin(fd_ctx* ctx, fd_five_stage_job* jobs, int n, fd_five_stage_batch** ticket) {
+    if (ticket) *ticket = nullptr;
+    return fd_guard(ctx, [&] {
+        if (!ticket) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_five_stage_batch_begin: NULL ticket");
+        std::unique_ptr<fd_five_stage_batch> b(new fd_five_stage_batch());
+        five_stage_batch_begin(ctx, jobs, n, *b);
+        *ticket = b.release();
+    });
+}
+
+int fd_five_stage_batch_end(fd_ctx* ctx, fd_five_stage_batch* ticket) {
+    std::unique_ptr<fd_five_stage_batch> b(ticket);   // released whatever happens
+    return fd_guard(ctx, [&] {
+        if (!ctx || !b) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_five_stage_batch_end: NULL argument");
+        five_stage_batch_end(ctx, *b);
     });
 }
 

@@ -176,6 +176,14 @@ typedef struct {
     int32_t image_w, image_h, image_channels, image_is_device;
 } fd_five_stage_job;
 int fd_detect_five_stage_batch(fd_ctx* ctx, fd_five_stage_job* jobs, int n);
+/* The same in two halves, for callers that keep more than one frame in flight: begin validates the jobs, queues the optional
+ * pyramid updates and all cascades and returns at once; end runs the host stages (read-back, overlap elimination, the SVM stage,
+ * NMS) and fills out / count / stage_counts / status of every job.  `jobs` (and the buffers it points to) must stay alive and
+ * untouched until end returns; every batch that has begun must be ended (end also releases the ticket, whatever it returns).
+ * Two batches in flight must not share pyramid or WVM handles: their scratch buffers belong to one run at a time. */
+typedef struct fd_five_stage_batch fd_five_stage_batch;
+int fd_five_stage_batch_begin(fd_ctx* ctx, fd_five_stage_job* jobs, int n, fd_five_stage_batch** ticket);
+int fd_five_stage_batch_end(fd_ctx* ctx, fd_five_stage_batch* ticket);
 
 /* detection::OverlapElimination::eliminate (OverlapElimination.cpp:44-105); host-side, deterministic */
 int fd_overlap_elimination(const fd_detection* in, int n, float dist, float ratio, int32_t* keep_idx, int* count);

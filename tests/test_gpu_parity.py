@@ -801,3 +801,29 @@ def test_golden_next_rows_fixture(capi, ctx):
     assert np.array_equal(capi.equalize_hist_batch(ctx, g["whi_patches"]), g["eqhist_out"])
     assert np.allclose(capi.whi_batch(ctx, g["whi_patches"], 1.0, 0.390625), g["whi_out"], rtol=1e-6, atol=1e-9)
     pg.close()
+
+
+def test_five_stage_batch_in_two_halves_with_two_frames_in_flight(oracle, capi, ctx, synth, frame640, small_models):
+    """fd_five_stage_batch_begin / _end: the cascades of a second frame (its own pyramid and handles) are queued before the
+    first frame's host stages run; both frames return exactly the oracle's detections."""
+    wvm, svm = small_models
+    frames = [frame640, synth.make_frame(640, 480, seed=424242)]
+    sets, exp = [], []
+    for f in frames:
+        po = oracle.Pyramid(**FF); po.update(f)
+        exp.append(oracle.five_stage(po, oracle.Wvm(wvm), oracle.Svm(svm), 5.0, 0.0, 1, 1, None))
+        sets.append((capi.Pyramid(ctx, **FF), capi.Wvm(ctx, wvm), capi.Svm(ctx, svm)))
+        po.close()
+    import torch
+    dfr = [torch.from_numpy(f).cuda() for f in frames]
+    b0 = capi.FiveStageBatch(ctx, [sets[0]], device_frames=[(dfr[0].data_ptr(), 640, 480, 3)])
+    b1 = capi.FiveStageBatch(ctx, [sets[1]], device_frames=[(dfr[1].data_ptr(), 640, 480, 3)])
+    for b, (do, sto) in ((b0, exp[0]), (b1, exp[1])):
+        (dg, stg), = b.end()
+        assert np.array_equal(stg, sto)
+        _same_geometry(dg, do)
+        assert np.array_equal(dg["probability"], do["prob"])
+    with pytest.raises(capi.FdError):
+        capi.FiveStageBatch(ctx, [sets[0], sets[0]])   # two jobs sharing a WVM handle
+    for p_, w_, s_ in sets:
+        w_.close(); s_.close(); p_.close()
