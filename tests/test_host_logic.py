@@ -61,6 +61,43 @@ def test_overlap_elimination_large_clustered(oracle, capi):
         assert np.array_equal(oracle.overlap_elimination(o, dist, ratio), capi.overlap_elimination(c, dist, ratio))
 
 
+def test_overlap_elimination_extreme_extents_use_the_hash_grid(oracle, capi):
+    """Centres spread over +-2^30 make the dense cell grid too large: the open-addressed fallback must give the same result."""
+    rng = np.random.default_rng(5)
+    n = 3000
+    o, c = _random_dets(oracle, capi, rng, n, w=1920, h=1080)
+    far = rng.integers(0, n, n // 7)
+    o["cx"][far] = rng.integers(-2 ** 30, 2 ** 30, len(far))
+    o["cy"][far[::2]] = rng.integers(-2 ** 30, 2 ** 30, len(far[::2]))
+    o["prob"] = np.round(rng.random(n), 2)
+    for f in ("cx", "cy"):
+        c[f] = o[f]
+    c["probability"] = o["prob"]
+    for dist, ratio in ((5.0, 0.0), (0.3, 0.5)):
+        assert np.array_equal(oracle.overlap_elimination(o, dist, ratio), capi.overlap_elimination(c, dist, ratio))
+
+
+def test_block_nms_random_maps_with_out_of_range_and_nonpositive_entries(oracle, capi):
+    """sorted-vector block NMS against the dense restatement on random sparse maps: detections outside the image and with
+    probability <= 0 must be ignored exactly like the dense map does (the map keeps its 0)."""
+    rng = np.random.default_rng(12)
+    for trial in range(40):
+        W, H = int(rng.integers(40, 400)), int(rng.integers(40, 300))
+        n = int(rng.integers(1, 2500))
+        d = np.zeros(n, capi.DET_DTYPE)
+        d["cx"] = rng.integers(-3, W + 3, n); d["cy"] = rng.integers(-3, H + 3, n); d["w"] = 20; d["h"] = 20
+        d["probability"] = np.round(rng.random(n), 2) - 0.05
+        pmap = np.zeros((H, W), np.float32)
+        for q in d:
+            if 0 <= q["cx"] < W and 0 <= q["cy"] < H and pmap[q["cy"], q["cx"]] < q["probability"]:
+                pmap[q["cy"], q["cx"]] = q["probability"]
+        for masked in (True, False):
+            mask = ((pmap > np.float32(0.3)) * 255).astype(np.uint8) if masked else None
+            ys, xs = np.nonzero(oracle.block_nms(pmap, 35, mask))
+            got = capi.block_nms(d, W, H, 35, masked)
+            assert np.array_equal(np.asarray(got).reshape(-1, 2), np.stack([xs, ys], 1).astype(np.int32).reshape(-1, 2)), (trial, masked)
+
+
 @pytest.mark.parametrize("mtype", [0, 1, 2])
 def test_iou_nms_matches_oracle(oracle, capi, mtype):
     """detection::NonMaximumSuppression (IoU clustering) through the C ABI against the oracle, plus the defining property
