@@ -18,6 +18,7 @@
 // practice VALU/LDS bound; both figures are reported by bench.py --workload wvm.
 #include "fd_internal.hpp"
 #include <chrono>
+#include <thread>
 #include <algorithm>
 #include <cstring>
 #include <memory>
@@ -1772,6 +1773,7 @@ struct fd_five_stage_batch {
 
 static void five_stage_batch_begin(fd_ctx* ctx, fd_five_stage_job* jobs, int n, fd_five_stage_batch& b) {
     if (!ctx || n < 0 || (n > 0 && !jobs)) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_batch: bad argument");
+    const auto tBegin0 = std::chrono::steady_clock::now();
     b.jobs = jobs;
     b.n = n;
     b.runs.assign((size_t)n, WvmRun());
@@ -1797,11 +1799,18 @@ static void five_stage_batch_begin(fd_ctx* ctx, fd_five_stage_job* jobs, int n, 
         }
         fd_wvm_launch(ctx, j.pyramid, const_cast<fd_wvm*>(j.wvm), j.step_x, j.step_y, j.roi, false, b.runs[i], false);
     }
+    static const bool trace = getenv("FD_TRACE") != nullptr;
+    if (trace)
+        fprintf(stderr, "[fd batch] begin: %d cascades queued in %.1f us\n", n,
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tBegin0).count());
 }
 
 static void five_stage_batch_end(fd_ctx* ctx, fd_five_stage_batch& b) {
     fd_five_stage_job* jobs = b.jobs;
     const int n = b.n;
+    static const bool trace = getenv("FD_TRACE") != nullptr;
+    const auto tEnd0 = std::chrono::steady_clock::now();
+    double waitUs = 0;
     // The host takes the detectors one by one: as soon as a cascade is done, its positives are read back and
     // thinned out by the overlap elimination while the GPU works on the later cascades; the SVM stage of the survivors is
     // only queued (high-priority stream), and its NMS runs whenever the result has arrived, at the latest after the loop.
@@ -1819,22 +1828,59 @@ static void five_stage_batch_end(fd_ctx* ctx, fd_five_stage_batch& b) {
         } catch (const FdError& e) { fail(i, e); }
     };
     static const bool tailOnPool = getenv("FD_TAIL_ON_POOL") != nullptr;
-    for (int i = 0; i < n; ++i) {
+    static const bool inOrder = getenv("FD_BATCH_IN_ORDER") != nullptr;
+    // Detectors are taken in the order their cascades complete, not in job order: the streams of the pool do not advance evenly
+    // (a trace showed the first job's event 34 ms into a 38 ms frame while jobs 1..14 had long finished), and blocking on job 0
+    // would push every host stage behind the last cascade.  While nothing is ready the host polls (events of the cascades, then of
+    // the queued SVM stages).
+    std::vector<char> begun((size_t)n, 0);
+    auto cascadeReady = [&](int i) {
+        const fd_wvm* m = jobs[i].wvm;
+        return b.runs[i].total == 0 || hipEventQuery(m->done) != hipErrorNotReady;   // an error surfaces in fd_wvm_finish
+    };
+    for (int nbegun = 0; nbegun < n;) {
+        int pick = -1;
+        if (inOrder) {
+            for (int i = 0; i < n && pick < 0; ++i)
+                if (!begun[i]) pick = i;
+        } else {
+            for (int i = 0; i < n && pick < 0; ++i)
+                if (!begun[i] && cascadeReady(i)) pick = i;
+        }
+        if (pick < 0) {   // nothing to start: use the time for the NMS of a detector whose SVM stage has arrived, else yield
+            bool did = false;
+            for (int k = 0; k < n && !did; ++k)
+                if (begun[k] && !tails[k].finished && tails[k].ready()) { finish(k); did = true; }
+            if (!did) std::this_thread::yield();
+            continue;
+        }
+        const int i = pick;
+        begun[i] = 1;
+        ++nbegun;
         fd_five_stage_job& j = jobs[i];
         fd_wvm* m = const_cast<fd_wvm*>(j.wvm);
         try {
+            const auto tw0 = std::chrono::steady_clock::now();
             fd_wvm_finish(ctx, m, b.runs[i]);
+            if (trace) {
+                const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw0).count();
+                waitUs += us;
+                fprintf(stderr, "[fd batch] job %2d cascade wait + read-back %8.1f us (%zu positives)\n", i, us, b.runs[i].pos.size());
+            }
             tails[i].begin(ctx, j.pyramid, m, j.svm, b.runs[i], j.oe_dist, j.oe_ratio, j.step_x, j.step_y, j.roi,
                            tailOnPool ? fd_pool_stream(ctx, i) : fd_tail_stream(ctx), j.out, j.cap, &counts[i], j.stage_counts);
         } catch (const FdError& e) {
             tails[i].finished = true;
             fail(i, e);
         }
-        for (int k = 0; k < i; ++k)
-            if (!tails[k].finished && tails[k].ready()) finish(k);
+        for (int k = 0; k < n; ++k)
+            if (begun[k] && !tails[k].finished && tails[k].ready()) finish(k);
     }
     for (int i = 0; i < n; ++i)
         if (!tails[i].finished) finish(i);
+    if (trace)
+        fprintf(stderr, "[fd batch] end: %.1f us in total, %.1f us of it waiting for cascades\n",
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tEnd0).count(), waitUs);
     if (firstError != FD_OK) throw FdError{firstError, ctx->error};
 }
 
