@@ -1,21 +1,34 @@
 #!/usr/bin/env python
-"""bench.py -- BASELINE.json metric: Mpatches/s (extract + classify) on a 640x480 pyramid.
+"""bench.py -- BASELINE.json metric: "Mpatches/s (extract+WVM+SVM) per GPU, 640x480 pyramid; SDM iters/s".
 
-Default workload (N=1): BASELINE config 2 -- 640x480 frame, ImagePyramid(octaveLayerCount=5, 1/16..1),
-20x20 windows at stride 2 (278,142 windows/frame), HOG-324 features + RBF SVM with 1024 support
-vectors.  One step = one frame through pyramid build + HOG extraction + SVM scoring; frames are
-resident in HBM before the timed region.  --workload wvm / sdm time the cascade and SDM paths.
+Headline (N=1 and N>1): the FaceFrontal.cfg five-stage cascade (FiveStageSlidingWindowDetector.cpp:187-320: pyramid -> sliding
+HistEq64 windows -> WVM -> overlap elimination -> RBF-SVM -> block NMS) on 640x480 frames, through the product entry point
+fd_detect_five_stage_batch; every frame's fd_detection records reach the host inside the timed region.  One step =
+--frames-per-step frames (default 512, so that 20 steps take about a second).
 
-Prints ONE JSON line (rank 0).  Multi-GPU: one process per GPU (torch.distributed, RCCL), frames
-sharded across ranks (weak scaling), ONE gather of detection records every --gather-every steps."""
+The other BASELINE configs ride along as sub-records under "also" (same JSON line), each with its own ms_per_step, roofline and
+cpu_baseline:
+  hog_svm  config 2: 640x480, 21-layer pyramid, 20x20 windows stride 2, HOG-324 + RBF-SVM 1024 SV   (fd_detect_hog_svm_begin/_end)
+  ffp15    config 3: the 15 detectors of ffpDetectApp/*.cfg on a 1920x1080 frame                    (fd_five_stage_batch_begin/_end)
+  sdm      config 4: 256 face crops x 68 landmarks x 4 cascade steps                                 (fd_sdm_fit_batch)
+Frames are resident in HBM before the timed region.  Multi-GPU (config 5): one process per GPU (torch.distributed, RCCL), image i
+-> rank i mod N, no data-path collective, ONE all_gather of the real detection records {image, detector, cx, cy, w, h, score,
+prob} every --gather-every steps.  `python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run.
+
+The cpu_baseline legs (rank 0, N=1 only) time the CPU oracle (oracle/, "port" of the reference's single-threaded CPU path) on a
+bounded sample of the same workload: 1 thread with the update / extract / classify split of BASELINE.md section 3, and an
+image-parallel (detector-parallel for ffp15) run on every host core."""
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
-# torch initialises the HIP runtime before libfd_hip.so is loaded: same default as the library's load-time constructor
-# (eight hardware queues, so that the stream pool of the batch entry points does not share queues)
+# eight hardware queues, so that the stream pool of the batch entry points does not share queues; read by
+# the HIP runtime when it initialises, i.e. at the first HIP call of the process
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
@@ -25,383 +38,736 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense f32 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+PEAK_VALU_GINST = 256 * 4 * 2.4 / 4.0   # wave64 VALU instructions per ns: 1024 SIMD16 x 2.4 GHz / 4 cycles per wave64 instruction
 
 
-def cpu_baseline_hog_svm(frame2, model, seconds_hint=20):
-    """Oracle ("port" of the reference CPU path, single thread like the reference) on a bounded sample:
-    a 416x312 frame of the same recipe (about 12 s of CPU work), same pyramid/window/HOG/SVM parameters."""
-    from oracle import pyoracle as O
-    from featuredetection_amd import synth
-    crop = synth.make_frame(416, 312, seed=20260927)
-    p = O.Pyramid(octave_layers=5, min_scale=1 / 16, max_scale=1.0)
-    p.set_layer_filter(1, bins=9)
-    s = O.Svm(model)
-    t0 = time.perf_counter()
-    p.update(crop)
-    _, dist, _ = O.sliding_hog_svm(p, s, 20, 20, 2, 2, 9, 5, 2)
-    dt = time.perf_counter() - t0
-    return dict(value=len(dist) / dt / 1e6, unit="Mpatches/s", cores=1, kind="port",
-                sample="416x312 frame, %d windows, %.1f s, oracle -O2 single thread (pyramid+HOG+RBF-SVM 1024 SV)" % (len(dist), dt))
-
-
-def cpu_baseline_wvm(frame, wvm, svm):
-    from oracle import pyoracle as O
-    p = O.Pyramid(inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))
-    w, s = O.Wvm(wvm), O.Svm(svm)
-    t0 = time.perf_counter()
-    n = 0
-    reps = 0
-    while time.perf_counter() - t0 < 10:
-        p.update(frame)
-        O.five_stage(p, w, s)
-        n += 16185
-        reps += 1
-    dt = time.perf_counter() - t0
-    return dict(value=n / dt / 1e6, unit="Mpatches/s", cores=1, kind="port",
-                sample="%d x 640x480 FaceFrontal five-stage cascade (16,185 windows each), %.1f s, oracle -O2 single thread" % (reps, dt))
-
-
-def pmc_traffic(workload, kernel_substr):
-    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json,
-    produced by tools/pmc_traffic.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+# ---------------------------------------------------------------------------------------------------------------- helpers
+def host_info():
+    model = ""
     try:
-        rec = json.load(open(path)).get(workload)
-        if rec and kernel_substr in rec["kernel"]:
-            return float(rec["hbm_bytes_per_launch"])
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return model, cores
+
+
+def pmc_record(workload, kernel_substr):
+    """Counter figures per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/r02_pmc.json, written by
+    tools/pmc_summary.py from runs of this script; every entry names the command and the git head it was measured at)."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+        for k, v in rec.get(workload, {}).get("kernels", {}).items():
+            if kernel_substr in k:
+                out = dict(v)
+                out["kernel"] = k
+                out["source"] = rec[workload].get("source", "")
+                return out
     except Exception:
         pass
     return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="hog_svm", choices=["hog_svm", "wvm", "ffp15", "rvm", "aggregated", "sdm"])
-    ap.add_argument("--gather-every", type=int, default=8)
-    ap.add_argument("--size", default="640x480", help="frame size WxH for the hog_svm / wvm workloads")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=0,
-                    help="frames in flight (0 = the workload's default).  hog_svm (default 1): one context + stream per frame, the "
-                         "pyramid / HOG kernels of one frame overlap the MFMA SVM kernel of the previous one.  ffp15 (default 1): one "
-                         "set of pyramids and detector handles per frame, the cascades of frame i+1 are queued "
-                         "(fd_five_stage_batch_begin) before the host stages of frame i run (fd_five_stage_batch_end)")
-    ap.add_argument("--frames-per-step", type=int, default=4,
-                    help="wvm workload: frames per step; their WVM stages are queued together (fd_detect_five_stage_batch), "
-                         "so the host stages of one frame overlap the kernels of the next")
-    args = ap.parse_args()
+def run_threads(fn, n):
+    """fn(thread_index) on n Python threads (the oracle's ctypes calls release the GIL); returns the results"""
+    res = [None] * n
+    err = []
 
-    import torch
-    import torch.distributed as dist
-    from featuredetection_amd import capi, synth, parallel
+    def wrap(i):
+        try:
+            res[i] = fn(i)
+        except Exception as e:   # pragma: no cover
+            err.append(e)
+    ts = [threading.Thread(target=wrap, args=(i,)) for i in range(n)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if err:
+        raise err[0]
+    return res
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = capi.Context(local_rank, stream)
 
-    NFRAMES = 4  # distinct frames per rank, cycled
-    out = {}
-    FW, FH = [int(v) for v in args.size.split("x")]
-    if args.workload == "hog_svm":
-        W, H = FW, FH
-        frames = [synth.make_frame(W, H, seed=20260927 + 1000 * rank + i) for i in range(NFRAMES)]
-        dframes = [torch.from_numpy(f).to(dev) for f in frames]
-        pyr = capi.Pyramid(ctx, octave_layers=5, min_scale=1 / 16, max_scale=1.0)
+def cpu_record(units_1t, dt_1t, phases, units_nt, dt_nt, nthreads, sample, unit):
+    model, cores = host_info()
+    rec = dict(value=units_1t / dt_1t / 1e6, unit=unit, cores=1, kind="port", sample=sample, cpu_model=model, nproc=cores)
+    if phases:
+        rec["phases_s"] = phases
+    if units_nt:
+        rec["n_thread"] = dict(value=units_nt / dt_nt / 1e6, unit=unit, cores=nthreads)
+    return rec
+
+
+# ---------------------------------------------------------------------------------------------------------------- workloads
+class Workload:
+    name = ""
+    unit = "Mpatches/s"
+    dtype = ""
+    units_name = "windows"
+    records_cap = 1 << 16     # rows of the padded all_gather buffer (multi-GPU)
+    gather_every = None       # None: --gather-every
+
+    def step(self, i):
+        """one step; returns (units, [(image_id, detector_id, detections)])"""
+        raise NotImplementedError
+
+    def flush(self):
+        return []
+
+    def sync(self):
+        pass
+
+    def kernel_probe(self):
+        return None
+
+    def cpu_baseline(self):
+        return None
+
+
+def cascade_models():
+    """FaceFrontal WVM (280 filters) + RBF-SVM (1024 SV) calibrated on the config-1 frame; identical on every rank"""
+    from featuredetection_amd import synth
+    from oracle import pyoracle as O   # calibration patches only (bgr2gray of the calibration frame), untimed setup
+    gray = O.bgr2gray(synth.make_frame(640, 480, seed=20260927))
+    calib = synth.random_patches(gray[::4, ::4].copy(), 20, 20, 8000, np.random.default_rng(1))
+    wvm_m = synth.make_wvm(7, calib_patches=calib)
+    eq = synth.histeq64_np(synth.random_patches(gray[::4, ::4].copy(), 20, 20, 1400, np.random.default_rng(2)))
+    svm_m = synth.make_svm_u8(3, eq, nsv=1024, calib=eq[1024:])
+    return wvm_m, svm_m
+
+
+class Cascade(Workload):
+    """BASELINE headline: FaceFrontal five-stage cascade, WxH frames (default 640x480)"""
+    name = "cascade"
+    dtype = "u8/i32/f32/f64"
+
+    def __init__(self, env, W=640, H=480, frames_per_step=512, nb=4):
+        import torch
+        from featuredetection_amd import capi, synth
+        self.env, self.capi, self.W, self.H = env, capi, W, H
+        ctx = env.ctx
+        self.NB = max(1, min(nb, frames_per_step))
+        self.FP = max(self.NB, frames_per_step // self.NB * self.NB)
+        self.NFR = 8
+        frames = [synth.make_frame(W, H, seed=20260927 + 1000 * env.rank + i) for i in range(self.NFR)]
+        self.frames = frames
+        self.dframes = [torch.from_numpy(f).to(env.dev) for f in frames]
+        self.wvm_m, self.svm_m = cascade_models()
+        kw = dict(inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))
+        self.pyrs = [capi.Pyramid(ctx, **kw) for _ in range(self.NB)]
+        self.wvms = [capi.Wvm(ctx, self.wvm_m) for _ in range(self.NB)]   # one handle (scratch + read-back buffers) per frame in flight
+        self.svm = capi.Svm(ctx, self.svm_m)
+        self.pyrs[0].update(frames[0])
+        self.nwin = self.pyrs[0].window_count(20, 20, 1, 1)
+        self.layer_bytes = sum(l["w"] * l["h"] for l in self.pyrs[0].layers())
+        self.nlayers = len(self.pyrs[0].layers())
+        self.metric = "Mpatches/s (extract+WVM+SVM) per GPU, %dx%d pyramid" % (W, H)
+        self.config = dict(workload="config 1/metric config: ffpDetectApp FaceFrontal.cfg five-stage cascade on %dx%d BGR frames: %d-layer pyramid, 20x20 "
+                                    "windows step 1 (%d windows/frame), HistEq64 -> WVM 280 filters -> OE -> RBF-SVM 1024 SV -> NMS; "
+                                    "fd_detect_five_stage_batch, detections delivered per frame" % (W, H, self.nlayers, self.nwin),
+                           frames_per_step=self.FP, frames_per_call=self.NB, parallelism="image-shard dp%d" % env.world)
+
+    def step(self, i):
+        capi, NB = self.capi, self.NB
+        out = []
+        base = i * self.FP
+        for c in range(self.FP // NB):
+            fr = [(self.dframes[(base + c * NB + j) % self.NFR].data_ptr(), self.W, self.H, 3) for j in range(NB)]
+            res = capi.detect_five_stage_batch(self.env.ctx, [(self.pyrs[j], self.wvms[j], self.svm) for j in range(NB)], device_frames=fr)
+            for j, (d_, _) in enumerate(res):
+                out.append(((base + c * NB + j) * self.env.world + self.env.rank, 0, d_))
+        return self.nwin * self.FP, out
+
+    def kernel_probe(self):
+        """hipEvent-timed duration of the cascade kernels (all WVM stages) of single-frame calls + the roofline entries"""
+        capi, ctx = self.capi, self.env.ctx
+        ctx.set_kernel_timing(True)
+        ms = []
+        for i in range(12):
+            self.pyrs[0].update_device(self.dframes[i % self.NFR].data_ptr(), self.W, self.H, 3)
+            capi.detect_five_stage(ctx, self.pyrs[0], self.wvms[0], self.svm)
+            ms.append(ctx.last_kernel_ms()[1])
+        ctx.set_kernel_timing(False)
+        kms = float(np.mean(ms[2:]))
+        bytes_per_launch = self.layer_bytes + self.nwin * 16
+        ach = bytes_per_launch / (kms * 1e-3) / 1e9
+        pm = pmc_record("cascade" if (self.W, self.H) == (640, 480) else "cascade_%dx%d" % (self.W, self.H), "k_wvm")
+        roof = dict(bound="hbm", kernel="k_wvm_* (all WVM stages of one frame)", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s",
+                    frac=ach / PEAK_HBM_GBS, traffic=pm.get("hbm_bytes") if pm else None, kernel_ms=kms,
+                    algorithmic="%d layer bytes + 16 B record x %d windows per frame (SURVEY 8(d))" % (self.layer_bytes, self.nwin))
+        extra = {}
+        if pm and pm.get("valu_insts"):
+            ai = pm["valu_insts"] / (kms * 1e-3) / 1e9
+            extra["roofline_issue"] = dict(bound="valu-issue", achieved=ai, peak=PEAK_VALU_GINST, unit="G wave-instr/s", frac=ai / PEAK_VALU_GINST,
+                                           valu_insts_per_frame=pm["valu_insts"], source=pm.get("source"),
+                                           note="SQ_INSTS_VALU per frame (rocprofv3 --pmc) / live kernel time; peak = 1024 SIMD x 2.4 GHz / 4 cycles")
+        return roof, extra
+
+    def cpu_baseline(self):
+        from oracle import pyoracle as O
+        kw = dict(inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))
+        wvm_m, svm_m, frames, nwin = self.wvm_m, self.svm_m, self.frames, self.nwin
+        if (self.W, self.H) != (640, 480):
+            return None
+
+        def worker(budget, split):
+            def run(t):
+                p, w, s = O.Pyramid(**kw), O.Wvm(wvm_m), O.Svm(svm_m)
+                if split:
+                    O.phase_timing(True)
+                t0 = time.perf_counter()
+                n, tu = 0, 0.0
+                while time.perf_counter() - t0 < budget:
+                    tu0 = time.perf_counter()
+                    p.update(frames[(t + n) % len(frames)])
+                    tu += time.perf_counter() - tu0
+                    O.five_stage(p, w, s)
+                    n += 1
+                dt = time.perf_counter() - t0
+                ph = O.phase_times() if split else (0, 0)
+                if split:
+                    O.phase_timing(False)
+                return n, dt, tu, ph
+            return run
+        n1, dt1, tu, (te, tc) = worker(8.0, True)(0)
+        _, cores = host_info()
+        nt = min(cores, 64)
+        rs = run_threads(worker(8.0, False), nt)
+        un, dtn = sum(r[0] for r in rs) * nwin, max(r[1] for r in rs)
+        return cpu_record(n1 * nwin, dt1, dict(update=tu, extract=te, classify=tc, total=dt1), un, dtn, nt,
+                          "%d x 640x480 FaceFrontal five-stage frames (16,185 windows each) in %.1f s, oracle -O2, 1 thread; "
+                          "n_thread: one frame stream per thread" % (n1, dt1), "Mpatches/s")
+
+
+class HogSvm(Workload):
+    """config 2: 640x480, ImagePyramid(octl=5, 1/16..1), 20x20 windows stride 2, HOG-324 + RBF SVM (1024 SV)"""
+    name = "hog_svm"
+    dtype = "f32"
+    records_cap = 1 << 17     # a single-stage detector returns every positive window (~2.8 k per frame here)
+    gather_every = 1
+
+    def __init__(self, env, W=640, H=480, frames_per_step=32, inflight=2):
+        import torch
+        from featuredetection_amd import capi, synth
+        self.env, self.capi, self.W, self.H = env, capi, W, H
+        self.FP = max(1, frames_per_step)
+        self.NFR = 4
+        self.frames = [synth.make_frame(W, H, seed=20260927 + 1000 * env.rank + i) for i in range(self.NFR)]
+        self.dframes = [torch.from_numpy(f).to(env.dev) for f in self.frames]
+        ctx = env.ctx
+        mk = lambda c: capi.Pyramid(c, octave_layers=5, min_scale=1 / 16, max_scale=1.0)
+        pyr = mk(ctx)
         pyr.set_layer_filter(capi.FD_LAYER_GRADBIN, bins=9)
-        hp = capi.hog_params(20, 20, 2, 2, 9, 5, 2, False)
-        # model: SVs drawn from the HOG features of a second seeded frame (same on every rank)
-        pyr.update(synth.make_frame(W, H, seed=4242))
-        feats2 = capi.extract_hog(ctx, pyr, hp)
-        model = synth.make_svm_f32(20260927, feats2, nsv=1024, gamma=0.5, positive_fraction=0.01)
-        svm = capi.Svm(ctx, model)
+        self.hp = capi.hog_params(20, 20, 2, 2, 9, 5, 2, False)
+        pyr.update(synth.make_frame(W, H, seed=4242))   # model: SVs drawn from the HOG features of a second seeded frame
+        feats2 = capi.extract_hog(ctx, pyr, self.hp)
+        self.model = synth.make_svm_f32(20260927, feats2, nsv=1024, gamma=0.5, positive_fraction=0.01)
         del feats2
-        # frames in flight: slot 0 is the context above; further slots have their own context (stream, scratch), pyramid and model copy
-        slots = [(ctx, pyr, svm)]
-        for _ in range(1, max(1, args.inflight or 1)):
-            c2 = capi.Context(local_rank)
-            p2 = capi.Pyramid(c2, octave_layers=5, min_scale=1 / 16, max_scale=1.0)
+        # frames in flight: one context (stream + scratch), pyramid and model copy each
+        self.slots = [(ctx, pyr, capi.Svm(ctx, self.model))]
+        for _ in range(1, max(1, inflight)):
+            c2 = capi.Context(env.local_rank)
+            p2 = mk(c2)
             p2.set_layer_filter(capi.FD_LAYER_GRADBIN, bins=9)
-            slots.append((c2, p2, capi.Svm(c2, model)))
+            self.slots.append((c2, p2, capi.Svm(c2, self.model)))
+        pyr.update(self.frames[0])
+        self.nwin = pyr.window_count(20, 20, 2, 2)
+        self.flying = []
+        self.metric = "Mpatches/s (extract+HOG+RBF-SVM), %dx%d pyramid" % (W, H)
+        self.config = dict(workload="config 2: %dx%d BGR frame, ImagePyramid(octl=5, 1/16..1) %d layers, 20x20 windows stride 2 (%d windows/frame), "
+                                    "GradientFilter+GradientBinning(9) layers, HogFilter(9,cell 5,block 2)=324 f32, RBF-SVM 1024 SV gamma 0.5; "
+                                    "fd_detect_hog_svm_begin/_end, detections delivered per frame" % (W, H, len(pyr.layers()), self.nwin),
+                           frames_per_step=self.FP, frames_in_flight=len(self.slots), parallelism="image-shard dp%d" % env.world)
 
-        def step(i, sync=False):
-            # asynchronous: pyramid + HOG + SVM + positive selection are only enqueued; detections stay in HBM
-            f = dframes[i % NFRAMES]
-            c_, p_, s_ = slots[0] if sync else slots[i % len(slots)]
-            p_.update_device(f.data_ptr(), W, H, 3)
-            return capi.bench_hog_svm(c_, p_, s_, hp, sync=sync)
+    def _collect(self):
+        img, run = self.flying.pop(0)
+        return (img, 0, run.end())
 
-        units_name = "windows"
-        config = dict(workload="config2: 640x480 BGR frame, ImagePyramid(octl=5, 1/16..1) 21 layers, 20x20 windows stride 2, "
-                               "GradientFilter+GradientBinning(9) layers, HogFilter(9,cell 5,block 2)=324 f32, RBF-SVM 1024 SV gamma 0.5",
-                      frames_per_step=1, frames_in_flight=len(slots), parallelism="image-shard dp%d" % world)
-        dtype = "f32"
-    elif args.workload == "wvm":
-        W, H = FW, FH
-        frames = [synth.make_frame(W, H, seed=20260927 + 1000 * rank + i) for i in range(NFRAMES)]
-        dframes = [torch.from_numpy(f).to(dev) for f in frames]
-        from oracle import pyoracle as O  # only to build the calibration patches identically to tests
-        gray = O.bgr2gray(synth.make_frame(640, 480, seed=20260927))   # models calibrated on the config-1 frame, whatever --size is
-        calib = synth.random_patches(gray[::4, ::4].copy(), 20, 20, 8000, np.random.default_rng(1))
-        wvm_m = synth.make_wvm(7, calib_patches=calib)
-        eq = synth.histeq64_np(synth.random_patches(gray[::4, ::4].copy(), 20, 20, 1400, np.random.default_rng(2)))
-        svm_m = synth.make_svm_u8(3, eq, nsv=1024, calib=eq[1024:])
-        NB = max(1, args.frames_per_step)
-        pyrs = [capi.Pyramid(ctx, inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))
-                for _ in range(NB)]
-        wvms = [capi.Wvm(ctx, wvm_m) for _ in range(NB)]   # one handle (scratch + read-back buffers) per frame in flight
-        svm = capi.Svm(ctx, svm_m)
-        pyr = pyrs[0]
-        pyr.update(frames[0])
-        nwin_wvm = pyr.window_count(20, 20, 1, 1)
-        layer_bytes = sum(l["w"] * l["h"] for l in pyr.layers())
+    def step(self, i):
+        out = []
+        for j in range(self.FP):
+            f = i * self.FP + j
+            c_, p_, s_ = self.slots[f % len(self.slots)]
+            if len(self.flying) >= len(self.slots):
+                out.append(self._collect())
+            p_.update_device(self.dframes[f % self.NFR].data_ptr(), self.W, self.H, 3)
+            self.flying.append((f * self.env.world + self.env.rank, self.capi.HogSvmRun(c_, p_, s_, self.hp)))
+        return self.nwin * self.FP, out
 
-        def step(i, sync=True):
-            if NB == 1:
-                pyrs[0].update_device(dframes[i % NFRAMES].data_ptr(), W, H, 3)
-                dets, st = capi.detect_five_stage(ctx, pyrs[0], wvms[0], svm)
-                return nwin_wvm, len(dets)
-            fr = [(dframes[(i * NB + j) % NFRAMES].data_ptr(), W, H, 3) for j in range(NB)]
-            res = capi.detect_five_stage_batch(ctx, [(pyrs[j], wvms[j], svm) for j in range(NB)], device_frames=fr)
-            return nwin_wvm * NB, sum(len(d_) for d_, _ in res)
+    def flush(self):
+        out = []
+        while self.flying:
+            out.append(self._collect())
+        return out
 
-        units_name = "windows"
-        config = dict(workload="FaceFrontal.cfg five-stage cascade on a %dx%d frame: %d-layer pyramid, 20x20 windows step 1 (%d windows), "
-                               "WVM 280 filters -> OE -> RBF-SVM 1024 SV -> NMS" % (W, H, len(pyr.layers()), nwin_wvm),
-                      frames_per_step=NB, parallelism="image-shard dp%d" % world)
-        dtype = "u8/f32/f64"
-    elif args.workload == "rvm":
-        # SURVEY 8(f) row 1: SlidingWindowDetector + ProbabilisticRvmClassifier ("prvm"), hq64 feature space + ConversionFilter
-        W, H = FW, FH
-        frames = [synth.make_frame(W, H, seed=20260927 + 1000 * rank + i) for i in range(NFRAMES)]
-        dframes = [torch.from_numpy(f).to(dev) for f in frames]
+    def sync(self):
+        for c_, _, _ in self.slots[1:]:
+            c_.synchronize()
+
+    def kernel_probe(self):
+        capi = self.capi
+        c_, p_, s_ = self.slots[0]
+        c_.set_kernel_timing(True)
+        ms = []
+        for i in range(10):
+            p_.update_device(self.dframes[i % self.NFR].data_ptr(), self.W, self.H, 3)
+            capi.detect_hog_svm(c_, p_, s_, self.hp, want_all=False, cap=1 << 16)
+            ms.append(c_.last_kernel_ms()[1])
+        c_.set_kernel_timing(False)
+        kms = float(np.mean(ms[2:]))
+        flops = 2.0 * 324 * 1024 * self.nwin
+        ach = flops / (kms * 1e-3) / 1e12
+        pm = pmc_record("hog_svm", "k_svm_rbf_mfma") if (self.W, self.H) == (640, 480) else None
+        return dict(bound="mfma", kernel="k_svm_rbf_mfma_svs", achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F32_MFMA_TFLOPS,
+                    traffic=pm.get("hbm_bytes") if pm else None, traffic_source=pm.get("source") if pm else None, kernel_ms=kms,
+                    algorithmic="2*324*1024 flop/window x %d windows/launch" % self.nwin), {}
+
+    def cpu_baseline(self):
+        from oracle import pyoracle as O
+        from featuredetection_amd import synth
+        model = self.model
+        SW, SH = 320, 240
+
+        def run(t, split=False):
+            crop = synth.make_frame(SW, SH, seed=20260927 + t)
+            p = O.Pyramid(octave_layers=5, min_scale=1 / 16, max_scale=1.0)
+            p.set_layer_filter(1, bins=9)
+            s = O.Svm(model)
+            if split:
+                O.phase_timing(True)
+            t0 = time.perf_counter()
+            p.update(crop)
+            tu = time.perf_counter() - t0
+            _, dist, _ = O.sliding_hog_svm(p, s, 20, 20, 2, 2, 9, 5, 2)
+            dt = time.perf_counter() - t0
+            ph = O.phase_times() if split else (0, 0)
+            if split:
+                O.phase_timing(False)
+            return len(dist), dt, tu, ph
+        n1, dt1, tu, (te, tc) = run(0, True)
+        _, cores = host_info()
+        nt = min(cores, 64)
+        rs = run_threads(run, nt)
+        return cpu_record(n1, dt1, dict(update=tu, extract=te, classify=tc, total=dt1), sum(r[0] for r in rs), max(r[1] for r in rs), nt,
+                          "one %dx%d frame of the same recipe (%d windows, %.1f s), same pyramid / HOG / SVM parameters, oracle -O2, 1 thread; "
+                          "n_thread: one frame per thread" % (SW, SH, n1, dt1), "Mpatches/s")
+
+
+def ffp15_models(nsv=1024):
+    """the 15 detectors of ffpDetectApp/*.cfg: (name, pyramid key, WVM, SVM, pw, ph); SURVEY 8(d) config 3: 1024 SVs each"""
+    from featuredetection_amd import synth
+    from oracle import pyoracle as O   # calibration patches only, untimed setup
+    gray = O.bgr2gray(synth.make_frame(640, 480, seed=20260927))
+    models = []
+    for di, (name, (inc, mn, mx, pw, ph, nper, nlev)) in enumerate(sorted(synth.DETECTOR_CFGS.items())):
+        src = gray[::4, ::4] if mx < 0.3 else gray[::2, ::2]
+        calib = synth.random_patches(src.copy(), pw, ph, 6000, np.random.default_rng(100 + di))
+        wm = synth.make_wvm(50 + di, fw=pw, fh=ph, n_per=nper, n_levels=nlev, calib_patches=calib, min_survivors=24)
+        eq = synth.histeq64_np(synth.random_patches(src.copy(), pw, ph, nsv + 200, np.random.default_rng(200 + di)))
+        sm = synth.make_svm_u8(300 + di, eq, nsv=nsv, calib=eq[nsv:])
+        models.append((name, (inc, mn, mx), wm, sm, pw, ph))
+    return models
+
+
+class Ffp15(Workload):
+    """config 3 (and the per-GPU work of config 5): 15 five-stage detectors on one 1920x1080 frame, 32.1 M windows"""
+    name = "ffp15"
+    dtype = "u8/i32/f32/f64"
+
+    def __init__(self, env, W=1920, H=1080, frames_per_step=1):
+        import torch
+        from featuredetection_amd import capi, synth
+        self.env, self.capi, self.W, self.H = env, capi, W, H
+        self.FP = max(1, frames_per_step)
+        self.frames = [synth.make_frame(W, H, seed=20260927 + 1000 * env.rank + i) for i in range(2)]
+        self.dframes = [torch.from_numpy(f).to(env.dev) for f in self.frames]
+        self.models = ffp15_models()
+        ctx = env.ctx
+        self.pyrs, self.dets = {}, []
+        for name, key, wm, sm, pw, ph in self.models:
+            if key not in self.pyrs:   # detectors with identical pyramid parameters share one pyramid (identical layers)
+                self.pyrs[key] = capi.Pyramid(ctx, inc=float(np.float32(key[0])), min_scale=float(np.float32(key[1])), max_scale=float(np.float32(key[2])))
+            self.dets.append((name, self.pyrs[key], capi.Wvm(ctx, wm), capi.Svm(ctx, sm), pw, ph))
+        for pr in self.pyrs.values():
+            pr.update(self.frames[0])
+        self.nwin = sum(pr.window_count(pw, ph, 1, 1) for _, pr, _, _, pw, ph in self.dets)
+        self.metric = "Mpatches/s (extract+WVM+SVM cascade, 15 detectors), %dx%d pyramid" % (W, H)
+        self.config = dict(workload="config 3: the 15 detectors of ffpDetectApp/*.cfg (five-stage WVM -> OE -> RBF-SVM 1024 SV -> NMS each), full %dx%d "
+                                    "frame, step 1: %d windows per frame; %d shared pyramids; fd_five_stage_batch_begin/_end" % (W, H, self.nwin, len(self.pyrs)),
+                           frames_per_step=self.FP, parallelism="image-shard dp%d" % env.world)
+
+    def step(self, i):
+        capi = self.capi
+        out = []
+        for j in range(self.FP):
+            f = i * self.FP + j
+            fr = self.dframes[f % 2]
+            for pr in self.pyrs.values():
+                pr.update_device(fr.data_ptr(), self.W, self.H, 3)
+            b = capi.FiveStageBatch(self.env.ctx, [(pr, wv, sv_) for _, pr, wv, sv_, _, _ in self.dets], cap=4096)
+            img = f * self.env.world + self.env.rank
+            for di, (d_, _) in enumerate(b.end()):
+                out.append((img, di, d_))
+        return self.nwin * self.FP, out
+
+    def kernel_probe(self):
+        """FaceFrontal's cascade kernels on the 1080p frame (single five-stage call) + the batch's issue roofline from the PMC passes"""
+        capi, ctx = self.capi, self.env.ctx
+        name, pr, wv, sv_, pw, ph = [d for d in self.dets if d[0] == "FaceFrontal"][0]
+        ctx.set_kernel_timing(True)
+        ms = []
+        for i in range(6):
+            pr.update_device(self.dframes[i % 2].data_ptr(), self.W, self.H, 3)
+            capi.detect_five_stage(ctx, pr, wv, sv_)
+            ms.append(ctx.last_kernel_ms()[1])
+        ctx.set_kernel_timing(False)
+        kms = float(np.mean(ms[1:]))
+        nwin = pr.window_count(pw, ph, 1, 1)
+        layer_bytes = sum(l["w"] * l["h"] for l in pr.layers())
+        ach = (layer_bytes + 16 * nwin) / (kms * 1e-3) / 1e9
+        pm = pmc_record("ffp15", "k_wvm") if (self.W, self.H) == (1920, 1080) else None
+        roof = dict(bound="hbm", kernel="k_wvm_* of the FaceFrontal detector (single call, %d windows)" % nwin, achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s",
+                    frac=ach / PEAK_HBM_GBS, traffic=None, kernel_ms=kms,
+                    algorithmic="%d layer bytes + 16 B record x %d windows" % (layer_bytes, nwin))
+        extra = {}
+        if pm and pm.get("valu_insts") and pm.get("kernel_ms"):
+            ai = pm["valu_insts"] / (pm["kernel_ms"] * 1e-3) / 1e9
+            extra["roofline_issue"] = dict(bound="valu-issue", achieved=ai, peak=PEAK_VALU_GINST, unit="G wave-instr/s", frac=ai / PEAK_VALU_GINST,
+                                           source=pm.get("source"), note="all k_wvm_* launches of one frame: SQ_INSTS_VALU / summed kernel time (profile)")
+        return roof, extra
+
+    def cpu_baseline(self):
+        from oracle import pyoracle as O
+        from featuredetection_amd import synth
+        SW, SH = 480, 270
+        frame = synth.make_frame(SW, SH, seed=20260927)
+        models = self.models
+
+        def run_dets(idx, split=False):
+            if split:
+                O.phase_timing(True)
+            t0 = time.perf_counter()
+            n, tu = 0, 0.0
+            for di in idx:
+                name, key, wm, sm, pw, ph = models[di]
+                p = O.Pyramid(inc=float(np.float32(key[0])), min_scale=float(np.float32(key[1])), max_scale=float(np.float32(key[2])))
+                tu0 = time.perf_counter()
+                p.update(frame)
+                tu += time.perf_counter() - tu0
+                n += len(p.windows(pw, ph, 1, 1))
+                O.five_stage(p, O.Wvm(wm), O.Svm(sm), cap=1 << 16)
+            dt = time.perf_counter() - t0
+            ph_ = O.phase_times() if split else (0, 0)
+            if split:
+                O.phase_timing(False)
+            return n, dt, tu, ph_
+        n1, dt1, tu, (te, tc) = run_dets(range(len(models)), True)
+        _, cores = host_info()
+        nt = min(cores, len(models))
+        rs = run_threads(lambda t: run_dets(range(t, len(models), nt)), nt)
+        return cpu_record(n1, dt1, dict(update=tu, extract=te, classify=tc, total=dt1), sum(r[0] for r in rs), max(r[1] for r in rs), nt,
+                          "the 15 detectors on one %dx%d frame of the same recipe (%d windows, %.1f s; the reference rebuilds the pyramid per detector), "
+                          "oracle -O2, 1 thread; n_thread: detectors spread over threads" % (SW, SH, n1, dt1), "Mpatches/s")
+
+
+class Sdm(Workload):
+    """config 4: 256 gray 256x256 face crops, 68 landmarks, 4 cascaded regressors on adaptive VlHog descriptors"""
+    name = "sdm"
+    unit = "M SDM iters/s"
+    dtype = "f32/f64"
+    units_name = "sdm_iters"
+
+    def __init__(self, env, batches_per_step=32):
+        import torch
+        from featuredetection_amd import capi, synth
+        self.env, self.capi = env, capi
+        self.B, self.W, self.H = 256, 256, 256
+        self.FP = max(1, batches_per_step)
+        imgs = np.stack([synth.make_frame(self.W, self.H, seed=9000 + 1000 * env.rank + i, channels=1) for i in range(16)])
+        self.imgs16 = imgs
+        imgs = np.concatenate([imgs] * (self.B // 16))
+        self.dimgs = torch.from_numpy(imgs).to(env.dev)
+        self.model = synth.make_sdm(9, L=68, S=4)
+        self.sdm = capi.Sdm(env.ctx, self.model)
+        self.boxes = np.array([[48, 48, 160, 160]] * self.B, np.int32)
+        self.metric = "SDM iters/s (x1e6): 68 landmarks, HOG at each point + linear regressor, 4 cascade steps, batch of 256 face crops"
+        self.config = dict(workload="config 4: 256 gray 256x256 crops, 68 landmarks, 4 cascade steps, adaptive VlHog 3x3x31 per landmark + regressor "
+                                    "18973x136 (f64 MFMA); fd_sdm_fit_batch, shapes delivered per batch", batches_per_step=self.FP,
+                           parallelism="face-shard dp%d" % env.world)
+
+    def step(self, i):
+        for _ in range(self.FP):
+            self.sdm.fit_device(self.dimgs.data_ptr(), self.W, self.H, self.B, self.boxes)
+        return self.B * 4 * self.FP, []
+
+    def kernel_probe(self):
+        ctx = self.env.ctx
+        ctx.set_kernel_timing(True)
+        ms = []
+        for _ in range(8):
+            self.sdm.fit_device(self.dimgs.data_ptr(), self.W, self.H, self.B, self.boxes)
+            ms.append(ctx.last_kernel_ms()[1])
+        ctx.set_kernel_timing(False)
+        kms = float(np.mean(ms[2:]))
+        items = self.B * 68
+        # SURVEY 8(d): compulsory bytes of a descriptor = its source crop (<= (2*wsh)^2 u8, here ~46x46) + 279 f32 written
+        bytes_per_launch = items * (46 * 46 + 4 * 279)
+        ach = bytes_per_launch / (kms * 1e-3) / 1e9
+        pm = pmc_record("sdm", "k_sdm_descriptors")
+        roof = dict(bound="hbm", kernel="k_sdm_descriptors", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
+                    traffic=pm.get("hbm_bytes") if pm else None, kernel_ms=kms,
+                    algorithmic="(46x46 B crop + 279 f32) x %d (face, landmark) items per launch" % items)
+        extra = {}
+        if pm and pm.get("valu_insts"):
+            ai = pm["valu_insts"] / (kms * 1e-3) / 1e9
+            extra["roofline_issue"] = dict(bound="valu-issue", achieved=ai, peak=PEAK_VALU_GINST, unit="G wave-instr/s", frac=ai / PEAK_VALU_GINST,
+                                           source=pm.get("source"))
+        return roof, extra
+
+    def cpu_baseline(self):
+        from oracle import pyoracle as O
+        imgs, model = self.imgs16, self.model
+
+        def run(t, budget=6.0):
+            t0 = time.perf_counter()
+            n = 0
+            while time.perf_counter() - t0 < budget:
+                O.sdm_fit(imgs[(t + n) % 16], model, [48, 48, 160, 160])
+                n += 1
+            return n * 4, time.perf_counter() - t0
+        n1, dt1 = run(0)
+        _, cores = host_info()
+        nt = min(cores, 64)
+        rs = run_threads(run, nt)
+        return cpu_record(n1, dt1, None, sum(r[0] for r in rs), max(r[1] for r in rs), nt,
+                          "%d faces x 4 cascade steps (68 landmarks) in %.1f s, oracle -O2, 1 thread; n_thread: one face stream per thread" % (n1 // 4, dt1),
+                          "M SDM iters/s")
+
+
+class Rvm(Workload):
+    """SURVEY 8(f) row 1 (not a BASELINE config): SlidingWindowDetector + ProbabilisticRvmClassifier"""
+    name = "rvm"
+    dtype = "u8/f32/f64"
+
+    def __init__(self, env, W=1920, H=1080):
+        import torch
+        from featuredetection_amd import capi, synth
         from oracle import pyoracle as O  # calibration patches only
+        self.env, self.capi, self.W, self.H = env, capi, W, H
+        self.dframes = [torch.from_numpy(synth.make_frame(W, H, seed=20260927 + 1000 * env.rank + i)).to(env.dev) for i in range(4)]
         gray = O.bgr2gray(synth.make_frame(640, 480, seed=20260927))
         calib = synth.histeq64_np(synth.random_patches(gray[::4, ::4].copy(), 20, 20, 6000, np.random.default_rng(1)))
         feats = calib.reshape(len(calib), -1).astype(np.float32) * np.float32(1.0 / 255.0)
-        rvm_m = synth.make_rvm(9, feats, 20, 20, n_filters=100, kernel=2, pass_rate=0.5)
-        pyr = capi.Pyramid(ctx, inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))
-        rvm = capi.Rvm(ctx, rvm_m)
-        pyr.update(frames[0])
-        nwin_rvm = pyr.window_count(20, 20, 1, 1)
+        self.pyr = capi.Pyramid(env.ctx, inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))
+        self.rvm = capi.Rvm(env.ctx, synth.make_rvm(9, feats, 20, 20, n_filters=100, kernel=2, pass_rate=0.5))
+        self.pyr.update_device(self.dframes[0].data_ptr(), W, H, 3)
+        self.nwin = self.pyr.window_count(20, 20, 1, 1)
+        self.metric = "Mpatches/s (extract+HistEq64+RVM cascade), %dx%d pyramid" % (W, H)
+        self.config = dict(workload="prvm single detector: FaceFrontal pyramid on a %dx%d frame, 20x20 windows step 1 (%d windows), hq64 + "
+                                    "ConversionFilter(CV_32F, 1/255), RBF RVM with 100 reduced set vectors" % (W, H, self.nwin), frames_per_step=1)
 
-        def step(i, sync=True):
-            f = dframes[i % NFRAMES]
-            pyr.update_device(f.data_ptr(), W, H, 3)
-            d_, _, _ = capi.detect_rvm(ctx, pyr, rvm, feature_space=capi.FEATURE_HQ64, conv_scale=1.0 / 255.0, want_all=False)
-            return nwin_rvm, len(d_)
+    def step(self, i):
+        self.pyr.update_device(self.dframes[i % 4].data_ptr(), self.W, self.H, 3)
+        d_, _, _ = self.capi.detect_rvm(self.env.ctx, self.pyr, self.rvm, feature_space=self.capi.FEATURE_HQ64, conv_scale=1.0 / 255.0, want_all=False)
+        return self.nwin, [(i * self.env.world + self.env.rank, 0, d_)]
 
-        units_name = "windows"
-        config = dict(workload="prvm single detector: FaceFrontal pyramid on a %dx%d frame, 20x20 windows step 1 (%d windows), hq64 + "
-                               "ConversionFilter(CV_32F, 1/255), RBF RVM with 100 reduced set vectors" % (W, H, nwin_rvm),
-                      frames_per_step=1, parallelism="image-shard dp%d" % world)
-        dtype = "u8/f32/f64"
-    elif args.workload == "aggregated":
-        # SURVEY 8(f) row 2: AggregatedFeaturesDetector (GrayscaleFilter + FhogFilter(8, 9), 10x10-cell window, 5 layers per octave)
-        W, H = (FW, FH) if args.size != "640x480" else (1920, 1080)
-        frames = [synth.make_frame(W, H, seed=20260927 + 1000 * rank + i) for i in range(2)]
+
+class Aggregated(Workload):
+    """SURVEY 8(f) row 2 (not a BASELINE config): AggregatedFeaturesDetector (FHOG + linear SVM convolution + IoU NMS)"""
+    name = "aggregated"
+    unit = "Mwindows/s"
+    dtype = "u8/f32"
+
+    def __init__(self, env, W=1920, H=1080):
+        import torch
+        from featuredetection_amd import capi, synth
+        self.env, self.capi, self.W, self.H = env, capi, W, H
+        self.dframes = [torch.from_numpy(synth.make_frame(W, H, seed=20260927 + 1000 * env.rank + i)).to(env.dev) for i in range(2)]
         wts = np.random.default_rng(3).normal(0, 0.05, (10, 10, 31)).astype(np.float32)
-        det = capi.Aggregated(ctx, wts, 0.1, 1.5, octave_layers=5, nms_overlap=0.3)
-        _, cand0 = det.detect(frames[0])
-        # windows = valid score positions over all layers (the unit of this detector)
-        from oracle import pyoracle as O  # only to count the positions with the same pyramid rules
-        nwin_agg = len(O.aggregated_candidates(frames[0], wts, 0.1, -1e30, octave_layers=5)[0]) if (W * H) <= 640 * 480 else None
-        if nwin_agg is None:
-            inc = 0.5 ** (1 / 5)
-            k, nwin_agg = 0, 0
-            while True:
-                sc = inc ** k
-                lw, lh = int(round(W * sc)), int(round(H * sc))
-                if lw // 8 < 10 or lh // 8 < 10:
-                    break
-                nwin_agg += (lw // 8 - 9) * (lh // 8 - 9)
-                k += 1
+        self.det = capi.Aggregated(env.ctx, wts, 0.1, 1.5, octave_layers=5, nms_overlap=0.3)
+        inc, k, n = 0.5 ** (1 / 5), 0, 0
+        while True:
+            sc = inc ** k
+            lw, lh = int(round(W * sc)), int(round(H * sc))
+            if lw // 8 < 10 or lh // 8 < 10:
+                break
+            n += (lw // 8 - 9) * (lh // 8 - 9)
+            k += 1
+        self.nwin = n
+        self.metric = "Mwindows/s (FHOG pyramid + linear SVM convolution + NMS), %dx%d" % (W, H)
+        self.config = dict(workload="AggregatedFeaturesDetector: %dx%d BGR frame, FhogFilter(8, 9 bins), 10x10-cell linear SVM, 5 layers per octave, "
+                                    "~%d window positions, IoU NMS 0.3 on the host" % (W, H, n), frames_per_step=1)
 
-        dframes = [torch.from_numpy(f).to(dev) for f in frames]
+    def step(self, i):
+        self.det.detect_device(self.dframes[i % 2].data_ptr(), self.W, self.H, 3)
+        return self.nwin, []
 
-        def step(i, sync=True):
-            fin, _ = det.detect_device(dframes[i % 2].data_ptr(), W, H, 3)
-            return nwin_agg, len(fin)
 
-        units_name = "windows"
-        config = dict(workload="AggregatedFeaturesDetector: %dx%d BGR frame, FhogFilter(8, 9 bins, cell interpolation), 10x10-cell linear SVM, "
-                               "5 layers per octave, ~%d window positions, IoU NMS 0.3 on the host" % (W, H, nwin_agg),
-                      frames_per_step=1, parallelism="image-shard dp%d" % world)
-        dtype = "u8/f32"
-    elif args.workload == "ffp15":
-        # BASELINE config 2/4 shape: all 15 detectors of ffpDetectApp/*.cfg full-frame (SURVEY.md App. D: 32.1 M windows
-        # per 1080p frame).  Detectors with identical pyramid parameters share one pyramid (identical layers).
-        W, H = (FW, FH) if args.size != "640x480" else (1920, 1080)
-        frames = [synth.make_frame(W, H, seed=20260927 + 1000 * rank + i) for i in range(2)]
-        dframes = [torch.from_numpy(f).to(dev) for f in frames]
-        from oracle import pyoracle as O  # calibration patches only
-        gray = O.bgr2gray(synth.make_frame(640, 480, seed=20260927))
-        nfly = max(1, args.inflight or 1)
-        models = []
-        for di, (name, (inc, mn, mx, pw, ph, nper, nlev)) in enumerate(sorted(synth.DETECTOR_CFGS.items())):
-            src = gray[::4, ::4] if mx < 0.3 else gray[::2, ::2]
-            calib = synth.random_patches(src.copy(), pw, ph, 6000, np.random.default_rng(100 + di))
-            wm = synth.make_wvm(50 + di, fw=pw, fh=ph, n_per=nper, n_levels=nlev, calib_patches=calib, min_survivors=24)
-            eq = synth.histeq64_np(synth.random_patches(src.copy(), pw, ph, 700, np.random.default_rng(200 + di)))
-            sm = synth.make_svm_u8(300 + di, eq, nsv=512, calib=eq[512:])
-            models.append((name, (inc, mn, mx), wm, sm, pw, ph))
-        # one set of pyramids + detector handles per frame in flight (a handle's scratch belongs to one run at a time)
-        sets = []
-        for _ in range(nfly):
-            pyrs, dets = {}, []
-            for name, key, wm, sm, pw, ph in models:
-                if key not in pyrs:
-                    pyrs[key] = capi.Pyramid(ctx, inc=float(np.float32(key[0])), min_scale=float(np.float32(key[1])), max_scale=float(np.float32(key[2])))
-                dets.append((name, pyrs[key], capi.Wvm(ctx, wm), capi.Svm(ctx, sm), pw, ph))
-            for pr in pyrs.values():
-                pr.update(frames[0])
-            sets.append((pyrs, dets))
-        pyrs, dets = sets[0]
-        nwin_all = sum(pr.window_count(pw, ph, 1, 1) for _, pr, _, _, pw, ph in dets)
-        flying = []
+# ---------------------------------------------------------------------------------------------------------------- driver
+class Env:
+    pass
 
-        def collect(batch):
-            return sum(len(d_) for d_, _ in batch.end())
 
-        def step(i, sync=True):
-            # frame i: pyramids + all cascades are queued; then the host stages of the oldest frame in flight are collected
-            prs, dts = sets[i % nfly]
-            f = dframes[i % 2]
-            for pr in prs.values():
-                pr.update_device(f.data_ptr(), W, H, 3)
-            flying.append(capi.FiveStageBatch(ctx, [(pr, wv, sv_) for _, pr, wv, sv_, _, _ in dts], cap=1 << 16))
-            npos = 0
-            while len(flying) >= nfly:
-                npos += collect(flying.pop(0))
-            return nwin_all, npos
-
-        def flush():
-            while flying:
-                collect(flying.pop(0))
-
-        units_name = "windows"
-        config = dict(workload="config 3: the 15 detectors of ffpDetectApp/*.cfg (five-stage WVM -> OE -> SVM -> NMS each), full %dx%d frame, "
-                               "step 1: %d windows per frame; %d shared pyramids" % (W, H, nwin_all, len(pyrs)),
-                      frames_per_step=1, frames_in_flight=nfly, parallelism="image-shard dp%d" % world)
-        dtype = "u8/f32/f64"
-    else:
-        B, W, H = 256, 256, 256
-        imgs = np.stack([synth.make_frame(W, H, seed=9000 + 1000 * rank + i, channels=1) for i in range(16)])
-        imgs = np.concatenate([imgs] * (B // 16))
-        dimgs = torch.from_numpy(imgs).to(dev)
-        model = synth.make_sdm(9, L=68, S=4)
-        sdm = capi.Sdm(ctx, model)
-        boxes = np.array([[48, 48, 160, 160]] * B, np.int32)
-
-        def step(i, sync=True):
-            sdm.fit_device(dimgs.data_ptr(), W, H, B, boxes)
-            return B * 4, 0
-
-        units_name = "sdm_iters"
-        config = dict(workload="config4: 256 gray 256x256 crops, 68 landmarks, 4 cascade steps, adaptive VlHog 3x3x31 + regressor 18973x136",
-                      frames_per_step=B, parallelism="face-shard dp%d" % world)
-        dtype = "f32/f64"
+def measure(wl, env, steps, warmup, gather_every, want_cpu):
+    import gc
+    import torch
+    import torch.distributed as dist
+    from featuredetection_amd import parallel
+    world, dev = env.world, env.dev
+    recs_cap = wl.records_cap
+    gather_every = wl.gather_every or gather_every
+    truncated = False
 
     def barrier():
-        if args.workload == "ffp15":
-            flush()   # frames still in flight are collected inside the timed region
+        wl.flush_out = wl.flush()
         if world > 1:
             dist.barrier()
-        if args.workload == "hog_svm":
-            for c_, _, _ in slots[1:]:
-                c_.synchronize()
+        wl.sync()
         torch.cuda.synchronize()
 
-    # setup: bring clocks, the stream pools and the pinned staging buffers to their steady state before the W warm-up steps
-    # (a 20 ms timed region after an idle start measures the power-management ramp, not the path)
+    # bring clocks, stream pools and pinned staging buffers to their steady state before the W warm-up steps
     tpre = time.perf_counter()
-    i = 0
-    while time.perf_counter() - tpre < 0.25:
-        step(i)
+    wl.step(0)
+    wl.flush()
+    est = time.perf_counter() - tpre
+    i = 1
+    while time.perf_counter() - tpre < 0.3 and est < 0.15:
+        wl.step(i)
         i += 1
-        if args.workload == "ffp15":
-            flush()
-        torch.cuda.synchronize()
-    for i in range(args.warmup):
-        step(i)
-    # a full Python gc pass over torch's object graph costs ~75 ms and would land on a random step
-    import gc
+    wl.flush()
+    for i in range(warmup):
+        wl.step(i)
     gc.collect()
-    gc.disable()
-    kernel_ms = []
-    recs_cap = 4096
+    gc.disable()   # a full gc pass over torch's object graph costs ~75 ms and would land on a random step
     barrier()
     t0 = time.perf_counter()
-    units = 0
-    pending = []
-    for i in range(args.steps):
-        n, npos = step(i)
+    units, ndet, pending, gathered = 0, 0, [], 0
+    for i in range(steps):
+        n, out = wl.step(i)
         units += n
-        pending.append((i, npos or 0))
-        if world > 1 and ((i + 1) % args.gather_every == 0 or i + 1 == args.steps):
-            local = np.array([[rank * 1e6 + s, 0, 0, 0, 0, 0, 0, p] for s, p in pending], np.float64)
-            parallel.gather_records(local, recs_cap, device=dev)
+        pending.extend(out)
+        if (i + 1) % gather_every == 0 or i + 1 == steps:
+            pending.extend(wl.flush())
+            # the detection records of this rank's images since the last gather: real fd_detection fields
+            recs = [parallel.pack_records(np.full(len(d_), img), np.full(len(d_), det), d_) for img, det, d_ in pending if len(d_)]
+            local = np.concatenate(recs) if recs else np.zeros((0, parallel.RECORD_FIELDS))
+            ndet += len(local)
+            if world > 1:
+                allr, tr = parallel.gather_records(local, recs_cap, device=dev)
+                gathered += len(allr)
+                truncated |= tr
             pending = []
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    uu = torch.tensor([float(units)], dtype=torch.float64, device=dev)
+    uu = torch.tensor([float(units), float(ndet)], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(uu, op=dist.ReduceOp.SUM)
-    dt, total_units = float(tt.item()), float(uu.item())
-
-    if args.workload == "wvm":
-        # cascade kernel duration (both stages): hipEvents on the launch stream, single-frame calls outside the timed region
-        for i in range(min(10, max(3, args.steps))):
-            pyrs[0].update_device(dframes[i % NFRAMES].data_ptr(), W, H, 3)
-            capi.detect_five_stage(ctx, pyrs[0], wvms[0], svm)
-            kernel_ms.append(ctx.last_kernel_ms()[1])
-    if args.workload == "hog_svm":
-        # dominant-kernel duration: hipEvents on the launch stream, synchronous steps outside the timed region
-        for i in range(min(10, max(3, args.steps))):
-            step(i, sync=True)
-            kernel_ms.append(ctx.last_kernel_ms()[1])
-    if rank == 0:
-        value = total_units / dt / 1e6
-        res = dict(metric="Mpatches/s (extract+HOG+RBF-SVM), 640x480 pyramid" if args.workload == "hog_svm" else
-                   ("Mpatches/s (extract+WVM+SVM cascade), %dx%d pyramid" % (W, H) if args.workload in ("wvm", "ffp15") else
-                    ("Mpatches/s (extract+HistEq64+RVM cascade), %dx%d pyramid" % (W, H) if args.workload == "rvm" else
-                     ("Mwindows/s (FHOG pyramid + linear SVM convolution + NMS), %dx%d" % (W, H) if args.workload == "aggregated" else "SDM iters/s (x1e6)"))),
-                   value=value, unit="Mpatches/s" if args.workload != "sdm" else "M SDM iters/s", n_gpus=world, steps=args.steps,
-                   warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
-                   dtype=dtype, data="synthetic", config=config)
-        if args.workload == "hog_svm":
-            kms = float(np.mean(kernel_ms))
-            nwin = units / args.steps
-            flops = 2.0 * 324 * 1024 * nwin
-            ach = flops / (kms * 1e-3) / 1e12
-            res["roofline"] = dict(bound="mfma", kernel="k_svm_rbf_mfma", achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                                   frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=pmc_traffic("hog_svm", "k_svm_rbf_mfma") if (W, H) == (640, 480) else None,
-                                   kernel_ms=kms,
-                                   algorithmic="2*324*1024 flop/window x %d windows/launch" % nwin)
-            if not args.no_cpu_baseline:
-                res["cpu_baseline"] = cpu_baseline_hog_svm(None, model)
-        elif args.workload == "wvm":
-            kms = float(np.mean(kernel_ms))
-            bytes_per_launch = layer_bytes + nwin_wvm * 16
-            ach = bytes_per_launch / (kms * 1e-3) / 1e9
-            res["roofline"] = dict(bound="hbm", kernel="k_wvm_cascade", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
-                                   traffic=pmc_traffic("wvm", "k_wvm_cascade") if (W, H) == (640, 480) else None, kernel_ms=kms,
-                                   algorithmic="%d layer bytes + 16 B record x %d windows per launch" % (layer_bytes, nwin_wvm))
-            if not args.no_cpu_baseline:
-                res["cpu_baseline"] = cpu_baseline_wvm(synth.make_frame(640, 480, seed=20260927), wvm_m, svm_m)
-        print(json.dumps(res))
+    dt, total_units, total_det = float(tt.item()), float(uu[0].item()), int(uu[1].item())
+    rec = dict(metric=wl.metric, value=total_units / dt / 1e6, unit=wl.unit, n_gpus=world, steps=steps, warmup=warmup,
+               ms_per_step=dt / steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype=wl.dtype, data="synthetic",
+               config=wl.config, detections_delivered=total_det)
     if world > 1:
+        rec["records_gathered"] = gathered
+        rec["records_truncated"] = bool(truncated)
+    probe = wl.kernel_probe() if env.rank == 0 else None
+    if probe:
+        rec["roofline"] = probe[0]
+        rec.update(probe[1])
+    if want_cpu and env.rank == 0 and world == 1:
+        cb = wl.cpu_baseline()
+        if cb:
+            rec["cpu_baseline"] = cb
+    return rec
+
+
+WORKLOADS = dict(cascade=Cascade, hog_svm=HogSvm, ffp15=Ffp15, sdm=Sdm, rvm=Rvm, aggregated=Aggregated)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cascade", choices=sorted(WORKLOADS) + ["wvm"], help="headline workload (wvm = cascade)")
+    ap.add_argument("--also", default=None, help="comma-separated sub-records (default: hog_svm,ffp15,sdm when the headline is the "
+                                                 "default cascade; 'none' for none)")
+    ap.add_argument("--gather-every", type=int, default=4)
+    ap.add_argument("--size", default=None, help="frame size WxH of the headline workload (cascade, hog_svm, ffp15, rvm, aggregated)")
+    ap.add_argument("--frames-per-step", type=int, default=0, help="frames (sdm: batches) per step of the headline workload; 0 = its default")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    if args.workload == "wvm":
+        args.workload = "cascade"
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start one rank per GPU ourselves (the same command the driver uses for the scaling runs)
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+
+    import torch
+    import torch.distributed as dist
+    from featuredetection_amd import capi
+
+    env = Env()
+    env.world = int(os.environ.get("WORLD_SIZE", "1"))
+    env.rank = int(os.environ.get("RANK", "0"))
+    env.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if env.world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", env.local_rank))
+    torch.cuda.set_device(env.local_rank)
+    env.dev = torch.device("cuda", env.local_rank)
+    env.ctx = capi.Context(env.local_rank, torch.cuda.current_stream().cuda_stream)
+
+    def build(name, headline):
+        kw = {}
+        if headline and args.size and name != "sdm":
+            kw["W"], kw["H"] = [int(v) for v in args.size.split("x")]
+        if headline and args.frames_per_step > 0:
+            kw["batches_per_step" if name == "sdm" else "frames_per_step"] = args.frames_per_step
+            if name in ("rvm", "aggregated"):
+                kw.pop("frames_per_step")
+        return WORKLOADS[name](env, **kw)
+
+    also = args.also
+    if also is None:
+        also = "hog_svm,ffp15,sdm" if (args.workload == "cascade" and not args.size) else "none"
+    also = [a for a in also.split(",") if a and a != "none"]
+    want_cpu = not args.no_cpu_baseline
+
+    wl = build(args.workload, True)
+    res = measure(wl, env, args.steps, args.warmup, args.gather_every, want_cpu)
+    del wl
+    subs = []
+    for name in also:
+        w2 = build(name, False)
+        subs.append(measure(w2, env, args.steps, args.warmup, args.gather_every, want_cpu))
+        del w2
+    if env.rank == 0:
+        if subs:
+            res["also"] = subs
+        print(json.dumps(res))
+    if env.world > 1:
         dist.destroy_process_group()
 
 

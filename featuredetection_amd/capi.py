@@ -173,10 +173,8 @@ _SIGS = {
     "fd_detect_rvm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(fd_rvm_detect_params), C.c_void_p, C.c_void_p, C.c_int64,
                                 C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
     "fd_extract_hog": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fd_hog_params), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
-    "fd_bench_hog_svm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(fd_hog_params), C.POINTER(C.c_int64),
-                                   C.POINTER(C.c_int64)]),
-    "fd_bench_wvm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
-    "fd_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
+    "fd_detect_hog_svm_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(fd_hog_params), C.POINTER(C.c_void_p)]),
+    "fd_detect_hog_svm_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "fd_sdm_create": (C.c_int, [C.c_void_p, C.POINTER(fd_sdm_model), C.POINTER(C.c_void_p)]),
     "fd_sdm_destroy": (None, [C.c_void_p]),
     "fd_sdm_descriptors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -184,6 +182,12 @@ _SIGS = {
     "fd_sdm_fit_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                    C.c_void_p]),
     "fd_sdm_optimize_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+}
+
+# include/fd_hip_bench.h: measurement hooks (not part of the drop-in boundary)
+_BENCH_SIGS = {
+    "fd_ctx_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "fd_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
 }
 
 
@@ -195,7 +199,7 @@ def lib():
             raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
         l = C.CDLL(LIB_PATH)
-        for name, (res, args) in _SIGS.items():
+        for name, (res, args) in list(_SIGS.items()) + list(_BENCH_SIGS.items()):
             f = getattr(l, name)  # AttributeError if the ABI lost a symbol
             f.restype = res
             f.argtypes = args
@@ -229,6 +233,9 @@ class Context:
         if self.h:
             lib().fd_ctx_destroy(self.h)
             self.h = C.c_void_p()
+
+    def set_kernel_timing(self, enable=True):
+        self.check(lib().fd_ctx_set_kernel_timing(self.h, int(enable)))
 
     def last_kernel_ms(self):
         name = C.c_char_p()
@@ -422,7 +429,7 @@ def detect_five_stage(ctx, pyr, wvm, svm, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1,
 def _five_stage_jobs(detectors, oe_dist, oe_ratio, sx, sy, cap, device_frames):
     n = len(detectors)
     jobs = (fd_five_stage_job * n)()
-    outs = [np.zeros(cap, DET_DTYPE) for _ in range(n)]
+    outs = [np.empty(cap, DET_DTYPE) for _ in range(n)]   # the library fills the first `count` records
     for j, (pyr, wvm, svm), o in zip(jobs, detectors, outs):
         j.pyramid, j.wvm, j.svm = pyr.h, wvm.h, svm.h
         j.oe_dist, j.oe_ratio, j.step_x, j.step_y, j.roi = oe_dist, oe_ratio, sx, sy, None
@@ -434,7 +441,7 @@ def _five_stage_jobs(detectors, oe_dist, oe_ratio, sx, sy, cap, device_frames):
 
 
 def _five_stage_results(jobs, outs):
-    return [(o[:j.count], np.array(list(j.stage_counts), np.int32)) for j, o in zip(jobs, outs)]
+    return [(o[:j.count].copy(), np.array(list(j.stage_counts), np.int32)) for j, o in zip(jobs, outs)]
 
 
 def detect_five_stage_batch(ctx, detectors, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1, cap=4096, device_frames=None):
@@ -689,17 +696,20 @@ def detect_hog_svm(ctx, pyr, svm, hp, want_all=True, cap=1 << 20):
     return out[:cnt.value], alld
 
 
-def bench_hog_svm(ctx, pyr, svm, hp, sync=True):
-    """sync=False: enqueue only (no read-back, no host synchronisation); positives is then None."""
-    n, p = C.c_int64(), C.c_int64()
-    ctx.check(lib().fd_bench_hog_svm(ctx.h, pyr.h, svm.h, C.byref(hp), C.byref(n), C.byref(p) if sync else None))
-    return n.value, (p.value if sync else None)
+class HogSvmRun:
+    """fd_detect_hog_svm_begin / _end: the frame's kernels and read-back are queued by the constructor, end() collects the detections."""
 
+    def __init__(self, ctx, pyr, svm, hp, cap=1 << 14):
+        self.ctx, self.cap = ctx, cap
+        self.ticket = C.c_void_p()
+        ctx.check(lib().fd_detect_hog_svm_begin(ctx.h, pyr.h, svm.h, C.byref(hp), C.byref(self.ticket)))
 
-def bench_wvm(ctx, pyr, wvm, sx=1, sy=1):
-    n, p = C.c_int64(), C.c_int64()
-    ctx.check(lib().fd_bench_wvm(ctx.h, pyr.h, wvm.h, sx, sy, C.byref(n), C.byref(p)))
-    return n.value, p.value
+    def end(self):
+        out = np.empty(self.cap, DET_DTYPE)
+        cnt = C.c_int64()
+        t, self.ticket = self.ticket, C.c_void_p()
+        self.ctx.check(lib().fd_detect_hog_svm_end(self.ctx.h, t, _ptr(out), out.shape[0], C.byref(cnt)))
+        return out[:cnt.value].copy()
 
 
 class Sdm:

@@ -3,12 +3,11 @@
 #include <cstdlib>
 #include <cstring>
 
-// The batch entry points spread independent frames / detectors over a pool of HIP streams; with the runtime's default of
-// four hardware queues the pool, the context stream and the read-back stream share queues and the short dependent kernels
-// of different frames serialise (640x480 five-stage batch: 115 -> 145 Mpatches/s with eight).  The runtime reads the
-// variable when it initialises, i.e. at the first HIP call of the process: this runs when the library is loaded and never
-// overrides a value the user set.
-__attribute__((constructor)) static void fd_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// Deployment note: the batch entry points spread independent frames / detectors over a pool of HIP streams; with the runtime's
+// default of four hardware queues the pool, the context stream and the read-back stream share queues and the short dependent
+// kernels of different frames serialise (640x480 five-stage batch: 115 -> 145 Mpatches/s with GPU_MAX_HW_QUEUES=8).  The
+// variable is read when the HIP runtime initialises, so it is the host process's to set (bench.py does); the library does
+// not touch the process environment.
 
 extern "C" {
 
@@ -74,6 +73,12 @@ int fd_ctx_synchronize(fd_ctx* ctx) {
         if (!ctx) FD_THROW(FD_ERR_INVALID_ARGUMENT, "NULL context");
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
     });
+}
+
+int fd_ctx_set_kernel_timing(fd_ctx* ctx, int enable) {
+    if (!ctx) return FD_ERR_INVALID_ARGUMENT;
+    ctx->kernel_timing = enable != 0;
+    return FD_OK;
 }
 
 int fd_last_kernel_ms(fd_ctx* ctx, const char** kernel_name, float* ms) {

@@ -13,6 +13,7 @@
 #include <vector>
 #include <stdexcept>
 #include "../../include/fd_hip.h"
+#include "../../include/fd_hip_bench.h"
 
 struct FdPinned {   // pinned host scratch (allocated lazily): pageable async copies cost ~1 ms each on this stack
     void* p = nullptr;
@@ -24,7 +25,8 @@ struct fd_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string error;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // brackets the dominant kernel of fd_bench_* calls
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the dominant kernel of a detect call when kernel_timing is on (fd_hip_bench.h)
+    bool kernel_timing = false;
     const char* last_kernel = "";
     float last_kernel_ms = 0.f;
     int num_cus = 256;

@@ -402,76 +402,102 @@ int fd_extract_hog(fd_ctx* ctx, fd_pyramid* p, const fd_hog_params* hp, float* f
     });
 }
 
+// Asynchronous half of SlidingWindowDetector::detect for the HOG chain: pyramid layers -> HOG tiles -> MFMA SVM -> positive
+// selection are queued on the context's stream together with the read-back of the counter and the first positives into pinned
+// memory; nothing blocks.  One ticket per context at a time (the scratch buffers belong to one run).
+struct fd_hog_svm_ticket {
+    fd_pyramid* p = nullptr;
+    const fd_svm* svm = nullptr;
+    fd_hog_params hp;
+    std::vector<WindowLayer> wls;
+    int64_t N = 0;
+    unsigned int pcap = 0;
+    hipEvent_t done = nullptr;
+    bool timed = false;
+    ~fd_hog_svm_ticket() { if (done) (void)hipEventDestroy(done); }
+};
+constexpr unsigned int HOG_FIRST_CHUNK = 4096;   // positives fetched together with the counter
+
+static void hog_svm_begin(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_hog_params* hp, fd_hog_svm_ticket& t) {
+    HogScratch& S = scratch(ctx);
+    t.p = p; t.svm = svm; t.hp = *hp;
+    t.timed = ctx->kernel_timing;
+    t.N = run_hog_svm(ctx, p, svm, hp, t.wls, S, t.timed);
+    if (t.N == 0) return;
+    hipStream_t st = ctx->stream;
+    t.pcap = (unsigned int)std::min<int64_t>(t.N, 1 << 22);
+    // record 0 of the positive buffer is the header (counter), so that counter + first positives come back in one copy
+    S.pos.reserve(sizeof(HogPos) * ((size_t)t.pcap + 1));
+    S.hcount.reserve(sizeof(HogPos) * ((size_t)t.pcap + 1));
+    HIP_CHECK(hipMemsetAsync(S.pos.p, 0, sizeof(HogPos), st));
+    hipLaunchKernelGGL(k_select_positives, dim3((unsigned)std::min<int64_t>((t.N + 255) / 256, 2048)), dim3(256), 0, st,
+                       S.dist.as<double>(), t.N, fd_svm_threshold(svm), S.pos.as<HogPos>() + 1, S.pos.as<unsigned int>(), t.pcap);
+    HIP_CHECK(hipGetLastError());
+    const size_t first = std::min<size_t>(t.pcap, HOG_FIRST_CHUNK);
+    HIP_CHECK(hipMemcpyAsync(S.hcount.p, S.pos.p, sizeof(HogPos) * (first + 1), hipMemcpyDeviceToHost, st));
+    if (!t.done) HIP_CHECK(hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(t.done, st));
+}
+
+static void hog_svm_end(fd_ctx* ctx, fd_hog_svm_ticket& t, fd_detection* out, int64_t cap, int64_t* count, double* all_distance) {
+    *count = 0;
+    if (t.N == 0) return;
+    HogScratch& S = scratch(ctx);
+    hipStream_t st = ctx->stream;
+    HIP_CHECK(hipEventSynchronize(t.done));
+    if (t.timed) {
+        HIP_CHECK(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev0, ctx->ev1));
+        ctx->last_kernel = "k_svm_rbf_mfma";
+    }
+    HogPos* h = S.hcount.as<HogPos>();
+    const unsigned int cnt = h[0].wid_lo;
+    if (cnt > t.pcap) FD_THROW(FD_ERR_CAPACITY, "fd_detect_hog_svm: %u positives exceed the device buffer", cnt);
+    const size_t first = std::min<size_t>(t.pcap, HOG_FIRST_CHUNK);
+    if (cnt > first) HIP_CHECK(hipMemcpyAsync(h + 1 + first, S.pos.as<HogPos>() + 1 + first, sizeof(HogPos) * (cnt - first), hipMemcpyDeviceToHost, st));
+    if (all_distance) HIP_CHECK(hipMemcpyAsync(all_distance, S.dist.p, sizeof(double) * (size_t)t.N, hipMemcpyDeviceToHost, st));
+    if (cnt > first || all_distance) HIP_CHECK(hipStreamSynchronize(st));
+    HogPos* raw = h + 1;
+    auto widof = [](const HogPos& r) { return ((uint64_t)r.wid_hi << 32) | r.wid_lo; };
+    std::sort(raw, raw + cnt, [&](const HogPos& a, const HogPos& b) { return widof(a) < widof(b); });   // extraction order
+    *count = cnt;
+    for (unsigned int i = 0; i < cnt && out && (int64_t)i < cap; ++i) {
+        fd_detection d;
+        std::memset(&d, 0, sizeof(d));
+        window_geometry(t.p, t.wls, t.hp.step_x, t.hp.step_y, (int64_t)widof(raw[i]), d);
+        d.level = -1;
+        d.positive = 1;
+        d.score = (float)raw[i].dist;
+        d.probability = fd_svm_probability(t.svm, raw[i].dist);
+        out[i] = d;
+    }
+    if (out && (int64_t)cnt > cap) FD_THROW(FD_ERR_CAPACITY, "fd_detect_hog_svm: %u positives, capacity %lld", cnt, (long long)cap);
+}
+
 int fd_detect_hog_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_hog_params* hp, fd_detection* out, int64_t cap,
                       int64_t* count, double* all_distance) {
     return fd_guard(ctx, [&] {
         if (!ctx || !p || !svm || !hp || !count) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_hog_svm: NULL argument");
-        HogScratch& S = scratch(ctx);
-        std::vector<WindowLayer> wls;
-        const int64_t N = run_hog_svm(ctx, p, svm, hp, wls, S, false);
-        *count = 0;
-        if (N == 0) return;
-        hipStream_t st = ctx->stream;
-        const unsigned int pcap = (unsigned int)std::min<int64_t>(N, 1 << 22);
-        S.pos.reserve(sizeof(HogPos) * (size_t)pcap);
-        S.counter.reserve(256);
-        HIP_CHECK(hipMemsetAsync(S.counter.p, 0, 4, st));
-        hipLaunchKernelGGL(k_select_positives, dim3((unsigned)std::min<int64_t>((N + 255) / 256, 2048)), dim3(256), 0, st,
-                           S.dist.as<double>(), N, fd_svm_threshold(svm), S.pos.as<HogPos>(), S.counter.as<unsigned int>(), pcap);
-        HIP_CHECK(hipGetLastError());
-        unsigned int* hcnt = (unsigned int*)fd_pinned(ctx, 64);
-        HIP_CHECK(hipMemcpyAsync(hcnt, S.counter.p, 4, hipMemcpyDeviceToHost, st));
-        if (all_distance) HIP_CHECK(hipMemcpyAsync(all_distance, S.dist.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        const unsigned int cnt = *hcnt;
-        if (cnt > pcap) FD_THROW(FD_ERR_CAPACITY, "fd_detect_hog_svm: %u positives exceed the device buffer", cnt);
-        std::vector<HogPos> raw(cnt);
-        if (cnt) HIP_CHECK(hipMemcpy(raw.data(), S.pos.p, sizeof(HogPos) * cnt, hipMemcpyDeviceToHost));
-        auto widof = [](const HogPos& r) { return ((uint64_t)r.wid_hi << 32) | r.wid_lo; };
-        std::sort(raw.begin(), raw.end(), [&](const HogPos& a, const HogPos& b) { return widof(a) < widof(b); });
-        *count = cnt;
-        for (unsigned int i = 0; i < cnt && out && (int64_t)i < cap; ++i) {
-            fd_detection d;
-            std::memset(&d, 0, sizeof(d));
-            window_geometry(p, wls, hp->step_x, hp->step_y, (int64_t)widof(raw[i]), d);
-            d.level = -1;
-            d.positive = 1;
-            d.score = (float)raw[i].dist;
-            d.probability = fd_svm_probability(svm, raw[i].dist);
-            out[i] = d;
-        }
-        if (out && (int64_t)cnt > cap) FD_THROW(FD_ERR_CAPACITY, "fd_detect_hog_svm: %u positives, capacity %lld", cnt, (long long)cap);
+        fd_hog_svm_ticket t;
+        hog_svm_begin(ctx, p, svm, hp, t);
+        hog_svm_end(ctx, t, out, cap, count, all_distance);
     });
 }
 
-int fd_bench_hog_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_hog_params* hp, int64_t* count, int64_t* positives) {
+int fd_detect_hog_svm_begin(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_hog_params* hp, fd_hog_svm_ticket** ticket) {
+    if (ticket) *ticket = nullptr;
     return fd_guard(ctx, [&] {
-        if (!ctx || !p || !svm || !hp) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_bench_hog_svm: NULL argument");
-        HogScratch& S = scratch(ctx);
-        std::vector<WindowLayer> wls;
-        // positives == NULL: fully asynchronous (nothing is read back, no host synchronisation; the
-        // caller brackets many calls with fd_ctx_synchronize).  Otherwise the call is synchronous and
-        // also records the hipEvent-timed duration of the dominant kernel.
-        const bool sync = positives != nullptr;
-        const int64_t N = run_hog_svm(ctx, p, svm, hp, wls, S, sync);
-        if (count) *count = N;
-        if (!N) { if (positives) *positives = 0; return; }
-        hipStream_t st = ctx->stream;
-        const unsigned int pcap = (unsigned int)std::min<int64_t>(N, 1 << 22);
-        S.pos.reserve(sizeof(HogPos) * (size_t)pcap);
-        S.counter.reserve(256);
-        S.hcount.reserve(64);
-        HIP_CHECK(hipMemsetAsync(S.counter.p, 0, 4, st));
-        hipLaunchKernelGGL(k_select_positives, dim3((unsigned)std::min<int64_t>((N + 255) / 256, 2048)), dim3(256), 0, st,
-                           S.dist.as<double>(), N, fd_svm_threshold(svm), S.pos.as<HogPos>(), S.counter.as<unsigned int>(), pcap);
-        HIP_CHECK(hipGetLastError());
-        if (sync) {
-            HIP_CHECK(hipMemcpyAsync(S.hcount.p, S.counter.p, 4, hipMemcpyDeviceToHost, st));
-            HIP_CHECK(hipStreamSynchronize(st));
-            HIP_CHECK(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev0, ctx->ev1));
-            ctx->last_kernel = "k_svm_rbf_mfma";
-            *positives = *S.hcount.as<unsigned int>();
-        }
+        if (!ctx || !p || !svm || !hp || !ticket) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_hog_svm_begin: NULL argument");
+        std::unique_ptr<fd_hog_svm_ticket> t(new fd_hog_svm_ticket());
+        hog_svm_begin(ctx, p, svm, hp, *t);
+        *ticket = t.release();
+    });
+}
+
+int fd_detect_hog_svm_end(fd_ctx* ctx, fd_hog_svm_ticket* ticket, fd_detection* out, int64_t cap, int64_t* count) {
+    std::unique_ptr<fd_hog_svm_ticket> t(ticket);   // released whatever happens
+    return fd_guard(ctx, [&] {
+        if (!ctx || !t || !count) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_hog_svm_end: NULL argument");
+        hog_svm_end(ctx, *t, out, cap, count, nullptr);
     });
 }
 

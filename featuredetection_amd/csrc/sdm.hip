@@ -627,7 +627,10 @@ static void sdm_optimize(fd_ctx* ctx, fd_sdm* m, const uint8_t* gray_images, int
         hipLaunchKernelGGL(k_sdm_prepare, dim3((B * L + 255) / 256), dim3(256), 0, st, m->shapes.as<float>(), B, L, W, H, 1, 0, 1 << 20, stepFactor,
                            m->origin.as<int32_t>(), m->dist.as<float>(), m->status.as<int32_t>());
         const int grid = (int)std::min<int64_t>((nitems + 1) / 2, (int64_t)ctx->num_cus * descriptor_blocks_per_cu(p));
+        const bool timeThis = ctx->kernel_timing && step + 1 == m->S;   // fd_hip_bench.h: the last step's descriptor launch
+        if (timeThis) HIP_CHECK(hipEventRecord(ctx->ev0, st));
         launch_descriptors(dim3(grid), st, dimg, m->origin.as<int32_t>(), p, nitems, m->desc.as<float>(), (int64_t)F);
+        if (timeThis) HIP_CHECK(hipEventRecord(ctx->ev1, st));
         const float* R = m->R[step]->as<float>();
         hipLaunchKernelGGL(k_sdm_regress, dim3((B + 15) / 16, ((N + 15) / 16 + RG_NT - 1) / RG_NT, nchunks), dim3(64), 0, st, m->desc.as<float>(), B, F, R, N,
                            m->partial.as<double>(), nchunks);
@@ -638,6 +641,10 @@ static void sdm_optimize(fd_ctx* ctx, fd_sdm* m, const uint8_t* gray_images, int
     HIP_CHECK(hipMemcpyAsync(shapes.data(), m->shapes.p, sizeof(float) * shapes.size(), hipMemcpyDeviceToHost, st));
     if (status_out) HIP_CHECK(hipMemcpyAsync(status_out, m->status.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
+    if (ctx->kernel_timing && m->S > 0) {
+        HIP_CHECK(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev0, ctx->ev1));
+        ctx->last_kernel = "k_sdm_descriptors";
+    }
 }
 
 int fd_sdm_fit_batch(fd_ctx* ctx, const fd_sdm* m_, const uint8_t* gray_images, int W, int H, int batch, const int32_t* face_boxes,

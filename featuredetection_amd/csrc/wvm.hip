@@ -1562,7 +1562,7 @@ int fd_detect_wvm(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, int sx, int sy
         fd_wvm* m = const_cast<fd_wvm*>(wvm_);
         WvmRun run;
         const bool want_all = all_level || all_score;
-        fd_wvm_run(ctx, p, m, sx, sy, roi, want_all, run, false);
+        fd_wvm_run(ctx, p, m, sx, sy, roi, want_all, run, ctx->kernel_timing);
         if (want_all && run.total) {
             if (all_level) HIP_CHECK(hipMemcpy(all_level, m->all_level.p, sizeof(int32_t) * (size_t)run.total, hipMemcpyDeviceToHost));
             if (all_score) HIP_CHECK(hipMemcpy(all_score, m->all_fout.p, sizeof(float) * (size_t)run.total, hipMemcpyDeviceToHost));
@@ -1612,16 +1612,6 @@ int fd_wvm_eval_batch(fd_ctx* ctx, const fd_wvm* wvm_, const uint8_t* patches, i
         if (out_level) HIP_CHECK(hipMemcpyAsync(out_level, m->all_level.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
         if (out_score) HIP_CHECK(hipMemcpyAsync(out_score, m->all_fout.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
-    });
-}
-
-int fd_bench_wvm(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, int sx, int sy, int64_t* count, int64_t* positives) {
-    return fd_guard(ctx, [&] {
-        if (!ctx || !p || !wvm_) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_bench_wvm: NULL argument");
-        WvmRun run;
-        fd_wvm_run(ctx, p, const_cast<fd_wvm*>(wvm_), sx, sy, nullptr, false, run, true);
-        if (count) *count = run.total;
-        if (positives) *positives = (int64_t)run.pos.size();
     });
 }
 
@@ -1760,7 +1750,7 @@ int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const f
         five_stage_check(m, svm);
         // stage 1: WVM over all windows (SlidingWindowDetector::detect), positives in extraction order
         WvmRun run;
-        fd_wvm_run(ctx, p, m, sx, sy, roi, false, run, true);
+        fd_wvm_run(ctx, p, m, sx, sy, roi, false, run, ctx->kernel_timing);
         five_stage_tail(ctx, p, m, svm, run, oe_dist, oe_ratio, sx, sy, roi, ctx->stream, out, cap, count, stage_counts);
     });
 }

@@ -205,6 +205,13 @@ typedef struct {
 int fd_hog_feature_length(const fd_hog_params* hp);
 int fd_detect_hog_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_hog_params* hp, fd_detection* out,
                       int64_t cap, int64_t* count, double* all_distance);
+/* The same in two halves, for callers that keep more than one frame in flight (one context per frame in flight: a context's
+ * scratch buffers belong to one run at a time).  begin queues pyramid-layer reads, HOG tiles, the SVM, the positive selection
+ * and the read-back of the positives on the context's stream and returns at once; end waits, orders the positives by
+ * extraction order and fills out / count.  Every ticket must be ended (end releases it, whatever it returns). */
+typedef struct fd_hog_svm_ticket fd_hog_svm_ticket;
+int fd_detect_hog_svm_begin(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_hog_params* hp, fd_hog_svm_ticket** ticket);
+int fd_detect_hog_svm_end(fd_ctx* ctx, fd_hog_svm_ticket* ticket, fd_detection* out, int64_t cap, int64_t* count);
 /* FeatureExtractor::extract for every window: n_windows x feature_length floats to host (tests) */
 int fd_extract_hog(fd_ctx* ctx, fd_pyramid* p, const fd_hog_params* hp, float* features, int64_t cap_windows,
                    int64_t* count);
@@ -336,15 +343,6 @@ typedef struct {
  * ffpDetectApp.cpp:484).  all_level / all_distance (may be NULL): per window in extraction order. */
 int fd_detect_rvm(fd_ctx* ctx, fd_pyramid* p, const fd_rvm* rvm, const fd_rvm_detect_params* dp, const int* roi, fd_detection* out,
                   int64_t cap, int64_t* count, int32_t* all_level, double* all_distance);
-
-/* Throughput entry points used by bench.py: everything stays on the device, no host copies of
- * per-window data; *count = enumerated windows, *positives = classifier positives. */
-int fd_bench_hog_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_hog_params* hp, int64_t* count,
-                     int64_t* positives);
-int fd_bench_wvm(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm, int step_x, int step_y, int64_t* count,
-                 int64_t* positives);
-/* hipEvent-timed duration (ms) of the dominant kernel of the last fd_bench_* call on this context */
-int fd_last_kernel_ms(fd_ctx* ctx, const char** kernel_name, float* ms);
 
 /* ---- supervised descent: superviseddescent::SdmLandmarkModel / SdmLandmarkModelFitting ---------- */
 typedef struct {

@@ -1,0 +1,21 @@
+/* include/fd_hip_bench.h -- measurement hooks of libfd_hip.so.  NOT part of the drop-in boundary (include/fd_hip.h): nothing a
+ * maintainer of the reference would bind.  bench.py and tools/ use them to time the dominant kernel of a product call with HIP
+ * events on the stream the kernel is launched on.
+ */
+#ifndef FD_HIP_BENCH_H_
+#define FD_HIP_BENCH_H_
+#include "fd_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* enable != 0: the detect entry points (fd_detect_five_stage, fd_detect_wvm, fd_detect_hog_svm[_begin/_end], fd_sdm_fit_batch)
+ * bracket their dominant kernel(s) with two hipEvents on the context's stream. */
+int fd_ctx_set_kernel_timing(fd_ctx* ctx, int enable);
+/* duration (ms) between those events for the last timed call on this context and the name of the bracketed kernel(s) */
+int fd_last_kernel_ms(fd_ctx* ctx, const char** kernel_name, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FD_HIP_BENCH_H_ */

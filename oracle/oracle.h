@@ -153,6 +153,9 @@ void orc_wvm_svm_evaluate(const orc_pyramid* p, const orc_wvm* wvm, const orc_sv
 int orc_five_stage(const orc_pyramid* p, int imgW, int imgH, const orc_wvm* wvm, const orc_svm* svm,
                    float oeDist, float oeRatio, int stepX, int stepY, const int* roi,
                    orc_det* out, int cap, int32_t* stage_counts);
+/* bench.py cpu_baseline only: per-thread phase timers (extract = patch filters, classify = classifiers + OE + NMS) */
+void orc_phase_timing(int enable);
+void orc_phase_get(double* extract_s, double* classify_s);
 /* Single-stage SlidingWindowDetector with HOG (pyramid layer filter kind 1) + HogFilter patch filter + SVM
  * (BenchmarkRunner.cpp:235-242 recipe).  all_dist receives every window's hyperplane distance. */
 int64_t orc_sliding_hog_svm(const orc_pyramid* p, const orc_svm* svm, int pw, int ph, int stepX, int stepY,

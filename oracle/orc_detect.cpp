@@ -5,8 +5,21 @@
 #include "oracle.h"
 #include <cstring>
 #include <memory>
+#include <chrono>
 
 namespace orc {
+
+// Phase timers of bench.py's cpu_baseline leg (update / extract / classify).  Thread-local, off by
+// default; the two clock reads per window cost ~50 ns against >= 2 us of work per window.
+struct PhaseTimes { bool on = false; double extract = 0, classify = 0; };
+static thread_local PhaseTimes g_phase;
+struct PhaseScope {
+    double& acc;
+    std::chrono::steady_clock::time_point t0;
+    bool on;
+    explicit PhaseScope(double& a) : acc(a), on(g_phase.on) { if (on) t0 = std::chrono::steady_clock::now(); }
+    ~PhaseScope() { if (on) acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 // OverlapElimination.cpp:44-105.  The reference sorts shared_ptrs through boost::indirect_iterator
 // with std::greater<ClassifiedPatch> (probability only), i.e. a plain std::sort on the same sequence.
@@ -109,9 +122,9 @@ static void sliding_wvm(const Pyramid& p, const Wvm& m, int stepX, int stepY, co
     for (size_t i = 0; i < wins.size(); ++i) {
         const Window& w = wins[i];
         const ImgU8& img = p.layers[w.layer].img;
-        histeq64(img.d.data() + (size_t)w.ly * img.w + w.lx, m.fw, m.fh, img.w, eq.data());
+        { PhaseScope ps(g_phase.extract); histeq64(img.d.data() + (size_t)w.ly * img.w + w.lx, m.fw, m.fh, img.w, eq.data()); }
         int level; float fout;
-        m.eval(eq.data(), level, fout);
+        { PhaseScope ps(g_phase.classify); m.eval(eq.data(), level, fout); }
         if (all_level) all_level[i] = level;
         if (all_fout) all_fout[i] = fout;
         if (m.classify(level, fout)) {
@@ -188,6 +201,7 @@ static std::vector<orc_det> five_stage(const Pyramid& p, int imgW, int imgH, con
     std::vector<Scored> cls;
     sliding_wvm(p, wvm, stepX, stepY, roi, cls, nullptr, nullptr);
     if (counts) counts[0] = (int)cls.size();
+    PhaseScope psTail(g_phase.classify);   // OE + SVM + NMS belong to the classify phase
     // OE
     std::vector<orc_det> dets(cls.size());
     for (size_t i = 0; i < cls.size(); ++i) dets[i] = cls[i].det;
@@ -396,6 +410,9 @@ int orc_five_stage(const orc_pyramid* p, int imgW, int imgH, const orc_wvm* wvm,
     return (int)r.size();
 }
 
+void orc_phase_timing(int enable) { g_phase.on = enable != 0; g_phase.extract = g_phase.classify = 0; }
+void orc_phase_get(double* extract_s, double* classify_s) { *extract_s = g_phase.extract; *classify_s = g_phase.classify; }
+
 int64_t orc_sliding_hog_svm(const orc_pyramid* p_, const orc_svm* svm_, int pw, int ph, int stepX, int stepY, int bins,
                             int cell, int block, int interpolate, int signedAndUnsigned, orc_det* out, int64_t cap,
                             double* all_dist, float* feat_out, int64_t feat_cap_windows) {
@@ -409,12 +426,14 @@ int64_t orc_sliding_hog_svm(const orc_pyramid* p_, const orc_svm* svm_, int pw, 
         const Window& w = wins[i];
         const ImgU8& img = p.layers[w.layer].img;
         const uchar* src = img.d.data() + ((size_t)w.ly * img.w + w.lx) * img.ch;
-        hog_filter(src, pw, ph, img.ch, img.w * img.ch, bins, cell, cell, block, block, interpolate != 0,
-                   signedAndUnsigned != 0, feat);
+        { PhaseScope ps(g_phase.extract);
+          hog_filter(src, pw, ph, img.ch, img.w * img.ch, bins, cell, cell, block, block, interpolate != 0,
+                     signedAndUnsigned != 0, feat); }
         if (feat_out && (int64_t)i < feat_cap_windows)
             std::memcpy(feat_out + i * feat.size(), feat.data(), sizeof(float) * feat.size());
         if (!svm) continue;
-        double dist = svm->distance(feat.data());
+        double dist;
+        { PhaseScope ps(g_phase.classify); dist = svm->distance(feat.data()); }
         if (all_dist) all_dist[i] = dist;
         if (svm->classify(dist)) {
             if (npos < cap && out) {

@@ -90,6 +90,8 @@ def lib():
         l.orc_sdm_optimize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         l.orc_equalize_hist.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         l.orc_whi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
+        l.orc_phase_timing.argtypes = [C.c_int]
+        l.orc_phase_get.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib = l
     return _lib
 
@@ -443,6 +445,17 @@ class Rvm:
         if self.h:
             lib().orc_rvm_destroy(self.h)
             self.h = None
+
+
+def phase_timing(enable=True):
+    """bench.py cpu_baseline: switch this thread's extract / classify phase timers on (and reset them) or off"""
+    lib().orc_phase_timing(int(enable))
+
+
+def phase_times():
+    e, c = C.c_double(), C.c_double()
+    lib().orc_phase_get(C.byref(e), C.byref(c))
+    return e.value, c.value
 
 
 def sliding_wvm(pyr, wvm, sx=1, sy=1, roi=None, want_all=True):

@@ -71,6 +71,69 @@ def test_shard_and_gather_world2():
     assert np.array_equal(allr, ref)   # ordered by image id, original order inside an image
 
 
+def _golden_image_detections(i, nimages):
+    """fd_detection records of "image" i: a slice of the committed cascade fixture's WVM positives (tests/golden/
+    orc_cascade_160x120.npz, written by the oracle), converted to the C ABI's record layout"""
+    from featuredetection_amd import capi
+    g = np.load(os.path.join(ROOT, "tests", "golden", "orc_cascade_160x120.npz"))
+    src = g["wvm_pos"][i::nimages]
+    d = np.zeros(len(src), capi.DET_DTYPE)
+    for f in ("cx", "cy", "w", "h", "layer", "lx", "ly", "level", "positive"):
+        d[f] = src[f]
+    d["score"], d["probability"] = src["fout"], src["prob"]
+    return d
+
+
+def _golden_worker(rank, world, port, nimages, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from featuredetection_amd import parallel
+    total = []
+    # two gathers (as bench.py does every --gather-every steps), detector id = pyramid layer of the record
+    for lo, hi in ((0, nimages // 2), (nimages // 2, nimages)):
+        mine = [i for i in parallel.shard_indices(nimages, rank, world) if lo <= i < hi]
+        recs = [parallel.pack_records(np.full(len(d), i), d["layer"], d) for i in mine for d in [_golden_image_detections(i, nimages)]]
+        local = np.concatenate(recs) if recs else np.zeros((0, parallel.RECORD_FIELDS))
+        allr, trunc = parallel.gather_records(local, cap=512)
+        assert not trunc
+        total.append(allr)
+    if rank == 0:
+        q.put(np.concatenate(total))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_real_detection_records_world2():
+    """world 2 over gloo with records packed from real fd_detection arrays (golden fixture): every field survives the gather
+    ({image, detector, cx, cy, w, h, score, prob}), ordered by (image, detector, extraction order)"""
+    from featuredetection_amd import parallel
+    nimages, world = 9, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_golden_worker, args=(r, world, port, nimages, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    allr = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    dets = [_golden_image_detections(i, nimages) for i in range(nimages)]
+    assert sum(len(d) for d in dets) == 305 == len(allr)
+    ref = np.concatenate([parallel.pack_records(np.full(len(d), i), d["layer"], d) for i, d in enumerate(dets)])
+    halves = [ref[ref[:, 0] < nimages // 2], ref[ref[:, 0] >= nimages // 2]]
+    exp = []
+    for h in halves:
+        exp.append(h[np.lexsort((np.arange(len(h)), h[:, 1], h[:, 0]))])
+    exp = np.concatenate(exp)
+    assert np.array_equal(allr, exp)
+    # field fidelity: scores are float32 values, probabilities float64, geometry integers
+    assert np.array_equal(allr[:, 6].astype(np.float32).astype(np.float64), allr[:, 6])
+    assert np.array_equal(np.sort(allr[:, 7]), np.sort(np.concatenate([d["probability"] for d in dets])))
+    assert np.array_equal(allr[:, 2:6], np.rint(allr[:, 2:6]))
+
+
 def test_gather_single_process_and_truncation():
     from featuredetection_amd import parallel
     d = _detect_image(3)

@@ -33,6 +33,12 @@ def test_symbols_match_header(capi):
     missing = [n for n in sorted(names) if not hasattr(lib, n)]
     assert not missing, "symbols declared in include/fd_hip.h but not exported: %s" % missing
     assert set(capi._SIGS) == names
+    # measurement hooks live in their own header, outside the drop-in boundary
+    bh = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "fd_hip_bench.h")).read(), flags=re.S)
+    bnames = set(re.findall(r"\b(fd_[a-z0-9_]+)\s*\(", bh))
+    assert bnames == set(capi._BENCH_SIGS) and not (bnames & names)
+    assert all(hasattr(lib, n) for n in bnames)
+    assert "fd_bench" not in hdr
 
 
 @pytest.mark.parametrize("dist,ratio", [(5.0, 0.0), (0.5, 0.0), (20.0, 0.8), (1.0, 1.5)])

@@ -1,0 +1,82 @@
+"""Per-launch counter figures of the kernels of one bench.py workload from rocprofv3 --pmc passes -> profiles/r02_pmc.json.
+
+usage: pmc_summary.py <workload> <out.json> <kernel-substring> <source-note> <pass_dir> [<pass_dir> ...]
+Every pass directory holds one `rocprofv3 --kernel-trace --pmc <counters>` run of the same bench command (counters are
+collected in separate passes, never together with other trace domains).  Values are averaged over the launches of every kernel
+whose name contains the substring; FETCH_SIZE is doubled (gfx950: 128-byte requests are tallied at 64 bytes,
+MI355X_MICROARCH.md section HBM) and both size counters are converted from KiB to bytes.  SQ_* cycle counters are in
+quad-cycles (same guide), SQ_INSTS_* in wave instructions."""
+import csv
+import glob
+import json
+import re
+import sys
+
+workload, out, substr, note = sys.argv[1:5]
+dirs = sys.argv[5:]
+
+
+def short(name):
+    m = re.match(r"(?:void\s+)?(?:\(anonymous namespace\)::)?([A-Za-z0-9_]+)", name)
+    return m.group(1) if m else name
+
+
+acc = {}   # kernel -> counter -> [sum, n]
+for d in dirs:
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if substr not in k:
+                continue
+            a = acc.setdefault(short(k), {}).setdefault(r["Counter_Name"], [0.0, 0])
+            a[0] += float(r["Counter_Value"])
+            a[1] += 1
+    # kernel durations of the same passes (kernel trace)
+    for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if substr not in k:
+                continue
+            a = acc.setdefault(short(k), {}).setdefault("_dur_ns", [0.0, 0])
+            a[0] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+            a[1] += 1
+if not acc:
+    raise SystemExit("no samples for kernels matching %r in %s" % (substr, dirs))
+kernels = {}
+for k, cs in acc.items():
+    rec = {}
+    for c, (s, n) in cs.items():
+        rec[c] = s / n
+        rec.setdefault("launches", n)
+    o = dict(launches=rec.get("launches", 0))
+    if "_dur_ns" in rec:
+        o["kernel_ms_profiled"] = rec["_dur_ns"] / 1e6
+    if "FETCH_SIZE" in rec or "WRITE_SIZE" in rec:
+        o["fetch_bytes"] = 2 * rec.get("FETCH_SIZE", 0.0) * 1024
+        o["write_bytes"] = rec.get("WRITE_SIZE", 0.0) * 1024
+        o["hbm_bytes"] = o["fetch_bytes"] + o["write_bytes"]
+    for c, key in (("SQ_INSTS_VALU", "valu_insts"), ("SQ_INSTS_SALU", "salu_insts"), ("SQ_INSTS_LDS", "lds_insts"), ("SQ_INSTS_VMEM_RD", "vmem_rd_insts"),
+                   ("SQ_INSTS_MFMA", "mfma_insts"), ("SQ_INSTS_VALU_MFMA_MOPS_I8", "mfma_mops_i8"), ("SQ_ACTIVE_INST_VALU", "active_inst_valu_quadcycles"),
+                   ("SQ_ACTIVE_INST_LDS", "active_inst_lds_quadcycles"), ("SQ_WAVE_CYCLES", "wave_quadcycles"), ("SQ_BUSY_CYCLES", "sq_busy_cycles"),
+                   ("SQ_WAVES", "waves"), ("GRBM_GUI_ACTIVE", "gui_active_cycles"), ("SQ_LDS_BANK_CONFLICT", "lds_bank_conflict_cycles"),
+                   ("SQ_LDS_IDX_ACTIVE", "lds_idx_active_cycles"), ("SQ_WAIT_INST_ANY", "wait_inst_any_quadcycles"), ("SQ_WAIT_ANY", "wait_any_quadcycles"),
+                   ("SQ_ACTIVE_INST_ANY", "active_inst_any_quadcycles"), ("SQ_VALU_MFMA_BUSY_CYCLES", "mfma_busy_cycles")):
+        if c in rec:
+            o[key] = rec[c]
+    kernels[k] = o
+# workload aggregate over the matched kernels: per-"frame" figures = sum over kernels of (per-launch value x launches) / launches of the
+# most frequent kernel would be ambiguous, so the aggregate is the plain sum of per-launch averages (one launch of each kernel)
+agg = {}
+for o in kernels.values():
+    for key, v in o.items():
+        if key != "launches":
+            agg[key] = agg.get(key, 0.0) + v
+agg["kernel_ms"] = agg.pop("kernel_ms_profiled", None)
+try:
+    allrec = json.load(open(out))
+except Exception:
+    allrec = {}
+kernels["k_all(" + substr + ")"] = agg
+allrec[workload] = dict(source=note, kernels=kernels)
+json.dump(allrec, open(out, "w"), indent=1)
+print(json.dumps(allrec[workload], indent=1))
