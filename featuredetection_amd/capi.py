@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("FD_HIP_LIB", os.path.join(_HERE, "libfd_hip.so"))
+LIB_PATH = os.environ.get("FD_HIP_LIB", os.path.join(_HERE, "libfd_hip.so"))   # FD_HIP_LIB: a differently built libfd_hip.so (A/B runs of kernel variants)
 
 FD_OK, FD_ERR_INVALID_ARGUMENT, FD_ERR_RUNTIME, FD_ERR_LOGIC, FD_ERR_HIP, FD_ERR_CAPACITY = range(6)
 FD_LAYER_NONE, FD_LAYER_GRADBIN, FD_LAYER_LBP = 0, 1, 2

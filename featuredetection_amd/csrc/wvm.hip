@@ -53,6 +53,9 @@ struct WinTable {
     int32_t raw;   // != 0: arena holds `total` contiguous, already equalised patches (fd_wvm_eval_batch)
     int64_t total;
     const int32_t* list;   // != NULL: `total` explicit windows {layer position, lx, ly}; l[i] then describes kept layer i
+    // != NULL: only the windows widq[0 .. *widq_count) are evaluated (written by k_wvm_prefilter earlier on the same stream)
+    const int64_t* widq;
+    const unsigned int* widq_count;
     WinLayerDev l[WVM_MAX_LAYERS];
 };
 
@@ -97,6 +100,10 @@ struct fd_wvm {
     std::vector<float> h_thresholds;
     // scratch reused across calls
     DevBuf all_level, all_fout, pos, pos_patches, counter, deep_q, list;
+    // dense pre-filter (wvm_dense.hpp): digit matrix, constants, queue of the windows it lets through
+    DevBuf denseB, denseC, pre_q;
+    int denseL = 0;   // 0: the model has no dense stage
+    double denseScale = 0;   // 2^-s of the quantised residual images
     HostBuf h_pos;
     int64_t pos_cap = 0;
     hipEvent_t done = nullptr;   // recorded after the cascade kernels + first read-back of a run
@@ -131,6 +138,10 @@ __device__ __forceinline__ int scan_half(int s) {
 __device__ __forceinline__ double readlane_d(double v, int lane) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
+
+// number of windows a cascade kernel has to evaluate and the id of the i-th one (all windows, or the pre-filter's queue)
+__device__ __forceinline__ int64_t wt_total(const WinTable& wt) { return wt.widq ? (int64_t)*wt.widq_count : wt.total; }
+__device__ __forceinline__ int64_t wt_wid(const WinTable& wt, int64_t i) { return wt.widq ? wt.widq[i] : i; }
 
 // PW_/PH_ != 0: patch size known at compile time (the 20x20 detectors of the reference configs);
 // 0: sizes from the model, up to 32x32.
@@ -378,7 +389,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     if (lane < WVM_MAX_VALS) L.sv[lane] = 0;
     wave_sync();
 
-    for (int64_t wid = (int64_t)blockIdx.x * 4 + wave; wid < wt.total; wid += nwaves) {
+    const int64_t totalA = wt_total(wt);
+    for (int64_t widx = (int64_t)blockIdx.x * 4 + wave; widx < totalA; widx += nwaves) {
+        const int64_t wid = wt_wid(wt, widx);
         int srcStride;
         const uint8_t* src = wvm_locate<RAW>(arena, wt, sFirst, wid, lane, g.pw, g.d, srcStride);
         // level-0 model data: requested now, consumed after the fixed part
@@ -470,10 +483,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     if (c < WVM_MAX_VALS) L.sv[half][c] = 0;
     wave_sync();
 
-    const int64_t npairs = (wt.total + 1) >> 1;
+    const int64_t totalA = wt_total(wt);
+    const int64_t npairs = (totalA + 1) >> 1;
     for (int64_t pair = (int64_t)blockIdx.x * 4 + wave; pair < npairs; pair += nwaves) {
-        const int64_t wid0 = 2 * pair, wid1 = wid0 + 1;
-        const bool has1 = wid1 < wt.total;
+        const bool has1 = 2 * pair + 1 < totalA;
+        const int64_t wid0 = wt_wid(wt, 2 * pair), wid1 = has1 ? wt_wid(wt, 2 * pair + 1) : wid0;
         const int64_t myWid = half ? wid1 : wid0;
         const bool valid = half ? has1 : true;
         int stride0, stride1;
@@ -705,7 +719,8 @@ __global__ __launch_bounds__(64 * WVM_QUAD_WAVES) __attribute__((amdgpu_waves_pe
     L.sv[q][r] = 0;
     wave_sync();
 
-    const int64_t nquads = (wt.total + 3) >> 2;
+    const int64_t totalA = wt_total(wt);
+    const int64_t nquads = (totalA + 3) >> 2;
     for (int64_t quad = (int64_t)blockIdx.x * WVM_QUAD_WAVES + wave; quad < nquads; quad += nwaves) {
         // level-0 model data: requested now, consumed after the fixed part
         uint4 lv = m.lvlRec[c];
@@ -718,10 +733,11 @@ __global__ __launch_bounds__(64 * WVM_QUAD_WAVES) __attribute__((amdgpu_waves_pe
 #pragma unroll 1
         for (int p = 0; p < 2; ++p) {
             // ---- fixed part of the pair (windows 4*quad + 2p, + 2p + 1), as in k_wvm_cascade2
-            const int64_t wid0 = 4 * quad + 2 * p, wid1 = wid0 + 1;
-            const bool has0 = wid0 < wt.total, has1 = wid1 < wt.total;
+            const int64_t widx0 = 4 * quad + 2 * p, widx1 = widx0 + 1;
+            const bool has0 = widx0 < totalA, has1 = widx1 < totalA;
+            const int64_t wid0 = wt_wid(wt, has0 ? widx0 : 4 * quad), wid1 = has1 ? wt_wid(wt, widx1) : wid0;
             int stride0, stride1;
-            const uint8_t* src0 = wvm_locate<RAW>(arena, wt, sFirst, has0 ? wid0 : 4 * quad, lane, PW_, d, stride0);
+            const uint8_t* src0 = wvm_locate<RAW>(arena, wt, sFirst, wid0, lane, PW_, d, stride0);
             const uint8_t* src1 = src0;
             stride1 = stride0;
             if (has1) src1 = wvm_locate<RAW>(arena, wt, sFirst, wid1, lane, PW_, d, stride1);
@@ -781,8 +797,8 @@ __global__ __launch_bounds__(64 * WVM_QUAD_WAVES) __attribute__((amdgpu_waves_pe
             wave_sync();
         }
         // ---- quarter layout: window q of the quad comes from half q & 1 of pair q >> 1
-        const int64_t myWid = 4 * quad + q;
-        const bool valid = myWid < wt.total;
+        const bool valid = 4 * quad + q < totalA;
+        const int64_t myWid = wt_wid(wt, valid ? 4 * quad + q : 4 * quad);
         float sxx;
         int sx_total;
         {
@@ -1204,7 +1220,7 @@ __global__ __launch_bounds__(256) void k_histeq64(const uint8_t* __restrict__ in
 // stage B is a persistent grid that reads the survivor count from device memory).
 template <int PW_, int PH_, bool RAW>
 void launch_sized(fd_ctx* ctx, hipStream_t st, int64_t total, const WvmDev& dev, const uint8_t* arena, const WinTable& wt,
-                  const CascadeOut& o) {
+                  const CascadeOut& o, bool skipA = false) {
     // both stages are persistent grids: exactly as many workgroups as fit on the device at once (a partial second
     // round of workgroups would run at a fraction of the occupancy)
     static int perCuA = 0;
@@ -1213,7 +1229,7 @@ void launch_sized(fd_ctx* ctx, hipStream_t st, int64_t total, const WvmDev& dev,
         if (const char* e = getenv("FD_WVM_GRID_PER_CU")) if (atoi(e) > 0) perCuA = atoi(e);
     }
     static const bool single = getenv("FD_WVM_SINGLE") != nullptr;
-    bool launched = false;
+    bool launched = skipA;   // skipA: the dense pre-filter has filled the stage-B queue itself
     if constexpr (PW_ > 0 && PW_ <= 32) {
         static const bool pairOnly = getenv("FD_WVM_PAIR") != nullptr;
         // four windows per wavefront where four integral images leave enough LDS for the occupancy of the fixed part (measured per
@@ -1221,7 +1237,7 @@ void launch_sized(fd_ctx* ctx, hipStream_t st, int64_t total, const WvmDev& dev,
         constexpr bool quadFits = PW_ * PH_ <= 576 && PW_ <= 24;
         bool quadLaunched = false;
         if constexpr (quadFits) {
-          if (dev.numPer <= 32 && !single && !pairOnly && dev.numUsed > WVM_LCAP) {
+          if (dev.numPer <= 32 && !single && !pairOnly && dev.numUsed > WVM_LCAP && !skipA) {
             static int perCu4q = 0;
             if (perCu4q == 0) {
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu4q, k_wvm_cascade4<PW_, PH_, RAW>, 64 * WVM_QUAD_WAVES, 0) != hipSuccess || perCu4q < 1)
@@ -1235,7 +1251,7 @@ void launch_sized(fd_ctx* ctx, hipStream_t st, int64_t total, const WvmDev& dev,
             launched = quadLaunched = true;
           }
         }
-        if (!quadLaunched && dev.numPer <= 32 && !single) {   // two windows per wavefront
+        if (!quadLaunched && dev.numPer <= 32 && !single && !skipA) {   // two windows per wavefront
             static int perCu2 = 0;
             if (perCu2 == 0) {
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu2, k_wvm_cascade2<PW_, PH_, RAW>, 256, 0) != hipSuccess || perCu2 < 1) perCu2 = 4;
@@ -1281,17 +1297,143 @@ void launch_sized(fd_ctx* ctx, hipStream_t st, int64_t total, const WvmDev& dev,
 
 template <bool RAW>
 void launch_cascade(fd_ctx* ctx, hipStream_t st, int64_t total, const WvmDev& dev, const uint8_t* arena, const WinTable& wt,
-                    const CascadeOut& o) {
+                    const CascadeOut& o, bool skipA = false) {
 #define FD_WVM_CASE(W, H) \
-    if (dev.fw == W && dev.fh == H) return launch_sized<W, H, RAW>(ctx, st, total, dev, arena, wt, o);
+    if (dev.fw == W && dev.fh == H) return launch_sized<W, H, RAW>(ctx, st, total, dev, arena, wt, o, skipA);
     FD_WVM_SIZES(FD_WVM_CASE)
 #undef FD_WVM_CASE
-    launch_sized<0, 0, RAW>(ctx, st, total, dev, arena, wt, o);
+    launch_sized<0, 0, RAW>(ctx, st, total, dev, arena, wt, o, skipA);
 }
 
 }  // namespace
 
+#include "wvm_dense.hpp"
+
 // ---- host side ---------------------------------------------------------------------------------
+
+// Dense stage of a model (wvm_dense.hpp): residual images of the first L filters, quantised to 32-bit integers and split into
+// four balanced base-256 digits in the B-operand layout of v_mfma_i32_32x32x32_i8.  L = 0 (no dense stage) when the model does
+// not qualify: fewer than 17 used filters (the exact stage-A kernels would emit positives themselves), fewer than 4 filters per
+// level, a patch size without a compile-time kernel, or FD_WVM_DENSE=0.
+static void wvm_build_dense(fd_wvm* m, const fd_wvm_model* md) {
+    m->denseL = 0;
+    static const bool off = [] { const char* e = getenv("FD_WVM_DENSE"); return e && atoi(e) == 0; }();
+    if (off) return;
+    const int pw = md->filter_w, ph = md->filter_h, d = pw * ph;
+    bool sized = false;
+#define FD_WVM_CASE(W, H) if (pw == W && ph == H) sized = true;
+    FD_WVM_CASE(20, 20) FD_WVM_CASE(24, 24) FD_WVM_CASE(16, 24) FD_WVM_CASE(32, 16) FD_WVM_CASE(32, 24)
+#undef FD_WVM_CASE
+    const int numUsed = m->dev.numUsed, numPer = m->dev.numPer;
+    if (!sized || numUsed <= WVM_LCAP || numPer > 32) return;
+    const int L = std::min(std::min(WVD_L, numPer), numUsed - 1);
+    if (L < 4) return;
+    // r_k[y][x] = val_k[0] + sum_{v >= 1} (val_k[v] - val_k[0]) * #{rects of v covering (x, y)}   
+    std::vector<double> r((size_t)L * d);
+    double rmax = 0;
+    for (int k = 0; k < L; ++k) {
+        const int v0 = md->val_off[k], cntval = md->val_off[k + 1] - v0;
+        double* rk = &r[(size_t)k * d];
+        for (int i = 0; i < d; ++i) rk[i] = md->val[v0];
+        for (int v = 1; v < cntval; ++v) {
+            const double dv = md->val[v0 + v] - md->val[v0];
+            for (int ri = md->rec_off[v0 + v]; ri < md->rec_off[v0 + v + 1]; ++ri) {
+                const uint8_t* rc = md->rects + 4 * (size_t)ri;
+                for (int y = rc[1]; y <= rc[3]; ++y)
+                    for (int x = rc[0]; x <= rc[2]; ++x) rk[y * pw + x] += dv;
+            }
+        }
+        for (int i = 0; i < d; ++i) {
+            if (!std::isfinite(rk[i])) return;
+            rmax = std::max(rmax, std::fabs(rk[i]));
+        }
+    }
+    if (!std::isfinite((double)md->basis_param) || !std::isfinite((double)md->bias)) return;
+    int sh = 40;
+    if (rmax > 0) sh = std::min(40, (int)std::floor(30.0 - std::log2(rmax)));
+    if (sh < 4) return;   // grey values far outside the 0..255 domain: nothing to gain
+    const double up = std::ldexp(1.0, sh);
+    WvdConst C;
+    std::memset(&C, 0, sizeof(C));
+    m->denseScale = std::ldexp(1.0, -sh);
+    // k-step = one patch row (two rows for 16-wide patches): slot t of step ks is pixel (ks * RPS + t / pw, t % pw)
+    const int RPS = pw == 16 ? 2 : 1;
+    if (ph % RPS != 0) return;
+    const int KS = ph / RPS;
+    std::vector<int8_t> B((size_t)KS * 2 * 64 * 16, 0);
+    for (int k = 0; k < L; ++k) {
+        double sumQ = 0;
+        for (int i = 0; i < d; ++i) {
+            long long Q = std::llround(r[(size_t)k * d + i] * up);   // |Q| <= 2^30
+            sumQ += (double)Q;
+            int dig[4];
+            for (int j = 0; j < 4; ++j) {
+                const int q0 = (int)(((Q + 128) & 255) - 128);
+                dig[j] = q0;
+                Q = (Q - q0) / 256;   // exact
+            }
+            if (Q != 0) return;   // cannot happen for |Q| < 2^31 - 2^23
+            const int prow = i / pw, pcol = i % pw;
+            const int ks = prow / RPS, slot = (prow % RPS) * pw + pcol, h = slot / 16, t = slot % 16;
+            for (int j = 0; j < 4; ++j) {
+                const int g = k + 16 * j, nt = g / 32, col = g % 32;
+                B[((((size_t)ks * 2 + nt) * 64) + (h * 32 + col)) * 16 + t] = (int8_t)dig[j];
+            }
+        }
+        C.c128[k] = 128.0 * sumQ;
+        C.pp[k] = md->pp[k];
+        C.thr[k] = md->thresholds[k];
+        for (int pidx = 0; pidx <= k; ++pidx) C.w[k][pidx] = md->hk_weights[(size_t)k * md->num_filters + pidx];
+        if (!std::isfinite(C.pp[k]) || !std::isfinite((double)C.thr[k])) return;
+    }
+    m->denseB.reserve(B.size());
+    HIP_CHECK(hipMemcpy(m->denseB.p, B.data(), B.size(), hipMemcpyHostToDevice));
+    m->denseC.reserve(sizeof(C));
+    HIP_CHECK(hipMemcpy(m->denseC.p, &C, sizeof(C), hipMemcpyHostToDevice));
+    m->denseL = L;
+}
+
+template <int PW_, int PH_>
+static void launch_prefilter_sized(fd_ctx* ctx, hipStream_t st, const uint8_t* arena, const WvdTable& wt, const WvdDev& dv) {
+    static int perCu = 0;
+    if (perCu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wvm_prefilter<PW_, PH_>, 256, 0) != hipSuccess || perCu < 1)) perCu = 2;
+    const int grid = (int)std::min<int64_t>(((int64_t)wt.ntiles + 3) / 4, (int64_t)ctx->num_cus * perCu * 2);
+    hipLaunchKernelGGL((k_wvm_prefilter<PW_, PH_>), dim3(grid), dim3(256), 0, st, arena, wt, dv);
+}
+
+// queues k_wvm_prefilter over all windows of `wt`; returns false when the model / call does not qualify
+static bool launch_prefilter(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const uint8_t* arena, const WinTable& wt, int64_t* q, unsigned int* qcount) {
+    if (m->denseL == 0 || wt.raw || wt.list || wt.total < 512) return false;
+    WvdTable t;
+    std::memset(&t, 0, sizeof(t));
+    t.n = wt.n; t.sx = wt.sx; t.sy = wt.sy;
+    int tiles = 0;
+    for (int i = 0; i < wt.n; ++i) {
+        const WinLayerDev& s = wt.l[i];
+        const int64_t nwin = (i + 1 < wt.n ? wt.l[i + 1].first : wt.total) - s.first;
+        if (nwin <= 0 || nwin > (int64_t)INT32_MAX - 64) return false;
+        WvdLayer& dl = t.l[i];
+        dl.bx = s.bx; dl.by = s.by; dl.nx = s.nx; dl.lw = s.lw; dl.off = s.off; dl.magic = s.magic; dl.first = s.first;
+        dl.nwin = (int32_t)nwin;
+        dl.tileFirst = tiles;
+        tiles += (int)((nwin + 63) / 64);
+    }
+    t.ntiles = tiles;
+    WvdDev dv;
+    dv.B = m->denseB.as<wvd_v4i>();
+    dv.c = m->denseC.as<WvdConst>();
+    dv.q = q;
+    dv.qcount = qcount;
+    dv.L = m->denseL;
+    dv.negBasis = m->dev.negBasis; dv.negBias = m->dev.negBias; dv.stretch = m->dev.stretch;
+    dv.sxxSlack = (float)(2 * m->dev.fh + 2);
+    dv.scale = m->denseScale;
+#define FD_WVM_CASE(W, H) \
+    if (m->dev.fw == W && m->dev.fh == H) { launch_prefilter_sized<W, H>(ctx, st, arena, t, dv); return true; }
+    FD_WVM_CASE(20, 20) FD_WVM_CASE(24, 24) FD_WVM_CASE(16, 24) FD_WVM_CASE(32, 16) FD_WVM_CASE(32, 24)
+#undef FD_WVM_CASE
+    return false;
+}
 
 void fd_wvm_build_table(const fd_pyramid* p, int pw, int ph, int sx, int sy, const int* roi, WinTable& wt,
                         std::vector<WindowLayer>& wls) {
@@ -1389,7 +1531,26 @@ static void wvm_launch_table(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, const WinTab
     o.deep_q = m->deep_q.as<int64_t>();
     o.deep_count = m->pos.as<unsigned int>() + 1;   // header word 1
     if (time_kernel) HIP_CHECK(hipEventRecord(ctx->ev0, st));
-    launch_cascade<false>(ctx, st, wt.total, m->dev, p->arena.as<uint8_t>(), wt, o);
+    WinTable wtq = wt;
+    bool skipA = false;
+    // production path: the dense pre-filter drops every window the first cascade levels reject with a margin; the exact
+    // cascade then only sees the queue (header word 2 = its length).  Per-window outputs need the exact path for all.
+    // Default: the pre-filter feeds stage B's queue directly (k_wvm_deep4 evaluates a window from level 0 anyway; measured
+    // 1157 -> 1445 Mpatches/s on config 3 against running the stage-A kernel on the queue first); FD_WVM_DENSE_DIRECT=0
+    // inserts stage A between them.
+    static const bool direct = [] { const char* e = getenv("FD_WVM_DENSE_DIRECT"); return !(e && atoi(e) == 0); }();
+    if (!want_all && m->denseL) {
+        if (direct) {
+            skipA = launch_prefilter(ctx, st, m, p->arena.as<uint8_t>(), wt, o.deep_q, o.deep_count);
+        } else {
+            m->pre_q.reserve(sizeof(int64_t) * (size_t)wt.total);
+            if (launch_prefilter(ctx, st, m, p->arena.as<uint8_t>(), wt, m->pre_q.as<int64_t>(), m->pos.as<unsigned int>() + 2)) {
+                wtq.widq = m->pre_q.as<int64_t>();
+                wtq.widq_count = m->pos.as<unsigned int>() + 2;
+            }
+        }
+    }
+    launch_cascade<false>(ctx, st, wt.total, m->dev, p->arena.as<uint8_t>(), wtq, o, skipA);
     if (time_kernel) HIP_CHECK(hipEventRecord(ctx->ev1, st));
     HIP_CHECK(hipGetLastError());
     const size_t firstChunk = (size_t)std::min<int64_t>(m->pos_cap, WVM_FIRST_CHUNK);
@@ -1549,6 +1710,7 @@ int fd_wvm_create(fd_ctx* ctx, const fd_wvm_model* md, fd_wvm** out) {
         m->logisticA = md->logistic_a;
         m->logisticB = md->logistic_b;
         m->h_thresholds.assign(md->thresholds, md->thresholds + F);
+        wvm_build_dense(m, md);
         *out = guard.release();
     });
 }

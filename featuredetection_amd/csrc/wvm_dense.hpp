@@ -6,13 +6,15 @@
 // So the first L <= min(16, numPer) kernel values of ALL windows are one [windows x d] . [d x L] contraction:
 //
 //   k_wvm_prefilter: lane == window (64 consecutive windows of a layer per wavefront).
-//     1. HistEq64 (HistEq64Filter.cpp:32-125) lane-serial: private 64-bin histogram column in LDS (u16 counters, two lanes share a
-//        dword: ds_add_u32 of 1 << 16*(lane&1)), the fp32 cdf as a plain 63-step chain in the lane's registers (same operation
-//        order as the reference, 64 windows per instruction instead of the DPP chain's one), LUT written back over the counters.
-//     2. the equalised pixels go to LDS as signed bytes (x - 128), 32 per k-step, and are multiplied on v_mfma_i32_32x32x32_i8
-//        against the residual images quantised to 32-bit integers Q = round(r * 2^s) and split into four balanced base-256 digits:
-//        integer arithmetic, so x . Q is EXACT; |x . r - 2^-s x . Q| <= 2^-(s+1) * sum(x) is the only approximation.
-//        The fp32 sum of squares is accumulated in the reference's own order (IImg.cpp:33-47), i.e. it is the reference's value.
+//     1. HistEq64 (HistEq64Filter.cpp:32-125) lane-serial: private 64-bin histogram column in LDS (u16 counters, lanes l and l + 32
+//        share a dword: ds_add_u32 of 1 << 16*(lane>>5), conflict-free), the fp32 cdf as a plain 63-step chain in the lane's
+//        registers (same operation order as the reference, 64 windows per instruction instead of the DPP chain's one), LUT written
+//        back over the counters.  sum(x) and sum(x^2) of the equalised patch come from the histogram (exact integers); the
+//        reference's fp32 sum of squares (IImg.cpp:33-47) equals the integer below 2^24 and is within 2*ph + 2 of it above.
+//     2. the equalised pixels go to LDS as signed bytes (x - 128), one patch row (two for 16-wide patches) per k-step, and are
+//        multiplied on v_mfma_i32_32x32x32_i8 against the residual images quantised to 32-bit integers Q = round(r * 2^s) and
+//        split into four balanced base-256 digits: integer arithmetic, so x . Q is EXACT; |x . r - 2^-s x . Q| <= 2^-(s+1) * sum(x)
+//        is the only approximation.
 //     3. per window: norm, K = exp(-basis * norm), res_k = -bias + sum_p w[k][p] K_p with a rigorous error bound eps_k on
 //        |res_k - reference res_k| (quantisation, fast fp32 exp, fp32 summation order).  A window with res_k + eps_k < thr_k at ANY
 //        level k < L is rejected by the reference at some level <= k, so it cannot be a WVM positive and is dropped here.
@@ -22,11 +24,13 @@
 #pragma once
 
 constexpr int WVD_L = 16;          // filters evaluated densely (columns: 16 filters x 4 digits = 2 N-tiles of 32)
-constexpr int WVD_XSTRIDE = 48;    // bytes per window row of the LDS pixel chunk: 32 pixels + 16 pad (16 x odd: conflict-free b128)
-constexpr int WVD_TSTRIDE = 17;    // doubles per window row of the transposed dot products (odd: conflict-free b64)
+// LDS pixel chunk of a k-step: two planes of 64 windows x 16 bytes (k-slots 0..15 / 16..31): b128 writes (lane == window) and
+// b128 reads (lane == matrix row, plane = lane >> 5) are both conflict-free without padding
 
 typedef int wvd_v4i __attribute__((ext_vector_type(4)));
 typedef int wvd_v16i __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) unsigned int wvd_lds_u32;
+typedef __attribute__((address_space(3))) unsigned short wvd_lds_u16;
 
 struct WvdLayer {
     int32_t bx, by, nx, lw;
@@ -39,60 +43,95 @@ struct WvdTable {
     WvdLayer l[WVM_MAX_LAYERS];
 };
 
-// model constants of the dense stage (device memory, read through scalar loads)
+// per-level model constants of the dense stage (device memory)
 struct WvdConst {
-    int32_t L, pad0;
-    double scale;              // 2^-s
     double c128[WVD_L];        // 128 * sum_i Q_k[i]
     double pp[WVD_L];
     float thr[WVD_L];
     float w[WVD_L][WVD_L];     // hkWeights[k][p], p <= k
-    float negBasis, negBias, stretch, pad1;
-    double dnScale;            // 2^-s: error of the quantised dot product per unit of sum(x) is 2^-(s+1); norm uses 2 * xp
 };
 
 struct WvdDev {
-    const wvd_v4i* B;          // [KS][2 N-tiles][64 lanes] 16 signed digit bytes each
+    const wvd_v4i* B;          // [k-step][2 N-tiles][64 lanes] 16 signed digit bytes each (k-step = patch row; two rows when pw == 16)
     const WvdConst* c;
     int64_t* q;                // windows that pass
     unsigned int* qcount;
+    // scalars (kernel arguments, so that they live in SGPRs)
+    int32_t L;
+    float negBasis, negBias, stretch;
+    float sxxSlack;            // 2 * ph + 2: |fp32 row-ordered sum of squares - exact integer| when the sum is >= 2^24
+    double scale;              // 2^-s; also the error of norm per unit of sum(x): 2 * 2^-(s+1)
 };
 
 namespace {
 
-template <int PW_, int PH_>
-struct __attribute__((aligned(16))) WvdLds {
-    union {
-        unsigned short hist[64][64];                 // [bin][lane]: counters, then the lane's LUT
-        double tr[64 * WVD_TSTRIDE];                 // [window][filter] exact dot products (after the MFMA loop)
-    };
-    unsigned char x[64 * WVD_XSTRIDE];               // current k-step: 32 equalised pixels of every window, as x - 128
+template <int PW_>
+struct WvdGeo {
+    static constexpr int RPS = PW_ == 16 ? 2 : 1;   // patch rows per k-step (32 k-slots)
+#ifndef FD_WVD_WPE
+#define FD_WVD_WPE 4
+#endif
+    // wavefronts per SIMD the register allocation aims at (LDS allows 4 workgroups = 16 wavefronts per CU): at 128 VGPRs the
+    // two-row k-step of the 16-wide patches spills 1 KB, the others ~140 B
+    static constexpr int WPE = PW_ == 16 ? 3 : FD_WVD_WPE;
 };
+
+// LDS of a workgroup (4 wavefronts).  Every wavefront's histogram block is 8 KB-aligned so that (bin << 7) | (block + lane slot)
+// is a complete LDS address; after the MFMA loop the block holds the transposed dot products [window][filter] as doubles, row
+// stride 16 with the column XOR-swizzled by the row (2-way bank conflicts at most).
+struct __attribute__((aligned(8192))) WvdLds {
+    unsigned short hist[4][64][64];                  // [wave][bin][slot of the lane]: counters, then the lane's LUT
+    unsigned char x[4][2][64 * 16];                  // [wave][plane] current k-step: the equalised pixels of every window, as x - 128
+};
+static_assert(sizeof(unsigned short[64][64]) == 8192 && sizeof(double) * 64 * 16 == 8192, "transpose buffer aliases one histogram block");
 
 __device__ __forceinline__ unsigned int wvd_load_u32(const uint8_t* p) {
     unsigned int v;
     __builtin_memcpy(&v, p, 4);   // unaligned global_load_dword
     return v;
 }
+// LDS byte address of (bin of byte b of w4, this lane): two VALU instructions per pixel
+template <int B_>
+__device__ __forceinline__ unsigned int wvd_slot(unsigned int w4, unsigned int laneOff) {
+    unsigned int bin, a;
+    asm("v_bfe_u32 %0, %1, %2, 6" : "=v"(bin) : "v"(w4), "n"(8 * B_ + 2));
+    asm("v_lshl_or_b32 %0, %1, 7, %2" : "=v"(a) : "v"(bin), "v"(laneOff));
+    return a;
+}
+__device__ __forceinline__ void wvd_count(unsigned int ldsAddr, unsigned int inc) {   // ds_add_u32, no return value
+    __hip_atomic_fetch_add((wvd_lds_u32*)(uintptr_t)ldsAddr, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+__device__ __forceinline__ unsigned int wvd_lut(unsigned int ldsAddr) { return *(wvd_lds_u16*)(uintptr_t)ldsAddr; }   // ds_read_u16
+__device__ __forceinline__ unsigned int wvd_lshl_or(unsigned int a, int sh, unsigned int b) {
+    unsigned int r;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(sh), "v"(b));
+    return r;
+}
 
 // 64 consecutive windows of one layer per wavefront; 4 wavefronts per workgroup, persistent grid over the tiles.
 template <int PW_, int PH_>
-__global__ __launch_bounds__(256) void k_wvm_prefilter(const uint8_t* __restrict__ arena, WvdTable wt, WvdDev dv) {
-    static_assert(PW_ % 4 == 0 && PW_ >= 4 && PW_ <= 32, "rows are read as dwords");
-    constexpr int d = PW_ * PH_;
-    constexpr int KS = (d + 31) / 32;
-    __shared__ WvdLds<PW_, PH_> lds[4];
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>::WPE, 4))) void k_wvm_prefilter(const uint8_t* __restrict__ arena, WvdTable wt, WvdDev dv) {
+    static_assert(PW_ % 4 == 0 && PW_ >= 16 && PW_ <= 32, "rows are read as dwords; a row (or two 16-wide rows) fills one k-step");
+    constexpr int RPS = WvdGeo<PW_>::RPS;
+    static_assert(PH_ % RPS == 0, "whole k-steps");
+    constexpr int KS = PH_ / RPS;
+    constexpr int NW = PW_ / 4;          // dwords per patch row
+    __shared__ WvdLds S;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    WvdLds<PW_, PH_>& S = lds[wave];
-    const WvdConst& C = *dv.c;
-    const int L = C.L;
+    // constant address space: scalar loads (SMEM) even though the kernel also stores to global memory
+    const __attribute__((address_space(4))) WvdConst& C = *(const __attribute__((address_space(4))) WvdConst*)(uintptr_t)dv.c;
+    const int L = dv.L;
     const int ntiles = wt.ntiles;
     int li = 0;
-    unsigned char* histBase = reinterpret_cast<unsigned char*>(&S.hist[0][0]);
-    const unsigned int laneOff16 = (unsigned int)lane * 2u;             // byte offset of this lane's u16 slot inside a bin row
-    const unsigned int laneOff32 = (unsigned int)(lane >> 1) * 4u;      // dword holding it
-    const unsigned int inc = 1u << (16 * (lane & 1));
+    unsigned char* histPtr = reinterpret_cast<unsigned char*>(&S.hist[wave][0][0]);
+    unsigned char* xPtr = &S.x[wave][0][0];
+    double* trPtr = reinterpret_cast<double*>(histPtr);
+    const unsigned int histLds = (unsigned int)(uintptr_t)(wvd_lds_u16*)&S.hist[wave][0][0];   // LDS byte address, 8 KB-aligned
+    // lanes l and l + 32 share a dword of every bin row: they are served in different LDS cycles, so nothing conflicts
+    const unsigned int laneOff32 = histLds + (unsigned int)(lane & 31) * 4u;
+    const unsigned int laneOff16 = laneOff32 + (unsigned int)(lane >> 5) * 2u;
+    const unsigned int inc = 1u << (16 * (lane >> 5));
 
     for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
         while (li + 1 < wt.n && tile >= wt.l[li + 1].tileFirst) ++li;   // tiles ascend per wavefront
@@ -109,91 +148,123 @@ __global__ __launch_bounds__(256) void k_wvm_prefilter(const uint8_t* __restrict
 
         // ---- 1. histogram: 64 bins x 64 lanes of u16 counters
         {
-            uint4* z = reinterpret_cast<uint4*>(histBase);
+            uint4* z = reinterpret_cast<uint4*>(histPtr);
 #pragma unroll
             for (int i = 0; i < 8; ++i) z[i * 64 + lane] = make_uint4(0, 0, 0, 0);
         }
-        wave_sync();
+        __builtin_amdgcn_wave_barrier();
+        {
+            unsigned int wn[NW];
 #pragma unroll
-        for (int r = 0; r < PH_; ++r) {
+            for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(src + 4 * j);
+#pragma unroll 1
+            for (int r = 0; r < PH_; ++r) {   // one patch row per iteration, the next row's loads in flight
+                unsigned int w4[NW];
 #pragma unroll
-            for (int j = 0; j < PW_ / 4; ++j) {
-                const unsigned int w4 = wvd_load_u32(src + (size_t)r * lw + 4 * j);
+                for (int j = 0; j < NW; ++j) w4[j] = wn[j];
+                const uint8_t* nsrc = src + (size_t)(r + 1 < PH_ ? r + 1 : r) * lw;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const unsigned int bin = __builtin_amdgcn_ubfe(w4, 8 * b + 2, 6);
-                    atomicAdd(reinterpret_cast<unsigned int*>(histBase + (bin << 7) + laneOff32), inc);
+                for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(nsrc + 4 * j);
+#pragma unroll
+                for (int j = 0; j < NW; ++j) {
+                    wvd_count(wvd_slot<0>(w4[j], laneOff32), inc);
+                    wvd_count(wvd_slot<1>(w4[j], laneOff32), inc);
+                    wvd_count(wvd_slot<2>(w4[j], laneOff32), inc);
+                    wvd_count(wvd_slot<3>(w4[j], laneOff32), inc);
                 }
             }
         }
         wave_sync();
-        // ---- 2. the fp32 cdf in the reference's order (cdf[0] = pdf[0]; cdf[b] = cdf[b-1] + pdf[b]) and the LUT
+        // ---- 2. the fp32 cdf in the reference's order (cdf[0] = pdf[0]; cdf[b] = cdf[b-1] + pdf[b]), the LUT, and the exact
+        //         integer sum / sum of squares of the equalised patch
+        unsigned int sumx = 0, sumxx = 0;
         {
             float cdf = 0.f;
 #pragma unroll
             for (int b = 0; b < 64; ++b) {
-                unsigned short* slot = reinterpret_cast<unsigned short*>(histBase + (b << 7) + laneOff16);
-                const float pdf = (float)(unsigned int)*slot * C.stretch;
+                wvd_lds_u16* slot = (wvd_lds_u16*)(uintptr_t)((unsigned int)(b << 7) + laneOff16);   // laneOff16 is a complete LDS address
+                const unsigned int cnt = *slot;
+                const float pdf = (float)cnt * dv.stretch;
                 cdf = b == 0 ? pdf : cdf + pdf;
                 // (uchar)floor((double)cdf + 0.5): cdf < 2^9 has at most 24 significant bits, so cdf + 0.5 is exact in double;
-                // floor(cdf) + (frac >= 0.5) is the same value without leaving fp32
+                // floor(cdf) + (frac >= 0.5) is the same value without leaving fp32 (cdf + 0.5f itself can round up to an integer)
                 const float fl = floorf(cdf);
                 const float up = (cdf - fl >= 0.5f) ? fl + 1.0f : fl;
-                *slot = (unsigned short)((unsigned int)up & 255u);
+                const unsigned int e = (unsigned int)up & 255u;
+                *slot = (unsigned short)e;
+                const unsigned int ce = cnt * e;   // <= 768 * 255
+                sumx += ce;
+                sumxx += ce * e;                   // <= 768 * 65025 < 2^26
+                asm("" : "+v"(sumx), "+v"(sumxx));   // accumulate here (sunk to their use, the 128 products spill)
             }
         }
         wave_sync();
-        // ---- 3. equalise, sum of squares in the reference's order, exact dot products on the matrix pipe
+        // ---- 3. equalise, exact dot products on the matrix pipe: one k-step per patch row (two rows when the patch is 16 wide)
         wvd_v16i acc00 = {}, acc01 = {}, acc10 = {}, acc11 = {};
-        float sxx = 0.f;
-        unsigned int rowq = 0, sumx = 0;
+        {
+            unsigned int wn[RPS][NW];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const wvd_v4i b0 = dv.B[(ks * 2 + 0) * 64 + lane];
-            const wvd_v4i b1 = dv.B[(ks * 2 + 1) * 64 + lane];
+            for (int rr = 0; rr < RPS; ++rr)
 #pragma unroll
-            for (int qd = 0; qd < 2; ++qd) {
-                unsigned int pk[4];
+                for (int j = 0; j < NW; ++j) wn[rr][j] = wvd_load_u32(src + (size_t)rr * lw + 4 * j);
+            wvd_v4i bn0 = dv.B[lane], bn1 = dv.B[64 + lane];
+#pragma unroll 1
+            for (int ks = 0; ks < KS; ++ks) {
+                const wvd_v4i b0 = bn0, b1 = bn1;
+                unsigned int w4[RPS][NW];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int p0 = ks * 32 + qd * 16 + g * 4;   // first pixel of this dword (compile time)
-                    unsigned int packed = 0;
-                    if (p0 < d) {
-                        const int r = p0 / PW_, c0 = p0 % PW_;
-                        const unsigned int w4 = wvd_load_u32(src + (size_t)r * lw + c0);
+                for (int rr = 0; rr < RPS; ++rr)
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) {
-                            const unsigned int bin = __builtin_amdgcn_ubfe(w4, 8 * b + 2, 6);
-                            const unsigned int e = *reinterpret_cast<unsigned short*>(histBase + (bin << 7) + laneOff16);
-                            rowq += e * e;
-                            packed |= e << (8 * b);
-                        }
-                        sumx += __builtin_amdgcn_sad_u8(packed, 0u, 0u);
-                        if (c0 + 4 == PW_) {   // end of patch row r: IImg.cpp:33-47 adds the row's exact int sum in fp32
-                            sxx = r == 0 ? (float)rowq : sxx + (float)rowq;
-                            rowq = 0;
-                        }
-                        packed ^= 0x80808080u;   // x - 128 as int8
-                    }
-                    pk[g] = packed;
+                    for (int j = 0; j < NW; ++j) w4[rr][j] = wn[rr][j];
+                {   // next k-step's rows and digits (the last step re-reads its own)
+                    const int kn = ks + 1 < KS ? ks + 1 : ks;
+                    const uint8_t* nsrc = src + (size_t)(kn * RPS) * lw;
+#pragma unroll
+                    for (int rr = 0; rr < RPS; ++rr)
+#pragma unroll
+                        for (int j = 0; j < NW; ++j) wn[rr][j] = wvd_load_u32(nsrc + (size_t)rr * lw + 4 * j);
+                    bn0 = dv.B[(kn * 2 + 0) * 64 + lane];
+                    bn1 = dv.B[(kn * 2 + 1) * 64 + lane];
                 }
-                *reinterpret_cast<uint4*>(&S.x[lane * WVD_XSTRIDE + qd * 16]) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                unsigned int pk[RPS * NW];
+#pragma unroll
+                for (int rr = 0; rr < RPS; ++rr) {
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) {
+                        const unsigned int w = w4[rr][j];
+                        const unsigned int e0 = wvd_lut(wvd_slot<0>(w, laneOff16));
+                        const unsigned int e1 = wvd_lut(wvd_slot<1>(w, laneOff16));
+                        const unsigned int e2 = wvd_lut(wvd_slot<2>(w, laneOff16));
+                        const unsigned int e3 = wvd_lut(wvd_slot<3>(w, laneOff16));
+                        pk[rr * NW + j] = wvd_lshl_or(e3, 24, wvd_lshl_or(e2, 16, wvd_lshl_or(e1, 8, e0))) ^ 0x80808080u;   // x - 128 as int8
+                    }
+                }
+                // slots RPS * PW_ .. 31 of the k-step are never written: their digits are zero, so stale bytes multiply into nothing
+                unsigned char* xrow = xPtr + lane * 16;
+                constexpr int ND = RPS * NW;   // 4, 5, 6 or 8 dwords
+                *reinterpret_cast<uint4*>(xrow) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                if constexpr (ND == 5) *reinterpret_cast<unsigned int*>(xrow + 1024) = pk[4];
+                if constexpr (ND == 6) *reinterpret_cast<uint2*>(xrow + 1024) = make_uint2(pk[4], pk[5]);
+                if constexpr (ND == 8) *reinterpret_cast<uint4*>(xrow + 1024) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+                __builtin_amdgcn_wave_barrier();   // LDS operations of a wavefront execute in order: the reads below see these writes
+                const wvd_v4i a0 = *reinterpret_cast<const wvd_v4i*>(xPtr + (lane >> 5) * 1024 + (lane & 31) * 16);
+                const wvd_v4i a1 = *reinterpret_cast<const wvd_v4i*>(xPtr + (lane >> 5) * 1024 + (32 + (lane & 31)) * 16);
+                __builtin_amdgcn_wave_barrier();
+                acc00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc11, 0, 0, 0);
             }
-            wave_sync();
-            const wvd_v4i a0 = *reinterpret_cast<const wvd_v4i*>(&S.x[(lane & 31) * WVD_XSTRIDE + (lane >> 5) * 16]);
-            const wvd_v4i a1 = *reinterpret_cast<const wvd_v4i*>(&S.x[(32 + (lane & 31)) * WVD_XSTRIDE + (lane >> 5) * 16]);
-            wave_sync();
-            acc00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc01, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc11, 0, 0, 0);
         }
         // ---- 4. digits -> exact integer dot products, transposed to lane == window.  Column g = f + 16 j of N-tile g / 32 holds
         //         digit j of filter f: this lane (column lane & 31) has digit j0 = (lane >> 4) & 1 in tile 0 and digit j0 + 2 in tile 1
         wave_sync();   // the LUT is dead: the region becomes the transpose buffer
         {
-            const int f = lane & 15;
-            const bool lowDigit = (lane & 16) == 0;
+            int laneT = lane;
+            asm volatile("" : "+v"(laneT));   // the 32 slot addresses are cheap: computed here, not hoisted out of the tile loop and spilled
+            const bool lowDigit = (laneT & 16) == 0;
+            const int h4 = 4 * (laneT >> 5);
+            const int fh = (laneT & 15) ^ h4;   // row & 15 = (rowc & 15) | h4 (rowc & 15 has bit 2 clear), so f ^ (row & 15) = fh ^ (rowc & 15)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -202,8 +273,8 @@ __global__ __launch_bounds__(256) void k_wvm_prefilter(const uint8_t* __restrict
                     const int s2 = mt == 0 ? acc01[rg] : acc11[rg];
                     const double part = (double)s0 + 65536.0 * (double)s2;          // exact: |s| < 2^24
                     const double other = __shfl_xor(part, 16);
-                    const int row = (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
-                    if (lowDigit) S.tr[(mt * 32 + row) * WVD_TSTRIDE + f] = part + 256.0 * other;   // exact: < 2^53
+                    const int rowc = mt * 32 + (rg & 3) + 8 * (rg >> 2);             // window row = rowc + h4
+                    if (lowDigit) trPtr[(rowc + h4) * 16 + (fh ^ (rowc & 15))] = part + 256.0 * other;   // exact: < 2^53
                 }
             }
         }
@@ -211,39 +282,44 @@ __global__ __launch_bounds__(256) void k_wvm_prefilter(const uint8_t* __restrict
         // ---- 5. the first L cascade levels of this lane's window with error bounds
         bool undecided = valid;
         {
+            int laneC = lane;
+            asm volatile("" : "+v"(laneC));   // as above, for the 16 read addresses
             float Kv[WVD_L], Ke[WVD_L];
-            const double dn = C.dnScale * (double)sumx + 1e-5;   // |norm - reference norm| (2 * quantisation error + fp64 slack)
-            const float relDn = (float)(-(double)C.negBasis * dn) * 1.0001f;
+            // the reference's fp32 sum of squares: row totals (exact ints) added in fp32, so it IS the integer below 2^24
+            const float sxx = (float)sumxx;
+            // |norm - reference norm|: 2 * quantisation error of xp, the fp32 sum of squares above 2^24, slack for the reference's
+            // fp64 roundings (< 1e-5)
+            const double dn = dv.scale * (double)sumx + (sumxx >= (1u << 24) ? (double)dv.sxxSlack : 0.0) + 1e-4;
+            const float relDn = (float)(-(double)dv.negBasis * dn) * 1.0001f;
 #pragma unroll
             for (int k = 0; k < WVD_L; ++k) {
                 if (k < L) {
-                    const double xp = (S.tr[lane * WVD_TSTRIDE + k] + C.c128[k]) * C.scale;
+                    const double xp = (trPtr[laneC * 16 + (k ^ (laneC & 15))] + C.c128[k]) * dv.scale;
                     double norm = (double)sxx;
                     norm = norm - 2 * xp;
                     norm = norm + C.pp[k];
-                    const float arg = (float)((double)C.negBasis * norm);
+                    const float arg = (float)((double)dv.negBasis * norm);
                     float Kk, Kerr;
                     if (arg < -80.0f) { Kk = 0.f; Kerr = 2e-35f; }           // true K <= e^-80 (1 + tiny)
                     else if (arg > 80.0f) { Kk = 0.f; Kerr = 3.0e38f; }       // cannot happen for a sane model: never reject
                     else {
                         Kk = __expf(arg);
-                        // relative: exponent error (quantisation, float cast of the argument, x*log2e, 2^x) + final rounding
-                        const float rho = relDn + fabsf(arg) * 2.4e-7f + 6.0e-7f;
-                        Kerr = Kk * rho * 1.01f + 1e-37f;
+                        // relative error of K: exponent error (quantisation, float cast of the argument, x * log2e, 2^x), the final
+                        // rounding, and -- folded in here -- the fp32 summation-order term (4k + 16) 2^-24 <= 4.6e-6 of the level sums
+                        const float rho = (relDn + fabsf(arg) * 2.4e-7f + 6.0e-7f) * 1.01f + 4.6e-6f;
+                        Kerr = Kk * rho + 1e-37f;
                     }
                     Kv[k] = Kk;
                     Ke[k] = Kerr;
-                    float R = C.negBias, A = fabsf(C.negBias), E = 0.f;
+                    float R = dv.negBias, E = fabsf(dv.negBias) * 4.6e-6f + 1e-37f;
 #pragma unroll
                     for (int p = 0; p <= k; ++p) {
                         const float w = C.w[k][p];
                         R = fmaf(w, Kv[p], R);
-                        A = fmaf(fabsf(w), Kv[p], A);
                         E = fmaf(fabsf(w), Ke[p], E);
                     }
-                    const float eps = E + A * ((float)(4 * k + 16) * 5.97e-8f) + 1e-37f;
-                    // the reference leaves at the first level with res < thr; res_ref <= R + eps
-                    if (undecided && (R + eps < C.thr[k])) undecided = false;
+                    // the reference leaves at the first level with res < thr, and res_ref <= R + E
+                    if (undecided && (R + E < C.thr[k])) undecided = false;
                 }
             }
         }

@@ -4,6 +4,14 @@ import sys
 import numpy as np
 import pytest
 
+# torch wheels bundle their own HIP runtime (torch/lib/libamdhip64.so): whichever of torch / libfd_hip.so is loaded first decides
+# which runtime the process uses, and torch initialised AFTER the system runtime reports "No HIP GPUs are available".  The GPU
+# tests that stage frames in HBM through torch therefore need torch first -- exactly the order bench.py uses.
+try:
+    import torch  # noqa: F401
+except Exception:   # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
