@@ -12,12 +12,70 @@
 #include <typeinfo>
 #include <vector>
 #include <stdexcept>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include "../../include/fd_hip.h"
 #include "../../include/fd_hip_bench.h"
 
 struct FdPinned {   // pinned host scratch (allocated lazily): pageable async copies cost ~1 ms each on this stack
     void* p = nullptr;
     size_t cap = 0;
+};
+
+// A few persistent host threads for the per-detector host stages of the batch entry points (ordering the positives, overlap
+// elimination, the SVM launch, NMS): run(f) executes f on every worker and on the caller and returns when all are done.
+struct FdWorkerPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, cvDone;
+    std::function<void()> job;
+    uint64_t gen = 0;
+    int pending = 0;
+    bool stop = false;
+    explicit FdWorkerPool(int n) {
+        for (int i = 0; i < n; ++i) th.emplace_back([this] { loop(); });
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            std::function<void()> j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen;
+                j = job;
+            }
+            j();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--pending == 0) cvDone.notify_one();
+            }
+        }
+    }
+    void run(const std::function<void()>& f) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = f;
+            pending = (int)th.size();
+            ++gen;
+        }
+        cv.notify_all();
+        f();
+        std::unique_lock<std::mutex> lk(mu);
+        cvDone.wait(lk, [&] { return pending == 0; });
+    }
+    ~FdWorkerPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
 };
 
 struct fd_ctx {
@@ -34,6 +92,7 @@ struct fd_ctx {
     hipStream_t aux = nullptr;   // second stream (created on first use): small follow-up work that must not queue behind ctx->stream
     hipStream_t pool[8] = {};   // batch jobs are spread over these (created on first use)
     hipStream_t tail = nullptr; // high-priority stream of the batch entry points' follow-up kernels (created on first use)
+    std::unique_ptr<FdWorkerPool> workers;   // created on first use by the batch entry points (FD_BATCH_THREADS)
     // per-context device scratch of the translation units (fd_scratch<T>): owned by the context, freed with it
     std::map<std::type_index, std::shared_ptr<void>> scratch;
 };
@@ -215,7 +274,17 @@ struct fd_pyramid {
     uint32_t gray_full_off = 0;
     size_t arena_bytes = 0;
     uint64_t version = 0;            // bumped by every update
+    // recorded on the updating stream after the last kernel of an update: consumers on OTHER streams (the stream pool of the
+    // batch entry points) wait for it; consumers on the same stream are ordered anyway
+    hipEvent_t ready = nullptr;
+    hipStream_t readyStream = nullptr;
+    ~fd_pyramid() { if (ready) (void)hipEventDestroy(ready); }
 };
+
+// makes `consumer` wait for the pyramid's last update when that ran on another stream
+static inline void fd_pyramid_wait(const fd_pyramid* p, hipStream_t consumer) {
+    if (p->ready && consumer != p->readyStream) HIP_CHECK(hipStreamWaitEvent(consumer, p->ready, 0));
+}
 
 void fd_enumerate_layers(const fd_pyramid* p, int pw, int ph, int sx, int sy, const int* roi,
                          std::vector<WindowLayer>& out, int64_t& total);

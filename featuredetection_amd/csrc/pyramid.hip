@@ -423,6 +423,9 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
         flush();
     }
     HIP_CHECK(hipGetLastError());
+    if (!p->ready) HIP_CHECK(hipEventCreateWithFlags(&p->ready, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(p->ready, st));
+    p->readyStream = st;
     p->version++;
 }
 

@@ -530,23 +530,30 @@ void fd_svm_rbf_mfma_launch(fd_ctx* ctx, const fd_svm* m, const float* xFrag, co
 }
 
 // generic scoring of n device-resident feature vectors (optionally gathered by slot index)
+void fd_svm_generic_launch_on(hipStream_t st, const fd_svm* m, const void* dfeat, const uint32_t* didx, int64_t stride_bytes,
+                              int64_t n, double* dout);
 void fd_svm_generic_launch(fd_ctx* ctx, const fd_svm* m, const void* dfeat, const uint32_t* didx, int64_t stride_bytes,
                            int64_t n, double* dout) {
+    fd_svm_generic_launch_on(ctx->stream, m, dfeat, didx, stride_bytes, n, dout);
+}
+// explicit stream: callable from the worker threads of the batch entry points (touches no context state)
+void fd_svm_generic_launch_on(hipStream_t st, const fd_svm* m, const void* dfeat, const uint32_t* didx, int64_t stride_bytes,
+                              int64_t n, double* dout) {
     if (n <= 0) return;
     if (m->dev.dtype == FD_DTYPE_U8) {
         const size_t lb = (size_t)SU_PB * m->dev.dpad;
         if (lb > 64 * 1024) FD_THROW(FD_ERR_INVALID_ARGUMENT, "feature vector too long (%d)", m->dev.dim);
         const unsigned grid = (unsigned)((n + SU_PB - 1) / SU_PB);
         if (m->dev.kernel == FD_KERNEL_HIK)
-            hipLaunchKernelGGL(k_svm_u8_lanes<true>, dim3(grid), dim3(256), lb, ctx->stream, m->dev, dfeat, didx, stride_bytes, n, dout);
+            hipLaunchKernelGGL(k_svm_u8_lanes<true>, dim3(grid), dim3(256), lb, st, m->dev, dfeat, didx, stride_bytes, n, dout);
         else
-            hipLaunchKernelGGL(k_svm_u8_lanes<false>, dim3(grid), dim3(256), lb, ctx->stream, m->dev, dfeat, didx, stride_bytes, n, dout);
+            hipLaunchKernelGGL(k_svm_u8_lanes<false>, dim3(grid), dim3(256), lb, st, m->dev, dfeat, didx, stride_bytes, n, dout);
         HIP_CHECK(hipGetLastError());
         return;
     }
     const size_t ldsBytes = m->dev.dtype == FD_DTYPE_U8 ? (size_t)m->dev.dpad : (size_t)m->dev.dim * 4;
     if (ldsBytes > 64 * 1024) FD_THROW(FD_ERR_INVALID_ARGUMENT, "feature vector too long (%d)", m->dev.dim);
-    hipLaunchKernelGGL(k_svm_generic, dim3((unsigned)n), dim3(256), ldsBytes, ctx->stream, m->dev, dfeat, didx, stride_bytes, dout);
+    hipLaunchKernelGGL(k_svm_generic, dim3((unsigned)n), dim3(256), ldsBytes, st, m->dev, dfeat, didx, stride_bytes, dout);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -22,6 +22,8 @@
 #include <algorithm>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <atomic>
 
 
 // from svm.hip
@@ -31,6 +33,7 @@ bool fd_svm_is_u8(const fd_svm* m);
 float fd_svm_threshold(const fd_svm* m);
 double fd_svm_probability(const fd_svm* m, double d);
 void fd_svm_generic_launch(fd_ctx* ctx, const fd_svm* m, const void* dfeat, const uint32_t* didx, int64_t stride_bytes, int64_t n, double* dout);
+void fd_svm_generic_launch_on(hipStream_t st, const fd_svm* m, const void* dfeat, const uint32_t* didx, int64_t stride_bytes, int64_t n, double* dout);
 
 constexpr int WVM_MAX_LAYERS = 64;
 constexpr int WVM_MAX_DIM = 32;      // patch width/height limit of this kernel
@@ -1492,6 +1495,7 @@ void fd_wvm_launch(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, int sx, int sy, const 
         FD_THROW(FD_ERR_INVALID_ARGUMENT, "WVM detection needs a gray pyramid (no layer filter)");
     if (p->all.empty()) FD_THROW(FD_ERR_RUNTIME, "pyramid has not been updated with an image");
     HIP_CHECK(hipSetDevice(ctx->device));
+    fd_pyramid_wait(p, ctx->stream);   // the batch entry points launch on pool streams, the caller may have updated on the context's
     WinTable wt;
     fd_wvm_build_table(p, m->dev.fw, m->dev.fh, sx, sy, roi, wt, run.wls);
     wvm_launch_table(ctx, p, m, wt, want_all, run, time_kernel);
@@ -1809,7 +1813,8 @@ struct FiveStageTail {
                const int* roi_, hipStream_t st, fd_detection* out_, int cap_, int* count_, int32_t* stage_counts_) {
         ctx = ctx_; p = p_; m = m_; svm = svm_; roi = roi_; out = out_; cap = cap_; count = count_; stage_counts = stage_counts_;
         t0 = std::chrono::steady_clock::now();
-        FdStreamSwap swap(ctx, st);   // fd_svm_generic_launch works on ctx->stream
+        // everything below launches on `st` explicitly and touches no shared context state: tails of different jobs may run on
+        // different host threads (five_stage_batch_end)
         fd_wvm_positives_to_detections(p, m, run, sx, sy, wvmPos);
         if (stage_counts) stage_counts[0] = (int)wvmPos.size();
         lap("to_dets");
@@ -1830,7 +1835,7 @@ struct FiveStageTail {
             char* pin = m->h_tail.as<char>();
             std::memcpy(pin, slots.data(), sizeof(uint32_t) * slots.size());
             HIP_CHECK(hipMemcpyAsync(idx.p, pin, sizeof(uint32_t) * slots.size(), hipMemcpyHostToDevice, st));
-            fd_svm_generic_launch(ctx, svm, m->pos_patches.p, idx.as<uint32_t>(), (int64_t)m->dev.d, (int64_t)slots.size(), m->all_fout.as<double>());
+            fd_svm_generic_launch_on(st, svm, m->pos_patches.p, idx.as<uint32_t>(), (int64_t)m->dev.d, (int64_t)slots.size(), m->all_fout.as<double>());
             HIP_CHECK(hipMemcpyAsync(pin + distOff, m->all_fout.p, sizeof(double) * slots.size(), hipMemcpyDeviceToHost, st));
             if (!m->tailDone) HIP_CHECK(hipEventCreateWithFlags(&m->tailDone, hipEventDisableTiming));
             HIP_CHECK(hipEventRecord(m->tailDone, st));
@@ -1981,6 +1986,62 @@ static void five_stage_batch_end(fd_ctx* ctx, fd_five_stage_batch& b) {
     };
     static const bool tailOnPool = getenv("FD_TAIL_ON_POOL") != nullptr;
     static const bool inOrder = getenv("FD_BATCH_IN_ORDER") != nullptr;
+    // Large batches (config 3: 15 detectors, thousands of WVM positives each) take ~1 ms of host work per detector -- more than
+    // the GPU needs for its cascade since the dense pre-filter -- so the detectors are handed to a few host threads: each worker
+    // claims a detector whose cascade has finished, reads its positives back, runs the overlap elimination, queues the SVM stage
+    // on the shared high-priority stream, waits for it and finishes with the NMS.  Everything a worker touches belongs to its
+    // job (WVM handle, pinned staging, events); the streams are created up front.  FD_BATCH_THREADS=1 keeps it on the caller.
+    static const int nthreads = [] { const char* e = getenv("FD_BATCH_THREADS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+    int64_t totalWindows = 0;
+    for (int i = 0; i < n; ++i) totalWindows += b.runs[i].total;
+    if (nthreads > 1 && !inOrder && (n >= 6 || totalWindows >= (int64_t)4 << 20) && n >= 2) {
+        if (!ctx->workers) ctx->workers.reset(new FdWorkerPool(nthreads - 1));
+        hipStream_t tailStream = tailOnPool ? nullptr : fd_tail_stream(ctx);
+        (void)fd_aux_stream(ctx);
+        for (int i = 0; tailOnPool && i < n; ++i) (void)fd_pool_stream(ctx, i);
+        std::vector<std::atomic<char>> claimed((size_t)n);
+        for (auto& c : claimed) c.store(0);
+        std::mutex errMu;
+        auto cascadeDone = [&](int i) {
+            return b.runs[i].total == 0 || hipEventQuery(jobs[i].wvm->done) != hipErrorNotReady;
+        };
+        auto work = [&] {
+            (void)hipSetDevice(ctx->device);
+            for (;;) {
+                int pick = -1;
+                bool open = false;
+                for (int i = 0; i < n && pick < 0; ++i) {
+                    if (claimed[i].load(std::memory_order_relaxed)) continue;
+                    open = true;
+                    if (cascadeDone(i) && claimed[i].exchange(1) == 0) pick = i;
+                }
+                if (pick < 0) {
+                    if (!open) return;
+                    std::this_thread::yield();
+                    continue;
+                }
+                fd_five_stage_job& j = jobs[pick];
+                fd_wvm* m = const_cast<fd_wvm*>(j.wvm);
+                try {
+                    fd_wvm_finish(ctx, m, b.runs[pick]);
+                    tails[pick].begin(ctx, j.pyramid, m, j.svm, b.runs[pick], j.oe_dist, j.oe_ratio, j.step_x, j.step_y, j.roi,
+                                      tailOnPool ? fd_pool_stream(ctx, pick) : tailStream, j.out, j.cap, &counts[pick], j.stage_counts);
+                    tails[pick].end();
+                    j.count = counts[pick];
+                } catch (const FdError& e) {
+                    std::lock_guard<std::mutex> lk(errMu);
+                    tails[pick].finished = true;
+                    fail(pick, e);
+                }
+            }
+        };
+        ctx->workers->run(work);
+        if (trace)
+            fprintf(stderr, "[fd batch] end: %.1f us in total on %d host threads\n",
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tEnd0).count(), nthreads);
+        if (firstError != FD_OK) throw FdError{firstError, ctx->error};
+        return;
+    }
     // Detectors are taken in the order their cascades complete, not in job order: the streams of the pool do not advance evenly
     // (a trace showed the first job's event 34 ms into a 38 ms frame while jobs 1..14 had long finished), and blocking on job 0
     // would push every host stage behind the last cascade.  While nothing is ready the host polls (events of the cascades, then of

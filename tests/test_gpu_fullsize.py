@@ -201,3 +201,39 @@ def test_config2_full_size_tiles_and_positives(oracle, capi, ctx, synth):
     flips = (do >= thr) != (dist[idx] >= thr)
     assert np.all(np.abs(do[flips] - thr) <= 1e-4 * scale)
     sg.close(); pg.close(); po.close()
+
+
+def test_batch_on_pool_streams_waits_for_the_pyramid_update(oracle, capi, ctx, synth):
+    """The batch entry points launch the cascades on a pool of streams while fd_pyramid_update runs on the context's stream: the
+    cascades must wait for the update they read (event recorded by the update).  Two 1080p frames alternate through
+    update_device + fd_five_stage_batch_begin/_end without any host synchronisation in between; every repetition must return
+    the detections of a fully synchronous run."""
+    import torch
+    models = [m for m in _models(synth, oracle, nsv=128) if m[0] in ("FaceLeftProfile", "LeftEarCenter", "LeftEyeOuterCorner", "NoseTip", "LeftLipCorner")]
+    frames = [synth.make_frame(1920, 1080, seed=s) for s in (11, 12)]
+    dfr = [torch.from_numpy(f).cuda() for f in frames]
+    torch.cuda.synchronize()
+    pyrs, dets = {}, []
+    for name, key, wm, sm, pw, ph in models:
+        if key not in pyrs:
+            pyrs[key] = capi.Pyramid(ctx, **_kw(key))
+        dets.append((pyrs[key], capi.Wvm(ctx, wm), capi.Svm(ctx, sm)))
+    ref = []
+    for f in frames:   # synchronous reference: host update, context synchronised, single calls
+        for p in pyrs.values():
+            p.update(f)
+        ctx.synchronize()
+        ref.append([capi.detect_five_stage(ctx, p, w, s, cap=1 << 13) for p, w, s in dets])
+    assert sum(len(d) for d, _ in ref[0]) > 10
+    for it in range(8):
+        k = it % 2
+        for p in pyrs.values():
+            p.update_device(dfr[k].data_ptr(), 1920, 1080, 3)
+        res = capi.FiveStageBatch(ctx, dets, cap=1 << 13).end()
+        for (d, s), (dr, sr) in zip(res, ref[k]):
+            assert np.array_equal(s, sr), (it, s, sr)
+            assert d.tobytes() == dr.tobytes(), it
+    for p, w, s in dets:
+        w.close(); s.close()
+    for p in pyrs.values():
+        p.close()
