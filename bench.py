@@ -147,7 +147,7 @@ class Cascade(Workload):
     name = "cascade"
     dtype = "u8/i32/f32/f64"
 
-    def __init__(self, env, W=640, H=480, frames_per_step=512, nb=4):
+    def __init__(self, env, W=640, H=480, frames_per_step=512, nb=16):
         import torch
         from featuredetection_amd import capi, synth
         self.env, self.capi, self.W, self.H = env, capi, W, H
@@ -711,6 +711,7 @@ def main():
     ap.add_argument("--gather-every", type=int, default=4)
     ap.add_argument("--size", default=None, help="frame size WxH of the headline workload (cascade, hog_svm, ffp15, rvm, aggregated)")
     ap.add_argument("--frames-per-step", type=int, default=0, help="frames (sdm: batches) per step of the headline workload; 0 = its default")
+    ap.add_argument("--frames-per-call", type=int, default=0, help="cascade workload: frames per fd_detect_five_stage_batch call; 0 = default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.workload == "wvm":
@@ -747,6 +748,8 @@ def main():
             kw["batches_per_step" if name == "sdm" else "frames_per_step"] = args.frames_per_step
             if name in ("rvm", "aggregated"):
                 kw.pop("frames_per_step")
+        if headline and args.frames_per_call > 0 and name == "cascade":
+            kw["nb"] = args.frames_per_call
         return WORKLOADS[name](env, **kw)
 
     also = args.also

@@ -286,6 +286,7 @@ static inline void fd_pyramid_wait(const fd_pyramid* p, hipStream_t consumer) {
     if (p->ready && consumer != p->readyStream) HIP_CHECK(hipStreamWaitEvent(consumer, p->ready, 0));
 }
 
+void fd_pyramid_update_on(fd_pyramid* p, const uint8_t* image, int w, int h, int ch, int is_device, hipStream_t st);
 void fd_enumerate_layers(const fd_pyramid* p, int pw, int ph, int sx, int sy, const int* roi,
                          std::vector<WindowLayer>& out, int64_t& total);
 

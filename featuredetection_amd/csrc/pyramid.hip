@@ -331,11 +331,10 @@ void build_layout(fd_pyramid* p, int W, int H) {
 
 int grid_for(int npix) { return std::max(1, std::min(1024, (npix + 255) / 256)); }
 
-void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, int is_device) {
+void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, int is_device, hipStream_t st) {
     if (!image) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_update: image is NULL");
     if (W < 1 || H < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_update: empty image");
     if (ch != 1 && ch != 3) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_update: image must have 1 or 3 channels");
-    hipStream_t st = p->ctx->stream;
     if (W != p->img_w || H != p->img_h || p->all.empty()) build_layout(p, W, H);
     uint8_t* arena = p->arena.as<uint8_t>();
     const size_t npix = (size_t)W * H;
@@ -430,6 +429,13 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
 }
 
 }  // namespace
+
+// fd_pyramid_update on an explicit stream (worker threads of the batch entry points); throws FdError
+void fd_pyramid_update_on(fd_pyramid* p, const uint8_t* image, int w, int h, int ch, int is_device, hipStream_t st) {
+    if (!p) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_update: NULL pyramid");
+    HIP_CHECK(hipSetDevice(p->ctx->device));
+    pyramid_update(p, image, w, h, ch, is_device, st);
+}
 
 // DirectPyramidFeatureExtractor::extract(stepX, stepY, roi) window grid, :75-123
 void fd_enumerate_layers(const fd_pyramid* p, int pw, int ph, int sx, int sy, const int* roiIn,
@@ -539,7 +545,7 @@ int fd_pyramid_update(fd_pyramid* p, const uint8_t* image, int w, int h, int ch,
     return fd_guard(p ? p->ctx : nullptr, [&] {
         if (!p) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_update: NULL pyramid");
         HIP_CHECK(hipSetDevice(p->ctx->device));
-        pyramid_update(p, image, w, h, ch, is_device);
+        pyramid_update(p, image, w, h, ch, is_device, p->ctx->stream);
     });
 }
 

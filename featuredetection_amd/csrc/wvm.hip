@@ -105,6 +105,8 @@ struct fd_wvm {
     DevBuf all_level, all_fout, pos, pos_patches, counter, deep_q, list;
     // dense pre-filter (wvm_dense.hpp): digit matrix, constants, queue of the windows it lets through
     DevBuf denseB, denseC, pre_q;
+    bool hdrClean = false;    // device header words are zero (left so by a zero-copy run): no memset needed
+    bool zcRun = false;       // the run in flight reads back zero-copy
     int denseL = 0;   // 0: the model has no dense stage
     double denseScale = 0;   // 2^-s of the quantised residual images
     HostBuf h_pos;
@@ -328,15 +330,40 @@ __device__ __forceinline__ float wvm_level_K(const WvmDev& m, const unsigned int
 }
 
 struct CascadeOut {
-    int32_t* all_level;
-    float* all_fout;
-    PosRec* pos;
-    uint8_t* pos_patches;
-    unsigned int* pos_count;
-    unsigned int pos_cap;
-    int64_t* deep_q;           // windows that survive the first WVM_LCAP levels (finished by k_wvm_deep)
-    unsigned int* deep_count;
+    int32_t* all_level = nullptr;
+    float* all_fout = nullptr;
+    PosRec* pos = nullptr;
+    uint8_t* pos_patches = nullptr;
+    unsigned int* pos_count = nullptr;
+    unsigned int pos_cap = 0;
+    int64_t* deep_q = nullptr;           // windows that survive the first WVM_LCAP levels (finished by k_wvm_deep)
+    unsigned int* deep_count = nullptr;
+    // zero-copy read-back (host_count != NULL): `pos` is host-mapped pinned memory, and the last workgroup of stage B to retire
+    // stores the positive count there and clears the device header {pos_count, deep_count, pre-queue count, done_blocks} for
+    // the next run -- no copy, no memset on the stream, the event can be recorded straight after stage B
+    unsigned int* host_count = nullptr;
+    unsigned int* done_blocks = nullptr;
 };
+
+// end of a stage-B kernel: see CascadeOut::host_count
+__device__ __forceinline__ void wvm_finalize(const CascadeOut& o) {
+    if (!o.host_count) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned int done = atomicAdd(o.done_blocks, 1u);
+        if (done == gridDim.x - 1) {
+            __threadfence();
+            const unsigned int cnt = __hip_atomic_load(o.pos_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(o.host_count, cnt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // header words 0..3 of the device buffer: positives, stage-B queue, pre-filter queue, retired workgroups
+            __hip_atomic_store(o.pos_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(o.deep_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(o.deep_count + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(o.done_blocks, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
 
 template <int PW_, int PH_>
 __device__ __forceinline__ void wvm_emit(const Geo<PW_, PH_>& g, const WvmDev& m, const CascadeOut& o, int64_t wid, int lane,
@@ -1030,6 +1057,7 @@ __global__ __launch_bounds__(64 * NW) void k_wvm_deep(const uint8_t* __restrict_
         if (wave == 0) wvm_emit<PW_, PH_>(g, m, o, wid, lane, level, fout, m.thresholds[level], px);
         __syncthreads();
     }
+    wvm_finalize(o);
 }
 
 // ---- stage B, four filters per wavefront -----------------------------------------------------------
@@ -1189,6 +1217,7 @@ __global__ __launch_bounds__(64 * NW) void k_wvm_deep4(const uint8_t* __restrict
         if (wave == 0) wvm_emit<PW_, PH_>(g, m, o, wid, lane, level, fout, m.thresholds[level], px);
         __syncthreads();
     }
+    wvm_finalize(o);
 }
 
 // HistEq64 only (fd_histeq64_batch): same steps 1-3 on contiguous patches
@@ -1487,27 +1516,32 @@ struct WvmRun {
 
 // Asynchronous half of a WVM run: enumerates the windows, launches both cascade stages on the context's stream,
 // queues the read-back of the counter + first positives into the model's own pinned buffer and records m->done.
-static void wvm_launch_table(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, const WinTable& wt, bool want_all, WvmRun& run, bool time_kernel);
+static void wvm_launch_table(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm* m, const WinTable& wt, bool want_all, WvmRun& run, bool time_kernel);
+void fd_wvm_launch_on(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm* m, int sx, int sy, const int* roi, bool want_all, WvmRun& run, bool time_kernel);
 
 void fd_wvm_launch(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, int sx, int sy, const int* roi, bool want_all, WvmRun& run, bool time_kernel) {
+    fd_wvm_launch_on(ctx, ctx->stream, p, m, sx, sy, roi, want_all, run, time_kernel);
+}
+
+// explicit stream; touches no mutable context state (callable from the worker threads of the batch entry points)
+void fd_wvm_launch_on(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm* m, int sx, int sy, const int* roi, bool want_all, WvmRun& run, bool time_kernel) {
     if (p->ctx != ctx || m->ctx != ctx) FD_THROW(FD_ERR_INVALID_ARGUMENT, "objects belong to different contexts");
     if (p->filter_kind != FD_LAYER_NONE)
         FD_THROW(FD_ERR_INVALID_ARGUMENT, "WVM detection needs a gray pyramid (no layer filter)");
     if (p->all.empty()) FD_THROW(FD_ERR_RUNTIME, "pyramid has not been updated with an image");
     HIP_CHECK(hipSetDevice(ctx->device));
-    fd_pyramid_wait(p, ctx->stream);   // the batch entry points launch on pool streams, the caller may have updated on the context's
+    fd_pyramid_wait(p, st);   // the batch entry points launch on pool streams, the caller may have updated on the context's
     WinTable wt;
     fd_wvm_build_table(p, m->dev.fw, m->dev.fh, sx, sy, roi, wt, run.wls);
-    wvm_launch_table(ctx, p, m, wt, want_all, run, time_kernel);
+    wvm_launch_table(ctx, st, p, m, wt, want_all, run, time_kernel);
 }
 
-static void wvm_launch_table(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, const WinTable& wt, bool want_all, WvmRun& run, bool time_kernel) {
+static void wvm_launch_table(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm* m, const WinTable& wt, bool want_all, WvmRun& run, bool time_kernel) {
     run.total = wt.total;
     run.pos.clear();
     run.slots.clear();
     run.timed = time_kernel;
     if (wt.total == 0) return;
-    hipStream_t st = ctx->stream;
     if (want_all) {
         m->all_level.reserve(sizeof(int32_t) * (size_t)wt.total);
         m->all_fout.reserve(sizeof(float) * (size_t)wt.total);
@@ -1523,17 +1557,26 @@ static void wvm_launch_table(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, const WinTab
     m->pos_patches.reserve((size_t)m->dev.d * (size_t)m->pos_cap);
     m->h_pos.reserve(sizeof(PosRec) * ((size_t)m->pos_cap + 1));
     if (!m->done) HIP_CHECK(hipEventCreateWithFlags(&m->done, hipEventDisableTiming));
-    HIP_CHECK(hipMemsetAsync(m->pos.p, 0, sizeof(PosRec), st));
     m->deep_q.reserve(sizeof(int64_t) * (size_t)wt.total);
+    // Zero-copy read-back when the run ends in a stage-B kernel (every production run of a model with more than WVM_LCAP
+    // filters): positives and their count go straight to the pinned host buffer.  FD_WVM_ZEROCOPY=0 restores copy + memset.
+    static const bool zcOff = [] { const char* e = getenv("FD_WVM_ZEROCOPY"); return e && atoi(e) == 0; }();
+    const bool zc = !zcOff && !want_all && m->dev.numUsed > WVM_LCAP;
+    m->zcRun = zc;
+    if (!(zc && m->hdrClean)) HIP_CHECK(hipMemsetAsync(m->pos.p, 0, sizeof(PosRec), st));
+    m->hdrClean = false;   // set again by fd_wvm_finish once a zero-copy run has completed
     CascadeOut o;
     o.all_level = want_all ? m->all_level.as<int32_t>() : nullptr;
     o.all_fout = want_all ? m->all_fout.as<float>() : nullptr;
-    o.pos = m->pos.as<PosRec>() + 1;
+    o.pos = (zc ? m->h_pos.as<PosRec>() : m->pos.as<PosRec>()) + 1;   // pinned host memory is device-accessible under the same address
     o.pos_patches = m->pos_patches.as<uint8_t>();
     o.pos_count = m->pos.as<unsigned int>();        // header word 0
     o.pos_cap = (unsigned int)m->pos_cap;
     o.deep_q = m->deep_q.as<int64_t>();
     o.deep_count = m->pos.as<unsigned int>() + 1;   // header word 1
+    o.host_count = zc ? m->h_pos.as<unsigned int>() : nullptr;
+    o.done_blocks = m->pos.as<unsigned int>() + 3;  // header word 3
+    if (zc) *m->h_pos.as<unsigned int>() = 0xffffffffu;   // overwritten by the last stage-B workgroup
     if (time_kernel) HIP_CHECK(hipEventRecord(ctx->ev0, st));
     WinTable wtq = wt;
     bool skipA = false;
@@ -1557,8 +1600,10 @@ static void wvm_launch_table(fd_ctx* ctx, fd_pyramid* p, fd_wvm* m, const WinTab
     launch_cascade<false>(ctx, st, wt.total, m->dev, p->arena.as<uint8_t>(), wtq, o, skipA);
     if (time_kernel) HIP_CHECK(hipEventRecord(ctx->ev1, st));
     HIP_CHECK(hipGetLastError());
-    const size_t firstChunk = (size_t)std::min<int64_t>(m->pos_cap, WVM_FIRST_CHUNK);
-    HIP_CHECK(hipMemcpyAsync(m->h_pos.p, m->pos.p, sizeof(PosRec) * (firstChunk + 1), hipMemcpyDeviceToHost, st));
+    if (!zc) {
+        const size_t firstChunk = (size_t)std::min<int64_t>(m->pos_cap, WVM_FIRST_CHUNK);
+        HIP_CHECK(hipMemcpyAsync(m->h_pos.p, m->pos.p, sizeof(PosRec) * (firstChunk + 1), hipMemcpyDeviceToHost, st));
+    }
     HIP_CHECK(hipEventRecord(m->done, st));
 }
 
@@ -1572,10 +1617,12 @@ void fd_wvm_finish(fd_ctx* ctx, fd_wvm* m, WvmRun& run) {
         HIP_CHECK(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev0, ctx->ev1));
         ctx->last_kernel = "k_wvm_cascade";
     }
+    if (m->zcRun && cnt == 0xffffffffu) FD_THROW(FD_ERR_HIP, "WVM stage B did not deliver its positive count");
     if ((int64_t)cnt > m->pos_cap)
         FD_THROW(FD_ERR_CAPACITY, "WVM produced %u positives, device buffer holds %lld (set FD_WVM_POS_CAP)", cnt, (long long)m->pos_cap);
+    if (m->zcRun) m->hdrClean = true;   // the last stage-B workgroup has cleared the device header
     if (cnt) {
-        const size_t firstChunk = (size_t)std::min<int64_t>(m->pos_cap, WVM_FIRST_CHUNK);
+        const size_t firstChunk = m->zcRun ? (size_t)cnt : (size_t)std::min<int64_t>(m->pos_cap, WVM_FIRST_CHUNK);
         if (cnt > firstChunk) {   // on the auxiliary stream: the main stream may already hold the next detectors' kernels
             hipStream_t ax = fd_aux_stream(ctx);
             HIP_CHECK(hipMemcpyAsync(hraw + 1 + firstChunk, m->pos.as<PosRec>() + 1 + firstChunk, sizeof(PosRec) * (cnt - firstChunk),
@@ -1829,14 +1876,21 @@ struct FiveStageTail {
             DevBuf& idx = m->all_level;  // reuse scratch (not used by this call)
             idx.reserve(sizeof(uint32_t) * slots.size());
             m->all_fout.reserve(sizeof(double) * slots.size());
-            // pinned staging of this detector: [slots (u32) | distances (f64)]
+            // pinned staging of this detector: [slots (u32) | distances (f64)].  The kernel reads the slot list from, and writes
+            // the distances to, this host-mapped buffer directly (a few KB over the fabric instead of two blit kernels and their
+            // launch gaps on the tail stream); FD_WVM_ZEROCOPY=0: explicit copies through device scratch.
+            static const bool zcOff = [] { const char* e = getenv("FD_WVM_ZEROCOPY"); return e && atoi(e) == 0; }();
             distOff = (sizeof(uint32_t) * slots.size() + 15) & ~(size_t)15;
             m->h_tail.reserve(distOff + sizeof(double) * slots.size());
             char* pin = m->h_tail.as<char>();
             std::memcpy(pin, slots.data(), sizeof(uint32_t) * slots.size());
-            HIP_CHECK(hipMemcpyAsync(idx.p, pin, sizeof(uint32_t) * slots.size(), hipMemcpyHostToDevice, st));
-            fd_svm_generic_launch_on(st, svm, m->pos_patches.p, idx.as<uint32_t>(), (int64_t)m->dev.d, (int64_t)slots.size(), m->all_fout.as<double>());
-            HIP_CHECK(hipMemcpyAsync(pin + distOff, m->all_fout.p, sizeof(double) * slots.size(), hipMemcpyDeviceToHost, st));
+            if (zcOff) {
+                HIP_CHECK(hipMemcpyAsync(idx.p, pin, sizeof(uint32_t) * slots.size(), hipMemcpyHostToDevice, st));
+                fd_svm_generic_launch_on(st, svm, m->pos_patches.p, idx.as<uint32_t>(), (int64_t)m->dev.d, (int64_t)slots.size(), m->all_fout.as<double>());
+                HIP_CHECK(hipMemcpyAsync(pin + distOff, m->all_fout.p, sizeof(double) * slots.size(), hipMemcpyDeviceToHost, st));
+            } else {
+                fd_svm_generic_launch_on(st, svm, m->pos_patches.p, (const uint32_t*)pin, (int64_t)m->dev.d, (int64_t)slots.size(), (double*)(pin + distOff));
+            }
             if (!m->tailDone) HIP_CHECK(hipEventCreateWithFlags(&m->tailDone, hipEventDisableTiming));
             HIP_CHECK(hipEventRecord(m->tailDone, st));
             pending = true;
@@ -1946,15 +2000,50 @@ static void five_stage_batch_begin(fd_ctx* ctx, fd_five_stage_job* jobs, int n, 
     // jobs are spread over a few streams so that the small kernels of different jobs (pyramid levels, the deep
     // cascade stage, the SVM stage) overlap each other; a job's optional frame upload / pyramid update runs on its stream
     for (int i = 0; i < n; ++i) {
-        FdStreamSwap sw(ctx, fd_pool_stream(ctx, i));
+        (void)fd_pool_stream(ctx, i);
+        if (!jobs[i].image) continue;
+        for (int k = 0; k < i; ++k)
+            if (jobs[k].image && jobs[k].pyramid == jobs[i].pyramid)
+                FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_batch: jobs %d and %d update the same pyramid", k, i);
+    }
+    auto updateJob = [&](int i) {
         fd_five_stage_job& j = jobs[i];
-        if (j.image) {
-            for (int k = 0; k < i; ++k)
-                if (jobs[k].pyramid == j.pyramid) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_batch: jobs %d and %d update the same pyramid", k, i);
-            const int rc = fd_pyramid_update(j.pyramid, j.image, j.image_w, j.image_h, j.image_channels, j.image_is_device);
-            if (rc != FD_OK) throw FdError{rc, ctx->error};
+        if (j.image) fd_pyramid_update_on(j.pyramid, j.image, j.image_w, j.image_h, j.image_channels, j.image_is_device, fd_pool_stream(ctx, i));
+    };
+    auto cascadeJob = [&](int i) {
+        fd_five_stage_job& j = jobs[i];
+        fd_wvm_launch_on(ctx, fd_pool_stream(ctx, i), j.pyramid, const_cast<fd_wvm*>(j.wvm), j.step_x, j.step_y, j.roi, false, b.runs[i], false);
+    };
+    // A frame costs ~15 runtime calls (pyramid kernels, cascade kernels, copies, events): with many small jobs the single host
+    // thread issuing them is the bottleneck, so batches of >= 6 jobs are issued by the worker pool -- all pyramid updates first
+    // (jobs may share a pyramid one of them updates), then all cascades.  Each job has its own stream, handles and buffers.
+    static const int nthreads = [] { const char* e = getenv("FD_BATCH_THREADS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+    if (nthreads > 1 && n >= 6) {
+        if (!ctx->workers) ctx->workers.reset(new FdWorkerPool(nthreads - 1));
+        std::mutex errMu;
+        FdError firstErr{FD_OK, std::string()};
+        auto phase = [&](const std::function<void(int)>& f) {
+            std::atomic<int> next{0};
+            ctx->workers->run([&] {
+                (void)hipSetDevice(ctx->device);
+                for (int i; (i = next.fetch_add(1)) < n;) {
+                    try { f(i); } catch (const FdError& e) {
+                        std::lock_guard<std::mutex> lk(errMu);
+                        if (firstErr.code == FD_OK) firstErr = e;
+                    }
+                }
+            });
+            if (firstErr.code != FD_OK) throw firstErr;
+        };
+        bool anyImage = false;
+        for (int i = 0; i < n; ++i) anyImage |= jobs[i].image != nullptr;
+        if (anyImage) phase(updateJob);
+        phase(cascadeJob);
+    } else {
+        for (int i = 0; i < n; ++i) {
+            updateJob(i);
+            cascadeJob(i);
         }
-        fd_wvm_launch(ctx, j.pyramid, const_cast<fd_wvm*>(j.wvm), j.step_x, j.step_y, j.roi, false, b.runs[i], false);
     }
     static const bool trace = getenv("FD_TRACE") != nullptr;
     if (trace)
@@ -2180,7 +2269,7 @@ int fd_wvm_svm_evaluate_samples(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, 
             wt.l[i].lw = L.w; wt.l[i].off = L.gray_off; wt.l[i].nx = 1; wt.l[i].ny = 1; wt.l[i].magic = 0xffffffffu; wt.l[i].first = INT64_MAX;
         }
         WvmRun run;
-        wvm_launch_table(ctx, p, m, wt, true, run, false);
+        wvm_launch_table(ctx, ctx->stream, p, m, wt, true, run, false);
         fd_wvm_finish(ctx, m, run);
         std::vector<float> fout((size_t)nv);
         HIP_CHECK(hipMemcpy(fout.data(), m->all_fout.p, sizeof(float) * (size_t)nv, hipMemcpyDeviceToHost));
