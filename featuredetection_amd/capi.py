@@ -125,6 +125,7 @@ _SIGS = {
     "fd_pyramid_layer_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int),
                                         C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "fd_pyramid_layer_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "fd_pyramid_select": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "fd_pyramid_window_count": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]),
     "fd_pyramid_windows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
                                      C.POINTER(C.c_int64)]),
@@ -173,6 +174,13 @@ _SIGS = {
     "fd_detect_rvm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(fd_rvm_detect_params), C.c_void_p, C.c_void_p, C.c_int64,
                                 C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
     "fd_extract_hog": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fd_hog_params), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "fd_gradient_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "fd_gradient_binning_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "fd_lbp_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "fd_hist_patch_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(fd_hist_params), C.c_void_p]),
+    "fd_whitening_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "fd_convert_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_int]),
+    "fd_unit_norm_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "fd_detect_hog_svm_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(fd_hog_params), C.POINTER(C.c_void_p)]),
     "fd_detect_hog_svm_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "fd_sdm_create": (C.c_int, [C.c_void_p, C.POINTER(fd_sdm_model), C.POINTER(C.c_void_p)]),
@@ -303,6 +311,11 @@ class Pyramid:
         a = np.empty(shape, np.uint8)
         self.ctx.check(lib().fd_pyramid_layer_download(self.h, i, _ptr(a)))
         return a
+
+    def select(self, first_layer=-1, last_layer=-1, step_layer=1, roi=None):
+        """layer sub-range / default roi of every enumeration that follows; select() resets"""
+        r = _c(roi, np.int32) if roi is not None else None
+        self.ctx.check(lib().fd_pyramid_select(self.h, first_layer, last_layer, step_layer, _ptr(r)))
 
     def window_count(self, pw, ph, sx, sy, roi=None):
         n = C.c_int64()
@@ -694,6 +707,64 @@ def detect_hog_svm(ctx, pyr, svm, hp, want_all=True, cap=1 << 20):
     cnt = C.c_int64()
     ctx.check(lib().fd_detect_hog_svm(ctx.h, pyr.h, svm.h, C.byref(hp), _ptr(out), out.shape[0], C.byref(cnt), _ptr(alld)))
     return out[:cnt.value], alld
+
+
+# ---- stand-alone ImageFilter::applyTo forms
+def gradient_image(ctx, gray, ksize=1):
+    g = _c(gray, np.uint8)
+    out = np.empty(g.shape + (2,), np.uint8)
+    ctx.check(lib().fd_gradient_image(ctx.h, _ptr(g), g.shape[1], g.shape[0], ksize, _ptr(out)))
+    return out
+
+
+def gradient_binning_image(ctx, grad2ch, bins, signed_gradients=False, interpolate=False):
+    g = _c(grad2ch, np.uint8)
+    out = np.empty(g.shape[:2] + (4 if interpolate else 2,), np.uint8)
+    ctx.check(lib().fd_gradient_binning_image(ctx.h, _ptr(g), g.shape[1], g.shape[0], bins, int(signed_gradients), int(interpolate), _ptr(out)))
+    return out
+
+
+def lbp_image(ctx, gray, lbp_type=0):
+    g = _c(gray, np.uint8)
+    out = np.empty(g.shape, np.uint8)
+    ctx.check(lib().fd_lbp_image(ctx.h, _ptr(g), g.shape[1], g.shape[0], lbp_type, _ptr(out)))
+    return out
+
+
+def hist_patch_batch(ctx, bin_patches, hp):
+    """bin_patches: [n, ph, pw, channels] u8 (or [n, ph, pw]); hp from hist_params(...)"""
+    b = _c(bin_patches, np.uint8)
+    ch = b.shape[3] if b.ndim == 4 else 1
+    F = lib().fd_hist_feature_length(C.byref(hp), ch)
+    if F < 0:
+        raise FdError(FD_ERR_INVALID_ARGUMENT, "invalid histogram parameters")
+    out = np.empty((b.shape[0], F), np.float32)
+    ctx.check(lib().fd_hist_patch_batch(ctx.h, _ptr(b), b.shape[0], ch, C.byref(hp), _ptr(out)))
+    return out
+
+
+def whitening_batch(ctx, patches, alpha=1.0, cutoff=0.390625):
+    p = _c(patches, np.uint8)
+    out = np.empty(p.shape, np.uint8)
+    ctx.check(lib().fd_whitening_batch(ctx.h, _ptr(p), p.shape[0], p.shape[2], p.shape[1], alpha, cutoff, _ptr(out)))
+    return out
+
+
+def convert_batch(ctx, src, alpha=1.0, beta=0.0, to_f32=True):
+    s = np.ascontiguousarray(src)
+    if s.dtype not in (np.uint8, np.float32):
+        raise ValueError("u8 or f32")
+    out = np.empty(s.shape, np.float32 if to_f32 else np.uint8)
+    ctx.check(lib().fd_convert_batch(ctx.h, _ptr(s), FD_DTYPE_F32 if s.dtype == np.float32 else FD_DTYPE_U8, s.size, alpha, beta, _ptr(out),
+                                     FD_DTYPE_F32 if to_f32 else FD_DTYPE_U8))
+    return out
+
+
+def unit_norm_batch(ctx, vecs, norm_type=4):
+    v = _c(vecs, np.float32)
+    out = np.empty(v.shape, np.float32)
+    ctx.check(lib().fd_unit_norm_batch(ctx.h, _ptr(v), v.shape[0], int(np.prod(v.shape[1:])), norm_type, _ptr(out)))
+    return out
 
 
 class HogSvmRun:

@@ -274,6 +274,11 @@ struct fd_pyramid {
     uint32_t gray_full_off = 0;
     size_t arena_bytes = 0;
     uint64_t version = 0;            // bumped by every update
+    // fd_pyramid_select: layer sub-range (pyramid layer indices, -1 = open end), layer step (over the kept layers, starting at the
+    // first) and default region of interest of every window enumeration that follows (DirectPyramidFeatureExtractor.cpp:75-123)
+    int sel_first = -1, sel_last = -1, sel_step = 1;
+    bool sel_has_roi = false;
+    int sel_roi[4] = {0, 0, 0, 0};
     // recorded on the updating stream after the last kernel of an update: consumers on OTHER streams (the stream pool of the
     // batch entry points) wait for it; consumers on the same stream are ordered anyway
     hipEvent_t ready = nullptr;

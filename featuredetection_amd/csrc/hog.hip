@@ -227,7 +227,7 @@ __global__ void k_select_positives(const double* __restrict__ dist, int64_t n, f
 }
 
 struct HogScratch {
-    DevBuf feat, xx, dist, pos, counter, tables, histTables;
+    DevBuf feat, xx, dist, pos, counter, tables, histTables, patchIn;
     HostBuf hcount;       // pinned read-back slot
     HogDev tabFor;        // parameters the tables were built for
     bool tabValid = false;
@@ -901,6 +901,21 @@ void hist_tables(fd_ctx* ctx, HogScratch& S, const HistDev& d, HistTables& tb) {
     tb.colRange = (const int32_t*)((const char*)S.histTables.p + o3);
 }
 
+// k_hist_features over the windows of `wt` inside `arena` -> S.feat ([N][F] floats)
+void launch_hist_features(fd_ctx* ctx, const uint8_t* arena, const HogWinTable& wt, const HistDev& hd, HogScratch& S) {
+    HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t lds = hist_lds_bytes(hd);
+    if (lds > 160 * 1024) FD_THROW(FD_ERR_INVALID_ARGUMENT, "histogram feature vector too long for the LDS (%d floats)", hd.F);
+    static uint64_t lds_allowed = 0;
+    fd_allow_lds(ctx, (const void*)k_hist_features, 160 * 1024, lds_allowed);
+    HistTables tb;
+    hist_tables(ctx, S, hd, tb);
+    S.feat.reserve(sizeof(float) * (size_t)wt.total * hd.F);
+    const int grid = (int)std::min<int64_t>(wt.total, (int64_t)ctx->num_cus * 32);
+    hipLaunchKernelGGL(k_hist_features, dim3(grid), dim3(64), lds, ctx->stream, arena, wt, hd, tb, S.feat.as<float>());
+    HIP_CHECK(hipGetLastError());
+}
+
 // features of every window, plain [N][F] layout, into S.feat; returns N
 int64_t run_hist_features(fd_ctx* ctx, fd_pyramid* p, const fd_hist_params* hp, std::vector<WindowLayer>& wls, HogScratch& S, HistDev& hd) {
     if (!hp) FD_THROW(FD_ERR_INVALID_ARGUMENT, "NULL histogram parameters");
@@ -920,17 +935,7 @@ int64_t run_hist_features(fd_ctx* ctx, fd_pyramid* p, const fd_hist_params* hp, 
     build_table(p, &g, wt, wls, /*any_bin_image=*/true);
     const int64_t N = wt.total;
     if (N == 0) return 0;
-    HIP_CHECK(hipSetDevice(ctx->device));
-    const size_t lds = hist_lds_bytes(hd);
-    if (lds > 160 * 1024) FD_THROW(FD_ERR_INVALID_ARGUMENT, "histogram feature vector too long for the LDS (%d floats)", hd.F);
-    static uint64_t lds_allowed = 0;
-    fd_allow_lds(ctx, (const void*)k_hist_features, 160 * 1024, lds_allowed);
-    HistTables tb;
-    hist_tables(ctx, S, hd, tb);
-    S.feat.reserve(sizeof(float) * (size_t)N * hd.F);
-    const int grid = (int)std::min<int64_t>(N, (int64_t)ctx->num_cus * 32);
-    hipLaunchKernelGGL(k_hist_features, dim3(grid), dim3(64), lds, ctx->stream, p->arena.as<uint8_t>(), wt, hd, tb, S.feat.as<float>());
-    HIP_CHECK(hipGetLastError());
+    launch_hist_features(ctx, p->arena.as<uint8_t>(), wt, hd, S);
     return N;
 }
 
@@ -1002,6 +1007,34 @@ int fd_extract_hist(fd_ctx* ctx, fd_pyramid* p, const fd_hist_params* hp, float*
 
 // SlidingWindowDetector::detect (SlidingWindowDetector.cpp:87-98) with a histogram patch filter and a
 // ProbabilisticSvmClassifier on f32 feature vectors (any kernel; BenchmarkRunner.cpp:185-263 wiring)
+// HistogramFilter::applyTo(Mat) of the four histogram patch filters (HogFilter.cpp:58-122, SpatialHistogramFilter.cpp:56-94,
+// PyramidHogFilter.cpp:33-113, SpatialPyramidHistogramFilter.cpp:37-81) on n contiguous bin-image patches of hp->patch_w x
+// hp->patch_h pixels with `channels` bytes per pixel (1: bin, 2: bin + weight, 4: two bins + weights): the batch is addressed as
+// one layer whose windows are hp->patch_h rows apart.  out: n x fd_hist_feature_length(hp, channels) floats.
+int fd_hist_patch_batch(fd_ctx* ctx, const uint8_t* bin_patches, int64_t n, int channels, const fd_hist_params* hp, float* out) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !hp || n < 0 || (n > 0 && (!bin_patches || !out))) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_hist_patch_batch: bad argument");
+        if (channels != 1 && channels != 2 && channels != 4) FD_THROW(FD_ERR_INVALID_ARGUMENT, "HistogramFilter: the image must have one, two or four channels");
+        if ((hp->kind == FD_HIST_HOG || hp->kind == FD_HIST_PYRAMID_HOG) && channels == 1)
+            FD_THROW(FD_ERR_INVALID_ARGUMENT, "HOG features need a gradient bin image (two or four channels)");
+        if (n == 0) return;
+        if (n > (int64_t)1 << 24) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_hist_patch_batch: too many patches in one call");
+        HogScratch& S = scratch(ctx);
+        const HistDev hd = make_histdev(hp, channels);
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const size_t bytes = (size_t)n * hp->patch_w * hp->patch_h * channels;
+        S.patchIn.reserve(bytes);
+        HIP_CHECK(hipMemcpyAsync(S.patchIn.p, bin_patches, bytes, hipMemcpyHostToDevice, ctx->stream));
+        HogWinTable wt;
+        std::memset(&wt, 0, sizeof(wt));
+        wt.n = 1; wt.sx = 1; wt.sy = hp->patch_h; wt.total = n;
+        wt.l[0].bx = 0; wt.l[0].by = 0; wt.l[0].nx = 1; wt.l[0].ny = (int32_t)n; wt.l[0].lw = hp->patch_w; wt.l[0].off = 0; wt.l[0].first = 0;
+        launch_hist_features(ctx, S.patchIn.as<uint8_t>(), wt, hd, S);
+        HIP_CHECK(hipMemcpyAsync(out, S.feat.p, sizeof(float) * (size_t)n * hd.F, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
 int fd_detect_hist_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_hist_params* hp, fd_detection* out, int64_t cap,
                        int64_t* count, double* all_distance) {
     return fd_guard(ctx, [&] {

@@ -155,6 +155,38 @@ __global__ void k_gradbin(uint8_t* __restrict__ arena, const uint8_t* __restrict
     }
 }
 
+// GradientFilter::applyTo alone (GradientFilter.cpp:38-59): the CV_8UC2 gradient image (x, y), same arithmetic as k_gradbin
+__global__ void k_gradient_image(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int w, int h, int ksize) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < w * h; i += gridDim.x * blockDim.x) {
+        int y = i / w, x = i - y * w;
+        int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+        int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
+        const uint8_t *S0 = src + (size_t)ym * w, *S1 = src + (size_t)y * w, *S2 = src + (size_t)yp * w;
+        int gx, gy;
+        float scale;
+        if (ksize == 1) {
+            gx = S1[xp] - S1[xm];
+            gy = S2[x] - S0[x];
+            scale = 0.5f;
+        } else {
+            gx = (S0[xp] - S0[xm]) + 2 * (S1[xp] - S1[xm]) + (S2[xp] - S2[xm]);
+            gy = (S2[xm] - S0[xm]) + 2 * (S2[x] - S0[x]) + (S2[xp] - S0[xp]);
+            scale = 0.125f;
+        }
+        int vx = __float2int_rn(127.f + scale * gx), vy = __float2int_rn(127.f + scale * gy);
+        dst[2 * (size_t)i] = (uint8_t)min(255, max(0, vx));
+        dst[2 * (size_t)i + 1] = (uint8_t)min(255, max(0, vy));
+    }
+}
+// GradientBinningFilter::applyTo alone (GradientBinningFilter.cpp:62-93): LUT look-up of a CV_8UC2 gradient image
+template <int E>
+__global__ void k_binning_image(const uint8_t* __restrict__ grad, const uint8_t* __restrict__ lut, uint8_t* __restrict__ dst, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t idx = (uint32_t)grad[2 * (size_t)i] | ((uint32_t)grad[2 * (size_t)i + 1] << 8);
+        for (int e = 0; e < E; ++e) dst[(size_t)E * i + e] = lut[(size_t)E * idx + e];
+    }
+}
+
 // LbpFilter 3x3 codes with BORDER_REPLICATE (LbpFilter.hpp:88-180), optional uniform map
 __global__ void k_lbp(uint8_t* __restrict__ arena, int type, FilterJobs jobs) {
     const FilterJob jb = jobs.j[blockIdx.y];
@@ -444,6 +476,7 @@ void fd_enumerate_layers(const fd_pyramid* p, int pw, int ph, int sx, int sy, co
     if (sy < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "DirectPyramidFeatureExtractor: stepY has to be greater than zero");
     if (pw < 1 || ph < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "DirectPyramidFeatureExtractor: empty patch size");
     int rx = 0, ry = 0, rw = 0, rh = 0;
+    if (!roiIn && p->sel_has_roi) roiIn = p->sel_roi;   // fd_pyramid_select
     if (roiIn) { rx = roiIn[0]; ry = roiIn[1]; rw = roiIn[2]; rh = roiIn[3]; }
     if (rx == 0 && ry == 0 && rw == 0 && rh == 0) {
         rw = p->img_w;
@@ -472,6 +505,11 @@ void fd_enumerate_layers(const fd_pyramid* p, int pw, int ph, int sx, int sy, co
         long spanx = (long)ex - pw - wl.bx, spany = (long)ey - ph - wl.by;
         wl.nx = spanx > 0 ? (int)((spanx - 1) / sx + 1) : 0;
         wl.ny = spany > 0 ? (int)((spany - 1) / sy + 1) : 0;
+        // layer selection (DirectPyramidFeatureExtractor.cpp:99-107): every sel_step-th layer counted from the first one,
+        // skipping indices below sel_first, stopping above sel_last
+        const bool selected = (li % (size_t)p->sel_step == 0) && (p->sel_first < 0 || L.index >= p->sel_first) &&
+                              (p->sel_last < 0 || L.index <= p->sel_last);
+        if (!selected) wl.nx = wl.ny = 0;
         // windows must lie inside the layer (cv::Mat(image, bounds) would assert otherwise)
         if (wl.nx > 0 && wl.ny > 0) {
             if (wl.bx < 0 || wl.by < 0 || wl.bx + (wl.nx - 1) * sx + pw > L.w || wl.by + (wl.ny - 1) * sy + ph > L.h)
@@ -546,6 +584,18 @@ int fd_pyramid_update(fd_pyramid* p, const uint8_t* image, int w, int h, int ch,
         if (!p) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_update: NULL pyramid");
         HIP_CHECK(hipSetDevice(p->ctx->device));
         pyramid_update(p, image, w, h, ch, is_device, p->ctx->stream);
+    });
+}
+
+int fd_pyramid_select(fd_pyramid* p, int first_layer, int last_layer, int step_layer, const int* roi) {
+    return fd_guard(p ? p->ctx : nullptr, [&] {
+        if (!p) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_select: NULL pyramid");
+        if (step_layer < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "DirectPyramidFeatureExtractor: stepLayer has to be greater than zero");
+        p->sel_first = first_layer < 0 ? -1 : first_layer;
+        p->sel_last = last_layer < 0 ? -1 : last_layer;
+        p->sel_step = step_layer;
+        p->sel_has_roi = roi != nullptr;
+        if (roi) std::memcpy(p->sel_roi, roi, sizeof(p->sel_roi));
     });
 }
 
@@ -644,6 +694,66 @@ int fd_greyworld(fd_ctx* ctx, const uint8_t* bgr, int w, int h, uint8_t* dst, in
         hipLaunchKernelGGL(k_greyworld_apply, dim3(grid_for(n)), dim3(256), 0, ctx->stream, din, dout, n, scale[0], scale[1], scale[2]);
         HIP_CHECK(hipGetLastError());
         if (!is_device) HIP_CHECK(hipMemcpyAsync(dst, dout, (size_t)n * 3, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+// ---- stand-alone ImageFilter::applyTo(Mat) forms of the layer filters (ImageFilter.hpp:18-57) on one host image ----------
+int fd_gradient_image(fd_ctx* ctx, const uint8_t* gray, int w, int h, int grad_kernel, uint8_t* dst2ch) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !gray || !dst2ch || w < 1 || h < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_gradient_image: bad argument");
+        if (grad_kernel != 1 && grad_kernel != 3) FD_THROW(FD_ERR_INVALID_ARGUMENT, "GradientFilter: the kernel size must be 1 or 3 on this backend");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const size_t n = (size_t)w * h;
+        DevBuf in, out;
+        in.reserve(n);
+        out.reserve(2 * n);
+        HIP_CHECK(hipMemcpyAsync(in.p, gray, n, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_gradient_image, dim3(grid_for((int)n)), dim3(256), 0, ctx->stream, in.as<uint8_t>(), out.as<uint8_t>(), w, h, grad_kernel);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(dst2ch, out.p, 2 * n, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int fd_gradient_binning_image(fd_ctx* ctx, const uint8_t* grad2ch, int w, int h, int bins, int signed_gradients, int interpolate, uint8_t* dst) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !grad2ch || !dst || w < 1 || h < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_gradient_binning_image: bad argument");
+        if (bins < 1 || bins > 255) FD_THROW(FD_ERR_INVALID_ARGUMENT, "GradientBinningFilter: bins must be in 1..255");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const size_t n = (size_t)w * h;
+        const int E = interpolate ? 4 : 2;
+        std::vector<uint8_t> lut;
+        build_gradient_lut(bins, signed_gradients != 0, interpolate != 0, lut);
+        DevBuf in, out, dl;
+        in.reserve(2 * n);
+        out.reserve((size_t)E * n);
+        dl.reserve(lut.size());
+        HIP_CHECK(hipMemcpyAsync(dl.p, lut.data(), lut.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(in.p, grad2ch, 2 * n, hipMemcpyHostToDevice, ctx->stream));
+        if (E == 2) hipLaunchKernelGGL(k_binning_image<2>, dim3(grid_for((int)n)), dim3(256), 0, ctx->stream, in.as<uint8_t>(), dl.as<uint8_t>(), out.as<uint8_t>(), (int)n);
+        else hipLaunchKernelGGL(k_binning_image<4>, dim3(grid_for((int)n)), dim3(256), 0, ctx->stream, in.as<uint8_t>(), dl.as<uint8_t>(), out.as<uint8_t>(), (int)n);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(dst, out.p, (size_t)E * n, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int fd_lbp_image(fd_ctx* ctx, const uint8_t* gray, int w, int h, int lbp_type, uint8_t* dst) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !gray || !dst || w < 1 || h < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_lbp_image: bad argument");
+        if (lbp_type < 0 || lbp_type > 3) FD_THROW(FD_ERR_INVALID_ARGUMENT, "LbpFilter: invalid type");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const size_t n = (size_t)w * h, doff = (n + 255) & ~(size_t)255;
+        DevBuf buf;   // [gray | codes]: k_lbp addresses both through one base pointer
+        buf.reserve(doff + n);
+        HIP_CHECK(hipMemcpyAsync(buf.p, gray, n, hipMemcpyHostToDevice, ctx->stream));
+        FilterJobs jobs;
+        jobs.n = 1;
+        jobs.j[0].w = w; jobs.j[0].h = h; jobs.j[0].src_off = 0; jobs.j[0].dst_off = (uint32_t)doff;
+        hipLaunchKernelGGL(k_lbp, dim3(grid_for((int)n), 1), dim3(256), 0, ctx->stream, buf.as<uint8_t>(), lbp_type, jobs);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(dst, buf.as<uint8_t>() + doff, n, hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
     });
 }

@@ -64,7 +64,8 @@ __device__ __forceinline__ const uint8_t* locate(const uint8_t* arena, const Whi
 }
 
 // EQ_ONLY: HistogramEqualizationFilter alone, u8 output
-template <bool EQ_ONLY>
+// MODE 0: the whole whi chain -> unit-norm floats; 1: cv::equalizeHist only -> u8; 2: WhiteningFilter only -> u8
+template <int MODE>
 __global__ __launch_bounds__(64) void k_whi(const uint8_t* __restrict__ arena, WhiWinTable wt, WhiDev d, float* __restrict__ feat,
                                             uint8_t* __restrict__ eqOut) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(64) void k_whi(const uint8_t* __restrict__ arena, W
             px[i] = src[(size_t)y * stride + x];
         }
         wave_sync();
-        if (!EQ_ONLY) {
+        if (MODE != 1) {
             // forward DFT (DFT_SCALE | DFT_COMPLEX_OUTPUT): rows
             for (int o = lane; o < n; o += 64) {
                 const int v = o / w, x = o - v * w;
@@ -150,8 +151,13 @@ __global__ __launch_bounds__(64) void k_whi(const uint8_t* __restrict__ arena, W
             }
             wave_sync();
         }
+        if (MODE == 2) {   // WhiteningFilter::applyTo alone (WhiteningFilter.cpp:20-58): the whitened u8 image
+            for (int i = lane; i < n; i += 64) eqOut[(size_t)wid * n + i] = px[i];
+            wave_sync();
+            continue;
+        }
         equalize_hist_wave(px, eq, n, hist, lut, lane);
-        if (EQ_ONLY) {
+        if (MODE == 1) {
             for (int i = lane; i < n; i += 64) eqOut[(size_t)wid * n + i] = eq[i];
         } else {
             const float a = (float)(1.0 / 127.5), b = -1.0f;
@@ -230,14 +236,51 @@ size_t lds_bytes(int w, int h) {
     return 4 * n * sizeof(double) + 512 * sizeof(int) + 2 * ((n + 15) & ~(size_t)15);
 }
 
-template <bool EQ_ONLY>
+template <int MODE>
 void launch(fd_ctx* ctx, const uint8_t* arena, const WhiWinTable& wt, const WhiDev& d, float* feat, uint8_t* eqOut) {
     const size_t lds = lds_bytes(d.w, d.h);
     static uint64_t lds_allowed = 0;   // per instantiation
-    fd_allow_lds(ctx, (const void*)k_whi<EQ_ONLY>, 64 * 1024, lds_allowed);
+    fd_allow_lds(ctx, (const void*)k_whi<MODE>, 64 * 1024, lds_allowed);
     const int grid = (int)std::min<int64_t>(wt.total, (int64_t)ctx->num_cus * 16);
-    hipLaunchKernelGGL(k_whi<EQ_ONLY>, dim3(grid), dim3(64), lds, ctx->stream, arena, wt, d, feat, eqOut);
+    hipLaunchKernelGGL(k_whi<MODE>, dim3(grid), dim3(64), lds, ctx->stream, arena, wt, d, feat, eqOut);
     HIP_CHECK(hipGetLastError());
+}
+
+// ConversionFilter::applyTo (cv::Mat::convertTo, OpenCV 2.4 cvtScale_<T, DT, float>): value * (float)alpha + (float)beta in float,
+// then saturate_cast<uchar>(cvRound(.)) for a CV_8U destination
+__global__ void k_convert(const void* __restrict__ src, int srcF32, void* __restrict__ dst, int dstF32, int64_t n, double alpha, double beta) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (dstF32) {
+            const float v = srcF32 ? ((const float*)src)[i] : (float)((const uint8_t*)src)[i];
+            ((float*)dst)[i] = v * (float)alpha + (float)beta;
+        } else {
+            const float v = srcF32 ? ((const float*)src)[i] : (float)((const uint8_t*)src)[i];
+            ((uint8_t*)dst)[i] = sat_u8_d((double)(v * (float)alpha + (float)beta));
+        }
+    }
+}
+
+// UnitNormFilter::applyTo (UnitNormFilter.cpp:24-43): image / (cv::norm(image, normType) + 1e-4f) per image, one wavefront each;
+// the norm is accumulated in double over the float values like cv::norm
+__global__ __launch_bounds__(64) void k_unit_norm(const float* __restrict__ src, float* __restrict__ dst, int64_t nimg, int len, int normType) {
+    const int lane = threadIdx.x;
+    for (int64_t im = blockIdx.x; im < nimg; im += gridDim.x) {
+        const float* s = src + (size_t)im * len;
+        double part = 0;
+        for (int i = lane; i < len; i += 64) {
+            const double v = (double)s[i];
+            if (normType == 4) part += v * v;             // cv::NORM_L2
+            else if (normType == 2) part += fabs(v);      // cv::NORM_L1
+            else part = fmax(part, fabs(v));              // cv::NORM_INF
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const double other = __shfl_xor(part, o, 64);
+            part = (normType == 4 || normType == 2) ? part + other : fmax(part, other);
+        }
+        const double norm = normType == 4 ? sqrt(part) : part;
+        const float inv = (float)(1.0 / (norm + (double)1e-4f));   // image / (norm + eps): MatExpr scale 1/d, applied in float
+        for (int i = lane; i < len; i += 64) dst[(size_t)im * len + i] = s[i] * inv;
+    }
 }
 
 void build_table(const fd_pyramid* p, const fd_whi_params* wp, WhiWinTable& wt, std::vector<WindowLayer>& wls) {
@@ -265,7 +308,7 @@ int64_t run_whi(fd_ctx* ctx, fd_pyramid* p, const fd_whi_params* wp, std::vector
     build_table(p, wp, wt, wls);
     if (wt.total == 0) return 0;
     S.feat.reserve(sizeof(float) * (size_t)wt.total * d.w * d.h);
-    launch<false>(ctx, p->arena.as<uint8_t>(), wt, d, S.feat.as<float>(), nullptr);
+    launch<0>(ctx, p->arena.as<uint8_t>(), wt, d, S.feat.as<float>(), nullptr);
     return wt.total;
 }
 
@@ -288,7 +331,7 @@ int fd_whi_batch(fd_ctx* ctx, const uint8_t* patches, int64_t n, int w, int h, f
         std::memset(&wt, 0, sizeof(wt));
         wt.raw = 1;
         wt.total = n;
-        launch<false>(ctx, S.in.as<uint8_t>(), wt, d, S.feat.as<float>(), nullptr);
+        launch<0>(ctx, S.in.as<uint8_t>(), wt, d, S.feat.as<float>(), nullptr);
         HIP_CHECK(hipMemcpyAsync(dst, S.feat.p, bytes * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
     });
@@ -312,7 +355,67 @@ int fd_equalize_hist_batch(fd_ctx* ctx, const uint8_t* patches, int64_t n, int w
         WhiDev d;
         std::memset(&d, 0, sizeof(d));
         d.w = w; d.h = h;
-        launch<true>(ctx, S.in.as<uint8_t>(), wt, d, nullptr, S.feat.as<uint8_t>());
+        launch<1>(ctx, S.in.as<uint8_t>(), wt, d, nullptr, S.feat.as<uint8_t>());
+        HIP_CHECK(hipMemcpyAsync(dst, S.feat.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+// WhiteningFilter::applyTo alone (WhiteningFilter.cpp:20-58) on n contiguous w x h u8 patches -> u8 (convertTo(CV_8U, 1, 127))
+int fd_whitening_batch(fd_ctx* ctx, const uint8_t* patches, int64_t n, int w, int h, float alpha, float cutoff, uint8_t* dst) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || n < 0 || (n > 0 && (!patches || !dst))) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_whitening_batch: bad argument");
+        if (n == 0) return;
+        HIP_CHECK(hipSetDevice(ctx->device));
+        WhiScratch& S = scratch(ctx);
+        const WhiDev& d = tables(ctx, S, w, h, alpha, cutoff);
+        const size_t bytes = (size_t)n * w * h;
+        S.in.reserve(bytes);
+        S.feat.reserve(bytes);
+        HIP_CHECK(hipMemcpyAsync(S.in.p, patches, bytes, hipMemcpyHostToDevice, ctx->stream));
+        WhiWinTable wt;
+        std::memset(&wt, 0, sizeof(wt));
+        wt.raw = 1;
+        wt.total = n;
+        launch<2>(ctx, S.in.as<uint8_t>(), wt, d, nullptr, S.feat.as<uint8_t>());
+        HIP_CHECK(hipMemcpyAsync(dst, S.feat.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int fd_convert_batch(fd_ctx* ctx, const void* src, int src_dtype, int64_t count, double alpha, double beta, void* dst, int dst_dtype) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || count < 0 || (count > 0 && (!src || !dst))) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_convert_batch: bad argument");
+        if ((src_dtype != FD_DTYPE_U8 && src_dtype != FD_DTYPE_F32) || (dst_dtype != FD_DTYPE_U8 && dst_dtype != FD_DTYPE_F32))
+            FD_THROW(FD_ERR_INVALID_ARGUMENT, "ConversionFilter: CV_8U and CV_32F are supported on this backend");
+        if (count == 0) return;
+        HIP_CHECK(hipSetDevice(ctx->device));
+        WhiScratch& S = scratch(ctx);
+        const size_t sb = (size_t)count * (src_dtype == FD_DTYPE_F32 ? 4 : 1), db = (size_t)count * (dst_dtype == FD_DTYPE_F32 ? 4 : 1);
+        S.in.reserve(sb);
+        S.feat.reserve(db);
+        HIP_CHECK(hipMemcpyAsync(S.in.p, src, sb, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_convert, dim3((unsigned)std::min<int64_t>((count + 255) / 256, 4096)), dim3(256), 0, ctx->stream, S.in.p,
+                           src_dtype == FD_DTYPE_F32, S.feat.p, dst_dtype == FD_DTYPE_F32, count, alpha, beta);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(dst, S.feat.p, db, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int fd_unit_norm_batch(fd_ctx* ctx, const float* src, int64_t n, int len, int norm_type, float* dst) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || n < 0 || len < 1 || (n > 0 && (!src || !dst))) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_unit_norm_batch: bad argument");
+        if (norm_type != 1 && norm_type != 2 && norm_type != 4) FD_THROW(FD_ERR_INVALID_ARGUMENT, "UnitNormFilter: norm type must be NORM_INF (1), NORM_L1 (2) or NORM_L2 (4)");
+        if (n == 0) return;
+        HIP_CHECK(hipSetDevice(ctx->device));
+        WhiScratch& S = scratch(ctx);
+        const size_t bytes = sizeof(float) * (size_t)n * len;
+        S.in.reserve(bytes);
+        S.feat.reserve(bytes);
+        HIP_CHECK(hipMemcpyAsync(S.in.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_unit_norm, dim3((unsigned)std::min<int64_t>(n, 65535)), dim3(64), 0, ctx->stream, S.in.as<float>(), S.feat.as<float>(), n, len, norm_type);
+        HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(dst, S.feat.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
     });

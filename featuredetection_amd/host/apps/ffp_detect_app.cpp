@@ -63,28 +63,32 @@ int main(int argc, char** argv) {
                 auto swd = make_shared<SlidingWindowDetector>(firstClassifier, featureExtractor);
                 det = make_shared<FiveStageSlidingWindowDetector>(swd, oe, secondClassifier);
             } else if (type == "single") {   // ffpDetectApp.cpp:427-500
+                // one DirectPyramidFeatureExtractor per pyramid, one FilteringPyramidFeatureExtractor per classifier (:445)
+                auto filteringExtractor = make_shared<FilteringPyramidFeatureExtractor>(featureExtractor);
                 const string featurespace = node.get<string>("feature", "hq64");
                 if (featurespace == "histeq") {
-                    featureExtractor->addPatchFilter(make_shared<HistogramEqualizationFilter>());
+                    filteringExtractor->addPatchFilter(make_shared<HistogramEqualizationFilter>());
                 } else if (featurespace == "whi") {
-                    featureExtractor->addPatchFilter(make_shared<WhiteningFilter>());
-                    featureExtractor->addPatchFilter(make_shared<HistogramEqualizationFilter>());
-                    featureExtractor->addPatchFilter(make_shared<ConversionFilter>(CV_32F, 1.0 / 127.5, -1.0));
-                    featureExtractor->addPatchFilter(make_shared<UnitNormFilter>(cv::NORM_L2));
+                    filteringExtractor->addPatchFilter(make_shared<WhiteningFilter>());
+                    filteringExtractor->addPatchFilter(make_shared<HistogramEqualizationFilter>());
+                    filteringExtractor->addPatchFilter(make_shared<ConversionFilter>(CV_32F, 1.0 / 127.5, -1.0));
+                    filteringExtractor->addPatchFilter(make_shared<UnitNormFilter>(cv::NORM_L2));
                 } else if (featurespace == "hq64") {
-                    featureExtractor->addPatchFilter(make_shared<HistEq64Filter>());
+                    filteringExtractor->addPatchFilter(make_shared<HistEq64Filter>());
                 } else if (featurespace != "gray") {
                     throw std::invalid_argument("unknown feature space " + featurespace);
                 }
                 if (node.count("patchFilter")) {   // ffpDetectApp.cpp:462-476
                     for (const auto& filterNode : node.get_child("patchFilter")) {
-                        if (filterNode.first == "conversionFilter") {
+                        if (filterNode.first == "reshapingFilter") {
+                            filteringExtractor->addPatchFilter(make_shared<ReshapingFilter>(filterNode.second.get_value<int>()));
+                        } else if (filterNode.first == "conversionFilter") {
                             std::stringstream ss(filterNode.second.get_value<string>());
                             int type; double scaling;
                             ss >> type >> scaling;
-                            featureExtractor->addPatchFilter(make_shared<ConversionFilter>(type, scaling));
+                            filteringExtractor->addPatchFilter(make_shared<ConversionFilter>(type, scaling));
                         } else {
-                            throw std::invalid_argument("unknown patch filter " + filterNode.first);   // reshapingFilter: a no-op for contiguous patches
+                            throw std::invalid_argument("unknown patch filter " + filterNode.first);
                         }
                     }
                 }
@@ -94,7 +98,7 @@ int main(int argc, char** argv) {
                 if (classifierType == "psvm") classifier = ProbabilisticSvmClassifier::load(classifierNode);
                 else if (classifierType == "prvm") classifier = ProbabilisticRvmClassifier::load(classifierNode);
                 else classifier = ProbabilisticWvmClassifier::load(classifierNode);   // "pwvm"
-                det = make_shared<SlidingWindowDetector>(classifier, featureExtractor);
+                det = make_shared<SlidingWindowDetector>(classifier, filteringExtractor);
             } else {
                 throw std::invalid_argument("unknown detector type " + type);
             }

@@ -92,6 +92,7 @@ public:
     void setThreshold(float t) override { threshold = t; dirty = true; }
     void store(std::ofstream& file);                       // SvmClassifier.cpp:68-107 text format
     static std::shared_ptr<SvmClassifier> load(std::ifstream& file);   // :109-159
+    static std::shared_ptr<SvmClassifier> loadFromText(const std::string& classifierFilename);   // :161-239 (FullPolynomial text models)
     const std::vector<cv::Mat>& getSupportVectors() const { return supportVectors; }
     const std::vector<float>& getCoefficients() const { return coefficients; }
     const fd_svm* native(double logisticA = 0.00556, double logisticB = -2.95) const;   // (re)builds the device model lazily
@@ -116,7 +117,8 @@ public:
     void setLogisticParameters(double a, double b) { logisticA = a; logisticB = b; }
     void store(std::ofstream& file);
     static std::shared_ptr<ProbabilisticSvmClassifier> load(std::ifstream& file);
-    // ptree: classifierFile (text format of SvmClassifier::store), optional logisticA/logisticB/threshold
+    // ptree: classifierFile (SvmClassifier::loadFromText format, or the SvmClassifier::store stream format as the stand-in for
+    // .mat models), optional logisticA / logisticB / threshold (ProbabilisticSvmClassifier.cpp:80-104)
     static std::shared_ptr<ProbabilisticSvmClassifier> load(const boost::property_tree::ptree& subtree);
     std::shared_ptr<SvmClassifier> getSvm() { return svm; }
     const std::shared_ptr<SvmClassifier> getSvm() const { return svm; }

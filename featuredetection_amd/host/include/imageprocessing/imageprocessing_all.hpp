@@ -2,7 +2,9 @@
 // Class names, namespaces, constructor and method signatures follow the reference headers cited per
 // class; the work is done by the HIP kernels behind fd_hip.h.  Filters that the GPU path fuses into a
 // kernel (GradientFilter, GradientBinningFilter, HogFilter, LbpFilter as layer filter, HistEq64Filter as
-// patch filter) are recognised by type when they are added to a pyramid / extractor.
+// patch filter) are recognised by type when they are added to a pyramid / extractor; every filter also has
+// its stand-alone ImageFilter::applyTo(const Mat&) form (one kernel launch per Mat: for composition and
+// tests, not for the sliding-window hot loop).
 #pragma once
 #include <memory>
 #include <string>
@@ -79,9 +81,9 @@ public:
     cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;
 };
 
-// The "whi" patch filter chain of ffpDetectApp.cpp:449-454.  Added in this order to a DirectPyramidFeatureExtractor
-// the four filters run as one fused kernel (fd_extract_whi / fd_detect_whi_svm); stand-alone only the
-// HistogramEqualizationFilter has a per-Mat form (fd_equalize_hist_batch).
+// The "whi" patch filter chain of ffpDetectApp.cpp:449-454.  Added in this order to a (Filtering / Direct) pyramid feature
+// extractor the four filters run as one fused kernel (fd_extract_whi / fd_detect_whi_svm); each also has its per-Mat form
+// (fd_whitening_batch, fd_equalize_hist_batch, fd_convert_batch, fd_unit_norm_batch).
 // WhiteningFilter.hpp:31 / WhiteningFilter.cpp:18-81
 class WhiteningFilter : public ImageFilter {
 public:
@@ -113,6 +115,15 @@ public:
     cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;
     int normType;
 };
+// ReshapingFilter.hpp: Mat::reshape(channels, rows) (ffpDetectApp.cpp:465-467 turns patches into row vectors); the fused
+// kernels work on flat vectors, so inside a fused chain it is a no-op
+class ReshapingFilter : public ImageFilter {
+public:
+    using ImageFilter::applyTo;
+    explicit ReshapingFilter(int rows, int channels = 0) : rows(rows), channels(channels) {}
+    cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;
+    int rows, channels;
+};
 
 // GreyWorldNormalizationFilter.cpp:20-71
 class GreyWorldNormalizationFilter : public ImageFilter {
@@ -121,7 +132,7 @@ public:
     cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;
 };
 
-// GradientFilter.cpp:16-59 (layer filter only on this backend)
+// GradientFilter.cpp:16-59 (fused as a layer filter; applyTo: CV_8UC1 -> CV_8UC2 via fd_gradient_image)
 class GradientFilter : public ImageFilter {
 public:
     using ImageFilter::applyTo;
@@ -130,7 +141,7 @@ public:
     int kernelSize, blurKernelSize;
 };
 
-// GradientBinningFilter.cpp:18-93 (layer filter only on this backend)
+// GradientBinningFilter.cpp:18-93 (fused as a layer filter; applyTo: CV_8UC2 -> CV_8UC2 / CV_8UC4 via fd_gradient_binning_image)
 class GradientBinningFilter : public ImageFilter {
 public:
     using ImageFilter::applyTo;
@@ -141,7 +152,7 @@ public:
     bool signedGradients, interpolate;
 };
 
-// LbpFilter.hpp (layer filter only on this backend)
+// LbpFilter.hpp (fused as a layer filter; applyTo via fd_lbp_image)
 class LbpFilter : public ImageFilter {
 public:
     using ImageFilter::applyTo;
@@ -153,7 +164,8 @@ public:
 };
 
 // HistogramFilter.hpp:24-33 -- base of the histogram patch filters.  On this backend they run fused on the
-// pyramid's bin-image layers (k_hog_tile / k_hist_features); applyTo(Mat) throws std::logic_error.
+// pyramid's bin-image layers (k_hog_tile / k_hist_features); applyTo(Mat) runs the same kernel on one bin-image
+// patch (fd_hist_patch_batch) and returns the 1 x F CV_32F feature vector.
 class HistogramFilter : public ImageFilter {
 public:
     enum class Normalization { NONE, L2NORM, L2HYS, L1NORM, L1SQRT };
@@ -228,6 +240,10 @@ class ImagePyramid {
 public:
     ImagePyramid(size_t octaveLayerCount, double minScaleFactor, double maxScaleFactor = 1);
     ImagePyramid(double incrementalScaleFactor, double minScaleFactor, double maxScaleFactor = 1);
+    // ImagePyramid.cpp:100-104: same layers as `pyramid`, restricted to scale factors within [min, max]; nothing is rebuilt,
+    // the layers of the source (and its device arena) are shared (createLayers(const ImagePyramid&), :200-235, without the
+    // approximated in-between layers of createApproximated)
+    ImagePyramid(std::shared_ptr<ImagePyramid> pyramid, double minScaleFactor, double maxScaleFactor = 1);
     ~ImagePyramid();
     ImagePyramid(const ImagePyramid&) = delete;
     ImagePyramid& operator=(const ImagePyramid&) = delete;
@@ -235,6 +251,10 @@ public:
     void addLayerFilter(const std::shared_ptr<ImageFilter>& filter);   // GradientFilter, GradientBinningFilter, LbpFilter
     void update(const cv::Mat& image);
     void update(const std::shared_ptr<VersionedImage>& image);
+    void setSource(const cv::Mat& image) { setSource(std::make_shared<VersionedImage>(image)); }
+    void setSource(const std::shared_ptr<VersionedImage>& image);     // ImagePyramid.cpp:132-139
+    void setSource(const std::shared_ptr<ImagePyramid>& pyramid);     // ImagePyramid.cpp:141-144
+    void update();                                                     // ImagePyramid.cpp:146-168
     const std::vector<std::shared_ptr<ImagePyramidLayer>>& getLayers() const;  // downloads the layers on first use
     const std::shared_ptr<ImagePyramidLayer> getLayer(int index) const;
     double getMinScaleFactor() const { return minScaleFactor; }
@@ -243,10 +263,27 @@ public:
     cv::Size getImageSize() const { return imageSize; }
     std::vector<std::pair<int, double>> getLayerScales() const;
     std::vector<cv::Size> getLayerSizes() const;
-    fd_pyramid* native() const { return handle; }
+    fd_pyramid* native() const { return sourcePyramid ? sourcePyramid->native() : handle; }
+    std::shared_ptr<ImagePyramid> getSourcePyramid() const { return sourcePyramid; }
+    // Layer sub-range / region of interest of the extraction or detection call that follows (fd_pyramid_select), intersected
+    // with the scale range of a pyramid that views another one; reset when the guard goes out of scope.
+    class Selection {
+    public:
+        Selection(fd_pyramid* h, int first, int last, int step, const cv::Rect* roi);
+        ~Selection();
+        Selection(Selection&& o) : handle(o.handle) { o.handle = nullptr; }
+        Selection(const Selection&) = delete;
+    private:
+        fd_pyramid* handle;
+    };
+    Selection select(int firstLayer = -1, int lastLayer = -1, int stepLayer = 1, const cv::Rect* roi = nullptr) const;
+    static long buildCount();   // pyramids actually (re)built so far: the VersionedImage mechanism at work (tests)
 private:
     void applyLayerFilterConfig();
+    void viewRange(int& first, int& last) const;   // layer indices of the source inside [minScaleFactor, maxScaleFactor]
     fd_pyramid* handle;
+    std::shared_ptr<ImagePyramid> sourcePyramid;
+    std::shared_ptr<VersionedImage> sourceImage;
     double minScaleFactor, maxScaleFactor;
     cv::Size imageSize;
     Version version;
@@ -344,6 +381,7 @@ public:
     // ConversionFilter(CV_32F, scale, shift): the input of a ProbabilisticRvmClassifier (fd_detect_rvm)
     std::shared_ptr<ConversionFilter> getConversion() const { return whiStage == 0 ? conversion : nullptr; }
     int getU8FeatureSpace() const { return histeq ? 1 : (equalization ? 2 : 0); }
+    bool hasPatchFilters() const { return histeq || hist || whitening || equalization || conversion || reshaping; }
 private:
     std::shared_ptr<Patch> extractFromLayer(const ImagePyramidLayer& layer, cv::Rect bounds) const;
     std::shared_ptr<ImagePyramid> pyramid;
@@ -354,7 +392,43 @@ private:
     std::shared_ptr<WhiteningFilter> whitening;
     std::shared_ptr<HistogramEqualizationFilter> equalization;
     std::shared_ptr<ConversionFilter> conversion;
+    std::shared_ptr<ReshapingFilter> reshaping;
     int whiStage = 0;   // number of whi chain filters added so far (in order)
+};
+
+// FilteringPyramidFeatureExtractor.hpp:20-90 -- applies additional patch filters to the patches of another pyramid feature
+// extractor (ffpDetectApp.cpp:445).  When the underlying extractor is a DirectPyramidFeatureExtractor without patch filters of
+// its own and the added chain is one the kernels fuse (hq64, histeq, whi, histogram filters, + ConversionFilter /
+// ReshapingFilter), the detectors run the fused GPU path (getFusedExtractor()); otherwise every patch goes through the filters'
+// per-Mat applyTo, exactly like the reference.
+class FilteringPyramidFeatureExtractor : public PyramidFeatureExtractor {
+public:
+    using PyramidFeatureExtractor::update;
+    using PyramidFeatureExtractor::extract;
+    explicit FilteringPyramidFeatureExtractor(std::shared_ptr<PyramidFeatureExtractor> extractor);
+    void addPatchFilter(std::shared_ptr<ImageFilter> filter);
+    void update(std::shared_ptr<VersionedImage> image) override { extractor->update(image); }
+    std::shared_ptr<Patch> extract(int x, int y, int width, int height) const override;
+    std::vector<std::shared_ptr<Patch>> extract(int stepX, int stepY, cv::Rect roi = cv::Rect(), int firstLayer = -1, int lastLayer = -1,
+                                                int stepLayer = 1) const override;
+    std::shared_ptr<Patch> extract(int layer, int x, int y) const override;
+    int getLayerIndex(int width, int height) const override { return extractor->getLayerIndex(width, height); }
+    double getMinScaleFactor() const override { return extractor->getMinScaleFactor(); }
+    double getMaxScaleFactor() const override { return extractor->getMaxScaleFactor(); }
+    double getIncrementalScaleFactor() const override { return extractor->getIncrementalScaleFactor(); }
+    cv::Size getPatchSize() const override { return extractor->getPatchSize(); }
+    cv::Size getImageSize() const override { return extractor->getImageSize(); }
+    std::vector<std::pair<int, double>> getLayerScales() const override { return extractor->getLayerScales(); }
+    std::vector<cv::Size> getLayerSizes() const override { return extractor->getLayerSizes(); }
+    std::vector<cv::Size> getPatchSizes() const override { return extractor->getPatchSizes(); }
+    std::shared_ptr<PyramidFeatureExtractor> getExtractor() const { return extractor; }
+    // the equivalent DirectPyramidFeatureExtractor (same pyramid, same patch size, the whole chain as its patch filters) when the
+    // chain maps to a fused kernel, else null
+    std::shared_ptr<DirectPyramidFeatureExtractor> getFusedExtractor() const { return fused; }
+private:
+    std::shared_ptr<PyramidFeatureExtractor> extractor;
+    std::shared_ptr<ChainedFilter> patchFilter;
+    std::shared_ptr<DirectPyramidFeatureExtractor> fused;
 };
 
 // filtering/FhogFilter.hpp:55-56 / FhogFilter.cpp:20-72 (the cell descriptors of the AggregatedFeaturesDetector family)

@@ -75,14 +75,33 @@ GradientFilter::GradientFilter(int kernelSize, int blurKernelSize) : kernelSize(
         throw std::invalid_argument("GradientFilter: the kernel size must be 1 or 3 on this backend (reference: 1, 3, 5, 7 or CV_SCHARR)");
     if (blurKernelSize != 0) throw std::invalid_argument("GradientFilter: blurring is not available on this backend");
 }
-static Mat fused_only(const char* what) {
-    throw std::logic_error(string(what) + " is fused into the pyramid / feature kernels of this backend: add it as a layer or patch filter");
+// ---- stand-alone ImageFilter::applyTo(const Mat&) forms (ImageFilter.hpp:18-57): one kernel launch per Mat through the C ABI
+Mat GradientFilter::applyTo(const Mat& image, Mat& filtered) const {
+    if (image.type() != CV_8UC1) throw std::invalid_argument("GradientFilter: the image must be of type CV_8UC1");
+    Mat src = contiguous(image);
+    Mat dst(src.rows, src.cols, CV_8UC2);
+    check(fd_gradient_image(context(), src.data, src.cols, src.rows, kernelSize, dst.data));
+    filtered = dst;
+    return filtered;
 }
-Mat GradientFilter::applyTo(const Mat&, Mat&) const { return fused_only("GradientFilter"); }
 GradientBinningFilter::GradientBinningFilter(unsigned int bins, bool signedGradients, bool interpolate)
     : bins(bins), signedGradients(signedGradients), interpolate(interpolate) {}
-Mat GradientBinningFilter::applyTo(const Mat&, Mat&) const { return fused_only("GradientBinningFilter"); }
-Mat LbpFilter::applyTo(const Mat&, Mat&) const { return fused_only("LbpFilter"); }
+Mat GradientBinningFilter::applyTo(const Mat& image, Mat& filtered) const {
+    if (image.type() != CV_8UC2) throw std::invalid_argument("GradientBinningFilter: the image must be of type CV_8UC2");
+    Mat src = contiguous(image);
+    Mat dst(src.rows, src.cols, interpolate ? CV_8UC4 : CV_8UC2);
+    check(fd_gradient_binning_image(context(), src.data, src.cols, src.rows, (int)bins, signedGradients, interpolate, dst.data));
+    filtered = dst;
+    return filtered;
+}
+Mat LbpFilter::applyTo(const Mat& image, Mat& filtered) const {
+    if (image.type() != CV_8UC1) throw std::invalid_argument("LbpFilter: the image must be of type CV_8UC1");
+    Mat src = contiguous(image);
+    Mat dst(src.rows, src.cols, CV_8UC1);
+    check(fd_lbp_image(context(), src.data, src.cols, src.rows, (int)type, dst.data));
+    filtered = dst;
+    return filtered;
+}
 unsigned int LbpFilter::getBinCount() const {
     switch (type) {
         case Type::LBP8: return 256;
@@ -90,9 +109,45 @@ unsigned int LbpFilter::getBinCount() const {
         default: return 16;
     }
 }
-Mat WhiteningFilter::applyTo(const Mat&, Mat&) const { return fused_only("WhiteningFilter"); }
-Mat ConversionFilter::applyTo(const Mat&, Mat&) const { return fused_only("ConversionFilter"); }
-Mat UnitNormFilter::applyTo(const Mat&, Mat&) const { return fused_only("UnitNormFilter"); }
+Mat WhiteningFilter::applyTo(const Mat& image, Mat& filtered) const {
+    if (image.channels() > 1) throw std::invalid_argument("WhiteningFilter: the image must have exactly one channel");
+    if (image.type() != CV_8UC1) throw std::invalid_argument("WhiteningFilter: CV_8UC1 images are supported on this backend");
+    Mat src = contiguous(image);
+    Mat dst(src.rows, src.cols, CV_8UC1);
+    check(fd_whitening_batch(context(), src.data, 1, src.cols, src.rows, alpha, cutoffFrequency, dst.data));
+    filtered = dst;
+    return filtered;
+}
+Mat ConversionFilter::applyTo(const Mat& image, Mat& filtered) const {
+    const int sd = image.depth(), dd = type & 7;
+    if ((sd != CV_8U && sd != CV_32F) || (dd != CV_8U && dd != CV_32F))
+        throw std::invalid_argument("ConversionFilter: CV_8U and CV_32F are supported on this backend");
+    Mat src = contiguous(image);
+    Mat dst(src.rows, src.cols, CV_MAKETYPE(dd, src.channels()));
+    check(fd_convert_batch(context(), src.data, sd == CV_32F ? FD_DTYPE_F32 : FD_DTYPE_U8, (int64_t)src.rows * src.cols * src.channels(), alpha, beta,
+                           dst.data, dd == CV_32F ? FD_DTYPE_F32 : FD_DTYPE_U8));
+    filtered = dst;
+    return filtered;
+}
+Mat UnitNormFilter::applyTo(const Mat& image, Mat& filtered) const {
+    if (image.channels() > 1) throw std::invalid_argument("UnitNormFilter: The image must have exactly one channel.");
+    Mat f32 = image.depth() == CV_32F ? contiguous(image) : ConversionFilter(CV_32F).applyTo(image);   // image.convertTo(filtered, CV_32F)
+    Mat dst(f32.rows, f32.cols, CV_32FC1);
+    check(fd_unit_norm_batch(context(), f32.ptr<float>(0), 1, f32.rows * f32.cols, normType, dst.ptr<float>(0)));
+    filtered = dst;
+    return filtered;
+}
+Mat ReshapingFilter::applyTo(const Mat& image, Mat& filtered) const {   // Mat::reshape(cn, rows) of a continuous matrix
+    Mat src = contiguous(image).clone();
+    const int cn = channels == 0 ? src.channels() : channels;
+    const size_t total = (size_t)src.rows * src.cols * src.channels();
+    const int r = rows == 0 ? src.rows : rows;
+    if (r <= 0 || total % ((size_t)r * cn) != 0) throw std::invalid_argument("ReshapingFilter: the matrix cannot be reshaped to the requested number of rows");
+    Mat dst(r, (int)(total / ((size_t)r * cn)), CV_MAKETYPE(src.depth(), cn));
+    std::memcpy(dst.data, src.data, total * Mat::elemSizeOf(src.depth()));
+    filtered = dst;
+    return filtered;
+}
 Mat HistogramEqualizationFilter::applyTo(const Mat& image, Mat& filtered) const {
     if (image.type() != CV_8UC1) throw std::invalid_argument("HistogramEqualizationFilter: the image must be of type CV_8UC1");
     Mat src = image.isContinuous() ? image : image.clone();
@@ -125,7 +180,8 @@ SpatialHistogramFilter::SpatialHistogramFilter(int binCount, int cellWidth, int 
     if (blockWidth <= 0) throw std::invalid_argument("SpatialHistogramFilter: blockWidth must be greater than zero");
     if (blockHeight <= 0) throw std::invalid_argument("SpatialHistogramFilter: blockHeight must be greater than zero");
 }
-Mat SpatialHistogramFilter::applyTo(const Mat&, Mat&) const { return fused_only("SpatialHistogramFilter"); }
+static Mat hist_apply(const HistogramFilter& f, const Mat& image, Mat& filtered);
+Mat SpatialHistogramFilter::applyTo(const Mat& image, Mat& filtered) const { return hist_apply(*this, image, filtered); }
 PyramidHogFilter::PyramidHogFilter(int binCount, int levelCount, bool interpolate, bool signedAndUnsigned)
     : HistogramFilter(Normalization::L2NORM), binCount(binCount), levelCount(levelCount), interpolate(interpolate),
       signedAndUnsigned(signedAndUnsigned) {
@@ -134,13 +190,13 @@ PyramidHogFilter::PyramidHogFilter(int binCount, int levelCount, bool interpolat
     if (signedAndUnsigned && binCount % 2 != 0)
         throw std::invalid_argument("PyramidHogFilter: the bin size must be even for signed and unsigned gradients to be combined");
 }
-Mat PyramidHogFilter::applyTo(const Mat&, Mat&) const { return fused_only("PyramidHogFilter"); }
+Mat PyramidHogFilter::applyTo(const Mat& image, Mat& filtered) const { return hist_apply(*this, image, filtered); }
 SpatialPyramidHistogramFilter::SpatialPyramidHistogramFilter(int binCount, int levelCount, bool interpolate, Normalization normalization)
     : HistogramFilter(normalization), binCount(binCount), levelCount(levelCount), interpolate(interpolate) {
     if (binCount <= 0) throw std::invalid_argument("SpatialPyramidHistogramFilter: binCount must be greater than zero");
     if (levelCount <= 0) throw std::invalid_argument("SpatialPyramidHistogramFilter: levelCount must be greater than zero");
 }
-Mat SpatialPyramidHistogramFilter::applyTo(const Mat&, Mat&) const { return fused_only("SpatialPyramidHistogramFilter"); }
+Mat SpatialPyramidHistogramFilter::applyTo(const Mat& image, Mat& filtered) const { return hist_apply(*this, image, filtered); }
 
 // parameters of the fused histogram kernels for a patch filter
 static fd_hist_params hist_params_of(const HistogramFilter& f, int pw, int ph, int stepX, int stepY) {
@@ -164,7 +220,21 @@ static fd_hist_params hist_params_of(const HistogramFilter& f, int pw, int ph, i
     }
     return hp;
 }
-Mat HogFilter::applyTo(const Mat&, Mat&) const { return fused_only("HogFilter"); }
+// HistogramFilter::applyTo(const Mat&): the bin image of one patch (CV_8UC1 bins, CV_8UC2 bin + weight, CV_8UC4 two bins + weights)
+// -> 1 x F CV_32F feature vector
+static Mat hist_apply(const HistogramFilter& f, const Mat& image, Mat& filtered) {
+    if (image.depth() != CV_8U || (image.channels() != 1 && image.channels() != 2 && image.channels() != 4))
+        throw std::invalid_argument("HistogramFilter: The image must have one, two or four channels and be of depth CV_8U");
+    Mat src = contiguous(image);
+    fd_hist_params hp = hist_params_of(f, src.cols, src.rows, 1, 1);
+    const int F = fd_hist_feature_length(&hp, src.channels());
+    if (F < 0) throw std::invalid_argument("HistogramFilter: invalid parameters for this patch size");
+    Mat dst(1, F, CV_32FC1);
+    check(fd_hist_patch_batch(context(), src.data, 1, src.channels(), &hp, dst.ptr<float>(0)));
+    filtered = dst;
+    return filtered;
+}
+Mat HogFilter::applyTo(const Mat& image, Mat& filtered) const { return hist_apply(*this, image, filtered); }
 
 // ---- ImagePyramid -------------------------------------------------------------------------------
 ImagePyramid::ImagePyramid(size_t octaveLayerCount, double minS, double maxS)
@@ -174,14 +244,71 @@ ImagePyramid::ImagePyramid(size_t octaveLayerCount, double minS, double maxS)
 ImagePyramid::ImagePyramid(double inc, double minS, double maxS) : handle(nullptr), minScaleFactor(minS), maxScaleFactor(maxS), layersValid(false) {
     check(fd_pyramid_create_inc(context(), inc, minS, maxS, &handle));
 }
-ImagePyramid::~ImagePyramid() { fd_pyramid_destroy(handle); }
-double ImagePyramid::getIncrementalScaleFactor() const { return fd_pyramid_incremental_scale(handle); }
+ImagePyramid::ImagePyramid(shared_ptr<ImagePyramid> pyramid, double minS, double maxS)
+    : handle(nullptr), sourcePyramid(pyramid), minScaleFactor(minS), maxScaleFactor(maxS), layersValid(false) {
+    if (!pyramid) throw std::invalid_argument("ImagePyramid: the source pyramid must not be null");
+}
+ImagePyramid::~ImagePyramid() { if (handle) fd_pyramid_destroy(handle); }
+double ImagePyramid::getIncrementalScaleFactor() const { return fd_pyramid_incremental_scale(native()); }
+static long g_pyramidBuilds = 0;
+long ImagePyramid::buildCount() { return g_pyramidBuilds; }
 
 void ImagePyramid::addImageFilter(const shared_ptr<ImageFilter>& filter) {
     if (!std::dynamic_pointer_cast<GrayscaleFilter>(filter))
         throw std::logic_error("ImagePyramid: only GrayscaleFilter is supported as image filter on this backend");
+    if (sourcePyramid) sourcePyramid->addImageFilter(filter);   // ImagePyramid.cpp:108-110
+}
+void ImagePyramid::setSource(const shared_ptr<VersionedImage>& image) {
+    if (sourcePyramid && !handle)
+        throw std::logic_error("ImagePyramid: a pyramid that was constructed on another pyramid has no layer parameters of its own to build from an image");
+    sourcePyramid.reset();
+    sourceImage = image;
+}
+void ImagePyramid::setSource(const shared_ptr<ImagePyramid>& pyramid) {
+    if (!pyramid) throw std::invalid_argument("ImagePyramid: the source pyramid must not be null");
+    if (gradient || binning || lbp) throw std::logic_error("ImagePyramid: layer filters on top of a source pyramid are not available on this backend");
+    sourceImage.reset();
+    sourcePyramid = pyramid;
+    version = Version();
+    layersValid = false;
+}
+void ImagePyramid::update() {   // ImagePyramid.cpp:146-168
+    if (sourcePyramid) {
+        if (version != sourcePyramid->version) { version = sourcePyramid->version; imageSize = sourcePyramid->imageSize; layersValid = false; }
+    } else if (sourceImage) {
+        update(sourceImage);
+    }
+}
+// layer indices of the source pyramid whose scale factors lie inside [minScaleFactor, maxScaleFactor] (ImagePyramid.cpp:217-222)
+void ImagePyramid::viewRange(int& first, int& last) const {
+    first = -1; last = -1;
+    if (!sourcePyramid) return;
+    first = 1 << 30; last = -2;   // empty unless a layer qualifies
+    for (const auto& sc : sourcePyramid->getLayerScales())
+        if (sc.second >= minScaleFactor && sc.second <= maxScaleFactor) { first = std::min(first, sc.first); last = std::max(last, sc.first); }
+}
+ImagePyramid::Selection::Selection(fd_pyramid* h, int first, int last, int step, const cv::Rect* roi) : handle(h) {
+    int r[4] = {0, 0, 0, 0};
+    if (roi) { r[0] = roi->x; r[1] = roi->y; r[2] = roi->width; r[3] = roi->height; }
+    // an empty range (first > last) selects nothing: express it as an index range no layer has
+    if (last != -1 && first > last) { first = 1 << 30; last = 1 << 30; }
+    check(fd_pyramid_select(handle, first, last, step, roi ? r : nullptr));
+}
+ImagePyramid::Selection::~Selection() { if (handle) fd_pyramid_select(handle, -1, -1, 1, nullptr); }
+ImagePyramid::Selection ImagePyramid::select(int firstLayer, int lastLayer, int stepLayer, const cv::Rect* roi) const {
+    if (stepLayer < 1) throw std::invalid_argument("DirectPyramidFeatureExtractor: stepLayer has to be greater than zero");
+    int vf, vl;
+    viewRange(vf, vl);
+    if (sourcePyramid) {   // intersect with the view's scale range
+        firstLayer = firstLayer < 0 ? vf : std::max(firstLayer, vf);
+        lastLayer = lastLayer < 0 ? vl : std::min(lastLayer, vl);
+        if (vl == -2) { firstLayer = 1; lastLayer = 0; }
+    }
+    const cv::Rect* r = (roi && (roi->x != 0 || roi->y != 0 || roi->width != 0 || roi->height != 0)) ? roi : nullptr;
+    return Selection(native(), firstLayer, lastLayer, stepLayer, r);
 }
 void ImagePyramid::addLayerFilter(const shared_ptr<ImageFilter>& filter) {
+    if (sourcePyramid) throw std::logic_error("ImagePyramid: layer filters on top of a source pyramid are not available on this backend");
     if (auto g = std::dynamic_pointer_cast<GradientFilter>(filter)) gradient = g;
     else if (auto b = std::dynamic_pointer_cast<GradientBinningFilter>(filter)) binning = b;
     else if (auto l = std::dynamic_pointer_cast<LbpFilter>(filter)) lbp = l;
@@ -198,16 +325,32 @@ void ImagePyramid::applyLayerFilterConfig() {
 }
 void ImagePyramid::update(const Mat& image) { update(make_shared<VersionedImage>(image)); }
 void ImagePyramid::update(const shared_ptr<VersionedImage>& image) {
+    if (sourcePyramid) {   // ImagePyramid.cpp:121-124: the source pyramid is updated (once per image version), this one follows
+        sourcePyramid->update(image);
+        update();
+        return;
+    }
     if ((gradient != nullptr) != (binning != nullptr))
         throw std::logic_error("ImagePyramid: GradientFilter and GradientBinningFilter have to be added together");
+    sourceImage = image;
     if (version == image->getVersion()) return;   // ImagePyramid.cpp:150
     Mat src = contiguous(image->getData());
     check(fd_pyramid_update(handle, src.data, src.cols, src.rows, src.channels(), 0));
+    ++g_pyramidBuilds;
     imageSize = cv::Size(src.cols, src.rows);
     version = image->getVersion();
     layersValid = false;
 }
 const vector<shared_ptr<ImagePyramidLayer>>& ImagePyramid::getLayers() const {
+    if (sourcePyramid) {
+        if (!layersValid) {
+            layers.clear();
+            for (const auto& l : sourcePyramid->getLayers())
+                if (l->getScaleFactor() >= minScaleFactor && l->getScaleFactor() <= maxScaleFactor) layers.push_back(l);
+            layersValid = true;
+        }
+        return layers;
+    }
     if (!layersValid) {
         layers.clear();
         const int n = fd_pyramid_layer_count(handle);
@@ -232,6 +375,11 @@ const shared_ptr<ImagePyramidLayer> ImagePyramid::getLayer(int index) const {
 }
 vector<std::pair<int, double>> ImagePyramid::getLayerScales() const {
     vector<std::pair<int, double>> out;
+    if (sourcePyramid) {
+        for (const auto& sc : sourcePyramid->getLayerScales())
+            if (sc.second >= minScaleFactor && sc.second <= maxScaleFactor) out.push_back(sc);
+        return out;
+    }
     for (int i = 0; i < fd_pyramid_layer_count(handle); ++i) {
         int index, w, h, ch; double scale;
         fd_pyramid_layer_info(handle, i, &index, &scale, &w, &h, &ch);
@@ -241,6 +389,13 @@ vector<std::pair<int, double>> ImagePyramid::getLayerScales() const {
 }
 vector<cv::Size> ImagePyramid::getLayerSizes() const {
     vector<cv::Size> out;
+    if (sourcePyramid) {
+        auto scales = sourcePyramid->getLayerScales();
+        auto sizes = sourcePyramid->getLayerSizes();
+        for (size_t i = 0; i < scales.size(); ++i)
+            if (scales[i].second >= minScaleFactor && scales[i].second <= maxScaleFactor) out.push_back(sizes[i]);
+        return out;
+    }
     for (int i = 0; i < fd_pyramid_layer_count(handle); ++i) {
         int index, w, h, ch; double scale;
         fd_pyramid_layer_info(handle, i, &index, &scale, &w, &h, &ch);
@@ -272,6 +427,11 @@ Mat FhogFilter::applyTo(const Mat& image, Mat& descriptors) const {
 DirectPyramidFeatureExtractor::DirectPyramidFeatureExtractor(shared_ptr<ImagePyramid> pyramid, int width, int height)
     : pyramid(pyramid), patchWidth(width), patchHeight(height) {}
 void DirectPyramidFeatureExtractor::addPatchFilter(shared_ptr<ImageFilter> filter) {
+    if (auto rf = std::dynamic_pointer_cast<ReshapingFilter>(filter)) {   // the fused kernels work on flat vectors: nothing to do
+        if (rf->rows != 1 || rf->channels > 1) throw std::logic_error("DirectPyramidFeatureExtractor: ReshapingFilter(1) (row vectors) is available in a fused chain");
+        reshaping = rf;
+        return;
+    }
     if (auto h = std::dynamic_pointer_cast<HistEq64Filter>(filter)) histeq = h;
     else if (auto wf = std::dynamic_pointer_cast<WhiteningFilter>(filter)) {
         if (whiStage != 0) throw std::logic_error("DirectPyramidFeatureExtractor: WhiteningFilter must be the first filter of the whi chain");
@@ -334,17 +494,16 @@ shared_ptr<Patch> DirectPyramidFeatureExtractor::extract(int layerIndex, int x, 
 }
 vector<shared_ptr<Patch>> DirectPyramidFeatureExtractor::extract(int stepX, int stepY, cv::Rect roi, int firstLayer, int lastLayer,
                                                                  int stepLayer) const {
-    if (firstLayer != -1 || lastLayer != -1 || stepLayer != 1)
-        throw std::logic_error("DirectPyramidFeatureExtractor: layer sub-ranges are not available on this backend");
-    int r[4] = {roi.x, roi.y, roi.width, roi.height};
+    // DirectPyramidFeatureExtractor.cpp:75-123: the layer sub-range, the layer step and the region of interest apply to the window
+    // enumeration of every chain (fd_pyramid_select); a pyramid built on another pyramid adds its scale range
+    auto selection = pyramid->select(firstLayer, lastLayer, stepLayer, &roi);
     int64_t n = 0;
-    check(fd_pyramid_window_count(pyramid->native(), patchWidth, patchHeight, stepX, stepY, r, &n));
+    check(fd_pyramid_window_count(pyramid->native(), patchWidth, patchHeight, stepX, stepY, nullptr, &n));
     vector<int32_t> wins((size_t)n * 7);
-    if (n) check(fd_pyramid_windows(pyramid->native(), patchWidth, patchHeight, stepX, stepY, r, wins.data(), n, &n));
+    if (n) check(fd_pyramid_windows(pyramid->native(), patchWidth, patchHeight, stepX, stepY, nullptr, wins.data(), n, &n));
     vector<shared_ptr<Patch>> patches;
     patches.reserve((size_t)n);
     if (hog) {
-        if (roi.area() != 0) throw std::logic_error("DirectPyramidFeatureExtractor: HOG extraction works on the whole image only");
         fd_hog_params hp = {patchWidth, patchHeight, stepX, stepY, hog->binCount, hog->cellWidth, hog->blockWidth, hog->signedAndUnsigned};
         const int F = fd_hog_feature_length(&hp);
         Mat all((int)n, F, CV_32FC1);
@@ -358,7 +517,6 @@ vector<shared_ptr<Patch>> DirectPyramidFeatureExtractor::extract(int stepX, int 
     }
     if (whiStage != 0 && whiStage != 4) throw std::logic_error("DirectPyramidFeatureExtractor: incomplete whi filter chain");
     if (whiStage == 4) {
-        if (roi.area() != 0) throw std::logic_error("DirectPyramidFeatureExtractor: whi extraction works on the whole image only");
         fd_whi_params wp = {patchWidth, patchHeight, stepX, stepY, whitening->alpha, whitening->cutoffFrequency};
         const int F = patchWidth * patchHeight;
         Mat all((int)std::max<int64_t>(n, 1), F, CV_32FC1);
@@ -373,7 +531,6 @@ vector<shared_ptr<Patch>> DirectPyramidFeatureExtractor::extract(int stepX, int 
         return patches;
     }
     if (hist) {
-        if (roi.area() != 0) throw std::logic_error("DirectPyramidFeatureExtractor: histogram feature extraction works on the whole image only");
         fd_hist_params hp = hist_params_of(*hist, patchWidth, patchHeight, stepX, stepY);
         int index, lw, lh, ch = 1; double scale;
         if (fd_pyramid_layer_count(pyramid->native()) > 0) fd_pyramid_layer_info(pyramid->native(), 0, &index, &scale, &lw, &lh, &ch);
@@ -388,7 +545,7 @@ vector<shared_ptr<Patch>> DirectPyramidFeatureExtractor::extract(int stepX, int 
         }
         return patches;
     }
-    const auto& layers = pyramid->getLayers();
+    const auto& layers = (pyramid->getSourcePyramid() ? pyramid->getSourcePyramid() : pyramid)->getLayers();   // w[0] = position in the underlying pyramid
     const int d = patchWidth * patchHeight;
     Mat raw((int)std::max<int64_t>(n, 1), d, CV_8UC1), eq;
     for (int64_t i = 0; i < n; ++i) {
@@ -421,6 +578,38 @@ vector<shared_ptr<Patch>> DirectPyramidFeatureExtractor::extract(int stepX, int 
         patches.push_back(make_shared<Patch>(w[3], w[4], w[5], w[6], data));
     }
     return patches;
+}
+
+// ---- FilteringPyramidFeatureExtractor (FilteringPyramidFeatureExtractor.hpp:20-90) ------------------------------------------
+FilteringPyramidFeatureExtractor::FilteringPyramidFeatureExtractor(shared_ptr<PyramidFeatureExtractor> extractor)
+    : extractor(extractor), patchFilter(make_shared<ChainedFilter>()) {
+    if (!extractor) throw std::invalid_argument("FilteringPyramidFeatureExtractor: the underlying extractor must not be null");
+    auto direct = std::dynamic_pointer_cast<DirectPyramidFeatureExtractor>(extractor);
+    if (direct && !direct->hasPatchFilters())
+        fused = make_shared<DirectPyramidFeatureExtractor>(direct->getPyramid(), direct->getPatchWidth(), direct->getPatchHeight());
+}
+void FilteringPyramidFeatureExtractor::addPatchFilter(shared_ptr<ImageFilter> filter) {
+    patchFilter->add(filter);
+    if (fused) {
+        try { fused->addPatchFilter(filter); }
+        catch (const std::logic_error&) { fused.reset(); }   // not a chain the kernels fuse: per-Mat composition from now on
+    }
+}
+shared_ptr<Patch> FilteringPyramidFeatureExtractor::extract(int x, int y, int width, int height) const {
+    shared_ptr<Patch> patch = extractor->extract(x, y, width, height);
+    if (patch) patchFilter->applyInPlace(patch->getData());
+    return patch;
+}
+vector<shared_ptr<Patch>> FilteringPyramidFeatureExtractor::extract(int stepX, int stepY, cv::Rect roi, int firstLayer, int lastLayer, int stepLayer) const {
+    if (fused) return fused->extract(stepX, stepY, roi, firstLayer, lastLayer, stepLayer);   // batched kernels, same values
+    vector<shared_ptr<Patch>> patches = extractor->extract(stepX, stepY, roi, firstLayer, lastLayer, stepLayer);
+    for (shared_ptr<Patch>& patch : patches) patchFilter->applyInPlace(patch->getData());
+    return patches;
+}
+shared_ptr<Patch> FilteringPyramidFeatureExtractor::extract(int layer, int x, int y) const {
+    shared_ptr<Patch> patch = extractor->extract(layer, x, y);
+    if (patch) patchFilter->applyInPlace(patch->getData());
+    return patch;
 }
 
 }  // namespace imageprocessing
@@ -582,13 +771,81 @@ shared_ptr<ProbabilisticSvmClassifier> ProbabilisticSvmClassifier::load(std::ifs
     file >> tmp >> a >> b;
     return make_shared<ProbabilisticSvmClassifier>(svm, a, b);
 }
+// SvmClassifier::loadFromText (SvmClassifier.cpp:161-239): the line-based text format of the reference's polynomial SVMs --
+//   FullPolynomial <degree> <constant> <scale> / Number of SV : n / Dim of SV : d / B0 : b / alphas[i]=a (n lines) /
+//   "Support vectors: " / n lines of d floats -- CV_32F support vectors, PolynomialKernel(scale, constant, degree)
+shared_ptr<SvmClassifier> SvmClassifier::loadFromText(const string& classifierFilename) {
+    std::ifstream file(classifierFilename.c_str());
+    if (!file.is_open()) throw std::runtime_error("SvmClassifier: Invalid classifier file");
+    string line;
+    if (!std::getline(file, line)) throw std::runtime_error("SvmClassifier: Invalid classifier file");
+    shared_ptr<Kernel> kernel;
+    {
+        std::istringstream lineStream(line);
+        string kernelType;
+        lineStream >> kernelType;
+        if (kernelType != "FullPolynomial") throw std::runtime_error("SvmClassifier: Invalid kernel type: " + kernelType);
+        int degree = 0;
+        double constant = 0, scale = 0;
+        lineStream >> degree >> constant >> scale;
+        kernel.reset(new PolynomialKernel(scale, constant, degree));
+    }
+    auto svm = make_shared<SvmClassifier>(kernel);
+    auto next = [&]() { if (!std::getline(file, line)) throw std::runtime_error("SvmClassifier: Invalid classifier file"); };
+    int svCount = 0, dimensionCount = 0;
+    float bias = 0;
+    next();
+    if (std::sscanf(line.c_str(), "Number of SV : %d", &svCount) != 1 || svCount < 1) throw std::runtime_error("SvmClassifier: Invalid classifier file");
+    next();
+    if (std::sscanf(line.c_str(), "Dim of SV : %d", &dimensionCount) != 1 || dimensionCount < 1) throw std::runtime_error("SvmClassifier: Invalid classifier file");
+    next();
+    if (std::sscanf(line.c_str(), "B0 : %f", &bias) != 1) throw std::runtime_error("SvmClassifier: Invalid classifier file");
+    vector<float> coefficients((size_t)svCount, 0.f);
+    for (int i = 0; i < svCount; ++i) {
+        float alpha;
+        int index;
+        next();
+        if (std::sscanf(line.c_str(), "alphas[%d]=%f", &index, &alpha) != 2 || index < 0 || index >= svCount)
+            throw std::runtime_error("SvmClassifier: Invalid classifier file");
+        coefficients[(size_t)index] = alpha;
+    }
+    next();   // "Support vectors: "
+    vector<Mat> supportVectors;
+    supportVectors.reserve((size_t)svCount);
+    for (int i = 0; i < svCount; ++i) {
+        Mat vec(1, dimensionCount, CV_32FC1);
+        next();
+        std::istringstream lineStream(line);
+        float* values = vec.ptr<float>(0);
+        for (int j = 0; j < dimensionCount; ++j)
+            if (!(lineStream >> values[j])) throw std::runtime_error("SvmClassifier: Invalid classifier file");
+        supportVectors.push_back(vec);
+    }
+    svm->setSvmParameters(supportVectors, coefficients, (double)bias);
+    return svm;
+}
+
+// ProbabilisticSvmClassifier.cpp:80-104.  Non-.mat files are text models: the reference's own text format (loadFromText:
+// polynomial SVMs, first token "FullPolynomial") -- or, as the stand-in for the Matlab models the reference loads through libmat
+// (RBF / HIK SVMs on u8 patches exist upstream only as .mat files), the stream format of SvmClassifier::store (first token
+// "Kernel"; see DESIGN.md section "model formats").
 shared_ptr<ProbabilisticSvmClassifier> ProbabilisticSvmClassifier::load(const boost::property_tree::ptree& subtree) {
     string classifierFile = subtree.get<string>("classifierFile");
     if (classifierFile.size() > 4 && classifierFile.substr(classifierFile.size() - 4) == ".mat")
-        throw std::runtime_error("ProbabilisticSvmClassifier: Cannot load a Matlab classifier (the reference needs libmat; this backend reads the text format of SvmClassifier::store)");
-    std::ifstream f(classifierFile.c_str());
-    if (!f.is_open()) throw std::runtime_error("SvmClassifier: Invalid classifier file");
-    auto psvm = load(f);
+        throw std::runtime_error("ProbabilisticSvmClassifier: Cannot load a Matlab classifier (the reference needs libmat; this backend reads text models)");
+    shared_ptr<ProbabilisticSvmClassifier> psvm;
+    {
+        std::ifstream probe(classifierFile.c_str());
+        if (!probe.is_open()) throw std::runtime_error("SvmClassifier: Invalid classifier file");
+        string first;
+        probe >> first;
+        if (first == "Kernel") {
+            std::ifstream f(classifierFile.c_str());
+            psvm = load(f);
+        } else {
+            psvm = make_shared<ProbabilisticSvmClassifier>(SvmClassifier::loadFromText(classifierFile));
+        }
+    }
     double la = subtree.get("logisticA", 0.0), lb = subtree.get("logisticB", 0.0);
     if (la != 0.0 && lb != 0.0) psvm->setLogisticParameters(la, lb);
     psvm->getSvm()->setThreshold(subtree.get("threshold", 0.0f));
@@ -885,6 +1142,12 @@ SlidingWindowDetector::SlidingWindowDetector(shared_ptr<classification::Probabil
 vector<shared_ptr<ClassifiedPatch>> SlidingWindowDetector::detect(const cv::Rect* roi) const {
     vector<shared_ptr<ClassifiedPatch>> out;
     auto direct = std::dynamic_pointer_cast<DirectPyramidFeatureExtractor>(featureExtractor);
+    if (auto filtering = std::dynamic_pointer_cast<imageprocessing::FilteringPyramidFeatureExtractor>(featureExtractor))
+        direct = filtering->getFusedExtractor();   // ffpDetectApp.cpp:445: same pyramid, the chain as patch filters; null = generic composition
+    // the region of interest (SlidingWindowDetector.cpp:53-78) and the scale range of a pyramid built on another pyramid
+    // apply to the window enumeration of every fused chain
+    std::unique_ptr<imageprocessing::ImagePyramid::Selection> selection;
+    if (direct) selection.reset(new imageprocessing::ImagePyramid::Selection(direct->getPyramid()->select(-1, -1, 1, roi)));
     auto pwvm = std::dynamic_pointer_cast<ProbabilisticWvmClassifier>(classifier);
     auto psvm = std::dynamic_pointer_cast<ProbabilisticSvmClassifier>(classifier);
     int r[4] = {0, 0, 0, 0};
@@ -903,7 +1166,7 @@ vector<shared_ptr<ClassifiedPatch>> SlidingWindowDetector::detect(const cv::Rect
         return out;
     }
     const bool f32sv = psvm && !psvm->getSvm()->getSupportVectors().empty() && psvm->getSvm()->getSupportVectors()[0].depth() == CV_32F;
-    if (direct && psvm && direct->getHogFilter() && !roi && f32sv &&
+    if (direct && psvm && direct->getHogFilter() && f32sv &&
         std::dynamic_pointer_cast<classification::RbfKernel>(psvm->getSvm()->getKernel())) {   // fused HOG + MFMA RBF-SVM
         auto hog = direct->getHogFilter();
         fd_hog_params hp = {direct->getPatchWidth(), direct->getPatchHeight(), stepSizeX, stepSizeY, hog->binCount, hog->cellWidth, hog->blockWidth,
@@ -936,7 +1199,7 @@ vector<shared_ptr<ClassifiedPatch>> SlidingWindowDetector::detect(const cv::Rect
         for (int64_t i = 0; i < cnt; ++i) out.push_back(to_patch(dets[i]));
         return out;
     }
-    if (direct && psvm && direct->getWhiChain() && !roi && f32sv) {   // fused whi chain + SVM (ffpDetectApp.cpp:449-454, "psvm")
+    if (direct && psvm && direct->getWhiChain() && f32sv) {   // fused whi chain + SVM (ffpDetectApp.cpp:449-454, "psvm")
         auto wf = direct->getWhiChain();
         fd_whi_params wp = {direct->getPatchWidth(), direct->getPatchHeight(), stepSizeX, stepSizeY, wf->alpha, wf->cutoffFrequency};
         const fd_svm* s = psvm->getSvm()->native(psvm->getLogisticA(), psvm->getLogisticB());
@@ -951,7 +1214,7 @@ vector<shared_ptr<ClassifiedPatch>> SlidingWindowDetector::detect(const cv::Rect
         for (int64_t i = 0; i < cnt; ++i) out.push_back(to_patch(dets[i]));
         return out;
     }
-    if (direct && psvm && direct->getHistogramFilter() && !roi && f32sv) {   // fused histogram features + SVM (any kernel)
+    if (direct && psvm && direct->getHistogramFilter() && f32sv) {   // fused histogram features + SVM (any kernel)
         fd_hist_params hp = hist_params_of(*direct->getHistogramFilter(), direct->getPatchWidth(), direct->getPatchHeight(), stepSizeX, stepSizeY);
         const fd_svm* s = psvm->getSvm()->native(psvm->getLogisticA(), psvm->getLogisticB());
         int64_t cnt = 0, cap = 1 << 16;
@@ -966,6 +1229,7 @@ vector<shared_ptr<ClassifiedPatch>> SlidingWindowDetector::detect(const cv::Rect
         return out;
     }
     // generic composition (SlidingWindowDetector.cpp:87-98): extract all, classify each through the per-Mat interface
+    selection.reset();
     auto patches = roi ? featureExtractor->extract(stepSizeX, stepSizeY, *roi) : featureExtractor->extract(stepSizeX, stepSizeY);
     for (auto& p : patches) {
         auto res = classifier->getProbability(p->getData());
@@ -992,12 +1256,15 @@ FiveStageSlidingWindowDetector::FiveStageSlidingWindowDetector(shared_ptr<Slidin
 
 vector<shared_ptr<ClassifiedPatch>> FiveStageSlidingWindowDetector::run(const Mat& image, const cv::Rect* roi) {
     auto direct = std::dynamic_pointer_cast<DirectPyramidFeatureExtractor>(slidingWindowDetector->getPyramidFeatureExtractor());
+    if (auto filtering = std::dynamic_pointer_cast<imageprocessing::FilteringPyramidFeatureExtractor>(slidingWindowDetector->getPyramidFeatureExtractor()))
+        direct = filtering->getFusedExtractor();
     auto pwvm = std::dynamic_pointer_cast<ProbabilisticWvmClassifier>(slidingWindowDetector->getClassifier());
     auto psvm = std::dynamic_pointer_cast<ProbabilisticSvmClassifier>(strongClassifier);
     if (!direct || !pwvm || !psvm || !direct->hasHistEq64())
         throw std::logic_error("FiveStageSlidingWindowDetector: this backend needs DirectPyramidFeatureExtractor + HistEq64Filter, a "
                                "ProbabilisticWvmClassifier first stage and a ProbabilisticSvmClassifier second stage (ffpDetectApp.cpp:398-419)");
     direct->update(image);
+    auto selection = direct->getPyramid()->select();   // the scale range of a pyramid built on another pyramid
     int r[4] = {0, 0, 0, 0};
     if (roi) { r[0] = roi->x; r[1] = roi->y; r[2] = roi->width; r[3] = roi->height; }
     int cnt = 0, cap = 4096;

@@ -65,6 +65,13 @@ int fd_pyramid_layer_count(const fd_pyramid* p);
 int fd_pyramid_layer_info(const fd_pyramid* p, int i, int* index, double* scale, int* width, int* height, int* channels);
 /* copy the (filtered) layer i to host: width*height*channels bytes */
 int fd_pyramid_layer_download(fd_pyramid* p, int i, uint8_t* host_dst);
+/* Layer sub-range and default region of interest of every window enumeration that follows on this pyramid -- the firstLayer /
+ * lastLayer / stepLayer / roi arguments of DirectPyramidFeatureExtractor::extract(stepX, stepY, roi, firstLayer, lastLayer,
+ * stepLayer) (:75-123), for every extraction / detection entry point (also those without a roi argument), and the layer range of
+ * an ImagePyramid built on another pyramid (ImagePyramid.cpp:100-104,200-235: same layers, scale factors within [min, max]).
+ * first_layer / last_layer: pyramid layer indices, -1 = open; step_layer >= 1 counts over the kept layers from the first one;
+ * roi: {x, y, w, h} or NULL (none; an explicit roi argument of a call takes precedence).  Reset with (-1, -1, 1, NULL). */
+int fd_pyramid_select(fd_pyramid* p, int first_layer, int last_layer, int step_layer, const int* roi);
 /* Window enumeration of DirectPyramidFeatureExtractor::extract(stepX, stepY, roi) (:75-123).
  * roi = {x,y,w,h} or NULL (whole image).  rows of out: {layerPos, lx, ly, cx, cy, ow, oh}. */
 int fd_pyramid_window_count(const fd_pyramid* p, int patch_w, int patch_h, int step_x, int step_y,
@@ -76,6 +83,17 @@ int fd_pyramid_windows(const fd_pyramid* p, int patch_w, int patch_h, int step_x
 int fd_greyworld(fd_ctx* ctx, const uint8_t* bgr, int width, int height, uint8_t* dst, int is_device);
 /* HistEq64Filter::applyTo (HistEq64Filter.cpp:32-125) on n contiguous patches of w*h bytes (host buffers) */
 int fd_histeq64_batch(fd_ctx* ctx, const uint8_t* patches, int64_t n, int w, int h, uint8_t* dst);
+
+/* Stand-alone ImageFilter::applyTo(const Mat&) forms (ImageFilter.hpp:18-57) of the filters the detection kernels fuse into the
+ * pyramid / feature kernels; host buffers in, host buffers out.
+ *  fd_gradient_image          GradientFilter(grad_kernel 1|3, no blur) (GradientFilter.cpp:38-59): CV_8UC1 -> CV_8UC2 (x, y)
+ *  fd_gradient_binning_image  GradientBinningFilter(bins, signed, interpolate) (GradientBinningFilter.cpp:62-93): CV_8UC2 -> CV_8UC2
+ *                             (bin, weight) or CV_8UC4 (two bins + weights)
+ *  fd_lbp_image               LbpFilter(type) (LbpFilter.cpp:56-85): CV_8UC1 -> CV_8UC1 codes */
+int fd_gradient_image(fd_ctx* ctx, const uint8_t* gray, int width, int height, int grad_kernel, uint8_t* dst2ch);
+int fd_gradient_binning_image(fd_ctx* ctx, const uint8_t* grad2ch, int width, int height, int bins, int signed_gradients,
+                              int interpolate, uint8_t* dst);
+int fd_lbp_image(fd_ctx* ctx, const uint8_t* gray, int width, int height, int lbp_type, uint8_t* dst);
 
 /* ---- classification::WvmClassifier / ProbabilisticWvmClassifier --------------------------------
  * Field meaning as in WvmClassifier.hpp / the Matlab loader WvmClassifier.cpp:352-769 (values already
@@ -289,6 +307,10 @@ int fd_hist_feature_length(const fd_hist_params* hp, int channels);
  * features == NULL: only *count is set. */
 int fd_extract_hist(fd_ctx* ctx, fd_pyramid* p, const fd_hist_params* hp, float* features, int64_t cap_windows,
                     int64_t* count);
+/* HistogramFilter::applyTo(const Mat&) of the same four patch filters on n contiguous bin-image patches (hp->patch_w x hp->patch_h
+ * pixels, `channels` bytes per pixel: 1 bin, 2 bin + weight, 4 two bins + weights; hp->step_x / step_y are ignored).
+ * out: n x fd_hist_feature_length(hp, channels) floats. */
+int fd_hist_patch_batch(fd_ctx* ctx, const uint8_t* bin_patches, int64_t n, int channels, const fd_hist_params* hp, float* out);
 /* SlidingWindowDetector::detect with the histogram patch filter + ProbabilisticSvmClassifier on the f32
  * vectors (any kernel; wiring of BenchmarkRunner.cpp:185-263) */
 int fd_detect_hist_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_hist_params* hp, fd_detection* out,
@@ -305,6 +327,14 @@ typedef struct {
 int fd_whi_batch(fd_ctx* ctx, const uint8_t* patches, int64_t n, int w, int h, float alpha, float cutoff, float* dst);
 /* HistogramEqualizationFilter::applyTo ("histeq" feature space, ffpDetectApp.cpp:446-448) on n patches */
 int fd_equalize_hist_batch(fd_ctx* ctx, const uint8_t* patches, int64_t n, int w, int h, uint8_t* dst);
+/* the single filters of that chain on n contiguous host patches / vectors (their per-Mat ImageFilter::applyTo):
+ *  fd_whitening_batch  WhiteningFilter(alpha, cutoff) alone (WhiteningFilter.cpp:20-58): u8 -> u8 (convertTo(CV_8U, 1, 127))
+ *  fd_convert_batch    ConversionFilter(type, alpha, beta) (cv::Mat::convertTo): src/dst dtype FD_DTYPE_U8 | FD_DTYPE_F32, `count` values
+ *  fd_unit_norm_batch  UnitNormFilter(normType) (UnitNormFilter.cpp:24-43): n vectors of `len` floats, norm_type = cv::NORM_INF 1,
+ *                      NORM_L1 2, NORM_L2 4 */
+int fd_whitening_batch(fd_ctx* ctx, const uint8_t* patches, int64_t n, int w, int h, float alpha, float cutoff, uint8_t* dst);
+int fd_convert_batch(fd_ctx* ctx, const void* src, int src_dtype, int64_t count, double alpha, double beta, void* dst, int dst_dtype);
+int fd_unit_norm_batch(fd_ctx* ctx, const float* src, int64_t n, int len, int norm_type, float* dst);
 /* every window of the pyramid: n_windows x (patch_w*patch_h) floats to host; features == NULL: count only */
 int fd_extract_whi(fd_ctx* ctx, fd_pyramid* p, const fd_whi_params* wp, float* features, int64_t cap_windows, int64_t* count);
 /* SlidingWindowDetector::detect with the whi feature space + ProbabilisticSvmClassifier (any kernel, f32 vectors) */

@@ -21,6 +21,7 @@ void orc_greyworld(const uint8_t* bgr, int w, int h, uint8_t* dst);             
 void orc_equalize_hist(const uint8_t* src, int w, int h, int stride, uint8_t* dst);  /* HistogramEqualizationFilter.cpp (cv::equalizeHist) */
 void orc_histeq64(const uint8_t* src, int w, int h, int stride, uint8_t* dst);       /* HistEq64Filter.cpp:32-125 */
 void orc_whi(const uint8_t* src, int w, int h, int stride, float alpha, float cutoff, float* dst); /* ffpDetectApp.cpp:449-454 chain */
+void orc_whitening(const uint8_t* src, int w, int h, int stride, float alpha, float cutoff, uint8_t* dst); /* WhiteningFilter.cpp:20-58 alone */
 
 /* ---------------- histogram features ---------------- */
 /* HogFilter.cpp:58-122 on a bin image patch (ch = 1, 2 or 4).  Returns feature length. */

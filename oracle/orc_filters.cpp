@@ -184,7 +184,7 @@ void whi_tables(int w, int h, float alpha, float cutoff, std::vector<double>& tw
         }
 }
 
-static void whi(const uchar* src, int w, int h, int stride, float alpha, float cutoff, float* dst) {
+static void whi(const uchar* src, int w, int h, int stride, float alpha, float cutoff, float* dst, uchar* whitened = nullptr) {
     const int n = w * h;
     std::vector<double> twRow, twCol;
     std::vector<float> filt;
@@ -245,6 +245,10 @@ static void whi(const uchar* src, int w, int h, int stride, float alpha, float c
             const float val = (float)sr;
             u8[(size_t)y * w + x] = sat_u8((double)(val * 1.0f + 127.0f));
         }
+    if (whitened) {   // WhiteningFilter::applyTo alone (WhiteningFilter.cpp:20-58)
+        std::copy(u8.begin(), u8.end(), whitened);
+        return;
+    }
     equalize_hist(u8.data(), w, h, w, eq.data());
     const float a = (float)(1.0 / 127.5), b = -1.0f;
     double norm2 = 0;
@@ -697,6 +701,7 @@ void orc_gradient_binning(const uint8_t* g, int n, int bins, int sg, int interp,
 void orc_lbp(const uint8_t* s, int w, int h, int type, uint8_t* d) { lbp(s, w, h, type, d); }
 void orc_greyworld(const uint8_t* s, int w, int h, uint8_t* d) { greyworld(s, w, h, d); }
 void orc_whi(const uint8_t* s, int w, int h, int stride, float alpha, float cutoff, float* d) { whi(s, w, h, stride, alpha, cutoff, d); }
+void orc_whitening(const uint8_t* s, int w, int h, int stride, float alpha, float cutoff, uint8_t* d) { whi(s, w, h, stride, alpha, cutoff, nullptr, d); }
 int orc_hog_filter(const uint8_t* img, int w, int h, int ch, int stride, int bins, int cw, int chh, int bw, int bh,
                    int interp, int sau, float* out) {
     std::vector<float> v;

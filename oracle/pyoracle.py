@@ -90,6 +90,10 @@ def lib():
         l.orc_sdm_optimize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         l.orc_equalize_hist.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         l.orc_whi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
+        l.orc_whitening.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
+        l.orc_gradient_filter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        l.orc_gradient_binning.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        l.orc_lbp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         l.orc_phase_timing.argtypes = [C.c_int]
         l.orc_phase_get.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib = l
@@ -177,6 +181,37 @@ def whi(patch, alpha=1.0, cutoff=0.390625):
     patch = _c(patch, np.uint8)
     out = np.empty(patch.shape, np.float32)
     lib().orc_whi(_p(patch), patch.shape[1], patch.shape[0], patch.shape[1], alpha, cutoff, _p(out))
+    return out
+
+
+def whitening(patch, alpha=1.0, cutoff=0.390625):
+    """WhiteningFilter::applyTo alone: u8 -> u8"""
+    p = _c(patch, np.uint8)
+    out = np.empty(p.shape, np.uint8)
+    lib().orc_whitening(_p(p), p.shape[1], p.shape[0], p.shape[1], alpha, cutoff, _p(out))
+    return out
+
+
+def gradient_filter(gray, ksize=1):
+    """GradientFilter::applyTo: CV_8UC1 -> CV_8UC2"""
+    g = _c(gray, np.uint8)
+    out = np.empty(g.shape + (2,), np.uint8)
+    lib().orc_gradient_filter(_p(g), g.shape[1], g.shape[0], ksize, 0, _p(out))
+    return out
+
+
+def gradient_binning(grad2ch, bins, signed_gradients=False, interpolate=False):
+    """GradientBinningFilter::applyTo: CV_8UC2 -> CV_8UC2 / CV_8UC4"""
+    g = _c(grad2ch, np.uint8)
+    out = np.empty(g.shape[:2] + (4 if interpolate else 2,), np.uint8)
+    lib().orc_gradient_binning(_p(g), g.shape[0] * g.shape[1], bins, int(signed_gradients), int(interpolate), _p(out))
+    return out
+
+
+def lbp(gray, lbp_type=0):
+    g = _c(gray, np.uint8)
+    out = np.empty(g.shape, np.uint8)
+    lib().orc_lbp(_p(g), g.shape[1], g.shape[0], lbp_type, _p(out))
     return out
 
 

@@ -281,3 +281,143 @@ def test_condensation_eval_app_matches_oracle(tmp_path, oracle, synth, frame640,
     assert len(got) == len(samples)
     assert np.array_equal(got[:, 0].astype(bool), to) and (wt > 0).sum() > 20
     assert np.allclose(got[:, 1], wt, rtol=1e-12, atol=0)
+
+
+def test_host_selftest_app(tmp_path, oracle, capi, ctx, synth, frame640):
+    """Pyramid-on-pyramid views, layer sub-ranges + ROI on a fused chain, FilteringPyramidFeatureExtractor and the stand-alone
+    applyTo of every filter, through the reference-shaped C++ classes (host_selftest_app) against the oracle."""
+    app = os.path.join(PKG, "host_selftest_app")
+    if not os.path.exists(app):
+        pytest.fail("host apps not built (make -C featuredetection_amd/host)")
+    gray = oracle.bgr2gray(frame640)[:300, :400].copy()
+    synth.save_pnm(str(tmp_path / "g.pgm"), gray)
+    out = _run([app, str(tmp_path / "g.pgm"), str(tmp_path)])
+    kv = {l.split()[0] + ("_" + l.split()[1] if l.split()[0] == "view" else ""): l.split() for l in out.strip().splitlines()}
+    lines = out.strip().splitlines()
+    # 1. fifteen extractors on views of one source pyramid: built once per image version
+    assert "builds 1" in lines and "builds_after_new_version 2" in lines, out
+    po = oracle.Pyramid(inc=0.9, min_scale=0.09, max_scale=0.7)
+    po.update(gray)
+    assert "source_layers %d" % len(po.layers()) in lines
+    for i, (lo, hi, pw) in enumerate(((0.09, 0.25, 20), (0.5, 0.7, 24), (0.3, 0.45, 20))):
+        sel = [k for k, l in enumerate(po.layers()) if lo <= l["scale"] <= hi]
+        assert "view %d layers %d first %d last %d" % (i, len(sel), po.layers()[sel[0]]["index"], po.layers()[sel[-1]]["index"]) in lines
+        wins = po.windows(pw, pw, 4, 4)
+        wins = wins[np.isin(wins[:, 0], sel)]
+        geo = np.fromfile(str(tmp_path / ("view%d_geo.bin" % i)), np.int32).reshape(-1, 4)
+        assert np.array_equal(geo, wins[:, 3:7]), i
+    # 2. layer sub-range (first, last, step 2) + ROI on the HOG chain: geometry and features
+    ph = oracle.Pyramid(octave_layers=3, min_scale=0.2, max_scale=0.8)
+    ph.set_layer_filter(1, bins=9)
+    ph.update(gray)
+    L = ph.layers()
+    first, last = L[1]["index"], L[-2]["index"]
+    sel = [k for k, l in enumerate(L) if k % 2 == 0 and first <= l["index"] <= last]
+    wins = ph.windows(20, 20, 3, 3, (40, 30, 200, 160))
+    wins = wins[np.isin(wins[:, 0], sel)]
+    assert len(wins) > 20
+    geo = np.fromfile(str(tmp_path / "hog_sub_geo.bin"), np.int32).reshape(-1, 4)
+    assert np.array_equal(geo, wins[:, 3:7])
+    feat = np.fromfile(str(tmp_path / "hog_sub_feat.bin"), np.float32).reshape(len(wins), -1)
+    layers = [ph.layer(k) for k in range(len(L))]
+    exp = np.stack([oracle.hog_filter(np.ascontiguousarray(layers[w[0]][w[2]:w[2] + 20, w[1]:w[1] + 20]), 9, 5, 2) for w in wins])
+    assert np.array_equal(feat, exp)
+    # 3. FilteringPyramidFeatureExtractor: the whi chain is fused and equals the per-Mat composition; an unfused chain composes per Mat
+    fl = [l for l in lines if l.startswith("filtering")][0].split()
+    assert fl[2] == "1" and int(fl[4]) > 0 and fl[-1] == "0" and int(fl[6]) > 0, fl
+    gl = [l for l in lines if l.startswith("generic")][0].split()
+    assert gl[2] == "0" and int(gl[4]) > 0
+    raw0 = np.fromfile(str(tmp_path / "raw_patch0.bin"), np.uint8).reshape(20, 20)
+    assert np.array_equal(np.fromfile(str(tmp_path / "generic_lbp_patch0.bin"), np.uint8).reshape(20, 20), oracle.lbp(raw0, 0))
+    # 4. stand-alone applyTo of every filter
+    crop = np.fromfile(str(tmp_path / "crop.bin"), np.uint8).reshape(48, 64)
+    assert np.array_equal(crop, gray[24:72, 16:80])
+    grad = oracle.gradient_filter(crop, 3)
+    assert np.array_equal(np.fromfile(str(tmp_path / "grad.bin"), np.uint8).reshape(48, 64, 2), grad)
+    bins = oracle.gradient_binning(grad, 9, False, True)
+    assert np.array_equal(np.fromfile(str(tmp_path / "bins.bin"), np.uint8).reshape(48, 64, 4), bins)
+    assert np.array_equal(np.fromfile(str(tmp_path / "lbp.bin"), np.uint8).reshape(48, 64), oracle.lbp(crop, 1))
+    p20 = np.ascontiguousarray(bins[4:24, 4:24])
+    f32 = lambda name: np.fromfile(str(tmp_path / name), np.float32)
+    assert np.array_equal(f32("hog.bin"), np.asarray(oracle.hog_filter(p20, 9, 5, 2, interpolate=True), np.float32).ravel())
+    assert np.array_equal(f32("sphist.bin"), np.asarray(oracle.spatial_histogram(p20, 9, 5, 2, interpolate=True, normalization=2), np.float32).ravel())
+    assert np.array_equal(f32("phog.bin"), np.asarray(oracle.pyramid_hog(p20, 9, 2, interpolate=True), np.float32).ravel())
+    assert np.array_equal(f32("sppyr.bin"), np.asarray(oracle.spatial_pyramid_histogram(p20, 9, 2, interpolate=True, normalization=3), np.float32).ravel())
+    g20 = np.ascontiguousarray(crop[10:30, 10:30])
+    assert np.array_equal(np.fromfile(str(tmp_path / "whitened.bin"), np.uint8).reshape(20, 20), oracle.whitening(g20))
+    assert np.array_equal(f32("converted.bin"), (g20.astype(np.float32) * np.float32(1.0 / 255.0) + np.float32(0.0)).ravel())
+    v = g20.astype(np.float32).ravel()
+    inv = np.float32(1.0 / (np.sqrt((v.astype(np.float64) ** 2).sum()) + np.float64(np.float32(1e-4))))
+    assert np.array_equal(f32("unitnorm.bin"), v * inv)
+    assert "reshaped 1 x 400" in lines
+
+
+def test_svm_text_format_fixture(tmp_path, capi, ctx):
+    """SvmClassifier::loadFromText (SvmClassifier.cpp:161-239) on a fixture written by hand in the reference's format (out-of-order
+    alphas, FullPolynomial degree 2): the app's single psvm detector loads it through ProbabilisticSvmClassifier::load(ptree); its
+    decision values are checked through the C ABI against the closed form (scale * <x, s> + constant)^degree."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    txt = open(os.path.join(here, "golden", "svm_fullpolynomial.txt")).read().splitlines()
+    assert txt[0].split() == ["FullPolynomial", "2", "1.5", "0.25"]
+    sv = np.array([[float(v) for v in l.split()] for l in txt[8:11]], np.float32)
+    coeff = np.zeros(3, np.float32)
+    for l in txt[4:7]:
+        i, a = l[len("alphas["):].split("]=")
+        coeff[int(i)] = np.float32(a)
+    m = dict(kernel=1, p0=0.25, p1=1.5, p2=2.0, dtype=1, sv=sv, coeff=coeff, bias=np.float32(0.125), threshold=0.0, logistic_a=0.00556, logistic_b=-2.95)
+    x = np.array([[0.5, -1.0, 2.0, 0.25], [3.0, 1.0, 0.0, -2.0]], np.float32)
+    d = capi.Svm(ctx, m).distance(x)
+    exp = ((0.25 * (x.astype(np.float64) @ sv.astype(np.float64).T) + 1.5) ** 2) @ coeff.astype(np.float64) - 0.125
+    assert np.allclose(d, exp, rtol=1e-6)
+    # through the host layer: a "single" psvm detector on gray 2x2 patches reads the same file with the reference's loader
+    app = os.path.join(PKG, "ffp_detect_app")
+    img = np.zeros((40, 40), np.uint8)
+    img[10:30, 10:30] = 200
+    from featuredetection_amd import synth
+    synth.save_pnm(str(tmp_path / "i.pgm"), img)
+    cfg = """detectors
+{
+    Blob
+    {
+        landmark "face"
+        type single
+        feature gray
+        patchFilter
+        {
+            reshapingFilter 1
+            conversionFilter "5 0.00392156862745098"
+        }
+        classifier psvm
+        {
+            classifierFile %s
+            threshold 0.0
+        }
+        pyramid
+        {
+            minScaleFactor 0.5
+            maxScaleFactor 1.0
+            incrementalScaleFactor 0.5
+            patch
+            {
+                width 2
+                height 2
+            }
+        }
+    }
+}
+""" % os.path.join(here, "golden", "svm_fullpolynomial.txt")
+    (tmp_path / "c.cfg").write_text(cfg)
+    out = _run([app, str(tmp_path / "c.cfg"), str(tmp_path / "i.pgm")])
+    got = sorted(tuple(int(v) for v in l.split()[2:6]) for l in out.strip().splitlines())
+    # expected: every 2x2 window (step 1) of the oracle's pyramid, gray / 255 features, closed-form decision value >= 0
+    from oracle import pyoracle as O
+    po = O.Pyramid(inc=0.5, min_scale=0.5, max_scale=1.0)
+    po.update(img)
+    layers = [po.layer(k) for k in range(len(po.layers()))]
+    exp_boxes = []
+    for w in po.windows(2, 2, 1, 1):
+        f = layers[w[0]][w[2]:w[2] + 2, w[1]:w[1] + 2].astype(np.float32).ravel() * np.float32(0.00392156862745098)
+        dv = ((0.25 * (f.astype(np.float64) @ sv.astype(np.float64).T) + 1.5) ** 2) @ coeff.astype(np.float64) - 0.125
+        if dv >= 0.0:
+            exp_boxes.append((int(w[3] - w[5] // 2), int(w[4] - w[6] // 2), int(w[5]), int(w[6])))
+    assert len(exp_boxes) > 0 and got == sorted(exp_boxes)
