@@ -63,7 +63,9 @@ def pmc_record(workload, kernel_substr):
     tools/pmc_summary.py from runs of this script; every entry names the command and the git head it was measured at)."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
-        for k, v in rec.get(workload, {}).get("kernels", {}).items():
+        ks = rec.get(workload, {}).get("kernels", {})
+        agg = "k_all(%s)" % kernel_substr
+        for k, v in ([(agg, ks[agg])] if agg in ks else []) + list(ks.items()):
             if kernel_substr in k:
                 out = dict(v)
                 out["kernel"] = k
@@ -72,6 +74,19 @@ def pmc_record(workload, kernel_substr):
     except Exception:
         pass
     return None
+
+
+def issue_roofline(pm):
+    """VALU-issue roofline of the cascade / descriptor kernels (they are bound by instruction issue, not by HBM): fraction of the
+    wave64 VALU issue slots (one per 4 cycles per SIMD16, 1024 SIMDs) used while the kernels ran, from the committed counter passes
+    (SQ_INSTS_VALU, GRBM_GUI_ACTIVE; tools/pmc_summary.py) -- counters cannot be read inside a plain run."""
+    f = float(pm["valu_issue_frac"])
+    out = dict(bound="valu-issue", achieved=f * PEAK_VALU_GINST, peak=PEAK_VALU_GINST, unit="G wave-instr/s", frac=f, kernel=pm.get("kernel"),
+               source=pm.get("source"), formula="4 cycles x SQ_INSTS_VALU / (128 SIMDs x GRBM_GUI_ACTIVE summed over the 8 XCDs)")
+    for k in ("wave_time_valu", "wave_time_lds", "wave_time_waitcnt", "wave_time_issue_stall", "clock_ghz", "hbm_bytes"):
+        if k in pm:
+            out[k] = pm[k]
+    return out
 
 
 def run_threads(fn, n):
@@ -202,11 +217,8 @@ class Cascade(Workload):
                     frac=ach / PEAK_HBM_GBS, traffic=pm.get("hbm_bytes") if pm else None, kernel_ms=kms,
                     algorithmic="%d layer bytes + 16 B record x %d windows per frame (SURVEY 8(d))" % (self.layer_bytes, self.nwin))
         extra = {}
-        if pm and pm.get("valu_insts"):
-            ai = pm["valu_insts"] / (kms * 1e-3) / 1e9
-            extra["roofline_issue"] = dict(bound="valu-issue", achieved=ai, peak=PEAK_VALU_GINST, unit="G wave-instr/s", frac=ai / PEAK_VALU_GINST,
-                                           valu_insts_per_frame=pm["valu_insts"], source=pm.get("source"),
-                                           note="SQ_INSTS_VALU per frame (rocprofv3 --pmc) / live kernel time; peak = 1024 SIMD x 2.4 GHz / 4 cycles")
+        if pm and pm.get("valu_issue_frac"):
+            extra["roofline_issue"] = issue_roofline(pm)
         return roof, extra
 
     def cpu_baseline(self):
@@ -436,10 +448,8 @@ class Ffp15(Workload):
                     frac=ach / PEAK_HBM_GBS, traffic=None, kernel_ms=kms,
                     algorithmic="%d layer bytes + 16 B record x %d windows" % (layer_bytes, nwin))
         extra = {}
-        if pm and pm.get("valu_insts") and pm.get("kernel_ms"):
-            ai = pm["valu_insts"] / (pm["kernel_ms"] * 1e-3) / 1e9
-            extra["roofline_issue"] = dict(bound="valu-issue", achieved=ai, peak=PEAK_VALU_GINST, unit="G wave-instr/s", frac=ai / PEAK_VALU_GINST,
-                                           source=pm.get("source"), note="all k_wvm_* launches of one frame: SQ_INSTS_VALU / summed kernel time (profile)")
+        if pm and pm.get("valu_issue_frac"):
+            extra["roofline_issue"] = issue_roofline(pm)
         return roof, extra
 
     def cpu_baseline(self):
@@ -524,10 +534,8 @@ class Sdm(Workload):
                     traffic=pm.get("hbm_bytes") if pm else None, kernel_ms=kms,
                     algorithmic="(46x46 B crop + 279 f32) x %d (face, landmark) items per launch" % items)
         extra = {}
-        if pm and pm.get("valu_insts"):
-            ai = pm["valu_insts"] / (kms * 1e-3) / 1e9
-            extra["roofline_issue"] = dict(bound="valu-issue", achieved=ai, peak=PEAK_VALU_GINST, unit="G wave-instr/s", frac=ai / PEAK_VALU_GINST,
-                                           source=pm.get("source"))
+        if pm and pm.get("valu_issue_frac"):
+            extra["roofline_issue"] = issue_roofline(pm)
         return roof, extra
 
     def cpu_baseline(self):

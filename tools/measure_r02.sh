@@ -31,7 +31,7 @@ if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
       i=$((i+1))
       timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc_${wl}_$i -- $CMD > /dev/null 2> $O/pmc_${wl}_$i.err
     done
-    K=k_wvm; [ $wl = sdm ] && K=k_sdm; [ $wl = hog_svm ] && K=k_svm_rbf_mfma
+    K=k_wvm; [ $wl = sdm ] && K=k_sdm_descriptors; [ $wl = hog_svm ] && K=k_svm_rbf_mfma
     python $R/tools/pmc_summary.py $wl $O/r02_pmc.json $K "rocprofv3 --kernel-trace --pmc <group> (4 separate passes) -- python bench.py --workload $wl --also none --steps $S --warmup 1 $FP --no-cpu-baseline; git head $HEAD" $O/pmc_${wl}_1 $O/pmc_${wl}_2 $O/pmc_${wl}_3 $O/pmc_${wl}_4 > $O/pmc_$wl.summary 2>&1
   done
 fi

@@ -72,6 +72,26 @@ for o in kernels.values():
         if key != "launches":
             agg[key] = agg.get(key, 0.0) + v
 agg["kernel_ms"] = agg.pop("kernel_ms_profiled", None)
+# time-weighted totals over ALL launches of the matched kernels (counter passes serialise the dispatches): the fraction of the
+# VALU issue slots that were used while these kernels ran = 4 cycles x SQ_INSTS_VALU / (128 SIMDs per XCD x GRBM_GUI_ACTIVE summed
+# over the 8 XCDs), and the same for LDS instructions per cycle
+tot, cnt = {}, {}
+for cs in acc.values():
+    for c, (sv, n) in cs.items():
+        tot[c] = tot.get(c, 0.0) + sv
+        cnt[c] = cnt.get(c, 0) + n
+if tot.get("GRBM_GUI_ACTIVE"):
+    if "SQ_INSTS_VALU" in tot:
+        agg["valu_issue_frac"] = 4.0 * tot["SQ_INSTS_VALU"] / (128.0 * tot["GRBM_GUI_ACTIVE"])
+    if "SQ_INSTS_LDS" in tot:
+        agg["lds_insts_per_simd_cycle"] = tot["SQ_INSTS_LDS"] / (128.0 * tot["GRBM_GUI_ACTIVE"])
+    if "_dur_ns" in tot:   # durations come from every pass, the counter from one: compare per-launch averages
+        agg["clock_ghz"] = (tot["GRBM_GUI_ACTIVE"] / cnt["GRBM_GUI_ACTIVE"]) / 8.0 / (tot["_dur_ns"] / cnt["_dur_ns"])
+if tot.get("SQ_WAVE_CYCLES"):
+    for c, key in (("SQ_ACTIVE_INST_VALU", "wave_time_valu"), ("SQ_ACTIVE_INST_LDS", "wave_time_lds"), ("SQ_WAIT_ANY", "wave_time_waitcnt"),
+                   ("SQ_WAIT_INST_ANY", "wave_time_issue_stall"), ("SQ_ACTIVE_INST_ANY", "wave_time_active")):
+        if c in tot:
+            agg[key] = tot[c] / tot["SQ_WAVE_CYCLES"]
 try:
     allrec = json.load(open(out))
 except Exception:
