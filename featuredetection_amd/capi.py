@@ -28,7 +28,8 @@ class fd_wvm_model(C.Structure):
                 ("num_per_level", C.c_int32), ("basis_param", C.c_float), ("bias", C.c_float),
                 ("thresholds", C.POINTER(C.c_float)), ("hk_weights", C.POINTER(C.c_float)), ("pp", C.POINTER(C.c_double)),
                 ("val_off", C.POINTER(C.c_int32)), ("val", C.POINTER(C.c_double)), ("rec_off", C.POINTER(C.c_int32)),
-                ("rects", C.POINTER(C.c_uint8)), ("logistic_a", C.c_double), ("logistic_b", C.c_double)]
+                ("rects", C.POINTER(C.c_uint8)), ("logistic_a", C.c_double), ("logistic_b", C.c_double),
+                ("num_vals", C.c_int32), ("num_rects", C.c_int32)]
 
 
 class fd_svm_model(C.Structure):
@@ -354,6 +355,8 @@ def _wvm_struct(m, cls):
     s.rec_off = keep["rec_off"].ctypes.data_as(C.POINTER(C.c_int32))
     s.rects = keep["rects"].ctypes.data_as(C.POINTER(C.c_uint8))
     s.logistic_a, s.logistic_b = float(m["logistic_a"]), float(m["logistic_b"])
+    if hasattr(s, "num_vals"):   # fd_wvm_model: array lengths, so that the library can reject truncated models
+        s.num_vals, s.num_rects = len(keep["val"]), len(keep["rects"].reshape(-1, 4))
     return s, keep
 
 

@@ -190,9 +190,19 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         S.yrange[2 * c + 1] = hi;
     }
     wave_sync();
-    for (int64_t item = (int64_t)blockIdx.x * 2 + wave; item < nitems; item += (int64_t)gridDim.x * 2) {
-        const int64_t face = item / p.L;
-        const int lm = (int)(item - face * p.L);
+    // XCD-aware item order: workgroup b runs on XCD b % 8 (round-robin dispatch), and every XCD has its own 4 MB L2.  With the
+    // plain order every XCD touches every face image (256 x 64 KB = 16.8 MB: the crops stream through the L2s, 263 MB of fabric
+    // traffic per launch by the FETCH_SIZE counter); here XCD x only works on the faces f = x (mod 8), whose images stay resident.
+    const bool byXcd = (gridDim.x % 8 == 0) && (nitems % p.L == 0);
+    const int64_t nfaces = nitems / p.L;
+    const int xcd = blockIdx.x & 7;
+    const int64_t myFaces = byXcd ? (nfaces - xcd + 7) / 8 : 0;
+    const int64_t jEnd = byXcd ? myFaces * p.L : nitems;
+    const int64_t jStep = byXcd ? (int64_t)(gridDim.x / 8) * 2 : (int64_t)gridDim.x * 2;
+    for (int64_t j = byXcd ? (int64_t)(blockIdx.x / 8) * 2 + wave : (int64_t)blockIdx.x * 2 + wave; j < jEnd; j += jStep) {
+        const int64_t face = byXcd ? (j / p.L) * 8 + xcd : j / p.L;
+        const int lm = (int)(j % p.L);
+        const int64_t item = face * p.L + lm;
         const int32_t* org = origin + 4 * item;
         const int ox = org[0], oy = org[1], side = org[2], valid = org[3];
         float* dst = out + face * out_stride + (size_t)lm * p.len;
@@ -626,7 +636,8 @@ static void sdm_optimize(fd_ctx* ctx, fd_sdm* m, const uint8_t* gray_images, int
         const double stepFactor = 1 / (1 + std::exp((double)((step + 1) - m->S)));  // :226, double on the host
         hipLaunchKernelGGL(k_sdm_prepare, dim3((B * L + 255) / 256), dim3(256), 0, st, m->shapes.as<float>(), B, L, W, H, 1, 0, 1 << 20, stepFactor,
                            m->origin.as<int32_t>(), m->dist.as<float>(), m->status.as<int32_t>());
-        const int grid = (int)std::min<int64_t>((nitems + 1) / 2, (int64_t)ctx->num_cus * descriptor_blocks_per_cu(p));
+        int grid = (int)std::min<int64_t>((nitems + 1) / 2, (int64_t)ctx->num_cus * descriptor_blocks_per_cu(p));
+        if (grid >= 16) grid &= ~7;   // a multiple of the 8 XCDs: the kernel then keeps every face on one XCD
         const bool timeThis = ctx->kernel_timing && step + 1 == m->S;   // fd_hip_bench.h: the last step's descriptor launch
         if (timeThis) HIP_CHECK(hipEventRecord(ctx->ev0, st));
         launch_descriptors(dim3(grid), st, dimg, m->origin.as<int32_t>(), p, nitems, m->desc.as<float>(), (int64_t)F);

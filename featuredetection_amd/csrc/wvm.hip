@@ -1546,10 +1546,11 @@ static void wvm_launch_table(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm*
         m->all_level.reserve(sizeof(int32_t) * (size_t)wt.total);
         m->all_fout.reserve(sizeof(float) * (size_t)wt.total);
     }
-    if (m->pos_cap == 0) {
-        m->pos_cap = 1 << 18;
-        const char* e = getenv("FD_WVM_POS_CAP");
-        if (e && atoll(e) > 0) m->pos_cap = atoll(e);
+    {   // capacity of the positive buffers (records + 1 patch each): never more than the window count, 2^18 at most unless
+        // FD_WVM_POS_CAP says otherwise; grows with the largest run seen (a 640x480 FaceFrontal handle holds 6.5 MB, not 105 MB)
+        static const int64_t capEnv = [] { const char* e = getenv("FD_WVM_POS_CAP"); return e && atoll(e) > 0 ? (int64_t)atoll(e) : (int64_t)0; }();
+        const int64_t want = capEnv ? capEnv : std::min<int64_t>(wt.total, (int64_t)1 << 18);
+        if (want > m->pos_cap) { m->pos_cap = want; m->hdrClean = false; }
     }
     // pos buffer: record 0 is the header (positive counter), records 1.. are the positives, so that the
     // counter and the first records come back in a single read
@@ -1687,7 +1688,18 @@ int fd_wvm_create(fd_ctx* ctx, const fd_wvm_model* md, fd_wvm** out) {
         fd_wvm* m = new fd_wvm();
         std::unique_ptr<fd_wvm> guard(m);
         m->ctx = ctx;
+        // the offset tables index the caller's val / rects arrays: they must start at 0 and ascend, and stay inside the arrays
+        // when the caller states their lengths (num_vals / num_rects; 0 = not stated)
+        if (md->val_off[0] != 0) FD_THROW(FD_ERR_INVALID_ARGUMENT, "WvmClassifier: val_off[0] must be 0");
+        for (int k = 0; k < F; ++k)
+            if (md->val_off[k + 1] <= md->val_off[k]) FD_THROW(FD_ERR_INVALID_ARGUMENT, "WvmClassifier: val_off is not ascending at filter %d", k);
         const int nval = md->val_off[F];
+        if (md->num_vals > 0 && nval > md->num_vals) FD_THROW(FD_ERR_INVALID_ARGUMENT, "WvmClassifier: val_off[num_filters] = %d exceeds num_vals = %d", nval, md->num_vals);
+        if (md->rec_off[0] < 0) FD_THROW(FD_ERR_INVALID_ARGUMENT, "WvmClassifier: rec_off[0] must not be negative");
+        for (int v = 0; v < nval; ++v)
+            if (md->rec_off[v + 1] < md->rec_off[v]) FD_THROW(FD_ERR_INVALID_ARGUMENT, "WvmClassifier: rec_off is not ascending at grey value %d", v);
+        if (md->num_rects > 0 && md->rec_off[nval] > md->num_rects)
+            FD_THROW(FD_ERR_INVALID_ARGUMENT, "WvmClassifier: rec_off[%d] = %d exceeds num_rects = %d", nval, md->rec_off[nval], md->num_rects);
         std::vector<float> wT((size_t)F * F + 64, 0.f);   // +64: a block of lanes may read past the last row
         for (int k = 0; k < F; ++k)
             for (int pidx = 0; pidx <= k; ++pidx) wT[(size_t)pidx * F + k] = md->hk_weights[(size_t)k * F + pidx];

@@ -883,6 +883,10 @@ const fd_wvm* WvmClassifier::native(double la, double lb) const {
         m.thresholds = hierarchicalThresholds.data(); m.hk_weights = model.hk_weights.data(); m.pp = model.pp.data();
         m.val_off = model.val_off.data(); m.val = model.val.data(); m.rec_off = model.rec_off.data(); m.rects = model.rects.data();
         m.logistic_a = la; m.logistic_b = lb;
+        m.num_vals = (int32_t)model.val.size(); m.num_rects = (int32_t)(model.rects.size() / 4);   // a truncated model file is rejected
+        // a file with too short offset tables would be read out of bounds before the library sees it
+        if ((int)model.val_off.size() != model.num_filters + 1 || model.val_off.back() < 0 || (int)model.rec_off.size() != model.val_off.back() + 1)
+            throw std::invalid_argument("WvmClassifier: inconsistent offset tables in the model");
         check(fd_wvm_create(context(), &m, &handle));
         dirty = false;
     }

@@ -113,6 +113,8 @@ typedef struct {
     const int32_t* rec_off;      /* [val_off[num_filters]+1]; rects of (k,v) */
     const uint8_t* rects;        /* {x1,y1,x2,y2} inclusive patch coordinates, 4 bytes per rect */
     double logistic_a, logistic_b; /* ProbabilisticWvmClassifier.hpp:36 */
+    int32_t num_vals, num_rects; /* lengths of val / rects (entries), so that a truncated model is rejected instead of read out
+                                  * of bounds; 0 = not stated (offsets are still checked for order) */
 } fd_wvm_model;
 int fd_wvm_create(fd_ctx* ctx, const fd_wvm_model* model, fd_wvm** out);
 void fd_wvm_destroy(fd_wvm* m);

@@ -827,3 +827,20 @@ def test_five_stage_batch_in_two_halves_with_two_frames_in_flight(oracle, capi, 
         capi.FiveStageBatch(ctx, [sets[0], sets[0]])   # two jobs sharing a WVM handle
     for p_, w_, s_ in sets:
         w_.close(); s_.close(); p_.close()
+
+
+def test_wvm_model_validation(capi, ctx, synth):
+    """fd_wvm_create rejects models whose offset tables are not ascending or point past the stated array lengths (a truncated or
+    corrupt model file must not turn into out-of-bounds reads)."""
+    m = synth.make_wvm(5, n_per=4, n_levels=5)
+    capi.Wvm(ctx, m).close()
+    bad = dict(m); bad["val_off"] = m["val_off"].copy(); bad["val_off"][3] = bad["val_off"][2]
+    with pytest.raises(capi.FdError) as e:
+        capi.Wvm(ctx, bad)
+    assert e.value.code == capi.FD_ERR_INVALID_ARGUMENT
+    bad = dict(m); bad["rec_off"] = m["rec_off"].copy(); bad["rec_off"][-1] += 7    # past the rects array
+    with pytest.raises(capi.FdError):
+        capi.Wvm(ctx, bad)
+    bad = dict(m); bad["val"] = m["val"][:-3]                                       # truncated grey values
+    with pytest.raises(capi.FdError):
+        capi.Wvm(ctx, bad)
