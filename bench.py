@@ -162,7 +162,7 @@ class Cascade(Workload):
     name = "cascade"
     dtype = "u8/i32/f32/f64"
 
-    def __init__(self, env, W=640, H=480, frames_per_step=512, nb=16):
+    def __init__(self, env, W=640, H=480, frames_per_step=512, nb=32, multi=True):
         import torch
         from featuredetection_amd import capi, synth
         self.env, self.capi, self.W, self.H = env, capi, W, H
@@ -175,9 +175,20 @@ class Cascade(Workload):
         self.dframes = [torch.from_numpy(f).to(env.dev) for f in frames]
         self.wvm_m, self.svm_m = cascade_models()
         kw = dict(inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))
-        self.pyrs = [capi.Pyramid(ctx, **kw) for _ in range(self.NB)]
-        self.wvms = [capi.Wvm(ctx, self.wvm_m) for _ in range(self.NB)]   # one handle (scratch + read-back buffers) per frame in flight
+        self.multi = multi and self.NB > 1
+        npyr = 1 if self.multi else self.NB
+        self.pyrs = [capi.Pyramid(ctx, **kw) for _ in range(npyr)]
+        self.wvms = [capi.Wvm(ctx, self.wvm_m) for _ in range(npyr)]   # one handle (scratch + read-back buffers) per frame in flight
         self.svm = capi.Svm(ctx, self.svm_m)
+        self.slots, self.flying, self.ncalls = [], [], 0
+        if self.multi:
+            # two calls in flight, each on its own context (stream), multi-frame pyramid and handles: the cascade run of one call
+            # overlaps the host stages (overlap elimination, NMS) of the other
+            for k in range(2):
+                c_ = ctx if k == 0 else capi.Context(env.local_rank)
+                mp = capi.Pyramid(c_, **kw)
+                mp.set_frames(self.NB)
+                self.slots.append(dict(ctx=c_, pyr=mp, wvm=capi.Wvm(c_, self.wvm_m), svm=capi.Svm(c_, self.svm_m), run=None, ids=None))
         self.pyrs[0].update(frames[0])
         self.nwin = self.pyrs[0].window_count(20, 20, 1, 1)
         self.layer_bytes = sum(l["w"] * l["h"] for l in self.pyrs[0].layers())
@@ -185,7 +196,9 @@ class Cascade(Workload):
         self.metric = "Mpatches/s (extract+WVM+SVM) per GPU, %dx%d pyramid" % (W, H)
         self.config = dict(workload="config 1/metric config: ffpDetectApp FaceFrontal.cfg five-stage cascade on %dx%d BGR frames: %d-layer pyramid, 20x20 "
                                     "windows step 1 (%d windows/frame), HistEq64 -> WVM 280 filters -> OE -> RBF-SVM 1024 SV -> NMS; "
-                                    "fd_detect_five_stage_batch, detections delivered per frame" % (W, H, self.nlayers, self.nwin),
+                                    "%s, detections delivered per frame" % (W, H, self.nlayers, self.nwin, "fd_pyramid_update_frames + "
+                                    "fd_detect_five_stage_frames (the frames of a call share one pyramid arena, one cascade run and one SVM launch)"
+                                    if self.multi else "fd_detect_five_stage_batch"),
                            frames_per_step=self.FP, frames_per_call=self.NB, parallelism="image-shard dp%d" % env.world)
 
     def step(self, i):
@@ -193,11 +206,38 @@ class Cascade(Workload):
         out = []
         base = i * self.FP
         for c in range(self.FP // NB):
-            fr = [(self.dframes[(base + c * NB + j) % self.NFR].data_ptr(), self.W, self.H, 3) for j in range(NB)]
-            res = capi.detect_five_stage_batch(self.env.ctx, [(self.pyrs[j], self.wvms[j], self.svm) for j in range(NB)], device_frames=fr)
+            if self.multi:
+                # the NB frames of a call in ONE pyramid: one launch per pyramid stage, one cascade run and one SVM launch
+                sl = self.slots[self.ncalls % len(self.slots)]
+                self.ncalls += 1
+                if sl["run"] is not None:
+                    out.extend(self._collect(sl))
+                ptrs = [self.dframes[(base + c * NB + j) % self.NFR].data_ptr() for j in range(NB)]
+                sl["pyr"].update_frames(device_ptrs=ptrs, w=self.W, h=self.H, ch=3)
+                sl["run"] = capi.FiveStageFrames(sl["ctx"], sl["pyr"], sl["wvm"], sl["svm"], NB)
+                sl["ids"] = [(base + c * NB + j) * self.env.world + self.env.rank for j in range(NB)]
+                continue
+            else:
+                fr = [(self.dframes[(base + c * NB + j) % self.NFR].data_ptr(), self.W, self.H, 3) for j in range(NB)]
+                res = capi.detect_five_stage_batch(self.env.ctx, [(self.pyrs[j], self.wvms[j], self.svm) for j in range(NB)], device_frames=fr)
             for j, (d_, _) in enumerate(res):
                 out.append(((base + c * NB + j) * self.env.world + self.env.rank, 0, d_))
         return self.nwin * self.FP, out
+
+    def _collect(self, sl):
+        res, sl["run"] = sl["run"].end(), None
+        return [(img, 0, d_) for img, (d_, _) in zip(sl["ids"], res)]
+
+    def flush(self):
+        out = []
+        for sl in self.slots:
+            if sl["run"] is not None:
+                out.extend(self._collect(sl))
+        return out
+
+    def sync(self):
+        for sl in self.slots[1:]:
+            sl["ctx"].synchronize()
 
     def kernel_probe(self):
         """hipEvent-timed duration of the cascade kernels (all WVM stages) of single-frame calls + the roofline entries"""
@@ -719,7 +759,9 @@ def main():
     ap.add_argument("--gather-every", type=int, default=4)
     ap.add_argument("--size", default=None, help="frame size WxH of the headline workload (cascade, hog_svm, ffp15, rvm, aggregated)")
     ap.add_argument("--frames-per-step", type=int, default=0, help="frames (sdm: batches) per step of the headline workload; 0 = its default")
-    ap.add_argument("--frames-per-call", type=int, default=0, help="cascade workload: frames per fd_detect_five_stage_batch call; 0 = default")
+    ap.add_argument("--frames-per-call", type=int, default=0, help="cascade workload: frames per call (one multi-frame pyramid); 0 = default")
+    ap.add_argument("--per-frame-launches", action="store_true", help="cascade workload: one pyramid + cascade per frame (fd_detect_five_stage_batch) "
+                                                                      "instead of the multi-frame entry points")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.workload == "wvm":
@@ -758,6 +800,9 @@ def main():
                 kw.pop("frames_per_step")
         if headline and args.frames_per_call > 0 and name == "cascade":
             kw["nb"] = args.frames_per_call
+        if headline and args.per_frame_launches and name == "cascade":
+            kw["multi"] = False
+            kw.setdefault("nb", 16)
         return WORKLOADS[name](env, **kw)
 
     also = args.also

@@ -126,6 +126,14 @@ _SIGS = {
     "fd_pyramid_layer_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int),
                                         C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "fd_pyramid_layer_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "fd_pyramid_set_frames": (C.c_int, [C.c_void_p, C.c_int]),
+    "fd_pyramid_update_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "fd_pyramid_frame_layer_download": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "fd_detect_five_stage_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "fd_detect_five_stage_frames_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int,
+                                                    C.c_void_p, C.POINTER(C.c_void_p)]),
+    "fd_detect_five_stage_frames_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "fd_pyramid_select": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "fd_pyramid_window_count": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]),
     "fd_pyramid_windows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
@@ -313,6 +321,30 @@ class Pyramid:
         self.ctx.check(lib().fd_pyramid_layer_download(self.h, i, _ptr(a)))
         return a
 
+    def set_frames(self, n):
+        """the pyramid holds n frames of identical size (one launch per pyramid stage, one cascade run for all of them)"""
+        self.ctx.check(lib().fd_pyramid_set_frames(self.h, n))
+        self.nframes = n
+
+    def update_frames(self, images=None, device_ptrs=None, w=0, h=0, ch=0):
+        """images: list of equally sized host arrays, or device_ptrs + (w, h, ch) for frames resident in HBM"""
+        if images is not None:
+            imgs = [np.ascontiguousarray(i, np.uint8) for i in images]
+            h, w = imgs[0].shape[:2]
+            ch = 1 if imgs[0].ndim == 2 else imgs[0].shape[2]
+            ptrs = (C.c_void_p * len(imgs))(*[i.ctypes.data for i in imgs])
+            self.ctx.check(lib().fd_pyramid_update_frames(self.h, ptrs, len(imgs), w, h, ch, 0))
+        else:
+            ptrs = (C.c_void_p * len(device_ptrs))(*device_ptrs)
+            self.ctx.check(lib().fd_pyramid_update_frames(self.h, ptrs, len(device_ptrs), w, h, ch, 1))
+
+    def frame_layer(self, frame, i):
+        info = self.layers()[i]
+        shape = (info["h"], info["w"]) if info["ch"] == 1 else (info["h"], info["w"], info["ch"])
+        out = np.empty(shape, np.uint8)
+        self.ctx.check(lib().fd_pyramid_frame_layer_download(self.h, frame, i, _ptr(out)))
+        return out
+
     def select(self, first_layer=-1, last_layer=-1, step_layer=1, roi=None):
         """layer sub-range / default roi of every enumeration that follows; select() resets"""
         r = _c(roi, np.int32) if roi is not None else None
@@ -440,6 +472,35 @@ def detect_five_stage(ctx, pyr, wvm, svm, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1,
     ctx.check(lib().fd_detect_five_stage(ctx.h, pyr.h, wvm.h, svm.h, oe_dist, oe_ratio, sx, sy, _ptr(r), _ptr(out), cap,
                                          C.byref(cnt), _ptr(stages)))
     return out[:cnt.value], stages
+
+
+def detect_five_stage_frames(ctx, pyr, wvm, svm, nframes, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1, roi=None, cap=256):
+    """fd_detect_five_stage_frames on a multi-frame pyramid: [(detections, stage_counts)] per frame"""
+    out = np.empty((nframes, cap), DET_DTYPE)
+    counts = np.zeros(nframes, np.int32)
+    stages = np.zeros((nframes, 4), np.int32)
+    r = _c(roi, np.int32) if roi is not None else None
+    ctx.check(lib().fd_detect_five_stage_frames(ctx.h, pyr.h, wvm.h, svm.h, oe_dist, oe_ratio, sx, sy, _ptr(r), _ptr(out), cap, _ptr(counts), _ptr(stages)))
+    return [(out[f, :counts[f]].copy(), stages[f].copy()) for f in range(nframes)]
+
+
+class FiveStageFrames:
+    """fd_detect_five_stage_frames_begin / _end: the cascade run of all frames of a multi-frame pyramid is queued by the constructor,
+    end() runs the host stages + the SVM launch and returns [(detections, stage_counts)] per frame"""
+
+    def __init__(self, ctx, pyr, wvm, svm, nframes, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1, roi=None, cap=256):
+        self.ctx, self.nframes, self.cap = ctx, nframes, cap
+        self.ticket = C.c_void_p()
+        r = _c(roi, np.int32) if roi is not None else None
+        ctx.check(lib().fd_detect_five_stage_frames_begin(ctx.h, pyr.h, wvm.h, svm.h, oe_dist, oe_ratio, sx, sy, _ptr(r), C.byref(self.ticket)))
+
+    def end(self):
+        out = np.empty((self.nframes, self.cap), DET_DTYPE)
+        counts = np.zeros(self.nframes, np.int32)
+        stages = np.zeros((self.nframes, 4), np.int32)
+        t, self.ticket = self.ticket, C.c_void_p()
+        self.ctx.check(lib().fd_detect_five_stage_frames_end(self.ctx.h, t, _ptr(out), self.cap, _ptr(counts), _ptr(stages)))
+        return [(out[f, :counts[f]].copy(), stages[f].copy()) for f in range(self.nframes)]
 
 
 def _five_stage_jobs(detectors, oe_dist, oe_ratio, sx, sy, cap, device_frames):

@@ -274,6 +274,11 @@ struct fd_pyramid {
     uint32_t gray_full_off = 0;
     size_t arena_bytes = 0;
     uint64_t version = 0;            // bumped by every update
+    // several frames of identical size in one pyramid (fd_pyramid_set_frames): frame f's layers live at arena + f * image_stride
+    // with the layout of frame 0.  One launch per pyramid stage and ONE cascade / SVM launch serve all frames of a call
+    // (fd_detect_five_stage_frames); the per-frame launch chain is what bounds small frames.
+    int nimg = 1;
+    size_t image_stride = 0;
     // fd_pyramid_select: layer sub-range (pyramid layer indices, -1 = open end), layer step (over the kept layers, starting at the
     // first) and default region of interest of every window enumeration that follows (DirectPyramidFeatureExtractor.cpp:75-123)
     int sel_first = -1, sel_last = -1, sel_step = 1;
@@ -286,12 +291,18 @@ struct fd_pyramid {
     ~fd_pyramid() { if (ready) (void)hipEventDestroy(ready); }
 };
 
+// entry points that only know single-frame pyramids
+static inline void fd_pyramid_require_single(const fd_pyramid* p, const char* who) {
+    if (p->nimg > 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "%s: the pyramid holds %d frames (fd_pyramid_set_frames); use fd_detect_five_stage_frames", who, p->nimg);
+}
+
 // makes `consumer` wait for the pyramid's last update when that ran on another stream
 static inline void fd_pyramid_wait(const fd_pyramid* p, hipStream_t consumer) {
     if (p->ready && consumer != p->readyStream) HIP_CHECK(hipStreamWaitEvent(consumer, p->ready, 0));
 }
 
 void fd_pyramid_update_on(fd_pyramid* p, const uint8_t* image, int w, int h, int ch, int is_device, hipStream_t st);
+constexpr int FD_MAX_FRAMES = 64;
 void fd_enumerate_layers(const fd_pyramid* p, int pw, int ph, int sx, int sy, const int* roi,
                          std::vector<WindowLayer>& out, int64_t& total);
 

@@ -494,6 +494,7 @@ int fd_pyramid_fhog_layer(fd_ctx* ctx, fd_pyramid* p, int layer, const fd_fhog_p
         if (!ctx || !p || !fp || !out) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_fhog_layer: NULL argument");
         if (p->ctx != ctx) FD_THROW(FD_ERR_INVALID_ARGUMENT, "objects belong to different contexts");
         if (p->filter_kind != FD_LAYER_NONE) FD_THROW(FD_ERR_INVALID_ARGUMENT, "FhogFilter needs a gray pyramid (no layer filter)");
+        fd_pyramid_require_single(p, "fd_pyramid_fhog_layer");
         if (layer < 0 || layer >= (int)p->kept.size()) FD_THROW(FD_ERR_INVALID_ARGUMENT, "no such pyramid layer: %d", layer);
         HIP_CHECK(hipSetDevice(ctx->device));
         const HostLayer& L = p->all[p->kept[layer]];

@@ -54,6 +54,23 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 }
 
 // cv::cvtColor(BGR2GRAY), 8U: (B*1868 + G*9617 + R*4899 + 8192) >> 14
+struct FramePtrs {
+    const uint8_t* p[FD_MAX_FRAMES];
+};
+// the frames of a multi-frame pyramid: BGR -> gray (ch == 3) or copy (ch == 1) into frame blockIdx.y's arena
+__global__ void k_frames_to_gray(FramePtrs frames, uint8_t* __restrict__ grayBase, size_t imageStride, int n, int ch) {
+    const uint8_t* __restrict__ src = frames.p[blockIdx.y];
+    uint8_t* __restrict__ gray = grayBase + (size_t)blockIdx.y * imageStride;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (ch == 3) {
+            int b = src[3 * (size_t)i], g = src[3 * (size_t)i + 1], r = src[3 * (size_t)i + 2];
+            gray[i] = (uint8_t)((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14);
+        } else {
+            gray[i] = src[i];
+        }
+    }
+}
+
 __global__ void k_bgr2gray(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ gray, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int stride = gridDim.x * blockDim.x;
@@ -65,11 +82,11 @@ __global__ void k_bgr2gray(const uint8_t* __restrict__ bgr, uint8_t* __restrict_
 
 // cv::resize INTER_LINEAR 8UC1 -> all first-octave layers from the full-resolution gray image
 __global__ void k_resize_linear(const uint8_t* __restrict__ arena, uint8_t* __restrict__ out, uint32_t src_off, int sw,
-                                int sh, ResizeJobs jobs) {
+                                int sh, ResizeJobs jobs, size_t imageStride) {
     const ResizeJob jb = jobs.j[blockIdx.y];
     const int npix = jb.dw * jb.dh;
-    const uint8_t* src = arena + src_off;
-    uint8_t* dst = out + jb.dst_off;
+    const uint8_t* src = arena + (size_t)blockIdx.z * imageStride + src_off;   // blockIdx.z = frame of a multi-frame pyramid
+    uint8_t* dst = out + (size_t)blockIdx.z * imageStride + jb.dst_off;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
         int dy = i / jb.dw, dx = i - dy * jb.dw;
         float fx = (float)((dx + 0.5) * jb.scale_x - 0.5);
@@ -94,9 +111,10 @@ __global__ void k_resize_linear(const uint8_t* __restrict__ arena, uint8_t* __re
 }
 
 // cv::pyrDown 8UC1: separable [1 4 6 4 1], (sum + 128) >> 8, BORDER_REFLECT_101
-__global__ void k_pyrdown(uint8_t* __restrict__ arena, DownJobs jobs) {
+__global__ void k_pyrdown(uint8_t* __restrict__ arena, DownJobs jobs, size_t imageStride) {
     const DownJob jb = jobs.j[blockIdx.y];
     const int dw = (jb.sw + 1) / 2, dh = (jb.sh + 1) / 2;
+    arena += (size_t)blockIdx.z * imageStride;   // blockIdx.z = frame of a multi-frame pyramid
     const uint8_t* src = arena + jb.src_off;
     uint8_t* dst = arena + jb.dst_off;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dw * dh; i += gridDim.x * blockDim.x) {
@@ -349,7 +367,9 @@ void build_layout(fd_pyramid* p, int W, int H) {
     if (off > 0xfffffff0ull) FD_THROW(FD_ERR_INVALID_ARGUMENT, "ImagePyramid: pyramid exceeds 4 GB arena");
     std::sort(p->kept.begin(), p->kept.end(), [&](int a, int b) { return p->all[a].index < p->all[b].index; });
     p->arena_bytes = off + 256;
-    p->arena.reserve(p->arena_bytes);
+    p->image_stride = (p->arena_bytes + 255) & ~(size_t)255;
+    if (p->nimg > 1 && p->image_stride * (size_t)p->nimg > 0xfffffff0ull * 16) FD_THROW(FD_ERR_INVALID_ARGUMENT, "ImagePyramid: multi-frame pyramid too large");
+    p->arena.reserve(p->image_stride * (size_t)p->nimg);
     p->h_layer_table.clear();
     for (int k : p->kept) {
         const HostLayer& L = p->all[k];
@@ -363,23 +383,41 @@ void build_layout(fd_pyramid* p, int W, int H) {
 
 int grid_for(int npix) { return std::max(1, std::min(1024, (npix + 255) / 256)); }
 
-void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, int is_device, hipStream_t st) {
-    if (!image) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_update: image is NULL");
+void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, int is_device, hipStream_t st, const uint8_t* const* frames = nullptr) {
+    if (!image && !frames) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_update: image is NULL");
+    if (p->nimg > 1 && !frames) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_update: the pyramid holds %d frames, use fd_pyramid_update_frames", p->nimg);
+    if (p->nimg > 1 && p->filter_kind != FD_LAYER_NONE) FD_THROW(FD_ERR_INVALID_ARGUMENT, "multi-frame pyramids have no layer filters");
     if (W < 1 || H < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_update: empty image");
     if (ch != 1 && ch != 3) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_update: image must have 1 or 3 channels");
     if (W != p->img_w || H != p->img_h || p->all.empty()) build_layout(p, W, H);
     uint8_t* arena = p->arena.as<uint8_t>();
     const size_t npix = (size_t)W * H;
-    const uint8_t* dimg = image;
-    if (!is_device) {
-        p->input.reserve(npix * ch);
-        HIP_CHECK(hipMemcpyAsync(p->input.p, image, npix * ch, hipMemcpyHostToDevice, st));
-        dimg = p->input.as<uint8_t>();
-    }
-    if (ch == 3) {
-        hipLaunchKernelGGL(k_bgr2gray, dim3(grid_for((int)npix)), dim3(256), 0, st, dimg, arena + p->gray_full_off, (int)npix);
+    const int NI = frames ? p->nimg : 1;
+    const size_t IS = p->image_stride;
+    if (frames) {   // one launch converts / copies all frames into their arenas
+        FramePtrs fp;
+        if (!is_device) {
+            p->input.reserve(npix * ch * (size_t)NI);
+            for (int f = 0; f < NI; ++f) {
+                HIP_CHECK(hipMemcpyAsync(p->input.as<uint8_t>() + (size_t)f * npix * ch, frames[f], npix * ch, hipMemcpyHostToDevice, st));
+                fp.p[f] = p->input.as<uint8_t>() + (size_t)f * npix * ch;
+            }
+        } else {
+            for (int f = 0; f < NI; ++f) fp.p[f] = frames[f];
+        }
+        hipLaunchKernelGGL(k_frames_to_gray, dim3(grid_for((int)npix), NI), dim3(256), 0, st, fp, arena + p->gray_full_off, IS, (int)npix, ch);
     } else {
-        HIP_CHECK(hipMemcpyAsync(arena + p->gray_full_off, dimg, npix, hipMemcpyDeviceToDevice, st));
+        const uint8_t* dimg = image;
+        if (!is_device) {
+            p->input.reserve(npix * ch);
+            HIP_CHECK(hipMemcpyAsync(p->input.p, image, npix * ch, hipMemcpyHostToDevice, st));
+            dimg = p->input.as<uint8_t>();
+        }
+        if (ch == 3) {
+            hipLaunchKernelGGL(k_bgr2gray, dim3(grid_for((int)npix)), dim3(256), 0, st, dimg, arena + p->gray_full_off, (int)npix);
+        } else {
+            HIP_CHECK(hipMemcpyAsync(arena + p->gray_full_off, dimg, npix, hipMemcpyDeviceToDevice, st));
+        }
     }
     // depth 0: resize from the full-resolution gray image
     int maxDepth = 0;
@@ -390,7 +428,7 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
         int maxpix = 0;
         auto flush = [&]() {
             if (!jobs.n) return;
-            hipLaunchKernelGGL(k_resize_linear, dim3(grid_for(maxpix), jobs.n), dim3(256), 0, st, arena, arena, p->gray_full_off, W, H, jobs);
+            hipLaunchKernelGGL(k_resize_linear, dim3(grid_for(maxpix), jobs.n, NI), dim3(256), 0, st, arena, arena, p->gray_full_off, W, H, jobs, IS);
             jobs.n = 0;
             maxpix = 0;
         };
@@ -411,7 +449,7 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
         int maxpix = 0;
         auto flush = [&]() {
             if (!jobs.n) return;
-            hipLaunchKernelGGL(k_pyrdown, dim3(grid_for(maxpix), jobs.n), dim3(256), 0, st, arena, jobs);
+            hipLaunchKernelGGL(k_pyrdown, dim3(grid_for(maxpix), jobs.n, NI), dim3(256), 0, st, arena, jobs, IS);
             jobs.n = 0;
             maxpix = 0;
         };
@@ -587,6 +625,26 @@ int fd_pyramid_update(fd_pyramid* p, const uint8_t* image, int w, int h, int ch,
     });
 }
 
+int fd_pyramid_set_frames(fd_pyramid* p, int frames) {
+    return fd_guard(p ? p->ctx : nullptr, [&] {
+        if (!p) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_set_frames: NULL pyramid");
+        if (frames < 1 || frames > FD_MAX_FRAMES) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_set_frames: 1..%d frames", FD_MAX_FRAMES);
+        if (frames > 1 && p->filter_kind != FD_LAYER_NONE) FD_THROW(FD_ERR_INVALID_ARGUMENT, "multi-frame pyramids have no layer filters");
+        if (frames != p->nimg) { p->nimg = frames; p->all.clear(); p->img_w = p->img_h = 0; }   // new layout at the next update
+    });
+}
+
+int fd_pyramid_update_frames(fd_pyramid* p, const uint8_t* const* images, int n, int w, int h, int ch, int is_device) {
+    return fd_guard(p ? p->ctx : nullptr, [&] {
+        if (!p || !images) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_update_frames: NULL argument");
+        if (n != p->nimg) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_update_frames: %d images for a pyramid of %d frames", n, p->nimg);
+        for (int f = 0; f < n; ++f)
+            if (!images[f]) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_update_frames: image %d is NULL", f);
+        HIP_CHECK(hipSetDevice(p->ctx->device));
+        pyramid_update(p, nullptr, w, h, ch, is_device, p->ctx->stream, images);
+    });
+}
+
 int fd_pyramid_select(fd_pyramid* p, int first_layer, int last_layer, int step_layer, const int* roi) {
     return fd_guard(p ? p->ctx : nullptr, [&] {
         if (!p) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_select: NULL pyramid");
@@ -619,6 +677,17 @@ int fd_pyramid_layer_download(fd_pyramid* p, int i, uint8_t* host_dst) {
         if (!p || !host_dst || i < 0 || i >= (int)p->kept.size()) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_layer_download: bad argument");
         const HostLayer& L = p->all[p->kept[i]];
         HIP_CHECK(hipMemcpyAsync(host_dst, p->arena.as<uint8_t>() + L.filt_off, (size_t)L.w * L.h * L.ch, hipMemcpyDeviceToHost, p->ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    });
+}
+
+int fd_pyramid_frame_layer_download(fd_pyramid* p, int frame, int i, uint8_t* host_dst) {
+    return fd_guard(p ? p->ctx : nullptr, [&] {
+        if (!p || !host_dst || i < 0 || i >= (int)p->kept.size() || frame < 0 || frame >= p->nimg)
+            FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_frame_layer_download: bad argument");
+        const HostLayer& L = p->all[p->kept[i]];
+        HIP_CHECK(hipMemcpyAsync(host_dst, p->arena.as<uint8_t>() + (size_t)frame * p->image_stride + L.filt_off, (size_t)L.w * L.h * L.ch,
+                                 hipMemcpyDeviceToHost, p->ctx->stream));
         HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
     });
 }

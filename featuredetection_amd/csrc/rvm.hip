@@ -415,6 +415,7 @@ int fd_detect_rvm(fd_ctx* ctx, fd_pyramid* p, const fd_rvm* rvm_, const fd_rvm_d
         fd_rvm* m = const_cast<fd_rvm*>(rvm_);
         if (p->ctx != ctx || m->ctx != ctx) FD_THROW(FD_ERR_INVALID_ARGUMENT, "objects belong to different contexts");
         if (p->filter_kind != FD_LAYER_NONE) FD_THROW(FD_ERR_INVALID_ARGUMENT, "RVM detection needs a gray pyramid (no layer filter)");
+        fd_pyramid_require_single(p, "fd_detect_rvm");
         if (p->all.empty()) FD_THROW(FD_ERR_RUNTIME, "pyramid has not been updated with an image");
         if (dp->feature_space < FD_FEATURE_GRAY || dp->feature_space > FD_FEATURE_HISTEQ)
             FD_THROW(FD_ERR_INVALID_ARGUMENT, "unknown feature space %d", dp->feature_space);

@@ -285,6 +285,7 @@ __global__ __launch_bounds__(64) void k_unit_norm(const float* __restrict__ src,
 
 void build_table(const fd_pyramid* p, const fd_whi_params* wp, WhiWinTable& wt, std::vector<WindowLayer>& wls) {
     if (p->filter_kind != FD_LAYER_NONE) FD_THROW(FD_ERR_INVALID_ARGUMENT, "the whi chain needs a gray pyramid (no layer filter)");
+    fd_pyramid_require_single(p, "the whi chain");
     if (p->all.empty()) FD_THROW(FD_ERR_RUNTIME, "pyramid has not been updated with an image");
     int64_t total;
     fd_enumerate_layers(p, wp->patch_w, wp->patch_h, wp->step_x, wp->step_y, nullptr, wls, total);

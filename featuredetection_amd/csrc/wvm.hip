@@ -59,6 +59,11 @@ struct WinTable {
     // != NULL: only the windows widq[0 .. *widq_count) are evaluated (written by k_wvm_prefilter earlier on the same stream)
     const int64_t* widq;
     const unsigned int* widq_count;
+    // multi-frame pyramid (fd_pyramid_set_frames): window id = frame * per_image + id inside the frame; frame f's layers are at
+    // arena + f * image_stride.  total = nimg * per_image.
+    int32_t nimg, pad_;
+    int64_t per_image;
+    uint64_t image_stride;
     WinLayerDev l[WVM_MAX_LAYERS];
 };
 
@@ -181,6 +186,11 @@ __device__ __forceinline__ const uint8_t* wvm_locate(const uint8_t* arena, const
     if (RAW) {
         stride = pw;
         return arena + (size_t)wid * d;
+    }
+    if (wt.nimg > 1) {   // multi-frame pyramid: frame = wid / per_image (wave-uniform)
+        const int64_t f = wid / wt.per_image;
+        wid -= f * wt.per_image;
+        arena += (size_t)f * wt.image_stride;
     }
     if (wt.list) {   // explicit window list (single-patch extraction of sampled positions)
         const int32_t* e = wt.list + 3 * wid;
@@ -1439,10 +1449,11 @@ static bool launch_prefilter(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const uint8
     WvdTable t;
     std::memset(&t, 0, sizeof(t));
     t.n = wt.n; t.sx = wt.sx; t.sy = wt.sy;
+    const int64_t perImage = wt.nimg > 1 ? wt.per_image : wt.total;
     int tiles = 0;
     for (int i = 0; i < wt.n; ++i) {
         const WinLayerDev& s = wt.l[i];
-        const int64_t nwin = (i + 1 < wt.n ? wt.l[i + 1].first : wt.total) - s.first;
+        const int64_t nwin = (i + 1 < wt.n ? wt.l[i + 1].first : perImage) - s.first;
         if (nwin <= 0 || nwin > (int64_t)INT32_MAX - 64) return false;
         WvdLayer& dl = t.l[i];
         dl.bx = s.bx; dl.by = s.by; dl.nx = s.nx; dl.lw = s.lw; dl.off = s.off; dl.magic = s.magic; dl.first = s.first;
@@ -1450,7 +1461,12 @@ static bool launch_prefilter(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const uint8
         dl.tileFirst = tiles;
         tiles += (int)((nwin + 63) / 64);
     }
-    t.ntiles = tiles;
+    t.tilesPerImage = tiles;
+    t.nimg = wt.nimg > 1 ? wt.nimg : 1;
+    t.perImage = perImage;
+    t.imageStride = wt.image_stride;
+    if ((int64_t)tiles * t.nimg > (int64_t)INT32_MAX) return false;
+    t.ntiles = tiles * t.nimg;
     WvdDev dv;
     dv.B = m->denseB.as<wvd_v4i>();
     dv.c = m->denseC.as<WvdConst>();
@@ -1477,7 +1493,10 @@ void fd_wvm_build_table(const fd_pyramid* p, int pw, int ph, int sx, int sy, con
     wt.n = 0;
     wt.sx = sx;
     wt.sy = sy;
-    wt.total = total;
+    wt.nimg = p->nimg;
+    wt.per_image = total;
+    wt.image_stride = p->image_stride;
+    wt.total = total * p->nimg;
     for (const WindowLayer& w : wls) {
         if (w.nx == 0 || w.ny == 0) continue;  // layers without windows never match (first == next first)
         const HostLayer& L = p->all[p->kept[w.layer]];
@@ -1659,6 +1678,7 @@ void fd_wvm_positives_to_detections(const fd_pyramid* p, const fd_wvm* m, const 
         fd_detection d;
         std::memset(&d, 0, sizeof(d));
         int64_t wid = (int64_t)(((uint64_t)run.pos[i].wid_hi << 32) | run.pos[i].wid_lo);
+        if (p->nimg > 1) wid %= run.total / p->nimg;   // multi-frame pyramid: id inside its frame (the caller groups by frame)
         fd_window_to_detection(p, run.wls, sx, sy, wid, d);
         d.level = run.pos[i].level;
         d.positive = 1;
@@ -1784,6 +1804,7 @@ int fd_detect_wvm(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, int sx, int sy
                   int64_t cap, int64_t* count, int32_t* all_level, float* all_score) {
     return fd_guard(ctx, [&] {
         if (!ctx || !p || !wvm_ || !count) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_wvm: NULL argument");
+        fd_pyramid_require_single(p, "fd_detect_wvm");
         fd_wvm* m = const_cast<fd_wvm*>(wvm_);
         WvmRun run;
         const bool want_all = all_level || all_score;
@@ -1838,6 +1859,37 @@ int fd_wvm_eval_batch(fd_ctx* ctx, const fd_wvm* wvm_, const uint8_t* patches, i
         if (out_score) HIP_CHECK(hipMemcpyAsync(out_score, m->all_fout.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
     });
+}
+
+// Stages 4-5 of FiveStageSlidingWindowDetector::detect on the SVM positives of one image (FiveStageSlidingWindowDetector.cpp:
+// 262-320; the roi variant :360-380 only sorts): block NMS on the probability map, one detection per maximum, sorted by probability.
+static void five_stage_nms(const fd_pyramid* p, const int* roi, std::vector<fd_detection>& svmPos, fd_detection* out, int cap, int* count,
+                           int32_t* stage_counts) {
+    if (stage_counts) stage_counts[2] = (int)svmPos.size();
+    auto byProb = [](const fd_detection& a, const fd_detection& b) { return a.probability > b.probability; };
+    bool sortAtEnd = true;
+    if (!roi) {
+        std::vector<int> maxima;
+        fd_host_block_nms_sparse(svmPos, p->img_w, p->img_h, 35, true, maxima);
+        if (maxima.empty()) fd_host_block_nms_sparse(svmPos, p->img_w, p->img_h, 35, false, maxima);
+        if (maxima.empty()) {
+            sortAtEnd = false;  // "return svmPatchesPositive; // Should be empty." (:292-294), unsorted
+        } else {
+            std::sort(svmPos.begin(), svmPos.end(), byProb);
+            std::vector<fd_detection> res;
+            for (size_t i = 0; i + 1 < maxima.size(); i += 2) {
+                const int x = maxima[i], y = maxima[i + 1];
+                auto it = std::find_if(svmPos.begin(), svmPos.end(), [&](const fd_detection& a) { return a.cx == x && a.cy == y; });
+                if (it != svmPos.end()) res.push_back(*it);
+            }
+            svmPos.swap(res);
+        }
+    }
+    if (sortAtEnd) std::sort(svmPos.begin(), svmPos.end(), byProb);
+    if (stage_counts) stage_counts[3] = (int)svmPos.size();
+    *count = (int)svmPos.size();
+    for (size_t i = 0; i < svmPos.size() && (int)i < cap && out; ++i) out[i] = svmPos[i];
+    if (out && (int)svmPos.size() > cap) FD_THROW(FD_ERR_CAPACITY, "five-stage: %zu detections, capacity %d", svmPos.size(), cap);
 }
 
 // Stages 2-5 of FiveStageSlidingWindowDetector::detect (FiveStageSlidingWindowDetector.cpp:200-320 / :340-380) on a
@@ -1932,33 +1984,9 @@ struct FiveStageTail {
                 }
             }
         }
-        if (stage_counts) stage_counts[2] = (int)svmPos.size();
         lap("svm wait");
-        auto byProb = [](const fd_detection& a, const fd_detection& b) { return a.probability > b.probability; };
-        bool sortAtEnd = true;
-        if (!roi) {
-            std::vector<int> maxima;
-            fd_host_block_nms_sparse(svmPos, p->img_w, p->img_h, 35, true, maxima);
-            if (maxima.empty()) fd_host_block_nms_sparse(svmPos, p->img_w, p->img_h, 35, false, maxima);
-            if (maxima.empty()) {
-                sortAtEnd = false;  // "return svmPatchesPositive; // Should be empty." (:292-294), unsorted
-            } else {
-                std::sort(svmPos.begin(), svmPos.end(), byProb);
-                std::vector<fd_detection> res;
-                for (size_t i = 0; i + 1 < maxima.size(); i += 2) {
-                    const int x = maxima[i], y = maxima[i + 1];
-                    auto it = std::find_if(svmPos.begin(), svmPos.end(), [&](const fd_detection& a) { return a.cx == x && a.cy == y; });
-                    if (it != svmPos.end()) res.push_back(*it);
-                }
-                svmPos.swap(res);
-            }
-        }
-        if (sortAtEnd) std::sort(svmPos.begin(), svmPos.end(), byProb);
-        if (stage_counts) stage_counts[3] = (int)svmPos.size();
+        five_stage_nms(p, roi, svmPos, out, cap, count, stage_counts);
         lap("nms");
-        *count = (int)svmPos.size();
-        for (size_t i = 0; i < svmPos.size() && (int)i < cap && out; ++i) out[i] = svmPos[i];
-        if (out && (int)svmPos.size() > cap) FD_THROW(FD_ERR_CAPACITY, "five-stage: %zu detections, capacity %d", svmPos.size(), cap);
     }
 };
 
@@ -1979,12 +2007,137 @@ int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const f
                          int sx, int sy, const int* roi, fd_detection* out, int cap, int* count, int32_t* stage_counts) {
     return fd_guard(ctx, [&] {
         if (!ctx || !p || !wvm_ || !svm || !count) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage: NULL argument");
+        fd_pyramid_require_single(p, "fd_detect_five_stage");
         fd_wvm* m = const_cast<fd_wvm*>(wvm_);
         five_stage_check(m, svm);
         // stage 1: WVM over all windows (SlidingWindowDetector::detect), positives in extraction order
         WvmRun run;
         fd_wvm_run(ctx, p, m, sx, sy, roi, false, run, ctx->kernel_timing);
         five_stage_tail(ctx, p, m, svm, run, oe_dist, oe_ratio, sx, sy, roi, ctx->stream, out, cap, count, stage_counts);
+    });
+}
+
+// FiveStageSlidingWindowDetector::detect on every frame of a multi-frame pyramid (fd_pyramid_set_frames /
+// fd_pyramid_update_frames): ONE cascade run (pre-filter + stage B over the windows of all frames) and ONE SVM launch serve the
+// whole call; the host stages (overlap elimination, NMS) run per frame.  A 640x480 frame is a chain of ~12 dependent launches
+// and ~90 us of latency however many frames are in flight; here that chain is paid once per call.
+struct fd_five_stage_frames {   // ticket of fd_detect_five_stage_frames_begin
+    fd_pyramid* p = nullptr;
+    fd_wvm* m = nullptr;
+    const fd_svm* svm = nullptr;
+    float oe_dist = 5.f, oe_ratio = 0.f;
+    int sx = 1, sy = 1;
+    bool has_roi = false;
+    int roi[4] = {0, 0, 0, 0};
+    WvmRun run;
+};
+
+static void five_stage_frames_begin(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const fd_svm* svm, float oe_dist, float oe_ratio, int sx, int sy,
+                                    const int* roi, fd_five_stage_frames& t) {
+    if (!ctx || !p || !wvm_ || !svm) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_frames: NULL argument");
+    t.p = p; t.m = const_cast<fd_wvm*>(wvm_); t.svm = svm; t.oe_dist = oe_dist; t.oe_ratio = oe_ratio; t.sx = sx; t.sy = sy;
+    t.has_roi = roi != nullptr;
+    if (roi) std::memcpy(t.roi, roi, sizeof(t.roi));
+    five_stage_check(t.m, svm);
+    fd_wvm_launch(ctx, p, t.m, sx, sy, roi, false, t.run, ctx->kernel_timing);   // one cascade run over the windows of all frames
+}
+
+static void five_stage_frames_end(fd_ctx* ctx, fd_five_stage_frames& t, fd_detection* out, int cap_per_frame, int32_t* counts, int32_t* stage_counts) {
+    if (!counts || cap_per_frame < 0) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_frames: bad argument");
+    fd_pyramid* p = t.p;
+    fd_wvm* m = t.m;
+    const fd_svm* svm = t.svm;
+    const int* roi = t.has_roi ? t.roi : nullptr;
+    WvmRun& run = t.run;
+    const int NF = p->nimg;
+    fd_wvm_finish(ctx, m, run);
+    const int64_t perImage = NF > 0 ? run.total / NF : 0;
+    std::vector<fd_detection> dets;
+    fd_wvm_positives_to_detections(p, m, run, t.sx, t.sy, dets);   // sorted by window id = by frame, extraction order inside
+    // frame boundaries, overlap elimination per frame, survivors of all frames -> one slot list
+    std::vector<size_t> begin((size_t)NF + 1, dets.size());
+    {
+        size_t i = 0;
+        for (int f = 0; f < NF; ++f) {
+            begin[(size_t)f] = i;
+            while (i < dets.size()) {
+                const int64_t wid = (int64_t)(((uint64_t)run.pos[i].wid_hi << 32) | run.pos[i].wid_lo);
+                if (perImage == 0 || wid / perImage != f) break;
+                ++i;
+            }
+        }
+        begin[(size_t)NF] = i;
+    }
+    std::vector<std::vector<int>> keep((size_t)NF);
+    std::vector<uint32_t> slots;
+    for (int f = 0; f < NF; ++f) {
+        const size_t b = begin[(size_t)f], e = begin[(size_t)f + 1];
+        if (stage_counts) { stage_counts[4 * f] = (int)(e - b); stage_counts[4 * f + 1] = stage_counts[4 * f + 2] = stage_counts[4 * f + 3] = 0; }
+        counts[f] = 0;
+        if (e == b) continue;
+        fd_host_overlap_elimination(dets.data() + b, (int)(e - b), t.oe_dist, t.oe_ratio, keep[(size_t)f]);
+        if (stage_counts) stage_counts[4 * f + 1] = (int)keep[(size_t)f].size();
+        for (int k : keep[(size_t)f]) slots.push_back(run.slots[b + (size_t)k]);
+    }
+    const double* dist = nullptr;
+    if (!slots.empty()) {   // the SVM stage of all frames: the kernel reads the slot list from / writes the distances to pinned memory
+        hipStream_t st = ctx->stream;
+        const size_t distOff = (sizeof(uint32_t) * slots.size() + 15) & ~(size_t)15;
+        m->h_tail.reserve(distOff + sizeof(double) * slots.size());
+        char* pin = m->h_tail.as<char>();
+        std::memcpy(pin, slots.data(), sizeof(uint32_t) * slots.size());
+        fd_svm_generic_launch_on(st, svm, m->pos_patches.p, (const uint32_t*)pin, (int64_t)m->dev.d, (int64_t)slots.size(), (double*)(pin + distOff));
+        if (!m->tailDone) HIP_CHECK(hipEventCreateWithFlags(&m->tailDone, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(m->tailDone, st));
+        HIP_CHECK(hipEventSynchronize(m->tailDone));   // only this call's SVM stage, not what the caller queued behind it
+        dist = (const double*)(pin + distOff);
+    }
+    size_t si = 0;
+    for (int f = 0; f < NF; ++f) {
+        std::vector<fd_detection> svmPos;
+        const size_t b = begin[(size_t)f];
+        for (int k : keep[(size_t)f]) {
+            const double dv = dist[si++];
+            if (dv >= (double)fd_svm_threshold(svm)) {
+                fd_detection d = dets[b + (size_t)k];
+                d.score = (float)dv;
+                d.positive = 1;
+                d.probability = 0.5;   // ClassifiedPatch(patch, bool) default probability (ClassifiedPatch.hpp:29-30)
+                svmPos.push_back(d);
+            }
+        }
+        int cnt = 0;
+        five_stage_nms(p, roi, svmPos, out ? out + (size_t)f * cap_per_frame : nullptr, cap_per_frame, &cnt, stage_counts ? stage_counts + 4 * f : nullptr);
+        counts[f] = cnt;
+    }
+}
+
+int fd_detect_five_stage_frames(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const fd_svm* svm, float oe_dist, float oe_ratio, int sx,
+                                int sy, const int* roi, fd_detection* out, int cap_per_frame, int32_t* counts, int32_t* stage_counts) {
+    return fd_guard(ctx, [&] {
+        fd_five_stage_frames t;
+        five_stage_frames_begin(ctx, p, wvm_, svm, oe_dist, oe_ratio, sx, sy, roi, t);
+        five_stage_frames_end(ctx, t, out, cap_per_frame, counts, stage_counts);
+    });
+}
+
+int fd_detect_five_stage_frames_begin(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const fd_svm* svm, float oe_dist, float oe_ratio, int sx,
+                                      int sy, const int* roi, fd_five_stage_frames** ticket) {
+    if (ticket) *ticket = nullptr;
+    return fd_guard(ctx, [&] {
+        if (!ticket) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_frames_begin: NULL ticket");
+        std::unique_ptr<fd_five_stage_frames> t(new fd_five_stage_frames());
+        five_stage_frames_begin(ctx, p, wvm_, svm, oe_dist, oe_ratio, sx, sy, roi, *t);
+        *ticket = t.release();
+    });
+}
+
+int fd_detect_five_stage_frames_end(fd_ctx* ctx, fd_five_stage_frames* ticket, fd_detection* out, int cap_per_frame, int32_t* counts,
+                                    int32_t* stage_counts) {
+    std::unique_ptr<fd_five_stage_frames> t(ticket);   // released whatever happens
+    return fd_guard(ctx, [&] {
+        if (!ctx || !t) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_frames_end: NULL argument");
+        five_stage_frames_end(ctx, *t, out, cap_per_frame, counts, stage_counts);
     });
 }
 
@@ -2005,6 +2158,7 @@ static void five_stage_batch_begin(fd_ctx* ctx, fd_five_stage_job* jobs, int n, 
         j.count = 0;
         j.status = FD_OK;
         if (!j.pyramid || !j.wvm || !j.svm) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_batch: NULL handle in job %d", i);
+        fd_pyramid_require_single(j.pyramid, "fd_detect_five_stage_batch");
         for (int k = 0; k < i; ++k)
             if (jobs[k].wvm == j.wvm) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_batch: jobs %d and %d share a WVM handle", k, i);
         five_stage_check(j.wvm, j.svm);
@@ -2236,6 +2390,7 @@ int fd_wvm_svm_evaluate_samples(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, 
     return fd_guard(ctx, [&] {
         if (!ctx || !p || !wvm_ || !svm || n < 0 || (n > 0 && (!xywh || !target || !weight)))
             FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_wvm_svm_evaluate_samples: bad argument");
+        fd_pyramid_require_single(p, "fd_wvm_svm_evaluate_samples");
         fd_wvm* m = const_cast<fd_wvm*>(wvm_);
         five_stage_check(m, svm);
         if (p->ctx != ctx || m->ctx != ctx) FD_THROW(FD_ERR_INVALID_ARGUMENT, "objects belong to different contexts");

@@ -39,7 +39,10 @@ struct WvdLayer {
     int64_t first;
 };
 struct WvdTable {
-    int32_t n, sx, sy, ntiles;
+    int32_t n, sx, sy, ntiles;           // ntiles = tilesPerImage * nimg
+    int32_t nimg, tilesPerImage;         // multi-frame pyramid: tile -> (frame, tile inside the frame)
+    int64_t perImage;                    // windows per frame
+    uint64_t imageStride;                // bytes between the frames' arenas
     WvdLayer l[WVM_MAX_LAYERS];
 };
 
@@ -133,8 +136,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
     const unsigned int laneOff16 = laneOff32 + (unsigned int)(lane >> 5) * 2u;
     const unsigned int inc = 1u << (16 * (lane >> 5));
 
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
-        while (li + 1 < wt.n && tile >= wt.l[li + 1].tileFirst) ++li;   // tiles ascend per wavefront
+    int lastImg = 0;
+    for (int gtile = blockIdx.x * 4 + wave; gtile < ntiles; gtile += gridDim.x * 4) {
+        const int img = wt.nimg > 1 ? gtile / wt.tilesPerImage : 0;   // frame of a multi-frame pyramid
+        const int tile = gtile - img * wt.tilesPerImage;
+        if (img != lastImg) { li = 0; lastImg = img; }
+        while (li + 1 < wt.n && tile >= wt.l[li + 1].tileFirst) ++li;   // tiles ascend per wavefront inside a frame
         const WvdLayer& wl = wt.l[li];
         const int local0 = (tile - wl.tileFirst) * 64 + lane;
         const bool valid = local0 < wl.nwin;
@@ -143,8 +150,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
         unsigned int ix = local - iy * (unsigned int)wl.nx;
         if (ix >= (unsigned int)wl.nx) { ix -= wl.nx; ++iy; }
         const int lw = wl.lw;
-        const uint8_t* src = arena + wl.off + (size_t)(wl.by + (int)iy * wt.sy) * lw + (wl.bx + (int)ix * wt.sx);
-        const int64_t wid = wl.first + local;
+        const uint8_t* src = arena + (size_t)img * wt.imageStride + wl.off + (size_t)(wl.by + (int)iy * wt.sy) * lw + (wl.bx + (int)ix * wt.sx);
+        const int64_t wid = (int64_t)img * wt.perImage + wl.first + local;
 
         // ---- 1. histogram: 64 bins x 64 lanes of u16 counters
         {

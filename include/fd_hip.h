@@ -166,6 +166,27 @@ int fd_detect_wvm(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm, int step_x, int
 int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm, const fd_svm* svm, float oe_dist,
                          float oe_ratio, int step_x, int step_y, const int* roi, fd_detection* out, int cap,
                          int* count, int32_t* stage_counts);
+/* Several frames of identical size in ONE pyramid, for the small-frame regime where the per-frame chain of dependent launches
+ * (pyramid, cascade, SVM) bounds the throughput: fd_pyramid_set_frames(p, n) (1..64; gray pyramids only) makes p hold n frames,
+ * fd_pyramid_update_frames builds all of them with one launch per pyramid stage, and fd_detect_five_stage_frames runs
+ * FiveStageSlidingWindowDetector::detect (:187-320 / :331-380) on every frame with one cascade run and one SVM launch for the
+ * whole call.  out: frames x cap_per_frame records (frame f's detections start at out + f * cap_per_frame); counts[frames];
+ * stage_counts (may be NULL): frames x 4.  The results equal fd_detect_five_stage on each frame.  The other entry points
+ * reject multi-frame pyramids.  fd_pyramid_frame_layer_download copies layer i of frame f to the host. */
+int fd_pyramid_set_frames(fd_pyramid* p, int frames);
+int fd_pyramid_update_frames(fd_pyramid* p, const uint8_t* const* images, int n, int width, int height, int channels, int is_device);
+int fd_pyramid_frame_layer_download(fd_pyramid* p, int frame, int i, uint8_t* host_dst);
+int fd_detect_five_stage_frames(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm, const fd_svm* svm, float oe_dist, float oe_ratio,
+                                int step_x, int step_y, const int* roi, fd_detection* out, int cap_per_frame, int32_t* counts,
+                                int32_t* stage_counts);
+/* The same in two halves (frames in flight: a second pyramid + WVM handle on a second context): begin queues the cascade run of
+ * all frames and returns; end runs the host stages, the SVM launch and fills out / counts / stage_counts.  Every ticket must be
+ * ended (end releases it, whatever it returns). */
+typedef struct fd_five_stage_frames fd_five_stage_frames;
+int fd_detect_five_stage_frames_begin(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm, const fd_svm* svm, float oe_dist, float oe_ratio,
+                                      int step_x, int step_y, const int* roi, fd_five_stage_frames** ticket);
+int fd_detect_five_stage_frames_end(fd_ctx* ctx, fd_five_stage_frames* ticket, fd_detection* out, int cap_per_frame, int32_t* counts,
+                                    int32_t* stage_counts);
 /* condensation::WvmSvmModel::evaluate(image, samples) (WvmSvmModel.cpp:69-118): the particle-filter
  * measurement model of the tracking apps on an updated gray pyramid.  xywh: n samples {x, y, width, height} (Sample::getX/
  * getY/getWidth/getHeight).  Every sample maps to one window (DirectPyramidFeatureExtractor::extract(x, y, width, height)),

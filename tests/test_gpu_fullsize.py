@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+FF_ = dict(inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))  # FaceFrontal.cfg
 
 
 def _models(synth, oracle, nsv):
@@ -237,3 +238,87 @@ def test_batch_on_pool_streams_waits_for_the_pyramid_update(oracle, capi, ctx, s
         w.close(); s.close()
     for p in pyrs.values():
         p.close()
+
+
+@pytest.mark.parametrize("nframes,size", [(5, (640, 480)), (16, (320, 240)), (3, (960, 540))])
+def test_multi_frame_pyramid_equals_single_frames(oracle, capi, ctx, synth, small_models, nframes, size):
+    """fd_pyramid_set_frames / fd_pyramid_update_frames / fd_detect_five_stage_frames: n frames in one pyramid, one launch per pyramid
+    stage, ONE cascade run and ONE SVM launch per call.  Every frame's layers and detections (boxes, order, scores, stage counts)
+    equal the single-frame entry points' -- and through them the oracle's (frame 0 is checked against the oracle directly)."""
+    wvm, svm = small_models
+    W, H = size
+    frames = [synth.make_frame(W, H, seed=500 + i) for i in range(nframes)]
+    wg, sg = capi.Wvm(ctx, wvm), capi.Svm(ctx, svm)
+    single = capi.Pyramid(ctx, **FF_)
+    ref = []
+    layers0 = None
+    for i, f in enumerate(frames):
+        single.update(f)
+        ref.append(capi.detect_five_stage(ctx, single, wg, sg, cap=256))
+        if i == nframes - 1:
+            layers0 = [single.layer(k) for k in range(len(single.layers()))]
+    multi = capi.Pyramid(ctx, **FF_)
+    multi.set_frames(nframes)
+    multi.update_frames(images=frames)
+    assert multi.layers() == single.layers()
+    for k in range(len(layers0)):
+        assert np.array_equal(multi.frame_layer(nframes - 1, k), layers0[k]), k
+    res = capi.detect_five_stage_frames(ctx, multi, wg, sg, nframes, cap=256)
+    assert sum(len(d) for d, _ in res) > 0
+    for f, ((d, s), (dr, sr)) in enumerate(zip(res, ref)):
+        assert np.array_equal(s, sr), (f, s, sr)
+        assert d.tobytes() == dr.tobytes(), f
+    # gray frames resident in HBM take the same path
+    import torch
+    gray = [oracle.bgr2gray(f) for f in frames]
+    dg = [torch.from_numpy(g).cuda() for g in gray]
+    multi.update_frames(device_ptrs=[t.data_ptr() for t in dg], w=W, h=H, ch=1)
+    res2 = capi.detect_five_stage_frames(ctx, multi, wg, sg, nframes, cap=256)
+    for (d, s), (dr, sr) in zip(res2, ref):
+        assert d.tobytes() == dr.tobytes() and np.array_equal(s, sr)
+    # frame 0 against the oracle
+    po = oracle.Pyramid(**FF_)
+    po.update(frames[0])
+    do, so = oracle.five_stage(po, oracle.Wvm(wvm), oracle.Svm(svm))
+    assert np.array_equal(res[0][1], so)
+    for fld in ("cx", "cy", "w", "h"):
+        assert np.array_equal(res[0][0][fld], do[fld])
+    # the single-frame entry points refuse a multi-frame pyramid
+    with pytest.raises(capi.FdError):
+        capi.detect_five_stage(ctx, multi, wg, sg)
+    wg.close(); sg.close(); single.close(); multi.close()
+
+
+def test_multi_frame_calls_in_flight_on_two_contexts(capi, ctx, synth, small_models):
+    """fd_detect_five_stage_frames_begin / _end with two calls in flight (each on its own context, pyramid and handles): the
+    pipelined results equal the synchronous ones."""
+    wvm, svm = small_models
+    NF = 6
+    sets = []
+    for k in range(2):
+        c_ = ctx if k == 0 else capi.Context(0)
+        p_ = capi.Pyramid(c_, **FF_)
+        p_.set_frames(NF)
+        sets.append((c_, p_, capi.Wvm(c_, wvm), capi.Svm(c_, svm)))
+    batches = [[synth.make_frame(320, 240, seed=900 + 10 * b + i) for i in range(NF)] for b in range(4)]
+    ref = []
+    for b, frames in enumerate(batches):
+        c_, p_, w_, s_ = sets[0]
+        p_.update_frames(images=frames)
+        ref.append(capi.detect_five_stage_frames(c_, p_, w_, s_, NF))
+    runs, got = [None, None], [None] * 4
+    for b, frames in enumerate(batches):
+        k = b % 2
+        c_, p_, w_, s_ = sets[k]
+        if runs[k] is not None:
+            got[runs[k][0]] = runs[k][1].end()
+        p_.update_frames(images=frames)
+        runs[k] = (b, capi.FiveStageFrames(c_, p_, w_, s_, NF))
+    for r in runs:
+        got[r[0]] = r[1].end()
+    for b in range(4):
+        for (d, s), (dr, sr) in zip(got[b], ref[b]):
+            assert d.tobytes() == dr.tobytes() and np.array_equal(s, sr), b
+    for c_, p_, w_, s_ in sets:
+        w_.close(); s_.close(); p_.close()
+    sets[1][0].close()
