@@ -80,59 +80,74 @@ __global__ void k_bgr2gray(const uint8_t* __restrict__ bgr, uint8_t* __restrict_
     }
 }
 
-// cv::resize INTER_LINEAR 8UC1 -> all first-octave layers from the full-resolution gray image
-__global__ void k_resize_linear(const uint8_t* __restrict__ arena, uint8_t* __restrict__ out, uint32_t src_off, int sw,
-                                int sh, ResizeJobs jobs, size_t imageStride) {
+// cv::resize INTER_LINEAR 8UC1 -> all first-octave layers from the full-resolution gray image.  A thread owns one destination
+// column of a band of RS_ROWS rows: the horizontal coordinates / fixed-point weights are computed once per thread, the vertical
+// ones are workgroup-uniform (scalar); per pixel that leaves four byte loads and a dozen integer operations.
+constexpr int RS_ROWS = 8;
+__global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict__ arena, uint8_t* __restrict__ out, uint32_t src_off, int sw,
+                                                       int sh, ResizeJobs jobs, size_t imageStride) {
     const ResizeJob jb = jobs.j[blockIdx.y];
-    const int npix = jb.dw * jb.dh;
     const uint8_t* src = arena + (size_t)blockIdx.z * imageStride + src_off;   // blockIdx.z = frame of a multi-frame pyramid
     uint8_t* dst = out + (size_t)blockIdx.z * imageStride + jb.dst_off;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
-        int dy = i / jb.dw, dx = i - dy * jb.dw;
+    const int colBlocks = (jb.dw + 255) / 256, rowBands = (jb.dh + RS_ROWS - 1) / RS_ROWS;
+    for (int t = blockIdx.x; t < colBlocks * rowBands; t += gridDim.x) {
+        const int band = t / colBlocks, cb = t - band * colBlocks;
+        const int dx = cb * 256 + threadIdx.x;
+        if (dx >= jb.dw) continue;
         float fx = (float)((dx + 0.5) * jb.scale_x - 0.5);
         int sx = (int)floorf(fx);
         fx -= sx;
         if (sx < 0) { fx = 0; sx = 0; }
         if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
-        int a0 = __float2int_rn((1.f - fx) * 2048), a1 = __float2int_rn(fx * 2048);
-        float fy = (float)((dy + 0.5) * jb.scale_y - 0.5);
-        int sy = (int)floorf(fy);
-        fy -= sy;
-        int b0 = __float2int_rn((1.f - fy) * 2048), b1 = __float2int_rn(fy * 2048);
-        int y0 = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);
-        int y1 = sy + 1 < 0 ? 0 : (sy + 1 >= sh ? sh - 1 : sy + 1);
-        int sx1 = sx + 1 < sw ? sx + 1 : sx;
-        const uint8_t* S0 = src + (size_t)y0 * sw;
-        const uint8_t* S1 = src + (size_t)y1 * sw;
-        int r0 = S0[sx] * a0 + S0[sx1] * a1;
-        int r1 = S1[sx] * a0 + S1[sx1] * a1;
-        dst[i] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+        const int a0 = __float2int_rn((1.f - fx) * 2048), a1 = __float2int_rn(fx * 2048);
+        const int sx1 = sx + 1 < sw ? sx + 1 : sx;
+        const int dyEnd = min(jb.dh, (band + 1) * RS_ROWS);
+        for (int dy = band * RS_ROWS; dy < dyEnd; ++dy) {
+            float fy = (float)((dy + 0.5) * jb.scale_y - 0.5);
+            int sy = (int)floorf(fy);
+            fy -= sy;
+            const int b0 = __float2int_rn((1.f - fy) * 2048), b1 = __float2int_rn(fy * 2048);
+            const int y0 = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);
+            const int y1 = sy + 1 < 0 ? 0 : (sy + 1 >= sh ? sh - 1 : sy + 1);
+            const uint8_t* S0 = src + (size_t)y0 * sw;
+            const uint8_t* S1 = src + (size_t)y1 * sw;
+            const int r0 = S0[sx] * a0 + S0[sx1] * a1;
+            const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+            dst[(size_t)dy * jb.dw + dx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+        }
     }
 }
 
-// cv::pyrDown 8UC1: separable [1 4 6 4 1], (sum + 128) >> 8, BORDER_REFLECT_101
-__global__ void k_pyrdown(uint8_t* __restrict__ arena, DownJobs jobs, size_t imageStride) {
+// cv::pyrDown 8UC1: separable [1 4 6 4 1], (sum + 128) >> 8, BORDER_REFLECT_101.  A thread computes PD_ROWS vertically adjacent
+// outputs of one column: the 2 * PD_ROWS + 3 horizontal 5-tap sums it needs are formed once each (55 loads for 4 outputs instead
+// of 100).
+constexpr int PD_ROWS = 4;
+__global__ __launch_bounds__(256) void k_pyrdown(uint8_t* __restrict__ arena, DownJobs jobs, size_t imageStride) {
     const DownJob jb = jobs.j[blockIdx.y];
     const int dw = (jb.sw + 1) / 2, dh = (jb.sh + 1) / 2;
     arena += (size_t)blockIdx.z * imageStride;   // blockIdx.z = frame of a multi-frame pyramid
     const uint8_t* src = arena + jb.src_off;
     uint8_t* dst = arena + jb.dst_off;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dw * dh; i += gridDim.x * blockDim.x) {
-        int y = i / dw, x = i - y * dw;
-        int xs[5], ys[5];
+    const int bands = (dh + PD_ROWS - 1) / PD_ROWS;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dw * bands; i += gridDim.x * blockDim.x) {
+        const int band = i / dw, x = i - band * dw;
+        const int y0 = band * PD_ROWS;
+        int xs[5];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            xs[k] = reflect101(2 * x - 2 + k, jb.sw);
-            ys[k] = reflect101(2 * y - 2 + k, jb.sh);
-        }
-        int rows[5];
+        for (int k = 0; k < 5; ++k) xs[k] = reflect101(2 * x - 2 + k, jb.sw);
+        int h[2 * PD_ROWS + 3];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const uint8_t* S = src + (size_t)ys[k] * jb.sw;
-            rows[k] = S[xs[2]] * 6 + (S[xs[1]] + S[xs[3]]) * 4 + S[xs[0]] + S[xs[4]];
+        for (int r = 0; r < 2 * PD_ROWS + 3; ++r) {
+            const uint8_t* S = src + (size_t)reflect101(2 * y0 - 2 + r, jb.sh) * jb.sw;
+            h[r] = S[xs[2]] * 6 + (S[xs[1]] + S[xs[3]]) * 4 + S[xs[0]] + S[xs[4]];
         }
-        int v = rows[2] * 6 + (rows[1] + rows[3]) * 4 + rows[0] + rows[4];
-        dst[i] = (uint8_t)((v + 128) >> 8);
+#pragma unroll
+        for (int j = 0; j < PD_ROWS; ++j) {
+            if (y0 + j < dh) {
+                const int v = h[2 * j + 2] * 6 + (h[2 * j + 1] + h[2 * j + 3]) * 4 + h[2 * j] + h[2 * j + 4];
+                dst[(size_t)(y0 + j) * dw + x] = (uint8_t)((v + 128) >> 8);
+            }
+        }
     }
 }
 

@@ -1399,7 +1399,7 @@ static void wvm_build_dense(fd_wvm* m, const fd_wvm_model* md) {
     std::memset(&C, 0, sizeof(C));
     m->denseScale = std::ldexp(1.0, -sh);
     // k-step = one patch row (two rows for 16-wide patches): slot t of step ks is pixel (ks * RPS + t / pw, t % pw)
-    const int RPS = pw == 16 ? 2 : 1;
+    const int RPS = WvdGeo<16>::RPS == 2 && pw == 16 ? 2 : 1;   // must match the kernel's k-step geometry
     if (ph % RPS != 0) return;
     const int KS = ph / RPS;
     std::vector<int8_t> B((size_t)KS * 2 * 64 * 16, 0);

@@ -70,13 +70,19 @@ namespace {
 
 template <int PW_>
 struct WvdGeo {
-    static constexpr int RPS = PW_ == 16 ? 2 : 1;   // patch rows per k-step (32 k-slots)
+#ifndef FD_WVD_RPS16
+#define FD_WVD_RPS16 2
+#endif
+    // patch rows per k-step (32 k-slots).  Two 16-wide rows fill a step; one row per step (FD_WVD_RPS16=1) needs fewer
+    // registers (4 instead of 3 wavefronts per SIMD) but twice the steps -- measured equal (0.806 vs 0.794 ms, 16x24 ear
+    // detector at 1080p), so the two-row form stays
+    static constexpr int RPS = PW_ == 16 ? FD_WVD_RPS16 : 1;
 #ifndef FD_WVD_WPE
 #define FD_WVD_WPE 4
 #endif
     // wavefronts per SIMD the register allocation aims at (LDS allows 4 workgroups = 16 wavefronts per CU): at 128 VGPRs the
     // two-row k-step of the 16-wide patches spills 1 KB, the others ~140 B
-    static constexpr int WPE = PW_ == 16 ? 3 : FD_WVD_WPE;
+    static constexpr int WPE = (PW_ == 16 && RPS == 2) ? 3 : FD_WVD_WPE;
 };
 
 // LDS of a workgroup (4 wavefronts).  Every wavefront's histogram block is 8 KB-aligned so that (bin << 7) | (block + lane slot)

@@ -22,7 +22,7 @@ if [ "$WHAT" = stats ] || [ "$WHAT" = all ]; then
 fi
 if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
   for wl in cascade ffp15 sdm hog_svm; do
-    S=3; FP=""; [ $wl = cascade ] && FP="--frames-per-step 16"; [ $wl = ffp15 ] && S=2; [ $wl = sdm ] && FP="--frames-per-step 2"; [ $wl = hog_svm ] && FP="--frames-per-step 4"
+    S=3; FP=""; [ $wl = cascade ] && FP="--frames-per-step 64"; [ $wl = ffp15 ] && S=2; [ $wl = sdm ] && FP="--frames-per-step 2"; [ $wl = hog_svm ] && FP="--frames-per-step 4"
     CMD="$B --workload $wl --also none --steps $S --warmup 1 $FP --no-cpu-baseline"
     i=0
     for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" \
