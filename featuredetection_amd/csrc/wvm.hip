@@ -41,6 +41,7 @@ constexpr int WVM_MAX_VALS = 16;     // grey values per filter
 constexpr int WVM_FIRST_CHUNK = 4096;  // positives fetched together with the counter
 constexpr int WVM_LCAP = 16;         // filters evaluated by the one-wave-per-window stage; survivors go to k_wvm_deep
 constexpr int WVM_PJ = 5;            // up to 320 filters (largest cfg-implied WVM: 280)
+constexpr int WVM_SVS = 17;          // stride of a class's grey-value sums in k_wvm_deepB (odd: lane == class reads are conflict-free)
 
 struct WinLayerDev {
     int32_t bx, by, nx, ny;
@@ -92,6 +93,14 @@ struct WvmDev {
     const uint8_t* rectV;      // grey-value index v (>= 1) of each rect
     const uint4* lvlRec;       // [numFilters][64]: lane l -> {rect l, v tag of rect l, val[l] (double bits)}
     const struct WvmLevelHdr* lvlHdr;   // [numFilters]
+    // generation-major tables of k_wvm_deepB (generation g = filters g * numPer .. g * numPer + numPer - 1; numPer <= 32)
+    const uint2* genRec;       // all rects of a generation, class by class: {rect, class * WVM_SVS + grey-value index}; 64 zero records appended
+    const int32_t* genBegin;   // [generations + 1] into genRec
+    const int32_t* genMaxCnt;  // [generations] largest grey-value count of the generation
+    const int32_t* cntG;       // [generations][32] grey-value count of class n
+    const double* ppG;         // [generations][32]
+    const double* valG;        // [generations][16][32]: val[v] of class n
+    int32_t maxCnt;            // largest grey-value count of the model
 };
 
 struct PosRec {
@@ -103,7 +112,7 @@ struct PosRec {
 struct fd_wvm {
     fd_ctx* ctx;
     WvmDev dev;
-    DevBuf thresholds, wT, pp, valOff, val, rectBegin, rects, rectV, lvlRec, lvlHdr;
+    DevBuf thresholds, wT, pp, valOff, val, rectBegin, rects, rectV, lvlRec, lvlHdr, genRec, genBegin, genMaxCnt, cntG, ppG, valG;
     double logisticA, logisticB;
     std::vector<float> h_thresholds;
     // scratch reused across calls
@@ -1078,6 +1087,19 @@ __global__ __launch_bounds__(64 * NW) void k_wvm_deep(const uint8_t* __restrict_
 // four filters; val[v] / the grey-value sums reach the lanes of their quarter by DPP row broadcasts.  With numPer <= 16 a
 // whole generation of filters is in flight at once in four waves, so the serial chain of a surviving window is one filter
 // evaluation per generation.
+#ifdef FD_DEEP4_PROF
+__device__ unsigned long long fd_deep4_prof[16];
+extern "C" void fd_debug_deep4_prof(unsigned long long* out, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(fd_deep4_prof), sizeof(fd_deep4_prof));
+    if (reset) { unsigned long long z[16] = {}; hipMemcpyToSymbol(HIP_SYMBOL(fd_deep4_prof), z, sizeof(z)); }
+}
+#define FD_PROF_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define FD_PROF_ADD(i, v) do { if (threadIdx.x == 0) atomicAdd(&fd_deep4_prof[i], (unsigned long long)(v)); } while (0)
+#else
+#define FD_PROF_T(var)
+#define FD_PROF_ADD(i, v)
+#endif
 template <int PW_, int PH_, bool RAW, int NW>
 __global__ __launch_bounds__(64 * NW) void k_wvm_deep4(const uint8_t* __restrict__ arena, WinTable wt, WvmDev m, CascadeOut o) {
     constexpr int RHMAX = Geo<PW_, PH_>::RHMAX;
@@ -1104,6 +1126,7 @@ __global__ __launch_bounds__(64 * NW) void k_wvm_deep4(const uint8_t* __restrict
     const unsigned int ndeep = *o.deep_count;
 
     for (unsigned int qi = blockIdx.x; qi < ndeep; qi += gridDim.x) {
+        FD_PROF_T(tp0);
         const int64_t wid = o.deep_q[qi];
         int srcStride;
         const uint8_t* src = wvm_locate<RAW>(arena, wt, sFirst, wid, lane, g.pw, g.d, srcStride);
@@ -1114,6 +1137,9 @@ __global__ __launch_bounds__(64 * NW) void k_wvm_deep4(const uint8_t* __restrict
         wvm_prepare<PW_, PH_, RAW>(g, src, srcStride, m.stretch, lane, hist[wave], ii, px, sxx, sx_total);
         if (threadIdx.x == 0) sExit = ~0ull;
         __syncthreads();
+        FD_PROF_T(tp1);
+        FD_PROF_ADD(0, 1);
+        FD_PROF_ADD(1, tp1 - tp0);
 
         float u[MAXR];   // u_kernel_eval of this quarter's class in each round
 #pragma unroll
@@ -1126,6 +1152,7 @@ __global__ __launch_bounds__(64 * NW) void k_wvm_deep4(const uint8_t* __restrict
         int* svq = sv[wave][q];
         for (int c0 = 0; c0 < NU; c0 += chunk) {
             const int c1 = min(c0 + chunk, NU);
+            FD_PROF_T(tc0);
             // ---- kernel values of this wave's filters in [c0, c1): generation by generation, four classes per round
             for (int gbase = c0; gbase < c1; gbase += NP) {
 #pragma unroll
@@ -1191,7 +1218,9 @@ __global__ __launch_bounds__(64 * NW) void k_wvm_deep4(const uint8_t* __restrict
                     wave_sync();
                 }
             }
+            FD_PROF_T(tc1);
             __syncthreads();
+            FD_PROF_T(tc2);
             // ---- hierarchical sums: add the chunk's terms to every owned level >= c0; check the levels inside the chunk
 #pragma unroll
             for (int ow = 0; ow < MAXOWN; ++ow) {
@@ -1216,7 +1245,14 @@ __global__ __launch_bounds__(64 * NW) void k_wvm_deep4(const uint8_t* __restrict
                     if (lane == e) atomicMin(&sExit, ((unsigned long long)(unsigned int)mm << 32) | (unsigned int)__float_as_int(P));
                 }
             }
+            FD_PROF_T(tc3);
             __syncthreads();
+            FD_PROF_T(tc4);
+            FD_PROF_ADD(2, 1);
+            FD_PROF_ADD(3, tc1 - tc0);
+            FD_PROF_ADD(4, tc2 - tc1);
+            FD_PROF_ADD(5, tc3 - tc2);
+            FD_PROF_ADD(6, tc4 - tc3);
             const unsigned long long ex = sExit;
             if (ex != ~0ull) {
                 level = (int)(ex >> 32);
@@ -1224,7 +1260,190 @@ __global__ __launch_bounds__(64 * NW) void k_wvm_deep4(const uint8_t* __restrict
                 break;
             }
         }
+        FD_PROF_T(te0);
         if (wave == 0) wvm_emit<PW_, PH_>(g, m, o, wid, lane, level, fout, m.thresholds[level], px);
+        __syncthreads();
+        FD_PROF_T(te1);
+        FD_PROF_ADD(7, te1 - te0);
+        FD_PROF_ADD(8, te1 - tp0);
+        FD_PROF_ADD(9, level + 1);
+    }
+    wvm_finalize(o);
+}
+
+// ---- stage B, four windows per workgroup ---------------------------------------------------------------
+// Every window that reaches stage B behind the dense pre-filter runs deep (measured: all of them to the last level with the
+// bench models), so the cost that matters is the full-length evaluation.  In-kernel timestamps of k_wvm_deep4 put 60-65 % of it
+// into the kernel values -- mostly the wave-uniform fp64 chain + exp, issued once per FOUR filters -- and 27 % into the
+// hierarchical sums, whose weight matrix (numFilters^2 / 2 floats) every window re-read from L2.  Here a workgroup takes four
+// windows in lockstep:
+//   * wave b owns window b: it prepares it (no redundant HistEq64 / integral image), and evaluates ALL filters of a generation for it
+//     -- rect sums with lane == rect over the generation's flattened rect list (records prefetched one pass ahead), then the
+//     fp64 chain + exp once per generation with lane == class (the reference's order per class: WvmClassifier.cpp:308-346);
+//     no cross-wave synchronisation inside a chunk;
+//   * the hierarchical sums keep the block ownership (wave w owns the 64-level blocks w, w + 4, lane == level) but add each weight
+//     to the sums of all four windows: one weight load and one 16-byte LDS broadcast of the four kernel values per term.
+// A window that leaves early idles its wave until the batch is done (the exit bookkeeping is per window).
+// MAXV: compile-time bound of the grey values per filter (8 or 16, chosen by the model): val[] of the class lives in registers.
+template <int PW_, int PH_, bool RAW, int MAXV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_ == 0 ? 2 : 4, 8))) void k_wvm_deepB(const uint8_t* __restrict__ arena, WinTable wt, WvmDev m, CascadeOut o) {
+    constexpr int RHMAX = Geo<PW_, PH_>::RHMAX;
+    constexpr int MAXOWN = (WVM_PJ + 3) / 4;
+    __shared__ unsigned int ii[4][Geo<PW_, PH_>::IISZ];
+    __shared__ unsigned int hist[4][64];
+    __shared__ int sv[4][32 * WVM_SVS];
+    __shared__ float4 kh4[64 * WVM_PJ];   // kernel values: component b = window b
+    __shared__ int64_t sFirst[WVM_MAX_LAYERS];
+    __shared__ unsigned long long sExit[4];   // per window: (first failed level << 32 | fp32 bits of its sum)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cls = lane & 31;
+    const Geo<PW_, PH_> g(m, lane);
+    const int F = m.numFilters, NU = m.numUsed, NP = m.numPer;
+    const int chunk = max(1, 64 / NP) * NP;
+    const int pw = g.pw;
+    int* svw = sv[wave];
+    float* khf = reinterpret_cast<float*>(kh4);
+
+    if (!RAW && threadIdx.x < WVM_MAX_LAYERS) sFirst[threadIdx.x] = (int)threadIdx.x < wt.n ? wt.l[threadIdx.x].first : INT64_MAX;
+    for (int i = lane; i < 32 * WVM_SVS; i += 64) svw[i] = 0;
+    __syncthreads();
+    const unsigned int ndeep = *o.deep_count;
+    const unsigned int nbatch = (ndeep + 3) >> 2;
+
+    for (unsigned int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+        const unsigned int qi = batch * 4 + wave;
+        const bool valid = qi < ndeep;                       // wave-uniform
+        const int64_t wid = o.deep_q[valid ? qi : batch * 4];
+        int srcStride;
+        const uint8_t* src = wvm_locate<RAW>(arena, wt, sFirst, wid, lane, g.pw, g.d, srcStride);
+        unsigned int px[RHMAX];
+        float sxx;
+        int sx_total;
+        wvm_prepare<PW_, PH_, RAW>(g, src, srcStride, m.stretch, lane, hist[wave], ii[wave], px, sxx, sx_total);
+        if (lane == 0) sExit[wave] = ~0ull;
+        const unsigned int* iiw = ii[wave];
+
+        float u = 0.f;   // lane n (< numPer): u_kernel_eval of class n
+        float P[MAXOWN][4];
+#pragma unroll
+        for (int ow = 0; ow < MAXOWN; ++ow)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) P[ow][b] = m.negBias;
+        bool alive = valid;
+        int level = NU - 1;
+        float fout = 0.f;
+        for (int c0 = 0; c0 < NU; c0 += chunk) {
+            const int c1 = min(c0 + chunk, NU);
+            if (alive) {
+                int gi = c0 / NP;
+                uint2 nxt = m.genRec[m.genBegin[gi] + lane];
+                for (int gbase = c0; gbase < c1; gbase += NP, ++gi) {
+                    // ---- chain constants of the generation: requested now, consumed after the rect passes
+                    const int k = gbase + cls;
+                    const bool act = lane < NP && k < c1;
+                    const int maxCnt = __builtin_amdgcn_readfirstlane(m.genMaxCnt[gi]);
+                    const int cnt = act ? m.cntG[gi * 32 + cls] : 0;
+                    const double ppv = m.ppG[gi * 32 + cls];
+                    double valr[MAXV];
+#pragma unroll
+                    for (int v = 0; v < MAXV; ++v) valr[v] = v < maxCnt ? m.valG[((size_t)gi * 16 + v) * 32 + cls] : 0.0;
+                    // ---- rect sums of all classes of the generation: lane == rect
+                    const int rb0 = __builtin_amdgcn_readfirstlane(m.genBegin[gi]), rb1 = __builtin_amdgcn_readfirstlane(m.genBegin[gi + 1]);
+                    for (int jb = rb0; jb < rb1; jb += 64) {
+                        const uint2 rec = nxt;
+                        nxt = m.genRec[(jb + 64 < rb1 ? jb + 64 : rb1) + lane];
+                        if (jb + lane < rb1) {
+                            const unsigned int rc = rec.x;
+                            const int x1 = rc & 255, y1 = (rc >> 8) & 255, x2 = (rc >> 16) & 255, y2 = rc >> 24;
+                            int sm = (int)iiw[y2 * pw + x2];
+                            if (x1 > 0) sm -= (int)iiw[y2 * pw + x1 - 1];
+                            if (y1 > 0) sm -= (int)iiw[(y1 - 1) * pw + x2];
+                            if (x1 > 0 && y1 > 0) sm += (int)iiw[(y1 - 1) * pw + x1 - 1];
+                            atomicAdd(&svw[rec.y], sm);
+                        }
+                    }
+                    wave_sync();
+                    // ---- the reference's scalar chain, lane == class (lanes 32-63 idle); the sums are cleared as they are read
+                    if (lane < 32) {
+                        int* svn = svw + cls * WVM_SVS;
+                        double sum_xp = 0.0;
+                        int sumv0 = sx_total;
+#pragma unroll
+                        for (int v = 1; v < MAXV; ++v) {
+                            if (v < maxCnt) {
+                                const int s_ = svn[v];
+                                svn[v] = 0;
+                                if (v < cnt) {
+                                    sumv0 -= s_;
+                                    const double prod = (double)s_ * valr[v];
+                                    sum_xp = sum_xp + prod;
+                                }
+                            }
+                        }
+                        const double t0 = (double)sumv0 * valr[0];
+                        sum_xp = sum_xp + t0;
+                        sum_xp = sum_xp + (double)u;
+                        const float unew = (float)sum_xp;
+                        double norm = (double)sxx;
+                        norm = norm - 2 * sum_xp;
+                        norm = norm + ppv;
+                        const float Kk = (float)exp((double)m.negBasis * norm);
+                        if (act) {
+                            u = unew;
+                            khf[k * 4 + wave] = Kk;
+                        }
+                    }
+                    wave_sync();
+                }
+            }
+            __syncthreads();
+            // ---- hierarchical sums of the four windows: add the chunk's terms to every owned level >= c0; check the levels inside
+#pragma unroll
+            for (int ow = 0; ow < MAXOWN; ++ow) {
+                const int blk = wave + ow * 4;
+                if (blk * 64 >= NU || blk * 64 + 63 < c0) continue;   // nothing owned here / already decided
+                const int mm = blk * 64 + lane;
+                const float* wq = m.wT + mm + (size_t)c0 * F;
+                float P0 = P[ow][0], P1 = P[ow][1], P2 = P[ow][2], P3 = P[ow][3];
+#pragma unroll 8
+                for (int i = c0; i < c1; ++i, wq += F) {
+                    const float w_ = *wq;
+                    const float4 k4 = kh4[i];
+                    const float t0 = w_ * k4.x, t1 = w_ * k4.y, t2 = w_ * k4.z, t3 = w_ * k4.w;
+                    P0 = P0 + t0;
+                    P1 = P1 + t1;
+                    P2 = P2 + t2;
+                    P3 = P3 + t3;
+                }
+                P[ow][0] = P0; P[ow][1] = P1; P[ow][2] = P2; P[ow][3] = P3;
+                const bool mine = mm >= c0 && mm < c1;
+                const float thrm = mine ? m.thresholds[mm] : 0.f;
+                const bool last = !(mm + 1 < NU);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float Pb = P[ow][b];
+                    const bool fail = mine && (!(Pb >= thrm) || last);
+                    const unsigned long long fm = __ballot(fail);
+                    if (fm) {
+                        const int e = __builtin_ctzll(fm);
+                        if (lane == e) atomicMin(&sExit[b], ((unsigned long long)(unsigned int)mm << 32) | (unsigned int)__float_as_int(Pb));
+                    }
+                }
+            }
+            __syncthreads();
+            const unsigned long long ex = sExit[wave];
+            if (alive && ex != ~0ull) {
+                level = (int)(ex >> 32);
+                fout = __int_as_float((int)(unsigned int)ex);
+                alive = false;
+            }
+            bool allDone = true;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) allDone = allDone && (batch * 4 + b >= ndeep || sExit[b] != ~0ull);
+            if (allDone) break;
+        }
+        if (valid) wvm_emit<PW_, PH_>(g, m, o, wid, lane, level, fout, m.thresholds[level], px);
         __syncthreads();
     }
     wvm_finalize(o);
@@ -1316,6 +1535,21 @@ void launch_sized(fd_ctx* ctx, hipStream_t st, int64_t total, const WvmDev& dev,
     }
     static const char* nwEnv = getenv("FD_WVM_DEEP_WAVES");
     static const bool deepOld = getenv("FD_WVM_DEEP_OLD") != nullptr;
+    static const bool deep4Env = getenv("FD_WVM_DEEP4") != nullptr;
+    if (dev.numPer <= 32 && !deepOld && !deep4Env && dev.genRec) {   // four windows per workgroup, one wave per window
+        if (dev.maxCnt <= 8) {
+            static int perCuB = 0;
+            if (perCuB == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuB, k_wvm_deepB<PW_, PH_, RAW, 8>, 256, 0) != hipSuccess || perCuB < 1)) perCuB = 2;
+            const int gridB = (int)std::min<int64_t>((total + 3) / 4, (int64_t)ctx->num_cus * perCuB);
+            hipLaunchKernelGGL((k_wvm_deepB<PW_, PH_, RAW, 8>), dim3(gridB), dim3(256), 0, st, arena, wt, dev, o);
+        } else {
+            static int perCuB = 0;
+            if (perCuB == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuB, k_wvm_deepB<PW_, PH_, RAW, WVM_MAX_VALS>, 256, 0) != hipSuccess || perCuB < 1)) perCuB = 2;
+            const int gridB = (int)std::min<int64_t>((total + 3) / 4, (int64_t)ctx->num_cus * perCuB);
+            hipLaunchKernelGGL((k_wvm_deepB<PW_, PH_, RAW, WVM_MAX_VALS>), dim3(gridB), dim3(256), 0, st, arena, wt, dev, o);
+        }
+        return;
+    }
     if (dev.numPer <= 32 && !deepOld) {   // four filters per wavefront, four waves per surviving window
         static int perCuQ = 0;
         if (perCuQ == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuQ, k_wvm_deep4<PW_, PH_, RAW, 4>, 256, 0) != hipSuccess || perCuQ < 1)) perCuQ = 2;
@@ -1779,6 +2013,38 @@ int fd_wvm_create(fd_ctx* ctx, const fd_wvm_model* md, fd_wvm** out) {
             up(m->lvlHdr, hdr.data(), sizeof(WvmLevelHdr) * hdr.size());
         }
         WvmDev& d = m->dev;
+        if (md->num_per_level >= 1 && md->num_per_level <= 32) {   // generation-major tables (k_wvm_deepB)
+            const int NP = md->num_per_level, G = (F + NP - 1) / NP;
+            std::vector<uint32_t> grec;
+            std::vector<int32_t> gbeg(G + 1), gmax(G, 1), cntg((size_t)G * 32, 0);
+            std::vector<double> ppg((size_t)G * 32, 0.0), valg((size_t)G * 16 * 32, 0.0);
+            for (int g = 0; g < G; ++g) {
+                gbeg[g] = (int32_t)(grec.size() / 2);
+                for (int n = 0; n < NP && g * NP + n < F; ++n) {
+                    const int k = g * NP + n;
+                    const int v0 = md->val_off[k], cntval = md->val_off[k + 1] - v0;
+                    gmax[g] = std::max(gmax[g], cntval);
+                    cntg[(size_t)g * 32 + n] = cntval;
+                    ppg[(size_t)g * 32 + n] = md->pp[k];
+                    for (int v = 0; v < cntval; ++v) valg[((size_t)g * 16 + v) * 32 + n] = md->val[v0 + v];
+                    for (int r = rectBegin[k]; r < rectBegin[k + 1]; ++r) {
+                        grec.push_back(rects[r]);
+                        grec.push_back((uint32_t)(n * WVM_SVS + rectV[r]));
+                    }
+                }
+            }
+            gbeg[G] = (int32_t)(grec.size() / 2);
+            grec.resize(grec.size() + 2 * 64, 0u);   // the record prefetch runs one pass ahead
+            up(m->genRec, grec.data(), sizeof(uint32_t) * grec.size());
+            up(m->genBegin, gbeg.data(), sizeof(int32_t) * gbeg.size());
+            up(m->genMaxCnt, gmax.data(), sizeof(int32_t) * gmax.size());
+            up(m->cntG, cntg.data(), sizeof(int32_t) * cntg.size());
+            up(m->ppG, ppg.data(), sizeof(double) * ppg.size());
+            up(m->valG, valg.data(), sizeof(double) * valg.size());
+            d.genRec = m->genRec.as<uint2>(); d.genBegin = m->genBegin.as<int32_t>(); d.genMaxCnt = m->genMaxCnt.as<int32_t>();
+            d.cntG = m->cntG.as<int32_t>(); d.ppG = m->ppG.as<double>(); d.valG = m->valG.as<double>();
+            d.maxCnt = *std::max_element(gmax.begin(), gmax.end());
+        }
         d.fw = md->filter_w; d.fh = md->filter_h; d.d = md->filter_w * md->filter_h;
         d.numFilters = F;
         d.numUsed = (md->num_used > F || md->num_used <= 0) ? F : md->num_used;  // WvmClassifier.cpp:151-158
