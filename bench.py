@@ -182,9 +182,10 @@ class Cascade(Workload):
         self.svm = capi.Svm(ctx, self.svm_m)
         self.slots, self.flying, self.ncalls = [], [], 0
         if self.multi:
-            # two calls in flight, each on its own context (stream), multi-frame pyramid and handles: the cascade run of one call
-            # overlaps the host stages (overlap elimination, NMS) of the other
-            for k in range(2):
+            # six calls in flight, each on its own context (stream), multi-frame pyramid and handles: the library runs the host
+            # stages of a call (overlap elimination, SVM launch, NMS) on its queue threads behind the cascade kernels, so this thread
+            # only queues kernels and collects finished calls
+            for k in range(max(1, int(os.environ.get("FD_BENCH_SLOTS", "6")))):
                 c_ = ctx if k == 0 else capi.Context(env.local_rank)
                 mp = capi.Pyramid(c_, **kw)
                 mp.set_frames(self.NB)
@@ -215,7 +216,7 @@ class Cascade(Workload):
                 ptrs = [self.dframes[(base + c * NB + j) % self.NFR].data_ptr() for j in range(NB)]
                 sl["pyr"].update_frames(device_ptrs=ptrs, w=self.W, h=self.H, ch=3)
                 sl["run"] = capi.FiveStageFrames(sl["ctx"], sl["pyr"], sl["wvm"], sl["svm"], NB)
-                sl["ids"] = [(base + c * NB + j) * self.env.world + self.env.rank for j in range(NB)]
+                sl["ids"] = (base + c * NB + np.arange(NB)) * self.env.world + self.env.rank
                 continue
             else:
                 fr = [(self.dframes[(base + c * NB + j) % self.NFR].data_ptr(), self.W, self.H, 3) for j in range(NB)]
@@ -225,8 +226,9 @@ class Cascade(Workload):
         return self.nwin * self.FP, out
 
     def _collect(self, sl):
-        res, sl["run"] = sl["run"].end(), None
-        return [(img, 0, d_) for img, (d_, _) in zip(sl["ids"], res)]
+        # one record block per call: (image id of every detection, detector 0, the detections of the call's frames in frame order)
+        (dets, fidx, _), sl["run"] = sl["run"].end_flat(), None
+        return [(sl["ids"][fidx], 0, dets)]
 
     def flush(self):
         out = []
@@ -709,7 +711,9 @@ def measure(wl, env, steps, warmup, gather_every, want_cpu):
         if (i + 1) % gather_every == 0 or i + 1 == steps:
             pending.extend(wl.flush())
             # the detection records of this rank's images since the last gather: real fd_detection fields
-            recs = [parallel.pack_records(np.full(len(d_), img), np.full(len(d_), det), d_) for img, det, d_ in pending if len(d_)]
+            # (image id(s), detector id, detections): the ids are scalars (one image) or one id per detection (a multi-frame call)
+            recs = [parallel.pack_records(img if isinstance(img, np.ndarray) else np.full(len(d_), img), np.full(len(d_), det), d_)
+                    for img, det, d_ in pending if len(d_)]
             local = np.concatenate(recs) if recs else np.zeros((0, parallel.RECORD_FIELDS))
             ndet += len(local)
             if world > 1:

@@ -502,6 +502,16 @@ class FiveStageFrames:
         self.ctx.check(lib().fd_detect_five_stage_frames_end(self.ctx.h, t, _ptr(out), self.cap, _ptr(counts), _ptr(stages)))
         return [(out[f, :counts[f]].copy(), stages[f].copy()) for f in range(self.nframes)]
 
+    def end_flat(self):
+        """as end(), but one array for the call: (detections of all frames in frame order, frame index of each, stage_counts[frames, 4])"""
+        out = np.empty((self.nframes, self.cap), DET_DTYPE)
+        counts = np.zeros(self.nframes, np.int32)
+        stages = np.zeros((self.nframes, 4), np.int32)
+        t, self.ticket = self.ticket, C.c_void_p()
+        self.ctx.check(lib().fd_detect_five_stage_frames_end(self.ctx.h, t, _ptr(out), self.cap, _ptr(counts), _ptr(stages)))
+        mask = np.arange(self.cap)[None, :] < counts[:, None]
+        return out[mask], np.repeat(np.arange(self.nframes), counts), stages
+
 
 def _five_stage_jobs(detectors, oe_dist, oe_ratio, sx, sy, cap, device_frames):
     n = len(detectors)

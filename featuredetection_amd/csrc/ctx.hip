@@ -89,3 +89,12 @@ int fd_last_kernel_ms(fd_ctx* ctx, const char** kernel_name, float* ms) {
 }
 
 }  // extern "C"
+
+FdAsyncQueue& fd_async_queue() {
+    static FdAsyncQueue q([] {
+        const char* e = getenv("FD_ASYNC_THREADS");
+        const int n = e ? atoi(e) : 2;
+        return n < 1 ? 1 : (n > 16 ? 16 : n);
+    }());
+    return q;
+}

@@ -17,6 +17,8 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <deque>
+#include <exception>
 #include "../../include/fd_hip.h"
 #include "../../include/fd_hip_bench.h"
 
@@ -77,6 +79,70 @@ struct FdWorkerPool {
         for (auto& t : th) t.join();
     }
 };
+
+// Process-wide queue of host continuations (a few persistent threads, FD_ASYNC_THREADS, default 2): the ticket entry points
+// (fd_detect_five_stage_frames_begin) hand the host stages that follow their kernels -- wait, order the positives, overlap
+// elimination, SVM launch, wait, NMS -- to it, so the calling thread is free to queue the next call's kernels and the GPU never waits
+// for a host stage of one call while another call has work ready.  submit() returns a handle; wait() rethrows the task's exception.
+struct FdAsyncTask {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    std::exception_ptr error;
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done; });
+        if (error) std::rethrow_exception(error);
+    }
+};
+struct FdAsyncQueue {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::pair<std::function<void()>, std::shared_ptr<FdAsyncTask>>> q;
+    bool stop = false;
+    explicit FdAsyncQueue(int n) {
+        for (int i = 0; i < n; ++i) th.emplace_back([this] { loop(); });
+    }
+    void loop() {
+        for (;;) {
+            std::pair<std::function<void()>, std::shared_ptr<FdAsyncTask>> item;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !q.empty(); });
+                if (q.empty()) return;   // stop requested and nothing left
+                item = std::move(q.front());
+                q.pop_front();
+            }
+            std::exception_ptr err;
+            try { item.first(); } catch (...) { err = std::current_exception(); }
+            {
+                std::lock_guard<std::mutex> lk(item.second->mu);
+                item.second->error = err;
+                item.second->done = true;
+            }
+            item.second->cv.notify_all();
+        }
+    }
+    std::shared_ptr<FdAsyncTask> submit(std::function<void()> f) {
+        auto t = std::make_shared<FdAsyncTask>();
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            q.emplace_back(std::move(f), t);
+        }
+        cv.notify_one();
+        return t;
+    }
+    ~FdAsyncQueue() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+};
+FdAsyncQueue& fd_async_queue();   // ctx.hip
 
 struct fd_ctx {
     int device = 0;

@@ -57,17 +57,43 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 struct FramePtrs {
     const uint8_t* p[FD_MAX_FRAMES];
 };
-// the frames of a multi-frame pyramid: BGR -> gray (ch == 3) or copy (ch == 1) into frame blockIdx.y's arena
+__device__ __forceinline__ uint32_t ld_u32_unaligned(const uint8_t* p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ uint32_t gray_of(uint32_t b, uint32_t g, uint32_t r) { return (b * 1868u + g * 9617u + r * 4899u + 8192u) >> 14; }
+
+// the frames of a multi-frame pyramid: BGR -> gray (ch == 3) or copy (ch == 1) into frame blockIdx.y's arena.  Four pixels per
+// thread: three dword loads, one dword store (the stage is bound by the number of memory instructions, not by their bytes).
 __global__ void k_frames_to_gray(FramePtrs frames, uint8_t* __restrict__ grayBase, size_t imageStride, int n, int ch) {
     const uint8_t* __restrict__ src = frames.p[blockIdx.y];
     uint8_t* __restrict__ gray = grayBase + (size_t)blockIdx.y * imageStride;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int nq = n >> 2;
+    const bool aligned = ((uintptr_t)src & 3) == 0;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
         if (ch == 3) {
-            int b = src[3 * (size_t)i], g = src[3 * (size_t)i + 1], r = src[3 * (size_t)i + 2];
-            gray[i] = (uint8_t)((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14);
+            uint32_t w0, w1, w2;
+            if (aligned) {
+                const uint32_t* s3 = reinterpret_cast<const uint32_t*>(src) + 3 * (size_t)q;
+                w0 = s3[0]; w1 = s3[1]; w2 = s3[2];
+            } else {
+                const uint8_t* s1 = src + 12 * (size_t)q;
+                w0 = ld_u32_unaligned(s1); w1 = ld_u32_unaligned(s1 + 4); w2 = ld_u32_unaligned(s1 + 8);
+            }
+            // bytes: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+            const uint32_t g0 = gray_of(w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u);
+            const uint32_t g1 = gray_of(w0 >> 24, w1 & 255u, (w1 >> 8) & 255u);
+            const uint32_t g2 = gray_of((w1 >> 16) & 255u, w1 >> 24, w2 & 255u);
+            const uint32_t g3 = gray_of((w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24);
+            reinterpret_cast<uint32_t*>(gray)[q] = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
         } else {
-            gray[i] = src[i];
+            reinterpret_cast<uint32_t*>(gray)[q] = ld_u32_unaligned(src + 4 * (size_t)q);
         }
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < (n & 3)) {   // tail
+        const int i = (nq << 2) + threadIdx.x;
+        gray[i] = ch == 3 ? (uint8_t)gray_of(src[3 * (size_t)i], src[3 * (size_t)i + 1], src[3 * (size_t)i + 2]) : src[i];
     }
 }
 
@@ -148,6 +174,145 @@ __global__ __launch_bounds__(256) void k_pyrdown(uint8_t* __restrict__ arena, Do
                 dst[(size_t)(y0 + j) * dw + x] = (uint8_t)((v + 128) >> 8);
             }
         }
+    }
+}
+
+// ---- LDS-tiled versions of the two kernels above -------------------------------------------------------------------------
+// The direct kernels issue four (resize) / 14 (pyrDown) byte loads per output pixel and are bound by the number of memory
+// instructions.  Here a workgroup stages the source rectangle of a 64 x 16 output tile in LDS with dword loads (unaligned where
+// the row start is) and every tap is an LDS byte read; the arithmetic is the same, value for value.
+constexpr int TL_W = 64, TL_H = 16, TL_PITCH = 136, TL_ROWS = 36;
+
+// resize: valid while a tile's source rectangle fits, i.e. scale_x, scale_y <= 2.05 (first-octave layers: 1 <= scale < 2)
+__global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict__ arena, uint8_t* __restrict__ out, uint32_t src_off, int sw,
+                                                      int sh, ResizeJobs jobs, size_t imageStride) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[TL_ROWS * TL_PITCH];
+    __shared__ int4 rowTab[TL_H];   // per dst row of the tile: LDS offsets of its two source rows, vertical weights
+    const ResizeJob jb = jobs.j[blockIdx.y];
+    const uint8_t* src = arena + (size_t)blockIdx.z * imageStride + src_off;   // blockIdx.z = frame of a multi-frame pyramid
+    uint8_t* dst = out + (size_t)blockIdx.z * imageStride + jb.dst_off;
+    const int tilesX = (jb.dw + TL_W - 1) / TL_W, tilesY = (jb.dh + TL_H - 1) / TL_H;
+    auto srcX = [&](int dx, float& fx) {   // cv::resize: left source column of dst column dx and its fraction
+        fx = (float)((dx + 0.5) * jb.scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        return sx;
+    };
+    auto srcY = [&](int dy, float& fy) {
+        fy = (float)((dy + 0.5) * jb.scale_y - 0.5);
+        const int sy = (int)floorf(fy);
+        fy -= sy;
+        return sy;
+    };
+    auto clampY = [&](int y) { return y < 0 ? 0 : (y >= sh ? sh - 1 : y); };
+    const int c = threadIdx.x & 63, rq = threadIdx.x >> 6;
+    for (int t = blockIdx.x; t < tilesX * tilesY; t += gridDim.x) {
+        const int ty = t / tilesX, tx = t - ty * tilesX;
+        const int dx0 = tx * TL_W, dy0 = ty * TL_H;
+        const int dxl = min(dx0 + TL_W, jb.dw) - 1, dyl = min(dy0 + TL_H, jb.dh) - 1;
+        float f_;
+        const int X0 = srcX(dx0, f_);
+        const int xl = srcX(dxl, f_);
+        const int X1 = xl + 1 < sw ? xl + 1 : xl;
+        const int Y0 = clampY(srcY(dy0, f_)), Y1 = clampY(srcY(dyl, f_) + 1);
+        const int ndw = (X1 - X0 + 4) >> 2, nrows = Y1 - Y0 + 1;
+        for (int e = threadIdx.x; e < nrows * ndw; e += 256) {
+            const int r = e / ndw, j = e - r * ndw;
+            const int x = X0 + 4 * j;
+            const uint8_t* gp = src + (size_t)(Y0 + r) * sw + x;
+            uint32_t v;
+            if (x + 3 < sw) {
+                v = ld_u32_unaligned(gp);
+            } else {   // right edge of the image: never past the row
+                v = 0;
+                for (int b = 0; b < 4; ++b) v |= (uint32_t)src[(size_t)(Y0 + r) * sw + min(x + b, sw - 1)] << (8 * b);
+            }
+            *reinterpret_cast<uint32_t*>(&tile[r * TL_PITCH + 4 * j]) = v;
+        }
+        if (threadIdx.x < TL_H) {   // vertical taps of the tile's rows, once per tile instead of once per thread and row
+            float fy;
+            const int sy = srcY(dy0 + threadIdx.x, fy);
+            rowTab[threadIdx.x] = make_int4((clampY(sy) - Y0) * TL_PITCH, (clampY(sy + 1) - Y0) * TL_PITCH, __float2int_rn((1.f - fy) * 2048),
+                                            __float2int_rn(fy * 2048));
+        }
+        __syncthreads();
+        const int dx = dx0 + c;
+        if (dx < jb.dw) {
+            float fx;
+            const int sx = srcX(dx, fx);
+            const int a0 = __float2int_rn((1.f - fx) * 2048), a1 = __float2int_rn(fx * 2048);
+            const int lx = sx - X0, lx1 = (sx + 1 < sw ? sx + 1 : sx) - X0;
+#pragma unroll
+            for (int k = 0; k < TL_H / 4; ++k) {
+                const int rr = rq * (TL_H / 4) + k;
+                const int dy = dy0 + rr;
+                if (dy < jb.dh) {
+                    const int4 rt = rowTab[rr];
+                    const uint8_t* S0 = tile + rt.x;
+                    const uint8_t* S1 = tile + rt.y;
+                    const int r0 = S0[lx] * a0 + S0[lx1] * a1;
+                    const int r1 = S1[lx] * a0 + S1[lx1] * a1;
+                    dst[(size_t)dy * jb.dw + dx] = (uint8_t)((((rt.z * (r0 >> 4)) >> 16) + ((rt.w * (r1 >> 4)) >> 16) + 2) >> 2);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pyrdown_tiled(uint8_t* __restrict__ arena, DownJobs jobs, size_t imageStride) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[TL_ROWS * TL_PITCH];
+    const DownJob jb = jobs.j[blockIdx.y];
+    const int sw = jb.sw, sh = jb.sh;
+    const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+    arena += (size_t)blockIdx.z * imageStride;   // blockIdx.z = frame of a multi-frame pyramid
+    const uint8_t* src = arena + jb.src_off;
+    uint8_t* dst = arena + jb.dst_off;
+    const int tilesX = (dw + TL_W - 1) / TL_W, tilesY = (dh + TL_H - 1) / TL_H;
+    const int c = threadIdx.x & 63, rq = threadIdx.x >> 6;
+    constexpr int NDW = (2 * TL_W + 3 + 3) / 4, NROWS = 2 * TL_H + 3;   // 131 source columns, 35 source rows per tile
+    for (int t = blockIdx.x; t < tilesX * tilesY; t += gridDim.x) {
+        const int ty = t / tilesX, tx = t - ty * tilesX;
+        const int dx0 = tx * TL_W, dy0 = ty * TL_H;
+        const int X0 = 2 * dx0 - 2, Y0 = 2 * dy0 - 2;
+        for (int e = threadIdx.x; e < NROWS * NDW; e += 256) {
+            const int r = e / NDW, j = e - r * NDW;
+            const int x = X0 + 4 * j;
+            const uint8_t* row = src + (size_t)reflect101(Y0 + r, sh) * sw;
+            uint32_t v;
+            if (x >= 0 && x + 3 < sw) {
+                v = ld_u32_unaligned(row + x);
+            } else {   // BORDER_REFLECT_101 columns
+                v = 0;
+                for (int b = 0; b < 4; ++b) v |= (uint32_t)row[reflect101(x + b, sw)] << (8 * b);
+            }
+            *reinterpret_cast<uint32_t*>(&tile[r * TL_PITCH + 4 * j]) = v;
+        }
+        __syncthreads();
+        const int x = dx0 + c;
+        if (x < dw) {
+            constexpr int PR = TL_H / 4;   // output rows per thread
+            const uint8_t* T = tile + (2 * rq * PR) * TL_PITCH + 2 * c;
+            int h[2 * PR + 3];
+#pragma unroll
+            for (int r = 0; r < 2 * PR + 3; ++r) {
+                const uint8_t* S = T + r * TL_PITCH;
+                const uint32_t p01 = *reinterpret_cast<const uint16_t*>(S), p23 = *reinterpret_cast<const uint16_t*>(S + 2);
+                const int s0 = p01 & 255u, s1 = p01 >> 8, s2 = p23 & 255u, s3 = p23 >> 8, s4 = S[4];
+                h[r] = s2 * 6 + (s1 + s3) * 4 + s0 + s4;
+            }
+#pragma unroll
+            for (int j = 0; j < PR; ++j) {
+                const int y = dy0 + rq * PR + j;
+                if (y < dh) {
+                    const int v = h[2 * j + 2] * 6 + (h[2 * j + 1] + h[2 * j + 3]) * 4 + h[2 * j] + h[2 * j + 4];
+                    dst[(size_t)y * dw + x] = (uint8_t)((v + 128) >> 8);
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -397,6 +562,7 @@ void build_layout(fd_pyramid* p, int W, int H) {
 }
 
 int grid_for(int npix) { return std::max(1, std::min(1024, (npix + 255) / 256)); }
+int tile_grid_for(int ntiles) { return std::max(1, std::min(1024, ntiles)); }
 
 void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, int is_device, hipStream_t st, const uint8_t* const* frames = nullptr) {
     if (!image && !frames) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_update: image is NULL");
@@ -420,7 +586,7 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
         } else {
             for (int f = 0; f < NI; ++f) fp.p[f] = frames[f];
         }
-        hipLaunchKernelGGL(k_frames_to_gray, dim3(grid_for((int)npix), NI), dim3(256), 0, st, fp, arena + p->gray_full_off, IS, (int)npix, ch);
+        hipLaunchKernelGGL(k_frames_to_gray, dim3(grid_for((int)(npix / 4 + 1)), NI), dim3(256), 0, st, fp, arena + p->gray_full_off, IS, (int)npix, ch);
     } else {
         const uint8_t* dimg = image;
         if (!is_device) {
@@ -440,12 +606,18 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
     {
         ResizeJobs jobs;
         jobs.n = 0;
-        int maxpix = 0;
+        int maxpix = 0, maxtiles = 0;
         auto flush = [&]() {
             if (!jobs.n) return;
-            hipLaunchKernelGGL(k_resize_linear, dim3(grid_for(maxpix), jobs.n, NI), dim3(256), 0, st, arena, arena, p->gray_full_off, W, H, jobs, IS);
+            bool fits = true;   // the tiled kernel stages at most TL_ROWS x TL_PITCH source bytes per 64 x 16 tile
+            for (int q = 0; q < jobs.n; ++q) fits = fits && jobs.j[q].scale_x <= 2.05 && jobs.j[q].scale_y <= 2.05;
+            if (fits)
+                hipLaunchKernelGGL(k_resize_tiled, dim3(tile_grid_for(maxtiles), jobs.n, NI), dim3(256), 0, st, arena, arena, p->gray_full_off, W, H, jobs, IS);
+            else
+                hipLaunchKernelGGL(k_resize_linear, dim3(grid_for(maxpix), jobs.n, NI), dim3(256), 0, st, arena, arena, p->gray_full_off, W, H, jobs, IS);
             jobs.n = 0;
             maxpix = 0;
+            maxtiles = 0;
         };
         for (const HostLayer& L : p->all) {
             if (L.depth != 0) continue;
@@ -454,6 +626,7 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
             j.scale_x = 1. / ((double)L.w / W);
             j.scale_y = 1. / ((double)L.h / H);
             maxpix = std::max(maxpix, L.w * L.h);
+            maxtiles = std::max(maxtiles, ((L.w + TL_W - 1) / TL_W) * ((L.h + TL_H - 1) / TL_H));
             if (jobs.n == MAXJ) flush();
         }
         flush();
@@ -461,12 +634,13 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
     for (int d = 1; d <= maxDepth; ++d) {
         DownJobs jobs;
         jobs.n = 0;
-        int maxpix = 0;
+        int maxpix = 0, maxtiles = 0;
         auto flush = [&]() {
             if (!jobs.n) return;
-            hipLaunchKernelGGL(k_pyrdown, dim3(grid_for(maxpix), jobs.n, NI), dim3(256), 0, st, arena, jobs, IS);
+            hipLaunchKernelGGL(k_pyrdown_tiled, dim3(tile_grid_for(maxtiles), jobs.n, NI), dim3(256), 0, st, arena, jobs, IS);
             jobs.n = 0;
             maxpix = 0;
+            maxtiles = 0;
         };
         for (size_t k = 0; k < p->all.size(); ++k) {
             const HostLayer& L = p->all[k];
@@ -475,6 +649,7 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
             DownJob& j = jobs.j[jobs.n++];
             j.sw = S.w; j.sh = S.h; j.src_off = S.gray_off; j.dst_off = L.gray_off;
             maxpix = std::max(maxpix, L.w * L.h);
+            maxtiles = std::max(maxtiles, ((L.w + TL_W - 1) / TL_W) * ((L.h + TL_H - 1) / TL_H));
             if (jobs.n == MAXJ) flush();
         }
         flush();

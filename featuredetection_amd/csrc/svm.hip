@@ -33,7 +33,7 @@ static inline size_t frag_index(int64_t row, int k, int KP) {
 
 struct SvmDev {
     int32_t kernel, nsv, dim, dtype;
-    int32_t dpad;            // generic path: row stride in elements (u8: multiple of 4, f32: == dim)
+    int32_t dpad;            // generic path: row stride in elements (u8: multiple of 16, f32: == dim)
     double p0, p1;
     int32_t degree;
     float bias;
@@ -41,7 +41,7 @@ struct SvmDev {
     const float* coeff;      // [nsv]
     const uint32_t* ss_u32;  // u8 rbf: sum of squares per SV
     int32_t nsvp;            // u8: nsv padded to a multiple of 64
-    const uint32_t* svT;     // u8: [dpad/4][nsvp], word i of support vector s at svT[i*nsvp + s]
+    const uint32_t* svT;     // u8: [dpad/16][nsvp][4]: words 4q..4q+3 of support vector s at svT[(q*nsvp + s)*4 ..] (one 16-byte load per lane)
     const float* coeffP;     // u8: [nsvp], zero padded
     const uint32_t* ssP;     // u8: [nsvp]
     // MFMA path (f32 RBF)
@@ -166,8 +166,10 @@ __global__ __launch_bounds__(256) void k_svm_generic(SvmDev m, const void* __res
 // vectors is one coalesced 256-byte access; every lane finishes its own kernel value (exp in fp64),
 // so the transcendental runs 64-wide instead of on one lane per support vector.  Integer SSD /
 // min-sum / dot stay exact (RbfKernel.hpp:78-88, HistogramIntersectionKernel.hpp:60-72).
-constexpr int SU_PB = 2;   // feature vectors per workgroup (each fetched support-vector word is used SU_PB times)
-template <bool HIK>
+// SU_PB feature vectors per workgroup: each fetched support-vector word is used SU_PB times.  The kernel is bound by the L2 traffic of
+// the support vectors (all of them once per workgroup), so large batches take 8 per workgroup (the multi-frame cascade scores
+// thousands of patches per launch), small ones 2 to keep enough workgroups in flight; the arithmetic per vector is the same.
+template <bool HIK, int SU_PB>
 __global__ __launch_bounds__(256) void k_svm_u8_lanes(SvmDev m, const void* __restrict__ features, const uint32_t* __restrict__ idx,
                                                       int64_t feat_stride_bytes, int64_t n, double* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -186,33 +188,40 @@ __global__ __launch_bounds__(256) void k_svm_u8_lanes(SvmDev m, const void* __re
     }
     __syncthreads();
     const uint32_t* xs = (const uint32_t*)smem;
-    if (wave < SU_PB) {
+    for (int p = wave; p < SU_PB; p += 4) {
         int xxp = 0;
-        for (int i = lane; i < nd; i += 64) xxp = __builtin_amdgcn_udot4(xs[wave * nd + i], xs[wave * nd + i], xxp, false);
+        for (int i = lane; i < nd; i += 64) xxp = __builtin_amdgcn_udot4(xs[p * nd + i], xs[p * nd + i], xxp, false);
         xxp = wave_sum_i(xxp);
-        if (lane == 0) xxs[wave] = xxp;
+        if (lane == 0) xxs[p] = xxp;
     }
     __syncthreads();
     double acc[SU_PB];
 #pragma unroll
     for (int p = 0; p < SU_PB; ++p) acc[p] = 0.0;
+    const uint4* xs4 = reinterpret_cast<const uint4*>(smem);
+    const int nq = nd >> 2;
     for (int s0 = wave * 64; s0 < m.nsvp; s0 += 256) {
         const int s = s0 + lane;
-        const uint32_t* colp = m.svT + s;
+        const uint4* colp = reinterpret_cast<const uint4*>(m.svT) + s;
         int dot[SU_PB];
 #pragma unroll
         for (int p = 0; p < SU_PB; ++p) dot[p] = 0;
 #pragma unroll 4
-        for (int i = 0; i < nd; ++i) {
-            const uint32_t b = colp[(size_t)i * m.nsvp];
+        for (int i = 0; i < nq; ++i) {
+            const uint4 b = colp[(size_t)i * m.nsvp];
 #pragma unroll
             for (int p = 0; p < SU_PB; ++p) {
-                const uint32_t a = xs[p * nd + i];
+                const uint4 a = xs4[p * nq + i];
                 if (HIK) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) dot[p] += (int)min((a >> (8 * q)) & 255u, (b >> (8 * q)) & 255u);
+                    for (int q = 0; q < 4; ++q)
+                        dot[p] += (int)min((a.x >> (8 * q)) & 255u, (b.x >> (8 * q)) & 255u) + (int)min((a.y >> (8 * q)) & 255u, (b.y >> (8 * q)) & 255u) +
+                                  (int)min((a.z >> (8 * q)) & 255u, (b.z >> (8 * q)) & 255u) + (int)min((a.w >> (8 * q)) & 255u, (b.w >> (8 * q)) & 255u);
                 } else {
-                    dot[p] = __builtin_amdgcn_udot4(a, b, dot[p], false);
+                    dot[p] = __builtin_amdgcn_udot4(a.x, b.x, dot[p], false);
+                    dot[p] = __builtin_amdgcn_udot4(a.y, b.y, dot[p], false);
+                    dot[p] = __builtin_amdgcn_udot4(a.z, b.z, dot[p], false);
+                    dot[p] = __builtin_amdgcn_udot4(a.w, b.w, dot[p], false);
                 }
             }
         }
@@ -541,14 +550,17 @@ void fd_svm_generic_launch_on(hipStream_t st, const fd_svm* m, const void* dfeat
                               int64_t n, double* dout) {
     if (n <= 0) return;
     if (m->dev.dtype == FD_DTYPE_U8) {
-        const size_t lb = (size_t)SU_PB * m->dev.dpad;
+        const int pb = n >= 16384 ? 8 : (n >= 8192 ? 4 : 2);   // measured: 4 per workgroup at n ~ 2000-4000 is slower than 2 (fewer workgroups)
+        const size_t lb = (size_t)pb * m->dev.dpad;
         if (lb > 64 * 1024) FD_THROW(FD_ERR_INVALID_ARGUMENT, "feature vector too long (%d)", m->dev.dim);
-        const unsigned grid = (unsigned)((n + SU_PB - 1) / SU_PB);
-        if (m->dev.kernel == FD_KERNEL_HIK)
-            hipLaunchKernelGGL(k_svm_u8_lanes<true>, dim3(grid), dim3(256), lb, st, m->dev, dfeat, didx, stride_bytes, n, dout);
-        else
-            hipLaunchKernelGGL(k_svm_u8_lanes<false>, dim3(grid), dim3(256), lb, st, m->dev, dfeat, didx, stride_bytes, n, dout);
-        HIP_CHECK(hipGetLastError());
+        const unsigned grid = (unsigned)((n + pb - 1) / pb);
+#define FD_SVM_U8(H, P) hipLaunchKernelGGL((k_svm_u8_lanes<H, P>), dim3(grid), dim3(256), lb, st, m->dev, dfeat, didx, stride_bytes, n, dout)
+        if (m->dev.kernel == FD_KERNEL_HIK) {
+            if (pb == 8) FD_SVM_U8(true, 8); else if (pb == 4) FD_SVM_U8(true, 4); else FD_SVM_U8(true, 2);
+        } else {
+            if (pb == 8) FD_SVM_U8(false, 8); else if (pb == 4) FD_SVM_U8(false, 4); else FD_SVM_U8(false, 2);
+        }
+#undef FD_SVM_U8
         return;
     }
     const size_t ldsBytes = m->dev.dtype == FD_DTYPE_U8 ? (size_t)m->dev.dpad : (size_t)m->dev.dim * 4;
@@ -584,7 +596,7 @@ int fd_svm_create(fd_ctx* ctx, const fd_svm_model* md, fd_svm** out) {
         up(m->coeff, md->coefficients, sizeof(float) * d.nsv);
         d.coeff = m->coeff.as<float>();
         if (d.dtype == FD_DTYPE_U8) {
-            d.dpad = (d.dim + 3) & ~3;
+            d.dpad = (d.dim + 15) & ~15;   // whole 16-byte groups: the lane == support-vector kernel fetches four words per load
             std::vector<uint8_t> sv((size_t)d.nsv * d.dpad, 0);
             std::vector<uint32_t> ss(d.nsv, 0);
             const uint8_t* src = (const uint8_t*)md->support_vectors;
@@ -607,7 +619,7 @@ int fd_svm_create(fd_ctx* ctx, const fd_svm_model* md, fd_svm** out) {
                     for (int i = 0; i < nd; ++i) {
                         uint32_t wv;
                         std::memcpy(&wv, &sv[(size_t)sI * d.dpad + 4 * i], 4);
-                        svT[(size_t)i * d.nsvp + sI] = wv;
+                        svT[((size_t)(i >> 2) * d.nsvp + sI) * 4 + (i & 3)] = wv;
                     }
                     ssP[sI] = ss[sI];
                     cP[sI] = md->coefficients[sI];

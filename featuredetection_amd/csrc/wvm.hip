@@ -41,6 +41,7 @@ constexpr int WVM_MAX_VALS = 16;     // grey values per filter
 constexpr int WVM_FIRST_CHUNK = 4096;  // positives fetched together with the counter
 constexpr int WVM_LCAP = 16;         // filters evaluated by the one-wave-per-window stage; survivors go to k_wvm_deep
 constexpr int WVM_PJ = 5;            // up to 320 filters (largest cfg-implied WVM: 280)
+constexpr int WVM_RECCAP = 1280;     // rect records of a chunk staged in LDS by k_wvm_deepB
 constexpr int WVM_SVS = 17;          // stride of a class's grey-value sums in k_wvm_deepB (odd: lane == class reads are conflict-free)
 
 struct WinLayerDev {
@@ -94,13 +95,18 @@ struct WvmDev {
     const uint4* lvlRec;       // [numFilters][64]: lane l -> {rect l, v tag of rect l, val[l] (double bits)}
     const struct WvmLevelHdr* lvlHdr;   // [numFilters]
     // generation-major tables of k_wvm_deepB (generation g = filters g * numPer .. g * numPer + numPer - 1; numPer <= 32)
-    const uint2* genRec;       // all rects of a generation, class by class: {rect, class * WVM_SVS + grey-value index}; 64 zero records appended
+    // all rects of a generation, class by class; 64 zero records appended.  x = A | B << 12 | tag[7:0] << 24, y = C | D << 12 | tag[9:8] << 24:
+    // sum = I[A] - I[B] - I[C] + I[D] in the zero-padded integral image, tag = class * WVM_SVS + grey-value index
+    const uint2* genRec;
     const int32_t* genBegin;   // [generations + 1] into genRec
     const int32_t* genMaxCnt;  // [generations] largest grey-value count of the generation
     const int32_t* cntG;       // [generations][32] grey-value count of class n
     const double* ppG;         // [generations][32]
     const double* valG;        // [generations][16][32]: val[v] of class n
     int32_t maxCnt;            // largest grey-value count of the model
+    // wT again, four terms per load: wP[(p / 4) * Fp + k] = {wT[p][k], wT[p + 1][k], wT[p + 2][k], wT[p + 3][k]}, p a multiple of 4
+    const float4* wP;
+    int32_t Fp;                // row length of wP (numFilters rounded up to 64, + 64)
 };
 
 struct PosRec {
@@ -112,7 +118,7 @@ struct PosRec {
 struct fd_wvm {
     fd_ctx* ctx;
     WvmDev dev;
-    DevBuf thresholds, wT, pp, valOff, val, rectBegin, rects, rectV, lvlRec, lvlHdr, genRec, genBegin, genMaxCnt, cntG, ppG, valG;
+    DevBuf thresholds, wT, pp, valOff, val, rectBegin, rects, rectV, lvlRec, lvlHdr, genRec, genBegin, genMaxCnt, cntG, ppG, valG, wP;
     double logisticA, logisticB;
     std::vector<float> h_thresholds;
     // scratch reused across calls
@@ -222,7 +228,9 @@ __device__ __forceinline__ const uint8_t* wvm_locate(const uint8_t* arena, const
 // and sum of squares (IImg.cpp:22-47).  Everything runs on registers + DPP; only the histogram and the
 // finished integral image go through LDS.  On return px[] holds the equalised patch, ii the integral
 // image (visible to this wave).
-template <int PW_, int PH_, bool RAW>
+// PAD: the integral image is stored with a zero row and column in front ((pw + 1) x (ph + 1) entries, row 0 / column 0 are left
+// untouched: the caller zeroes them once), so a rect sum is four unconditional reads.
+template <int PW_, int PH_, bool RAW, bool PAD = false>
 __device__ __forceinline__ void wvm_prepare(const Geo<PW_, PH_>& g, const uint8_t* src, int srcStride, float stretch, int lane,
                                             unsigned int* hist, unsigned int* ii,
                                             unsigned int (&px)[Geo<PW_, PH_>::RHMAX], float& sxx, int& sx_total) {
@@ -281,7 +289,7 @@ __device__ __forceinline__ void wvm_prepare(const Geo<PW_, PH_>& g, const uint8_
     if (g.colok) {
 #pragma unroll
         for (int j = 0; j < RHMAX; ++j)
-            if (g.rowok(j)) ii[(g.r0 + j) * g.pw + g.col] = (unsigned int)(s[j] + topTotal);
+            if (g.rowok(j)) ii[PAD ? (g.r0 + j + 1) * (g.pw + 1) + g.col + 1 : (g.r0 + j) * g.pw + g.col] = (unsigned int)(s[j] + topTotal);
     }
     // sum of squares: last column, fp32, row by row (IImg.cpp:33-47)
     sxx = (float)qTop[0];
@@ -292,7 +300,7 @@ __device__ __forceinline__ void wvm_prepare(const Geo<PW_, PH_>& g, const uint8_
     for (int j = 0; j < RHMAX; ++j)
         if (j < g.rh && g.rh + j < g.ph) sxx = sxx + (float)qBot[j];
     wave_sync();
-    sx_total = (int)ii[(g.ph - 1) * g.pw + (g.pw - 1)];
+    sx_total = (int)ii[PAD ? g.ph * (g.pw + 1) + g.pw : (g.ph - 1) * g.pw + (g.pw - 1)];
 }
 
 // Kernel value of one filter (WvmClassifier.cpp:190-350, linEvalWvmHisteq64): rect sums of the level
@@ -1095,10 +1103,14 @@ extern "C" void fd_debug_deep4_prof(unsigned long long* out, int reset) {
     if (reset) { unsigned long long z[16] = {}; hipMemcpyToSymbol(HIP_SYMBOL(fd_deep4_prof), z, sizeof(z)); }
 }
 #define FD_PROF_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#define FD_PROF_ADD(i, v) do { if (threadIdx.x == 0) atomicAdd(&fd_deep4_prof[i], (unsigned long long)(v)); } while (0)
+#define FD_PROF_DECL unsigned long long prof_acc[13] = {}
+#define FD_PROF_ADD(i, v) prof_acc[i] += (unsigned long long)(v)   /* registers; flushed once per batch */
+#define FD_PROF_FLUSH do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 13; ++i_) { atomicAdd(&fd_deep4_prof[i_], prof_acc[i_]); } } for (int i_ = 0; i_ < 13; ++i_) prof_acc[i_] = 0; } while (0)
 #else
 #define FD_PROF_T(var)
 #define FD_PROF_ADD(i, v)
+#define FD_PROF_DECL
+#define FD_PROF_FLUSH
 #endif
 template <int PW_, int PH_, bool RAW, int NW>
 __global__ __launch_bounds__(64 * NW) void k_wvm_deep4(const uint8_t* __restrict__ arena, WinTable wt, WvmDev m, CascadeOut o) {
@@ -1126,7 +1138,6 @@ __global__ __launch_bounds__(64 * NW) void k_wvm_deep4(const uint8_t* __restrict
     const unsigned int ndeep = *o.deep_count;
 
     for (unsigned int qi = blockIdx.x; qi < ndeep; qi += gridDim.x) {
-        FD_PROF_T(tp0);
         const int64_t wid = o.deep_q[qi];
         int srcStride;
         const uint8_t* src = wvm_locate<RAW>(arena, wt, sFirst, wid, lane, g.pw, g.d, srcStride);
@@ -1137,9 +1148,6 @@ __global__ __launch_bounds__(64 * NW) void k_wvm_deep4(const uint8_t* __restrict
         wvm_prepare<PW_, PH_, RAW>(g, src, srcStride, m.stretch, lane, hist[wave], ii, px, sxx, sx_total);
         if (threadIdx.x == 0) sExit = ~0ull;
         __syncthreads();
-        FD_PROF_T(tp1);
-        FD_PROF_ADD(0, 1);
-        FD_PROF_ADD(1, tp1 - tp0);
 
         float u[MAXR];   // u_kernel_eval of this quarter's class in each round
 #pragma unroll
@@ -1152,7 +1160,6 @@ __global__ __launch_bounds__(64 * NW) void k_wvm_deep4(const uint8_t* __restrict
         int* svq = sv[wave][q];
         for (int c0 = 0; c0 < NU; c0 += chunk) {
             const int c1 = min(c0 + chunk, NU);
-            FD_PROF_T(tc0);
             // ---- kernel values of this wave's filters in [c0, c1): generation by generation, four classes per round
             for (int gbase = c0; gbase < c1; gbase += NP) {
 #pragma unroll
@@ -1218,9 +1225,7 @@ __global__ __launch_bounds__(64 * NW) void k_wvm_deep4(const uint8_t* __restrict
                     wave_sync();
                 }
             }
-            FD_PROF_T(tc1);
             __syncthreads();
-            FD_PROF_T(tc2);
             // ---- hierarchical sums: add the chunk's terms to every owned level >= c0; check the levels inside the chunk
 #pragma unroll
             for (int ow = 0; ow < MAXOWN; ++ow) {
@@ -1245,14 +1250,7 @@ __global__ __launch_bounds__(64 * NW) void k_wvm_deep4(const uint8_t* __restrict
                     if (lane == e) atomicMin(&sExit, ((unsigned long long)(unsigned int)mm << 32) | (unsigned int)__float_as_int(P));
                 }
             }
-            FD_PROF_T(tc3);
             __syncthreads();
-            FD_PROF_T(tc4);
-            FD_PROF_ADD(2, 1);
-            FD_PROF_ADD(3, tc1 - tc0);
-            FD_PROF_ADD(4, tc2 - tc1);
-            FD_PROF_ADD(5, tc3 - tc2);
-            FD_PROF_ADD(6, tc4 - tc3);
             const unsigned long long ex = sExit;
             if (ex != ~0ull) {
                 level = (int)(ex >> 32);
@@ -1260,13 +1258,8 @@ __global__ __launch_bounds__(64 * NW) void k_wvm_deep4(const uint8_t* __restrict
                 break;
             }
         }
-        FD_PROF_T(te0);
         if (wave == 0) wvm_emit<PW_, PH_>(g, m, o, wid, lane, level, fout, m.thresholds[level], px);
         __syncthreads();
-        FD_PROF_T(te1);
-        FD_PROF_ADD(7, te1 - te0);
-        FD_PROF_ADD(8, te1 - tp0);
-        FD_PROF_ADD(9, level + 1);
     }
     wvm_finalize(o);
 }
@@ -1289,29 +1282,65 @@ template <int PW_, int PH_, bool RAW, int MAXV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_ == 0 ? 2 : 4, 8))) void k_wvm_deepB(const uint8_t* __restrict__ arena, WinTable wt, WvmDev m, CascadeOut o) {
     constexpr int RHMAX = Geo<PW_, PH_>::RHMAX;
     constexpr int MAXOWN = (WVM_PJ + 3) / 4;
-    __shared__ unsigned int ii[4][Geo<PW_, PH_>::IISZ];
+    constexpr int IIP = PW_ ? (PW_ + 1) * (PH_ + 1) : (WVM_MAX_DIM + 1) * (WVM_MAX_DIM + 1);
+    __shared__ unsigned int ii[4][IIP];     // zero-padded integral images
+    constexpr int RECCAP = (PW_ && IIP > 700) ? WVM_RECCAP * 3 / 5 : WVM_RECCAP;   // 32x24: keeps four workgroups per CU (LDS)
+    __shared__ uint2 recL[RECCAP];          // rect records of the chunk (the same for the four windows)
     __shared__ unsigned int hist[4][64];
     __shared__ int sv[4][32 * WVM_SVS];
     __shared__ float4 kh4[64 * WVM_PJ];   // kernel values: component b = window b
     __shared__ int64_t sFirst[WVM_MAX_LAYERS];
-    __shared__ unsigned long long sExit[4];   // per window: (first failed level << 32 | fp32 bits of its sum)
+    // per window: (first failed level << 32 | fp32 bits of its sum); two sets, alternating between batches: a wave may reset its entry
+    // for the next batch while the others still read the old one
+    __shared__ unsigned long long sExit2[2][4];
+    __shared__ double normL[4][64];         // exponents of the chunk's kernel values (exp runs once per chunk, lane == level)
+    __shared__ unsigned int patchL[4][(Geo<PW_, PH_>::IISZ + 3) / 4];   // equalised patch of a positive until its slot is known
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cls = lane & 31;
     const Geo<PW_, PH_> g(m, lane);
     const int F = m.numFilters, NU = m.numUsed, NP = m.numPer;
-    const int chunk = max(1, 64 / NP) * NP;
-    const int pw = g.pw;
+    const int gensPerChunk = max(1, 64 / NP), G = (F + NP - 1) / NP;
     int* svw = sv[wave];
     float* khf = reinterpret_cast<float*>(kh4);
+    // 64-level block ownership of the hierarchical sums, rotated between the workgroups that share a CU: wave w of every workgroup
+    // sits on SIMD w, and the owner of blocks 0 and 4 has up to twice the terms of the others
+    const int wown = (wave + (int)(blockIdx.x >> 8)) & 3;
+    // deferred write-out of a positive: the slot comes from a device-wide atomic (thousands of cycles under contention) that is issued
+    // at the end of a batch and consumed after the next window's preparation
+    bool pend = false;
+    unsigned int pendSlot = 0;
+    int64_t pendWid = 0;
+    int pendLevel = 0;
+    float pendFout = 0.f;
+    auto flushPending = [&]() {
+        if (!pend) return;
+        pend = false;
+        const unsigned int slot = (unsigned int)__builtin_amdgcn_readfirstlane((int)pendSlot);
+        if (slot >= o.pos_cap) return;
+        if (lane == 0) o.pos[slot] = PosRec{(uint32_t)pendWid, (uint32_t)(pendWid >> 32), pendLevel, pendFout};
+        uint8_t* dst = o.pos_patches + (size_t)slot * g.d;
+        if ((g.d & 3) == 0) {
+            for (int i = lane; i < (g.d >> 2); i += 64) reinterpret_cast<unsigned int*>(dst)[i] = patchL[wave][i];
+        } else {
+            const uint8_t* pb = reinterpret_cast<const uint8_t*>(patchL[wave]);
+            for (int i = lane; i < g.d; i += 64) dst[i] = pb[i];
+        }
+    };
 
     if (!RAW && threadIdx.x < WVM_MAX_LAYERS) sFirst[threadIdx.x] = (int)threadIdx.x < wt.n ? wt.l[threadIdx.x].first : INT64_MAX;
     for (int i = lane; i < 32 * WVM_SVS; i += 64) svw[i] = 0;
+    if (lane <= g.pw) ii[wave][lane] = 0;                          // row 0 and column 0 of the padded integral image stay zero
+    if (lane < g.ph) ii[wave][(lane + 1) * (g.pw + 1)] = 0;
     __syncthreads();
     const unsigned int ndeep = *o.deep_count;
     const unsigned int nbatch = (ndeep + 3) >> 2;
+    FD_PROF_DECL;
 
-    for (unsigned int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+    int parity = 0;
+    for (unsigned int batch = blockIdx.x; batch < nbatch; batch += gridDim.x, parity ^= 1) {
+        unsigned long long* sExit = sExit2[parity];
+        FD_PROF_T(tp0);
         const unsigned int qi = batch * 4 + wave;
         const bool valid = qi < ndeep;                       // wave-uniform
         const int64_t wid = o.deep_q[valid ? qi : batch * 4];
@@ -1320,9 +1349,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_ == 0 ? 
         unsigned int px[RHMAX];
         float sxx;
         int sx_total;
-        wvm_prepare<PW_, PH_, RAW>(g, src, srcStride, m.stretch, lane, hist[wave], ii[wave], px, sxx, sx_total);
+        wvm_prepare<PW_, PH_, RAW, true>(g, src, srcStride, m.stretch, lane, hist[wave], ii[wave], px, sxx, sx_total);
+        flushPending();
         if (lane == 0) sExit[wave] = ~0ull;
         const unsigned int* iiw = ii[wave];
+        FD_PROF_T(tp1);
+        FD_PROF_ADD(0, 1);
+        FD_PROF_ADD(1, tp1 - tp0);
 
         float u = 0.f;   // lane n (< numPer): u_kernel_eval of class n
         float P[MAXOWN][4];
@@ -1333,11 +1366,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_ == 0 ? 
         bool alive = valid;
         int level = NU - 1;
         float fout = 0.f;
-        for (int c0 = 0; c0 < NU; c0 += chunk) {
-            const int c1 = min(c0 + chunk, NU);
+        for (int c0 = 0, c1; c0 < NU; c0 = c1) {
+            // ---- chunk = as many generations (at most 64 levels) as have their rect records fit the LDS stage; the records are
+            // window-independent: one copy serves the four waves, and the passes below never wait for global memory
+            const int gi0 = c0 / NP;
+            const int r0 = __builtin_amdgcn_readfirstlane(m.genBegin[gi0]);
+            int gens = 0;
+            while (gens < gensPerChunk && gi0 + gens < G && m.genBegin[gi0 + gens + 1] - r0 <= RECCAP) ++gens;
+            const bool fits = gens > 0;       // else: a single generation with more rects than the stage holds, staged piecewise
+            if (!fits) gens = 1;
+            c1 = min(c0 + gens * NP, NU);
+            FD_PROF_T(tc0);
+            const int rEnd = __builtin_amdgcn_readfirstlane(m.genBegin[gi0 + gens]);
+            // rect sums of the staged records [jb0, jb1) (recL[0] = record `base`): lane == rect, four unconditional corner reads
+            auto rectPasses = [&](int jb0, int jb1, int base) {
+                for (int jb = jb0; jb < jb1; jb += 128) {   // two rects per lane and pass: eight independent corner reads in flight
+                    const int j0 = jb + lane, j1 = jb + 64 + lane;
+                    const uint2 ra = recL[min(j0, jb1 - 1) - base], rb = recL[min(j1, jb1 - 1) - base];
+                    const unsigned int sa = iiw[ra.x & 0xfffu] - iiw[(ra.x >> 12) & 0xfffu] - iiw[ra.y & 0xfffu] + iiw[(ra.y >> 12) & 0xfffu];
+                    const unsigned int sb = iiw[rb.x & 0xfffu] - iiw[(rb.x >> 12) & 0xfffu] - iiw[rb.y & 0xfffu] + iiw[(rb.y >> 12) & 0xfffu];
+                    if (j0 < jb1) atomicAdd(&svw[(ra.x >> 24) | ((ra.y >> 24) << 8)], (int)sa);
+                    if (j1 < jb1) atomicAdd(&svw[(rb.x >> 24) | ((rb.y >> 24) << 8)], (int)sb);
+                }
+            };
+            if (fits) {
+                for (int i = threadIdx.x; i < rEnd - r0; i += 256) recL[i] = m.genRec[r0 + i];
+                __syncthreads();
+            } else {
+                for (int sub = r0; sub < rEnd; sub += RECCAP) {
+                    const int subEnd = min(sub + RECCAP, rEnd);
+                    for (int i = threadIdx.x; i < subEnd - sub; i += 256) recL[i] = m.genRec[sub + i];
+                    __syncthreads();
+                    if (alive) rectPasses(sub, subEnd, sub);
+                    __syncthreads();
+                }
+            }
             if (alive) {
-                int gi = c0 / NP;
-                uint2 nxt = m.genRec[m.genBegin[gi] + lane];
+                int gi = gi0;
                 for (int gbase = c0; gbase < c1; gbase += NP, ++gi) {
                     // ---- chain constants of the generation: requested now, consumed after the rect passes
                     const int k = gbase + cls;
@@ -1348,22 +1413,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_ == 0 ? 
                     double valr[MAXV];
 #pragma unroll
                     for (int v = 0; v < MAXV; ++v) valr[v] = v < maxCnt ? m.valG[((size_t)gi * 16 + v) * 32 + cls] : 0.0;
-                    // ---- rect sums of all classes of the generation: lane == rect
-                    const int rb0 = __builtin_amdgcn_readfirstlane(m.genBegin[gi]), rb1 = __builtin_amdgcn_readfirstlane(m.genBegin[gi + 1]);
-                    for (int jb = rb0; jb < rb1; jb += 64) {
-                        const uint2 rec = nxt;
-                        nxt = m.genRec[(jb + 64 < rb1 ? jb + 64 : rb1) + lane];
-                        if (jb + lane < rb1) {
-                            const unsigned int rc = rec.x;
-                            const int x1 = rc & 255, y1 = (rc >> 8) & 255, x2 = (rc >> 16) & 255, y2 = rc >> 24;
-                            int sm = (int)iiw[y2 * pw + x2];
-                            if (x1 > 0) sm -= (int)iiw[y2 * pw + x1 - 1];
-                            if (y1 > 0) sm -= (int)iiw[(y1 - 1) * pw + x2];
-                            if (x1 > 0 && y1 > 0) sm += (int)iiw[(y1 - 1) * pw + x1 - 1];
-                            atomicAdd(&svw[rec.y], sm);
-                        }
-                    }
+                    FD_PROF_T(tr0);
+                    if (fits) rectPasses(__builtin_amdgcn_readfirstlane(m.genBegin[gi]), __builtin_amdgcn_readfirstlane(m.genBegin[gi + 1]), r0);
                     wave_sync();
+                    FD_PROF_T(tr1);
                     // ---- the reference's scalar chain, lane == class (lanes 32-63 idle); the sums are cleared as they are read
                     if (lane < 32) {
                         int* svn = svw + cls * WVM_SVS;
@@ -1388,34 +1441,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_ == 0 ? 
                         double norm = (double)sxx;
                         norm = norm - 2 * sum_xp;
                         norm = norm + ppv;
-                        const float Kk = (float)exp((double)m.negBasis * norm);
                         if (act) {
                             u = unew;
-                            khf[k * 4 + wave] = Kk;
+                            normL[wave][k - c0] = norm;
                         }
                     }
                     wave_sync();
+                    FD_PROF_T(tr2);
+                    FD_PROF_ADD(10, tr1 - tr0);
+                    FD_PROF_ADD(11, tr2 - tr1);
+                    FD_PROF_ADD(12, 1);
                 }
+                // ---- the chunk's kernel values: one exp per level, lane == level (off the u_kernel_eval dependency chain)
+                if (lane < c1 - c0) khf[(c0 + lane) * 4 + wave] = (float)exp((double)m.negBasis * normL[wave][lane]);
             }
+            FD_PROF_T(tc1);
             __syncthreads();
+            FD_PROF_T(tc2);
             // ---- hierarchical sums of the four windows: add the chunk's terms to every owned level >= c0; check the levels inside
 #pragma unroll
             for (int ow = 0; ow < MAXOWN; ++ow) {
-                const int blk = wave + ow * 4;
+                const int blk = wown + ow * 4;
                 if (blk * 64 >= NU || blk * 64 + 63 < c0) continue;   // nothing owned here / already decided
                 const int mm = blk * 64 + lane;
-                const float* wq = m.wT + mm + (size_t)c0 * F;
                 float P0 = P[ow][0], P1 = P[ow][1], P2 = P[ow][2], P3 = P[ow][3];
-#pragma unroll 8
-                for (int i = c0; i < c1; ++i, wq += F) {
-                    const float w_ = *wq;
-                    const float4 k4 = kh4[i];
-                    const float t0 = w_ * k4.x, t1 = w_ * k4.y, t2 = w_ * k4.z, t3 = w_ * k4.w;
-                    P0 = P0 + t0;
-                    P1 = P1 + t1;
-                    P2 = P2 + t2;
-                    P3 = P3 + t3;
+#define FD_HIER_TERM(W_, I_)                                                                  \
+    {                                                                                         \
+        const float4 k4 = kh4[I_];                                                            \
+        const float t0 = (W_) * k4.x, t1 = (W_) * k4.y, t2 = (W_) * k4.z, t3 = (W_) * k4.w;   \
+        P0 = P0 + t0;                                                                         \
+        P1 = P1 + t1;                                                                         \
+        P2 = P2 + t2;                                                                         \
+        P3 = P3 + t3;                                                                         \
+    }
+                // terms in the reference's order; the aligned middle of the chunk takes four weights per load (16 terms in flight
+                // per wave with the unroll below: the loop is bound by the latency of its L2 hits, not by their bandwidth)
+                int i = c0;
+                for (; i < c1 && (i & 3); ++i) FD_HIER_TERM(m.wT[(size_t)i * F + mm], i)
+                const float4* wp4 = m.wP + (size_t)(i >> 2) * m.Fp + mm;
+#pragma unroll 4
+                for (; i + 4 <= c1; i += 4, wp4 += m.Fp) {
+                    const float4 w4 = *wp4;
+                    FD_HIER_TERM(w4.x, i)
+                    FD_HIER_TERM(w4.y, i + 1)
+                    FD_HIER_TERM(w4.z, i + 2)
+                    FD_HIER_TERM(w4.w, i + 3)
                 }
+                for (; i < c1; ++i) FD_HIER_TERM(m.wT[(size_t)i * F + mm], i)
+#undef FD_HIER_TERM
                 P[ow][0] = P0; P[ow][1] = P1; P[ow][2] = P2; P[ow][3] = P3;
                 const bool mine = mm >= c0 && mm < c1;
                 const float thrm = mine ? m.thresholds[mm] : 0.f;
@@ -1431,7 +1504,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_ == 0 ? 
                     }
                 }
             }
+            FD_PROF_T(tc3);
             __syncthreads();
+            FD_PROF_T(tc4);
+            FD_PROF_ADD(2, 1);
+            FD_PROF_ADD(3, tc1 - tc0);
+            FD_PROF_ADD(4, tc2 - tc1);
+            FD_PROF_ADD(5, tc3 - tc2);
+            FD_PROF_ADD(6, tc4 - tc3);
             const unsigned long long ex = sExit[wave];
             if (alive && ex != ~0ull) {
                 level = (int)(ex >> 32);
@@ -1443,9 +1523,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_ == 0 ? 
             for (int b = 0; b < 4; ++b) allDone = allDone && (batch * 4 + b >= ndeep || sExit[b] != ~0ull);
             if (allDone) break;
         }
-        if (valid) wvm_emit<PW_, PH_>(g, m, o, wid, lane, level, fout, m.thresholds[level], px);
-        __syncthreads();
+        FD_PROF_T(te0);
+        // no barrier here: the next batch touches only per-wave state and the other sExit set before its first barrier, and the
+        // positives' stores / the counter atomic complete under its window preparation
+        if (valid) {
+            const bool positive = (level + 1 == m.numFilters) && (fout >= m.thresholds[level]);
+            if (lane == 0) {
+                if (o.all_level) o.all_level[wid] = level;
+                if (o.all_fout) o.all_fout[wid] = fout;
+            }
+            if (positive) {
+                if (lane == 0) {
+                    // an address the compiler cannot prove uniform: its atomic optimiser would otherwise wrap the add in a wave scan
+                    // that waits for the result on the spot
+                    unsigned int zero = 0;
+                    asm volatile("" : "+v"(zero));
+                    pendSlot = atomicAdd(o.pos_count + zero, 1u);
+                }
+                uint8_t* pb = reinterpret_cast<uint8_t*>(patchL[wave]);
+                if (g.colok) {
+#pragma unroll
+                    for (int j = 0; j < RHMAX; ++j)
+                        if (g.rowok(j)) pb[(g.r0 + j) * g.pw + g.col] = (uint8_t)px[j];
+                }
+                wave_sync();
+                pend = true;
+                pendWid = wid; pendLevel = level; pendFout = fout;
+            }
+        }
+        FD_PROF_T(te1);
+        FD_PROF_ADD(7, te1 - te0);
+        FD_PROF_ADD(8, te1 - tp0);
+        FD_PROF_ADD(9, level + 1);
+        FD_PROF_FLUSH;
     }
+    flushPending();
     wvm_finalize(o);
 }
 
@@ -2028,8 +2140,13 @@ int fd_wvm_create(fd_ctx* ctx, const fd_wvm_model* md, fd_wvm** out) {
                     ppg[(size_t)g * 32 + n] = md->pp[k];
                     for (int v = 0; v < cntval; ++v) valg[((size_t)g * 16 + v) * 32 + n] = md->val[v0 + v];
                     for (int r = rectBegin[k]; r < rectBegin[k + 1]; ++r) {
-                        grec.push_back(rects[r]);
-                        grec.push_back((uint32_t)(n * WVM_SVS + rectV[r]));
+                        // the four corners of the rect in the zero-padded integral image (k_wvm_deepB), 12 bits each, + the tag
+                        const uint32_t rc = rects[r], W1 = (uint32_t)md->filter_w + 1;
+                        const uint32_t x1 = rc & 255, y1 = (rc >> 8) & 255, x2 = (rc >> 16) & 255, y2 = rc >> 24;
+                        const uint32_t A = (y2 + 1) * W1 + x2 + 1, B = (y2 + 1) * W1 + x1, C = y1 * W1 + x2 + 1, D = y1 * W1 + x1;
+                        const uint32_t tag = (uint32_t)(n * WVM_SVS + rectV[r]);
+                        grec.push_back(A | (B << 12) | ((tag & 255u) << 24));
+                        grec.push_back(C | (D << 12) | ((tag >> 8) << 24));
                     }
                 }
             }
@@ -2044,6 +2161,12 @@ int fd_wvm_create(fd_ctx* ctx, const fd_wvm_model* md, fd_wvm** out) {
             d.genRec = m->genRec.as<uint2>(); d.genBegin = m->genBegin.as<int32_t>(); d.genMaxCnt = m->genMaxCnt.as<int32_t>();
             d.cntG = m->cntG.as<int32_t>(); d.ppG = m->ppG.as<double>(); d.valG = m->valG.as<double>();
             d.maxCnt = *std::max_element(gmax.begin(), gmax.end());
+            const int Fp = (F + 63) / 64 * 64 + 64;
+            std::vector<float> wp((size_t)((F + 3) / 4) * Fp * 4, 0.f);
+            for (int k = 0; k < F; ++k)
+                for (int pidx = 0; pidx <= k; ++pidx) wp[((size_t)(pidx >> 2) * Fp + k) * 4 + (pidx & 3)] = md->hk_weights[(size_t)k * F + pidx];
+            up(m->wP, wp.data(), sizeof(float) * wp.size());
+            d.wP = m->wP.as<float4>(); d.Fp = Fp;
         }
         d.fw = md->filter_w; d.fh = md->filter_h; d.d = md->filter_w * md->filter_h;
         d.numFilters = F;
@@ -2296,6 +2419,12 @@ struct fd_five_stage_frames {   // ticket of fd_detect_five_stage_frames_begin
     bool has_roi = false;
     int roi[4] = {0, 0, 0, 0};
     WvmRun run;
+    std::vector<std::vector<fd_detection>> res;   // per frame, after NMS
+    std::vector<int32_t> stages;                  // [frames][4]
+    std::shared_ptr<FdAsyncTask> task;            // host stages in flight on fd_async_queue() (ticket entry points)
+    ~fd_five_stage_frames() {                     // never freed under a running task
+        if (task) { try { task->wait(); } catch (...) {} }
+    }
 };
 
 static void five_stage_frames_begin(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const fd_svm* svm, float oe_dist, float oe_ratio, int sx, int sy,
@@ -2308,14 +2437,18 @@ static void five_stage_frames_begin(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wv
     fd_wvm_launch(ctx, p, t.m, sx, sy, roi, false, t.run, ctx->kernel_timing);   // one cascade run over the windows of all frames
 }
 
-static void five_stage_frames_end(fd_ctx* ctx, fd_five_stage_frames& t, fd_detection* out, int cap_per_frame, int32_t* counts, int32_t* stage_counts) {
-    if (!counts || cap_per_frame < 0) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_frames: bad argument");
+// Host stages of a multi-frame run (everything behind the cascade kernels): per-frame results into the ticket.  Runs on the calling
+// thread (blocking entry point) or on a thread of fd_async_queue() (ticket entry points): touches the ticket, the handles the
+// ticket holds and the context's stream only.
+static void five_stage_frames_host(fd_ctx* ctx, fd_five_stage_frames& t) {
     fd_pyramid* p = t.p;
     fd_wvm* m = t.m;
     const fd_svm* svm = t.svm;
     const int* roi = t.has_roi ? t.roi : nullptr;
     WvmRun& run = t.run;
     const int NF = p->nimg;
+    t.res.assign((size_t)NF, {});
+    t.stages.assign((size_t)NF * 4, 0);
     fd_wvm_finish(ctx, m, run);
     const int64_t perImage = NF > 0 ? run.total / NF : 0;
     std::vector<fd_detection> dets;
@@ -2338,11 +2471,10 @@ static void five_stage_frames_end(fd_ctx* ctx, fd_five_stage_frames& t, fd_detec
     std::vector<uint32_t> slots;
     for (int f = 0; f < NF; ++f) {
         const size_t b = begin[(size_t)f], e = begin[(size_t)f + 1];
-        if (stage_counts) { stage_counts[4 * f] = (int)(e - b); stage_counts[4 * f + 1] = stage_counts[4 * f + 2] = stage_counts[4 * f + 3] = 0; }
-        counts[f] = 0;
+        t.stages[4 * (size_t)f] = (int)(e - b);
         if (e == b) continue;
         fd_host_overlap_elimination(dets.data() + b, (int)(e - b), t.oe_dist, t.oe_ratio, keep[(size_t)f]);
-        if (stage_counts) stage_counts[4 * f + 1] = (int)keep[(size_t)f].size();
+        t.stages[4 * (size_t)f + 1] = (int)keep[(size_t)f].size();
         for (int k : keep[(size_t)f]) slots.push_back(run.slots[b + (size_t)k]);
     }
     const double* dist = nullptr;
@@ -2360,7 +2492,7 @@ static void five_stage_frames_end(fd_ctx* ctx, fd_five_stage_frames& t, fd_detec
     }
     size_t si = 0;
     for (int f = 0; f < NF; ++f) {
-        std::vector<fd_detection> svmPos;
+        std::vector<fd_detection>& svmPos = t.res[(size_t)f];
         const size_t b = begin[(size_t)f];
         for (int k : keep[(size_t)f]) {
             const double dv = dist[si++];
@@ -2373,8 +2505,26 @@ static void five_stage_frames_end(fd_ctx* ctx, fd_five_stage_frames& t, fd_detec
             }
         }
         int cnt = 0;
-        five_stage_nms(p, roi, svmPos, out ? out + (size_t)f * cap_per_frame : nullptr, cap_per_frame, &cnt, stage_counts ? stage_counts + 4 * f : nullptr);
-        counts[f] = cnt;
+        five_stage_nms(p, roi, svmPos, nullptr, 0, &cnt, &t.stages[4 * (size_t)f]);   // svmPos becomes the frame's result
+    }
+}
+
+static void five_stage_frames_end(fd_ctx* ctx, fd_five_stage_frames& t, fd_detection* out, int cap_per_frame, int32_t* counts, int32_t* stage_counts) {
+    if (t.task) {
+        std::shared_ptr<FdAsyncTask> task = std::move(t.task);
+        t.task.reset();
+        task->wait();   // rethrows what the host stages threw
+    } else {
+        five_stage_frames_host(ctx, t);
+    }
+    if (!counts || cap_per_frame < 0) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_frames: bad argument");
+    const int NF = t.p->nimg;
+    for (int f = 0; f < NF; ++f) {
+        const std::vector<fd_detection>& r = t.res[(size_t)f];
+        counts[f] = (int)r.size();
+        if (stage_counts) std::memcpy(stage_counts + 4 * f, &t.stages[4 * (size_t)f], 4 * sizeof(int32_t));
+        for (size_t i = 0; i < r.size() && (int)i < cap_per_frame && out; ++i) out[(size_t)f * cap_per_frame + i] = r[i];
+        if (out && (int)r.size() > cap_per_frame) FD_THROW(FD_ERR_CAPACITY, "five-stage: %zu detections, capacity %d", r.size(), cap_per_frame);
     }
 }
 
@@ -2394,6 +2544,16 @@ int fd_detect_five_stage_frames_begin(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* 
         if (!ticket) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_frames_begin: NULL ticket");
         std::unique_ptr<fd_five_stage_frames> t(new fd_five_stage_frames());
         five_stage_frames_begin(ctx, p, wvm_, svm, oe_dist, oe_ratio, sx, sy, roi, *t);
+        // the host stages follow on a queue thread as soon as the cascade kernels retire (zero-copy read-back runs only: the
+        // other read-back path and the kernel timer use per-context state); FD_FRAMES_ASYNC=0 keeps them inside _end
+        static const bool asyncOn = [] { const char* e = getenv("FD_FRAMES_ASYNC"); return !e || atoi(e) != 0; }();
+        if (asyncOn && t->m->zcRun && !t->run.timed) {
+            fd_five_stage_frames* tp = t.get();
+            tp->task = fd_async_queue().submit([ctx, tp] {
+                HIP_CHECK(hipSetDevice(ctx->device));
+                five_stage_frames_host(ctx, *tp);
+            });
+        }
         *ticket = t.release();
     });
 }

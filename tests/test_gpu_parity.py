@@ -123,11 +123,15 @@ def test_wvm_full_size_model_and_other_patch_shapes(oracle, capi, ctx, synth, fr
     cfgs["odd19x21"] = (0.9, 0.5, 0.7, 19, 21, 9, 4)   # run-time-sized kernel instance, odd height
     cfgs["tiny7x5"] = (0.9, 0.5, 0.7, 7, 5, 3, 4)
     cfgs["nper40"] = (0.9, 0.5, 0.7, 20, 20, 40, 1)   # numPer > 32: one-window stage A kernel with compile-time geometry
+    # 16 grey values x up to 8 rects x 14 classes: > 1280 rects per generation (stage B stages them piecewise) and the 16-value kernel
+    cfgs["manyrects"] = (0.9, 0.5, 0.7, 20, 20, 14, 1)
+    cfgs["manyrects24"] = (0.9, 0.5, 0.7, 24, 24, 9, 1)
+    extra = dict(manyrects=dict(cntval=16, rect_range=(6, 8)), manyrects24=dict(cntval=12, rect_range=(1, 8)))
     for (name, n_levels) in (("FaceFrontal", 20), ("LeftEyeCenter", 3), ("NoseTip", 2), ("LeftEarCenter", 2), ("LeftLipCorner", 2),
-                             ("odd19x21", 4), ("tiny7x5", 8), ("nper40", 2)):
+                             ("odd19x21", 4), ("tiny7x5", 8), ("nper40", 2), ("manyrects", 3), ("manyrects24", 9)):
         inc, mn, mx, pw, ph, nper, _ = cfgs[name]
         calib = synth.random_patches(gray[::2, ::2].copy(), pw, ph, 3000, rng)
-        wvm = synth.make_wvm(31, fw=pw, fh=ph, n_per=nper, n_levels=n_levels, calib_patches=calib, min_survivors=48)
+        wvm = synth.make_wvm(31, fw=pw, fh=ph, n_per=nper, n_levels=n_levels, calib_patches=calib, min_survivors=48, **extra.get(name, {}))
         kw = dict(inc=float(np.float32(inc)), min_scale=float(np.float32(mn)), max_scale=float(np.float32(mx)))
         small = frame640[:240, :320] if name != "FaceFrontal" else frame640
         po, pg = _pyr_pair(oracle, capi, ctx, small, **kw)

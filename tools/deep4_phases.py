@@ -1,4 +1,4 @@
-"""Dev tool: phase split of k_wvm_deep4 from in-kernel timestamps.  Needs a libfd_hip.so built with -DFD_DEEP4_PROF
+"""Dev tool: phase split of k_wvm_deepB (stage B of the WVM cascade) from in-kernel timestamps.  Needs a libfd_hip.so built with -DFD_DEEP4_PROF
 (FD_HIP_LIB=.../libfd_hip_prof.so); timestamps are taken by thread 0 of each workgroup (wave 0), s_memtime ticks (100 MHz).
 usage: deep4_phases.py [cascade|<ffp15 detector name>]"""
 import ctypes, os, sys
@@ -42,7 +42,10 @@ L.fd_debug_deep4_prof(buf, 0)
 v = [int(x) for x in buf]
 names = ["windows", "prepare", "chunks", "kernel values", "barrier 1", "hier sums", "barrier 2", "emit", "total", "levels evaluated"]
 tot = v[8]
-print("%s: per launch %d windows, %d chunks, mean levels/window %.1f" % (what, v[0] // N, v[2] // N, v[9] / max(v[0], 1)))
+print("%s: per launch %d batches of 4 windows, %d chunks, mean levels (window of wave 0) %.1f" % (what, v[0] // N, v[2] // N, v[9] / max(v[0], 1)))
 for i in (1, 3, 4, 5, 6, 7):
-    print("  %-14s %5.1f %%   %.0f ticks/window" % (names[i], 100.0 * v[i] / tot, v[i] / max(v[0], 1)))
-print("  total ticks/window %.0f (x10 ns)" % (tot / max(v[0], 1)))
+    print("  %-14s %5.1f %%   %.0f ticks/batch" % (names[i], 100.0 * v[i] / tot, v[i] / max(v[0], 1)))
+print("  total ticks/batch %.0f" % (tot / max(v[0], 1)))
+if v[12]:
+    print("  inside kernel values: rect passes %.0f ticks/generation, chain + exp %.0f ticks/generation (%d generations/batch)" %
+          (v[10] / v[12], v[11] / v[12], v[12] // max(v[0], 1)))
