@@ -179,11 +179,15 @@ __global__ __launch_bounds__(256) void k_pyrdown(uint8_t* __restrict__ arena, Do
 
 // ---- LDS-tiled versions of the two kernels above -------------------------------------------------------------------------
 // The direct kernels issue four (resize) / 14 (pyrDown) byte loads per output pixel and are bound by the number of memory
-// instructions.  Here a workgroup stages the source rectangle of a 64 x 16 output tile in LDS with dword loads (unaligned where
+// instructions.  Here a workgroup stages the source rectangle of a 64 x 32 output tile in LDS with dword loads (unaligned where
 // the row start is) and every tap is an LDS byte read; the arithmetic is the same, value for value.
-constexpr int TL_W = 64, TL_H = 16, TL_PITCH = 136, TL_ROWS = 36;
+constexpr int TL_W = 64, TL_H = 32, TL_PITCH = 136;   // 64 x 32 output pixels per tile, 8 rows per thread: the per-thread column set-up is the
+                                                        // larger part of the work of a row
+constexpr int PD_TH = 16;                               // pyrDown: 64 x 16 tiles (its layers are small: 32-row tiles leave CUs idle)
+constexpr int TL_ROWS = 72;                             // resize: 31 * 2.05 + 3 source rows; pyrDown: 2 * 32 + 3
 
-// resize: valid while a tile's source rectangle fits, i.e. scale_x, scale_y <= 2.05 (first-octave layers: 1 <= scale < 2)
+// resize: valid while a tile's source rectangle fits the stage from its conservative origin, i.e. 1 <= scale_x, scale_y <= 2.05
+// (first-octave layers: 1 <= scale < 2)
 __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict__ arena, uint8_t* __restrict__ out, uint32_t src_off, int sw,
                                                       int sh, ResizeJobs jobs, size_t imageStride) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[TL_ROWS * TL_PITCH];
@@ -207,29 +211,37 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
         return sy;
     };
     auto clampY = [&](int y) { return y < 0 ? 0 : (y >= sh ? sh - 1 : y); };
-    const int c = threadIdx.x & 63, rq = threadIdx.x >> 6;
+    const int c = threadIdx.x & 63, rq = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // rq scalar: row offsets on the scalar unit
     for (int t = blockIdx.x; t < tilesX * tilesY; t += gridDim.x) {
         const int ty = t / tilesX, tx = t - ty * tilesX;
         const int dx0 = tx * TL_W, dy0 = ty * TL_H;
-        const int dxl = min(dx0 + TL_W, jb.dw) - 1, dyl = min(dy0 + TL_H, jb.dh) - 1;
-        float f_;
-        const int X0 = srcX(dx0, f_);
-        const int xl = srcX(dxl, f_);
-        const int X1 = xl + 1 < sw ? xl + 1 : xl;
-        const int Y0 = clampY(srcY(dy0, f_)), Y1 = clampY(srcY(dyl, f_) + 1);
-        const int ndw = (X1 - X0 + 4) >> 2, nrows = Y1 - Y0 + 1;
-        for (int e = threadIdx.x; e < nrows * ndw; e += 256) {
-            const int r = e / ndw, j = e - r * ndw;
-            const int x = X0 + 4 * j;
-            const uint8_t* gp = src + (size_t)(Y0 + r) * sw + x;
-            uint32_t v;
-            if (x + 3 < sw) {
-                v = ld_u32_unaligned(gp);
-            } else {   // right edge of the image: never past the row
-                v = 0;
-                for (int b = 0; b < 4; ++b) v |= (uint32_t)src[(size_t)(Y0 + r) * sw + min(x + b, sw - 1)] << (8 * b);
+        // source rectangle of the tile: a conservative origin (one below the smallest coordinate any of its pixels can ask for:
+        // sx >= floor(dx * scale) for scale >= 1) and the full stage, TL_ROWS x TL_PITCH bytes -- cheaper than the exact extents,
+        // which need the fp64 coordinate of cv::resize per tile and thread
+        const int X0 = max(0, (int)((float)dx0 * (float)jb.scale_x) - 1), Y0 = max(0, (int)((float)dy0 * (float)jb.scale_y) - 1);
+        {   // lane == dword of a source row (34 per row), wave + 4 k == row: no index arithmetic, all loads of a thread in flight together
+            const int x = X0 + 4 * c;
+            const bool colok = c < TL_PITCH / 4;
+            uint32_t v[TL_ROWS / 4];
+#pragma unroll
+            for (int k = 0; k < TL_ROWS / 4; ++k) {
+                const int sy = min(Y0 + rq + 4 * k, sh - 1);
+                v[k] = 0;
+                if (colok && x + 3 < sw) v[k] = ld_u32_unaligned(src + (uint32_t)(sy * sw) + x);
             }
-            *reinterpret_cast<uint32_t*>(&tile[r * TL_PITCH + 4 * j]) = v;
+            if (colok && x + 3 >= sw) {   // right edge of the image: never past the row
+#pragma unroll 1
+                for (int k = 0; k < TL_ROWS / 4; ++k) {
+                    const uint8_t* row = src + (uint32_t)(min(Y0 + rq + 4 * k, sh - 1) * sw);
+                    uint32_t w = 0;
+                    for (int b = 0; b < 4; ++b) w |= (uint32_t)row[min(x + b, sw - 1)] << (8 * b);
+                    v[k] = w;
+                }
+            }
+            if (colok) {
+#pragma unroll
+                for (int k = 0; k < TL_ROWS / 4; ++k) *reinterpret_cast<uint32_t*>(&tile[(rq + 4 * k) * TL_PITCH + 4 * c]) = v[k];
+            }
         }
         if (threadIdx.x < TL_H) {   // vertical taps of the tile's rows, once per tile instead of once per thread and row
             float fy;
@@ -244,17 +256,19 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
             const int sx = srcX(dx, fx);
             const int a0 = __float2int_rn((1.f - fx) * 2048), a1 = __float2int_rn(fx * 2048);
             const int lx = sx - X0, lx1 = (sx + 1 < sw ? sx + 1 : sx) - X0;
+            // 24-bit multiplies (full rate; every factor is below 2^16) and a running destination pointer: the 32-bit multiplies /
+            // 64-bit multiply-adds the plain expressions compile to run at a quarter of the rate and made this kernel VALU-bound
+            uint8_t* dp = dst + (uint32_t)((dy0 + rq * (TL_H / 4)) * jb.dw) + dx;
 #pragma unroll
-            for (int k = 0; k < TL_H / 4; ++k) {
+            for (int k = 0; k < TL_H / 4; ++k, dp += jb.dw) {
                 const int rr = rq * (TL_H / 4) + k;
-                const int dy = dy0 + rr;
-                if (dy < jb.dh) {
+                if (dy0 + rr < jb.dh) {
                     const int4 rt = rowTab[rr];
                     const uint8_t* S0 = tile + rt.x;
                     const uint8_t* S1 = tile + rt.y;
-                    const int r0 = S0[lx] * a0 + S0[lx1] * a1;
-                    const int r1 = S1[lx] * a0 + S1[lx1] * a1;
-                    dst[(size_t)dy * jb.dw + dx] = (uint8_t)((((rt.z * (r0 >> 4)) >> 16) + ((rt.w * (r1 >> 4)) >> 16) + 2) >> 2);
+                    const unsigned int r0 = __umul24(S0[lx], a0) + __umul24(S0[lx1], a1);
+                    const unsigned int r1 = __umul24(S1[lx], a0) + __umul24(S1[lx1], a1);
+                    *dp = (uint8_t)(((__umul24(rt.z, r0 >> 4) >> 16) + (__umul24(rt.w, r1 >> 4) >> 16) + 2) >> 2);
                 }
             }
         }
@@ -270,30 +284,47 @@ __global__ __launch_bounds__(256) void k_pyrdown_tiled(uint8_t* __restrict__ are
     arena += (size_t)blockIdx.z * imageStride;   // blockIdx.z = frame of a multi-frame pyramid
     const uint8_t* src = arena + jb.src_off;
     uint8_t* dst = arena + jb.dst_off;
-    const int tilesX = (dw + TL_W - 1) / TL_W, tilesY = (dh + TL_H - 1) / TL_H;
-    const int c = threadIdx.x & 63, rq = threadIdx.x >> 6;
-    constexpr int NDW = (2 * TL_W + 3 + 3) / 4, NROWS = 2 * TL_H + 3;   // 131 source columns, 35 source rows per tile
+    const int tilesX = (dw + TL_W - 1) / TL_W, tilesY = (dh + PD_TH - 1) / PD_TH;
+    const int c = threadIdx.x & 63, rq = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // rq scalar: row offsets on the scalar unit
+    constexpr int NDW = (2 * TL_W + 3 + 3) / 4, NROWS = 2 * PD_TH + 3;   // 131 source columns, 35 source rows per tile
     for (int t = blockIdx.x; t < tilesX * tilesY; t += gridDim.x) {
         const int ty = t / tilesX, tx = t - ty * tilesX;
-        const int dx0 = tx * TL_W, dy0 = ty * TL_H;
+        const int dx0 = tx * TL_W, dy0 = ty * PD_TH;
         const int X0 = 2 * dx0 - 2, Y0 = 2 * dy0 - 2;
-        for (int e = threadIdx.x; e < NROWS * NDW; e += 256) {
-            const int r = e / NDW, j = e - r * NDW;
-            const int x = X0 + 4 * j;
-            const uint8_t* row = src + (size_t)reflect101(Y0 + r, sh) * sw;
-            uint32_t v;
-            if (x >= 0 && x + 3 < sw) {
-                v = ld_u32_unaligned(row + x);
-            } else {   // BORDER_REFLECT_101 columns
-                v = 0;
-                for (int b = 0; b < 4; ++b) v |= (uint32_t)row[reflect101(x + b, sw)] << (8 * b);
+        {   // stage the 35 x 33 dwords of the source rectangle: flat element index, all loads of a thread in flight together (measured
+            // against one row per wavefront with lane == dword: 20 vs 24 us per launch, half the lanes idle there)
+            constexpr int PD_LD = (NROWS * NDW + 255) / 256;
+            uint32_t v[PD_LD];
+#pragma unroll
+            for (int k = 0; k < PD_LD; ++k) {
+                const int e = threadIdx.x + 256 * k;
+                v[k] = 0;
+                if (e < NROWS * NDW) {
+                    const int r = e / NDW, j = e - r * NDW;
+                    const int xs = X0 + 4 * j;
+                    if (xs >= 0 && xs + 3 < sw) v[k] = ld_u32_unaligned(src + (uint32_t)(reflect101(Y0 + r, sh) * sw) + xs);
+                }
             }
-            *reinterpret_cast<uint32_t*>(&tile[r * TL_PITCH + 4 * j]) = v;
+#pragma unroll
+            for (int k = 0; k < PD_LD; ++k) {
+                const int e = threadIdx.x + 256 * k;
+                if (e < NROWS * NDW) {
+                    const int r = e / NDW, j = e - r * NDW;
+                    const int xs = X0 + 4 * j;
+                    uint32_t w = v[k];
+                    if (!(xs >= 0 && xs + 3 < sw)) {   // BORDER_REFLECT_101 columns
+                        const uint8_t* row = src + (uint32_t)(reflect101(Y0 + r, sh) * sw);
+                        w = 0;
+                        for (int b = 0; b < 4; ++b) w |= (uint32_t)row[reflect101(xs + b, sw)] << (8 * b);
+                    }
+                    *reinterpret_cast<uint32_t*>(&tile[r * TL_PITCH + 4 * j]) = w;
+                }
+            }
         }
         __syncthreads();
         const int x = dx0 + c;
         if (x < dw) {
-            constexpr int PR = TL_H / 4;   // output rows per thread
+            constexpr int PR = PD_TH / 4;   // output rows per thread
             const uint8_t* T = tile + (2 * rq * PR) * TL_PITCH + 2 * c;
             int h[2 * PR + 3];
 #pragma unroll
@@ -303,12 +334,12 @@ __global__ __launch_bounds__(256) void k_pyrdown_tiled(uint8_t* __restrict__ are
                 const int s0 = p01 & 255u, s1 = p01 >> 8, s2 = p23 & 255u, s3 = p23 >> 8, s4 = S[4];
                 h[r] = s2 * 6 + (s1 + s3) * 4 + s0 + s4;
             }
+            uint8_t* dp = dst + (uint32_t)((dy0 + rq * PR) * dw) + x;
 #pragma unroll
-            for (int j = 0; j < PR; ++j) {
-                const int y = dy0 + rq * PR + j;
-                if (y < dh) {
+            for (int j = 0; j < PR; ++j, dp += dw) {
+                if (dy0 + rq * PR + j < dh) {
                     const int v = h[2 * j + 2] * 6 + (h[2 * j + 1] + h[2 * j + 3]) * 4 + h[2 * j] + h[2 * j + 4];
-                    dst[(size_t)y * dw + x] = (uint8_t)((v + 128) >> 8);
+                    *dp = (uint8_t)((v + 128) >> 8);
                 }
             }
         }
@@ -609,8 +640,9 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
         int maxpix = 0, maxtiles = 0;
         auto flush = [&]() {
             if (!jobs.n) return;
-            bool fits = true;   // the tiled kernel stages at most TL_ROWS x TL_PITCH source bytes per 64 x 16 tile
-            for (int q = 0; q < jobs.n; ++q) fits = fits && jobs.j[q].scale_x <= 2.05 && jobs.j[q].scale_y <= 2.05;
+            bool fits = true;   // the tiled kernel stages at most TL_ROWS x TL_PITCH source bytes per 64 x 32 tile
+            for (int q = 0; q < jobs.n; ++q)
+                fits = fits && jobs.j[q].scale_x >= 1.0 && jobs.j[q].scale_x <= 2.05 && jobs.j[q].scale_y >= 1.0 && jobs.j[q].scale_y <= 2.05;
             if (fits)
                 hipLaunchKernelGGL(k_resize_tiled, dim3(tile_grid_for(maxtiles), jobs.n, NI), dim3(256), 0, st, arena, arena, p->gray_full_off, W, H, jobs, IS);
             else
@@ -649,7 +681,7 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
             DownJob& j = jobs.j[jobs.n++];
             j.sw = S.w; j.sh = S.h; j.src_off = S.gray_off; j.dst_off = L.gray_off;
             maxpix = std::max(maxpix, L.w * L.h);
-            maxtiles = std::max(maxtiles, ((L.w + TL_W - 1) / TL_W) * ((L.h + TL_H - 1) / TL_H));
+            maxtiles = std::max(maxtiles, ((L.w + TL_W - 1) / TL_W) * ((L.h + PD_TH - 1) / PD_TH));
             if (jobs.n == MAXJ) flush();
         }
         flush();

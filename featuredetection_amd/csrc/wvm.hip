@@ -42,6 +42,7 @@ constexpr int WVM_FIRST_CHUNK = 4096;  // positives fetched together with the co
 constexpr int WVM_LCAP = 16;         // filters evaluated by the one-wave-per-window stage; survivors go to k_wvm_deep
 constexpr int WVM_PJ = 5;            // up to 320 filters (largest cfg-implied WVM: 280)
 constexpr int WVM_RECCAP = 1280;     // rect records of a chunk staged in LDS by k_wvm_deepB
+constexpr int wvm_reccap_for(int pw, int ph) { return (pw && (pw + 1) * (ph + 1) > 700) ? WVM_RECCAP * 3 / 5 : WVM_RECCAP; }   // 32x24: four workgroups per CU
 constexpr int WVM_SVS = 17;          // stride of a class's grey-value sums in k_wvm_deepB (odd: lane == class reads are conflict-free)
 
 struct WinLayerDev {
@@ -107,6 +108,9 @@ struct WvmDev {
     // wT again, four terms per load: wP[(p / 4) * Fp + k] = {wT[p][k], wT[p + 1][k], wT[p + 2][k], wT[p + 3][k]}, p a multiple of 4
     const float4* wP;
     int32_t Fp;                // row length of wP (numFilters rounded up to 64, + 64)
+    // k_wvm_deepB's chunk starting at generation g: {generations whose rect records fit its LDS stage (0: not even one: staged
+    // piecewise), genBegin[g], genBegin[g + max(x, 1)], 0} -- one load instead of a chain of dependent ones per chunk
+    const int4* chunkPlan;
 };
 
 struct PosRec {
@@ -118,7 +122,7 @@ struct PosRec {
 struct fd_wvm {
     fd_ctx* ctx;
     WvmDev dev;
-    DevBuf thresholds, wT, pp, valOff, val, rectBegin, rects, rectV, lvlRec, lvlHdr, genRec, genBegin, genMaxCnt, cntG, ppG, valG, wP;
+    DevBuf thresholds, wT, pp, valOff, val, rectBegin, rects, rectV, lvlRec, lvlHdr, genRec, genBegin, genMaxCnt, cntG, ppG, valG, wP, chunkPlan;
     double logisticA, logisticB;
     std::vector<float> h_thresholds;
     // scratch reused across calls
@@ -1284,7 +1288,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_ == 0 ? 
     constexpr int MAXOWN = (WVM_PJ + 3) / 4;
     constexpr int IIP = PW_ ? (PW_ + 1) * (PH_ + 1) : (WVM_MAX_DIM + 1) * (WVM_MAX_DIM + 1);
     __shared__ unsigned int ii[4][IIP];     // zero-padded integral images
-    constexpr int RECCAP = (PW_ && IIP > 700) ? WVM_RECCAP * 3 / 5 : WVM_RECCAP;   // 32x24: keeps four workgroups per CU (LDS)
+    constexpr int RECCAP = wvm_reccap_for(PW_, PH_);
+    __shared__ int genTab[2][66];           // genBegin / genMaxCnt of the chunk's generations
     __shared__ uint2 recL[RECCAP];          // rect records of the chunk (the same for the four windows)
     __shared__ unsigned int hist[4][64];
     __shared__ int sv[4][32 * WVM_SVS];
@@ -1300,7 +1305,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_ == 0 ? 
     const int cls = lane & 31;
     const Geo<PW_, PH_> g(m, lane);
     const int F = m.numFilters, NU = m.numUsed, NP = m.numPer;
-    const int gensPerChunk = max(1, 64 / NP), G = (F + NP - 1) / NP;
     int* svw = sv[wave];
     float* khf = reinterpret_cast<float*>(kh4);
     // 64-level block ownership of the hierarchical sums, rotated between the workgroups that share a CU: wave w of every workgroup
@@ -1370,14 +1374,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_ == 0 ? 
             // ---- chunk = as many generations (at most 64 levels) as have their rect records fit the LDS stage; the records are
             // window-independent: one copy serves the four waves, and the passes below never wait for global memory
             const int gi0 = c0 / NP;
-            const int r0 = __builtin_amdgcn_readfirstlane(m.genBegin[gi0]);
-            int gens = 0;
-            while (gens < gensPerChunk && gi0 + gens < G && m.genBegin[gi0 + gens + 1] - r0 <= RECCAP) ++gens;
+            const int4 plan = m.chunkPlan[gi0];
+            const int r0 = __builtin_amdgcn_readfirstlane(plan.y), rEnd = __builtin_amdgcn_readfirstlane(plan.z);
+            int gens = __builtin_amdgcn_readfirstlane(plan.x);
             const bool fits = gens > 0;       // else: a single generation with more rects than the stage holds, staged piecewise
             if (!fits) gens = 1;
             c1 = min(c0 + gens * NP, NU);
             FD_PROF_T(tc0);
-            const int rEnd = __builtin_amdgcn_readfirstlane(m.genBegin[gi0 + gens]);
             // rect sums of the staged records [jb0, jb1) (recL[0] = record `base`): lane == rect, four unconditional corner reads
             auto rectPasses = [&](int jb0, int jb1, int base) {
                 for (int jb = jb0; jb < jb1; jb += 128) {   // two rects per lane and pass: eight independent corner reads in flight
@@ -1389,6 +1392,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_ == 0 ? 
                     if (j1 < jb1) atomicAdd(&svw[(rb.x >> 24) | ((rb.y >> 24) << 8)], (int)sb);
                 }
             };
+            if ((int)threadIdx.x <= gens) genTab[0][threadIdx.x] = m.genBegin[gi0 + threadIdx.x];
+            if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + gens) genTab[1][threadIdx.x - 64] = m.genMaxCnt[gi0 + threadIdx.x - 64];
             if (fits) {
                 for (int i = threadIdx.x; i < rEnd - r0; i += 256) recL[i] = m.genRec[r0 + i];
                 __syncthreads();
@@ -1407,14 +1412,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_ == 0 ? 
                     // ---- chain constants of the generation: requested now, consumed after the rect passes
                     const int k = gbase + cls;
                     const bool act = lane < NP && k < c1;
-                    const int maxCnt = __builtin_amdgcn_readfirstlane(m.genMaxCnt[gi]);
+                    const int maxCnt = __builtin_amdgcn_readfirstlane(genTab[1][gi - gi0]);
                     const int cnt = act ? m.cntG[gi * 32 + cls] : 0;
                     const double ppv = m.ppG[gi * 32 + cls];
                     double valr[MAXV];
 #pragma unroll
                     for (int v = 0; v < MAXV; ++v) valr[v] = v < maxCnt ? m.valG[((size_t)gi * 16 + v) * 32 + cls] : 0.0;
                     FD_PROF_T(tr0);
-                    if (fits) rectPasses(__builtin_amdgcn_readfirstlane(m.genBegin[gi]), __builtin_amdgcn_readfirstlane(m.genBegin[gi + 1]), r0);
+                    if (fits) rectPasses(__builtin_amdgcn_readfirstlane(genTab[0][gi - gi0]), __builtin_amdgcn_readfirstlane(genTab[0][gi - gi0 + 1]), r0);
                     wave_sync();
                     FD_PROF_T(tr1);
                     // ---- the reference's scalar chain, lane == class (lanes 32-63 idle); the sums are cleared as they are read
@@ -2167,6 +2172,21 @@ int fd_wvm_create(fd_ctx* ctx, const fd_wvm_model* md, fd_wvm** out) {
                 for (int pidx = 0; pidx <= k; ++pidx) wp[((size_t)(pidx >> 2) * Fp + k) * 4 + (pidx & 3)] = md->hk_weights[(size_t)k * F + pidx];
             up(m->wP, wp.data(), sizeof(float) * wp.size());
             d.wP = m->wP.as<float4>(); d.Fp = Fp;
+            {
+                bool sized = false;   // does this patch size have a compile-time kernel instance (FD_WVM_SIZES)?
+                const int fixed[][2] = {{20, 20}, {24, 24}, {16, 24}, {32, 16}, {32, 24}};
+                for (auto& f : fixed) sized = sized || (md->filter_w == f[0] && md->filter_h == f[1]);
+                const int cap = sized ? wvm_reccap_for(md->filter_w, md->filter_h) : wvm_reccap_for(0, 0);
+                const int gpc = std::max(1, 64 / NP);
+                std::vector<int32_t> plan((size_t)G * 4, 0);
+                for (int g = 0; g < G; ++g) {
+                    int gens = 0;
+                    while (gens < gpc && g + gens < G && gbeg[g + gens + 1] - gbeg[g] <= cap) ++gens;
+                    plan[4 * (size_t)g] = gens; plan[4 * (size_t)g + 1] = gbeg[g]; plan[4 * (size_t)g + 2] = gbeg[g + std::max(gens, 1)];
+                }
+                up(m->chunkPlan, plan.data(), sizeof(int32_t) * plan.size());
+                d.chunkPlan = m->chunkPlan.as<int4>();
+            }
         }
         d.fw = md->filter_w; d.fh = md->filter_h; d.d = md->filter_w * md->filter_h;
         d.numFilters = F;
