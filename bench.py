@@ -261,7 +261,7 @@ class Cascade(Workload):
         bytes_per_launch = nf * (self.layer_bytes + self.nwin * 16)
         ach = bytes_per_launch / (kms * 1e-3) / 1e9
         pm = pmc_record("cascade" if (self.W, self.H) == (640, 480) else "cascade_%dx%d" % (self.W, self.H), "k_wvm")
-        roof = dict(bound="hbm", kernel="k_wvm_prefilter + k_wvm_deep4 (one cascade run over the %d frames of a call)" % nf, achieved=ach,
+        roof = dict(bound="hbm", kernel="k_wvm_prefilter + k_wvm_deepB (one cascade run over the %d frames of a call)" % nf, achieved=ach,
                     peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=pm.get("hbm_bytes") if pm else None, kernel_ms=kms,
                     algorithmic="%d frames x (%d layer bytes + 16 B record x %d windows) per launch (SURVEY 8(d))" % (nf, self.layer_bytes, self.nwin))
         extra = {}

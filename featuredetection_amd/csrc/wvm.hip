@@ -1355,6 +1355,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_ == 0 ? 
         int sx_total;
         wvm_prepare<PW_, PH_, RAW, true>(g, src, srcStride, m.stretch, lane, hist[wave], ii[wave], px, sxx, sx_total);
         flushPending();
+        {   // the equalised patch leaves the registers here (only a positive needs it again, at write-out)
+            uint8_t* pb = reinterpret_cast<uint8_t*>(patchL[wave]);
+            if (g.colok) {
+#pragma unroll
+                for (int j = 0; j < RHMAX; ++j)
+                    if (g.rowok(j)) pb[(g.r0 + j) * g.pw + g.col] = (uint8_t)px[j];
+            }
+        }
         if (lane == 0) sExit[wave] = ~0ull;
         const unsigned int* iiw = ii[wave];
         FD_PROF_T(tp1);
@@ -1469,22 +1477,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_ == 0 ? 
                 const int blk = wown + ow * 4;
                 if (blk * 64 >= NU || blk * 64 + 63 < c0) continue;   // nothing owned here / already decided
                 const int mm = blk * 64 + lane;
-                float P0 = P[ow][0], P1 = P[ow][1], P2 = P[ow][2], P3 = P[ow][3];
-#define FD_HIER_TERM(W_, I_)                                                                  \
-    {                                                                                         \
-        const float4 k4 = kh4[I_];                                                            \
-        const float t0 = (W_) * k4.x, t1 = (W_) * k4.y, t2 = (W_) * k4.z, t3 = (W_) * k4.w;   \
-        P0 = P0 + t0;                                                                         \
-        P1 = P1 + t1;                                                                         \
-        P2 = P2 + t2;                                                                         \
-        P3 = P3 + t3;                                                                         \
+                // two windows per instruction: packed fp32 multiply / add (v_pk_mul_f32, v_pk_add_f32) round each component exactly
+                // like the scalar forms and halve the instruction count of this VALU-dense loop
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                f32x2 P01 = {P[ow][0], P[ow][1]}, P23 = {P[ow][2], P[ow][3]};
+                const f32x2* kh2 = reinterpret_cast<const f32x2*>(kh4);
+#define FD_HIER_TERM(W_, I_)                                  \
+    {                                                         \
+        const f32x2 w2 = {(W_), (W_)};                        \
+        const f32x2 ka = kh2[2 * (I_)], kb = kh2[2 * (I_) + 1]; \
+        const f32x2 ta = w2 * ka, tb = w2 * kb;               \
+        P01 = P01 + ta;                                       \
+        P23 = P23 + tb;                                       \
     }
                 // terms in the reference's order; the aligned middle of the chunk takes four weights per load (16 terms in flight
                 // per wave with the unroll below: the loop is bound by the latency of its L2 hits, not by their bandwidth)
                 int i = c0;
                 for (; i < c1 && (i & 3); ++i) FD_HIER_TERM(m.wT[(size_t)i * F + mm], i)
                 const float4* wp4 = m.wP + (size_t)(i >> 2) * m.Fp + mm;
-#pragma unroll 4
+#ifndef FD_HIER_UNROLL
+#define FD_HIER_UNROLL 4
+#endif
+#pragma unroll FD_HIER_UNROLL
                 for (; i + 4 <= c1; i += 4, wp4 += m.Fp) {
                     const float4 w4 = *wp4;
                     FD_HIER_TERM(w4.x, i)
@@ -1494,6 +1508,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_ == 0 ? 
                 }
                 for (; i < c1; ++i) FD_HIER_TERM(m.wT[(size_t)i * F + mm], i)
 #undef FD_HIER_TERM
+                const float P0 = P01.x, P1 = P01.y, P2 = P23.x, P3 = P23.y;
                 P[ow][0] = P0; P[ow][1] = P1; P[ow][2] = P2; P[ow][3] = P3;
                 const bool mine = mm >= c0 && mm < c1;
                 const float thrm = mine ? m.thresholds[mm] : 0.f;
@@ -1545,13 +1560,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_ == 0 ? 
                     asm volatile("" : "+v"(zero));
                     pendSlot = atomicAdd(o.pos_count + zero, 1u);
                 }
-                uint8_t* pb = reinterpret_cast<uint8_t*>(patchL[wave]);
-                if (g.colok) {
-#pragma unroll
-                    for (int j = 0; j < RHMAX; ++j)
-                        if (g.rowok(j)) pb[(g.r0 + j) * g.pw + g.col] = (uint8_t)px[j];
-                }
-                wave_sync();
                 pend = true;
                 pendWid = wid; pendLevel = level; pendFout = fout;
             }
