@@ -16,8 +16,12 @@ fi
 if [ "$WHAT" = stats ] || [ "$WHAT" = all ]; then
   for wl in cascade hog_svm ffp15 sdm; do
     S=10; [ $wl = ffp15 ] && S=3
-    FP=""; [ $wl = cascade ] && FP="--frames-per-step 64"
-    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$wl -- $B --workload $wl --also none --steps $S --warmup 2 $FP --no-cpu-baseline > $O/stats_$wl.json 2> $O/stats_$wl.err
+    FP=""; [ $wl = cascade ] && FP="--frames-per-step 128"
+    # cascade: ONE call in flight and the host stages inline, so that a kernel's duration is its own (with six calls in flight the
+    # kernels of different calls share the CUs and every average is inflated 2-3x); bench.py's live figure (kernel_probe) is taken
+    # the same way
+    ENVX=""; [ $wl = cascade ] && ENVX="env FD_BENCH_SLOTS=1 FD_FRAMES_ASYNC=0"
+    timeout 300 $ENVX rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$wl -- $B --workload $wl --also none --steps $S --warmup 2 $FP --no-cpu-baseline > $O/stats_$wl.json 2> $O/stats_$wl.err
   done
 fi
 if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
