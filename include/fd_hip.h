@@ -179,9 +179,11 @@ int fd_pyramid_frame_layer_download(fd_pyramid* p, int frame, int i, uint8_t* ho
 int fd_detect_five_stage_frames(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm, const fd_svm* svm, float oe_dist, float oe_ratio,
                                 int step_x, int step_y, const int* roi, fd_detection* out, int cap_per_frame, int32_t* counts,
                                 int32_t* stage_counts);
-/* The same in two halves (frames in flight: a second pyramid + WVM handle on a second context): begin queues the cascade run of
- * all frames and returns; end runs the host stages, the SVM launch and fills out / counts / stage_counts.  Every ticket must be
- * ended (end releases it, whatever it returns). */
+/* The same in two halves (frames in flight: further pyramid + WVM + SVM handles on further contexts): begin queues the cascade run
+ * of all frames and returns; the host stages (ordering the positives, overlap elimination, the SVM launch, NMS) follow on the
+ * library's queue threads as soon as the kernels retire (FD_FRAMES_ASYNC=0: inside end); end waits for them and fills out /
+ * counts / stage_counts, reporting whatever they failed with.  Between begin and end the ticket's pyramid, classifier handles
+ * and the context's stream must not be used by the caller.  Every ticket must be ended (end releases it, whatever it returns). */
 typedef struct fd_five_stage_frames fd_five_stage_frames;
 int fd_detect_five_stage_frames_begin(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm, const fd_svm* svm, float oe_dist, float oe_ratio,
                                       int step_x, int step_y, const int* roi, fd_five_stage_frames** ticket);

@@ -1,4 +1,4 @@
-# A/B of libfd_hip.so variants inside ONE gpurun call (boxes differ by up to 20 %): usage  bash tools/_ab.sh "" old4 old5 ...
+# A/B of libfd_hip.so variants inside ONE gpurun call (boxes differ by up to 20 %): usage  bash tools/ab_variants.sh "" old4 old5 ...
 R=$PWD
 for rep in 1 2; do
 for v in "$@"; do
