@@ -1391,13 +1391,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_ == 0 ? 
             FD_PROF_T(tc0);
             // rect sums of the staged records [jb0, jb1) (recL[0] = record `base`): lane == rect, four unconditional corner reads
             auto rectPasses = [&](int jb0, int jb1, int base) {
-                for (int jb = jb0; jb < jb1; jb += 128) {   // two rects per lane and pass: eight independent corner reads in flight
+                // two rects per lane and pass (eight independent corner reads in flight); the records of the next pass are requested
+                // before the corners of this one are read, so a pass costs one LDS round trip instead of two
+                uint2 ra = recL[min(jb0 + lane, jb1 - 1) - base], rb = recL[min(jb0 + 64 + lane, jb1 - 1) - base];
+                for (int jb = jb0; jb < jb1; jb += 128) {
                     const int j0 = jb + lane, j1 = jb + 64 + lane;
-                    const uint2 ra = recL[min(j0, jb1 - 1) - base], rb = recL[min(j1, jb1 - 1) - base];
+                    const uint2 na = recL[min(j0 + 128, jb1 - 1) - base], nb = recL[min(j1 + 128, jb1 - 1) - base];
                     const unsigned int sa = iiw[ra.x & 0xfffu] - iiw[(ra.x >> 12) & 0xfffu] - iiw[ra.y & 0xfffu] + iiw[(ra.y >> 12) & 0xfffu];
                     const unsigned int sb = iiw[rb.x & 0xfffu] - iiw[(rb.x >> 12) & 0xfffu] - iiw[rb.y & 0xfffu] + iiw[(rb.y >> 12) & 0xfffu];
                     if (j0 < jb1) atomicAdd(&svw[(ra.x >> 24) | ((ra.y >> 24) << 8)], (int)sa);
                     if (j1 < jb1) atomicAdd(&svw[(rb.x >> 24) | ((rb.y >> 24) << 8)], (int)sb);
+                    ra = na;
+                    rb = nb;
                 }
             };
             if ((int)threadIdx.x <= gens) genTab[0][threadIdx.x] = m.genBegin[gi0 + threadIdx.x];
@@ -1435,6 +1440,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_ == 0 ? 
                         int* svn = svw + cls * WVM_SVS;
                         double sum_xp = 0.0;
                         int sumv0 = sx_total;
+#ifndef FD_CHAIN_BATCHED
+#define FD_CHAIN_BATCHED 1
+#endif
+#if FD_CHAIN_BATCHED
+                        // all grey-value sums first (independent LDS reads, one wait), then their clearing, then the ordered arithmetic
+                        int sr[MAXV];
+#pragma unroll
+                        for (int v = 1; v < MAXV; ++v) sr[v] = v < maxCnt ? svn[v] : 0;
+#pragma unroll
+                        for (int v = 1; v < MAXV; ++v)
+                            if (v < maxCnt) svn[v] = 0;
+#pragma unroll
+                        for (int v = 1; v < MAXV; ++v) {
+                            if (v < cnt) {
+                                sumv0 -= sr[v];
+                                const double prod = (double)sr[v] * valr[v];
+                                sum_xp = sum_xp + prod;
+                            }
+                        }
+#else
 #pragma unroll
                         for (int v = 1; v < MAXV; ++v) {
                             if (v < maxCnt) {
@@ -1447,6 +1472,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_ == 0 ? 
                                 }
                             }
                         }
+#endif
                         const double t0 = (double)sumv0 * valr[0];
                         sum_xp = sum_xp + t0;
                         sum_xp = sum_xp + (double)u;

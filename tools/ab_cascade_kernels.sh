@@ -1,0 +1,25 @@
+R=$PWD
+for rep in 1 2 3; do for v in cur cb0; do
+  if [ "$v" != "cur" ]; then export FD_HIP_LIB=$R/featuredetection_amd/alt/libfd_hip_$v.so; else unset FD_HIP_LIB; fi
+  python - <<PY
+import os, sys
+sys.path.insert(0, "$R")
+os.environ.setdefault("GPU_MAX_HW_QUEUES","8")
+import numpy as np, torch, bench
+from featuredetection_amd import capi, synth
+ctx = capi.Context(0)
+wm, sm = bench.cascade_models()
+NB = 32
+frames = [synth.make_frame(640, 480, seed=20260927 + i) for i in range(8)]
+p = capi.Pyramid(ctx, inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))
+p.set_frames(NB)
+w, s = capi.Wvm(ctx, wm), capi.Svm(ctx, sm)
+ctx.set_kernel_timing(True)
+ms = []
+for i in range(14):
+    p.update_frames(images=[frames[(i + j) % 8] for j in range(NB)])
+    capi.detect_five_stage_frames(ctx, p, w, s, NB)
+    ms.append(ctx.last_kernel_ms()[1])
+print("variant $v: cascade kernels %.4f ms (min %.4f)" % (float(np.mean(ms[3:])), float(np.min(ms[3:]))))
+PY
+done; done
