@@ -119,8 +119,10 @@ __global__ void k_sdm_prepare(const float* __restrict__ shapes, int B, int L, in
     if (!valid) status[f] = 1;
 }
 
+// zero outside the image.  Unsigned compares fold the two-sided tests; the offset is a 24-bit multiply + add (images are far
+// below 2^24 pixels per side): the 64-bit multiply-add of the plain index runs at a quarter of the rate.
 __device__ __forceinline__ float src_px(const uint8_t* __restrict__ img, int W, int H, int x, int y) {
-    return (x >= 0 && y >= 0 && x < W && y < H) ? (float)img[(size_t)y * W + x] : 0.f;
+    return ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) ? (float)img[(unsigned int)(__mul24(y, W) + x)] : 0.f;
 }
 
 // one wavefront per (face, landmark).  LDS per wave is what bounds the occupancy of this latency-bound kernel, so regions
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             }
             wave_sync();
             for (int i = lane; i < npix; i += 64) {
-                const int dy = divw(i), dx = i - dy * iw;
+                const int dy = divw(i), dx = i - __mul24(dy, iw);
                 const float fx = rfx[dx], fy = rfy[dy];
                 const int sx = rsx[dx], sx1 = rsx1[dx], y0 = ry0[dy], y1 = ry1[dy];
                 const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             wave_sync();
         } else {
             for (int i = lane; i < npix; i += 64) {
-                const int dy = divw(i), dx = i - dy * iw;
+                const int dy = divw(i), dx = i - __mul24(dy, iw);
                 S.img[i] = src_px(img, p.W, p.H, ox + dx, oy + dy);
             }
         }
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         wave_sync();
         // ---- gradient magnitude and hard orientation assignment per interior pixel (hog.c:612-665)
         auto gradient = [&](int i, float& gout) -> int {   // returns the orientation bin or -1, -2 for border pixels
-            const int y = divw(i), x = i - y * iw;
+            const int y = divw(i), x = i - __mul24(y, iw);
             if (x < 1 || y < 1 || x >= iw - 1 || y >= ih - 1) return -2;
             const float* it = S.img + i;
             float gradx = *(it + 1) - *(it - 1);
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 const int i = lane + 64 * t;
                 if (ob[t] > -2) {
                     S.grad[i] = gr[t];
-                    if (ob[t] >= 0) { const int y = divw(i); atomicOr(&masks[ob[t] * ih + y], (mask_t)1 << (i - y * iw)); }
+                    if (ob[t] >= 0) { const int y = divw(i); atomicOr(&masks[__mul24(ob[t], ih) + y], (mask_t)1 << (i - __mul24(y, iw))); }
                 }
             }
         } else {
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 const int b0 = gradient(i, g);
                 if (b0 > -2) {
                     S.grad[i] = g;
-                    if (b0 >= 0) { const int y = divw(i); atomicOr(&masks[b0 * ih + y], (mask_t)1 << (i - y * iw)); }
+                    if (b0 >= 0) { const int y = divw(i); atomicOr(&masks[__mul24(b0, ih) + y], (mask_t)1 << (i - __mul24(y, iw))); }
                 }
             }
         }
@@ -325,11 +327,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             const float* __restrict__ wxs = S.wsel + cx * m_;
             const float* __restrict__ wys = S.wsel + cy * m_;
             float acc = 0.f;
+            const int oih = __mul24(o, ih);
             for (int y = ylo; y < yhi; ++y) {
-                mask_t mk = masks[o * ih + y] & cm;
+                mask_t mk = masks[oih + y] & cm;
                 if (!mk) continue;
                 const float wy = wys[y];
-                const float* __restrict__ grow = S.grad + y * iw;
+                const float* __restrict__ grow = S.grad + __mul24(y, iw);
                 while (mk) {
                     const int x = (SMALL ? __ffs((int)mk) : __ffsll((long long)mk)) - 1;
                     mk &= mk - 1;
