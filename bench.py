@@ -162,7 +162,7 @@ class Cascade(Workload):
     name = "cascade"
     dtype = "u8/i32/f32/f64"
 
-    def __init__(self, env, W=640, H=480, frames_per_step=512, nb=32, multi=True):
+    def __init__(self, env, W=640, H=480, frames_per_step=512, nb=64, multi=True):
         import torch
         from featuredetection_amd import capi, synth
         self.env, self.capi, self.W, self.H = env, capi, W, H

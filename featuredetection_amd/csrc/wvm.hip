@@ -1691,6 +1691,7 @@ void launch_sized(fd_ctx* ctx, hipStream_t st, int64_t total, const WvmDev& dev,
         if (dev.maxCnt <= 8) {
             static int perCuB = 0;
             if (perCuB == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuB, k_wvm_deepB<PW_, PH_, RAW, 8>, 256, 0) != hipSuccess || perCuB < 1)) perCuB = 2;
+            if (const char* e = getenv("FD_WVM_DEEPB_PER_CU")) if (atoi(e) > 0) perCuB = std::min(perCuB, atoi(e));
             const int gridB = (int)std::min<int64_t>((total + 3) / 4, (int64_t)ctx->num_cus * perCuB);
             hipLaunchKernelGGL((k_wvm_deepB<PW_, PH_, RAW, 8>), dim3(gridB), dim3(256), 0, st, arena, wt, dev, o);
         } else {
