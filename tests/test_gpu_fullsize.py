@@ -240,7 +240,7 @@ def test_batch_on_pool_streams_waits_for_the_pyramid_update(oracle, capi, ctx, s
         p.close()
 
 
-@pytest.mark.parametrize("nframes,size", [(5, (640, 480)), (16, (320, 240)), (3, (960, 540))])
+@pytest.mark.parametrize("nframes,size", [(5, (640, 480)), (16, (320, 240)), (3, (960, 540)), (64, (320, 240))])
 def test_multi_frame_pyramid_equals_single_frames(oracle, capi, ctx, synth, small_models, nframes, size):
     """fd_pyramid_set_frames / fd_pyramid_update_frames / fd_detect_five_stage_frames: n frames in one pyramid, one launch per pyramid
     stage, ONE cascade run and ONE SVM launch per call.  Every frame's layers and detections (boxes, order, scores, stage counts)
@@ -322,3 +322,28 @@ def test_multi_frame_calls_in_flight_on_two_contexts(capi, ctx, synth, small_mod
     for c_, p_, w_, s_ in sets:
         w_.close(); s_.close(); p_.close()
     sets[1][0].close()
+
+
+def test_multi_frame_ticket_reports_errors_and_stays_usable(capi, ctx, synth, small_models):
+    """The host stages of fd_detect_five_stage_frames_begin run on the library's queue threads: what they fail with (here: more
+    detections than the caller's capacity) is reported by _end, the handles stay usable, and end_flat() returns the same
+    detections as end()."""
+    wvm, svm = small_models
+    NF = 4
+    frames = [synth.make_frame(320, 240, seed=1300 + i) for i in range(NF)]
+    p_ = capi.Pyramid(ctx, **FF_)
+    p_.set_frames(NF)
+    w_, s_ = capi.Wvm(ctx, wvm), capi.Svm(ctx, svm)
+    p_.update_frames(images=frames)
+    ref = capi.detect_five_stage_frames(ctx, p_, w_, s_, NF, cap=256)
+    most = max(len(d) for d, _ in ref)
+    assert most >= 2
+    run = capi.FiveStageFrames(ctx, p_, w_, s_, NF, cap=most - 1)
+    with pytest.raises(capi.FdError):
+        run.end()
+    p_.update_frames(images=frames)
+    dets, fidx, stages = capi.FiveStageFrames(ctx, p_, w_, s_, NF, cap=256).end_flat()
+    assert len(dets) == sum(len(d) for d, _ in ref) and np.array_equal(np.bincount(fidx, minlength=NF), [len(d) for d, _ in ref])
+    assert dets.tobytes() == b"".join(d.tobytes() for d, _ in ref)
+    assert np.array_equal(stages, np.stack([s for _, s in ref]))
+    w_.close(); s_.close(); p_.close()
