@@ -161,8 +161,10 @@ class Cascade(Workload):
     """BASELINE headline: FaceFrontal five-stage cascade, WxH frames (default 640x480)"""
     name = "cascade"
     dtype = "u8/i32/f32/f64"
+    records_cap = 1 << 17     # ~3.4 detections per frame, 4096 frames per step, a gather every 2 steps
+    gather_every = 2
 
-    def __init__(self, env, W=640, H=480, frames_per_step=512, nb=64, multi=True):
+    def __init__(self, env, W=640, H=480, frames_per_step=4096, nb=64, multi=True):   # ~50 ms per step: 20 steps are a second of GPU work
         import torch
         from featuredetection_amd import capi, synth
         self.env, self.capi, self.W, self.H = env, capi, W, H
@@ -440,7 +442,7 @@ class Ffp15(Workload):
     name = "ffp15"
     dtype = "u8/i32/f32/f64"
 
-    def __init__(self, env, W=1920, H=1080, frames_per_step=1):
+    def __init__(self, env, W=1920, H=1080, frames_per_step=4):
         import torch
         from featuredetection_amd import capi, synth
         self.env, self.capi, self.W, self.H = env, capi, W, H
