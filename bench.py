@@ -451,32 +451,54 @@ class Ffp15(Workload):
         self.dframes = [torch.from_numpy(f).to(env.dev) for f in self.frames]
         self.models = ffp15_models()
         ctx = env.ctx
-        self.pyrs, self.dets = {}, []
-        for name, key, wm, sm, pw, ph in self.models:
-            if key not in self.pyrs:   # detectors with identical pyramid parameters share one pyramid (identical layers)
-                self.pyrs[key] = capi.Pyramid(ctx, inc=float(np.float32(key[0])), min_scale=float(np.float32(key[1])), max_scale=float(np.float32(key[2])))
-            self.dets.append((name, self.pyrs[key], capi.Wvm(ctx, wm), capi.Svm(ctx, sm), pw, ph))
+        # two frames in flight (FD_BENCH_FFP_SLOTS), each with its own pyramids and classifier handles: frame f + 1's pyramids and
+        # cascades are queued before frame f's host stages (ordering, overlap elimination, SVM launches, NMS) are collected
+        nslots = max(1, int(os.environ.get("FD_BENCH_FFP_SLOTS", "2")))
+        self.slots = []
+        for k in range(nslots):
+            pyrs, dets = {}, []
+            for name, key, wm, sm, pw, ph in self.models:
+                if key not in pyrs:   # detectors with identical pyramid parameters share one pyramid (identical layers)
+                    pyrs[key] = capi.Pyramid(ctx, inc=float(np.float32(key[0])), min_scale=float(np.float32(key[1])), max_scale=float(np.float32(key[2])))
+                dets.append((name, pyrs[key], capi.Wvm(ctx, wm), capi.Svm(ctx, sm), pw, ph))
+            self.slots.append(dict(pyrs=pyrs, dets=dets, run=None, img=None))
+        self.pyrs, self.dets = self.slots[0]["pyrs"], self.slots[0]["dets"]
         for pr in self.pyrs.values():
             pr.update(self.frames[0])
         self.nwin = sum(pr.window_count(pw, ph, 1, 1) for _, pr, _, _, pw, ph in self.dets)
+        self.ncalls = 0
         self.metric = "Mpatches/s (extract+WVM+SVM cascade, 15 detectors), %dx%d pyramid" % (W, H)
         self.config = dict(workload="config 3: the 15 detectors of ffpDetectApp/*.cfg (five-stage WVM -> OE -> RBF-SVM 1024 SV -> NMS each), full %dx%d "
-                                    "frame, step 1: %d windows per frame; %d shared pyramids; fd_five_stage_batch_begin/_end" % (W, H, self.nwin, len(self.pyrs)),
+                                    "frame, step 1: %d windows per frame; %d shared pyramids; fd_five_stage_batch_begin/_end, %d frames in flight" %
+                                    (W, H, self.nwin, len(self.pyrs), nslots),
                            frames_per_step=self.FP, parallelism="image-shard dp%d" % env.world)
+
+    def _collect(self, sl):
+        res, sl["run"] = sl["run"].end(), None
+        return [(sl["img"], di, d_) for di, (d_, _) in enumerate(res)]
 
     def step(self, i):
         capi = self.capi
         out = []
         for j in range(self.FP):
             f = i * self.FP + j
+            sl = self.slots[self.ncalls % len(self.slots)]
+            self.ncalls += 1
+            if sl["run"] is not None:
+                out.extend(self._collect(sl))
             fr = self.dframes[f % 2]
-            for pr in self.pyrs.values():
+            for pr in sl["pyrs"].values():
                 pr.update_device(fr.data_ptr(), self.W, self.H, 3)
-            b = capi.FiveStageBatch(self.env.ctx, [(pr, wv, sv_) for _, pr, wv, sv_, _, _ in self.dets], cap=4096)
-            img = f * self.env.world + self.env.rank
-            for di, (d_, _) in enumerate(b.end()):
-                out.append((img, di, d_))
+            sl["run"] = capi.FiveStageBatch(self.env.ctx, [(pr, wv, sv_) for _, pr, wv, sv_, _, _ in sl["dets"]], cap=4096)
+            sl["img"] = f * self.env.world + self.env.rank
         return self.nwin * self.FP, out
+
+    def flush(self):
+        out = []
+        for sl in self.slots:
+            if sl["run"] is not None:
+                out.extend(self._collect(sl))
+        return out
 
     def kernel_probe(self):
         """FaceFrontal's cascade kernels on the 1080p frame (single five-stage call) + the batch's issue roofline from the PMC passes"""
