@@ -577,15 +577,32 @@ class Sdm(Workload):
         self.dimgs = torch.from_numpy(imgs).to(env.dev)
         self.model = synth.make_sdm(9, L=68, S=4)
         self.sdm = capi.Sdm(env.ctx, self.model)
+        # fd_sdm_fit_batch blocks until a batch's shapes are on the host; three host threads, each with its own context and model handle
+        # (contexts are not shared between threads), keep a second batch's kernels queued meanwhile (FD_BENCH_SDM_THREADS)
+        self.nthreads = max(1, int(os.environ.get("FD_BENCH_SDM_THREADS", "3")))
+        self.extra = []
+        for _ in range(self.nthreads - 1):
+            c_ = capi.Context(env.local_rank)
+            self.extra.append((c_, capi.Sdm(c_, self.model)))
+        self.pool = None
+        if self.nthreads > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            self.pool = ThreadPoolExecutor(self.nthreads - 1)
         self.boxes = np.array([[48, 48, 160, 160]] * self.B, np.int32)
         self.metric = "SDM iters/s (x1e6): 68 landmarks, HOG at each point + linear regressor, 4 cascade steps, batch of 256 face crops"
         self.config = dict(workload="config 4: 256 gray 256x256 crops, 68 landmarks, 4 cascade steps, adaptive VlHog 3x3x31 per landmark + regressor "
-                                    "18973x136 (f64 MFMA); fd_sdm_fit_batch, shapes delivered per batch", batches_per_step=self.FP,
+                                    "18973x136 (f64 MFMA); fd_sdm_fit_batch, shapes delivered per batch, %d host threads" % self.nthreads, batches_per_step=self.FP,
                            parallelism="face-shard dp%d" % env.world)
 
     def step(self, i):
-        for _ in range(self.FP):
-            self.sdm.fit_device(self.dimgs.data_ptr(), self.W, self.H, self.B, self.boxes)
+        def run(sdm, n):
+            for _ in range(n):
+                sdm.fit_device(self.dimgs.data_ptr(), self.W, self.H, self.B, self.boxes)
+        share = self.FP // self.nthreads
+        futs = [self.pool.submit(run, sd, share) for _, sd in self.extra] if self.pool else []
+        run(self.sdm, self.FP - share * len(futs))
+        for f in futs:
+            f.result()
         return self.B * 4 * self.FP, []
 
     def kernel_probe(self):
