@@ -328,16 +328,28 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             const float* __restrict__ wys = S.wsel + cy * m_;
             float acc = 0.f;
             const int oih = __mul24(o, ih);
+            // software-pipelined: the next row's mask / weight and the next vote's two LDS operands are requested before the current
+            // vote is added (the loads do not depend on the running sum; issued in line they put one LDS round trip on every add)
+            mask_t mkN = ylo < yhi ? (mask_t)(masks[oih + ylo] & cm) : (mask_t)0;
+            float wyN = ylo < yhi ? wys[ylo] : 0.f;
             for (int y = ylo; y < yhi; ++y) {
-                mask_t mk = masks[oih + y] & cm;
+                mask_t mk = mkN;
+                const float wy = wyN;
+                if (y + 1 < yhi) { mkN = masks[oih + y + 1] & cm; wyN = wys[y + 1]; }
                 if (!mk) continue;
-                const float wy = wys[y];
                 const float* __restrict__ grow = S.grad + __mul24(y, iw);
+                int x = (SMALL ? __ffs((int)mk) : __ffsll((long long)mk)) - 1;
+                mk &= mk - 1;
+                float g = grow[x], wx = wxs[x];
                 while (mk) {
-                    const int x = (SMALL ? __ffs((int)mk) : __ffsll((long long)mk)) - 1;
+                    x = (SMALL ? __ffs((int)mk) : __ffsll((long long)mk)) - 1;
                     mk &= mk - 1;
-                    acc = acc + grow[x] * wxs[x] * wy;
+                    const float gn = grow[x], wxn = wxs[x];
+                    acc = acc + g * wx * wy;
+                    g = gn;
+                    wx = wxn;
                 }
+                acc = acc + g * wx * wy;
             }
             S.hog[e] = acc;  // layout hog[x + y*hogW + o*hogStride] == e
         }
