@@ -138,7 +138,8 @@ struct fd_wvm {
     hipEvent_t done = nullptr;   // recorded after the cascade kernels + first read-back of a run
     HostBuf h_tail;              // pinned staging of the SVM stage of a five-stage run: [slots | distances]
     hipEvent_t tailDone = nullptr;   // recorded after the SVM stage + its read-back
-    ~fd_wvm() { if (done) (void)hipEventDestroy(done); if (tailDone) (void)hipEventDestroy(tailDone); }
+    hipEvent_t prep = nullptr;       // grouped launches: header cleared (members) / shared pre-filter queued (leader)
+    ~fd_wvm() { if (done) (void)hipEventDestroy(done); if (tailDone) (void)hipEventDestroy(tailDone); if (prep) (void)hipEventDestroy(prep); }
 };
 
 namespace {
@@ -1829,10 +1830,9 @@ static void launch_prefilter_sized(fd_ctx* ctx, hipStream_t st, const uint8_t* a
     hipLaunchKernelGGL((k_wvm_prefilter<PW_, PH_>), dim3(grid), dim3(256), 0, st, arena, wt, dv);
 }
 
-// queues k_wvm_prefilter over all windows of `wt`; returns false when the model / call does not qualify
-static bool launch_prefilter(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const uint8_t* arena, const WinTable& wt, int64_t* q, unsigned int* qcount) {
-    if (m->denseL == 0 || wt.raw || wt.list || wt.total < 512) return false;
-    WvdTable t;
+// window table of the dense kernels from the cascade's; false when the call does not qualify
+static bool wvd_table_from(const WinTable& wt, WvdTable& t) {
+    if (wt.raw || wt.list || wt.total < 512) return false;
     std::memset(&t, 0, sizeof(t));
     t.n = wt.n; t.sx = wt.sx; t.sy = wt.sy;
     const int64_t perImage = wt.nimg > 1 ? wt.per_image : wt.total;
@@ -1853,7 +1853,9 @@ static bool launch_prefilter(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const uint8
     t.imageStride = wt.image_stride;
     if ((int64_t)tiles * t.nimg > (int64_t)INT32_MAX) return false;
     t.ntiles = tiles * t.nimg;
-    WvdDev dv;
+    return true;
+}
+static void wvd_dev_from(const fd_wvm* m, int64_t* q, unsigned int* qcount, WvdDev& dv) {
     dv.B = m->denseB.as<wvd_v4i>();
     dv.c = m->denseC.as<WvdConst>();
     dv.q = q;
@@ -1862,11 +1864,37 @@ static bool launch_prefilter(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const uint8
     dv.negBasis = m->dev.negBasis; dv.negBias = m->dev.negBias; dv.stretch = m->dev.stretch;
     dv.sxxSlack = (float)(2 * m->dev.fh + 2);
     dv.scale = m->denseScale;
+}
+
+// queues k_wvm_prefilter over all windows of `wt`; returns false when the model / call does not qualify
+static bool launch_prefilter(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const uint8_t* arena, const WinTable& wt, int64_t* q, unsigned int* qcount) {
+    if (m->denseL == 0) return false;
+    WvdTable t;
+    if (!wvd_table_from(wt, t)) return false;
+    WvdDev dv;
+    wvd_dev_from(m, q, qcount, dv);
 #define FD_WVM_CASE(W, H) \
     if (m->dev.fw == W && m->dev.fh == H) { launch_prefilter_sized<W, H>(ctx, st, arena, t, dv); return true; }
     FD_WVM_CASE(20, 20) FD_WVM_CASE(24, 24) FD_WVM_CASE(16, 24) FD_WVM_CASE(32, 16) FD_WVM_CASE(32, 24)
 #undef FD_WVM_CASE
     return false;
+}
+
+template <int PW_, int PH_>
+static void launch_prefilter_multi_sized(fd_ctx* ctx, hipStream_t st, const uint8_t* arena, const WvdTable& wt, const WvdMulti& mv) {
+    static int perCu = 0;
+    if (perCu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wvm_prefilter_multi<PW_, PH_>, 256, 0) != hipSuccess || perCu < 1)) perCu = 2;
+    const int grid = (int)std::min<int64_t>(((int64_t)wt.ntiles + 3) / 4, (int64_t)ctx->num_cus * perCu * 2);
+    hipLaunchKernelGGL((k_wvm_prefilter_multi<PW_, PH_>), dim3(grid), dim3(256), 0, st, arena, wt, mv);
+}
+static bool wvd_has_multi_kernel(int fw, int fh) {
+    return (fw == 20 && fh == 20) || (fw == 24 && fh == 24) || (fw == 16 && fh == 24) || (fw == 32 && fh == 16) || (fw == 32 && fh == 24);
+}
+static void launch_prefilter_multi(fd_ctx* ctx, hipStream_t st, int fw, int fh, const uint8_t* arena, const WvdTable& t, const WvdMulti& mv) {
+#define FD_WVM_CASE(W, H) \
+    if (fw == W && fh == H) { launch_prefilter_multi_sized<W, H>(ctx, st, arena, t, mv); return; }
+    FD_WVM_CASE(20, 20) FD_WVM_CASE(24, 24) FD_WVM_CASE(16, 24) FD_WVM_CASE(32, 16) FD_WVM_CASE(32, 24)
+#undef FD_WVM_CASE
 }
 
 void fd_wvm_build_table(const fd_pyramid* p, int pw, int ph, int sx, int sy, const int* roi, WinTable& wt,
@@ -1941,12 +1969,18 @@ void fd_wvm_launch_on(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm* m, int
     wvm_launch_table(ctx, st, p, m, wt, want_all, run, time_kernel);
 }
 
-static void wvm_launch_table(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm* m, const WinTable& wt, bool want_all, WvmRun& run, bool time_kernel) {
+// first half of a cascade launch: buffers, header, output descriptor (everything in front of the first kernel)
+struct WvmLaunch {
+    CascadeOut o;
+    bool zc = false;
+    bool headerMemset = false;   // a memset of the device header was queued on the stream
+};
+static bool wvm_launch_head(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const WinTable& wt, bool want_all, WvmRun& run, bool time_kernel, WvmLaunch& L) {
     run.total = wt.total;
     run.pos.clear();
     run.slots.clear();
     run.timed = time_kernel;
-    if (wt.total == 0) return;
+    if (wt.total == 0) return false;
     if (want_all) {
         m->all_level.reserve(sizeof(int32_t) * (size_t)wt.total);
         m->all_fout.reserve(sizeof(float) * (size_t)wt.total);
@@ -1969,9 +2003,11 @@ static void wvm_launch_table(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm*
     static const bool zcOff = [] { const char* e = getenv("FD_WVM_ZEROCOPY"); return e && atoi(e) == 0; }();
     const bool zc = !zcOff && !want_all && m->dev.numUsed > WVM_LCAP;
     m->zcRun = zc;
-    if (!(zc && m->hdrClean)) HIP_CHECK(hipMemsetAsync(m->pos.p, 0, sizeof(PosRec), st));
+    L.zc = zc;
+    L.headerMemset = !(zc && m->hdrClean);
+    if (L.headerMemset) HIP_CHECK(hipMemsetAsync(m->pos.p, 0, sizeof(PosRec), st));
     m->hdrClean = false;   // set again by fd_wvm_finish once a zero-copy run has completed
-    CascadeOut o;
+    CascadeOut& o = L.o;
     o.all_level = want_all ? m->all_level.as<int32_t>() : nullptr;
     o.all_fout = want_all ? m->all_fout.as<float>() : nullptr;
     o.pos = (zc ? m->h_pos.as<PosRec>() : m->pos.as<PosRec>()) + 1;   // pinned host memory is device-accessible under the same address
@@ -1984,11 +2020,30 @@ static void wvm_launch_table(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm*
     o.done_blocks = m->pos.as<unsigned int>() + 3;  // header word 3
     if (zc) *m->h_pos.as<unsigned int>() = 0xffffffffu;   // overwritten by the last stage-B workgroup
     if (time_kernel) HIP_CHECK(hipEventRecord(ctx->ev0, st));
+    return true;
+}
+// second half: the exact cascade kernels on `wtq`, read-back, completion event
+static void wvm_launch_tail(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm* m, const WinTable& wt, const WinTable& wtq, const WvmLaunch& L, bool skipA,
+                            bool time_kernel) {
+    launch_cascade<false>(ctx, st, wt.total, m->dev, p->arena.as<uint8_t>(), wtq, L.o, skipA);
+    if (time_kernel) HIP_CHECK(hipEventRecord(ctx->ev1, st));
+    HIP_CHECK(hipGetLastError());
+    if (!L.zc) {
+        const size_t firstChunk = (size_t)std::min<int64_t>(m->pos_cap, WVM_FIRST_CHUNK);
+        HIP_CHECK(hipMemcpyAsync(m->h_pos.p, m->pos.p, sizeof(PosRec) * (firstChunk + 1), hipMemcpyDeviceToHost, st));
+    }
+    HIP_CHECK(hipEventRecord(m->done, st));
+}
+
+static void wvm_launch_table(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm* m, const WinTable& wt, bool want_all, WvmRun& run, bool time_kernel) {
+    WvmLaunch L;
+    if (!wvm_launch_head(ctx, st, m, wt, want_all, run, time_kernel, L)) return;
+    const CascadeOut& o = L.o;
     WinTable wtq = wt;
     bool skipA = false;
     // production path: the dense pre-filter drops every window the first cascade levels reject with a margin; the exact
     // cascade then only sees the queue (header word 2 = its length).  Per-window outputs need the exact path for all.
-    // Default: the pre-filter feeds stage B's queue directly (k_wvm_deep4 evaluates a window from level 0 anyway; measured
+    // Default: the pre-filter feeds stage B's queue directly (stage B evaluates a window from level 0 anyway; measured
     // 1157 -> 1445 Mpatches/s on config 3 against running the stage-A kernel on the queue first); FD_WVM_DENSE_DIRECT=0
     // inserts stage A between them.
     static const bool direct = [] { const char* e = getenv("FD_WVM_DENSE_DIRECT"); return !(e && atoi(e) == 0); }();
@@ -2003,14 +2058,54 @@ static void wvm_launch_table(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm*
             }
         }
     }
-    launch_cascade<false>(ctx, st, wt.total, m->dev, p->arena.as<uint8_t>(), wtq, o, skipA);
-    if (time_kernel) HIP_CHECK(hipEventRecord(ctx->ev1, st));
-    HIP_CHECK(hipGetLastError());
-    if (!zc) {
-        const size_t firstChunk = (size_t)std::min<int64_t>(m->pos_cap, WVM_FIRST_CHUNK);
-        HIP_CHECK(hipMemcpyAsync(m->h_pos.p, m->pos.p, sizeof(PosRec) * (firstChunk + 1), hipMemcpyDeviceToHost, st));
+    wvm_launch_tail(ctx, st, p, m, wt, wtq, L, skipA, time_kernel);
+}
+
+// Several detectors on the SAME windows (one pyramid, one patch size, the same steps and roi): one pre-filter launch equalises
+// every tile once and runs each detector's dense levels on it (k_wvm_prefilter_multi); the exact stage B of detector d then
+// runs on streams[d] behind it.  Returns false (nothing queued) when the group does not qualify; the caller then launches the
+// detectors one by one.
+static bool fd_wvm_launch_group(fd_ctx* ctx, hipStream_t* streams, fd_pyramid* p, fd_wvm** ms, int nd, int sx, int sy, const int* roi, WvmRun** runs) {
+    // Off by default (FD_WVM_GROUP=1 enables it): measured on config 3, the shared pre-filter does 13 % less kernel time than
+    // seven single launches in isolation (3.85 vs 7 x 0.63 ms for the 24x24 group) but loses end to end (3470 vs 3575 Mpatches/s):
+    // the independent launches overlap each other and the stage-B kernels of the detectors in front, one long launch does not.
+    const bool off = [] { const char* e = getenv("FD_WVM_GROUP"); return !(e && atoi(e) == 1); }();   // read per call: tests toggle it
+    static const bool direct = [] { const char* e = getenv("FD_WVM_DENSE_DIRECT"); return !(e && atoi(e) == 0); }();
+    if (off || !direct || nd < 2 || nd > WVD_MAXD) return false;
+    for (int d = 0; d < nd; ++d) {
+        fd_wvm* m = ms[d];
+        if (p->ctx != ctx || m->ctx != ctx || m->denseL == 0 || m->dev.fw != ms[0]->dev.fw || m->dev.fh != ms[0]->dev.fh || m->dev.numUsed <= WVM_LCAP) return false;
     }
-    HIP_CHECK(hipEventRecord(m->done, st));
+    if (p->filter_kind != FD_LAYER_NONE || p->all.empty()) return false;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    WinTable wt;
+    fd_wvm_build_table(p, ms[0]->dev.fw, ms[0]->dev.fh, sx, sy, roi, wt, runs[0]->wls);
+    WvdTable t;
+    if (!wvd_table_from(wt, t)) return false;
+    if (!wvd_has_multi_kernel(ms[0]->dev.fw, ms[0]->dev.fh)) return false;
+    for (int d = 1; d < nd; ++d) runs[d]->wls = runs[0]->wls;
+    WvmLaunch L[WVD_MAXD];
+    WvdMulti mv;
+    std::memset(&mv, 0, sizeof(mv));
+    mv.nd = nd;
+    for (int d = 0; d < nd; ++d) {
+        fd_pyramid_wait(p, streams[d]);
+        if (!wvm_launch_head(ctx, streams[d], ms[d], wt, false, *runs[d], false, L[d])) return true;   // no windows: nothing to do for anyone
+        if (d > 0 && L[d].headerMemset && streams[d] != streams[0]) {   // the pre-filter (on streams[0]) counts into this header
+            if (!ms[d]->prep) HIP_CHECK(hipEventCreateWithFlags(&ms[d]->prep, hipEventDisableTiming));
+            HIP_CHECK(hipEventRecord(ms[d]->prep, streams[d]));
+            HIP_CHECK(hipStreamWaitEvent(streams[0], ms[d]->prep, 0));
+        }
+        wvd_dev_from(ms[d], L[d].o.deep_q, L[d].o.deep_count, mv.d[d]);
+    }
+    launch_prefilter_multi(ctx, streams[0], ms[0]->dev.fw, ms[0]->dev.fh, p->arena.as<uint8_t>(), t, mv);
+    if (!ms[0]->prep) HIP_CHECK(hipEventCreateWithFlags(&ms[0]->prep, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(ms[0]->prep, streams[0]));
+    for (int d = 0; d < nd; ++d) {
+        if (streams[d] != streams[0]) HIP_CHECK(hipStreamWaitEvent(streams[d], ms[0]->prep, 0));
+        wvm_launch_tail(ctx, streams[d], p, ms[d], wt, wt, L[d], true, false);
+    }
+    return true;
 }
 
 // Synchronous half: waits for m->done, fetches the remaining positives and sorts them into extraction order.
@@ -2657,9 +2752,47 @@ static void five_stage_batch_begin(fd_ctx* ctx, fd_five_stage_job* jobs, int n, 
         fd_five_stage_job& j = jobs[i];
         if (j.image) fd_pyramid_update_on(j.pyramid, j.image, j.image_w, j.image_h, j.image_channels, j.image_is_device, fd_pool_stream(ctx, i));
     };
-    auto cascadeJob = [&](int i) {
-        fd_five_stage_job& j = jobs[i];
-        fd_wvm_launch_on(ctx, fd_pool_stream(ctx, i), j.pyramid, const_cast<fd_wvm*>(j.wvm), j.step_x, j.step_y, j.roi, false, b.runs[i], false);
+    // units of cascade launches: detectors that scan the SAME windows (one pyramid, one patch size, same steps, no roi) share one
+    // pre-filter launch (fd_wvm_launch_group), everything else is launched on its own
+    std::vector<std::vector<int>> units;
+    {
+        std::vector<char> taken((size_t)n, 0);
+        for (int i = 0; i < n; ++i) {
+            if (taken[(size_t)i]) continue;
+            std::vector<int> u{i};
+            taken[(size_t)i] = 1;
+            const fd_five_stage_job& a = jobs[i];
+            if (!a.roi) {
+                for (int k = i + 1; k < n && (int)u.size() < WVD_MAXD; ++k) {
+                    const fd_five_stage_job& c = jobs[k];
+                    if (taken[(size_t)k] || c.roi || c.pyramid != a.pyramid || c.step_x != a.step_x || c.step_y != a.step_y) continue;
+                    if (c.wvm->dev.fw != a.wvm->dev.fw || c.wvm->dev.fh != a.wvm->dev.fh) continue;
+                    u.push_back(k);
+                    taken[(size_t)k] = 1;
+                }
+            }
+            units.push_back(std::move(u));
+        }
+    }
+    const int nunits = (int)units.size();
+    auto cascadeJob = [&](int ui) {
+        const std::vector<int>& u = units[(size_t)ui];
+        if (u.size() > 1) {
+            hipStream_t streams[WVD_MAXD];
+            fd_wvm* ms[WVD_MAXD];
+            WvmRun* runs[WVD_MAXD];
+            for (size_t d = 0; d < u.size(); ++d) {
+                streams[d] = fd_pool_stream(ctx, u[d]);
+                ms[d] = const_cast<fd_wvm*>(jobs[u[d]].wvm);
+                runs[d] = &b.runs[(size_t)u[d]];
+            }
+            const fd_five_stage_job& j0 = jobs[u[0]];
+            if (fd_wvm_launch_group(ctx, streams, j0.pyramid, ms, (int)u.size(), j0.step_x, j0.step_y, nullptr, runs)) return;
+        }
+        for (int i : u) {
+            fd_five_stage_job& j = jobs[i];
+            fd_wvm_launch_on(ctx, fd_pool_stream(ctx, i), j.pyramid, const_cast<fd_wvm*>(j.wvm), j.step_x, j.step_y, j.roi, false, b.runs[i], false);
+        }
     };
     // A frame costs ~15 runtime calls (pyramid kernels, cascade kernels, copies, events): with many small jobs the single host
     // thread issuing them is the bottleneck, so batches of >= 6 jobs are issued by the worker pool -- all pyramid updates first
@@ -2669,11 +2802,11 @@ static void five_stage_batch_begin(fd_ctx* ctx, fd_five_stage_job* jobs, int n, 
         if (!ctx->workers) ctx->workers.reset(new FdWorkerPool(nthreads - 1));
         std::mutex errMu;
         FdError firstErr{FD_OK, std::string()};
-        auto phase = [&](const std::function<void(int)>& f) {
+        auto phase = [&](const std::function<void(int)>& f, int count) {
             std::atomic<int> next{0};
             ctx->workers->run([&] {
                 (void)hipSetDevice(ctx->device);
-                for (int i; (i = next.fetch_add(1)) < n;) {
+                for (int i; (i = next.fetch_add(1)) < count;) {
                     try { f(i); } catch (const FdError& e) {
                         std::lock_guard<std::mutex> lk(errMu);
                         if (firstErr.code == FD_OK) firstErr = e;
@@ -2684,13 +2817,11 @@ static void five_stage_batch_begin(fd_ctx* ctx, fd_five_stage_job* jobs, int n, 
         };
         bool anyImage = false;
         for (int i = 0; i < n; ++i) anyImage |= jobs[i].image != nullptr;
-        if (anyImage) phase(updateJob);
-        phase(cascadeJob);
+        if (anyImage) phase(updateJob, n);
+        phase(cascadeJob, nunits);
     } else {
-        for (int i = 0; i < n; ++i) {
-            updateJob(i);
-            cascadeJob(i);
-        }
+        for (int i = 0; i < n; ++i) updateJob(i);
+        for (int ui = 0; ui < nunits; ++ui) cascadeJob(ui);
     }
     static const bool trace = getenv("FD_TRACE") != nullptr;
     if (trace)

@@ -66,6 +66,14 @@ struct WvdDev {
     double scale;              // 2^-s; also the error of norm per unit of sum(x): 2 * 2^-(s+1)
 };
 
+// several detectors on the same windows (same pyramid, patch size and steps: the lip / nose / eye-corner detectors of
+// ffpDetectApp): k_wvm_prefilter_multi equalises a tile once and runs the contraction + levels of every detector on it
+constexpr int WVD_MAXD = 8;
+struct WvdMulti {
+    int32_t nd;
+    WvdDev d[WVD_MAXD];
+};
+
 namespace {
 
 template <int PW_>
@@ -349,5 +357,265 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
         wave_sync();
     }
 }
+
+// ---- the same for several detectors that share their windows ------------------------------------------------------------
+// HistEq64 depends on the window only, so the histogram, the cdf chain and the LUT (steps 1-2, ~45 % of the single-detector
+// kernel) are done once per tile; the equalise + contraction + levels (steps 3-6) run once per detector against its own digit
+// matrix, constants and queue.  The LUT therefore has to outlive the transposes that reuse the histogram block: it is kept as
+// bytes in its own 4 KB block per wavefront ([bin][lane], 4 KB-aligned so that (bin << 6) | (block + lane) is a complete
+// address), and the k-step pixel chunk lives in the (then dead) histogram block.  48 KB of LDS per workgroup = 3 workgroups per
+// CU; three wavefronts per SIMD were measured equal to four for this kernel (it is bound by instruction issue).
+struct __attribute__((aligned(8192))) WvdLdsM {
+    unsigned short hist[4][64][64];                  // [wave][bin][slot of the lane]: counters; then the k-step chunk (first 2 KB); then the transposes
+    unsigned char lut[4][64][64];                    // [wave][bin][lane]
+};
+template <int B_>
+__device__ __forceinline__ unsigned int wvd_slot_lut(unsigned int w4, unsigned int laneOffLut) {
+    unsigned int bin, a;
+    asm("v_bfe_u32 %0, %1, %2, 6" : "=v"(bin) : "v"(w4), "n"(8 * B_ + 2));
+    asm("v_lshl_or_b32 %0, %1, 6, %2" : "=v"(a) : "v"(bin), "v"(laneOffLut));
+    return a;
+}
+__device__ __forceinline__ unsigned int wvd_lut8(unsigned int ldsAddr) { return *(__attribute__((address_space(3))) unsigned char*)(uintptr_t)ldsAddr; }   // ds_read_u8
+
+template <int PW_, int PH_>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_wvm_prefilter_multi(const uint8_t* __restrict__ arena, WvdTable wt, WvdMulti mv) {
+    static_assert(PW_ % 4 == 0 && PW_ >= 16 && PW_ <= 32, "rows are read as dwords; a row (or two 16-wide rows) fills one k-step");
+    constexpr int RPS = WvdGeo<PW_>::RPS;
+    static_assert(PH_ % RPS == 0, "whole k-steps");
+    constexpr int KS = PH_ / RPS;
+    constexpr int NW = PW_ / 4;          // dwords per patch row
+    __shared__ WvdLdsM S;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float stretch = mv.d[0].stretch, sxxSlack = mv.d[0].sxxSlack;   // the same for all detectors of a group (patch size)
+    const int ntiles = wt.ntiles;
+    int li = 0;
+    unsigned char* histPtr = reinterpret_cast<unsigned char*>(&S.hist[wave][0][0]);
+    unsigned char* xPtr = histPtr;   // the k-step chunk lives in the histogram block (dead between the LUT and the transposes)
+    const unsigned int lutLds = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&S.lut[wave][0][0];   // 4 KB-aligned
+    const unsigned int laneOffLut = lutLds + (unsigned int)lane;
+    double* trPtr = reinterpret_cast<double*>(histPtr);
+    const unsigned int histLds = (unsigned int)(uintptr_t)(wvd_lds_u16*)&S.hist[wave][0][0];   // LDS byte address, 8 KB-aligned
+    // lanes l and l + 32 share a dword of every bin row: they are served in different LDS cycles, so nothing conflicts
+    const unsigned int laneOff32 = histLds + (unsigned int)(lane & 31) * 4u;
+    const unsigned int laneOff16 = laneOff32 + (unsigned int)(lane >> 5) * 2u;
+    const unsigned int inc = 1u << (16 * (lane >> 5));
+
+    int lastImg = 0;
+    for (int gtile = blockIdx.x * 4 + wave; gtile < ntiles; gtile += gridDim.x * 4) {
+        const int img = wt.nimg > 1 ? gtile / wt.tilesPerImage : 0;   // frame of a multi-frame pyramid
+        const int tile = gtile - img * wt.tilesPerImage;
+        if (img != lastImg) { li = 0; lastImg = img; }
+        while (li + 1 < wt.n && tile >= wt.l[li + 1].tileFirst) ++li;   // tiles ascend per wavefront inside a frame
+        const WvdLayer& wl = wt.l[li];
+        const int local0 = (tile - wl.tileFirst) * 64 + lane;
+        const bool valid = local0 < wl.nwin;
+        const unsigned int local = (unsigned int)(valid ? local0 : wl.nwin - 1);
+        unsigned int iy = __umulhi(local, wl.magic);   // floor(local / nx) or one less
+        unsigned int ix = local - iy * (unsigned int)wl.nx;
+        if (ix >= (unsigned int)wl.nx) { ix -= wl.nx; ++iy; }
+        const int lw = wl.lw;
+        const uint8_t* src = arena + (size_t)img * wt.imageStride + wl.off + (size_t)(wl.by + (int)iy * wt.sy) * lw + (wl.bx + (int)ix * wt.sx);
+        const int64_t wid = (int64_t)img * wt.perImage + wl.first + local;
+
+        // ---- 1. histogram: 64 bins x 64 lanes of u16 counters
+        {
+            uint4* z = reinterpret_cast<uint4*>(histPtr);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) z[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            unsigned int wn[NW];
+#pragma unroll
+            for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(src + 4 * j);
+#pragma unroll 1
+            for (int r = 0; r < PH_; ++r) {   // one patch row per iteration, the next row's loads in flight
+                unsigned int w4[NW];
+#pragma unroll
+                for (int j = 0; j < NW; ++j) w4[j] = wn[j];
+                const uint8_t* nsrc = src + (size_t)(r + 1 < PH_ ? r + 1 : r) * lw;
+#pragma unroll
+                for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(nsrc + 4 * j);
+#pragma unroll
+                for (int j = 0; j < NW; ++j) {
+                    wvd_count(wvd_slot<0>(w4[j], laneOff32), inc);
+                    wvd_count(wvd_slot<1>(w4[j], laneOff32), inc);
+                    wvd_count(wvd_slot<2>(w4[j], laneOff32), inc);
+                    wvd_count(wvd_slot<3>(w4[j], laneOff32), inc);
+                }
+            }
+        }
+        wave_sync();
+        // ---- 2. the fp32 cdf in the reference's order (cdf[0] = pdf[0]; cdf[b] = cdf[b-1] + pdf[b]), the LUT, and the exact
+        //         integer sum / sum of squares of the equalised patch
+        unsigned int sumx = 0, sumxx = 0;
+        {
+            float cdf = 0.f;
+#pragma unroll
+            for (int b = 0; b < 64; ++b) {
+                wvd_lds_u16* slot = (wvd_lds_u16*)(uintptr_t)((unsigned int)(b << 7) + laneOff16);   // laneOff16 is a complete LDS address
+                const unsigned int cnt = *slot;
+                const float pdf = (float)cnt * stretch;
+                cdf = b == 0 ? pdf : cdf + pdf;
+                // (uchar)floor((double)cdf + 0.5): cdf < 2^9 has at most 24 significant bits, so cdf + 0.5 is exact in double;
+                // floor(cdf) + (frac >= 0.5) is the same value without leaving fp32 (cdf + 0.5f itself can round up to an integer)
+                const float fl = floorf(cdf);
+                const float up = (cdf - fl >= 0.5f) ? fl + 1.0f : fl;
+                const unsigned int e = (unsigned int)up & 255u;
+                *(__attribute__((address_space(3))) unsigned char*)(uintptr_t)(lutLds + (unsigned int)(b << 6) + (unsigned int)lane) = (unsigned char)e;
+                const unsigned int ce = cnt * e;   // <= 768 * 255
+                sumx += ce;
+                sumxx += ce * e;                   // <= 768 * 65025 < 2^26
+                asm("" : "+v"(sumx), "+v"(sumxx));   // accumulate here (sunk to their use, the 128 products spill)
+            }
+        }
+        wave_sync();
+#pragma unroll 1
+        for (int det = 0; det < mv.nd; ++det) {
+        const WvdDev& dv = mv.d[det];
+        // constant address space: scalar loads (SMEM) even though the kernel also stores to global memory
+        const __attribute__((address_space(4))) WvdConst& C = *(const __attribute__((address_space(4))) WvdConst*)(uintptr_t)dv.c;
+        const int L = dv.L;
+        // ---- 3. equalise, exact dot products on the matrix pipe: one k-step per patch row (two rows when the patch is 16 wide)
+        wvd_v16i acc00 = {}, acc01 = {}, acc10 = {}, acc11 = {};
+        {
+            unsigned int wn[RPS][NW];
+#pragma unroll
+            for (int rr = 0; rr < RPS; ++rr)
+#pragma unroll
+                for (int j = 0; j < NW; ++j) wn[rr][j] = wvd_load_u32(src + (size_t)rr * lw + 4 * j);
+            wvd_v4i bn0 = dv.B[lane], bn1 = dv.B[64 + lane];
+#pragma unroll 1
+            for (int ks = 0; ks < KS; ++ks) {
+                const wvd_v4i b0 = bn0, b1 = bn1;
+                unsigned int w4[RPS][NW];
+#pragma unroll
+                for (int rr = 0; rr < RPS; ++rr)
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) w4[rr][j] = wn[rr][j];
+                {   // next k-step's rows and digits (the last step re-reads its own)
+                    const int kn = ks + 1 < KS ? ks + 1 : ks;
+                    const uint8_t* nsrc = src + (size_t)(kn * RPS) * lw;
+#pragma unroll
+                    for (int rr = 0; rr < RPS; ++rr)
+#pragma unroll
+                        for (int j = 0; j < NW; ++j) wn[rr][j] = wvd_load_u32(nsrc + (size_t)rr * lw + 4 * j);
+                    bn0 = dv.B[(kn * 2 + 0) * 64 + lane];
+                    bn1 = dv.B[(kn * 2 + 1) * 64 + lane];
+                }
+                unsigned int pk[RPS * NW];
+#pragma unroll
+                for (int rr = 0; rr < RPS; ++rr) {
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) {
+                        const unsigned int w = w4[rr][j];
+                        const unsigned int e0 = wvd_lut8(wvd_slot_lut<0>(w, laneOffLut));
+                        const unsigned int e1 = wvd_lut8(wvd_slot_lut<1>(w, laneOffLut));
+                        const unsigned int e2 = wvd_lut8(wvd_slot_lut<2>(w, laneOffLut));
+                        const unsigned int e3 = wvd_lut8(wvd_slot_lut<3>(w, laneOffLut));
+                        pk[rr * NW + j] = wvd_lshl_or(e3, 24, wvd_lshl_or(e2, 16, wvd_lshl_or(e1, 8, e0))) ^ 0x80808080u;   // x - 128 as int8
+                    }
+                }
+                // slots RPS * PW_ .. 31 of the k-step are never written: their digits are zero, so stale bytes multiply into nothing
+                unsigned char* xrow = xPtr + lane * 16;
+                constexpr int ND = RPS * NW;   // 4, 5, 6 or 8 dwords
+                *reinterpret_cast<uint4*>(xrow) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                if constexpr (ND == 5) *reinterpret_cast<unsigned int*>(xrow + 1024) = pk[4];
+                if constexpr (ND == 6) *reinterpret_cast<uint2*>(xrow + 1024) = make_uint2(pk[4], pk[5]);
+                if constexpr (ND == 8) *reinterpret_cast<uint4*>(xrow + 1024) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+                __builtin_amdgcn_wave_barrier();   // LDS operations of a wavefront execute in order: the reads below see these writes
+                const wvd_v4i a0 = *reinterpret_cast<const wvd_v4i*>(xPtr + (lane >> 5) * 1024 + (lane & 31) * 16);
+                const wvd_v4i a1 = *reinterpret_cast<const wvd_v4i*>(xPtr + (lane >> 5) * 1024 + (32 + (lane & 31)) * 16);
+                __builtin_amdgcn_wave_barrier();
+                acc00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc11, 0, 0, 0);
+            }
+        }
+        // ---- 4. digits -> exact integer dot products, transposed to lane == window.  Column g = f + 16 j of N-tile g / 32 holds
+        //         digit j of filter f: this lane (column lane & 31) has digit j0 = (lane >> 4) & 1 in tile 0 and digit j0 + 2 in tile 1
+        wave_sync();   // the k-step chunk is dead: the histogram block becomes the transpose buffer
+        {
+            int laneT = lane;
+            asm volatile("" : "+v"(laneT));   // the 32 slot addresses are cheap: computed here, not hoisted out of the tile loop and spilled
+            const bool lowDigit = (laneT & 16) == 0;
+            const int h4 = 4 * (laneT >> 5);
+            const int fh = (laneT & 15) ^ h4;   // row & 15 = (rowc & 15) | h4 (rowc & 15 has bit 2 clear), so f ^ (row & 15) = fh ^ (rowc & 15)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int s0 = mt == 0 ? acc00[rg] : acc10[rg];
+                    const int s2 = mt == 0 ? acc01[rg] : acc11[rg];
+                    const double part = (double)s0 + 65536.0 * (double)s2;          // exact: |s| < 2^24
+                    const double other = __shfl_xor(part, 16);
+                    const int rowc = mt * 32 + (rg & 3) + 8 * (rg >> 2);             // window row = rowc + h4
+                    if (lowDigit) trPtr[(rowc + h4) * 16 + (fh ^ (rowc & 15))] = part + 256.0 * other;   // exact: < 2^53
+                }
+            }
+        }
+        wave_sync();
+        // ---- 5. the first L cascade levels of this lane's window with error bounds
+        bool undecided = valid;
+        {
+            int laneC = lane;
+            asm volatile("" : "+v"(laneC));   // as above, for the 16 read addresses
+            float Kv[WVD_L], Ke[WVD_L];
+            // the reference's fp32 sum of squares: row totals (exact ints) added in fp32, so it IS the integer below 2^24
+            const float sxx = (float)sumxx;
+            // |norm - reference norm|: 2 * quantisation error of xp, the fp32 sum of squares above 2^24, slack for the reference's
+            // fp64 roundings (< 1e-5)
+            const double dn = dv.scale * (double)sumx + (sumxx >= (1u << 24) ? (double)sxxSlack : 0.0) + 1e-4;
+            const float relDn = (float)(-(double)dv.negBasis * dn) * 1.0001f;
+#pragma unroll
+            for (int k = 0; k < WVD_L; ++k) {
+                if (k < L) {
+                    const double xp = (trPtr[laneC * 16 + (k ^ (laneC & 15))] + C.c128[k]) * dv.scale;
+                    double norm = (double)sxx;
+                    norm = norm - 2 * xp;
+                    norm = norm + C.pp[k];
+                    const float arg = (float)((double)dv.negBasis * norm);
+                    float Kk, Kerr;
+                    if (arg < -80.0f) { Kk = 0.f; Kerr = 2e-35f; }           // true K <= e^-80 (1 + tiny)
+                    else if (arg > 80.0f) { Kk = 0.f; Kerr = 3.0e38f; }       // cannot happen for a sane model: never reject
+                    else {
+                        Kk = __expf(arg);
+                        // relative error of K: exponent error (quantisation, float cast of the argument, x * log2e, 2^x), the final
+                        // rounding, and -- folded in here -- the fp32 summation-order term (4k + 16) 2^-24 <= 4.6e-6 of the level sums
+                        const float rho = (relDn + fabsf(arg) * 2.4e-7f + 6.0e-7f) * 1.01f + 4.6e-6f;
+                        Kerr = Kk * rho + 1e-37f;
+                    }
+                    Kv[k] = Kk;
+                    Ke[k] = Kerr;
+                    float R = dv.negBias, E = fabsf(dv.negBias) * 4.6e-6f + 1e-37f;
+#pragma unroll
+                    for (int p = 0; p <= k; ++p) {
+                        const float w = C.w[k][p];
+                        R = fmaf(w, Kv[p], R);
+                        E = fmaf(fabsf(w), Ke[p], E);
+                    }
+                    // the reference leaves at the first level with res < thr, and res_ref <= R + E
+                    if (undecided && (R + E < C.thr[k])) undecided = false;
+                }
+            }
+        }
+        // ---- 6. survivors -> queue of the exact cascade (wave-aggregated)
+        {
+            const unsigned long long mask = __ballot(undecided);
+            if (mask) {
+                unsigned int base = 0;
+                if (lane == 0) base = atomicAdd(dv.qcount, (unsigned int)__popcll(mask));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (undecided) dv.q[base + __popcll(mask & ((1ull << lane) - 1ull))] = wid;
+            }
+        }
+        wave_sync();
+        }   // detectors
+    }
+}
+
 
 }  // namespace
