@@ -21,6 +21,7 @@ if [ "$WHAT" = stats ] || [ "$WHAT" = all ]; then
     # kernels of different calls share the CUs and every average is inflated 2-3x); bench.py's live figure (kernel_probe) is taken
     # the same way
     ENVX=""; [ $wl = cascade ] && ENVX="env FD_BENCH_SLOTS=1 FD_FRAMES_ASYNC=0"
+    [ $wl = sdm ] && ENVX="env FD_BENCH_SDM_THREADS=1"   # same reason: three batches in flight share the CUs
     timeout 300 $ENVX rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$wl -- $B --workload $wl --also none --steps $S --warmup 2 $FP --no-cpu-baseline > $O/stats_$wl.json 2> $O/stats_$wl.err
   done
 fi
