@@ -125,6 +125,20 @@ __device__ __forceinline__ float src_px(const uint8_t* __restrict__ img, int W, 
     return ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) ? (float)img[(unsigned int)(__mul24(y, W) + x)] : 0.f;
 }
 
+#ifdef FD_SDM_PROF
+__device__ unsigned long long fd_sdm_prof[8];
+extern "C" void fd_debug_sdm_prof(unsigned long long* out, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(fd_sdm_prof), sizeof(fd_sdm_prof));
+    if (reset) { unsigned long long z[8] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(fd_sdm_prof), z, sizeof(z)); }
+}
+#define SDM_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define SDM_ADD(i, x) pacc[i] += (unsigned long long)(x)
+#else
+#define SDM_T(v)
+#define SDM_ADD(i, x)
+#endif
+
 // one wavefront per (face, landmark).  LDS per wave is what bounds the occupancy of this latency-bound kernel, so regions
 // are reused: the gradient magnitudes overwrite the working image (SMALL: they wait in registers until every lane has read
 // its neighbours), the features overwrite it once the votes are in, the block factors reuse the orientation masks.
@@ -133,6 +147,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                                                          DescParams p, int64_t nitems, float* __restrict__ out, int64_t out_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifdef FD_SDM_PROF
+    unsigned long long pacc[8] = {};
+#endif
     const int iw = p.iw, ih = p.ih, cs = p.cellSize, nori = p.nori;
     const int hogW = p.hogW, hogH = p.hogH;
     const int ncell = hogW * hogH;
@@ -213,6 +230,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             continue;
         }
         const uint8_t* img = images + face * p.image_stride;
+        SDM_T(t0);
         // ---- working image: crop (+ fp32 bilinear resize to 30x30 when adaptive)
         if (p.adaptive && side != iw) {
             // cv::resize coordinates per destination column / row (the orientation-mask region is free until the gradients)
@@ -256,6 +274,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         for (int i = lane; i < ncell * nori * 2; i += 64) S.hog[i] = 0.f;
         for (int i = lane; i < 2 * nori * ih; i += 64) masks[i] = (mask_t)0;
         wave_sync();
+        SDM_T(t1);
         // ---- gradient magnitude and hard orientation assignment per interior pixel (hog.c:612-665)
         auto gradient = [&](int i, float& gout) -> int {   // returns the orientation bin or -1, -2 for border pixels
             const int y = divw(i), x = i - __mul24(y, iw);
@@ -317,6 +336,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             }
         }
         wave_sync();
+        SDM_T(t2);
         // ---- spatial voting: lane e = (orientation, cell) walks ITS contributing pixels (orientation bit
         // masks) in the reference's scan order (y outer, x inner) with sequential fp32 adds
         for (int e = lane; e < ncell * nori * 2; e += 64) {
@@ -354,6 +374,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             S.hog[e] = acc;  // layout hog[x + y*hogW + o*hogStride] == e
         }
         wave_sync();
+        SDM_T(t3);
         // ---- undirected squared norms (hog.c:878-893)
         for (int c = lane; c < ncell; c += 64) {
             float nrm = 0.f;
@@ -411,6 +432,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             }
         }
         wave_sync();
+        SDM_T(t4);
         // ---- per-plane transpose and stack (DescriptorExtractor.hpp:198-205): out[j][c][r] = feat[j][r][c]
         for (int i = lane; i < dim * ncell; i += 64) {
             const int j = i / ncell, rem = i - j * ncell;
@@ -418,7 +440,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             dst[i] = S.feat[j * ncell + r * hogW + cc];
         }
         wave_sync();
+#ifdef FD_SDM_PROF
+        { SDM_T(t5); SDM_ADD(0, 1); SDM_ADD(1, t1 - t0); SDM_ADD(2, t2 - t1); SDM_ADD(3, t3 - t2); SDM_ADD(4, t4 - t3); SDM_ADD(5, t5 - t4); SDM_ADD(6, t5 - t0); }
+#endif
     }
+#ifdef FD_SDM_PROF
+    if (lane == 0) for (int q_ = 0; q_ < 8; ++q_) atomicAdd(&fd_sdm_prof[q_], pacc[q_]);
+#endif
 }
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
