@@ -276,6 +276,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         wave_sync();
         SDM_T(t1);
         // ---- gradient magnitude and hard orientation assignment per interior pixel (hog.c:612-665)
+        float oXr[SDM_MAX_ORI], oYr[SDM_MAX_ORI];   // orientation unit vectors: registers (uniform), loaded once per item
+#pragma unroll
+        for (int k = 0; k < SDM_MAX_ORI; ++k) { oXr[k] = p.oX[k]; oYr[k] = p.oY[k]; }
         auto gradient = [&](int i, float& gout) -> int {   // returns the orientation bin or -1, -2 for border pixels
             const int y = divw(i), x = i - __mul24(y, iw);
             if (x < 1 || y < 1 || x >= iw - 1 || y >= ih - 1) return -2;
@@ -297,11 +300,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             }
             float w0 = 0.f;
             int b0 = -1;
-            for (int k = 0; k < nori; ++k) {
-                float score = gradx * p.oX[k] + grady * p.oY[k];
-                int bin = k;
-                if (score < 0) { score = -score; bin += nori; }
-                if (score > w0) { b0 = bin; w0 = score; }
+#pragma unroll
+            for (int k = 0; k < SDM_MAX_ORI; ++k) {   // unrolled over the register copies: indexed through the kernel arguments the
+                if (k < nori) {                        // loop issued two dependent scalar loads per orientation and pixel
+                    float score = gradx * oXr[k] + grady * oYr[k];
+                    int bin = k;
+                    if (score < 0) { score = -score; bin += nori; }
+                    if (score > w0) { b0 = bin; w0 = score; }
+                }
             }
             gout = grad;
             return b0;
