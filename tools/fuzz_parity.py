@@ -133,6 +133,59 @@ def case_cascade(rng, ctx):
     return None
 
 
+def case_frames(rng, ctx):
+    """multi-frame pyramids: fd_pyramid_update_frames + fd_detect_five_stage_frames (ticket entry points, host stages on the queue
+    threads) against the oracle's per-frame five-stage detector; every layer of one random frame against the oracle's pyramid"""
+    w, h = int(rng.integers(97, 420)), int(rng.integers(81, 330))
+    nf = int(rng.integers(2, 12))
+    frames = [synth.make_frame(w, h, seed=int(rng.integers(1 << 30))) for _ in range(nf)]
+    gray = O.bgr2gray(frames[0])
+    pw, ph = SIZES[int(rng.integers(len(SIZES)))]
+    kw = rand_pyr_kw(rng)
+    nper = int(rng.choice([3, 6, 10, 20]))
+    nlev = int(rng.integers(1, 4))
+    src = np.ascontiguousarray(gray[::2, ::2])
+    if src.shape[0] <= ph + 2 or src.shape[1] <= pw + 2:
+        src = gray
+    calib = synth.random_patches(src, pw, ph, 1500, rng)
+    wvm = synth.make_wvm(int(rng.integers(1 << 20)), fw=pw, fh=ph, n_per=nper, n_levels=nlev, calib_patches=calib,
+                         min_survivors=int(rng.integers(8, 64)))
+    eq = synth.histeq64_np(synth.random_patches(src, pw, ph, 260, rng))
+    svm = synth.make_svm_u8(int(rng.integers(1 << 20)), eq, nsv=int(rng.choice([17, 64, 100])), calib=eq[100:], positive_fraction=0.4)
+    po = O.Pyramid(**kw)
+    pg = capi.Pyramid(ctx, **kw)
+    wo, so = O.Wvm(wvm), O.Svm(svm)
+    wg, sg = capi.Wvm(ctx, wvm), capi.Svm(ctx, svm)
+    desc = "%d frames %dx%d, patch %dx%d nper %d lev %d pyr %s" % (nf, w, h, pw, ph, nper, nlev, kw)
+    try:
+        pg.set_frames(nf)
+        pg.update_frames(images=frames)
+        sx, sy = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+        dist, ratio = (5.0, 0.0) if rng.random() < 0.5 else (float(rng.uniform(0.2, 0.9)), float(rng.uniform(0.3, 0.9)))
+        res = capi.FiveStageFrames(ctx, pg, wg, sg, nf, oe_dist=dist, oe_ratio=ratio, sx=sx, sy=sy, cap=4096).end()
+        fchk = int(rng.integers(nf))
+        for f in range(nf):
+            po.update(frames[f])
+            if f == fchk:
+                if po.layers() != pg.layers():
+                    return "layer tables differ (%s)" % desc
+                for li in range(len(po.layers())):
+                    STATS['layers'] += 1
+                    if not np.array_equal(pg.frame_layer(f, li), po.layer(li)):
+                        return "layer %d of frame %d differs (%s)" % (li, f, desc)
+            do, sto = O.five_stage(po, wo, so, dist, ratio, sx, sy, None)
+            dg, stg = res[f]
+            STATS['detections'] += len(do)
+            if not np.array_equal(stg, sto):
+                return "frame %d: stage counts %s vs %s (%s)" % (f, stg, sto, desc)
+            e = same_geometry(dg, do)
+            if e:
+                return "frame %d: %s (%s)" % (f, e, desc)
+    finally:
+        wg.close(); sg.close(); pg.close(); po.close()
+    return None
+
+
 def case_hist(rng, ctx):
     frame = rand_frame(rng)
     kw = rand_pyr_kw(rng)
@@ -436,7 +489,7 @@ def case_sdm(rng, ctx):
     return None
 
 
-CASES = dict(pyramid=case_pyramid, cascade=case_cascade, hist=case_hist, fhog=case_fhog, aggregated=case_aggregated, svm=case_svm,
+CASES = dict(pyramid=case_pyramid, cascade=case_cascade, frames=case_frames, hist=case_hist, fhog=case_fhog, aggregated=case_aggregated, svm=case_svm,
              hog_svm=case_hog_svm, rvm=case_rvm, whi=case_whi, sdm=case_sdm)
 
 
