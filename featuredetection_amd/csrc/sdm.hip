@@ -51,6 +51,13 @@ struct DescLds {   // per-wave views carved out of dynamic LDS
     int* yrange;                  // [hogH][2]: first/last+1 row contributing to cell row cy
 };
 constexpr int SDM_SMALL_ITERS = 16;   // working images of up to 64 * 16 pixels keep their gradients in registers for one sync
+#ifndef FD_SDM_REGGRAD
+#define FD_SDM_REGGRAD 1
+#endif
+// 1: small working images keep the gradient magnitudes in registers until every lane has read its neighbours and then overwrite the
+// image (3.6 KB of LDS less per wave, 16 instead of 12 waves per CU, but 32 registers and a 16-fold unrolled gradient loop);
+// 0: they go to their own LDS block through the plain loop
+constexpr bool SDM_REGGRAD = FD_SDM_REGGRAD != 0;
 __host__ __device__ inline int align16i(int v) { return (v + 15) & ~15; }
 __host__ __device__ inline bool desc_small(int iw, int ih) { return iw * ih <= 64 * SDM_SMALL_ITERS && iw <= 32; }
 __host__ __device__ inline int desc_region_img(int iw, int ih, int ncell, int dim) {
@@ -64,7 +71,7 @@ __host__ __device__ inline int desc_region_masks(int iw, int ih, int ncell, int 
 }
 __host__ __device__ inline int desc_lds_bytes(int iw, int ih, int ncell, int nori, int dim, int hogMax) {
     const int m = iw > ih ? iw : ih;
-    return desc_region_img(iw, ih, ncell, dim) + (desc_small(iw, ih) ? 0 : align16i(iw * ih * 4)) + 3 * align16i(m * 4) +
+    return desc_region_img(iw, ih, ncell, dim) + ((desc_small(iw, ih) && SDM_REGGRAD) ? 0 : align16i(iw * ih * 4)) + 3 * align16i(m * 4) +
            align16i(ncell * nori * 2 * 4) + align16i(ncell * 4) + desc_region_masks(iw, ih, ncell, nori) + align16i(m * 8) + align16i(m * 2 * 4) +
            align16i(hogMax * m * 4);
 }
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         unsigned char* b = smem + (size_t)wave * p.ldsPerWave;
         const int m = iw > ih ? iw : ih;
         S.img = (float*)b; S.feat = (float*)b; b += desc_region_img(iw, ih, ncell, p.dim);
-        if (SMALL) S.grad = S.img;
+        if (SMALL && SDM_REGGRAD) S.grad = S.img;
         else { S.grad = (float*)b; b += align16i(npix * 4); }
         S.wx1 = (float*)b; b += align16i(m * 4);
         S.wx2 = (float*)b; b += align16i(m * 4);
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             gout = grad;
             return b0;
         };
-        if (SMALL) {
+        if (SMALL && SDM_REGGRAD) {
             float gr[SDM_SMALL_ITERS];
             int ob[SDM_SMALL_ITERS];
 #pragma unroll
