@@ -36,7 +36,7 @@ static cv::Mat read_pnm(const string& path) {
 
 int main(int argc, char** argv) {
     if (argc < 3) {
-        std::fprintf(stderr, "usage: %s <config.cfg> <image.ppm|pgm>\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <config.cfg> <image.ppm|pgm> [more images of a sequence ...]\n", argv[0]);
         return 2;
     }
     try {
@@ -104,6 +104,21 @@ int main(int argc, char** argv) {
             }
             det->landmark = landmarkName;
             (landmarkName == "face" ? faceDetectors : featureDetectors).emplace_back(kv.first, det);
+        }
+        if (argc > 3) {   // several images: the face detectors on all of them at once (detectFrames), one line per detection
+            std::vector<cv::Mat> imgs;
+            for (int a = 2; a < argc; ++a) imgs.push_back(read_pnm(argv[a]));
+            for (auto& d : faceDetectors) {
+                auto five = std::dynamic_pointer_cast<FiveStageSlidingWindowDetector>(d.second);
+                if (!five) throw std::invalid_argument("several images need a fiveStageCascade face detector");
+                const auto res = five->detectFrames(imgs);
+                for (size_t f = 0; f < res.size(); ++f)
+                    for (const auto& p : res[f]) {
+                        cv::Rect b = p->getPatch()->getBounds();
+                        std::printf("frame %zu %s %s %d %d %d %d %.17g\n", f, d.first.c_str(), d.second->landmark.c_str(), b.x, b.y, b.width, b.height, p->getProbability());
+                    }
+            }
+            return 0;
         }
         cv::Mat img = read_pnm(argv[2]);
         std::vector<shared_ptr<ClassifiedPatch>> facePatches;

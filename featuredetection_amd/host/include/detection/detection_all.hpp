@@ -120,8 +120,16 @@ public:
     const std::shared_ptr<imageprocessing::PyramidFeatureExtractor> getPyramidFeatureExtractor() const {
         return slidingWindowDetector->getPyramidFeatureExtractor();
     }
+    // Backend extension (not in the reference): detect(image) for every image of a sequence in one call.  Up to 64 equally sized
+    // images share one multi-frame pyramid, one cascade run and one SVM launch (fd_pyramid_update_frames +
+    // fd_detect_five_stage_frames); result i equals detect(images[i]).  Images of different sizes, pyramids on a source pyramid
+    // and more than 64 images are handled by splitting / falling back to detect().
+    std::vector<std::vector<std::shared_ptr<ClassifiedPatch>>> detectFrames(const std::vector<cv::Mat>& images);
+    ~FiveStageSlidingWindowDetector();
 private:
     std::vector<std::shared_ptr<ClassifiedPatch>> run(const cv::Mat& image, const cv::Rect* roi);
+    fd_pyramid* framesPyramid = nullptr;   // detectFrames: the multi-frame twin of the extractor's pyramid
+    int framesCount = 0;
     std::shared_ptr<SlidingWindowDetector> slidingWindowDetector;
     std::shared_ptr<OverlapElimination> overlapElimination;
     std::shared_ptr<classification::ProbabilisticClassifier> strongClassifier;

@@ -265,6 +265,9 @@ public:
     std::vector<cv::Size> getLayerSizes() const;
     fd_pyramid* native() const { return sourcePyramid ? sourcePyramid->native() : handle; }
     std::shared_ptr<ImagePyramid> getSourcePyramid() const { return sourcePyramid; }
+    // a second native pyramid with this pyramid's parameters that holds `frames` equally sized frames at once (backend extension
+    // behind FiveStageSlidingWindowDetector::detectFrames); NULL for pyramids on a source pyramid or with layer filters
+    fd_pyramid* createFramesPyramid(int frames) const;
     // Layer sub-range / region of interest of the extraction or detection call that follows (fd_pyramid_select), intersected
     // with the scale range of a pyramid that views another one; reset when the guard goes out of scope.
     class Selection {
@@ -285,6 +288,8 @@ private:
     std::shared_ptr<ImagePyramid> sourcePyramid;
     std::shared_ptr<VersionedImage> sourceImage;
     double minScaleFactor, maxScaleFactor;
+    size_t ctorOctaveLayers = 0;          // constructor arguments (one of the two forms)
+    double ctorIncremental = 0;
     cv::Size imageSize;
     Version version;
     std::shared_ptr<GradientFilter> gradient;

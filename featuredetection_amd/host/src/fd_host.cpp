@@ -238,11 +238,21 @@ Mat HogFilter::applyTo(const Mat& image, Mat& filtered) const { return hist_appl
 
 // ---- ImagePyramid -------------------------------------------------------------------------------
 ImagePyramid::ImagePyramid(size_t octaveLayerCount, double minS, double maxS)
-    : handle(nullptr), minScaleFactor(minS), maxScaleFactor(maxS), layersValid(false) {
+    : handle(nullptr), minScaleFactor(minS), maxScaleFactor(maxS), ctorOctaveLayers(octaveLayerCount), layersValid(false) {
     check(fd_pyramid_create(context(), (int)octaveLayerCount, minS, maxS, &handle));
 }
-ImagePyramid::ImagePyramid(double inc, double minS, double maxS) : handle(nullptr), minScaleFactor(minS), maxScaleFactor(maxS), layersValid(false) {
+ImagePyramid::ImagePyramid(double inc, double minS, double maxS)
+    : handle(nullptr), minScaleFactor(minS), maxScaleFactor(maxS), ctorIncremental(inc), layersValid(false) {
     check(fd_pyramid_create_inc(context(), inc, minS, maxS, &handle));
+}
+fd_pyramid* ImagePyramid::createFramesPyramid(int frames) const {
+    if (sourcePyramid || !handle || gradient || binning || lbp) return nullptr;
+    fd_pyramid* p = nullptr;
+    if (ctorOctaveLayers) check(fd_pyramid_create(context(), (int)ctorOctaveLayers, minScaleFactor, maxScaleFactor, &p));
+    else check(fd_pyramid_create_inc(context(), ctorIncremental, minScaleFactor, maxScaleFactor, &p));
+    const int rc = fd_pyramid_set_frames(p, frames);
+    if (rc != FD_OK) { fd_pyramid_destroy(p); check(rc); }
+    return p;
 }
 ImagePyramid::ImagePyramid(shared_ptr<ImagePyramid> pyramid, double minS, double maxS)
     : handle(nullptr), sourcePyramid(pyramid), minScaleFactor(minS), maxScaleFactor(maxS), layersValid(false) {
@@ -1286,6 +1296,60 @@ vector<shared_ptr<ClassifiedPatch>> FiveStageSlidingWindowDetector::run(const Ma
     check(rc);
     vector<shared_ptr<ClassifiedPatch>> out;
     for (int i = 0; i < cnt; ++i) out.push_back(to_patch(dets[i]));
+    return out;
+}
+FiveStageSlidingWindowDetector::~FiveStageSlidingWindowDetector() { if (framesPyramid) fd_pyramid_destroy(framesPyramid); }
+
+vector<vector<shared_ptr<ClassifiedPatch>>> FiveStageSlidingWindowDetector::detectFrames(const vector<Mat>& images) {
+    vector<vector<shared_ptr<ClassifiedPatch>>> out(images.size());
+    auto direct = std::dynamic_pointer_cast<DirectPyramidFeatureExtractor>(slidingWindowDetector->getPyramidFeatureExtractor());
+    if (auto filtering = std::dynamic_pointer_cast<imageprocessing::FilteringPyramidFeatureExtractor>(slidingWindowDetector->getPyramidFeatureExtractor()))
+        direct = filtering->getFusedExtractor();
+    auto pwvm = std::dynamic_pointer_cast<ProbabilisticWvmClassifier>(slidingWindowDetector->getClassifier());
+    auto psvm = std::dynamic_pointer_cast<ProbabilisticSvmClassifier>(strongClassifier);
+    size_t i = 0;
+    while (i < images.size()) {
+        // the longest run of images with the size and type of images[i], 64 at most
+        size_t j = i + 1;
+        while (j < images.size() && j - i < 64 && images[j].rows == images[i].rows && images[j].cols == images[i].cols && images[j].type() == images[i].type()) ++j;
+        const int n = (int)(j - i);
+        const int ch = images[i].channels();
+        bool fused = direct && pwvm && psvm && direct->hasHistEq64() && n > 1 && images[i].depth() == CV_8U && (ch == 1 || ch == 3);
+        if (fused && (!framesPyramid || framesCount != n)) {
+            if (framesPyramid) { fd_pyramid_destroy(framesPyramid); framesPyramid = nullptr; }
+            framesPyramid = direct->getPyramid()->createFramesPyramid(n);
+            framesCount = n;
+            fused = framesPyramid != nullptr;
+        }
+        if (!fused) {
+            for (size_t k = i; k < j; ++k) out[k] = detect(images[k]);
+            i = j;
+            continue;
+        }
+        vector<Mat> cont((size_t)n);
+        vector<const uint8_t*> ptrs((size_t)n);
+        for (int k = 0; k < n; ++k) {
+            cont[(size_t)k] = images[i + (size_t)k].isContinuous() ? images[i + (size_t)k] : images[i + (size_t)k].clone();
+            ptrs[(size_t)k] = cont[(size_t)k].data;
+        }
+        check(fd_pyramid_update_frames(framesPyramid, ptrs.data(), n, images[i].cols, images[i].rows, ch, 0));
+        int cap = 1024;
+        vector<fd_detection> dets;
+        vector<int32_t> counts((size_t)n);
+        for (;;) {
+            dets.resize((size_t)cap * (size_t)n);
+            const int rc = fd_detect_five_stage_frames(context(), framesPyramid, pwvm->getWvm()->native(pwvm->getLogisticA(), pwvm->getLogisticB()),
+                                                       psvm->getSvm()->native(psvm->getLogisticA(), psvm->getLogisticB()), overlapElimination->getDist(),
+                                                       overlapElimination->getRatio(), slidingWindowDetector->getStepSizeX(),
+                                                       slidingWindowDetector->getStepSizeY(), nullptr, dets.data(), cap, counts.data(), nullptr);
+            if (rc == FD_ERR_CAPACITY && cap < (1 << 20)) { cap *= 8; continue; }
+            check(rc);
+            break;
+        }
+        for (int k = 0; k < n; ++k)
+            for (int q = 0; q < counts[(size_t)k]; ++q) out[i + (size_t)k].push_back(to_patch(dets[(size_t)k * (size_t)cap + (size_t)q]));
+        i = j;
+    }
     return out;
 }
 vector<shared_ptr<ClassifiedPatch>> FiveStageSlidingWindowDetector::detect(const Mat& image) { return run(image, nullptr); }

@@ -18,15 +18,7 @@ def _run(args):
     return r.stdout
 
 
-def test_ffp_detect_app_matches_oracle(tmp_path, oracle, synth, frame640, small_models):
-    app = os.path.join(PKG, "ffp_detect_app")
-    if not os.path.exists(app):
-        pytest.fail("host apps not built (make -C featuredetection_amd/host)")
-    wvm, svm = small_models
-    synth.save_wvm(str(tmp_path / "face.fdwvm"), wvm)
-    synth.save_svm_text(str(tmp_path / "face.svm.txt"), svm, rows=20, cols=20)
-    synth.save_pnm(str(tmp_path / "frame.ppm"), frame640)
-    cfg = """detectors
+FACE_CFG = """detectors
 {
     FaceFrontal
     {
@@ -58,7 +50,18 @@ def test_ffp_detect_app_matches_oracle(tmp_path, oracle, synth, frame640, small_
         }
     }
 }
-""" % (tmp_path / "face.fdwvm", tmp_path / "face.svm.txt")
+"""
+
+
+def test_ffp_detect_app_matches_oracle(tmp_path, oracle, synth, frame640, small_models):
+    app = os.path.join(PKG, "ffp_detect_app")
+    if not os.path.exists(app):
+        pytest.fail("host apps not built (make -C featuredetection_amd/host)")
+    wvm, svm = small_models
+    synth.save_wvm(str(tmp_path / "face.fdwvm"), wvm)
+    synth.save_svm_text(str(tmp_path / "face.svm.txt"), svm, rows=20, cols=20)
+    synth.save_pnm(str(tmp_path / "frame.ppm"), frame640)
+    cfg = FACE_CFG % (tmp_path / "face.fdwvm", tmp_path / "face.svm.txt")
     (tmp_path / "face.cfg").write_text(cfg)
     out = _run([app, str(tmp_path / "face.cfg"), str(tmp_path / "frame.ppm")])
     got = [l.split() for l in out.strip().splitlines()]
@@ -72,6 +75,38 @@ def test_ffp_detect_app_matches_oracle(tmp_path, oracle, synth, frame640, small_
         assert [int(v) for v in g[2:6]] == [d["cx"] - d["w"] // 2, d["cy"] - d["h"] // 2, d["w"], d["h"]]
         assert float(g[6]) == d["prob"]
 
+
+
+def test_ffp_detect_app_image_sequence_detect_frames(tmp_path, oracle, synth, frame640, small_models):
+    """FiveStageSlidingWindowDetector::detectFrames (backend extension of the C++ mirror: all images of a sequence through one
+    multi-frame pyramid, one cascade run, one SVM launch): every frame's boxes and probabilities equal the oracle's detect(image)."""
+    app = os.path.join(PKG, "ffp_detect_app")
+    if not os.path.exists(app):
+        pytest.fail("host apps not built (make -C featuredetection_amd/host)")
+    wvm, svm = small_models
+    synth.save_wvm(str(tmp_path / "face.fdwvm"), wvm)
+    synth.save_svm_text(str(tmp_path / "face.svm.txt"), svm, rows=20, cols=20)
+    frames = [frame640, synth.make_frame(640, 480, seed=31), synth.make_frame(640, 480, seed=32)]
+    for i, f in enumerate(frames):
+        synth.save_pnm(str(tmp_path / ("frame%d.ppm" % i)), f)
+    cfg = FACE_CFG % (tmp_path / "face.fdwvm", tmp_path / "face.svm.txt")
+    (tmp_path / "face.cfg").write_text(cfg)
+    out = _run([app, str(tmp_path / "face.cfg")] + [str(tmp_path / ("frame%d.ppm" % i)) for i in range(len(frames))])
+    got = [l.split() for l in out.strip().splitlines()]
+    po = oracle.Pyramid(inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))
+    wo, so = oracle.Wvm(wvm), oracle.Svm(svm)
+    total = 0
+    for fi, f in enumerate(frames):
+        po.update(f)
+        dets, _ = oracle.five_stage(po, wo, so, 5.0, 0.0, 1, 1, None)
+        mine = [g for g in got if g[0] == "frame" and int(g[1]) == fi]
+        assert len(mine) == len(dets)
+        total += len(dets)
+        for g, d in zip(mine, dets):
+            assert g[2] == "FaceFrontal" and g[3] == "face"
+            assert [int(v) for v in g[4:8]] == [d["cx"] - d["w"] // 2, d["cy"] - d["h"] // 2, d["w"], d["h"]]
+            assert float(g[8]) == d["prob"]
+    assert total > 0 and len(got) == total
 
 
 SINGLE_CFG = """detectors
