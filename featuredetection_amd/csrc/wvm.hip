@@ -1826,7 +1826,9 @@ template <int PW_, int PH_>
 static void launch_prefilter_sized(fd_ctx* ctx, hipStream_t st, const uint8_t* arena, const WvdTable& wt, const WvdDev& dv) {
     static int perCu = 0;
     if (perCu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wvm_prefilter<PW_, PH_>, 256, 0) != hipSuccess || perCu < 1)) perCu = 2;
-    const int grid = (int)std::min<int64_t>(((int64_t)wt.ntiles + 3) / 4, (int64_t)ctx->num_cus * perCu * 2);
+    // rounds of resident workgroups the tiles are dealt over (FD_WVD_ROUNDS, default 2)
+    static const int rounds = [] { const char* e = getenv("FD_WVD_ROUNDS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+    const int grid = (int)std::min<int64_t>(((int64_t)wt.ntiles + 3) / 4, (int64_t)ctx->num_cus * perCu * rounds);
     hipLaunchKernelGGL((k_wvm_prefilter<PW_, PH_>), dim3(grid), dim3(256), 0, st, arena, wt, dv);
 }
 
