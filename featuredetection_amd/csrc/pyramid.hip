@@ -550,8 +550,11 @@ void build_layout(fd_pyramid* p, int W, int H) {
         int w = fd_cvRound(W * scaleFactor), h = fd_cvRound(H * scaleFactor);
         if (w < 1 || h < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "ImagePyramid: layer %zu would be empty", i);
         int depth = 0;
-        HostLayer L{(int)i, scaleFactor, w, h, 1, (uint32_t)off, 0, scaleFactor <= p->maxS && scaleFactor >= p->minS, (int)i, depth};
-        off = align256(off + (size_t)w * h);
+        // a first-octave layer of the image's own size (scale 1) IS the gray image: cv::resize to the same size copies every pixel
+        // (weights 2048 / 0: ((2048 * (S * 128)) >> 16) + 2 >> 2 == S), so it shares the gray image's storage and costs no launch
+        const bool isFull = (w == W && h == H);
+        HostLayer L{(int)i, scaleFactor, w, h, 1, (uint32_t)(isFull ? p->gray_full_off : off), 0, scaleFactor <= p->maxS && scaleFactor >= p->minS, (int)i, depth};
+        if (!isFull) off = align256(off + (size_t)w * h);
         p->all.push_back(L);
         int pw = w, ph = h;
         scaleFactor *= 0.5;
@@ -653,6 +656,7 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
         };
         for (const HostLayer& L : p->all) {
             if (L.depth != 0) continue;
+            if (L.w == W && L.h == H && L.gray_off == p->gray_full_off) continue;   // the gray image itself (build_layout)
             ResizeJob& j = jobs.j[jobs.n++];
             j.dw = L.w; j.dh = L.h; j.dst_off = L.gray_off;
             j.scale_x = 1. / ((double)L.w / W);
