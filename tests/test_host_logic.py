@@ -160,3 +160,37 @@ def test_no_silent_cpu_fallback(capi):
         pytest.skip("GPU present")
     with pytest.raises(capi.FdError):
         capi.Context(0)
+
+
+def test_c_abi_header_is_plain_c_and_the_frame_loop_binding_compiles(tmp_path):
+    """include/fd_hip.h is the drop-in boundary: it must be valid C99 on its own, and the frame-loop binding INTEGRATION.md shows for
+    the multi-frame entry points must compile against it (syntax only: no GPU, no linking)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("gcc not on PATH")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(root, "include")
+    for h in ("fd_hip.h", "fd_hip_bench.h"):
+        r = subprocess.run([gcc, "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror", os.path.join(inc, h)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    src = tmp_path / "frame_loop.c"
+    src.write_text("""
+#include <stdint.h>
+#include "fd_hip.h"
+int frame_loop(fd_ctx* ctx, fd_pyramid* pyr, const fd_wvm* wvm, const fd_svm* svm, const uint8_t* const* frames) {
+    fd_five_stage_frames* t = 0;
+    static fd_detection out[32 * 256];
+    int32_t counts[32], stages[32 * 4];
+    int rc = fd_pyramid_set_frames(pyr, 32);
+    if (rc) return rc;
+    rc = fd_pyramid_update_frames(pyr, frames, 32, 640, 480, 3, 1);
+    if (rc) return rc;
+    rc = fd_detect_five_stage_frames_begin(ctx, pyr, wvm, svm, 5.f, 0.f, 1, 1, 0, &t);
+    if (rc) return rc;
+    return fd_detect_five_stage_frames_end(ctx, t, out, 256, counts, stages);
+}
+""")
+    r = subprocess.run([gcc, "-fsyntax-only", "-std=c99", "-Wall", "-Werror", "-I", inc, str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
