@@ -205,6 +205,7 @@ _SIGS = {
 _BENCH_SIGS = {
     "fd_ctx_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "fd_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
+    "fd_debug_wvb_rect_sums": (C.c_int64, [C.POINTER(fd_wvm_model), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
 }
 
 
@@ -404,6 +405,21 @@ class Wvm:
         if self.h:
             lib().fd_wvm_destroy(self.h)
             self.h = C.c_void_p()
+
+
+def wvb_rect_sums(model, patches_eq):
+    """Test hook (no GPU): rect sums of every used level from the dense stage-B tables -> ([n, ncols] int32, phase boundaries),
+    or None when the model has no dense stage B."""
+    s, keep = _wvm_struct(model, fd_wvm_model)
+    patches_eq = _c(patches_eq, np.uint8)
+    n = patches_eq.shape[0]
+    gen = np.zeros(5, np.int32)
+    ncols = lib().fd_debug_wvb_rect_sums(C.byref(s), None, 0, None, _ptr(gen))
+    if ncols < 0:
+        return None
+    out = np.empty((n, ncols), np.int32)
+    lib().fd_debug_wvb_rect_sums(C.byref(s), _ptr(patches_eq), n, _ptr(out), None)
+    return out, [int(g) for g in gen if g >= 0]
 
 
 def wvm_eval(ctx, wvm, patches_eq):

@@ -119,6 +119,41 @@ struct PosRec {
     float fout;
 };
 
+// ---- stage B as dense contractions (wvm_stageb.hpp) ------------------------------------------------------------------
+// Model tables: the rect sums of level k, grey value v >= 1 are x . M_{k,v} with M_{k,v}[pixel] = number of rects of (k, v) that
+// cover the pixel (small integers), so all of them are one exact int8 contraction on v_mfma_i32_32x32x32_i8.  The rows
+// (k, v) are grouped class by class (class n = k mod numPer: the levels that depend on each other through u_kernel_eval[n],
+// WvmClassifier.cpp:308-333) into tiles of 32 rows; a level never straddles a tile, and a tile never straddles a phase.
+constexpr int WVB_MAXPHASE = 4;
+typedef int wvb_v4i __attribute__((ext_vector_type(4)));
+typedef int wvb_v16i __attribute__((ext_vector_type(16)));
+struct WvbDev {
+    const wvb_v4i* A;         // [tile][KS][64 lanes]: lane l = row l & 31 of the tile, pixels ks * 32 + (l >> 5) * 16 .. + 15 (zero padded)
+    const int4* lvl;          // [numFilters] {tile, first row inside the tile, grey-value count, val offset}
+    const int32_t* c128;      // [tile * 32 + row] 128 * sum of the row (the pixels are stored as x - 128)
+    const double* pp;         // [numFilters]
+    const double* val;        // the model's val[]
+    const float* thr;         // [numFilters]
+    const float* wR;          // wR[p * Fr + k] = hkWeights[k][p] (p <= k), rows padded so that eight weights from any k can be read
+    int32_t KS, dstride, Fr;  // k-steps (32 pixels each), bytes per equalised patch row of the state (KS * 32 + 16: an odd number of 16-byte slots)
+    int32_t numPer, numUsed, numFilters, d;
+    int32_t nphase;
+    int32_t phaseGen[WVB_MAXPHASE + 1];   // phase i = generations [phaseGen[i], phaseGen[i + 1])
+    float negBasis, negBias;
+};
+// Per-run state of the queued windows, two sets (a phase reads set phase & 1; its survivors are packed densely into the other).
+// Position pos = place in the current phase's dense list.  Row strides (kstride) are not powers of two on purpose.
+struct WvbState {
+    int8_t* X[2];             // [pos][dstride] equalised patch as x - 128, row-major, zero padded
+    int64_t* wid[2];          // [pos] window id
+    int2* aux[2];             // [pos] {sum of the equalised patch, fp32 bits of the reference's sum of squares (IImg.cpp:33-47)}
+    float* U[2];              // [class][kstride] u_kernel_eval[class]
+    float* K[2];              // [level][kstride] kernel values (filter_output[level])
+    float* R;                 // [level - first level of the phase][kstride] filter-output sums res_k of the phase
+    unsigned int* cnt;        // [1 + WVB_MAXPHASE]: cnt[i] = windows alive at the start of phase i (i >= 1; phase 0 reads the queue length)
+    int64_t cap, kstride;
+};
+
 struct fd_wvm {
     fd_ctx* ctx;
     WvmDev dev;
@@ -139,6 +174,14 @@ struct fd_wvm {
     HostBuf h_tail;              // pinned staging of the SVM stage of a five-stage run: [slots | distances]
     hipEvent_t tailDone = nullptr;   // recorded after the SVM stage + its read-back
     hipEvent_t prep = nullptr;       // grouped launches: header cleared (members) / shared pre-filter queued (leader)
+    // stage B as dense contractions (wvm_stageb.hpp): model tables, and the per-run state of the queued windows
+    WvbDev wvb;
+    bool wvbOk = false;
+    DevBuf wvbA, wvbLvl, wvbC128, wvbWR;
+    WvbState sb;
+    DevBuf sbX[2], sbWid[2], sbAux[2], sbU[2], sbK[2], sbR, sbCnt;
+    int64_t deepCap = 0;             // windows stage B can hold in this run (the queue itself holds every window)
+    bool sbRun = false;              // the run in flight uses the dense stage B
     ~fd_wvm() { if (done) (void)hipEventDestroy(done); if (tailDone) (void)hipEventDestroy(tailDone); if (prep) (void)hipEventDestroy(prep); }
 };
 
@@ -1631,9 +1674,12 @@ __global__ __launch_bounds__(256) void k_histeq64(const uint8_t* __restrict__ in
 
 // Launches stage A over all windows and stage B over its survivors (same stream, no host round trip:
 // stage B is a persistent grid that reads the survivor count from device memory).
+#include "wvm_stageb.hpp"
+
 template <int PW_, int PH_, bool RAW>
-void launch_sized(fd_ctx* ctx, hipStream_t st, int64_t total, const WvmDev& dev, const uint8_t* arena, const WinTable& wt,
+void launch_sized(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* mh, const uint8_t* arena, const WinTable& wt,
                   const CascadeOut& o, bool skipA = false) {
+    const WvmDev& dev = mh->dev;
     // both stages are persistent grids: exactly as many workgroups as fit on the device at once (a partial second
     // round of workgroups would run at a fraction of the occupancy)
     static int perCuA = 0;
@@ -1688,6 +1734,11 @@ void launch_sized(fd_ctx* ctx, hipStream_t st, int64_t total, const WvmDev& dev,
     static const char* nwEnv = getenv("FD_WVM_DEEP_WAVES");
     static const bool deepOld = getenv("FD_WVM_DEEP_OLD") != nullptr;
     static const bool deep4Env = getenv("FD_WVM_DEEP4") != nullptr;
+    // default: stage B as dense contractions (wvm_stageb.hpp); FD_WVM_STAGEB=old keeps the rect-lookup kernels below
+    if (mh->sbRun) {
+        launch_stageb<PW_, PH_, RAW>(ctx, st, total, mh, arena, wt, o);
+        return;
+    }
     if (dev.numPer <= 32 && !deepOld && !deep4Env && dev.genRec) {   // four windows per workgroup, one wave per window
         if (dev.maxCnt <= 8) {
             static int perCuB = 0;
@@ -1725,13 +1776,13 @@ void launch_sized(fd_ctx* ctx, hipStream_t st, int64_t total, const WvmDev& dev,
 #define FD_WVM_SIZES(X) X(20, 20) X(24, 24) X(16, 24) X(32, 16) X(32, 24)
 
 template <bool RAW>
-void launch_cascade(fd_ctx* ctx, hipStream_t st, int64_t total, const WvmDev& dev, const uint8_t* arena, const WinTable& wt,
+void launch_cascade(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* mh, const uint8_t* arena, const WinTable& wt,
                     const CascadeOut& o, bool skipA = false) {
 #define FD_WVM_CASE(W, H) \
-    if (dev.fw == W && dev.fh == H) return launch_sized<W, H, RAW>(ctx, st, total, dev, arena, wt, o, skipA);
+    if (mh->dev.fw == W && mh->dev.fh == H) return launch_sized<W, H, RAW>(ctx, st, total, mh, arena, wt, o, skipA);
     FD_WVM_SIZES(FD_WVM_CASE)
 #undef FD_WVM_CASE
-    launch_sized<0, 0, RAW>(ctx, st, total, dev, arena, wt, o, skipA);
+    launch_sized<0, 0, RAW>(ctx, st, total, mh, arena, wt, o, skipA);
 }
 
 }  // namespace
@@ -1820,6 +1871,149 @@ static void wvm_build_dense(fd_wvm* m, const fd_wvm_model* md) {
     m->denseC.reserve(sizeof(C));
     HIP_CHECK(hipMemcpy(m->denseC.p, &C, sizeof(C), hipMemcpyHostToDevice));
     m->denseL = L;
+}
+
+// Tables of the dense stage B (wvm_stageb.hpp), pure host part.  Returns false (the rect-lookup stage-B kernels run instead) when
+// the model never reaches stage B or when more than 127 rects of one grey value overlap on a pixel.
+struct WvbTables {
+    int KS = 0, DS = 0, Fr = 0, nphase = 0, ntile = 0;
+    int phaseGen[WVB_MAXPHASE + 1] = {};
+    std::vector<int32_t> lvl, c128;
+    std::vector<int8_t> A;
+    std::vector<float> wR;
+};
+static bool wvb_tables(const fd_wvm_model* md, int NU, WvbTables& T) {
+    const int F = md->num_filters, NP = md->num_per_level;
+    if (NU <= WVM_LCAP) return false;
+    const int pw = md->filter_w, ph = md->filter_h, d = pw * ph;
+    const int KS = (d + 31) / 32;
+    const int G = (NU + NP - 1) / NP;
+    T.KS = KS;
+    T.DS = KS * 32 + 16;
+    {   // phases: generations [0, 2), [2, 6), [6, G) by default; FD_WVB_PHASES="a,b,c" sets other cuts
+        std::vector<int> cuts = {2, 6};
+        if (const char* e = getenv("FD_WVB_PHASES")) {
+            cuts.clear();
+            for (const char* c = e; *c;) {
+                char* end = nullptr;
+                const long v = std::strtol(c, &end, 10);
+                if (end == c) break;
+                if (v > 0) cuts.push_back((int)v);
+                c = *end ? end + 1 : end;
+            }
+        }
+        std::sort(cuts.begin(), cuts.end());
+        T.nphase = 0;
+        T.phaseGen[0] = 0;
+        for (int c : cuts)
+            if (c > T.phaseGen[T.nphase] && c < G && T.nphase + 1 < WVB_MAXPHASE) T.phaseGen[++T.nphase] = c;
+        T.phaseGen[++T.nphase] = G;
+    }
+    auto phaseStart = [&](int g) {
+        for (int i = 1; i < T.nphase; ++i) if (T.phaseGen[i] == g) return true;
+        return false;
+    };
+    T.lvl.assign((size_t)F * 4, 0);
+    T.c128.clear();
+    T.A.clear();
+    std::vector<int> cover((size_t)d);
+    int ntile = 0;
+    for (int n = 0; n < NP; ++n) {
+        int cur = -1, rowc = 32;
+        for (int g = 0; g < G; ++g) {
+            const int k = g * NP + n;
+            if (k >= NU) break;
+            const int v0 = md->val_off[k], cntval = md->val_off[k + 1] - v0;
+            const int rows = cntval - 1;
+            if (cur < 0 || rowc + rows > 32 || phaseStart(g)) {
+                cur = ntile++;
+                rowc = 0;
+                T.A.resize((size_t)ntile * KS * 64 * 16, 0);
+                T.c128.resize((size_t)ntile * 32, 0);
+            }
+            int32_t* lv = &T.lvl[4 * (size_t)k];
+            lv[0] = cur; lv[1] = rowc; lv[2] = cntval; lv[3] = v0;
+            for (int v = 1; v < cntval; ++v) {
+                std::fill(cover.begin(), cover.end(), 0);
+                for (int ri = md->rec_off[v0 + v]; ri < md->rec_off[v0 + v + 1]; ++ri) {
+                    const uint8_t* rc = md->rects + 4 * (size_t)ri;
+                    for (int y = rc[1]; y <= rc[3]; ++y)
+                        for (int x = rc[0]; x <= rc[2]; ++x) ++cover[(size_t)y * pw + x];
+                }
+                const int row = rowc + v - 1;
+                long sum = 0;
+                for (int i = 0; i < d; ++i) {
+                    if (cover[i] > 127) return false;   // does not fit the int8 operand
+                    sum += cover[i];
+                    const int ks = i >> 5, h = (i >> 4) & 1, t = i & 15;   // lane h * 32 + row of k-step ks, byte t
+                    T.A[((((size_t)cur * KS + ks) * 64) + (size_t)(h * 32 + row)) * 16 + t] = (int8_t)cover[i];
+                }
+                T.c128[(size_t)cur * 32 + row] = (int32_t)(128 * sum);
+            }
+            rowc += rows;
+        }
+    }
+    T.ntile = ntile;
+    T.Fr = (F + 7) / 8 * 8 + 8;
+    T.wR.assign((size_t)F * T.Fr, 0.f);
+    for (int k = 0; k < F; ++k)
+        for (int pidx = 0; pidx <= k; ++pidx) T.wR[(size_t)pidx * T.Fr + k] = md->hk_weights[(size_t)k * F + pidx];
+    return true;
+}
+
+static void wvb_build(fd_wvm* m, const fd_wvm_model* md) {
+    m->wvbOk = false;
+    if (const char* e = getenv("FD_WVM_STAGEB")) if (!std::strcmp(e, "old")) return;   // read per model: the tests compare both
+    WvbTables T;
+    if (!wvb_tables(md, m->dev.numUsed, T)) return;
+    WvbDev& mv = m->wvb;
+    std::memset(&mv, 0, sizeof(mv));
+    auto up = [&](DevBuf& b, const void* src, size_t bytes) {
+        b.reserve(std::max<size_t>(bytes, 16));
+        HIP_CHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    };
+    up(m->wvbA, T.A.data(), T.A.size());
+    up(m->wvbLvl, T.lvl.data(), sizeof(int32_t) * T.lvl.size());
+    up(m->wvbC128, T.c128.data(), sizeof(int32_t) * T.c128.size());
+    up(m->wvbWR, T.wR.data(), sizeof(float) * T.wR.size());
+    m->sbCnt.reserve(64);
+    HIP_CHECK(hipMemset(m->sbCnt.p, 0, 64));
+    mv.A = m->wvbA.as<wvb_v4i>(); mv.lvl = m->wvbLvl.as<int4>(); mv.c128 = m->wvbC128.as<int32_t>();
+    mv.pp = m->pp.as<double>(); mv.val = m->val.as<double>(); mv.thr = m->thresholds.as<float>(); mv.wR = m->wvbWR.as<float>();
+    mv.KS = T.KS; mv.dstride = T.DS; mv.Fr = T.Fr;
+    mv.numPer = md->num_per_level; mv.numUsed = m->dev.numUsed; mv.numFilters = md->num_filters; mv.d = md->filter_w * md->filter_h;
+    mv.nphase = T.nphase;
+    for (int i = 0; i <= WVB_MAXPHASE; ++i) mv.phaseGen[i] = T.phaseGen[i];
+    mv.negBasis = m->dev.negBasis; mv.negBias = m->dev.negBias;
+    m->wvbOk = true;
+}
+
+// State buffers of a stage-B run over at most `total` queued windows (grow only); fills m->sb and m->deepCap.
+static void wvb_reserve(fd_wvm* m, int64_t total) {
+    int64_t capEnv = 0;   // read per run (the tests provoke the overflow report)
+    if (const char* e = getenv("FD_WVM_DEEP_CAP")) if (atoll(e) > 0) capEnv = (int64_t)atoll(e);
+    const WvbDev& mv = m->wvb;
+    const int64_t cap = std::max<int64_t>(64, std::min<int64_t>(total, capEnv ? capEnv : (int64_t)1 << 18));
+    const int64_t kstride = (cap + 63) / 64 * 64 + 96;   // not a power of two: the rows of K / R / U spread over the cache sets
+    int maxRows = 1;
+    for (int i = 0; i < mv.nphase; ++i)
+        maxRows = std::max(maxRows, std::min(mv.phaseGen[i + 1] * mv.numPer, mv.numUsed) - std::min(mv.phaseGen[i] * mv.numPer, mv.numUsed));
+    WvbState& s = m->sb;
+    for (int i = 0; i < 2; ++i) {
+        m->sbX[i].reserve((size_t)cap * mv.dstride);
+        m->sbWid[i].reserve(sizeof(int64_t) * (size_t)cap);
+        m->sbAux[i].reserve(sizeof(int2) * (size_t)cap);
+        m->sbU[i].reserve(sizeof(float) * (size_t)mv.numPer * kstride);
+        m->sbK[i].reserve(sizeof(float) * (size_t)mv.numUsed * kstride);
+        s.X[i] = m->sbX[i].as<int8_t>(); s.wid[i] = m->sbWid[i].as<int64_t>(); s.aux[i] = m->sbAux[i].as<int2>();
+        s.U[i] = m->sbU[i].as<float>(); s.K[i] = m->sbK[i].as<float>();
+    }
+    m->sbR.reserve(sizeof(float) * (size_t)maxRows * kstride);
+    s.R = m->sbR.as<float>();
+    s.cnt = m->sbCnt.as<unsigned int>();
+    s.cap = cap;
+    s.kstride = kstride;
+    m->deepCap = cap;
 }
 
 template <int PW_, int PH_>
@@ -2008,6 +2202,11 @@ static bool wvm_launch_head(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const WinTab
     L.zc = zc;
     L.headerMemset = !(zc && m->hdrClean);
     if (L.headerMemset) HIP_CHECK(hipMemsetAsync(m->pos.p, 0, sizeof(PosRec), st));
+    m->sbRun = m->wvbOk && m->dev.numUsed > WVM_LCAP;
+    if (m->sbRun) {
+        wvb_reserve(m, wt.total);
+        if (L.headerMemset) HIP_CHECK(hipMemsetAsync(m->sbCnt.p, 0, 64, st));   // phase counters (a zero-copy run clears them itself)
+    }
     m->hdrClean = false;   // set again by fd_wvm_finish once a zero-copy run has completed
     CascadeOut& o = L.o;
     o.all_level = want_all ? m->all_level.as<int32_t>() : nullptr;
@@ -2027,7 +2226,7 @@ static bool wvm_launch_head(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const WinTab
 // second half: the exact cascade kernels on `wtq`, read-back, completion event
 static void wvm_launch_tail(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm* m, const WinTable& wt, const WinTable& wtq, const WvmLaunch& L, bool skipA,
                             bool time_kernel) {
-    launch_cascade<false>(ctx, st, wt.total, m->dev, p->arena.as<uint8_t>(), wtq, L.o, skipA);
+    launch_cascade<false>(ctx, st, wt.total, m, p->arena.as<uint8_t>(), wtq, L.o, skipA);
     if (time_kernel) HIP_CHECK(hipEventRecord(ctx->ev1, st));
     HIP_CHECK(hipGetLastError());
     if (!L.zc) {
@@ -2124,6 +2323,8 @@ void fd_wvm_finish(fd_ctx* ctx, fd_wvm* m, WvmRun& run) {
     if ((int64_t)cnt > m->pos_cap)
         FD_THROW(FD_ERR_CAPACITY, "WVM produced %u positives, device buffer holds %lld (set FD_WVM_POS_CAP)", cnt, (long long)m->pos_cap);
     if (m->zcRun) m->hdrClean = true;   // the last stage-B workgroup has cleared the device header
+    if (m->sbRun && (int64_t)hraw[0].wid_hi > m->deepCap)   // header word 1: windows queued for stage B
+        FD_THROW(FD_ERR_CAPACITY, "WVM stage B: %u windows queued, its state holds %lld (set FD_WVM_DEEP_CAP)", hraw[0].wid_hi, (long long)m->deepCap);
     if (cnt) {
         const size_t firstChunk = m->zcRun ? (size_t)cnt : (size_t)std::min<int64_t>(m->pos_cap, WVM_FIRST_CHUNK);
         if (cnt > firstChunk) {   // on the auxiliary stream: the main stream may already hold the next detectors' kernels
@@ -2335,6 +2536,7 @@ int fd_wvm_create(fd_ctx* ctx, const fd_wvm_model* md, fd_wvm** out) {
         m->logisticB = md->logistic_b;
         m->h_thresholds.assign(md->thresholds, md->thresholds + F);
         wvm_build_dense(m, md);
+        wvb_build(m, md);
         *out = guard.release();
     });
 }
@@ -2380,7 +2582,13 @@ int fd_wvm_eval_batch(fd_ctx* ctx, const fd_wvm* wvm_, const uint8_t* patches, i
         m->counter.reserve(256);
         m->deep_q.reserve(sizeof(int64_t) * (size_t)n);
         HIP_CHECK(hipMemcpyAsync(in.p, patches, bytes, hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemsetAsync(m->counter.p, 0, 8, st));
+        HIP_CHECK(hipMemsetAsync(m->counter.p, 0, 16, st));
+        m->sbRun = m->wvbOk && m->dev.numUsed > WVM_LCAP;
+        if (m->sbRun) {
+            wvb_reserve(m, n);
+            HIP_CHECK(hipMemsetAsync(m->sbCnt.p, 0, 64, st));
+            m->hdrClean = false;   // the phase counters are left dirty: the next detect run clears them (and the header) first
+        }
         WinTable wt;
         std::memset(&wt, 0, sizeof(wt));
         wt.raw = 1;
@@ -2394,7 +2602,7 @@ int fd_wvm_eval_batch(fd_ctx* ctx, const fd_wvm* wvm_, const uint8_t* patches, i
         o.pos_cap = 0u;   // positives are not collected here
         o.deep_q = m->deep_q.as<int64_t>();
         o.deep_count = m->counter.as<unsigned int>() + 1;
-        launch_cascade<true>(ctx, st, n, m->dev, in.as<uint8_t>(), wt, o);
+        launch_cascade<true>(ctx, st, n, m, in.as<uint8_t>(), wt, o);
         HIP_CHECK(hipGetLastError());
         if (out_level) HIP_CHECK(hipMemcpyAsync(out_level, m->all_level.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
         if (out_score) HIP_CHECK(hipMemcpyAsync(out_score, m->all_fout.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
@@ -3086,6 +3294,43 @@ int fd_wvm_svm_evaluate_samples(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, 
             weight[sidx] = 2 * weight[sidx] * fd_svm_probability(svm, dist[i]);
         }
     });
+}
+
+// Test hook (include/fd_hip_bench.h; needs no GPU): the rect sums of every used level of `md` for n equalised patches, computed from
+// the stage-B tables with the operand addressing of k_wvb_chain (A fragment of lane h * 32 + row, byte t <-> pixel ks * 32 + h * 16 + t).
+// out[i * ncols + c]: c runs over the levels 0 .. numUsed - 1 in order, grey values 1 .. cntval - 1 inside a level.  Returns the number
+// of columns, or -1 when the model has no dense stage B.
+int64_t fd_debug_wvb_rect_sums(const fd_wvm_model* md, const uint8_t* patches, int64_t n, int32_t* out, int32_t* phase_gen /* [5] or NULL */) {
+    if (!md || md->num_filters < 1) return -1;
+    const int NU = (md->num_used > md->num_filters || md->num_used <= 0) ? md->num_filters : md->num_used;
+    WvbTables T;
+    try {
+        if (!wvb_tables(md, NU, T)) return -1;
+    } catch (...) { return -1; }
+    const int d = md->filter_w * md->filter_h;
+    int64_t ncols = 0;
+    for (int k = 0; k < NU; ++k) ncols += T.lvl[4 * (size_t)k + 2] - 1;
+    if (phase_gen) for (int i = 0; i <= WVB_MAXPHASE; ++i) phase_gen[i] = i <= T.nphase ? T.phaseGen[i] : -1;
+    if (!out || !patches) return ncols;
+    std::vector<int8_t> x((size_t)T.DS);
+    for (int64_t i = 0; i < n; ++i) {
+        std::fill(x.begin(), x.end(), 0);
+        for (int j = 0; j < d; ++j) x[j] = (int8_t)(patches[(size_t)i * d + j] ^ 0x80u);
+        int64_t c = 0;
+        for (int k = 0; k < NU; ++k) {
+            const int tile = T.lvl[4 * (size_t)k], row0 = T.lvl[4 * (size_t)k + 1], cnt = T.lvl[4 * (size_t)k + 2];
+            for (int v = 1; v < cnt; ++v, ++c) {
+                const int row = row0 + v - 1;
+                int32_t acc = 0;
+                for (int ks = 0; ks < T.KS; ++ks)
+                    for (int h = 0; h < 2; ++h)
+                        for (int t = 0; t < 16; ++t)
+                            acc += (int32_t)T.A[((((size_t)tile * T.KS + ks) * 64) + (size_t)(h * 32 + row)) * 16 + t] * (int32_t)x[(size_t)ks * 32 + h * 16 + t];
+                out[(size_t)i * ncols + c] = acc + T.c128[(size_t)tile * 32 + row];
+            }
+        }
+    }
+    return ncols;
 }
 
 int fd_histeq64_batch(fd_ctx* ctx, const uint8_t* patches, int64_t n, int w, int h, uint8_t* dst) {

@@ -83,12 +83,16 @@ def random_patches(frame_gray, pw, ph, n, rng):
 
 
 def make_wvm(seed, fw=20, fh=20, n_per=14, n_levels=20, r=0.04, calib_patches=None, pass_rate=0.65, min_survivors=32,
-             cntval=6, rect_range=(2, 8)):
+             cntval=6, rect_range=(2, 8), reject_every=1, hk_scale=1.0):
     """Synthetic wavelet reduced vector machine in the layout of fd_wvm_model / orc_wvm_desc.
 
     Structure follows the cfg-implied one (n_per x n_levels filters); thresholds are calibrated so that
     ~pass_rate of the surviving calibration patches pass each filter while at least min_survivors
-    remain, after that every survivor passes (mimics a cascade)."""
+    remain, after that every survivor passes (mimics a cascade).
+    Rejection profiles (the rejection rate per level drives throughput): pass_rate / min_survivors
+    set how fast and how far the cascade thins out; reject_every = n rejects only at every n-th filter (e.g. n_per:
+    only the last filter of a level group has a real threshold).  hk_scale scales the hyperplane weights (large
+    values give sums with heavy cancellation)."""
     rng = np.random.default_rng(seed)
     F = n_per * n_levels
     d = fw * fh
@@ -126,7 +130,7 @@ def make_wvm(seed, fw=20, fh=20, n_per=14, n_levels=20, r=0.04, calib_patches=No
     basis = np.float32(r / 65025.0)
     hk = np.zeros((F, F), np.float32)
     for k in range(F):
-        hk[k, :k + 1] = rng.normal(0, 1.0 / np.sqrt(k + 1), k + 1).astype(np.float32)
+        hk[k, :k + 1] = (hk_scale * rng.normal(0, 1.0 / np.sqrt(k + 1), k + 1)).astype(np.float32)
     bias = np.float32(0.0)
     thresholds = np.full(F, -1e30, np.float32)
     if calib_patches is not None and len(calib_patches):
@@ -139,7 +143,7 @@ def make_wvm(seed, fw=20, fh=20, n_per=14, n_levels=20, r=0.04, calib_patches=No
         alive = np.ones(len(X), bool)
         for k in range(F):
             vals = res[alive, k]
-            if vals.size >= min_survivors:
+            if vals.size >= min_survivors and (k + 1) % reject_every == 0:
                 thr = np.quantile(vals, 1.0 - pass_rate)
             else:
                 thr = (vals.min() - 1.0) if vals.size else -1e30

@@ -15,6 +15,12 @@ int fd_ctx_set_kernel_timing(fd_ctx* ctx, int enable);
 /* duration (ms) between those events for the last timed call on this context and the name of the bracketed kernel(s) */
 int fd_last_kernel_ms(fd_ctx* ctx, const char** kernel_name, float* ms);
 
+/* Test hook, needs no GPU: the rect sums (WvmClassifier.cpp:277-306) of every used level of `md` for n equalised patches, computed
+ * from the tables of the dense stage B with the operand addressing of its MFMA kernel.  out[i * ncols + c]: c runs over the levels
+ * 0 .. numUsed - 1, grey values 1 .. cntval - 1 inside a level.  Returns ncols (out may be NULL), -1 when the model has no dense
+ * stage B.  phase_gen (5 ints, may be NULL) receives the generation boundaries of the phases, -1 padded. */
+int64_t fd_debug_wvb_rect_sums(const fd_wvm_model* md, const uint8_t* patches, int64_t n, int32_t* out, int32_t* phase_gen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,211 @@
+"""Parity hardening of the production WVM cascade (VERDICT r02 task 1 + 3): the dense pre-filter rejects on an error-bounded
+inequality and stage B evaluates the survivors as dense contractions, so the places where a single ulp decides are tested
+explicitly: thresholds placed exactly ON a real window's filter output (and one ulp either side), sums of squares around 2^24,
+kernel arguments beyond the fast-exp range, weights with heavy cancellation, late-rejecting models, and the headline workload
+itself against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+FF = dict(inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))  # FaceFrontal.cfg
+EAR = dict(inc=float(np.float32(0.9)), min_scale=float(np.float32(0.5)), max_scale=float(np.float32(0.7)))
+
+
+def _pyr_pair(oracle, capi, ctx, frame, **kw):
+    po = oracle.Pyramid(**kw)
+    po.update(frame)
+    pg = capi.Pyramid(ctx, **kw)
+    pg.update(frame)
+    return po, pg
+
+
+def _eq_patches(oracle, po, pw, ph, idx):
+    wins = po.windows(pw, ph, 1, 1)
+    layers = {}
+    out = []
+    for i in idx:
+        l, x, y = int(wins[i, 0]), int(wins[i, 1]), int(wins[i, 2])
+        if l not in layers:
+            layers[l] = po.layer(l)
+        out.append(oracle.histeq64(layers[l][y:y + ph, x:x + pw].copy()))
+    return out
+
+
+def _level_output(oracle, model, k, patch_eq):
+    """res_k of one window (WvmClassifier.cpp:335-341), from the oracle: a copy of the model that stops at level k and never rejects"""
+    m = dict(model)
+    m["thresholds"] = np.full(model["num_filters"], -3e38, np.float32)
+    m["num_used"] = k + 1
+    lv, f = oracle.Wvm(m).eval(patch_eq)
+    assert lv == k
+    return np.float32(f)
+
+
+def _check_all_paths(oracle, capi, ctx, po, pg, model, tag):
+    """production path (pre-filter + stage B) == exact path (per-window outputs) == oracle"""
+    wo, wg = oracle.Wvm(model), capi.Wvm(ctx, model)
+    pos_o, lv_o, fo_o = oracle.sliding_wvm(po, wo, 1, 1)
+    pos_e, lv_e, fo_e = capi.detect_wvm(ctx, pg, wg, 1, 1, want_all=True)
+    pos_p, _, _ = capi.detect_wvm(ctx, pg, wg, 1, 1, want_all=False)
+    wg.close()
+    assert np.array_equal(lv_e, lv_o), tag
+    assert np.array_equal(fo_e, fo_o), tag
+    for pos in (pos_e, pos_p):
+        assert len(pos) == len(pos_o), (tag, len(pos), len(pos_o))
+        for f in ("cx", "cy", "w", "h", "layer", "lx", "ly"):
+            assert np.array_equal(pos[f], pos_o[f]), (tag, f)
+        assert np.array_equal(pos["score"], pos_o["fout"]), tag
+    return lv_o, fo_o
+
+
+CASES = {
+    # name: (pyramid, frame size, patch w, h, n_per, n_levels, make_wvm extras, brighten)
+    "face20_L14": (FF, (320, 240), 20, 20, 14, 3, {}, False),
+    "ear16x24_L16": (EAR, (200, 150), 16, 24, 20, 2, {}, False),
+    "nose32x24_sxx_2p24": (EAR, (220, 160), 32, 24, 16, 2, {}, True),
+    "face20_big_basis": (FF, (320, 240), 20, 20, 14, 2, dict(r=0.8), False),
+    "face20_cancellation": (FF, (320, 240), 20, 20, 14, 2, dict(hk_scale=3000.0), False),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_production_cascade_at_exact_threshold_ties(oracle, capi, ctx, synth, name):
+    """Thresholds of the pre-filter's levels are set to the exact fp32 filter output of a real window, and to the next float above
+    and below it: the window must pass / pass / be rejected exactly like in the reference (`fout >= threshold`,
+    WvmClassifier.cpp:139-141), in the production path, the exact path and the oracle alike."""
+    kw, size, pw, ph, nper, nlev, extra, bright = CASES[name]
+    frame = synth.make_frame(size[0], size[1], seed=77)
+    if bright:   # large equalised values everywhere: sum of squares of a 32x24 patch around and above 2^24
+        frame = np.clip(frame.astype(np.int32) // 3 + 170, 0, 255).astype(np.uint8)
+    po, pg = _pyr_pair(oracle, capi, ctx, frame, **kw)
+    gray = oracle.bgr2gray(frame)
+    rng = np.random.default_rng(9)
+    calib = synth.random_patches(gray[::2, ::2].copy(), pw, ph, 3000, rng)
+    base = synth.make_wvm(41, fw=pw, fh=ph, n_per=nper, n_levels=nlev, calib_patches=calib, min_survivors=40, **extra)
+    nwin = len(po.windows(pw, ph, 1, 1))
+    assert nwin >= 512   # below that the pre-filter is not used
+    if bright:
+        eq = _eq_patches(oracle, po, pw, ph, range(0, nwin, max(1, nwin // 64)))
+        assert max(int((e.astype(np.int64) ** 2).sum()) for e in eq) >= 1 << 24
+    L = min(16, nper, base["num_used"] - 1)
+    levels = sorted({0, L // 2, L - 1})
+    picks = rng.choice(nwin, 3, replace=False)
+    patches = _eq_patches(oracle, po, pw, ph, picks)
+    ran = 0
+    for k in levels:
+        for wi, pe in zip(picks, patches):
+            res = _level_output(oracle, base, k, pe)
+            if not np.isfinite(res):
+                continue
+            for which, thr in (("tie", res), ("above", np.nextafter(res, np.float32(np.inf))), ("below", np.nextafter(res, np.float32(-np.inf)))):
+                m = dict(base)
+                t = base["thresholds"].copy()
+                t[:k] = -3e38          # the window reaches level k
+                t[k] = thr
+                m["thresholds"] = t
+                lv_o, fo_o = _check_all_paths(oracle, capi, ctx, po, pg, m, (name, k, int(wi), which))
+                if which == "above":
+                    assert lv_o[wi] == k and fo_o[wi] == res
+                else:
+                    assert lv_o[wi] > k
+                ran += 1
+    assert ran >= 9
+    pg.close()
+
+
+PROFILES = {
+    # (ii) of VERDICT r02 task 3: 0.9 pass rate per filter down to ~0.1 % survivors; (iii): rejections only at level-group ends
+    "late_reject_0.9": dict(pass_rate=0.9, min_survivors=12),
+    "group_end_only": dict(pass_rate=0.5, min_survivors=12, reject_every=14),
+}
+
+
+@pytest.mark.parametrize("profile", sorted(PROFILES))
+def test_rejection_profiles_production_equals_exact_equals_oracle(oracle, capi, ctx, synth, frame640, profile):
+    """Models that keep rejecting deep into the cascade hand stage B a large part of the windows; its phases then thin the list out
+    between generations.  Every window's (level, output) and every positive must still equal the oracle's."""
+    gray = oracle.bgr2gray(frame640)
+    calib = synth.random_patches(gray[::4, ::4].copy(), 20, 20, 12000, np.random.default_rng(1))
+    model = synth.make_wvm(7, n_per=14, n_levels=8, calib_patches=calib, **PROFILES[profile])
+    po, pg = _pyr_pair(oracle, capi, ctx, frame640, **FF)
+    lv, _ = _check_all_paths(oracle, capi, ctx, po, pg, model, profile)
+    deep = int((lv >= 16).sum())
+    assert deep > 0.05 * len(lv), "the profile should send a sizeable share of the windows to stage B (%d of %d)" % (deep, len(lv))
+    if profile == "group_end_only":
+        assert all(k % 14 == 13 for k in set(lv.tolist()))   # exits only at the last filter of a level group
+    else:
+        assert len(set(lv.tolist())) > 20   # exits spread over many levels
+    pg.close()
+
+
+def test_stage_b_queue_overflow_is_reported(oracle, capi, ctx, synth, frame640):
+    """more queued windows than the stage-B state holds: an error (FD_ERR_CAPACITY), not a silently shorter result"""
+    model = synth.make_wvm(3, n_per=14, n_levels=2)   # thresholds -1e30: every window runs all 28 filters
+    _, pg = _pyr_pair(oracle, capi, ctx, frame640, **FF)
+    wg = capi.Wvm(ctx, model)
+    os.environ["FD_WVM_DEEP_CAP"] = "1000"
+    try:
+        with pytest.raises(capi.FdError) as e:
+            capi.detect_wvm(ctx, pg, wg, 1, 1, want_all=False)
+        assert "FD_WVM_DEEP_CAP" in str(e.value)
+    finally:
+        del os.environ["FD_WVM_DEEP_CAP"]
+    pos, _, _ = capi.detect_wvm(ctx, pg, wg, 1, 1, want_all=False)   # the handle is usable afterwards
+    assert len(pos) == 16185
+    wg.close(); pg.close()
+
+
+def test_stage_b_dense_equals_rect_lookup_kernels(capi, ctx, synth, oracle, frame640):
+    """FD_WVM_STAGEB=old keeps the rect-lookup stage-B kernels (k_wvm_deepB): both must deliver the same positive records"""
+    import bench
+    wvm_m, _ = bench.cascade_models()
+    _, pg = _pyr_pair(oracle, capi, ctx, frame640, **FF)
+    res = {}
+    for mode in ("new", "old"):
+        if mode == "old":
+            os.environ["FD_WVM_STAGEB"] = "old"
+        try:
+            wg = capi.Wvm(ctx, wvm_m)
+        finally:
+            os.environ.pop("FD_WVM_STAGEB", None)
+        res[mode] = (capi.detect_wvm(ctx, pg, wg, 1, 1, want_all=False)[0], capi.detect_wvm(ctx, pg, wg, 1, 1, want_all=True))
+        wg.close()
+    assert len(res["new"][0]) > 0
+    assert res["new"][0].tobytes() == res["old"][0].tobytes()
+    assert np.array_equal(res["new"][1][1], res["old"][1][1]) and np.array_equal(res["new"][1][2].view(np.uint32), res["old"][1][2].view(np.uint32))
+    pg.close()
+
+
+def test_headline_workload_against_the_oracle(oracle, capi, ctx, synth):
+    """The bench's headline call, verbatim: bench.cascade_models() (280-filter FaceFrontal WVM + 1024-SV SVM), 64 frames of 640x480
+    in one multi-frame pyramid, fd_detect_five_stage_frames_begin / _end.  Detections and stage counts of frames spread over the
+    call are compared with oracle.five_stage."""
+    import bench
+    wvm_m, svm_m = bench.cascade_models()
+    NF = 64
+    frames = [synth.make_frame(640, 480, seed=20260927 + i % 8) for i in range(NF)]   # the bench cycles through 8 frames
+    pm = capi.Pyramid(ctx, **FF)
+    pm.set_frames(NF)
+    pm.update_frames(images=frames)
+    wg, sg = capi.Wvm(ctx, wvm_m), capi.Svm(ctx, svm_m)
+    res = capi.FiveStageFrames(ctx, pm, wg, sg, NF).end()
+    wo, so = oracle.Wvm(wvm_m), oracle.Svm(svm_m)
+    po = oracle.Pyramid(**FF)
+    total = 0
+    for f in (0, 5, 18, 39, 63):
+        po.update(frames[f])
+        do, sto = oracle.five_stage(po, wo, so)
+        dg, stg = res[f]
+        assert np.array_equal(stg, sto), (f, stg, sto)
+        assert len(dg) == len(do)
+        for fld in ("cx", "cy", "w", "h"):
+            assert np.array_equal(dg[fld], do[fld]), (f, fld)
+        assert np.allclose(dg["probability"], do["prob"], rtol=1e-4, atol=0), f   # SVM distance tolerance of north_star
+        total += len(dg)
+    assert total > 0
+    # frames with the same content give the same result wherever they sit in the call
+    for f in range(8, NF):
+        assert res[f][0].tobytes() == res[f % 8][0].tobytes() and np.array_equal(res[f][1], res[f % 8][1])
+    wg.close(); sg.close(); pm.close()

@@ -194,3 +194,36 @@ int frame_loop(fd_ctx* ctx, fd_pyramid* pyr, const fd_wvm* wvm, const fd_svm* sv
 """)
     r = subprocess.run([gcc, "-fsyntax-only", "-std=c99", "-Wall", "-Werror", "-I", inc, str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.parametrize("shape", [(20, 20, 14, 3, 6, (2, 8)), (24, 24, 30, 2, 6, (2, 8)), (32, 24, 9, 3, 12, (1, 8)), (19, 21, 9, 4, 6, (2, 8)),
+                                   (16, 24, 20, 2, 16, (6, 8)), (7, 5, 3, 8, 6, (2, 8)), (20, 20, 40, 1, 6, (2, 8))])
+def test_stage_b_tables_reproduce_the_rect_sums(capi, synth, shape):
+    """The dense stage B (wvm_stageb.hpp) replaces the rect lookups on the integral image (WvmClassifier.cpp:277-306) by an int8
+    contraction against per-(level, grey value) coverage counts.  The host-built operand tables, read with the kernel's own
+    addressing, must give exactly the rect sums computed rect by rect."""
+    pw, ph, nper, nlev, cntval, rr = shape
+    wvm = synth.make_wvm(5, fw=pw, fh=ph, n_per=nper, n_levels=nlev, cntval=cntval, rect_range=rr)
+    rng = np.random.default_rng(pw * 100 + ph)
+    patches = rng.integers(0, 256, (40, ph, pw), dtype=np.uint8)
+    patches[0] = 255
+    patches[1] = 0
+    got = capi.wvb_rect_sums(wvm, patches)
+    if wvm["num_used"] <= 16:
+        assert got is None   # the one-wave-per-window stage finishes such models alone
+        return
+    sums, gens = got
+    assert gens[0] == 0 and gens[-1] == -(-wvm["num_used"] // nper) and all(a < b for a, b in zip(gens, gens[1:]))
+    ii = np.zeros((len(patches), ph + 1, pw + 1), np.int64)
+    ii[:, 1:, 1:] = patches.astype(np.int64).cumsum(1).cumsum(2)
+    c = 0
+    for k in range(wvm["num_used"]):
+        v0, v1 = wvm["val_off"][k], wvm["val_off"][k + 1]
+        for v in range(v0 + 1, v1):
+            want = np.zeros(len(patches), np.int64)
+            for r in range(wvm["rec_off"][v], wvm["rec_off"][v + 1]):
+                x1, y1, x2, y2 = (int(q) for q in wvm["rects"][r])
+                want += ii[:, y2 + 1, x2 + 1] - ii[:, y1, x2 + 1] - ii[:, y2 + 1, x1] + ii[:, y1, x1]
+            assert np.array_equal(sums[:, c], want), (k, v - v0)
+            c += 1
+    assert c == sums.shape[1]
