@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FD_HIP_LIB", os.path.join(_HERE, "libfd_hip.so"))   # FD_HIP_LIB: a differently built libfd_hip.so (A/B runs of kernel variants)
 
-FD_OK, FD_ERR_INVALID_ARGUMENT, FD_ERR_RUNTIME, FD_ERR_LOGIC, FD_ERR_HIP, FD_ERR_CAPACITY = range(6)
+FD_OK, FD_ERR_INVALID_ARGUMENT, FD_ERR_RUNTIME, FD_ERR_LOGIC, FD_ERR_HIP, FD_ERR_CAPACITY, FD_ERR_DEVICE_CAPACITY = range(7)
 FD_LAYER_NONE, FD_LAYER_GRADBIN, FD_LAYER_LBP = 0, 1, 2
 FD_KERNEL_LINEAR, FD_KERNEL_POLY, FD_KERNEL_RBF, FD_KERNEL_HIK = 0, 1, 2, 3
 FD_DTYPE_U8, FD_DTYPE_F32 = 0, 1
@@ -135,6 +135,7 @@ _SIGS = {
                                                     C.c_void_p, C.POINTER(C.c_void_p)]),
     "fd_detect_five_stage_frames_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "fd_pyramid_select": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "fd_pyramid_select_view": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "fd_pyramid_window_count": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]),
     "fd_pyramid_windows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
                                      C.POINTER(C.c_int64)]),
@@ -505,7 +506,12 @@ class FiveStageFrames:
     end() runs the host stages + the SVM launch and returns [(detections, stage_counts)] per frame"""
 
     def __init__(self, ctx, pyr, wvm, svm, nframes, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1, roi=None, cap=256):
-        self.ctx, self.nframes, self.cap = ctx, nframes, cap
+        # _end writes one entry per frame OF THE PYRAMID into counts / stages / out: the buffers are sized from the pyramid, and a
+        # caller who states another number is told so instead of getting a heap overflow
+        held = int(getattr(pyr, "nframes", 1) or 1)
+        if nframes != held:
+            raise ValueError("FiveStageFrames: nframes=%d but the pyramid holds %d frames" % (nframes, held))
+        self.ctx, self.nframes, self.cap = ctx, held, cap
         self.ticket = C.c_void_p()
         r = _c(roi, np.int32) if roi is not None else None
         ctx.check(lib().fd_detect_five_stage_frames_begin(ctx.h, pyr.h, wvm.h, svm.h, oe_dist, oe_ratio, sx, sy, _ptr(r), C.byref(self.ticket)))
@@ -517,6 +523,18 @@ class FiveStageFrames:
         t, self.ticket = self.ticket, C.c_void_p()
         self.ctx.check(lib().fd_detect_five_stage_frames_end(self.ctx.h, t, _ptr(out), self.cap, _ptr(counts), _ptr(stages)))
         return [(out[f, :counts[f]].copy(), stages[f].copy()) for f in range(self.nframes)]
+
+    def close(self):
+        """drops a ticket that was never ended (its host task is waited for, results are discarded)"""
+        if getattr(self, "ticket", None):
+            t, self.ticket = self.ticket, C.c_void_p()
+            lib().fd_detect_five_stage_frames_end(self.ctx.h, t, None, 0, None, None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def end_flat(self):
         """as end(), but one array for the call: (detections of all frames in frame order, frame index of each, stage_counts[frames, 4])"""

@@ -51,7 +51,7 @@ struct FdWorkerPool {
                 seen = gen;
                 j = job;
             }
-            j();
+            try { j(); } catch (...) {}   // jobs report their errors themselves; an escaping exception would terminate the process
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (--pending == 0) cvDone.notify_one();
@@ -66,9 +66,14 @@ struct FdWorkerPool {
             ++gen;
         }
         cv.notify_all();
-        f();
-        std::unique_lock<std::mutex> lk(mu);
-        cvDone.wait(lk, [&] { return pending == 0; });
+        // the workers reference the caller's stack through f: wait for them even when the caller's own share throws
+        std::exception_ptr err;
+        try { f(); } catch (...) { err = std::current_exception(); }
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cvDone.wait(lk, [&] { return pending == 0; });
+        }
+        if (err) std::rethrow_exception(err);
     }
     ~FdWorkerPool() {
         {
@@ -348,6 +353,9 @@ struct fd_pyramid {
     // fd_pyramid_select: layer sub-range (pyramid layer indices, -1 = open end), layer step (over the kept layers, starting at the
     // first) and default region of interest of every window enumeration that follows (DirectPyramidFeatureExtractor.cpp:75-123)
     int sel_first = -1, sel_last = -1, sel_step = 1;
+    // fd_pyramid_select_view: index range of the layers a pyramid built on this one exposes (ImagePyramid(pyramid, min, max)): the
+    // layers outside do not exist for the window enumeration, and the layer step counts from the first layer inside
+    int view_first = -1, view_last = -1;
     bool sel_has_roi = false;
     int sel_roi[4] = {0, 0, 0, 0};
     // recorded on the updating stream after the last kernel of an update: consumers on OTHER streams (the stream pool of the

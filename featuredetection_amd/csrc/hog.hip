@@ -385,6 +385,7 @@ int fd_hog_feature_length(const fd_hog_params* hp) {
 int fd_extract_hog(fd_ctx* ctx, fd_pyramid* p, const fd_hog_params* hp, float* features, int64_t cap_windows, int64_t* count) {
     return fd_guard(ctx, [&] {
         if (!ctx || !p || !hp || !count) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_extract_hog: NULL argument");
+        fd_pyramid_require_single(p, "fd_extract_hog");
         HogDev hd = make_hogdev(hp, 0);
         HogWinTable wt;
         std::vector<WindowLayer> wls;
@@ -477,6 +478,7 @@ int fd_detect_hog_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_ho
                       int64_t* count, double* all_distance) {
     return fd_guard(ctx, [&] {
         if (!ctx || !p || !svm || !hp || !count) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_hog_svm: NULL argument");
+        fd_pyramid_require_single(p, "fd_detect_hog_svm");
         fd_hog_svm_ticket t;
         hog_svm_begin(ctx, p, svm, hp, t);
         hog_svm_end(ctx, t, out, cap, count, all_distance);
@@ -487,6 +489,7 @@ int fd_detect_hog_svm_begin(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const
     if (ticket) *ticket = nullptr;
     return fd_guard(ctx, [&] {
         if (!ctx || !p || !svm || !hp || !ticket) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_hog_svm_begin: NULL argument");
+        fd_pyramid_require_single(p, "fd_detect_hog_svm_begin");
         std::unique_ptr<fd_hog_svm_ticket> t(new fd_hog_svm_ticket());
         hog_svm_begin(ctx, p, svm, hp, *t);
         *ticket = t.release();
@@ -987,6 +990,7 @@ int fd_hist_feature_length(const fd_hist_params* hp, int channels) {
 int fd_extract_hist(fd_ctx* ctx, fd_pyramid* p, const fd_hist_params* hp, float* features, int64_t cap_windows, int64_t* count) {
     return fd_guard(ctx, [&] {
         if (!ctx || !p || !hp || !count) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_extract_hist: NULL argument");
+        fd_pyramid_require_single(p, "fd_extract_hist");
         HogScratch& S = scratch(ctx);
         std::vector<WindowLayer> wls;
         HistDev hd;
@@ -1039,6 +1043,7 @@ int fd_detect_hist_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_h
                        int64_t* count, double* all_distance) {
     return fd_guard(ctx, [&] {
         if (!ctx || !p || !svm || !hp || !count) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_hist_svm: NULL argument");
+        fd_pyramid_require_single(p, "fd_detect_hist_svm");
         HogScratch& S = scratch(ctx);
         std::vector<WindowLayer> wls;
         HistDev hd;

@@ -754,6 +754,7 @@ void fd_enumerate_layers(const fd_pyramid* p, int pw, int ph, int sx, int sy, co
     }
     out.clear();
     total = 0;
+    size_t viewCount = 0;
     for (size_t li = 0; li < p->kept.size(); ++li) {
         const HostLayer& L = p->all[p->kept[li]];
         auto scaled = [&](int v) { return fd_cvRound(v * L.scale); };     // ImagePyramidLayer.hpp:65-67
@@ -771,7 +772,12 @@ void fd_enumerate_layers(const fd_pyramid* p, int pw, int ph, int sx, int sy, co
         wl.ny = spany > 0 ? (int)((spany - 1) / sy + 1) : 0;
         // layer selection (DirectPyramidFeatureExtractor.cpp:99-107): every sel_step-th layer counted from the first one,
         // skipping indices below sel_first, stopping above sel_last
-        const bool selected = (li % (size_t)p->sel_step == 0) && (p->sel_first < 0 || L.index >= p->sel_first) &&
+        // The step walks pyramid->getLayers() from its begin(): for a pyramid built on another one that is the first layer of its
+        // scale range (fd_pyramid_select_view), not the source's first layer.
+        const bool inView = (p->view_first < 0 || L.index >= p->view_first) && (p->view_last < 0 || L.index <= p->view_last);
+        const size_t viewPos = viewCount;
+        if (inView) ++viewCount;
+        const bool selected = inView && (viewPos % (size_t)p->sel_step == 0) && (p->sel_first < 0 || L.index >= p->sel_first) &&
                               (p->sel_last < 0 || L.index <= p->sel_last);
         if (!selected) wl.nx = wl.ny = 0;
         // windows must lie inside the layer (cv::Mat(image, bounds) would assert otherwise)
@@ -883,6 +889,14 @@ int fd_pyramid_select(fd_pyramid* p, int first_layer, int last_layer, int step_l
     });
 }
 
+int fd_pyramid_select_view(fd_pyramid* p, int first_layer, int last_layer) {
+    return fd_guard(p ? p->ctx : nullptr, [&] {
+        if (!p) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_select_view: NULL pyramid");
+        p->view_first = first_layer < 0 ? -1 : first_layer;
+        p->view_last = last_layer < 0 ? -1 : last_layer;
+    });
+}
+
 int fd_pyramid_octave_layer_count(const fd_pyramid* p) { return p ? (int)p->octl : 0; }
 double fd_pyramid_incremental_scale(const fd_pyramid* p) { return p ? p->inc : 0.0; }
 int fd_pyramid_layer_count(const fd_pyramid* p) { return p ? (int)p->kept.size() : 0; }
@@ -901,6 +915,7 @@ int fd_pyramid_layer_info(const fd_pyramid* p, int i, int* index, double* scale,
 int fd_pyramid_layer_download(fd_pyramid* p, int i, uint8_t* host_dst) {
     return fd_guard(p ? p->ctx : nullptr, [&] {
         if (!p || !host_dst || i < 0 || i >= (int)p->kept.size()) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_layer_download: bad argument");
+        if (p->nimg > 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_layer_download: the pyramid holds %d frames; use fd_pyramid_frame_layer_download", p->nimg);
         const HostLayer& L = p->all[p->kept[i]];
         HIP_CHECK(hipMemcpyAsync(host_dst, p->arena.as<uint8_t>() + L.filt_off, (size_t)L.w * L.h * L.ch, hipMemcpyDeviceToHost, p->ctx->stream));
         HIP_CHECK(hipStreamSynchronize(p->ctx->stream));

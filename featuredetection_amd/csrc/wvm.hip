@@ -135,23 +135,25 @@ struct WvbDev {
     const double* val;        // the model's val[]
     const float* thr;         // [numFilters]
     const float* wR;          // wR[p * Fr + k] = hkWeights[k][p] (p <= k), rows padded so that eight weights from any k can be read
+    const int32_t* rec;       // [numFilters][64 dwords] the chain's per-level record (layout: wvm_stageb.hpp, WVB_REC_DW)
     int32_t KS, dstride, Fr;  // k-steps (32 pixels each), bytes per equalised patch row of the state (KS * 32 + 16: an odd number of 16-byte slots)
     int32_t numPer, numUsed, numFilters, d;
+    int32_t maxCnt;           // largest grey-value count of a used filter
     int32_t nphase;
     int32_t phaseGen[WVB_MAXPHASE + 1];   // phase i = generations [phaseGen[i], phaseGen[i + 1])
     float negBasis, negBias;
 };
 // Per-run state of the queued windows, two sets (a phase reads set phase & 1; its survivors are packed densely into the other).
-// Position pos = place in the current phase's dense list.  Row strides (kstride) are not powers of two on purpose.
+// Position pos = place in the current phase's dense list.
 struct WvbState {
     int8_t* X[2];             // [pos][dstride] equalised patch as x - 128, row-major, zero padded
     int64_t* wid[2];          // [pos] window id
     int2* aux[2];             // [pos] {sum of the equalised patch, fp32 bits of the reference's sum of squares (IImg.cpp:33-47)}
-    float* U[2];              // [class][kstride] u_kernel_eval[class]
-    float* K[2];              // [level][kstride] kernel values (filter_output[level])
-    float* R;                 // [level - first level of the phase][kstride] filter-output sums res_k of the phase
+    float* U[2];              // [pos / 64][class][64] u_kernel_eval[class]
+    float* K[2];              // [pos / 64][level][64] kernel values (filter_output[level]): the history of a tile of 64 windows is contiguous
+    unsigned long long* exitKey;   // [pos] first failed level of the phase << 32 | fp32 bits of its filter-output sum; ~0: none
     unsigned int* cnt;        // [1 + WVB_MAXPHASE]: cnt[i] = windows alive at the start of phase i (i >= 1; phase 0 reads the queue length)
-    int64_t cap, kstride;
+    int64_t cap;
 };
 
 struct fd_wvm {
@@ -177,11 +179,16 @@ struct fd_wvm {
     // stage B as dense contractions (wvm_stageb.hpp): model tables, and the per-run state of the queued windows
     WvbDev wvb;
     bool wvbOk = false;
-    DevBuf wvbA, wvbLvl, wvbC128, wvbWR;
+    DevBuf wvbA, wvbLvl, wvbC128, wvbWR, wvbRec;
     WvbState sb;
-    DevBuf sbX[2], sbWid[2], sbAux[2], sbU[2], sbK[2], sbR, sbCnt;
+    DevBuf sbX[2], sbWid[2], sbAux[2], sbU[2], sbK[2], sbKey, sbCnt;
     int64_t deepCap = 0;             // windows stage B can hold in this run (the queue itself holds every window)
     bool sbRun = false;              // the run in flight uses the dense stage B
+    // what the handle's previous runs saw (-1: unknown): windows queued for stage B, windows alive behind each phase cut of the model.
+    // Sizes the grids and decides which cuts the next run keeps (launch_stageb).
+    int64_t sbDeep = -1, sbCutAlive[WVB_MAXPHASE] = {-1, -1, -1, -1};
+    uint32_t sbCutMask = ~0u, sbRuns = 0;
+    int sbPlanN = 0, sbPlanCut[WVB_MAXPHASE] = {};   // cuts of the run in flight
     ~fd_wvm() { if (done) (void)hipEventDestroy(done); if (tailDone) (void)hipEventDestroy(tailDone); if (prep) (void)hipEventDestroy(prep); }
 };
 
@@ -1876,9 +1883,9 @@ static void wvm_build_dense(fd_wvm* m, const fd_wvm_model* md) {
 // Tables of the dense stage B (wvm_stageb.hpp), pure host part.  Returns false (the rect-lookup stage-B kernels run instead) when
 // the model never reaches stage B or when more than 127 rects of one grey value overlap on a pixel.
 struct WvbTables {
-    int KS = 0, DS = 0, Fr = 0, nphase = 0, ntile = 0;
+    int KS = 0, DS = 0, Fr = 0, nphase = 0, ntile = 0, maxCnt = 1;
     int phaseGen[WVB_MAXPHASE + 1] = {};
-    std::vector<int32_t> lvl, c128;
+    std::vector<int32_t> lvl, c128, rec;
     std::vector<int8_t> A;
     std::vector<float> wR;
 };
@@ -1925,6 +1932,7 @@ static bool wvb_tables(const fd_wvm_model* md, int NU, WvbTables& T) {
             if (k >= NU) break;
             const int v0 = md->val_off[k], cntval = md->val_off[k + 1] - v0;
             const int rows = cntval - 1;
+            T.maxCnt = std::max(T.maxCnt, cntval);
             if (cur < 0 || rowc + rows > 32 || phaseStart(g)) {
                 cur = ntile++;
                 rowc = 0;
@@ -1954,6 +1962,18 @@ static bool wvb_tables(const fd_wvm_model* md, int NU, WvbTables& T) {
         }
     }
     T.ntile = ntile;
+    // the chain's per-level records (k_wvb_chain): one dword per lane
+    T.rec.assign((size_t)F * 64, 0);
+    for (int k = 0; k < NU; ++k) {
+        int32_t* r = &T.rec[(size_t)k * 64];
+        const int32_t* lv = &T.lvl[4 * (size_t)k];
+        r[0] = lv[0]; r[1] = lv[1]; r[2] = lv[2];
+        std::memcpy(r + 4, &md->pp[k], 8);
+        for (int v = 0; v < lv[2]; ++v) {
+            std::memcpy(r + 8 + 2 * v, &md->val[lv[3] + v], 8);
+            if (v >= 1) r[40 + v] = T.c128[(size_t)lv[0] * 32 + lv[1] + v - 1];
+        }
+    }
     T.Fr = (F + 7) / 8 * 8 + 8;
     T.wR.assign((size_t)F * T.Fr, 0.f);
     for (int k = 0; k < F; ++k)
@@ -1976,13 +1996,15 @@ static void wvb_build(fd_wvm* m, const fd_wvm_model* md) {
     up(m->wvbLvl, T.lvl.data(), sizeof(int32_t) * T.lvl.size());
     up(m->wvbC128, T.c128.data(), sizeof(int32_t) * T.c128.size());
     up(m->wvbWR, T.wR.data(), sizeof(float) * T.wR.size());
+    up(m->wvbRec, T.rec.data(), sizeof(int32_t) * T.rec.size());
     m->sbCnt.reserve(64);
     HIP_CHECK(hipMemset(m->sbCnt.p, 0, 64));
     mv.A = m->wvbA.as<wvb_v4i>(); mv.lvl = m->wvbLvl.as<int4>(); mv.c128 = m->wvbC128.as<int32_t>();
-    mv.pp = m->pp.as<double>(); mv.val = m->val.as<double>(); mv.thr = m->thresholds.as<float>(); mv.wR = m->wvbWR.as<float>();
+    mv.pp = m->pp.as<double>(); mv.val = m->val.as<double>(); mv.thr = m->thresholds.as<float>(); mv.wR = m->wvbWR.as<float>(); mv.rec = m->wvbRec.as<int32_t>();
     mv.KS = T.KS; mv.dstride = T.DS; mv.Fr = T.Fr;
     mv.numPer = md->num_per_level; mv.numUsed = m->dev.numUsed; mv.numFilters = md->num_filters; mv.d = md->filter_w * md->filter_h;
     mv.nphase = T.nphase;
+    mv.maxCnt = T.maxCnt;
     for (int i = 0; i <= WVB_MAXPHASE; ++i) mv.phaseGen[i] = T.phaseGen[i];
     mv.negBasis = m->dev.negBasis; mv.negBias = m->dev.negBias;
     m->wvbOk = true;
@@ -1994,25 +2016,21 @@ static void wvb_reserve(fd_wvm* m, int64_t total) {
     if (const char* e = getenv("FD_WVM_DEEP_CAP")) if (atoll(e) > 0) capEnv = (int64_t)atoll(e);
     const WvbDev& mv = m->wvb;
     const int64_t cap = std::max<int64_t>(64, std::min<int64_t>(total, capEnv ? capEnv : (int64_t)1 << 18));
-    const int64_t kstride = (cap + 63) / 64 * 64 + 96;   // not a power of two: the rows of K / R / U spread over the cache sets
-    int maxRows = 1;
-    for (int i = 0; i < mv.nphase; ++i)
-        maxRows = std::max(maxRows, std::min(mv.phaseGen[i + 1] * mv.numPer, mv.numUsed) - std::min(mv.phaseGen[i] * mv.numPer, mv.numUsed));
+    const int64_t tilesCap = (cap + 63) / 64;
     WvbState& s = m->sb;
     for (int i = 0; i < 2; ++i) {
         m->sbX[i].reserve((size_t)cap * mv.dstride);
         m->sbWid[i].reserve(sizeof(int64_t) * (size_t)cap);
         m->sbAux[i].reserve(sizeof(int2) * (size_t)cap);
-        m->sbU[i].reserve(sizeof(float) * (size_t)mv.numPer * kstride);
-        m->sbK[i].reserve(sizeof(float) * (size_t)mv.numUsed * kstride);
+        m->sbU[i].reserve(sizeof(float) * (size_t)mv.numPer * 64 * tilesCap);
+        m->sbK[i].reserve(sizeof(float) * (size_t)mv.numUsed * 64 * tilesCap);
         s.X[i] = m->sbX[i].as<int8_t>(); s.wid[i] = m->sbWid[i].as<int64_t>(); s.aux[i] = m->sbAux[i].as<int2>();
         s.U[i] = m->sbU[i].as<float>(); s.K[i] = m->sbK[i].as<float>();
     }
-    m->sbR.reserve(sizeof(float) * (size_t)maxRows * kstride);
-    s.R = m->sbR.as<float>();
+    m->sbKey.reserve(sizeof(unsigned long long) * (size_t)cap);
+    s.exitKey = m->sbKey.as<unsigned long long>();
     s.cnt = m->sbCnt.as<unsigned int>();
     s.cap = cap;
-    s.kstride = kstride;
     m->deepCap = cap;
 }
 
@@ -2321,10 +2339,24 @@ void fd_wvm_finish(fd_ctx* ctx, fd_wvm* m, WvmRun& run) {
     }
     if (m->zcRun && cnt == 0xffffffffu) FD_THROW(FD_ERR_HIP, "WVM stage B did not deliver its positive count");
     if ((int64_t)cnt > m->pos_cap)
-        FD_THROW(FD_ERR_CAPACITY, "WVM produced %u positives, device buffer holds %lld (set FD_WVM_POS_CAP)", cnt, (long long)m->pos_cap);
+        FD_THROW(FD_ERR_DEVICE_CAPACITY, "WVM produced %u positives, device buffer holds %lld (set FD_WVM_POS_CAP)", cnt, (long long)m->pos_cap);
     if (m->zcRun) m->hdrClean = true;   // the last stage-B workgroup has cleared the device header
+    if (m->sbRun) {   // header word 1: windows queued for stage B; zero-copy runs also deliver the counts of phases 1 and 2
+        m->sbDeep = (int64_t)hraw[0].wid_hi;
+        if (m->zcRun) {
+            uint32_t c2;
+            std::memcpy(&c2, &hraw[0].fout, 4);
+            const int64_t c[3] = {m->sbDeep, (int64_t)(uint32_t)hraw[0].level, (int64_t)c2};
+            for (int j = 1; j <= m->sbPlanN && j <= 2; ++j) {
+                const int cut = m->sbPlanCut[j - 1];
+                m->sbCutAlive[cut] = c[j];
+                if (c[j - 1] > 0 && c[j] * 10 >= c[j - 1] * 7) m->sbCutMask &= ~(1u << cut);
+                else m->sbCutMask |= 1u << cut;
+            }
+        }
+    }
     if (m->sbRun && (int64_t)hraw[0].wid_hi > m->deepCap)   // header word 1: windows queued for stage B
-        FD_THROW(FD_ERR_CAPACITY, "WVM stage B: %u windows queued, its state holds %lld (set FD_WVM_DEEP_CAP)", hraw[0].wid_hi, (long long)m->deepCap);
+        FD_THROW(FD_ERR_DEVICE_CAPACITY, "WVM stage B: %u windows queued, its state holds %lld (set FD_WVM_DEEP_CAP)", hraw[0].wid_hi, (long long)m->deepCap);
     if (cnt) {
         const size_t firstChunk = m->zcRun ? (size_t)cnt : (size_t)std::min<int64_t>(m->pos_cap, WVM_FIRST_CHUNK);
         if (cnt > firstChunk) {   // on the auxiliary stream: the main stream may already hold the next detectors' kernels
@@ -2879,13 +2911,15 @@ static void five_stage_frames_end(fd_ctx* ctx, fd_five_stage_frames& t, fd_detec
     }
     if (!counts || cap_per_frame < 0) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_frames: bad argument");
     const int NF = t.p->nimg;
-    for (int f = 0; f < NF; ++f) {
+    size_t most = 0;
+    for (int f = 0; f < NF; ++f) {   // every frame's count first: a caller whose buffer is too small sizes the retry from them
         const std::vector<fd_detection>& r = t.res[(size_t)f];
         counts[f] = (int)r.size();
+        most = std::max(most, r.size());
         if (stage_counts) std::memcpy(stage_counts + 4 * f, &t.stages[4 * (size_t)f], 4 * sizeof(int32_t));
         for (size_t i = 0; i < r.size() && (int)i < cap_per_frame && out; ++i) out[(size_t)f * cap_per_frame + i] = r[i];
-        if (out && (int)r.size() > cap_per_frame) FD_THROW(FD_ERR_CAPACITY, "five-stage: %zu detections, capacity %d", r.size(), cap_per_frame);
     }
+    if (out && (int)most > cap_per_frame) FD_THROW(FD_ERR_CAPACITY, "five-stage: %zu detections in one frame, capacity %d", most, cap_per_frame);
 }
 
 int fd_detect_five_stage_frames(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const fd_svm* svm, float oe_dist, float oe_ratio, int sx,
@@ -3017,9 +3051,16 @@ static void five_stage_batch_begin(fd_ctx* ctx, fd_five_stage_job* jobs, int n, 
             ctx->workers->run([&] {
                 (void)hipSetDevice(ctx->device);
                 for (int i; (i = next.fetch_add(1)) < count;) {
+                    // nothing may leave a pool thread's body (std::terminate): vector / DevBuf growth can throw bad_alloc etc.
                     try { f(i); } catch (const FdError& e) {
                         std::lock_guard<std::mutex> lk(errMu);
                         if (firstErr.code == FD_OK) firstErr = e;
+                    } catch (const std::exception& e) {
+                        std::lock_guard<std::mutex> lk(errMu);
+                        if (firstErr.code == FD_OK) firstErr = FdError{FD_ERR_RUNTIME, e.what()};
+                    } catch (...) {
+                        std::lock_guard<std::mutex> lk(errMu);
+                        if (firstErr.code == FD_OK) firstErr = FdError{FD_ERR_RUNTIME, "unknown error on a batch worker thread"};
                     }
                 }
             });
@@ -3109,6 +3150,14 @@ static void five_stage_batch_end(fd_ctx* ctx, fd_five_stage_batch& b) {
                     std::lock_guard<std::mutex> lk(errMu);
                     tails[pick].finished = true;
                     fail(pick, e);
+                } catch (const std::exception& e) {   // pool thread: nothing else may escape
+                    std::lock_guard<std::mutex> lk(errMu);
+                    tails[pick].finished = true;
+                    fail(pick, FdError{FD_ERR_RUNTIME, e.what()});
+                } catch (...) {
+                    std::lock_guard<std::mutex> lk(errMu);
+                    tails[pick].finished = true;
+                    fail(pick, FdError{FD_ERR_RUNTIME, "unknown error on a batch worker thread"});
                 }
             }
         };
@@ -3295,6 +3344,14 @@ int fd_wvm_svm_evaluate_samples(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, 
         }
     });
 }
+
+#ifdef FD_WVB_PROF
+// dev tool (tools/wvb_phases.py, -DFD_WVB_PROF builds only): the accumulated timestamps of the stage-B kernels
+void fd_debug_wvb_prof(unsigned long long* out, int reset) {
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(fd_wvb_prof), sizeof(unsigned long long) * 64);
+    if (reset) { unsigned long long z[64] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(fd_wvb_prof), z, sizeof(z)); }
+}
+#endif
 
 // Test hook (include/fd_hip_bench.h; needs no GPU): the rect sums of every used level of `md` for n equalised patches, computed from
 // the stage-B tables with the operand addressing of k_wvb_chain (A fragment of lane h * 32 + row, byte t <-> pixel ks * 32 + h * 16 + t).

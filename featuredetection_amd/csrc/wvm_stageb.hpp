@@ -24,6 +24,23 @@
 
 #define WVB_CONST(T, p) ((const __attribute__((address_space(4))) T*)(uintptr_t)(p))
 
+// -DFD_WVB_PROF: phase split of the stage-B kernels from in-kernel timestamps (thread 0 of every workgroup, s_memtime ticks),
+// read back through fd_debug_wvb_prof (tools/wvb_phases.py).  Slots: chain 8 * phase + i, sums 24 + 4 * phase + i, exit 36 + 8 * phase + i.
+#ifdef FD_WVB_PROF
+__device__ unsigned long long fd_wvb_prof[64];
+#define WVB_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define WVB_TW(v) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define WVB_DECL(base) unsigned long long wvb_acc[8] = {}; const int wvb_base = (base)
+#define WVB_ADD(i, d) wvb_acc[(i) - wvb_base] += (unsigned long long)(d)   /* registers; flushed once per workgroup */
+#define WVB_FLUSH do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 8; ++i_) if (wvb_acc[i_]) atomicAdd(&fd_wvb_prof[wvb_base + i_], wvb_acc[i_]); } while (0)
+#else
+#define WVB_T(v)
+#define WVB_TW(v)
+#define WVB_DECL(base)
+#define WVB_ADD(i, d)
+#define WVB_FLUSH
+#endif
+
 // windows alive at the start of a phase (wave-uniform), never more than the state holds
 __device__ __forceinline__ unsigned int wvb_count(const unsigned int* countPtr, const WvbState& s) {
     const unsigned int c = (unsigned int)__builtin_amdgcn_readfirstlane((int)*countPtr);
@@ -68,7 +85,16 @@ __global__ __launch_bounds__(256) void k_wvb_prepare(const uint8_t* __restrict__
     }
 }
 
-// LDS: [64 windows][dstride] equalised pixels of the tile, then per wavefront [32 rows][64 windows] rect sums of the current tile
+// Per-level record of the chain (host-packed, 256 bytes = one dword per lane): [0] tile, [1] first row inside the tile, [2] grey-value
+// count, [4..5] pp, [8 + 2v..] val[v] (16 doubles), [40 + v] 128 * sum of row (row0 + v - 1) (v >= 1)
+constexpr int WVB_REC_DW = 64;
+constexpr int WVB_RECS = 16;   // level records a wavefront keeps in LDS at a time
+
+// LDS: [64 windows][dstride] equalised pixels of the tile; per wavefront [32 rows][64 windows] rect sums of the current tile; per
+// wavefront WVB_RECS level records.  Memory latency (~0.5-0.8 us per dependent round trip on this part) is what bounds a unit, so
+// every stage issues all its loads before it consumes the first: the tile, the records, the operand fragments of a rect-sum tile.
+// MAXV: compile-time bound of the grey values per filter (8 or 16, chosen by the model).
+template <int MAXV>
 __global__ __launch_bounds__(256) void k_wvb_chain(WvbDev mv, WvbState s, int phase, const unsigned int* countPtr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wvb_lds[];
     const int lane = threadIdx.x & 63;
@@ -79,157 +105,263 @@ __global__ __launch_bounds__(256) void k_wvb_chain(WvbDev mv, WvbState s, int ph
     const int NQ = (NP + 3) >> 2;
     const int set = phase & 1;
     const int g0 = mv.phaseGen[phase], g1 = mv.phaseGen[phase + 1];
-    const auto* lvl = WVB_CONST(int32_t, mv.lvl);
-    const auto* c128 = WVB_CONST(int32_t, mv.c128);
-    const auto* ppC = WVB_CONST(double, mv.pp);
-    const auto* valC = WVB_CONST(double, mv.val);
     int* Sw = reinterpret_cast<int*>(wvb_lds + 64 * DS) + wave * (32 * 64);
+    int* Rw = reinterpret_cast<int*>(wvb_lds + 64 * DS) + 4 * (32 * 64) + wave * (WVB_RECS * WVB_REC_DW);
     const int cpr = DS >> 4;   // 16-byte slots per row
+    WVB_DECL(8 * phase);
     for (int unit = blockIdx.x; unit < ntiles * NQ; unit += gridDim.x) {
         const int t = unit / NQ, cq = unit - t * NQ;   // neighbouring workgroups share the window tile (L2)
+        WVB_T(tq0);
         __syncthreads();   // the previous unit's MFMA operand reads are done
         {
             const uint4* xg = reinterpret_cast<const uint4*>(s.X[set] + (size_t)t * 64 * DS);
-            const unsigned int rows = min(64u, n - (unsigned int)t * 64u);
-            for (int c = threadIdx.x; c < 64 * cpr; c += 256) {
-                const unsigned int row = (unsigned int)c / (unsigned int)cpr;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (row < rows) v = xg[c];
-                reinterpret_cast<uint4*>(wvb_lds)[c] = v;
+            const int live = (int)min(64u, n - (unsigned int)t * 64u) * cpr;   // slots of the tile's real windows (rows are contiguous)
+            for (int c0 = threadIdx.x; c0 < 64 * cpr; c0 += 8 * 256) {
+                uint4 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = c0 + i * 256;
+                    v[i] = make_uint4(0, 0, 0, 0);
+                    if (c < live) v[i] = xg[c];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = c0 + i * 256;
+                    if (c < 64 * cpr) reinterpret_cast<uint4*>(wvb_lds)[c] = v[i];
+                }
             }
+        }
+        const int cls = cq * 4 + wave;
+        const unsigned int pos = (unsigned int)t * 64u + (unsigned int)lane;
+        const bool valid = pos < n;
+        float u = 0.f;
+        int sx_total = 0;
+        float sxx = 0.f;
+        if (cls < NP && valid) {
+            const int2 ax = s.aux[set][pos];
+            sx_total = ax.x;
+            sxx = __int_as_float(ax.y);
+            if (phase > 0) u = s.U[set][((size_t)t * NP + cls) * 64 + lane];
+            if (cls == 0) s.exitKey[pos] = ~0ull;   // k_wvb_sums of this phase takes the minimum over the failed levels
         }
         __syncthreads();
-        const int cls = cq * 4 + wave;
+        WVB_T(tq1);
+        WVB_ADD(8 * phase + 0, 1);
+        WVB_ADD(8 * phase + 1, tq1 - tq0);
         if (cls < NP) {
-            const unsigned int pos = (unsigned int)t * 64u + (unsigned int)lane;
-            const bool valid = pos < n;
-            float u = 0.f;
-            int sx_total = 0;
-            float sxx = 0.f;
-            if (valid) {
-                const int2 ax = s.aux[set][pos];
-                sx_total = ax.x;
-                sxx = __int_as_float(ax.y);
-                if (phase > 0) u = s.U[set][(size_t)cls * s.kstride + pos];
-            }
             int curTile = -1;
-            for (int g = g0; g < g1; ++g) {
-                const int k = g * NP + cls;
-                if (k >= NU) break;
-                const int tile = lvl[4 * k], row0 = lvl[4 * k + 1], cnt = lvl[4 * k + 2], vo = lvl[4 * k + 3];
-                if (tile != curTile) {
-                    // ---- rect sums of the tile's rows for the 64 windows: C[row][window] = sum_pixel M[row][pixel] * x[window][pixel]
-                    curTile = tile;
-                    wvb_v16i acc0 = {}, acc1 = {};
-                    const wvb_v4i* Ap = mv.A + (size_t)tile * KS * 64 + lane;
-                    const unsigned char* xb = wvb_lds + (lane & 31) * DS + (lane >> 5) * 16;
-                    // the tile's operand streams from L2 through a ring of four fragments (a k-step is two MFMAs: far shorter than a load)
-                    wvb_v4i an[4];
+            for (int gb = g0; gb < g1; gb += WVB_RECS) {
+                WVB_T(tq2);
+                // the level records of the next WVB_RECS levels of this class: one coalesced load each, all in flight together
+                const int rem = NU - 1 - cls - gb * NP;
+                if (rem < 0) break;
+                const int nl = min(min(WVB_RECS, g1 - gb), rem / NP + 1);   // levels of this batch (k < NU)
+                wave_sync();
+                {
+                    int rv[WVB_RECS];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) an[i] = Ap[min(i, KS - 1) * 64];
-                    for (int ks = 0; ks < KS; ks += 4) {
+                    for (int i = 0; i < WVB_RECS; ++i) rv[i] = mv.rec[(size_t)((gb + min(i, nl - 1)) * NP + cls) * WVB_REC_DW + lane];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const wvb_v4i a = an[i];
-                            an[i] = Ap[min(ks + 4 + i, KS - 1) * 64];
-                            if (ks + i < KS) {
-                                const wvb_v4i b0 = *reinterpret_cast<const wvb_v4i*>(xb + (ks + i) * 32);
-                                const wvb_v4i b1 = *reinterpret_cast<const wvb_v4i*>(xb + 32 * DS + (ks + i) * 32);
-                                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b0, acc0, 0, 0, 0);
-                                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1, acc1, 0, 0, 0);
+                    for (int i = 0; i < WVB_RECS; ++i) Rw[i * WVB_REC_DW + lane] = rv[i];
+                }
+                wave_sync();
+                WVB_T(tq3);
+                WVB_ADD(8 * phase + 2, tq3 - tq2);
+                for (int i0 = 0; i0 < nl; i0 += 4) {
+                    WVB_T(tq4);
+                    // ---- four levels at a time: everything up to the u_kernel_eval dependency is independent between them
+                    double part[4], ppv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int* rc = Rw + min(i0 + j, nl - 1) * WVB_REC_DW;   // past the end: the last level again (discarded)
+                        const int tile = __builtin_amdgcn_readfirstlane(rc[0]), row0 = __builtin_amdgcn_readfirstlane(rc[1]);
+                        const int cnt = __builtin_amdgcn_readfirstlane(rc[2]);
+                        if (tile != curTile) {
+                            // ---- rect sums of the tile's rows for the 64 windows: C[row][window] = sum_pixel M[row][pixel] * x[window][pixel]
+                            curTile = tile;
+                            wvb_v16i acc0 = {}, acc1 = {};
+                            const wvb_v4i* Ap = mv.A + (size_t)tile * KS * 64 + lane;
+                            const unsigned char* xb = wvb_lds + (lane & 31) * DS + (lane >> 5) * 16;
+                            // the tile's operand streams from L2 through a ring of eight fragments
+                            wvb_v4i an[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) an[q] = Ap[min(q, KS - 1) * 64];
+                            for (int ks = 0; ks < KS; ks += 8) {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) {
+                                    const wvb_v4i a = an[q];
+                                    an[q] = Ap[min(ks + 8 + q, KS - 1) * 64];
+                                    if (ks + q < KS) {
+                                        const wvb_v4i b0 = *reinterpret_cast<const wvb_v4i*>(xb + (ks + q) * 32);
+                                        const wvb_v4i b1 = *reinterpret_cast<const wvb_v4i*>(xb + 32 * DS + (ks + q) * 32);
+                                        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b0, acc0, 0, 0, 0);
+                                        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1, acc1, 0, 0, 0);
+                                    }
+                                }
                             }
-                        }
-                    }
-                    wave_sync();   // the chain reads of the previous tile are done
+                            wave_sync();   // the reads of the previous tile's sums are done
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        Sw[row * 64 + (lane & 31)] = acc0[r];
-                        Sw[row * 64 + 32 + (lane & 31)] = acc1[r];
+                            for (int r = 0; r < 16; ++r) {
+                                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                                Sw[row * 64 + (lane & 31)] = acc0[r];
+                                Sw[row * 64 + 32 + (lane & 31)] = acc1[r];
+                            }
+                            wave_sync();
+                        }
+                        // the reference's sums in its order (WvmClassifier.cpp:277-309); grey values past cnt add an exact +0
+                        const double* valL = reinterpret_cast<const double*>(rc + 8);
+                        double sum_xp = 0.0;
+                        int sumv0 = sx_total;
+#pragma unroll
+                        for (int v = 1; v < MAXV; ++v) {
+                            int sv = Sw[min(row0 + v - 1, 31) * 64 + lane] + rc[40 + v];
+                            sv = v < cnt ? sv : 0;
+                            sumv0 -= sv;
+                            const double prod = (double)sv * valL[v];   // val[v] is stored as 0 for v >= cnt
+                            sum_xp = sum_xp + prod;
+                        }
+                        const double t0 = (double)sumv0 * valL[0];
+                        part[j] = sum_xp + t0;
+                        ppv[j] = *reinterpret_cast<const double*>(rc + 4);
                     }
-                    wave_sync();
+                    // ---- the serial part: u_kernel_eval of the class from level to level (WvmClassifier.cpp:310-316)
+                    double arg[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        double sum_xp = part[j] + (double)u;
+                        if (i0 + j < nl) u = (float)sum_xp;
+                        double norm = (double)sxx;
+                        norm = norm - 2 * sum_xp;
+                        norm = norm + ppv[j];
+                        arg[j] = (double)mv.negBasis * norm;
+                    }
+                    // ---- the kernel values: independent again
+                    float Kk[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Kk[j] = (float)exp(arg[j]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (i0 + j < nl && valid) s.K[set][((size_t)t * NU + (gb + i0 + j) * NP + cls) * 64 + lane] = Kk[j];
+                    WVB_T(tq6);
+                    WVB_ADD(8 * phase + 4, tq6 - tq4);
+                    WVB_ADD(8 * phase + 6, min(4, nl - i0));
                 }
-                // ---- the reference's chain for this lane's window (WvmClassifier.cpp:277-333)
-                double sum_xp = 0.0;
-                int sumv0 = sx_total;
-                for (int v = 1; v < cnt; ++v) {
-                    const int sv = Sw[(row0 + v - 1) * 64 + lane] + c128[tile * 32 + row0 + v - 1];
-                    sumv0 -= sv;
-                    const double prod = (double)sv * valC[vo + v];
-                    sum_xp = sum_xp + prod;
-                }
-                const double t0 = (double)sumv0 * valC[vo];
-                sum_xp = sum_xp + t0;
-                sum_xp = sum_xp + (double)u;
-                u = (float)sum_xp;
-                double norm = (double)sxx;
-                norm = norm - 2 * sum_xp;
-                norm = norm + ppC[k];
-                const float Kk = (float)exp((double)mv.negBasis * norm);
-                if (valid) s.K[set][(size_t)k * s.kstride + pos] = Kk;
             }
-            if (valid && phase + 1 < mv.nphase) s.U[set][(size_t)cls * s.kstride + pos] = u;
+            if (valid && phase + 1 < mv.nphase) s.U[set][((size_t)t * NP + cls) * 64 + lane] = u;
         }
+        WVB_T(tq7);
+        WVB_ADD(8 * phase + 5, tq7 - tq0);
     }
+    WVB_FLUSH;
 }
 
-// res_k = -bias + sum_{p <= k} w[k][p] K_p for the rows of the phase; one wavefront per (64 windows, 8 rows)
+// res_k = -bias + sum_{p <= k} w[k][p] K_p for the rows of the phase and the cascade's exit rule on them (WvmClassifier.cpp:139-141).
+// A workgroup takes one block of 8 consecutive rows for four tiles of 64 windows (one per wavefront, lane == window): the block's
+// weights are staged in LDS once and read as broadcasts, every K_p load (256 B, coalesced) feeds 8 multiply-adds; the terms keep the
+// reference's order.  The first failed row of a window inside the block goes into exitKey by a 64-bit minimum (level << 32 | fp32 bits).
+constexpr int WVB_MAXF = 64 * WVM_PJ;
 __global__ __launch_bounds__(256) void k_wvb_sums(WvbDev mv, WvbState s, int phase, const unsigned int* countPtr) {
+    __shared__ __attribute__((aligned(16))) float wl[(WVB_MAXF + 8) * 8];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned int n = wvb_count(countPtr, s);
     const int ntiles = (int)((n + 63u) >> 6);
+    const int nquads = (ntiles + 3) >> 2;
     const int NU = mv.numUsed, Fr = mv.Fr;
     const int k0 = min(mv.phaseGen[phase] * mv.numPer, NU), k1 = min(mv.phaseGen[phase + 1] * mv.numPer, NU);
     const int nrb = (k1 - k0 + 7) >> 3;
     const int set = phase & 1;
-    const auto* wR = WVB_CONST(float, mv.wR);
-    const size_t ks = (size_t)s.kstride;
-    for (int unit = blockIdx.x * 4 + wave; unit < ntiles * nrb; unit += gridDim.x * 4) {
-        const int t = unit / nrb, rb = nrb - 1 - (unit - t * nrb);   // the longest rows first
+    constexpr size_t ks = 64;   // K[tile][level][64 windows]: a tile's history is one contiguous block
+    WVB_DECL(24 + 4 * phase);
+    for (int unit = blockIdx.x; unit < nquads * nrb; unit += gridDim.x) {
+        const int rb = nrb - 1 - unit / nquads, q = unit - (unit / nquads) * nquads;   // the longest rows first
         const int kb = k0 + rb * 8;
+        const int kend = min(kb + 8, k1);   // terms p < kend
+        WVB_T(ts0);
+        __syncthreads();   // the previous unit's weight reads are done
+        for (int i = threadIdx.x; i < kend * 8; i += 256) wl[i] = mv.wR[(size_t)(i >> 3) * Fr + kb + (i & 7)];
+        __syncthreads();
+        WVB_T(ts1);
+        WVB_ADD(24 + 4 * phase + 0, 1);
+        WVB_ADD(24 + 4 * phase + 1, ts1 - ts0);
+        const int t = q * 4 + wave;
+        if (t >= ntiles) continue;   // no barrier below this line
         const unsigned int pos = (unsigned int)t * 64u + (unsigned int)lane;
         const bool valid = pos < n;
-        const float* Kp = s.K[set] + (valid ? pos : 0u);
+        const float* Kp = s.K[set] + (size_t)t * NU * 64 + lane;
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = mv.negBias;
-        int p = 0;
-        // terms every row of the block takes (p < kb), four loads in flight
-        for (; p + 4 <= kb; p += 4) {
-            const float ka = Kp[(size_t)p * ks], kb_ = Kp[(size_t)(p + 1) * ks], kc = Kp[(size_t)(p + 2) * ks], kd = Kp[(size_t)(p + 3) * ks];
-            const auto* w0 = wR + (size_t)p * Fr + kb;
+        // terms every row of the block takes (p < kb): groups of 16 K loads, the next group in flight while one is consumed
+        auto loadK = [&](float (&kv)[16], int p0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float tt = w0[j] * ka; acc[j] = acc[j] + tt; }
+            for (int i = 0; i < 16; ++i) kv[i] = Kp[(size_t)(p0 + i) * ks];
+        };
+        auto useK = [&](const float (&kv)[16], int p0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float tt = w0[Fr + j] * kb_; acc[j] = acc[j] + tt; }
+            for (int i = 0; i < 16; ++i) {
+                const float4 wa = *reinterpret_cast<const float4*>(wl + (p0 + i) * 8), wb = *reinterpret_cast<const float4*>(wl + (p0 + i) * 8 + 4);
+                const float w8[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float tt = w0[2 * Fr + j] * kc; acc[j] = acc[j] + tt; }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float tt = w0[3 * Fr + j] * kd; acc[j] = acc[j] + tt; }
-        }
-        for (; p < kb; ++p) {
-            const float ka = Kp[(size_t)p * ks];
-            const auto* w0 = wR + (size_t)p * Fr + kb;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float tt = w0[j] * ka; acc[j] = acc[j] + tt; }
-        }
-        // the diagonal block: row kb + j ends with term p = kb + j
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            if (kb + jj < k1) {
-                const float ka = Kp[(size_t)(kb + jj) * ks];
-                const auto* w0 = wR + (size_t)(kb + jj) * Fr + kb;
-#pragma unroll
-                for (int j = jj; j < 8; ++j) { const float tt = w0[j] * ka; acc[j] = acc[j] + tt; }
+                for (int j = 0; j < 8; ++j) { const float tt = w8[j] * kv[i]; acc[j] = acc[j] + tt; }
+            }
+        };
+        const int ngroups = kb >> 4;
+        {
+            float ka[16], kc[16];
+            if (ngroups > 0) loadK(ka, 0);
+            for (int g = 0; g < ngroups; g += 2) {
+                if (g + 1 < ngroups) loadK(kc, (g + 1) * 16);
+                useK(ka, g * 16);
+                if (g + 1 < ngroups) {
+                    if (g + 2 < ngroups) loadK(ka, (g + 2) * 16);
+                    useK(kc, (g + 1) * 16);
+                }
             }
         }
-        if (valid) {
+        int p = ngroups * 16;
+        {   // the up to 15 terms left before the diagonal block: loads together
+            float kv[16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (kb + j < k1) s.R[(size_t)(kb + j - k0) * ks + pos] = acc[j];
+            for (int i = 0; i < 16; ++i) kv[i] = Kp[(size_t)min(p + i, kb) * ks];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (p + i < kb) {
+                    const float* w0 = wl + (p + i) * 8;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float tt = w0[j] * kv[i]; acc[j] = acc[j] + tt; }
+                }
+            }
         }
+        // the diagonal block: row kb + j ends with term p = kb + j
+        {
+            float kv[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) kv[jj] = Kp[(size_t)min(kb + jj, k1 - 1) * ks];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                if (kb + jj < k1) {
+                    const float* w0 = wl + (kb + jj) * 8;
+#pragma unroll
+                    for (int j = jj; j < 8; ++j) { const float tt = w0[j] * kv[jj]; acc[j] = acc[j] + tt; }
+                }
+            }
+        }
+        // exit rule, first failed row of the block
+        if (valid) {
+            int fj = -1;
+            float fv = 0.f;
+#pragma unroll
+            for (int j = 7; j >= 0; --j) {
+                const int k = kb + j;
+                if (k < k1 && (!(acc[j] >= mv.thr[k]) || k + 1 == NU)) { fj = k; fv = acc[j]; }
+            }
+            if (fj >= 0) atomicMin(s.exitKey + pos, ((unsigned long long)(unsigned int)fj << 32) | (unsigned long long)(unsigned int)__float_as_int(fv));
+        }
+        WVB_T(ts2);
+        WVB_ADD(24 + 4 * phase + 2, ts2 - ts1);
     }
+    WVB_FLUSH;
 }
 
 // end of the last phase: see CascadeOut::host_count; also hands the queue length to the host (overflow check) and clears the
@@ -244,7 +376,10 @@ __device__ __forceinline__ void wvb_finalize(const CascadeOut& o, const WvbState
             __threadfence();
             const unsigned int cnt = __hip_atomic_load(o.pos_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned int dq = __hip_atomic_load(o.deep_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // host header words 1..3: windows queued for stage B, alive at the start of phases 1 and 2 (the host adapts its phase plan)
             __hip_atomic_store(o.host_count + 1, dq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(o.host_count + 2, __hip_atomic_load(s.cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(o.host_count + 3, __hip_atomic_load(s.cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(o.host_count, cnt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(o.pos_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(o.deep_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -255,119 +390,207 @@ __device__ __forceinline__ void wvb_finalize(const CascadeOut& o, const WvbState
     }
 }
 
-// lane == window: the cascade's exit rule on the phase's rows (WvmClassifier.cpp:139-141), outputs, positives, and the dense
-// list + state of the windows that go on to the next phase
+// One workgroup per tile of 64 windows (every wavefront sees lane == window): outputs and positives of the windows that left the
+// cascade in this phase; the windows that go on are appended to the next phase's dense list and their state (patch, u, K history)
+// is copied to the other set -- the four wavefronts share the rows / patch slots, all loads of a batch in flight together.
 __global__ __launch_bounds__(256) void k_wvb_exit(WvbDev mv, WvbState s, CascadeOut o, int phase, const unsigned int* countPtr, unsigned int* nextCount) {
+    __shared__ unsigned int sBase[2];
+    __shared__ unsigned char sLaneOf[2][64];   // lane of the r-th survivor / positive of the tile
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned int n = wvb_count(countPtr, s);
     const int ntiles = (int)((n + 63u) >> 6);
     const int NU = mv.numUsed, NP = mv.numPer, DS = mv.dstride, d = mv.d;
-    const int k0 = min(mv.phaseGen[phase] * NP, NU), k1 = min(mv.phaseGen[phase + 1] * NP, NU);
+    const int k1 = min(mv.phaseGen[phase + 1] * NP, NU);
     const int set = phase & 1;
-    const size_t ks = (size_t)s.kstride;
-    const auto* thrC = WVB_CONST(float, mv.thr);
-    for (int t = blockIdx.x * 4 + wave; t < ntiles; t += gridDim.x * 4) {
+    constexpr size_t ks = 64;
+    const int cpr = DS >> 4;
+    WVB_DECL(36 + 8 * phase);
+    WVB_T(te00);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        WVB_T(te0);
         const unsigned int pos = (unsigned int)t * 64u + (unsigned int)lane;
         const bool valid = pos < n;
-        int exitk = -1;
-        float fout = 0.f;
-        {
-            const float* Rp = s.R + (valid ? pos : 0u);
-            for (int k = k0; k < k1; ++k) {
-                const float r = Rp[(size_t)(k - k0) * ks];
-                if (valid && exitk < 0 && (!(r >= thrC[k]) || k + 1 == NU)) { exitk = k; fout = r; }
-                if (__ballot(valid && exitk < 0) == 0ull) break;
-            }
-        }
-        const bool exited = valid && exitk >= 0;
+        const unsigned long long key = valid ? s.exitKey[pos] : 0ull;
+        const bool exited = valid && key != ~0ull;
+        const int exitk = (int)(key >> 32);
+        const float fout = __int_as_float((int)(unsigned int)key);
         const int64_t wid = valid ? s.wid[set][pos] : 0;
-        if (exited) {
-            if (o.all_level) o.all_level[wid] = exitk;
-            if (o.all_fout) o.all_fout[wid] = fout;
+        const bool positive = exited && (exitk + 1 == mv.numFilters) && (fout >= mv.thr[exitk]);   // WvmClassifier.cpp:143-148
+        const bool surv = valid && !exited;
+        const unsigned long long pmask = __ballot(positive), smask = __ballot(surv);
+        const unsigned int prank = (unsigned int)__popcll(pmask & ((1ull << lane) - 1ull)), srank = (unsigned int)__popcll(smask & ((1ull << lane) - 1ull));
+        WVB_TW(tx0);
+        __syncthreads();   // the previous tile's readers of the shared words are done
+        WVB_TW(tx1);
+        if (wave == 0) {
+            if (exited) {
+                if (o.all_level) o.all_level[wid] = exitk;
+                if (o.all_fout) o.all_fout[wid] = fout;
+            }
+            if (lane == 0) {
+                sBase[0] = pmask ? atomicAdd(o.pos_count, (unsigned int)__popcll(pmask)) : 0u;
+                sBase[1] = smask ? atomicAdd(nextCount, (unsigned int)__popcll(smask)) : 0u;
+            }
+            if (positive) sLaneOf[0][prank] = (unsigned char)lane;
+            if (surv) sLaneOf[1][srank] = (unsigned char)lane;
         }
-        // ---- positives (WvmClassifier.cpp:143-148: all filters passed)
-        const bool positive = exited && (exitk + 1 == mv.numFilters) && (fout >= thrC[exitk]);
-        const unsigned long long pmask = __ballot(positive);
+        WVB_TW(tx2);
+        WVB_ADD(36 + 8 * phase + 7, tx2 - tx1);
+        WVB_ADD(36 + 8 * phase + 4, tx0 - te0);
+        __syncthreads();
+        WVB_T(te1);
+        WVB_ADD(36 + 8 * phase + 0, 1);
+        WVB_ADD(36 + 8 * phase + 1, te1 - te0);
+        const unsigned int pbase = sBase[0], sbase = sBase[1];
+        // ---- positives: record + equalised patch
         if (pmask) {
-            unsigned int base = 0;
-            if (lane == 0) base = atomicAdd(o.pos_count, (unsigned int)__popcll(pmask));
-            base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-            const unsigned int slot = base + (unsigned int)__popcll(pmask & ((1ull << lane) - 1ull));
-            if (positive && slot < o.pos_cap) o.pos[slot] = PosRec{(uint32_t)wid, (uint32_t)(wid >> 32), exitk, fout};
-            unsigned long long rest = pmask;
-            unsigned int sl = base;
-            while (rest) {   // the equalised patch of each positive, copied by the whole wavefront
-                const int b = __builtin_ctzll(rest);
-                rest &= rest - 1;
-                if (sl < o.pos_cap) {
-                    const int8_t* src = s.X[set] + (size_t)((unsigned int)t * 64u + (unsigned int)b) * DS;
-                    uint8_t* dst = o.pos_patches + (size_t)sl * d;
-                    if ((d & 3) == 0) {
-                        for (int i = lane; i < (d >> 2); i += 64)
-                            reinterpret_cast<unsigned int*>(dst)[i] = reinterpret_cast<const unsigned int*>(src)[i] ^ 0x80808080u;
-                    } else {
-                        for (int i = lane; i < d; i += 64) dst[i] = (uint8_t)((unsigned int)(uint8_t)src[i] ^ 0x80u);
+            const int np_ = __popcll(pmask);
+            if ((d & 15) == 0) {   // every cfg-implied patch size: 16-byte slots, four loads per thread in flight
+                const int dq = d >> 4;
+                for (int c0 = threadIdx.x; c0 < np_ * dq; c0 += 4 * 256) {
+                    uint4 v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int c = c0 + i * 256;
+                        if (c < np_ * dq) {
+                            const int r = c / dq, cc = c - r * dq;
+                            v[i] = reinterpret_cast<const uint4*>(s.X[set] + (size_t)((unsigned int)t * 64u + sLaneOf[0][r]) * DS)[cc];
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int c = c0 + i * 256;
+                        if (c < np_ * dq) {
+                            const int r = c / dq, cc = c - r * dq;
+                            if (pbase + r < o.pos_cap)
+                                reinterpret_cast<uint4*>(o.pos_patches + (size_t)(pbase + r) * d)[cc] =
+                                    make_uint4(v[i].x ^ 0x80808080u, v[i].y ^ 0x80808080u, v[i].z ^ 0x80808080u, v[i].w ^ 0x80808080u);
+                        }
                     }
                 }
-                ++sl;
+            } else {
+                for (int c = threadIdx.x; c < np_ * d; c += 256) {
+                    const int r = c / d, i = c - r * d;
+                    if (pbase + r < o.pos_cap)
+                        o.pos_patches[(size_t)(pbase + r) * d + i] = (uint8_t)((unsigned int)(uint8_t)s.X[set][(size_t)((unsigned int)t * 64u + sLaneOf[0][r]) * DS + i] ^ 0x80u);
+                }
             }
         }
+        WVB_T(te2);
+        WVB_ADD(36 + 8 * phase + 2, te2 - te1);
         // ---- windows that go on: dense list of the next phase, state copied to the other set
-        const bool surv = valid && exitk < 0;
-        const unsigned long long smask = __ballot(surv);
         if (smask) {
-            unsigned int base = 0;
-            if (lane == 0) base = atomicAdd(nextCount, (unsigned int)__popcll(smask));
-            base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-            const unsigned int np = base + (unsigned int)__popcll(smask & ((1ull << lane) - 1ull));
-            if (surv) {
+            const int ns_ = __popcll(smask);
+            const unsigned int np = sbase + srank;
+            if (surv && wave == 0) {
                 s.wid[set ^ 1][np] = wid;
                 s.aux[set ^ 1][np] = s.aux[set][pos];
-                for (int c = 0; c < NP; ++c) s.U[set ^ 1][(size_t)c * ks + np] = s.U[set][(size_t)c * ks + pos];
-                for (int p = 0; p < k1; ++p) s.K[set ^ 1][(size_t)p * ks + np] = s.K[set][(size_t)p * ks + pos];
             }
-            unsigned long long rest = smask;
-            unsigned int dp = base;
-            const int cpr = DS >> 4;
-            while (rest) {
-                const int b = __builtin_ctzll(rest);
-                rest &= rest - 1;
-                const uint4* src = reinterpret_cast<const uint4*>(s.X[set] + (size_t)((unsigned int)t * 64u + (unsigned int)b) * DS);
-                uint4* dst = reinterpret_cast<uint4*>(s.X[set ^ 1] + (size_t)dp * DS);
-                for (int i = lane; i < cpr; i += 64) dst[i] = src[i];
-                ++dp;
+            if (surv) {
+                const float* Us = s.U[set] + (size_t)t * NP * 64 + lane;
+                float* Ud = s.U[set ^ 1] + (size_t)(np >> 6) * NP * 64 + (np & 63u);
+                for (int c = wave; c < NP; c += 4) Ud[(size_t)c * ks] = Us[(size_t)c * ks];
+                const float* Ksrc = s.K[set] + (size_t)t * NU * 64 + lane;
+                float* Kdst = s.K[set ^ 1] + (size_t)(np >> 6) * NU * 64 + (np & 63u);
+                int p = wave * 8;
+                for (; p + 8 <= k1; p += 32) {   // eight rows per wavefront and pass, loads first
+                    float kv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) kv[i] = Ksrc[(size_t)(p + i) * ks];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) Kdst[(size_t)(p + i) * ks] = kv[i];
+                }
+                for (; p < k1; ++p) Kdst[(size_t)p * ks] = Ksrc[(size_t)p * ks];   // this wavefront's last group, when it is a partial one (p + 8 > k1 here)
+            }
+            for (int c0 = threadIdx.x; c0 < ns_ * cpr; c0 += 4 * 256) {   // four 16-byte slots per thread and pass
+                uint4 v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = c0 + i * 256;
+                    if (c < ns_ * cpr) {
+                        const int r = c / cpr, cc = c - r * cpr;
+                        v[i] = reinterpret_cast<const uint4*>(s.X[set] + (size_t)((unsigned int)t * 64u + sLaneOf[1][r]) * DS)[cc];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = c0 + i * 256;
+                    if (c < ns_ * cpr) {
+                        const int r = c / cpr, cc = c - r * cpr;
+                        reinterpret_cast<uint4*>(s.X[set ^ 1] + (size_t)(sbase + r) * DS)[cc] = v[i];
+                    }
+                }
             }
         }
+        WVB_T(te3);
+        WVB_ADD(36 + 8 * phase + 3, te3 - te2);
+        // the positives' records last: with the zero-copy read-back they are stores to host memory, and anything that waits for a
+        // later load would wait for their PCIe round trip as well
+        if (pmask && wave == 0 && positive && pbase + prank < o.pos_cap) o.pos[pbase + prank] = PosRec{(uint32_t)wid, (uint32_t)(wid >> 32), exitk, fout};
     }
+    WVB_T(te4);
     if (phase + 1 == mv.nphase) wvb_finalize(o, s);
+    WVB_T(te5);
+    WVB_ADD(36 + 8 * phase + 5, te5 - te00);
+    WVB_ADD(36 + 8 * phase + 6, 1);
+    WVB_FLUSH;
 }
 
-// queues stage B on `st` behind whatever filled the queue (o.deep_q / o.deep_count)
+// queues stage B on `st` behind whatever filled the queue (o.deep_q / o.deep_count).  Grids: the kernels are grid-stride loops over
+// device-side counts, correct for any grid; workgroups without work are not free though (2048 idle workgroups delayed the loads of
+// the 148 working ones by 15 us), so the grids follow the counts of the handle's previous run (m->sbPred) with a margin.
 template <int PW_, int PH_, bool RAW>
 static void launch_stageb(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* m, const uint8_t* arena, const WinTable& wt, const CascadeOut& o) {
-    const WvbDev& mv = m->wvb;
+    // The plan of this run: the model's phase cuts (tile breaks of the tables) that are still worth a compaction.  A cut whose
+    // phase let >= 70 % of its windows through in the handle's previous runs is skipped (its generations join the next phase: three
+    // launches and a state copy less); every 64th run tries all cuts again.  The results do not depend on the plan.
+    WvbDev mv = m->wvb;
+    {
+        static const bool adapt = [] { const char* e = getenv("FD_WVB_ADAPT"); return !(e && atoi(e) == 0); }();
+        const int ncuts = m->wvb.nphase - 1;
+        const bool probe = !adapt || (m->sbRuns % 64) == 0;
+        int np = 0;
+        for (int i = 0; i < ncuts; ++i)
+            if (probe || (m->sbCutMask >> i & 1u)) { mv.phaseGen[++np] = m->wvb.phaseGen[i + 1]; m->sbPlanCut[np - 1] = i; }
+        mv.phaseGen[++np] = m->wvb.phaseGen[m->wvb.nphase];
+        mv.nphase = np;
+        m->sbPlanN = np - 1;
+        ++m->sbRuns;
+    }
     const WvbState& s = m->sb;
     const int64_t ub = std::min<int64_t>(total, s.cap);   // upper bound of the windows in any phase
     if (ub <= 0) return;
     const int cus = ctx->num_cus;
-    const int64_t tiles = (ub + 63) / 64;
-    const int ldsBytes = 64 * mv.dstride + 4 * 32 * 64 * (int)sizeof(int);
-    static uint64_t ldsDone = 0;
-    fd_allow_lds(ctx, (const void*)k_wvb_chain, 160 * 1024, ldsDone);
+    const int ldsBytes = 64 * mv.dstride + 4 * (32 * 64 + WVB_RECS * WVB_REC_DW) * (int)sizeof(int);
+    static uint64_t ldsDone8 = 0, ldsDone16 = 0;
+    const bool v8 = mv.maxCnt <= 8;
+    if (v8) fd_allow_lds(ctx, (const void*)k_wvb_chain<8>, 160 * 1024, ldsDone8);
+    else fd_allow_lds(ctx, (const void*)k_wvb_chain<WVM_MAX_VALS>, 160 * 1024, ldsDone16);
     const int perCuC = std::max(1, std::min(8, (160 * 1024) / ldsBytes));
-    const int gridP = (int)std::min<int64_t>((ub + 3) / 4, (int64_t)cus * 8);
-    hipLaunchKernelGGL((k_wvb_prepare<PW_, PH_, RAW>), dim3(gridP), dim3(256), 0, st, arena, wt, m->dev, mv, s, o.deep_q, o.deep_count);
+    auto expect = [&](int ph) {   // windows expected at the start of phase ph, with a margin
+        int64_t pred = ph == 0 ? m->sbDeep : m->sbCutAlive[m->sbPlanCut[ph - 1]];
+        if (pred < 0) pred = m->sbDeep;
+        if (pred < 0) pred = std::max<int64_t>(2048, total / 64);
+        return std::min<int64_t>(ub, pred + pred / 4 + 64);
+    };
+    {
+        const int64_t e = expect(0);
+        const int gridP = (int)std::min<int64_t>((e + 3) / 4, (int64_t)cus * 8);
+        hipLaunchKernelGGL((k_wvb_prepare<PW_, PH_, RAW>), dim3(gridP), dim3(256), 0, st, arena, wt, m->dev, mv, s, o.deep_q, o.deep_count);
+    }
     const int NQ = (mv.numPer + 3) / 4;
     for (int ph = 0; ph < mv.nphase; ++ph) {
         const unsigned int* countPtr = ph == 0 ? o.deep_count : s.cnt + ph;
         const int k0 = std::min(mv.phaseGen[ph] * mv.numPer, mv.numUsed), k1 = std::min(mv.phaseGen[ph + 1] * mv.numPer, mv.numUsed);
         const int nrb = (k1 - k0 + 7) / 8;
+        const int64_t tiles = (expect(ph) + 63) / 64;
         const int gridC = (int)std::min<int64_t>(tiles * NQ, (int64_t)cus * perCuC);
-        hipLaunchKernelGGL(k_wvb_chain, dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
-        const int gridH = (int)std::min<int64_t>((tiles * nrb + 3) / 4, (int64_t)cus * 8);
+        if (v8) hipLaunchKernelGGL(k_wvb_chain<8>, dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
+        else hipLaunchKernelGGL(k_wvb_chain<WVM_MAX_VALS>, dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
+        const int gridH = (int)std::min<int64_t>((tiles + 3) / 4 * nrb, (int64_t)cus * 8);
         hipLaunchKernelGGL(k_wvb_sums, dim3(gridH), dim3(256), 0, st, mv, s, ph, countPtr);
-        const int gridE = (int)std::min<int64_t>((tiles + 3) / 4, (int64_t)cus * 4);
+        const int gridE = (int)std::min<int64_t>(tiles, (int64_t)cus * 4);
         hipLaunchKernelGGL(k_wvb_exit, dim3(gridE), dim3(256), 0, st, mv, s, o, ph, countPtr, s.cnt + ph + 1);
     }
 }

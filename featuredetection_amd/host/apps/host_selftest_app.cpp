@@ -67,6 +67,14 @@ int main(int argc, char** argv) {
             for (auto& p : patches) { geo.push_back(p->getX()); geo.push_back(p->getY()); geo.push_back(p->getWidth()); geo.push_back(p->getHeight()); }
             dump(out + "view" + std::to_string(i) + "_geo.bin", geo.data(), geo.size() * 4);
         }
+        // the layer step of extract() counts from the FIRST LAYER OF THE VIEW (pyramid->getLayers().begin(),
+        // DirectPyramidFeatureExtractor.cpp:94-99), wherever that layer sits in the source pyramid
+        for (int i = 0; i < 3; ++i) {
+            auto patches = extractors[i]->extract(4, 4, cv::Rect(), -1, -1, 2);
+            std::vector<int32_t> geo;
+            for (auto& p : patches) { geo.push_back(p->getX()); geo.push_back(p->getY()); geo.push_back(p->getWidth()); geo.push_back(p->getHeight()); }
+            dump(out + "view" + std::to_string(i) + "_step2_geo.bin", geo.data(), geo.size() * 4);
+        }
         image->setData(img);   // new version: exactly one rebuild, whoever asks first
         for (auto& e : extractors) e->update(image);
         std::printf("builds_after_new_version %ld\n", ImagePyramid::buildCount() - before);

@@ -272,7 +272,8 @@ public:
     // with the scale range of a pyramid that views another one; reset when the guard goes out of scope.
     class Selection {
     public:
-        Selection(fd_pyramid* h, int first, int last, int step, const cv::Rect* roi);
+        // viewFirst / viewLast: layer index range of a pyramid built on another one (-1: the pyramid owns its layers)
+        Selection(fd_pyramid* h, int first, int last, int step, const cv::Rect* roi, int viewFirst = -1, int viewLast = -1);
         ~Selection();
         Selection(Selection&& o) : handle(o.handle) { o.handle = nullptr; }
         Selection(const Selection&) = delete;

@@ -297,14 +297,18 @@ void ImagePyramid::viewRange(int& first, int& last) const {
     for (const auto& sc : sourcePyramid->getLayerScales())
         if (sc.second >= minScaleFactor && sc.second <= maxScaleFactor) { first = std::min(first, sc.first); last = std::max(last, sc.first); }
 }
-ImagePyramid::Selection::Selection(fd_pyramid* h, int first, int last, int step, const cv::Rect* roi) : handle(h) {
+ImagePyramid::Selection::Selection(fd_pyramid* h, int first, int last, int step, const cv::Rect* roi, int viewFirst, int viewLast) : handle(h) {
     int r[4] = {0, 0, 0, 0};
     if (roi) { r[0] = roi->x; r[1] = roi->y; r[2] = roi->width; r[3] = roi->height; }
     // an empty range (first > last) selects nothing: express it as an index range no layer has
     if (last != -1 && first > last) { first = 1 << 30; last = 1 << 30; }
     check(fd_pyramid_select(handle, first, last, step, roi ? r : nullptr));
+    // the layer step of extract() walks getLayers() of THIS pyramid: a view starts counting at its own first layer
+    check(fd_pyramid_select_view(handle, viewFirst, viewLast));
 }
-ImagePyramid::Selection::~Selection() { if (handle) fd_pyramid_select(handle, -1, -1, 1, nullptr); }
+ImagePyramid::Selection::~Selection() {
+    if (handle) { fd_pyramid_select(handle, -1, -1, 1, nullptr); fd_pyramid_select_view(handle, -1, -1); }
+}
 ImagePyramid::Selection ImagePyramid::select(int firstLayer, int lastLayer, int stepLayer, const cv::Rect* roi) const {
     if (stepLayer < 1) throw std::invalid_argument("DirectPyramidFeatureExtractor: stepLayer has to be greater than zero");
     int vf, vl;
@@ -315,7 +319,8 @@ ImagePyramid::Selection ImagePyramid::select(int firstLayer, int lastLayer, int 
         if (vl == -2) { firstLayer = 1; lastLayer = 0; }
     }
     const cv::Rect* r = (roi && (roi->x != 0 || roi->y != 0 || roi->width != 0 || roi->height != 0)) ? roi : nullptr;
-    return Selection(native(), firstLayer, lastLayer, stepLayer, r);
+    const bool view = sourcePyramid && vl != -2;
+    return Selection(native(), firstLayer, lastLayer, stepLayer, r, view ? vf : -1, view ? vl : -1);
 }
 void ImagePyramid::addLayerFilter(const shared_ptr<ImageFilter>& filter) {
     if (sourcePyramid) throw std::logic_error("ImagePyramid: layer filters on top of a source pyramid are not available on this backend");
@@ -1342,7 +1347,12 @@ vector<vector<shared_ptr<ClassifiedPatch>>> FiveStageSlidingWindowDetector::dete
                                                        psvm->getSvm()->native(psvm->getLogisticA(), psvm->getLogisticB()), overlapElimination->getDist(),
                                                        overlapElimination->getRatio(), slidingWindowDetector->getStepSizeX(),
                                                        slidingWindowDetector->getStepSizeY(), nullptr, dets.data(), cap, counts.data(), nullptr);
-            if (rc == FD_ERR_CAPACITY && cap < (1 << 20)) { cap *= 8; continue; }
+            // FD_ERR_CAPACITY: the output buffer was too small; counts[] holds every frame's count, so ONE retry fits.  (An overflow
+            // of a device-side buffer is FD_ERR_DEVICE_CAPACITY: a larger output buffer would not help, no retry.)
+            if (rc == FD_ERR_CAPACITY) {
+                const int need = *std::max_element(counts.begin(), counts.end());
+                if (need > cap) { cap = need; continue; }
+            }
             check(rc);
             break;
         }

@@ -24,7 +24,9 @@ enum {
     FD_ERR_RUNTIME = 2,          /* std::runtime_error */
     FD_ERR_LOGIC = 3,            /* std::logic_error */
     FD_ERR_HIP = 4,              /* HIP runtime failure / no device */
-    FD_ERR_CAPACITY = 5          /* caller buffer too small; required count is still reported */
+    FD_ERR_CAPACITY = 5,         /* caller buffer too small; required count is still reported */
+    FD_ERR_DEVICE_CAPACITY = 6   /* a device-side buffer of the library overflowed (FD_WVM_POS_CAP / FD_WVM_DEEP_CAP in the
+                                    environment raise them); a larger caller buffer does not help */
 };
 
 typedef struct fd_ctx fd_ctx;
@@ -72,6 +74,11 @@ int fd_pyramid_layer_download(fd_pyramid* p, int i, uint8_t* host_dst);
  * first_layer / last_layer: pyramid layer indices, -1 = open; step_layer >= 1 counts over the kept layers from the first one;
  * roi: {x, y, w, h} or NULL (none; an explicit roi argument of a call takes precedence).  Reset with (-1, -1, 1, NULL). */
 int fd_pyramid_select(fd_pyramid* p, int first_layer, int last_layer, int step_layer, const int* roi);
+/* ImagePyramid(shared_ptr<ImagePyramid> pyramid, minScale, maxScale) (ImagePyramid.cpp:100-104,200-235): a pyramid built on another
+ * one shares its layers but exposes only those inside its scale range; its getLayers() -- and therefore the layer step of
+ * DirectPyramidFeatureExtractor::extract (:99) -- starts at the first layer of that range.  first_layer / last_layer: pyramid layer
+ * indices of the range, -1 = open.  Applies to the window enumerations that follow; reset with (-1, -1). */
+int fd_pyramid_select_view(fd_pyramid* p, int first_layer, int last_layer);
 /* Window enumeration of DirectPyramidFeatureExtractor::extract(stepX, stepY, roi) (:75-123).
  * roi = {x,y,w,h} or NULL (whole image).  rows of out: {layerPos, lx, ly, cx, cy, ow, oh}. */
 int fd_pyramid_window_count(const fd_pyramid* p, int patch_w, int patch_h, int step_x, int step_y,

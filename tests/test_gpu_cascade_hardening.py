@@ -131,6 +131,10 @@ def test_rejection_profiles_production_equals_exact_equals_oracle(oracle, capi, 
     model = synth.make_wvm(7, n_per=14, n_levels=8, calib_patches=calib, **PROFILES[profile])
     po, pg = _pyr_pair(oracle, capi, ctx, frame640, **FF)
     lv, _ = _check_all_paths(oracle, capi, ctx, po, pg, model, profile)
+    wg = capi.Wvm(ctx, model)   # one handle, several runs: the phase plan settles, the positives stay
+    runs = [capi.detect_wvm(ctx, pg, wg, 1, 1, want_all=False)[0].tobytes() for _ in range(4)]
+    assert all(r == runs[0] for r in runs)
+    wg.close()
     deep = int((lv >= 16).sum())
     assert deep > 0.05 * len(lv), "the profile should send a sizeable share of the windows to stage B (%d of %d)" % (deep, len(lv))
     if profile == "group_end_only":
@@ -171,6 +175,9 @@ def test_stage_b_dense_equals_rect_lookup_kernels(capi, ctx, synth, oracle, fram
         finally:
             os.environ.pop("FD_WVM_STAGEB", None)
         res[mode] = (capi.detect_wvm(ctx, pg, wg, 1, 1, want_all=False)[0], capi.detect_wvm(ctx, pg, wg, 1, 1, want_all=True))
+        # the dense stage B adapts its phase plan and grids to what the previous runs of the handle saw: same result every time
+        for _ in range(3):
+            assert capi.detect_wvm(ctx, pg, wg, 1, 1, want_all=False)[0].tobytes() == res[mode][0].tobytes()
         wg.close()
     assert len(res["new"][0]) > 0
     assert res["new"][0].tobytes() == res["old"][0].tobytes()

@@ -341,6 +341,9 @@ def test_host_selftest_app(tmp_path, oracle, capi, ctx, synth, frame640):
         wins = wins[np.isin(wins[:, 0], sel)]
         geo = np.fromfile(str(tmp_path / ("view%d_geo.bin" % i)), np.int32).reshape(-1, 4)
         assert np.array_equal(geo, wins[:, 3:7]), i
+        # stepLayer = 2 counts from the view's first layer (views 1 and 2 start in the middle of the source pyramid)
+        geo2 = np.fromfile(str(tmp_path / ("view%d_step2_geo.bin" % i)), np.int32).reshape(-1, 4)
+        assert len(sel[::2]) < len(sel) and np.array_equal(geo2, wins[np.isin(wins[:, 0], sel[::2])][:, 3:7]), i
     # 2. layer sub-range (first, last, step 2) + ROI on the HOG chain: geometry and features
     ph = oracle.Pyramid(octave_layers=3, min_scale=0.2, max_scale=0.8)
     ph.set_layer_filter(1, bins=9)
