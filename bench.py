@@ -145,13 +145,25 @@ class Workload:
         return None
 
 
-def cascade_models():
+# Rejection profiles of the synthetic WVM (the rejection rate per level drives throughput).  "default" is the model of
+# the headline: 65 % of the calibration patches pass each filter until 32 are left (the cascade then stops rejecting, after ~13
+# filters).  "late": 90 % pass per filter down to ~0.1 % survivors -- the cascade keeps rejecting through ~65 filters and hands stage B
+# a large share of the windows.  "group": real thresholds only at the last filter of every level group (every 14th filter).
+WVM_PROFILES = {
+    "default": dict(ncalib=8000, kw={}),
+    "late": dict(ncalib=40000, kw=dict(pass_rate=0.9, min_survivors=40)),
+    "group": dict(ncalib=8000, kw=dict(reject_every=14)),
+}
+
+
+def cascade_models(profile="default"):
     """FaceFrontal WVM (280 filters) + RBF-SVM (1024 SV) calibrated on the config-1 frame; identical on every rank"""
     from featuredetection_amd import synth
     from oracle import pyoracle as O   # calibration patches only (bgr2gray of the calibration frame), untimed setup
     gray = O.bgr2gray(synth.make_frame(640, 480, seed=20260927))
-    calib = synth.random_patches(gray[::4, ::4].copy(), 20, 20, 8000, np.random.default_rng(1))
-    wvm_m = synth.make_wvm(7, calib_patches=calib)
+    prof = WVM_PROFILES[profile]
+    calib = synth.random_patches(gray[::4, ::4].copy(), 20, 20, prof["ncalib"], np.random.default_rng(1))
+    wvm_m = synth.make_wvm(7, calib_patches=calib, **prof["kw"])
     eq = synth.histeq64_np(synth.random_patches(gray[::4, ::4].copy(), 20, 20, 1400, np.random.default_rng(2)))
     svm_m = synth.make_svm_u8(3, eq, nsv=1024, calib=eq[1024:])
     return wvm_m, svm_m
@@ -164,6 +176,8 @@ class Cascade(Workload):
     records_cap = 1 << 17     # ~3.4 detections per frame, 4096 frames per step, a gather every 2 steps
     gather_every = 2
 
+    profile = "default"
+
     def __init__(self, env, W=640, H=480, frames_per_step=4096, nb=64, multi=True):   # ~50 ms per step: 20 steps are a second of GPU work
         import torch
         from featuredetection_amd import capi, synth
@@ -175,7 +189,7 @@ class Cascade(Workload):
         frames = [synth.make_frame(W, H, seed=20260927 + 1000 * env.rank + i) for i in range(self.NFR)]
         self.frames = frames
         self.dframes = [torch.from_numpy(f).to(env.dev) for f in frames]
-        self.wvm_m, self.svm_m = cascade_models()
+        self.wvm_m, self.svm_m = cascade_models(self.profile)
         kw = dict(inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))
         self.multi = multi and self.NB > 1
         npyr = 1 if self.multi else self.NB
@@ -203,6 +217,8 @@ class Cascade(Workload):
                                     "fd_detect_five_stage_frames (the frames of a call share one pyramid arena, one cascade run and one SVM launch)"
                                     if self.multi else "fd_detect_five_stage_batch"),
                            frames_per_step=self.FP, frames_per_call=self.NB, parallelism="image-shard dp%d" % env.world)
+        if self.profile != "default":
+            self.config["wvm_rejection_profile"] = "%s: %s" % (self.profile, WVM_PROFILES[self.profile]["kw"])
 
     def step(self, i):
         capi, NB = self.capi, self.NB
@@ -263,7 +279,7 @@ class Cascade(Workload):
         bytes_per_launch = nf * (self.layer_bytes + self.nwin * 16)
         ach = bytes_per_launch / (kms * 1e-3) / 1e9
         pm = pmc_record("cascade" if (self.W, self.H) == (640, 480) else "cascade_%dx%d" % (self.W, self.H), "k_wvm")
-        roof = dict(bound="hbm", kernel="k_wvm_prefilter + k_wvm_deepB (one cascade run over the %d frames of a call)" % nf, achieved=ach,
+        roof = dict(bound="hbm", kernel="k_wvm_prefilter + stage B (k_wvb_prepare / _chain / _sums / _exit): one cascade run over the %d frames of a call" % nf, achieved=ach,
                     peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=pm.get("hbm_bytes") if pm else None, kernel_ms=kms,
                     algorithmic="%d frames x (%d layer bytes + 16 B record x %d windows) per launch (SURVEY 8(d))" % (nf, self.layer_bytes, self.nwin))
         extra = {}
@@ -275,7 +291,7 @@ class Cascade(Workload):
         from oracle import pyoracle as O
         kw = dict(inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))
         wvm_m, svm_m, frames, nwin = self.wvm_m, self.svm_m, self.frames, self.nwin
-        if (self.W, self.H) != (640, 480):
+        if (self.W, self.H) != (640, 480) or self.profile != "default":
             return None
 
         def worker(budget, split):
@@ -305,6 +321,24 @@ class Cascade(Workload):
         return cpu_record(n1 * nwin, dt1, dict(update=tu, extract=te, classify=tc, total=dt1), un, dtn, nt,
                           "%d x 640x480 FaceFrontal five-stage frames (16,185 windows each) in %.1f s, oracle -O2, 1 thread; "
                           "n_thread: one frame stream per thread" % (n1, dt1), "Mpatches/s")
+
+
+class CascadeLate(Cascade):
+    """the headline workload with a WVM that keeps rejecting deep into the cascade (VERDICT r02 task 3, profile ii)"""
+    name = "cascade_late"
+    profile = "late"
+
+    def __init__(self, env, W=640, H=480, frames_per_step=1024, nb=64, multi=True):
+        super().__init__(env, W, H, frames_per_step, nb, multi)
+
+
+class CascadeGroup(Cascade):
+    """... with a WVM that rejects only at the end of every level group (profile iii)"""
+    name = "cascade_group"
+    profile = "group"
+
+    def __init__(self, env, W=640, H=480, frames_per_step=1024, nb=64, multi=True):
+        super().__init__(env, W, H, frames_per_step, nb, multi)
 
 
 class HogSvm(Workload):
@@ -788,7 +822,7 @@ def measure(wl, env, steps, warmup, gather_every, want_cpu):
     return rec
 
 
-WORKLOADS = dict(cascade=Cascade, hog_svm=HogSvm, ffp15=Ffp15, sdm=Sdm, rvm=Rvm, aggregated=Aggregated)
+WORKLOADS = dict(cascade=Cascade, cascade_late=CascadeLate, cascade_group=CascadeGroup, hog_svm=HogSvm, ffp15=Ffp15, sdm=Sdm, rvm=Rvm, aggregated=Aggregated)
 
 
 def free_port():
@@ -805,7 +839,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cascade", choices=sorted(WORKLOADS) + ["wvm"], help="headline workload (wvm = cascade)")
-    ap.add_argument("--also", default=None, help="comma-separated sub-records (default: hog_svm,ffp15,sdm when the headline is the "
+    ap.add_argument("--also", default=None, help="comma-separated sub-records (default: hog_svm,ffp15,sdm,cascade_late,cascade_group when the headline is the "
                                                  "default cascade; 'none' for none)")
     ap.add_argument("--gather-every", type=int, default=4)
     ap.add_argument("--size", default=None, help="frame size WxH of the headline workload (cascade, hog_svm, ffp15, rvm, aggregated)")
@@ -858,7 +892,7 @@ def main():
 
     also = args.also
     if also is None:
-        also = "hog_svm,ffp15,sdm" if (args.workload == "cascade" and not args.size) else "none"
+        also = "hog_svm,ffp15,sdm,cascade_late,cascade_group" if (args.workload == "cascade" and not args.size) else "none"
     also = [a for a in also.split(",") if a and a != "none"]
     want_cpu = not args.no_cpu_baseline
 

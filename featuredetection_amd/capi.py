@@ -136,6 +136,7 @@ _SIGS = {
     "fd_detect_five_stage_frames_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "fd_pyramid_select": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "fd_pyramid_select_view": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "fd_pyramid_set_gradient_blur": (C.c_int, [C.c_void_p, C.c_int]),
     "fd_pyramid_window_count": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]),
     "fd_pyramid_windows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
                                      C.POINTER(C.c_int64)]),
@@ -185,6 +186,7 @@ _SIGS = {
                                 C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
     "fd_extract_hog": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fd_hog_params), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "fd_gradient_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "fd_gradient_filter_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "fd_gradient_binning_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "fd_lbp_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "fd_hist_patch_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(fd_hist_params), C.c_void_p]),
@@ -286,9 +288,10 @@ class Pyramid:
         else:
             ctx.check(lib().fd_pyramid_create(ctx.h, octave_layers, min_scale, max_scale, C.byref(self.h)))
 
-    def set_layer_filter(self, kind, bins=9, signed_gradients=False, interpolate=False, grad_kernel=1, lbp_type=0):
+    def set_layer_filter(self, kind, bins=9, signed_gradients=False, interpolate=False, grad_kernel=1, lbp_type=0, blur_kernel=0):
         self.ctx.check(lib().fd_pyramid_set_layer_filter(self.h, kind, bins, int(signed_gradients), int(interpolate), grad_kernel,
                                                          lbp_type))
+        self.ctx.check(lib().fd_pyramid_set_gradient_blur(self.h, blur_kernel))
 
     def update(self, image):
         image = _c(image, np.uint8)
@@ -818,10 +821,13 @@ def detect_hog_svm(ctx, pyr, svm, hp, want_all=True, cap=1 << 20):
 
 
 # ---- stand-alone ImageFilter::applyTo forms
-def gradient_image(ctx, gray, ksize=1):
+def gradient_image(ctx, gray, ksize=1, blur=0):
     g = _c(gray, np.uint8)
     out = np.empty(g.shape + (2,), np.uint8)
-    ctx.check(lib().fd_gradient_image(ctx.h, _ptr(g), g.shape[1], g.shape[0], ksize, _ptr(out)))
+    if blur:
+        ctx.check(lib().fd_gradient_filter_image(ctx.h, _ptr(g), g.shape[1], g.shape[0], ksize, blur, _ptr(out)))
+    else:
+        ctx.check(lib().fd_gradient_image(ctx.h, _ptr(g), g.shape[1], g.shape[0], ksize, _ptr(out)))
     return out
 
 

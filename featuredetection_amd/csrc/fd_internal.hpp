@@ -319,6 +319,7 @@ struct HostLayer {
     uint32_t gray_off, filt_off;
     bool kept;
     int chain, depth;       // first-octave slot i and pyrDown depth j
+    uint32_t blur_off = 0;  // kept layers of a gradient pyramid with blurring: the blurred gray layer (GradientFilter.cpp:43-46)
 };
 
 struct WindowLayer {        // per kept layer, for the window enumeration of one (patch, step, roi)
@@ -334,6 +335,7 @@ struct fd_pyramid {
     size_t octl;
     double inc, minS, maxS;
     int filter_kind = FD_LAYER_NONE, bins = 9, signed_gradients = 0, interpolate = 0, grad_kernel = 1, lbp_type = 0;
+    int grad_blur = 0;               // GradientFilter's blurKernelSize (0: none); blurred copies of the kept layers live at blur_off
     int img_w = 0, img_h = 0;
     std::vector<HostLayer> all;      // every computed layer (kept or only a pyrDown source)
     std::vector<int> kept;           // indices into all, sorted by layer index

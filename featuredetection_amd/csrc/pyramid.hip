@@ -347,8 +347,70 @@ __global__ __launch_bounds__(256) void k_pyrdown_tiled(uint8_t* __restrict__ are
     }
 }
 
-// GradientFilter (Sobel ksize 1 or 3, scale 1/2 or 1/8, delta 127, 8U saturate + cvRound) fused
-// with the GradientBinningFilter 64K-entry look-up (index = gx | gy << 8).
+// cv::Sobel derivatives of GradientFilter (GradientFilter.cpp:16-59; taps of getDerivKernels, see oracle/orc_image.cpp): ksize 1, 3
+// take the short forms; 5, 7 and CV_SCHARR (-1) the separable sums.  Returns the scale 1 / 2^(2 ksize - 3) (1/2, 1/32 for ksize 1 /
+// Scharr).  Everything is an exact integer; 127 + scale * g is exact in float.
+__device__ __forceinline__ float grad_pair(const uint8_t* __restrict__ src, int w, int h, int x, int y, int ksize, int& gx, int& gy) {
+    if (ksize == 1 || ksize == 3) {
+        const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+        const int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
+        const uint8_t *S0 = src + (size_t)ym * w, *S1 = src + (size_t)y * w, *S2 = src + (size_t)yp * w;
+        if (ksize == 1) {
+            gx = S1[xp] - S1[xm];
+            gy = S2[x] - S0[x];
+            return 0.5f;
+        }
+        gx = (S0[xp] - S0[xm]) + 2 * (S1[xp] - S1[xm]) + (S2[xp] - S2[xm]);
+        gy = (S2[xm] - S0[xm]) + 2 * (S2[x] - S0[x]) + (S2[xp] - S0[xp]);
+        return 0.125f;
+    }
+    // derivative taps d (odd symmetry) and smoothing taps s (even symmetry), both of length n = 2 a + 1
+    int a, d1, d2, d3, s0, s1, s2, s3;
+    float scale;
+    if (ksize == 5) { a = 2; d1 = 2; d2 = 1; d3 = 0; s0 = 6; s1 = 4; s2 = 1; s3 = 0; scale = 1.f / 128.f; }
+    else if (ksize == 7) { a = 3; d1 = 5; d2 = 4; d3 = 1; s0 = 20; s1 = 15; s2 = 6; s3 = 1; scale = 1.f / 2048.f; }
+    else { a = 1; d1 = 1; d2 = 0; d3 = 0; s0 = 10; s1 = 3; s2 = 0; s3 = 0; scale = 1.f / 32.f; }   // CV_SCHARR
+    const int dk[4] = {0, d1, d2, d3}, sk[4] = {s0, s1, s2, s3};
+    int cx[7], cy[7];
+    for (int t = -a; t <= a; ++t) { cx[t + a] = reflect101(x + t, w); cy[t + a] = reflect101(y + t, h); }
+    gx = 0;
+    gy = 0;
+    for (int j = -a; j <= a; ++j) {
+        const uint8_t* S = src + (size_t)cy[j + a] * w;
+        int rd = 0, rs = 0;   // derivative / smoothing along x of row y + j
+        for (int i = 1; i <= a; ++i) {
+            const int hi = S[cx[a + i]], lo = S[cx[a - i]];
+            rd += dk[i] * (hi - lo);
+            rs += sk[i] * (hi + lo);
+        }
+        rs += sk[0] * S[cx[a]];
+        const int aj = j < 0 ? -j : j;
+        gx += sk[aj] * rd;
+        gy += (j < 0 ? -dk[aj] : dk[aj]) * rs;
+    }
+    return scale;
+}
+
+// cv::blur(image, Size(k, k)) of GradientFilter's optional blur (GradientFilter.cpp:43-46): normalised box filter, anchor k / 2,
+// BORDER_REFLECT_101, saturate_cast<uchar>(sum * (1.0 / (k * k))) in double
+__global__ void k_box_blur(uint8_t* __restrict__ arena, int k, FilterJobs jobs) {
+    const FilterJob jb = jobs.j[blockIdx.y];
+    const uint8_t* src = arena + jb.src_off;
+    uint8_t* dst = arena + jb.dst_off;
+    const int w = jb.w, h = jb.h, a = k / 2;
+    const double scale = 1.0 / ((double)k * k);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < w * h; i += gridDim.x * blockDim.x) {
+        const int y = i / w, x = i - y * w;
+        int s = 0;
+        for (int j = 0; j < k; ++j) {
+            const uint8_t* S = src + (size_t)reflect101(y - a + j, h) * w;
+            for (int q = 0; q < k; ++q) s += S[reflect101(x - a + q, w)];
+        }
+        dst[i] = (uint8_t)min(255, max(0, __double2int_rn((double)s * scale)));
+    }
+}
+
+// GradientFilter (delta 127, 8U saturate + cvRound) fused with the GradientBinningFilter 64K-entry look-up (index = gx | gy << 8).
 template <int E>  // bytes per LUT entry: 2 (one bin + weight) or 4 (two bins + weights)
 __global__ void k_gradbin(uint8_t* __restrict__ arena, const uint8_t* __restrict__ lut, int ksize, FilterJobs jobs) {
     const FilterJob jb = jobs.j[blockIdx.y];
@@ -357,20 +419,8 @@ __global__ void k_gradbin(uint8_t* __restrict__ arena, const uint8_t* __restrict
     const int w = jb.w, h = jb.h;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < w * h; i += gridDim.x * blockDim.x) {
         int y = i / w, x = i - y * w;
-        int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
-        int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
-        const uint8_t *S0 = src + (size_t)ym * w, *S1 = src + (size_t)y * w, *S2 = src + (size_t)yp * w;
         int gx, gy;
-        float scale;
-        if (ksize == 1) {
-            gx = S1[xp] - S1[xm];
-            gy = S2[x] - S0[x];
-            scale = 0.5f;
-        } else {
-            gx = (S0[xp] - S0[xm]) + 2 * (S1[xp] - S1[xm]) + (S2[xp] - S2[xm]);
-            gy = (S2[xm] - S0[xm]) + 2 * (S2[x] - S0[x]) + (S2[xp] - S0[xp]);
-            scale = 0.125f;
-        }
+        const float scale = grad_pair(src, w, h, x, y, ksize, gx, gy);
         // exact in float; cvRound = round-half-even; saturate to 0..255
         int vx = __float2int_rn(127.f + scale * gx), vy = __float2int_rn(127.f + scale * gy);
         vx = min(255, max(0, vx));
@@ -388,20 +438,8 @@ __global__ void k_gradbin(uint8_t* __restrict__ arena, const uint8_t* __restrict
 __global__ void k_gradient_image(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int w, int h, int ksize) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < w * h; i += gridDim.x * blockDim.x) {
         int y = i / w, x = i - y * w;
-        int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
-        int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
-        const uint8_t *S0 = src + (size_t)ym * w, *S1 = src + (size_t)y * w, *S2 = src + (size_t)yp * w;
         int gx, gy;
-        float scale;
-        if (ksize == 1) {
-            gx = S1[xp] - S1[xm];
-            gy = S2[x] - S0[x];
-            scale = 0.5f;
-        } else {
-            gx = (S0[xp] - S0[xm]) + 2 * (S1[xp] - S1[xm]) + (S2[xp] - S2[xm]);
-            gy = (S2[xm] - S0[xm]) + 2 * (S2[x] - S0[x]) + (S2[xp] - S0[xp]);
-            scale = 0.125f;
-        }
+        const float scale = grad_pair(src, w, h, x, y, ksize, gx, gy);
         int vx = __float2int_rn(127.f + scale * gx), vy = __float2int_rn(127.f + scale * gy);
         dst[2 * (size_t)i] = (uint8_t)min(255, max(0, vx));
         dst[2 * (size_t)i + 1] = (uint8_t)min(255, max(0, vy));
@@ -575,6 +613,10 @@ void build_layout(fd_pyramid* p, int W, int H) {
         else {
             L.filt_off = (uint32_t)off;
             off = align256(off + (size_t)L.w * L.h * fch);
+            if (p->filter_kind == FD_LAYER_GRADBIN && p->grad_blur > 0) {
+                L.blur_off = (uint32_t)off;
+                off = align256(off + (size_t)L.w * L.h);
+            }
         }
         p->kept.push_back((int)k);
     }
@@ -691,12 +733,17 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
         flush();
     }
     if (p->filter_kind != FD_LAYER_NONE) {
-        FilterJobs jobs;
+        FilterJobs jobs, bjobs;
         jobs.n = 0;
+        bjobs.n = 0;
         int maxpix = 0;
+        const bool blur = p->filter_kind == FD_LAYER_GRADBIN && p->grad_blur > 0;
         auto flush = [&]() {
             if (!jobs.n) return;
             dim3 g(grid_for(maxpix), jobs.n);
+            // GradientFilter's blur: gray layer -> blurred copy; the gradients are then taken of the copy
+            if (blur) hipLaunchKernelGGL(k_box_blur, g, dim3(256), 0, st, arena, p->grad_blur, bjobs);
+            bjobs.n = 0;
             if (p->filter_kind == FD_LAYER_GRADBIN) {
                 if (p->interpolate)
                     hipLaunchKernelGGL(k_gradbin<4>, g, dim3(256), 0, st, arena, p->lut.as<uint8_t>(), p->grad_kernel, jobs);
@@ -711,7 +758,11 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
         for (int k : p->kept) {
             const HostLayer& L = p->all[k];
             FilterJob& j = jobs.j[jobs.n++];
-            j.w = L.w; j.h = L.h; j.src_off = L.gray_off; j.dst_off = L.filt_off;
+            j.w = L.w; j.h = L.h; j.src_off = blur ? L.blur_off : L.gray_off; j.dst_off = L.filt_off;
+            if (blur) {
+                FilterJob& b = bjobs.j[bjobs.n++];
+                b.w = L.w; b.h = L.h; b.src_off = L.gray_off; b.dst_off = L.blur_off;
+            }
             maxpix = std::max(maxpix, L.w * L.h);
             if (jobs.n == MAXJ) flush();
         }
@@ -825,8 +876,8 @@ int fd_pyramid_set_layer_filter(fd_pyramid* p, int kind, int bins, int signed_gr
     return fd_guard(p ? p->ctx : nullptr, [&] {
         if (!p) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_set_layer_filter: NULL pyramid");
         if (kind == FD_LAYER_GRADBIN) {
-            if (grad_kernel != 1 && grad_kernel != 3)
-                FD_THROW(FD_ERR_INVALID_ARGUMENT, "GradientFilter: the kernel size must be 1 or 3 on this backend");
+            if (grad_kernel != 1 && grad_kernel != 3 && grad_kernel != 5 && grad_kernel != 7 && grad_kernel != FD_GRAD_SCHARR)
+                FD_THROW(FD_ERR_INVALID_ARGUMENT, "GradientFilter: the kernel size must be 1, 3, 5, 7 or CV_SCHARR");
             if (bins < 1 || bins > 255) FD_THROW(FD_ERR_INVALID_ARGUMENT, "GradientBinningFilter: bins must be in 1..255");
             std::vector<uint8_t> lut;
             build_gradient_lut(bins, signed_gradients != 0, interpolate != 0, lut);
@@ -886,6 +937,18 @@ int fd_pyramid_select(fd_pyramid* p, int first_layer, int last_layer, int step_l
         p->sel_step = step_layer;
         p->sel_has_roi = roi != nullptr;
         if (roi) std::memcpy(p->sel_roi, roi, sizeof(p->sel_roi));
+    });
+}
+
+int fd_pyramid_set_gradient_blur(fd_pyramid* p, int blur_kernel) {
+    return fd_guard(p ? p->ctx : nullptr, [&] {
+        if (!p) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_set_gradient_blur: NULL pyramid");
+        if (blur_kernel < 0 || blur_kernel > 31) FD_THROW(FD_ERR_INVALID_ARGUMENT, "GradientFilter: the blur kernel size must be in 0..31");
+        if (blur_kernel != p->grad_blur) {
+            p->grad_blur = blur_kernel;
+            p->all.clear();  // force a new layout
+            p->img_w = p->img_h = 0;
+        }
     });
 }
 
@@ -1009,21 +1072,34 @@ int fd_greyworld(fd_ctx* ctx, const uint8_t* bgr, int w, int h, uint8_t* dst, in
 }
 
 // ---- stand-alone ImageFilter::applyTo(Mat) forms of the layer filters (ImageFilter.hpp:18-57) on one host image ----------
-int fd_gradient_image(fd_ctx* ctx, const uint8_t* gray, int w, int h, int grad_kernel, uint8_t* dst2ch) {
+int fd_gradient_filter_image(fd_ctx* ctx, const uint8_t* gray, int w, int h, int grad_kernel, int blur_kernel, uint8_t* dst2ch) {
     return fd_guard(ctx, [&] {
-        if (!ctx || !gray || !dst2ch || w < 1 || h < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_gradient_image: bad argument");
-        if (grad_kernel != 1 && grad_kernel != 3) FD_THROW(FD_ERR_INVALID_ARGUMENT, "GradientFilter: the kernel size must be 1 or 3 on this backend");
+        if (!ctx || !gray || !dst2ch || w < 1 || h < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_gradient_filter_image: bad argument");
+        if (grad_kernel != 1 && grad_kernel != 3 && grad_kernel != 5 && grad_kernel != 7 && grad_kernel != FD_GRAD_SCHARR)
+            FD_THROW(FD_ERR_INVALID_ARGUMENT, "GradientFilter: the kernel size must be 1, 3, 5, 7 or CV_SCHARR");
+        if (blur_kernel < 0 || blur_kernel > 31) FD_THROW(FD_ERR_INVALID_ARGUMENT, "GradientFilter: the blur kernel size must be in 0..31");
         HIP_CHECK(hipSetDevice(ctx->device));
-        const size_t n = (size_t)w * h;
-        DevBuf in, out;
-        in.reserve(n);
+        const size_t n = (size_t)w * h, boff = (n + 255) & ~(size_t)255;
+        DevBuf in, out;   // in: [gray | blurred]: k_box_blur addresses both through one base pointer
+        in.reserve(boff + n);
         out.reserve(2 * n);
         HIP_CHECK(hipMemcpyAsync(in.p, gray, n, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_gradient_image, dim3(grid_for((int)n)), dim3(256), 0, ctx->stream, in.as<uint8_t>(), out.as<uint8_t>(), w, h, grad_kernel);
+        const uint8_t* src = in.as<uint8_t>();
+        if (blur_kernel > 0) {
+            FilterJobs jobs;
+            jobs.n = 1;
+            jobs.j[0].w = w; jobs.j[0].h = h; jobs.j[0].src_off = 0; jobs.j[0].dst_off = (uint32_t)boff;
+            hipLaunchKernelGGL(k_box_blur, dim3(grid_for((int)n), 1), dim3(256), 0, ctx->stream, in.as<uint8_t>(), blur_kernel, jobs);
+            src += boff;
+        }
+        hipLaunchKernelGGL(k_gradient_image, dim3(grid_for((int)n)), dim3(256), 0, ctx->stream, src, out.as<uint8_t>(), w, h, grad_kernel);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(dst2ch, out.p, 2 * n, hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
     });
+}
+int fd_gradient_image(fd_ctx* ctx, const uint8_t* gray, int w, int h, int grad_kernel, uint8_t* dst2ch) {
+    return fd_gradient_filter_image(ctx, gray, w, h, grad_kernel, 0, dst2ch);
 }
 
 int fd_gradient_binning_image(fd_ctx* ctx, const uint8_t* grad2ch, int w, int h, int bins, int signed_gradients, int interpolate, uint8_t* dst) {

@@ -189,6 +189,8 @@ struct fd_wvm {
     int64_t sbDeep = -1, sbCutAlive[WVB_MAXPHASE] = {-1, -1, -1, -1};
     uint32_t sbCutMask = ~0u, sbRuns = 0;
     int sbPlanN = 0, sbPlanCut[WVB_MAXPHASE] = {};   // cuts of the run in flight
+    int64_t sbGrown = 0;             // capacity a queue overflow made the handle grow to
+    std::shared_ptr<void> relaunch;   // WvbRelaunch: what fd_wvm_finish needs to run stage B again with a larger state (queue overflow)
     ~fd_wvm() { if (done) (void)hipEventDestroy(done); if (tailDone) (void)hipEventDestroy(tailDone); if (prep) (void)hipEventDestroy(prep); }
 };
 
@@ -425,6 +427,13 @@ struct CascadeOut {
     // the next run -- no copy, no memset on the stream, the event can be recorded straight after stage B
     unsigned int* host_count = nullptr;
     unsigned int* done_blocks = nullptr;
+};
+
+struct WvbRelaunch {   // see fd_wvm::relaunch
+    const uint8_t* arena;
+    WinTable wt;
+    CascadeOut o;
+    hipStream_t st;
 };
 
 // end of a stage-B kernel: see CascadeOut::host_count
@@ -2011,11 +2020,17 @@ static void wvb_build(fd_wvm* m, const fd_wvm_model* md) {
 }
 
 // State buffers of a stage-B run over at most `total` queued windows (grow only); fills m->sb and m->deepCap.
-static void wvb_reserve(fd_wvm* m, int64_t total) {
-    int64_t capEnv = 0;   // read per run (the tests provoke the overflow report)
-    if (const char* e = getenv("FD_WVM_DEEP_CAP")) if (atoll(e) > 0) capEnv = (int64_t)atoll(e);
+// Capacity: min(total, 2^18) windows, never less than what the handle already holds or than minCap (fd_wvm_finish grows the state when
+// a run queued more); FD_WVM_DEEP_CAP fixes it (then an overflow is an error).
+static int64_t wvb_cap_env() {   // read per run (the tests provoke the overflow report)
+    if (const char* e = getenv("FD_WVM_DEEP_CAP")) if (atoll(e) > 0) return (int64_t)atoll(e);
+    return 0;
+}
+static void wvb_reserve(fd_wvm* m, int64_t total, int64_t minCap = 0) {
+    const int64_t capEnv = wvb_cap_env();
     const WvbDev& mv = m->wvb;
-    const int64_t cap = std::max<int64_t>(64, std::min<int64_t>(total, capEnv ? capEnv : (int64_t)1 << 18));
+    int64_t cap = capEnv ? capEnv : std::max<int64_t>(std::max<int64_t>(minCap, m->sbGrown), (int64_t)1 << 18);
+    cap = std::max<int64_t>(64, std::min<int64_t>(total, cap));
     const int64_t tilesCap = (cap + 63) / 64;
     WvbState& s = m->sb;
     for (int i = 0; i < 2; ++i) {
@@ -2245,6 +2260,11 @@ static bool wvm_launch_head(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const WinTab
 static void wvm_launch_tail(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm* m, const WinTable& wt, const WinTable& wtq, const WvmLaunch& L, bool skipA,
                             bool time_kernel) {
     launch_cascade<false>(ctx, st, wt.total, m, p->arena.as<uint8_t>(), wtq, L.o, skipA);
+    if (m->sbRun) {
+        if (!m->relaunch) m->relaunch = std::shared_ptr<void>(new WvbRelaunch(), [](void* q) { delete static_cast<WvbRelaunch*>(q); });
+        WvbRelaunch* R = static_cast<WvbRelaunch*>(m->relaunch.get());
+        R->arena = p->arena.as<uint8_t>(); R->wt = wtq; R->o = L.o; R->st = st;
+    }
     if (time_kernel) HIP_CHECK(hipEventRecord(ctx->ev1, st));
     HIP_CHECK(hipGetLastError());
     if (!L.zc) {
@@ -2338,6 +2358,32 @@ void fd_wvm_finish(fd_ctx* ctx, fd_wvm* m, WvmRun& run) {
         ctx->last_kernel = "k_wvm_cascade";
     }
     if (m->zcRun && cnt == 0xffffffffu) FD_THROW(FD_ERR_HIP, "WVM stage B did not deliver its positive count");
+    if (m->sbRun && (int64_t)hraw[0].wid_hi > m->deepCap && !wvb_cap_env() && m->relaunch) {
+        // More windows reached stage B than its state holds (header word 1 = queue length; stage B took the first deepCap of them).
+        // The queue is intact: grow the state and run stage B again over all of it (the pyramid must not have been updated in between,
+        // which the entry points guarantee).  One extra run per growth; the handle keeps the larger state.
+        const int64_t deep = (int64_t)hraw[0].wid_hi;
+        WvbRelaunch* R = static_cast<WvbRelaunch*>(m->relaunch.get());
+        m->sbGrown = deep + deep / 8 + 64;
+        wvb_reserve(m, run.total, m->sbGrown);
+        if (deep <= m->deepCap) {
+            const uint32_t hdr[4] = {0u, (uint32_t)deep, 0u, 0u};   // positives 0, queue length, pre-filter queue, retired workgroups
+            HIP_CHECK(hipMemcpyAsync(m->pos.p, hdr, sizeof(hdr), hipMemcpyHostToDevice, R->st));
+            HIP_CHECK(hipMemsetAsync(m->sbCnt.p, 0, 64, R->st));
+            if (m->zcRun) *m->h_pos.as<unsigned int>() = 0xffffffffu;
+            m->sbDeep = deep;
+            launch_cascade<false>(ctx, R->st, run.total, m, R->arena, R->wt, R->o, true);   // stage B only
+            HIP_CHECK(hipGetLastError());
+            if (!m->zcRun) {
+                const size_t firstChunk = (size_t)std::min<int64_t>(m->pos_cap, WVM_FIRST_CHUNK);
+                HIP_CHECK(hipMemcpyAsync(m->h_pos.p, m->pos.p, sizeof(PosRec) * (firstChunk + 1), hipMemcpyDeviceToHost, R->st));
+            }
+            HIP_CHECK(hipEventRecord(m->done, R->st));
+            run.timed = false;
+            fd_wvm_finish(ctx, m, run);
+            return;
+        }
+    }
     if ((int64_t)cnt > m->pos_cap)
         FD_THROW(FD_ERR_DEVICE_CAPACITY, "WVM produced %u positives, device buffer holds %lld (set FD_WVM_POS_CAP)", cnt, (long long)m->pos_cap);
     if (m->zcRun) m->hdrClean = true;   // the last stage-B workgroup has cleared the device header
@@ -2617,7 +2663,7 @@ int fd_wvm_eval_batch(fd_ctx* ctx, const fd_wvm* wvm_, const uint8_t* patches, i
         HIP_CHECK(hipMemsetAsync(m->counter.p, 0, 16, st));
         m->sbRun = m->wvbOk && m->dev.numUsed > WVM_LCAP;
         if (m->sbRun) {
-            wvb_reserve(m, n);
+            wvb_reserve(m, n, n);   // explicit patches: every one of them may reach stage B
             HIP_CHECK(hipMemsetAsync(m->sbCnt.p, 0, 64, st));
             m->hdrClean = false;   // the phase counters are left dirty: the next detect run clears them (and the header) first
         }

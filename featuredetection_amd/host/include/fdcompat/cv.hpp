@@ -16,6 +16,7 @@
 #define CV_8U 0
 #define CV_32S 4
 #define CV_32F 5
+#define CV_SCHARR -1   /* cv::Sobel kernel size constant used by GradientFilter (GradientFilter.cpp:17) */
 #define CV_64F 6
 #define CV_CN_SHIFT 3
 #define CV_MAKETYPE(depth, cn) (((depth) & 7) + (((cn)-1) << CV_CN_SHIFT))

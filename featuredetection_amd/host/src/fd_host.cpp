@@ -71,16 +71,15 @@ Mat GreyWorldNormalizationFilter::applyTo(const Mat& image, Mat& filtered) const
 }
 
 GradientFilter::GradientFilter(int kernelSize, int blurKernelSize) : kernelSize(kernelSize), blurKernelSize(blurKernelSize) {
-    if (kernelSize != 1 && kernelSize != 3)
-        throw std::invalid_argument("GradientFilter: the kernel size must be 1 or 3 on this backend (reference: 1, 3, 5, 7 or CV_SCHARR)");
-    if (blurKernelSize != 0) throw std::invalid_argument("GradientFilter: blurring is not available on this backend");
+    if (kernelSize != 1 && kernelSize != 3 && kernelSize != 5 && kernelSize != 7 && kernelSize != CV_SCHARR)
+        throw std::invalid_argument("GradientFilter: the kernel size must be 1, 3, 5, 7 or CV_SCHARR");   // GradientFilter.cpp:16-19
 }
 // ---- stand-alone ImageFilter::applyTo(const Mat&) forms (ImageFilter.hpp:18-57): one kernel launch per Mat through the C ABI
 Mat GradientFilter::applyTo(const Mat& image, Mat& filtered) const {
     if (image.type() != CV_8UC1) throw std::invalid_argument("GradientFilter: the image must be of type CV_8UC1");
     Mat src = contiguous(image);
     Mat dst(src.rows, src.cols, CV_8UC2);
-    check(fd_gradient_image(context(), src.data, src.cols, src.rows, kernelSize, dst.data));
+    check(fd_gradient_filter_image(context(), src.data, src.cols, src.rows, kernelSize, blurKernelSize > 0 ? blurKernelSize : 0, dst.data));
     filtered = dst;
     return filtered;
 }
@@ -332,8 +331,11 @@ void ImagePyramid::addLayerFilter(const shared_ptr<ImageFilter>& filter) {
 }
 void ImagePyramid::applyLayerFilterConfig() {
     if (gradient && binning)
+    {
         check(fd_pyramid_set_layer_filter(handle, FD_LAYER_GRADBIN, (int)binning->bins, binning->signedGradients, binning->interpolate,
                                           gradient->kernelSize, 0));
+        check(fd_pyramid_set_gradient_blur(handle, gradient->blurKernelSize > 0 ? gradient->blurKernelSize : 0));
+    }
     else if (lbp)
         check(fd_pyramid_set_layer_filter(handle, FD_LAYER_LBP, 0, 0, 0, 1, (int)lbp->type));
     version = Version();

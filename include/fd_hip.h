@@ -51,13 +51,17 @@ int fd_pyramid_create_inc(fd_ctx* ctx, double incremental_scale, double min_scal
 void fd_pyramid_destroy(fd_pyramid* p);
 /* Layer filters (ImagePyramid::addLayerFilter, ImagePyramid.cpp:112-114):
  *  FD_LAYER_NONE       gray layers (u8, 1 channel)
- *  FD_LAYER_GRADBIN    GradientFilter(grad_kernel, blur=0) -> GradientBinningFilter(bins, signed, interpolate)
- *                      (GradientFilter.cpp:38-59, GradientBinningFilter.cpp:18-93); 2 or 4 channels
+ *  FD_LAYER_GRADBIN    GradientFilter(grad_kernel, blur) -> GradientBinningFilter(bins, signed, interpolate)
+ *                      (GradientFilter.cpp:16-59, GradientBinningFilter.cpp:18-93); 2 or 4 channels.
+ *                      grad_kernel: 1, 3, 5, 7 or FD_GRAD_SCHARR (the reference's CV_SCHARR = -1);
+ *                      blur: fd_pyramid_set_gradient_blur (blurKernelSize of the reference's constructor, default 0 = none)
  *  FD_LAYER_LBP        LbpFilter(lbp_type) (LbpFilter.cpp:56-85); 1 channel */
 enum { FD_LAYER_NONE = 0, FD_LAYER_GRADBIN = 1, FD_LAYER_LBP = 2 };
 enum { FD_LBP8 = 0, FD_LBP8_UNIFORM = 1, FD_LBP4 = 2, FD_LBP4_ROTATED = 3 };
+enum { FD_GRAD_SCHARR = -1 };
 int fd_pyramid_set_layer_filter(fd_pyramid* p, int kind, int bins, int signed_gradients, int interpolate,
                                 int grad_kernel, int lbp_type);
+int fd_pyramid_set_gradient_blur(fd_pyramid* p, int blur_kernel);
 /* channels 1 (gray) or 3 (BGR, interleaved).  is_device != 0: image already resident in HBM. */
 int fd_pyramid_update(fd_pyramid* p, const uint8_t* image, int width, int height, int channels, int is_device);
 int fd_pyramid_octave_layer_count(const fd_pyramid* p);
@@ -93,11 +97,14 @@ int fd_histeq64_batch(fd_ctx* ctx, const uint8_t* patches, int64_t n, int w, int
 
 /* Stand-alone ImageFilter::applyTo(const Mat&) forms (ImageFilter.hpp:18-57) of the filters the detection kernels fuse into the
  * pyramid / feature kernels; host buffers in, host buffers out.
- *  fd_gradient_image          GradientFilter(grad_kernel 1|3, no blur) (GradientFilter.cpp:38-59): CV_8UC1 -> CV_8UC2 (x, y)
+ *  fd_gradient_image          GradientFilter(grad_kernel 1|3|5|7|FD_GRAD_SCHARR, no blur) (GradientFilter.cpp:16-59): CV_8UC1 -> CV_8UC2 (x, y)
  *  fd_gradient_binning_image  GradientBinningFilter(bins, signed, interpolate) (GradientBinningFilter.cpp:62-93): CV_8UC2 -> CV_8UC2
  *                             (bin, weight) or CV_8UC4 (two bins + weights)
  *  fd_lbp_image               LbpFilter(type) (LbpFilter.cpp:56-85): CV_8UC1 -> CV_8UC1 codes */
 int fd_gradient_image(fd_ctx* ctx, const uint8_t* gray, int width, int height, int grad_kernel, uint8_t* dst2ch);
+/* ... with GradientFilter's blurKernelSize (cv::blur before the derivatives, GradientFilter.cpp:43-46; 0 = none).
+ * grad_kernel: 1, 3, 5, 7 or FD_GRAD_SCHARR (CV_SCHARR), as in the reference */
+int fd_gradient_filter_image(fd_ctx* ctx, const uint8_t* gray, int width, int height, int grad_kernel, int blur_kernel, uint8_t* dst2ch);
 int fd_gradient_binning_image(fd_ctx* ctx, const uint8_t* grad2ch, int width, int height, int bins, int signed_gradients,
                               int interpolate, uint8_t* dst);
 int fd_lbp_image(fd_ctx* ctx, const uint8_t* gray, int width, int height, int lbp_type, uint8_t* dst);

@@ -145,31 +145,52 @@ static void box_blur_u8(const uchar* src, int w, int h, int k, uchar* dst) {
         }
 }
 
-// GradientFilter.cpp:38-59: optional blur, cv::Sobel(dx) and cv::Sobel(dy) with ddepth = 8U,
-// scale = 1/2^(2k-3) (k=1 -> 1/2), delta = 127, merged into 2 channels (x first).
-// All intermediate values are exact in float, so out = saturate(cvRound(127 + scale*deriv)).
+// GradientFilter.cpp:16-59: optional blur, cv::Sobel(dx) and cv::Sobel(dy) with ddepth = 8U, delta = 127, merged into 2 channels
+// (x first).  cv::Sobel = sepFilter2D with the kernels of getDerivKernels (OpenCV imgproc/deriv.cpp, getSobelKernels /
+// getScharrKernels): derivative taps d and smoothing taps s,
+//   ksize 1: d = [-1 0 1], s = [1]               scale 1/2      (GradientFilter::getScale: 1 / 2^(2 ksize - 3); 1/2 for ksize 1)
+//   ksize 3: d = [-1 0 1], s = [1 2 1]           scale 1/8
+//   ksize 5: d = [-1 -2 0 2 1], s = [1 4 6 4 1]  scale 1/128
+//   ksize 7: d = [-1 -4 -5 0 5 4 1], s = [1 6 15 20 15 6 1]   scale 1/2048
+//   CV_SCHARR (-1): d = [-1 0 1], s = [3 10 3]   scale 1/32
+// (the scale is folded into one of the float kernels, cv::Sobel).  BORDER_REFLECT_101.  Every scale is a power of two and every
+// partial sum fits 24 bits, so sepFilter2D's float arithmetic is exact whatever its order: out = saturate(cvRound(127 + scale * D))
+// with the integer 2-D derivative D.
 void gradient_filter(const uchar* src, int w, int h, int ksize, int blur, uchar* dst2) {
-    if (ksize != 1 && ksize != 3)
-        throw std::invalid_argument("oracle gradient_filter: only kernel sizes 1 and 3 are restated");
+    static const int D1[3] = {-1, 0, 1}, S1[1] = {1}, S3[3] = {1, 2, 1}, D5[5] = {-1, -2, 0, 2, 1}, S5[5] = {1, 4, 6, 4, 1},
+                     D7[7] = {-1, -4, -5, 0, 5, 4, 1}, S7[7] = {1, 6, 15, 20, 15, 6, 1}, SS[3] = {3, 10, 3};
+    const int *dk, *sk;
+    int nd, ns;
+    double scale;
+    switch (ksize) {
+        case 1: dk = D1; nd = 3; sk = S1; ns = 1; scale = 1.0 / 2; break;
+        case 3: dk = D1; nd = 3; sk = S3; ns = 3; scale = 1.0 / 8; break;
+        case 5: dk = D5; nd = 5; sk = S5; ns = 5; scale = 1.0 / 128; break;
+        case 7: dk = D7; nd = 7; sk = S7; ns = 7; scale = 1.0 / 2048; break;
+        case -1: dk = D1; nd = 3; sk = SS; ns = 3; scale = 1.0 / 32; break;   // CV_SCHARR
+        default: throw std::invalid_argument("GradientFilter: the kernel size must be 1, 3, 5, 7 or CV_SCHARR");
+    }
     std::vector<uchar> tmp;
     if (blur > 0) {
         tmp.resize((size_t)w * h);
         box_blur_u8(src, w, h, blur, tmp.data());
         src = tmp.data();
     }
-    const double scale = ksize == 1 ? 0.5 : 1.0 / 8;
+    const int ad = nd / 2, as = ns / 2;
     for (int y = 0; y < h; ++y) {
-        int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
-        const uchar *S0 = src + (size_t)ym * w, *S1 = src + (size_t)y * w, *S2 = src + (size_t)yp * w;
         for (int x = 0; x < w; ++x) {
-            int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
-            int gx, gy;
-            if (ksize == 1) {
-                gx = S1[xp] - S1[xm];
-                gy = S2[x] - S0[x];
-            } else {
-                gx = (S0[xp] - S0[xm]) + 2 * (S1[xp] - S1[xm]) + (S2[xp] - S2[xm]);
-                gy = (S2[xm] - S0[xm]) + 2 * (S2[x] - S0[x]) + (S2[xp] - S0[xp]);
+            int gx = 0, gy = 0;
+            for (int j = 0; j < ns; ++j) {       // gx: derivative along x, smoothing along y
+                const uchar* S = src + (size_t)reflect101(y + j - as, h) * w;
+                int r = 0;
+                for (int i = 0; i < nd; ++i) r += dk[i] * S[reflect101(x + i - ad, w)];
+                gx += sk[j] * r;
+            }
+            for (int j = 0; j < nd; ++j) {       // gy: derivative along y, smoothing along x
+                const uchar* S = src + (size_t)reflect101(y + j - ad, h) * w;
+                int r = 0;
+                for (int i = 0; i < ns; ++i) r += sk[i] * S[reflect101(x + i - as, w)];
+                gy += dk[j] * r;
             }
             dst2[2 * ((size_t)y * w + x)] = sat_u8(127.0 + scale * gx);
             dst2[2 * ((size_t)y * w + x) + 1] = sat_u8(127.0 + scale * gy);

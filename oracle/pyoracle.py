@@ -192,11 +192,11 @@ def whitening(patch, alpha=1.0, cutoff=0.390625):
     return out
 
 
-def gradient_filter(gray, ksize=1):
-    """GradientFilter::applyTo: CV_8UC1 -> CV_8UC2"""
+def gradient_filter(gray, ksize=1, blur=0):
+    """GradientFilter::applyTo: CV_8UC1 -> CV_8UC2; ksize 1, 3, 5, 7 or -1 (CV_SCHARR), blur = blurKernelSize (0: none)"""
     g = _c(gray, np.uint8)
     out = np.empty(g.shape + (2,), np.uint8)
-    lib().orc_gradient_filter(_p(g), g.shape[1], g.shape[0], ksize, 0, _p(out))
+    lib().orc_gradient_filter(_p(g), g.shape[1], g.shape[0], ksize, blur, _p(out))
     return out
 
 

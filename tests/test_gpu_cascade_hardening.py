@@ -161,6 +161,39 @@ def test_stage_b_queue_overflow_is_reported(oracle, capi, ctx, synth, frame640):
     wg.close(); pg.close()
 
 
+def test_stage_b_state_grows_with_the_queue(oracle, capi, ctx, synth, small_models):
+    """A model whose first 27 filters reject nothing sends every window of a 24-frame call to stage B (388 k > the default state of
+    2^18 windows): the library grows the state and runs stage B again -- same detections as frame-by-frame calls."""
+    _, svm = small_models
+    frames = [synth.make_frame(640, 480, seed=900 + i) for i in range(24)]
+    gray = oracle.bgr2gray(frames[0])
+    calib = synth.random_patches(gray[::4, ::4].copy(), 20, 20, 4000, np.random.default_rng(4))
+    model = synth.make_wvm(19, n_per=14, n_levels=2, calib_patches=calib)
+    po = oracle.Pyramid(**FF)
+    po.update(frames[0])
+    t = np.full(28, -3e38, np.float32)
+    model["thresholds"] = t
+    _, lv0, fo0 = oracle.sliding_wvm(po, oracle.Wvm(model), 1, 1)
+    assert (lv0 == 27).all()
+    t[27] = np.quantile(fo0, 0.99)   # ~160 WVM positives per frame, everything else leaves at the very last filter
+    wg, sg = capi.Wvm(ctx, model), capi.Svm(ctx, svm)
+    single = capi.Pyramid(ctx, **FF)
+    ref = []
+    for f in frames[:3] + frames[-2:]:
+        single.update(f)
+        ref.append(capi.detect_five_stage(ctx, single, wg, sg, cap=1024))
+    multi = capi.Pyramid(ctx, **FF)
+    multi.set_frames(len(frames))
+    multi.update_frames(images=frames)
+    for _ in range(2):   # the first call grows the state, the second finds it large enough
+        res = capi.detect_five_stage_frames(ctx, multi, wg, sg, len(frames), cap=1024)
+        got = res[:3] + res[-2:]
+        assert sum(int(s[0]) for _, s in got) > 0
+        for (d, s), (dr, sr) in zip(got, ref):
+            assert np.array_equal(s, sr) and d.tobytes() == dr.tobytes()
+    wg.close(); sg.close(); single.close(); multi.close()
+
+
 def test_stage_b_dense_equals_rect_lookup_kernels(capi, ctx, synth, oracle, frame640):
     """FD_WVM_STAGEB=old keeps the rect-lookup stage-B kernels (k_wvm_deepB): both must deliver the same positive records"""
     import bench

@@ -6,7 +6,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("ksize", [1, 3])
+@pytest.mark.parametrize("ksize", [1, 3, 5, 7, -1])
 def test_gradient_and_binning_images(oracle, capi, ctx, frame640, ksize):
     """GradientFilter(ksize) -> CV_8UC2, GradientBinningFilter(bins, signed, interpolate) -> CV_8UC2 / CV_8UC4: bit-exact, and the
     two stand-alone filters chained equal the fused layer filter of the pyramid."""
@@ -24,6 +24,13 @@ def test_gradient_and_binning_images(oracle, capi, ctx, frame640, ksize):
     pg.update(gray)
     assert np.array_equal(pg.layer(0), capi.gradient_binning_image(ctx, gg, 9))
     pg.close()
+    # GradientFilter's blurKernelSize (cv::blur before the derivatives), odd and even box sizes, also on a tiny image where the
+    # reflected border is wider than the image
+    for blur in (3, 4, 5):
+        assert np.array_equal(capi.gradient_image(ctx, gray, ksize, blur), oracle.gradient_filter(gray, ksize, blur)), blur
+    tiny = gray[:3, :5].copy()
+    assert np.array_equal(capi.gradient_image(ctx, tiny, ksize, 3), oracle.gradient_filter(tiny, ksize, 3))
+    assert np.array_equal(capi.gradient_image(ctx, tiny, ksize), oracle.gradient_filter(tiny, ksize))
 
 
 @pytest.mark.parametrize("lbp_type", [0, 1, 2, 3])

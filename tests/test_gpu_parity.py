@@ -60,7 +60,9 @@ def test_window_enumeration(oracle, capi, ctx, frame640, roi):
 def test_layer_filters_bit_exact(oracle, capi, ctx, frame640):
     kw = dict(octave_layers=3, min_scale=0.2, max_scale=1.0)
     for filt in (dict(kind=1, bins=9), dict(kind=1, bins=8, signed_gradients=True), dict(kind=1, bins=9, interpolate=True),
-                 dict(kind=1, bins=9, grad_kernel=3), dict(kind=2, lbp_type=0), dict(kind=2, lbp_type=1), dict(kind=2, lbp_type=2),
+                 dict(kind=1, bins=9, grad_kernel=3), dict(kind=1, bins=9, grad_kernel=5), dict(kind=1, bins=12, grad_kernel=7, signed_gradients=True),
+                 dict(kind=1, bins=9, grad_kernel=-1, interpolate=True), dict(kind=1, bins=9, grad_kernel=3, blur_kernel=3),
+                 dict(kind=1, bins=9, grad_kernel=1, blur_kernel=4), dict(kind=2, lbp_type=0), dict(kind=2, lbp_type=1), dict(kind=2, lbp_type=2),
                  dict(kind=2, lbp_type=3)):
         po = oracle.Pyramid(**kw)
         po.set_layer_filter(**filt)
