@@ -136,6 +136,14 @@ _SIGS = {
     "fd_detect_five_stage_frames_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "fd_pyramid_select": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "fd_pyramid_select_view": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "fd_dist_owner": (C.c_int, [C.c_int64, C.c_int]),
+    "fd_dist_unique_id": (C.c_int, [C.c_void_p]),
+    "fd_dist_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "fd_dist_destroy": (None, [C.c_void_p]),
+    "fd_dist_rank": (C.c_int, [C.c_void_p]),
+    "fd_dist_world": (C.c_int, [C.c_void_p]),
+    "fd_pack_records": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_int, C.c_void_p]),
+    "fd_dist_gather_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "fd_pyramid_set_gradient_blur": (C.c_int, [C.c_void_p, C.c_int]),
     "fd_pyramid_window_count": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]),
     "fd_pyramid_windows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
@@ -408,6 +416,47 @@ class Wvm:
     def close(self):
         if self.h:
             lib().fd_wvm_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def pack_records(image_id, detector_id, dets):
+    """fd_pack_records: fd_detection array -> float64 [n, 8] {image, detector, cx, cy, w, h, score, probability} (host only)"""
+    dets = np.ascontiguousarray(dets, DET_DTYPE)
+    out = np.zeros((len(dets), 8), np.float64)
+    rc = lib().fd_pack_records(int(image_id), int(detector_id), _ptr(dets), len(dets), _ptr(out))
+    if rc != FD_OK:
+        raise FdError(rc, "fd_pack_records")
+    return out
+
+
+class Dist:
+    """fd_dist_*: image-shard data parallelism, one process per GPU; gather() = one ncclAllGather of the detection records"""
+
+    def __init__(self, ctx, rank=0, world=1, unique_id=None):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        idb = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id)) if unique_id is not None else None
+        ctx.check(lib().fd_dist_init(ctx.h, rank, world, idb, C.byref(self.h)))
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        rc = lib().fd_dist_unique_id(buf)
+        if rc != FD_OK:
+            raise FdError(rc, "fd_dist_unique_id (librccl)")
+        return bytes(buf)
+
+    def gather(self, local, cap):
+        local = np.ascontiguousarray(local, np.float64).reshape(-1, 8)
+        world = lib().fd_dist_world(self.h)
+        out = np.zeros((world * cap, 8), np.float64)
+        n, tr = C.c_int64(), C.c_int()
+        self.ctx.check(lib().fd_dist_gather_records(self.h, _ptr(local), len(local), cap, _ptr(out), len(out), C.byref(n), C.byref(tr)))
+        return out[:n.value], bool(tr.value)
+
+    def close(self):
+        if self.h:
+            lib().fd_dist_destroy(self.h)
             self.h = C.c_void_p()
 
 

@@ -1,0 +1,168 @@
+// featuredetection_amd/csrc/dist.hip -- image-shard data parallelism in the product (north_star: "images shard
+// embarrassingly across the 8 GPUs of one node with a single RCCL gather of detections over xGMI").
+//
+// One process per GPU.  Image i belongs to rank i mod world (fd_dist_owner); models are replicated; there is NO data-path
+// collective.  The only exchange is fd_dist_gather_records: every rank contributes its detection records of the images it owned since
+// the last gather, one ncclAllGather of a fixed-stride padded buffer (row 0 = count) on the context's stream, and every rank
+// receives all records ordered by (image, detector, original order) -- the order a single process would have produced them in.
+// Payloads are KBs to MBs, i.e. latency-bound; callers batch many images per gather.
+//
+// librccl.so is loaded on first use (dlopen): a single-GPU process never pays for it, and libfd_hip.so has no link-time dependency.
+#include "fd_internal.hpp"
+#include <dlfcn.h>
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <rccl/rccl.h>
+
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* n : names)
+            if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!r.lib) return;
+        r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+        r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+    });
+    if (!r.lib || !r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy)
+        FD_THROW(FD_ERR_RUNTIME, "librccl.so is not available: %s", r.lib ? "missing symbols" : dlerror());
+    return r;
+}
+
+#define RCCL_CHECK(expr)                                                                                          \
+    do {                                                                                                          \
+        ncclResult_t _r = (expr);                                                                                 \
+        if (_r != ncclSuccess) FD_THROW(FD_ERR_RUNTIME, "%s failed: %s", #expr, rccl().GetErrorString ? rccl().GetErrorString(_r) : "?"); \
+    } while (0)
+
+}  // namespace
+
+struct fd_dist {
+    fd_ctx* ctx = nullptr;
+    int rank = 0, world = 1;
+    ncclComm_t comm = nullptr;
+    DevBuf dsend, drecv;
+    HostBuf hsend, hrecv;
+};
+
+static_assert(sizeof(fd_record) == 64, "fd_record is eight doubles");
+static_assert(sizeof(ncclUniqueId) == FD_DIST_ID_BYTES, "fd_dist id size");
+
+extern "C" {
+
+int fd_dist_owner(int64_t image_index, int world) { return world > 0 ? (int)(image_index % world) : 0; }
+
+int fd_dist_unique_id(uint8_t* id) {
+    return fd_guard(nullptr, [&] {
+        if (!id) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_dist_unique_id: NULL argument");
+        ncclUniqueId u;
+        RCCL_CHECK(rccl().GetUniqueId(&u));
+        std::memcpy(id, &u, sizeof(u));
+    });
+}
+
+int fd_dist_init(fd_ctx* ctx, int rank, int world, const uint8_t* id, fd_dist** out) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !out || world < 1 || rank < 0 || rank >= world) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_dist_init: bad argument");
+        if (world > 1 && !id) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_dist_init: the communicator id is needed for more than one rank");
+        std::unique_ptr<fd_dist> d(new fd_dist());
+        d->ctx = ctx;
+        d->rank = rank;
+        d->world = world;
+        if (world > 1) {   // a single rank gathers from itself: no communicator, no librccl
+            HIP_CHECK(hipSetDevice(ctx->device));
+            ncclUniqueId u;
+            std::memcpy(&u, id, sizeof(u));
+            RCCL_CHECK(rccl().CommInitRank(&d->comm, world, u, rank));
+        }
+        *out = d.release();
+    });
+}
+
+void fd_dist_destroy(fd_dist* d) {
+    if (!d) return;
+    if (d->comm) (void)rccl().CommDestroy(d->comm);
+    delete d;
+}
+
+int fd_dist_rank(const fd_dist* d) { return d ? d->rank : 0; }
+int fd_dist_world(const fd_dist* d) { return d ? d->world : 1; }
+
+// {image, detector, cx, cy, w, h, score, probability} of every detection, as doubles (ints and the fp32 score are exact in fp64)
+int fd_pack_records(int64_t image_id, int32_t detector_id, const fd_detection* dets, int n, fd_record* out) {
+    if (n < 0 || (n > 0 && (!dets || !out))) return FD_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < n; ++i) {
+        fd_record& r = out[i];
+        r.image = (double)image_id; r.detector = (double)detector_id;
+        r.cx = dets[i].cx; r.cy = dets[i].cy; r.w = dets[i].w; r.h = dets[i].h;
+        r.score = (double)dets[i].score; r.probability = dets[i].probability;
+    }
+    return FD_OK;
+}
+
+int fd_dist_gather_records(fd_dist* d, const fd_record* local, int n_local, int cap_per_rank, fd_record* all, int64_t all_cap, int64_t* n_all,
+                           int* truncated) {
+    return fd_guard(d ? d->ctx : nullptr, [&] {
+        if (!d || n_local < 0 || cap_per_rank < 1 || (n_local > 0 && !local) || !n_all) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_dist_gather_records: bad argument");
+        const int W = d->world;
+        const size_t rows = (size_t)cap_per_rank + 1, bytes = rows * sizeof(fd_record);
+        const int n = std::min(n_local, cap_per_rank);
+        d->hsend.reserve(bytes);
+        d->hrecv.reserve(bytes * (size_t)W);
+        fd_record* hs = d->hsend.as<fd_record>();
+        std::memset(hs, 0, sizeof(fd_record));
+        hs[0].image = (double)n_local;   // row 0: how many records this rank had (more than cap: the receivers flag the truncation)
+        if (n) std::memcpy(hs + 1, local, sizeof(fd_record) * (size_t)n);
+        const fd_record* hr = hs;
+        const size_t used = sizeof(fd_record) * ((size_t)n + 1);
+        if (W > 1) {
+            HIP_CHECK(hipSetDevice(d->ctx->device));
+            hipStream_t st = d->ctx->stream;
+            d->dsend.reserve(bytes);
+            d->drecv.reserve(bytes * (size_t)W);
+            // only the used prefix travels over PCIe; the collective moves the fixed-stride buffers (every rank the same size)
+            HIP_CHECK(hipMemcpyAsync(d->dsend.p, hs, used, hipMemcpyHostToDevice, st));
+            RCCL_CHECK(rccl().AllGather(d->dsend.p, d->drecv.p, bytes, ncclUint8, d->comm, st));
+            HIP_CHECK(hipMemcpyAsync(d->hrecv.p, d->drecv.p, bytes * (size_t)W, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            hr = d->hrecv.as<fd_record>();
+        }
+        // records of all ranks, ordered by (image, detector, original order): stable sort of (key, position)
+        std::vector<const fd_record*> ptrs;
+        bool trunc = false;
+        for (int r = 0; r < W; ++r) {
+            const fd_record* part = hr + (size_t)r * rows;
+            const int64_t cnt = (int64_t)part[0].image;
+            trunc = trunc || cnt > cap_per_rank;
+            const int64_t take = std::min<int64_t>(cnt, cap_per_rank);
+            for (int64_t i = 0; i < take; ++i) ptrs.push_back(part + 1 + i);
+        }
+        std::stable_sort(ptrs.begin(), ptrs.end(), [](const fd_record* a, const fd_record* b) {
+            return a->image != b->image ? a->image < b->image : a->detector < b->detector;
+        });
+        *n_all = (int64_t)ptrs.size();
+        if (truncated) *truncated = trunc ? 1 : 0;
+        if (all) {
+            if ((int64_t)ptrs.size() > all_cap) FD_THROW(FD_ERR_CAPACITY, "fd_dist_gather_records: %zu records, capacity %lld", ptrs.size(), (long long)all_cap);
+            for (size_t i = 0; i < ptrs.size(); ++i) all[i] = *ptrs[i];
+        }
+    });
+}
+
+}  // extern "C"

@@ -3,10 +3,18 @@
 // `detectors` node exactly like ffpDetectApp/*.cfg (type fiveStageCascade | single), a binary PPM/PGM
 // image, runs every face detector on the whole image and every feature detector inside the first face
 // box, and prints one line per detection:  <detector> <landmark> x y w h probability
+//
+// --gpus N (several images): image-shard data parallelism.  The process starts N copies of itself, one per GPU
+// (FD_DEVICE = rank); rank r runs the face detectors on the images i with i mod N == r, all ranks exchange their detection records with
+// ONE RCCL all-gather (fd_dist_gather_records) and rank 0 prints them in image order -- the same lines a single process prints.
+#include <sys/wait.h>
+#include <unistd.h>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <algorithm>
 #include <unordered_map>
 #include "detection/detection_all.hpp"
 
@@ -34,11 +42,55 @@ static cv::Mat read_pnm(const string& path) {
     return img;
 }
 
+// --gpus N: start one process per GPU and wait for them (the communicator id travels in a file)
+static int launch_ranks(int gpus, int argc, char** argv) {
+    uint8_t id[FD_DIST_ID_BYTES] = {0};
+    if (gpus > 1 && fd_dist_unique_id(id) != FD_OK) { std::fprintf(stderr, "runtime error: librccl.so is not available\n"); return 1; }
+    char path[] = "/tmp/fd_dist_id_XXXXXX";
+    const int fdesc = mkstemp(path);
+    if (fdesc < 0 || write(fdesc, id, sizeof(id)) != (ssize_t)sizeof(id)) { std::fprintf(stderr, "runtime error: cannot write %s\n", path); return 1; }
+    close(fdesc);
+    std::vector<pid_t> kids;
+    for (int r = 0; r < gpus; ++r) {
+        const pid_t pid = fork();
+        if (pid == 0) {
+            setenv("FD_DEVICE", std::to_string(r).c_str(), 1);
+            setenv("FD_DIST_RANK", std::to_string(r).c_str(), 1);
+            setenv("FD_DIST_WORLD", std::to_string(gpus).c_str(), 1);
+            setenv("FD_DIST_ID_FILE", path, 1);
+            execv("/proc/self/exe", argv);
+            std::perror("execv");
+            _exit(127);
+        }
+        kids.push_back(pid);
+    }
+    int rc = 0;
+    for (pid_t k : kids) {
+        int st = 0;
+        waitpid(k, &st, 0);
+        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = 1;
+    }
+    unlink(path);
+    (void)argc;
+    return rc;
+}
+
 int main(int argc, char** argv) {
-    if (argc < 3) {
-        std::fprintf(stderr, "usage: %s <config.cfg> <image.ppm|pgm> [more images of a sequence ...]\n", argv[0]);
+    int gpus = 0;
+    std::vector<char*> args;   // argv without --gpus N
+    for (int a = 0; a < argc; ++a) {
+        if (string(argv[a]) == "--gpus" && a + 1 < argc) { gpus = std::atoi(argv[++a]); continue; }
+        args.push_back(argv[a]);
+    }
+    if ((int)args.size() < 3 || (gpus != 0 && (gpus < 1 || gpus > 64 || args.size() < 4))) {
+        std::fprintf(stderr, "usage: %s [--gpus N] <config.cfg> <image.ppm|pgm> [more images of a sequence ...]\n", argv[0]);
         return 2;
     }
+    const char* rankEnv = std::getenv("FD_DIST_RANK");
+    if (gpus > 0 && !rankEnv) return launch_ranks(gpus, argc, argv);
+    const int rank = rankEnv ? std::atoi(rankEnv) : 0, world = rankEnv ? std::atoi(std::getenv("FD_DIST_WORLD")) : 1;
+    argc = (int)args.size();
+    argv = args.data();
     try {
         ptree pt;
         boost::property_tree::read_info(string(argv[1]), pt);
@@ -104,6 +156,55 @@ int main(int argc, char** argv) {
             }
             det->landmark = landmarkName;
             (landmarkName == "face" ? faceDetectors : featureDetectors).emplace_back(kv.first, det);
+        }
+        if (argc > 3 && rankEnv) {   // --gpus N: this rank's shard of the images, one gather of the detection records
+            uint8_t id[FD_DIST_ID_BYTES] = {0};
+            {
+                std::ifstream f(std::getenv("FD_DIST_ID_FILE"), std::ios::binary);
+                f.read((char*)id, sizeof(id));
+                if (!f) throw std::runtime_error("cannot read the communicator id");
+            }
+            fd_dist* dist = nullptr;
+            fdhost::check(fd_dist_init(fdhost::context(), rank, world, id, &dist));
+            std::vector<cv::Mat> imgs;
+            std::vector<int64_t> ids;
+            const int nimg = argc - 2;
+            for (int i = 0; i < nimg; ++i)
+                if (fd_dist_owner(i, world) == rank) { imgs.push_back(read_pnm(argv[2 + i])); ids.push_back(i); }
+            std::vector<fd_record> local;
+            for (size_t di = 0; di < faceDetectors.size(); ++di) {
+                auto five = std::dynamic_pointer_cast<FiveStageSlidingWindowDetector>(faceDetectors[di].second);
+                if (!five) throw std::invalid_argument("several images need a fiveStageCascade face detector");
+                const auto res = imgs.empty() ? std::vector<std::vector<shared_ptr<ClassifiedPatch>>>() : five->detectFrames(imgs);
+                for (size_t f = 0; f < res.size(); ++f)
+                    for (const auto& p : res[f]) {
+                        const auto patch = p->getPatch();
+                        fd_record r = {(double)ids[f], (double)di, (double)patch->getX(), (double)patch->getY(), (double)patch->getWidth(),
+                                       (double)patch->getHeight(), 0.0, p->getProbability()};
+                        local.push_back(r);
+                    }
+            }
+            const int cap = 1 << 16;
+            std::vector<fd_record> all((size_t)cap * world);
+            int64_t nall = 0;
+            int truncated = 0;
+            fdhost::check(fd_dist_gather_records(dist, local.data(), (int)local.size(), cap, all.data(), (int64_t)all.size(), &nall, &truncated));
+            fd_dist_destroy(dist);
+            if (truncated) throw std::runtime_error("more than 65536 detections on one rank");
+            if (rank == 0) {
+                // the single-process order: detector by detector, frames ascending inside a detector
+                std::stable_sort(all.begin(), all.begin() + nall, [](const fd_record& a, const fd_record& b) {
+                    return a.detector != b.detector ? a.detector < b.detector : a.image < b.image;
+                });
+                for (int64_t i = 0; i < nall; ++i) {
+                    const fd_record& r = all[(size_t)i];
+                    const auto& d = faceDetectors[(size_t)r.detector];
+                    const int w = (int)r.w, h = (int)r.h;
+                    std::printf("frame %d %s %s %d %d %d %d %.17g\n", (int)r.image, d.first.c_str(), d.second->landmark.c_str(), (int)r.cx - w / 2,
+                                (int)r.cy - h / 2, w, h, r.probability);
+                }
+            }
+            return 0;
         }
         if (argc > 3) {   // several images: the face detectors on all of them at once (detectFrames), one line per detection
             std::vector<cv::Mat> imgs;

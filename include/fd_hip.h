@@ -441,6 +441,31 @@ int fd_sdm_fit_batch(fd_ctx* ctx, const fd_sdm* m, const uint8_t* gray_images, i
 int fd_sdm_optimize_batch(fd_ctx* ctx, const fd_sdm* m, const uint8_t* gray_images, int width, int height, int batch,
                           int images_on_device, float* shapes_inout, int32_t* status_out);
 
+/* ---- image-shard data parallelism (north_star: "images shard embarrassingly across the 8 GPUs of one node with a single RCCL gather
+ * of detections over xGMI").  One process per GPU; image i belongs to rank i mod world; models are replicated; no data-path
+ * collective.  The reference has no counterpart (it is single-threaded, ffpDetectApp.cpp:548-659 loops over the images of a
+ * source); a maintainer binds these around that loop (ffp_detect_app --gpus N).
+ *   fd_dist_unique_id   rank 0 creates the communicator id (ncclGetUniqueId, 128 bytes) and hands it to the other ranks by any means
+ *   fd_dist_init        joins the communicator on the context's device (ncclCommInitRank); world 1 needs no id and no librccl
+ *   fd_pack_records     fd_detection -> fixed-stride records {image, detector, cx, cy, w, h, score, probability} (all exact in fp64)
+ *   fd_dist_gather_records  ONE ncclAllGather of a padded [cap_per_rank + 1] record buffer per rank (row 0 = count) on the context's
+ *                       stream; every rank receives the records of all ranks ordered by (image, detector, original order).
+ *                       *truncated != 0: a rank had more than cap_per_rank records (the surplus was dropped). */
+#define FD_DIST_ID_BYTES 128
+typedef struct fd_dist fd_dist;
+typedef struct fd_record {
+    double image, detector, cx, cy, w, h, score, probability;
+} fd_record;
+int fd_dist_owner(int64_t image_index, int world);
+int fd_dist_unique_id(uint8_t* id /* FD_DIST_ID_BYTES */);
+int fd_dist_init(fd_ctx* ctx, int rank, int world, const uint8_t* id, fd_dist** out);
+void fd_dist_destroy(fd_dist* d);
+int fd_dist_rank(const fd_dist* d);
+int fd_dist_world(const fd_dist* d);
+int fd_pack_records(int64_t image_id, int32_t detector_id, const fd_detection* dets, int n, fd_record* out);
+int fd_dist_gather_records(fd_dist* d, const fd_record* local, int n_local, int cap_per_rank, fd_record* all, int64_t all_cap,
+                           int64_t* n_all, int* truncated);
+
 #ifdef __cplusplus
 }
 #endif

@@ -143,3 +143,18 @@ def test_gather_single_process_and_truncation():
     big = np.zeros((10, parallel.RECORD_FIELDS))
     allr, trunc = parallel.gather_records(big, cap=4)
     assert trunc and len(allr) == 4
+
+
+def test_native_record_packing_equals_the_python_twin():
+    """fd_pack_records / fd_dist_owner (the C ABI's multi-GPU entry points, csrc/dist.hip) against parallel.pack_records /
+    shard_indices on the committed fd_detection fixture: identical bytes, identical ownership (no GPU needed for these two)."""
+    from featuredetection_amd import capi, parallel
+    nimages = 9
+    for i in range(nimages):
+        d = _golden_image_detections(i, nimages)
+        a = capi.pack_records(i, 3, d)
+        b = parallel.pack_records(np.full(len(d), i), np.full(len(d), 3), d)
+        assert a.shape == b.shape and a.tobytes() == b.tobytes()
+    for world in (1, 2, 4, 8):
+        for r in range(world):
+            assert parallel.shard_indices(37, r, world) == [i for i in range(37) if capi.lib().fd_dist_owner(i, world) == r]

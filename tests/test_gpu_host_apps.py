@@ -107,6 +107,32 @@ def test_ffp_detect_app_image_sequence_detect_frames(tmp_path, oracle, synth, fr
             assert [int(v) for v in g[4:8]] == [d["cx"] - d["w"] // 2, d["cy"] - d["h"] // 2, d["w"], d["h"]]
             assert float(g[8]) == d["prob"]
     assert total > 0 and len(got) == total
+    # --gpus 1: the image-shard path (one process per GPU, records through fd_dist_gather_records) prints the same lines
+    out1 = _run([app, "--gpus", "1", str(tmp_path / "face.cfg")] + [str(tmp_path / ("frame%d.ppm" % i)) for i in range(len(frames))])
+    assert out1 == out
+
+
+def test_native_gather_world1_equals_python_twin(capi, ctx):
+    """fd_dist_* on one GPU: the communicator id comes from librccl (ncclGetUniqueId), a world of one gathers from itself and orders
+    the records like parallel.gather_records (image, detector, original order); truncation is reported"""
+    from featuredetection_amd import parallel
+    uid = capi.Dist.unique_id()
+    assert len(uid) == 128 and any(uid)
+    d = capi.Dist(ctx, 0, 1, uid)
+    rng = np.random.default_rng(5)
+    local = np.zeros((300, 8))
+    local[:, 0] = rng.integers(0, 12, 300)   # image ids out of order
+    local[:, 1] = rng.integers(0, 3, 300)
+    local[:, 2:] = rng.normal(size=(300, 6))
+    got, tr = d.gather(local, 512)
+    ref, tr2 = parallel.gather_records(local, 512)
+    assert not tr and not tr2 and got.tobytes() == ref.tobytes()
+    got, tr = d.gather(local, 100)
+    ref, tr2 = parallel.gather_records(local, 100)
+    assert tr and tr2 and got.tobytes() == ref.tobytes()
+    got, tr = d.gather(np.zeros((0, 8)), 16)
+    assert len(got) == 0 and not tr
+    d.close()
 
 
 SINGLE_CFG = """detectors
