@@ -611,32 +611,23 @@ class Sdm(Workload):
         self.dimgs = torch.from_numpy(imgs).to(env.dev)
         self.model = synth.make_sdm(9, L=68, S=4)
         self.sdm = capi.Sdm(env.ctx, self.model)
-        # fd_sdm_fit_batch blocks until a batch's shapes are on the host; three host threads, each with its own context and model handle
-        # (contexts are not shared between threads), keep a second batch's kernels queued meanwhile (FD_BENCH_SDM_THREADS)
-        self.nthreads = max(1, int(os.environ.get("FD_BENCH_SDM_THREADS", "3")))
-        self.extra = []
-        for _ in range(self.nthreads - 1):
-            c_ = capi.Context(env.local_rank)
-            self.extra.append((c_, capi.Sdm(c_, self.model)))
-        self.pool = None
-        if self.nthreads > 1:
-            from concurrent.futures import ThreadPoolExecutor
-            self.pool = ThreadPoolExecutor(self.nthreads - 1)
+        # fd_sdm_fit_batch_begin / _end: ONE host thread keeps a few batches queued (each ticket has its own scratch set, consecutive
+        # tickets alternate between two streams); FD_BENCH_SDM_INFLIGHT sets how many
+        self.inflight = max(1, int(os.environ.get("FD_BENCH_SDM_INFLIGHT", "3")))
         self.boxes = np.array([[48, 48, 160, 160]] * self.B, np.int32)
         self.metric = "SDM iters/s (x1e6): 68 landmarks, HOG at each point + linear regressor, 4 cascade steps, batch of 256 face crops"
         self.config = dict(workload="config 4: 256 gray 256x256 crops, 68 landmarks, 4 cascade steps, adaptive VlHog 3x3x31 per landmark + regressor "
-                                    "18973x136 (f64 MFMA); fd_sdm_fit_batch, shapes delivered per batch, %d host threads" % self.nthreads, batches_per_step=self.FP,
-                           parallelism="face-shard dp%d" % env.world)
+                                    "18973x136 (f64 MFMA); fd_sdm_fit_batch_begin/_end, shapes delivered per batch, one host thread, %d batches in flight" % self.inflight,
+                           batches_per_step=self.FP, parallelism="face-shard dp%d" % env.world)
 
     def step(self, i):
-        def run(sdm, n):
-            for _ in range(n):
-                sdm.fit_device(self.dimgs.data_ptr(), self.W, self.H, self.B, self.boxes)
-        share = self.FP // self.nthreads
-        futs = [self.pool.submit(run, sd, share) for _, sd in self.extra] if self.pool else []
-        run(self.sdm, self.FP - share * len(futs))
-        for f in futs:
-            f.result()
+        flying = []
+        for _ in range(self.FP):
+            if len(flying) == self.inflight:
+                self.sdm.fit_end(flying.pop(0))
+            flying.append(self.sdm.fit_device_begin(self.dimgs.data_ptr(), self.W, self.H, self.B, self.boxes))
+        for t in flying:
+            self.sdm.fit_end(t)
         return self.B * 4 * self.FP, []
 
     def kernel_probe(self):

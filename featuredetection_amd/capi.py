@@ -209,6 +209,8 @@ _SIGS = {
                                      C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     "fd_sdm_fit_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                    C.c_void_p]),
+    "fd_sdm_fit_batch_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "fd_sdm_fit_batch_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fd_sdm_optimize_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }
 
@@ -980,6 +982,28 @@ class Sdm:
         out = np.empty((B, 2 * self.L), np.float32)
         st = np.zeros(B, np.int32)
         self.ctx.check(lib().fd_sdm_fit_batch(self.ctx.h, self.h, C.c_void_p(dev_ptr), W, H, B, _ptr(fb), 1, _ptr(out), _ptr(st)))
+        return out, st
+
+    def fit_device_begin(self, dev_ptr, W, H, B, face_boxes):
+        """fd_sdm_fit_batch_begin on images resident in HBM: returns a ticket for fit_end; several can be in flight"""
+        fb = _c(face_boxes, np.int32).reshape(B, 4)
+        t = C.c_void_p()
+        self.ctx.check(lib().fd_sdm_fit_batch_begin(self.ctx.h, self.h, C.c_void_p(dev_ptr), W, H, B, _ptr(fb), 1, C.byref(t)))
+        return (t, B, fb)
+
+    def fit_begin(self, gray_images, face_boxes):
+        imgs = _c(gray_images, np.uint8)
+        B, H, W = imgs.shape
+        fb = _c(face_boxes, np.int32).reshape(B, 4)
+        t = C.c_void_p()
+        self.ctx.check(lib().fd_sdm_fit_batch_begin(self.ctx.h, self.h, _ptr(imgs), W, H, B, _ptr(fb), 0, C.byref(t)))
+        return (t, B, (fb, imgs))   # host images stay alive with the ticket
+
+    def fit_end(self, ticket):
+        t, B, _keep = ticket
+        out = np.empty((B, 2 * self.L), np.float32)
+        st = np.zeros(B, np.int32)
+        self.ctx.check(lib().fd_sdm_fit_batch_end(self.ctx.h, t, _ptr(out), _ptr(st)))
         return out, st
 
     def close(self):

@@ -533,13 +533,27 @@ __global__ void k_sdm_update(float* __restrict__ shapes, const double* __restric
 
 }  // namespace
 
+// device + pinned scratch of one batch in flight (fd_sdm_fit_batch_begin / _end: several batches of one model can be queued)
+struct SdmScratch {
+    DevBuf images, shapes, origin, dist, status, desc, partial;
+    HostBuf hshapes, hstatus;
+    hipEvent_t done = nullptr;
+    ~SdmScratch() { if (done) (void)hipEventDestroy(done); }
+};
 struct fd_sdm {
     fd_ctx* ctx;
     int L, S, variant;
     std::vector<float> mean;
     std::vector<int> Rrows;
     std::vector<std::unique_ptr<DevBuf>> R;
-    DevBuf images, shapes, origin, dist, status, desc, partial;
+    std::vector<std::unique_ptr<SdmScratch>> idle;   // scratch sets not in use (handles are single-threaded: no lock)
+    unsigned int launches = 0;
+};
+struct fd_sdm_ticket {
+    fd_sdm* m = nullptr;
+    std::unique_ptr<SdmScratch> s;
+    int B = 0;
+    bool timed = false;
 };
 
 namespace {
@@ -663,68 +677,79 @@ int fd_sdm_descriptors(fd_ctx* ctx, const uint8_t* gray, int W, int H, const flo
     });
 }
 
-static void sdm_optimize(fd_ctx* ctx, fd_sdm* m, const uint8_t* gray_images, int W, int H, int B, int images_on_device,
-                         std::vector<float>& shapes, int32_t* status_out) {
+// Queues one batch (S cascade steps: prepare -> descriptors -> regress -> update, then the read-back into the scratch set's pinned
+// buffers) on `st` and records sc.done; nothing waits.  sc.hshapes holds the start shapes on entry.
+static void sdm_launch(fd_ctx* ctx, fd_sdm* m, SdmScratch& sc, hipStream_t st, const uint8_t* gray_images, int W, int H, int B, int images_on_device,
+                       bool timeIt) {
     HIP_CHECK(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
     const int L = m->L, N = 2 * L;
     const uint8_t* dimg = gray_images;
     if (!images_on_device) {
-        m->images.reserve((size_t)W * H * B);
-        HIP_CHECK(hipMemcpyAsync(m->images.p, gray_images, (size_t)W * H * B, hipMemcpyHostToDevice, st));
-        dimg = m->images.as<uint8_t>();
+        sc.images.reserve((size_t)W * H * B);
+        HIP_CHECK(hipMemcpyAsync(sc.images.p, gray_images, (size_t)W * H * B, hipMemcpyHostToDevice, st));
+        dimg = sc.images.as<uint8_t>();
     }
     DescParams p;
     fill_desc_params(p, W, H, L, true, m->variant, 3, 10, 9, 30);
     p.image_stride = (int64_t)W * H;
     const int F = L * p.len;
     const int nchunks = (F + RG_KCHUNK - 1) / RG_KCHUNK;
-    m->shapes.reserve(sizeof(float) * shapes.size());
-    m->origin.reserve(sizeof(int32_t) * 4 * (size_t)B * L);
-    m->dist.reserve(sizeof(float) * B);
-    m->status.reserve(sizeof(int32_t) * B);
-    m->desc.reserve(sizeof(float) * (size_t)B * F);
-    m->partial.reserve(sizeof(double) * (size_t)nchunks * B * N);
-    HIP_CHECK(hipMemcpyAsync(m->shapes.p, shapes.data(), sizeof(float) * shapes.size(), hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemsetAsync(m->status.p, 0, sizeof(int32_t) * B, st));
+    const size_t nshape = (size_t)B * N;
+    sc.shapes.reserve(sizeof(float) * nshape);
+    sc.origin.reserve(sizeof(int32_t) * 4 * (size_t)B * L);
+    sc.dist.reserve(sizeof(float) * B);
+    sc.status.reserve(sizeof(int32_t) * B);
+    sc.desc.reserve(sizeof(float) * (size_t)B * F);
+    sc.partial.reserve(sizeof(double) * (size_t)nchunks * B * N);
+    sc.hstatus.reserve(sizeof(int32_t) * B);
+    HIP_CHECK(hipMemcpyAsync(sc.shapes.p, sc.hshapes.p, sizeof(float) * nshape, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemsetAsync(sc.status.p, 0, sizeof(int32_t) * B, st));
     const int64_t nitems = (int64_t)B * L;
     for (int step = 0; step < m->S; ++step) {
         const double stepFactor = 1 / (1 + std::exp((double)((step + 1) - m->S)));  // :226, double on the host
-        hipLaunchKernelGGL(k_sdm_prepare, dim3((B * L + 255) / 256), dim3(256), 0, st, m->shapes.as<float>(), B, L, W, H, 1, 0, 1 << 20, stepFactor,
-                           m->origin.as<int32_t>(), m->dist.as<float>(), m->status.as<int32_t>());
+        hipLaunchKernelGGL(k_sdm_prepare, dim3((B * L + 255) / 256), dim3(256), 0, st, sc.shapes.as<float>(), B, L, W, H, 1, 0, 1 << 20, stepFactor,
+                           sc.origin.as<int32_t>(), sc.dist.as<float>(), sc.status.as<int32_t>());
         int grid = (int)std::min<int64_t>((nitems + 1) / 2, (int64_t)ctx->num_cus * descriptor_blocks_per_cu(p));
         if (grid >= 16) grid &= ~7;   // a multiple of the 8 XCDs: the kernel then keeps every face on one XCD
-        const bool timeThis = ctx->kernel_timing && step + 1 == m->S;   // fd_hip_bench.h: the last step's descriptor launch
+        const bool timeThis = timeIt && step + 1 == m->S;   // fd_hip_bench.h: the last step's descriptor launch
         if (timeThis) HIP_CHECK(hipEventRecord(ctx->ev0, st));
-        launch_descriptors(dim3(grid), st, dimg, m->origin.as<int32_t>(), p, nitems, m->desc.as<float>(), (int64_t)F);
+        launch_descriptors(dim3(grid), st, dimg, sc.origin.as<int32_t>(), p, nitems, sc.desc.as<float>(), (int64_t)F);
         if (timeThis) HIP_CHECK(hipEventRecord(ctx->ev1, st));
         const float* R = m->R[step]->as<float>();
-        hipLaunchKernelGGL(k_sdm_regress, dim3((B + 15) / 16, ((N + 15) / 16 + RG_NT - 1) / RG_NT, nchunks), dim3(64), 0, st, m->desc.as<float>(), B, F, R, N,
-                           m->partial.as<double>(), nchunks);
-        hipLaunchKernelGGL(k_sdm_update, dim3((B * N + 255) / 256), dim3(256), 0, st, m->shapes.as<float>(), m->partial.as<double>(), nchunks,
-                           R + (size_t)F * N, m->dist.as<float>(), B, N);
+        hipLaunchKernelGGL(k_sdm_regress, dim3((B + 15) / 16, ((N + 15) / 16 + RG_NT - 1) / RG_NT, nchunks), dim3(64), 0, st, sc.desc.as<float>(), B, F, R, N,
+                           sc.partial.as<double>(), nchunks);
+        hipLaunchKernelGGL(k_sdm_update, dim3((B * N + 255) / 256), dim3(256), 0, st, sc.shapes.as<float>(), sc.partial.as<double>(), nchunks,
+                           R + (size_t)F * N, sc.dist.as<float>(), B, N);
     }
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipMemcpyAsync(shapes.data(), m->shapes.p, sizeof(float) * shapes.size(), hipMemcpyDeviceToHost, st));
-    if (status_out) HIP_CHECK(hipMemcpyAsync(status_out, m->status.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    if (ctx->kernel_timing && m->S > 0) {
-        HIP_CHECK(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev0, ctx->ev1));
-        ctx->last_kernel = "k_sdm_descriptors";
-    }
+    HIP_CHECK(hipMemcpyAsync(sc.hshapes.p, sc.shapes.p, sizeof(float) * nshape, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(sc.hstatus.p, sc.status.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+    if (!sc.done) HIP_CHECK(hipEventCreateWithFlags(&sc.done, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(sc.done, st));
 }
 
-int fd_sdm_fit_batch(fd_ctx* ctx, const fd_sdm* m_, const uint8_t* gray_images, int W, int H, int batch, const int32_t* face_boxes,
-                     int images_on_device, float* shapes_out, int32_t* status_out) {
-    return fd_guard(ctx, [&] {
-        if (!ctx || !m_ || !gray_images || !face_boxes || !shapes_out || batch < 0 || W < 1 || H < 1)
-            FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_sdm_fit_batch: bad argument");
-        if (batch == 0) return;
-        fd_sdm* m = const_cast<fd_sdm*>(m_);
-        const int L = m->L, N = 2 * L, B = batch;
+static std::unique_ptr<SdmScratch> sdm_take_scratch(fd_sdm* m) {
+    if (m->idle.empty()) return std::unique_ptr<SdmScratch>(new SdmScratch());
+    std::unique_ptr<SdmScratch> s = std::move(m->idle.back());
+    m->idle.pop_back();
+    return s;
+}
+
+// begin: start shapes -> pinned buffer, kernels queued; end: wait, copy out, scratch back to the model
+static void sdm_begin(fd_ctx* ctx, fd_sdm* m, fd_sdm_ticket& t, const uint8_t* gray_images, int W, int H, int B, int images_on_device,
+                      const float* start_shapes, const int32_t* face_boxes, hipStream_t st, bool timeIt) {
+    const int L = m->L, N = 2 * L;
+    t.m = m;
+    t.B = B;
+    t.timed = timeIt;
+    t.s = sdm_take_scratch(m);
+    t.s->hshapes.reserve(sizeof(float) * (size_t)B * N);
+    float* shapes = t.s->hshapes.as<float>();
+    if (start_shapes) {
+        std::memcpy(shapes, start_shapes, sizeof(float) * (size_t)B * N);
+    } else {
         // alignRigid (SdmLandmarkModel.hpp:156-192) on the host, exactly as the cv::MatExpr evaluates it:
         // x * float(w) + float(0.5 * w + bx)
-        std::vector<float> shapes((size_t)B * N);
         for (int f = 0; f < B; ++f) {
             const int32_t* fb = face_boxes + 4 * f;
             const float ax = (float)(double)fb[2], bx = (float)(0.5 * fb[2] + fb[0]);
@@ -734,8 +759,56 @@ int fd_sdm_fit_batch(fd_ctx* ctx, const fd_sdm* m_, const uint8_t* gray_images, 
                 shapes[(size_t)f * N + i + L] = m->mean[i + L] * ay + by;
             }
         }
-        sdm_optimize(ctx, m, gray_images, W, H, B, images_on_device, shapes, status_out);
-        std::memcpy(shapes_out, shapes.data(), sizeof(float) * shapes.size());
+    }
+    sdm_launch(ctx, m, *t.s, st, gray_images, W, H, B, images_on_device, timeIt);
+}
+static void sdm_end(fd_ctx* ctx, fd_sdm_ticket& t, float* shapes_out, int32_t* status_out) {
+    if (!t.s) return;
+    HIP_CHECK(hipEventSynchronize(t.s->done));
+    const int N = 2 * t.m->L;
+    if (shapes_out) std::memcpy(shapes_out, t.s->hshapes.p, sizeof(float) * (size_t)t.B * N);
+    if (status_out) std::memcpy(status_out, t.s->hstatus.p, sizeof(int32_t) * t.B);
+    if (t.timed && t.m->S > 0) {
+        HIP_CHECK(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev0, ctx->ev1));
+        ctx->last_kernel = "k_sdm_descriptors";
+    }
+    t.m->idle.push_back(std::move(t.s));
+}
+
+int fd_sdm_fit_batch(fd_ctx* ctx, const fd_sdm* m_, const uint8_t* gray_images, int W, int H, int batch, const int32_t* face_boxes,
+                     int images_on_device, float* shapes_out, int32_t* status_out) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !m_ || !gray_images || !face_boxes || !shapes_out || batch < 0 || W < 1 || H < 1)
+            FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_sdm_fit_batch: bad argument");
+        if (batch == 0) return;
+        fd_sdm_ticket t;
+        sdm_begin(ctx, const_cast<fd_sdm*>(m_), t, gray_images, W, H, batch, images_on_device, nullptr, face_boxes, ctx->stream, ctx->kernel_timing);
+        sdm_end(ctx, t, shapes_out, status_out);
+    });
+}
+
+// Asynchronous form: _begin queues the whole fit of a batch and returns; _end waits for it and delivers the shapes.  Several
+// batches of one model can be in flight (each has its own scratch set); consecutive tickets alternate between two streams so that
+// the small regress / update kernels of one batch run beside the descriptor kernel of the next.  The images (and face boxes) of a
+// batch must stay valid until its _end when they are host memory.
+int fd_sdm_fit_batch_begin(fd_ctx* ctx, const fd_sdm* m_, const uint8_t* gray_images, int W, int H, int batch, const int32_t* face_boxes,
+                           int images_on_device, fd_sdm_ticket** ticket) {
+    if (ticket) *ticket = nullptr;
+    return fd_guard(ctx, [&] {
+        if (!ctx || !m_ || !gray_images || !face_boxes || !ticket || batch < 1 || W < 1 || H < 1)
+            FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_sdm_fit_batch_begin: bad argument");
+        fd_sdm* m = const_cast<fd_sdm*>(m_);
+        std::unique_ptr<fd_sdm_ticket> t(new fd_sdm_ticket());
+        hipStream_t st = (m->launches++ & 1u) ? fd_aux_stream(ctx) : ctx->stream;
+        sdm_begin(ctx, m, *t, gray_images, W, H, batch, images_on_device, nullptr, face_boxes, st, false);
+        *ticket = t.release();
+    });
+}
+int fd_sdm_fit_batch_end(fd_ctx* ctx, fd_sdm_ticket* ticket, float* shapes_out, int32_t* status_out) {
+    std::unique_ptr<fd_sdm_ticket> t(ticket);
+    return fd_guard(ctx, [&] {
+        if (!ctx || !t) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_sdm_fit_batch_end: bad argument");
+        sdm_end(ctx, *t, shapes_out, status_out);
     });
 }
 
@@ -745,10 +818,9 @@ int fd_sdm_optimize_batch(fd_ctx* ctx, const fd_sdm* m_, const uint8_t* gray_ima
         if (!ctx || !m_ || !gray_images || !shapes_inout || batch < 0 || W < 1 || H < 1)
             FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_sdm_optimize_batch: bad argument");
         if (batch == 0) return;
-        fd_sdm* m = const_cast<fd_sdm*>(m_);
-        std::vector<float> shapes(shapes_inout, shapes_inout + (size_t)batch * 2 * m->L);
-        sdm_optimize(ctx, m, gray_images, W, H, batch, images_on_device, shapes, status_out);
-        std::memcpy(shapes_inout, shapes.data(), sizeof(float) * shapes.size());
+        fd_sdm_ticket t;
+        sdm_begin(ctx, const_cast<fd_sdm*>(m_), t, gray_images, W, H, batch, images_on_device, shapes_inout, nullptr, ctx->stream, ctx->kernel_timing);
+        sdm_end(ctx, t, shapes_inout, status_out);
     });
 }
 

@@ -440,6 +440,13 @@ int fd_sdm_fit_batch(fd_ctx* ctx, const fd_sdm* m, const uint8_t* gray_images, i
  * shapes (2L floats each: x0..xL-1, y0..yL-1) and receives the optimised ones. */
 int fd_sdm_optimize_batch(fd_ctx* ctx, const fd_sdm* m, const uint8_t* gray_images, int width, int height, int batch,
                           int images_on_device, float* shapes_inout, int32_t* status_out);
+/* Asynchronous form of fd_sdm_fit_batch (the five-stage path has _begin/_end, so has this): _begin queues the whole fit of a batch
+ * (its S cascade steps and the read-back) and returns; _end waits and delivers shapes / status.  Several batches of one model can be
+ * in flight from ONE host thread; each has its own scratch set.  Host images / boxes of a batch must stay valid until its _end. */
+typedef struct fd_sdm_ticket fd_sdm_ticket;
+int fd_sdm_fit_batch_begin(fd_ctx* ctx, const fd_sdm* model, const uint8_t* gray_images, int width, int height, int batch,
+                           const int32_t* face_boxes, int images_on_device, fd_sdm_ticket** ticket);
+int fd_sdm_fit_batch_end(fd_ctx* ctx, fd_sdm_ticket* ticket, float* shapes_out, int32_t* status_out);
 
 /* ---- image-shard data parallelism (north_star: "images shard embarrassingly across the 8 GPUs of one node with a single RCCL gather
  * of detections over xGMI").  One process per GPU; image i belongs to rank i mod world; models are replicated; no data-path

@@ -725,6 +725,14 @@ def test_sdm_fit_batch(oracle, capi, ctx, synth):
     s0, _ = capi.Sdm(ctx, zero).fit(imgs[:1], boxes[:1])
     _, r0 = oracle.sdm_fit(imgs[0], zero, boxes[0])
     assert np.array_equal(s0[0], r0)
+    # fd_sdm_fit_batch_begin / _end: four batches of different content queued by one host thread, collected out of order -- the same
+    # shapes as the blocking calls (each ticket owns its scratch set; consecutive tickets run on alternating streams)
+    batches = [(imgs[k:k + 3], boxes[k:k + 3]) for k in (0, 3, 1, 2)]
+    ref = [sg.fit(*b) for b in batches]
+    tickets = [sg.fit_begin(*b) for b in batches]
+    for k in (2, 0, 3, 1):
+        sh, st = sg.fit_end(tickets[k])
+        assert np.array_equal(sh, ref[k][0]) and np.array_equal(st, ref[k][1]), k
     sg.close()
 
 
