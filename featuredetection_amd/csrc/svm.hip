@@ -44,6 +44,12 @@ struct SvmDev {
     const uint32_t* svT;     // u8: [dpad/16][nsvp][4]: words 4q..4q+3 of support vector s at svT[(q*nsvp + s)*4 ..] (one 16-byte load per lane)
     const float* coeffP;     // u8: [nsvp], zero padded
     const uint32_t* ssP;     // u8: [nsvp]
+    // u8 RBF on the i8 MFMA pipe (k_svm_u8_rbf_mfma): support vectors as s - 128 in the A-operand order of v_mfma_i32_32x32x32_i8,
+    // [SV tile of 32][k-step of 32 dims][64 lanes] 16 bytes (lane l: SV l & 31, dims ks * 32 + (l >> 5) * 16 .. + 15, zero padded)
+    const void* svA;
+    const int32_t* ssShift;  // [nsv32] sum of (s - 128)^2 per support vector
+    const double* coeffD;    // [nsv32], zero padded
+    int32_t nsv32, KS;       // support vectors padded to 32, k-steps
     // MFMA path (f32 RBF)
     int32_t KP;              // padded feature length (multiple of 8)
     int32_t nsv_pad;         // multiple of 256
@@ -57,7 +63,7 @@ struct fd_svm {
     SvmDev dev;
     float threshold;
     double logisticA, logisticB;
-    DevBuf sv, coeff, ss, svFrag, ssF, coeffPad, svT, coeffP, ssP;
+    DevBuf sv, coeff, ss, svFrag, ssF, coeffPad, svT, coeffP, ssP, svA, ssShift, coeffD;
     DevBuf feat, dist, idx;  // scratch for batch calls
 };
 
@@ -250,6 +256,93 @@ __global__ __launch_bounds__(256) void k_svm_u8_lanes(SvmDev m, const void* __re
     if (threadIdx.x < SU_PB && item0 + threadIdx.x < n) {
         const int p = threadIdx.x;
         out[item0 + p] = -(double)m.bias + ((red[p][0] + red[p][1]) + (red[p][2] + red[p][3]));
+    }
+}
+
+// ---- u8 RBF on the i8 MFMA pipe (second cascade stage: HistEq64 patches against the RBF support vectors) -------------------
+// RbfKernel.hpp:78-88 on CV_8U data is an exact integer sum of squared differences; (x - s) = (x - 128) - (s - 128), so
+// ssd = |x'|^2 + |s'|^2 - 2 x'.s' with the cross term from v_mfma_i32_32x32x32_i8 on the shifted (signed) bytes: exact.  A workgroup
+// (8 wavefronts) takes 32 feature vectors: their bytes are staged in LDS once (B operand), wavefront w streams the support-vector
+// tiles w, w + 8, ... from L2 (A operand, four fragments in flight), and every lane finishes the 16 kernel values of its patch with
+// the fp64 exp of the reference and adds them into its fp64 sum.  The lane-per-support-vector kernel (k_svm_u8_lanes) re-read all
+// support vectors per 2 patches (426 KB of L2 traffic per pair) and spent 68 us per 64-frame call; this one reads them once per 32.
+typedef int svm_v4i __attribute__((ext_vector_type(4)));
+typedef int svm_v16i __attribute__((ext_vector_type(16)));
+constexpr int SU_W = 8;   // wavefronts per workgroup
+__global__ __launch_bounds__(64 * SU_W) void k_svm_u8_rbf_mfma(SvmDev m, const void* __restrict__ features, const uint32_t* __restrict__ idx,
+                                                               int64_t feat_stride_bytes, int64_t n, double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int KS = m.KS, DS = KS * 32 + 16;   // row stride: an odd number of 16-byte slots (conflict-free ds_read_b128 across the rows)
+    unsigned char* xs = smem;                                                   // [32][DS] x - 128
+    int* xxs = reinterpret_cast<int*>(smem + 32 * DS);                          // [32] |x'|^2
+    double* red = reinterpret_cast<double*>(smem + 32 * DS + 128);              // [SU_W][32]
+    const int64_t item0 = (int64_t)blockIdx.x * 32;
+    {   // stage the 32 feature vectors (gathered through idx), zero padded; dwords where the layout allows
+        const bool words = (m.dim & 3) == 0 && (feat_stride_bytes & 3) == 0 && ((uintptr_t)features & 3) == 0;
+        const int wpr = DS >> 2;
+        for (int i = threadIdx.x; i < 32 * wpr; i += 64 * SU_W) {
+            const int row = i / wpr, col = (i - row * wpr) * 4;
+            const int64_t item = item0 + row;
+            uint32_t v = 0;
+            if (item < n && col < m.dim) {
+                const int64_t slot = idx ? (int64_t)idx[item] : item;
+                const unsigned char* x = (const unsigned char*)features + slot * feat_stride_bytes + col;
+                if (words) {
+                    v = *reinterpret_cast<const uint32_t*>(x) ^ 0x80808080u;
+                } else {
+                    for (int b = 0; b < 4; ++b)
+                        if (col + b < m.dim) v |= (uint32_t)(x[b] ^ 0x80u) << (8 * b);
+                }
+            }
+            *reinterpret_cast<uint32_t*>(xs + row * DS + col) = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {   // |x'|^2 of the 32 vectors
+        const uint32_t* r = reinterpret_cast<const uint32_t*>(xs + threadIdx.x * DS);
+        int acc = 0;
+        for (int i = 0; i < KS * 8; ++i) acc = __builtin_amdgcn_sdot4((int)r[i], (int)r[i], acc, false);
+        xxs[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    const int xxv = xxs[lane & 31];
+    const unsigned char* xb = xs + (lane & 31) * DS + (lane >> 5) * 16;
+    const svm_v4i* A = reinterpret_cast<const svm_v4i*>(m.svA);
+    const int ntiles = m.nsv32 >> 5;
+    double sum = 0.0;
+    for (int t = wave; t < ntiles; t += SU_W) {
+        const svm_v4i* Ap = A + (size_t)t * KS * 64 + lane;
+        svm_v16i acc = {};
+        svm_v4i an[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) an[q] = Ap[min(q, KS - 1) * 64];
+        for (int ks = 0; ks < KS; ks += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const svm_v4i a = an[q];
+                an[q] = Ap[min(ks + 4 + q, KS - 1) * 64];
+                if (ks + q < KS) {
+                    const svm_v4i b = *reinterpret_cast<const svm_v4i*>(xb + (ks + q) * 32);
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc, 0, 0, 0);
+                }
+            }
+        }
+        // acc[r] = x' . s' for support vector t * 32 + row(r) and this lane's patch
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int sv = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int ssd = xxv + m.ssShift[sv] - 2 * acc[r];
+            sum += m.coeffD[sv] * exp(-m.p0 * (double)ssd);   // padded support vectors have coefficient 0
+        }
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    if (lane < 32) red[wave * 32 + lane] = sum;
+    __syncthreads();
+    if (threadIdx.x < 32 && item0 + threadIdx.x < n) {
+        const double* r = red + threadIdx.x;
+        out[item0 + threadIdx.x] = -(double)m.bias + (((r[0] + r[32]) + (r[64] + r[96])) + ((r[128] + r[160]) + (r[192] + r[224])));
     }
 }
 
@@ -549,6 +642,14 @@ void fd_svm_generic_launch(fd_ctx* ctx, const fd_svm* m, const void* dfeat, cons
 void fd_svm_generic_launch_on(hipStream_t st, const fd_svm* m, const void* dfeat, const uint32_t* didx, int64_t stride_bytes,
                               int64_t n, double* dout) {
     if (n <= 0) return;
+    static const bool u8Lanes = [] { const char* e = getenv("FD_SVM_U8_LANES"); return e && atoi(e) != 0; }();   // A/B: the older kernel
+    if (m->dev.dtype == FD_DTYPE_U8 && m->dev.kernel == FD_KERNEL_RBF && m->dev.svA && !u8Lanes) {
+        const size_t lb = (size_t)32 * (m->dev.KS * 32 + 16) + 128 + sizeof(double) * SU_W * 32;
+        const unsigned grid = (unsigned)((n + 31) / 32);
+        hipLaunchKernelGGL(k_svm_u8_rbf_mfma, dim3(grid), dim3(64 * SU_W), lb, st, m->dev, dfeat, didx, stride_bytes, n, dout);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (m->dev.dtype == FD_DTYPE_U8) {
         const int pb = n >= 16384 ? 8 : (n >= 8192 ? 4 : 2);   // measured: 4 per workgroup at n ~ 2000-4000 is slower than 2 (fewer workgroups)
         const size_t lb = (size_t)pb * m->dev.dpad;
@@ -628,6 +729,27 @@ int fd_svm_create(fd_ctx* ctx, const fd_svm_model* md, fd_svm** out) {
                 up(m->ssP, ssP.data(), sizeof(uint32_t) * ssP.size());
                 up(m->coeffP, cP.data(), sizeof(float) * cP.size());
                 d.svT = m->svT.as<uint32_t>(); d.ssP = m->ssP.as<uint32_t>(); d.coeffP = m->coeffP.as<float>();
+            }
+            if (d.kernel == FD_KERNEL_RBF && d.dim <= 1536) {   // operand tables of k_svm_u8_rbf_mfma (LDS: 32 rows of KS * 32 + 16 bytes)
+                d.KS = (d.dim + 31) / 32;
+                d.nsv32 = (d.nsv + 31) & ~31;
+                std::vector<int8_t> A((size_t)(d.nsv32 / 32) * d.KS * 64 * 16, 0);
+                std::vector<int32_t> ssS(d.nsv32, 0);
+                std::vector<double> cD(d.nsv32, 0.0);
+                for (int sI = 0; sI < d.nsv; ++sI) {
+                    const int tile = sI >> 5, row = sI & 31;
+                    for (int k = 0; k < d.dim; ++k) {
+                        const int v = (int)src[(size_t)sI * d.dim + k] - 128;
+                        ssS[sI] += v * v;
+                        const int ks = k >> 5, h = (k >> 4) & 1, t = k & 15;
+                        A[((((size_t)tile * d.KS + ks) * 64) + (size_t)(h * 32 + row)) * 16 + t] = (int8_t)v;
+                    }
+                    cD[sI] = (double)md->coefficients[sI];
+                }
+                up(m->svA, A.data(), A.size());
+                up(m->ssShift, ssS.data(), sizeof(int32_t) * ssS.size());
+                up(m->coeffD, cD.data(), sizeof(double) * cD.size());
+                d.svA = m->svA.p; d.ssShift = m->ssShift.as<int32_t>(); d.coeffD = m->coeffD.as<double>();
             }
         } else {
             d.dpad = d.dim;
