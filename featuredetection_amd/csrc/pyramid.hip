@@ -31,6 +31,17 @@ struct DownJob {
     int sw, sh;
     uint32_t src_off, dst_off;
 };
+// one first-octave chain of k_resize_down: cv::resize of the frame to dw0 x dh0 and its pyrDown to dw1 x dh1
+struct FusedJob {
+    int dw0, dh0, dw1, dh1;
+    uint32_t dst0_off;      // resized layer, written only when it is a kept layer (0xffffffff: stays in LDS)
+    uint32_t dst1_off;      // its pyrDown
+    uint32_t xtab, ytab;    // offsets (in int2 entries) into the coordinate tables
+};
+struct FusedJobs {
+    int n;
+    FusedJob j[MAXJ];
+};
 struct DownJobs {
     int n;
     DownJob j[MAXJ];
@@ -270,6 +281,133 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
                     const unsigned int r1 = __umul24(S1[lx], a0) + __umul24(S1[lx1], a1);
                     *dp = (uint8_t)(((__umul24(rt.z, r0 >> 4) >> 16) + (__umul24(rt.w, r1 >> 4) >> 16) + 2) >> 2);
                 }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- cv::resize of the frame + the first cv::pyrDown of the result in one kernel ---------------------------------------------
+// Most first-octave layers of a detection pyramid are not kept themselves (FaceFrontal keeps scales 0.05 .. 0.16): they only exist as the
+// source of their pyrDown chain, and writing 1.2 Mpixels per frame to memory only to read them back in the next launch is what the
+// pyramid stage spent its time on.  A workgroup computes the resized pixels under one 62 x 16 tile of the pyrDown layer (127 x 35, the
+// 5-tap halo included; BORDER_REFLECT_101 columns / rows are the resized pixels at the reflected coordinates) into LDS and takes the
+// pyrDown from there; the resized layer goes to memory only when it is a kept layer.  Same integer arithmetic as k_resize_tiled /
+// k_pyrdown_tiled, value for value (ImagePyramid.cpp:177,186), with two savings per resized pixel:
+//   * the cv::resize coordinates and fixed-point weights come from per-layer tables built on the host with the kernel's own float
+//     expressions (xtab[dx] = {left source column, a0 | a1 << 16}, ytab[dy] = {y0 | y1 << 16, b0 | b1 << 16});
+//   * a thread walks down one column and keeps the horizontally interpolated value of the last two source rows: consecutive
+//     destination rows share them (1 <= scale < 2), so a destination pixel costs ~1.4 horizontal interpolations instead of 2.
+constexpr int FT_W1 = 62, FT_H1 = 16;                    // pyrDown tile
+constexpr int G0_W = 2 * FT_W1 + 3, G0_H = 2 * FT_H1 + 3, G0_PITCH = 128;   // resized pixels under it: 127 x 35
+constexpr int FS_PITCH = 272, FS_ROWS = 76;             // source stage: 126 * 2.05 + 3 columns, 34 * 2.05 + 3 rows
+__global__ __launch_bounds__(256) void k_resize_down(uint8_t* __restrict__ arena, uint32_t src_off, int sw, int sh, const int2* __restrict__ tabs,
+                                                     FusedJobs jobs, size_t imageStride) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[FS_ROWS * FS_PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t g0[G0_H * G0_PITCH];
+    __shared__ int4 rowTab[G0_H];   // per resized row of the tile: LDS offsets of its two source rows, vertical weights
+    const FusedJob jb = jobs.j[blockIdx.y];
+    arena += (size_t)blockIdx.z * imageStride;   // blockIdx.z = frame of a multi-frame pyramid
+    const uint8_t* src = arena + src_off;
+    const int2* xtab = tabs + jb.xtab;
+    const int2* ytab = tabs + jb.ytab;
+    const int tilesX = (jb.dw1 + FT_W1 - 1) / FT_W1, tilesY = (jb.dh1 + FT_H1 - 1) / FT_H1;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int t = blockIdx.x; t < tilesX * tilesY; t += gridDim.x) {
+        const int ty = t / tilesX, tx = t - ty * tilesX;
+        const int x1 = tx * FT_W1, y1 = ty * FT_H1;          // first pyrDown pixel of the tile
+        const int gx0 = 2 * x1 - 2, gy0 = 2 * y1 - 2;        // resized pixel of tile entry (0, 0), before the border reflection
+        // resized columns / rows the tile touches (after reflection: a contiguous interval) and their source rectangle
+        const int cLo = max(0, gx0), cHi = min(jb.dw0 - 1, gx0 + G0_W - 1), rLo = max(0, gy0), rHi = min(jb.dh0 - 1, gy0 + G0_H - 1);
+        const int X0 = xtab[cLo].x, Y0 = ytab[rLo].x & 0xffff;
+        const int ncol = min(sw - 1, xtab[cHi].x + 1) - X0 + 1, nrow = (ytab[rHi].x >> 16) - Y0 + 1;   // <= FS_PITCH, FS_ROWS (host checks)
+        {   // stage the source rectangle: wavefront w takes rows w, w + 4, ..., a lane the dwords lane and lane + 64 of a row
+            const int ndw = (ncol + 3) >> 2;
+            for (int r0 = wave; r0 < nrow; r0 += 4 * 8) {
+                uint32_t v[8][2];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = r0 + 4 * k;
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int j = lane + 64 * hh, x = X0 + 4 * j;
+                        v[k][hh] = 0;
+                        if (r < nrow && j < ndw) {
+                            const uint8_t* row = src + (uint32_t)((Y0 + r) * sw);
+                            if (x + 3 < sw) v[k][hh] = ld_u32_unaligned(row + x);
+                            else for (int b = 0; b < 4; ++b) v[k][hh] |= (uint32_t)row[min(x + b, sw - 1)] << (8 * b);   // right edge of the image
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = r0 + 4 * k;
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int j = lane + 64 * hh;
+                        if (r < nrow && j < ndw) *reinterpret_cast<uint32_t*>(&stage[r * FS_PITCH + 4 * j]) = v[k][hh];
+                    }
+                }
+            }
+        }
+        if (threadIdx.x < G0_H) {   // vertical taps of the tile's resized rows
+            const int2 e = ytab[reflect101(gy0 + (int)threadIdx.x, jb.dh0)];
+            rowTab[threadIdx.x] = make_int4(((e.x & 0xffff) - Y0) * FS_PITCH, ((e.x >> 16) - Y0) * FS_PITCH, e.y & 0xffff, e.y >> 16);
+        }
+        __syncthreads();
+        {   // ---- resize: thread = one column of the tile, half of its rows
+            const int c = threadIdx.x & 127, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
+            if (c < G0_W) {
+                const int2 ex = xtab[reflect101(gx0 + c, jb.dw0)];
+                const int lx = ex.x - X0, lx1 = min(ex.x + 1, sw - 1) - X0;
+                const unsigned int a0 = ex.y & 0xffff, a1 = (unsigned int)ex.y >> 16;
+                auto hcalc = [&](int rowOff) {   // horizontal interpolation of one source row, already >> 4 (cv::resize's intermediate)
+                    return (__umul24(stage[rowOff + lx], a0) + __umul24(stage[rowOff + lx1], a1)) >> 4;
+                };
+                int ta = -1, tb = -1;
+                unsigned int ha = 0, hb = 0;
+                const int rBeg = half * 18, rEnd = half ? G0_H : 18;
+                for (int r = rBeg; r < rEnd; ++r) {
+                    const int4 rt = rowTab[r];
+                    const int o0 = __builtin_amdgcn_readfirstlane(rt.x), o1 = __builtin_amdgcn_readfirstlane(rt.y);   // wave-uniform: scalar branches
+                    unsigned int h0, h1;
+                    if (o0 == ta) h0 = ha; else if (o0 == tb) h0 = hb; else h0 = hcalc(o0);
+                    if (o1 == o0) h1 = h0; else if (o1 == tb) h1 = hb; else if (o1 == ta) h1 = ha; else h1 = hcalc(o1);
+                    ta = o0; ha = h0; tb = o1; hb = h1;
+                    g0[r * G0_PITCH + c] = (uint8_t)(((__umul24(rt.z, h0) >> 16) + (__umul24(rt.w, h1) >> 16) + 2) >> 2);
+                }
+            }
+        }
+        __syncthreads();
+        {   // ---- pyrDown of the tile (k_pyrdown_tiled's arithmetic on the LDS copy)
+            const int c1 = lane;
+            const int x = x1 + c1;
+            if (c1 < FT_W1 && x < jb.dw1) {
+                constexpr int PR = FT_H1 / 4;   // output rows per thread
+                const uint8_t* T = g0 + (2 * wave * PR) * G0_PITCH + 2 * c1;
+                int h[2 * PR + 3];
+#pragma unroll
+                for (int r = 0; r < 2 * PR + 3; ++r) {
+                    const uint8_t* S = T + r * G0_PITCH;
+                    const uint32_t p01 = *reinterpret_cast<const uint16_t*>(S), p23 = *reinterpret_cast<const uint16_t*>(S + 2);
+                    h[r] = (int)__builtin_amdgcn_udot4(p01 | (p23 << 16), 0x04060401u, (uint32_t)S[4], false);
+                }
+                uint8_t* dp = arena + jb.dst1_off + (uint32_t)((y1 + wave * PR) * jb.dw1) + x;
+#pragma unroll
+                for (int j = 0; j < PR; ++j, dp += jb.dw1) {
+                    if (y1 + wave * PR + j < jb.dh1) {
+                        const int v = h[2 * j + 2] * 6 + (h[2 * j + 1] + h[2 * j + 3]) * 4 + h[2 * j] + h[2 * j + 4];
+                        *dp = (uint8_t)((v + 128) >> 8);
+                    }
+                }
+            }
+        }
+        if (jb.dst0_off != 0xffffffffu) {   // the resized layer is a kept layer: the tile's own 124 x 32 pixels of it
+            uint8_t* d0 = arena + jb.dst0_off;
+            for (int i = threadIdx.x; i < 32 * 128; i += 256) {
+                const int r = 2 + (i >> 7), c = 2 + (i & 127);
+                const int gx = gx0 + c, gy = gy0 + r;
+                if (c < 2 + 2 * FT_W1 && gx < jb.dw0 && gy < jb.dh0) d0[(uint32_t)(gy * jb.dw0) + gx] = g0[r * G0_PITCH + c];
             }
         }
         __syncthreads();
@@ -574,6 +712,62 @@ void build_gradient_lut(int bins, bool signedGradients, bool interpolate, std::v
     }
 }
 
+// cv::resize coordinate tables of the first-octave layers that feed a pyrDown chain (k_resize_down): the kernel's own float
+// expressions (k_resize_tiled's srcX / srcY), evaluated once per geometry on the host (this file is built with -ffp-contract=off)
+void build_resize_tables(fd_pyramid* p, int W, int H) {
+    p->rtab_x.assign(p->all.size(), ~0u);
+    p->rtab_y.assign(p->all.size(), ~0u);
+    static const bool off = [] { const char* e = getenv("FD_PYR_FUSED"); return e && atoi(e) == 0; }();
+    if (off) return;
+    std::vector<int2> tab;
+    for (size_t k = 0; k + 1 < p->all.size(); ++k) {
+        const HostLayer& L = p->all[k];
+        const HostLayer& D = p->all[k + 1];
+        if (L.depth != 0 || D.depth != 1 || D.chain != L.chain) continue;
+        // the scale-1 layer IS the gray image: its pyrDown stays with k_pyrdown_tiled (through this kernel with identity tables it
+        // costs +35 us per 64-frame call against 15 us saved: the resize arithmetic is not free)
+        if (L.w == W && L.h == H && L.gray_off == p->gray_full_off) continue;
+        if (L.w < 3 || L.h < 3 || W > 65535 || H > 65535) continue;
+        const double scale_x = 1. / ((double)L.w / W), scale_y = 1. / ((double)L.h / H);
+        std::vector<int2> xt((size_t)L.w), yt((size_t)L.h);
+        for (int dx = 0; dx < L.w; ++dx) {
+            float fx = (float)((dx + 0.5) * scale_x - 0.5);
+            int sx = (int)floorf(fx);
+            fx -= sx;
+            if (sx < 0) { fx = 0; sx = 0; }
+            if (sx >= W - 1) { fx = 0; sx = W - 1; }
+            const int a0 = (int)nearbyintf((1.f - fx) * 2048), a1 = (int)nearbyintf(fx * 2048);
+            xt[(size_t)dx] = make_int2(sx, a0 | (a1 << 16));
+        }
+        for (int dy = 0; dy < L.h; ++dy) {
+            float fy = (float)((dy + 0.5) * scale_y - 0.5);
+            const int sy = (int)floorf(fy);
+            fy -= sy;
+            const int b0 = (int)nearbyintf((1.f - fy) * 2048), b1 = (int)nearbyintf(fy * 2048);
+            const int y0 = sy < 0 ? 0 : (sy >= H ? H - 1 : sy), y1 = sy + 1 < 0 ? 0 : (sy + 1 >= H ? H - 1 : sy + 1);
+            yt[(size_t)dy] = make_int2(y0 | (y1 << 16), b0 | (b1 << 16));
+        }
+        // every tile's source rectangle must fit the kernel's stage
+        bool fits = true;
+        for (int x1 = 0; x1 < D.w && fits; x1 += FT_W1) {
+            const int cLo = std::max(0, 2 * x1 - 2), cHi = std::min(L.w - 1, 2 * x1 - 2 + G0_W - 1);
+            fits = std::min(W - 1, xt[(size_t)cHi].x + 1) - xt[(size_t)cLo].x + 1 <= FS_PITCH - 4;
+        }
+        for (int y1 = 0; y1 < D.h && fits; y1 += FT_H1) {
+            const int rLo = std::max(0, 2 * y1 - 2), rHi = std::min(L.h - 1, 2 * y1 - 2 + G0_H - 1);
+            fits = (yt[(size_t)rHi].x >> 16) - (yt[(size_t)rLo].x & 0xffff) + 1 <= FS_ROWS;
+        }
+        if (!fits) continue;
+        p->rtab_x[k] = (uint32_t)tab.size();
+        tab.insert(tab.end(), xt.begin(), xt.end());
+        p->rtab_y[k] = (uint32_t)tab.size();
+        tab.insert(tab.end(), yt.begin(), yt.end());
+    }
+    if (tab.empty()) return;
+    p->rtab.reserve(sizeof(int2) * tab.size());
+    HIP_CHECK(hipMemcpy(p->rtab.p, tab.data(), sizeof(int2) * tab.size(), hipMemcpyHostToDevice));
+}
+
 void build_layout(fd_pyramid* p, int W, int H) {
     p->img_w = W;
     p->img_h = H;
@@ -635,6 +829,7 @@ void build_layout(fd_pyramid* p, int W, int H) {
     if (!p->h_layer_table.empty())
         HIP_CHECK(hipMemcpyAsync(p->layer_table.p, p->h_layer_table.data(), sizeof(LayerDesc) * p->h_layer_table.size(),
                                  hipMemcpyHostToDevice, p->ctx->stream));
+    build_resize_tables(p, W, H);
 }
 
 int grid_for(int npix) { return std::max(1, std::min(1024, (npix + 255) / 256)); }
@@ -696,15 +891,41 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
             maxpix = 0;
             maxtiles = 0;
         };
-        for (const HostLayer& L : p->all) {
+        for (size_t k = 0; k < p->all.size(); ++k) {
+            const HostLayer& L = p->all[k];
             if (L.depth != 0) continue;
             if (L.w == W && L.h == H && L.gray_off == p->gray_full_off) continue;   // the gray image itself (build_layout)
+            if (p->rtab_x[k] != ~0u) continue;   // resized and pyrDown'ed by k_resize_down below
             ResizeJob& j = jobs.j[jobs.n++];
             j.dw = L.w; j.dh = L.h; j.dst_off = L.gray_off;
             j.scale_x = 1. / ((double)L.w / W);
             j.scale_y = 1. / ((double)L.h / H);
             maxpix = std::max(maxpix, L.w * L.h);
             maxtiles = std::max(maxtiles, ((L.w + TL_W - 1) / TL_W) * ((L.h + TL_H - 1) / TL_H));
+            if (jobs.n == MAXJ) flush();
+        }
+        flush();
+    }
+    {   // first-octave layers with a pyrDown chain: resize + first pyrDown in one kernel, the resized pixels stay in LDS
+        FusedJobs jobs;
+        jobs.n = 0;
+        int maxtiles = 0;
+        auto flush = [&]() {
+            if (!jobs.n) return;
+            hipLaunchKernelGGL(k_resize_down, dim3(tile_grid_for(maxtiles), jobs.n, NI), dim3(256), 0, st, arena, p->gray_full_off, W, H, p->rtab.as<int2>(), jobs, IS);
+            jobs.n = 0;
+            maxtiles = 0;
+        };
+        for (size_t k = 0; k + 1 < p->all.size(); ++k) {
+            if (p->rtab_x[k] == ~0u) continue;
+            const HostLayer& L = p->all[k];
+            const HostLayer& D = p->all[k + 1];
+            FusedJob& j = jobs.j[jobs.n++];
+            j.dw0 = L.w; j.dh0 = L.h; j.dw1 = D.w; j.dh1 = D.h;
+            j.dst0_off = (L.kept && L.gray_off != p->gray_full_off) ? L.gray_off : 0xffffffffu;   // the scale-1 layer IS the gray image
+            j.dst1_off = D.gray_off;
+            j.xtab = p->rtab_x[k]; j.ytab = p->rtab_y[k];
+            maxtiles = std::max(maxtiles, ((D.w + FT_W1 - 1) / FT_W1) * ((D.h + FT_H1 - 1) / FT_H1));
             if (jobs.n == MAXJ) flush();
         }
         flush();
@@ -723,6 +944,7 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
         for (size_t k = 0; k < p->all.size(); ++k) {
             const HostLayer& L = p->all[k];
             if (L.depth != d) continue;
+            if (d == 1 && p->rtab_x[k - 1] != ~0u) continue;   // done by k_resize_down
             const HostLayer& S = p->all[k - 1];  // previous entry of the same chain
             DownJob& j = jobs.j[jobs.n++];
             j.sw = S.w; j.sh = S.h; j.src_off = S.gray_off; j.dst_off = L.gray_off;
