@@ -123,7 +123,7 @@ struct PosRec {
 // Model tables: the rect sums of level k, grey value v >= 1 are x . M_{k,v} with M_{k,v}[pixel] = number of rects of (k, v) that
 // cover the pixel (small integers), so all of them are one exact int8 contraction on v_mfma_i32_32x32x32_i8.  The rows
 // (k, v) are grouped class by class (class n = k mod numPer: the levels that depend on each other through u_kernel_eval[n],
-// WvmClassifier.cpp:308-333) into tiles of 32 rows; a level never straddles a tile, and a tile never straddles a phase.
+// WvmClassifier.cpp:308-333) into tiles of 32 rows; a level never straddles a tile.
 constexpr int WVB_MAXPHASE = 4;
 typedef int wvb_v4i __attribute__((ext_vector_type(4)));
 typedef int wvb_v16i __attribute__((ext_vector_type(16)));
@@ -137,6 +137,7 @@ struct WvbDev {
     const float* wR;          // wR[p * Fr + k] = hkWeights[k][p] (p <= k), rows padded so that eight weights from any k can be read
     const int32_t* rec;       // [numFilters][64 dwords] the chain's per-level record (layout: wvm_stageb.hpp, WVB_REC_DW)
     int32_t KS, dstride, Fr;  // k-steps (32 pixels each), bytes per equalised patch row of the state (KS * 32 + 16: an odd number of 16-byte slots)
+    int32_t KSP;              // k-steps per tile in A (KS rounded up to 8: the fragment ring of k_wvb_chain wraps from tile to tile)
     int32_t numPer, numUsed, numFilters, d;
     int32_t maxCnt;           // largest grey-value count of a used filter
     int32_t nphase;
@@ -1892,7 +1893,7 @@ static void wvm_build_dense(fd_wvm* m, const fd_wvm_model* md) {
 // Tables of the dense stage B (wvm_stageb.hpp), pure host part.  Returns false (the rect-lookup stage-B kernels run instead) when
 // the model never reaches stage B or when more than 127 rects of one grey value overlap on a pixel.
 struct WvbTables {
-    int KS = 0, DS = 0, Fr = 0, nphase = 0, ntile = 0, maxCnt = 1;
+    int KS = 0, KSP = 0, DS = 0, Fr = 0, nphase = 0, ntile = 0, maxCnt = 1;
     int phaseGen[WVB_MAXPHASE + 1] = {};
     std::vector<int32_t> lvl, c128, rec;
     std::vector<int8_t> A;
@@ -1903,8 +1904,10 @@ static bool wvb_tables(const fd_wvm_model* md, int NU, WvbTables& T) {
     if (NU <= WVM_LCAP) return false;
     const int pw = md->filter_w, ph = md->filter_h, d = pw * ph;
     const int KS = (d + 31) / 32;
+    const int KSP = (KS + 7) / 8 * 8;   // k-steps per tile in the operand table: whole groups of eight (zero fragments behind the patch)
     const int G = (NU + NP - 1) / NP;
     T.KS = KS;
+    T.KSP = KSP;
     T.DS = KS * 32 + 16;
     {   // phases: generations [0, 2), [2, 6), [6, G) by default; FD_WVB_PHASES="a,b,c" sets other cuts
         std::vector<int> cuts = {2, 6};
@@ -1925,10 +1928,6 @@ static bool wvb_tables(const fd_wvm_model* md, int NU, WvbTables& T) {
             if (c > T.phaseGen[T.nphase] && c < G && T.nphase + 1 < WVB_MAXPHASE) T.phaseGen[++T.nphase] = c;
         T.phaseGen[++T.nphase] = G;
     }
-    auto phaseStart = [&](int g) {
-        for (int i = 1; i < T.nphase; ++i) if (T.phaseGen[i] == g) return true;
-        return false;
-    };
     T.lvl.assign((size_t)F * 4, 0);
     T.c128.clear();
     T.A.clear();
@@ -1942,10 +1941,11 @@ static bool wvb_tables(const fd_wvm_model* md, int NU, WvbTables& T) {
             const int v0 = md->val_off[k], cntval = md->val_off[k + 1] - v0;
             const int rows = cntval - 1;
             T.maxCnt = std::max(T.maxCnt, cntval);
-            if (cur < 0 || rowc + rows > 32 || phaseStart(g)) {
+            // a tile may hold levels of two phases: a phase then evaluates the whole tile and uses its own rows (the contraction is cheap)
+            if (cur < 0 || rowc + rows > 32) {
                 cur = ntile++;
                 rowc = 0;
-                T.A.resize((size_t)ntile * KS * 64 * 16, 0);
+                T.A.resize((size_t)ntile * KSP * 64 * 16, 0);
                 T.c128.resize((size_t)ntile * 32, 0);
             }
             int32_t* lv = &T.lvl[4 * (size_t)k];
@@ -1963,7 +1963,7 @@ static bool wvb_tables(const fd_wvm_model* md, int NU, WvbTables& T) {
                     if (cover[i] > 127) return false;   // does not fit the int8 operand
                     sum += cover[i];
                     const int ks = i >> 5, h = (i >> 4) & 1, t = i & 15;   // lane h * 32 + row of k-step ks, byte t
-                    T.A[((((size_t)cur * KS + ks) * 64) + (size_t)(h * 32 + row)) * 16 + t] = (int8_t)cover[i];
+                    T.A[((((size_t)cur * KSP + ks) * 64) + (size_t)(h * 32 + row)) * 16 + t] = (int8_t)cover[i];
                 }
                 T.c128[(size_t)cur * 32 + row] = (int32_t)(128 * sum);
             }
@@ -1971,6 +1971,7 @@ static bool wvb_tables(const fd_wvm_model* md, int NU, WvbTables& T) {
         }
     }
     T.ntile = ntile;
+    T.A.resize((size_t)(ntile + 1) * KSP * 64 * 16, 0);   // a spare zero tile: the operand prefetch runs one tile ahead
     // the chain's per-level records (k_wvb_chain): one dword per lane
     T.rec.assign((size_t)F * 64, 0);
     for (int k = 0; k < NU; ++k) {
@@ -2010,7 +2011,7 @@ static void wvb_build(fd_wvm* m, const fd_wvm_model* md) {
     HIP_CHECK(hipMemset(m->sbCnt.p, 0, 64));
     mv.A = m->wvbA.as<wvb_v4i>(); mv.lvl = m->wvbLvl.as<int4>(); mv.c128 = m->wvbC128.as<int32_t>();
     mv.pp = m->pp.as<double>(); mv.val = m->val.as<double>(); mv.thr = m->thresholds.as<float>(); mv.wR = m->wvbWR.as<float>(); mv.rec = m->wvbRec.as<int32_t>();
-    mv.KS = T.KS; mv.dstride = T.DS; mv.Fr = T.Fr;
+    mv.KS = T.KS; mv.KSP = T.KSP; mv.dstride = T.DS; mv.Fr = T.Fr;
     mv.numPer = md->num_per_level; mv.numUsed = m->dev.numUsed; mv.numFilters = md->num_filters; mv.d = md->filter_w * md->filter_h;
     mv.nphase = T.nphase;
     mv.maxCnt = T.maxCnt;
@@ -3428,7 +3429,7 @@ int64_t fd_debug_wvb_rect_sums(const fd_wvm_model* md, const uint8_t* patches, i
                 for (int ks = 0; ks < T.KS; ++ks)
                     for (int h = 0; h < 2; ++h)
                         for (int t = 0; t < 16; ++t)
-                            acc += (int32_t)T.A[((((size_t)tile * T.KS + ks) * 64) + (size_t)(h * 32 + row)) * 16 + t] * (int32_t)x[(size_t)ks * 32 + h * 16 + t];
+                            acc += (int32_t)T.A[((((size_t)tile * T.KSP + ks) * 64) + (size_t)(h * 32 + row)) * 16 + t] * (int32_t)x[(size_t)ks * 32 + h * 16 + t];
                 out[(size_t)i * ncols + c] = acc + T.c128[(size_t)tile * 32 + row];
             }
         }

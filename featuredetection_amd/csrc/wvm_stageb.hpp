@@ -95,13 +95,13 @@ constexpr int WVB_RECS = 16;   // level records a wavefront keeps in LDS at a ti
 // every stage issues all its loads before it consumes the first: the tile, the records, the operand fragments of a rect-sum tile.
 // MAXV: compile-time bound of the grey values per filter (8 or 16, chosen by the model).
 template <int MAXV>
-__global__ __launch_bounds__(256) void k_wvb_chain(WvbDev mv, WvbState s, int phase, const unsigned int* countPtr) {
+__global__ __launch_bounds__(256, 2) void k_wvb_chain(WvbDev mv, WvbState s, int phase, const unsigned int* countPtr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wvb_lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned int n = wvb_count(countPtr, s);
     const int ntiles = (int)((n + 63u) >> 6);
-    const int NP = mv.numPer, NU = mv.numUsed, KS = mv.KS, DS = mv.dstride;
+    const int NP = mv.numPer, NU = mv.numUsed, KS = mv.KS, KSP = mv.KSP, DS = mv.dstride;
     const int NQ = (NP + 3) >> 2;
     const int set = phase & 1;
     const int g0 = mv.phaseGen[phase], g1 = mv.phaseGen[phase + 1];
@@ -149,7 +149,10 @@ __global__ __launch_bounds__(256) void k_wvb_chain(WvbDev mv, WvbState s, int ph
         WVB_ADD(8 * phase + 0, 1);
         WVB_ADD(8 * phase + 1, tq1 - tq0);
         if (cls < NP) {
-            int curTile = -1;
+            int curTile = -1, ringTile = -1;   // tile whose sums are in Sw; tile whose first eight fragments are in the ring
+            wvb_v4i an[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) an[q] = wvb_v4i{0, 0, 0, 0};
             for (int gb = g0; gb < g1; gb += WVB_RECS) {
                 WVB_T(tq2);
                 // the level records of the next WVB_RECS levels of this class: one coalesced load each, all in flight together
@@ -178,19 +181,23 @@ __global__ __launch_bounds__(256) void k_wvb_chain(WvbDev mv, WvbState s, int ph
                         const int cnt = __builtin_amdgcn_readfirstlane(rc[2]);
                         if (tile != curTile) {
                             // ---- rect sums of the tile's rows for the 64 windows: C[row][window] = sum_pixel M[row][pixel] * x[window][pixel]
-                            curTile = tile;
-                            wvb_v16i acc0 = {}, acc1 = {};
-                            const wvb_v4i* Ap = mv.A + (size_t)tile * KS * 64 + lane;
-                            const unsigned char* xb = wvb_lds + (lane & 31) * DS + (lane >> 5) * 16;
-                            // the tile's operand streams from L2 through a ring of eight fragments
-                            wvb_v4i an[8];
+                            // The operand fragments stream from L2 through a ring of eight that runs one group ahead AND wraps into the next
+                            // tile of the class (tiles of a class are consecutive, KSP is a multiple of eight): when the levels of this tile
+                            // have been chained, the first eight fragments of the next one are already in registers.
+                            const wvb_v4i* Ap = mv.A + (size_t)tile * KSP * 64 + lane;
+                            if (tile != ringTile) {
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) an[q] = Ap[min(q, KS - 1) * 64];
-                            for (int ks = 0; ks < KS; ks += 8) {
+                                for (int q = 0; q < 8; ++q) an[q] = Ap[q * 64];
+                            }
+                            curTile = tile;
+                            ringTile = tile + 1;
+                            wvb_v16i acc0 = {}, acc1 = {};
+                            const unsigned char* xb = wvb_lds + (lane & 31) * DS + (lane >> 5) * 16;
+                            for (int ks = 0; ks < KSP; ks += 8) {
 #pragma unroll
                                 for (int q = 0; q < 8; ++q) {
                                     const wvb_v4i a = an[q];
-                                    an[q] = Ap[min(ks + 8 + q, KS - 1) * 64];
+                                    an[q] = Ap[(ks + 8 + q) * 64];   // past this tile: the next tile's fragments (a zero tile ends the table)
                                     if (ks + q < KS) {
                                         const wvb_v4i b0 = *reinterpret_cast<const wvb_v4i*>(xb + (ks + q) * 32);
                                         const wvb_v4i b1 = *reinterpret_cast<const wvb_v4i*>(xb + 32 * DS + (ks + q) * 32);
