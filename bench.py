@@ -59,10 +59,13 @@ def host_info():
 
 
 def pmc_record(workload, kernel_substr):
-    """Counter figures per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/r02_pmc.json, written by
+    """Counter figures per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/r03_pmc.json, written by
     tools/pmc_summary.py from runs of this script; every entry names the command and the git head it was measured at)."""
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+        path = os.path.join(ROOT, "profiles", "r03_pmc.json")
+        if not os.path.exists(path):
+            path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+        rec = json.load(open(path))
         ks = rec.get(workload, {}).get("kernels", {})
         agg = "k_all(%s)" % kernel_substr
         for k, v in ([(agg, ks[agg])] if agg in ks else []) + list(ks.items()):
@@ -260,32 +263,54 @@ class Cascade(Workload):
             sl["ctx"].synchronize()
 
     def kernel_probe(self):
-        """hipEvent-timed duration of the cascade kernels (all WVM stages) of single-frame calls + the roofline entries"""
+        """hipEvent-timed duration of the dominant kernel (the dense pre-filter over all windows of a call) and of all cascade kernels of
+        a call, the roofline entries, and the single-frame latency of the detector"""
         capi, ctx = self.capi, self.env.ctx
-        ctx.set_kernel_timing(True)
-        ms = []
         nf = self.NB if self.multi else 1
-        for i in range(12):
-            if self.multi:   # the production launch: one cascade run over the NB frames of a call
-                sl = self.slots[0]
-                sl["pyr"].update_frames(device_ptrs=[self.dframes[(i + j) % self.NFR].data_ptr() for j in range(nf)], w=self.W, h=self.H, ch=3)
-                capi.detect_five_stage_frames(ctx, sl["pyr"], sl["wvm"], sl["svm"], nf)
-            else:
-                self.pyrs[0].update_device(self.dframes[i % self.NFR].data_ptr(), self.W, self.H, 3)
-                capi.detect_five_stage(ctx, self.pyrs[0], self.wvms[0], self.svm)
-            ms.append(ctx.last_kernel_ms()[1])
+        times = {}
+        for mode in (2, 1):   # 2: k_wvm_prefilter alone; 1: every WVM kernel of the call (pre-filter + stage B)
+            ctx.set_kernel_timing(mode)
+            ms = []
+            for i in range(12):
+                if self.multi:   # the production launch: one cascade run over the NB frames of a call
+                    sl = self.slots[0]
+                    sl["pyr"].update_frames(device_ptrs=[self.dframes[(i + j) % self.NFR].data_ptr() for j in range(nf)], w=self.W, h=self.H, ch=3)
+                    capi.detect_five_stage_frames(ctx, sl["pyr"], sl["wvm"], sl["svm"], nf)
+                else:
+                    self.pyrs[0].update_device(self.dframes[i % self.NFR].data_ptr(), self.W, self.H, 3)
+                    capi.detect_five_stage(ctx, self.pyrs[0], self.wvms[0], self.svm)
+                ms.append(ctx.last_kernel_ms()[1])
+            times[mode] = float(np.mean(ms[2:]))
         ctx.set_kernel_timing(False)
-        kms = float(np.mean(ms[2:]))
+        kms = times[2]
         bytes_per_launch = nf * (self.layer_bytes + self.nwin * 16)
         ach = bytes_per_launch / (kms * 1e-3) / 1e9
-        pm = pmc_record("cascade" if (self.W, self.H) == (640, 480) else "cascade_%dx%d" % (self.W, self.H), "k_wvm")
-        roof = dict(bound="hbm", kernel="k_wvm_prefilter + stage B (k_wvb_prepare / _chain / _sums / _exit): one cascade run over the %d frames of a call" % nf, achieved=ach,
-                    peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=pm.get("hbm_bytes") if pm else None, kernel_ms=kms,
+        pm = pmc_record("cascade" if (self.W, self.H) == (640, 480) else "cascade_%dx%d" % (self.W, self.H), "k_wv")
+        pmk = pmc_record("cascade" if (self.W, self.H) == (640, 480) else "cascade_%dx%d" % (self.W, self.H), "k_wvm_prefilter")
+        roof = dict(bound="hbm", kernel="k_wvm_prefilter<20, 20> (HistEq64 + the first cascade levels of every window of the %d frames of a call; the "
+                    "dominant kernel)" % nf, achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
+                    traffic=pmk.get("hbm_bytes") if pmk else None, kernel_ms=kms, cascade_kernels_ms=times[1],
                     algorithmic="%d frames x (%d layer bytes + 16 B record x %d windows) per launch (SURVEY 8(d))" % (nf, self.layer_bytes, self.nwin))
         extra = {}
         if pm and pm.get("valu_issue_frac"):
             extra["roofline_issue"] = issue_roofline(pm)
+        if (self.W, self.H) == (640, 480) and self.profile == "default":
+            extra["latency_us_single_frame"] = self.single_frame_latency()
         return roof, extra
+
+    def single_frame_latency(self, n=400):
+        """one frame resident in HBM -> its detections on the host, one frame at a time (fd_pyramid_update + fd_detect_five_stage)"""
+        capi, ctx = self.capi, self.env.ctx
+        pyr, wvm = self.pyrs[0], self.wvms[0]
+        lat = []
+        for i in range(n + 40):
+            t0 = time.perf_counter()
+            pyr.update_device(self.dframes[i % self.NFR].data_ptr(), self.W, self.H, 3)
+            capi.detect_five_stage(ctx, pyr, wvm, self.svm)
+            lat.append((time.perf_counter() - t0) * 1e6)
+        lat = np.array(lat[40:])
+        return dict(p50=float(np.percentile(lat, 50)), p99=float(np.percentile(lat, 99)), frames=n,
+                    what="blocking per frame through the Python ctypes binding: pyramid update + five-stage cascade, detections delivered")
 
     def cpu_baseline(self):
         from oracle import pyoracle as O
@@ -535,23 +560,29 @@ class Ffp15(Workload):
         return out
 
     def kernel_probe(self):
-        """FaceFrontal's cascade kernels on the 1080p frame (single five-stage call) + the batch's issue roofline from the PMC passes"""
+        """the dominant kernel of the batch -- k_wvm_prefilter<24, 24> of one of the seven 24x24 detectors on the 1080p frame, timed
+        alone with HIP events -- + the batch's issue roofline from the PMC passes"""
         capi, ctx = self.capi, self.env.ctx
-        name, pr, wv, sv_, pw, ph = [d for d in self.dets if d[0] == "FaceFrontal"][0]
-        ctx.set_kernel_timing(True)
-        ms = []
-        for i in range(6):
-            pr.update_device(self.dframes[i % 2].data_ptr(), self.W, self.H, 3)
-            capi.detect_five_stage(ctx, pr, wv, sv_)
-            ms.append(ctx.last_kernel_ms()[1])
+        name, pr, wv, sv_, pw, ph = [d for d in self.dets if (d[4], d[5]) == (24, 24)][0]
+        times = {}
+        for mode in (2, 1):
+            ctx.set_kernel_timing(mode)
+            ms = []
+            for i in range(6):
+                pr.update_device(self.dframes[i % 2].data_ptr(), self.W, self.H, 3)
+                capi.detect_five_stage(ctx, pr, wv, sv_, cap=1 << 14)
+                ms.append(ctx.last_kernel_ms()[1])
+            times[mode] = float(np.mean(ms[1:]))
         ctx.set_kernel_timing(False)
-        kms = float(np.mean(ms[1:]))
+        kms = times[2]
         nwin = pr.window_count(pw, ph, 1, 1)
         layer_bytes = sum(l["w"] * l["h"] for l in pr.layers())
         ach = (layer_bytes + 16 * nwin) / (kms * 1e-3) / 1e9
-        pm = pmc_record("ffp15", "k_wvm") if (self.W, self.H) == (1920, 1080) else None
-        roof = dict(bound="hbm", kernel="k_wvm_* of the FaceFrontal detector (single call, %d windows)" % nwin, achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s",
-                    frac=ach / PEAK_HBM_GBS, traffic=None, kernel_ms=kms,
+        pm = pmc_record("ffp15", "k_wv") if (self.W, self.H) == (1920, 1080) else None
+        pmk = pmc_record("ffp15", "k_wvm_prefilter") if (self.W, self.H) == (1920, 1080) else None
+        roof = dict(bound="hbm", kernel="k_wvm_prefilter<24, 24> of the %s detector (%d windows; the 24x24 pre-filters are the largest share of the "
+                    "batch's kernel time)" % (name, nwin), achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s",
+                    frac=ach / PEAK_HBM_GBS, traffic=pmk.get("hbm_bytes") if pmk else None, kernel_ms=kms, cascade_kernels_ms=times[1],
                     algorithmic="%d layer bytes + 16 B record x %d windows" % (layer_bytes, nwin))
         extra = {}
         if pm and pm.get("valu_issue_frac"):

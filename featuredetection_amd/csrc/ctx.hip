@@ -78,6 +78,7 @@ int fd_ctx_synchronize(fd_ctx* ctx) {
 int fd_ctx_set_kernel_timing(fd_ctx* ctx, int enable) {
     if (!ctx) return FD_ERR_INVALID_ARGUMENT;
     ctx->kernel_timing = enable != 0;
+    ctx->kernel_timing_mode = enable == 2 ? 2 : 1;
     return FD_OK;
 }
 

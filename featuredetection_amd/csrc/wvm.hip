@@ -2290,6 +2290,10 @@ static void wvm_launch_table(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm*
     if (!want_all && m->denseL) {
         if (direct) {
             skipA = launch_prefilter(ctx, st, m, p->arena.as<uint8_t>(), wt, o.deep_q, o.deep_count);
+            if (skipA && time_kernel && ctx->kernel_timing_mode == 2) {   // bench hook: the pre-filter alone
+                HIP_CHECK(hipEventRecord(ctx->ev1, st));
+                time_kernel = false;
+            }
         } else {
             m->pre_q.reserve(sizeof(int64_t) * (size_t)wt.total);
             if (launch_prefilter(ctx, st, m, p->arena.as<uint8_t>(), wt, m->pre_q.as<int64_t>(), m->pos.as<unsigned int>() + 2)) {

@@ -11,7 +11,7 @@ extern "C" {
 
 /* enable != 0: the detect entry points (fd_detect_five_stage, fd_detect_wvm, fd_detect_hog_svm[_begin/_end], fd_sdm_fit_batch)
  * bracket their dominant kernel(s) with two hipEvents on the context's stream. */
-int fd_ctx_set_kernel_timing(fd_ctx* ctx, int enable);
+int fd_ctx_set_kernel_timing(fd_ctx* ctx, int enable);   /* enable == 2: WVM cascades bracket the dense pre-filter kernel only */
 /* duration (ms) between those events for the last timed call on this context and the name of the bracketed kernel(s) */
 int fd_last_kernel_ms(fd_ctx* ctx, const char** kernel_name, float* ms);
 
