@@ -833,7 +833,7 @@ def measure(wl, env, steps, warmup, gather_every, want_cpu):
     if world > 1:
         rec["records_gathered"] = gathered
         rec["records_truncated"] = bool(truncated)
-    probe = wl.kernel_probe() if env.rank == 0 else None
+    probe = wl.kernel_probe() if (env.rank == 0 and not getattr(env, "no_probe", False)) else None
     if probe:
         rec["roofline"] = probe[0]
         rec.update(probe[1])
@@ -870,6 +870,8 @@ def main():
     ap.add_argument("--per-frame-launches", action="store_true", help="cascade workload: one pyramid + cascade per frame (fd_detect_five_stage_batch) "
                                                                       "instead of the multi-frame entry points")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true", help="skip kernel_probe (the HIP-event timing of the dominant kernel and the single-frame "
+                                                            "latency loop): profiler runs want the timed steps' launches only")
     args = ap.parse_args()
     if args.workload == "wvm":
         args.workload = "cascade"
@@ -917,6 +919,7 @@ def main():
         also = "hog_svm,ffp15,sdm,cascade_late,cascade_group" if (args.workload == "cascade" and not args.size) else "none"
     also = [a for a in also.split(",") if a and a != "none"]
     want_cpu = not args.no_cpu_baseline
+    env.no_probe = args.no_probe
 
     wl = build(args.workload, True)
     res = measure(wl, env, args.steps, args.warmup, args.gather_every, want_cpu)

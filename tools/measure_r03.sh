@@ -23,7 +23,7 @@ if [ "$WHAT" = stats ] || [ "$WHAT" = all ]; then
     # the same way
     ENVX=""; case $wl in cascade*) ENVX="env FD_BENCH_SLOTS=1 FD_FRAMES_ASYNC=0";; esac
     [ $wl = sdm ] && ENVX="env FD_BENCH_SDM_INFLIGHT=1"   # same reason
-    timeout 300 $ENVX rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$wl -- $B --workload $wl --also none --steps $S --warmup 2 $FP --no-cpu-baseline > $O/stats_$wl.json 2> $O/stats_$wl.err
+    timeout 300 $ENVX rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$wl -- $B --workload $wl --also none --steps $S --warmup 2 $FP --no-cpu-baseline --no-probe > $O/stats_$wl.json 2> $O/stats_$wl.err
     f=$(find $O/stats_$wl -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/r03_${wl}_kernel_stats.csv
     rm -rf $O/stats_$wl
   done
@@ -32,7 +32,7 @@ fi
 if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
   for wl in cascade ffp15 sdm hog_svm; do
     S=3; FP=""; [ $wl = cascade ] && FP="--frames-per-step 64"; [ $wl = ffp15 ] && S=2; [ $wl = sdm ] && FP="--frames-per-step 2"; [ $wl = hog_svm ] && FP="--frames-per-step 4"
-    CMD="$B --workload $wl --also none --steps $S --warmup 1 $FP --no-cpu-baseline"
+    CMD="$B --workload $wl --also none --steps $S --warmup 1 $FP --no-cpu-baseline --no-probe"
     i=0
     for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" \
                "SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES" \
@@ -41,7 +41,7 @@ if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
       timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc_${wl}_$i -- $CMD > /dev/null 2> $O/pmc_${wl}_$i.err
     done
     K=k_wv; [ $wl = sdm ] && K=k_sdm_descriptors; [ $wl = hog_svm ] && K=k_svm_rbf_mfma
-    python $R/tools/pmc_summary.py $wl $O/r03_pmc.json $K "rocprofv3 --kernel-trace --pmc <group> (4 separate passes) -- python bench.py --workload $wl --also none --steps $S --warmup 1 $FP --no-cpu-baseline; git head $HEAD" $O/pmc_${wl}_1 $O/pmc_${wl}_2 $O/pmc_${wl}_3 $O/pmc_${wl}_4 > $O/pmc_$wl.summary 2>&1
+    python $R/tools/pmc_summary.py $wl $O/r03_pmc.json $K "rocprofv3 --kernel-trace --pmc <group> (4 separate passes) -- python bench.py --workload $wl --also none --steps $S --warmup 1 $FP --no-cpu-baseline --no-probe; git head $HEAD" $O/pmc_${wl}_1 $O/pmc_${wl}_2 $O/pmc_${wl}_3 $O/pmc_${wl}_4 > $O/pmc_$wl.summary 2>&1
     rm -rf $O/pmc_${wl}_1 $O/pmc_${wl}_2 $O/pmc_${wl}_3 $O/pmc_${wl}_4
   done
 fi
