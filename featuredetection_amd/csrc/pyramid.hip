@@ -414,14 +414,18 @@ __global__ __launch_bounds__(256) void k_resize_down(uint8_t* __restrict__ arena
     }
 }
 
-// the tiles tileBegin, tileBegin + tileStep, ... of one pyrDown (src: sw x sh -> dst); `tile` = the workgroup's LDS stage
-__device__ __forceinline__ void pyrdown_tiles(uint8_t* __restrict__ tile, const uint8_t* __restrict__ src, int sw, int sh, uint8_t* __restrict__ dst,
-                                              int tileBegin, int tileStep) {
+__global__ __launch_bounds__(256) void k_pyrdown_tiled(uint8_t* __restrict__ arena, DownJobs jobs, size_t imageStride) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[TL_ROWS * TL_PITCH];
+    const DownJob jb = jobs.j[blockIdx.y];
+    const int sw = jb.sw, sh = jb.sh;
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+    arena += (size_t)blockIdx.z * imageStride;   // blockIdx.z = frame of a multi-frame pyramid
+    const uint8_t* src = arena + jb.src_off;
+    uint8_t* dst = arena + jb.dst_off;
     const int tilesX = (dw + TL_W - 1) / TL_W, tilesY = (dh + PD_TH - 1) / PD_TH;
     const int c = threadIdx.x & 63, rq = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // rq scalar: row offsets on the scalar unit
     constexpr int NDW = (2 * TL_W + 3 + 3) / 4, NROWS = 2 * PD_TH + 3;   // 131 source columns, 35 source rows per tile
-    for (int t = tileBegin; t < tilesX * tilesY; t += tileStep) {
+    for (int t = blockIdx.x; t < tilesX * tilesY; t += gridDim.x) {
         const int ty = t / tilesX, tx = t - ty * tilesX;
         const int dx0 = tx * TL_W, dy0 = ty * PD_TH;
         const int X0 = 2 * dx0 - 2, Y0 = 2 * dy0 - 2;
@@ -478,38 +482,6 @@ __device__ __forceinline__ void pyrdown_tiles(uint8_t* __restrict__ tile, const 
             }
         }
         __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(256) void k_pyrdown_tiled(uint8_t* __restrict__ arena, DownJobs jobs, size_t imageStride) {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[TL_ROWS * TL_PITCH];
-    const DownJob jb = jobs.j[blockIdx.y];
-    arena += (size_t)blockIdx.z * imageStride;   // blockIdx.z = frame of a multi-frame pyramid
-    pyrdown_tiles(tile, arena + jb.src_off, jb.sw, jb.sh, arena + jb.dst_off, blockIdx.x, gridDim.x);
-}
-
-// The deeper generations of one chain (pyrDown of pyrDown ...) by ONE workgroup: their layers are small (640x480 frames: 19 k, 4.8 k,
-// 1.2 k pixels) and each generation needs the whole previous one, so as separate launches they were three dependent, latency-bound
-// kernels per call (37 + 15 + 5 us for 64 frames).  A workgroup writes a generation, synchronises (its own stores are visible to it
-// after the barrier) and reads it back as the next source.  blockIdx.x = chain, blockIdx.y = frame.
-struct ChainJob {
-    int sw, sh, n;             // size of the first source layer, generations to compute
-    uint32_t off[6];           // arena offsets: source, then the n destinations
-};
-struct ChainJobs {
-    int n;
-    ChainJob j[MAXJ];
-};
-__global__ __launch_bounds__(256) void k_pyrdown_chain(uint8_t* __restrict__ arena, ChainJobs jobs, size_t imageStride) {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[TL_ROWS * TL_PITCH];
-    const ChainJob jb = jobs.j[blockIdx.x];
-    arena += (size_t)blockIdx.y * imageStride;
-    int sw = jb.sw, sh = jb.sh;
-    for (int d = 0; d < jb.n; ++d) {
-        pyrdown_tiles(tile, arena + jb.off[d], sw, sh, arena + jb.off[d + 1], 0, 1);   // ends with a barrier
-        __threadfence_block();
-        sw = (sw + 1) / 2;
-        sh = (sh + 1) / 2;
     }
 }
 
@@ -979,36 +951,8 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
         }
         flush1();
     }
-    // chains whose generations >= 2 are small: all of them in one launch, one workgroup per (chain, frame)
-    std::vector<char> chained(p->all.size(), 0);
-    {
-        // Off unless FD_PYR_CHAIN=1: measured on the headline (64 frames of 640x480 per call), one workgroup walking the 32 tiles of a
-        // chain's generations 2-4 takes 160 us against 57 us for the three per-generation launches (512 long-running workgroups with a
-        // serial tile loop instead of thousands of short ones), and a single frame's 8 workgroups add 110 us of latency.
-        static const bool off = [] { const char* e = getenv("FD_PYR_CHAIN"); return !(e && atoi(e) == 1); }();
-        ChainJobs jobs;
-        jobs.n = 0;
-        auto flush = [&]() {
-            if (!jobs.n) return;
-            hipLaunchKernelGGL(k_pyrdown_chain, dim3(jobs.n, NI), dim3(256), 0, st, arena, jobs, IS);
-            jobs.n = 0;
-        };
-        for (size_t k = 0; !off && k + 1 < p->all.size(); ++k) {
-            const HostLayer& S = p->all[k];
-            if (S.depth != 1 || p->all[k + 1].depth != 2 || p->all[k + 1].chain != S.chain) continue;
-            if ((int64_t)p->all[k + 1].w * p->all[k + 1].h > 40000) continue;   // larger layers keep one launch per generation (many workgroups)
-            ChainJob& j = jobs.j[jobs.n];
-            j.sw = S.w; j.sh = S.h; j.n = 0;
-            j.off[0] = S.gray_off;
-            for (size_t q = k + 1; q < p->all.size() && p->all[q].chain == S.chain && p->all[q].depth == j.n + 2 && j.n < 5; ++q) {
-                j.off[++j.n] = p->all[q].gray_off;
-                chained[q] = 1;
-            }
-            ++jobs.n;
-            if (jobs.n == MAXJ) flush();
-        }
-        flush();
-    }
+    // (One workgroup walking all deeper generations of a chain -- no launches between them -- was measured and dropped: 160 us per
+    // 64-frame call against 57 us for the per-generation launches, and +110 us of single-frame latency: 32 serial tiles per workgroup.)
     for (int d = 2; d <= maxDepth; ++d) {
         DownJobs jobs;
         jobs.n = 0;
@@ -1022,7 +966,7 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
         };
         for (size_t k = 0; k < p->all.size(); ++k) {
             const HostLayer& L = p->all[k];
-            if (L.depth != d || chained[k]) continue;   // chained: done by k_pyrdown_chain
+            if (L.depth != d) continue;
             const HostLayer& S = p->all[k - 1];  // previous entry of the same chain
             DownJob& j = jobs.j[jobs.n++];
             j.sw = S.w; j.sh = S.h; j.src_off = S.gray_off; j.dst_off = L.gray_off;
