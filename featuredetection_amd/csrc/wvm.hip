@@ -2056,7 +2056,8 @@ static void launch_prefilter_sized(fd_ctx* ctx, hipStream_t st, const uint8_t* a
     if (perCu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wvm_prefilter<PW_, PH_>, 256, 0) != hipSuccess || perCu < 1)) perCu = 2;
     // rounds of resident workgroups the tiles are dealt over (FD_WVD_ROUNDS, default 2)
     static const int rounds = [] { const char* e = getenv("FD_WVD_ROUNDS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
-    const int grid = (int)std::min<int64_t>(((int64_t)wt.ntiles + 3) / 4, (int64_t)ctx->num_cus * perCu * rounds);
+    int grid = (int)std::min<int64_t>(((int64_t)wt.ntiles + 3) / 4, (int64_t)ctx->num_cus * perCu * rounds);
+    if (wt.nimg >= 8 && grid >= 64) grid &= ~7;   // a multiple of the 8 XCDs: the kernel then keeps every frame on one XCD
     hipLaunchKernelGGL((k_wvm_prefilter<PW_, PH_>), dim3(grid), dim3(256), 0, st, arena, wt, dv);
 }
 

@@ -150,10 +150,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
     const unsigned int laneOff16 = laneOff32 + (unsigned int)(lane >> 5) * 2u;
     const unsigned int inc = 1u << (16 * (lane >> 5));
 
-    int lastImg = 0;
-    for (int gtile = blockIdx.x * 4 + wave; gtile < ntiles; gtile += gridDim.x * 4) {
-        const int img = wt.nimg > 1 ? gtile / wt.tilesPerImage : 0;   // frame of a multi-frame pyramid
-        const int tile = gtile - img * wt.tilesPerImage;
+    int lastImg = -1;
+    // Multi-frame pyramids: workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on it), and every XCD has its own
+    // L2.  With the plain round-robin every L2 pulled the layers of ALL frames across the fabric (162 MB per 64-frame call against
+    // 2.5 MB of kept layers); here XCD x takes the frames x, x + 8, ...: each frame's layers live in one L2.
+    const bool byXcd = wt.nimg >= 8 && (gridDim.x & 7u) == 0;
+    const int xcd = blockIdx.x & 7, vStride = byXcd ? (int)(gridDim.x >> 3) * 4 : (int)gridDim.x * 4;
+    const int vEnd = byXcd ? ((wt.nimg - xcd + 7) >> 3) * wt.tilesPerImage : ntiles;
+    for (int v = (byXcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x) * 4 + wave; v < vEnd; v += vStride) {
+        const int fi = wt.nimg > 1 ? v / wt.tilesPerImage : 0;
+        const int img = byXcd ? xcd + 8 * fi : fi;   // frame of a multi-frame pyramid
+        const int tile = v - fi * wt.tilesPerImage;
         if (img != lastImg) { li = 0; lastImg = img; }
         while (li + 1 < wt.n && tile >= wt.l[li + 1].tileFirst) ++li;   // tiles ascend per wavefront inside a frame
         const WvdLayer& wl = wt.l[li];
