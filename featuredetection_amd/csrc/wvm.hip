@@ -3403,6 +3403,12 @@ void fd_debug_wvb_prof(unsigned long long* out, int reset) {
     if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(fd_wvb_prof), sizeof(unsigned long long) * 64);
     if (reset) { unsigned long long z[64] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(fd_wvb_prof), z, sizeof(z)); }
 }
+// tools/wvd_residency.py: the per-wavefront records of the LAST k_wvm_prefilter launch (see wvm_dense.hpp); returns the record capacity
+int fd_debug_wvd_prof(unsigned long long* out, int nwaves) {
+    if (nwaves > WVD_PROF_WAVES) nwaves = WVD_PROF_WAVES;
+    if (out && nwaves > 0) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(fd_wvd_prof), sizeof(unsigned long long) * 8 * (size_t)nwaves);
+    return WVD_PROF_WAVES;
+}
 #endif
 
 // Test hook (include/fd_hip_bench.h; needs no GPU): the rect sums of every used level of `md` for n equalised patches, computed from

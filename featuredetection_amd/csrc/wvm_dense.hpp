@@ -76,6 +76,16 @@ struct WvdMulti {
 
 namespace {
 
+// -DFD_WVB_PROF (tools/build_prof_lib.sh, tools/wvd_residency.py): every wavefront of k_wvm_prefilter leaves {start, end, HW_ID | XCC_ID << 32,
+// tiles, ticks in: histogram, cdf + LUT, equalise + MFMA, transposes + levels + queue} (s_memtime ticks of the shader clock)
+#ifdef FD_WVB_PROF
+constexpr int WVD_PROF_WAVES = 16384;
+__device__ unsigned long long fd_wvd_prof[WVD_PROF_WAVES * 8];
+#define WVD_T(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
+#else
+#define WVD_T(x)
+#endif
+
 template <int PW_>
 struct WvdGeo {
 #ifndef FD_WVD_RPS16
@@ -93,14 +103,61 @@ struct WvdGeo {
     static constexpr int WPE = (PW_ == 16 && RPS == 2) ? 3 : FD_WVD_WPE;
 };
 
-// LDS of a workgroup (4 wavefronts).  Every wavefront's histogram block is 8 KB-aligned so that (bin << 7) | (block + lane slot)
-// is a complete LDS address; after the MFMA loop the block holds the transposed dot products [window][filter] as doubles, row
-// stride 16 with the column XOR-swizzled by the row (2-way bank conflicts at most).
-struct __attribute__((aligned(8192))) WvdLds {
-    unsigned short hist[4][64][64];                  // [wave][bin][slot of the lane]: counters, then the lane's LUT
+// LDS of a workgroup (4 wavefronts).  Histogram rows are 256 B: [wave pair][bin][wave of the pair][lane & 31] dwords, the u16 counters
+// of lanes l (low half) and l + 32 (high half) in one dword.  With the pair's block 16 KB-aligned, the LDS address of (bin, lane) is
+// {byte 3: 0, byte 2: lane word, byte 1: bin | block bits, byte 0: lane word}: ONE v_perm_b32 per pixel takes the bin byte out of a
+// dword of four pre-shifted pixels and drops it into the lane's address word (wvd_bins / wvd_addr; 1.5 VALU per pixel instead of 2).
+// After the MFMA loop a wavefront's 64 half rows hold the transposed dot products [window][filter] as doubles (one window per half
+// row, the column XOR-swizzled by the row: 2-way bank conflicts at most).
+struct WvdLds {   // the variable is 16 KB-aligned (not the type: 40 KB must stay 40 KB, four workgroups per CU)
+    unsigned int hist[2][64][2][32];                 // counters, then the lane's LUT in the low byte of its u16, then the transposes
     unsigned char x[4][2][64 * 16];                  // [wave][plane] current k-step: the equalised pixels of every window, as x - 128
 };
-static_assert(sizeof(unsigned short[64][64]) == 8192 && sizeof(double) * 64 * 16 == 8192, "transpose buffer aliases one histogram block");
+static_assert(sizeof(unsigned int[64][2][32]) == 16384, "one 16 KB block per pair of wavefronts, 256 B per bin");
+
+typedef __attribute__((address_space(3))) unsigned char wvd_lds_u8;
+typedef unsigned short wvd_u16x2 __attribute__((ext_vector_type(2)));
+// the four bins (pixel >> 2) of a dword of pixels, each OR-ed with the block bits of the address byte
+__device__ __forceinline__ unsigned int wvd_bins(unsigned int w4, unsigned int blk4) { return ((w4 >> 2) & 0x3F3F3F3Fu) | blk4; }
+// LDS address of (bin of pixel B_, this lane): laneWord has byte 1 clear
+template <int B_>
+__device__ __forceinline__ unsigned int wvd_addr(unsigned int bins, unsigned int laneWord) {
+    return __builtin_amdgcn_perm(bins, laneWord, 0x0c020000u | ((4u + B_) << 8));   // {0, laneWord.b2, bins.b[B_], laneWord.b0}
+}
+// Equalise N_ dwords of pixels (N_ = 3, 4, 5) through the lane's LUT: out[j] = the four LUT bytes of w[j].  Written out as one block so
+// that all 4 N_ ds_read_u8 are in flight together and the wavefront waits for the LDS once (the compiler's schedule under this
+// kernel's register pressure waited after every second read); the address registers double as the read destinations.
+// Per dword: shift, and-or, 4 address perms, 4 reads, 3 packing perms.
+#define WVD_EQ_ISSUE(j)                                                                                   \
+    "v_lshrrev_b32 %[t], 2, %[w" #j "]\n v_and_or_b32 %[t], %[t], %[mask], %[blk]\n"                     \
+    "v_perm_b32 %[a" #j "], %[t], %[lane], %[s0]\n v_perm_b32 %[b" #j "], %[t], %[lane], %[s1]\n"          \
+    "v_perm_b32 %[c" #j "], %[t], %[lane], %[s2]\n v_perm_b32 %[d" #j "], %[t], %[lane], %[s3]\n"          \
+    "ds_read_u8 %[a" #j "], %[a" #j "]\n ds_read_u8 %[b" #j "], %[b" #j "]\n"                              \
+    "ds_read_u8 %[c" #j "], %[c" #j "]\n ds_read_u8 %[d" #j "], %[d" #j "]\n"
+#define WVD_EQ_PACK(j)                                                                                    \
+    "v_perm_b32 %[a" #j "], %[b" #j "], %[a" #j "], %[sp]\n v_perm_b32 %[c" #j "], %[d" #j "], %[c" #j "], %[sp]\n" \
+    "v_perm_b32 %[a" #j "], %[c" #j "], %[a" #j "], %[sq]\n"
+#define WVD_EQ_OUT(j) [a##j] "=&v"(out[j]), [b##j] "=&v"(tb[j]), [c##j] "=&v"(tc[j]), [d##j] "=&v"(td[j])
+#define WVD_EQ_IN [lane] "v"(laneWord), [blk] "v"(blk4), [mask] "s"(0x3F3F3F3Fu), [s0] "s"(0x0c020400u), [s1] "s"(0x0c020500u), \
+                  [s2] "s"(0x0c020600u), [s3] "s"(0x0c020700u), [sp] "s"(0x0c0c0400u), [sq] "s"(0x05040100u)
+template <int N_>
+__device__ __forceinline__ void wvd_equalise(const unsigned int* w, unsigned int* out, unsigned int laneWord, unsigned int blk4) {
+    static_assert(N_ >= 3 && N_ <= 5, "block sizes");
+    unsigned int t, tb[N_], tc[N_], td[N_];
+    if constexpr (N_ == 3)
+        asm volatile(WVD_EQ_ISSUE(0) WVD_EQ_ISSUE(1) WVD_EQ_ISSUE(2) "s_waitcnt lgkmcnt(0)\n" WVD_EQ_PACK(0) WVD_EQ_PACK(1) WVD_EQ_PACK(2)
+                     : [t] "=&v"(t), WVD_EQ_OUT(0), WVD_EQ_OUT(1), WVD_EQ_OUT(2)
+                     : [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), WVD_EQ_IN);
+    if constexpr (N_ == 4)
+        asm volatile(WVD_EQ_ISSUE(0) WVD_EQ_ISSUE(1) WVD_EQ_ISSUE(2) WVD_EQ_ISSUE(3) "s_waitcnt lgkmcnt(0)\n" WVD_EQ_PACK(0) WVD_EQ_PACK(1) WVD_EQ_PACK(2) WVD_EQ_PACK(3)
+                     : [t] "=&v"(t), WVD_EQ_OUT(0), WVD_EQ_OUT(1), WVD_EQ_OUT(2), WVD_EQ_OUT(3)
+                     : [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), WVD_EQ_IN);
+    if constexpr (N_ == 5)
+        asm volatile(WVD_EQ_ISSUE(0) WVD_EQ_ISSUE(1) WVD_EQ_ISSUE(2) WVD_EQ_ISSUE(3) WVD_EQ_ISSUE(4) "s_waitcnt lgkmcnt(0)\n"
+                     WVD_EQ_PACK(0) WVD_EQ_PACK(1) WVD_EQ_PACK(2) WVD_EQ_PACK(3) WVD_EQ_PACK(4)
+                     : [t] "=&v"(t), WVD_EQ_OUT(0), WVD_EQ_OUT(1), WVD_EQ_OUT(2), WVD_EQ_OUT(3), WVD_EQ_OUT(4)
+                     : [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[4]), WVD_EQ_IN);
+}
 
 __device__ __forceinline__ unsigned int wvd_load_u32(const uint8_t* p) {
     unsigned int v;
@@ -133,7 +190,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
     static_assert(PH_ % RPS == 0, "whole k-steps");
     constexpr int KS = PH_ / RPS;
     constexpr int NW = PW_ / 4;          // dwords per patch row
-    __shared__ WvdLds S;
+    __shared__ __attribute__((aligned(16384))) WvdLds S;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // constant address space: scalar loads (SMEM) even though the kernel also stores to global memory
@@ -141,16 +198,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
     const int L = dv.L;
     const int ntiles = wt.ntiles;
     int li = 0;
-    unsigned char* histPtr = reinterpret_cast<unsigned char*>(&S.hist[wave][0][0]);
+    unsigned char* histPtr = reinterpret_cast<unsigned char*>(&S.hist[wave >> 1][0][wave & 1][0]);   // this wavefront's half rows, 256 B apart
     unsigned char* xPtr = &S.x[wave][0][0];
-    double* trPtr = reinterpret_cast<double*>(histPtr);
-    const unsigned int histLds = (unsigned int)(uintptr_t)(wvd_lds_u16*)&S.hist[wave][0][0];   // LDS byte address, 8 KB-aligned
+    double* trPtr = reinterpret_cast<double*>(histPtr);   // window r: trPtr[r * 32 ..]
+    const unsigned int histLds = (unsigned int)(uintptr_t)(wvd_lds_u16*)histPtr;   // LDS byte address: 16 KB block + (wave & 1) * 128
+    const unsigned int blk4 = ((histLds >> 8) & 0xC0u) * 0x01010101u;               // block bits of the address byte, for all four pixels
     // lanes l and l + 32 share a dword of every bin row: they are served in different LDS cycles, so nothing conflicts
-    const unsigned int laneOff32 = histLds + (unsigned int)(lane & 31) * 4u;
+    const unsigned int laneOff32 = (histLds & ~0xFF00u) + (unsigned int)(lane & 31) * 4u;
     const unsigned int laneOff16 = laneOff32 + (unsigned int)(lane >> 5) * 2u;
     const unsigned int inc = 1u << (16 * (lane >> 5));
 
     int lastImg = -1;
+#ifdef FD_WVB_PROF
+    const unsigned long long pT0 = __builtin_amdgcn_s_memtime();
+    unsigned long long pAcc[4] = {0, 0, 0, 0}, pTiles = 0;
+#endif
     // Multi-frame pyramids: workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on it), and every XCD has its own
     // L2.  With the plain round-robin every L2 pulled the layers of ALL frames across the fabric (162 MB per 64-frame call against
     // 2.5 MB of kept layers); here XCD x takes the frames x, x + 8, ...: each frame's layers live in one L2.
@@ -174,18 +236,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
         const uint8_t* src = arena + (size_t)img * wt.imageStride + wl.off + (size_t)(wl.by + (int)iy * wt.sy) * lw + (wl.bx + (int)ix * wt.sx);
         const int64_t wid = (int64_t)img * wt.perImage + wl.first + local;
 
+        WVD_T(pa);
         // ---- 1. histogram: 64 bins x 64 lanes of u16 counters
         {
-            uint4* z = reinterpret_cast<uint4*>(histPtr);
+            unsigned char* z = histPtr + (lane >> 3) * 256 + (lane & 7) * 16;   // 8 rows of 128 B per step
 #pragma unroll
-            for (int i = 0; i < 8; ++i) z[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(z + i * 2048) = make_uint4(0, 0, 0, 0);
         }
         __builtin_amdgcn_wave_barrier();
         {
             unsigned int wn[NW];
 #pragma unroll
             for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(src + 4 * j);
-#pragma unroll 1
+#pragma unroll 2
             for (int r = 0; r < PH_; ++r) {   // one patch row per iteration, the next row's loads in flight
                 unsigned int w4[NW];
 #pragma unroll
@@ -195,38 +258,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
                 for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(nsrc + 4 * j);
 #pragma unroll
                 for (int j = 0; j < NW; ++j) {
-                    wvd_count(wvd_slot<0>(w4[j], laneOff32), inc);
-                    wvd_count(wvd_slot<1>(w4[j], laneOff32), inc);
-                    wvd_count(wvd_slot<2>(w4[j], laneOff32), inc);
-                    wvd_count(wvd_slot<3>(w4[j], laneOff32), inc);
+                    const unsigned int bins = wvd_bins(w4[j], blk4);
+                    wvd_count(wvd_addr<0>(bins, laneOff32), inc);
+                    wvd_count(wvd_addr<1>(bins, laneOff32), inc);
+                    wvd_count(wvd_addr<2>(bins, laneOff32), inc);
+                    wvd_count(wvd_addr<3>(bins, laneOff32), inc);
                 }
             }
         }
         wave_sync();
+        WVD_T(pb);
         // ---- 2. the fp32 cdf in the reference's order (cdf[0] = pdf[0]; cdf[b] = cdf[b-1] + pdf[b]), the LUT, and the exact
         //         integer sum / sum of squares of the equalised patch
+        // The LUT keeps e + 128 (low byte = e - 128 as int8, what the contraction wants); the sums are taken over e + 128 too and
+        // corrected once.  e <= 255 without the reference's (uchar) cast: the counts add up to PW_ * PH_ and stretch = 255 / (PW_ * PH_),
+        // so cdf <= 255 (1 + 66 * 2^-24) < 255.5.
         unsigned int sumx = 0, sumxx = 0;
         {
             float cdf = 0.f;
+            unsigned int s1 = 0, s2 = 0;   // sum cnt * (e + 128), sum cnt * (e + 128)^2 <= 768 * 383^2 < 2^27
+            // bin b: + b * 256 bytes (an instruction offset); the lane words have the block bits (byte 1) taken out, put them back
+            wvd_lds_u16* slot0 = (wvd_lds_u16*)(uintptr_t)(laneOff16 | (histLds & 0xFF00u));
 #pragma unroll
-            for (int b = 0; b < 64; ++b) {
-                wvd_lds_u16* slot = (wvd_lds_u16*)(uintptr_t)((unsigned int)(b << 7) + laneOff16);   // laneOff16 is a complete LDS address
-                const unsigned int cnt = *slot;
-                const float pdf = (float)cnt * dv.stretch;
-                cdf = b == 0 ? pdf : cdf + pdf;
-                // (uchar)floor((double)cdf + 0.5): cdf < 2^9 has at most 24 significant bits, so cdf + 0.5 is exact in double;
-                // floor(cdf) + (frac >= 0.5) is the same value without leaving fp32 (cdf + 0.5f itself can round up to an integer)
-                const float fl = floorf(cdf);
-                const float up = (cdf - fl >= 0.5f) ? fl + 1.0f : fl;
-                const unsigned int e = (unsigned int)up & 255u;
-                *slot = (unsigned short)e;
-                const unsigned int ce = cnt * e;   // <= 768 * 255
-                sumx += ce;
-                sumxx += ce * e;                   // <= 768 * 65025 < 2^26
-                asm("" : "+v"(sumx), "+v"(sumxx));   // accumulate here (sunk to their use, the 128 products spill)
+            for (int bb = 0; bb < 64; bb += 16) {
+                unsigned int cnt[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) cnt[j] = slot0[(bb + j) * 128];   // one LDS round trip per 16 bins, not per bin
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float pdf = (float)cnt[j] * dv.stretch;
+                    cdf = (bb + j) == 0 ? pdf : cdf + pdf;
+                    // (uchar)floor((double)cdf + 0.5): cdf < 2^9 has at most 24 significant bits, so cdf + 0.5 is exact in double;
+                    // floor(cdf) + (frac >= 0.5) is the same value without leaving fp32 (cdf + 0.5f itself can round up to an integer)
+                    const unsigned int e1 = (unsigned int)cdf + 128u + (__builtin_amdgcn_fractf(cdf) >= 0.5f ? 1u : 0u);
+                    *(wvd_lds_u8*)(slot0 + (bb + j) * 128) = (unsigned char)e1;
+                    const unsigned int ce = __umul24(cnt[j], e1);   // <= 768 * 383: all three products are 24-bit multiplies
+                    s1 = ce + s1;
+                    s2 = __umul24(ce, e1) + s2;
+                    asm("" : "+v"(s1), "+v"(s2));   // accumulate here (sunk to their use, the 128 products spill)
+                }
             }
+            constexpr unsigned int N = PW_ * PH_;
+            sumx = s1 - 128u * N;
+            sumxx = s2 - 256u * s1 + 16384u * N;   // sum cnt (e1 - 128)^2
         }
         wave_sync();
+        WVD_T(pc);
         // ---- 3. equalise, exact dot products on the matrix pipe: one k-step per patch row (two rows when the patch is 16 wide)
         wvd_v16i acc00 = {}, acc01 = {}, acc10 = {}, acc11 = {};
         {
@@ -236,7 +313,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
 #pragma unroll
                 for (int j = 0; j < NW; ++j) wn[rr][j] = wvd_load_u32(src + (size_t)rr * lw + 4 * j);
             wvd_v4i bn0 = dv.B[lane], bn1 = dv.B[64 + lane];
-#pragma unroll 1
+#pragma unroll 2
             for (int ks = 0; ks < KS; ++ks) {
                 const wvd_v4i b0 = bn0, b1 = bn1;
                 unsigned int w4[RPS][NW];
@@ -255,17 +332,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
                     bn1 = dv.B[(kn * 2 + 1) * 64 + lane];
                 }
                 unsigned int pk[RPS * NW];
+                {
+                    constexpr int ND_ = RPS * NW;   // 4, 5, 6 or 8 dwords: one block, or two of 3 / 4
+                    unsigned int wl[ND_];
 #pragma unroll
-                for (int rr = 0; rr < RPS; ++rr) {
+                    for (int rr = 0; rr < RPS; ++rr)
 #pragma unroll
-                    for (int j = 0; j < NW; ++j) {
-                        const unsigned int w = w4[rr][j];
-                        const unsigned int e0 = wvd_lut(wvd_slot<0>(w, laneOff16));
-                        const unsigned int e1 = wvd_lut(wvd_slot<1>(w, laneOff16));
-                        const unsigned int e2 = wvd_lut(wvd_slot<2>(w, laneOff16));
-                        const unsigned int e3 = wvd_lut(wvd_slot<3>(w, laneOff16));
-                        pk[rr * NW + j] = wvd_lshl_or(e3, 24, wvd_lshl_or(e2, 16, wvd_lshl_or(e1, 8, e0))) ^ 0x80808080u;   // x - 128 as int8
-                    }
+                        for (int j = 0; j < NW; ++j) wl[rr * NW + j] = w4[rr][j];
+                    if constexpr (ND_ <= 5) wvd_equalise<ND_>(wl, pk, laneOff16, blk4);
+                    else { wvd_equalise<ND_ / 2>(wl, pk, laneOff16, blk4); wvd_equalise<ND_ / 2>(wl + ND_ / 2, pk + ND_ / 2, laneOff16, blk4); }
                 }
                 // slots RPS * PW_ .. 31 of the k-step are never written: their digits are zero, so stale bytes multiply into nothing
                 unsigned char* xrow = xPtr + lane * 16;
@@ -284,6 +359,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
                 acc11 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc11, 0, 0, 0);
             }
         }
+        WVD_T(pd);
         // ---- 4. digits -> exact integer dot products, transposed to lane == window.  Column g = f + 16 j of N-tile g / 32 holds
         //         digit j of filter f: this lane (column lane & 31) has digit j0 = (lane >> 4) & 1 in tile 0 and digit j0 + 2 in tile 1
         wave_sync();   // the LUT is dead: the region becomes the transpose buffer
@@ -302,7 +378,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
                     const double part = (double)s0 + 65536.0 * (double)s2;          // exact: |s| < 2^24
                     const double other = __shfl_xor(part, 16);
                     const int rowc = mt * 32 + (rg & 3) + 8 * (rg >> 2);             // window row = rowc + h4
-                    if (lowDigit) trPtr[(rowc + h4) * 16 + (fh ^ (rowc & 15))] = part + 256.0 * other;   // exact: < 2^53
+                    if (lowDigit) trPtr[(rowc + h4) * 32 + (fh ^ (rowc & 15))] = part + 256.0 * other;   // exact: < 2^53
                 }
             }
         }
@@ -322,7 +398,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
 #pragma unroll
             for (int k = 0; k < WVD_L; ++k) {
                 if (k < L) {
-                    const double xp = (trPtr[laneC * 16 + (k ^ (laneC & 15))] + C.c128[k]) * dv.scale;
+                    const double xp = (trPtr[laneC * 32 + (k ^ (laneC & 15))] + C.c128[k]) * dv.scale;
                     double norm = (double)sxx;
                     norm = norm - 2 * xp;
                     norm = norm + C.pp[k];
@@ -362,7 +438,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
             }
         }
         wave_sync();
+#ifdef FD_WVB_PROF
+        {
+            const unsigned long long pe = __builtin_amdgcn_s_memtime();
+            pAcc[0] += pb - pa; pAcc[1] += pc - pb; pAcc[2] += pd - pc; pAcc[3] += pe - pd; ++pTiles;
+        }
+#endif
     }
+#ifdef FD_WVB_PROF
+    if (lane == 0) {
+        const unsigned int gw = blockIdx.x * 4 + wave;
+        if (gw < (unsigned int)WVD_PROF_WAVES) {
+            unsigned int hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* r = fd_wvd_prof + (size_t)gw * 8;
+            r[0] = pT0; r[1] = __builtin_amdgcn_s_memtime(); r[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32); r[3] = pTiles;
+            r[4] = pAcc[0]; r[5] = pAcc[1]; r[6] = pAcc[2]; r[7] = pAcc[3];
+        }
+    }
+#endif
 }
 
 // ---- the same for several detectors that share their windows ------------------------------------------------------------
