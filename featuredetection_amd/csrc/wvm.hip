@@ -2050,13 +2050,46 @@ static void wvb_reserve(fd_wvm* m, int64_t total, int64_t minCap = 0) {
     m->deepCap = cap;
 }
 
+// k_wvm_prefilter's tiles for K windows per lane: 64 (column, row group of K) tasks of a layer each
+static int wvd_plan_sliding(WvdTable& t, int K) {
+    t.K = K;
+    int tiles = 0;
+    for (int i = 0; i < t.n; ++i) {
+        WvdLayer& l = t.l[i];
+        l.G = (l.ny + K - 1) / K;
+        l.sTileFirst = tiles;
+        tiles += (int)(((int64_t)l.nx * l.G + 63) / 64);
+    }
+    t.sTilesPerImage = tiles;
+    return tiles;
+}
+// How many windows a lane walks down.  More is cheaper per window (the first window of a lane pays the full histogram, ~0.45 of a
+// window's other work; each later one a slide of 2 sy rows, ~0.04 each) but makes the tiles longer: the launch takes
+// rounds(K) x (first + K x step) with rounds = tiles / wavefront slots rounded up.  FD_WVD_K fixes it.
+static int wvd_choose_k(WvdTable t, int slots, int ph) {
+    static const int forced = [] { const char* e = getenv("FD_WVD_K"); const int v = e ? atoi(e) : 0; return v < 1 ? 0 : (v > WVD_KMAX ? WVD_KMAX : v); }();
+    if (2 * t.sy > ph) return 1;   // windows of a column barely overlap: nothing to slide
+    if (forced) return forced;
+    int best = 1;
+    double bestCost = 0;
+    for (int K = 1; K <= WVD_KMAX; ++K) {
+        const int64_t tiles = (int64_t)wvd_plan_sliding(t, K) * t.nimg;
+        const double rounds = (double)((tiles + slots - 1) / slots);
+        const double cost = rounds * (0.45 + K * (1.0 + (K > 1 ? 0.04 * t.sy : 0.0)));
+        if (K == 1 || cost < bestCost * 0.999) { best = K; bestCost = cost; }
+    }
+    return best;
+}
+
 template <int PW_, int PH_>
-static void launch_prefilter_sized(fd_ctx* ctx, hipStream_t st, const uint8_t* arena, const WvdTable& wt, const WvdDev& dv) {
+static void launch_prefilter_sized(fd_ctx* ctx, hipStream_t st, const uint8_t* arena, WvdTable wt, const WvdDev& dv) {
     static int perCu = 0;
     if (perCu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wvm_prefilter<PW_, PH_>, 256, 0) != hipSuccess || perCu < 1)) perCu = 2;
+    const int slots = ctx->num_cus * perCu * 4;
+    const int64_t tiles = (int64_t)wvd_plan_sliding(wt, wvd_choose_k(wt, slots, PH_)) * wt.nimg;
     // rounds of resident workgroups the tiles are dealt over (FD_WVD_ROUNDS, default 2)
     static const int rounds = [] { const char* e = getenv("FD_WVD_ROUNDS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
-    int grid = (int)std::min<int64_t>(((int64_t)wt.ntiles + 3) / 4, (int64_t)ctx->num_cus * perCu * rounds);
+    int grid = (int)std::min<int64_t>((tiles + 3) / 4, (int64_t)ctx->num_cus * perCu * rounds);
     if (wt.nimg >= 8 && grid >= 64) grid &= ~7;   // a multiple of the 8 XCDs: the kernel then keeps every frame on one XCD
     hipLaunchKernelGGL((k_wvm_prefilter<PW_, PH_>), dim3(grid), dim3(256), 0, st, arena, wt, dv);
 }
@@ -2075,6 +2108,8 @@ static bool wvd_table_from(const WinTable& wt, WvdTable& t) {
         WvdLayer& dl = t.l[i];
         dl.bx = s.bx; dl.by = s.by; dl.nx = s.nx; dl.lw = s.lw; dl.off = s.off; dl.magic = s.magic; dl.first = s.first;
         dl.nwin = (int32_t)nwin;
+        dl.ny = s.ny;
+        if ((int64_t)s.nx * s.ny != nwin) return false;
         dl.tileFirst = tiles;
         tiles += (int)((nwin + 63) / 64);
     }

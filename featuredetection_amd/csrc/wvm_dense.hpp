@@ -35,12 +35,14 @@ typedef __attribute__((address_space(3))) unsigned short wvd_lds_u16;
 struct WvdLayer {
     int32_t bx, by, nx, lw;
     uint32_t off, magic;
-    int32_t nwin, tileFirst;
+    int32_t nwin, tileFirst;             // k_wvm_prefilter_multi: tiles of 64 consecutive windows
     int64_t first;
+    int32_t ny, G, sTileFirst, pad;      // k_wvm_prefilter: G = ceil(ny / K) row groups; tiles of 64 (column, row group) tasks
 };
 struct WvdTable {
     int32_t n, sx, sy, ntiles;           // ntiles = tilesPerImage * nimg
     int32_t nimg, tilesPerImage;         // multi-frame pyramid: tile -> (frame, tile inside the frame)
+    int32_t K, sTilesPerImage;           // k_wvm_prefilter: windows a lane walks down (WVD_KMAX at most), its tiles per frame
     int64_t perImage;                    // windows per frame
     uint64_t imageStride;                // bytes between the frames' arenas
     WvdLayer l[WVM_MAX_LAYERS];
@@ -104,16 +106,16 @@ struct WvdGeo {
 };
 
 // LDS of a workgroup (4 wavefronts).  Histogram rows are 256 B: [wave pair][bin][wave of the pair][lane & 31] dwords, the u16 counters
-// of lanes l (low half) and l + 32 (high half) in one dword.  With the pair's block 16 KB-aligned, the LDS address of (bin, lane) is
-// {byte 3: 0, byte 2: lane word, byte 1: bin | block bits, byte 0: lane word}: ONE v_perm_b32 per pixel takes the bin byte out of a
-// dword of four pre-shifted pixels and drops it into the lane's address word (wvd_bins / wvd_addr; 1.5 VALU per pixel instead of 2).
-// After the MFMA loop a wavefront's 64 half rows hold the transposed dot products [window][filter] as doubles (one window per half
-// row, the column XOR-swizzled by the row: 2-way bank conflicts at most).
-struct WvdLds {   // the variable is 16 KB-aligned (not the type: 40 KB must stay 40 KB, four workgroups per CU)
-    unsigned int hist[2][64][2][32];                 // counters, then the lane's LUT in the low byte of its u16, then the transposes
-    unsigned char x[4][2][64 * 16];                  // [wave][plane] current k-step: the equalised pixels of every window, as x - 128
+// of lanes l (low half) and l + 32 (high half) in one dword; LUT rows are 256 B too: [bin][wave][lane] bytes.  With every 16 KB block
+// 16 KB-aligned, the LDS address of (bin, lane) is {byte 3: 0, byte 2: lane word, byte 1: bin | block bits, byte 0: lane word}: ONE
+// v_perm_b32 per pixel takes the bin byte out of a dword of four pre-shifted pixels and drops it into the lane's address word
+// (wvd_bins / wvd_addr; 1.5 VALU per pixel instead of 2).  The histogram survives the window (the next one down slides it), so the
+// LUT has a block of its own.
+struct WvdLds {   // the variable is 16 KB-aligned (not the type: 48 KB must stay 48 KB, three workgroups per CU)
+    unsigned int hist[2][64][2][32];                 // counters
+    unsigned char lut[64][4][64];                    // the lanes' LUTs: e - 128 as int8
 };
-static_assert(sizeof(unsigned int[64][2][32]) == 16384, "one 16 KB block per pair of wavefronts, 256 B per bin");
+static_assert(sizeof(unsigned int[64][2][32]) == 16384 && sizeof(unsigned char[64][4][64]) == 16384, "16 KB blocks, 256 B per bin");
 
 typedef __attribute__((address_space(3))) unsigned char wvd_lds_u8;
 typedef unsigned short wvd_u16x2 __attribute__((ext_vector_type(2)));
@@ -175,6 +177,9 @@ __device__ __forceinline__ unsigned int wvd_slot(unsigned int w4, unsigned int l
 __device__ __forceinline__ void wvd_count(unsigned int ldsAddr, unsigned int inc) {   // ds_add_u32, no return value
     __hip_atomic_fetch_add((wvd_lds_u32*)(uintptr_t)ldsAddr, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
+__device__ __forceinline__ void wvd_uncount(unsigned int ldsAddr, unsigned int inc) {   // ds_sub_u32: the counter is >= 1, no borrow into the other half
+    __hip_atomic_fetch_sub((wvd_lds_u32*)(uintptr_t)ldsAddr, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
 __device__ __forceinline__ unsigned int wvd_lut(unsigned int ldsAddr) { return *(wvd_lds_u16*)(uintptr_t)ldsAddr; }   // ds_read_u16
 __device__ __forceinline__ unsigned int wvd_lshl_or(unsigned int a, int sh, unsigned int b) {
     unsigned int r;
@@ -182,31 +187,64 @@ __device__ __forceinline__ unsigned int wvd_lshl_or(unsigned int a, int sh, unsi
     return r;
 }
 
-// 64 consecutive windows of one layer per wavefront; 4 wavefronts per workgroup, persistent grid over the tiles.
+// One wavefront = 64 (column, row group) tasks of a layer: lane == task, and a lane walks DOWN its column through up to K windows
+// (wt.K, WVD_KMAX at most).  Windows one step apart share all but `sy` rows, so after the first window a lane takes the rows that
+// left its window out of its private histogram and adds the ones that entered: 2 * sy * PW_ LDS atomics per window instead of
+// PW_ * PH_ (the histogram pass was a third of the kernel, bound by the LDS pipe).
+// The contraction runs with the roles swapped against k_wvm_prefilter_multi -- A = the digit matrix, B = the pixels -- so that the
+// accumulators come out as C[digit row][window]: a lane holds 16 of the 32 digit rows of windows lane & 31 and 32 + (lane & 31), i.e. all
+// four digits of 8 of the 16 filters.  v_permlane32_swap builds the pixel operands (a lane's 32 row bytes -> the k-halves the two
+// N-tiles want) and, after the digits are folded into exact doubles, brings the two halves of a window's filters together:
+// lane == window again without the LDS round trips (pixel staging, 8 KB transpose) of the other formulation.
+constexpr int WVD_KMAX = 16;
+
+// one patch row into (ADD_) or out of the lane's histogram
+template <int NW_, bool ADD_>
+__device__ __forceinline__ void wvd_hist_row(const unsigned int* w4, unsigned int blk4, unsigned int laneOff32, unsigned int inc) {
+#pragma unroll
+    for (int j = 0; j < NW_; ++j) {
+        const unsigned int bins = wvd_bins(w4[j], blk4);
+        if (ADD_) {
+            wvd_count(wvd_addr<0>(bins, laneOff32), inc); wvd_count(wvd_addr<1>(bins, laneOff32), inc);
+            wvd_count(wvd_addr<2>(bins, laneOff32), inc); wvd_count(wvd_addr<3>(bins, laneOff32), inc);
+        } else {
+            wvd_uncount(wvd_addr<0>(bins, laneOff32), inc); wvd_uncount(wvd_addr<1>(bins, laneOff32), inc);
+            wvd_uncount(wvd_addr<2>(bins, laneOff32), inc); wvd_uncount(wvd_addr<3>(bins, laneOff32), inc);
+        }
+    }
+}
+// v0's lanes 32..63 <-> v1's lanes 0..31
+__device__ __forceinline__ void wvd_swap32(unsigned int& v0, unsigned int& v1) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v0, v1, false, false);
+    v0 = r[0]; v1 = r[1];
+}
+
 template <int PW_, int PH_>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>::WPE, 4))) void k_wvm_prefilter(const uint8_t* __restrict__ arena, WvdTable wt, WvdDev dv) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_wvm_prefilter(const uint8_t* __restrict__ arena, WvdTable wt, WvdDev dv) {
     static_assert(PW_ % 4 == 0 && PW_ >= 16 && PW_ <= 32, "rows are read as dwords; a row (or two 16-wide rows) fills one k-step");
     constexpr int RPS = WvdGeo<PW_>::RPS;
     static_assert(PH_ % RPS == 0, "whole k-steps");
     constexpr int KS = PH_ / RPS;
     constexpr int NW = PW_ / 4;          // dwords per patch row
+    constexpr int ND = RPS * NW;         // dwords per k-step: 4, 5, 6 or 8
     __shared__ __attribute__((aligned(16384))) WvdLds S;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // constant address space: scalar loads (SMEM) even though the kernel also stores to global memory
     const __attribute__((address_space(4))) WvdConst& C = *(const __attribute__((address_space(4))) WvdConst*)(uintptr_t)dv.c;
     const int L = dv.L;
-    const int ntiles = wt.ntiles;
+    const int K = wt.K;
     int li = 0;
     unsigned char* histPtr = reinterpret_cast<unsigned char*>(&S.hist[wave >> 1][0][wave & 1][0]);   // this wavefront's half rows, 256 B apart
-    unsigned char* xPtr = &S.x[wave][0][0];
-    double* trPtr = reinterpret_cast<double*>(histPtr);   // window r: trPtr[r * 32 ..]
     const unsigned int histLds = (unsigned int)(uintptr_t)(wvd_lds_u16*)histPtr;   // LDS byte address: 16 KB block + (wave & 1) * 128
-    const unsigned int blk4 = ((histLds >> 8) & 0xC0u) * 0x01010101u;               // block bits of the address byte, for all four pixels
+    const unsigned int blkH4 = ((histLds >> 8) & 0xC0u) * 0x01010101u;             // block bits of the address byte, for all four pixels
     // lanes l and l + 32 share a dword of every bin row: they are served in different LDS cycles, so nothing conflicts
     const unsigned int laneOff32 = (histLds & ~0xFF00u) + (unsigned int)(lane & 31) * 4u;
-    const unsigned int laneOff16 = laneOff32 + (unsigned int)(lane >> 5) * 2u;
+    const unsigned int cntLds = histLds + (unsigned int)(lane & 31) * 4u + (unsigned int)(lane >> 5) * 2u;   // this lane's u16 counter of bin 0
     const unsigned int inc = 1u << (16 * (lane >> 5));
+    const unsigned int lutLds = (unsigned int)(uintptr_t)(wvd_lds_u8*)&S.lut[0][wave][0] + (unsigned int)lane;   // this lane's LUT byte of bin 0
+    const unsigned int blkL4 = ((lutLds >> 8) & 0xC0u) * 0x01010101u;
+    const unsigned int lutWord = lutLds & ~0xFF00u;
 
     int lastImg = -1;
 #ifdef FD_WVB_PROF
@@ -218,26 +256,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
     // 2.5 MB of kept layers); here XCD x takes the frames x, x + 8, ...: each frame's layers live in one L2.
     const bool byXcd = wt.nimg >= 8 && (gridDim.x & 7u) == 0;
     const int xcd = blockIdx.x & 7, vStride = byXcd ? (int)(gridDim.x >> 3) * 4 : (int)gridDim.x * 4;
-    const int vEnd = byXcd ? ((wt.nimg - xcd + 7) >> 3) * wt.tilesPerImage : ntiles;
+    const int vEnd = byXcd ? ((wt.nimg - xcd + 7) >> 3) * wt.sTilesPerImage : wt.sTilesPerImage * wt.nimg;
     for (int v = (byXcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x) * 4 + wave; v < vEnd; v += vStride) {
-        const int fi = wt.nimg > 1 ? v / wt.tilesPerImage : 0;
+        const int fi = wt.nimg > 1 ? v / wt.sTilesPerImage : 0;
         const int img = byXcd ? xcd + 8 * fi : fi;   // frame of a multi-frame pyramid
-        const int tile = v - fi * wt.tilesPerImage;
+        const int tile = v - fi * wt.sTilesPerImage;
         if (img != lastImg) { li = 0; lastImg = img; }
-        while (li + 1 < wt.n && tile >= wt.l[li + 1].tileFirst) ++li;   // tiles ascend per wavefront inside a frame
+        while (li + 1 < wt.n && tile >= wt.l[li + 1].sTileFirst) ++li;   // tiles ascend per wavefront inside a frame
         const WvdLayer& wl = wt.l[li];
-        const int local0 = (tile - wl.tileFirst) * 64 + lane;
-        const bool valid = local0 < wl.nwin;
-        const unsigned int local = (unsigned int)(valid ? local0 : wl.nwin - 1);
-        unsigned int iy = __umulhi(local, wl.magic);   // floor(local / nx) or one less
-        unsigned int ix = local - iy * (unsigned int)wl.nx;
-        if (ix >= (unsigned int)wl.nx) { ix -= wl.nx; ++iy; }
+        const int ntask = wl.nx * wl.G;
+        const int task0 = (tile - wl.sTileFirst) * 64 + lane;
+        const unsigned int task = (unsigned int)(task0 < ntask ? task0 : ntask - 1);
+        unsigned int g = __umulhi(task, wl.magic);   // floor(task / nx) or one less
+        unsigned int ix = task - g * (unsigned int)wl.nx;
+        if (ix >= (unsigned int)wl.nx) { ix -= wl.nx; ++g; }
+        const int iy0 = (int)g * K;
+        const int rows = task0 < ntask ? min(K, wl.ny - iy0) : 0;   // windows of this lane; 0: a lane past the layer's last task (it repeats that task, unseen)
         const int lw = wl.lw;
-        const uint8_t* src = arena + (size_t)img * wt.imageStride + wl.off + (size_t)(wl.by + (int)iy * wt.sy) * lw + (wl.bx + (int)ix * wt.sx);
-        const int64_t wid = (int64_t)img * wt.perImage + wl.first + local;
+        const size_t rowStep = (size_t)wt.sy * lw;   // bytes between the windows of a column
+        const uint8_t* src0 = arena + (size_t)img * wt.imageStride + wl.off + (size_t)(wl.by + iy0 * wt.sy) * lw + (wl.bx + (int)ix * wt.sx);
+        const int64_t wid0 = (int64_t)img * wt.perImage + wl.first + (int64_t)iy0 * wl.nx + ix;
 
         WVD_T(pa);
-        // ---- 1. histogram: 64 bins x 64 lanes of u16 counters
+        // ---- 1. histogram of the lane's first window: 64 bins x 64 lanes of u16 counters
         {
             unsigned char* z = histPtr + (lane >> 3) * 256 + (lane & 7) * 16;   // 8 rows of 128 B per step
 #pragma unroll
@@ -247,25 +288,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
         {
             unsigned int wn[NW];
 #pragma unroll
-            for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(src + 4 * j);
+            for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(src0 + 4 * j);
 #pragma unroll 2
             for (int r = 0; r < PH_; ++r) {   // one patch row per iteration, the next row's loads in flight
                 unsigned int w4[NW];
 #pragma unroll
                 for (int j = 0; j < NW; ++j) w4[j] = wn[j];
-                const uint8_t* nsrc = src + (size_t)(r + 1 < PH_ ? r + 1 : r) * lw;
+                const uint8_t* nsrc = src0 + (size_t)(r + 1 < PH_ ? r + 1 : r) * lw;
 #pragma unroll
                 for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(nsrc + 4 * j);
-#pragma unroll
-                for (int j = 0; j < NW; ++j) {
-                    const unsigned int bins = wvd_bins(w4[j], blk4);
-                    wvd_count(wvd_addr<0>(bins, laneOff32), inc);
-                    wvd_count(wvd_addr<1>(bins, laneOff32), inc);
-                    wvd_count(wvd_addr<2>(bins, laneOff32), inc);
-                    wvd_count(wvd_addr<3>(bins, laneOff32), inc);
-                }
+                wvd_hist_row<NW, true>(w4, blkH4, laneOff32, inc);
             }
         }
+        WVD_T(pb0);
+#ifdef FD_WVB_PROF
+        pAcc[0] += pb0 - pa;
+#endif
+#pragma unroll 1
+        for (int step = 0; step < K; ++step) {
+        const bool active = step < rows;
+        if (__ballot(active) == 0) break;
+        WVD_T(ps);
+        if (step > 0 && active) {   // ---- 1'. slide the histogram down by one window: rows leave at the top, rows enter at the bottom
+            const uint8_t* out0 = src0 + (size_t)(step - 1) * rowStep;
+            for (int q = 0; q < wt.sy; ++q) {
+                unsigned int wo[NW], wi[NW];
+#pragma unroll
+                for (int j = 0; j < NW; ++j) { wo[j] = wvd_load_u32(out0 + (size_t)q * lw + 4 * j); wi[j] = wvd_load_u32(out0 + (size_t)(q + PH_) * lw + 4 * j); }
+                wvd_hist_row<NW, false>(wo, blkH4, laneOff32, inc);
+                wvd_hist_row<NW, true>(wi, blkH4, laneOff32, inc);
+            }
+        }
+        // the window this lane evaluates now (a lane that has run out of windows repeats its last one, unseen)
+        const uint8_t* src = src0 + (size_t)(active ? step : (rows > 0 ? rows - 1 : 0)) * rowStep;
         wave_sync();
         WVD_T(pb);
         // ---- 2. the fp32 cdf in the reference's order (cdf[0] = pdf[0]; cdf[b] = cdf[b-1] + pdf[b]), the LUT, and the exact
@@ -277,13 +332,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
         {
             float cdf = 0.f;
             unsigned int s1 = 0, s2 = 0;   // sum cnt * (e + 128), sum cnt * (e + 128)^2 <= 768 * 383^2 < 2^27
-            // bin b: + b * 256 bytes (an instruction offset); the lane words have the block bits (byte 1) taken out, put them back
-            wvd_lds_u16* slot0 = (wvd_lds_u16*)(uintptr_t)(laneOff16 | (histLds & 0xFF00u));
+            wvd_lds_u16* cnt0 = (wvd_lds_u16*)(uintptr_t)cntLds;   // bin b: + b * 256 bytes (an instruction offset)
+            wvd_lds_u8* lut0 = (wvd_lds_u8*)(uintptr_t)lutLds;
 #pragma unroll
             for (int bb = 0; bb < 64; bb += 16) {
                 unsigned int cnt[16];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) cnt[j] = slot0[(bb + j) * 128];   // one LDS round trip per 16 bins, not per bin
+                for (int j = 0; j < 16; ++j) cnt[j] = cnt0[(bb + j) * 128];   // one LDS round trip per 16 bins, not per bin
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const float pdf = (float)cnt[j] * dv.stretch;
@@ -291,7 +346,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
                     // (uchar)floor((double)cdf + 0.5): cdf < 2^9 has at most 24 significant bits, so cdf + 0.5 is exact in double;
                     // floor(cdf) + (frac >= 0.5) is the same value without leaving fp32 (cdf + 0.5f itself can round up to an integer)
                     const unsigned int e1 = (unsigned int)cdf + 128u + (__builtin_amdgcn_fractf(cdf) >= 0.5f ? 1u : 0u);
-                    *(wvd_lds_u8*)(slot0 + (bb + j) * 128) = (unsigned char)e1;
+                    lut0[(bb + j) * 256] = (unsigned char)e1;
                     const unsigned int ce = __umul24(cnt[j], e1);   // <= 768 * 383: all three products are 24-bit multiplies
                     s1 = ce + s1;
                     s2 = __umul24(ce, e1) + s2;
@@ -304,7 +359,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
         }
         wave_sync();
         WVD_T(pc);
-        // ---- 3. equalise, exact dot products on the matrix pipe: one k-step per patch row (two rows when the patch is 16 wide)
+        // ---- 3. equalise, exact dot products on the matrix pipe: one k-step per patch row (two rows when the patch is 16 wide).
+        //         acc[M][N]: digit tile M (rows f + 16 j', digits 2 M + j') x window tile N (windows 32 N + (lane & 31))
         wvd_v16i acc00 = {}, acc01 = {}, acc10 = {}, acc11 = {};
         {
             unsigned int wn[RPS][NW];
@@ -312,15 +368,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
             for (int rr = 0; rr < RPS; ++rr)
 #pragma unroll
                 for (int j = 0; j < NW; ++j) wn[rr][j] = wvd_load_u32(src + (size_t)rr * lw + 4 * j);
-            wvd_v4i bn0 = dv.B[lane], bn1 = dv.B[64 + lane];
+            wvd_v4i an0 = dv.B[lane], an1 = dv.B[64 + lane];
 #pragma unroll 2
             for (int ks = 0; ks < KS; ++ks) {
-                const wvd_v4i b0 = bn0, b1 = bn1;
-                unsigned int w4[RPS][NW];
+                const wvd_v4i a0 = an0, a1 = an1;
+                unsigned int wl4[ND];
 #pragma unroll
                 for (int rr = 0; rr < RPS; ++rr)
 #pragma unroll
-                    for (int j = 0; j < NW; ++j) w4[rr][j] = wn[rr][j];
+                    for (int j = 0; j < NW; ++j) wl4[rr * NW + j] = wn[rr][j];
                 {   // next k-step's rows and digits (the last step re-reads its own)
                     const int kn = ks + 1 < KS ? ks + 1 : ks;
                     const uint8_t* nsrc = src + (size_t)(kn * RPS) * lw;
@@ -328,31 +384,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
                     for (int rr = 0; rr < RPS; ++rr)
 #pragma unroll
                         for (int j = 0; j < NW; ++j) wn[rr][j] = wvd_load_u32(nsrc + (size_t)rr * lw + 4 * j);
-                    bn0 = dv.B[(kn * 2 + 0) * 64 + lane];
-                    bn1 = dv.B[(kn * 2 + 1) * 64 + lane];
+                    an0 = dv.B[(kn * 2 + 0) * 64 + lane];
+                    an1 = dv.B[(kn * 2 + 1) * 64 + lane];
                 }
-                unsigned int pk[RPS * NW];
-                {
-                    constexpr int ND_ = RPS * NW;   // 4, 5, 6 or 8 dwords: one block, or two of 3 / 4
-                    unsigned int wl[ND_];
+                unsigned int pk[8];
+                if constexpr (ND <= 5) wvd_equalise<ND>(wl4, pk, lutWord, blkL4);
+                else { wvd_equalise<ND / 2>(wl4, pk, lutWord, blkL4); wvd_equalise<ND / 2>(wl4 + ND / 2, pk + ND / 2, lutWord, blkL4); }
 #pragma unroll
-                    for (int rr = 0; rr < RPS; ++rr)
-#pragma unroll
-                        for (int j = 0; j < NW; ++j) wl[rr * NW + j] = w4[rr][j];
-                    if constexpr (ND_ <= 5) wvd_equalise<ND_>(wl, pk, laneOff16, blk4);
-                    else { wvd_equalise<ND_ / 2>(wl, pk, laneOff16, blk4); wvd_equalise<ND_ / 2>(wl + ND_ / 2, pk + ND_ / 2, laneOff16, blk4); }
-                }
-                // slots RPS * PW_ .. 31 of the k-step are never written: their digits are zero, so stale bytes multiply into nothing
-                unsigned char* xrow = xPtr + lane * 16;
-                constexpr int ND = RPS * NW;   // 4, 5, 6 or 8 dwords
-                *reinterpret_cast<uint4*>(xrow) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                if constexpr (ND == 5) *reinterpret_cast<unsigned int*>(xrow + 1024) = pk[4];
-                if constexpr (ND == 6) *reinterpret_cast<uint2*>(xrow + 1024) = make_uint2(pk[4], pk[5]);
-                if constexpr (ND == 8) *reinterpret_cast<uint4*>(xrow + 1024) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-                __builtin_amdgcn_wave_barrier();   // LDS operations of a wavefront execute in order: the reads below see these writes
-                const wvd_v4i a0 = *reinterpret_cast<const wvd_v4i*>(xPtr + (lane >> 5) * 1024 + (lane & 31) * 16);
-                const wvd_v4i a1 = *reinterpret_cast<const wvd_v4i*>(xPtr + (lane >> 5) * 1024 + (32 + (lane & 31)) * 16);
-                __builtin_amdgcn_wave_barrier();
+                for (int j = ND; j < 8; ++j) pk[j] = 0;   // k-slots past the row(s): zero pixels against zero digits
+                // this lane's 32 row bytes -> the k-half each N-tile wants from it: lanes 0..31 give bytes 0..15 of windows 0..31 (tile 0) /
+                // 32..63 (tile 1), lanes 32..63 bytes 16..31
+                wvd_swap32(pk[0], pk[4]); wvd_swap32(pk[1], pk[5]); wvd_swap32(pk[2], pk[6]); wvd_swap32(pk[3], pk[7]);
+                const wvd_v4i b0 = {(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]}, b1 = {(int)pk[4], (int)pk[5], (int)pk[6], (int)pk[7]};
                 acc00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc00, 0, 0, 0);
                 acc01 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc01, 0, 0, 0);
                 acc10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc10, 0, 0, 0);
@@ -360,34 +403,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
             }
         }
         WVD_T(pd);
-        // ---- 4. digits -> exact integer dot products, transposed to lane == window.  Column g = f + 16 j of N-tile g / 32 holds
-        //         digit j of filter f: this lane (column lane & 31) has digit j0 = (lane >> 4) & 1 in tile 0 and digit j0 + 2 in tile 1
-        wave_sync();   // the LUT is dead: the region becomes the transpose buffer
-        {
-            int laneT = lane;
-            asm volatile("" : "+v"(laneT));   // the 32 slot addresses are cheap: computed here, not hoisted out of the tile loop and spilled
-            const bool lowDigit = (laneT & 16) == 0;
-            const int h4 = 4 * (laneT >> 5);
-            const int fh = (laneT & 15) ^ h4;   // row & 15 = (rowc & 15) | h4 (rowc & 15 has bit 2 clear), so f ^ (row & 15) = fh ^ (rowc & 15)
+        // ---- 4. digits -> exact integer dot products, lane == window.  Register r of acc[M][N] is digit row (r & 3) + 8 (r >> 2) + 4 h
+        //         (h = lane >> 5) of tile M: filter fs(i) = (i & 3) + 8 (i >> 2) + 4 h for i = r & 7, digit 2 M + (r >> 3).  After the
+        //         swap, xq[0][i] is filter (i & 3) + 8 (i >> 2) of THIS lane's window and xq[1][i] filter (i & 3) + 8 (i >> 2) + 4.
+        double xq[2][8];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-                for (int rg = 0; rg < 16; ++rg) {
-                    const int s0 = mt == 0 ? acc00[rg] : acc10[rg];
-                    const int s2 = mt == 0 ? acc01[rg] : acc11[rg];
-                    const double part = (double)s0 + 65536.0 * (double)s2;          // exact: |s| < 2^24
-                    const double other = __shfl_xor(part, 16);
-                    const int rowc = mt * 32 + (rg & 3) + 8 * (rg >> 2);             // window row = rowc + h4
-                    if (lowDigit) trPtr[(rowc + h4) * 32 + (fh ^ (rowc & 15))] = part + 256.0 * other;   // exact: < 2^53
-                }
-            }
+        for (int i = 0; i < 8; ++i) {
+            // exact: |digit sums| < 2^24, the result < 2^53
+            const double v0 = ((double)acc00[i] + 65536.0 * (double)acc10[i]) + 256.0 * ((double)acc00[8 + i] + 65536.0 * (double)acc10[8 + i]);
+            const double v1 = ((double)acc01[i] + 65536.0 * (double)acc11[i]) + 256.0 * ((double)acc01[8 + i] + 65536.0 * (double)acc11[8 + i]);
+            uint2 u0 = __builtin_bit_cast(uint2, v0), u1 = __builtin_bit_cast(uint2, v1);
+            wvd_swap32(u0.x, u1.x);
+            wvd_swap32(u0.y, u1.y);
+            xq[0][i] = __builtin_bit_cast(double, u0);
+            xq[1][i] = __builtin_bit_cast(double, u1);
         }
-        wave_sync();
         // ---- 5. the first L cascade levels of this lane's window with error bounds
-        bool undecided = valid;
+        bool undecided = active;
         {
-            int laneC = lane;
-            asm volatile("" : "+v"(laneC));   // as above, for the 16 read addresses
             float Kv[WVD_L], Ke[WVD_L];
             // the reference's fp32 sum of squares: row totals (exact ints) added in fp32, so it IS the integer below 2^24
             const float sxx = (float)sumxx;
@@ -398,7 +431,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
 #pragma unroll
             for (int k = 0; k < WVD_L; ++k) {
                 if (k < L) {
-                    const double xp = (trPtr[laneC * 32 + (k ^ (laneC & 15))] + C.c128[k]) * dv.scale;
+                    const double xp = (xq[(k >> 2) & 1][(k & 3) + 4 * (k >> 3)] + C.c128[k]) * dv.scale;
                     double norm = (double)sxx;
                     norm = norm - 2 * xp;
                     norm = norm + C.pp[k];
@@ -434,16 +467,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WvdGeo<PW_>
                 unsigned int base = 0;
                 if (lane == 0) base = atomicAdd(dv.qcount, (unsigned int)__popcll(mask));
                 base = __builtin_amdgcn_readfirstlane(base);
-                if (undecided) dv.q[base + __popcll(mask & ((1ull << lane) - 1ull))] = wid;
+                if (undecided) dv.q[base + __popcll(mask & ((1ull << lane) - 1ull))] = wid0 + (int64_t)step * wl.nx;
             }
         }
-        wave_sync();
 #ifdef FD_WVB_PROF
         {
             const unsigned long long pe = __builtin_amdgcn_s_memtime();
-            pAcc[0] += pb - pa; pAcc[1] += pc - pb; pAcc[2] += pd - pc; pAcc[3] += pe - pd; ++pTiles;
+            pAcc[0] += pb - ps; pAcc[1] += pc - pb; pAcc[2] += pd - pc; pAcc[3] += pe - pd; ++pTiles;
         }
 #endif
+        }   // windows of the column
+        wave_sync();
     }
 #ifdef FD_WVB_PROF
     if (lane == 0) {
