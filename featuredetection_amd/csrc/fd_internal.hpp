@@ -345,6 +345,8 @@ struct fd_pyramid {
     DevBuf lut;                      // gradient binning LUT (65536 * 2|4 bytes)
     DevBuf rtab;                     // cv::resize coordinate / weight tables of the first-octave layers (k_resize_down, pyramid.hip)
     std::vector<uint32_t> rtab_x, rtab_y;   // per entry of `all` (depth-0 layers with a pyrDown successor): offsets into rtab, ~0u = none
+    std::vector<uint32_t> rtile_off;        // per k_resize_down launch (MAXJ chains): its tile list in rtab (offset in int2 entries) ...
+    std::vector<int> rtile_cnt;             // ... and the number of tiles per frame
     DevBuf layer_table;              // LayerDesc per kept layer
     std::vector<LayerDesc> h_layer_table;
     uint32_t gray_full_off = 0;

@@ -68,6 +68,17 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 struct FramePtrs {
     const uint8_t* p[FD_MAX_FRAMES];
 };
+// 24-bit multiplies by name: __umul24 became v_and + v_mul_lo_u32 (quarter rate) wherever the compiler could not see the operand ranges
+__device__ __forceinline__ unsigned int mul24(unsigned int a, unsigned int b) {
+    unsigned int r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned int mad24(unsigned int a, unsigned int b, unsigned int c) {
+    unsigned int r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ uint32_t ld_u32_unaligned(const uint8_t* p) {
     uint32_t v;
     __builtin_memcpy(&v, p, 4);
@@ -298,83 +309,112 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
 //     expressions (xtab[dx] = {left source column, a0 | a1 << 16}, ytab[dy] = {y0 | y1 << 16, b0 | b1 << 16});
 //   * a thread walks down one column and keeps the horizontally interpolated value of the last two source rows: consecutive
 //     destination rows share them (1 <= scale < 2), so a destination pixel costs ~1.4 horizontal interpolations instead of 2.
+// -DFD_PYR_PROF (tools/build_prof_lib.sh, tools/pyr_phases.py): ticks thread 0 of every workgroup spends in the phases of k_resize_down
+#ifdef FD_PYR_PROF
+constexpr int PYR_PROF_WGS = 65536;
+__device__ unsigned long long fd_pyr_prof[PYR_PROF_WGS * 8];   // one record per workgroup: same-address atomics would serialise the launch
+#define PYR_T(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
+#else
+#define PYR_T(x)
+#endif
 constexpr int FT_W1 = 62, FT_H1 = 16;                    // pyrDown tile
 constexpr int G0_W = 2 * FT_W1 + 3, G0_H = 2 * FT_H1 + 3, G0_PITCH = 128;   // resized pixels under it: 127 x 35
-constexpr int FS_PITCH = 272, FS_ROWS = 76;             // source stage: 126 * 2.05 + 3 columns, 34 * 2.05 + 3 rows
-__global__ __launch_bounds__(256) void k_resize_down(uint8_t* __restrict__ arena, uint32_t src_off, int sw, int sh, const int2* __restrict__ tabs,
-                                                     FusedJobs jobs, size_t imageStride) {
+constexpr int FS_PITCH = 256, FS_ROWS = 76;             // source stage: 126 * 2.0 + 3 columns (64 dwords: one per lane), 34 * 2.05 + 3 rows
+// Persistent workgroups walk a host-built list of tiles ({source rectangle, tile position, chain} per entry: the layout is static) and keep
+// the NEXT tile's global loads -- ~20 source dwords, the column's xtab entry, a row's ytab entry per thread -- in flight in registers
+// while they resize the current one: a tile used to spend 45 % of its 7.6 us waiting for them (in-kernel timestamps, tools/pyr_phases.py).
+// Multi-frame pyramids: workgroup b runs on XCD b % 8 and takes the frames b % 8, b % 8 + 8, ...: a frame's gray image is read by one L2.
+constexpr int FS_LOADS = (FS_ROWS + 3) / 4;   // source rows per wavefront: wavefront w holds rows w, w + 4, ..., a lane one dword of each
+struct FusedFetch {   // what a thread holds for a tile before it is in LDS
+    uint32_t v[FS_LOADS];
+    int2 ex, ey;   // ex: thread = column of the tile; ey: lane = resized row of the tile (every wavefront its own copy)
+};
+__device__ __forceinline__ void fused_issue(FusedFetch& f, const uint8_t* __restrict__ src, int sw, const int2* __restrict__ tabs, const FusedJob& jb,
+                                            const int4 d) {
+    const int X0 = d.x & 0xffff, Y0 = (int)((uint32_t)d.x >> 16), ncol = d.y & 0xffff, nrow = (int)((uint32_t)d.y >> 16);
+    const int gx0 = 2 * (d.z & 0xffff) * FT_W1 - 2;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = X0 + 4 * lane;
+    const bool mine = 4 * lane < ncol;
+    const uint8_t* row = src + (uint32_t)((Y0 + wave) * sw);
+    if (x + 3 < sw) {
+#pragma unroll
+        for (int q = 0; q < FS_LOADS; ++q, row += 4 * sw) {
+            f.v[q] = 0;
+            if (mine && wave + 4 * q < nrow) f.v[q] = ld_u32_unaligned(row + x);
+        }
+    } else {   // the dword hangs over the right edge of the image
+#pragma unroll
+        for (int q = 0; q < FS_LOADS; ++q, row += 4 * sw) {
+            uint32_t v = 0;
+            if (mine && wave + 4 * q < nrow)
+                for (int b = 0; b < 4; ++b) v |= (uint32_t)row[min(x + b, sw - 1)] << (8 * b);
+            f.v[q] = v;
+        }
+    }
+    f.ex = tabs[jb.xtab + reflect101(gx0 + (int)(threadIdx.x & 127), jb.dw0)];
+    {   // BORDER_REFLECT_101 of the resized rows the kept pyrDown rows reach (one reflection); rows further out only feed pyrDown
+        // rows past the layer's end, any valid row will do for them
+        const int py = 2 * (int)((uint32_t)d.z >> 16) * FT_H1 - 2 + min(lane, G0_H - 1), pr = py < 0 ? -py : (py >= jb.dh0 ? 2 * jb.dh0 - 2 - py : py);
+        f.ey = tabs[jb.ytab + min(max(pr, 0), jb.dh0 - 1)];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_resize_down(uint8_t* __restrict__ arena0, uint32_t src_off, int sw, int sh, const int2* __restrict__ tabs,
+                                                     FusedJobs jobs, uint32_t tileTab, int tilesPerFrame, int nimg, size_t imageStride) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[FS_ROWS * FS_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t g0[G0_H * G0_PITCH];
-    __shared__ int4 rowTab[G0_H];   // per resized row of the tile: LDS offsets of its two source rows, vertical weights
-    const FusedJob jb = jobs.j[blockIdx.y];
-    arena += (size_t)blockIdx.z * imageStride;   // blockIdx.z = frame of a multi-frame pyramid
-    const uint8_t* src = arena + src_off;
-    const int2* xtab = tabs + jb.xtab;
-    const int2* ytab = tabs + jb.ytab;
-    const int tilesX = (jb.dw1 + FT_W1 - 1) / FT_W1, tilesY = (jb.dh1 + FT_H1 - 1) / FT_H1;
+    const int4* tiles = reinterpret_cast<const int4*>(tabs + tileTab);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int t = blockIdx.x; t < tilesX * tilesY; t += gridDim.x) {
-        const int ty = t / tilesX, tx = t - ty * tilesX;
-        const int x1 = tx * FT_W1, y1 = ty * FT_H1;          // first pyrDown pixel of the tile
-        const int gx0 = 2 * x1 - 2, gy0 = 2 * y1 - 2;        // resized pixel of tile entry (0, 0), before the border reflection
-        // resized columns / rows the tile touches (after reflection: a contiguous interval) and their source rectangle
-        const int cLo = max(0, gx0), cHi = min(jb.dw0 - 1, gx0 + G0_W - 1), rLo = max(0, gy0), rHi = min(jb.dh0 - 1, gy0 + G0_H - 1);
-        const int X0 = xtab[cLo].x, Y0 = ytab[rLo].x & 0xffff;
-        const int ncol = min(sw - 1, xtab[cHi].x + 1) - X0 + 1, nrow = (ytab[rHi].x >> 16) - Y0 + 1;   // <= FS_PITCH, FS_ROWS (host checks)
-        {   // stage the source rectangle: wavefront w takes rows w, w + 4, ..., a lane the dwords lane and lane + 64 of a row
-            const int ndw = (ncol + 3) >> 2;
-            for (int r0 = wave; r0 < nrow; r0 += 4 * 8) {
-                uint32_t v[8][2];
+    const bool byXcd = nimg >= 8 && (gridDim.x & 7u) == 0;
+    const int xcd = blockIdx.x & 7;
+    const int slot = byXcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, nslot = byXcd ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int items = (byXcd ? (nimg - xcd + 7) >> 3 : nimg) * tilesPerFrame;
+    auto frame_of = [&](int item) { const int fi = item / tilesPerFrame; return byXcd ? xcd + 8 * fi : fi; };
+    auto desc_of = [&](int item) { return item < items ? tiles[item % tilesPerFrame] : make_int4(0, 0, 0, 0); };
+
+    int item = slot;
+    if (item >= items) return;
+    int4 d = desc_of(item);
+    FusedFetch f;
+    fused_issue(f, arena0 + (size_t)frame_of(item) * imageStride + src_off, sw, tabs, jobs.j[d.w], d);
+    int itemN = item + nslot;
+    int4 dN = desc_of(itemN);
+    for (; item < items; item = itemN, d = dN, itemN += nslot, dN = desc_of(itemN)) {
+        const FusedJob jb = jobs.j[d.w];
+        uint8_t* arena = arena0 + (size_t)frame_of(item) * imageStride;
+        const int X0 = d.x & 0xffff, Y0 = (int)((uint32_t)d.x >> 16), ncol = d.y & 0xffff, nrow = (int)((uint32_t)d.y >> 16);
+        const int x1 = (d.z & 0xffff) * FT_W1, y1 = (int)((uint32_t)d.z >> 16) * FT_H1;   // first pyrDown pixel of the tile
+        const int gx0 = 2 * x1 - 2, gy0 = 2 * y1 - 2;                      // resized pixel of tile entry (0, 0), before the border reflection
+        {   // the fetched source rectangle and row table -> LDS
+            if (4 * lane < ncol) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int r = r0 + 4 * k;
-#pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        const int j = lane + 64 * hh, x = X0 + 4 * j;
-                        v[k][hh] = 0;
-                        if (r < nrow && j < ndw) {
-                            const uint8_t* row = src + (uint32_t)((Y0 + r) * sw);
-                            if (x + 3 < sw) v[k][hh] = ld_u32_unaligned(row + x);
-                            else for (int b = 0; b < 4; ++b) v[k][hh] |= (uint32_t)row[min(x + b, sw - 1)] << (8 * b);   // right edge of the image
-                        }
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int r = r0 + 4 * k;
-#pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        const int j = lane + 64 * hh;
-                        if (r < nrow && j < ndw) *reinterpret_cast<uint32_t*>(&stage[r * FS_PITCH + 4 * j]) = v[k][hh];
-                    }
-                }
+                for (int q = 0; q < FS_LOADS; ++q)
+                    if (wave + 4 * q < nrow) *reinterpret_cast<uint32_t*>(&stage[(wave + 4 * q) * FS_PITCH + 4 * lane]) = f.v[q];
             }
         }
-        if (threadIdx.x < G0_H) {   // vertical taps of the tile's resized rows
-            const int2 e = ytab[reflect101(gy0 + (int)threadIdx.x, jb.dh0)];
-            rowTab[threadIdx.x] = make_int4(((e.x & 0xffff) - Y0) * FS_PITCH, ((e.x >> 16) - Y0) * FS_PITCH, e.y & 0xffff, e.y >> 16);
-        }
+        const int2 ex = f.ex, ey = f.ey;
         __syncthreads();
-        {   // ---- resize: thread = one column of the tile, half of its rows
+        if (itemN < items)   // the next tile's loads fly while this one is resized
+            fused_issue(f, arena0 + (size_t)frame_of(itemN) * imageStride + src_off, sw, tabs, jobs.j[dN.w], dN);
+        {   // ---- resize: thread = one column of the tile, half of its rows.  A row's vertical taps (ytab) are the same for the whole
+            //      wavefront (fetched with the tile, lane = row; v_readlane): scalar address arithmetic; every row reads its four source bytes whether or not the
+            //      previous row shared one (reusing them saved 0.6 interpolations per pixel but chained every row behind an LDS round trip)
             const int c = threadIdx.x & 127, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
             if (c < G0_W) {
-                const int2 ex = xtab[reflect101(gx0 + c, jb.dw0)];
-                const int lx = ex.x - X0, lx1 = min(ex.x + 1, sw - 1) - X0;
+                // the right neighbour is the next byte except in the image's last column, where its weight a1 is 0
+                const uint8_t* sp = stage + (ex.x - X0);
                 const unsigned int a0 = ex.y & 0xffff, a1 = (unsigned int)ex.y >> 16;
-                auto hcalc = [&](int rowOff) {   // horizontal interpolation of one source row, already >> 4 (cv::resize's intermediate)
-                    return (__umul24(stage[rowOff + lx], a0) + __umul24(stage[rowOff + lx1], a1)) >> 4;
-                };
-                int ta = -1, tb = -1;
-                unsigned int ha = 0, hb = 0;
-                const int rBeg = half * 18, rEnd = half ? G0_H : 18;
-                for (int r = rBeg; r < rEnd; ++r) {
-                    const int4 rt = rowTab[r];
-                    const int o0 = __builtin_amdgcn_readfirstlane(rt.x), o1 = __builtin_amdgcn_readfirstlane(rt.y);   // wave-uniform: scalar branches
-                    unsigned int h0, h1;
-                    if (o0 == ta) h0 = ha; else if (o0 == tb) h0 = hb; else h0 = hcalc(o0);
-                    if (o1 == o0) h1 = h0; else if (o1 == tb) h1 = hb; else if (o1 == ta) h1 = ha; else h1 = hcalc(o1);
-                    ta = o0; ha = h0; tb = o1; hb = h1;
-                    g0[r * G0_PITCH + c] = (uint8_t)(((__umul24(rt.z, h0) >> 16) + (__umul24(rt.w, h1) >> 16) + 2) >> 2);
+                uint8_t* gp = g0 + c;
+#pragma unroll 6
+                for (int i = 0; i < 18; ++i) {
+                    const int r = half * 18 + i, rr = min(r, G0_H - 1);   // rows 0..17 / 18..34 (the 18th of the second half is a repeat, not stored)
+                    const unsigned int e0 = (unsigned int)__builtin_amdgcn_readlane(ey.x, rr), e1 = (unsigned int)__builtin_amdgcn_readlane(ey.y, rr);
+                    const int o0 = ((int)(e0 & 0xffff) - Y0) * FS_PITCH, o1 = ((int)(e0 >> 16) - Y0) * FS_PITCH;
+                    const unsigned int h0 = mad24(sp[o0 + 1], a1, mul24(sp[o0], a0)) >> 4;   // cv::resize's horizontal intermediate
+                    const unsigned int h1 = mad24(sp[o1 + 1], a1, mul24(sp[o1], a0)) >> 4;
+                    const unsigned int v = ((mul24(e1 & 0xffff, h0) >> 16) + (mul24(e1 >> 16, h1) >> 16) + 2) >> 2;
+                    if (r < G0_H) gp[r * G0_PITCH] = (uint8_t)v;
                 }
             }
         }
@@ -720,6 +760,11 @@ void build_resize_tables(fd_pyramid* p, int W, int H) {
     static const bool off = [] { const char* e = getenv("FD_PYR_FUSED"); return e && atoi(e) == 0; }();
     if (off) return;
     std::vector<int2> tab;
+    // tiles of k_resize_down, one list per launch (MAXJ chains): {X0 | Y0 << 16, ncol | nrow << 16, tx | ty << 16, chain of the launch}
+    std::vector<std::vector<int4>> tiles;
+    p->rtile_off.clear();
+    p->rtile_cnt.clear();
+    int nfused = 0;
     for (size_t k = 0; k + 1 < p->all.size(); ++k) {
         const HostLayer& L = p->all[k];
         const HostLayer& D = p->all[k + 1];
@@ -751,19 +796,39 @@ void build_resize_tables(fd_pyramid* p, int W, int H) {
         bool fits = true;
         for (int x1 = 0; x1 < D.w && fits; x1 += FT_W1) {
             const int cLo = std::max(0, 2 * x1 - 2), cHi = std::min(L.w - 1, 2 * x1 - 2 + G0_W - 1);
-            fits = std::min(W - 1, xt[(size_t)cHi].x + 1) - xt[(size_t)cLo].x + 1 <= FS_PITCH - 4;
+            fits = std::min(W - 1, xt[(size_t)cHi].x + 1) - xt[(size_t)cLo].x + 1 <= FS_PITCH;
         }
         for (int y1 = 0; y1 < D.h && fits; y1 += FT_H1) {
             const int rLo = std::max(0, 2 * y1 - 2), rHi = std::min(L.h - 1, 2 * y1 - 2 + G0_H - 1);
             fits = (yt[(size_t)rHi].x >> 16) - (yt[(size_t)rLo].x & 0xffff) + 1 <= FS_ROWS;
         }
         if (!fits) continue;
+        {   // the source rectangle of every tile, exactly as the kernel's addressing expects it
+            if (nfused % MAXJ == 0) tiles.emplace_back();
+            std::vector<int4>& tl = tiles.back();
+            for (int ty = 0; ty * FT_H1 < D.h; ++ty)
+                for (int tx = 0; tx * FT_W1 < D.w; ++tx) {
+                    const int gx0 = 2 * tx * FT_W1 - 2, gy0 = 2 * ty * FT_H1 - 2;
+                    const int cLo = std::max(0, gx0), cHi = std::min(L.w - 1, gx0 + G0_W - 1), rLo = std::max(0, gy0), rHi = std::min(L.h - 1, gy0 + G0_H - 1);
+                    const int X0 = xt[(size_t)cLo].x, Y0 = yt[(size_t)rLo].x & 0xffff;
+                    const int ncol = std::min(W - 1, xt[(size_t)cHi].x + 1) - X0 + 1, nrow = (yt[(size_t)rHi].x >> 16) - Y0 + 1;
+                    tl.push_back(make_int4((int)((uint32_t)X0 | (uint32_t)Y0 << 16), (int)((uint32_t)ncol | (uint32_t)nrow << 16),
+                                           (int)((uint32_t)tx | (uint32_t)ty << 16), nfused % MAXJ));
+                }
+            ++nfused;
+        }
         p->rtab_x[k] = (uint32_t)tab.size();
         tab.insert(tab.end(), xt.begin(), xt.end());
         p->rtab_y[k] = (uint32_t)tab.size();
         tab.insert(tab.end(), yt.begin(), yt.end());
     }
     if (tab.empty()) return;
+    for (const std::vector<int4>& tl : tiles) {   // 16-byte entries behind the 8-byte ones, 16-byte aligned
+        if (tab.size() & 1) tab.push_back(make_int2(0, 0));
+        p->rtile_off.push_back((uint32_t)tab.size());
+        p->rtile_cnt.push_back((int)tl.size());
+        for (const int4& t : tl) { tab.push_back(make_int2(t.x, t.y)); tab.push_back(make_int2(t.z, t.w)); }
+    }
     p->rtab.reserve(sizeof(int2) * tab.size());
     HIP_CHECK(hipMemcpy(p->rtab.p, tab.data(), sizeof(int2) * tab.size(), hipMemcpyHostToDevice));
 }
@@ -909,12 +974,18 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
     {   // first-octave layers with a pyrDown chain: resize + first pyrDown in one kernel, the resized pixels stay in LDS
         FusedJobs jobs;
         jobs.n = 0;
-        int maxtiles = 0;
+        size_t group = 0;
         auto flush = [&]() {
             if (!jobs.n) return;
-            hipLaunchKernelGGL(k_resize_down, dim3(tile_grid_for(maxtiles), jobs.n, NI), dim3(256), 0, st, arena, p->gray_full_off, W, H, p->rtab.as<int2>(), jobs, IS);
+            static int perCu = 0;
+            if (perCu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_resize_down, 256, 0) != hipSuccess || perCu < 1)) perCu = 4;
+            const int tilesPerFrame = p->rtile_cnt[group];
+            // persistent workgroups; a multiple of the 8 XCDs for a multi-frame pyramid (every frame is then resized on one XCD)
+            int grid = (int)std::min<int64_t>((int64_t)tilesPerFrame * NI, (int64_t)p->ctx->num_cus * perCu);
+            if (NI >= 8 && grid >= 64) grid &= ~7;
+            hipLaunchKernelGGL(k_resize_down, dim3(grid), dim3(256), 0, st, arena, p->gray_full_off, W, H, p->rtab.as<int2>(), jobs, p->rtile_off[group], tilesPerFrame, NI, IS);
             jobs.n = 0;
-            maxtiles = 0;
+            ++group;
         };
         for (size_t k = 0; k + 1 < p->all.size(); ++k) {
             if (p->rtab_x[k] == ~0u) continue;
@@ -925,7 +996,6 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
             j.dst0_off = (L.kept && L.gray_off != p->gray_full_off) ? L.gray_off : 0xffffffffu;   // the scale-1 layer IS the gray image
             j.dst1_off = D.gray_off;
             j.xtab = p->rtab_x[k]; j.ytab = p->rtab_y[k];
-            maxtiles = std::max(maxtiles, ((D.w + FT_W1 - 1) / FT_W1) * ((D.h + FT_H1 - 1) / FT_H1));
             if (jobs.n == MAXJ) flush();
         }
         flush();
@@ -1389,3 +1459,10 @@ int fd_lbp_image(fd_ctx* ctx, const uint8_t* gray, int w, int h, int lbp_type, u
 }
 
 }  // extern "C"
+
+#ifdef FD_PYR_PROF
+extern "C" int fd_debug_pyr_prof(unsigned long long* out) {   // the records of the last k_resize_down launch; returns the capacity
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(fd_pyr_prof), sizeof(unsigned long long) * 8 * PYR_PROF_WGS);
+    return PYR_PROF_WGS;
+}
+#endif
