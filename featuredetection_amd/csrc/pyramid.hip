@@ -450,7 +450,8 @@ __global__ __launch_bounds__(256) void k_resize_down(uint8_t* __restrict__ arena
                 if (c < 2 + 2 * FT_W1 && gx < jb.dw0 && gy < jb.dh0) d0[(uint32_t)(gy * jb.dw0) + gx] = g0[r * G0_PITCH + c];
             }
         }
-        __syncthreads();
+        // no barrier here: the next tile's stage is free since the barrier after the resize, and its resize writes g0 only behind the
+        // next barrier, which every wavefront reaches after its pyrDown reads above
     }
 }
 
