@@ -380,7 +380,11 @@ __global__ __launch_bounds__(256) void k_resize_down(uint8_t* __restrict__ arena
     fused_issue(f, arena0 + (size_t)frame_of(item) * imageStride + src_off, sw, tabs, jobs.j[d.w], d);
     int itemN = item + nslot;
     int4 dN = desc_of(itemN);
+#ifdef FD_PYR_PROF
+    unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0}, ptiles = 0;
+#endif
     for (; item < items; item = itemN, d = dN, itemN += nslot, dN = desc_of(itemN)) {
+        PYR_T(p0);
         const FusedJob jb = jobs.j[d.w];
         uint8_t* arena = arena0 + (size_t)frame_of(item) * imageStride;
         const int X0 = d.x & 0xffff, Y0 = (int)((uint32_t)d.x >> 16), ncol = d.y & 0xffff, nrow = (int)((uint32_t)d.y >> 16);
@@ -394,9 +398,12 @@ __global__ __launch_bounds__(256) void k_resize_down(uint8_t* __restrict__ arena
             }
         }
         const int2 ex = f.ex, ey = f.ey;
+        PYR_T(p1);
         __syncthreads();
+        PYR_T(p2);
         if (itemN < items)   // the next tile's loads fly while this one is resized
             fused_issue(f, arena0 + (size_t)frame_of(itemN) * imageStride + src_off, sw, tabs, jobs.j[dN.w], dN);
+        PYR_T(p3);
         {   // ---- resize: thread = one column of the tile, half of its rows.  A row's vertical taps (ytab) are the same for the whole
             //      wavefront (fetched with the tile, lane = row; v_readlane): scalar address arithmetic; every row reads its four source bytes whether or not the
             //      previous row shared one (reusing them saved 0.6 interpolations per pixel but chained every row behind an LDS round trip)
@@ -406,19 +413,32 @@ __global__ __launch_bounds__(256) void k_resize_down(uint8_t* __restrict__ arena
                 const uint8_t* sp = stage + (ex.x - X0);
                 const unsigned int a0 = ex.y & 0xffff, a1 = (unsigned int)ex.y >> 16;
                 uint8_t* gp = g0 + c;
-#pragma unroll 6
-                for (int i = 0; i < 18; ++i) {
-                    const int r = half * 18 + i, rr = min(r, G0_H - 1);   // rows 0..17 / 18..34 (the 18th of the second half is a repeat, not stored)
-                    const unsigned int e0 = (unsigned int)__builtin_amdgcn_readlane(ey.x, rr), e1 = (unsigned int)__builtin_amdgcn_readlane(ey.y, rr);
-                    const int o0 = ((int)(e0 & 0xffff) - Y0) * FS_PITCH, o1 = ((int)(e0 >> 16) - Y0) * FS_PITCH;
-                    const unsigned int h0 = mad24(sp[o0 + 1], a1, mul24(sp[o0], a0)) >> 4;   // cv::resize's horizontal intermediate
-                    const unsigned int h1 = mad24(sp[o1 + 1], a1, mul24(sp[o1], a0)) >> 4;
-                    const unsigned int v = ((mul24(e1 & 0xffff, h0) >> 16) + (mul24(e1 >> 16, h1) >> 16) + 2) >> 2;
-                    if (r < G0_H) gp[r * G0_PITCH] = (uint8_t)v;
+                // three rows at a time: their twelve byte loads first, then the arithmetic (one LDS round trip per three rows)
+#pragma unroll 2
+                for (int i = 0; i < 18; i += 3) {
+                    unsigned int s00[3], s01[3], s10[3], s11[3], e1[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const int rr = min(half * 18 + i + q, G0_H - 1);   // rows 0..17 / 18..34 (the 18th of the second half is a repeat, not stored)
+                        const unsigned int e0 = (unsigned int)__builtin_amdgcn_readlane(ey.x, rr);
+                        e1[q] = (unsigned int)__builtin_amdgcn_readlane(ey.y, rr);
+                        const int o0 = ((int)(e0 & 0xffff) - Y0) * FS_PITCH, o1 = ((int)(e0 >> 16) - Y0) * FS_PITCH;
+                        s00[q] = sp[o0]; s01[q] = sp[o0 + 1]; s10[q] = sp[o1]; s11[q] = sp[o1 + 1];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const int r = half * 18 + i + q;
+                        const unsigned int h0 = mad24(s01[q], a1, mul24(s00[q], a0)) >> 4;   // cv::resize's horizontal intermediate
+                        const unsigned int h1 = mad24(s11[q], a1, mul24(s10[q], a0)) >> 4;
+                        const unsigned int v = ((mul24(e1[q] & 0xffff, h0) >> 16) + (mul24(e1[q] >> 16, h1) >> 16) + 2) >> 2;
+                        if (r < G0_H) gp[r * G0_PITCH] = (uint8_t)v;
+                    }
                 }
             }
         }
+        PYR_T(p4);
         __syncthreads();
+        PYR_T(p5);
         {   // ---- pyrDown of the tile (k_pyrdown_tiled's arithmetic on the LDS copy)
             const int c1 = lane;
             const int x = x1 + c1;
@@ -450,9 +470,21 @@ __global__ __launch_bounds__(256) void k_resize_down(uint8_t* __restrict__ arena
                 if (c < 2 + 2 * FT_W1 && gx < jb.dw0 && gy < jb.dh0) d0[(uint32_t)(gy * jb.dw0) + gx] = g0[r * G0_PITCH + c];
             }
         }
+#ifdef FD_PYR_PROF
+        {
+            const unsigned long long p6 = __builtin_amdgcn_s_memtime();
+            pacc[0] += p1 - p0; pacc[1] += p2 - p1; pacc[2] += p3 - p2; pacc[3] += p4 - p3; pacc[4] += p5 - p4; pacc[5] += p6 - p5; ++ptiles;
+        }
+#endif
         // no barrier here: the next tile's stage is free since the barrier after the resize, and its resize writes g0 only behind the
         // next barrier, which every wavefront reaches after its pyrDown reads above
     }
+#ifdef FD_PYR_PROF
+    if (threadIdx.x == 0 && blockIdx.x < (unsigned int)PYR_PROF_WGS) {
+        for (int i = 0; i < 6; ++i) fd_pyr_prof[blockIdx.x * 8 + i] = pacc[i];
+        fd_pyr_prof[blockIdx.x * 8 + 6] = ptiles;
+    }
+#endif
 }
 
 __global__ __launch_bounds__(256) void k_pyrdown_tiled(uint8_t* __restrict__ arena, DownJobs jobs, size_t imageStride) {

@@ -24,12 +24,12 @@ for _ in range(3):
     run()
 rec = np.zeros((cap, 8), dtype=np.uint64)
 L.fd_debug_pyr_prof(rec.ctypes.data_as(ctypes.c_void_p))
-rec = rec[rec[:, 5] > 0].astype(np.float64)
-work = rec[rec[:, :5].sum(axis=1) > 0]
+rec = rec[rec[:, 6] > 0].astype(np.float64)
 T = 1.0 / 2400
-names = ["stage source + row table (to the barrier)", "resize", "wait at the barrier", "pyrDown + store", "kept-layer copy + barrier"]
-tot = work[:, :5].sum()
-print("%d workgroups, %d with a tile; per working workgroup us:" % (len(rec), len(work)))
+names = ["fetched tile -> LDS (waits for its loads)", "barrier", "issue the next tile's loads", "resize", "barrier", "pyrDown + stores"]
+tiles = rec[:, 6].sum()
+tot = rec[:, :6].sum()
+print("%d workgroups, %d tiles; per tile us (thread 0):" % (len(rec), int(tiles)))
 for i, n in enumerate(names):
-    print("  %-44s %7.2f  (%4.1f %%)" % (n, work[:, i].mean() * T, 100.0 * work[:, i].sum() / max(tot, 1)))
-print("  total %.2f us per workgroup" % (tot * T / max(len(work), 1)))
+    print("  %-44s %7.2f  (%4.1f %%)" % (n, rec[:, i].sum() * T / tiles, 100.0 * rec[:, i].sum() / max(tot, 1)))
+print("  total %.2f us per tile" % (tot * T / tiles))
