@@ -219,6 +219,40 @@ __device__ __forceinline__ void wvd_swap32(unsigned int& v0, unsigned int& v1) {
     v0 = r[0]; v1 = r[1];
 }
 
+// The fp32 cdf of a lane's histogram in the reference's order (cdf[0] = pdf[0]; cdf[b] = cdf[b-1] + pdf[b]) -> the lane's LUT, and
+// the exact integer sum / sum of squares of the equalised patch.  cntLds / lutLds: LDS addresses of the lane's u16 counter / LUT byte of
+// bin 0 (bin b: + 256 b).  The LUT keeps e + 128 (low byte = e - 128 as int8, what the contractions want); the sums are taken over
+// e + 128 too and corrected once.  e <= 255 without the reference's (uchar) cast: the counts add up to N_ and stretch = 255 / N_, so
+// cdf <= 255 (1 + 66 * 2^-24) < 255.5.
+template <unsigned int N_>
+__device__ __forceinline__ void wvd_cdf_lut(unsigned int cntLds, unsigned int lutLds, float stretch, unsigned int& sumx, unsigned int& sumxx) {
+    float cdf = 0.f;
+    unsigned int s1 = 0, s2 = 0;   // sum cnt * (e + 128), sum cnt * (e + 128)^2 <= 768 * 383^2 < 2^27
+    wvd_lds_u16* cnt0 = (wvd_lds_u16*)(uintptr_t)cntLds;   // bin b: + b * 256 bytes (an instruction offset)
+    wvd_lds_u8* lut0 = (wvd_lds_u8*)(uintptr_t)lutLds;
+#pragma unroll
+    for (int bb = 0; bb < 64; bb += 16) {
+        unsigned int cnt[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) cnt[j] = cnt0[(bb + j) * 128];   // one LDS round trip per 16 bins, not per bin
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float pdf = (float)cnt[j] * stretch;
+            cdf = (bb + j) == 0 ? pdf : cdf + pdf;
+            // (uchar)floor((double)cdf + 0.5): cdf < 2^9 has at most 24 significant bits, so cdf + 0.5 is exact in double;
+            // floor(cdf) + (frac >= 0.5) is the same value without leaving fp32 (cdf + 0.5f itself can round up to an integer)
+            const unsigned int e1 = (unsigned int)cdf + 128u + (__builtin_amdgcn_fractf(cdf) >= 0.5f ? 1u : 0u);
+            lut0[(bb + j) * 256] = (unsigned char)e1;
+            const unsigned int ce = __umul24(cnt[j], e1);   // <= 768 * 383: all three products are 24-bit multiplies
+            s1 = ce + s1;
+            s2 = __umul24(ce, e1) + s2;
+            asm("" : "+v"(s1), "+v"(s2));   // accumulate here (sunk to their use, the 128 products spill)
+        }
+    }
+    sumx = s1 - 128u * N_;
+    sumxx = s2 - 256u * s1 + 16384u * N_;   // sum cnt (e1 - 128)^2
+}
+
 template <int PW_, int PH_>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_wvm_prefilter(const uint8_t* __restrict__ arena, WvdTable wt, WvdDev dv) {
     static_assert(PW_ % 4 == 0 && PW_ >= 16 && PW_ <= 32, "rows are read as dwords; a row (or two 16-wide rows) fills one k-step");
@@ -323,40 +357,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         const uint8_t* src = src0 + (size_t)(active ? step : (rows > 0 ? rows - 1 : 0)) * rowStep;
         wave_sync();
         WVD_T(pb);
-        // ---- 2. the fp32 cdf in the reference's order (cdf[0] = pdf[0]; cdf[b] = cdf[b-1] + pdf[b]), the LUT, and the exact
-        //         integer sum / sum of squares of the equalised patch
-        // The LUT keeps e + 128 (low byte = e - 128 as int8, what the contraction wants); the sums are taken over e + 128 too and
-        // corrected once.  e <= 255 without the reference's (uchar) cast: the counts add up to PW_ * PH_ and stretch = 255 / (PW_ * PH_),
-        // so cdf <= 255 (1 + 66 * 2^-24) < 255.5.
-        unsigned int sumx = 0, sumxx = 0;
-        {
-            float cdf = 0.f;
-            unsigned int s1 = 0, s2 = 0;   // sum cnt * (e + 128), sum cnt * (e + 128)^2 <= 768 * 383^2 < 2^27
-            wvd_lds_u16* cnt0 = (wvd_lds_u16*)(uintptr_t)cntLds;   // bin b: + b * 256 bytes (an instruction offset)
-            wvd_lds_u8* lut0 = (wvd_lds_u8*)(uintptr_t)lutLds;
-#pragma unroll
-            for (int bb = 0; bb < 64; bb += 16) {
-                unsigned int cnt[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) cnt[j] = cnt0[(bb + j) * 128];   // one LDS round trip per 16 bins, not per bin
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const float pdf = (float)cnt[j] * dv.stretch;
-                    cdf = (bb + j) == 0 ? pdf : cdf + pdf;
-                    // (uchar)floor((double)cdf + 0.5): cdf < 2^9 has at most 24 significant bits, so cdf + 0.5 is exact in double;
-                    // floor(cdf) + (frac >= 0.5) is the same value without leaving fp32 (cdf + 0.5f itself can round up to an integer)
-                    const unsigned int e1 = (unsigned int)cdf + 128u + (__builtin_amdgcn_fractf(cdf) >= 0.5f ? 1u : 0u);
-                    lut0[(bb + j) * 256] = (unsigned char)e1;
-                    const unsigned int ce = __umul24(cnt[j], e1);   // <= 768 * 383: all three products are 24-bit multiplies
-                    s1 = ce + s1;
-                    s2 = __umul24(ce, e1) + s2;
-                    asm("" : "+v"(s1), "+v"(s2));   // accumulate here (sunk to their use, the 128 products spill)
-                }
-            }
-            constexpr unsigned int N = PW_ * PH_;
-            sumx = s1 - 128u * N;
-            sumxx = s2 - 256u * s1 + 16384u * N;   // sum cnt (e1 - 128)^2
-        }
+        // ---- 2. the fp32 cdf, the LUT, and the exact integer sum / sum of squares of the equalised patch
+        unsigned int sumx, sumxx;
+        wvd_cdf_lut<PW_ * PH_>(cntLds, lutLds, dv.stretch, sumx, sumxx);
         wave_sync();
         WVD_T(pc);
         // ---- 3. equalise, exact dot products on the matrix pipe: one k-step per patch row (two rows when the patch is 16 wide).
@@ -492,6 +495,129 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         }
     }
 #endif
+}
+
+// ---- stage B's k_wvb_prepare with lane == window ---------------------------------------------------------------------------
+// HistEq64 + sums of the windows queued for stage B -> state set 0 (wvm_stageb.hpp), 64 queued windows per wavefront with the
+// pre-filter's machinery (private histogram columns, register cdf chain, LUT gather) instead of one window per wavefront: models
+// that keep rejecting deep into the cascade queue 28-64 % of all windows, and the wave == window kernel was 18 % of such a call.
+// A lane locates its window from the id (frame, layer, row, column: a table of the layers in LDS), equalises it and writes the patch
+// as x - 128 bytes, the window id, sum(x) (exact) and the reference's fp32 row-ordered sum of squares (IImg.cpp:33-47: the row totals,
+// exact integers, added in fp32 from the top row down).
+struct WvdPrepLds {
+    unsigned int hist[2][64][2][32];
+    unsigned char lut[64][4][64];
+    int4 layer[WVM_MAX_LAYERS][2];   // {bx, by, nx, lw}, {off, magic, first, 0}
+};
+template <int PW_, int PH_>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_wvb_prepare_lanes(const uint8_t* __restrict__ arena, WinTable wt, float stretch,
+                                                                                                       WvbDev mv, WvbState s, const int64_t* q, const unsigned int* qcount) {
+    constexpr int NW = PW_ / 4;
+    __shared__ __attribute__((aligned(16384))) WvdPrepLds S;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if ((int)threadIdx.x < wt.n) {
+        const WinLayerDev& l = wt.l[threadIdx.x];
+        S.layer[threadIdx.x][0] = make_int4(l.bx, l.by, l.nx, l.lw);
+        S.layer[threadIdx.x][1] = make_int4((int)l.off, (int)l.magic, (int)l.first, 0);
+    }
+    __syncthreads();
+    unsigned char* histPtr = reinterpret_cast<unsigned char*>(&S.hist[wave >> 1][0][wave & 1][0]);
+    const unsigned int histLds = (unsigned int)(uintptr_t)(wvd_lds_u16*)histPtr;
+    const unsigned int blkH4 = ((histLds >> 8) & 0xC0u) * 0x01010101u;
+    const unsigned int laneOff32 = (histLds & ~0xFF00u) + (unsigned int)(lane & 31) * 4u;
+    const unsigned int cntLds = histLds + (unsigned int)(lane & 31) * 4u + (unsigned int)(lane >> 5) * 2u;
+    const unsigned int inc = 1u << (16 * (lane >> 5));
+    const unsigned int lutLds = (unsigned int)(uintptr_t)(wvd_lds_u8*)&S.lut[0][wave][0] + (unsigned int)lane;
+    const unsigned int blkL4 = ((lutLds >> 8) & 0xC0u) * 0x01010101u;
+    const unsigned int lutWord = lutLds & ~0xFF00u;
+    const unsigned int perImage = (unsigned int)wt.per_image;                          // the launcher checks that all ids fit 32 bits
+    const unsigned int magicPI = wt.nimg > 1 ? (unsigned int)(0xffffffffu / perImage) : 0u;   // mulhi(id, magic) = id / perImage or one less
+    const unsigned int n = wvb_count(qcount, s);
+    for (unsigned int tile = blockIdx.x * 4 + wave; tile * 64 < n; tile += gridDim.x * 4) {
+        const unsigned int pos = tile * 64 + lane;
+        const bool valid = pos < n;
+        const int64_t wid = q[valid ? pos : n - 1];
+        // ---- locate
+        unsigned int local = (unsigned int)wid, img = 0;
+        if (wt.nimg > 1) {
+            img = __umulhi(local, magicPI);
+            local -= img * perImage;
+            if (local >= perImage) { local -= perImage; ++img; }
+        }
+        int li = 0;
+        for (int l = 1; l < wt.n; ++l) li += local >= (unsigned int)wt.l[l].first ? 1 : 0;   // layer starts: scalar operands
+        const int4 la = S.layer[li][0], lb = S.layer[li][1];
+        const unsigned int idx = local - (unsigned int)lb.z;
+        unsigned int iy = __umulhi(idx, (unsigned int)lb.y);
+        unsigned int ix = idx - iy * (unsigned int)la.z;
+        if (ix >= (unsigned int)la.z) { ix -= la.z; ++iy; }
+        const int lw = la.w;
+        const uint8_t* src = arena + (size_t)img * wt.image_stride + (unsigned int)lb.x + (size_t)(la.y + (int)iy * wt.sy) * lw + (la.x + (int)ix * wt.sx);
+        // ---- histogram, cdf, LUT
+        {
+            unsigned char* z = histPtr + (lane >> 3) * 256 + (lane & 7) * 16;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(z + i * 2048) = make_uint4(0, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            unsigned int wn[NW];
+#pragma unroll
+            for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(src + 4 * j);
+#pragma unroll 2
+            for (int r = 0; r < PH_; ++r) {
+                unsigned int w4[NW];
+#pragma unroll
+                for (int j = 0; j < NW; ++j) w4[j] = wn[j];
+                const uint8_t* nsrc = src + (size_t)(r + 1 < PH_ ? r + 1 : r) * lw;
+#pragma unroll
+                for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(nsrc + 4 * j);
+                wvd_hist_row<NW, true>(w4, blkH4, laneOff32, inc);
+            }
+        }
+        wave_sync();
+        unsigned int sumx, sumxx;
+        wvd_cdf_lut<PW_ * PH_>(cntLds, lutLds, stretch, sumx, sumxx);
+        wave_sync();
+        // ---- equalise row by row: the patch as x - 128 bytes, the fp32 sum of squares in row order
+        int8_t* xr = s.X[0] + (size_t)pos * mv.dstride;
+        float sxx = 0.f;
+        {
+            unsigned int wn[NW];
+#pragma unroll
+            for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(src + 4 * j);
+#pragma unroll 2
+            for (int r = 0; r < PH_; ++r) {
+                unsigned int w4[NW], pk[NW];
+#pragma unroll
+                for (int j = 0; j < NW; ++j) w4[j] = wn[j];
+                const uint8_t* nsrc = src + (size_t)(r + 1 < PH_ ? r + 1 : r) * lw;
+#pragma unroll
+                for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(nsrc + 4 * j);
+                if constexpr (NW <= 5) wvd_equalise<NW>(w4, pk, lutWord, blkL4);
+                else { wvd_equalise<NW / 2>(w4, pk, lutWord, blkL4); wvd_equalise<NW / 2>(w4 + NW / 2, pk + NW / 2, lutWord, blkL4); }
+                unsigned int rowsq = 0;
+#pragma unroll
+                for (int j = 0; j < NW; ++j) {
+                    const unsigned int x4 = pk[j] ^ 0x80808080u;
+                    rowsq = __builtin_amdgcn_udot4(x4, x4, rowsq, false);
+                }
+                sxx = r == 0 ? (float)rowsq : sxx + (float)rowsq;
+                if (valid) {
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) *reinterpret_cast<unsigned int*>(xr + r * PW_ + 4 * j) = pk[j];
+                }
+            }
+        }
+        if (valid) {
+            for (int i = PW_ * PH_; i < mv.dstride; i += 4) *reinterpret_cast<unsigned int*>(xr + i) = 0;
+            s.wid[0][pos] = wid;
+            s.aux[0][pos] = make_int2((int)sumx, __float_as_int(sxx));
+        }
+        (void)sumxx;
+        wave_sync();
+    }
 }
 
 // ---- the same for several detectors that share their windows ------------------------------------------------------------

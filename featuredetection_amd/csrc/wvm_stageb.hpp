@@ -47,6 +47,11 @@ __device__ __forceinline__ unsigned int wvb_count(const unsigned int* countPtr, 
     return (int64_t)c > s.cap ? (unsigned int)s.cap : c;
 }
 
+// the same with lane == window, for the patch sizes of the dense pre-filter (wvm_dense.hpp)
+template <int PW_, int PH_>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_wvb_prepare_lanes(const uint8_t* __restrict__ arena, WinTable wt, float stretch,
+                                                                                                       WvbDev mv, WvbState s, const int64_t* q, const unsigned int* qcount);
+
 template <int PW_, int PH_, bool RAW>
 __global__ __launch_bounds__(256) void k_wvb_prepare(const uint8_t* __restrict__ arena, WinTable wt, WvmDev m, WvbDev mv, WvbState s, const int64_t* q,
                                                      const unsigned int* qcount) {
@@ -583,8 +588,21 @@ static void launch_stageb(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* m,
     };
     {
         const int64_t e = expect(0);
-        const int gridP = (int)std::min<int64_t>((e + 3) / 4, (int64_t)cus * 8);
-        hipLaunchKernelGGL((k_wvb_prepare<PW_, PH_, RAW>), dim3(gridP), dim3(256), 0, st, arena, wt, m->dev, mv, s, o.deep_q, o.deep_count);
+        // lane == window when the queue is long enough to fill wavefronts (FD_WVB_PREP_LANES: the queue length from which it is taken,
+        // default 4096; 0 = never); window ids must fit 32 bits and be positions of the layer table
+        static const int64_t lanesFrom = [] { const char* v = getenv("FD_WVB_PREP_LANES"); const long long x = v ? atoll(v) : 4096; return (int64_t)(x < 0 ? 0 : x); }();
+        bool lanes = false;
+        if constexpr (!RAW && PW_ != 0) {
+            if (lanesFrom > 0 && e >= lanesFrom && !wt.list && wt.total < ((int64_t)1 << 32) && (mv.dstride & 3) == 0) {
+                const int gridL = (int)std::min<int64_t>((e + 255) / 256, (int64_t)cus * 3);
+                hipLaunchKernelGGL((k_wvb_prepare_lanes<PW_, PH_>), dim3(gridL), dim3(256), 0, st, arena, wt, m->dev.stretch, mv, s, o.deep_q, o.deep_count);
+                lanes = true;
+            }
+        }
+        if (!lanes) {
+            const int gridP = (int)std::min<int64_t>((e + 3) / 4, (int64_t)cus * 8);
+            hipLaunchKernelGGL((k_wvb_prepare<PW_, PH_, RAW>), dim3(gridP), dim3(256), 0, st, arena, wt, m->dev, mv, s, o.deep_q, o.deep_count);
+        }
     }
     const int NQ = (mv.numPer + 3) / 4;
     for (int ph = 0; ph < mv.nphase; ++ph) {
