@@ -67,7 +67,7 @@ def test_two_caller_threads_with_their_own_contexts(capi, ctx, synth, small_mode
 NONSENSE = {
     "FD_ASYNC_THREADS": "-7", "FD_BATCH_THREADS": "0", "FD_BATCH_STREAMS": "9999", "FD_WVM_GRID_PER_CU": "-3", "FD_WVM_ROUNDS": "100000000",
     "FD_WVD_ROUNDS": "-1", "FD_WVM_POS_CAP": "banana", "FD_WVM_DEEP_CAP": "-12", "FD_WVB_PHASES": ",,x,0,-4,1,1,99999", "FD_WVM_DEEPB_PER_CU": "0",
-    "FD_WVB_EXIT_PER_CU": "-2", "FD_SVM_KERNEL": "77", "FD_WVM_DEEP_WAVES": "3", "FD_WVB_ADAPT": "maybe", "FD_PYR_FUSED": "", "FD_WVD_K": "-5",
+    "FD_WVB_EXIT_PER_CU": "-2", "FD_SVM_KERNEL": "77", "FD_WVM_DEEP_WAVES": "3", "FD_WVB_ADAPT": "maybe", "FD_PYR_FUSED": "", "FD_WVD_K": "-5", "FD_WVB_PREP_LANES": "-9",
 }
 
 
@@ -86,10 +86,12 @@ def test_prefilter_column_walks_of_every_length(k):
     """k_wvm_prefilter's lanes walk down their column through K windows, sliding the histogram; the library picks K per launch (1 for the
     small pyramids of most tests, 3 for the 64-frame headline, 16 on 1080p layers).  With K pinned (FD_WVD_K, read once per process) the
     production path must still give the exact path's positives byte for byte -- window steps 1, 2 and 3 (two and three rows leave and enter
-    per window), ragged row groups, a roi, six patch sizes -- and the 64-frame headline check against the oracle must still pass."""
+    per window), ragged row groups, a roi, six patch sizes -- and the 64-frame headline check against the oracle, the threshold-tie cases
+    of all five patch sizes and the late-rejecting models must still pass."""
     env = dict(os.environ)
     env["FD_WVD_K"] = str(k)
+    env["FD_WVB_PREP_LANES"] = "1"   # and stage B's lane == window prepare kernel for every queue, however short (default: from 4096 windows)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_fullsize.py", "tests/test_gpu_cascade_hardening.py", "-k",
-                        "production_path_equals_exact or headline_workload_against_the_oracle or exact_threshold_ties"],
+                        "production_path_equals_exact or headline_workload_against_the_oracle or exact_threshold_ties or rejection_profiles"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
