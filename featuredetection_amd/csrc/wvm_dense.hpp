@@ -127,8 +127,9 @@ __device__ __forceinline__ unsigned int wvd_addr(unsigned int bins, unsigned int
     return __builtin_amdgcn_perm(bins, laneWord, 0x0c020000u | ((4u + B_) << 8));   // {0, laneWord.b2, bins.b[B_], laneWord.b0}
 }
 // Equalise N_ dwords of pixels (N_ = 3, 4, 5) through the lane's LUT: out[j] = the four LUT bytes of w[j].  Written out as one block so
-// that all 4 N_ ds_read_u8 are in flight together and the wavefront waits for the LDS once (the compiler's schedule under this
-// kernel's register pressure waited after every second read); the address registers double as the read destinations.
+// that all 4 N_ ds_read_u8 are in flight together (the compiler's schedule under this kernel's register pressure waited after every
+// second read); the LDS answers in order, so the first dwords are packed while the last reads are still on their way; the address
+// registers double as the read destinations.
 // Per dword: shift, and-or, 4 address perms, 4 reads, 3 packing perms.
 #define WVD_EQ_ISSUE(j)                                                                                   \
     "v_lshrrev_b32 %[t], 2, %[w" #j "]\n v_and_or_b32 %[t], %[t], %[mask], %[blk]\n"                     \
@@ -147,16 +148,16 @@ __device__ __forceinline__ void wvd_equalise(const unsigned int* w, unsigned int
     static_assert(N_ >= 3 && N_ <= 5, "block sizes");
     unsigned int t, tb[N_], tc[N_], td[N_];
     if constexpr (N_ == 3)
-        asm volatile(WVD_EQ_ISSUE(0) WVD_EQ_ISSUE(1) WVD_EQ_ISSUE(2) "s_waitcnt lgkmcnt(0)\n" WVD_EQ_PACK(0) WVD_EQ_PACK(1) WVD_EQ_PACK(2)
+        asm volatile(WVD_EQ_ISSUE(0) WVD_EQ_ISSUE(1) WVD_EQ_ISSUE(2) "s_waitcnt lgkmcnt(4)\n" WVD_EQ_PACK(0) WVD_EQ_PACK(1) "s_waitcnt lgkmcnt(0)\n" WVD_EQ_PACK(2)
                      : [t] "=&v"(t), WVD_EQ_OUT(0), WVD_EQ_OUT(1), WVD_EQ_OUT(2)
                      : [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), WVD_EQ_IN);
     if constexpr (N_ == 4)
-        asm volatile(WVD_EQ_ISSUE(0) WVD_EQ_ISSUE(1) WVD_EQ_ISSUE(2) WVD_EQ_ISSUE(3) "s_waitcnt lgkmcnt(0)\n" WVD_EQ_PACK(0) WVD_EQ_PACK(1) WVD_EQ_PACK(2) WVD_EQ_PACK(3)
+        asm volatile(WVD_EQ_ISSUE(0) WVD_EQ_ISSUE(1) WVD_EQ_ISSUE(2) WVD_EQ_ISSUE(3) "s_waitcnt lgkmcnt(8)\n" WVD_EQ_PACK(0) WVD_EQ_PACK(1) "s_waitcnt lgkmcnt(0)\n" WVD_EQ_PACK(2) WVD_EQ_PACK(3)
                      : [t] "=&v"(t), WVD_EQ_OUT(0), WVD_EQ_OUT(1), WVD_EQ_OUT(2), WVD_EQ_OUT(3)
                      : [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), WVD_EQ_IN);
     if constexpr (N_ == 5)
-        asm volatile(WVD_EQ_ISSUE(0) WVD_EQ_ISSUE(1) WVD_EQ_ISSUE(2) WVD_EQ_ISSUE(3) WVD_EQ_ISSUE(4) "s_waitcnt lgkmcnt(0)\n"
-                     WVD_EQ_PACK(0) WVD_EQ_PACK(1) WVD_EQ_PACK(2) WVD_EQ_PACK(3) WVD_EQ_PACK(4)
+        asm volatile(WVD_EQ_ISSUE(0) WVD_EQ_ISSUE(1) WVD_EQ_ISSUE(2) WVD_EQ_ISSUE(3) WVD_EQ_ISSUE(4) "s_waitcnt lgkmcnt(8)\n"
+                     WVD_EQ_PACK(0) WVD_EQ_PACK(1) WVD_EQ_PACK(2) "s_waitcnt lgkmcnt(0)\n" WVD_EQ_PACK(3) WVD_EQ_PACK(4)
                      : [t] "=&v"(t), WVD_EQ_OUT(0), WVD_EQ_OUT(1), WVD_EQ_OUT(2), WVD_EQ_OUT(3), WVD_EQ_OUT(4)
                      : [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[4]), WVD_EQ_IN);
 }
