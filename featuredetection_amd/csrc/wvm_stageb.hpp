@@ -588,9 +588,11 @@ static void launch_stageb(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* m,
     };
     {
         const int64_t e = expect(0);
-        // lane == window when the queue is long enough to fill wavefronts (FD_WVB_PREP_LANES: the queue length from which it is taken,
-        // default 4096; 0 = never); window ids must fit 32 bits and be positions of the layer table
-        static const int64_t lanesFrom = [] { const char* v = getenv("FD_WVB_PREP_LANES"); const long long x = v ? atoll(v) : 4096; return (int64_t)(x < 0 ? 0 : x); }();
+        // lane == window when the queue is long (FD_WVB_PREP_LANES: the queue length from which it is taken, default 32768; 0 = never): a
+        // tile of 64 windows takes a wavefront ~26 us whatever the queue, one window per wavefront ~0.8 ns per window -- 16.6 K queued
+        // windows (the headline) are 11 us that way and 27 us this way, 290 K (cascade_late) 237 and 128 us.  Window ids must fit 32 bits
+        // and be positions of the layer table
+        static const int64_t lanesFrom = [] { const char* v = getenv("FD_WVB_PREP_LANES"); const long long x = v ? atoll(v) : 32768; return (int64_t)(x < 0 ? 0 : x); }();
         bool lanes = false;
         if constexpr (!RAW && PW_ != 0) {
             if (lanesFrom > 0 && e >= lanesFrom && !wt.list && wt.total < ((int64_t)1 << 32) && (mv.dstride & 3) == 0) {

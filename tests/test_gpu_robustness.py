@@ -90,7 +90,7 @@ def test_prefilter_column_walks_of_every_length(k):
     of all five patch sizes and the late-rejecting models must still pass."""
     env = dict(os.environ)
     env["FD_WVD_K"] = str(k)
-    env["FD_WVB_PREP_LANES"] = "1"   # and stage B's lane == window prepare kernel for every queue, however short (default: from 4096 windows)
+    env["FD_WVB_PREP_LANES"] = "1"   # and stage B's lane == window prepare kernel for every queue, however short (default: from 32 K windows)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_fullsize.py", "tests/test_gpu_cascade_hardening.py", "-k",
                         "production_path_equals_exact or headline_workload_against_the_oracle or exact_threshold_ties or rejection_profiles"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
