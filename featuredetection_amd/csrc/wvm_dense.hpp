@@ -97,12 +97,6 @@ struct WvdGeo {
     // registers (4 instead of 3 wavefronts per SIMD) but twice the steps -- measured equal (0.806 vs 0.794 ms, 16x24 ear
     // detector at 1080p), so the two-row form stays
     static constexpr int RPS = PW_ == 16 ? FD_WVD_RPS16 : 1;
-#ifndef FD_WVD_WPE
-#define FD_WVD_WPE 4
-#endif
-    // wavefronts per SIMD the register allocation aims at (LDS allows 4 workgroups = 16 wavefronts per CU): at 128 VGPRs the
-    // two-row k-step of the 16-wide patches spills 1 KB, the others ~140 B
-    static constexpr int WPE = (PW_ == 16 && RPS == 2) ? 3 : FD_WVD_WPE;
 };
 
 // LDS of a workgroup (4 wavefronts).  Histogram rows are 256 B: [wave pair][bin][wave of the pair][lane & 31] dwords, the u16 counters
