@@ -240,7 +240,7 @@ def test_batch_on_pool_streams_waits_for_the_pyramid_update(oracle, capi, ctx, s
         p.close()
 
 
-@pytest.mark.parametrize("nframes,size", [(5, (640, 480)), (16, (320, 240)), (3, (960, 540)), (64, (320, 240))])
+@pytest.mark.parametrize("nframes,size", [(5, (640, 480)), (16, (320, 240)), (3, (960, 540)), (64, (320, 240)), (11, (321, 243))])
 def test_multi_frame_pyramid_equals_single_frames(oracle, capi, ctx, synth, small_models, nframes, size):
     """fd_pyramid_set_frames / fd_pyramid_update_frames / fd_detect_five_stage_frames: n frames in one pyramid, one launch per pyramid
     stage, ONE cascade run and ONE SVM launch per call.  Every frame's layers and detections (boxes, order, scores, stage counts)

@@ -32,6 +32,8 @@ def test_native_library_loaded(capi, ctx):
 
 @pytest.mark.parametrize("size,kw", [((640, 480), FF), ((640, 480), dict(octave_layers=5, min_scale=1 / 16, max_scale=1.0)),
                                       ((321, 243), dict(octave_layers=3, min_scale=0.1, max_scale=0.8)),
+                                      ((1283, 721), dict(octave_layers=4, min_scale=0.05, max_scale=0.6)),   # width % 4 != 0: dwords over the right edge
+                                      ((97, 131), dict(octave_layers=6, min_scale=0.2, max_scale=1.0)),
                                       ((1920, 1080), dict(inc=float(np.float32(0.9)), min_scale=float(np.float32(0.09)),
                                                           max_scale=float(np.float32(0.25))))])
 def test_pyramid_layers_bit_exact(oracle, capi, ctx, synth, size, kw):
