@@ -1880,7 +1880,11 @@ static void wvm_build_dense(fd_wvm* m, const fd_wvm_model* md) {
         C.c128[k] = 128.0 * sumQ;
         C.pp[k] = md->pp[k];
         C.thr[k] = md->thresholds[k];
-        for (int pidx = 0; pidx <= k; ++pidx) C.w[k][pidx] = md->hk_weights[(size_t)k * md->num_filters + pidx];
+        for (int pidx = 0; pidx <= k; ++pidx) {
+            C.w[k][pidx] = md->hk_weights[(size_t)k * md->num_filters + pidx];
+            C.w2[k][pidx][0] = C.w[k][pidx];
+            C.w2[k][pidx][1] = std::fabs(C.w[k][pidx]);
+        }
         if (!std::isfinite(C.pp[k]) || !std::isfinite((double)C.thr[k])) return;
     }
     m->denseB.reserve(B.size());

@@ -54,6 +54,7 @@ struct WvdConst {
     double pp[WVD_L];
     float thr[WVD_L];
     float w[WVD_L][WVD_L];     // hkWeights[k][p], p <= k
+    float w2[WVD_L][WVD_L][2]; // {w, |w|}: the level sum and its error bound as one packed fma (k_wvm_prefilter)
 };
 
 struct WvdDev {
@@ -419,13 +420,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         // ---- 5. the first L cascade levels of this lane's window with error bounds
         bool undecided = active;
         {
-            float Kv[WVD_L], Ke[WVD_L];
+            typedef float wvd_v2f __attribute__((ext_vector_type(2)));
+            wvd_v2f KK[WVD_L];   // {K_p, bound of its error}: the level sum and its bound run as ONE v_pk_fma_f32 per term
             // the reference's fp32 sum of squares: row totals (exact ints) added in fp32, so it IS the integer below 2^24
             const float sxx = (float)sumxx;
             // |norm - reference norm|: 2 * quantisation error of xp, the fp32 sum of squares above 2^24, slack for the reference's
             // fp64 roundings (< 1e-5)
             const double dn = dv.scale * (double)sumx + (sumxx >= (1u << 24) ? (double)dv.sxxSlack : 0.0) + 1e-4;
             const float relDn = (float)(-(double)dv.negBasis * dn) * 1.0001f;
+            const __attribute__((address_space(4))) wvd_v2f* W2 = (const __attribute__((address_space(4))) wvd_v2f*)&C.w2[0][0][0];
 #pragma unroll
             for (int k = 0; k < WVD_L; ++k) {
                 if (k < L) {
@@ -444,17 +447,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
                         const float rho = (relDn + fabsf(arg) * 2.4e-7f + 6.0e-7f) * 1.01f + 4.6e-6f;
                         Kerr = Kk * rho + 1e-37f;
                     }
-                    Kv[k] = Kk;
-                    Ke[k] = Kerr;
-                    float R = dv.negBias, E = fabsf(dv.negBias) * 4.6e-6f + 1e-37f;
+                    KK[k] = wvd_v2f{Kk, Kerr};
+                    wvd_v2f RE = {dv.negBias, fabsf(dv.negBias) * 4.6e-6f + 1e-37f};
 #pragma unroll
-                    for (int p = 0; p <= k; ++p) {
-                        const float w = C.w[k][p];
-                        R = fmaf(w, Kv[p], R);
-                        E = fmaf(fabsf(w), Ke[p], E);
-                    }
+                    for (int p = 0; p <= k; ++p) RE = __builtin_elementwise_fma(W2[k * WVD_L + p], KK[p], RE);   // R += w K_p, E += |w| dK_p
                     // the reference leaves at the first level with res < thr, and res_ref <= R + E
-                    if (undecided && (R + E < C.thr[k])) undecided = false;
+                    if (undecided && (RE.x + RE.y < C.thr[k])) undecided = false;
                 }
             }
         }
