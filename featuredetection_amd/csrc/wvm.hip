@@ -425,7 +425,8 @@ struct CascadeOut {
     unsigned int* deep_count = nullptr;
     // zero-copy read-back (host_count != NULL): `pos` is host-mapped pinned memory, and the last workgroup of stage B to retire
     // stores the positive count there and clears the device header {pos_count, deep_count, pre-queue count, done_blocks} for
-    // the next run -- no copy, no memset on the stream, the event can be recorded straight after stage B
+    // the next run -- no copy, no memset on the stream, the event can be recorded straight after stage B.  The host reads the buffer
+    // only after that event (fd_wvm_finish): its release is what makes the kernel's stores visible, the kernels themselves do not fence
     unsigned int* host_count = nullptr;
     unsigned int* done_blocks = nullptr;
 };
@@ -442,12 +443,12 @@ __device__ __forceinline__ void wvm_finalize(const CascadeOut& o) {
     if (!o.host_count) return;
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
+        // no fences (see wvb_finalize): the count is an agent-scope atomic, and the host reads the pinned buffer only after the
+        // stream's completion event
         const unsigned int done = atomicAdd(o.done_blocks, 1u);
         if (done == gridDim.x - 1) {
-            __threadfence();
             const unsigned int cnt = __hip_atomic_load(o.pos_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(o.host_count, cnt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(o.host_count, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             // header words 0..3 of the device buffer: positives, stage-B queue, pre-filter queue, retired workgroups
             __hip_atomic_store(o.pos_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(o.deep_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -382,17 +382,18 @@ __device__ __forceinline__ void wvb_finalize(const CascadeOut& o, const WvbState
     if (!o.host_count) return;
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
+        // No fences: everything the last workgroup reads here was written with agent-scope atomics, and the host reads the pinned
+        // buffer only after the stream's completion event (fd_wvm_finish), whose release makes every store of the kernel visible.
+        // (__threadfence() is an L2 write-back per workgroup on this part -- buffer_wbl2 -- and the system-scope release store another.)
         const unsigned int done = atomicAdd(o.done_blocks, 1u);
         if (done == gridDim.x - 1) {
-            __threadfence();
             const unsigned int cnt = __hip_atomic_load(o.pos_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned int dq = __hip_atomic_load(o.deep_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // host header words 1..3: windows queued for stage B, alive at the start of phases 1 and 2 (the host adapts its phase plan)
             __hip_atomic_store(o.host_count + 1, dq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(o.host_count + 2, __hip_atomic_load(s.cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(o.host_count + 3, __hip_atomic_load(s.cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(o.host_count, cnt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(o.host_count, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(o.pos_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(o.deep_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(o.deep_count + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
