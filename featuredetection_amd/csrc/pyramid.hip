@@ -44,6 +44,7 @@ struct FusedJobs {
 };
 struct DownJobs {
     int n;
+    int tile0[MAXJ + 1];   // k_pyrdown_tiled: first tile of every job in the launch's flat tile list (exact grids: no empty workgroups)
     DownJob j[MAXJ];
 };
 struct FilterJob {
@@ -489,16 +490,19 @@ __global__ __launch_bounds__(256) void k_resize_down(uint8_t* __restrict__ arena
 
 __global__ __launch_bounds__(256) void k_pyrdown_tiled(uint8_t* __restrict__ arena, DownJobs jobs, size_t imageStride) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[TL_ROWS * TL_PITCH];
-    const DownJob jb = jobs.j[blockIdx.y];
-    const int sw = jb.sw, sh = jb.sh;
-    const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
     arena += (size_t)blockIdx.z * imageStride;   // blockIdx.z = frame of a multi-frame pyramid
-    const uint8_t* src = arena + jb.src_off;
-    uint8_t* dst = arena + jb.dst_off;
-    const int tilesX = (dw + TL_W - 1) / TL_W, tilesY = (dh + PD_TH - 1) / PD_TH;
     const int c = threadIdx.x & 63, rq = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // rq scalar: row offsets on the scalar unit
     constexpr int NDW = (2 * TL_W + 3 + 3) / 4, NROWS = 2 * PD_TH + 3;   // 131 source columns, 35 source rows per tile
-    for (int t = blockIdx.x; t < tilesX * tilesY; t += gridDim.x) {
+    for (int g = blockIdx.x; g < jobs.tile0[jobs.n]; g += gridDim.x) {   // flat list of the tiles of all jobs
+        int ji = 0;
+        while (ji + 1 < jobs.n && g >= jobs.tile0[ji + 1]) ++ji;
+        const DownJob jb = jobs.j[ji];
+        const int t = g - jobs.tile0[ji];
+        const int sw = jb.sw, sh = jb.sh;
+        const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+        const uint8_t* src = arena + jb.src_off;
+        uint8_t* dst = arena + jb.dst_off;
+        const int tilesX = (dw + TL_W - 1) / TL_W;
         const int ty = t / tilesX, tx = t - ty * tilesX;
         const int dx0 = tx * TL_W, dy0 = ty * PD_TH;
         const int X0 = 2 * dx0 - 2, Y0 = 2 * dy0 - 2;
@@ -1036,12 +1040,11 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
     {   // generation 1 of the chains k_resize_down does not cover (the scale-1 chain: pyrDown of the gray image itself)
         DownJobs dj;
         dj.n = 0;
-        int maxtiles = 0;
+        dj.tile0[0] = 0;
         auto flush1 = [&]() {
             if (!dj.n) return;
-            hipLaunchKernelGGL(k_pyrdown_tiled, dim3(tile_grid_for(maxtiles), dj.n, NI), dim3(256), 0, st, arena, dj, IS);
+            hipLaunchKernelGGL(k_pyrdown_tiled, dim3(tile_grid_for(dj.tile0[dj.n]), 1, NI), dim3(256), 0, st, arena, dj, IS);
             dj.n = 0;
-            maxtiles = 0;
         };
         for (size_t k = 1; k < p->all.size(); ++k) {
             const HostLayer& L = p->all[k];
@@ -1049,7 +1052,7 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
             const HostLayer& S = p->all[k - 1];
             DownJob& j = dj.j[dj.n++];
             j.sw = S.w; j.sh = S.h; j.src_off = S.gray_off; j.dst_off = L.gray_off;
-            maxtiles = std::max(maxtiles, ((L.w + TL_W - 1) / TL_W) * ((L.h + PD_TH - 1) / PD_TH));
+            dj.tile0[dj.n] = dj.tile0[dj.n - 1] + ((L.w + TL_W - 1) / TL_W) * ((L.h + PD_TH - 1) / PD_TH);
             if (dj.n == MAXJ) flush1();
         }
         flush1();
@@ -1059,13 +1062,11 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
     for (int d = 2; d <= maxDepth; ++d) {
         DownJobs jobs;
         jobs.n = 0;
-        int maxpix = 0, maxtiles = 0;
+        jobs.tile0[0] = 0;
         auto flush = [&]() {
             if (!jobs.n) return;
-            hipLaunchKernelGGL(k_pyrdown_tiled, dim3(tile_grid_for(maxtiles), jobs.n, NI), dim3(256), 0, st, arena, jobs, IS);
+            hipLaunchKernelGGL(k_pyrdown_tiled, dim3(tile_grid_for(jobs.tile0[jobs.n]), 1, NI), dim3(256), 0, st, arena, jobs, IS);
             jobs.n = 0;
-            maxpix = 0;
-            maxtiles = 0;
         };
         for (size_t k = 0; k < p->all.size(); ++k) {
             const HostLayer& L = p->all[k];
@@ -1073,8 +1074,7 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
             const HostLayer& S = p->all[k - 1];  // previous entry of the same chain
             DownJob& j = jobs.j[jobs.n++];
             j.sw = S.w; j.sh = S.h; j.src_off = S.gray_off; j.dst_off = L.gray_off;
-            maxpix = std::max(maxpix, L.w * L.h);
-            maxtiles = std::max(maxtiles, ((L.w + TL_W - 1) / TL_W) * ((L.h + PD_TH - 1) / PD_TH));
+            jobs.tile0[jobs.n] = jobs.tile0[jobs.n - 1] + ((L.w + TL_W - 1) / TL_W) * ((L.h + PD_TH - 1) / PD_TH);
             if (jobs.n == MAXJ) flush();
         }
         flush();
