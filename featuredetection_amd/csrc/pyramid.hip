@@ -335,23 +335,14 @@ __device__ __forceinline__ void fused_issue(FusedFetch& f, const uint8_t* __rest
     const int X0 = d.x & 0xffff, Y0 = (int)((uint32_t)d.x >> 16), ncol = d.y & 0xffff, nrow = (int)((uint32_t)d.y >> 16);
     const int gx0 = 2 * (d.z & 0xffff) * FT_W1 - 2;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int x = X0 + 4 * lane;
     const bool mine = 4 * lane < ncol;
     const uint8_t* row = src + (uint32_t)((Y0 + wave) * sw);
-    if (x + 3 < sw) {
+    // A dword that hangs over the right edge of the image takes its last bytes from the next row (or, in the last row, from the arena
+    // behind the gray image): they stand for columns >= sw, which no tap reads (the last column's right neighbour has weight 0).
 #pragma unroll
-        for (int q = 0; q < FS_LOADS; ++q, row += 4 * sw) {
-            f.v[q] = 0;
-            if (mine && wave + 4 * q < nrow) f.v[q] = ld_u32_unaligned(row + x);
-        }
-    } else {   // the dword hangs over the right edge of the image
-#pragma unroll
-        for (int q = 0; q < FS_LOADS; ++q, row += 4 * sw) {
-            uint32_t v = 0;
-            if (mine && wave + 4 * q < nrow)
-                for (int b = 0; b < 4; ++b) v |= (uint32_t)row[min(x + b, sw - 1)] << (8 * b);
-            f.v[q] = v;
-        }
+    for (int q = 0; q < FS_LOADS; ++q, row += 4 * sw) {
+        f.v[q] = 0;
+        if (mine && wave + 4 * q < nrow) f.v[q] = ld_u32_unaligned(row + 4 * lane + X0);
     }
     f.ex = tabs[jb.xtab + reflect101(gx0 + (int)(threadIdx.x & 127), jb.dw0)];
     {   // BORDER_REFLECT_101 of the resized rows the kept pyrDown rows reach (one reflection); rows further out only feed pyrDown
