@@ -75,6 +75,11 @@ __device__ __forceinline__ unsigned int mul24(unsigned int a, unsigned int b) {
     asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ unsigned int mul24_s(unsigned int a_uniform, unsigned int b) {   // a wave-uniform factor stays in its SGPR
+    unsigned int r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "s"(a_uniform), "v"(b));
+    return r;
+}
 __device__ __forceinline__ unsigned int mad24(unsigned int a, unsigned int b, unsigned int c) {
     unsigned int r;
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -405,25 +410,26 @@ __global__ __launch_bounds__(256) void k_resize_down(uint8_t* __restrict__ arena
                 const uint8_t* sp = stage + (ex.x - X0);
                 const unsigned int a0 = ex.y & 0xffff, a1 = (unsigned int)ex.y >> 16;
                 uint8_t* gp = g0 + c;
-                // three rows at a time: their twelve byte loads first, then the arithmetic (one LDS round trip per three rows)
+                // three rows at a time: their twelve byte loads first, then the arithmetic (one LDS round trip per three rows).  The 35 rows
+                // are dealt as 0..17 / 17..34: row 17 is computed by both halves (the same value, stored twice) and nothing is predicated
+                const int rBase = half * (G0_H - 18);
 #pragma unroll 2
                 for (int i = 0; i < 18; i += 3) {
                     unsigned int s00[3], s01[3], s10[3], s11[3], e1[3];
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
-                        const int rr = min(half * 18 + i + q, G0_H - 1);   // rows 0..17 / 18..34 (the 18th of the second half is a repeat, not stored)
-                        const unsigned int e0 = (unsigned int)__builtin_amdgcn_readlane(ey.x, rr);
-                        e1[q] = (unsigned int)__builtin_amdgcn_readlane(ey.y, rr);
+                        const int r = rBase + i + q;
+                        const unsigned int e0 = (unsigned int)__builtin_amdgcn_readlane(ey.x, r);
+                        e1[q] = (unsigned int)__builtin_amdgcn_readlane(ey.y, r);
                         const int o0 = ((int)(e0 & 0xffff) - Y0) * FS_PITCH, o1 = ((int)(e0 >> 16) - Y0) * FS_PITCH;
                         s00[q] = sp[o0]; s01[q] = sp[o0 + 1]; s10[q] = sp[o1]; s11[q] = sp[o1 + 1];
                     }
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
-                        const int r = half * 18 + i + q;
                         const unsigned int h0 = mad24(s01[q], a1, mul24(s00[q], a0)) >> 4;   // cv::resize's horizontal intermediate
                         const unsigned int h1 = mad24(s11[q], a1, mul24(s10[q], a0)) >> 4;
-                        const unsigned int v = ((mul24(e1[q] & 0xffff, h0) >> 16) + (mul24(e1[q] >> 16, h1) >> 16) + 2) >> 2;
-                        if (r < G0_H) gp[r * G0_PITCH] = (uint8_t)v;
+                        const unsigned int v = ((mul24_s(e1[q] & 0xffff, h0) >> 16) + (mul24_s(e1[q] >> 16, h1) >> 16) + 2) >> 2;
+                        gp[(rBase + i + q) * G0_PITCH] = (uint8_t)v;
                     }
                 }
             }
