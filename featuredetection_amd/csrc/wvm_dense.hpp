@@ -437,16 +437,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
                     norm = norm - 2 * xp;
                     norm = norm + C.pp[k];
                     const float arg = (float)((double)dv.negBasis * norm);
-                    float Kk, Kerr;
-                    if (arg < -80.0f) { Kk = 0.f; Kerr = 2e-35f; }           // true K <= e^-80 (1 + tiny)
-                    else if (arg > 80.0f) { Kk = 0.f; Kerr = 3.0e38f; }       // cannot happen for a sane model: never reject
-                    else {
-                        Kk = __expf(arg);
-                        // relative error of K: exponent error (quantisation, float cast of the argument, x * log2e, 2^x), the final
-                        // rounding, and -- folded in here -- the fp32 summation-order term (4k + 16) 2^-24 <= 4.6e-6 of the level sums
-                        const float rho = (relDn + fabsf(arg) * 2.4e-7f + 6.0e-7f) * 1.01f + 4.6e-6f;
-                        Kerr = Kk * rho + 1e-37f;
-                    }
+                    // relative error of K: exponent error (quantisation, float cast of the argument, x * log2e, 2^x), the final
+                    // rounding, and -- folded in here -- the fp32 summation-order term (4k + 16) 2^-24 <= 4.6e-6 of the level sums.
+                    // Branch-free: the exponential is taken of every argument and replaced where it is out of range (selects, not the
+                    // three exec-masked blocks per level the if / else chain compiled to)
+                    const float Kraw = __expf(arg);
+                    const float rho = (relDn + fabsf(arg) * 2.4e-7f + 6.0e-7f) * 1.01f + 4.6e-6f;
+                    const bool lo = arg < -80.0f, hi = arg > 80.0f;   // lo: true K <= e^-80 (1 + tiny); hi cannot happen for a sane model: never reject
+                    const float Kk = (lo || hi) ? 0.f : Kraw;
+                    const float Kerr = hi ? 3.0e38f : (lo ? 2e-35f : Kraw * rho + 1e-37f);
                     KK[k] = wvd_v2f{Kk, Kerr};
                     wvd_v2f RE = {dv.negBias, fabsf(dv.negBias) * 4.6e-6f + 1e-37f};
 #pragma unroll
