@@ -64,6 +64,13 @@ __device__ __forceinline__ int reflect101(int p, int len) {
     }
     return p;
 }
+// BORDER_REFLECT_101 for a coordinate at most one reflection away; anything further out is clamped (the tiled kernels only meet
+// such coordinates under outputs that lie outside the layer and are not stored)
+__device__ __forceinline__ int reflect1(int p, int len) {
+    if (len < 3) return reflect101(p, len);   // the 5-tap halo reaches two pixels out: one reflection needs three pixels
+    const int q = p < 0 ? -p : (p >= len ? 2 * len - 2 - p : p);
+    return min(max(q, 0), len - 1);
+}
 
 // cv::cvtColor(BGR2GRAY), 8U: (B*1868 + G*9617 + R*4899 + 8192) >> 14
 struct FramePtrs {
@@ -514,7 +521,7 @@ __global__ __launch_bounds__(256) void k_pyrdown_tiled(uint8_t* __restrict__ are
                 if (e < NROWS * NDW) {
                     const int r = e / NDW, j = e - r * NDW;
                     const int xs = X0 + 4 * j;
-                    if (xs >= 0 && xs + 3 < sw) v[k] = ld_u32_unaligned(src + (uint32_t)(reflect101(Y0 + r, sh) * sw) + xs);
+                    if (xs >= 0 && xs + 3 < sw) v[k] = ld_u32_unaligned(src + (uint32_t)(reflect1(Y0 + r, sh) * sw) + xs);
                 }
             }
 #pragma unroll
@@ -525,9 +532,10 @@ __global__ __launch_bounds__(256) void k_pyrdown_tiled(uint8_t* __restrict__ are
                     const int xs = X0 + 4 * j;
                     uint32_t w = v[k];
                     if (!(xs >= 0 && xs + 3 < sw)) {   // BORDER_REFLECT_101 columns
-                        const uint8_t* row = src + (uint32_t)(reflect101(Y0 + r, sh) * sw);
+                        const uint8_t* row = src + (uint32_t)(reflect1(Y0 + r, sh) * sw);
                         w = 0;
-                        for (int b = 0; b < 4; ++b) w |= (uint32_t)row[reflect101(xs + b, sw)] << (8 * b);
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) w |= (uint32_t)row[reflect1(xs + b, sw)] << (8 * b);
                     }
                     *reinterpret_cast<uint32_t*>(&tile[r * TL_PITCH + 4 * j]) = w;
                 }
