@@ -268,7 +268,9 @@ __global__ __launch_bounds__(256) void k_svm_u8_lanes(SvmDev m, const void* __re
 // support vectors per 2 patches (426 KB of L2 traffic per pair) and spent 68 us per 64-frame call; this one reads them once per 32.
 typedef int svm_v4i __attribute__((ext_vector_type(4)));
 typedef int svm_v16i __attribute__((ext_vector_type(16)));
-constexpr int SU_W = 8;   // wavefronts per workgroup
+// SU_W wavefronts per workgroup (8, or 16 when the launch has fewer workgroups than the chip has CUs).  The result does not depend on
+// it: every tile of 32 support vectors leaves one partial sum per patch, and the partials are added in a fixed pairwise order.
+template <int SU_W>
 __global__ __launch_bounds__(64 * SU_W) void k_svm_u8_rbf_mfma(SvmDev m, const void* __restrict__ features, const uint32_t* __restrict__ idx,
                                                                int64_t feat_stride_bytes, int64_t n, double* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(64 * SU_W) void k_svm_u8_rbf_mfma(SvmDev m, const v
     const int KS = m.KS, DS = KS * 32 + 16;   // row stride: an odd number of 16-byte slots (conflict-free ds_read_b128 across the rows)
     unsigned char* xs = smem;                                                   // [32][DS] x - 128
     int* xxs = reinterpret_cast<int*>(smem + 32 * DS);                          // [32] |x'|^2
-    double* red = reinterpret_cast<double*>(smem + 32 * DS + 128);              // [SU_W][32]
+    double* ts = reinterpret_cast<double*>(smem + 32 * DS + 128);               // [tiles][32]: a tile's partial sum for every patch
     const int64_t item0 = (int64_t)blockIdx.x * 32;
     {   // stage the 32 feature vectors (gathered through idx), zero padded; dwords where the layout allows
         const bool words = (m.dim & 3) == 0 && (feat_stride_bytes & 3) == 0 && ((uintptr_t)features & 3) == 0;
@@ -311,7 +313,6 @@ __global__ __launch_bounds__(64 * SU_W) void k_svm_u8_rbf_mfma(SvmDev m, const v
     const unsigned char* xb = xs + (lane & 31) * DS + (lane >> 5) * 16;
     const svm_v4i* A = reinterpret_cast<const svm_v4i*>(m.svA);
     const int ntiles = m.nsv32 >> 5;
-    double sum = 0.0;
     for (int t = wave; t < ntiles; t += SU_W) {
         const svm_v4i* Ap = A + (size_t)t * KS * 64 + lane;
         svm_v16i acc = {};
@@ -330,19 +331,22 @@ __global__ __launch_bounds__(64 * SU_W) void k_svm_u8_rbf_mfma(SvmDev m, const v
             }
         }
         // acc[r] = x' . s' for support vector t * 32 + row(r) and this lane's patch
+        double sum = 0.0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int sv = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const int ssd = xxv + m.ssShift[sv] - 2 * acc[r];
             sum += m.coeffD[sv] * exp(-m.p0 * (double)ssd);   // padded support vectors have coefficient 0
         }
+        sum += __shfl_xor(sum, 32, 64);   // the two halves of the tile's rows
+        if (lane < 32) ts[t * 32 + lane] = sum;
     }
-    sum += __shfl_xor(sum, 32, 64);
-    if (lane < 32) red[wave * 32 + lane] = sum;
     __syncthreads();
-    if (threadIdx.x < 32 && item0 + threadIdx.x < n) {
-        const double* r = red + threadIdx.x;
-        out[item0 + threadIdx.x] = -(double)m.bias + (((r[0] + r[32]) + (r[64] + r[96])) + ((r[128] + r[160]) + (r[192] + r[224])));
+    if (threadIdx.x < 32) {   // the tiles' partials of patch threadIdx.x, pairwise: (t0 + t1) + (t2 + t3) ...
+        double* c = ts + threadIdx.x;
+        for (int step = 1; step < ntiles; step <<= 1)
+            for (int t = 0; t + step < ntiles; t += 2 * step) c[t * 32] += c[(t + step) * 32];
+        if (item0 + threadIdx.x < n) out[item0 + threadIdx.x] = -(double)m.bias + c[0];
     }
 }
 
@@ -643,10 +647,14 @@ void fd_svm_generic_launch_on(hipStream_t st, const fd_svm* m, const void* dfeat
                               int64_t n, double* dout) {
     if (n <= 0) return;
     static const bool u8Lanes = [] { const char* e = getenv("FD_SVM_U8_LANES"); return e && atoi(e) != 0; }();   // A/B: the older kernel
-    if (m->dev.dtype == FD_DTYPE_U8 && m->dev.kernel == FD_KERNEL_RBF && m->dev.svA && !u8Lanes) {
-        const size_t lb = (size_t)32 * (m->dev.KS * 32 + 16) + 128 + sizeof(double) * SU_W * 32;
+    // LDS of k_svm_u8_rbf_mfma: 32 patches + one partial sum per (tile of 32 support vectors, patch); beyond the 64 KB a launch gets
+    // without opting in (very long vectors with thousands of support vectors) the lane-per-support-vector kernel takes over
+    const size_t lb = (size_t)32 * (m->dev.KS * 32 + 16) + 128 + sizeof(double) * (size_t)(m->dev.nsv32 >> 5) * 32;
+    if (m->dev.dtype == FD_DTYPE_U8 && m->dev.kernel == FD_KERNEL_RBF && m->dev.svA && !u8Lanes && lb <= 64 * 1024) {
         const unsigned grid = (unsigned)((n + 31) / 32);
-        hipLaunchKernelGGL(k_svm_u8_rbf_mfma, dim3(grid), dim3(64 * SU_W), lb, st, m->dev, dfeat, didx, stride_bytes, n, dout);
+        // fewer workgroups than CUs (n < 8 K patches: a 64-frame call of the headline has 4.7 K, a single frame 80): 16 wavefronts each
+        if (grid < 256u) hipLaunchKernelGGL(k_svm_u8_rbf_mfma<16>, dim3(grid), dim3(64 * 16), lb, st, m->dev, dfeat, didx, stride_bytes, n, dout);
+        else hipLaunchKernelGGL(k_svm_u8_rbf_mfma<8>, dim3(grid), dim3(64 * 8), lb, st, m->dev, dfeat, didx, stride_bytes, n, dout);
         HIP_CHECK(hipGetLastError());
         return;
     }
