@@ -279,17 +279,22 @@ __global__ __launch_bounds__(64 * SU_W) void k_svm_u8_rbf_mfma(SvmDev m, const v
     const int KS = m.KS, DS = KS * 32 + 16;   // row stride: an odd number of 16-byte slots (conflict-free ds_read_b128 across the rows)
     unsigned char* xs = smem;                                                   // [32][DS] x - 128
     int* xxs = reinterpret_cast<int*>(smem + 32 * DS);                          // [32] |x'|^2
-    double* ts = reinterpret_cast<double*>(smem + 32 * DS + 128);               // [tiles][32]: a tile's partial sum for every patch
+    int64_t* slots = reinterpret_cast<int64_t*>(smem + 32 * DS + 128);          // [32] where the patches are (-1: past the end)
+    double* ts = reinterpret_cast<double*>(smem + 32 * DS + 384);               // [tiles][32]: a tile's partial sum for every patch
     const int64_t item0 = (int64_t)blockIdx.x * 32;
+    if (threadIdx.x < 32) {   // the slot list may live in host memory (zero-copy): ONE read per patch, not one per staged dword
+        const int64_t item = item0 + threadIdx.x;
+        slots[threadIdx.x] = item < n ? (idx ? (int64_t)idx[item] : item) : -1;
+    }
+    __syncthreads();
     {   // stage the 32 feature vectors (gathered through idx), zero padded; dwords where the layout allows
         const bool words = (m.dim & 3) == 0 && (feat_stride_bytes & 3) == 0 && ((uintptr_t)features & 3) == 0;
         const int wpr = DS >> 2;
         for (int i = threadIdx.x; i < 32 * wpr; i += 64 * SU_W) {
             const int row = i / wpr, col = (i - row * wpr) * 4;
-            const int64_t item = item0 + row;
+            const int64_t slot = slots[row];
             uint32_t v = 0;
-            if (item < n && col < m.dim) {
-                const int64_t slot = idx ? (int64_t)idx[item] : item;
+            if (slot >= 0 && col < m.dim) {
                 const unsigned char* x = (const unsigned char*)features + slot * feat_stride_bytes + col;
                 if (words) {
                     v = *reinterpret_cast<const uint32_t*>(x) ^ 0x80808080u;
@@ -302,11 +307,15 @@ __global__ __launch_bounds__(64 * SU_W) void k_svm_u8_rbf_mfma(SvmDev m, const v
         }
     }
     __syncthreads();
-    if (threadIdx.x < 32) {   // |x'|^2 of the 32 vectors
-        const uint32_t* r = reinterpret_cast<const uint32_t*>(xs + threadIdx.x * DS);
+    {   // |x'|^2 of the 32 vectors: P consecutive lanes share a vector (exact integers: any order)
+        constexpr int P = 2 * SU_W;
+        const int row = threadIdx.x / P, part = threadIdx.x % P;
+        const uint32_t* r = reinterpret_cast<const uint32_t*>(xs + row * DS);
         int acc = 0;
-        for (int i = 0; i < KS * 8; ++i) acc = __builtin_amdgcn_sdot4((int)r[i], (int)r[i], acc, false);
-        xxs[threadIdx.x] = acc;
+        for (int i = part; i < KS * 8; i += P) acc = __builtin_amdgcn_sdot4((int)r[i], (int)r[i], acc, false);
+#pragma unroll
+        for (int o = P / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (part == 0) xxs[row] = acc;
     }
     __syncthreads();
     const int xxv = xxs[lane & 31];
@@ -649,7 +658,7 @@ void fd_svm_generic_launch_on(hipStream_t st, const fd_svm* m, const void* dfeat
     static const bool u8Lanes = [] { const char* e = getenv("FD_SVM_U8_LANES"); return e && atoi(e) != 0; }();   // A/B: the older kernel
     // LDS of k_svm_u8_rbf_mfma: 32 patches + one partial sum per (tile of 32 support vectors, patch); beyond the 64 KB a launch gets
     // without opting in (very long vectors with thousands of support vectors) the lane-per-support-vector kernel takes over
-    const size_t lb = (size_t)32 * (m->dev.KS * 32 + 16) + 128 + sizeof(double) * (size_t)(m->dev.nsv32 >> 5) * 32;
+    const size_t lb = (size_t)32 * (m->dev.KS * 32 + 16) + 384 + sizeof(double) * (size_t)(m->dev.nsv32 >> 5) * 32;
     if (m->dev.dtype == FD_DTYPE_U8 && m->dev.kernel == FD_KERNEL_RBF && m->dev.svA && !u8Lanes && lb <= 64 * 1024) {
         const unsigned grid = (unsigned)((n + 31) / 32);
         // fewer workgroups than CUs (n < 8 K patches: a 64-frame call of the headline has 4.7 K, a single frame 80): 16 wavefronts each
