@@ -325,17 +325,37 @@ __global__ __launch_bounds__(64 * SU_W) void k_svm_u8_rbf_mfma(SvmDev m, const v
     for (int t = wave; t < ntiles; t += SU_W) {
         const svm_v4i* Ap = A + (size_t)t * KS * 64 + lane;
         svm_v16i acc = {};
-        svm_v4i an[4];
+        if constexpr (SU_W == 16) {
+            // Small launches (a tile or two per wavefront) wait for latency: the tile's operands sixteen k-steps ahead -- a 20 x 20 patch
+            // has 13 steps: one L2 round trip per tile instead of one per four steps
+            constexpr int AD = 16;
+            svm_v4i an[AD];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) an[q] = Ap[min(q, KS - 1) * 64];
-        for (int ks = 0; ks < KS; ks += 4) {
+            for (int q = 0; q < AD; ++q) an[q] = Ap[min(q, KS - 1) * 64];
+            for (int ks = 0; ks < KS; ks += AD) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const svm_v4i a = an[q];
-                an[q] = Ap[min(ks + 4 + q, KS - 1) * 64];
-                if (ks + q < KS) {
-                    const svm_v4i b = *reinterpret_cast<const svm_v4i*>(xb + (ks + q) * 32);
-                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc, 0, 0, 0);
+                for (int q = 0; q < AD; ++q) {
+                    const svm_v4i a = an[q];
+                    if (ks + AD < KS) an[q] = Ap[min(ks + AD + q, KS - 1) * 64];
+                    if (ks + q < KS) {
+                        const svm_v4i b = *reinterpret_cast<const svm_v4i*>(xb + (ks + q) * 32);
+                        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc, 0, 0, 0);
+                    }
+                }
+            }
+        } else {   // large launches keep their registers for occupancy: four steps ahead
+            svm_v4i an[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) an[q] = Ap[min(q, KS - 1) * 64];
+            for (int ks = 0; ks < KS; ks += 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const svm_v4i a = an[q];
+                    an[q] = Ap[min(ks + 4 + q, KS - 1) * 64];
+                    if (ks + q < KS) {
+                        const svm_v4i b = *reinterpret_cast<const svm_v4i*>(xb + (ks + q) * 32);
+                        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc, 0, 0, 0);
+                    }
                 }
             }
         }
