@@ -681,8 +681,12 @@ void fd_svm_generic_launch_on(hipStream_t st, const fd_svm* m, const void* dfeat
     const size_t lb = (size_t)32 * (m->dev.KS * 32 + 16) + 384 + sizeof(double) * (size_t)(m->dev.nsv32 >> 5) * 32;
     if (m->dev.dtype == FD_DTYPE_U8 && m->dev.kernel == FD_KERNEL_RBF && m->dev.svA && !u8Lanes && lb <= 64 * 1024) {
         const unsigned grid = (unsigned)((n + 31) / 32);
-        // fewer workgroups than CUs (n < 8 K patches: a 64-frame call of the headline has 4.7 K, a single frame 80): 16 wavefronts each
-        if (grid < 256u) hipLaunchKernelGGL(k_svm_u8_rbf_mfma<16>, dim3(grid), dim3(64 * 16), lb, st, m->dev, dfeat, didx, stride_bytes, n, dout);
+        // Sixteen wavefronts per workgroup (and a tile's operands sixteen k-steps ahead) make a lone small launch faster -- 25 -> 21 us for
+        // the 4.7 K patches of a headline call, 156 instead of 160 us for a single frame -- but its 1024-thread, 106-register workgroups
+        // take whole CUs away from the kernels of other calls: config 3 (30 cascades in flight) fell from 5.5 to 3.9 G patches/s.  Hence
+        // only on request (FD_SVM_WAVES=16), never by default.
+        static const bool wide = [] { const char* e = getenv("FD_SVM_WAVES"); return e && atoi(e) == 16; }();
+        if (wide && grid < 256u) hipLaunchKernelGGL(k_svm_u8_rbf_mfma<16>, dim3(grid), dim3(64 * 16), lb, st, m->dev, dfeat, didx, stride_bytes, n, dout);
         else hipLaunchKernelGGL(k_svm_u8_rbf_mfma<8>, dim3(grid), dim3(64 * 8), lb, st, m->dev, dfeat, didx, stride_bytes, n, dout);
         HIP_CHECK(hipGetLastError());
         return;

@@ -67,7 +67,7 @@ def test_two_caller_threads_with_their_own_contexts(capi, ctx, synth, small_mode
 NONSENSE = {
     "FD_ASYNC_THREADS": "-7", "FD_BATCH_THREADS": "0", "FD_BATCH_STREAMS": "9999", "FD_WVM_GRID_PER_CU": "-3", "FD_WVM_ROUNDS": "100000000",
     "FD_WVD_ROUNDS": "-1", "FD_WVM_POS_CAP": "banana", "FD_WVM_DEEP_CAP": "-12", "FD_WVB_PHASES": ",,x,0,-4,1,1,99999", "FD_WVM_DEEPB_PER_CU": "0",
-    "FD_WVB_EXIT_PER_CU": "-2", "FD_SVM_KERNEL": "77", "FD_WVM_DEEP_WAVES": "3", "FD_WVB_ADAPT": "maybe", "FD_PYR_FUSED": "", "FD_WVD_K": "-5", "FD_WVB_PREP_LANES": "-9",
+    "FD_WVB_EXIT_PER_CU": "-2", "FD_SVM_KERNEL": "77", "FD_WVM_DEEP_WAVES": "3", "FD_WVB_ADAPT": "maybe", "FD_PYR_FUSED": "", "FD_WVD_K": "-5", "FD_WVB_PREP_LANES": "-9", "FD_SVM_WAVES": "7",
 }
 
 
