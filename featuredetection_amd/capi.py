@@ -219,6 +219,7 @@ _BENCH_SIGS = {
     "fd_ctx_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "fd_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
     "fd_debug_wvb_rect_sums": (C.c_int64, [C.POINTER(fd_wvm_model), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "fd_debug_wvd_plan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 
 
@@ -460,6 +461,16 @@ class Dist:
         if self.h:
             lib().fd_dist_destroy(self.h)
             self.h = C.c_void_p()
+
+
+def wvd_plan(nx, ny, frames, sy, ph, slots):
+    """Test hook (no GPU): the dense pre-filter's plan for layers of nx[i] x ny[i] windows -> (K, first tile of every layer + tiles per frame)"""
+    nx, ny = _c(nx, np.int32), _c(ny, np.int32)
+    first = np.zeros(len(nx) + 1, np.int32)
+    k = lib().fd_debug_wvd_plan(_ptr(nx), _ptr(ny), len(nx), frames, sy, ph, slots, _ptr(first))
+    if k < 1:
+        raise FdError(k, "fd_debug_wvd_plan")
+    return k, first
 
 
 def wvb_rect_sums(model, patches_eq):

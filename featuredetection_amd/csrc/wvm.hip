@@ -3451,6 +3451,25 @@ int fd_debug_wvd_prof(unsigned long long* out, int nwaves) {
 }
 #endif
 
+// Test hook (include/fd_hip_bench.h; needs no GPU): the pre-filter's plan -- K and the tile list -- for a set of layers
+int fd_debug_wvd_plan(const int32_t* nx, const int32_t* ny, int n_layers, int frames, int sy, int ph, int slots, int32_t* tile_first) {
+    if (!nx || !ny || n_layers < 1 || n_layers > WVM_MAX_LAYERS || frames < 1 || sy < 1 || ph < 1 || slots < 1) return FD_ERR_INVALID_ARGUMENT;
+    WvdTable t;
+    std::memset(&t, 0, sizeof(t));
+    t.n = n_layers; t.sx = 1; t.sy = sy; t.nimg = frames;
+    for (int i = 0; i < n_layers; ++i) {
+        if (nx[i] < 1 || ny[i] < 1) return FD_ERR_INVALID_ARGUMENT;
+        t.l[i].nx = nx[i]; t.l[i].ny = ny[i];
+    }
+    const int K = wvd_choose_k(t, slots, ph);
+    const int tiles = wvd_plan_sliding(t, K);
+    if (tile_first) {
+        for (int i = 0; i < n_layers; ++i) tile_first[i] = t.l[i].sTileFirst;
+        tile_first[n_layers] = tiles;
+    }
+    return K;
+}
+
 // Test hook (include/fd_hip_bench.h; needs no GPU): the rect sums of every used level of `md` for n equalised patches, computed from
 // the stage-B tables with the operand addressing of k_wvb_chain (A fragment of lane h * 32 + row, byte t <-> pixel ks * 32 + h * 16 + t).
 // out[i * ncols + c]: c runs over the levels 0 .. numUsed - 1 in order, grey values 1 .. cntval - 1 inside a level.  Returns the number

@@ -21,6 +21,13 @@ int fd_last_kernel_ms(fd_ctx* ctx, const char** kernel_name, float* ms);
  * stage B.  phase_gen (5 ints, may be NULL) receives the generation boundaries of the phases, -1 padded. */
 int64_t fd_debug_wvb_rect_sums(const fd_wvm_model* md, const uint8_t* patches, int64_t n, int32_t* out, int32_t* phase_gen);
 
+/* Test hook, needs no GPU: the work plan of the dense pre-filter (k_wvm_prefilter) for n_layers layers of nx[i] x ny[i] windows,
+ * `frames` frames per launch, vertical window step sy, patch height ph, on a device with `slots` resident wavefronts.  A lane walks
+ * down a column through K windows; lane task t of layer i is column t % nx[i], row group t / nx[i] (rows g K .. min(ny, (g + 1) K) - 1),
+ * 64 tasks per tile.  Returns K (FD_WVD_K pins it); tile_first[i] = first tile of layer i inside a frame, tile_first[n_layers] = tiles
+ * per frame. */
+int fd_debug_wvd_plan(const int32_t* nx, const int32_t* ny, int n_layers, int frames, int sy, int ph, int slots, int32_t* tile_first);
+
 #ifdef __cplusplus
 }
 #endif

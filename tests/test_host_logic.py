@@ -227,3 +227,39 @@ def test_stage_b_tables_reproduce_the_rect_sums(capi, synth, shape):
             assert np.array_equal(sums[:, c], want), (k, v - v0)
             c += 1
     assert c == sums.shape[1]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_prefilter_plan_covers_every_window_once(capi, seed):
+    """k_wvm_prefilter's lanes walk down a column through K windows.  The host's plan (fd_debug_wvd_plan, no GPU): K from the cost
+    model (1 when the vertical step leaves nothing to slide, more when there are more tiles than wavefront slots), the tile list
+    contiguous, and the kernel's task -> (column, row group) mapping reaches every window of every layer exactly once."""
+    rng = np.random.default_rng(seed)
+    for _ in range(40):
+        n = int(rng.integers(1, 14))
+        nx = rng.integers(1, 400, n).astype(np.int32)
+        ny = rng.integers(1, 300, n).astype(np.int32)
+        frames = int(rng.choice([1, 1, 8, 64]))
+        sy = int(rng.choice([1, 1, 2, 3, 12]))
+        ph = int(rng.choice([16, 20, 24]))
+        slots = int(rng.choice([256, 3072]))
+        k, first = capi.wvd_plan(nx, ny, frames, sy, ph, slots)
+        assert 1 <= k <= 16
+        if 2 * sy > ph:
+            assert k == 1
+        assert first[0] == 0
+        for i in range(n):
+            g = -(-int(ny[i]) // k)
+            assert first[i + 1] - first[i] == -(-int(nx[i]) * g // 64), (i, k)
+            seen = np.zeros((int(ny[i]), int(nx[i])), np.int32)
+            t = np.arange(int(nx[i]) * g)
+            col, grp = t % int(nx[i]), t // int(nx[i])
+            for s in range(k):
+                row = grp * k + s
+                ok = row < int(ny[i])
+                np.add.at(seen, (row[ok], col[ok]), 1)
+            assert np.all(seen == 1)
+    # one tile's worth of work per slot at most: a single small frame is not walked at all, a big launch gets long columns
+    assert capi.wvd_plan([77, 45], [53, 29], 1, 1, 20, 3072)[0] == 1
+    assert capi.wvd_plan([1901], [1061], 1, 1, 24, 3072)[0] >= 8
+    assert capi.wvd_plan([1901], [1061], 64, 1, 24, 3072)[0] == 16
