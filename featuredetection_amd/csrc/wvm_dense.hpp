@@ -5,27 +5,30 @@
 // (SURVEY.md App. A.3), and for k < numFiltersPerLevel nothing is carried over from earlier levels (u_kernel_eval[n] is still 0).
 // So the first L <= min(16, numPer) kernel values of ALL windows are one [windows x d] . [d x L] contraction:
 //
-//   k_wvm_prefilter: lane == window (64 consecutive windows of a layer per wavefront).
+//   k_wvm_prefilter: lane == window; a lane walks down its column of a layer through K windows (64 columns / row groups per wavefront).
 //     1. HistEq64 (HistEq64Filter.cpp:32-125) lane-serial: private 64-bin histogram column in LDS (u16 counters, lanes l and l + 32
-//        share a dword: ds_add_u32 of 1 << 16*(lane>>5), conflict-free), the fp32 cdf as a plain 63-step chain in the lane's
-//        registers (same operation order as the reference, 64 windows per instruction instead of the DPP chain's one), LUT written
-//        back over the counters.  sum(x) and sum(x^2) of the equalised patch come from the histogram (exact integers); the
-//        reference's fp32 sum of squares (IImg.cpp:33-47) equals the integer below 2^24 and is within 2*ph + 2 of it above.
-//     2. the equalised pixels go to LDS as signed bytes (x - 128), one patch row (two for 16-wide patches) per k-step, and are
-//        multiplied on v_mfma_i32_32x32x32_i8 against the residual images quantised to 32-bit integers Q = round(r * 2^s) and
-//        split into four balanced base-256 digits: integer arithmetic, so x . Q is EXACT; |x . r - 2^-s x . Q| <= 2^-(s+1) * sum(x)
-//        is the only approximation.
+//        share a dword: ds_add_u32 of 1 << 16*(lane>>5), conflict-free; one v_perm_b32 per pixel address) that survives the window:
+//        the next window down takes the rows that left out of it and adds the rows that entered.  The fp32 cdf is a plain 63-step
+//        chain in the lane's registers (same operation order as the reference, 64 windows per instruction instead of the DPP chain's
+//        one), the LUT goes to its own LDS block.  sum(x) and sum(x^2) of the equalised patch come from the histogram (exact integers);
+//        the reference's fp32 sum of squares (IImg.cpp:33-47) equals the integer below 2^24 and is within 2*ph + 2 of it above.
+//     2. the equalised pixels (x - 128 as int8, gathered through the LUT one patch row -- two for 16-wide patches -- per k-step) are
+//        the B operand of v_mfma_i32_32x32x32_i8, built in registers with v_permlane32_swap; the A operand is the residual images
+//        quantised to 32-bit integers Q = round(r * 2^s) and split into four balanced base-256 digits: integer arithmetic, so x . Q is
+//        EXACT; |x . r - 2^-s x . Q| <= 2^-(s+1) * sum(x) is the only approximation.  The accumulators C[digit row][window] are folded
+//        into exact doubles and brought back to lane == window with v_permlane32_swap.
 //     3. per window: norm, K = exp(-basis * norm), res_k = -bias + sum_p w[k][p] K_p with a rigorous error bound eps_k on
 //        |res_k - reference res_k| (quantisation, fast fp32 exp, fp32 summation order).  A window with res_k + eps_k < thr_k at ANY
 //        level k < L is rejected by the reference at some level <= k, so it cannot be a WVM positive and is dropped here.
-//        Everything else is appended to a queue and runs the exact cascade kernels (k_wvm_cascade4/2 -> k_wvm_deep4) unchanged,
-//        so positives, their levels and their fp32 outputs stay bit-identical to the rectangle-sum formulation.
+//        Everything else is appended to a queue and runs the exact stage B (wvm_stageb.hpp) from level 0, so positives, their levels
+//        and their fp32 outputs stay bit-identical to the rectangle-sum formulation.
+//   k_wvm_prefilter_multi: the first formulation (64 consecutive windows per wavefront, pixels staged and results transposed through
+//     LDS) for several detectors on the same windows; off by default (FD_WVM_GROUP=1).
+//   k_wvb_prepare_lanes: stage B's preparation of long queues with the same per-lane machinery.
 //   Only used when no per-window outputs are requested (fd_detect_wvm with all_level / all_score takes the exact path for every window).
 #pragma once
 
-constexpr int WVD_L = 16;          // filters evaluated densely (columns: 16 filters x 4 digits = 2 N-tiles of 32)
-// LDS pixel chunk of a k-step: two planes of 64 windows x 16 bytes (k-slots 0..15 / 16..31): b128 writes (lane == window) and
-// b128 reads (lane == matrix row, plane = lane >> 5) are both conflict-free without padding
+constexpr int WVD_L = 16;          // filters evaluated densely (16 filters x 4 digits = two tiles of 32 digit rows)
 
 typedef int wvd_v4i __attribute__((ext_vector_type(4)));
 typedef int wvd_v16i __attribute__((ext_vector_type(16)));
