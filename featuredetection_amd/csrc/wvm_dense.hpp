@@ -104,16 +104,19 @@ struct WvdGeo {
 };
 
 // LDS of a workgroup (4 wavefronts).  Histogram rows are 256 B: [wave pair][bin][wave of the pair][lane & 31] dwords, the u16 counters
-// of lanes l (low half) and l + 32 (high half) in one dword; LUT rows are 256 B too: [bin][wave][lane] bytes.  With every 16 KB block
+// of lanes l (low half) and l + 32 (high half) in one dword; LUT rows are 256 B too: [bin][lane][wave] bytes -- the byte of lane l sits
+// in dword l of its bin row, so the 32 lanes of a ds_read_u8 lane group hit 32 different banks whatever their bins are (round 3's
+// [bin][wave][lane] order put lanes 4j..4j+3 into one dword: a 4-way conflict whenever their bins differed, 63 % of the kernel's LDS
+// cycles by SQ_LDS_BANK_CONFLICT).  With every 16 KB block
 // 16 KB-aligned, the LDS address of (bin, lane) is {byte 3: 0, byte 2: lane word, byte 1: bin | block bits, byte 0: lane word}: ONE
 // v_perm_b32 per pixel takes the bin byte out of a dword of four pre-shifted pixels and drops it into the lane's address word
 // (wvd_bins / wvd_addr; 1.5 VALU per pixel instead of 2).  The histogram survives the window (the next one down slides it), so the
 // LUT has a block of its own.
 struct WvdLds {   // the variable is 16 KB-aligned (not the type: 48 KB must stay 48 KB, three workgroups per CU)
     unsigned int hist[2][64][2][32];                 // counters
-    unsigned char lut[64][4][64];                    // the lanes' LUTs: e - 128 as int8
+    unsigned char lut[64][64][4];                    // the lanes' LUTs: e - 128 as int8, [bin][lane][wave] (see below)
 };
-static_assert(sizeof(unsigned int[64][2][32]) == 16384 && sizeof(unsigned char[64][4][64]) == 16384, "16 KB blocks, 256 B per bin");
+static_assert(sizeof(unsigned int[64][2][32]) == 16384 && sizeof(unsigned char[64][64][4]) == 16384, "16 KB blocks, 256 B per bin");
 
 typedef __attribute__((address_space(3))) unsigned char wvd_lds_u8;
 typedef unsigned short wvd_u16x2 __attribute__((ext_vector_type(2)));
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     const unsigned int laneOff32 = (histLds & ~0xFF00u) + (unsigned int)(lane & 31) * 4u;
     const unsigned int cntLds = histLds + (unsigned int)(lane & 31) * 4u + (unsigned int)(lane >> 5) * 2u;   // this lane's u16 counter of bin 0
     const unsigned int inc = 1u << (16 * (lane >> 5));
-    const unsigned int lutLds = (unsigned int)(uintptr_t)(wvd_lds_u8*)&S.lut[0][wave][0] + (unsigned int)lane;   // this lane's LUT byte of bin 0
+    const unsigned int lutLds = (unsigned int)(uintptr_t)(wvd_lds_u8*)&S.lut[0][lane][wave];   // this lane's LUT byte of bin 0
     const unsigned int blkL4 = ((lutLds >> 8) & 0xC0u) * 0x01010101u;
     const unsigned int lutWord = lutLds & ~0xFF00u;
 
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
 // exact integers, added in fp32 from the top row down).
 struct WvdPrepLds {
     unsigned int hist[2][64][2][32];
-    unsigned char lut[64][4][64];
+    unsigned char lut[64][64][4];        // [bin][lane][wave], like WvdLds
     int4 layer[WVM_MAX_LAYERS][2];   // {bx, by, nx, lw}, {off, magic, first, 0}
 };
 template <int PW_, int PH_>
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     const unsigned int laneOff32 = (histLds & ~0xFF00u) + (unsigned int)(lane & 31) * 4u;
     const unsigned int cntLds = histLds + (unsigned int)(lane & 31) * 4u + (unsigned int)(lane >> 5) * 2u;
     const unsigned int inc = 1u << (16 * (lane >> 5));
-    const unsigned int lutLds = (unsigned int)(uintptr_t)(wvd_lds_u8*)&S.lut[0][wave][0] + (unsigned int)lane;
+    const unsigned int lutLds = (unsigned int)(uintptr_t)(wvd_lds_u8*)&S.lut[0][lane][wave];
     const unsigned int blkL4 = ((lutLds >> 8) & 0xC0u) * 0x01010101u;
     const unsigned int lutWord = lutLds & ~0xFF00u;
     const unsigned int perImage = (unsigned int)wt.per_image;                          // the launcher checks that all ids fit 32 bits
