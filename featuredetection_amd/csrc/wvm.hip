@@ -1854,11 +1854,11 @@ static void wvm_build_dense(fd_wvm* m, const fd_wvm_model* md) {
     WvdConst C;
     std::memset(&C, 0, sizeof(C));
     m->denseScale = std::ldexp(1.0, -sh);
-    // k-step = one patch row (two rows for 16-wide patches): slot t of step ks is pixel (ks * RPS + t / pw, t % pw)
-    const int RPS = WvdGeo<16>::RPS == 2 && pw == 16 ? 2 : 1;   // must match the kernel's k-step geometry
-    if (ph % RPS != 0) return;
-    const int KS = ph / RPS;
+    // k-step ks, slot t = pixel 32 ks + t of the row-major patch (k_wvm_prefilter walks the patch as a flat run of dwords)
+    const int KS = (d + 31) / 32;
     std::vector<int8_t> B((size_t)KS * 2 * 64 * 16, 0);
+    const double nb2 = (double)m->dev.negBasis * 1.4426950408889634;   // log2(e) * (-basis): K = 2^(nb2 * norm)
+    for (int k = 0; k < WVD_L; ++k) C.thr[k] = -INFINITY;              // levels past L never reject
     for (int k = 0; k < L; ++k) {
         double sumQ = 0;
         for (int i = 0; i < d; ++i) {
@@ -1871,22 +1871,21 @@ static void wvm_build_dense(fd_wvm* m, const fd_wvm_model* md) {
                 Q = (Q - q0) / 256;   // exact
             }
             if (Q != 0) return;   // cannot happen for |Q| < 2^31 - 2^23
-            const int prow = i / pw, pcol = i % pw;
-            const int ks = prow / RPS, slot = (prow % RPS) * pw + pcol, h = slot / 16, t = slot % 16;
+            const int ks = i / 32, slot = i % 32, h = slot / 16, t = slot % 16;
             for (int j = 0; j < 4; ++j) {
                 const int g = k + 16 * j, nt = g / 32, col = g % 32;
                 B[((((size_t)ks * 2 + nt) * 64) + (h * 32 + col)) * 16 + t] = (int8_t)dig[j];
             }
         }
-        C.c128[k] = 128.0 * sumQ;
-        C.pp[k] = md->pp[k];
+        // x . Q = x' . Q + 128 sum Q (x' = x - 128); xp = 2^-s x . Q; norm = sxx - 2 xp + pp
+        C.cA[k] = nb2 * ((double)md->pp[k] - 2.0 * m->denseScale * (128.0 * sumQ));
         C.thr[k] = md->thresholds[k];
         for (int pidx = 0; pidx <= k; ++pidx) {
-            C.w[k][pidx] = md->hk_weights[(size_t)k * md->num_filters + pidx];
-            C.w2[k][pidx][0] = C.w[k][pidx];
-            C.w2[k][pidx][1] = std::fabs(C.w[k][pidx]);
+            const float w = md->hk_weights[(size_t)k * md->num_filters + pidx];
+            C.w2[k][pidx][0] = w;
+            C.w2[k][pidx][1] = std::fabs(w);
         }
-        if (!std::isfinite(C.pp[k]) || !std::isfinite((double)C.thr[k])) return;
+        if (!std::isfinite(C.cA[k]) || !std::isfinite((double)C.thr[k])) return;
     }
     m->denseB.reserve(B.size());
     HIP_CHECK(hipMemcpy(m->denseB.p, B.data(), B.size(), hipMemcpyHostToDevice));
@@ -2115,15 +2114,12 @@ static bool wvd_table_from(const WinTable& wt, WvdTable& t) {
         dl.nwin = (int32_t)nwin;
         dl.ny = s.ny;
         if ((int64_t)s.nx * s.ny != nwin) return false;
-        dl.tileFirst = tiles;
         tiles += (int)((nwin + 63) / 64);
     }
-    t.tilesPerImage = tiles;
     t.nimg = wt.nimg > 1 ? wt.nimg : 1;
     t.perImage = perImage;
     t.imageStride = wt.image_stride;
     if ((int64_t)tiles * t.nimg > (int64_t)INT32_MAX) return false;
-    t.ntiles = tiles * t.nimg;
     return true;
 }
 static void wvd_dev_from(const fd_wvm* m, int64_t* q, unsigned int* qcount, WvdDev& dv) {
@@ -2135,6 +2131,8 @@ static void wvd_dev_from(const fd_wvm* m, int64_t* q, unsigned int* qcount, WvdD
     dv.negBasis = m->dev.negBasis; dv.negBias = m->dev.negBias; dv.stretch = m->dev.stretch;
     dv.sxxSlack = (float)(2 * m->dev.fh + 2);
     dv.scale = m->denseScale;
+    dv.nb2 = (double)m->dev.negBasis * 1.4426950408889634;
+    dv.mXq = -2.0 * m->denseScale * dv.nb2;
 }
 
 // queues k_wvm_prefilter over all windows of `wt`; returns false when the model / call does not qualify
@@ -2149,23 +2147,6 @@ static bool launch_prefilter(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const uint8
     FD_WVM_CASE(20, 20) FD_WVM_CASE(24, 24) FD_WVM_CASE(16, 24) FD_WVM_CASE(32, 16) FD_WVM_CASE(32, 24)
 #undef FD_WVM_CASE
     return false;
-}
-
-template <int PW_, int PH_>
-static void launch_prefilter_multi_sized(fd_ctx* ctx, hipStream_t st, const uint8_t* arena, const WvdTable& wt, const WvdMulti& mv) {
-    static int perCu = 0;
-    if (perCu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wvm_prefilter_multi<PW_, PH_>, 256, 0) != hipSuccess || perCu < 1)) perCu = 2;
-    const int grid = (int)std::min<int64_t>(((int64_t)wt.ntiles + 3) / 4, (int64_t)ctx->num_cus * perCu * 2);
-    hipLaunchKernelGGL((k_wvm_prefilter_multi<PW_, PH_>), dim3(grid), dim3(256), 0, st, arena, wt, mv);
-}
-static bool wvd_has_multi_kernel(int fw, int fh) {
-    return (fw == 20 && fh == 20) || (fw == 24 && fh == 24) || (fw == 16 && fh == 24) || (fw == 32 && fh == 16) || (fw == 32 && fh == 24);
-}
-static void launch_prefilter_multi(fd_ctx* ctx, hipStream_t st, int fw, int fh, const uint8_t* arena, const WvdTable& t, const WvdMulti& mv) {
-#define FD_WVM_CASE(W, H) \
-    if (fw == W && fh == H) { launch_prefilter_multi_sized<W, H>(ctx, st, arena, t, mv); return; }
-    FD_WVM_CASE(20, 20) FD_WVM_CASE(24, 24) FD_WVM_CASE(16, 24) FD_WVM_CASE(32, 16) FD_WVM_CASE(32, 24)
-#undef FD_WVM_CASE
 }
 
 void fd_wvm_build_table(const fd_pyramid* p, int pw, int ph, int sx, int sy, const int* roi, WinTable& wt,
@@ -2344,53 +2325,6 @@ static void wvm_launch_table(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm*
         }
     }
     wvm_launch_tail(ctx, st, p, m, wt, wtq, L, skipA, time_kernel);
-}
-
-// Several detectors on the SAME windows (one pyramid, one patch size, the same steps and roi): one pre-filter launch equalises
-// every tile once and runs each detector's dense levels on it (k_wvm_prefilter_multi); the exact stage B of detector d then
-// runs on streams[d] behind it.  Returns false (nothing queued) when the group does not qualify; the caller then launches the
-// detectors one by one.
-static bool fd_wvm_launch_group(fd_ctx* ctx, hipStream_t* streams, fd_pyramid* p, fd_wvm** ms, int nd, int sx, int sy, const int* roi, WvmRun** runs) {
-    // Off by default (FD_WVM_GROUP=1 enables it): measured on config 3, the shared pre-filter does 13 % less kernel time than
-    // seven single launches in isolation (3.85 vs 7 x 0.63 ms for the 24x24 group) but loses end to end (3470 vs 3575 Mpatches/s):
-    // the independent launches overlap each other and the stage-B kernels of the detectors in front, one long launch does not.
-    const bool off = [] { const char* e = getenv("FD_WVM_GROUP"); return !(e && atoi(e) == 1); }();   // read per call: tests toggle it
-    static const bool direct = [] { const char* e = getenv("FD_WVM_DENSE_DIRECT"); return !(e && atoi(e) == 0); }();
-    if (off || !direct || nd < 2 || nd > WVD_MAXD) return false;
-    for (int d = 0; d < nd; ++d) {
-        fd_wvm* m = ms[d];
-        if (p->ctx != ctx || m->ctx != ctx || m->denseL == 0 || m->dev.fw != ms[0]->dev.fw || m->dev.fh != ms[0]->dev.fh || m->dev.numUsed <= WVM_LCAP) return false;
-    }
-    if (p->filter_kind != FD_LAYER_NONE || p->all.empty()) return false;
-    HIP_CHECK(hipSetDevice(ctx->device));
-    WinTable wt;
-    fd_wvm_build_table(p, ms[0]->dev.fw, ms[0]->dev.fh, sx, sy, roi, wt, runs[0]->wls);
-    WvdTable t;
-    if (!wvd_table_from(wt, t)) return false;
-    if (!wvd_has_multi_kernel(ms[0]->dev.fw, ms[0]->dev.fh)) return false;
-    for (int d = 1; d < nd; ++d) runs[d]->wls = runs[0]->wls;
-    WvmLaunch L[WVD_MAXD];
-    WvdMulti mv;
-    std::memset(&mv, 0, sizeof(mv));
-    mv.nd = nd;
-    for (int d = 0; d < nd; ++d) {
-        fd_pyramid_wait(p, streams[d]);
-        if (!wvm_launch_head(ctx, streams[d], ms[d], wt, false, *runs[d], false, L[d])) return true;   // no windows: nothing to do for anyone
-        if (d > 0 && L[d].headerMemset && streams[d] != streams[0]) {   // the pre-filter (on streams[0]) counts into this header
-            if (!ms[d]->prep) HIP_CHECK(hipEventCreateWithFlags(&ms[d]->prep, hipEventDisableTiming));
-            HIP_CHECK(hipEventRecord(ms[d]->prep, streams[d]));
-            HIP_CHECK(hipStreamWaitEvent(streams[0], ms[d]->prep, 0));
-        }
-        wvd_dev_from(ms[d], L[d].o.deep_q, L[d].o.deep_count, mv.d[d]);
-    }
-    launch_prefilter_multi(ctx, streams[0], ms[0]->dev.fw, ms[0]->dev.fh, p->arena.as<uint8_t>(), t, mv);
-    if (!ms[0]->prep) HIP_CHECK(hipEventCreateWithFlags(&ms[0]->prep, hipEventDisableTiming));
-    HIP_CHECK(hipEventRecord(ms[0]->prep, streams[0]));
-    for (int d = 0; d < nd; ++d) {
-        if (streams[d] != streams[0]) HIP_CHECK(hipStreamWaitEvent(streams[d], ms[0]->prep, 0));
-        wvm_launch_tail(ctx, streams[d], p, ms[d], wt, wt, L[d], true, false);
-    }
-    return true;
 }
 
 // Synchronous half: waits for m->done, fetches the remaining positives and sorts them into extraction order.
@@ -3088,47 +3022,10 @@ static void five_stage_batch_begin(fd_ctx* ctx, fd_five_stage_job* jobs, int n, 
         fd_five_stage_job& j = jobs[i];
         if (j.image) fd_pyramid_update_on(j.pyramid, j.image, j.image_w, j.image_h, j.image_channels, j.image_is_device, fd_pool_stream(ctx, i));
     };
-    // units of cascade launches: detectors that scan the SAME windows (one pyramid, one patch size, same steps, no roi) share one
-    // pre-filter launch (fd_wvm_launch_group), everything else is launched on its own
-    std::vector<std::vector<int>> units;
-    {
-        std::vector<char> taken((size_t)n, 0);
-        for (int i = 0; i < n; ++i) {
-            if (taken[(size_t)i]) continue;
-            std::vector<int> u{i};
-            taken[(size_t)i] = 1;
-            const fd_five_stage_job& a = jobs[i];
-            if (!a.roi) {
-                for (int k = i + 1; k < n && (int)u.size() < WVD_MAXD; ++k) {
-                    const fd_five_stage_job& c = jobs[k];
-                    if (taken[(size_t)k] || c.roi || c.pyramid != a.pyramid || c.step_x != a.step_x || c.step_y != a.step_y) continue;
-                    if (c.wvm->dev.fw != a.wvm->dev.fw || c.wvm->dev.fh != a.wvm->dev.fh) continue;
-                    u.push_back(k);
-                    taken[(size_t)k] = 1;
-                }
-            }
-            units.push_back(std::move(u));
-        }
-    }
-    const int nunits = (int)units.size();
-    auto cascadeJob = [&](int ui) {
-        const std::vector<int>& u = units[(size_t)ui];
-        if (u.size() > 1) {
-            hipStream_t streams[WVD_MAXD];
-            fd_wvm* ms[WVD_MAXD];
-            WvmRun* runs[WVD_MAXD];
-            for (size_t d = 0; d < u.size(); ++d) {
-                streams[d] = fd_pool_stream(ctx, u[d]);
-                ms[d] = const_cast<fd_wvm*>(jobs[u[d]].wvm);
-                runs[d] = &b.runs[(size_t)u[d]];
-            }
-            const fd_five_stage_job& j0 = jobs[u[0]];
-            if (fd_wvm_launch_group(ctx, streams, j0.pyramid, ms, (int)u.size(), j0.step_x, j0.step_y, nullptr, runs)) return;
-        }
-        for (int i : u) {
-            fd_five_stage_job& j = jobs[i];
-            fd_wvm_launch_on(ctx, fd_pool_stream(ctx, i), j.pyramid, const_cast<fd_wvm*>(j.wvm), j.step_x, j.step_y, j.roi, false, b.runs[i], false);
-        }
+    const int nunits = n;
+    auto cascadeJob = [&](int i) {
+        fd_five_stage_job& j = jobs[i];
+        fd_wvm_launch_on(ctx, fd_pool_stream(ctx, i), j.pyramid, const_cast<fd_wvm*>(j.wvm), j.step_x, j.step_y, j.roi, false, b.runs[i], false);
     };
     // A frame costs ~15 runtime calls (pyramid kernels, cascade kernels, copies, events): with many small jobs the single host
     // thread issuing them is the bottleneck, so batches of >= 6 jobs are issued by the worker pool -- all pyramid updates first

@@ -12,8 +12,8 @@
 //        chain in the lane's registers (same operation order as the reference, 64 windows per instruction instead of the DPP chain's
 //        one), the LUT goes to its own LDS block.  sum(x) and sum(x^2) of the equalised patch come from the histogram (exact integers);
 //        the reference's fp32 sum of squares (IImg.cpp:33-47) equals the integer below 2^24 and is within 2*ph + 2 of it above.
-//     2. the equalised pixels (x - 128 as int8, gathered through the LUT one patch row -- two for 16-wide patches -- per k-step) are
-//        the B operand of v_mfma_i32_32x32x32_i8, built in registers with v_permlane32_swap; the A operand is the residual images
+//     2. the equalised pixels (x - 128 as int8, gathered through the LUT; a k-step is 32 consecutive pixels of the row-major patch,
+//        whatever the row length: 13 k-steps for 20x20, not 20) are the B operand of v_mfma_i32_32x32x32_i8, built in registers with v_permlane32_swap; the A operand is the residual images
 //        quantised to 32-bit integers Q = round(r * 2^s) and split into four balanced base-256 digits: integer arithmetic, so x . Q is
 //        EXACT; |x . r - 2^-s x . Q| <= 2^-(s+1) * sum(x) is the only approximation.  The accumulators C[digit row][window] are folded
 //        into exact doubles and brought back to lane == window with v_permlane32_swap.
@@ -22,8 +22,6 @@
 //        level k < L is rejected by the reference at some level <= k, so it cannot be a WVM positive and is dropped here.
 //        Everything else is appended to a queue and runs the exact stage B (wvm_stageb.hpp) from level 0, so positives, their levels
 //        and their fp32 outputs stay bit-identical to the rectangle-sum formulation.
-//   k_wvm_prefilter_multi: the first formulation (64 consecutive windows per wavefront, pixels staged and results transposed through
-//     LDS) for several detectors on the same windows; off by default (FD_WVM_GROUP=1).
 //   k_wvb_prepare_lanes: stage B's preparation of long queues with the same per-lane machinery.
 //   Only used when no per-window outputs are requested (fd_detect_wvm with all_level / all_score takes the exact path for every window).
 #pragma once
@@ -38,30 +36,28 @@ typedef __attribute__((address_space(3))) unsigned short wvd_lds_u16;
 struct WvdLayer {
     int32_t bx, by, nx, lw;
     uint32_t off, magic;
-    int32_t nwin, tileFirst;             // k_wvm_prefilter_multi: tiles of 64 consecutive windows
+    int32_t nwin, pad0;
     int64_t first;
-    int32_t ny, G, sTileFirst, pad;      // k_wvm_prefilter: G = ceil(ny / K) row groups; tiles of 64 (column, row group) tasks
+    int32_t ny, G, sTileFirst, pad;      // G = ceil(ny / K) row groups; tiles of 64 (column, row group) tasks
 };
 struct WvdTable {
-    int32_t n, sx, sy, ntiles;           // ntiles = tilesPerImage * nimg
-    int32_t nimg, tilesPerImage;         // multi-frame pyramid: tile -> (frame, tile inside the frame)
-    int32_t K, sTilesPerImage;           // k_wvm_prefilter: windows a lane walks down (WVD_KMAX at most), its tiles per frame
+    int32_t n, sx, sy, pad0;
+    int32_t nimg, pad1;                  // multi-frame pyramid: tile -> (frame, tile inside the frame)
+    int32_t K, sTilesPerImage;           // windows a lane walks down (WVD_KMAX at most), tiles per frame
     int64_t perImage;                    // windows per frame
     uint64_t imageStride;                // bytes between the frames' arenas
     WvdLayer l[WVM_MAX_LAYERS];
 };
 
-// per-level model constants of the dense stage (device memory)
+// per-level model constants of the dense stage (device memory, read through the scalar cache)
 struct WvdConst {
-    double c128[WVD_L];        // 128 * sum_i Q_k[i]
-    double pp[WVD_L];
-    float thr[WVD_L];
-    float w[WVD_L][WVD_L];     // hkWeights[k][p], p <= k
-    float w2[WVD_L][WVD_L][2]; // {w, |w|}: the level sum and its error bound as one packed fma (k_wvm_prefilter)
+    double cA[WVD_L];          // log2(e) * (-basis) * (pp_k - 2 * 2^-s * 128 * sum_i Q_k[i]): the window-independent part of level k's exponent
+    float thr[WVD_L];          // -inf from level L on (those levels never reject)
+    float w2[WVD_L][WVD_L][2]; // {hkWeights[k][p], |hkWeights[k][p]|}, p <= k: the level sum and its error bound as one packed fma
 };
 
 struct WvdDev {
-    const wvd_v4i* B;          // [k-step][2 N-tiles][64 lanes] 16 signed digit bytes each (k-step = patch row; two rows when pw == 16)
+    const wvd_v4i* B;          // [k-step][2 M-tiles][64 lanes] 16 signed digit bytes each; k-step ks, slot t = pixel 32 ks + t of the row-major patch
     const WvdConst* c;
     int64_t* q;                // windows that pass
     unsigned int* qcount;
@@ -70,14 +66,8 @@ struct WvdDev {
     float negBasis, negBias, stretch;
     float sxxSlack;            // 2 * ph + 2: |fp32 row-ordered sum of squares - exact integer| when the sum is >= 2^24
     double scale;              // 2^-s; also the error of norm per unit of sum(x): 2 * 2^-(s+1)
-};
-
-// several detectors on the same windows (same pyramid, patch size and steps: the lip / nose / eye-corner detectors of
-// ffpDetectApp): k_wvm_prefilter_multi equalises a tile once and runs the contraction + levels of every detector on it
-constexpr int WVD_MAXD = 8;
-struct WvdMulti {
-    int32_t nd;
-    WvdDev d[WVD_MAXD];
+    double nb2;                // log2(e) * (-basis): exponent of 2 per unit of norm
+    double mXq;                // -2 * 2^-s * nb2: exponent of 2 per unit of the integer dot product x' . Q
 };
 
 namespace {
@@ -91,17 +81,6 @@ __device__ unsigned long long fd_wvd_prof[WVD_PROF_WAVES * 8];
 #else
 #define WVD_T(x)
 #endif
-
-template <int PW_>
-struct WvdGeo {
-#ifndef FD_WVD_RPS16
-#define FD_WVD_RPS16 2
-#endif
-    // patch rows per k-step (32 k-slots).  Two 16-wide rows fill a step; one row per step (FD_WVD_RPS16=1) needs fewer
-    // registers (4 instead of 3 wavefronts per SIMD) but twice the steps -- measured equal (0.806 vs 0.794 ms, 16x24 ear
-    // detector at 1080p), so the two-row form stays
-    static constexpr int RPS = PW_ == 16 ? FD_WVD_RPS16 : 1;
-};
 
 // LDS of a workgroup (4 wavefronts).  Histogram rows are 256 B: [wave pair][bin][wave of the pair][lane & 31] dwords, the u16 counters
 // of lanes l (low half) and l + 32 (high half) in one dword; LUT rows are 256 B too: [bin][lane][wave] bytes -- the byte of lane l sits
@@ -168,6 +147,13 @@ __device__ __forceinline__ unsigned int wvd_load_u32(const uint8_t* p) {
     __builtin_memcpy(&v, p, 4);   // unaligned global_load_dword
     return v;
 }
+// the same with a wave-uniform base and a 32-bit lane offset: global_load_dword v, v_off, s[base] offset:imm -- no address arithmetic
+// on the vector unit (the uniform part of an address advances on the scalar unit)
+__device__ __forceinline__ unsigned int wvd_load_u32(const uint8_t* ubase, unsigned int voff) {
+    unsigned int v;
+    __builtin_memcpy(&v, ubase + voff, 4);
+    return v;
+}
 // LDS byte address of (bin of byte b of w4, this lane): two VALU instructions per pixel
 template <int B_>
 __device__ __forceinline__ unsigned int wvd_slot(unsigned int w4, unsigned int laneOff) {
@@ -223,13 +209,31 @@ __device__ __forceinline__ void wvd_swap32(unsigned int& v0, unsigned int& v1) {
 
 // The fp32 cdf of a lane's histogram in the reference's order (cdf[0] = pdf[0]; cdf[b] = cdf[b-1] + pdf[b]) -> the lane's LUT, and
 // the exact integer sum / sum of squares of the equalised patch.  cntLds / lutLds: LDS addresses of the lane's u16 counter / LUT byte of
-// bin 0 (bin b: + 256 b).  The LUT keeps e + 128 (low byte = e - 128 as int8, what the contractions want); the sums are taken over
-// e + 128 too and corrected once.  e <= 255 without the reference's (uchar) cast: the counts add up to N_ and stretch = 255 / N_, so
-// cdf <= 255 (1 + 66 * 2^-24) < 255.5.
+// bin 0 (bin b: + 256 b).  (uchar)floor((double)cdf + 0.5) (HistEq64Filter.cpp:118) is ONE instruction: v_cvt_rpi_i32_f32 is
+// floor(x + 0.5) without an intermediate rounding (a float cdf + 0.5f can round up to an integer; tools/microbench/rpi_check.hip
+// compares it with floor((double)x + 0.5) for every float in [0, 1024) on the device: no mismatch).  e <= 255 without the
+// reference's (uchar) cast: the counts add up to N_ and stretch = 255 / N_, so cdf <= 255 (1 + 66 * 2^-24) < 255.5.
+// The LUT keeps e ^ 0x80 = e - 128 as int8, what the contractions want.  8 VALU per bin (round 3: 11).
+__device__ __forceinline__ unsigned int wvd_rpi(float x) {
+    unsigned int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ unsigned int wvd_mul24(unsigned int a, unsigned int b) {   // by name: __umul24 of opaque operands becomes v_and + quarter-rate v_mul_lo
+    unsigned int r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned int wvd_mad24(unsigned int a, unsigned int b, unsigned int c) {
+    unsigned int r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 template <unsigned int N_>
 __device__ __forceinline__ void wvd_cdf_lut(unsigned int cntLds, unsigned int lutLds, float stretch, unsigned int& sumx, unsigned int& sumxx) {
+    static_assert(N_ <= 1024, "count * e and count * e * e are 24-bit multiplies");
     float cdf = 0.f;
-    unsigned int s1 = 0, s2 = 0;   // sum cnt * (e + 128), sum cnt * (e + 128)^2 <= 768 * 383^2 < 2^27
+    unsigned int s1 = 0, s2 = 0;   // sum cnt * e <= 255 N_, sum cnt * e^2 <= 65025 N_ < 2^26
     wvd_lds_u16* cnt0 = (wvd_lds_u16*)(uintptr_t)cntLds;   // bin b: + b * 256 bytes (an instruction offset)
     wvd_lds_u8* lut0 = (wvd_lds_u8*)(uintptr_t)lutLds;
 #pragma unroll
@@ -241,28 +245,25 @@ __device__ __forceinline__ void wvd_cdf_lut(unsigned int cntLds, unsigned int lu
         for (int j = 0; j < 16; ++j) {
             const float pdf = (float)cnt[j] * stretch;
             cdf = (bb + j) == 0 ? pdf : cdf + pdf;
-            // (uchar)floor((double)cdf + 0.5): cdf < 2^9 has at most 24 significant bits, so cdf + 0.5 is exact in double;
-            // floor(cdf) + (frac >= 0.5) is the same value without leaving fp32 (cdf + 0.5f itself can round up to an integer)
-            const unsigned int e1 = (unsigned int)cdf + 128u + (__builtin_amdgcn_fractf(cdf) >= 0.5f ? 1u : 0u);
-            lut0[(bb + j) * 256] = (unsigned char)e1;
-            const unsigned int ce = __umul24(cnt[j], e1);   // <= 768 * 383: all three products are 24-bit multiplies
+            const unsigned int e = wvd_rpi(cdf);
+            lut0[(bb + j) * 256] = (unsigned char)(e ^ 0x80u);
+            const unsigned int ce = wvd_mul24(cnt[j], e);
             s1 = ce + s1;
-            s2 = __umul24(ce, e1) + s2;
+            s2 = wvd_mad24(ce, e, s2);
             asm("" : "+v"(s1), "+v"(s2));   // accumulate here (sunk to their use, the 128 products spill)
         }
     }
-    sumx = s1 - 128u * N_;
-    sumxx = s2 - 256u * s1 + 16384u * N_;   // sum cnt (e1 - 128)^2
+    sumx = s1;
+    sumxx = s2;
 }
 
 template <int PW_, int PH_>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_wvm_prefilter(const uint8_t* __restrict__ arena, WvdTable wt, WvdDev dv) {
-    static_assert(PW_ % 4 == 0 && PW_ >= 16 && PW_ <= 32, "rows are read as dwords; a row (or two 16-wide rows) fills one k-step");
-    constexpr int RPS = WvdGeo<PW_>::RPS;
-    static_assert(PH_ % RPS == 0, "whole k-steps");
-    constexpr int KS = PH_ / RPS;
+    static_assert(PW_ % 4 == 0 && PW_ >= 16 && PW_ <= 32, "rows are read as dwords");
     constexpr int NW = PW_ / 4;          // dwords per patch row
-    constexpr int ND = RPS * NW;         // dwords per k-step: 4, 5, 6 or 8
+    constexpr int D4 = NW * PH_;         // dwords of the row-major patch; a k-step takes 8 of them (32 pixels), whatever the row length
+    static_assert(D4 % 4 == 0, "the equalise blocks take 4 dwords");
+    constexpr int KS = (D4 + 7) / 8;
     __shared__ __attribute__((aligned(16384))) WvdLds S;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -309,8 +310,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         const int iy0 = (int)g * K;
         const int rows = task0 < ntask ? min(K, wl.ny - iy0) : 0;   // windows of this lane; 0: a lane past the layer's last task (it repeats that task, unseen)
         const int lw = wl.lw;
-        const size_t rowStep = (size_t)wt.sy * lw;   // bytes between the windows of a column
-        const uint8_t* src0 = arena + (size_t)img * wt.imageStride + wl.off + (size_t)(wl.by + iy0 * wt.sy) * lw + (wl.bx + (int)ix * wt.sx);
+        const unsigned int rowStep = (unsigned int)(wt.sy * lw);   // bytes between the windows of a column
+        // addresses = a wave-uniform base (scalar registers) + a 32-bit lane offset
+        const uint8_t* ubase = arena + (size_t)img * wt.imageStride + wl.off;
+        const unsigned int lo0 = (unsigned int)((wl.by + iy0 * wt.sy) * lw + (wl.bx + (int)ix * wt.sx));
         const int64_t wid0 = (int64_t)img * wt.perImage + wl.first + (int64_t)iy0 * wl.nx + ix;
 
         WVD_T(pa);
@@ -324,15 +327,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         {
             unsigned int wn[NW];
 #pragma unroll
-            for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(src0 + 4 * j);
+            for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(ubase + 4 * j, lo0);
 #pragma unroll 2
             for (int r = 0; r < PH_; ++r) {   // one patch row per iteration, the next row's loads in flight
                 unsigned int w4[NW];
 #pragma unroll
                 for (int j = 0; j < NW; ++j) w4[j] = wn[j];
-                const uint8_t* nsrc = src0 + (size_t)(r + 1 < PH_ ? r + 1 : r) * lw;
+                const uint8_t* nsrc = ubase + (size_t)(r + 1 < PH_ ? r + 1 : r) * lw;
 #pragma unroll
-                for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(nsrc + 4 * j);
+                for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(nsrc + 4 * j, lo0);
                 wvd_hist_row<NW, true>(w4, blkH4, laneOff32, inc);
             }
         }
@@ -346,17 +349,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         if (__ballot(active) == 0) break;
         WVD_T(ps);
         if (step > 0 && active) {   // ---- 1'. slide the histogram down by one window: rows leave at the top, rows enter at the bottom
-            const uint8_t* out0 = src0 + (size_t)(step - 1) * rowStep;
+            const uint8_t* out0 = ubase + (size_t)(step - 1) * rowStep;
             for (int q = 0; q < wt.sy; ++q) {
                 unsigned int wo[NW], wi[NW];
 #pragma unroll
-                for (int j = 0; j < NW; ++j) { wo[j] = wvd_load_u32(out0 + (size_t)q * lw + 4 * j); wi[j] = wvd_load_u32(out0 + (size_t)(q + PH_) * lw + 4 * j); }
+                for (int j = 0; j < NW; ++j) { wo[j] = wvd_load_u32(out0 + (size_t)q * lw + 4 * j, lo0); wi[j] = wvd_load_u32(out0 + (size_t)(q + PH_) * lw + 4 * j, lo0); }
                 wvd_hist_row<NW, false>(wo, blkH4, laneOff32, inc);
                 wvd_hist_row<NW, true>(wi, blkH4, laneOff32, inc);
             }
         }
         // the window this lane evaluates now (a lane that has run out of windows repeats its last one, unseen)
-        const uint8_t* src = src0 + (size_t)(active ? step : (rows > 0 ? rows - 1 : 0)) * rowStep;
+        const unsigned int lo = lo0 + (unsigned int)(active ? step : (rows > 0 ? rows - 1 : 0)) * rowStep;
         wave_sync();
         WVD_T(pb);
         // ---- 2. the fp32 cdf, the LUT, and the exact integer sum / sum of squares of the equalised patch
@@ -364,40 +367,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         wvd_cdf_lut<PW_ * PH_>(cntLds, lutLds, dv.stretch, sumx, sumxx);
         wave_sync();
         WVD_T(pc);
-        // ---- 3. equalise, exact dot products on the matrix pipe: one k-step per patch row (two rows when the patch is 16 wide).
+        // ---- 3. equalise, exact dot products on the matrix pipe.  k-step ks takes the dwords 8 ks .. 8 ks + 7 of the row-major patch
+        //         (dword q = row q / NW, columns 4 (q % NW) ..): the loop is unrolled completely, so every row / column is a constant.
         //         acc[M][N]: digit tile M (rows f + 16 j', digits 2 M + j') x window tile N (windows 32 N + (lane & 31))
         wvd_v16i acc00 = {}, acc01 = {}, acc10 = {}, acc11 = {};
         {
-            unsigned int wn[RPS][NW];
+            unsigned int nx[8];
+            wvd_v4i an0, an1;
+            const char* Bb = reinterpret_cast<const char*>(dv.B);   // uniform base + lane * 16
+            unsigned int lane16 = (unsigned int)lane * 16u;
+            asm volatile("" : "+v"(lane16));   // stays an offset register (hoisted out of the loops as 2 KS address pairs, the fragment addresses spill)
+            auto fetch = [&](int ks) {   // pixel dwords and digit fragments of k-step ks
 #pragma unroll
-            for (int rr = 0; rr < RPS; ++rr)
+                for (int j = 0; j < 8; ++j) {
+                    const int q = 8 * ks + j;
+                    if (q < D4) nx[j] = wvd_load_u32(ubase + (size_t)(q / NW) * lw + 4 * (q % NW), lo);
+                }
+                an0 = *reinterpret_cast<const wvd_v4i*>(Bb + (size_t)(ks * 2 + 0) * 1024 + lane16);
+                an1 = *reinterpret_cast<const wvd_v4i*>(Bb + (size_t)(ks * 2 + 1) * 1024 + lane16);
+            };
+            fetch(0);
 #pragma unroll
-                for (int j = 0; j < NW; ++j) wn[rr][j] = wvd_load_u32(src + (size_t)rr * lw + 4 * j);
-            wvd_v4i an0 = dv.B[lane], an1 = dv.B[64 + lane];
-#pragma unroll 2
             for (int ks = 0; ks < KS; ++ks) {
                 const wvd_v4i a0 = an0, a1 = an1;
-                unsigned int wl4[ND];
+                unsigned int cur[8], pk[8];
 #pragma unroll
-                for (int rr = 0; rr < RPS; ++rr)
-#pragma unroll
-                    for (int j = 0; j < NW; ++j) wl4[rr * NW + j] = wn[rr][j];
-                {   // next k-step's rows and digits (the last step re-reads its own)
-                    const int kn = ks + 1 < KS ? ks + 1 : ks;
-                    const uint8_t* nsrc = src + (size_t)(kn * RPS) * lw;
-#pragma unroll
-                    for (int rr = 0; rr < RPS; ++rr)
-#pragma unroll
-                        for (int j = 0; j < NW; ++j) wn[rr][j] = wvd_load_u32(nsrc + (size_t)rr * lw + 4 * j);
-                    an0 = dv.B[(kn * 2 + 0) * 64 + lane];
-                    an1 = dv.B[(kn * 2 + 1) * 64 + lane];
-                }
-                unsigned int pk[8];
-                if constexpr (ND <= 5) wvd_equalise<ND>(wl4, pk, lutWord, blkL4);
-                else { wvd_equalise<ND / 2>(wl4, pk, lutWord, blkL4); wvd_equalise<ND / 2>(wl4 + ND / 2, pk + ND / 2, lutWord, blkL4); }
-#pragma unroll
-                for (int j = ND; j < 8; ++j) pk[j] = 0;   // k-slots past the row(s): zero pixels against zero digits
-                // this lane's 32 row bytes -> the k-half each N-tile wants from it: lanes 0..31 give bytes 0..15 of windows 0..31 (tile 0) /
+                for (int j = 0; j < 8; ++j) cur[j] = nx[j];
+                if (ks + 1 < KS) fetch(ks + 1);
+                wvd_equalise<4>(cur, pk, lutWord, blkL4);
+                if (8 * ks + 4 < D4) wvd_equalise<4>(cur + 4, pk + 4, lutWord, blkL4);
+                else pk[4] = pk[5] = pk[6] = pk[7] = 0;   // k-slots past the patch: zero pixels against zero digits
+                // this lane's 32 bytes -> the k-half each N-tile wants from it: lanes 0..31 give bytes 0..15 of windows 0..31 (tile 0) /
                 // 32..63 (tile 1), lanes 32..63 bytes 16..31
                 wvd_swap32(pk[0], pk[4]); wvd_swap32(pk[1], pk[5]); wvd_swap32(pk[2], pk[6]); wvd_swap32(pk[3], pk[7]);
                 const wvd_v4i b0 = {(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]}, b1 = {(int)pk[4], (int)pk[5], (int)pk[6], (int)pk[7]};
@@ -414,52 +414,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         double xq[2][8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            // exact: |digit sums| < 2^24, the result < 2^53
-            const double v0 = ((double)acc00[i] + 65536.0 * (double)acc10[i]) + 256.0 * ((double)acc00[8 + i] + 65536.0 * (double)acc10[8 + i]);
-            const double v1 = ((double)acc01[i] + 65536.0 * (double)acc11[i]) + 256.0 * ((double)acc01[8 + i] + 65536.0 * (double)acc11[8 + i]);
+            // exact (explicit fma: -ffp-contract=off): |digit sums| < 2^24, every intermediate is an integer below 2^53
+            const double v0 = __builtin_fma(256.0, __builtin_fma(65536.0, (double)acc10[8 + i], (double)acc00[8 + i]), __builtin_fma(65536.0, (double)acc10[i], (double)acc00[i]));
+            const double v1 = __builtin_fma(256.0, __builtin_fma(65536.0, (double)acc11[8 + i], (double)acc01[8 + i]), __builtin_fma(65536.0, (double)acc11[i], (double)acc01[i]));
             uint2 u0 = __builtin_bit_cast(uint2, v0), u1 = __builtin_bit_cast(uint2, v1);
             wvd_swap32(u0.x, u1.x);
             wvd_swap32(u0.y, u1.y);
             xq[0][i] = __builtin_bit_cast(double, u0);
             xq[1][i] = __builtin_bit_cast(double, u1);
         }
-        // ---- 5. the first L cascade levels of this lane's window with error bounds
+        // ---- 5. the first L cascade levels of this lane's window with error bounds.  Branch-free per window (selects became plain
+        //         arithmetic: an exponent below the float range gives K = 0 within the absolute slack, one above it makes the sums
+        //         inf / NaN, which never compare below a threshold); levels come in pairs behind one uniform test of L, the level
+        //         constants of a pair are scalar loads the scheduler can issue ahead of the arithmetic.
         bool undecided = active;
         {
             typedef float wvd_v2f __attribute__((ext_vector_type(2)));
             wvd_v2f KK[WVD_L];   // {K_p, bound of its error}: the level sum and its bound run as ONE v_pk_fma_f32 per term
             // the reference's fp32 sum of squares: row totals (exact ints) added in fp32, so it IS the integer below 2^24
             const float sxx = (float)sumxx;
-            // |norm - reference norm|: 2 * quantisation error of xp, the fp32 sum of squares above 2^24, slack for the reference's
-            // fp64 roundings (< 1e-5)
+            // |norm - reference norm|: 2 * quantisation error of xp, the fp32 sum of squares above 2^24, slack for the fp64 roundings on
+            // both sides (the reference's chain and the regrouped one below: < 1e-5)
             const double dn = dv.scale * (double)sumx + (sumxx >= (1u << 24) ? (double)dv.sxxSlack : 0.0) + 1e-4;
             const float relDn = (float)(-(double)dv.negBasis * dn) * 1.0001f;
+            // relative error of K: exponent error (quantisation; float cast of the exponent and 2^x: 1.69e-7 |log2 K| + 6e-7), the final
+            // rounding, and -- folded in here -- the fp32 summation-order term (4k + 16) 2^-24 <= 4.6e-6 of the level sums
+            const float rho0 = (relDn + 6.0e-7f) * 1.01f + 4.6e-6f;
+            const double e0 = dv.nb2 * (double)sxx;   // log2 K = nb2 (sxx - 2 xp + pp) = e0 + cA[k] + mXq (x' . Q)
+            const wvd_v2f RE0 = {dv.negBias, fabsf(dv.negBias) * 4.6e-6f + 1e-37f};
             const __attribute__((address_space(4))) wvd_v2f* W2 = (const __attribute__((address_space(4))) wvd_v2f*)&C.w2[0][0][0];
+            unsigned long long und = __ballot(undecided);
 #pragma unroll
-            for (int k = 0; k < WVD_L; ++k) {
-                if (k < L) {
-                    const double xp = (xq[(k >> 2) & 1][(k & 3) + 4 * (k >> 3)] + C.c128[k]) * dv.scale;
-                    double norm = (double)sxx;
-                    norm = norm - 2 * xp;
-                    norm = norm + C.pp[k];
-                    const float arg = (float)((double)dv.negBasis * norm);
-                    // relative error of K: exponent error (quantisation, float cast of the argument, x * log2e, 2^x), the final
-                    // rounding, and -- folded in here -- the fp32 summation-order term (4k + 16) 2^-24 <= 4.6e-6 of the level sums.
-                    // Branch-free: the exponential is taken of every argument and replaced where it is out of range (selects, not the
-                    // three exec-masked blocks per level the if / else chain compiled to)
-                    const float Kraw = __expf(arg);
-                    const float rho = (relDn + fabsf(arg) * 2.4e-7f + 6.0e-7f) * 1.01f + 4.6e-6f;
-                    const bool lo = arg < -80.0f, hi = arg > 80.0f;   // lo: true K <= e^-80 (1 + tiny); hi cannot happen for a sane model: never reject
-                    const float Kk = (lo || hi) ? 0.f : Kraw;
-                    const float Kerr = hi ? 3.0e38f : (lo ? 2e-35f : Kraw * rho + 1e-37f);
-                    KK[k] = wvd_v2f{Kk, Kerr};
-                    wvd_v2f RE = {dv.negBias, fabsf(dv.negBias) * 4.6e-6f + 1e-37f};
+            for (int k2 = 0; k2 < WVD_L; k2 += 2) {
+                if (k2 < L) {
 #pragma unroll
-                    for (int p = 0; p <= k; ++p) RE = __builtin_elementwise_fma(W2[k * WVD_L + p], KK[p], RE);   // R += w K_p, E += |w| dK_p
-                    // the reference leaves at the first level with res < thr, and res_ref <= R + E
-                    if (undecided && (RE.x + RE.y < C.thr[k])) undecided = false;
+                    for (int k = k2; k < k2 + 2; ++k) {
+                        const double ex = __builtin_fma(xq[(k >> 2) & 1][(k & 3) + 4 * (k >> 3)], dv.mXq, e0 + C.cA[k]);
+                        const float lg = (float)ex;
+                        const float Kraw = __builtin_amdgcn_exp2f(lg);   // <= 2^-115 where the old form tested arg < -80: inside the 3e-35 below
+                        const float rho = __builtin_fmaf(fabsf(lg), 1.69e-7f, rho0);
+                        KK[k] = wvd_v2f{Kraw, __builtin_fmaf(Kraw, rho, 3e-35f)};
+                        wvd_v2f RE = RE0;
+#pragma unroll
+                        for (int p = 0; p <= k; ++p) RE = __builtin_elementwise_fma(W2[k * WVD_L + p], KK[p], RE);   // R += w K_p, E += |w| dK_p
+                        // the reference leaves at the first level with res < thr, and res_ref <= R + E
+                        und &= ~__ballot(RE.x + RE.y < C.thr[k]);
+                    }
                 }
             }
+            undecided = (und >> lane) & 1ull;
         }
         // ---- 6. survivors -> queue of the exact cascade (wave-aggregated)
         {
@@ -615,265 +618,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         }
         (void)sumxx;
         wave_sync();
-    }
-}
-
-// ---- the same for several detectors that share their windows ------------------------------------------------------------
-// HistEq64 depends on the window only, so the histogram, the cdf chain and the LUT (steps 1-2, ~45 % of the single-detector
-// kernel) are done once per tile; the equalise + contraction + levels (steps 3-6) run once per detector against its own digit
-// matrix, constants and queue.  The LUT therefore has to outlive the transposes that reuse the histogram block: it is kept as
-// bytes in its own 4 KB block per wavefront ([bin][lane], 4 KB-aligned so that (bin << 6) | (block + lane) is a complete
-// address), and the k-step pixel chunk lives in the (then dead) histogram block.  48 KB of LDS per workgroup = 3 workgroups per
-// CU; three wavefronts per SIMD were measured equal to four for this kernel (it is bound by instruction issue).
-struct __attribute__((aligned(8192))) WvdLdsM {
-    unsigned short hist[4][64][64];                  // [wave][bin][slot of the lane]: counters; then the k-step chunk (first 2 KB); then the transposes
-    unsigned char lut[4][64][64];                    // [wave][bin][lane]
-};
-template <int B_>
-__device__ __forceinline__ unsigned int wvd_slot_lut(unsigned int w4, unsigned int laneOffLut) {
-    unsigned int bin, a;
-    asm("v_bfe_u32 %0, %1, %2, 6" : "=v"(bin) : "v"(w4), "n"(8 * B_ + 2));
-    asm("v_lshl_or_b32 %0, %1, 6, %2" : "=v"(a) : "v"(bin), "v"(laneOffLut));
-    return a;
-}
-__device__ __forceinline__ unsigned int wvd_lut8(unsigned int ldsAddr) { return *(__attribute__((address_space(3))) unsigned char*)(uintptr_t)ldsAddr; }   // ds_read_u8
-
-template <int PW_, int PH_>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_wvm_prefilter_multi(const uint8_t* __restrict__ arena, WvdTable wt, WvdMulti mv) {
-    static_assert(PW_ % 4 == 0 && PW_ >= 16 && PW_ <= 32, "rows are read as dwords; a row (or two 16-wide rows) fills one k-step");
-    constexpr int RPS = WvdGeo<PW_>::RPS;
-    static_assert(PH_ % RPS == 0, "whole k-steps");
-    constexpr int KS = PH_ / RPS;
-    constexpr int NW = PW_ / 4;          // dwords per patch row
-    __shared__ WvdLdsM S;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const float stretch = mv.d[0].stretch, sxxSlack = mv.d[0].sxxSlack;   // the same for all detectors of a group (patch size)
-    const int ntiles = wt.ntiles;
-    int li = 0;
-    unsigned char* histPtr = reinterpret_cast<unsigned char*>(&S.hist[wave][0][0]);
-    unsigned char* xPtr = histPtr;   // the k-step chunk lives in the histogram block (dead between the LUT and the transposes)
-    const unsigned int lutLds = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&S.lut[wave][0][0];   // 4 KB-aligned
-    const unsigned int laneOffLut = lutLds + (unsigned int)lane;
-    double* trPtr = reinterpret_cast<double*>(histPtr);
-    const unsigned int histLds = (unsigned int)(uintptr_t)(wvd_lds_u16*)&S.hist[wave][0][0];   // LDS byte address, 8 KB-aligned
-    // lanes l and l + 32 share a dword of every bin row: they are served in different LDS cycles, so nothing conflicts
-    const unsigned int laneOff32 = histLds + (unsigned int)(lane & 31) * 4u;
-    const unsigned int laneOff16 = laneOff32 + (unsigned int)(lane >> 5) * 2u;
-    const unsigned int inc = 1u << (16 * (lane >> 5));
-
-    int lastImg = 0;
-    for (int gtile = blockIdx.x * 4 + wave; gtile < ntiles; gtile += gridDim.x * 4) {
-        const int img = wt.nimg > 1 ? gtile / wt.tilesPerImage : 0;   // frame of a multi-frame pyramid
-        const int tile = gtile - img * wt.tilesPerImage;
-        if (img != lastImg) { li = 0; lastImg = img; }
-        while (li + 1 < wt.n && tile >= wt.l[li + 1].tileFirst) ++li;   // tiles ascend per wavefront inside a frame
-        const WvdLayer& wl = wt.l[li];
-        const int local0 = (tile - wl.tileFirst) * 64 + lane;
-        const bool valid = local0 < wl.nwin;
-        const unsigned int local = (unsigned int)(valid ? local0 : wl.nwin - 1);
-        unsigned int iy = __umulhi(local, wl.magic);   // floor(local / nx) or one less
-        unsigned int ix = local - iy * (unsigned int)wl.nx;
-        if (ix >= (unsigned int)wl.nx) { ix -= wl.nx; ++iy; }
-        const int lw = wl.lw;
-        const uint8_t* src = arena + (size_t)img * wt.imageStride + wl.off + (size_t)(wl.by + (int)iy * wt.sy) * lw + (wl.bx + (int)ix * wt.sx);
-        const int64_t wid = (int64_t)img * wt.perImage + wl.first + local;
-
-        // ---- 1. histogram: 64 bins x 64 lanes of u16 counters
-        {
-            uint4* z = reinterpret_cast<uint4*>(histPtr);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) z[i * 64 + lane] = make_uint4(0, 0, 0, 0);
-        }
-        __builtin_amdgcn_wave_barrier();
-        {
-            unsigned int wn[NW];
-#pragma unroll
-            for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(src + 4 * j);
-#pragma unroll 1
-            for (int r = 0; r < PH_; ++r) {   // one patch row per iteration, the next row's loads in flight
-                unsigned int w4[NW];
-#pragma unroll
-                for (int j = 0; j < NW; ++j) w4[j] = wn[j];
-                const uint8_t* nsrc = src + (size_t)(r + 1 < PH_ ? r + 1 : r) * lw;
-#pragma unroll
-                for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(nsrc + 4 * j);
-#pragma unroll
-                for (int j = 0; j < NW; ++j) {
-                    wvd_count(wvd_slot<0>(w4[j], laneOff32), inc);
-                    wvd_count(wvd_slot<1>(w4[j], laneOff32), inc);
-                    wvd_count(wvd_slot<2>(w4[j], laneOff32), inc);
-                    wvd_count(wvd_slot<3>(w4[j], laneOff32), inc);
-                }
-            }
-        }
-        wave_sync();
-        // ---- 2. the fp32 cdf in the reference's order (cdf[0] = pdf[0]; cdf[b] = cdf[b-1] + pdf[b]), the LUT, and the exact
-        //         integer sum / sum of squares of the equalised patch
-        unsigned int sumx = 0, sumxx = 0;
-        {
-            float cdf = 0.f;
-#pragma unroll
-            for (int b = 0; b < 64; ++b) {
-                wvd_lds_u16* slot = (wvd_lds_u16*)(uintptr_t)((unsigned int)(b << 7) + laneOff16);   // laneOff16 is a complete LDS address
-                const unsigned int cnt = *slot;
-                const float pdf = (float)cnt * stretch;
-                cdf = b == 0 ? pdf : cdf + pdf;
-                // (uchar)floor((double)cdf + 0.5): cdf < 2^9 has at most 24 significant bits, so cdf + 0.5 is exact in double;
-                // floor(cdf) + (frac >= 0.5) is the same value without leaving fp32 (cdf + 0.5f itself can round up to an integer)
-                const float fl = floorf(cdf);
-                const float up = (cdf - fl >= 0.5f) ? fl + 1.0f : fl;
-                const unsigned int e = (unsigned int)up & 255u;
-                *(__attribute__((address_space(3))) unsigned char*)(uintptr_t)(lutLds + (unsigned int)(b << 6) + (unsigned int)lane) = (unsigned char)e;
-                const unsigned int ce = cnt * e;   // <= 768 * 255
-                sumx += ce;
-                sumxx += ce * e;                   // <= 768 * 65025 < 2^26
-                asm("" : "+v"(sumx), "+v"(sumxx));   // accumulate here (sunk to their use, the 128 products spill)
-            }
-        }
-        wave_sync();
-#pragma unroll 1
-        for (int det = 0; det < mv.nd; ++det) {
-        const WvdDev& dv = mv.d[det];
-        // constant address space: scalar loads (SMEM) even though the kernel also stores to global memory
-        const __attribute__((address_space(4))) WvdConst& C = *(const __attribute__((address_space(4))) WvdConst*)(uintptr_t)dv.c;
-        const int L = dv.L;
-        // ---- 3. equalise, exact dot products on the matrix pipe: one k-step per patch row (two rows when the patch is 16 wide)
-        wvd_v16i acc00 = {}, acc01 = {}, acc10 = {}, acc11 = {};
-        {
-            unsigned int wn[RPS][NW];
-#pragma unroll
-            for (int rr = 0; rr < RPS; ++rr)
-#pragma unroll
-                for (int j = 0; j < NW; ++j) wn[rr][j] = wvd_load_u32(src + (size_t)rr * lw + 4 * j);
-            wvd_v4i bn0 = dv.B[lane], bn1 = dv.B[64 + lane];
-#pragma unroll 1
-            for (int ks = 0; ks < KS; ++ks) {
-                const wvd_v4i b0 = bn0, b1 = bn1;
-                unsigned int w4[RPS][NW];
-#pragma unroll
-                for (int rr = 0; rr < RPS; ++rr)
-#pragma unroll
-                    for (int j = 0; j < NW; ++j) w4[rr][j] = wn[rr][j];
-                {   // next k-step's rows and digits (the last step re-reads its own)
-                    const int kn = ks + 1 < KS ? ks + 1 : ks;
-                    const uint8_t* nsrc = src + (size_t)(kn * RPS) * lw;
-#pragma unroll
-                    for (int rr = 0; rr < RPS; ++rr)
-#pragma unroll
-                        for (int j = 0; j < NW; ++j) wn[rr][j] = wvd_load_u32(nsrc + (size_t)rr * lw + 4 * j);
-                    bn0 = dv.B[(kn * 2 + 0) * 64 + lane];
-                    bn1 = dv.B[(kn * 2 + 1) * 64 + lane];
-                }
-                unsigned int pk[RPS * NW];
-#pragma unroll
-                for (int rr = 0; rr < RPS; ++rr) {
-#pragma unroll
-                    for (int j = 0; j < NW; ++j) {
-                        const unsigned int w = w4[rr][j];
-                        const unsigned int e0 = wvd_lut8(wvd_slot_lut<0>(w, laneOffLut));
-                        const unsigned int e1 = wvd_lut8(wvd_slot_lut<1>(w, laneOffLut));
-                        const unsigned int e2 = wvd_lut8(wvd_slot_lut<2>(w, laneOffLut));
-                        const unsigned int e3 = wvd_lut8(wvd_slot_lut<3>(w, laneOffLut));
-                        pk[rr * NW + j] = wvd_lshl_or(e3, 24, wvd_lshl_or(e2, 16, wvd_lshl_or(e1, 8, e0))) ^ 0x80808080u;   // x - 128 as int8
-                    }
-                }
-                // slots RPS * PW_ .. 31 of the k-step are never written: their digits are zero, so stale bytes multiply into nothing
-                unsigned char* xrow = xPtr + lane * 16;
-                constexpr int ND = RPS * NW;   // 4, 5, 6 or 8 dwords
-                *reinterpret_cast<uint4*>(xrow) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                if constexpr (ND == 5) *reinterpret_cast<unsigned int*>(xrow + 1024) = pk[4];
-                if constexpr (ND == 6) *reinterpret_cast<uint2*>(xrow + 1024) = make_uint2(pk[4], pk[5]);
-                if constexpr (ND == 8) *reinterpret_cast<uint4*>(xrow + 1024) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-                __builtin_amdgcn_wave_barrier();   // LDS operations of a wavefront execute in order: the reads below see these writes
-                const wvd_v4i a0 = *reinterpret_cast<const wvd_v4i*>(xPtr + (lane >> 5) * 1024 + (lane & 31) * 16);
-                const wvd_v4i a1 = *reinterpret_cast<const wvd_v4i*>(xPtr + (lane >> 5) * 1024 + (32 + (lane & 31)) * 16);
-                __builtin_amdgcn_wave_barrier();
-                acc00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc00, 0, 0, 0);
-                acc01 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc01, 0, 0, 0);
-                acc10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc10, 0, 0, 0);
-                acc11 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc11, 0, 0, 0);
-            }
-        }
-        // ---- 4. digits -> exact integer dot products, transposed to lane == window.  Column g = f + 16 j of N-tile g / 32 holds
-        //         digit j of filter f: this lane (column lane & 31) has digit j0 = (lane >> 4) & 1 in tile 0 and digit j0 + 2 in tile 1
-        wave_sync();   // the k-step chunk is dead: the histogram block becomes the transpose buffer
-        {
-            int laneT = lane;
-            asm volatile("" : "+v"(laneT));   // the 32 slot addresses are cheap: computed here, not hoisted out of the tile loop and spilled
-            const bool lowDigit = (laneT & 16) == 0;
-            const int h4 = 4 * (laneT >> 5);
-            const int fh = (laneT & 15) ^ h4;   // row & 15 = (rowc & 15) | h4 (rowc & 15 has bit 2 clear), so f ^ (row & 15) = fh ^ (rowc & 15)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-                for (int rg = 0; rg < 16; ++rg) {
-                    const int s0 = mt == 0 ? acc00[rg] : acc10[rg];
-                    const int s2 = mt == 0 ? acc01[rg] : acc11[rg];
-                    const double part = (double)s0 + 65536.0 * (double)s2;          // exact: |s| < 2^24
-                    const double other = __shfl_xor(part, 16);
-                    const int rowc = mt * 32 + (rg & 3) + 8 * (rg >> 2);             // window row = rowc + h4
-                    if (lowDigit) trPtr[(rowc + h4) * 16 + (fh ^ (rowc & 15))] = part + 256.0 * other;   // exact: < 2^53
-                }
-            }
-        }
-        wave_sync();
-        // ---- 5. the first L cascade levels of this lane's window with error bounds
-        bool undecided = valid;
-        {
-            int laneC = lane;
-            asm volatile("" : "+v"(laneC));   // as above, for the 16 read addresses
-            float Kv[WVD_L], Ke[WVD_L];
-            // the reference's fp32 sum of squares: row totals (exact ints) added in fp32, so it IS the integer below 2^24
-            const float sxx = (float)sumxx;
-            // |norm - reference norm|: 2 * quantisation error of xp, the fp32 sum of squares above 2^24, slack for the reference's
-            // fp64 roundings (< 1e-5)
-            const double dn = dv.scale * (double)sumx + (sumxx >= (1u << 24) ? (double)sxxSlack : 0.0) + 1e-4;
-            const float relDn = (float)(-(double)dv.negBasis * dn) * 1.0001f;
-#pragma unroll
-            for (int k = 0; k < WVD_L; ++k) {
-                if (k < L) {
-                    const double xp = (trPtr[laneC * 16 + (k ^ (laneC & 15))] + C.c128[k]) * dv.scale;
-                    double norm = (double)sxx;
-                    norm = norm - 2 * xp;
-                    norm = norm + C.pp[k];
-                    const float arg = (float)((double)dv.negBasis * norm);
-                    float Kk, Kerr;
-                    if (arg < -80.0f) { Kk = 0.f; Kerr = 2e-35f; }           // true K <= e^-80 (1 + tiny)
-                    else if (arg > 80.0f) { Kk = 0.f; Kerr = 3.0e38f; }       // cannot happen for a sane model: never reject
-                    else {
-                        Kk = __expf(arg);
-                        // relative error of K: exponent error (quantisation, float cast of the argument, x * log2e, 2^x), the final
-                        // rounding, and -- folded in here -- the fp32 summation-order term (4k + 16) 2^-24 <= 4.6e-6 of the level sums
-                        const float rho = (relDn + fabsf(arg) * 2.4e-7f + 6.0e-7f) * 1.01f + 4.6e-6f;
-                        Kerr = Kk * rho + 1e-37f;
-                    }
-                    Kv[k] = Kk;
-                    Ke[k] = Kerr;
-                    float R = dv.negBias, E = fabsf(dv.negBias) * 4.6e-6f + 1e-37f;
-#pragma unroll
-                    for (int p = 0; p <= k; ++p) {
-                        const float w = C.w[k][p];
-                        R = fmaf(w, Kv[p], R);
-                        E = fmaf(fabsf(w), Ke[p], E);
-                    }
-                    // the reference leaves at the first level with res < thr, and res_ref <= R + E
-                    if (undecided && (R + E < C.thr[k])) undecided = false;
-                }
-            }
-        }
-        // ---- 6. survivors -> queue of the exact cascade (wave-aggregated)
-        {
-            const unsigned long long mask = __ballot(undecided);
-            if (mask) {
-                unsigned int base = 0;
-                if (lane == 0) base = atomicAdd(dv.qcount, (unsigned int)__popcll(mask));
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (undecided) dv.q[base + __popcll(mask & ((1ull << lane) - 1ull))] = wid;
-            }
-        }
-        wave_sync();
-        }   // detectors
     }
 }
 

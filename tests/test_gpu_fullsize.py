@@ -347,34 +347,3 @@ def test_multi_frame_ticket_reports_errors_and_stays_usable(capi, ctx, synth, sm
     assert dets.tobytes() == b"".join(d.tobytes() for d, _ in ref)
     assert np.array_equal(stages, np.stack([s for _, s in ref]))
     w_.close(); s_.close(); p_.close()
-
-
-def test_shared_prefilter_of_a_detector_group_equals_separate_launches(capi, ctx, synth, monkeypatch):
-    """FD_WVM_GROUP=1: detectors of a batch that scan the same windows (one pyramid, one patch size) share one pre-filter launch
-    (k_wvm_prefilter_multi: HistEq64 once per tile, dense levels per detector).  Detections, order, scores and stage counts equal
-    the default path's (separate launches), for a group of three 24x24 detectors + one 20x20 detector on its own."""
-    frame = synth.make_frame(960, 540, seed=77)
-    gray = frame[..., 1].copy()
-    rng = np.random.default_rng(12)
-    kw = dict(inc=float(np.float32(0.9)), min_scale=float(np.float32(0.5)), max_scale=float(np.float32(0.7)))
-    p_ = capi.Pyramid(ctx, **kw)
-    p_.update(frame)
-    dets = []
-    for k, (pw, ph, nper) in enumerate([(24, 24, 20), (24, 24, 30), (24, 24, 12), (20, 20, 14)]):
-        calib = synth.random_patches(gray[::2, ::2].copy(), pw, ph, 3000, rng)
-        wm = synth.make_wvm(200 + k, fw=pw, fh=ph, n_per=nper, n_levels=2, calib_patches=calib, min_survivors=48)
-        eq = synth.histeq64_np(synth.random_patches(gray[::2, ::2].copy(), pw, ph, 400, rng))
-        sm = synth.make_svm_u8(30 + k, eq, nsv=64, calib=eq[64:], positive_fraction=0.4)
-        dets.append((p_, capi.Wvm(ctx, wm), capi.Svm(ctx, sm)))
-    monkeypatch.delenv("FD_WVM_GROUP", raising=False)
-    ref = capi.FiveStageBatch(ctx, dets, cap=1 << 14).end()
-    monkeypatch.setenv("FD_WVM_GROUP", "1")
-    got = capi.FiveStageBatch(ctx, dets, cap=1 << 14).end()
-    got2 = capi.FiveStageBatch(ctx, dets, cap=1 << 14).end()   # steady state (headers left clean by the previous run)
-    assert sum(len(d) for d, _ in ref) > 0
-    for (d, s), (dr, sr), (d2, s2) in zip(got, ref, got2):
-        assert np.array_equal(s, sr) and d.tobytes() == dr.tobytes()
-        assert np.array_equal(s2, sr) and d2.tobytes() == dr.tobytes()
-    for _, w_, s_ in dets:
-        w_.close(); s_.close()
-    p_.close()
