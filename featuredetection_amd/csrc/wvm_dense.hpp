@@ -372,27 +372,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         //         acc[M][N]: digit tile M (rows f + 16 j', digits 2 M + j') x window tile N (windows 32 N + (lane & 31))
         wvd_v16i acc00 = {}, acc01 = {}, acc10 = {}, acc11 = {};
         {
-            unsigned int nx[8];
+            constexpr int PF = 1;   // k-steps the pixel dwords are requested ahead of their use (2: measured 4 % slower, the registers cost more)
+            unsigned int nxq[PF][8];
             wvd_v4i an0, an1;
             const char* Bb = reinterpret_cast<const char*>(dv.B);   // uniform base + lane * 16
             unsigned int lane16 = (unsigned int)lane * 16u;
             asm volatile("" : "+v"(lane16));   // stays an offset register (hoisted out of the loops as 2 KS address pairs, the fragment addresses spill)
-            auto fetch = [&](int ks) {   // pixel dwords and digit fragments of k-step ks
+            auto fetchPx = [&](int ks) {   // pixel dwords of k-step ks
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int q = 8 * ks + j;
-                    if (q < D4) nx[j] = wvd_load_u32(ubase + (size_t)(q / NW) * lw + 4 * (q % NW), lo);
+                    if (q < D4) nxq[ks % PF][j] = wvd_load_u32(ubase + (size_t)(q / NW) * lw + 4 * (q % NW), lo);
                 }
+            };
+            auto fetch = [&](int ks) {   // digit fragments of k-step ks
                 an0 = *reinterpret_cast<const wvd_v4i*>(Bb + (size_t)(ks * 2 + 0) * 1024 + lane16);
                 an1 = *reinterpret_cast<const wvd_v4i*>(Bb + (size_t)(ks * 2 + 1) * 1024 + lane16);
             };
+#pragma unroll
+            for (int i = 0; i < PF; ++i)
+                if (i < KS) fetchPx(i);
             fetch(0);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const wvd_v4i a0 = an0, a1 = an1;
                 unsigned int cur[8], pk[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) cur[j] = nx[j];
+                for (int j = 0; j < 8; ++j) cur[j] = nxq[ks % PF][j];
+                if (ks + PF < KS) fetchPx(ks + PF);
                 if (ks + 1 < KS) fetch(ks + 1);
                 wvd_equalise<4>(cur, pk, lutWord, blkL4);
                 if (8 * ks + 4 < D4) wvd_equalise<4>(cur + 4, pk + 4, lutWord, blkL4);
@@ -444,24 +451,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             const wvd_v2f RE0 = {dv.negBias, fabsf(dv.negBias) * 4.6e-6f + 1e-37f};
             const __attribute__((address_space(4))) wvd_v2f* W2 = (const __attribute__((address_space(4))) wvd_v2f*)&C.w2[0][0][0];
             unsigned long long und = __ballot(undecided);
+            // NL levels as ONE basic block (no test of L between levels: the scheduler issues the scalar loads of the level constants
+            // ahead of the arithmetic; with a test per level pair every pair waited for its own loads: 132 -> 127 us per headline launch).
+            // Levels L .. NL - 1 are padding (thr = -inf, weights 0): evaluated, never rejecting.
+            auto levels = [&](auto nl) {
+                constexpr int NL = decltype(nl)::value;
 #pragma unroll
-            for (int k2 = 0; k2 < WVD_L; k2 += 2) {
-                if (k2 < L) {
+                for (int k = 0; k < NL; ++k) {
+                    const double ex = __builtin_fma(xq[(k >> 2) & 1][(k & 3) + 4 * (k >> 3)], dv.mXq, e0 + C.cA[k]);
+                    const float lg = (float)ex;
+                    const float Kraw = __builtin_amdgcn_exp2f(lg);   // <= 2^-115 where the old form tested arg < -80: inside the 3e-35 below
+                    const float rho = __builtin_fmaf(fabsf(lg), 1.69e-7f, rho0);
+                    KK[k] = wvd_v2f{Kraw, __builtin_fmaf(Kraw, rho, 3e-35f)};
+                    wvd_v2f RE = RE0;
 #pragma unroll
-                    for (int k = k2; k < k2 + 2; ++k) {
-                        const double ex = __builtin_fma(xq[(k >> 2) & 1][(k & 3) + 4 * (k >> 3)], dv.mXq, e0 + C.cA[k]);
-                        const float lg = (float)ex;
-                        const float Kraw = __builtin_amdgcn_exp2f(lg);   // <= 2^-115 where the old form tested arg < -80: inside the 3e-35 below
-                        const float rho = __builtin_fmaf(fabsf(lg), 1.69e-7f, rho0);
-                        KK[k] = wvd_v2f{Kraw, __builtin_fmaf(Kraw, rho, 3e-35f)};
-                        wvd_v2f RE = RE0;
-#pragma unroll
-                        for (int p = 0; p <= k; ++p) RE = __builtin_elementwise_fma(W2[k * WVD_L + p], KK[p], RE);   // R += w K_p, E += |w| dK_p
-                        // the reference leaves at the first level with res < thr, and res_ref <= R + E
-                        und &= ~__ballot(RE.x + RE.y < C.thr[k]);
-                    }
+                    for (int p = 0; p <= k; ++p) RE = __builtin_elementwise_fma(W2[k * WVD_L + p], KK[p], RE);   // R += w K_p, E += |w| dK_p
+                    // the reference leaves at the first level with res < thr, and res_ref <= R + E
+                    und &= ~__ballot(RE.x + RE.y < C.thr[k]);
                 }
-            }
+            };
+            if (L > 14) levels(std::integral_constant<int, 16>());
+            else if (L > 12) levels(std::integral_constant<int, 14>());
+            else if (L > 8) levels(std::integral_constant<int, 12>());
+            else levels(std::integral_constant<int, 8>());
             undecided = (und >> lane) & 1ull;
         }
         // ---- 6. survivors -> queue of the exact cascade (wave-aggregated)
