@@ -59,12 +59,10 @@ def host_info():
 
 
 def pmc_record(workload, kernel_substr):
-    """Counter figures per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/r03_pmc.json, written by
+    """Counter figures per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/r04_pmc.json, written by
     tools/pmc_summary.py from runs of this script; every entry names the command and the git head it was measured at)."""
     try:
-        path = os.path.join(ROOT, "profiles", "r03_pmc.json")
-        if not os.path.exists(path):
-            path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+        path = next(p_ for p_ in (os.path.join(ROOT, "profiles", "r0%d_pmc.json" % r) for r in (4, 3, 2)) if os.path.exists(p_))
         rec = json.load(open(path))
         ks = rec.get(workload, {}).get("kernels", {})
         agg = "k_all(%s)" % kernel_substr
@@ -181,6 +179,8 @@ class Cascade(Workload):
 
     profile = "default"
 
+    content = "varied"
+
     def __init__(self, env, W=640, H=480, frames_per_step=4096, nb=64, multi=True):   # ~50 ms per step: 20 steps are a second of GPU work
         import torch
         from featuredetection_amd import capi, synth
@@ -188,10 +188,23 @@ class Cascade(Workload):
         ctx = env.ctx
         self.NB = max(1, min(nb, frames_per_step))
         self.FP = max(self.NB, frames_per_step // self.NB * self.NB)
-        self.NFR = 8
-        frames = [synth.make_frame(W, H, seed=20260927 + 1000 * env.rank + i) for i in range(self.NFR)]
+        if self.content == "varied":
+            # 256 distinct frames in 8 'scenes' of 32 (synth.make_frames_varied): the share of windows that survive the first cascade
+            # levels differs ~7x between scenes, and the scenes are reshuffled every pass, so consecutive calls queue different
+            # numbers of windows for stage B (its launch plan follows the previous run) and no call repeats its predecessor
+            self.NFR, self.SCENE = 256, 32
+            frames, self.busy = synth.make_frames_varied(self.NFR, W, H, seed=20260927 + 1000 * env.rank, scene_len=self.SCENE)
+        else:
+            # round 1-3 content: 8 frames of one recipe, every call holds the same 8 frames x NB / 8
+            self.NFR, self.SCENE = 8, 8
+            frames = [synth.make_frame(W, H, seed=20260927 + 1000 * env.rank + i) for i in range(self.NFR)]
+        self.order_rng = np.random.default_rng(77 + env.rank)
+        self.order = np.arange(self.NFR)
+        self.qlens = []
         self.frames = frames
         self.dframes = [torch.from_numpy(f).to(env.dev) for f in frames]
+        self.dptrs = [t.data_ptr() for t in self.dframes]
+        self.nframes_fed = 0
         self.wvm_m, self.svm_m = cascade_models(self.profile)
         kw = dict(inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))
         self.multi = multi and self.NB > 1
@@ -219,9 +232,27 @@ class Cascade(Workload):
                                     "%s, detections delivered per frame" % (W, H, self.nlayers, self.nwin, "fd_pyramid_update_frames + "
                                     "fd_detect_five_stage_frames (the frames of a call share one pyramid arena, one cascade run and one SVM launch)"
                                     if self.multi else "fd_detect_five_stage_batch"),
-                           frames_per_step=self.FP, frames_per_call=self.NB, parallelism="image-shard dp%d" % env.world)
+                           frames_per_step=self.FP, frames_per_call=self.NB, parallelism="image-shard dp%d" % env.world,
+                           content=("%d distinct frames resident in HBM, %d scenes of %d with different busy-ness, scene order reshuffled every pass"
+                                    % (self.NFR, self.NFR // self.SCENE, self.SCENE)) if self.content == "varied" else
+                                   "8 distinct frames, every call holds the same frames (the content of rounds 1-3)")
         if self.profile != "default":
             self.config["wvm_rejection_profile"] = "%s: %s" % (self.profile, WVM_PROFILES[self.profile]["kw"])
+
+    def _frame_ids(self, n):
+        """the next n frames of the endless frame sequence: whole scenes, in an order reshuffled at the start of every pass"""
+        ids = np.empty(n, np.int64)
+        done = 0
+        while done < n:
+            pos = self.nframes_fed % self.NFR
+            if pos == 0 and self.content == "varied":
+                sc = self.order_rng.permutation(self.NFR // self.SCENE)
+                self.order = (sc[:, None] * self.SCENE + np.arange(self.SCENE)[None, :]).ravel()
+            m = min(n - done, self.NFR - pos)
+            ids[done:done + m] = self.order[pos:pos + m]
+            done += m
+            self.nframes_fed += m
+        return ids
 
     def step(self, i):
         capi, NB = self.capi, self.NB
@@ -234,7 +265,7 @@ class Cascade(Workload):
                 self.ncalls += 1
                 if sl["run"] is not None:
                     out.extend(self._collect(sl))
-                ptrs = [self.dframes[(base + c * NB + j) % self.NFR].data_ptr() for j in range(NB)]
+                ptrs = [self.dptrs[f] for f in self._frame_ids(NB)]
                 sl["pyr"].update_frames(device_ptrs=ptrs, w=self.W, h=self.H, ch=3)
                 sl["run"] = capi.FiveStageFrames(sl["ctx"], sl["pyr"], sl["wvm"], sl["svm"], NB)
                 sl["ids"] = (base + c * NB + np.arange(NB)) * self.env.world + self.env.rank
@@ -249,7 +280,17 @@ class Cascade(Workload):
     def _collect(self, sl):
         # one record block per call: (image id of every detection, detector 0, the detections of the call's frames in frame order)
         (dets, fidx, _), sl["run"] = sl["run"].end_flat(), None
+        self.qlens.append(sl["wvm"].last_queue_length())
         return [(sl["ids"][fidx], 0, dets)]
+
+    def extra_record(self):
+        """spread of the stage-B queue lengths (windows per call that survive the dense pre-filter) over the calls of the run"""
+        q = np.array([v for v in self.qlens if v >= 0], np.float64)
+        if not len(q):
+            return {}
+        return dict(stage_b_queue_per_call=dict(calls=int(len(q)), min=int(q.min()), p10=float(np.percentile(q, 10)), median=float(np.median(q)),
+                                                p90=float(np.percentile(q, 90)), max=int(q.max()), mean=float(q.mean()),
+                                                mean_abs_change_between_consecutive_calls=float(np.abs(np.diff(q)).mean()) if len(q) > 1 else 0.0))
 
     def flush(self):
         out = []
@@ -274,7 +315,7 @@ class Cascade(Workload):
             for i in range(12):
                 if self.multi:   # the production launch: one cascade run over the NB frames of a call
                     sl = self.slots[0]
-                    sl["pyr"].update_frames(device_ptrs=[self.dframes[(i + j) % self.NFR].data_ptr() for j in range(nf)], w=self.W, h=self.H, ch=3)
+                    sl["pyr"].update_frames(device_ptrs=[self.dptrs[(i * nf + j) % self.NFR] for j in range(nf)], w=self.W, h=self.H, ch=3)
                     capi.detect_five_stage_frames(ctx, sl["pyr"], sl["wvm"], sl["svm"], nf)
                 else:
                     self.pyrs[0].update_device(self.dframes[i % self.NFR].data_ptr(), self.W, self.H, 3)
@@ -354,6 +395,15 @@ class CascadeLate(Cascade):
     profile = "late"
 
     def __init__(self, env, W=640, H=480, frames_per_step=1024, nb=64, multi=True):
+        super().__init__(env, W, H, frames_per_step, nb, multi)
+
+
+class Cascade8(Cascade):
+    """the headline workload on the content of rounds 1-3 (8 frames, every call identical): kept as a second record for continuity"""
+    name = "cascade_8frames"
+    content = "8frames"
+
+    def __init__(self, env, W=640, H=480, frames_per_step=2048, nb=64, multi=True):
         super().__init__(env, W, H, frames_per_step, nb, multi)
 
 
@@ -799,6 +849,8 @@ def measure(wl, env, steps, warmup, gather_every, want_cpu):
     gc.collect()
     gc.disable()   # a full gc pass over torch's object graph costs ~75 ms and would land on a random step
     barrier()
+    if hasattr(wl, "qlens"):
+        wl.qlens = []
     t0 = time.perf_counter()
     units, ndet, pending, gathered = 0, 0, [], 0
     for i in range(steps):
@@ -833,6 +885,8 @@ def measure(wl, env, steps, warmup, gather_every, want_cpu):
     if world > 1:
         rec["records_gathered"] = gathered
         rec["records_truncated"] = bool(truncated)
+    if hasattr(wl, "extra_record") and env.rank == 0:
+        rec.update(wl.extra_record())
     probe = wl.kernel_probe() if (env.rank == 0 and not getattr(env, "no_probe", False)) else None
     if probe:
         rec["roofline"] = probe[0]
@@ -844,7 +898,7 @@ def measure(wl, env, steps, warmup, gather_every, want_cpu):
     return rec
 
 
-WORKLOADS = dict(cascade=Cascade, cascade_late=CascadeLate, cascade_group=CascadeGroup, hog_svm=HogSvm, ffp15=Ffp15, sdm=Sdm, rvm=Rvm, aggregated=Aggregated)
+WORKLOADS = dict(cascade=Cascade, cascade_8frames=Cascade8, cascade_late=CascadeLate, cascade_group=CascadeGroup, hog_svm=HogSvm, ffp15=Ffp15, sdm=Sdm, rvm=Rvm, aggregated=Aggregated)
 
 
 def free_port():
@@ -861,7 +915,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cascade", choices=sorted(WORKLOADS) + ["wvm"], help="headline workload (wvm = cascade)")
-    ap.add_argument("--also", default=None, help="comma-separated sub-records (default: hog_svm,ffp15,sdm,cascade_late,cascade_group when the headline is the "
+    ap.add_argument("--also", default=None, help="comma-separated sub-records (default: hog_svm,ffp15,sdm,cascade_late,cascade_group,cascade_8frames when the headline is the "
                                                  "default cascade; 'none' for none)")
     ap.add_argument("--gather-every", type=int, default=4)
     ap.add_argument("--size", default=None, help="frame size WxH of the headline workload (cascade, hog_svm, ffp15, rvm, aggregated)")
@@ -916,7 +970,7 @@ def main():
 
     also = args.also
     if also is None:
-        also = "hog_svm,ffp15,sdm,cascade_late,cascade_group" if (args.workload == "cascade" and not args.size) else "none"
+        also = "hog_svm,ffp15,sdm,cascade_late,cascade_group,cascade_8frames" if (args.workload == "cascade" and not args.size) else "none"
     also = [a for a in also.split(",") if a and a != "none"]
     want_cpu = not args.no_cpu_baseline
     env.no_probe = args.no_probe
@@ -932,6 +986,13 @@ def main():
     if env.rank == 0:
         if subs:
             res["also"] = subs
+            # the line is long; whatever keeps only its tail still sees every record's value
+            summ = {args.workload: dict(value=res["value"], unit=res["unit"], ms_per_step=res["ms_per_step"])}
+            for w2, r2 in zip(also, subs):
+                summ[w2] = dict(value=r2["value"], unit=r2["unit"], ms_per_step=r2["ms_per_step"])
+            if "latency_us_single_frame" in res:
+                summ["latency_us_single_frame"] = {k: res["latency_us_single_frame"][k] for k in ("p50", "p99")}
+            res["summary"] = summ
         print(json.dumps(res))
     if env.world > 1:
         dist.destroy_process_group()

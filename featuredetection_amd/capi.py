@@ -219,6 +219,8 @@ _BENCH_SIGS = {
     "fd_ctx_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "fd_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
     "fd_debug_wvb_rect_sums": (C.c_int64, [C.POINTER(fd_wvm_model), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "fd_wvm_last_queue_length": (C.c_int64, [C.c_void_p]),
+    "fd_wvm_last_tail_state": (C.c_int, [C.c_void_p]),
     "fd_debug_wvd_plan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 
@@ -415,6 +417,14 @@ class Wvm:
         s, keep = _wvm_struct(model, fd_wvm_model)
         self.h = C.c_void_p()
         ctx.check(lib().fd_wvm_create(ctx.h, C.byref(s), C.byref(self.h)))
+
+    def last_queue_length(self):
+        """measurement hook: windows the last finished run queued for stage B (-1 before the first run)"""
+        return int(lib().fd_wvm_last_queue_length(self.h))
+
+    def last_tail_state(self):
+        """test hook: -1 overlap elimination on the host, 0 on the device, > 0 the device kernel gave up (fd_hip_bench.h)"""
+        return int(lib().fd_wvm_last_tail_state(self.h))
 
     def close(self):
         if self.h:

@@ -1,0 +1,307 @@
+// featuredetection_amd/csrc/fs_tail.hpp -- stage 2 of FiveStageSlidingWindowDetector::detect on the device (included by wvm.hip only).
+//
+// FiveStageSlidingWindowDetector.cpp:200-240 hands the WVM positives of a frame to OverlapElimination::eliminate
+// (OverlapElimination.cpp:44-105: std::sort by probability, descending, then a greedy sweep -- an element survives iff no earlier
+// survivor overlaps it) and the survivors to the SVM.  Rounds 1-3 did that on the host between two kernel chains: positives over PCIe,
+// ~0.7 ms of host work per 64-frame call (ordering ~10 K positives, their geometry and logistic, the sweep), SVM launch, second wait --
+// the host stages, not the GPU, bounded the headline once the content of the frames varied, and a single frame paid two round trips.
+// k_fs_oe runs the elimination where the positives are: one workgroup per frame gathers the frame's records, computes the geometry of
+// ImagePyramid / PyramidFeatureExtractor (cvRound(x / scale) + w / 2, IEEE double division and round-half-even like the host),
+// sorts, sweeps, and appends the survivors' patch slots to the list the SVM kernel behind it reads (its count stays on the device).
+//
+// Exactness.  The reference's order is std::sort on the probability 1 / (1 + exp(A + B fout)) computed with libm in double.  The
+// kernel sorts by the fp32 filter output instead (descending for B < 0), which is the same permutation iff the probabilities of the
+// frame are pairwise different and ordered like the outputs.  It proves that per frame or gives up: equal outputs (the reference's
+// order of ties is whatever its std::sort does with them), B = 0 or not finite, and neighbours in sorted order whose probabilities
+// could collapse in double (the logistic saturates: relative gap of 1 + e below 1e-14, a margin of ~100 ulp over the error of any
+// libm) set FST_AMBIGUOUS, and the host then runs its own elimination for the whole call (five_stage_frames_host's first form).
+// Everything else the sweep needs is integer or correctly rounded fp32 arithmetic, the same on both sides.
+#pragma once
+
+constexpr int FST_RANKMAX = 512;        // up to here the order comes from a rank sort (one barrier), above from a bitonic network
+constexpr int FST_NMAX = 1024;           // positives of one frame the device sweep takes (more: FST_OVERFLOW, the host path runs)
+constexpr unsigned int FST_AMBIGUOUS = 1u, FST_OVERFLOW = 2u, FST_WIDE_ID = 4u;
+
+struct FstLayer {        // a non-empty window layer of the call (fd_window_to_detection)
+    double scale;
+    int32_t first, nx, bx, by, ow, oh;
+};
+struct FstTable {
+    int32_t n, sx, sy, nimg;
+    uint32_t perImage, magic;      // windows per frame; mulhi(id, magic) = id / perImage or one less (ids of a call fit 32 bits)
+    float oeDist, oeRatio;         // OverlapElimination(dist, ratio) with the constructor's clamping of ratio applied
+    double logA, logB;             // ProbabilisticWvmClassifier's logistic
+    FstLayer l[WVM_MAX_LAYERS];
+};
+struct FstKeep { uint32_t slot, wid; float fout; int32_t level; };   // a survivor: patch slot, window id inside its frame, WVM output
+struct FstFrame { uint32_t npos, nkeep, base, flags; };              // per frame: positives, survivors, where they start in the lists
+struct FstHdr { uint32_t keepTotal, done, svmCount, pad; };          // device counters of a handle
+struct FstIO {
+    const PosRec* pos;              // the cascade's positives (device memory), in no particular order
+    const unsigned int* posCount;   // their number (written by stage B's last workgroup)
+    unsigned int posCap;
+    FstHdr* hdr;
+    uint32_t* slots;                // [posCap] device: patch slots of the survivors, frame after frame in sweep order -> the SVM kernel
+    FstKeep* keep;                  // [posCap] pinned host memory: the same survivors for the host's result records
+    FstFrame* frames;               // [nimg] pinned host memory
+    uint32_t* hostHdr;              // pinned host memory: {survivors of the call, OR of the frames' flags}
+};
+
+namespace {
+
+// -DFD_FST_PROF (dev builds): s_memtime ticks of workgroup 0 at the phase boundaries of k_fs_oe
+#ifdef FD_FST_PROF
+__device__ unsigned long long fd_fst_prof[8];
+#define FST_T(i) if (threadIdx.x == 0 && blockIdx.x == 0) fd_fst_prof[i] = __builtin_amdgcn_s_memtime()
+#else
+#define FST_T(i)
+#endif
+
+__device__ __forceinline__ unsigned int fst_sortable(float x) {   // ascending with x (no NaNs reach this: outputs of finite sums)
+    const unsigned int b = __float_as_uint(x);
+    return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float fst_unsortable(unsigned int s) {
+    return __uint_as_float(s ^ ((s >> 31) ? 0x80000000u : 0xffffffffu));
+}
+
+__global__ __launch_bounds__(256) void k_fs_oe(FstTable T, FstIO io) {
+    __shared__ unsigned long long key[FST_NMAX];   // sort key << 32 | entry
+    __shared__ uint32_t eSlot[FST_NMAX], eWid[FST_NMAX], eFoutBits[FST_NMAX];   // eFoutBits is dead after the keys are built: sCx's storage
+    __shared__ FstLayer sL[WVM_MAX_LAYERS];   // the layer table (a per-thread index into the kernel arguments would spill them)
+    __shared__ int sCy[FST_NMAX];   // geometry in sorted order (sCx aliases eFoutBits)
+    __shared__ unsigned short sW[FST_NMAX], aIdx[FST_NMAX];   // patch width in sorted order; sorted positions of the accepted elements
+    __shared__ int aCx[FST_NMAX], aCy[FST_NMAX];              // the accepted elements' geometry, packed in acceptance order
+    __shared__ unsigned short aW[FST_NMAX];
+    __shared__ unsigned int deadPart[4][64];                   // sweep: candidate c is overlapped by an accepted element (per wavefront)
+    __shared__ unsigned short rowPart[4][64];                  // sweep: which of the candidates 16 q .. 16 q + 15 candidate c overlaps
+    __shared__ unsigned int cnt, flags, nkeepS, baseS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned int frame = blockIdx.x;
+    int* sCx = reinterpret_cast<int*>(eFoutBits);
+    if (tid == 0) { cnt = 0; flags = 0; nkeepS = 0; baseS = 0; }
+    for (int l = 0; l < T.n; ++l)   // uniform index: scalar loads
+        if (tid == 0) sL[l] = T.l[l];
+    __syncthreads();
+    FST_T(0);
+    // ---- 1. this frame's positives
+    const unsigned int npos = min(*io.posCount, io.posCap);
+    for (unsigned int i = tid; i < npos; i += 256) {
+        const PosRec r = io.pos[i];
+        if (r.wid_hi) { atomicOr(&flags, FST_WIDE_ID); continue; }
+        unsigned int f = T.nimg > 1 ? __umulhi(r.wid_lo, T.magic) : 0u;
+        unsigned int local = r.wid_lo - f * T.perImage;
+        if (T.nimg > 1 && local >= T.perImage) { local -= T.perImage; ++f; }
+        if (f != frame) continue;
+        const unsigned int e = atomicAdd(&cnt, 1u);
+        if (e < (unsigned int)FST_NMAX) { eSlot[e] = i; eWid[e] = local; eFoutBits[e] = __float_as_uint(r.fout); }
+    }
+    __syncthreads();
+    const unsigned int n = cnt;
+    unsigned int fl = flags;
+    if (n > (unsigned int)FST_NMAX) fl |= FST_OVERFLOW;
+    if (!(T.logB < 0.0 || T.logB > 0.0) || !(fabs(T.logB) < 1e300) || !(fabs(T.logA) < 1e300)) fl |= FST_AMBIGUOUS;
+    unsigned int nkeep = 0;
+    if (fl == 0 && n > 0) {
+        FST_T(1);
+        // ---- 2. sort by probability, descending: descending output for B < 0 (p falls with A + B x), ascending for B > 0
+        unsigned int npad = 64;
+        while (npad < n) npad <<= 1;
+        const bool desc = T.logB < 0.0;
+        for (unsigned int i = tid; i < npad; i += 256) {
+            unsigned long long k = ~0ull;
+            if (i < n) {
+                const unsigned int s = fst_sortable(__uint_as_float(eFoutBits[i]));
+                k = ((unsigned long long)(desc ? ~s : s) << 32) | i;
+            }
+            key[i] = k;
+        }
+        __syncthreads();
+        if (n <= (unsigned int)FST_RANKMAX) {
+            // small frames (the usual case): every thread ranks its key against all others (broadcast reads, one barrier) -- the keys
+            // are pairwise different (entry number in the low word), so the ranks are a permutation
+            unsigned long long mine[FST_RANKMAX / 256];
+            unsigned int rank[FST_RANKMAX / 256];
+#pragma unroll
+            for (int q = 0; q < FST_RANKMAX / 256; ++q) { mine[q] = tid + 256 * q < (int)n ? key[tid + 256 * q] : ~0ull; rank[q] = 0; }
+            for (unsigned int j = 0; j < n; ++j) {
+                const unsigned long long kj = key[j];
+#pragma unroll
+                for (int q = 0; q < FST_RANKMAX / 256; ++q) rank[q] += kj < mine[q] ? 1u : 0u;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < FST_RANKMAX / 256; ++q)
+                if (tid + 256 * q < (int)n) key[rank[q]] = mine[q];
+            __syncthreads();
+        } else {
+            for (unsigned int k = 2; k <= npad; k <<= 1)
+                for (unsigned int j = k >> 1; j > 0; j >>= 1) {
+                    for (unsigned int i = tid; i < npad; i += 256) {
+                        const unsigned int x = i ^ j;
+                        if (x > i) {
+                            const unsigned long long a = key[i], b = key[x];
+                            if ((a > b) == ((i & k) == 0)) { key[i] = b; key[x] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+        }
+        FST_T(2);
+        // ---- 3. geometry in sorted order (fd_window_to_detection), and the proof that the order is the reference's
+        unsigned int amb = 0;
+        for (unsigned int i = tid; i < n; i += 256) {
+            const unsigned int e = (unsigned int)key[i];
+            const unsigned int wid = eWid[e];
+            int li = 0;
+            for (int l = 1; l < T.n; ++l) li += wid >= (unsigned int)sL[l].first ? 1 : 0;
+            const FstLayer L = sL[li];
+            const unsigned int local = wid - (unsigned int)L.first;
+            const unsigned int iy = local / (unsigned int)L.nx, ix = local - iy * (unsigned int)L.nx;
+            const int lx = L.bx + (int)ix * T.sx, ly = L.by + (int)iy * T.sy;
+            const int cxv = (int)rint((double)lx / L.scale) + L.ow / 2;   // written behind the barrier: sCx is the keys' source array
+            sCy[i] = (int)rint((double)ly / L.scale) + L.oh / 2;
+            sW[i] = (unsigned short)L.ow;
+            if (L.ow > 65535) amb = 1;
+            if (i + 1 < n) {
+                const unsigned int e2 = (unsigned int)key[i + 1];
+                const float x1 = fst_unsortable(desc ? ~(unsigned int)(key[i] >> 32) : (unsigned int)(key[i] >> 32));
+                const float x2 = fst_unsortable(desc ? ~(unsigned int)(key[i + 1] >> 32) : (unsigned int)(key[i + 1] >> 32));
+                (void)e2;
+                if ((unsigned int)(key[i] >> 32) == (unsigned int)(key[i + 1] >> 32)) amb = 1;   // equal outputs: a tie of the reference's sort
+                const double t1 = T.logA + T.logB * (double)x1, t2 = T.logA + T.logB * (double)x2;
+                const double ex = exp(t1 < t2 ? t1 : t2);   // the smaller e of the pair: where 1 + e resolves least
+                const double gap = ex / (1.0 + ex) * fabs(T.logB) * fabs((double)x1 - (double)x2);
+                if (!(gap > 1e-14)) amb = 1;
+            }
+            sCx[i] = cxv;   // entry i of eFoutBits: only this thread's key was built from it, and the keys are complete
+        }
+        if (amb) atomicOr(&flags, FST_AMBIGUOUS);
+        __syncthreads();
+        fl |= flags;
+        FST_T(3);
+        // ---- 4. the greedy sweep (OverlapElimination.cpp:60-100: an element survives iff no earlier survivor overlaps it), 64
+        //         candidates at a time.  All pair tests are data parallel: A) the chunk against the survivors so far, thread = (candidate,
+        //         every fourth survivor); M) the chunk's own 64 x 64 overlap matrix, thread = (candidate, 16 others) -> one 64-bit row
+        //         per candidate in the first wavefront's registers.  What is sequential -- the first candidate still alive survives and
+        //         kills the later ones it overlaps -- is then a loop over mask words: find-first-set, two v_readlane, an and-not.
+        if (fl == 0) {
+            const float dist = T.oeDist, ratio = T.oeRatio;
+            const bool scaled = dist <= 1.0f;
+            auto overlaps = [&](int acx, int acy, int aw, int pcx, int pcy, int pw) {
+                const int wmax = max(aw, pw), wmin = min(aw, pw);
+                const float d = scaled ? dist * (float)wmax : dist;
+                // (float)min / (float)max > ratio; for ratio == 0 that is min > 0 (a quotient of positive integers is positive)
+                const bool r = ratio == 0.0f ? wmin > 0 : ((float)wmin / (float)wmax) > ratio;
+                return ((float)abs(acx - pcx) < d) && ((float)abs(acy - pcy) < d) && r;
+            };
+            // the usual parameters (an absolute distance, no size ratio: dist > 1, ratio == 0 -- FaceFrontal.cfg's 5 / 0) make the test two
+            // integer window checks: |dx| < d for an integer |dx| is |dx| < ceil(d), and min(w) / max(w) > 0 always holds
+            const bool simple = !scaled && ratio == 0.0f && dist > 1.0f && dist < 1e6f;
+            const int dI = simple ? (int)ceilf(dist) : 0;
+            auto near = [&](int acx, int acy, int pcx, int pcy) {   // |dx| < dI && |dy| < dI
+                return (unsigned int)(acx - pcx + dI - 1) < (unsigned int)(2 * dI - 1) && (unsigned int)(acy - pcy + dI - 1) < (unsigned int)(2 * dI - 1);
+            };
+            unsigned int na = 0;   // survivors so far (the same in every thread)
+            for (unsigned int i0 = 0; i0 < n; i0 += 64) {
+                const unsigned int i = i0 + lane;
+                const bool valid = i < n;
+                const int pcx = valid ? sCx[i] : 0, pcy = valid ? sCy[i] : 0, pw = valid ? (int)sW[i] : 1;
+                // A: against the survivors wave, wave + 4, ... (four at a time: their reads are in flight together)
+                bool dead = false;
+                if (simple) {
+                    for (unsigned int a0 = wave; a0 < na; a0 += 16) {
+                        int ax[4], ay[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const unsigned int a = min(a0 + 4u * u, na - 1); ax[u] = aCx[a]; ay[u] = aCy[a]; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) dead |= (a0 + 4u * u < na) && near(ax[u], ay[u], pcx, pcy);
+                    }
+                } else {
+                    for (unsigned int a = wave; a < na; a += 4)
+                        if (overlaps(aCx[a], aCy[a], (int)aW[a], pcx, pcy, pw)) dead = true;
+                }
+                deadPart[wave][lane] = dead ? 1u : 0u;
+                // M: against the candidates 16 wave .. 16 wave + 15 of the chunk (bit b: candidate 16 wave + b)
+                unsigned int bits = 0;
+                if (simple) {
+#pragma unroll
+                    for (int b0 = 0; b0 < 16; b0 += 8) {
+                        int ox[8], oy[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { const unsigned int o = min(i0 + 16u * wave + b0 + u, n - 1); ox[u] = sCx[o]; oy[u] = sCy[o]; }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (i0 + 16u * wave + b0 + u < n && near(ox[u], oy[u], pcx, pcy)) bits |= 1u << (b0 + u);
+                    }
+                } else {
+#pragma unroll 4
+                    for (int b = 0; b < 16; ++b) {
+                        const unsigned int o = i0 + 16u * wave + b;
+                        if (o < n && overlaps(sCx[o], sCy[o], (int)sW[o], pcx, pcy, pw)) bits |= 1u << b;
+                    }
+                }
+                rowPart[wave][lane] = (unsigned short)bits;
+                __syncthreads();
+                unsigned long long acc = 0;   // the chunk's survivors
+                if (wave == 0) {
+                    const bool alive = valid && !(deadPart[0][lane] | deadPart[1][lane] | deadPart[2][lane] | deadPart[3][lane]);
+                    const unsigned int rlo = (unsigned int)rowPart[0][lane] | ((unsigned int)rowPart[1][lane] << 16);
+                    const unsigned int rhi = (unsigned int)rowPart[2][lane] | ((unsigned int)rowPart[3][lane] << 16);
+                    unsigned long long m = __ballot(alive);
+                    while (m) {
+                        const int c = __builtin_ctzll(m);   // the first candidate still alive: it survives
+                        const unsigned long long row = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)rhi, c) << 32) |
+                                                       (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)rlo, c);
+                        acc |= 1ull << c;
+                        m &= ~(row | (1ull << c));   // (row has bit c set: an element overlaps itself)
+                    }
+                    // the survivors' geometry, packed in order behind the earlier ones
+                    if ((acc >> lane) & 1ull) {
+                        const unsigned int r = na + (unsigned int)__popcll(acc & ((1ull << lane) - 1ull));
+                        aIdx[r] = (unsigned short)i; aCx[r] = pcx; aCy[r] = pcy; aW[r] = (unsigned short)pw;
+                    }
+                    if (lane == 0) nkeepS = na + (unsigned int)__popcll(acc);
+                }
+                __syncthreads();
+                na = nkeepS;
+            }
+        }
+        __syncthreads();
+        nkeep = fl == 0 ? nkeepS : 0u;
+    }
+    FST_T(4);
+    // ---- 5. survivors -> the SVM's slot list (device) and the host's records, in sweep order
+    if (tid == 0) baseS = nkeep ? atomicAdd(&io.hdr->keepTotal, nkeep) : 0u;
+    __syncthreads();
+    const unsigned int base = baseS;
+    for (unsigned int j = tid; j < nkeep; j += 256) {
+        const unsigned int e = (unsigned int)key[aIdx[j]];
+        const unsigned int slot = eSlot[e];
+        if (base + j < io.posCap) {
+            io.slots[base + j] = slot;
+            io.keep[base + j] = FstKeep{slot, eWid[e], io.pos[slot].fout, io.pos[slot].level};
+        }
+    }
+    if (tid == 0) io.frames[frame] = FstFrame{n, nkeep, base, fl};
+    FST_T(5);
+    // ---- 6. the last workgroup publishes the call's totals and leaves the counters clean for the next run
+    __syncthreads();
+    if (tid == 0) {
+        if (fl) atomicOr(&io.hdr->pad, fl);
+        const unsigned int done = atomicAdd(&io.hdr->done, 1u);
+        if (done == gridDim.x - 1) {
+            const unsigned int total = __hip_atomic_load(&io.hdr->keepTotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int anyFlags = __hip_atomic_load(&io.hdr->pad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&io.hdr->svmCount, anyFlags ? 0u : total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by the SVM launch behind this kernel
+            io.hostHdr[0] = total;
+            io.hostHdr[1] = anyFlags;
+            __hip_atomic_store(&io.hdr->keepTotal, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&io.hdr->pad, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&io.hdr->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    FST_T(6);
+}
+
+}  // namespace

@@ -272,8 +272,15 @@ typedef int svm_v16i __attribute__((ext_vector_type(16)));
 // it: every tile of 32 support vectors leaves one partial sum per patch, and the partials are added in a fixed pairwise order.
 template <int SU_W>
 __global__ __launch_bounds__(64 * SU_W) void k_svm_u8_rbf_mfma(SvmDev m, const void* __restrict__ features, const uint32_t* __restrict__ idx,
-                                                               int64_t feat_stride_bytes, int64_t n, double* __restrict__ out) {
+                                                               int64_t feat_stride_bytes, int64_t n, double* __restrict__ out,
+                                                               const unsigned int* __restrict__ dcount) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (dcount) {   // the number of vectors is on the device (five-stage tail: survivors of the overlap elimination kernel in front);
+                    // the launch was sized for n, workgroups past the count have nothing to do
+        const int64_t dn = (int64_t)*dcount;
+        n = dn < n ? dn : n;
+        if ((int64_t)blockIdx.x * 32 >= n) return;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int KS = m.KS, DS = KS * 32 + 16;   // row stride: an odd number of 16-byte slots (conflict-free ds_read_b128 across the rows)
@@ -686,8 +693,8 @@ void fd_svm_generic_launch_on(hipStream_t st, const fd_svm* m, const void* dfeat
         // take whole CUs away from the kernels of other calls: config 3 (30 cascades in flight) fell from 5.5 to 3.9 G patches/s.  Hence
         // only on request (FD_SVM_WAVES=16), never by default.
         static const bool wide = [] { const char* e = getenv("FD_SVM_WAVES"); return e && atoi(e) == 16; }();
-        if (wide && grid < 256u) hipLaunchKernelGGL(k_svm_u8_rbf_mfma<16>, dim3(grid), dim3(64 * 16), lb, st, m->dev, dfeat, didx, stride_bytes, n, dout);
-        else hipLaunchKernelGGL(k_svm_u8_rbf_mfma<8>, dim3(grid), dim3(64 * 8), lb, st, m->dev, dfeat, didx, stride_bytes, n, dout);
+        if (wide && grid < 256u) hipLaunchKernelGGL(k_svm_u8_rbf_mfma<16>, dim3(grid), dim3(64 * 16), lb, st, m->dev, dfeat, didx, stride_bytes, n, dout, (const unsigned int*)nullptr);
+        else hipLaunchKernelGGL(k_svm_u8_rbf_mfma<8>, dim3(grid), dim3(64 * 8), lb, st, m->dev, dfeat, didx, stride_bytes, n, dout, (const unsigned int*)nullptr);
         HIP_CHECK(hipGetLastError());
         return;
     }
@@ -708,6 +715,21 @@ void fd_svm_generic_launch_on(hipStream_t st, const fd_svm* m, const void* dfeat
     const size_t ldsBytes = m->dev.dtype == FD_DTYPE_U8 ? (size_t)m->dev.dpad : (size_t)m->dev.dim * 4;
     if (ldsBytes > 64 * 1024) FD_THROW(FD_ERR_INVALID_ARGUMENT, "feature vector too long (%d)", m->dev.dim);
     hipLaunchKernelGGL(k_svm_generic, dim3((unsigned)n), dim3(256), ldsBytes, st, m->dev, dfeat, didx, stride_bytes, dout);
+    HIP_CHECK(hipGetLastError());
+}
+
+// The u8 RBF stage with the vector count on the device (the five-stage tail: overlap elimination and this launch are queued behind the
+// cascade without a host round trip).  The launch covers nmax vectors; min(*dcount, nmax) are scored.  false: this model has no
+// k_svm_u8_rbf_mfma tables (the caller keeps the host-driven path).
+bool fd_svm_u8_mfma_available(const fd_svm* m) {
+    const size_t lb = (size_t)32 * (m->dev.KS * 32 + 16) + 384 + sizeof(double) * (size_t)(m->dev.nsv32 >> 5) * 32;
+    return m->dev.dtype == FD_DTYPE_U8 && m->dev.kernel == FD_KERNEL_RBF && m->dev.svA && lb <= 64 * 1024;
+}
+void fd_svm_u8_mfma_launch_counted(hipStream_t st, const fd_svm* m, const void* dfeat, const uint32_t* didx, int64_t stride_bytes, int64_t nmax,
+                                   const unsigned int* dcount, double* dout) {
+    if (nmax <= 0) return;
+    const size_t lb = (size_t)32 * (m->dev.KS * 32 + 16) + 384 + sizeof(double) * (size_t)(m->dev.nsv32 >> 5) * 32;
+    hipLaunchKernelGGL(k_svm_u8_rbf_mfma<8>, dim3((unsigned)((nmax + 31) / 32)), dim3(64 * 8), lb, st, m->dev, dfeat, didx, stride_bytes, nmax, dout, dcount);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -34,6 +34,9 @@ float fd_svm_threshold(const fd_svm* m);
 double fd_svm_probability(const fd_svm* m, double d);
 void fd_svm_generic_launch(fd_ctx* ctx, const fd_svm* m, const void* dfeat, const uint32_t* didx, int64_t stride_bytes, int64_t n, double* dout);
 void fd_svm_generic_launch_on(hipStream_t st, const fd_svm* m, const void* dfeat, const uint32_t* didx, int64_t stride_bytes, int64_t n, double* dout);
+bool fd_svm_u8_mfma_available(const fd_svm* m);
+void fd_svm_u8_mfma_launch_counted(hipStream_t st, const fd_svm* m, const void* dfeat, const uint32_t* didx, int64_t stride_bytes, int64_t nmax,
+                                   const unsigned int* dcount, double* dout);
 
 constexpr int WVM_MAX_LAYERS = 64;
 constexpr int WVM_MAX_DIM = 32;      // patch width/height limit of this kernel
@@ -192,6 +195,15 @@ struct fd_wvm {
     int sbPlanN = 0, sbPlanCut[WVB_MAXPHASE] = {};   // cuts of the run in flight
     int64_t sbGrown = 0;             // capacity a queue overflow made the handle grow to
     std::shared_ptr<void> relaunch;   // WvbRelaunch: what fd_wvm_finish needs to run stage B again with a larger state (queue overflow)
+    // five-stage tail on the device (fs_tail.hpp): overlap elimination + SVM queued behind the cascade
+    bool tailWanted = false;         // set by the five-stage entry points before the launch
+    bool tailRun = false;            // the run in flight keeps its positives on the device and is followed by k_fs_oe
+    DevBuf fstHdr, fstSlots;         // FstHdr + the positive count stage B leaves; the SVM's slot list
+    HostBuf h_fst;                   // pinned: [hostHdr 16 B | FstFrame x frames | FstKeep x pos_cap | double x pos_cap]
+    int64_t fstLaunched = 0;         // vectors the SVM launch of the run in flight covers
+    int64_t fstPrevKeep = -1;        // survivors of the previous run (sizes the next SVM launch)
+    int fstFrames = 0;
+    int fstLastState = -1;           // measurement / test hook: -1 no device tail in the last run, else the flags it ended with (0: its results were used)
     ~fd_wvm() { if (done) (void)hipEventDestroy(done); if (tailDone) (void)hipEventDestroy(tailDone); if (prep) (void)hipEventDestroy(prep); }
 };
 
@@ -429,6 +441,9 @@ struct CascadeOut {
     // only after that event (fd_wvm_finish): its release is what makes the kernel's stores visible, the kernels themselves do not fence
     unsigned int* host_count = nullptr;
     unsigned int* done_blocks = nullptr;
+    // five-stage tail on the device (fs_tail.hpp): `pos` stays in device memory, and stage B's last workgroup leaves the positive
+    // count here for the overlap-elimination kernel queued behind it (the header's own counter is cleared for the next run)
+    unsigned int* tail_count = nullptr;
 };
 
 struct WvbRelaunch {   // see fd_wvm::relaunch
@@ -1806,6 +1821,7 @@ void launch_cascade(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* mh, cons
 }  // namespace
 
 #include "wvm_dense.hpp"
+#include "fs_tail.hpp"
 
 // ---- host side ---------------------------------------------------------------------------------
 
@@ -2232,6 +2248,10 @@ static bool wvm_launch_head(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const WinTab
     run.pos.clear();
     run.slots.clear();
     run.timed = time_kernel;
+    const bool tailWanted = m->tailWanted;
+    m->tailWanted = false;
+    m->tailRun = false;
+    m->fstLastState = -1;
     if (wt.total == 0) return false;
     if (want_all) {
         m->all_level.reserve(sizeof(int32_t) * (size_t)wt.total);
@@ -2255,6 +2275,7 @@ static bool wvm_launch_head(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const WinTab
     static const bool zcOff = [] { const char* e = getenv("FD_WVM_ZEROCOPY"); return e && atoi(e) == 0; }();
     const bool zc = !zcOff && !want_all && m->dev.numUsed > WVM_LCAP;
     m->zcRun = zc;
+    m->tailRun = tailWanted && zc && m->wvbOk && wt.total < ((int64_t)1 << 32);   // decided per run; the caller queues the tail kernels iff it is set
     L.zc = zc;
     L.headerMemset = !(zc && m->hdrClean);
     if (L.headerMemset) HIP_CHECK(hipMemsetAsync(m->pos.p, 0, sizeof(PosRec), st));
@@ -2267,7 +2288,14 @@ static bool wvm_launch_head(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const WinTab
     CascadeOut& o = L.o;
     o.all_level = want_all ? m->all_level.as<int32_t>() : nullptr;
     o.all_fout = want_all ? m->all_fout.as<float>() : nullptr;
-    o.pos = (zc ? m->h_pos.as<PosRec>() : m->pos.as<PosRec>()) + 1;   // pinned host memory is device-accessible under the same address
+    o.pos = ((zc && !m->tailRun) ? m->h_pos.as<PosRec>() : m->pos.as<PosRec>()) + 1;   // pinned host memory is device-accessible under the same address
+    if (m->tailRun) {
+        if (!m->fstHdr.p) {
+            m->fstHdr.reserve(64);
+            HIP_CHECK(hipMemsetAsync(m->fstHdr.p, 0, 64, st));
+        }
+        o.tail_count = m->fstHdr.as<unsigned int>() + 8;   // behind the FstHdr words
+    }
     o.pos_patches = m->pos_patches.as<uint8_t>();
     o.pos_count = m->pos.as<unsigned int>();        // header word 0
     o.pos_cap = (unsigned int)m->pos_cap;
@@ -2327,6 +2355,25 @@ static void wvm_launch_table(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm*
     wvm_launch_tail(ctx, st, p, m, wt, wtq, L, skipA, time_kernel);
 }
 
+// what a finished run's header tells the handle about the next one (idempotent)
+static void wvm_finish_header(fd_wvm* m, const PosRec* hraw) {
+    if (m->zcRun) m->hdrClean = true;   // the last stage-B workgroup has cleared the device header
+    if (m->sbRun) {   // header word 1: windows queued for stage B; zero-copy runs also deliver the counts of phases 1 and 2
+        m->sbDeep = (int64_t)hraw[0].wid_hi;
+        if (m->zcRun) {
+            uint32_t c2;
+            std::memcpy(&c2, &hraw[0].fout, 4);
+            const int64_t c[3] = {m->sbDeep, (int64_t)(uint32_t)hraw[0].level, (int64_t)c2};
+            for (int j = 1; j <= m->sbPlanN && j <= 2; ++j) {
+                const int cut = m->sbPlanCut[j - 1];
+                m->sbCutAlive[cut] = c[j];
+                if (c[j - 1] > 0 && c[j] * 10 >= c[j - 1] * 7) m->sbCutMask &= ~(1u << cut);
+                else m->sbCutMask |= 1u << cut;
+            }
+        }
+    }
+}
+
 // Synchronous half: waits for m->done, fetches the remaining positives and sorts them into extraction order.
 void fd_wvm_finish(fd_ctx* ctx, fd_wvm* m, WvmRun& run) {
     if (run.total == 0) return;
@@ -2366,25 +2413,11 @@ void fd_wvm_finish(fd_ctx* ctx, fd_wvm* m, WvmRun& run) {
     }
     if ((int64_t)cnt > m->pos_cap)
         FD_THROW(FD_ERR_DEVICE_CAPACITY, "WVM produced %u positives, device buffer holds %lld (set FD_WVM_POS_CAP)", cnt, (long long)m->pos_cap);
-    if (m->zcRun) m->hdrClean = true;   // the last stage-B workgroup has cleared the device header
-    if (m->sbRun) {   // header word 1: windows queued for stage B; zero-copy runs also deliver the counts of phases 1 and 2
-        m->sbDeep = (int64_t)hraw[0].wid_hi;
-        if (m->zcRun) {
-            uint32_t c2;
-            std::memcpy(&c2, &hraw[0].fout, 4);
-            const int64_t c[3] = {m->sbDeep, (int64_t)(uint32_t)hraw[0].level, (int64_t)c2};
-            for (int j = 1; j <= m->sbPlanN && j <= 2; ++j) {
-                const int cut = m->sbPlanCut[j - 1];
-                m->sbCutAlive[cut] = c[j];
-                if (c[j - 1] > 0 && c[j] * 10 >= c[j - 1] * 7) m->sbCutMask &= ~(1u << cut);
-                else m->sbCutMask |= 1u << cut;
-            }
-        }
-    }
+    wvm_finish_header(m, hraw);
     if (m->sbRun && (int64_t)hraw[0].wid_hi > m->deepCap)   // header word 1: windows queued for stage B
         FD_THROW(FD_ERR_DEVICE_CAPACITY, "WVM stage B: %u windows queued, its state holds %lld (set FD_WVM_DEEP_CAP)", hraw[0].wid_hi, (long long)m->deepCap);
     if (cnt) {
-        const size_t firstChunk = m->zcRun ? (size_t)cnt : (size_t)std::min<int64_t>(m->pos_cap, WVM_FIRST_CHUNK);
+        const size_t firstChunk = m->tailRun ? (size_t)0 : (m->zcRun ? (size_t)cnt : (size_t)std::min<int64_t>(m->pos_cap, WVM_FIRST_CHUNK));
         if (cnt > firstChunk) {   // on the auxiliary stream: the main stream may already hold the next detectors' kernels
             hipStream_t ax = fd_aux_stream(ctx);
             HIP_CHECK(hipMemcpyAsync(hraw + 1 + firstChunk, m->pos.as<PosRec>() + 1 + firstChunk, sizeof(PosRec) * (cnt - firstChunk),
@@ -2809,6 +2842,116 @@ static void five_stage_check(const fd_wvm* m, const fd_svm* svm) {
         FD_THROW(FD_ERR_INVALID_ARGUMENT, "second classifier must work on the %d-byte HistEq64 patch", m->dev.d);
 }
 
+// ---- stages 2-3 on the device (fs_tail.hpp) ------------------------------------------------------------------------------------
+// Whether a five-stage run of (m, svm) can keep its tail on the device: the cascade ends in the dense stage B with its zero-copy
+// header, the second classifier has the u8 RBF MFMA kernel, and the window ids of the call fit 32 bits.  FD_FS_TAIL=0: never.
+static bool fst_possible(const fd_wvm* m, const fd_svm* svm) {
+    const char* e = getenv("FD_FS_TAIL");   // read per call: tests toggle it
+    const bool off = e && atoi(e) == 0;
+    return !off && m->wvbOk && m->dev.numUsed > WVM_LCAP && fd_svm_u8_mfma_available(svm);
+}
+static size_t fst_host_offsets(int nimg, int64_t cap, size_t& keepOff, size_t& distOff) {
+    keepOff = (16 + sizeof(FstFrame) * (size_t)nimg + 15) & ~(size_t)15;
+    distOff = (keepOff + sizeof(FstKeep) * (size_t)cap + 15) & ~(size_t)15;
+    return distOff + sizeof(double) * (size_t)cap;
+}
+// queues k_fs_oe and the SVM stage behind the cascade of `run` (m->tailRun is set) and records m->tailDone
+static void fst_launch(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm* m, const fd_svm* svm, const WvmRun& run, float oe_dist, float oe_ratio, int sx, int sy) {
+    const int nimg = p->nimg > 1 ? p->nimg : 1;
+    FstTable T;
+    std::memset(&T, 0, sizeof(T));
+    T.sx = sx; T.sy = sy; T.nimg = nimg;
+    const int64_t perImage = run.total / nimg;
+    T.perImage = (uint32_t)perImage;
+    T.magic = perImage > 0 ? (uint32_t)(0xffffffffu / (uint32_t)perImage) : 0u;
+    T.oeDist = oe_dist;
+    T.oeRatio = ((oe_ratio > 0.0f) && (oe_ratio <= 1.0f)) ? oe_ratio : 0.0f;   // OverlapElimination's constructor
+    T.logA = m->logisticA; T.logB = m->logisticB;
+    for (const WindowLayer& w : run.wls) {
+        if (w.nx == 0 || w.ny == 0) continue;
+        FstLayer& l = T.l[T.n++];
+        l.scale = p->all[p->kept[w.layer]].scale;
+        l.first = (int32_t)w.first; l.nx = w.nx; l.bx = w.bx; l.by = w.by; l.ow = w.ow; l.oh = w.oh;
+    }
+    size_t keepOff, distOff;
+    const size_t bytes = fst_host_offsets(nimg, m->pos_cap, keepOff, distOff);
+    m->h_fst.reserve(bytes);
+    m->fstSlots.reserve(sizeof(uint32_t) * (size_t)m->pos_cap);
+    m->fstFrames = nimg;
+    char* hb = m->h_fst.as<char>();
+    FstIO io;
+    io.pos = m->pos.as<PosRec>() + 1;
+    io.posCount = m->fstHdr.as<unsigned int>() + 8;
+    io.posCap = (unsigned int)m->pos_cap;
+    io.hdr = m->fstHdr.as<FstHdr>();
+    io.slots = m->fstSlots.as<uint32_t>();
+    io.hostHdr = reinterpret_cast<uint32_t*>(hb);
+    io.frames = reinterpret_cast<FstFrame*>(hb + 16);
+    io.keep = reinterpret_cast<FstKeep*>(hb + keepOff);
+    io.hostHdr[0] = 0xffffffffu;
+    hipLaunchKernelGGL(k_fs_oe, dim3((unsigned)nimg), dim3(256), 0, st, T, io);
+    HIP_CHECK(hipGetLastError());
+    // the SVM launch covers what the previous run kept, with a margin; a run that keeps more gets a second launch for the rest
+    int64_t nmax = m->fstPrevKeep >= 0 ? m->fstPrevKeep * 2 + 256 : std::max<int64_t>(1024, run.total / 256);
+    nmax = std::min<int64_t>(std::max<int64_t>(nmax, 256), m->pos_cap);
+    m->fstLaunched = nmax;
+    fd_svm_u8_mfma_launch_counted(st, svm, m->pos_patches.p, io.slots, (int64_t)m->dev.d, nmax, &io.hdr->svmCount, reinterpret_cast<double*>(hb + distOff));
+    if (!m->tailDone) HIP_CHECK(hipEventCreateWithFlags(&m->tailDone, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(m->tailDone, st));
+}
+// Waits for a tail run and hands out its survivors.  false: the device gave up (ambiguous order, too many positives in a frame,
+// stage-B queue overflow, ...): the caller runs the host stages (fd_wvm_finish + host elimination) on the same cascade results.
+struct FstResult {
+    const FstFrame* frames = nullptr;
+    const FstKeep* keep = nullptr;
+    const double* dist = nullptr;
+};
+static bool fst_collect(fd_ctx* ctx, fd_wvm* m, const fd_svm* svm, const WvmRun& run, FstResult& R) {
+    HIP_CHECK(hipEventSynchronize(m->tailDone));
+    const PosRec* hraw = m->h_pos.as<PosRec>();
+    const unsigned int cnt = hraw[0].wid_lo;
+    if (cnt == 0xffffffffu) FD_THROW(FD_ERR_HIP, "WVM stage B did not deliver its positive count");
+    if (run.timed) {
+        HIP_CHECK(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev0, ctx->ev1));
+        ctx->last_kernel = "k_wvm_cascade";
+    }
+    m->fstLastState = 0x100;
+    if ((int64_t)hraw[0].wid_hi > m->deepCap || (int64_t)cnt > m->pos_cap) return false;   // overflow: fd_wvm_finish grows / reports
+    char* hb = m->h_fst.as<char>();
+    const uint32_t* hh = reinterpret_cast<const uint32_t*>(hb);
+    if (hh[0] == 0xffffffffu) FD_THROW(FD_ERR_HIP, "five-stage tail did not deliver its survivor count");
+    m->fstLastState = (int)hh[1];
+    if (hh[1] != 0u) return false;
+    wvm_finish_header(m, hraw);
+    size_t keepOff, distOff;
+    fst_host_offsets(m->fstFrames, m->pos_cap, keepOff, distOff);
+    const int64_t total = (int64_t)hh[0];
+    if (total > m->fstLaunched) {   // more survivors than the SVM launch covered: score the rest now
+        const int64_t rest = total - m->fstLaunched;
+        fd_svm_generic_launch_on(ctx->stream, svm, m->pos_patches.p, m->fstSlots.as<uint32_t>() + m->fstLaunched, (int64_t)m->dev.d, rest,
+                                 reinterpret_cast<double*>(hb + distOff) + m->fstLaunched);
+        HIP_CHECK(hipEventRecord(m->tailDone, ctx->stream));
+        HIP_CHECK(hipEventSynchronize(m->tailDone));
+    }
+    m->fstPrevKeep = total;
+    R.frames = reinterpret_cast<const FstFrame*>(hb + 16);
+    R.keep = reinterpret_cast<const FstKeep*>(hb + keepOff);
+    R.dist = reinterpret_cast<const double*>(hb + distOff);
+    (void)run;
+    return true;
+}
+// a survivor record -> the detection the reference's ClassifiedPatch stands for
+static fd_detection fst_detection(const fd_pyramid* p, const fd_wvm* m, const WvmRun& run, int sx, int sy, const FstKeep& k) {
+    fd_detection d;
+    std::memset(&d, 0, sizeof(d));
+    fd_window_to_detection(p, run.wls, sx, sy, (int64_t)k.wid, d);
+    d.level = k.level;
+    d.positive = 1;
+    d.score = k.fout;
+    d.probability = wvm_probability(m, (double)k.fout);
+    return d;
+}
+
 // detection::FiveStageSlidingWindowDetector::detect, FiveStageSlidingWindowDetector.cpp:187-320 / :331-380
 int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const fd_svm* svm, float oe_dist, float oe_ratio,
                          int sx, int sy, const int* roi, fd_detection* out, int cap, int* count, int32_t* stage_counts) {
@@ -2817,9 +2960,33 @@ int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const f
         fd_pyramid_require_single(p, "fd_detect_five_stage");
         fd_wvm* m = const_cast<fd_wvm*>(wvm_);
         five_stage_check(m, svm);
-        // stage 1: WVM over all windows (SlidingWindowDetector::detect), positives in extraction order
+        // stage 1: WVM over all windows (SlidingWindowDetector::detect); stages 2-3 (overlap elimination, SVM) are queued behind it on
+        // the device where the model allows (fs_tail.hpp): one wait instead of two round trips
         WvmRun run;
-        fd_wvm_run(ctx, p, m, sx, sy, roi, false, run, ctx->kernel_timing);
+        m->tailWanted = fst_possible(m, svm);
+        fd_wvm_launch(ctx, p, m, sx, sy, roi, false, run, ctx->kernel_timing);
+        if (m->tailRun) {
+            fst_launch(ctx, ctx->stream, p, m, svm, run, oe_dist, oe_ratio, sx, sy);
+            FstResult R;
+            if (fst_collect(ctx, m, svm, run, R)) {
+                const FstFrame fr = R.frames[0];
+                std::vector<fd_detection> svmPos;
+                for (uint32_t j = 0; j < fr.nkeep; ++j) {
+                    const double dv = R.dist[fr.base + j];
+                    if (dv >= (double)fd_svm_threshold(svm)) {
+                        fd_detection d = fst_detection(p, m, run, sx, sy, R.keep[fr.base + j]);
+                        d.score = (float)dv;
+                        d.probability = 0.5;   // ClassifiedPatch(patch, bool) default probability (ClassifiedPatch.hpp:29-30)
+                        svmPos.push_back(d);
+                    }
+                }
+                if (stage_counts) { stage_counts[0] = (int)fr.npos; stage_counts[1] = (int)fr.nkeep; }
+                five_stage_nms(p, roi, svmPos, out, cap, count, stage_counts);
+                return;
+            }
+            run.timed = false;   // read above
+        }
+        fd_wvm_finish(ctx, m, run);
         five_stage_tail(ctx, p, m, svm, run, oe_dist, oe_ratio, sx, sy, roi, ctx->stream, out, cap, count, stage_counts);
     });
 }
@@ -2835,6 +3002,7 @@ struct fd_five_stage_frames {   // ticket of fd_detect_five_stage_frames_begin
     float oe_dist = 5.f, oe_ratio = 0.f;
     int sx = 1, sy = 1;
     bool has_roi = false;
+    bool tail = false;                            // overlap elimination + SVM were queued on the device (fs_tail.hpp)
     int roi[4] = {0, 0, 0, 0};
     WvmRun run;
     std::vector<std::vector<fd_detection>> res;   // per frame, after NMS
@@ -2852,13 +3020,39 @@ static void five_stage_frames_begin(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wv
     t.has_roi = roi != nullptr;
     if (roi) std::memcpy(t.roi, roi, sizeof(t.roi));
     five_stage_check(t.m, svm);
+    t.m->tailWanted = fst_possible(t.m, svm);
     fd_wvm_launch(ctx, p, t.m, sx, sy, roi, false, t.run, ctx->kernel_timing);   // one cascade run over the windows of all frames
+    t.tail = t.m->tailRun;
+    if (t.tail) fst_launch(ctx, ctx->stream, p, t.m, svm, t.run, oe_dist, oe_ratio, sx, sy);   // overlap elimination + SVM behind it, no host in between
 }
 
 // Host stages of a multi-frame run (everything behind the cascade kernels): per-frame results into the ticket.  Runs on the calling
 // thread (blocking entry point) or on a thread of fd_async_queue() (ticket entry points): touches the ticket, the handles the
 // ticket holds and the context's stream only.
+// FD_TRACE: where the host stages of the multi-frame calls spend their time (averages per call on stderr at process exit)
+struct FramesHostTrace {
+    const bool on = getenv("FD_TRACE") != nullptr;
+    std::atomic<int64_t> ns[6], calls{0};
+    FramesHostTrace() { for (auto& v : ns) v = 0; }
+    ~FramesHostTrace() {
+        const int64_t n = calls.load();
+        if (!on || n == 0) return;
+        static const char* name[6] = {"wait for the cascade + order positives", "positives -> detections", "overlap elimination", "SVM launch + wait", "NMS", "total"};
+        for (int i = 0; i < 6; ++i) fprintf(stderr, "[fd frames host] %-40s %9.1f us per call (%lld calls)\n", name[i], ns[i].load() / 1e3 / n, (long long)n);
+    }
+};
+static FramesHostTrace g_framesTrace;
+
 static void five_stage_frames_host(fd_ctx* ctx, fd_five_stage_frames& t) {
+    using clk = std::chrono::steady_clock;
+    const bool tr = g_framesTrace.on;
+    clk::time_point tp0 = tr ? clk::now() : clk::time_point(), tp = tp0;
+    auto lap = [&](int i) {
+        if (!tr) return;
+        const clk::time_point n = clk::now();
+        g_framesTrace.ns[i] += std::chrono::duration_cast<std::chrono::nanoseconds>(n - tp).count();
+        tp = n;
+    };
     fd_pyramid* p = t.p;
     fd_wvm* m = t.m;
     const fd_svm* svm = t.svm;
@@ -2867,10 +3061,42 @@ static void five_stage_frames_host(fd_ctx* ctx, fd_five_stage_frames& t) {
     const int NF = p->nimg;
     t.res.assign((size_t)NF, {});
     t.stages.assign((size_t)NF * 4, 0);
+    if (t.tail) {
+        FstResult R;
+        if (fst_collect(ctx, m, svm, run, R)) {   // the device did stages 2-3: per frame the SVM's verdicts, then the block NMS
+            lap(0);
+            for (int f = 0; f < NF; ++f) {
+                const FstFrame fr = R.frames[f];
+                t.stages[4 * (size_t)f] = (int)fr.npos;
+                t.stages[4 * (size_t)f + 1] = (int)fr.nkeep;
+                std::vector<fd_detection>& svmPos = t.res[(size_t)f];
+                for (uint32_t j = 0; j < fr.nkeep; ++j) {
+                    const double dv = R.dist[fr.base + j];
+                    if (dv >= (double)fd_svm_threshold(svm)) {
+                        fd_detection d = fst_detection(p, m, run, t.sx, t.sy, R.keep[fr.base + j]);
+                        d.score = (float)dv;
+                        d.probability = 0.5;   // ClassifiedPatch(patch, bool) default probability (ClassifiedPatch.hpp:29-30)
+                        svmPos.push_back(d);
+                    }
+                }
+                int cnt = 0;
+                five_stage_nms(p, roi, svmPos, nullptr, 0, &cnt, &t.stages[4 * (size_t)f]);
+            }
+            lap(4);
+            if (tr) {
+                g_framesTrace.ns[5] += std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - tp0).count();
+                ++g_framesTrace.calls;
+            }
+            return;
+        }
+        run.timed = false;   // fst_collect has read the kernel timing
+    }
     fd_wvm_finish(ctx, m, run);
+    lap(0);
     const int64_t perImage = NF > 0 ? run.total / NF : 0;
     std::vector<fd_detection> dets;
     fd_wvm_positives_to_detections(p, m, run, t.sx, t.sy, dets);   // sorted by window id = by frame, extraction order inside
+    lap(1);
     // frame boundaries, overlap elimination per frame, survivors of all frames -> one slot list
     std::vector<size_t> begin((size_t)NF + 1, dets.size());
     {
@@ -2895,6 +3121,7 @@ static void five_stage_frames_host(fd_ctx* ctx, fd_five_stage_frames& t) {
         t.stages[4 * (size_t)f + 1] = (int)keep[(size_t)f].size();
         for (int k : keep[(size_t)f]) slots.push_back(run.slots[b + (size_t)k]);
     }
+    lap(2);
     const double* dist = nullptr;
     if (!slots.empty()) {   // the SVM stage of all frames: the kernel reads the slot list from / writes the distances to pinned memory
         hipStream_t st = ctx->stream;
@@ -2908,6 +3135,7 @@ static void five_stage_frames_host(fd_ctx* ctx, fd_five_stage_frames& t) {
         HIP_CHECK(hipEventSynchronize(m->tailDone));   // only this call's SVM stage, not what the caller queued behind it
         dist = (const double*)(pin + distOff);
     }
+    lap(3);
     size_t si = 0;
     for (int f = 0; f < NF; ++f) {
         std::vector<fd_detection>& svmPos = t.res[(size_t)f];
@@ -2924,6 +3152,11 @@ static void five_stage_frames_host(fd_ctx* ctx, fd_five_stage_frames& t) {
         }
         int cnt = 0;
         five_stage_nms(p, roi, svmPos, nullptr, 0, &cnt, &t.stages[4 * (size_t)f]);   // svmPos becomes the frame's result
+    }
+    lap(4);
+    if (tr) {
+        g_framesTrace.ns[5] += std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - tp0).count();
+        ++g_framesTrace.calls;
     }
 }
 
@@ -3346,6 +3579,13 @@ int fd_debug_wvd_prof(unsigned long long* out, int nwaves) {
     if (out && nwaves > 0) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(fd_wvd_prof), sizeof(unsigned long long) * 8 * (size_t)nwaves);
     return WVD_PROF_WAVES;
 }
+#endif
+
+// Measurement hook (include/fd_hip_bench.h): windows the last finished run of this handle queued for stage B (-1: none yet)
+int64_t fd_wvm_last_queue_length(const fd_wvm* m) { return m ? m->sbDeep : -1; }
+int fd_wvm_last_tail_state(const fd_wvm* m) { return m ? m->fstLastState : -1; }
+#ifdef FD_FST_PROF
+int fd_debug_fst_prof(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(fd_fst_prof), 64) == hipSuccess ? 0 : -1; }
 #endif
 
 // Test hook (include/fd_hip_bench.h; needs no GPU): the pre-filter's plan -- K and the tile list -- for a set of layers

@@ -394,6 +394,7 @@ __device__ __forceinline__ void wvb_finalize(const CascadeOut& o, const WvbState
             __hip_atomic_store(o.host_count + 2, __hip_atomic_load(s.cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(o.host_count + 3, __hip_atomic_load(s.cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(o.host_count, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (o.tail_count) __hip_atomic_store(o.tail_count, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(o.pos_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(o.deep_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(o.deep_count + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -60,6 +60,47 @@ def make_frame(width=640, height=480, seed=20260927, channels=3):
     return out if channels == 3 else out[..., 0]
 
 
+def make_frames_varied(n, width=640, height=480, seed=20260927, scene_len=32, nbase=9):
+    """n distinct frames as a run of short 'scenes' (bench.py's headline content): smooth noise fields drifting like a camera pan,
+    per-frame fine noise, and 0..10 high-contrast blobs that move through the scene.  The busy-ness (blob count, fine-noise share,
+    contrast) is drawn per scene, so consecutive multi-frame calls hand the cascade different numbers of surviving windows.
+    Returns (list of HxWx3 uint8 frames, per-frame busy-ness in [0, 1])."""
+    rng = np.random.default_rng(seed)
+    bases = []
+    for i in range(nbase):
+        b = _blur(rng.random((height, width)), (4.0, 8.0, 14.0)[i % 3])
+        bases.append(((b - b.min()) / max(b.max() - b.min(), 1e-12)).astype(np.float32))
+    frames, busy = [], []
+    yy, xx = np.mgrid[0:160, 0:160].astype(np.float32)
+    while len(frames) < n:
+        b = float(rng.random())
+        nblob = int(round(b * 10))
+        fine = np.float32(0.05 + 0.35 * rng.random())
+        gain = np.float32(0.5 + 0.5 * rng.random())          # contrast of the smooth part
+        idx = rng.integers(0, nbase, 3)
+        vel = rng.integers(-3, 4, (3, 2))
+        blobs = [dict(s=int(rng.integers(48, 161)), y=float(rng.uniform(0, height - 161)), x=float(rng.uniform(0, width - 161)),
+                      vy=float(rng.uniform(-2, 2)), vx=float(rng.uniform(-2, 2)), fy=float(rng.uniform(4, 12)), fx=float(rng.uniform(4, 12)))
+                 for _ in range(nblob)]
+        for t in range(scene_len):
+            if len(frames) >= n:
+                break
+            img = np.empty((height, width, 3), np.float32)
+            noise = rng.random((height, width, 3), dtype=np.float32)
+            for c in range(3):
+                base = np.roll(bases[idx[c]], (int(vel[c, 0]) * t, int(vel[c, 1]) * t), axis=(0, 1))
+                img[..., c] = (np.float32(1) - fine) * (np.float32(0.5) + gain * (base - np.float32(0.5))) + fine * noise[..., c]
+            for bl in blobs:
+                s = bl["s"]
+                y0 = int(min(max(bl["y"] + bl["vy"] * t, 0), height - s - 1))
+                x0 = int(min(max(bl["x"] + bl["vx"] * t, 0), width - s - 1))
+                blob = 0.5 + 0.5 * np.sin(yy[:s, :s] / s * bl["fy"]) * np.cos(xx[:s, :s] / s * bl["fx"])
+                img[y0:y0 + s, x0:x0 + s, :] = 0.15 * img[y0:y0 + s, x0:x0 + s, :] + 0.85 * blob[..., None]
+            frames.append(np.clip(np.rint(img * 255), 0, 255).astype(np.uint8))
+            busy.append(b)
+    return frames, np.asarray(busy)
+
+
 def histeq64_np(patches):
     """Vectorised HistEq64 used only for threshold calibration / SV synthesis (not a parity reference)."""
     p = np.asarray(patches, np.uint8)

@@ -15,6 +15,15 @@ int fd_ctx_set_kernel_timing(fd_ctx* ctx, int enable);   /* enable == 2: WVM cas
 /* duration (ms) between those events for the last timed call on this context and the name of the bracketed kernel(s) */
 int fd_last_kernel_ms(fd_ctx* ctx, const char** kernel_name, float* ms);
 
+/* Windows the last finished cascade run of this handle handed to stage B (the pre-filter's queue; all frames of a multi-frame call
+ * together); -1 before the first run.  bench.py reports the spread over the calls of a run. */
+int64_t fd_wvm_last_queue_length(const fd_wvm* wvm);
+/* How the last finished five-stage run of this handle did its overlap elimination: -1 on the host (no device tail was queued), 0 on
+ * the device (csrc/fs_tail.hpp), > 0: the device kernel gave up and the host redid it -- 1 the order of the positives could not be
+ * proven to be the reference's (tied or saturated probabilities), 2 more positives in a frame than the kernel holds, 4 window ids
+ * beyond 32 bits, 0x100 stage-B queue / positive buffer overflow. */
+int fd_wvm_last_tail_state(const fd_wvm* wvm);
+
 /* Test hook, needs no GPU: the rect sums (WvmClassifier.cpp:277-306) of every used level of `md` for n equalised patches, computed
  * from the tables of the dense stage B with the operand addressing of its MFMA kernel.  out[i * ncols + c]: c runs over the levels
  * 0 .. numUsed - 1, grey values 1 .. cntval - 1 inside a level.  Returns ncols (out may be NULL), -1 when the model has no dense

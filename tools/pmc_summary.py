@@ -14,6 +14,12 @@ import sys
 
 workload, out, substr, note = sys.argv[1:5]
 dirs = sys.argv[5:]
+subs = substr.split(",")   # kernels matching ANY are listed; the k_all(...) aggregate covers those matching the FIRST
+substr = subs[0]
+
+
+def wanted(k):
+    return any(x in k for x in subs)
 
 
 def short(name):
@@ -26,7 +32,7 @@ for d in dirs:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if substr not in k:
+            if not wanted(k):
                 continue
             a = acc.setdefault(short(k), {}).setdefault(r["Counter_Name"], [0.0, 0])
             a[0] += float(r["Counter_Value"])
@@ -35,7 +41,7 @@ for d in dirs:
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if substr not in k:
+            if not wanted(k):
                 continue
             a = acc.setdefault(short(k), {}).setdefault("_dur_ns", [0.0, 0])
             a[0] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
@@ -63,20 +69,28 @@ for k, cs in acc.items():
                    ("SQ_ACTIVE_INST_ANY", "active_inst_any_quadcycles"), ("SQ_VALU_MFMA_BUSY_CYCLES", "mfma_busy_cycles")):
         if c in rec:
             o[key] = rec[c]
+    if rec.get("GRBM_GUI_ACTIVE") and "SQ_INSTS_VALU" in rec:
+        o["valu_issue_frac"] = 4.0 * rec["SQ_INSTS_VALU"] / (128.0 * rec["GRBM_GUI_ACTIVE"])
+    if rec.get("SQ_LDS_IDX_ACTIVE"):
+        o["lds_bank_conflict_frac"] = rec.get("SQ_LDS_BANK_CONFLICT", 0.0) / rec["SQ_LDS_IDX_ACTIVE"]
     kernels[k] = o
 # workload aggregate over the matched kernels: per-"frame" figures = sum over kernels of (per-launch value x launches) / launches of the
 # most frequent kernel would be ambiguous, so the aggregate is the plain sum of per-launch averages (one launch of each kernel)
 agg = {}
-for o in kernels.values():
+for kn, o in kernels.items():
+    if substr not in kn:
+        continue
     for key, v in o.items():
-        if key != "launches":
+        if key not in ("launches", "valu_issue_frac", "lds_bank_conflict_frac"):
             agg[key] = agg.get(key, 0.0) + v
 agg["kernel_ms"] = agg.pop("kernel_ms_profiled", None)
 # time-weighted totals over ALL launches of the matched kernels (counter passes serialise the dispatches): the fraction of the
 # VALU issue slots that were used while these kernels ran = 4 cycles x SQ_INSTS_VALU / (128 SIMDs per XCD x GRBM_GUI_ACTIVE summed
 # over the 8 XCDs), and the same for LDS instructions per cycle
 tot, cnt = {}, {}
-for cs in acc.values():
+for kn, cs in acc.items():
+    if substr not in kn:
+        continue
     for c, (sv, n) in cs.items():
         tot[c] = tot.get(c, 0.0) + sv
         cnt[c] = cnt.get(c, 0) + n
