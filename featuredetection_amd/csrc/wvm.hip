@@ -1953,14 +1953,18 @@ static bool wvb_tables(const fd_wvm_model* md, int NU, WvbTables& T) {
     T.A.clear();
     std::vector<int> cover((size_t)d);
     int ntile = 0;
+    for (int k = 0; k < NU; ++k) T.maxCnt = std::max(T.maxCnt, md->val_off[k + 1] - md->val_off[k]);
+    // Fixed slots: every level takes 7 rows of its tile (15 when a filter has more than 8 grey values), unused rows stay zero -- generation g
+    // of a class is slot g % 4 (g % 2) of the class's tile g / 4 (g / 2), so k_wvb_chain2 addresses a level's rect sums with constants
+    // (they stay in the accumulator registers).  The operand table grows by the padding (7 rows for a 6-value filter); it stays in L2.
+    const int RPL = T.maxCnt <= 8 ? 7 : 15;
     for (int n = 0; n < NP; ++n) {
         int cur = -1, rowc = 32;
         for (int g = 0; g < G; ++g) {
             const int k = g * NP + n;
             if (k >= NU) break;
             const int v0 = md->val_off[k], cntval = md->val_off[k + 1] - v0;
-            const int rows = cntval - 1;
-            T.maxCnt = std::max(T.maxCnt, cntval);
+            const int rows = RPL;
             // a tile may hold levels of two phases: a phase then evaluates the whole tile and uses its own rows (the contraction is cheap)
             if (cur < 0 || rowc + rows > 32) {
                 cur = ntile++;

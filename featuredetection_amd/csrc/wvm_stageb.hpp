@@ -267,6 +267,189 @@ __global__ __launch_bounds__(256, 2) void k_wvb_chain(WvbDev mv, WvbState s, int
     WVB_FLUSH;
 }
 
+// k_wvb_chain2 (round 4): the same unit -- one wavefront per (64 windows, class), four classes per workgroup -- on the fixed-slot
+// tables (wvb_tables: generation g of a class = slot g % LPT of the class's tile g / LPT, RPL rows per slot).  The rect sums of a tile
+// never leave the registers: v_permlane32_swap turns the two accumulators (rows x windows 0..31 / 32..63) into "every lane holds the
+// 32 rows of ITS window", and a level's rows are compile-time register names.  No 32 KB of staging per workgroup, no LDS round trip
+// per grey value, no selects for the unused values (their rows and constants are zero: exact +0 terms); the level records of the next
+// tile are requested while the current one is contracted.  17 KB of LDS less per wavefront pair and ~half the registers: four
+// workgroups per CU instead of two.  Bit-identical to k_wvb_chain (same operations in the same order).
+// RING: operand fragments in flight per wavefront.  16 when a tile has 16 k-steps (patches of up to 512 pixels): the whole next tile is
+// requested while the current tile's levels are chained, so the contraction never waits for L2 (8: two L2 round trips per tile, 3 us
+// of a 4 us tile).  Two workgroups per CU: with a third (168 registers) the exp temporaries spilled and a level took 1 us instead of 0.27.
+template <int MAXV, int RING>
+__global__ __launch_bounds__(256, 2) void k_wvb_chain2(WvbDev mv, WvbState s, int phase, const unsigned int* countPtr) {
+    constexpr int RPL = MAXV <= 8 ? 7 : 15;   // rows per level slot
+    constexpr int LPT = 32 / RPL;             // level slots per tile: 4 or 2
+    extern __shared__ __attribute__((aligned(16))) unsigned char wvb_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned int n = wvb_count(countPtr, s);
+    const int ntiles = (int)((n + 63u) >> 6);
+    const int NP = mv.numPer, NU = mv.numUsed, KS = mv.KS, KSP = mv.KSP, DS = mv.dstride;
+    const int NQ = (NP + 3) >> 2;
+    const int set = phase & 1;
+    const int g0 = mv.phaseGen[phase], g1 = mv.phaseGen[phase + 1];
+    int* Rw = reinterpret_cast<int*>(wvb_lds + 64 * DS) + wave * (2 * LPT * WVB_REC_DW);   // two sets of LPT level records
+    const int cpr = DS >> 4;   // 16-byte slots per row
+    WVB_DECL(8 * phase);
+    for (int unit = blockIdx.x; unit < ntiles * NQ; unit += gridDim.x) {
+        const int t = unit / NQ, cq = unit - t * NQ;   // neighbouring workgroups share the window tile (L2)
+        WVB_T(tq0);
+        __syncthreads();   // the previous unit's MFMA operand reads are done
+        {
+            const uint4* xg = reinterpret_cast<const uint4*>(s.X[set] + (size_t)t * 64 * DS);
+            const int live = (int)min(64u, n - (unsigned int)t * 64u) * cpr;   // slots of the tile's real windows (rows are contiguous)
+            for (int c0 = threadIdx.x; c0 < 64 * cpr; c0 += 8 * 256) {
+                uint4 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = c0 + i * 256;
+                    v[i] = make_uint4(0, 0, 0, 0);
+                    if (c < live) v[i] = xg[c];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = c0 + i * 256;
+                    if (c < 64 * cpr) reinterpret_cast<uint4*>(wvb_lds)[c] = v[i];
+                }
+            }
+        }
+        const int cls = cq * 4 + wave;
+        const unsigned int pos = (unsigned int)t * 64u + (unsigned int)lane;
+        const bool valid = pos < n;
+        float u = 0.f;
+        int sx_total = 0;
+        float sxx = 0.f;
+        if (cls < NP && valid) {
+            const int2 ax = s.aux[set][pos];
+            sx_total = ax.x;
+            sxx = __int_as_float(ax.y);
+            if (phase > 0) u = s.U[set][((size_t)t * NP + cls) * 64 + lane];
+            if (cls == 0) s.exitKey[pos] = ~0ull;   // k_wvb_sums of this phase takes the minimum over the failed levels
+        }
+        // level records of a tile of the class: slot j = generation T * LPT + j (one dword per lane each); past the class's last level
+        // the last level again (never used)
+        const int gLast = cls < NP ? (NU - 1 - cls) / NP : 0;   // last generation of this class
+        auto loadRecs = [&](int T, int (&rv)[LPT]) {
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) rv[j] = mv.rec[(size_t)(min(T * LPT + j, gLast) * NP + min(cls, NP - 1)) * WVB_REC_DW + lane];
+        };
+        auto storeRecs = [&](int T, const int (&rv)[LPT]) {
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) Rw[((T & 1) * LPT + j) * WVB_REC_DW + lane] = rv[j];
+        };
+        __syncthreads();
+        WVB_T(tq1);
+        WVB_ADD(8 * phase + 0, 1);
+        WVB_ADD(8 * phase + 1, tq1 - tq0);
+        if (cls < NP && g0 <= gLast) {
+            const int T0 = g0 / LPT, T1 = min(g1 - 1, gLast) / LPT;
+            int rv[LPT];
+            loadRecs(T0, rv);
+            storeRecs(T0, rv);
+            wave_sync();
+            wvb_v4i an[RING];
+            {
+                const int tile0 = __builtin_amdgcn_readfirstlane(Rw[((T0 & 1) * LPT + (g0 - T0 * LPT)) * WVB_REC_DW]);   // tile of the phase's first level
+                const wvb_v4i* Ap = mv.A + (size_t)tile0 * KSP * 64 + lane;
+#pragma unroll
+                for (int q = 0; q < RING; ++q) an[q] = Ap[q * 64];
+            }
+            for (int T = T0; T <= T1; ++T) {
+                const int* Rt = Rw + (T & 1) * LPT * WVB_REC_DW;
+                const int jFirst = T == T0 ? g0 - T0 * LPT : 0;
+                const int tile = __builtin_amdgcn_readfirstlane(Rt[jFirst * WVB_REC_DW]);
+                WVB_T(tq2);
+                if (T < T1) loadRecs(T + 1, rv);   // in flight during the contraction
+                // ---- rect sums of the tile's 32 rows for the 64 windows: C[row][window] = sum_pixel M[row][pixel] * x[window][pixel].  The
+                // operand fragments stream from L2 through a ring of eight that runs one group ahead and wraps into the class's next tile
+                const wvb_v4i* Ap = mv.A + (size_t)tile * KSP * 64 + lane;
+                wvb_v16i acc0 = {}, acc1 = {};
+                const unsigned char* xb = wvb_lds + (lane & 31) * DS + (lane >> 5) * 16;
+                for (int ks = 0; ks < KSP; ks += RING) {
+#pragma unroll
+                    for (int q = 0; q < RING; ++q) {
+                        const wvb_v4i a = an[q];
+                        an[q] = Ap[(ks + RING + q) * 64];   // past this tile: the next tile's fragments (a zero tile ends the table)
+                        if (ks + q < KS) {
+                            const wvb_v4i b0 = *reinterpret_cast<const wvb_v4i*>(xb + (ks + q) * 32);
+                            const wvb_v4i b1 = *reinterpret_cast<const wvb_v4i*>(xb + 32 * DS + (ks + q) * 32);
+                            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b0, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1, acc1, 0, 0, 0);
+                        }
+                    }
+                }
+                // acc0[r] / acc1[r]: row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of windows lane & 31 / 32 + (lane & 31).  After the swap every
+                // lane holds the rows of window `lane`: row R = (R & 4) ? acc1[i] : acc0[i], i = (R & 3) + 4 (R >> 3)
+                int a0[16], a1[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap((unsigned int)acc0[r], (unsigned int)acc1[r], false, false);
+                    a0[r] = (int)sw[0]; a1[r] = (int)sw[1];
+                }
+                WVB_T(tq3);
+                WVB_ADD(8 * phase + 3, tq3 - tq2);
+                // ---- the tile's levels.  Everything up to the u_kernel_eval dependency is independent between them
+                double part[LPT], ppv[LPT];
+#pragma unroll
+                for (int j = 0; j < LPT; ++j) {
+                    const int* rc = Rt + j * WVB_REC_DW;
+                    const double* valL = reinterpret_cast<const double*>(rc + 8);
+                    // the reference's sums in its order (WvmClassifier.cpp:277-309); grey values the filter does not have add an exact +0
+                    double sum_xp = 0.0;
+                    int sumv0 = sx_total;
+#pragma unroll
+                    for (int v = 1; v < MAXV; ++v) {
+                        constexpr int dummy = 0; (void)dummy;
+                        const int R = RPL * j + v - 1;
+                        const int i = (R & 3) + 4 * (R >> 3);
+                        const int sv = ((R & 4) ? a1[i] : a0[i]) + rc[40 + v];
+                        sumv0 -= sv;
+                        const double prod = (double)sv * valL[v];
+                        sum_xp = sum_xp + prod;
+                    }
+                    const double t0 = (double)sumv0 * valL[0];
+                    part[j] = sum_xp + t0;
+                    ppv[j] = *reinterpret_cast<const double*>(rc + 4);
+                }
+                // ---- the serial part: u_kernel_eval of the class from level to level (WvmClassifier.cpp:310-316)
+                double arg[LPT];
+                bool act[LPT];
+#pragma unroll
+                for (int j = 0; j < LPT; ++j) {
+                    const int g = T * LPT + j;
+                    act[j] = g >= g0 && g < g1 && g <= gLast;
+                    double sum_xp = part[j] + (double)u;
+                    if (act[j]) u = (float)sum_xp;
+                    double norm = (double)sxx;
+                    norm = norm - 2 * sum_xp;
+                    norm = norm + ppv[j];
+                    arg[j] = (double)mv.negBasis * norm;
+                }
+                // ---- the kernel values: independent again
+#pragma unroll
+                for (int j = 0; j < LPT; ++j) {
+                    const float Kk = (float)exp(arg[j]);
+                    if (act[j] && valid) s.K[set][((size_t)t * NU + (T * LPT + j) * NP + cls) * 64 + lane] = Kk;
+                }
+                WVB_T(tq4);
+                WVB_ADD(8 * phase + 4, tq4 - tq3);
+                WVB_ADD(8 * phase + 6, LPT);
+                wave_sync();   // this tile's record reads are done before the set is overwritten two tiles on
+                if (T < T1) storeRecs(T + 1, rv);
+                wave_sync();
+                WVB_T(tq5);
+                WVB_ADD(8 * phase + 2, tq5 - tq4);
+            }
+            if (valid && phase + 1 < mv.nphase) s.U[set][((size_t)t * NP + cls) * 64 + lane] = u;
+        }
+        WVB_T(tq7);
+        WVB_ADD(8 * phase + 5, tq7 - tq0);
+    }
+    WVB_FLUSH;
+}
+
 // res_k = -bias + sum_{p <= k} w[k][p] K_p for the rows of the phase and the cascade's exit rule on them (WvmClassifier.cpp:139-141).
 // A workgroup takes one block of 8 consecutive rows for four tiles of 64 windows (one per wavefront, lane == window): the block's
 // weights are staged in LDS once and read as broadcasts, every K_p load (256 B, coalesced) feeds 8 multiply-adds; the terms keep the
@@ -576,12 +759,15 @@ static void launch_stageb(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* m,
     const int64_t ub = std::min<int64_t>(total, s.cap);   // upper bound of the windows in any phase
     if (ub <= 0) return;
     const int cus = ctx->num_cus;
-    const int ldsBytes = 64 * mv.dstride + 4 * (32 * 64 + WVB_RECS * WVB_REC_DW) * (int)sizeof(int);
+    static const bool chainOld = [] { const char* e = getenv("FD_WVB_CHAIN"); return e && !std::strcmp(e, "old"); }();
+    const int lpt = mv.maxCnt <= 8 ? 4 : 2;
+    const int ldsBytes = chainOld ? 64 * mv.dstride + 4 * (32 * 64 + WVB_RECS * WVB_REC_DW) * (int)sizeof(int)
+                                  : 64 * mv.dstride + 4 * (2 * lpt * WVB_REC_DW) * (int)sizeof(int);
     static uint64_t ldsDone8 = 0, ldsDone16 = 0;
     const bool v8 = mv.maxCnt <= 8;
     if (v8) fd_allow_lds(ctx, (const void*)k_wvb_chain<8>, 160 * 1024, ldsDone8);
     else fd_allow_lds(ctx, (const void*)k_wvb_chain<WVM_MAX_VALS>, 160 * 1024, ldsDone16);
-    const int perCuC = std::max(1, std::min(8, (160 * 1024) / ldsBytes));
+    const int perCuC = chainOld ? std::max(1, std::min(8, (160 * 1024) / ldsBytes)) : 2;
     auto expect = [&](int ph) {   // windows expected at the start of phase ph, with a margin
         int64_t pred = ph == 0 ? m->sbDeep : m->sbCutAlive[m->sbPlanCut[ph - 1]];
         if (pred < 0) pred = m->sbDeep;
@@ -615,8 +801,16 @@ static void launch_stageb(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* m,
         const int nrb = (k1 - k0 + 7) / 8;
         const int64_t tiles = (expect(ph) + 63) / 64;
         const int gridC = (int)std::min<int64_t>(tiles * NQ, (int64_t)cus * perCuC);
-        if (v8) hipLaunchKernelGGL(k_wvb_chain<8>, dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
-        else hipLaunchKernelGGL(k_wvb_chain<WVM_MAX_VALS>, dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
+        if (chainOld) {
+            if (v8) hipLaunchKernelGGL(k_wvb_chain<8>, dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
+            else hipLaunchKernelGGL(k_wvb_chain<WVM_MAX_VALS>, dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
+        } else {
+            const bool r16 = mv.KSP == 16;
+            if (v8 && r16) hipLaunchKernelGGL((k_wvb_chain2<8, 16>), dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
+            else if (v8) hipLaunchKernelGGL((k_wvb_chain2<8, 8>), dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
+            else if (r16) hipLaunchKernelGGL((k_wvb_chain2<WVM_MAX_VALS, 16>), dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
+            else hipLaunchKernelGGL((k_wvb_chain2<WVM_MAX_VALS, 8>), dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
+        }
         const int gridH = (int)std::min<int64_t>((tiles + 3) / 4 * nrb, (int64_t)cus * 8);
         hipLaunchKernelGGL(k_wvb_sums, dim3(gridH), dim3(256), 0, st, mv, s, ph, countPtr);
         const int gridE = (int)std::min<int64_t>(tiles, (int64_t)cus * 4);
