@@ -547,7 +547,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     const unsigned int perImage = (unsigned int)wt.per_image;                          // the launcher checks that all ids fit 32 bits
     const unsigned int magicPI = wt.nimg > 1 ? (unsigned int)(0xffffffffu / perImage) : 0u;   // mulhi(id, magic) = id / perImage or one less
     const unsigned int n = wvb_count(qcount, s);
-    for (unsigned int tile = blockIdx.x * 4 + wave; tile * 64 < n; tile += gridDim.x * 4) {
+    const WvbXcd X((int)((n + 63u) >> 6));   // tile -> XCD like the kernels that read this state (wvm_stageb.hpp)
+    for (int lt = X.wg * 4 + wave; lt < X.ntl; lt += X.nwg * 4) {
+        const unsigned int tile = (unsigned int)X.tile(lt);
         const unsigned int pos = tile * 64 + lane;
         const bool valid = pos < n;
         const int64_t wid = q[valid ? pos : n - 1];

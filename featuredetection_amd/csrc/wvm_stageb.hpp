@@ -47,6 +47,24 @@ __device__ __forceinline__ unsigned int wvb_count(const unsigned int* countPtr, 
     return (int64_t)c > s.cap ? (unsigned int)s.cap : c;
 }
 
+// Tiles of 64 queued windows stay on one XCD through the kernels of a phase: tile t belongs to XCD t % 8, and workgroup b runs on XCD
+// b % 8 (the observed dispatch order; only speed depends on it).  The eight L2s are not coherent with each other, so state written
+// on one XCD and read on another comes back from memory (1-2 us per dependent round trip instead of an L2 hit): k_wvb_sums spent
+// 23 us per unit mostly waiting for the K rows k_wvb_chain had written elsewhere.  Grids that are not a multiple of 8 fall back to
+// the plain enumeration.
+struct WvbXcd {
+    int xcd, wg, nwg, ntl;
+    bool on;
+    __device__ __forceinline__ WvbXcd(int ntiles) {
+        on = (gridDim.x & 7u) == 0u;
+        xcd = on ? (int)(blockIdx.x & 7u) : 0;
+        wg = on ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+        nwg = on ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+        ntl = on ? max(0, (ntiles - xcd + 7) >> 3) : ntiles;   // tiles of this XCD
+    }
+    __device__ __forceinline__ int tile(int local) const { return on ? xcd + 8 * local : local; }
+};
+
 // the same with lane == window, for the patch sizes of the dense pre-filter (wvm_dense.hpp)
 template <int PW_, int PH_>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_wvb_prepare_lanes(const uint8_t* __restrict__ arena, WinTable wt, float stretch,
@@ -67,7 +85,10 @@ __global__ __launch_bounds__(256) void k_wvb_prepare(const uint8_t* __restrict__
         __syncthreads();
     }
     const unsigned int n = wvb_count(qcount, s);
-    for (unsigned int pos = blockIdx.x * 4 + wave; pos < n; pos += gridDim.x * 4) {
+    const WvbXcd X((int)((n + 63u) >> 6));
+    for (int lp = X.wg * 4 + wave; lp < X.ntl * 64; lp += X.nwg * 4) {
+        const unsigned int pos = (unsigned int)X.tile(lp >> 6) * 64u + (unsigned int)(lp & 63);
+        if (pos >= n) continue;   // (no workgroup barrier inside the loop)
         const int64_t wid = q[pos];
         int srcStride;
         const uint8_t* src = wvm_locate<RAW>(arena, wt, sFirst, wid, lane, g.pw, g.d, srcStride);
@@ -114,8 +135,10 @@ __global__ __launch_bounds__(256, 2) void k_wvb_chain(WvbDev mv, WvbState s, int
     int* Rw = reinterpret_cast<int*>(wvb_lds + 64 * DS) + 4 * (32 * 64) + wave * (WVB_RECS * WVB_REC_DW);
     const int cpr = DS >> 4;   // 16-byte slots per row
     WVB_DECL(8 * phase);
-    for (int unit = blockIdx.x; unit < ntiles * NQ; unit += gridDim.x) {
-        const int t = unit / NQ, cq = unit - t * NQ;   // neighbouring workgroups share the window tile (L2)
+    const WvbXcd X(ntiles);
+    for (int unit = X.wg; unit < X.ntl * NQ; unit += X.nwg) {
+        const int tl = unit / NQ, cq = unit - tl * NQ;   // neighbouring workgroups share the window tile (L2)
+        const int t = X.tile(tl);
         WVB_T(tq0);
         __syncthreads();   // the previous unit's MFMA operand reads are done
         {
@@ -293,8 +316,10 @@ __global__ __launch_bounds__(256, 2) void k_wvb_chain2(WvbDev mv, WvbState s, in
     int* Rw = reinterpret_cast<int*>(wvb_lds + 64 * DS) + wave * (2 * LPT * WVB_REC_DW);   // two sets of LPT level records
     const int cpr = DS >> 4;   // 16-byte slots per row
     WVB_DECL(8 * phase);
-    for (int unit = blockIdx.x; unit < ntiles * NQ; unit += gridDim.x) {
-        const int t = unit / NQ, cq = unit - t * NQ;   // neighbouring workgroups share the window tile (L2)
+    const WvbXcd X(ntiles);
+    for (int unit = X.wg; unit < X.ntl * NQ; unit += X.nwg) {
+        const int tl = unit / NQ, cq = unit - tl * NQ;   // neighbouring workgroups share the window tile (L2)
+        const int t = X.tile(tl);
         WVB_T(tq0);
         __syncthreads();   // the previous unit's MFMA operand reads are done
         {
@@ -461,14 +486,15 @@ __global__ __launch_bounds__(256) void k_wvb_sums(WvbDev mv, WvbState s, int pha
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned int n = wvb_count(countPtr, s);
     const int ntiles = (int)((n + 63u) >> 6);
-    const int nquads = (ntiles + 3) >> 2;
+    const WvbXcd X(ntiles);
+    const int nquads = (X.ntl + 3) >> 2;
     const int NU = mv.numUsed, Fr = mv.Fr;
     const int k0 = min(mv.phaseGen[phase] * mv.numPer, NU), k1 = min(mv.phaseGen[phase + 1] * mv.numPer, NU);
     const int nrb = (k1 - k0 + 7) >> 3;
     const int set = phase & 1;
     constexpr size_t ks = 64;   // K[tile][level][64 windows]: a tile's history is one contiguous block
     WVB_DECL(24 + 4 * phase);
-    for (int unit = blockIdx.x; unit < nquads * nrb; unit += gridDim.x) {
+    for (int unit = X.wg; unit < nquads * nrb; unit += X.nwg) {
         const int rb = nrb - 1 - unit / nquads, q = unit - (unit / nquads) * nquads;   // the longest rows first
         const int kb = k0 + rb * 8;
         const int kend = min(kb + 8, k1);   // terms p < kend
@@ -479,8 +505,8 @@ __global__ __launch_bounds__(256) void k_wvb_sums(WvbDev mv, WvbState s, int pha
         WVB_T(ts1);
         WVB_ADD(24 + 4 * phase + 0, 1);
         WVB_ADD(24 + 4 * phase + 1, ts1 - ts0);
-        const int t = q * 4 + wave;
-        if (t >= ntiles) continue;   // no barrier below this line
+        if (q * 4 + wave >= X.ntl) continue;   // no barrier below this line
+        const int t = X.tile(q * 4 + wave);
         const unsigned int pos = (unsigned int)t * 64u + (unsigned int)lane;
         const bool valid = pos < n;
         const float* Kp = s.K[set] + (size_t)t * NU * 64 + lane;
@@ -604,7 +630,9 @@ __global__ __launch_bounds__(256) void k_wvb_exit(WvbDev mv, WvbState s, Cascade
     const int cpr = DS >> 4;
     WVB_DECL(36 + 8 * phase);
     WVB_T(te00);
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const WvbXcd X(ntiles);
+    for (int tl = X.wg; tl < X.ntl; tl += X.nwg) {
+        const int t = X.tile(tl);
         WVB_T(te0);
         const unsigned int pos = (unsigned int)t * 64u + (unsigned int)lane;
         const bool valid = pos < n;
@@ -737,6 +765,7 @@ __global__ __launch_bounds__(256) void k_wvb_exit(WvbDev mv, WvbState s, Cascade
 // queues stage B on `st` behind whatever filled the queue (o.deep_q / o.deep_count).  Grids: the kernels are grid-stride loops over
 // device-side counts, correct for any grid; workgroups without work are not free though (2048 idle workgroups delayed the loads of
 // the 148 working ones by 15 us), so the grids follow the counts of the handle's previous run (m->sbPred) with a margin.
+static int wvb_grid8(int64_t g) { return (int)std::max<int64_t>(8, (g + 7) / 8 * 8); }   // a multiple of the 8 XCDs (WvbXcd)
 template <int PW_, int PH_, bool RAW>
 static void launch_stageb(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* m, const uint8_t* arena, const WinTable& wt, const CascadeOut& o) {
     // The plan of this run: the model's phase cuts (tile breaks of the tables) that are still worth a compaction.  A cut whose
@@ -784,13 +813,13 @@ static void launch_stageb(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* m,
         bool lanes = false;
         if constexpr (!RAW && PW_ != 0) {
             if (lanesFrom > 0 && e >= lanesFrom && !wt.list && wt.total < ((int64_t)1 << 32) && (mv.dstride & 3) == 0) {
-                const int gridL = (int)std::min<int64_t>((e + 255) / 256, (int64_t)cus * 3);
+                const int gridL = wvb_grid8(std::min<int64_t>((e + 255) / 256, (int64_t)cus * 3));
                 hipLaunchKernelGGL((k_wvb_prepare_lanes<PW_, PH_>), dim3(gridL), dim3(256), 0, st, arena, wt, m->dev.stretch, mv, s, o.deep_q, o.deep_count);
                 lanes = true;
             }
         }
         if (!lanes) {
-            const int gridP = (int)std::min<int64_t>((e + 3) / 4, (int64_t)cus * 8);
+            const int gridP = wvb_grid8(std::min<int64_t>((e + 3) / 4, (int64_t)cus * 8));
             hipLaunchKernelGGL((k_wvb_prepare<PW_, PH_, RAW>), dim3(gridP), dim3(256), 0, st, arena, wt, m->dev, mv, s, o.deep_q, o.deep_count);
         }
     }
@@ -800,7 +829,7 @@ static void launch_stageb(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* m,
         const int k0 = std::min(mv.phaseGen[ph] * mv.numPer, mv.numUsed), k1 = std::min(mv.phaseGen[ph + 1] * mv.numPer, mv.numUsed);
         const int nrb = (k1 - k0 + 7) / 8;
         const int64_t tiles = (expect(ph) + 63) / 64;
-        const int gridC = (int)std::min<int64_t>(tiles * NQ, (int64_t)cus * perCuC);
+        const int gridC = wvb_grid8(std::min<int64_t>(tiles * NQ, (int64_t)cus * perCuC));
         if (chainOld) {
             if (v8) hipLaunchKernelGGL(k_wvb_chain<8>, dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
             else hipLaunchKernelGGL(k_wvb_chain<WVM_MAX_VALS>, dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
@@ -811,9 +840,9 @@ static void launch_stageb(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* m,
             else if (r16) hipLaunchKernelGGL((k_wvb_chain2<WVM_MAX_VALS, 16>), dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
             else hipLaunchKernelGGL((k_wvb_chain2<WVM_MAX_VALS, 8>), dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
         }
-        const int gridH = (int)std::min<int64_t>((tiles + 3) / 4 * nrb, (int64_t)cus * 8);
+        const int gridH = wvb_grid8(std::min<int64_t>((tiles + 3) / 4 * nrb, (int64_t)cus * 8));
         hipLaunchKernelGGL(k_wvb_sums, dim3(gridH), dim3(256), 0, st, mv, s, ph, countPtr);
-        const int gridE = (int)std::min<int64_t>(tiles, (int64_t)cus * 4);
+        const int gridE = wvb_grid8(std::min<int64_t>(tiles, (int64_t)cus * 4));
         hipLaunchKernelGGL(k_wvb_exit, dim3(gridE), dim3(256), 0, st, mv, s, o, ph, countPtr, s.cnt + ph + 1);
     }
 }
