@@ -866,7 +866,9 @@ def measure(wl, env, steps, warmup, gather_every, want_cpu):
             local = np.concatenate(recs) if recs else np.zeros((0, parallel.RECORD_FIELDS))
             ndet += len(local)
             if world > 1:
-                allr, tr = parallel.gather_records(local, recs_cap, device=dev)
+                # the product's gather: fd_dist_gather_records = ONE ncclAllGather (librccl) of the padded record buffers on the
+                # context's stream (csrc/dist.hip); parallel.gather_records is its torch.distributed twin, used by the CPU tests
+                allr, tr = env.dist.gather(local, recs_cap)
                 gathered += len(allr)
                 truncated |= tr
             pending = []
@@ -946,12 +948,31 @@ def main():
     env.world = int(os.environ.get("WORLD_SIZE", "1"))
     env.rank = int(os.environ.get("RANK", "0"))
     env.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # smoke tests of the N > 1 path on a one-GPU box: every rank on device 0, torch.distributed over gloo, and the librccl
+    # stand-in for fd_dist_* (FD_DIST_ONE_DEVICE=1 FD_BENCH_DIST_BACKEND=gloo FD_RCCL_LIB=tests/stub_rccl/librccl_stub.so)
+    one_device = os.environ.get("FD_DIST_ONE_DEVICE", "0") == "1"
+    if one_device:
+        env.local_rank = 0
     if env.world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", env.local_rank))
+        # N ranks share one host: at most 8 host threads per rank (this thread + the library's queue threads + its batch workers)
+        os.environ.setdefault("FD_ASYNC_THREADS", "2")
+        os.environ.setdefault("FD_BATCH_THREADS", "4")
+        os.environ.setdefault("FD_BENCH_SDM_THREADS", "1")
+        backend = os.environ.get("FD_BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", env.local_rank))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(env.local_rank)
     env.dev = torch.device("cuda", env.local_rank)
     env.ctx = capi.Context(env.local_rank, torch.cuda.current_stream().cuda_stream)
+    env.dist = None
+    if env.world > 1:
+        # fd_dist_*: rank 0 makes the communicator id (ncclGetUniqueId of librccl), torch.distributed only carries its 128 bytes
+        uid = [capi.Dist.unique_id() if env.rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        env.dist = capi.Dist(env.ctx, env.rank, env.world, uid[0])
 
     def build(name, headline):
         kw = {}
@@ -995,6 +1016,7 @@ def main():
             res["summary"] = summ
         print(json.dumps(res))
     if env.world > 1:
+        env.dist.close()
         dist.destroy_process_group()
 
 

@@ -111,6 +111,7 @@ HIST_HOG, HIST_SPATIAL, HIST_PYRAMID_HOG, HIST_SPATIAL_PYRAMID = 0, 1, 2, 3
 
 _SIGS = {
     "fd_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "fd_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "fd_ctx_destroy": (None, [C.c_void_p]),
     "fd_last_error": (C.c_char_p, [C.c_void_p]),
     "fd_ctx_synchronize": (C.c_int, [C.c_void_p]),
@@ -471,6 +472,14 @@ class Dist:
         if self.h:
             lib().fd_dist_destroy(self.h)
             self.h = C.c_void_p()
+
+
+def dist_gather_count(dist, local, cap):
+    """fd_dist_gather_records with all == NULL: runs the collective and returns the number of records waiting in the handle"""
+    local = np.ascontiguousarray(local, np.float64).reshape(-1, 8)
+    n, tr = C.c_int64(), C.c_int()
+    dist.ctx.check(lib().fd_dist_gather_records(dist.h, _ptr(local), len(local), cap, None, 0, C.byref(n), C.byref(tr)))
+    return int(n.value)
 
 
 def wvd_plan(nx, ny, frames, sy, ph, slots):

@@ -13,6 +13,14 @@ extern "C" {
 
 const char* fd_version(void) { return "fd_hip 0.1 (gfx950)"; }
 
+int fd_device_count(int* n) {
+    if (!n) return FD_ERR_INVALID_ARGUMENT;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) { *n = 0; return FD_ERR_HIP; }
+    *n = c;
+    return FD_OK;
+}
+
 int fd_ctx_create(int device_id, void* hip_stream, fd_ctx** out) {
     if (!out) return FD_ERR_INVALID_ARGUMENT;
     *out = nullptr;

@@ -13,6 +13,9 @@
 #include <algorithm>
 #include <cstring>
 #include <numeric>
+#include <string>
+#include <vector>
+#include <mutex>
 #include <rccl/rccl.h>
 
 namespace {
@@ -28,11 +31,17 @@ struct Rccl {
 
 Rccl& rccl() {
     static Rccl r;
+    static std::string loadError;   // dlerror() text of the one attempt (dlerror returns NULL once it has been read)
     static std::once_flag once;
     std::call_once(once, [] {
-        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-        for (const char* n : names)
+        // FD_RCCL_LIB: another library with the same five entry points (tests/stub_rccl: ranks of one GPU meeting in shared memory)
+        const char* env = getenv("FD_RCCL_LIB");
+        const char* names[] = {env && *env ? env : "librccl.so", "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* n : names) {
             if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+            if (const char* e = dlerror()) { if (loadError.empty()) loadError = e; }
+            if (env && *env) break;   // an explicit library that does not load is an error, not a reason to take another one
+        }
         if (!r.lib) return;
         r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
         r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
@@ -41,7 +50,7 @@ Rccl& rccl() {
         r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
     });
     if (!r.lib || !r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy)
-        FD_THROW(FD_ERR_RUNTIME, "librccl.so is not available: %s", r.lib ? "missing symbols" : dlerror());
+        FD_THROW(FD_ERR_RUNTIME, "librccl.so is not available: %s", r.lib ? "missing symbols" : (loadError.empty() ? "not found" : loadError.c_str()));
     return r;
 }
 
@@ -59,6 +68,10 @@ struct fd_dist {
     ncclComm_t comm = nullptr;
     DevBuf dsend, drecv;
     HostBuf hsend, hrecv;
+    // result of the last collective, kept until it has been delivered: a caller whose `all` was too small (FD_ERR_CAPACITY) calls again
+    // with a larger buffer and gets THESE records -- no second ncclAllGather that only some ranks would enter
+    std::vector<fd_record> pending;
+    bool havePending = false, pendingTrunc = false;
 };
 
 static_assert(sizeof(fd_record) == 64, "fd_record is eight doubles");
@@ -121,47 +134,60 @@ int fd_dist_gather_records(fd_dist* d, const fd_record* local, int n_local, int 
     return fd_guard(d ? d->ctx : nullptr, [&] {
         if (!d || n_local < 0 || cap_per_rank < 1 || (n_local > 0 && !local) || !n_all) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_dist_gather_records: bad argument");
         const int W = d->world;
-        const size_t rows = (size_t)cap_per_rank + 1, bytes = rows * sizeof(fd_record);
-        const int n = std::min(n_local, cap_per_rank);
-        d->hsend.reserve(bytes);
-        d->hrecv.reserve(bytes * (size_t)W);
-        fd_record* hs = d->hsend.as<fd_record>();
-        std::memset(hs, 0, sizeof(fd_record));
-        hs[0].image = (double)n_local;   // row 0: how many records this rank had (more than cap: the receivers flag the truncation)
-        if (n) std::memcpy(hs + 1, local, sizeof(fd_record) * (size_t)n);
-        const fd_record* hr = hs;
-        const size_t used = sizeof(fd_record) * ((size_t)n + 1);
-        if (W > 1) {
-            HIP_CHECK(hipSetDevice(d->ctx->device));
-            hipStream_t st = d->ctx->stream;
-            d->dsend.reserve(bytes);
-            d->drecv.reserve(bytes * (size_t)W);
-            // only the used prefix travels over PCIe; the collective moves the fixed-stride buffers (every rank the same size)
-            HIP_CHECK(hipMemcpyAsync(d->dsend.p, hs, used, hipMemcpyHostToDevice, st));
-            RCCL_CHECK(rccl().AllGather(d->dsend.p, d->drecv.p, bytes, ncclUint8, d->comm, st));
-            HIP_CHECK(hipMemcpyAsync(d->hrecv.p, d->drecv.p, bytes * (size_t)W, hipMemcpyDeviceToHost, st));
-            HIP_CHECK(hipStreamSynchronize(st));
-            hr = d->hrecv.as<fd_record>();
+        if (!d->havePending) {
+            // The collective.  EVERY rank must make this call, with the SAME cap_per_rank (the fixed-stride buffers of all ranks have
+            // one size; fd_hip.h).  It runs once per set of records: what it delivered stays in the handle until a call takes it.
+            const size_t rows = (size_t)cap_per_rank + 1, bytes = rows * sizeof(fd_record);
+            const int n = std::min(n_local, cap_per_rank);
+            d->hsend.reserve(bytes);
+            d->hrecv.reserve(bytes * (size_t)W);
+            fd_record* hs = d->hsend.as<fd_record>();
+            std::memset(hs, 0, sizeof(fd_record));
+            hs[0].image = (double)n_local;   // row 0: how many records this rank had (more than cap: the receivers flag the truncation)
+            hs[0].detector = (double)cap_per_rank;   // ... and the stride it was packed with (checked by the receivers)
+            if (n) std::memcpy(hs + 1, local, sizeof(fd_record) * (size_t)n);
+            const fd_record* hr = hs;
+            const size_t used = sizeof(fd_record) * ((size_t)n + 1);
+            if (W > 1) {
+                HIP_CHECK(hipSetDevice(d->ctx->device));
+                hipStream_t st = d->ctx->stream;
+                d->dsend.reserve(bytes);
+                d->drecv.reserve(bytes * (size_t)W);
+                // only the used prefix travels over PCIe; the collective moves the fixed-stride buffers (every rank the same size)
+                HIP_CHECK(hipMemcpyAsync(d->dsend.p, hs, used, hipMemcpyHostToDevice, st));
+                RCCL_CHECK(rccl().AllGather(d->dsend.p, d->drecv.p, bytes, ncclUint8, d->comm, st));
+                HIP_CHECK(hipMemcpyAsync(d->hrecv.p, d->drecv.p, bytes * (size_t)W, hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                hr = d->hrecv.as<fd_record>();
+            }
+            // records of all ranks, ordered by (image, detector, original order): stable sort of (key, position)
+            std::vector<const fd_record*> ptrs;
+            bool trunc = false;
+            for (int r = 0; r < W; ++r) {
+                const fd_record* part = hr + (size_t)r * rows;
+                if ((int64_t)part[0].detector != (int64_t)cap_per_rank)
+                    FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_dist_gather_records: rank %d packed with cap_per_rank %lld, this rank with %d", r, (long long)part[0].detector, cap_per_rank);
+                const int64_t cnt = (int64_t)part[0].image;
+                trunc = trunc || cnt > cap_per_rank;
+                const int64_t take = std::min<int64_t>(cnt, cap_per_rank);
+                for (int64_t i = 0; i < take; ++i) ptrs.push_back(part + 1 + i);
+            }
+            std::stable_sort(ptrs.begin(), ptrs.end(), [](const fd_record* a, const fd_record* b) {
+                return a->image != b->image ? a->image < b->image : a->detector < b->detector;
+            });
+            d->pending.resize(ptrs.size());
+            for (size_t i = 0; i < ptrs.size(); ++i) d->pending[i] = *ptrs[i];
+            d->pendingTrunc = trunc;
+            d->havePending = true;
         }
-        // records of all ranks, ordered by (image, detector, original order): stable sort of (key, position)
-        std::vector<const fd_record*> ptrs;
-        bool trunc = false;
-        for (int r = 0; r < W; ++r) {
-            const fd_record* part = hr + (size_t)r * rows;
-            const int64_t cnt = (int64_t)part[0].image;
-            trunc = trunc || cnt > cap_per_rank;
-            const int64_t take = std::min<int64_t>(cnt, cap_per_rank);
-            for (int64_t i = 0; i < take; ++i) ptrs.push_back(part + 1 + i);
-        }
-        std::stable_sort(ptrs.begin(), ptrs.end(), [](const fd_record* a, const fd_record* b) {
-            return a->image != b->image ? a->image < b->image : a->detector < b->detector;
-        });
-        *n_all = (int64_t)ptrs.size();
-        if (truncated) *truncated = trunc ? 1 : 0;
-        if (all) {
-            if ((int64_t)ptrs.size() > all_cap) FD_THROW(FD_ERR_CAPACITY, "fd_dist_gather_records: %zu records, capacity %lld", ptrs.size(), (long long)all_cap);
-            for (size_t i = 0; i < ptrs.size(); ++i) all[i] = *ptrs[i];
-        }
+        *n_all = (int64_t)d->pending.size();
+        if (truncated) *truncated = d->pendingTrunc ? 1 : 0;
+        if (!all) return;   // count only: the records stay for the call that brings a buffer
+        if ((int64_t)d->pending.size() > all_cap)
+            FD_THROW(FD_ERR_CAPACITY, "fd_dist_gather_records: %zu records, capacity %lld (call again with a larger buffer: no new collective)", d->pending.size(), (long long)all_cap);
+        if (!d->pending.empty()) std::memcpy(all, d->pending.data(), sizeof(fd_record) * d->pending.size());
+        d->pending.clear();
+        d->havePending = false;
     });
 }
 

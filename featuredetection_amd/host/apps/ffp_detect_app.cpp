@@ -7,8 +7,10 @@
 // --gpus N (several images): image-shard data parallelism.  The process starts N copies of itself, one per GPU
 // (FD_DEVICE = rank); rank r runs the face detectors on the images i with i mod N == r, all ranks exchange their detection records with
 // ONE RCCL all-gather (fd_dist_gather_records) and rank 0 prints them in image order -- the same lines a single process prints.
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -42,8 +44,22 @@ static cv::Mat read_pnm(const string& path) {
     return img;
 }
 
-// --gpus N: start one process per GPU and wait for them (the communicator id travels in a file)
-static int launch_ranks(int gpus, int argc, char** argv) {
+// --gpus N: start one process per GPU and wait for them (the communicator id travels in a file).  Everything a single rank could
+// fail on alone is checked HERE, before any rank joins the communicator -- a rank that dies while the others sit in
+// ncclCommInitRank / ncclAllGather would leave them waiting forever: all images must be readable and N devices must exist
+// (FD_DIST_ONE_DEVICE=1: every rank on device 0, for tests on a one-GPU box).  The first rank that exits with an error takes the
+// others down, and so does a timeout (FD_DIST_TIMEOUT_S, default 600).
+static int launch_ranks(int gpus, int argc, char** argv, const std::vector<char*>& args) {
+    for (size_t a = 2; a < args.size(); ++a) {
+        try { (void)read_pnm(args[a]); }
+        catch (const std::exception& e) { std::fprintf(stderr, "runtime error: %s\n", e.what()); return 1; }
+    }
+    const bool oneDevice = std::getenv("FD_DIST_ONE_DEVICE") && std::atoi(std::getenv("FD_DIST_ONE_DEVICE")) != 0;
+    {
+        int ndev = 0;
+        if (fd_device_count(&ndev) != FD_OK || ndev < 1) { std::fprintf(stderr, "runtime error: no usable GPU\n"); return 1; }
+        if (!oneDevice && gpus > ndev) { std::fprintf(stderr, "invalid argument: --gpus %d, but %d device(s) are visible\n", gpus, ndev); return 1; }
+    }
     uint8_t id[FD_DIST_ID_BYTES] = {0};
     if (gpus > 1 && fd_dist_unique_id(id) != FD_OK) { std::fprintf(stderr, "runtime error: librccl.so is not available\n"); return 1; }
     char path[] = "/tmp/fd_dist_id_XXXXXX";
@@ -54,7 +70,7 @@ static int launch_ranks(int gpus, int argc, char** argv) {
     for (int r = 0; r < gpus; ++r) {
         const pid_t pid = fork();
         if (pid == 0) {
-            setenv("FD_DEVICE", std::to_string(r).c_str(), 1);
+            setenv("FD_DEVICE", oneDevice ? "0" : std::to_string(r).c_str(), 1);
             setenv("FD_DIST_RANK", std::to_string(r).c_str(), 1);
             setenv("FD_DIST_WORLD", std::to_string(gpus).c_str(), 1);
             setenv("FD_DIST_ID_FILE", path, 1);
@@ -62,13 +78,32 @@ static int launch_ranks(int gpus, int argc, char** argv) {
             std::perror("execv");
             _exit(127);
         }
+        if (pid < 0) { std::perror("fork"); break; }
         kids.push_back(pid);
     }
-    int rc = 0;
-    for (pid_t k : kids) {
+    const char* te = std::getenv("FD_DIST_TIMEOUT_S");
+    const double timeoutS = te && std::atof(te) > 0 ? std::atof(te) : 600.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = (int)kids.size() == gpus ? 0 : 1;
+    size_t left = kids.size();
+    bool killed = false;
+    while (left > 0) {
         int st = 0;
-        waitpid(k, &st, 0);
-        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = 1;
+        const pid_t k = waitpid(-1, &st, WNOHANG);
+        if (k > 0) {
+            --left;
+            if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = 1;
+        } else if (k < 0) {
+            break;
+        } else {
+            usleep(2000);
+        }
+        const bool late = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeoutS;
+        if ((rc != 0 || late) && !killed) {   // one rank failed (or nothing happens any more): the others would wait for it forever
+            if (late) { std::fprintf(stderr, "runtime error: the ranks did not finish within %.0f s\n", timeoutS); rc = 1; }
+            for (pid_t p : kids) kill(p, SIGTERM);
+            killed = true;
+        }
     }
     unlink(path);
     (void)argc;
@@ -87,7 +122,7 @@ int main(int argc, char** argv) {
         return 2;
     }
     const char* rankEnv = std::getenv("FD_DIST_RANK");
-    if (gpus > 0 && !rankEnv) return launch_ranks(gpus, argc, argv);
+    if (gpus > 0 && !rankEnv) return launch_ranks(gpus, argc, argv, args);
     const int rank = rankEnv ? std::atoi(rankEnv) : 0, world = rankEnv ? std::atoi(std::getenv("FD_DIST_WORLD")) : 1;
     argc = (int)args.size();
     argv = args.data();

@@ -39,6 +39,7 @@ typedef struct fd_sdm fd_sdm;
 /* hip_stream: an existing hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream),
  * or NULL to create a private stream. */
 int fd_ctx_create(int device_id, void* hip_stream, fd_ctx** out);
+int fd_device_count(int* n);   /* visible HIP devices (a multi-rank launcher checks its --gpus against it before any rank starts) */
 void fd_ctx_destroy(fd_ctx* ctx);
 const char* fd_last_error(const fd_ctx* ctx); /* valid until the next failing call on ctx */
 int fd_ctx_synchronize(fd_ctx* ctx);
@@ -457,7 +458,13 @@ int fd_sdm_fit_batch_end(fd_ctx* ctx, fd_sdm_ticket* ticket, float* shapes_out, 
  *   fd_pack_records     fd_detection -> fixed-stride records {image, detector, cx, cy, w, h, score, probability} (all exact in fp64)
  *   fd_dist_gather_records  ONE ncclAllGather of a padded [cap_per_rank + 1] record buffer per rank (row 0 = count) on the context's
  *                       stream; every rank receives the records of all ranks ordered by (image, detector, original order).
- *                       *truncated != 0: a rank had more than cap_per_rank records (the surplus was dropped). */
+ *                       *truncated != 0: a rank had more than cap_per_rank records (the surplus was dropped).
+ *                       COLLECTIVE: every rank of the communicator makes the call, with the same cap_per_rank (a rank that packed with
+ *                       another stride is reported as FD_ERR_INVALID_ARGUMENT on all ranks).  The collective runs once per set of
+ *                       records: with all == NULL the call returns the count, with all_cap too small FD_ERR_CAPACITY -- either way the
+ *                       gathered records stay in the handle, and the next call with a large enough buffer delivers them WITHOUT another
+ *                       collective (so a retry on some ranks only cannot deadlock).  local / n_local of such a follow-up call are ignored.
+ *                       FD_RCCL_LIB names another library with the five nccl entry points (tests: tests/stub_rccl). */
 #define FD_DIST_ID_BYTES 128
 typedef struct fd_dist fd_dist;
 typedef struct fd_record {

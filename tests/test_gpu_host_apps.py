@@ -135,6 +135,100 @@ def test_native_gather_world1_equals_python_twin(capi, ctx):
     d.close()
 
 
+STUB_RCCL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stub_rccl", "librccl_stub.so")
+
+
+def test_ffp_detect_app_two_ranks_on_one_gpu(tmp_path, synth, frame640, small_models):
+    """ffp_detect_app --gpus 2 as two processes on GPU 0 (FD_DIST_ONE_DEVICE=1) with the test-only librccl stand-in (tests/stub_rccl:
+    the ranks meet in shared memory): the multi-rank branch of fd_dist_init / fd_dist_gather_records, the unique-id hand-off through a
+    file and the rank launcher run for real; the lines rank 0 prints are the single process's.  A rank that cannot do its part (an
+    unreadable image) ends the run with an error instead of leaving the other rank in the collective."""
+    app = os.path.join(PKG, "ffp_detect_app")
+    if not os.path.exists(app):
+        pytest.fail("host apps not built (make -C featuredetection_amd/host)")
+    if not os.path.exists(STUB_RCCL):
+        pytest.fail("tests/stub_rccl/librccl_stub.so not built (__graft_entry__.build() / make -C tests/stub_rccl)")
+    wvm, svm = small_models
+    synth.save_wvm(str(tmp_path / "face.fdwvm"), wvm)
+    synth.save_svm_text(str(tmp_path / "face.svm.txt"), svm, rows=20, cols=20)
+    frames = [frame640] + [synth.make_frame(640, 480, seed=40 + i) for i in range(4)]
+    names = []
+    for i, f in enumerate(frames):
+        names.append(str(tmp_path / ("frame%d.ppm" % i)))
+        synth.save_pnm(names[-1], f)
+    (tmp_path / "face.cfg").write_text(FACE_CFG % (tmp_path / "face.fdwvm", tmp_path / "face.svm.txt"))
+    single = _run([app, str(tmp_path / "face.cfg")] + names)
+    assert len(single.strip().splitlines()) > 0
+    env = dict(os.environ, LD_LIBRARY_PATH=PKG + ":" + os.environ.get("LD_LIBRARY_PATH", ""), FD_RCCL_LIB=STUB_RCCL, FD_DIST_ONE_DEVICE="1",
+               FD_DIST_TIMEOUT_S="120")
+    import subprocess
+    r = subprocess.run([app, "--gpus", "2", str(tmp_path / "face.cfg")] + names, capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == single
+    r3 = subprocess.run([app, "--gpus", "3", str(tmp_path / "face.cfg")] + names, capture_output=True, text=True, env=env, timeout=300)
+    assert r3.returncode == 0 and r3.stdout == single, r3.stderr
+    # failure modes: reported before any rank starts, nothing hangs
+    bad = subprocess.run([app, "--gpus", "2", str(tmp_path / "face.cfg")] + names[:2] + [str(tmp_path / "missing.ppm")],
+                         capture_output=True, text=True, env=env, timeout=120)
+    assert bad.returncode != 0 and "cannot open image" in bad.stderr
+    env2 = dict(env)
+    env2.pop("FD_DIST_ONE_DEVICE")
+    many = subprocess.run([app, "--gpus", "64", str(tmp_path / "face.cfg")] + names, capture_output=True, text=True, env=env2, timeout=120)
+    assert many.returncode != 0 and "device(s) are visible" in many.stderr
+
+
+def _dist_rank_main(rank, world, uid_hex, cap, q):
+    """a rank of test_native_gather_two_ranks (own process: own HIP runtime and context)"""
+    import numpy as np
+    import torch  # noqa: F401  (before libfd_hip.so)
+    from featuredetection_amd import capi as C
+    ctx = C.Context(0)
+    d = C.Dist(ctx, rank, world, bytes.fromhex(uid_hex))
+    rng = np.random.default_rng(100 + rank)
+    local = np.zeros((50 + 30 * rank, 8))
+    local[:, 0] = rng.integers(0, 9, len(local)) * world + rank
+    local[:, 1] = rng.integers(0, 3, len(local))
+    local[:, 2:] = rng.normal(size=(len(local), 6))
+    got, tr = d.gather(local, cap)
+    got2, tr2 = d.gather(local[:7], cap)   # a second collective on the same communicator
+    # count-then-fetch: the collective runs in the first call, the second one only delivers
+    n = C.dist_gather_count(d, local, cap)
+    got3, _ = d.gather(np.zeros((0, 8)), cap)
+    q.put((rank, local, got, tr, got2, n, got3))
+    d.close()
+
+
+def test_native_gather_two_ranks(capi, ctx):
+    """capi.Dist with world 2: two processes on GPU 0 and the librccl stand-in.  Every rank receives the records of both, ordered like
+    the torch.distributed twin orders them; a count-only call followed by a fetch is ONE collective."""
+    if not os.path.exists(STUB_RCCL):
+        pytest.fail("tests/stub_rccl/librccl_stub.so not built")
+    import multiprocessing as mp
+    from featuredetection_amd import parallel
+    os.environ["FD_RCCL_LIB"] = STUB_RCCL
+    try:
+        mpc = mp.get_context("spawn")
+        uid = capi.Dist.unique_id()   # loads the stand-in in this process as well
+        q = mpc.Queue()
+        ps = [mpc.Process(target=_dist_rank_main, args=(r, 2, uid.hex(), 256, q)) for r in range(2)]
+        for p_ in ps:
+            p_.start()
+        res = sorted([q.get(timeout=240) for _ in ps], key=lambda t: t[0])
+        for p_ in ps:
+            p_.join(timeout=60)
+            assert p_.exitcode == 0
+    finally:
+        os.environ.pop("FD_RCCL_LIB", None)
+    both = np.concatenate([res[0][1], res[1][1]])
+    order = np.lexsort((np.arange(len(both)), both[:, 1], both[:, 0]))   # (image, detector, original order)
+    exp = both[order]
+    for rank, local, got, tr, got2, n, got3 in res:
+        assert not tr and got.tobytes() == exp.tobytes(), rank
+        b2 = np.concatenate([res[0][1][:7], res[1][1][:7]])
+        assert got2.tobytes() == b2[np.lexsort((np.arange(len(b2)), b2[:, 1], b2[:, 0]))].tobytes()
+        assert n == len(exp) and got3.tobytes() == exp.tobytes()
+
+
 SINGLE_CFG = """detectors
 {
     Face
@@ -485,3 +579,24 @@ def test_svm_text_format_fixture(tmp_path, capi, ctx):
         if dv >= 0.0:
             exp_boxes.append((int(w[3] - w[5] // 2), int(w[4] - w[6] // 2), int(w[5]), int(w[6])))
     assert len(exp_boxes) > 0 and got == sorted(exp_boxes)
+
+
+def test_bench_two_ranks_gather_through_fd_dist(tmp_path):
+    """bench.py --gpus 2 the way the driver launches it (torch.distributed.run, one process per rank), on a one-GPU box: both ranks on
+    device 0, torch.distributed over gloo, fd_dist_* over the librccl stand-in.  The records every rank produced arrive on rank 0
+    through fd_dist_gather_records (records_gathered == detections_delivered), nothing is truncated."""
+    import json
+    import subprocess
+    import sys
+    if not os.path.exists(STUB_RCCL):
+        pytest.fail("tests/stub_rccl/librccl_stub.so not built")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FD_DIST_ONE_DEVICE="1", FD_BENCH_DIST_BACKEND="gloo", FD_RCCL_LIB=STUB_RCCL)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29571",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--also", "none", "--no-cpu-baseline", "--no-probe",
+           "--frames-per-step", "256"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"
+    assert rec["records_gathered"] == rec["detections_delivered"] > 0 and not rec["records_truncated"]
