@@ -799,8 +799,8 @@ void build_gradient_lut(int bins, bool signedGradients, bool interpolate, std::v
 void build_resize_tables(fd_pyramid* p, int W, int H) {
     p->rtab_x.assign(p->all.size(), ~0u);
     p->rtab_y.assign(p->all.size(), ~0u);
-    static const bool off = [] { const char* e = getenv("FD_PYR_FUSED"); return e && atoi(e) == 0; }();
-    if (off) return;
+    static const int mode = [] { const char* e = getenv("FD_PYR_FUSED"); return e ? atoi(e) : 1; }();   // 0: never, 1: default, 2: kept layers too
+    if (mode == 0) return;
     std::vector<int2> tab;
     // tiles of k_resize_down, one list per launch (MAXJ chains): {X0 | Y0 << 16, ncol | nrow << 16, tx | ty << 16, chain of the launch}
     std::vector<std::vector<int4>> tiles;
@@ -815,6 +815,11 @@ void build_resize_tables(fd_pyramid* p, int W, int H) {
         // costs +35 us per 64-frame call against 15 us saved: the resize arithmetic is not free)
         if (L.w == W && L.h == H && L.gray_off == p->gray_full_off) continue;
         if (L.w < 3 || L.h < 3 || W > 65535 || H > 65535) continue;
+        // A first-octave layer that is itself a kept layer (config 2's pyramid: scales up to 1) has to be written anyway: the fusion saves
+        // nothing there and the fused kernel is the slower resize (round 3: 699 us per 640x480 frame; k_resize_tiled + k_pyrdown_tiled:
+        // 101 + 4 x 68 us, round 4).  FD_PYR_FUSED=2 fuses those too (A/B).  Also measured in round 4 and dropped: persistent
+        // k_pyrdown_tiled workgroups with the next tile's loads in flight (69 vs 63 us per 64-frame headline call).
+        if (L.kept && mode != 2) continue;
         const double scale_x = 1. / ((double)L.w / W), scale_y = 1. / ((double)L.h / H);
         std::vector<int2> xt((size_t)L.w), yt((size_t)L.h);
         for (int dx = 0; dx < L.w; ++dx) {
