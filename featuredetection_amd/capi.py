@@ -577,6 +577,9 @@ def detect_five_stage(ctx, pyr, wvm, svm, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1,
 
 def detect_five_stage_frames(ctx, pyr, wvm, svm, nframes, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1, roi=None, cap=256):
     """fd_detect_five_stage_frames on a multi-frame pyramid: [(detections, stage_counts)] per frame"""
+    held = int(getattr(pyr, "nframes", 1) or 1)   # the C side writes one entry per frame OF THE PYRAMID (see FiveStageFrames)
+    if nframes != held:
+        raise ValueError("detect_five_stage_frames: nframes=%d but the pyramid holds %d frames" % (nframes, held))
     out = np.empty((nframes, cap), DET_DTYPE)
     counts = np.zeros(nframes, np.int32)
     stages = np.zeros((nframes, 4), np.int32)

@@ -452,7 +452,7 @@ static void hog_svm_end(fd_ctx* ctx, fd_hog_svm_ticket& t, fd_detection* out, in
     }
     HogPos* h = S.hcount.as<HogPos>();
     const unsigned int cnt = h[0].wid_lo;
-    if (cnt > t.pcap) FD_THROW(FD_ERR_CAPACITY, "fd_detect_hog_svm: %u positives exceed the device buffer", cnt);
+    if (cnt > t.pcap) FD_THROW(FD_ERR_DEVICE_CAPACITY, "fd_detect_hog_svm: %u positives exceed the device buffer", cnt);
     const size_t first = std::min<size_t>(t.pcap, HOG_FIRST_CHUNK);
     if (cnt > first) HIP_CHECK(hipMemcpyAsync(h + 1 + first, S.pos.as<HogPos>() + 1 + first, sizeof(HogPos) * (cnt - first), hipMemcpyDeviceToHost, st));
     if (all_distance) HIP_CHECK(hipMemcpyAsync(all_distance, S.dist.p, sizeof(double) * (size_t)t.N, hipMemcpyDeviceToHost, st));
@@ -962,7 +962,7 @@ void fd_svm_positives_to_detections(fd_ctx* ctx, const fd_pyramid* p, const fd_s
     if (all_distance) HIP_CHECK(hipMemcpyAsync(all_distance, ddist, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     const unsigned int cnt = *hcnt;
-    if (cnt > pcap) FD_THROW(FD_ERR_CAPACITY, "%u positives exceed the device buffer", cnt);
+    if (cnt > pcap) FD_THROW(FD_ERR_DEVICE_CAPACITY, "%u positives exceed the device buffer", cnt);
     std::vector<HogPos> raw(cnt);
     if (cnt) HIP_CHECK(hipMemcpy(raw.data(), S.pos.p, sizeof(HogPos) * cnt, hipMemcpyDeviceToHost));
     auto widof = [](const HogPos& r) { return ((uint64_t)r.wid_hi << 32) | r.wid_lo; };

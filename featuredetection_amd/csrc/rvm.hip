@@ -451,7 +451,7 @@ int fd_detect_rvm(fd_ctx* ctx, fd_pyramid* p, const fd_rvm* rvm_, const fd_rvm_d
         if (all_distance) HIP_CHECK(hipMemcpyAsync(all_distance, m->dist.p, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         const unsigned int cnt = *hcnt;
-        if (cnt > pos_cap) FD_THROW(FD_ERR_CAPACITY, "fd_detect_rvm: %u positives exceed the device buffer", cnt);
+        if (cnt > pos_cap) FD_THROW(FD_ERR_DEVICE_CAPACITY, "fd_detect_rvm: %u positives exceed the device buffer", cnt);
         std::vector<RvmRec> raw(cnt);
         if (cnt) HIP_CHECK(hipMemcpy(raw.data(), m->pos.p, sizeof(RvmRec) * cnt, hipMemcpyDeviceToHost));
         auto widof = [](const RvmRec& r) { return ((uint64_t)r.wid_hi << 32) | r.wid_lo; };

@@ -548,6 +548,8 @@ struct fd_sdm {
     std::vector<std::unique_ptr<DevBuf>> R;
     std::vector<std::unique_ptr<SdmScratch>> idle;   // scratch sets not in use (handles are single-threaded: no lock)
     unsigned int launches = 0;
+    hipEvent_t order = nullptr;   // orders the auxiliary stream of odd tickets behind the context's stream (device-resident images)
+    ~fd_sdm() { if (order) (void)hipEventDestroy(order); }
 };
 struct fd_sdm_ticket {
     fd_sdm* m = nullptr;
@@ -800,6 +802,13 @@ int fd_sdm_fit_batch_begin(fd_ctx* ctx, const fd_sdm* m_, const uint8_t* gray_im
         fd_sdm* m = const_cast<fd_sdm*>(m_);
         std::unique_ptr<fd_sdm_ticket> t(new fd_sdm_ticket());
         hipStream_t st = (m->launches++ & 1u) ? fd_aux_stream(ctx) : ctx->stream;
+        if (st != ctx->stream && images_on_device) {
+            // device-resident images may still be being written by work the caller queued on the context's stream: the auxiliary stream
+            // starts behind everything queued there so far
+            if (!m->order) HIP_CHECK(hipEventCreateWithFlags(&m->order, hipEventDisableTiming));
+            HIP_CHECK(hipEventRecord(m->order, ctx->stream));
+            HIP_CHECK(hipStreamWaitEvent(st, m->order, 0));
+        }
         sdm_begin(ctx, m, *t, gray_images, W, H, batch, images_on_device, nullptr, face_boxes, st, false);
         *ticket = t.release();
     });

@@ -1922,6 +1922,21 @@ struct WvbTables {
 static bool wvb_tables(const fd_wvm_model* md, int NU, WvbTables& T) {
     const int F = md->num_filters, NP = md->num_per_level;
     if (NU <= WVM_LCAP) return false;
+    // the callers outside fd_wvm_create (test hooks) bring unvalidated models: everything the loops below index with is checked here
+    if (F < 1 || NU > F || NP < 1 || md->filter_w < 1 || md->filter_h < 1 || !md->val_off || !md->rec_off || !md->rects || !md->val || !md->pp ||
+        !md->hk_weights) return false;
+    if (md->val_off[0] != 0) return false;
+    for (int k = 0; k < NU; ++k) {
+        const int cnt = md->val_off[k + 1] - md->val_off[k];
+        if (cnt < 1 || cnt > WVM_MAX_VALS) return false;   // a level is one slot of at most 15 rows, its record holds 16 grey values
+    }
+    for (int v = 0; v < md->val_off[NU]; ++v) {
+        if (md->rec_off[v] < 0 || md->rec_off[v + 1] < md->rec_off[v]) return false;
+        for (int ri = md->rec_off[v]; ri < md->rec_off[v + 1]; ++ri) {
+            const uint8_t* rc = md->rects + 4 * (size_t)ri;
+            if (rc[0] > rc[2] || rc[1] > rc[3] || rc[2] >= md->filter_w || rc[3] >= md->filter_h) return false;
+        }
+    }
     const int pw = md->filter_w, ph = md->filter_h, d = pw * ph;
     const int KS = (d + 31) / 32;
     const int KSP = (KS + 7) / 8 * 8;   // k-steps per tile in the operand table: whole groups of eight (zero fragments behind the patch)

@@ -10,6 +10,10 @@
 #include <fstream>
 #include <iostream>
 #include "detection/detection_all.hpp"
+#include "classification/RvmClassifier.hpp"
+#include "classification/ProbabilisticRvmClassifier.hpp"
+#include "imageprocessing/FilteringFeatureExtractor.hpp"
+#include "imageprocessing/ZeroMeanUnitVarianceFilter.hpp"
 
 using namespace imageprocessing;
 using std::make_shared;
@@ -150,6 +154,17 @@ int main(int argc, char** argv) {
         dumpMat(out + "whitened.bin", WhiteningFilter().applyTo(g20));
         dumpMat(out + "converted.bin", ConversionFilter(CV_32F, 1.0 / 255.0, 0.0).applyTo(g20));
         dumpMat(out + "unitnorm.bin", UnitNormFilter(cv::NORM_L2).applyTo(g20));
+        dumpMat(out + "zmuv.bin", ZeroMeanUnitVarianceFilter().applyTo(g20));
+        {   // FilteringFeatureExtractor (FilteringFeatureExtractor.hpp:20-62): single-patch extraction + a patch filter applied per Mat
+            auto ffe = make_shared<FilteringFeatureExtractor>(direct);
+            ffe->addPatchFilter(make_shared<ZeroMeanUnitVarianceFilter>());
+            ffe->update(image);
+            auto pf = ffe->extract(200, 150, 60, 60), pr = direct->extract(200, 150, 60, 60);
+            if (pf && pr) {
+                dumpMat(out + "ffe_patch.bin", pf->getData());
+                dumpMat(out + "ffe_raw.bin", pr->getData());
+            }
+        }
         cv::Mat row = ReshapingFilter(1).applyTo(g20);
         std::printf("reshaped %d x %d\n", row.rows, row.cols);
     } catch (const std::exception& e) {

@@ -1,0 +1,3 @@
+// ZeroMeanUnitVarianceFilter.hpp of the reference -- see imageprocessing_all.hpp
+#pragma once
+#include "imageprocessing/imageprocessing_all.hpp"

@@ -115,6 +115,14 @@ public:
     cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;
     int normType;
 };
+// ZeroMeanUnitVarianceFilter.cpp:21-34 (ffpDetectApp.cpp:77 includes it; host only: cv::meanStdDev in double, then (x - mean) / deviation
+// on the CV_32F copy, all zeros for a constant image)
+class ZeroMeanUnitVarianceFilter : public ImageFilter {
+public:
+    using ImageFilter::applyTo;
+    ZeroMeanUnitVarianceFilter() {}
+    cv::Mat applyTo(const cv::Mat& image, cv::Mat& filtered) const override;
+};
 // ReshapingFilter.hpp: Mat::reshape(channels, rows) (ffpDetectApp.cpp:465-467 turns patches into row vectors); the fused
 // kernels work on flat vectors, so inside a fused chain it is a no-op
 class ReshapingFilter : public ImageFilter {
@@ -435,6 +443,23 @@ private:
     std::shared_ptr<PyramidFeatureExtractor> extractor;
     std::shared_ptr<ChainedFilter> patchFilter;
     std::shared_ptr<DirectPyramidFeatureExtractor> fused;
+};
+
+// FilteringFeatureExtractor.hpp:20-62 (ffpDetectApp.cpp:74 includes it): any FeatureExtractor plus patch filters applied per Mat
+class FilteringFeatureExtractor : public FeatureExtractor {
+public:
+    using FeatureExtractor::update;
+    explicit FilteringFeatureExtractor(std::shared_ptr<FeatureExtractor> extractor) : extractor(extractor), patchFilter(std::make_shared<ChainedFilter>()) {}
+    void addPatchFilter(std::shared_ptr<ImageFilter> filter) { patchFilter->add(filter); }
+    void update(std::shared_ptr<VersionedImage> image) override { extractor->update(image); }
+    std::shared_ptr<Patch> extract(int x, int y, int width, int height) const override {
+        std::shared_ptr<Patch> patch = extractor->extract(x, y, width, height);
+        if (patch) patchFilter->applyInPlace(patch->getData());
+        return patch;
+    }
+private:
+    std::shared_ptr<FeatureExtractor> extractor;
+    std::shared_ptr<ChainedFilter> patchFilter;
 };
 
 // filtering/FhogFilter.hpp:55-56 / FhogFilter.cpp:20-72 (the cell descriptors of the AggregatedFeaturesDetector family)

@@ -136,6 +136,21 @@ Mat UnitNormFilter::applyTo(const Mat& image, Mat& filtered) const {
     filtered = dst;
     return filtered;
 }
+Mat ZeroMeanUnitVarianceFilter::applyTo(const Mat& image, Mat& filtered) const {   // ZeroMeanUnitVarianceFilter.cpp:21-34
+    if (image.channels() > 1) throw std::invalid_argument("ZeroMeanUnitVarianceFilter: The image must have exactly one channel.");
+    Mat f32 = image.depth() == CV_32F ? contiguous(image).clone() : ConversionFilter(CV_32F).applyTo(image);   // image.convertTo(filtered, CV_32F)
+    const size_t n = (size_t)f32.rows * f32.cols;
+    const float* x = f32.ptr<float>(0);
+    double s = 0, sq = 0;   // cv::meanStdDev: sums in double, population deviation
+    for (size_t i = 0; i < n; ++i) { s += x[i]; sq += (double)x[i] * x[i]; }
+    const double mean = n ? s / (double)n : 0.0;
+    const double dev = n ? std::sqrt(std::max(sq / (double)n - mean * mean, 0.0)) : 0.0;
+    Mat dst(f32.rows, f32.cols, CV_32FC1);
+    float* o = dst.ptr<float>(0);
+    for (size_t i = 0; i < n; ++i) o[i] = dev == 0 ? 0.f : (float)(((double)x[i] - mean) / dev);
+    filtered = dst;
+    return filtered;
+}
 Mat ReshapingFilter::applyTo(const Mat& image, Mat& filtered) const {   // Mat::reshape(cn, rows) of a continuous matrix
     Mat src = contiguous(image).clone();
     const int cn = channels == 0 ? src.channels() : channels;

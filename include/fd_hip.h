@@ -443,7 +443,9 @@ int fd_sdm_optimize_batch(fd_ctx* ctx, const fd_sdm* m, const uint8_t* gray_imag
                           int images_on_device, float* shapes_inout, int32_t* status_out);
 /* Asynchronous form of fd_sdm_fit_batch (the five-stage path has _begin/_end, so has this): _begin queues the whole fit of a batch
  * (its S cascade steps and the read-back) and returns; _end waits and delivers shapes / status.  Several batches of one model can be
- * in flight from ONE host thread; each has its own scratch set.  Host images / boxes of a batch must stay valid until its _end. */
+ * in flight from ONE host thread; each has its own scratch set.  Host images / boxes of a batch must stay valid until its _end, and the
+ * model must outlive its tickets (a ticket holds a plain pointer to it).  Device-resident images are read behind everything queued on
+ * the context's stream at the time of _begin. */
 typedef struct fd_sdm_ticket fd_sdm_ticket;
 int fd_sdm_fit_batch_begin(fd_ctx* ctx, const fd_sdm* model, const uint8_t* gray_images, int width, int height, int batch,
                            const int32_t* face_boxes, int images_on_device, fd_sdm_ticket** ticket);

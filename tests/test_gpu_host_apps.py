@@ -508,6 +508,13 @@ def test_host_selftest_app(tmp_path, oracle, capi, ctx, synth, frame640):
     inv = np.float32(1.0 / (np.sqrt((v.astype(np.float64) ** 2).sum()) + np.float64(np.float32(1e-4))))
     assert np.array_equal(f32("unitnorm.bin"), v * inv)
     assert "reshaped 1 x 400" in lines
+    # ZeroMeanUnitVarianceFilter.cpp:21-34 (mean / population deviation in double) and FilteringFeatureExtractor applying it to one patch
+    def zmuv(a):
+        a = a.astype(np.float32).astype(np.float64)
+        return ((a - a.mean()) / a.std()).astype(np.float32).ravel()
+    assert np.array_equal(f32("zmuv.bin"), zmuv(g20))
+    raw = np.fromfile(str(tmp_path / "ffe_raw.bin"), np.uint8)
+    assert len(raw) == 400 and np.array_equal(f32("ffe_patch.bin"), zmuv(raw))
 
 
 def test_svm_text_format_fixture(tmp_path, capi, ctx):
