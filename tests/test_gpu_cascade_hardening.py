@@ -91,27 +91,34 @@ def test_production_cascade_at_exact_threshold_ties(oracle, capi, ctx, synth, na
         assert max(int((e.astype(np.int64) ** 2).sum()) for e in eq) >= 1 << 24
     L = min(16, nper, base["num_used"] - 1)
     levels = sorted({0, L // 2, L - 1})
-    picks = rng.choice(nwin, 3, replace=False)
+    # 32 windows per case, each at one of the three levels (rotating); every window's exact output as the threshold ("tie": the window
+    # passes), and the next float above it ("above": the exact cascade rejects the window at this level while the pre-filter, whose
+    # bound cannot tell a one-ulp difference, lets it through by its guard band only -- stage B has to do the rejecting); the first
+    # windows also with the next float below.
+    picks = rng.choice(nwin, 32, replace=False)
     patches = _eq_patches(oracle, po, pw, ph, picks)
     ran = 0
-    for k in levels:
-        for wi, pe in zip(picks, patches):
-            res = _level_output(oracle, base, k, pe)
-            if not np.isfinite(res):
-                continue
-            for which, thr in (("tie", res), ("above", np.nextafter(res, np.float32(np.inf))), ("below", np.nextafter(res, np.float32(-np.inf)))):
-                m = dict(base)
-                t = base["thresholds"].copy()
-                t[:k] = -3e38          # the window reaches level k
-                t[k] = thr
-                m["thresholds"] = t
-                lv_o, fo_o = _check_all_paths(oracle, capi, ctx, po, pg, m, (name, k, int(wi), which))
-                if which == "above":
-                    assert lv_o[wi] == k and fo_o[wi] == res
-                else:
-                    assert lv_o[wi] > k
-                ran += 1
-    assert ran >= 9
+    for i, (wi, pe) in enumerate(zip(picks, patches)):
+        k = levels[i % len(levels)]
+        res = _level_output(oracle, base, k, pe)
+        if not np.isfinite(res):
+            continue
+        variants = [("tie", res), ("above", np.nextafter(res, np.float32(np.inf)))]
+        if i < 3:
+            variants.append(("below", np.nextafter(res, np.float32(-np.inf))))
+        for which, thr in variants:
+            m = dict(base)
+            t = base["thresholds"].copy()
+            t[:k] = -3e38          # the window reaches level k
+            t[k] = thr
+            m["thresholds"] = t
+            lv_o, fo_o = _check_all_paths(oracle, capi, ctx, po, pg, m, (name, k, int(wi), which))
+            if which == "above":
+                assert lv_o[wi] == k and fo_o[wi] == res
+            else:
+                assert lv_o[wi] > k
+            ran += 1
+    assert ran >= 60
     pg.close()
 
 
