@@ -261,7 +261,41 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 ry1[d] = sy + 1 < 0 ? 0 : (sy + 1 >= side ? side - 1 : sy + 1);
                 rfy[d] = fy;
             }
+            // The source square goes to LDS first, row by row (64 consecutive bytes of the crop per load instruction: two or three cache
+            // lines; the resize's own taps are four scattered bytes per lane, ~30 lines per instruction -- the phase was 27 % of the kernel,
+            // nearly all of it the texture path).  The bytes sit behind the six tables in the (still unused) orientation-mask region.
+            uint8_t* cropB = reinterpret_cast<uint8_t*>(rfy + m_);
+            const int cropCap = desc_region_masks(iw, ih, ncell, nori) - 6 * m_ * 4;
+            const bool staged = side * side <= cropCap;
+            if (staged) {
+                const float invS = 1.0f / (float)side;
+                const int nsrc = side * side;
+                constexpr int CU = 8;
+                for (int q0 = lane; q0 < nsrc; q0 += 64 * CU) {
+                    float t[CU];
+#pragma unroll
+                    for (int u = 0; u < CU; ++u) {
+                        const int q = min(q0 + 64 * u, nsrc - 1);
+                        const int r = (int)(((float)q + 0.5f) * invS), c = q - __mul24(r, side);
+                        t[u] = src_px(img, p.W, p.H, ox + c, oy + r);
+                    }
+#pragma unroll
+                    for (int u = 0; u < CU; ++u)
+                        if (q0 + 64 * u < nsrc) cropB[q0 + 64 * u] = (uint8_t)t[u];
+                }
+            }
             wave_sync();
+            if (staged) {
+                for (int i = lane; i < npix; i += 64) {
+                    const int dy = divw(i), dx = i - __mul24(dy, iw);
+                    const float fx = rfx[dx], fy = rfy[dy];
+                    const int sx = rsx[dx], sx1 = rsx1[dx], y0 = __mul24(ry0[dy], side), y1 = __mul24(ry1[dy], side);
+                    const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+                    const float r0 = (float)cropB[y0 + sx] * a0 + (float)cropB[y0 + sx1] * a1;
+                    const float r1 = (float)cropB[y1 + sx] * a0 + (float)cropB[y1 + sx1] * a1;
+                    S.img[i] = r0 * b0 + r1 * b1;
+                }
+            } else
             for (int i = lane; i < npix; i += 64) {
                 const int dy = divw(i), dx = i - __mul24(dy, iw);
                 const float fx = rfx[dx], fy = rfy[dy];
@@ -307,14 +341,23 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             }
             float w0 = 0.f;
             int b0 = -1;
+            // hog.c:640-655 without branches: |score| through the sign bit, "score > best" as a compare + two selects (v_max keeps the
+            // first maximum like the reference's strict >).  Branchy, every orientation of every unrolled pixel was three basic blocks.
+            auto consider = [&](int k) {
+                const float dot = gradx * oXr[k] + grady * oYr[k];
+                const float score = fabsf(dot);
+                const int bin = dot < 0.f ? k + nori : k;
+                const bool gt = score > w0;
+                b0 = gt ? bin : b0;
+                w0 = fmaxf(w0, score);
+            };
+            if (nori == 9) {   // the SDM models of the reference (9 orientations): one straight block
 #pragma unroll
-            for (int k = 0; k < SDM_MAX_ORI; ++k) {   // unrolled over the register copies: indexed through the kernel arguments the
-                if (k < nori) {                        // loop issued two dependent scalar loads per orientation and pixel
-                    float score = gradx * oXr[k] + grady * oYr[k];
-                    int bin = k;
-                    if (score < 0) { score = -score; bin += nori; }
-                    if (score > w0) { b0 = bin; w0 = score; }
-                }
+                for (int k = 0; k < 9; ++k) consider(k);
+            } else {
+#pragma unroll
+                for (int k = 0; k < SDM_MAX_ORI; ++k)
+                    if (k < nori) consider(k);
             }
             gout = grad;
             return b0;
