@@ -46,6 +46,7 @@ struct DescLds {   // per-wave views carved out of dynamic LDS
     float *hog, *norm, *feat;
     void* masks;                  // [2*nori][ih] words (32 bits SMALL, else 64): bit x set iff pixel (y, x) voted for that orientation
     float* wsel;                  // [max(hogW, hogH)][m]: interpolation weight of column / row p towards cell column / row c
+    float2* oxy;                  // [SDM_MAX_ORI] orientation unit vectors (a lane picks three of them by index)
     double *fac, *hc;             // block factors [ncell][4], clamped undirected terms [ncell*nori][4] (reuse the mask region)
     unsigned long long* colmask;  // [hogW]: columns x contributing to cell column cx
     int* yrange;                  // [hogH][2]: first/last+1 row contributing to cell row cy
@@ -73,7 +74,7 @@ __host__ __device__ inline int desc_lds_bytes(int iw, int ih, int ncell, int nor
     const int m = iw > ih ? iw : ih;
     return desc_region_img(iw, ih, ncell, dim) + ((desc_small(iw, ih) && SDM_REGGRAD) ? 0 : align16i(iw * ih * 4)) + 3 * align16i(m * 4) +
            align16i(ncell * nori * 2 * 4) + align16i(ncell * 4) + desc_region_masks(iw, ih, ncell, nori) + align16i(m * 8) + align16i(m * 2 * 4) +
-           align16i(hogMax * m * 4);
+           align16i(hogMax * m * 4) + align16i(SDM_MAX_ORI * 8);
 }
 
 __device__ __forceinline__ void wave_sync() {
@@ -149,8 +150,11 @@ extern "C" void fd_debug_sdm_prof(unsigned long long* out, int reset) {
 // one wavefront per (face, landmark).  LDS per wave is what bounds the occupancy of this latency-bound kernel, so regions
 // are reused: the gradient magnitudes overwrite the working image (SMALL: they wait in registers until every lane has read
 // its neighbours), the features overwrite it once the votes are in, the block factors reuse the orientation masks.
+#ifndef FD_SDM_WPE
+#define FD_SDM_WPE 4
+#endif
 template <bool SMALL>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_sdm_descriptors(const uint8_t* __restrict__ images, const int32_t* __restrict__ origin,
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(FD_SDM_WPE, 8))) void k_sdm_descriptors(const uint8_t* __restrict__ images, const int32_t* __restrict__ origin,
                                                          DescParams p, int64_t nitems, float* __restrict__ out, int64_t out_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -182,7 +186,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         b += desc_region_masks(iw, ih, ncell, nori);
         S.colmask = (unsigned long long*)b; b += align16i(m * 8);
         S.yrange = (int*)b; b += align16i(m * 2 * 4);
-        S.wsel = (float*)b;
+        S.wsel = (float*)b; b += align16i((hogW > hogH ? hogW : hogH) * m * 4);
+        S.oxy = (float2*)b;
     }
     mask_t* const masks = (mask_t*)S.masks;
     const int hogMax = hogW > hogH ? hogW : hogH;
@@ -196,6 +201,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         const float w1 = (float)(1.0 - (double)w2);
         S.binx[x] = b; S.wx1[x] = w1; S.wx2[x] = w2;
     }
+#pragma unroll
+    for (int k = 0; k < SDM_MAX_ORI; ++k)
+        if (lane == k) S.oxy[k] = make_float2(p.oX[k], p.oY[k]);
     wave_sync();
     for (int i = lane; i < hogMax * m_; i += 64) {   // weight of pixel column / row p towards cell column / row c
         const int c = i / m_, p_ = i - c * m_;
@@ -317,9 +325,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         wave_sync();
         SDM_T(t1);
         // ---- gradient magnitude and hard orientation assignment per interior pixel (hog.c:612-665)
-        float oXr[SDM_MAX_ORI], oYr[SDM_MAX_ORI];   // orientation unit vectors: registers (uniform), loaded once per item
-#pragma unroll
-        for (int k = 0; k < SDM_MAX_ORI; ++k) { oXr[k] = p.oX[k]; oYr[k] = p.oY[k]; }
+        // (the orientation unit vectors come from the per-wave LDS table S.oxy)
         auto gradient = [&](int i, float& gout) -> int {   // returns the orientation bin or -1, -2 for border pixels
             const int y = divw(i), x = i - __mul24(y, iw);
             if (x < 1 || y < 1 || x >= iw - 1 || y >= ih - 1) return -2;
@@ -329,35 +335,68 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             float grad2 = gradx * gradx + grady * grady;
             if (!(grad2 > 0.f)) { gradx = 0.f; grady = 0.f; grad2 = 0.f; }
             const float grad = sqrtf(grad2);
-            if ((double)grad > 1e-10) {
-                // (float)((double)a / (double)b) == a / b for fp32 a, b: rounding the fp64 quotient (53 >= 2 * 24 + 2 bits) to
-                // fp32 cannot double-round, and the device's fp32 division is correctly rounded
-                gradx = gradx / grad;
-                grady = grady / grad;
-            } else {
-                asm volatile("" ::: "memory");   // a real branch: the fp64 divisions must not be if-converted into every pixel
-                gradx = (float)((double)gradx / 1e-10);
-                grady = (float)((double)grady / 1e-10);
-            }
             float w0 = 0.f;
             int b0 = -1;
-            // hog.c:640-655 without branches: |score| through the sign bit, "score > best" as a compare + two selects (v_max keeps the
-            // first maximum like the reference's strict >).  Branchy, every orientation of every unrolled pixel was three basic blocks.
-            auto consider = [&](int k) {
-                const float dot = gradx * oXr[k] + grady * oYr[k];
-                const float score = fabsf(dot);
-                const int bin = dot < 0.f ? k + nori : k;
-                const bool gt = score > w0;
-                b0 = gt ? bin : b0;
-                w0 = fmaxf(w0, score);
-            };
-            if (nori == 9) {   // the SDM models of the reference (9 orientations): one straight block
+            bool exact = true;
+            if (nori == 9) {
+                // Nine orientations (the reference's SDM models): the winner of hog.c:640-655 from THREE candidates.  The undirected angle
+                // of the gradient is estimated through its "diamond angle" |gy| / (|gx| + |gy|) (off by at most 4.1 degrees); the direction
+                // of the 20-degree fan nearest to the estimate and its two neighbours contain the two directions nearest to the true
+                // angle, and every other direction scores at least 4 % lower.  The three dot products are taken on the unnormalised
+                // gradient; they differ from the reference's (normalised, separately rounded) scores by less than 1.2e-6 |g|, so a winner
+                // that leads by more than 4e-6 of its score is the reference's winner.  Anything closer, a zero or a tiny gradient takes
+                // the exact path below (nine normalised scores in order, ties to the first): the two IEEE divisions and six of the nine
+                // evaluations are gone for all but a handful of pixels.
+                exact = !((double)grad > 1e-10);
+                if (grad2 > 0.f && !exact) {
+                    const float ax = fabsf(gradx), ay = fabsf(grady);
+                    const float d = ay * __builtin_amdgcn_rcpf(ax + ay);
+                    const float u = ((gradx < 0.f) == (grady < 0.f) || ay == 0.f) ? 4.5f * d : 9.0f - 4.5f * d;   // angle / 20 degrees
+                    int ke = (int)(u + 0.5f);
+                    ke = ke >= 9 ? ke - 9 : ke;
+                    const int ka = ke == 0 ? 8 : ke - 1, kc = ke == 8 ? 0 : ke + 1;
+                    const float2 oa = S.oxy[ka], ob = S.oxy[ke], oc = S.oxy[kc];
+                    const float da = gradx * oa.x + grady * oa.y, db = gradx * ob.x + grady * ob.y, dc = gradx * oc.x + grady * oc.y;
+                    const float sa = fabsf(da), sb = fabsf(db), sc = fabsf(dc);
+                    const float m1 = fmaxf(fmaxf(sa, sb), sc), m2 = __builtin_amdgcn_fmed3f(sa, sb, sc);
+                    exact = !(m1 - m2 > m1 * 4.0e-6f);
+                    const int kb = sa == m1 ? ka : (sb == m1 ? ke : kc);
+                    const float dbest = sa == m1 ? da : (sb == m1 ? db : dc);
+                    b0 = kb + (dbest < 0.f ? 9 : 0);
+                }
+            }
+            if (exact) {
+                b0 = -1;
+                if ((double)grad > 1e-10) {
+                    // (float)((double)a / (double)b) == a / b for fp32 a, b: rounding the fp64 quotient (53 >= 2 * 24 + 2 bits) to
+                    // fp32 cannot double-round, and the device's fp32 division is correctly rounded
+                    gradx = gradx / grad;
+                    grady = grady / grad;
+                } else {
+                    asm volatile("" ::: "memory");   // a real branch: the fp64 divisions must not be if-converted into every pixel
+                    gradx = (float)((double)gradx / 1e-10);
+                    grady = (float)((double)grady / 1e-10);
+                }
+                // hog.c:640-655 without branches: |score| through the sign bit, "score > best" as a compare + two selects (v_max keeps
+                // the first maximum like the reference's strict >)
+                auto consider = [&](int k) {
+                    const float2 ok = S.oxy[k];
+                    const float dot = gradx * ok.x + grady * ok.y;
+                    const float score = fabsf(dot);
+                    const int bin = dot < 0.f ? k + nori : k;
+                    const bool gt = score > w0;
+                    b0 = gt ? bin : b0;
+                    w0 = fmaxf(w0, score);
+                };
+                if (nori == 9) {
+                    asm volatile("" ::: "memory");   // a real branch (rare lanes): not if-converted into every pixel
 #pragma unroll
-                for (int k = 0; k < 9; ++k) consider(k);
-            } else {
+                    for (int k = 0; k < 9; ++k) consider(k);
+                } else {
 #pragma unroll
-                for (int k = 0; k < SDM_MAX_ORI; ++k)
-                    if (k < nori) consider(k);
+                    for (int k = 0; k < SDM_MAX_ORI; ++k)
+                        if (k < nori) consider(k);
+                }
             }
             gout = grad;
             return b0;
