@@ -340,18 +340,30 @@ class Cascade(Workload):
         return roof, extra
 
     def single_frame_latency(self, n=400):
-        """one frame resident in HBM -> its detections on the host, one frame at a time (fd_pyramid_update + fd_detect_five_stage)"""
+        """one frame resident in HBM -> its detections on the host, one frame at a time: Detector::detect(image) of the reference =
+        fd_detect_five_stage_image (pyramid update + five-stage cascade in one call)"""
         capi, ctx = self.capi, self.env.ctx
-        pyr, wvm = self.pyrs[0], self.wvms[0]
+        det = capi.FiveStageImage(ctx, self.pyrs[0], self.wvms[0], self.svm)
         lat = []
         for i in range(n + 40):
             t0 = time.perf_counter()
-            pyr.update_device(self.dframes[i % self.NFR].data_ptr(), self.W, self.H, 3)
-            capi.detect_five_stage(ctx, pyr, wvm, self.svm)
+            det.detect_device(self.dptrs[i % self.NFR], self.W, self.H, 3)
             lat.append((time.perf_counter() - t0) * 1e6)
         lat = np.array(lat[40:])
+        # rounds 1-3 measured the same work as two calls through the binding (fd_pyramid_update, then fd_detect_five_stage)
+        pyr, wvm = self.pyrs[0], self.wvms[0]
+        lat2 = []
+        for i in range(n // 2 + 40):
+            t0 = time.perf_counter()
+            pyr.update_device(self.dptrs[i % self.NFR], self.W, self.H, 3)
+            capi.detect_five_stage(ctx, pyr, wvm, self.svm)
+            lat2.append((time.perf_counter() - t0) * 1e6)
+        lat2 = np.array(lat2[40:])
         return dict(p50=float(np.percentile(lat, 50)), p99=float(np.percentile(lat, 99)), frames=n,
-                    what="blocking per frame through the Python ctypes binding: pyramid update + five-stage cascade, detections delivered")
+                    what="blocking per frame through the Python ctypes binding: fd_detect_five_stage_image (pyramid update + five-stage cascade in "
+                         "one call, the reference's Detector::detect(image)), detections delivered",
+                    two_calls=dict(p50=float(np.percentile(lat2, 50)), p99=float(np.percentile(lat2, 99)),
+                                   what="fd_pyramid_update + fd_detect_five_stage as two calls (the figure of rounds 1-3)"))
 
     def cpu_baseline(self):
         from oracle import pyoracle as O

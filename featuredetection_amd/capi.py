@@ -161,6 +161,8 @@ _SIGS = {
                                 C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
     "fd_detect_five_stage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
+    "fd_detect_five_stage_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                             C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
     "fd_overlap_elimination": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.POINTER(C.c_int)]),
     "fd_block_nms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "fd_hog_feature_length": (C.c_int, [C.POINTER(fd_hog_params)]),
@@ -573,6 +575,35 @@ def detect_five_stage(ctx, pyr, wvm, svm, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1,
     ctx.check(lib().fd_detect_five_stage(ctx.h, pyr.h, wvm.h, svm.h, oe_dist, oe_ratio, sx, sy, _ptr(r), _ptr(out), cap,
                                          C.byref(cnt), _ptr(stages)))
     return out[:cnt.value], stages
+
+
+class FiveStageImage:
+    """fd_detect_five_stage_image with preallocated result buffers: Detector::detect(image) for one frame after the other (the output
+    arrays are reused: copy what must outlive the next call)"""
+
+    def __init__(self, ctx, pyr, wvm, svm, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1, cap=4096):
+        self.ctx, self.pyr, self.wvm, self.svm = ctx, pyr, wvm, svm
+        self.args = (oe_dist, oe_ratio, sx, sy)
+        self.cap = cap
+        self.out = np.zeros(cap, DET_DTYPE)
+        self.cnt = C.c_int()
+        self.stages = np.zeros(4, np.int32)
+        self._fn = lib().fd_detect_five_stage_image
+        self._outp, self._stp, self._cntp = _ptr(self.out), _ptr(self.stages), C.byref(self.cnt)
+
+    def detect_device(self, dev_ptr, w, h, ch):
+        a = self.args
+        self.ctx.check(self._fn(self.ctx.h, self.pyr.h, self.wvm.h, self.svm.h, C.c_void_p(dev_ptr), w, h, ch, 1, a[0], a[1], a[2], a[3], None,
+                                self._outp, self.cap, self._cntp, self._stp))
+        return self.out[:self.cnt.value], self.stages
+
+    def detect(self, image):
+        image = np.ascontiguousarray(image, np.uint8)
+        ch = 1 if image.ndim == 2 else image.shape[2]
+        a = self.args
+        self.ctx.check(self._fn(self.ctx.h, self.pyr.h, self.wvm.h, self.svm.h, _ptr(image), image.shape[1], image.shape[0], ch, 0, a[0], a[1], a[2], a[3],
+                                None, self._outp, self.cap, self._cntp, self._stp))
+        return self.out[:self.cnt.value], self.stages
 
 
 def detect_five_stage_frames(ctx, pyr, wvm, svm, nframes, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1, roi=None, cap=256):

@@ -41,6 +41,8 @@ struct FstIO {
     const unsigned int* posCount;   // their number (written by stage B's last workgroup)
     unsigned int posCap;
     FstHdr* hdr;
+    unsigned int* frameCount;       // [nimg] positives of every frame (k_wvb_exit counted them; this kernel clears its frame's counter)
+    const uint32_t* frameList;      // [nimg][FST_NMAX] their slots in pos
     uint32_t* slots;                // [posCap] device: patch slots of the survivors, frame after frame in sweep order -> the SVM kernel
     FstKeep* keep;                  // [posCap] pinned host memory: the same survivors for the host's result records
     FstFrame* frames;               // [nimg] pinned host memory
@@ -84,18 +86,19 @@ __global__ __launch_bounds__(256) void k_fs_oe(FstTable T, FstIO io) {
         if (tid == 0) sL[l] = T.l[l];
     __syncthreads();
     FST_T(0);
-    // ---- 1. this frame's positives
+    // ---- 1. this frame's positives: k_wvb_exit filed their slots under the frame (with every workgroup scanning all records of a 64-frame
+    //         call the scan alone was 13 us: 64 CUs pulling the same lines).  Ids beyond 32 bits cannot occur here (the launcher checks).
     const unsigned int npos = min(*io.posCount, io.posCap);
-    for (unsigned int i = tid; i < npos; i += 256) {
-        const PosRec r = io.pos[i];
-        if (r.wid_hi) { atomicOr(&flags, FST_WIDE_ID); continue; }
-        unsigned int f = T.nimg > 1 ? __umulhi(r.wid_lo, T.magic) : 0u;
-        unsigned int local = r.wid_lo - f * T.perImage;
-        if (T.nimg > 1 && local >= T.perImage) { local -= T.perImage; ++f; }
-        if (f != frame) continue;
-        const unsigned int e = atomicAdd(&cnt, 1u);
-        if (e < (unsigned int)FST_NMAX) { eSlot[e] = i; eWid[e] = local; eFoutBits[e] = __float_as_uint(r.fout); }
+    const unsigned int nmine = io.frameCount[frame];
+    for (unsigned int e = tid; e < min(nmine, (unsigned int)FST_NMAX); e += 256) {
+        const unsigned int i = io.frameList[(size_t)frame * FST_NMAX + e];
+        const PosRec r = io.pos[i < npos ? i : 0];
+        if (r.wid_hi || i >= npos) { atomicOr(&flags, FST_WIDE_ID); continue; }
+        eSlot[e] = i;
+        eWid[e] = T.nimg > 1 ? r.wid_lo - frame * T.perImage : r.wid_lo;
+        eFoutBits[e] = __float_as_uint(r.fout);
     }
+    if (tid == 0) { cnt = nmine; io.frameCount[frame] = 0u; }   // the counter is this workgroup's: clean for the next run
     __syncthreads();
     const unsigned int n = cnt;
     unsigned int fl = flags;

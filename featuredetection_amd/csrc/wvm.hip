@@ -199,6 +199,7 @@ struct fd_wvm {
     bool tailWanted = false;         // set by the five-stage entry points before the launch
     bool tailRun = false;            // the run in flight keeps its positives on the device and is followed by k_fs_oe
     DevBuf fstHdr, fstSlots;         // FstHdr + the positive count stage B leaves; the SVM's slot list
+    DevBuf fstFrameCount, fstFrameList;   // positives per frame and their slots (filled by k_wvb_exit, consumed and cleared by k_fs_oe)
     HostBuf h_fst;                   // pinned: [hostHdr 16 B | FstFrame x frames | FstKeep x pos_cap | double x pos_cap]
     int64_t fstLaunched = 0;         // vectors the SVM launch of the run in flight covers
     int64_t fstPrevKeep = -1;        // survivors of the previous run (sizes the next SVM launch)
@@ -444,6 +445,12 @@ struct CascadeOut {
     // five-stage tail on the device (fs_tail.hpp): `pos` stays in device memory, and stage B's last workgroup leaves the positive
     // count here for the overlap-elimination kernel queued behind it (the header's own counter is cleared for the next run)
     unsigned int* tail_count = nullptr;
+    // ... and files every positive under its frame for that kernel (one workgroup per frame; with every workgroup scanning all ~10 K
+    // records of a 64-frame call the scan was 13 us of hot-spotted L2 reads): frame_count[f] positives, their slots in
+    // frame_list[f * frame_cap ..]
+    unsigned int* frame_count = nullptr;
+    uint32_t* frame_list = nullptr;
+    unsigned int frame_cap = 0, frame_per_image = 0, frame_magic = 0, frame_n = 1;
 };
 
 struct WvbRelaunch {   // see fd_wvm::relaunch
@@ -2314,6 +2321,18 @@ static bool wvm_launch_head(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const WinTab
             HIP_CHECK(hipMemsetAsync(m->fstHdr.p, 0, 64, st));
         }
         o.tail_count = m->fstHdr.as<unsigned int>() + 8;   // behind the FstHdr words
+        const int nimg = wt.nimg > 1 ? wt.nimg : 1;
+        if (!m->fstFrameCount.p) {
+            m->fstFrameCount.reserve(sizeof(unsigned int) * FD_MAX_FRAMES);
+            HIP_CHECK(hipMemsetAsync(m->fstFrameCount.p, 0, sizeof(unsigned int) * FD_MAX_FRAMES, st));
+        }
+        m->fstFrameList.reserve(sizeof(uint32_t) * (size_t)FST_NMAX * nimg);
+        o.frame_count = m->fstFrameCount.as<unsigned int>();
+        o.frame_list = m->fstFrameList.as<uint32_t>();
+        o.frame_cap = (unsigned int)FST_NMAX;
+        o.frame_n = (unsigned int)nimg;
+        o.frame_per_image = (unsigned int)(wt.total / nimg);
+        o.frame_magic = o.frame_per_image ? 0xffffffffu / o.frame_per_image : 0u;
     }
     o.pos_patches = m->pos_patches.as<uint8_t>();
     o.pos_count = m->pos.as<unsigned int>();        // header word 0
@@ -2418,7 +2437,9 @@ void fd_wvm_finish(fd_ctx* ctx, fd_wvm* m, WvmRun& run) {
             HIP_CHECK(hipMemsetAsync(m->sbCnt.p, 0, 64, R->st));
             if (m->zcRun) *m->h_pos.as<unsigned int>() = 0xffffffffu;
             m->sbDeep = deep;
-            launch_cascade<false>(ctx, R->st, run.total, m, R->arena, R->wt, R->o, true);   // stage B only
+            CascadeOut o2 = R->o;   // no k_fs_oe follows this run: it must not file positives under frames (the host does stages 2-5)
+            o2.frame_list = nullptr; o2.frame_count = nullptr; o2.tail_count = nullptr;
+            launch_cascade<false>(ctx, R->st, run.total, m, R->arena, R->wt, o2, true);   // stage B only
             HIP_CHECK(hipGetLastError());
             if (!m->zcRun) {
                 const size_t firstChunk = (size_t)std::min<int64_t>(m->pos_cap, WVM_FIRST_CHUNK);
@@ -2864,10 +2885,14 @@ static void five_stage_check(const fd_wvm* m, const fd_svm* svm) {
 // ---- stages 2-3 on the device (fs_tail.hpp) ------------------------------------------------------------------------------------
 // Whether a five-stage run of (m, svm) can keep its tail on the device: the cascade ends in the dense stage B with its zero-copy
 // header, the second classifier has the u8 RBF MFMA kernel, and the window ids of the call fit 32 bits.  FD_FS_TAIL=0: never.
-static bool fst_possible(const fd_wvm* m, const fd_svm* svm) {
-    const char* e = getenv("FD_FS_TAIL");   // read per call: tests toggle it
-    const bool off = e && atoi(e) == 0;
-    return !off && m->wvbOk && m->dev.numUsed > WVM_LCAP && fd_svm_u8_mfma_available(svm);
+static bool fst_possible(const fd_wvm* m, const fd_svm* svm, int nimg) {
+    // FD_FS_TAIL (read per call: tests toggle it): 0 never, 1 always, unset: for multi-frame calls only.  A single frame has ~150
+    // positives: the host sorts and sweeps them in ~7 us, less than k_fs_oe's launch + its 15 us (measured: 155 vs 167 us per blocking
+    // single-frame call); a 64-frame call has ~10 K, 0.7 ms of host work that the device does in the shadow of the next call's kernels.
+    const char* e = getenv("FD_FS_TAIL");
+    const int mode = e ? atoi(e) : -1;
+    if (mode == 0 || (mode != 1 && nimg < 2)) return false;
+    return m->wvbOk && m->dev.numUsed > WVM_LCAP && fd_svm_u8_mfma_available(svm);
 }
 static size_t fst_host_offsets(int nimg, int64_t cap, size_t& keepOff, size_t& distOff) {
     keepOff = (16 + sizeof(FstFrame) * (size_t)nimg + 15) & ~(size_t)15;
@@ -2904,6 +2929,8 @@ static void fst_launch(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm* m, co
     io.posCap = (unsigned int)m->pos_cap;
     io.hdr = m->fstHdr.as<FstHdr>();
     io.slots = m->fstSlots.as<uint32_t>();
+    io.frameCount = m->fstFrameCount.as<unsigned int>();
+    io.frameList = m->fstFrameList.as<uint32_t>();
     io.hostHdr = reinterpret_cast<uint32_t*>(hb);
     io.frames = reinterpret_cast<FstFrame*>(hb + 16);
     io.keep = reinterpret_cast<FstKeep*>(hb + keepOff);
@@ -2982,7 +3009,7 @@ int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const f
         // stage 1: WVM over all windows (SlidingWindowDetector::detect); stages 2-3 (overlap elimination, SVM) are queued behind it on
         // the device where the model allows (fs_tail.hpp): one wait instead of two round trips
         WvmRun run;
-        m->tailWanted = fst_possible(m, svm);
+        m->tailWanted = fst_possible(m, svm, 1);
         fd_wvm_launch(ctx, p, m, sx, sy, roi, false, run, ctx->kernel_timing);
         if (m->tailRun) {
             fst_launch(ctx, ctx->stream, p, m, svm, run, oe_dist, oe_ratio, sx, sy);
@@ -3008,6 +3035,22 @@ int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const f
         fd_wvm_finish(ctx, m, run);
         five_stage_tail(ctx, p, m, svm, run, oe_dist, oe_ratio, sx, sy, roi, ctx->stream, out, cap, count, stage_counts);
     });
+}
+
+// Detector::detect(const Mat& image) (Detector.hpp:59; FiveStageSlidingWindowDetector.cpp:187-190: update the extractor with the image,
+// then detect): the pyramid update and the detection of ONE frame as one entry point -- what a caller of the reference's interface does
+// per image, without a second trip through the binding between the two halves.
+int fd_detect_five_stage_image(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm, const fd_svm* svm, const uint8_t* image, int width, int height,
+                               int channels, int image_is_device, float oe_dist, float oe_ratio, int sx, int sy, const int* roi, fd_detection* out,
+                               int cap, int* count, int32_t* stage_counts) {
+    const int rc = fd_guard(ctx, [&] {
+        if (!ctx || !p || !image) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_image: NULL argument");
+        if (p->ctx != ctx) FD_THROW(FD_ERR_INVALID_ARGUMENT, "objects belong to different contexts");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        fd_pyramid_update_on(p, image, width, height, channels, image_is_device, ctx->stream);
+    });
+    if (rc != FD_OK) return rc;
+    return fd_detect_five_stage(ctx, p, wvm, svm, oe_dist, oe_ratio, sx, sy, roi, out, cap, count, stage_counts);
 }
 
 // FiveStageSlidingWindowDetector::detect on every frame of a multi-frame pyramid (fd_pyramid_set_frames /
@@ -3039,7 +3082,7 @@ static void five_stage_frames_begin(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wv
     t.has_roi = roi != nullptr;
     if (roi) std::memcpy(t.roi, roi, sizeof(t.roi));
     five_stage_check(t.m, svm);
-    t.m->tailWanted = fst_possible(t.m, svm);
+    t.m->tailWanted = fst_possible(t.m, svm, p->nimg);
     fd_wvm_launch(ctx, p, t.m, sx, sy, roi, false, t.run, ctx->kernel_timing);   // one cascade run over the windows of all frames
     t.tail = t.m->tailRun;
     if (t.tail) fst_launch(ctx, ctx->stream, p, t.m, svm, t.run, oe_dist, oe_ratio, sx, sy);   // overlap elimination + SVM behind it, no host in between

@@ -50,13 +50,14 @@ __device__ __forceinline__ unsigned int wvb_count(const unsigned int* countPtr, 
 // Tiles of 64 queued windows stay on one XCD through the kernels of a phase: tile t belongs to XCD t % 8, and workgroup b runs on XCD
 // b % 8 (the observed dispatch order; only speed depends on it).  The eight L2s are not coherent with each other, so state written
 // on one XCD and read on another comes back from memory (1-2 us per dependent round trip instead of an L2 hit): k_wvb_sums spent
-// 23 us per unit mostly waiting for the K rows k_wvb_chain had written elsewhere.  Grids that are not a multiple of 8 fall back to
-// the plain enumeration.
+// 23 us per unit mostly waiting for the K rows k_wvb_chain had written elsewhere.  Grids that are not a multiple of 8, and queues of
+// fewer than 64 tiles, take the plain enumeration (a single frame queues 3 tiles: pinned to their XCDs, its 35 row blocks of
+// k_wvb_sums ran on 5 workgroups instead of 35 -- 50 instead of 14 us).
 struct WvbXcd {
     int xcd, wg, nwg, ntl;
     bool on;
     __device__ __forceinline__ WvbXcd(int ntiles) {
-        on = (gridDim.x & 7u) == 0u;
+        on = (gridDim.x & 7u) == 0u && ntiles >= 64;   // a handful of tiles (one frame) must spread over all workgroups, not over an eighth of them
         xcd = on ? (int)(blockIdx.x & 7u) : 0;
         wg = on ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
         nwg = on ? (int)(gridDim.x >> 3) : (int)gridDim.x;
@@ -618,6 +619,7 @@ __device__ __forceinline__ void wvb_finalize(const CascadeOut& o, const WvbState
 // is copied to the other set -- the four wavefronts share the rows / patch slots, all loads of a batch in flight together.
 __global__ __launch_bounds__(256) void k_wvb_exit(WvbDev mv, WvbState s, CascadeOut o, int phase, const unsigned int* countPtr, unsigned int* nextCount) {
     __shared__ unsigned int sBase[2];
+    __shared__ unsigned int sFrame[2][64];     // five-stage tail: the tile's positives per frame, and where each frame's run starts in its list
     __shared__ unsigned char sLaneOf[2][64];   // lane of the r-th survivor / positive of the tile
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -753,6 +755,26 @@ __global__ __launch_bounds__(256) void k_wvb_exit(WvbDev mv, WvbState s, Cascade
         // the positives' records last: with the zero-copy read-back they are stores to host memory, and anything that waits for a
         // later load would wait for their PCIe round trip as well
         if (pmask && wave == 0 && positive && pbase + prank < o.pos_cap) o.pos[pbase + prank] = PosRec{(uint32_t)wid, (uint32_t)(wid >> 32), exitk, fout};
+        if (o.frame_list && wave == 0 && pmask) {
+            // five-stage tail on the device: every positive's slot goes to its frame's list (CascadeOut).  The tile's positives are
+            // counted per frame in LDS first (a tile of the queue mixes many frames), then lane f adds the tile's count of frame f to the
+            // frame's counter: ONE device-memory round trip per tile, whatever the number of frames in it.  (One returning atomic per
+            // positive: 150 on each of 64 addresses, +19 us; one per (tile, frame) in a loop: ~8 dependent round trips per tile, +11 us.)
+            unsigned int f = o.frame_n > 1 ? __umulhi((unsigned int)wid, o.frame_magic) : 0u;
+            if (o.frame_n > 1 && (unsigned int)wid - f * o.frame_per_image >= o.frame_per_image) ++f;
+            const bool mine = positive && pbase + prank < o.pos_cap && f < o.frame_n;
+            sFrame[0][lane] = 0u;
+            wave_sync();
+            const unsigned int rank = mine ? atomicAdd(&sFrame[0][f], 1u) : 0u;
+            wave_sync();
+            const unsigned int c = sFrame[0][lane];   // lane == frame (at most 64 frames per call)
+            sFrame[1][lane] = (c && (unsigned int)lane < o.frame_n) ? atomicAdd(o.frame_count + lane, c) : 0u;
+            wave_sync();
+            if (mine) {
+                const unsigned int j = sFrame[1][f] + rank;
+                if (j < o.frame_cap) o.frame_list[(size_t)f * o.frame_cap + j] = pbase + prank;
+            }
+        }
     }
     WVB_T(te4);
     if (phase + 1 == mv.nphase) wvb_finalize(o, s);

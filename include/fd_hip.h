@@ -181,6 +181,11 @@ int fd_detect_wvm(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm, int step_x, int
 int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm, const fd_svm* svm, float oe_dist,
                          float oe_ratio, int step_x, int step_y, const int* roi, fd_detection* out, int cap,
                          int* count, int32_t* stage_counts);
+/* detection::Detector::detect(const Mat& image) (Detector.hpp:59; FiveStageSlidingWindowDetector.cpp:187-190 updates its extractor
+ * with the image and detects): fd_pyramid_update + fd_detect_five_stage in one call. */
+int fd_detect_five_stage_image(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm, const fd_svm* svm, const uint8_t* image, int width,
+                               int height, int channels, int image_is_device, float oe_dist, float oe_ratio, int step_x, int step_y,
+                               const int* roi, fd_detection* out, int cap, int* count, int32_t* stage_counts);
 /* Several frames of identical size in ONE pyramid, for the small-frame regime where the per-frame chain of dependent launches
  * (pyramid, cascade, SVM) bounds the throughput: fd_pyramid_set_frames(p, n) (1..64; gray pyramids only) makes p hold n frames,
  * fd_pyramid_update_frames builds all of them with one launch per pyramid stage, and fd_detect_five_stage_frames runs

@@ -287,6 +287,7 @@ def test_device_overlap_elimination_equals_the_host_path(oracle, capi, ctx, synt
     wo, so = oracle.Wvm(wvm_m), oracle.Svm(svm_m)
     po = oracle.Pyramid(**FF)
     p1 = capi.Pyramid(ctx, **FF)
+    monkeypatch.setenv("FD_FS_TAIL", "1")   # single-frame calls take the host tail by default (it is faster for ~150 positives)
     for f in (0, 7, 13, 23):
         po.update(frames[f])
         do, sto = oracle.five_stage(po, wo, so)
@@ -303,11 +304,12 @@ def test_device_overlap_elimination_equals_the_host_path(oracle, capi, ctx, synt
 
 
 @pytest.mark.parametrize("reps,expect", [((2, 3), 1), ((4, 5), 2)])
-def test_device_overlap_elimination_gives_up_on_ties(oracle, capi, ctx, synth, reps, expect):
+def test_device_overlap_elimination_gives_up_on_ties(oracle, capi, ctx, synth, monkeypatch, reps, expect):
     """The reference orders the positives with std::sort on the probability; what it does with equal keys is a property of that sort,
     which the device kernel cannot reproduce.  A frame of repeated tiles on a scale-1 pyramid gives windows with identical pixels, hence
     identical outputs: k_fs_oe must flag the frame (state 1) and the host's elimination must produce the oracle's detections.  The larger
     frame has more positives than the kernel holds per frame (state 2): same fallback."""
+    monkeypatch.setenv("FD_FS_TAIL", "1")   # the device tail also for this single-frame call
     rng = np.random.default_rng(3)
     tile = synth.make_frame(48, 40, seed=11)
     frame = np.tile(tile, (reps[0], reps[1], 1))
@@ -328,3 +330,30 @@ def test_device_overlap_elimination_gives_up_on_ties(oracle, capi, ctx, synth, r
     for fld in ("cx", "cy", "w", "h"):
         assert np.array_equal(dg[fld], do[fld]), fld
     wg.close(); sg.close(); pg.close()
+
+
+def test_detect_image_equals_update_then_detect(oracle, capi, ctx, synth, small_models):
+    """fd_detect_five_stage_image (Detector::detect(const Mat&), Detector.hpp:59): the pyramid update and the detection in one call give
+    what the two calls give, for host and device-resident images, frame after frame on the same handles."""
+    import torch
+    wvm, svm = small_models
+    pg = capi.Pyramid(ctx, **FF)
+    pg2 = capi.Pyramid(ctx, **FF)
+    wg, sg = capi.Wvm(ctx, wvm), capi.Svm(ctx, svm)
+    one = capi.FiveStageImage(ctx, pg, wg, sg)
+    po = oracle.Pyramid(**FF)
+    for seed in (5, 6, 7):
+        frame = synth.make_frame(640, 480, seed=seed)
+        d1, st1 = one.detect(frame)
+        d1, st1 = d1.copy(), st1.copy()
+        dev = torch.from_numpy(frame).cuda()
+        d3, st3 = one.detect_device(dev.data_ptr(), 640, 480, 3)
+        pg2.update(frame)
+        d2, st2 = capi.detect_five_stage(ctx, pg2, wg, sg)
+        assert np.array_equal(st1, st2) and d1.tobytes() == d2.tobytes()
+        assert np.array_equal(st3, st2) and d3.tobytes() == d2.tobytes()
+        po.update(frame)
+        do, sto = oracle.five_stage(po, oracle.Wvm(wvm), oracle.Svm(svm))
+        assert np.array_equal(st1, sto)
+    for h in (wg, sg, pg, pg2):
+        h.close()

@@ -1,5 +1,5 @@
 """Single-frame latency of the headline detector: one 640x480 BGR frame resident in HBM -> detections on the host, one frame at a
-time (fd_pyramid_update + fd_detect_five_stage, blocking).  Prints p50 / p90 / p99 over N frames and the stage split from FD_TRACE-free
+time (fd_pyramid_update + fd_detect_five_stage, blocking; and the same through the one-call entry point fd_detect_five_stage_image).  Prints p50 / p90 / p99 over N frames and the stage split from FD_TRACE-free
 host timers."""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -35,5 +35,16 @@ for i in range(N):
     lat.append((t2 - t0) * 1e6)
     tu.append((t1 - t0) * 1e6)
 lat = np.array(lat); tu = np.array(tu)
+one_call = capi.FiveStageImage(ctx, pyr, w, s)
+lat2 = []
+for i in range(50):
+    one_call.detect_device(frames[i % 8].data_ptr(), 640, 480, 3)
+for i in range(N):
+    t0 = time.perf_counter()
+    d2, st2 = one_call.detect_device(frames[i % 8].data_ptr(), 640, 480, 3)
+    lat2.append((time.perf_counter() - t0) * 1e6)
+lat2 = np.array(lat2)
+print("fd_detect_five_stage_image (Detector::detect(image): update + detect in one call) us: p50 %.1f p90 %.1f p99 %.1f mean %.1f"
+      % (np.percentile(lat2, 50), np.percentile(lat2, 90), np.percentile(lat2, 99), lat2.mean()))
 print("single-frame latency us: p50 %.1f p90 %.1f p99 %.1f mean %.1f (pyramid-update call returns after %.1f us); detections/frame %d; %.1f Mpatches/s at batch 1"
       % (np.percentile(lat, 50), np.percentile(lat, 90), np.percentile(lat, 99), lat.mean(), np.median(tu), len(d), 16185 / np.percentile(lat, 50)))

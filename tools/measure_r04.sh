@@ -40,7 +40,7 @@ if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
       i=$((i+1))
       timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc_${wl}_$i -- $CMD > /dev/null 2> $O/pmc_${wl}_$i.err
     done
-    K=k_wv,k_resize,k_pyrdown,k_frames_to_gray,k_svm_u8; [ $wl = sdm ] && K=k_sdm_descriptors; [ $wl = hog_svm ] && K=k_svm_rbf_mfma,k_hog,k_resize,k_pyrdown,k_gradbin,k_sum,k_frames_to_gray,k_bgr2gray
+    K=k_wv,k_resize,k_pyrdown,k_frames_to_gray,k_svm_u8,k_fs_oe; [ $wl = sdm ] && K=k_sdm_descriptors; [ $wl = hog_svm ] && K=k_svm_rbf_mfma,k_hog,k_resize,k_pyrdown,k_gradbin,k_sum,k_frames_to_gray,k_bgr2gray
     python $R/tools/pmc_summary.py $wl $O/r04_pmc.json $K "rocprofv3 --kernel-trace --pmc <group> (4 separate passes) -- python bench.py --workload $wl --also none --steps $S --warmup 1 $FP --no-cpu-baseline --no-probe; git head $HEAD" $O/pmc_${wl}_1 $O/pmc_${wl}_2 $O/pmc_${wl}_3 $O/pmc_${wl}_4 > $O/pmc_$wl.summary 2>&1
     rm -rf $O/pmc_${wl}_1 $O/pmc_${wl}_2 $O/pmc_${wl}_3 $O/pmc_${wl}_4
   done
