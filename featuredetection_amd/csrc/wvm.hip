@@ -2017,6 +2017,15 @@ static bool wvb_tables(const fd_wvm_model* md, int NU, WvbTables& T) {
         }
     }
     T.ntile = ntile;
+    {   // k_wvb_chain2 computes a level's tile instead of reading it from the record: classes 0 .. rem - 1 have G generations, tiles of a class are consecutive
+        const int LPT = 32 / RPL, rem = NU - (G - 1) * NP;
+        const int tf = (G + LPT - 1) / LPT, tsh = (G - 1 + LPT - 1) / LPT;
+        for (int k = 0; k < NU; ++k) {
+            const int n = k % NP, g = k / NP;
+            const int tile = std::min(n, rem) * tf + std::max(0, n - rem) * tsh + g / LPT;
+            if (T.lvl[4 * (size_t)k] != tile || T.lvl[4 * (size_t)k + 1] != (g % LPT) * RPL) return false;
+        }
+    }
     T.A.resize((size_t)(ntile + 1) * KSP * 64 * 16, 0);   // a spare zero tile: the operand prefetch runs one tile ahead
     // the chain's per-level records (k_wvb_chain): one dword per lane
     T.rec.assign((size_t)F * 64, 0);

@@ -291,6 +291,29 @@ __global__ __launch_bounds__(256, 2) void k_wvb_chain(WvbDev mv, WvbState s, int
     WVB_FLUSH;
 }
 
+// Window operands of four k-steps (2 N-tiles each) from LDS with all eight ds_read_b128 in flight, and the wait that hands them to the
+// MFMAs.  Left to the compiler every read was waited for one MFMA ahead (register pressure): 26 exposed LDS round trips per tile,
+// 1.2 of a tile's 1.8 us.  lgkmcnt retires LDS reads in order, so "at most N outstanding" with the next batch's N = 8 reads behind
+// this one means this batch has arrived whatever else the compiler has in flight.
+template <int OFF>
+__device__ __forceinline__ void wvb_rd8(wvb_v4i (&b)[8], unsigned int a0, unsigned int a1) {
+    asm volatile(
+        "ds_read_b128 %0, %8 offset:%10\n ds_read_b128 %1, %9 offset:%10\n"
+        "ds_read_b128 %2, %8 offset:%11\n ds_read_b128 %3, %9 offset:%11\n"
+        "ds_read_b128 %4, %8 offset:%12\n ds_read_b128 %5, %9 offset:%12\n"
+        "ds_read_b128 %6, %8 offset:%13\n ds_read_b128 %7, %9 offset:%13\n"
+        : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6]), "=&v"(b[7])
+        : "v"(a0), "v"(a1), "n"(OFF), "n"(OFF + 32), "n"(OFF + 64), "n"(OFF + 96));   // (no memory clobber: the level records' LDS
+                                                                                       // reads may move across; the tile is written
+                                                                                       // before a workgroup barrier and read-only after)
+}
+template <int N>
+__device__ __forceinline__ void wvb_wait8(wvb_v4i (&b)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7])
+                 : "n"(N));
+}
+
 // k_wvb_chain2 (round 4): the same unit -- one wavefront per (64 windows, class), four classes per workgroup -- on the fixed-slot
 // tables (wvb_tables: generation g of a class = slot g % LPT of the class's tile g / LPT, RPL rows per slot).  The rect sums of a tile
 // never leave the registers: v_permlane32_swap turns the two accumulators (rows x windows 0..31 / 32..63) into "every lane holds the
@@ -322,6 +345,41 @@ __global__ __launch_bounds__(256, 2) void k_wvb_chain2(WvbDev mv, WvbState s, in
         const int tl = unit / NQ, cq = unit - tl * NQ;   // neighbouring workgroups share the window tile (L2)
         const int t = X.tile(tl);
         WVB_T(tq0);
+        // Everything the unit needs from memory is requested at once -- the first tile's operand fragments, its level records, the
+        // windows' pixels -- instead of three dependent round trips (pixels -> records -> the tile id in the record -> fragments):
+        // tiles of a class are consecutive (wvb_tables), so the tile of generation g is a closed form.
+        const int cls = cq * 4 + wave;
+        const int gLast = cls < NP ? (NU - 1 - cls) / NP : 0;   // last generation of this class
+        const bool work = cls < NP && g0 <= gLast;
+        const int T0 = g0 / LPT, T1 = min(g1 - 1, gLast) / LPT;
+        int tile0;
+        {
+            const int G = (NU + NP - 1) / NP, rem = NU - (G - 1) * NP;   // classes 0 .. rem - 1 have G generations, the others G - 1
+            const int tf = (G + LPT - 1) / LPT, tsh = (G - 1 + LPT - 1) / LPT;
+            tile0 = min(cls, rem) * tf + max(0, cls - rem) * tsh;
+        }
+        wvb_v4i an[RING];
+        int rv[LPT];
+        auto loadRecs = [&](int T, int (&r)[LPT]) {
+            // level records of a tile of the class: slot j = generation T * LPT + j (one dword per lane each); past the class's last level
+            // the last level again (never used)
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) r[j] = mv.rec[(size_t)(min(T * LPT + j, gLast) * NP + min(cls, NP - 1)) * WVB_REC_DW + lane];
+        };
+        const unsigned int pos = (unsigned int)t * 64u + (unsigned int)lane;
+        const bool valid = pos < n;
+        float u = 0.f;
+        int2 ax = make_int2(0, 0);
+        if (work) {
+            const wvb_v4i* Ap = mv.A + (size_t)(tile0 + T0) * KSP * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < RING; ++q) an[q] = Ap[q * 64];
+            loadRecs(T0, rv);
+            if (valid) {
+                ax = s.aux[set][pos];
+                if (phase > 0) u = s.U[set][((size_t)t * NP + cls) * 64 + lane];
+            }
+        }
         __syncthreads();   // the previous unit's MFMA operand reads are done
         {
             const uint4* xg = reinterpret_cast<const uint4*>(s.X[set] + (size_t)t * 64 * DS);
@@ -341,26 +399,11 @@ __global__ __launch_bounds__(256, 2) void k_wvb_chain2(WvbDev mv, WvbState s, in
                 }
             }
         }
-        const int cls = cq * 4 + wave;
-        const unsigned int pos = (unsigned int)t * 64u + (unsigned int)lane;
-        const bool valid = pos < n;
-        float u = 0.f;
-        int sx_total = 0;
-        float sxx = 0.f;
-        if (cls < NP && valid) {
-            const int2 ax = s.aux[set][pos];
-            sx_total = ax.x;
-            sxx = __int_as_float(ax.y);
-            if (phase > 0) u = s.U[set][((size_t)t * NP + cls) * 64 + lane];
-            if (cls == 0) s.exitKey[pos] = ~0ull;   // k_wvb_sums of this phase takes the minimum over the failed levels
-        }
-        // level records of a tile of the class: slot j = generation T * LPT + j (one dword per lane each); past the class's last level
-        // the last level again (never used)
-        const int gLast = cls < NP ? (NU - 1 - cls) / NP : 0;   // last generation of this class
-        auto loadRecs = [&](int T, int (&rv)[LPT]) {
-#pragma unroll
-            for (int j = 0; j < LPT; ++j) rv[j] = mv.rec[(size_t)(min(T * LPT + j, gLast) * NP + min(cls, NP - 1)) * WVB_REC_DW + lane];
-        };
+        WVB_T(tqc);
+        WVB_ADD(8 * phase + 7, tqc - tq0);
+        const int sx_total = ax.x;
+        const float sxx = __int_as_float(ax.y);
+        if (cls == 0 && valid) s.exitKey[pos] = ~0ull;   // k_wvb_sums of this phase takes the minimum over the failed levels
         auto storeRecs = [&](int T, const int (&rv)[LPT]) {
 #pragma unroll
             for (int j = 0; j < LPT; ++j) Rw[((T & 1) * LPT + j) * WVB_REC_DW + lane] = rv[j];
@@ -369,43 +412,73 @@ __global__ __launch_bounds__(256, 2) void k_wvb_chain2(WvbDev mv, WvbState s, in
         WVB_T(tq1);
         WVB_ADD(8 * phase + 0, 1);
         WVB_ADD(8 * phase + 1, tq1 - tq0);
-        if (cls < NP && g0 <= gLast) {
-            const int T0 = g0 / LPT, T1 = min(g1 - 1, gLast) / LPT;
-            int rv[LPT];
-            loadRecs(T0, rv);
+        if (work) {
             storeRecs(T0, rv);
             wave_sync();
-            wvb_v4i an[RING];
-            {
-                const int tile0 = __builtin_amdgcn_readfirstlane(Rw[((T0 & 1) * LPT + (g0 - T0 * LPT)) * WVB_REC_DW]);   // tile of the phase's first level
-                const wvb_v4i* Ap = mv.A + (size_t)tile0 * KSP * 64 + lane;
+            // kernel values of the last chained tile, stored behind the next tile's contraction (kmask: its active levels, wave-uniform)
+            float kst[LPT];
+            unsigned int kmask = 0;
+            int kT = T0;
+            auto flushK = [&]() {
 #pragma unroll
-                for (int q = 0; q < RING; ++q) an[q] = Ap[q * 64];
-            }
+                for (int j = 0; j < LPT; ++j)
+                    if (((kmask >> j) & 1u) && valid) s.K[set][((size_t)t * NU + (kT * LPT + j) * NP + cls) * 64 + lane] = kst[j];
+                kmask = 0;
+            };
             for (int T = T0; T <= T1; ++T) {
                 const int* Rt = Rw + (T & 1) * LPT * WVB_REC_DW;
-                const int jFirst = T == T0 ? g0 - T0 * LPT : 0;
-                const int tile = __builtin_amdgcn_readfirstlane(Rt[jFirst * WVB_REC_DW]);
+                const int tile = tile0 + T;
                 WVB_T(tq2);
-                if (T < T1) loadRecs(T + 1, rv);   // in flight during the contraction
                 // ---- rect sums of the tile's 32 rows for the 64 windows: C[row][window] = sum_pixel M[row][pixel] * x[window][pixel].  The
-                // operand fragments stream from L2 through a ring of eight that runs one group ahead and wraps into the class's next tile
+                // operand fragments stream from L2 through a ring that runs one group ahead and wraps into the class's next tile
                 const wvb_v4i* Ap = mv.A + (size_t)tile * KSP * 64 + lane;
                 wvb_v16i acc0 = {}, acc1 = {};
-                const unsigned char* xb = wvb_lds + (lane & 31) * DS + (lane >> 5) * 16;
+                // LDS byte address of this lane's window row (windows lane & 31 and 32 + (lane & 31)), bytes 16 (lane >> 5) .. + 15 of a k-step
+                const unsigned int xa = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)wvb_lds + (unsigned int)((lane & 31) * DS + (lane >> 5) * 16);
+                // A group of RING k-steps is straight-line code: the fragments behind the patch (k-steps KS .. KSP - 1; KSP rounds KS up to
+                // eight, so every group has live steps) are zero in the table, and whatever those LDS reads return (the next window's row,
+                // the records behind the tile) adds an exact 0.  The window operands are read four k-steps ahead of their MFMAs.
                 for (int ks = 0; ks < KSP; ks += RING) {
+                    const unsigned int a0 = xa + (unsigned int)ks * 32u, a1 = a0 + 32u * (unsigned int)DS;
+                    wvb_v4i bq[2][8];
+                    // (the matrix pipe is what bounds a tile -- 38 cycles per MFMA, shared by the SIMD's two wavefronts -- so the last batch
+                    // of a group skips the k-steps behind the patch: 26 instead of 32 MFMAs for 20 x 20)
+                    auto mfma4 = [&](const wvb_v4i (&b)[8], int sub, bool last) {
 #pragma unroll
-                    for (int q = 0; q < RING; ++q) {
-                        const wvb_v4i a = an[q];
-                        an[q] = Ap[(ks + RING + q) * 64];   // past this tile: the next tile's fragments (a zero tile ends the table)
-                        if (ks + q < KS) {
-                            const wvb_v4i b0 = *reinterpret_cast<const wvb_v4i*>(xb + (ks + q) * 32);
-                            const wvb_v4i b1 = *reinterpret_cast<const wvb_v4i*>(xb + 32 * DS + (ks + q) * 32);
-                            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b0, acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1, acc1, 0, 0, 0);
+                        for (int i = 0; i < 4; ++i) {
+                            const int q = 4 * sub + i;
+                            const wvb_v4i a = an[q];
+                            an[q] = Ap[(ks + RING + q) * 64];   // past this tile: the next tile's fragments (a zero tile ends the table)
+                            if (!last || ks + q < KS) {   // wave-uniform
+                                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b[2 * i], acc0, 0, 0, 0);
+                                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b[2 * i + 1], acc1, 0, 0, 0);
+                            }
                         }
+                    };
+                    wvb_rd8<0>(bq[0], a0, a1);
+                    wvb_rd8<128>(bq[1], a0, a1);
+                    wvb_wait8<8>(bq[0]);
+                    mfma4(bq[0], 0, false);
+                    if constexpr (RING == 16) {
+                        wvb_rd8<256>(bq[0], a0, a1);
+                        wvb_wait8<8>(bq[1]);
+                        mfma4(bq[1], 1, false);
+                        wvb_rd8<384>(bq[1], a0, a1);
+                        wvb_wait8<8>(bq[0]);
+                        mfma4(bq[0], 2, false);
+                        wvb_wait8<0>(bq[1]);
+                        mfma4(bq[1], 3, true);
+                    } else {
+                        wvb_wait8<0>(bq[1]);
+                        mfma4(bq[1], 1, true);
                     }
                 }
+                // The next tile's level records are requested BEHIND the contraction: vmcnt retires in order, so requested in front of it
+                // (where they used to be) the first MFMA waited for their L2 round trip although it only needed fragments that had
+                // arrived a tile ago.  Here the levels' chain hides them.
+                __builtin_amdgcn_sched_barrier(0);
+                flushK();   // the previous tile's kernel values: a store issued just in front of the contraction would be waited for like a load
+                if (T < T1) loadRecs(T + 1, rv);
                 // acc0[r] / acc1[r]: row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of windows lane & 31 / 32 + (lane & 31).  After the swap every
                 // lane holds the rows of window `lane`: row R = (R & 4) ? acc1[i] : acc0[i], i = (R & 3) + 4 (R >> 3)
                 int a0[16], a1[16];
@@ -456,9 +529,10 @@ __global__ __launch_bounds__(256, 2) void k_wvb_chain2(WvbDev mv, WvbState s, in
                 // ---- the kernel values: independent again
 #pragma unroll
                 for (int j = 0; j < LPT; ++j) {
-                    const float Kk = (float)exp(arg[j]);
-                    if (act[j] && valid) s.K[set][((size_t)t * NU + (T * LPT + j) * NP + cls) * 64 + lane] = Kk;
+                    kst[j] = (float)exp(arg[j]);
+                    kmask |= act[j] ? 1u << j : 0u;
                 }
+                kT = T;
                 WVB_T(tq4);
                 WVB_ADD(8 * phase + 4, tq4 - tq3);
                 WVB_ADD(8 * phase + 6, LPT);
@@ -468,6 +542,7 @@ __global__ __launch_bounds__(256, 2) void k_wvb_chain2(WvbDev mv, WvbState s, in
                 WVB_T(tq5);
                 WVB_ADD(8 * phase + 2, tq5 - tq4);
             }
+            flushK();
             if (valid && phase + 1 < mv.nphase) s.U[set][((size_t)t * NP + cls) * 64 + lane] = u;
         }
         WVB_T(tq7);

@@ -36,6 +36,8 @@ for ph in range(3):
     if c[0]:
         print("chain phase %d: %d units/launch; per unit (thread 0 = wave 0): stage X %.2f us, records %.2f, GEMM %.2f, chain %.2f (%.1f levels, %.2f us/level), total %.2f us"
               % (ph, c[0] // N, c[1] * T / c[0], c[2] * T / c[0], c[3] * T / c[0], c[4] * T / c[0], c[6] / c[0], c[4] * T / max(c[6], 1), c[5] * T / c[0]))
+        if c[7]:
+            print("   of stage X: %.2f us until the windows' pixels are in LDS (behind the first tile's fragments and records in vmcnt order)" % (c[7] * T / c[0]))
 for ph in range(3):
     c = v[24 + 4 * ph:24 + 4 * ph + 4]
     if c[0]:
