@@ -347,14 +347,16 @@ __device__ __forceinline__ void fused_issue(FusedFetch& f, const uint8_t* __rest
     const int X0 = d.x & 0xffff, Y0 = (int)((uint32_t)d.x >> 16), ncol = d.y & 0xffff, nrow = (int)((uint32_t)d.y >> 16);
     const int gx0 = 2 * (d.z & 0xffff) * FT_W1 - 2;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool mine = 4 * lane < ncol;
-    const uint8_t* row = src + (uint32_t)((Y0 + wave) * sw);
     // A dword that hangs over the right edge of the image takes its last bytes from the next row (or, in the last row, from the arena
     // behind the gray image): they stand for columns >= sw, which no tap reads (the last column's right neighbour has weight 0).
+    // No predication: lanes right of the rectangle and rows below it load its last dword / last row again (valid addresses, values
+    // nobody reads) -- with a test per load the 19 loads were 19 basic blocks of exec-mask bookkeeping, 400 instructions per tile.
+    const uint32_t voff = (uint32_t)(4 * min(lane, (ncol - 1) >> 2) + X0);
+    const int rlast = nrow - 1;
 #pragma unroll
-    for (int q = 0; q < FS_LOADS; ++q, row += 4 * sw) {
-        f.v[q] = 0;
-        if (mine && wave + 4 * q < nrow) f.v[q] = ld_u32_unaligned(row + 4 * lane + X0);
+    for (int q = 0; q < FS_LOADS; ++q) {
+        const int r = min(wave + 4 * q, rlast);   // scalar
+        f.v[q] = ld_u32_unaligned(src + (uint32_t)((Y0 + r) * sw) + voff);
     }
     f.ex = tabs[jb.xtab + reflect101(gx0 + (int)(threadIdx.x & 127), jb.dw0)];
     {   // BORDER_REFLECT_101 of the resized rows the kept pyrDown rows reach (one reflection); rows further out only feed pyrDown
@@ -395,11 +397,11 @@ __global__ __launch_bounds__(256) void k_resize_down(uint8_t* __restrict__ arena
         const int x1 = (d.z & 0xffff) * FT_W1, y1 = (int)((uint32_t)d.z >> 16) * FT_H1;   // first pyrDown pixel of the tile
         const int gx0 = 2 * x1 - 2, gy0 = 2 * y1 - 2;                      // resized pixel of tile entry (0, 0), before the border reflection
         {   // the fetched source rectangle and row table -> LDS
-            if (4 * lane < ncol) {
+            // every lane stores its dword of every row (the stage has a dword per lane and FS_ROWS rows; what lies outside the
+            // rectangle is never read)
+            static_assert(4 * (FS_LOADS - 1) + 3 < FS_ROWS && FS_PITCH == 256, "stage holds a dword per lane for rows wave + 4 q");
 #pragma unroll
-                for (int q = 0; q < FS_LOADS; ++q)
-                    if (wave + 4 * q < nrow) *reinterpret_cast<uint32_t*>(&stage[(wave + 4 * q) * FS_PITCH + 4 * lane]) = f.v[q];
-            }
+            for (int q = 0; q < FS_LOADS; ++q) *reinterpret_cast<uint32_t*>(&stage[(wave + 4 * q) * FS_PITCH + 4 * lane]) = f.v[q];
         }
         const int2 ex = f.ex, ey = f.ey;
         PYR_T(p1);
