@@ -27,9 +27,11 @@ import sys
 import threading
 import time
 
-# eight hardware queues, so that the stream pool of the batch entry points does not share queues; read by
-# the HIP runtime when it initialises, i.e. at the first HIP call of the process
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# hardware queues of the HIP runtime (read when it initialises, i.e. at the first HIP call of the process).  Four, the runtime's
+# default, since round 4: with the device tail a multi-frame call is one chain of ~14 kernels on its own stream, and six such
+# streams on four queues ran 3 % faster than on eight (3062-3104 vs 2974-2998 Mpatches/s, five paired runs; 2, 3 and 5 queues lost
+# 5 %); the 15-detector batch (config 3) measures the same either way.  Rounds 1-3 set eight
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 
 import numpy as np
 
