@@ -494,11 +494,21 @@ __global__ __launch_bounds__(256) void k_resize_down(uint8_t* __restrict__ arena
 #endif
 }
 
+// BORDER_REFLECT_101 without branches for the coordinates a 5-tap pyrDown USES (two pixels out on either side): |p|, one reflection
+// at the far end, then a clamp.  Exact for every len >= 1 there (len 1: everything is 0; len 2: -2 -> 0, -1 -> 1, 2 -> 0); coordinates
+// further out only feed outputs outside the layer and may be anything valid.
+__device__ __forceinline__ int reflect_cf(int p, int len) {
+    int q = p < 0 ? -p : p;
+    q = q >= len ? 2 * len - 2 - q : q;
+    return min(max(q, 0), len - 1);
+}
+constexpr int PD_W = 62;   // pyrDown tile: 62 x 16 outputs = 127 x 35 source bytes = 32 dwords per row: two rows per wavefront load
 __global__ __launch_bounds__(256) void k_pyrdown_tiled(uint8_t* __restrict__ arena, DownJobs jobs, size_t imageStride) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[TL_ROWS * TL_PITCH];
     arena += (size_t)blockIdx.z * imageStride;   // blockIdx.z = frame of a multi-frame pyramid
     const int c = threadIdx.x & 63, rq = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // rq scalar: row offsets on the scalar unit
-    constexpr int NDW = (2 * TL_W + 3 + 3) / 4, NROWS = 2 * PD_TH + 3;   // 131 source columns, 35 source rows per tile
+    constexpr int NROWS = 2 * PD_TH + 3, PD_LD = (NROWS + 7) / 8;   // 35 source rows; a wavefront stages rows 2 (rq + 4 k) and the next
+    static_assert(2 * (3 + 4 * (PD_LD - 1)) + 1 < TL_ROWS && 128 <= TL_PITCH && 2 * PD_W + 3 <= 128, "pyrDown stage");
     for (int g = blockIdx.x; g < jobs.tile0[jobs.n]; g += gridDim.x) {   // flat list of the tiles of all jobs
         int ji = 0;
         while (ji + 1 < jobs.n && g >= jobs.tile0[ji + 1]) ++ji;
@@ -508,44 +518,43 @@ __global__ __launch_bounds__(256) void k_pyrdown_tiled(uint8_t* __restrict__ are
         const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
         const uint8_t* src = arena + jb.src_off;
         uint8_t* dst = arena + jb.dst_off;
-        const int tilesX = (dw + TL_W - 1) / TL_W;
+        const int tilesX = (dw + PD_W - 1) / PD_W;
         const int ty = t / tilesX, tx = t - ty * tilesX;
-        const int dx0 = tx * TL_W, dy0 = ty * PD_TH;
+        const int dx0 = tx * PD_W, dy0 = ty * PD_TH;
         const int X0 = 2 * dx0 - 2, Y0 = 2 * dy0 - 2;
-        {   // stage the 35 x 33 dwords of the source rectangle: flat element index, all loads of a thread in flight together (measured
-            // against one row per wavefront with lane == dword: 20 vs 24 us per launch, half the lanes idle there)
-            constexpr int PD_LD = (NROWS * NDW + 255) / 256;
+        {   // stage the source rectangle: lane = dword j of row 2 (rq + 4 k) + (lane >> 5).  No tests in the common path: the row is
+            // reflected in closed form, the column clamped into the row; only tiles on the left / right edge of the layer rebuild the
+            // dwords that hang over it from reflected bytes.  (Round 3 staged a flat element list -- a division by 33, two range
+            // tests and a loop-form reflection per element: 170 branches in the kernel, the staging was most of a tile's time.)
+            const int j4 = 4 * (c & 31), half = c >> 5;
+            const int xs = X0 + j4;
+            const int xc = min(max(xs, 0), max(sw - 4, 0));
+            const uint32_t lastDw = (uint32_t)max(sw * sh - 4, 0);
             uint32_t v[PD_LD];
 #pragma unroll
             for (int k = 0; k < PD_LD; ++k) {
-                const int e = threadIdx.x + 256 * k;
-                v[k] = 0;
-                if (e < NROWS * NDW) {
-                    const int r = e / NDW, j = e - r * NDW;
-                    const int xs = X0 + 4 * j;
-                    if (xs >= 0 && xs + 3 < sw) v[k] = ld_u32_unaligned(src + (uint32_t)(reflect1(Y0 + r, sh) * sw) + xs);
-                }
+                const int r = 2 * (rq + 4 * k) + half;
+                v[k] = ld_u32_unaligned(src + min((uint32_t)(reflect_cf(Y0 + r, sh) * sw + xc), lastDw));
             }
+            if (X0 < 0 || X0 + 128 > sw) {   // wave-uniform: an edge tile
+                if (!(xs >= 0 && xs + 3 < sw)) {
 #pragma unroll
-            for (int k = 0; k < PD_LD; ++k) {
-                const int e = threadIdx.x + 256 * k;
-                if (e < NROWS * NDW) {
-                    const int r = e / NDW, j = e - r * NDW;
-                    const int xs = X0 + 4 * j;
-                    uint32_t w = v[k];
-                    if (!(xs >= 0 && xs + 3 < sw)) {   // BORDER_REFLECT_101 columns
-                        const uint8_t* row = src + (uint32_t)(reflect1(Y0 + r, sh) * sw);
-                        w = 0;
+                    for (int k = 0; k < PD_LD; ++k) {
+                        const int r = 2 * (rq + 4 * k) + half;
+                        const uint8_t* row = src + (uint32_t)(reflect_cf(Y0 + r, sh) * sw);
+                        uint32_t w = 0;
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) w |= (uint32_t)row[reflect1(xs + b, sw)] << (8 * b);
+                        for (int b = 0; b < 4; ++b) w |= (uint32_t)row[reflect_cf(xs + b, sw)] << (8 * b);
+                        v[k] = w;
                     }
-                    *reinterpret_cast<uint32_t*>(&tile[r * TL_PITCH + 4 * j]) = w;
                 }
             }
+#pragma unroll
+            for (int k = 0; k < PD_LD; ++k) *reinterpret_cast<uint32_t*>(&tile[(2 * (rq + 4 * k) + half) * TL_PITCH + j4]) = v[k];
         }
         __syncthreads();
         const int x = dx0 + c;
-        if (x < dw) {
+        if (c < PD_W && x < dw) {
             constexpr int PR = PD_TH / 4;   // output rows per thread
             const uint8_t* T = tile + (2 * rq * PR) * TL_PITCH + 2 * c;
             int h[2 * PR + 3];
@@ -1064,7 +1073,7 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
             const HostLayer& S = p->all[k - 1];
             DownJob& j = dj.j[dj.n++];
             j.sw = S.w; j.sh = S.h; j.src_off = S.gray_off; j.dst_off = L.gray_off;
-            dj.tile0[dj.n] = dj.tile0[dj.n - 1] + ((L.w + TL_W - 1) / TL_W) * ((L.h + PD_TH - 1) / PD_TH);
+            dj.tile0[dj.n] = dj.tile0[dj.n - 1] + ((L.w + PD_W - 1) / PD_W) * ((L.h + PD_TH - 1) / PD_TH);
             if (dj.n == MAXJ) flush1();
         }
         flush1();
@@ -1086,7 +1095,7 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
             const HostLayer& S = p->all[k - 1];  // previous entry of the same chain
             DownJob& j = jobs.j[jobs.n++];
             j.sw = S.w; j.sh = S.h; j.src_off = S.gray_off; j.dst_off = L.gray_off;
-            jobs.tile0[jobs.n] = jobs.tile0[jobs.n - 1] + ((L.w + TL_W - 1) / TL_W) * ((L.h + PD_TH - 1) / PD_TH);
+            jobs.tile0[jobs.n] = jobs.tile0[jobs.n - 1] + ((L.w + PD_W - 1) / PD_W) * ((L.h + PD_TH - 1) / PD_TH);
             if (jobs.n == MAXJ) flush();
         }
         flush();
