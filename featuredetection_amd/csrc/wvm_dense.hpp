@@ -343,6 +343,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
 #ifdef FD_WVB_PROF
         pAcc[0] += pb0 - pa;
 #endif
+        unsigned int survBits = 0;   // bit s: the lane's window s of this column goes to the exact cascade
 #pragma unroll 1
         for (int step = 0; step < K; ++step) {
         const bool active = step < rows;
@@ -476,16 +477,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             else levels(std::integral_constant<int, 8>());
             undecided = (und >> lane) & 1ull;
         }
-        // ---- 6. survivors -> queue of the exact cascade (wave-aggregated)
-        {
-            const unsigned long long mask = __ballot(undecided);
-            if (mask) {
-                unsigned int base = 0;
-                if (lane == 0) base = atomicAdd(dv.qcount, (unsigned int)__popcll(mask));
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (undecided) dv.q[base + __popcll(mask & ((1ull << lane) - 1ull))] = wid0 + (int64_t)step * wl.nx;
-            }
-        }
+        survBits |= undecided ? 1u << step : 0u;
 #ifdef FD_WVB_PROF
         {
             const unsigned long long pe = __builtin_amdgcn_s_memtime();
@@ -493,6 +485,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         }
 #endif
         }   // windows of the column
+        // ---- 6. survivors -> queue of the exact cascade: ONE returning atomic per wavefront and column walk (it was one per window step:
+        // with a model that lets a quarter of the windows through, 48 K of them per 64-frame launch and each waited for on the spot --
+        // the launch took 231 instead of 126 us)
+        if (__ballot(survBits != 0)) {
+            unsigned int total = 0;
+            for (int st = 0; st < K; ++st) total += (unsigned int)__popcll(__ballot((survBits >> st) & 1u));
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(dv.qcount, total);
+            base = __builtin_amdgcn_readfirstlane(base);
+            for (int st = 0; st < K; ++st) {
+                const bool mine = (survBits >> st) & 1u;
+                const unsigned long long mask = __ballot(mine);
+                if (mine) dv.q[base + __popcll(mask & ((1ull << lane) - 1ull))] = wid0 + (int64_t)st * wl.nx;
+                base += (unsigned int)__popcll(mask);
+            }
+        }
         wave_sync();
     }
 #ifdef FD_WVB_PROF
