@@ -569,10 +569,6 @@ __global__ __launch_bounds__(256) void k_wvb_sums(WvbDev mv, WvbState s, int pha
     const int nrb = (k1 - k0 + 7) >> 3;
     const int set = phase & 1;
     constexpr size_t ks = 64;   // K[tile][level][64 windows]: a tile's history is one contiguous block
-#ifndef FD_WVB_KG
-#define FD_WVB_KG 16
-#endif
-    constexpr int KG = FD_WVB_KG;   // K rows per group of loads (two groups in flight)
     WVB_DECL(24 + 4 * phase);
     for (int unit = X.wg; unit < nquads * nrb; unit += X.nwg) {
         const int rb = nrb - 1 - unit / nquads, q = unit - (unit / nquads) * nquads;   // the longest rows first
@@ -594,39 +590,39 @@ __global__ __launch_bounds__(256) void k_wvb_sums(WvbDev mv, WvbState s, int pha
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = mv.negBias;
         // terms every row of the block takes (p < kb): groups of 16 K loads, the next group in flight while one is consumed
-        auto loadK = [&](float (&kv)[KG], int p0) {
+        auto loadK = [&](float (&kv)[16], int p0) {
 #pragma unroll
-            for (int i = 0; i < KG; ++i) kv[i] = Kp[(size_t)(p0 + i) * ks];
+            for (int i = 0; i < 16; ++i) kv[i] = Kp[(size_t)(p0 + i) * ks];
         };
-        auto useK = [&](const float (&kv)[KG], int p0) {
+        auto useK = [&](const float (&kv)[16], int p0) {
 #pragma unroll
-            for (int i = 0; i < KG; ++i) {
+            for (int i = 0; i < 16; ++i) {
                 const float4 wa = *reinterpret_cast<const float4*>(wl + (p0 + i) * 8), wb = *reinterpret_cast<const float4*>(wl + (p0 + i) * 8 + 4);
                 const float w8[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float tt = w8[j] * kv[i]; acc[j] = acc[j] + tt; }
             }
         };
-        const int ngroups = kb / KG;
+        const int ngroups = kb >> 4;
         {
-            float ka[KG], kc[KG];
+            float ka[16], kc[16];
             if (ngroups > 0) loadK(ka, 0);
             for (int g = 0; g < ngroups; g += 2) {
-                if (g + 1 < ngroups) loadK(kc, (g + 1) * KG);
-                useK(ka, g * KG);
+                if (g + 1 < ngroups) loadK(kc, (g + 1) * 16);
+                useK(ka, g * 16);
                 if (g + 1 < ngroups) {
-                    if (g + 2 < ngroups) loadK(ka, (g + 2) * KG);
-                    useK(kc, (g + 1) * KG);
+                    if (g + 2 < ngroups) loadK(ka, (g + 2) * 16);
+                    useK(kc, (g + 1) * 16);
                 }
             }
         }
-        int p = ngroups * KG;
-        {   // the up to KG - 1 terms left before the diagonal block: loads together
-            float kv[KG];
+        int p = ngroups * 16;
+        {   // the up to 15 terms left before the diagonal block: loads together
+            float kv[16];
 #pragma unroll
-            for (int i = 0; i < KG; ++i) kv[i] = Kp[(size_t)min(p + i, kb) * ks];
+            for (int i = 0; i < 16; ++i) kv[i] = Kp[(size_t)min(p + i, kb) * ks];
 #pragma unroll
-            for (int i = 0; i < KG; ++i) {
+            for (int i = 0; i < 16; ++i) {
                 if (p + i < kb) {
                     const float* w0 = wl + (p + i) * 8;
 #pragma unroll
