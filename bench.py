@@ -440,6 +440,9 @@ class HogSvm(Workload):
     def __init__(self, env, W=640, H=480, frames_per_step=32, inflight=2):
         import torch
         from featuredetection_amd import capi, synth
+        # three frames in flight (FD_BENCH_HOG_INFLIGHT): with two, a pair of streams that the runtime maps onto the same one of its four
+        # hardware queues serialises the frames (160 instead of 166-168 Mpatches/s when the contexts of other workloads exist already)
+        inflight = max(1, int(os.environ.get("FD_BENCH_HOG_INFLIGHT", "3")))
         self.env, self.capi, self.W, self.H = env, capi, W, H
         self.FP = max(1, frames_per_step)
         self.NFR = 4
