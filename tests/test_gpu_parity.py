@@ -51,6 +51,20 @@ def test_pyramid_layers_bit_exact(oracle, capi, ctx, synth, size, kw):
     pg.close()
 
 
+@pytest.mark.parametrize("size", [(13, 9), (7, 5), (9, 2), (3, 37), (130, 3), (2, 2), (257, 5)])
+def test_pyramid_of_tiny_frames_bit_exact(oracle, capi, ctx, synth, size):
+    """Layers of one to three pixels across: the pyrDown kernels' closed-form BORDER_REFLECT_101 (two pixels out on either side, so a
+    1- or 2-pixel layer is reflected more than once by the reference) and the clamped, unpredicated tile fetch at both edges at once."""
+    frame = synth.make_frame(size[0], size[1], seed=7 + size[0] * size[1])
+    for kw in (dict(octave_layers=1, min_scale=0.03, max_scale=1.0), dict(octave_layers=3, min_scale=0.06, max_scale=1.0)):
+        po, pg = _pyr_pair(oracle, capi, ctx, frame, **kw)
+        lo, lg = po.layers(), pg.layers()
+        assert lo == lg and len(lo) >= 2
+        for i in range(len(lo)):
+            assert np.array_equal(pg.layer(i), po.layer(i)), (kw, "layer %d of %s" % (i, lo))
+        pg.close()
+
+
 @pytest.mark.parametrize("roi", [None, (100, 80, 300, 200), (-20, -10, 200, 100), (500, 400, 400, 400)])
 def test_window_enumeration(oracle, capi, ctx, frame640, roi):
     po, pg = _pyr_pair(oracle, capi, ctx, frame640, **FF)
