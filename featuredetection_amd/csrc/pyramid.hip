@@ -106,24 +106,42 @@ __global__ void k_frames_to_gray(FramePtrs frames, uint8_t* __restrict__ grayBas
     uint8_t* __restrict__ gray = grayBase + (size_t)blockIdx.y * imageStride;
     const int nq = n >> 2;
     const bool aligned = ((uintptr_t)src & 3) == 0;
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
-        if (ch == 3) {
-            uint32_t w0, w1, w2;
-            if (aligned) {
-                const uint32_t* s3 = reinterpret_cast<const uint32_t*>(src) + 3 * (size_t)q;
-                w0 = s3[0]; w1 = s3[1]; w2 = s3[2];
-            } else {
-                const uint8_t* s1 = src + 12 * (size_t)q;
-                w0 = ld_u32_unaligned(s1); w1 = ld_u32_unaligned(s1 + 4); w2 = ld_u32_unaligned(s1 + 8);
-            }
-            // bytes: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
-            const uint32_t g0 = gray_of(w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u);
-            const uint32_t g1 = gray_of(w0 >> 24, w1 & 255u, (w1 >> 8) & 255u);
-            const uint32_t g2 = gray_of((w1 >> 16) & 255u, w1 >> 24, w2 & 255u);
-            const uint32_t g3 = gray_of((w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24);
-            reinterpret_cast<uint32_t*>(gray)[q] = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+    const int stride = gridDim.x * blockDim.x;
+    auto load3 = [&](int q, uint32_t (&w)[3]) {
+        if (aligned) {
+            const uint32_t* s3 = reinterpret_cast<const uint32_t*>(src) + 3 * (size_t)q;
+            w[0] = s3[0]; w[1] = s3[1]; w[2] = s3[2];
         } else {
-            reinterpret_cast<uint32_t*>(gray)[q] = ld_u32_unaligned(src + 4 * (size_t)q);
+            const uint8_t* s1 = src + 12 * (size_t)q;
+            w[0] = ld_u32_unaligned(s1); w[1] = ld_u32_unaligned(s1 + 4); w[2] = ld_u32_unaligned(s1 + 8);
+        }
+    };
+    auto gray4 = [&](const uint32_t (&w)[3]) {
+        // bytes: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+        const uint32_t g0 = gray_of(w[0] & 255u, (w[0] >> 8) & 255u, (w[0] >> 16) & 255u);
+        const uint32_t g1 = gray_of(w[0] >> 24, w[1] & 255u, (w[1] >> 8) & 255u);
+        const uint32_t g2 = gray_of((w[1] >> 16) & 255u, w[1] >> 24, w[2] & 255u);
+        const uint32_t g3 = gray_of((w[2] >> 8) & 255u, (w[2] >> 16) & 255u, w[2] >> 24);
+        return g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+    };
+    // GQ quads per thread and pass, their loads in flight together: with one 12-byte load per thread the stage moved 4.5 TB/s -- the
+    // bytes a full chip of wavefronts keeps in flight (6 MB) over the memory latency -- not what the memory can deliver
+    constexpr int GQ = 4;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += GQ * stride) {
+        if (ch == 3) {
+            uint32_t w[GQ][3];
+#pragma unroll
+            for (int i = 0; i < GQ; ++i) load3(min(q + i * stride, nq - 1), w[i]);
+#pragma unroll
+            for (int i = 0; i < GQ; ++i)
+                if (q + i * stride < nq) reinterpret_cast<uint32_t*>(gray)[q + i * stride] = gray4(w[i]);
+        } else {
+            uint32_t w[GQ];
+#pragma unroll
+            for (int i = 0; i < GQ; ++i) w[i] = ld_u32_unaligned(src + 4 * (size_t)min(q + i * stride, nq - 1));
+#pragma unroll
+            for (int i = 0; i < GQ; ++i)
+                if (q + i * stride < nq) reinterpret_cast<uint32_t*>(gray)[q + i * stride] = w[i];
         }
     }
     if (blockIdx.x == 0 && (int)threadIdx.x < (n & 3)) {   // tail
@@ -980,7 +998,7 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
         } else {
             for (int f = 0; f < NI; ++f) fp.p[f] = frames[f];
         }
-        hipLaunchKernelGGL(k_frames_to_gray, dim3(grid_for((int)(npix / 4 + 1)), NI), dim3(256), 0, st, fp, arena + p->gray_full_off, IS, (int)npix, ch);
+        hipLaunchKernelGGL(k_frames_to_gray, dim3(grid_for((int)(npix / 16 + 1)), NI), dim3(256), 0, st, fp, arena + p->gray_full_off, IS, (int)npix, ch);   // four quads per thread
     } else {
         const uint8_t* dimg = image;
         if (!is_device) {
