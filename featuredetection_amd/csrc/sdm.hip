@@ -606,7 +606,18 @@ __global__ void k_sdm_update(float* __restrict__ shapes, const double* __restric
     if (idx >= B * N) return;
     const int f = idx / N, j = idx - f * N;
     double acc = 0.0;
-    for (int c = 0; c < nchunks; ++c) acc = acc + partial[((size_t)c * B + f) * N + j];
+    // the chunks' partial sums, sixteen loads in flight at a time, added in chunk order (one load per round trip made this 20 us of a 330 us step)
+    const double* pp = partial + (size_t)f * N + j;
+    const size_t cs = (size_t)B * N;
+    int c = 0;
+    for (; c + 16 <= nchunks; c += 16) {
+        double v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = pp[(size_t)(c + i) * cs];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = acc + v[i];
+    }
+    for (; c < nchunks; ++c) acc = acc + pp[(size_t)c * cs];
     acc = acc + (double)biasRow[j];
     const float delta = (float)acc;
     const float t = delta * dist[f];
