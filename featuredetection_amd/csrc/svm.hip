@@ -297,6 +297,31 @@ __global__ __launch_bounds__(64 * SU_W) void k_svm_u8_rbf_mfma(SvmDev m, const v
     {   // stage the 32 feature vectors (gathered through idx), zero padded; dwords where the layout allows
         const bool words = (m.dim & 3) == 0 && (feat_stride_bytes & 3) == 0 && ((uintptr_t)features & 3) == 0;
         const int wpr = DS >> 2;
+        if (words) {
+            // all of a thread's dwords (seven for a 20 x 20 patch) in flight together, from clamped addresses: one load per trip through the
+            // loop was seven dependent memory round trips, a third of the kernel's 25 us (the launch is a chain of latencies, not of work)
+            constexpr int GU = 8;
+            for (int i0 = threadIdx.x; i0 < 32 * wpr; i0 += 64 * SU_W * GU) {
+                uint32_t v[GU];
+                bool ok[GU];
+#pragma unroll
+                for (int k = 0; k < GU; ++k) {
+                    const int i = min(i0 + k * 64 * SU_W, 32 * wpr - 1);
+                    const int row = i / wpr, col = (i - row * wpr) * 4;
+                    const int64_t slot = slots[row];
+                    ok[k] = slot >= 0 && col < m.dim;
+                    v[k] = *reinterpret_cast<const uint32_t*>((const unsigned char*)features + (ok[k] ? slot * feat_stride_bytes + col : 0));
+                }
+#pragma unroll
+                for (int k = 0; k < GU; ++k) {
+                    const int i = i0 + k * 64 * SU_W;
+                    if (i < 32 * wpr) {
+                        const int row = i / wpr, col = (i - row * wpr) * 4;
+                        *reinterpret_cast<uint32_t*>(xs + row * DS + col) = ok[k] ? v[k] ^ 0x80808080u : 0u;
+                    }
+                }
+            }
+        } else
         for (int i = threadIdx.x; i < 32 * wpr; i += 64 * SU_W) {
             const int row = i / wpr, col = (i - row * wpr) * 4;
             const int64_t slot = slots[row];
@@ -612,7 +637,15 @@ __global__ void k_sum_partials(const double* __restrict__ partial, int ngroups, 
                                double* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         double s = 0.0;
-        for (int g = 0; g < ngroups; ++g) s += partial[(size_t)g * npadRows + i];
+        int g = 0;
+        for (; g + 8 <= ngroups; g += 8) {   // eight loads in flight, added in group order
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = partial[(size_t)(g + k) * npadRows + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; g < ngroups; ++g) s += partial[(size_t)g * npadRows + i];
         out[i] = -(double)bias + s;
     }
 }
