@@ -756,12 +756,7 @@ class Sdm(Workload):
                     traffic=pm.get("hbm_bytes") if pm else None, kernel_ms=kms,
                     algorithmic="(46x46 B crop + 279 f32) x %d (face, landmark) items per launch" % items)
         extra = {}
-        # the issue roofline of the DOMINANT kernel (the one `roofline` names); the figure over all cascade kernels of a call beside it
-        if pmk and pmk.get("valu_issue_frac"):
-            extra["roofline_issue"] = issue_roofline(pmk)
-            if pm and pm.get("valu_issue_frac"):
-                extra["roofline_issue"]["all_cascade_kernels"] = dict(kernel=pm.get("kernel"), frac=float(pm["valu_issue_frac"]))
-        elif pm and pm.get("valu_issue_frac"):
+        if pm and pm.get("valu_issue_frac"):
             extra["roofline_issue"] = issue_roofline(pm)
         return roof, extra
 
