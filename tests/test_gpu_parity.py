@@ -134,6 +134,27 @@ def test_wvm_all_windows_bit_exact(oracle, capi, ctx, frame640, small_models):
     wg.close(); pg.close()
 
 
+@pytest.mark.parametrize("num_used", [17, 23, 29])
+def test_wvm_with_a_used_filter_count_between_level_groups(oracle, capi, ctx, frame640, small_models, num_used):
+    """numUsedFilters (WvmClassifier.cpp:151-158) that is not a multiple of numFiltersPerLevel: the classes of stage B have different
+    numbers of generations; every window's (last level, fp32 output) and the positives against the CPU cascade, production and exact path."""
+    wvm = dict(small_models[0])
+    wvm["num_used"] = num_used
+    po, pg = _pyr_pair(oracle, capi, ctx, frame640, **FF)
+    wo = oracle.Wvm(wvm)
+    wg = capi.Wvm(ctx, wvm)
+    pos_o, lv_o, fo_o = oracle.sliding_wvm(po, wo, 1, 1)
+    pos_g, lv_g, fo_g = capi.detect_wvm(ctx, pg, wg, 1, 1, want_all=True)
+    assert np.array_equal(lv_g, lv_o) and np.array_equal(fo_g, fo_o)
+    assert int((lv_o == num_used - 1).sum()) > 100   # windows do run to the last used level (whether they are positives is the threshold's matter)
+    pos_p, _, _ = capi.detect_wvm(ctx, pg, wg, 1, 1, want_all=False)   # dense pre-filter + stage B
+    assert len(pos_p) == len(pos_o) == len(pos_g)
+    if len(pos_o):
+        _same_geometry(pos_p, pos_o)
+        assert np.array_equal(pos_p["score"], pos_o["fout"])
+    wg.close(); pg.close()
+
+
 def test_wvm_full_size_model_and_other_patch_shapes(oracle, capi, ctx, synth, frame640):
     gray = oracle.bgr2gray(frame640)
     rng = np.random.default_rng(8)

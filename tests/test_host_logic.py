@@ -197,13 +197,19 @@ int frame_loop(fd_ctx* ctx, fd_pyramid* pyr, const fd_wvm* wvm, const fd_svm* sv
 
 
 @pytest.mark.parametrize("shape", [(20, 20, 14, 3, 6, (2, 8)), (24, 24, 30, 2, 6, (2, 8)), (32, 24, 9, 3, 12, (1, 8)), (19, 21, 9, 4, 6, (2, 8)),
-                                   (16, 24, 20, 2, 16, (6, 8)), (7, 5, 3, 8, 6, (2, 8)), (20, 20, 40, 1, 6, (2, 8))])
+                                   (16, 24, 20, 2, 16, (6, 8)), (7, 5, 3, 8, 6, (2, 8)), (20, 20, 40, 1, 6, (2, 8)),
+                                   # numUsedFilters that is not a multiple of numFiltersPerLevel: classes with different numbers of
+                                   # generations (k_wvb_chain2 computes a level's operand tile from (class, generation) in closed form)
+                                   (20, 20, 14, 3, 6, (2, 8), 37), (24, 24, 30, 2, 6, (2, 8), 47), (32, 24, 9, 3, 12, (1, 8), 22),
+                                   (20, 20, 14, 20, 6, (2, 4), 269), (16, 24, 20, 2, 16, (6, 8), 21)])
 def test_stage_b_tables_reproduce_the_rect_sums(capi, synth, shape):
     """The dense stage B (wvm_stageb.hpp) replaces the rect lookups on the integral image (WvmClassifier.cpp:277-306) by an int8
     contraction against per-(level, grey value) coverage counts.  The host-built operand tables, read with the kernel's own
     addressing, must give exactly the rect sums computed rect by rect."""
-    pw, ph, nper, nlev, cntval, rr = shape
+    pw, ph, nper, nlev, cntval, rr = shape[:6]
     wvm = synth.make_wvm(5, fw=pw, fh=ph, n_per=nper, n_levels=nlev, cntval=cntval, rect_range=rr)
+    if len(shape) > 6:
+        wvm["num_used"] = shape[6]
     rng = np.random.default_rng(pw * 100 + ph)
     patches = rng.integers(0, 256, (40, ph, pw), dtype=np.uint8)
     patches[0] = 255
