@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void k_resize_down(uint8_t* __restrict__ arena
         PYR_T(p0);
         const FusedJob jb = jobs.j[d.w];
         uint8_t* arena = arena0 + (size_t)frame_of(item) * imageStride;
-        const int X0 = d.x & 0xffff, Y0 = (int)((uint32_t)d.x >> 16), ncol = d.y & 0xffff, nrow = (int)((uint32_t)d.y >> 16);
+        const int X0 = d.x & 0xffff, Y0 = (int)((uint32_t)d.x >> 16);
         const int x1 = (d.z & 0xffff) * FT_W1, y1 = (int)((uint32_t)d.z >> 16) * FT_H1;   // first pyrDown pixel of the tile
         const int gx0 = 2 * x1 - 2, gy0 = 2 * y1 - 2;                      // resized pixel of tile entry (0, 0), before the border reflection
         {   // the fetched source rectangle and row table -> LDS
