@@ -607,3 +607,25 @@ def test_bench_two_ranks_gather_through_fd_dist(tmp_path):
     rec = json.loads(r.stdout.strip().splitlines()[-1])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"
     assert rec["records_gathered"] == rec["detections_delivered"] > 0 and not rec["records_truncated"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["cascade", "hog_svm", "ffp15", "sdm"])
+def test_bench_line_of_every_workload_with_its_probe(workload):
+    """One short run of bench.py per workload WITH its kernel probe and roofline records (the multi-rank test above runs without them):
+    the JSON line parses and carries the contract's fields.  (A NameError in one workload's probe once left the driver's default run
+    without a line.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", workload, "--also", "none", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    if workload == "cascade":
+        cmd += ["--frames-per-step", "128"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in rec, key
+    assert rec["value"] > 0 and rec["roofline"]["bound"] in ("hbm", "mfma") and 0 < rec["roofline"]["frac"] <= 1.0
+    assert rec["roofline"]["achieved"] > 0 and rec["roofline"]["peak"] > 0 and "workload" in rec["config"]
