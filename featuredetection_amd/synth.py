@@ -102,7 +102,7 @@ def make_frames_varied(n, width=640, height=480, seed=20260927, scene_len=32, nb
 
 
 def histeq64_np(patches):
-    """Vectorised HistEq64 used only for threshold calibration / SV synthesis (not a parity reference)."""
+    """Vectorised HistEq64 used for threshold calibration / SV synthesis; tests/test_oracle_golden.py also checks the C++ oracle against it."""
     p = np.asarray(patches, np.uint8)
     n = p.shape[0]
     flat = p.reshape(n, -1)

@@ -353,3 +353,90 @@ def test_next_rows_regression_vectors(oracle):
     assert np.array_equal(lo, g["rvm_level"]) and np.array_equal(do, g["rvm_dist"])
     assert np.array_equal(np.stack([oracle.whi(q, 1.0, 0.390625) for q in g["whi_patches"]]), g["whi_out"])
     assert np.array_equal(np.stack([oracle.equalize_hist(q) for q in g["whi_patches"]]), g["eqhist_out"])
+
+
+def _np_reflect101(p, n):
+    """cv::borderInterpolate(p, n, BORDER_REFLECT_101)"""
+    if n == 1:
+        return 0
+    while p < 0 or p >= n:
+        p = -p if p < 0 else 2 * n - 2 - p
+    return p
+
+
+def _np_pyrdown(img):
+    """cv::pyrDown, 8U: separable [1 4 6 4 1], BORDER_REFLECT_101, (sum + 128) >> 8 -- written from the definition, rows first"""
+    h, w = img.shape
+    dh, dw = (h + 1) // 2, (w + 1) // 2
+    k = (1, 4, 6, 4, 1)
+    a = img.astype(np.int64)
+    hor = np.zeros((h, dw), np.int64)
+    for dx in range(dw):
+        for t in range(5):
+            hor[:, dx] += k[t] * a[:, _np_reflect101(2 * dx + t - 2, w)]
+    out = np.zeros((dh, dw), np.int64)
+    for dy in range(dh):
+        for t in range(5):
+            out[dy] += k[t] * hor[_np_reflect101(2 * dy + t - 2, h)]
+    return ((out + 128) >> 8).astype(np.uint8)
+
+
+def _np_resize_linear_u8(img, dw, dh):
+    """cv::resize(INTER_LINEAR) for 8UC1 as OpenCV 2.4 computes it: float coordinates from double scales, 11-bit coefficients rounded
+    half-to-even, horizontal pass in int32, vertical pass (b * (r >> 4)) >> 16, + 2, >> 2 -- vectorised, independent of oracle/orc_image.cpp"""
+    sh, sw = img.shape
+
+    def axis(dn, sn, clampCoeff):
+        scale = 1.0 / (dn / float(sn))
+        f = ((np.arange(dn) + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        if clampCoeff:
+            lo, hi = s < 0, s >= sn - 1
+            f[lo | hi] = 0
+            s[lo] = 0
+            s[hi] = sn - 1
+        c0 = np.rint((np.float32(1) - f).astype(np.float32) * np.float32(2048)).astype(np.int64)
+        c1 = np.rint(f * np.float32(2048)).astype(np.int64)
+        return s, c0, c1
+    xs, a0, a1 = axis(dw, sw, True)
+    ys, b0, b1 = axis(dh, sh, False)
+    a = img.astype(np.int64)
+    x1 = np.minimum(xs + 1, sw - 1)
+    hor = a[:, xs] * a0[None, :] + a[:, x1] * a1[None, :]   # [sh, dw]
+    r0 = hor[np.clip(ys, 0, sh - 1)]
+    r1 = hor[np.clip(ys + 1, 0, sh - 1)]
+    v = (((b0[:, None] * (r0 >> 4)) >> 16) + ((b1[:, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return v.astype(np.uint8)
+
+
+def test_opencv_primitives_against_numpy_restatement(oracle):
+    """cvtColor(BGR2GRAY), cv::resize(INTER_LINEAR) and cv::pyrDown on 8-bit images: the C++ restatement (oracle/orc_image.cpp, what the
+    HIP pyramid kernels are compared with) against a second, independently written numpy restatement of the OpenCV 2.4 arithmetic --
+    including images of one to three pixels across (multiple border reflections) and up- as well as down-scaling."""
+    rng = np.random.default_rng(77)
+    bgr = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    want = ((bgr[..., 0].astype(np.int64) * 1868 + bgr[..., 1].astype(np.int64) * 9617 + bgr[..., 2].astype(np.int64) * 4899 + 8192) >> 14).astype(np.uint8)
+    assert np.array_equal(oracle.bgr2gray(bgr), want)
+    for (w, h) in ((53, 37), (64, 48), (5, 4), (3, 3), (2, 7), (1, 5), (9, 1), (1, 1), (131, 2)):
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        assert np.array_equal(oracle.pyrdown(img), _np_pyrdown(img)), ("pyrDown", w, h)
+    for (w, h, dw, dh) in ((640, 480, 589, 442), (97, 81, 50, 41), (97, 81, 96, 80), (33, 21, 33, 21), (20, 20, 31, 29), (7, 5, 3, 2),
+                           (300, 200, 151, 199), (5, 3, 9, 7), (2, 2, 1, 1)):
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        assert np.array_equal(oracle.resize_linear_u8(img, dw, dh), _np_resize_linear_u8(img, dw, dh)), ("resize", w, h, dw, dh)
+
+
+def test_histeq64_against_numpy_restatement(oracle, synth):
+    """HistEq64Filter.cpp:32-125 (64 bins of the pixel >> 2, fp32 pdf and sequential fp32 cdf, (uchar)floor(cdf + 0.5)) restated twice:
+    the C++ oracle against a vectorised numpy form, on patches of every cfg-implied size, flat and two-valued ones included (exact .5 ties)."""
+    rng = np.random.default_rng(123)
+    for (pw, ph) in ((20, 20), (24, 24), (16, 24), (32, 16), (32, 24), (19, 21), (7, 5)):
+        pats = rng.integers(0, 256, (64, ph, pw), dtype=np.uint8)
+        pats[0] = 200
+        pats[1, : ph // 2] = 3
+        pats[1, ph // 2:] = 251
+        pats[2] = (np.arange(ph * pw).reshape(ph, pw) * 40 // (ph * pw) * 4).astype(np.uint8)   # 40 bins, equal counts when 40 | d: ties at .5
+        want = synth.histeq64_np(pats)
+        for i in range(len(pats)):
+            assert np.array_equal(oracle.histeq64(pats[i]), want[i]), (pw, ph, i)
