@@ -440,3 +440,163 @@ def test_histeq64_against_numpy_restatement(oracle, synth):
         want = synth.histeq64_np(pats)
         for i in range(len(pats)):
             assert np.array_equal(oracle.histeq64(pats[i]), want[i]), (pw, ph, i)
+
+
+def _np_wvm_eval(m, patch):
+    """WvmClassifier.cpp:100-149,191-346 + IImg.cpp:26-65 written a second time, in numpy scalars with the reference's types (float
+    integral images, double sum_xp / norm, float kernel values and level sums); independent of oracle/orc_classify.cpp."""
+    f32, f64 = np.float32, np.float64
+    fw, fh, F, NP = int(m["filter_w"]), int(m["filter_h"]), int(m["num_filters"]), int(m["num_per_level"])
+    nu = int(m["num_used"])
+    nu = F if (nu > F or nu == 0) else nu
+    p = patch.astype(np.int64)
+    ii = np.zeros((fh + 1, fw + 1), np.int64)
+    ii[1:, 1:] = p.cumsum(0).cumsum(1)              # every partial sum is an integer below 2^24: exact in the reference's floats
+    total = f32(0)                                   # the squared image's bottom-right entry: float row sums added row by row
+    for r in range(fh):
+        rowsum = f32(0)
+        for c in range(fw):
+            rowsum = f32(rowsum + f32(int(p[r, c]) * int(p[r, c])))
+        total = f32(total + rowsum)
+    basis, bias = f32(m["basis_param"]), f32(m["bias"])
+    u = np.zeros(NP, np.float32)
+    out = np.zeros(F, np.float32)
+    level = -1
+    while True:
+        level += 1
+        n = level % NP
+        v0, cnt = int(m["val_off"][level]), int(m["val_off"][level + 1] - m["val_off"][level])
+        sumv0 = f32(ii[fh, fw])
+        sum_xp = f64(0)
+        for v in range(1, cnt):
+            sv = 0
+            for r in range(int(m["rec_off"][v0 + v]), int(m["rec_off"][v0 + v + 1])):
+                x1, y1, x2, y2 = (int(q) for q in m["rects"][r])
+                sv += int(ii[y2 + 1, x2 + 1] - ii[y1, x2 + 1] - ii[y2 + 1, x1] + ii[y1, x1])
+            sumv0 = f32(sumv0 - f32(sv))
+            sum_xp = f64(sum_xp + f64(f32(sv)) * f64(m["val"][v0 + v]))
+        sum_xp = f64(sum_xp + f64(sumv0) * f64(m["val"][v0]))
+        sum_xp = f64(sum_xp + f64(u[n]))
+        u[n] = f32(sum_xp)
+        norm = f64(total)
+        norm = f64(norm - f64(2) * sum_xp)
+        norm = f64(norm + f64(m["pp"][level]))
+        out[level] = f32(np.exp(f64(-basis) * norm))
+        res = f32(-bias)
+        w = m["hk_weights"].reshape(F, F)[level]
+        for q in range(level + 1):
+            res = f32(res + f32(f32(w[q]) * out[q]))
+        if not (res >= f32(m["thresholds"][level]) and level + 1 < nu):
+            return level, res
+
+
+def test_wvm_cascade_against_numpy_restatement(oracle, synth, small_models, frame640):
+    """The C++ restatement of the WVM cascade (what every window's level and fp32 output on the GPU is compared with) against a second
+    restatement in numpy scalars: same last level and bit-identical fp32 output on equalised patches, for the full model and for
+    numUsedFilters between level groups."""
+    wvm = small_models[0]
+    gray = oracle.bgr2gray(frame640)
+    rng = np.random.default_rng(31)
+    pats = synth.histeq64_np(synth.random_patches(gray[::4, ::4].copy(), 20, 20, 120, rng))
+    pats[0] = 255
+    pats[1] = 0
+    for nu in (wvm["num_used"], 17):
+        m = dict(wvm)
+        m["num_used"] = nu
+        wo = oracle.Wvm(m)
+        deep = 0
+        for p in pats:
+            lo, fo = wo.eval(p)
+            ln, fn = _np_wvm_eval(m, p)
+            assert lo == ln and np.float32(fo).tobytes() == np.float32(fn).tobytes(), (nu, lo, ln, fo, fn)
+            deep += lo >= 6
+        assert deep >= 5   # the comparison is not only about first-level rejects
+
+
+def _np_hog_filter(binimg, bins, cw, chh, bw, bh, sau):
+    """HogFilter::applyTo without cell interpolation on a (bin, weight) image: HistogramFilter.cpp:140-175 (cell bounds by integer
+    division, histogram[bin] += factor * weight in scan order), HogFilter.cpp:102-122 (cell energies), :66-100 (block normalisation and
+    output order) -- a second restatement in numpy float32 scalars, written from the reference's source."""
+    f32 = np.float32
+    h, w = binimg.shape[:2]
+    rows, cols = int(np.rint(h / chh)), int(np.rint(w / cw))   # cvRound (these quotients are never at .5 in the test)
+    factor = f32(1.0) / f32(255.0)
+    hist = np.zeros((rows, cols, bins), np.float32)
+    for cr in range(rows):
+        for cc in range(cols):
+            for y in range((cr * h) // rows, ((cr + 1) * h) // rows):
+                for x in range((cc * w) // cols, ((cc + 1) * w) // cols):
+                    b, wt = int(binimg[y, x, 0]), int(binimg[y, x, 1])
+                    hist[cr, cc, b] = f32(hist[cr, cc, b] + f32(factor * f32(wt)))
+    half = bins // 2
+    energy = np.zeros((rows, cols), np.float32)
+    for cr in range(rows):
+        for cc in range(cols):
+            e = f32(0)
+            if sau:
+                for b in range(half):
+                    u = f32(hist[cr, cc, b] + hist[cr, cc, half + b])
+                    e = f32(e + f32(u * u))
+            else:
+                for b in range(bins):
+                    e = f32(e + f32(hist[cr, cc, b] * hist[cr, cc, b]))
+            energy[cr, cc] = e
+    out = []
+    for br in range(rows - bh + 1):
+        for bc in range(cols - bw + 1):
+            e = f32(0)
+            for cr in range(br, br + bh):
+                for cc in range(bc, bc + bw):
+                    e = f32(e + energy[cr, cc])
+            nrm = f32(f32(1) / f32(np.sqrt(f32(e + f32(1e-4)))))
+            for cr in range(br, br + bh):
+                for cc in range(bc, bc + bw):
+                    out += [f32(nrm * hist[cr, cc, b]) for b in range(bins)]
+                    if sau:
+                        out += [f32(nrm * f32(hist[cr, cc, b] + hist[cr, cc, half + b])) for b in range(half)]
+    return np.asarray(out, np.float32)
+
+
+def test_hog_filter_against_numpy_restatement(oracle):
+    """HistogramFilter / HogFilter (rows a23, a24) restated twice: oracle/orc_features.cpp against numpy float32 scalars, bit for bit,
+    on (bin, weight) patches of the config-2 shape and of shapes whose cells do not divide the patch."""
+    rng = np.random.default_rng(9)
+    for (w, h, bins, cw, chh, bw, bh, sau) in ((20, 20, 9, 5, 5, 2, 2, False), (20, 20, 8, 5, 5, 2, 2, True), (24, 16, 6, 5, 4, 2, 1, False),
+                                                (19, 21, 9, 6, 5, 1, 2, False), (32, 24, 12, 8, 8, 3, 2, True)):
+        img = np.zeros((h, w, 2), np.uint8)
+        img[..., 0] = rng.integers(0, bins, (h, w))
+        img[..., 1] = rng.integers(0, 256, (h, w))
+        got = oracle.hog_filter(img, bins, cw, bw, interpolate=False, signed_and_unsigned=sau, cell_h=chh, block_h=bh)
+        want = _np_hog_filter(img, bins, cw, chh, bw, bh, sau)
+        assert got.shape == want.shape and got.tobytes() == want.tobytes(), (w, h, bins, cw, chh, bw, bh, sau, np.abs(got - want).max())
+
+
+def test_overlap_elimination_against_python_restatement(oracle):
+    """OverlapElimination.cpp:44-105 restated twice: the C++ oracle against the reference's loop written in Python (sort by probability,
+    descending; an element survives unless an earlier survivor lies within d in x and y and the width ratio exceeds `ratio`; d = dist
+    pixels above 1, dist x the larger width otherwise; ratio outside (0, 1] counts as 0).  Distinct probabilities: the reference's
+    order of equal ones is whatever its std::sort leaves."""
+    from oracle.pyoracle import DET_DTYPE
+    rng = np.random.default_rng(4)
+    for n in (1, 2, 40, 500):
+        d = np.zeros(n, DET_DTYPE)
+        d["cx"] = rng.integers(-20, 300, n)
+        d["cy"] = rng.integers(-20, 200, n)
+        d["w"] = rng.choice([20, 22, 25, 31, 40, 63], n)
+        d["h"] = d["w"]
+        d["prob"] = rng.permutation(n) / float(n) * 0.9 + 0.05
+        for dist, ratio in ((5.0, 0.0), (0.5, 0.0), (1.0, 0.0), (20.0, 0.8), (12.5, 1.0), (3.0, 1.5), (3.0, -1.0)):
+            r = np.float32(ratio) if 0.0 < ratio <= 1.0 else np.float32(0)
+            order = sorted(range(n), key=lambda i: -d["prob"][i])
+            keep = []
+            for i in order:
+                ok = True
+                for a in keep:
+                    dd = np.float32(dist) * np.float32(max(d["w"][a], d["w"][i])) if dist <= 1.0 else np.float32(dist)
+                    if (abs(int(d["cx"][a]) - int(d["cx"][i])) < dd and abs(int(d["cy"][a]) - int(d["cy"][i])) < dd
+                            and np.float32(min(d["w"][a], d["w"][i])) / np.float32(max(d["w"][a], d["w"][i])) > r):
+                        ok = False
+                        break
+                if ok:
+                    keep.append(i)
+            assert list(oracle.overlap_elimination(d, dist, ratio)) == keep, (n, dist, ratio)
