@@ -600,3 +600,43 @@ def test_overlap_elimination_against_python_restatement(oracle):
                 if ok:
                     keep.append(i)
             assert list(oracle.overlap_elimination(d, dist, ratio)) == keep, (n, dist, ratio)
+
+
+def test_block_nms_against_numpy_restatement(oracle):
+    """nonMaximaSuppression (FiveStageSlidingWindowDetector.cpp:143-184) restated twice, unmasked and masked maps whose selections are
+    never empty (what cv::minMaxLoc returns for an empty selection is an OpenCV property both restatements would only assume): a block's
+    first maximum (row-major) is a local maximum iff it exceeds the maximum of its (2 sz + 1)^2 neighbourhood outside the block."""
+    rng = np.random.default_rng(12)
+    for (M, N, sz) in ((40, 50, 3), (37, 29, 5), (64, 64, 7), (20, 33, 1), (90, 70, 35)):
+        src = rng.random((M, N)).astype(np.float32) + np.float32(0.01)
+        src[rng.random((M, N)) < 0.1] = np.float32(0.5)   # equal values: the first one in scan order is the block's candidate
+        for masked in (False, True):
+            mask = None
+            if masked:
+                mask = np.where(rng.random((M, N)) < 0.8, 255, 0).astype(np.uint8)
+            want = np.zeros((M, N), np.uint8)
+            skip = False
+            for m in range(0, M, sz + 1):
+                for n in range(0, N, sz + 1):
+                    i1, j1 = min(m + sz + 1, M), min(n + sz + 1, N)
+                    blk = src[m:i1, n:j1].astype(np.float64)
+                    sel = np.ones(blk.shape, bool) if mask is None else mask[m:i1, n:j1] != 0
+                    if not sel.any():
+                        skip = True
+                        continue
+                    v = np.where(sel, blk, -np.inf)
+                    k = int(np.argmax(v))   # first occurrence, row-major
+                    cy, cx = m + k // blk.shape[1], n + k % blk.shape[1]
+                    a0, a1, b0, b1 = max(cy - sz, 0), min(cy + sz + 1, M), max(cx - sz, 0), min(cx + sz + 1, N)
+                    nb = src[a0:a1, b0:b1].astype(np.float64)
+                    ns = np.ones(nb.shape, bool) if mask is None else mask[a0:a1, b0:b1] != 0
+                    r0, c0 = m - a0, n - b0
+                    ns[r0:min(r0 + sz + 1, nb.shape[0]), c0:min(c0 + sz + 1, nb.shape[1])] = False
+                    if not ns.any():
+                        skip = True
+                        continue
+                    if v.max() > np.where(ns, nb, -np.inf).max():
+                        want[cy, cx] = 255
+            if skip:
+                continue
+            assert np.array_equal(oracle.block_nms(src, sz, mask), want), (M, N, sz, masked)
