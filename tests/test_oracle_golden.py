@@ -640,3 +640,18 @@ def test_block_nms_against_numpy_restatement(oracle):
             if skip:
                 continue
             assert np.array_equal(oracle.block_nms(src, sz, mask), want), (M, N, sz, masked)
+
+
+def test_greyworld_against_numpy_restatement(oracle):
+    """GreyWorldNormalizationFilter.cpp:20-71 (continuous image) restated twice: channel sums and maxima, the largest max / mean sets the
+    common scale, cvRound (half to even) and saturation -- numpy doubles against the C++ oracle."""
+    rng = np.random.default_rng(21)
+    for shape, hi in (((37, 53, 3), 256), ((8, 8, 3), 40), ((20, 31, 3), 200)):
+        img = rng.integers(0, hi, shape, dtype=np.uint8)
+        img[0, 0] = (hi - 1, 1, 3)
+        n = shape[0] * shape[1]
+        mean = img.reshape(-1, 3).astype(np.float64).sum(0) / n
+        mx = (img.reshape(-1, 3).max(0).astype(np.float64) / mean).max()
+        scale = 255.0 / (mean * mx)
+        want = np.clip(np.rint(scale[None, None, :] * img.astype(np.float64)), 0, 255).astype(np.uint8)
+        assert np.array_equal(oracle.greyworld(img), want), shape
