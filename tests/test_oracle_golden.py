@@ -513,7 +513,25 @@ def test_wvm_cascade_against_numpy_restatement(oracle, synth, small_models, fram
         assert deep >= 5   # the comparison is not only about first-level rejects
 
 
-def _np_hog_filter(binimg, bins, cw, chh, bw, bh, sau):
+def _np_hist_cache(size, count):
+    """HistogramFilter::createCache (HistogramFilter.cpp:198-219): the two cells a pixel row / column feeds and their float weights"""
+    f32 = np.float32
+    out = []
+    for i in range(size):
+        real = float(count) * (float(i) + 0.5) / float(size) - 0.5
+        i1 = int(np.floor(real))
+        i2 = i1 + 1
+        w2 = f32(real - i1)
+        w1 = f32(f32(1) - w2)
+        if i1 < 0:
+            i1, w1 = i2, f32(0)
+        elif i2 >= count:
+            i2, w2 = i1, f32(0)
+        out.append((i1, i2, w1, w2))
+    return out
+
+
+def _np_hog_filter(binimg, bins, cw, chh, bw, bh, sau, interpolate=False):
     """HogFilter::applyTo without cell interpolation on a (bin, weight) image: HistogramFilter.cpp:140-175 (cell bounds by integer
     division, histogram[bin] += factor * weight in scan order), HogFilter.cpp:102-122 (cell energies), :66-100 (block normalisation and
     output order) -- a second restatement in numpy float32 scalars, written from the reference's source."""
@@ -522,7 +540,19 @@ def _np_hog_filter(binimg, bins, cw, chh, bw, bh, sau):
     rows, cols = int(np.rint(h / chh)), int(np.rint(w / cw))   # cvRound (these quotients are never at .5 in the test)
     factor = f32(1.0) / f32(255.0)
     hist = np.zeros((rows, cols, bins), np.float32)
-    for cr in range(rows):
+    if interpolate:   # HistogramFilter.cpp:66-99: every pixel feeds up to four cells, (weight * row weight) * column weight
+        rc, ccache = _np_hist_cache(h, rows), _np_hist_cache(w, cols)
+        for y in range(h):
+            r0, r1, rw0, rw1 = rc[y]
+            for x in range(w):
+                b, wt = int(binimg[y, x, 0]), f32(factor * f32(int(binimg[y, x, 1])))
+                c0, c1, cw0, cw1 = ccache[x]
+                for (ri, rwt, ok_r) in ((r0, rw0, r0 >= 0), (r1, rw1, r1 < rows)):
+                    for (ci, cwt, ok_c) in ((c0, cw0, c0 >= 0), (c1, cw1, c1 < cols)):
+                        if ok_r and ok_c:
+                            hist[ri, ci, b] = f32(hist[ri, ci, b] + f32(f32(wt * rwt) * cwt))
+    else:
+      for cr in range(rows):
         for cc in range(cols):
             for y in range((cr * h) // rows, ((cr + 1) * h) // rows):
                 for x in range((cc * w) // cols, ((cc + 1) * w) // cols):
@@ -559,16 +589,18 @@ def _np_hog_filter(binimg, bins, cw, chh, bw, bh, sau):
 
 def test_hog_filter_against_numpy_restatement(oracle):
     """HistogramFilter / HogFilter (rows a23, a24) restated twice: oracle/orc_features.cpp against numpy float32 scalars, bit for bit,
-    on (bin, weight) patches of the config-2 shape and of shapes whose cells do not divide the patch."""
+    on (bin, weight) patches of the config-2 shape and of shapes whose cells do not divide the patch, without and with the bilinear
+    interpolation between cells (the pixel order of the interpolating form matters: four cells per pixel, row-major pixels)."""
     rng = np.random.default_rng(9)
     for (w, h, bins, cw, chh, bw, bh, sau) in ((20, 20, 9, 5, 5, 2, 2, False), (20, 20, 8, 5, 5, 2, 2, True), (24, 16, 6, 5, 4, 2, 1, False),
                                                 (19, 21, 9, 6, 5, 1, 2, False), (32, 24, 12, 8, 8, 3, 2, True)):
         img = np.zeros((h, w, 2), np.uint8)
         img[..., 0] = rng.integers(0, bins, (h, w))
         img[..., 1] = rng.integers(0, 256, (h, w))
-        got = oracle.hog_filter(img, bins, cw, bw, interpolate=False, signed_and_unsigned=sau, cell_h=chh, block_h=bh)
-        want = _np_hog_filter(img, bins, cw, chh, bw, bh, sau)
-        assert got.shape == want.shape and got.tobytes() == want.tobytes(), (w, h, bins, cw, chh, bw, bh, sau, np.abs(got - want).max())
+        for interp in (False, True):
+            got = oracle.hog_filter(img, bins, cw, bw, interpolate=interp, signed_and_unsigned=sau, cell_h=chh, block_h=bh)
+            want = _np_hog_filter(img, bins, cw, chh, bw, bh, sau, interp)
+            assert got.shape == want.shape and got.tobytes() == want.tobytes(), (w, h, bins, cw, chh, bw, bh, sau, interp, np.abs(got - want).max())
 
 
 def test_overlap_elimination_against_python_restatement(oracle):
