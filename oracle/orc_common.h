@@ -11,7 +11,11 @@
 // by tests/ to validate the corresponding restatements bit-for-bit (VLFeat HOG, integral
 // image) or to fp64 round-off (libsvm RBF/HIK/poly/linear decision values).  OpenCV primitives
 // (cvtColor, resize, pyrDown, Sobel, equalizeHist, minMaxLoc) are restated from the OpenCV
-// 2.4 algorithms and are *defined* as the spec here.
+// 2.4 algorithms and are *defined* as the spec here.  Guard against slips in
+// this restatement: tests/test_oracle_golden.py holds SECOND restatements, written separately in
+// numpy / Python scalars from the reference's source, of cvtColor / resize / pyrDown, HistEq64,
+// the WVM cascade, the HOG filter chain, OverlapElimination, nonMaximaSuppression and the
+// grey-world filter; the C++ code here must agree with them bit for bit.
 #pragma once
 #include <cstdint>
 #include <cmath>
