@@ -14,8 +14,8 @@
 // 2.4 algorithms and are *defined* as the spec here.  Guard against slips in
 // this restatement: tests/test_oracle_golden.py holds SECOND restatements, written separately in
 // numpy / Python scalars from the reference's source, of cvtColor / resize / pyrDown, HistEq64,
-// the WVM cascade, the HOG filter chain, OverlapElimination, nonMaximaSuppression and the
-// grey-world filter; the C++ code here must agree with them bit for bit.
+// the WVM cascade, the gradient / binning / HOG filter chain, OverlapElimination,
+// nonMaximaSuppression and the grey-world filter; the C++ code here must agree with them bit for bit.
 #pragma once
 #include <cstdint>
 #include <cmath>

@@ -687,3 +687,57 @@ def test_greyworld_against_numpy_restatement(oracle):
         scale = 255.0 / (mean * mx)
         want = np.clip(np.rint(scale[None, None, :] * img.astype(np.float64)), 0, 255).astype(np.uint8)
         assert np.array_equal(oracle.greyworld(img), want), shape
+
+
+def test_gradient_filter_and_binning_against_numpy_restatement(oracle):
+    """GradientFilter.cpp:38-59 (cv::Sobel with ksize 1 / 3, scale 1/2 / 1/8, delta 127, BORDER_REFLECT_101, 8-bit saturation) and
+    GradientBinningFilter.cpp:18-93 (the 65536-entry look-up table from atan2 / sqrt in double) restated twice, numpy against the C++ oracle."""
+    import math
+    rng = np.random.default_rng(17)
+    img = rng.integers(0, 256, (23, 31), dtype=np.uint8)
+    a = img.astype(np.int64)
+
+    def refl(p, n):
+        return _np_reflect101(p, n)
+    H, W = a.shape
+    for ksize in (1, 3):
+        gx = np.zeros_like(a)
+        gy = np.zeros_like(a)
+        for y in range(H):
+            for x in range(W):
+                xm, xp, ym, yp = refl(x - 1, W), refl(x + 1, W), refl(y - 1, H), refl(y + 1, H)
+                if ksize == 1:
+                    gx[y, x] = a[y, xp] - a[y, xm]
+                    gy[y, x] = a[yp, x] - a[ym, x]
+                else:
+                    gx[y, x] = (a[ym, xp] - a[ym, xm]) + 2 * (a[y, xp] - a[y, xm]) + (a[yp, xp] - a[yp, xm])
+                    gy[y, x] = (a[yp, xm] - a[ym, xm]) + 2 * (a[yp, x] - a[ym, x]) + (a[yp, xp] - a[ym, xp])
+        scale = 0.5 if ksize == 1 else 1.0 / 8
+        want = np.stack([np.clip(np.rint(gx * scale + 127), 0, 255), np.clip(np.rint(gy * scale + 127), 0, 255)], -1).astype(np.uint8)
+        got = oracle.gradient_filter(img, ksize, 0)
+        assert np.array_equal(got, want), ksize
+    grad = rng.integers(0, 256, (40, 40, 2), dtype=np.uint8)
+    grad[0, :16, 0] = 127   # zero x gradient: atan2(+-y, 0)
+    grad[1, :16, 1] = 127
+    grad[2, 0] = (127, 127)
+    for bins, signed in ((9, False), (8, True), (12, True), (6, False)):
+        for interp in (False, True):
+            want = np.zeros((40, 40, 4 if interp else 2), np.uint8)
+            for y in range(40):
+                for x in range(40):
+                    gxv, gyv = (float(grad[y, x, 0]) - 127) / 255, (float(grad[y, x, 1]) - 127) / 255
+                    d = math.atan2(gyv, gxv)
+                    mag = math.sqrt(gxv * gxv + gyv * gyv)
+                    if signed:
+                        b = (d + math.pi) * bins / (2 * math.pi)
+                    else:
+                        b = (d + math.pi if d < 0 else d) * bins / math.pi
+                    sat = lambda v: int(min(255, max(0, np.rint(v))))
+                    fl = math.floor(b)
+                    if interp:
+                        w3 = sat(255 * mag * (b - fl))
+                        want[y, x] = (int(fl) % 256 % bins, sat(255 * mag - w3), int(math.ceil(b)) % 256 % bins, w3)
+                    else:
+                        want[y, x] = (int(fl + (1 if b - fl >= 0.5 else 0)) % 256 % bins, sat(255 * mag))
+            got = oracle.gradient_binning(grad, bins, signed, interp)
+            assert np.array_equal(got, want), (bins, signed, interp)
