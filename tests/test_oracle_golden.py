@@ -741,3 +741,30 @@ def test_gradient_filter_and_binning_against_numpy_restatement(oracle):
                         want[y, x] = (int(fl + (1 if b - fl >= 0.5 else 0)) % 256 % bins, sat(255 * mag))
             got = oracle.gradient_binning(grad, bins, signed, interp)
             assert np.array_equal(got, want), (bins, signed, interp)
+
+
+def test_lbp_against_numpy_restatement(oracle):
+    """LbpFilter.cpp:20-85 + LbpFilter.hpp:88-178 restated twice: the three neighbourhood codes with BORDER_REPLICATE, and the uniform
+    map (patterns with at most two 0/1 transitions get 1..58 in code order, the rest 0)."""
+    rng = np.random.default_rng(23)
+    img = rng.integers(0, 256, (19, 27), dtype=np.uint8)
+    img[5:9, 5:9] = 77   # ties: strictly greater only
+    p = np.pad(img.astype(np.int64), 1, mode="edge")
+    H, W = img.shape
+    c = p[1:-1, 1:-1]
+    nb = lambda dy, dx: (p[1 + dy:1 + dy + H, 1 + dx:1 + dx + W] > c).astype(np.int64)
+    lbp8 = (nb(-1, -1) << 7) | (nb(-1, 0) << 6) | (nb(-1, 1) << 5) | (nb(0, 1) << 4) | (nb(1, 1) << 3) | (nb(1, 0) << 2) | (nb(1, -1) << 1) | nb(0, -1)
+    lbp4 = (nb(-1, 0) << 3) | (nb(0, 1) << 2) | (nb(1, 0) << 1) | nb(0, -1)
+    lbp4r = (nb(-1, -1) << 3) | (nb(-1, 1) << 2) | (nb(1, 1) << 1) | nb(1, -1)
+    umap, nxt = np.zeros(256, np.int64), 1
+    for code in range(256):
+        bits = [(code >> k) & 1 for k in range(8)]
+        prev, tr = bits[7], 0
+        for b in bits:
+            if b != prev:
+                tr, prev = tr + 1, b
+        if tr <= 2:
+            umap[code], nxt = nxt, nxt + 1
+    assert nxt == 59
+    for lbp_type, want in ((0, lbp8), (1, umap[lbp8]), (2, lbp4), (3, lbp4r)):
+        assert np.array_equal(oracle.lbp(img, lbp_type), want.astype(np.uint8)), lbp_type
