@@ -51,7 +51,8 @@ class fd_hog_params(C.Structure):
 
 class fd_sdm_model(C.Structure):
     _fields_ = [("num_landmarks", C.c_int32), ("num_steps", C.c_int32), ("mean", C.POINTER(C.c_float)),
-                ("R", C.POINTER(C.POINTER(C.c_float))), ("R_rows", C.POINTER(C.c_int32)), ("hog_variant", C.c_int32)]
+                ("R", C.POINTER(C.POINTER(C.c_float))), ("R_rows", C.POINTER(C.c_int32)), ("hog_variant", C.c_int32),
+                ("desc_params", C.POINTER(C.c_int32))]
 
 
 DET_DTYPE = np.dtype([("cx", "<i4"), ("cy", "<i4"), ("w", "<i4"), ("h", "<i4"), ("layer", "<i4"), ("lx", "<i4"),
@@ -1027,6 +1028,11 @@ class Sdm:
         s.R = C.cast(ptrs, C.POINTER(C.POINTER(C.c_float)))
         s.R_rows = rows.ctypes.data_as(C.POINTER(C.c_int32))
         s.hog_variant = int(model["variant"])
+        # per step {numCells, cellSize, numBins}: the non-adaptive branch of optimize() (SdmLandmarkModel.hpp:236-238,246-248)
+        self._dp = _c(model["desc_params"], np.int32) if model.get("desc_params") is not None else None
+        if self._dp is not None:
+            assert self._dp.size == 3 * S
+            s.desc_params = self._dp.ctypes.data_as(C.POINTER(C.c_int32))
         self.h = C.c_void_p()
         ctx.check(lib().fd_sdm_create(ctx.h, C.byref(s), C.byref(self.h)))
         self.L, self.S = L, S

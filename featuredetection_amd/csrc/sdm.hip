@@ -93,7 +93,7 @@ __global__ void k_sdm_prepare(const float* __restrict__ shapes, int B, int L, in
     const int f = t / L, i = t - f * L;
     const float* s = shapes + (size_t)f * 2 * L;
     int pwh = fixedHalf;
-    float dist = 0.f;
+    float dist = 1.f;   // non-adaptive: modelShape + deltaShape.t() (SdmLandmarkModel.hpp:246-248); delta * 1.0f is exact
     if (adaptive) {
         // SdmLandmarkModel.hpp:212-229
         const float a1x = (s[8] + s[9]) / 2.0f, a1y = (s[8 + L] + s[9 + L]) / 2.0f;
@@ -636,6 +636,7 @@ struct SdmScratch {
 struct fd_sdm {
     fd_ctx* ctx;
     int L, S, variant;
+    std::vector<int> descParams;   // empty: adaptive; else 3 per step {numCells, cellSize, numBins}
     std::vector<float> mean;
     std::vector<int> Rrows;
     std::vector<std::unique_ptr<DevBuf>> R;
@@ -704,7 +705,9 @@ extern "C" {
 int fd_sdm_create(fd_ctx* ctx, const fd_sdm_model* md, fd_sdm** out) {
     return fd_guard(ctx, [&] {
         if (!ctx || !md || !out || !md->mean || !md->R || !md->R_rows) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_sdm_create: NULL argument");
-        if (md->num_landmarks < 13) FD_THROW(FD_ERR_INVALID_ARGUMENT, "SdmLandmarkModelFitting needs landmarks 8,9,11,12 (SdmLandmarkModel.hpp:212-216)");
+        if (md->num_landmarks < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "SdmLandmarkModel: no landmarks");
+        if (!md->desc_params && md->num_landmarks < 13)
+            FD_THROW(FD_ERR_INVALID_ARGUMENT, "SdmLandmarkModelFitting needs landmarks 8,9,11,12 (SdmLandmarkModel.hpp:212-216)");
         if (md->num_steps < 1) FD_THROW(FD_ERR_INVALID_ARGUMENT, "SdmLandmarkModel: no cascade steps");
         if (md->hog_variant != 0 && md->hog_variant != 1)
             FD_THROW(FD_ERR_LOGIC, "descriptorType does not match 'vlhog-dt' or 'vlhog-uoctti'");
@@ -716,8 +719,18 @@ int fd_sdm_create(fd_ctx* ctx, const fd_sdm_model* md, fd_sdm** out) {
         m->variant = md->hog_variant;
         m->mean.assign(md->mean, md->mean + 2 * m->L);
         const int dim = m->variant == 1 ? 31 : 36;
+        if (md->desc_params) m->descParams.assign(md->desc_params, md->desc_params + 3 * (size_t)m->S);
         for (int s = 0; s < m->S; ++s) {
-            if (md->R_rows[s] != m->L * 9 * dim + 1)
+            if (md->desc_params) {
+                // the non-adaptive branch: the descriptor length follows from the step's own {numCells, cellSize, numBins}
+                const int32_t* dp = md->desc_params + 3 * s;
+                if (dp[0] < 1 || dp[1] < 1 || dp[2] < 1) FD_THROW(FD_ERR_LOGIC, "descriptorParameters must contain numCells, cellSize and numBins.");
+                DescParams p;
+                fill_desc_params(p, 64, 64, m->L, false, m->variant, dp[0], dp[1], dp[2], 2 * (dp[0] * (dp[1] / 2)));
+                if (md->R_rows[s] != m->L * p.len + 1)
+                    FD_THROW(FD_ERR_INVALID_ARGUMENT, "regressor %d has %d rows, expected %d (%dx%dx%d descriptor per landmark + bias)",
+                             s, md->R_rows[s], m->L * p.len + 1, p.hogW, p.hogH, p.dim);
+            } else if (md->R_rows[s] != m->L * 9 * dim + 1)
                 FD_THROW(FD_ERR_INVALID_ARGUMENT, "regressor %d has %d rows, expected %d (adaptive 3x3x%d descriptor per landmark + bias)",
                          s, md->R_rows[s], m->L * 9 * dim + 1, dim);
             m->Rrows.push_back(md->R_rows[s]);
@@ -784,25 +797,40 @@ static void sdm_launch(fd_ctx* ctx, fd_sdm* m, SdmScratch& sc, hipStream_t st, c
         HIP_CHECK(hipMemcpyAsync(sc.images.p, gray_images, (size_t)W * H * B, hipMemcpyHostToDevice, st));
         dimg = sc.images.as<uint8_t>();
     }
-    DescParams p;
-    fill_desc_params(p, W, H, L, true, m->variant, 3, 10, 9, 30);
-    p.image_stride = (int64_t)W * H;
-    const int F = L * p.len;
-    const int nchunks = (F + RG_KCHUNK - 1) / RG_KCHUNK;
+    const bool adaptive = m->descParams.empty();
+    // per step: the descriptor geometry (one for all steps when adaptive) and the half window of the non-adaptive branch
+    std::vector<DescParams> ps(adaptive ? 1 : m->S);
+    std::vector<int> half(ps.size(), 0);
+    int Fmax = 0;
+    for (size_t s = 0; s < ps.size(); ++s) {
+        if (adaptive) fill_desc_params(ps[s], W, H, L, true, m->variant, 3, 10, 9, 30);
+        else {
+            const int* dp = &m->descParams[3 * s];
+            half[s] = dp[0] * (dp[1] / 2);   // patchWidthHalf = numCells * (cellSize / 2), DescriptorExtractor.hpp:142
+            fill_desc_params(ps[s], W, H, L, false, m->variant, dp[0], dp[1], dp[2], 2 * half[s]);
+        }
+        ps[s].image_stride = (int64_t)W * H;
+        Fmax = std::max(Fmax, L * ps[s].len);
+    }
+    const int nchunksMax = (Fmax + RG_KCHUNK - 1) / RG_KCHUNK;
     const size_t nshape = (size_t)B * N;
     sc.shapes.reserve(sizeof(float) * nshape);
     sc.origin.reserve(sizeof(int32_t) * 4 * (size_t)B * L);
     sc.dist.reserve(sizeof(float) * B);
     sc.status.reserve(sizeof(int32_t) * B);
-    sc.desc.reserve(sizeof(float) * (size_t)B * F);
-    sc.partial.reserve(sizeof(double) * (size_t)nchunks * B * N);
+    sc.desc.reserve(sizeof(float) * (size_t)B * Fmax);
+    sc.partial.reserve(sizeof(double) * (size_t)nchunksMax * B * N);
     sc.hstatus.reserve(sizeof(int32_t) * B);
     HIP_CHECK(hipMemcpyAsync(sc.shapes.p, sc.hshapes.p, sizeof(float) * nshape, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemsetAsync(sc.status.p, 0, sizeof(int32_t) * B, st));
     const int64_t nitems = (int64_t)B * L;
     for (int step = 0; step < m->S; ++step) {
         const double stepFactor = 1 / (1 + std::exp((double)((step + 1) - m->S)));  // :226, double on the host
-        hipLaunchKernelGGL(k_sdm_prepare, dim3((B * L + 255) / 256), dim3(256), 0, st, sc.shapes.as<float>(), B, L, W, H, 1, 0, 1 << 20, stepFactor,
+        const DescParams& p = ps[adaptive ? 0 : step];
+        const int F = L * p.len;
+        const int nchunks = (F + RG_KCHUNK - 1) / RG_KCHUNK;
+        hipLaunchKernelGGL(k_sdm_prepare, dim3((B * L + 255) / 256), dim3(256), 0, st, sc.shapes.as<float>(), B, L, W, H, adaptive ? 1 : 0,
+                           adaptive ? 0 : half[step], adaptive ? (1 << 20) : SDM_IMG, stepFactor,
                            sc.origin.as<int32_t>(), sc.dist.as<float>(), sc.status.as<int32_t>());
         int grid = (int)std::min<int64_t>((nitems + 1) / 2, (int64_t)ctx->num_cus * descriptor_blocks_per_cu(p));
         if (grid >= 16) grid &= ~7;   // a multiple of the 8 XCDs: the kernel then keeps every face on one XCD

@@ -26,6 +26,9 @@ public:
     cv::Mat getDescriptors(const cv::Mat image, std::vector<cv::Point2f> locations, int windowSizeHalf) override;
     std::string getParameterString() const override;
     VlHogType getType() const { return hogType; }
+    int getNumCells() const { return numCells; }
+    int getCellSize() const { return cellSize; }
+    int getNumBins() const { return numBins; }
 private:
     VlHogType hogType;
     int numCells, cellSize, numBins;
@@ -59,7 +62,10 @@ private:
 // SdmLandmarkModel.hpp:143-259
 class SdmLandmarkModelFitting {
 public:
-    explicit SdmLandmarkModelFitting(SdmLandmarkModel model);
+    // adaptive = true is the reference as compiled (`if (true) { // adaptive`, SdmLandmarkModel.hpp:209,243).  adaptive = false is the
+    // `else` branch of the same lines (the extractors' own numCells / cellSize / numBins, no face-size factor), which upstream cannot
+    // reach at run time; it exists here because the one model the reference ships (SDM_Model_HOG_Zhenhua_11012014.txt) needs it.
+    explicit SdmLandmarkModelFitting(SdmLandmarkModel model, bool adaptive = true);
     ~SdmLandmarkModelFitting();
     cv::Mat alignRigid(cv::Mat modelShape, cv::Rect faceBox) const;    // :156-192
     cv::Mat optimize(cv::Mat modelShape, cv::Mat image);               // :199-256 -> fd_sdm_optimize_batch

@@ -1508,7 +1508,7 @@ SdmLandmarkModel SdmLandmarkModel::load(string filename) {   // SdmLandmarkModel
     return model;
 }
 
-SdmLandmarkModelFitting::SdmLandmarkModelFitting(SdmLandmarkModel m) : model(m), handle(nullptr) {
+SdmLandmarkModelFitting::SdmLandmarkModelFitting(SdmLandmarkModel m, bool adaptive) : model(m), handle(nullptr) {
     const int L = model.getNumLandmarks(), S = model.getNumCascadeSteps();
     if (S == 0) return;
     Mat mean = model.getMeanShape();
@@ -1520,9 +1520,18 @@ SdmLandmarkModelFitting::SdmLandmarkModelFitting(SdmLandmarkModel m) : model(m),
     for (int s = 0; s < S; ++s) { regs.push_back(contiguous(model.getRegressorData(s))); R.push_back(regs.back().ptr<float>(0)); rows.push_back(regs.back().rows); }
     auto vl = std::dynamic_pointer_cast<VlHogDescriptorExtractor>(model.getDescriptorExtractor(0));
     if (!vl) throw std::logic_error("SdmLandmarkModelFitting: only VlHog descriptors are available on this backend");
-    fd_sdm_model md;
+    fd_sdm_model md = {};
     md.num_landmarks = L; md.num_steps = S; md.mean = meanv.data(); md.R = R.data(); md.R_rows = rows.data();
     md.hog_variant = vl->getType() == VlHogDescriptorExtractor::VlHogType::Uoctti ? 1 : 0;
+    vector<int32_t> dp;
+    if (!adaptive) {   // SdmLandmarkModel.hpp:236-238: "non-adaptive, the descriptorExtractor has all necessary params"
+        for (int s = 0; s < S; ++s) {
+            auto e = std::dynamic_pointer_cast<VlHogDescriptorExtractor>(model.getDescriptorExtractor(s));
+            if (!e || e->getType() != vl->getType()) throw std::logic_error("SdmLandmarkModelFitting: the cascade steps must share one VlHog type");
+            dp.push_back(e->getNumCells()); dp.push_back(e->getCellSize()); dp.push_back(e->getNumBins());
+        }
+        md.desc_params = dp.data();
+    }
     check(fd_sdm_create(context(), &md, &handle));
 }
 SdmLandmarkModelFitting::~SdmLandmarkModelFitting() { fd_sdm_destroy(handle); }

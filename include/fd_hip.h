@@ -427,6 +427,15 @@ typedef struct {
     const float* const* R;      /* per step: (feature_dim+1) x 2L row-major regressor (last row = bias) */
     const int32_t* R_rows;      /* per step: feature_dim + 1 */
     int32_t hog_variant;        /* 0 DalalTriggs, 1 UoCTTI (VlHogDescriptorExtractor::VlHogType) */
+    const int32_t* desc_params; /* NULL: optimize() as the reference compiles it -- `if (true) { // adaptive` (SdmLandmarkModel.hpp:209,
+                                 * 243): every step uses the 30x30 / 3x3 cells / 9 bins descriptor whatever the model file says
+                                 * (DescriptorExtractor.hpp:132-139), R_rows[s] = L*279 + 1 (UoCTTI) or L*324 + 1.  Non-NULL: the
+                                 * non-adaptive `else` branches of :236-238 and :246-248 (present upstream, compiled out by the `if
+                                 * (true)`): per step {numCells, cellSize, numBins} of VlHogDescriptorExtractor(type, numCells, cellSize,
+                                 * numBins) (SdmLandmarkModel.cpp:188-204), getDescriptors(image, points) with windowSizeHalf = 0 and
+                                 * modelShape + deltaShape.t() without the face-size factor.  This is the only way the regressors of the
+                                 * reference's shipped model (detect-landmarks/share/models/SDM_Model_HOG_Zhenhua_11012014.txt: 144 / 144 /
+                                 * 64 / 64 / 16 dimensions per landmark) can be applied at all. */
 } fd_sdm_model;
 int fd_sdm_create(fd_ctx* ctx, const fd_sdm_model* model, fd_sdm** out);
 void fd_sdm_destroy(fd_sdm* m);

@@ -176,6 +176,12 @@ void orc_sdm_align_rigid(float* shape, int L, const int* faceBox);
 /* SdmLandmarkModel.hpp:199-256 (adaptive branch).  R[s] = (featDim+1) x 2L row-major.  Returns 0 or -1 */
 int orc_sdm_optimize(const uint8_t* gray, int w, int h, float* shape, int L, int S,
                      const float* const* R, const int* Rrows, int variant);
+/* The non-adaptive branches of the same function (:236-238, :246-248; compiled out upstream by `if (true)`): getDescriptors(image,
+ * points) with the extractor's own parameters descParams[3*step + {0,1,2}] = {numCells, cellSize, numBins}, shape += delta.
+ * Used for the reference's one shipped model (detect-landmarks/share/models/SDM_Model_HOG_Zhenhua_11012014.txt), whose regressors
+ * are 144/144/64/64/16 dimensions per landmark and cannot be multiplied with the adaptive 279-dimensional descriptors. */
+int orc_sdm_optimize_fixed(const uint8_t* gray, int w, int h, float* shape, int L, int S,
+                           const float* const* R, const int* Rrows, int variant, const int* descParams);
 
 #ifdef __cplusplus
 }

@@ -174,11 +174,31 @@ static int sdm_descriptors(const uchar* gray, int W, int H, const float* px, con
 // OpenCV's GEMM for CV_32F (gemmImpl<float,double>) accumulates each dot product in double and
 // rounds once to float; the bias row is added afterwards in float (MatExpr a*b + c -> gemm with
 // beta=1 adds inside the double accumulator).  We restate it as double accumulate + one rounding.
+// descParams == NULL: the branch the reference compiles in (`if (true) { // adaptive`, :209,243).  Otherwise the `else` branches of
+// :236-238 and :246-248 ("non-adaptive, the descriptorExtractor has all necessary params"): getDescriptors(image, points) with
+// windowSizeHalf = 0, i.e. the extractor's own {numCells, cellSize, numBins} (descParams[3*step ..]), and modelShape + deltaShape.t()
+// without the face-size factor.
 static int sdm_optimize(const uchar* gray, int W, int H, float* shape, int L, int S, const float* const* R,
-                        const int* Rrows, int variant) {
+                        const int* Rrows, int variant, const int* descParams = nullptr) {
     std::vector<float> px(L), py(L), feats, delta(2 * (size_t)L);
     for (int step = 0; step < S; ++step) {
         for (int i = 0; i < L; ++i) { px[i] = shape[i]; py[i] = shape[i + L]; }
+        if (descParams) {
+            const int* dp = descParams + 3 * step;
+            int len = sdm_descriptors(gray, W, H, px.data(), py.data(), L, 0, variant, dp[0], dp[1], dp[2], feats);
+            if (len < 0) return -1;
+            const int F = len * L;
+            if (Rrows[step] != F + 1) return -2;
+            const float* Rm = R[step];
+            for (int j = 0; j < 2 * L; ++j) {
+                double acc = 0;
+                for (int k = 0; k < F; ++k) acc += (double)feats[k] * (double)Rm[(size_t)k * 2 * L + j];
+                acc += (double)Rm[(size_t)F * 2 * L + j];
+                delta[j] = (float)acc;
+            }
+            for (int j = 0; j < 2 * L; ++j) shape[j] = shape[j] + delta[j];
+            continue;
+        }
         float a1x = (shape[8] + shape[9]) / 2.0f, a1y = (shape[8 + L] + shape[9 + L]) / 2.0f;
         float a2x = (shape[11] + shape[12]) / 2.0f, a2y = (shape[11 + L] + shape[12 + L]) / 2.0f;
         // cv::norm(Vec2f) = sqrt of the double-accumulated squares
@@ -235,5 +255,9 @@ void orc_sdm_align_rigid(float* shape, int L, const int* fb) {
 int orc_sdm_optimize(const uint8_t* gray, int w, int h, float* shape, int L, int S, const float* const* R,
                      const int* Rrows, int variant) {
     return sdm_optimize(gray, w, h, shape, L, S, R, Rrows, variant);
+}
+int orc_sdm_optimize_fixed(const uint8_t* gray, int w, int h, float* shape, int L, int S, const float* const* R,
+                           const int* Rrows, int variant, const int* descParams) {
+    return sdm_optimize(gray, w, h, shape, L, S, R, Rrows, variant, descParams);
 }
 }

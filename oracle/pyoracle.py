@@ -88,6 +88,7 @@ def lib():
                                           C.c_int, C.c_int, C.c_void_p]
         l.orc_sdm_align_rigid.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         l.orc_sdm_optimize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        l.orc_sdm_optimize_fixed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         l.orc_equalize_hist.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         l.orc_whi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
         l.orc_whitening.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
@@ -586,5 +587,9 @@ def sdm_fit(gray, model, face_box):
     Rs = [_c(r, np.float32) for r in model["R"]]
     ptrs = (C.c_void_p * S)(*[r.ctypes.data for r in Rs])
     rows = _c([r.shape[0] for r in Rs], np.int32)
+    if model.get("desc_params") is not None:   # the non-adaptive branch (SdmLandmarkModel.hpp:236-238,246-248)
+        dp = _c(model["desc_params"], np.int32)
+        st = lib().orc_sdm_optimize_fixed(_p(gray), gray.shape[1], gray.shape[0], _p(shape), L, S, ptrs, _p(rows), int(model["variant"]), _p(dp))
+        return st, shape
     st = lib().orc_sdm_optimize(_p(gray), gray.shape[1], gray.shape[0], _p(shape), L, S, ptrs, _p(rows), int(model["variant"]))
     return st, shape

@@ -773,6 +773,52 @@ def test_sdm_fit_batch(oracle, capi, ctx, synth):
     sg.close()
 
 
+def test_sdm_real_regressors(oracle, capi, ctx, synth):
+    """VERDICT r04 task 2: the reference's real trained regressors (SDM_Model_HOG_Zhenhua_11012014.txt re-packed by
+    tests/golden/make_sdm_real.py; coefficients ~5e-2, landmarks move 5-15 px per step) through fd_sdm_fit_batch, all 5 steps, on the
+    32 seeded crops of the fixture.  Tolerance: 1e-4 relative per landmark coordinate (north_star).  Descriptors of every step at the
+    oracle's landmark positions are bit-identical to the reference's own hog.c (the committed ref_desc arrays)."""
+    import importlib.util
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_sdm_real", os.path.join(G, "make_sdm_real.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = np.load(os.path.join(G, "sdm_real_11012014.npz"))
+    model = mod.unpack_model(g)
+    L, S, B = model["L"], model["S"], int(g["nfaces"])
+    imgs = np.stack([synth.make_frame(256, 256, seed=int(g["frame_seed0"]) + i, channels=1) for i in range(B)])
+    boxes = np.tile(g["face_box"].astype(np.int32), (B, 1))
+    sg = capi.Sdm(ctx, model)
+    shapes, status = sg.fit(imgs, boxes)
+    assert not status.any()
+    ref = g["oracle_shapes"][:, S]
+    err = np.abs(shapes - ref) / np.maximum(np.abs(ref), 1.0)
+    assert err.max() <= 1e-4, (err.max(), np.argwhere(err > 1e-4)[:5])
+    # every intermediate step as well (prefix models): a cvRound(landmark) that flipped at step s would show here first
+    for s in range(1, S):
+        sub = dict(model, S=s, R=model["R"][:s], desc_params=model["desc_params"][:3 * s])
+        sh, st = capi.Sdm(ctx, sub).fit(imgs, boxes)
+        ref_s = g["oracle_shapes"][:, s]
+        e = np.abs(sh - ref_s) / np.maximum(np.abs(ref_s), 1.0)
+        assert not st.any() and e.max() <= 1e-4, (s, e.max())
+    # live oracle on two faces (the committed shapes are its output in the build container)
+    for f in (3, 29):
+        st, r = oracle.sdm_fit(imgs[f], model, boxes[f])
+        assert st == 0 and np.array_equal(r, ref[f])
+    # descriptors of every step: HIP kernel == the reference's hog.c
+    for f in (0, 17):
+        for s in range(S):
+            nc, cp, nb = [int(v) for v in model["desc_params"][3 * s:3 * s + 3]]
+            shp = g["oracle_shapes"][f, s]
+            d = capi.sdm_descriptors(ctx, imgs[f], shp[:L].copy(), shp[L:].copy(), 0, variant=1, num_cells=nc, cell_size=cp, num_bins=nb)
+            assert np.array_equal(d, g["ref_desc_f%d_s%d" % (f, s)]), (f, s)
+    sg.close()
+    # a model whose rows do not fit its descriptor parameters is refused (the reference's gemm would assert)
+    bad = dict(model, desc_params=np.array([3, 3, 4] * S, np.int32))
+    with pytest.raises(capi.FdError):
+        capi.Sdm(ctx, bad)
+
+
 def test_errors_are_reported_not_swallowed(capi, ctx):
     with pytest.raises(capi.FdError) as e:
         capi.Pyramid(ctx, octave_layers=0, min_scale=0.1, max_scale=1.0)

@@ -18,6 +18,40 @@ def test_vlhog_matches_reference_hog_c(oracle):
         assert np.array_equal(out, g["out%d" % i]), "case %d differs from hog.c" % i  # bit-exact
 
 
+def _sdm_real():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_sdm_real", os.path.join(G, "make_sdm_real.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)   # only defines functions; main() (which reads /root/reference) is not run
+    g = np.load(os.path.join(G, "sdm_real_11012014.npz"))
+    return g, mod.unpack_model(g)
+
+
+def test_sdm_real_regressors_oracle(oracle, synth):
+    """The reference's one trained model (detect-landmarks/share/models/SDM_Model_HOG_Zhenhua_11012014.txt, re-packed by
+    tests/golden/make_sdm_real.py: 22 landmarks, 5 steps, non-adaptive branch of optimize()) through the oracle: the committed per-step
+    shapes are reproduced, and the oracle's descriptors at every step equal what the reference's own hog.c produced for them."""
+    g, model = _sdm_real()
+    L, S = model["L"], model["S"]
+    assert [r.shape for r in model["R"]] == [(3169, 44), (3169, 44), (1409, 44), (1409, 44), (353, 44)]
+    fb = g["face_box"]
+    for f in (0, 17, 31):
+        img = synth.make_frame(256, 256, seed=int(g["frame_seed0"]) + f, channels=1)
+        st, sh = oracle.sdm_fit(img, model, fb)
+        assert st == 0 and np.array_equal(sh, g["oracle_shapes"][f, S])
+        if f == 31:
+            continue
+        for s in range(S):
+            nc, cp, nb = [int(v) for v in model["desc_params"][3 * s:3 * s + 3]]
+            sh = g["oracle_shapes"][f, s]
+            d = oracle.sdm_descriptors(img, sh[:L], sh[L:], 0, variant=1, num_cells=nc, cell_size=cp, num_bins=nb)
+            assert d.shape == (L, nc * nc * 16)
+            assert np.array_equal(d, g["ref_desc_f%d_s%d" % (f, s)]), (f, s)   # bit-exact against hog.c
+    # the landmarks really move at these magnitudes (the synthetic models of config 4 move them by ~1e-2 px)
+    mv = np.abs(np.diff(g["oracle_shapes"], axis=1)).max(axis=(0, 2))
+    assert mv.min() > 1.0
+
+
 def test_iimg_matches_reference_iimg_cpp(oracle):
     g = np.load(os.path.join(G, "ref_iimg.npz"))
     for i in range(int(g["n"])):
