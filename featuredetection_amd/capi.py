@@ -146,6 +146,8 @@ _SIGS = {
     "fd_dist_world": (C.c_int, [C.c_void_p]),
     "fd_pack_records": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_int, C.c_void_p]),
     "fd_dist_gather_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "fd_dist_gather_discard": (None, [C.c_void_p]),
+    "fd_dist_gather_pending": (C.c_int, [C.c_void_p]),
     "fd_pyramid_set_gradient_blur": (C.c_int, [C.c_void_p, C.c_int]),
     "fd_pyramid_window_count": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]),
     "fd_pyramid_windows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
@@ -470,6 +472,13 @@ class Dist:
         n, tr = C.c_int64(), C.c_int()
         self.ctx.check(lib().fd_dist_gather_records(self.h, _ptr(local), len(local), cap, _ptr(out), len(out), C.byref(n), C.byref(tr)))
         return out[:n.value], bool(tr.value)
+
+    def discard(self):
+        """fd_dist_gather_discard: drop the gathered set a count-only call / FD_ERR_CAPACITY left in the handle"""
+        lib().fd_dist_gather_discard(self.h)
+
+    def pending(self):
+        return bool(lib().fd_dist_gather_pending(self.h))
 
     def close(self):
         if self.h:

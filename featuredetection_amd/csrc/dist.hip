@@ -98,7 +98,9 @@ int fd_dist_init(fd_ctx* ctx, int rank, int world, const uint8_t* id, fd_dist** 
         d->ctx = ctx;
         d->rank = rank;
         d->world = world;
-        if (world > 1) {   // a single rank gathers from itself: no communicator, no librccl
+        // A single rank gathers from itself: no communicator, no librccl -- unless the caller hands in a communicator id, which asks for a
+        // real one-rank communicator (ncclCommInitRank(world = 1)); the gather then goes through ncclAllGather like with N ranks.
+        if (world > 1 || id) {
             HIP_CHECK(hipSetDevice(ctx->device));
             ncclUniqueId u;
             std::memcpy(&u, id, sizeof(u));
@@ -113,6 +115,17 @@ void fd_dist_destroy(fd_dist* d) {
     if (d->comm) (void)rccl().CommDestroy(d->comm);
     delete d;
 }
+
+// Drops the records a finished collective left in the handle (a count-only call, or FD_ERR_CAPACITY, that the caller does not follow up):
+// the next fd_dist_gather_records is a new collective again.  EVERY rank must drop (or take) a set -- a rank that still holds one
+// would answer the next call from its handle while the others enter ncclAllGather.
+void fd_dist_gather_discard(fd_dist* d) {
+    if (!d) return;
+    d->pending.clear();
+    d->havePending = false;
+    d->pendingTrunc = false;
+}
+int fd_dist_gather_pending(const fd_dist* d) { return d && d->havePending ? 1 : 0; }
 
 int fd_dist_rank(const fd_dist* d) { return d ? d->rank : 0; }
 int fd_dist_world(const fd_dist* d) { return d ? d->world : 1; }
@@ -148,7 +161,7 @@ int fd_dist_gather_records(fd_dist* d, const fd_record* local, int n_local, int 
             if (n) std::memcpy(hs + 1, local, sizeof(fd_record) * (size_t)n);
             const fd_record* hr = hs;
             const size_t used = sizeof(fd_record) * ((size_t)n + 1);
-            if (W > 1) {
+            if (d->comm) {
                 HIP_CHECK(hipSetDevice(d->ctx->device));
                 hipStream_t st = d->ctx->stream;
                 d->dsend.reserve(bytes);

@@ -175,6 +175,13 @@ __global__ __launch_bounds__(256) void k_fs_oe(FstTable T, FstIO io) {
                 const double t1 = T.logA + T.logB * (double)x1, t2 = T.logA + T.logB * (double)x2;
                 const double ex = exp(t1 < t2 ? t1 : t2);   // the smaller e of the pair: where 1 + e resolves least
                 const double gap = ex / (1.0 + ex) * fabs(T.logB) * fabs((double)x1 - (double)x2);
+                // gap = relative distance of the two (1 + e) values, to first order.  The host evaluates p = 1.0f / (1.0f + exp(t)) in double:
+                // exp is within 1 ulp (glibc states < 1 ulp for its double exp; ocml the same), the sum and the quotient add 0.5 ulp each,
+                // so a computed p is within ~3 ulp (6.7e-16 relative) of the exact one, and two p whose exact values differ by more than
+                // ~1.4e-15 relative keep their order whatever the libm.  1e-14 (45 ulp) leaves a factor of seven for a libm with a 5-ulp
+                // exp and for the first-order estimate; anything closer goes to the host path, which sorts the doubles it computed itself.
+                // tests/test_host_logic.py::test_probability_order_margin_of_the_device_overlap_elimination sweeps adjacent fp32 outputs
+                // up to saturation against THIS host's libm.
                 if (!(gap > 1e-14)) amb = 1;
             }
             sCx[i] = cxv;   // entry i of eFoutBits: only this thread's key was built from it, and the keys are complete

@@ -704,6 +704,7 @@ void fd_svm_rbf_mfma_launch(fd_ctx* ctx, const fd_svm* m, const float* xFrag, co
     HIP_CHECK(hipGetLastError());
 }
 
+bool fd_svm_u8_mfma_available(const fd_svm* m);
 // generic scoring of n device-resident feature vectors (optionally gathered by slot index)
 void fd_svm_generic_launch_on(hipStream_t st, const fd_svm* m, const void* dfeat, const uint32_t* didx, int64_t stride_bytes,
                               int64_t n, double* dout);
@@ -715,19 +716,15 @@ void fd_svm_generic_launch(fd_ctx* ctx, const fd_svm* m, const void* dfeat, cons
 void fd_svm_generic_launch_on(hipStream_t st, const fd_svm* m, const void* dfeat, const uint32_t* didx, int64_t stride_bytes,
                               int64_t n, double* dout) {
     if (n <= 0) return;
-    static const bool u8Lanes = [] { const char* e = getenv("FD_SVM_U8_LANES"); return e && atoi(e) != 0; }();   // A/B: the older kernel
-    // LDS of k_svm_u8_rbf_mfma: 32 patches + one partial sum per (tile of 32 support vectors, patch); beyond the 64 KB a launch gets
-    // without opting in (very long vectors with thousands of support vectors) the lane-per-support-vector kernel takes over
-    const size_t lb = (size_t)32 * (m->dev.KS * 32 + 16) + 384 + sizeof(double) * (size_t)(m->dev.nsv32 >> 5) * 32;
-    if (m->dev.dtype == FD_DTYPE_U8 && m->dev.kernel == FD_KERNEL_RBF && m->dev.svA && !u8Lanes && lb <= 64 * 1024) {
+    // u8 RBF: k_svm_u8_rbf_mfma wherever fd_svm_u8_mfma_available says so -- ONE predicate for this launcher and for the device tail
+    // of the five-stage entry points, so a call never mixes two kernels with different summation orders.  (Its LDS: 32 patches + one
+    // partial sum per (tile of 32 support vectors, patch); beyond the 64 KB a launch gets without opting in -- very long vectors with
+    // thousands of support vectors -- the lane-per-support-vector kernel takes over.  A 16-wavefront variant made a lone small launch
+    // faster, 25 -> 21 us, and cost config 3 a third of its throughput: whole CUs taken from the other calls' kernels; removed.)
+    if (fd_svm_u8_mfma_available(m)) {
+        const size_t lb = (size_t)32 * (m->dev.KS * 32 + 16) + 384 + sizeof(double) * (size_t)(m->dev.nsv32 >> 5) * 32;
         const unsigned grid = (unsigned)((n + 31) / 32);
-        // Sixteen wavefronts per workgroup (and a tile's operands sixteen k-steps ahead) make a lone small launch faster -- 25 -> 21 us for
-        // the 4.7 K patches of a headline call, 156 instead of 160 us for a single frame -- but its 1024-thread, 106-register workgroups
-        // take whole CUs away from the kernels of other calls: config 3 (30 cascades in flight) fell from 5.5 to 3.9 G patches/s.  Hence
-        // only on request (FD_SVM_WAVES=16), never by default.
-        static const bool wide = [] { const char* e = getenv("FD_SVM_WAVES"); return e && atoi(e) == 16; }();
-        if (wide && grid < 256u) hipLaunchKernelGGL(k_svm_u8_rbf_mfma<16>, dim3(grid), dim3(64 * 16), lb, st, m->dev, dfeat, didx, stride_bytes, n, dout, (const unsigned int*)nullptr);
-        else hipLaunchKernelGGL(k_svm_u8_rbf_mfma<8>, dim3(grid), dim3(64 * 8), lb, st, m->dev, dfeat, didx, stride_bytes, n, dout, (const unsigned int*)nullptr);
+        hipLaunchKernelGGL(k_svm_u8_rbf_mfma<8>, dim3(grid), dim3(64 * 8), lb, st, m->dev, dfeat, didx, stride_bytes, n, dout, (const unsigned int*)nullptr);
         HIP_CHECK(hipGetLastError());
         return;
     }

@@ -44,9 +44,6 @@ constexpr int WVM_MAX_VALS = 16;     // grey values per filter
 constexpr int WVM_FIRST_CHUNK = 4096;  // positives fetched together with the counter
 constexpr int WVM_LCAP = 16;         // filters evaluated by the one-wave-per-window stage; survivors go to k_wvm_deep
 constexpr int WVM_PJ = 5;            // up to 320 filters (largest cfg-implied WVM: 280)
-constexpr int WVM_RECCAP = 1280;     // rect records of a chunk staged in LDS by k_wvm_deepB
-constexpr int wvm_reccap_for(int pw, int ph) { return (pw && (pw + 1) * (ph + 1) > 700) ? WVM_RECCAP * 3 / 5 : WVM_RECCAP; }   // 32x24: four workgroups per CU
-constexpr int WVM_SVS = 17;          // stride of a class's grey-value sums in k_wvm_deepB (odd: lane == class reads are conflict-free)
 
 struct WinLayerDev {
     int32_t bx, by, nx, ny;
@@ -62,9 +59,6 @@ struct WinTable {
     int32_t raw;   // != 0: arena holds `total` contiguous, already equalised patches (fd_wvm_eval_batch)
     int64_t total;
     const int32_t* list;   // != NULL: `total` explicit windows {layer position, lx, ly}; l[i] then describes kept layer i
-    // != NULL: only the windows widq[0 .. *widq_count) are evaluated (written by k_wvm_prefilter earlier on the same stream)
-    const int64_t* widq;
-    const unsigned int* widq_count;
     // multi-frame pyramid (fd_pyramid_set_frames): window id = frame * per_image + id inside the frame; frame f's layers are at
     // arena + f * image_stride.  total = nimg * per_image.
     int32_t nimg, pad_;
@@ -98,22 +92,6 @@ struct WvmDev {
     const uint8_t* rectV;      // grey-value index v (>= 1) of each rect
     const uint4* lvlRec;       // [numFilters][64]: lane l -> {rect l, v tag of rect l, val[l] (double bits)}
     const struct WvmLevelHdr* lvlHdr;   // [numFilters]
-    // generation-major tables of k_wvm_deepB (generation g = filters g * numPer .. g * numPer + numPer - 1; numPer <= 32)
-    // all rects of a generation, class by class; 64 zero records appended.  x = A | B << 12 | tag[7:0] << 24, y = C | D << 12 | tag[9:8] << 24:
-    // sum = I[A] - I[B] - I[C] + I[D] in the zero-padded integral image, tag = class * WVM_SVS + grey-value index
-    const uint2* genRec;
-    const int32_t* genBegin;   // [generations + 1] into genRec
-    const int32_t* genMaxCnt;  // [generations] largest grey-value count of the generation
-    const int32_t* cntG;       // [generations][32] grey-value count of class n
-    const double* ppG;         // [generations][32]
-    const double* valG;        // [generations][16][32]: val[v] of class n
-    int32_t maxCnt;            // largest grey-value count of the model
-    // wT again, four terms per load: wP[(p / 4) * Fp + k] = {wT[p][k], wT[p + 1][k], wT[p + 2][k], wT[p + 3][k]}, p a multiple of 4
-    const float4* wP;
-    int32_t Fp;                // row length of wP (numFilters rounded up to 64, + 64)
-    // k_wvm_deepB's chunk starting at generation g: {generations whose rect records fit its LDS stage (0: not even one: staged
-    // piecewise), genBegin[g], genBegin[g + max(x, 1)], 0} -- one load instead of a chain of dependent ones per chunk
-    const int4* chunkPlan;
 };
 
 struct PosRec {
@@ -163,13 +141,13 @@ struct WvbState {
 struct fd_wvm {
     fd_ctx* ctx;
     WvmDev dev;
-    DevBuf thresholds, wT, pp, valOff, val, rectBegin, rects, rectV, lvlRec, lvlHdr, genRec, genBegin, genMaxCnt, cntG, ppG, valG, wP, chunkPlan;
+    DevBuf thresholds, wT, pp, valOff, val, rectBegin, rects, rectV, lvlRec, lvlHdr;
     double logisticA, logisticB;
     std::vector<float> h_thresholds;
     // scratch reused across calls
     DevBuf all_level, all_fout, pos, pos_patches, counter, deep_q, list;
     // dense pre-filter (wvm_dense.hpp): digit matrix, constants, queue of the windows it lets through
-    DevBuf denseB, denseC, pre_q;
+    DevBuf denseB, denseC;
     bool hdrClean = false;    // device header words are zero (left so by a zero-copy run): no memset needed
     bool zcRun = false;       // the run in flight reads back zero-copy
     int denseL = 0;   // 0: the model has no dense stage
@@ -204,6 +182,7 @@ struct fd_wvm {
     int64_t fstLaunched = 0;         // vectors the SVM launch of the run in flight covers
     int64_t fstPrevKeep = -1;        // survivors of the previous run (sizes the next SVM launch)
     int fstFrames = 0;
+    bool fstDirty = false;           // a cascade with the device tail was queued and k_fs_oe (which clears the tail's counters) not yet
     int fstLastState = -1;           // measurement / test hook: -1 no device tail in the last run, else the flags it ended with (0: its results were used)
     ~fd_wvm() { if (done) (void)hipEventDestroy(done); if (tailDone) (void)hipEventDestroy(tailDone); if (prep) (void)hipEventDestroy(prep); }
 };
@@ -236,8 +215,8 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
 }
 
 // number of windows a cascade kernel has to evaluate and the id of the i-th one (all windows, or the pre-filter's queue)
-__device__ __forceinline__ int64_t wt_total(const WinTable& wt) { return wt.widq ? (int64_t)*wt.widq_count : wt.total; }
-__device__ __forceinline__ int64_t wt_wid(const WinTable& wt, int64_t i) { return wt.widq ? wt.widq[i] : i; }
+__device__ __forceinline__ int64_t wt_total(const WinTable& wt) { return wt.total; }
+__device__ __forceinline__ int64_t wt_wid(const WinTable&, int64_t i) { return i; }
 
 // PW_/PH_ != 0: patch size known at compile time (the 20x20 detectors of the reference configs);
 // 0: sizes from the model, up to 32x32.
@@ -584,218 +563,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             if (lane == 0) o.deep_q[atomicAdd(o.deep_count, 1u)] = wid;
         } else {
             wvm_emit<PW_, PH_>(g, m, o, wid, lane, level, fout, thr, px);
-        }
-        wave_sync();
-    }
-}
-
-// ---- stage A, two windows per wavefront -------------------------------------------------------------
-// Lanes 0-31 hold the columns of window 2p, lanes 32-63 of window 2p+1 (adjacent in extraction order), one register
-// per patch row.  Per wave-instruction count is that of the one-window kernel, but it serves two windows wherever the
-// work was wave-uniform before: the level evaluation (rect lookups use 32 lanes per window, the scalar fp64 chain runs
-// once per half), the sum-of-squares chain, window decode and the model prefetch; the two fp32 cdf chains interleave.
-// The two windows run the cascade in lockstep (same level k); a half that has left simply idles.
-// Requires a compile-time patch size with PW <= 32 and numPer <= 32.
-template <int PW_, int PH_>
-struct __attribute__((aligned(16))) PairLds {
-    unsigned int hist[2][64];   // histograms, then the two LUTs
-    int sv[2][WVM_MAX_VALS];
-    float u[2][32];             // u_kernel_eval of each window
-    unsigned int ii[2][PW_ * PH_];
-};
-
-template <int PW_, int PH_, bool RAW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_wvm_cascade2(const uint8_t* __restrict__ arena, WinTable wt, WvmDev m,
-                                                                                                  CascadeOut o) {
-    static_assert(PW_ > 0 && PW_ <= 32, "two-window layout needs a compile-time width <= 32");
-    __shared__ PairLds<PW_, PH_> lds[4];
-    __shared__ int64_t sFirst[WVM_MAX_LAYERS];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    PairLds<PW_, PH_>& L = lds[wave];
-    const int half = lane >> 5, c = lane & 31;
-    const bool colok = c < PW_;
-    constexpr int d = PW_ * PH_;
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    const int F = m.numFilters;
-    const int nA = min(m.numUsed, WVM_LCAP);
-    const int halfBase = lane & 32;
-
-    if (!RAW) {
-        if (threadIdx.x < WVM_MAX_LAYERS) sFirst[threadIdx.x] = (int)threadIdx.x < wt.n ? wt.l[threadIdx.x].first : INT64_MAX;
-        __syncthreads();
-    }
-    if (c < WVM_MAX_VALS) L.sv[half][c] = 0;
-    wave_sync();
-
-    const int64_t totalA = wt_total(wt);
-    const int64_t npairs = (totalA + 1) >> 1;
-    for (int64_t pair = (int64_t)blockIdx.x * 4 + wave; pair < npairs; pair += nwaves) {
-        const bool has1 = 2 * pair + 1 < totalA;
-        const int64_t wid0 = wt_wid(wt, 2 * pair), wid1 = has1 ? wt_wid(wt, 2 * pair + 1) : wid0;
-        const int64_t myWid = half ? wid1 : wid0;
-        const bool valid = half ? has1 : true;
-        int stride0, stride1;
-        const uint8_t* src0 = wvm_locate<RAW>(arena, wt, sFirst, wid0, lane, PW_, d, stride0);
-        const uint8_t* src1 = src0;
-        stride1 = stride0;
-        if (has1) src1 = wvm_locate<RAW>(arena, wt, sFirst, wid1, lane, PW_, d, stride1);
-        const uint8_t* src = half ? src1 : src0;
-        const int stride = half ? stride1 : stride0;
-
-        // level-0 model data: requested now, consumed after the fixed part
-        uint4 lv = m.lvlRec[c];
-        WvmLevelHdr hd = m.lvlHdr[0];
-        float w = m.wT[c];
-
-        // ---- 1. load the two windows (columns beyond the patch read column 0 and are masked later)
-        unsigned int px[PH_];
-        {
-            const uint8_t* sp = src + (colok ? c : 0);
-#pragma unroll
-            for (int r = 0; r < PH_; ++r) px[r] = sp[(size_t)r * stride];
-        }
-        if (!RAW) {
-            // ---- 2. HistEq64 of both windows: histograms by LDS atomics, the two fp32 cdf chains interleaved
-            L.hist[0][lane] = 0;
-            L.hist[1][lane] = 0;
-            wave_sync();
-            if (colok) {
-#pragma unroll
-                for (int r = 0; r < PH_; ++r) atomicAdd(&L.hist[half][px[r] >> 2], 1u);
-            }
-            wave_sync();
-            const float pdfA = (float)L.hist[0][lane] * m.stretch, pdfB = (float)L.hist[1][lane] * m.stretch;
-            float xA = pdfA, xB = pdfB;
-#pragma unroll
-            for (int t = 1; t < 64; ++t) {
-                const float sa = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(xA), DPP_WAVE_SHR1, 0xf, 0xf, true));
-                const float sb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(xB), DPP_WAVE_SHR1, 0xf, 0xf, true));
-                xA = sa + pdfA;
-                xB = sb + pdfB;
-            }
-            wave_sync();
-            L.hist[0][lane] = (unsigned int)(unsigned char)floor((double)xA + 0.5);
-            L.hist[1][lane] = (unsigned int)(unsigned char)floor((double)xB + 0.5);
-            wave_sync();
-#pragma unroll
-            for (int r = 0; r < PH_; ++r) {
-                const unsigned int e = L.hist[half][px[r] >> 2];
-                px[r] = colok ? e : 0u;
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < PH_; ++r) px[r] = colok ? px[r] : 0u;
-        }
-        // ---- 3. integral images (row prefix by DPP inside each half, running column sum) and the sum of squares:
-        // lanes 31 / 63 see the row totals and run the fp32 chain of IImg.cpp:33-47 for their window
-        int colsum = 0;
-        float sxxc = 0.f;
-#pragma unroll
-        for (int r = 0; r < PH_; ++r) {
-            colsum += scan_half((int)px[r]);
-            if (colok) L.ii[half][r * PW_ + c] = (unsigned int)colsum;
-            const float qf = (float)scan_half((int)(px[r] * px[r]));
-            sxxc = r == 0 ? qf : sxxc + qf;
-        }
-        const float sxx = __int_as_float(__builtin_amdgcn_ds_bpermute((lane | 31) << 2, __float_as_int(sxxc)));
-        const int sx_total = __builtin_amdgcn_ds_bpermute((halfBase + PW_ - 1) << 2, colsum);
-        L.u[half][c] = 0.f;
-        wave_sync();
-
-        // ---- 4. first levels of the cascade, both windows in lockstep
-        const unsigned int* ii = L.ii[half];
-        int* sv = L.sv[half];
-        float Pb = m.negBias;   // lane c of each half: running sum of level c (c < 32)
-        bool alive = valid, deep = false;
-        int level = 0, n = 0;
-        float fout = 0.f, thr = 0.f;
-        for (int k = 0;; ++k) {
-            const int kn = min(k + 1, nA - 1);
-            const uint4 lvN = m.lvlRec[(size_t)kn * 64 + c];
-            const WvmLevelHdr hdN = m.lvlHdr[kn];
-            const float wN = m.wT[(size_t)kn * F + c];
-            // rect sums: 32 rects per pass and window
-            for (int rb = 0; rb < hd.nrects; rb += 32) {
-                unsigned int rc, vt;
-                if (rb == 0) { rc = lv.x; vt = lv.y; }
-                else if (rb < 64) { const uint4 t = m.lvlRec[(size_t)k * 64 + rb + c]; rc = t.x; vt = t.y; }
-                else { const int ri = m.rectBegin[k] + min(rb + c, hd.nrects - 1); rc = m.rects[ri]; vt = m.rectV[ri]; }
-                if (alive && rb + c < hd.nrects) {
-                    const int x1 = rc & 255, y1 = (rc >> 8) & 255, x2 = (rc >> 16) & 255, y2 = rc >> 24;
-                    int s = (int)ii[y2 * PW_ + x2];
-                    if (x1 > 0) s -= (int)ii[y2 * PW_ + x1 - 1];
-                    if (y1 > 0) s -= (int)ii[(y1 - 1) * PW_ + x2];
-                    if (x1 > 0 && y1 > 0) s += (int)ii[(y1 - 1) * PW_ + x1 - 1];
-                    atomicAdd(&sv[vt], s);
-                }
-            }
-            wave_sync();
-            // the reference's scalar chain (WvmClassifier.cpp:308-346), once per half
-            const double valL = __hiloint2double((int)lv.w, (int)lv.z);
-            double sum_xp = 0.0;
-            int sumv0 = sx_total;
-            for (int v = 1; v < hd.cntval; ++v) {
-                const int s = sv[v];
-                sumv0 -= s;
-                const double prod = (double)s * readlane_d(valL, v);
-                sum_xp = sum_xp + prod;
-            }
-            const double t0 = (double)sumv0 * readlane_d(valL, 0);
-            sum_xp = sum_xp + t0;
-            sum_xp = sum_xp + (double)L.u[half][n];
-            const float unew = (float)sum_xp;
-            wave_sync();
-            if (c < WVM_MAX_VALS) sv[c] = 0;
-            if (c == 0) L.u[half][n] = unew;
-            double norm = (double)sxx;
-            norm = norm - 2 * sum_xp;
-            norm = norm + hd.pp;
-            const float Kk = (float)exp((double)m.negBasis * norm);
-            {
-                const float t = w * Kk;   // weights above the diagonal are stored as 0
-                Pb = Pb + t;
-            }
-            const float fk = __int_as_float(__builtin_amdgcn_ds_bpermute((halfBase + k) << 2, __float_as_int(Pb)));
-            if (alive) {
-                if (!(fk >= hd.thr && k + 1 < m.numUsed)) {   // leaves the cascade here
-                    level = k; fout = fk; thr = hd.thr;
-                    alive = false;
-                } else if (k + 1 == nA) {                     // survives stage A: finished by k_wvm_deep
-                    deep = true;
-                    alive = false;
-                }
-            }
-            if (!__any(alive)) break;
-            lv = lvN;
-            hd = hdN;
-            w = wN;
-            if (++n == m.numPer) n = 0;
-        }
-        // ---- 5. results, per half
-        if (valid) {
-            if (deep) {
-                if (c == 0) o.deep_q[atomicAdd(o.deep_count, 1u)] = myWid;
-            } else {
-                const bool positive = (level + 1 == m.numFilters) && (fout >= thr);
-                if (c == 0) {
-                    if (o.all_level) o.all_level[myWid] = level;
-                    if (o.all_fout) o.all_fout[myWid] = fout;
-                }
-                if (positive) {
-                    unsigned int slot = 0;
-                    if (c == 0) slot = atomicAdd(o.pos_count, 1u);
-                    slot = (unsigned int)__builtin_amdgcn_ds_bpermute(halfBase << 2, (int)slot);
-                    if (slot < o.pos_cap) {
-                        if (c == 0) o.pos[slot] = PosRec{(uint32_t)myWid, (uint32_t)(myWid >> 32), level, fout};
-                        uint8_t* dst = o.pos_patches + (size_t)slot * d;
-                        if (colok) {
-#pragma unroll
-                            for (int r = 0; r < PH_; ++r) dst[r * PW_ + c] = (uint8_t)px[r];
-                        }
-                    }
-                }
-            }
         }
         wave_sync();
     }
@@ -1175,515 +942,6 @@ __global__ __launch_bounds__(64 * NW) void k_wvm_deep(const uint8_t* __restrict_
     wvm_finalize(o);
 }
 
-// ---- stage B, four filters per wavefront -----------------------------------------------------------
-// Same decomposition as k_wvm_deep (one workgroup per surviving window, waves on disjoint residue classes n = k % numPer,
-// block-owned hierarchical sums), but a wavefront evaluates four filters of the window at once in the quarter layout of
-// k_wvm_cascade4: lanes 16q..16q+15 work on the filter of class n = 4 * (wave + round * NW) + q -- lane == rect (16 per pass)
-// for the rect sums, then the wave-uniform part of the evaluation (fp64 grey-value chain, exp) once per instruction for
-// four filters; val[v] / the grey-value sums reach the lanes of their quarter by DPP row broadcasts.  With numPer <= 16 a
-// whole generation of filters is in flight at once in four waves, so the serial chain of a surviving window is one filter
-// evaluation per generation.
-#ifdef FD_DEEP4_PROF
-__device__ unsigned long long fd_deep4_prof[16];
-extern "C" void fd_debug_deep4_prof(unsigned long long* out, int reset) {
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(fd_deep4_prof), sizeof(fd_deep4_prof));
-    if (reset) { unsigned long long z[16] = {}; hipMemcpyToSymbol(HIP_SYMBOL(fd_deep4_prof), z, sizeof(z)); }
-}
-#define FD_PROF_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#define FD_PROF_DECL unsigned long long prof_acc[13] = {}
-#define FD_PROF_ADD(i, v) prof_acc[i] += (unsigned long long)(v)   /* registers; flushed once per batch */
-#define FD_PROF_FLUSH do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 13; ++i_) { atomicAdd(&fd_deep4_prof[i_], prof_acc[i_]); } } for (int i_ = 0; i_ < 13; ++i_) prof_acc[i_] = 0; } while (0)
-#else
-#define FD_PROF_T(var)
-#define FD_PROF_ADD(i, v)
-#define FD_PROF_DECL
-#define FD_PROF_FLUSH
-#endif
-template <int PW_, int PH_, bool RAW, int NW>
-__global__ __launch_bounds__(64 * NW) void k_wvm_deep4(const uint8_t* __restrict__ arena, WinTable wt, WvmDev m, CascadeOut o) {
-    constexpr int RHMAX = Geo<PW_, PH_>::RHMAX;
-    constexpr int MAXOWN = (WVM_PJ + NW - 1) / NW;   // 64-level blocks owned by one wave (block j belongs to wave j % NW)
-    constexpr int MAXR = (32 + 4 * NW - 1) / (4 * NW);   // rounds of 4 * NW classes (numPer <= 32)
-    __shared__ unsigned int ii[Geo<PW_, PH_>::IISZ];
-    __shared__ unsigned int hist[NW][64];
-    __shared__ int sv[NW][4][WVM_MAX_VALS];
-    __shared__ float kh[64 * WVM_PJ];
-    __shared__ int64_t sFirst[WVM_MAX_LAYERS];
-    __shared__ unsigned long long sExit;   // (first failed level << 32 | fp32 bits of its sum), minimum over the candidates
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int q = lane >> 4, r = lane & 15;
-    const Geo<PW_, PH_> g(m, lane);
-    const int F = m.numFilters, NU = m.numUsed, NP = m.numPer;
-    const int gensPerChunk = max(1, 64 / NP);
-    const int chunk = gensPerChunk * NP;
-    const int pw = g.pw;
-
-    if (!RAW && threadIdx.x < WVM_MAX_LAYERS) sFirst[threadIdx.x] = (int)threadIdx.x < wt.n ? wt.l[threadIdx.x].first : INT64_MAX;
-    sv[wave][q][r] = 0;
-    __syncthreads();
-    const unsigned int ndeep = *o.deep_count;
-
-    for (unsigned int qi = blockIdx.x; qi < ndeep; qi += gridDim.x) {
-        const int64_t wid = o.deep_q[qi];
-        int srcStride;
-        const uint8_t* src = wvm_locate<RAW>(arena, wt, sFirst, wid, lane, g.pw, g.d, srcStride);
-        unsigned int px[RHMAX];
-        float sxx;
-        int sx_total;
-        // every wave prepares the window (identical values; they all write the one integral image)
-        wvm_prepare<PW_, PH_, RAW>(g, src, srcStride, m.stretch, lane, hist[wave], ii, px, sxx, sx_total);
-        if (threadIdx.x == 0) sExit = ~0ull;
-        __syncthreads();
-
-        float u[MAXR];   // u_kernel_eval of this quarter's class in each round
-#pragma unroll
-        for (int rd = 0; rd < MAXR; ++rd) u[rd] = 0.f;
-        float Pacc[MAXOWN];
-#pragma unroll
-        for (int ow = 0; ow < MAXOWN; ++ow) Pacc[ow] = m.negBias;
-        int level = NU - 1;
-        float fout = 0.f;
-        int* svq = sv[wave][q];
-        for (int c0 = 0; c0 < NU; c0 += chunk) {
-            const int c1 = min(c0 + chunk, NU);
-            // ---- kernel values of this wave's filters in [c0, c1): generation by generation, four classes per round
-            for (int gbase = c0; gbase < c1; gbase += NP) {
-#pragma unroll
-                for (int rd = 0; rd < MAXR; ++rd) {
-                    const int nFirst = 4 * (wave + rd * NW);
-                    if (nFirst >= NP || gbase + nFirst >= c1) break;   // wave-uniform
-                    const int n = nFirst + q;
-                    const int k = gbase + n;
-                    const bool active = n < NP && k < c1;
-                    const int kc = active ? k : gbase + nFirst;   // in-range model record for idle quarters
-                    const uint4 lv = m.lvlRec[(size_t)kc * 64 + r];
-                    const WvmLevelHdr hd = m.lvlHdr[kc];
-                    const int nr = active ? hd.nrects : 0;
-                    // rect sums: lane == rect of this quarter's filter, 16 per pass
-                    for (int rb = 0; __any(rb < nr); rb += 16) {
-                        unsigned int rc, vt;
-                        if (rb == 0) { rc = lv.x; vt = lv.y; }
-                        else if (rb < 64) { const uint4 t = m.lvlRec[(size_t)kc * 64 + rb + r]; rc = t.x; vt = t.y; }
-                        else { const int ri = m.rectBegin[kc] + min(rb + r, max(nr, 1) - 1); rc = m.rects[ri]; vt = m.rectV[ri]; }
-                        if (rb + r < nr) {
-                            const int x1 = rc & 255, y1 = (rc >> 8) & 255, x2 = (rc >> 16) & 255, y2 = rc >> 24;
-                            int sm = (int)ii[y2 * pw + x2];
-                            if (x1 > 0) sm -= (int)ii[y2 * pw + x1 - 1];
-                            if (y1 > 0) sm -= (int)ii[(y1 - 1) * pw + x2];
-                            if (x1 > 0 && y1 > 0) sm += (int)ii[(y1 - 1) * pw + x1 - 1];
-                            atomicAdd(&svq[vt], sm);
-                        }
-                    }
-                    wave_sync();
-                    // lane v of the quarter takes the sum of grey value v (and clears it), its product with val[v]; the chain of
-                    // the reference (WvmClassifier.cpp:308-346) then runs in value order on row broadcasts
-                    const int svr = svq[r];
-                    svq[r] = 0;
-                    const double valL = __hiloint2double((int)lv.w, (int)lv.z);
-                    const double prod = (double)svr * valL;
-                    const int cntval = hd.cntval;
-                    const int maxCnt = __builtin_amdgcn_readfirstlane(max(max(__builtin_amdgcn_readlane(cntval, 0), __builtin_amdgcn_readlane(cntval, 16)),
-                                                                        max(__builtin_amdgcn_readlane(cntval, 32), __builtin_amdgcn_readlane(cntval, 48))));
-                    double sum_xp = 0.0;
-                    int sumv0 = sx_total;
-#define FD_CHAIN_STEP(V)                                                      \
-    if ((V) < maxCnt) {                                                       \
-        const int s_ = FD_ROW_BCAST_I(svr, V);                                \
-        const double p_ = row_bcast_d<V>(prod);                               \
-        if ((V) < cntval) { sumv0 -= s_; sum_xp = sum_xp + p_; }              \
-    }
-                    FD_CHAIN_STEP(1) FD_CHAIN_STEP(2) FD_CHAIN_STEP(3) FD_CHAIN_STEP(4) FD_CHAIN_STEP(5)
-                    FD_CHAIN_STEP(6) FD_CHAIN_STEP(7) FD_CHAIN_STEP(8) FD_CHAIN_STEP(9) FD_CHAIN_STEP(10)
-                    FD_CHAIN_STEP(11) FD_CHAIN_STEP(12) FD_CHAIN_STEP(13) FD_CHAIN_STEP(14) FD_CHAIN_STEP(15)
-#undef FD_CHAIN_STEP
-                    const double t0 = (double)sumv0 * row_bcast_d<0>(valL);
-                    sum_xp = sum_xp + t0;
-                    sum_xp = sum_xp + (double)u[rd];
-                    const float unew = (float)sum_xp;
-                    double norm = (double)sxx;
-                    norm = norm - 2 * sum_xp;
-                    norm = norm + hd.pp;
-                    const float Kk = (float)exp((double)m.negBasis * norm);
-                    if (active) {
-                        u[rd] = unew;
-                        if (r == 0) kh[k] = Kk;
-                    }
-                    wave_sync();
-                }
-            }
-            __syncthreads();
-            // ---- hierarchical sums: add the chunk's terms to every owned level >= c0; check the levels inside the chunk
-#pragma unroll
-            for (int ow = 0; ow < MAXOWN; ++ow) {
-                const int blk = wave + ow * NW;
-                if (blk * 64 >= NU || blk * 64 + 63 < c0) continue;   // nothing owned here / already decided
-                const int mm = blk * 64 + lane;
-                const float* wp = m.wT + mm;
-                float P = Pacc[ow];
-                const float* wq = wp + (size_t)c0 * F;
-#pragma unroll 8
-                for (int i = c0; i < c1; ++i, wq += F) {
-                    const float t = *wq * kh[i];
-                    P = P + t;
-                }
-                Pacc[ow] = P;
-                const bool mine = mm >= c0 && mm < c1;
-                const float thrm = mine ? m.thresholds[mm] : 0.f;
-                const bool fail = mine && !(P >= thrm && mm + 1 < NU);
-                const unsigned long long fm = __ballot(fail);
-                if (fm) {
-                    const int e = __builtin_ctzll(fm);
-                    if (lane == e) atomicMin(&sExit, ((unsigned long long)(unsigned int)mm << 32) | (unsigned int)__float_as_int(P));
-                }
-            }
-            __syncthreads();
-            const unsigned long long ex = sExit;
-            if (ex != ~0ull) {
-                level = (int)(ex >> 32);
-                fout = __int_as_float((int)(unsigned int)ex);
-                break;
-            }
-        }
-        if (wave == 0) wvm_emit<PW_, PH_>(g, m, o, wid, lane, level, fout, m.thresholds[level], px);
-        __syncthreads();
-    }
-    wvm_finalize(o);
-}
-
-// ---- stage B, four windows per workgroup ---------------------------------------------------------------
-// Every window that reaches stage B behind the dense pre-filter runs deep (measured: all of them to the last level with the
-// bench models), so the cost that matters is the full-length evaluation.  In-kernel timestamps of k_wvm_deep4 put 60-65 % of it
-// into the kernel values -- mostly the wave-uniform fp64 chain + exp, issued once per FOUR filters -- and 27 % into the
-// hierarchical sums, whose weight matrix (numFilters^2 / 2 floats) every window re-read from L2.  Here a workgroup takes four
-// windows in lockstep:
-//   * wave b owns window b: it prepares it (no redundant HistEq64 / integral image), and evaluates ALL filters of a generation for it
-//     -- rect sums with lane == rect over the generation's flattened rect list (records prefetched one pass ahead), then the
-//     fp64 chain + exp once per generation with lane == class (the reference's order per class: WvmClassifier.cpp:308-346);
-//     no cross-wave synchronisation inside a chunk;
-//   * the hierarchical sums keep the block ownership (wave w owns the 64-level blocks w, w + 4, lane == level) but add each weight
-//     to the sums of all four windows: one weight load and one 16-byte LDS broadcast of the four kernel values per term.
-// A window that leaves early idles its wave until the batch is done (the exit bookkeeping is per window).
-// MAXV: compile-time bound of the grey values per filter (8 or 16, chosen by the model): val[] of the class lives in registers.
-template <int PW_, int PH_, bool RAW, int MAXV>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW_ == 0 ? 2 : 4, 8))) void k_wvm_deepB(const uint8_t* __restrict__ arena, WinTable wt, WvmDev m, CascadeOut o) {
-    constexpr int RHMAX = Geo<PW_, PH_>::RHMAX;
-    constexpr int MAXOWN = (WVM_PJ + 3) / 4;
-    constexpr int IIP = PW_ ? (PW_ + 1) * (PH_ + 1) : (WVM_MAX_DIM + 1) * (WVM_MAX_DIM + 1);
-    __shared__ unsigned int ii[4][IIP];     // zero-padded integral images
-    constexpr int RECCAP = wvm_reccap_for(PW_, PH_);
-    __shared__ int genTab[2][66];           // genBegin / genMaxCnt of the chunk's generations
-    __shared__ uint2 recL[RECCAP];          // rect records of the chunk (the same for the four windows)
-    __shared__ unsigned int hist[4][64];
-    __shared__ int sv[4][32 * WVM_SVS];
-    __shared__ float4 kh4[64 * WVM_PJ];   // kernel values: component b = window b
-    __shared__ int64_t sFirst[WVM_MAX_LAYERS];
-    // per window: (first failed level << 32 | fp32 bits of its sum); two sets, alternating between batches: a wave may reset its entry
-    // for the next batch while the others still read the old one
-    __shared__ unsigned long long sExit2[2][4];
-    __shared__ double normL[4][64];         // exponents of the chunk's kernel values (exp runs once per chunk, lane == level)
-    __shared__ unsigned int patchL[4][(Geo<PW_, PH_>::IISZ + 3) / 4];   // equalised patch of a positive until its slot is known
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int cls = lane & 31;
-    const Geo<PW_, PH_> g(m, lane);
-    const int F = m.numFilters, NU = m.numUsed, NP = m.numPer;
-    int* svw = sv[wave];
-    float* khf = reinterpret_cast<float*>(kh4);
-    // 64-level block ownership of the hierarchical sums, rotated between the workgroups that share a CU: wave w of every workgroup
-    // sits on SIMD w, and the owner of blocks 0 and 4 has up to twice the terms of the others
-    const int wown = (wave + (int)(blockIdx.x >> 8)) & 3;
-    // deferred write-out of a positive: the slot comes from a device-wide atomic (thousands of cycles under contention) that is issued
-    // at the end of a batch and consumed after the next window's preparation
-    bool pend = false;
-    unsigned int pendSlot = 0;
-    int64_t pendWid = 0;
-    int pendLevel = 0;
-    float pendFout = 0.f;
-    auto flushPending = [&]() {
-        if (!pend) return;
-        pend = false;
-        const unsigned int slot = (unsigned int)__builtin_amdgcn_readfirstlane((int)pendSlot);
-        if (slot >= o.pos_cap) return;
-        if (lane == 0) o.pos[slot] = PosRec{(uint32_t)pendWid, (uint32_t)(pendWid >> 32), pendLevel, pendFout};
-        uint8_t* dst = o.pos_patches + (size_t)slot * g.d;
-        if ((g.d & 3) == 0) {
-            for (int i = lane; i < (g.d >> 2); i += 64) reinterpret_cast<unsigned int*>(dst)[i] = patchL[wave][i];
-        } else {
-            const uint8_t* pb = reinterpret_cast<const uint8_t*>(patchL[wave]);
-            for (int i = lane; i < g.d; i += 64) dst[i] = pb[i];
-        }
-    };
-
-    if (!RAW && threadIdx.x < WVM_MAX_LAYERS) sFirst[threadIdx.x] = (int)threadIdx.x < wt.n ? wt.l[threadIdx.x].first : INT64_MAX;
-    for (int i = lane; i < 32 * WVM_SVS; i += 64) svw[i] = 0;
-    if (lane <= g.pw) ii[wave][lane] = 0;                          // row 0 and column 0 of the padded integral image stay zero
-    if (lane < g.ph) ii[wave][(lane + 1) * (g.pw + 1)] = 0;
-    __syncthreads();
-    const unsigned int ndeep = *o.deep_count;
-    const unsigned int nbatch = (ndeep + 3) >> 2;
-    FD_PROF_DECL;
-
-    int parity = 0;
-    for (unsigned int batch = blockIdx.x; batch < nbatch; batch += gridDim.x, parity ^= 1) {
-        unsigned long long* sExit = sExit2[parity];
-        FD_PROF_T(tp0);
-        const unsigned int qi = batch * 4 + wave;
-        const bool valid = qi < ndeep;                       // wave-uniform
-        const int64_t wid = o.deep_q[valid ? qi : batch * 4];
-        int srcStride;
-        const uint8_t* src = wvm_locate<RAW>(arena, wt, sFirst, wid, lane, g.pw, g.d, srcStride);
-        unsigned int px[RHMAX];
-        float sxx;
-        int sx_total;
-        wvm_prepare<PW_, PH_, RAW, true>(g, src, srcStride, m.stretch, lane, hist[wave], ii[wave], px, sxx, sx_total);
-        flushPending();
-        {   // the equalised patch leaves the registers here (only a positive needs it again, at write-out)
-            uint8_t* pb = reinterpret_cast<uint8_t*>(patchL[wave]);
-            if (g.colok) {
-#pragma unroll
-                for (int j = 0; j < RHMAX; ++j)
-                    if (g.rowok(j)) pb[(g.r0 + j) * g.pw + g.col] = (uint8_t)px[j];
-            }
-        }
-        if (lane == 0) sExit[wave] = ~0ull;
-        const unsigned int* iiw = ii[wave];
-        FD_PROF_T(tp1);
-        FD_PROF_ADD(0, 1);
-        FD_PROF_ADD(1, tp1 - tp0);
-
-        float u = 0.f;   // lane n (< numPer): u_kernel_eval of class n
-        float P[MAXOWN][4];
-#pragma unroll
-        for (int ow = 0; ow < MAXOWN; ++ow)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) P[ow][b] = m.negBias;
-        bool alive = valid;
-        int level = NU - 1;
-        float fout = 0.f;
-        for (int c0 = 0, c1; c0 < NU; c0 = c1) {
-            // ---- chunk = as many generations (at most 64 levels) as have their rect records fit the LDS stage; the records are
-            // window-independent: one copy serves the four waves, and the passes below never wait for global memory
-            const int gi0 = c0 / NP;
-            const int4 plan = m.chunkPlan[gi0];
-            const int r0 = __builtin_amdgcn_readfirstlane(plan.y), rEnd = __builtin_amdgcn_readfirstlane(plan.z);
-            int gens = __builtin_amdgcn_readfirstlane(plan.x);
-            const bool fits = gens > 0;       // else: a single generation with more rects than the stage holds, staged piecewise
-            if (!fits) gens = 1;
-            c1 = min(c0 + gens * NP, NU);
-            FD_PROF_T(tc0);
-            // rect sums of the staged records [jb0, jb1) (recL[0] = record `base`): lane == rect, four unconditional corner reads
-            auto rectPasses = [&](int jb0, int jb1, int base) {
-                // two rects per lane and pass (eight independent corner reads in flight); the records of the next pass are requested
-                // before the corners of this one are read, so a pass costs one LDS round trip instead of two
-                uint2 ra = recL[min(jb0 + lane, jb1 - 1) - base], rb = recL[min(jb0 + 64 + lane, jb1 - 1) - base];
-                for (int jb = jb0; jb < jb1; jb += 128) {
-                    const int j0 = jb + lane, j1 = jb + 64 + lane;
-                    const uint2 na = recL[min(j0 + 128, jb1 - 1) - base], nb = recL[min(j1 + 128, jb1 - 1) - base];
-                    const unsigned int sa = iiw[ra.x & 0xfffu] - iiw[(ra.x >> 12) & 0xfffu] - iiw[ra.y & 0xfffu] + iiw[(ra.y >> 12) & 0xfffu];
-                    const unsigned int sb = iiw[rb.x & 0xfffu] - iiw[(rb.x >> 12) & 0xfffu] - iiw[rb.y & 0xfffu] + iiw[(rb.y >> 12) & 0xfffu];
-                    if (j0 < jb1) atomicAdd(&svw[(ra.x >> 24) | ((ra.y >> 24) << 8)], (int)sa);
-                    if (j1 < jb1) atomicAdd(&svw[(rb.x >> 24) | ((rb.y >> 24) << 8)], (int)sb);
-                    ra = na;
-                    rb = nb;
-                }
-            };
-            if ((int)threadIdx.x <= gens) genTab[0][threadIdx.x] = m.genBegin[gi0 + threadIdx.x];
-            if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + gens) genTab[1][threadIdx.x - 64] = m.genMaxCnt[gi0 + threadIdx.x - 64];
-            if (fits) {
-                for (int i = threadIdx.x; i < rEnd - r0; i += 256) recL[i] = m.genRec[r0 + i];
-                __syncthreads();
-            } else {
-                for (int sub = r0; sub < rEnd; sub += RECCAP) {
-                    const int subEnd = min(sub + RECCAP, rEnd);
-                    for (int i = threadIdx.x; i < subEnd - sub; i += 256) recL[i] = m.genRec[sub + i];
-                    __syncthreads();
-                    if (alive) rectPasses(sub, subEnd, sub);
-                    __syncthreads();
-                }
-            }
-            if (alive) {
-                int gi = gi0;
-                for (int gbase = c0; gbase < c1; gbase += NP, ++gi) {
-                    // ---- chain constants of the generation: requested now, consumed after the rect passes
-                    const int k = gbase + cls;
-                    const bool act = lane < NP && k < c1;
-                    const int maxCnt = __builtin_amdgcn_readfirstlane(genTab[1][gi - gi0]);
-                    const int cnt = act ? m.cntG[gi * 32 + cls] : 0;
-                    const double ppv = m.ppG[gi * 32 + cls];
-                    double valr[MAXV];
-#pragma unroll
-                    for (int v = 0; v < MAXV; ++v) valr[v] = v < maxCnt ? m.valG[((size_t)gi * 16 + v) * 32 + cls] : 0.0;
-                    FD_PROF_T(tr0);
-                    if (fits) rectPasses(__builtin_amdgcn_readfirstlane(genTab[0][gi - gi0]), __builtin_amdgcn_readfirstlane(genTab[0][gi - gi0 + 1]), r0);
-                    wave_sync();
-                    FD_PROF_T(tr1);
-                    // ---- the reference's scalar chain, lane == class (lanes 32-63 idle); the sums are cleared as they are read
-                    if (lane < 32) {
-                        int* svn = svw + cls * WVM_SVS;
-                        double sum_xp = 0.0;
-                        int sumv0 = sx_total;
-#ifndef FD_CHAIN_BATCHED
-#define FD_CHAIN_BATCHED 1
-#endif
-#if FD_CHAIN_BATCHED
-                        // all grey-value sums first (independent LDS reads, one wait), then their clearing, then the ordered arithmetic
-                        int sr[MAXV];
-#pragma unroll
-                        for (int v = 1; v < MAXV; ++v) sr[v] = v < maxCnt ? svn[v] : 0;
-#pragma unroll
-                        for (int v = 1; v < MAXV; ++v)
-                            if (v < maxCnt) svn[v] = 0;
-#pragma unroll
-                        for (int v = 1; v < MAXV; ++v) {
-                            if (v < cnt) {
-                                sumv0 -= sr[v];
-                                const double prod = (double)sr[v] * valr[v];
-                                sum_xp = sum_xp + prod;
-                            }
-                        }
-#else
-#pragma unroll
-                        for (int v = 1; v < MAXV; ++v) {
-                            if (v < maxCnt) {
-                                const int s_ = svn[v];
-                                svn[v] = 0;
-                                if (v < cnt) {
-                                    sumv0 -= s_;
-                                    const double prod = (double)s_ * valr[v];
-                                    sum_xp = sum_xp + prod;
-                                }
-                            }
-                        }
-#endif
-                        const double t0 = (double)sumv0 * valr[0];
-                        sum_xp = sum_xp + t0;
-                        sum_xp = sum_xp + (double)u;
-                        const float unew = (float)sum_xp;
-                        double norm = (double)sxx;
-                        norm = norm - 2 * sum_xp;
-                        norm = norm + ppv;
-                        if (act) {
-                            u = unew;
-                            normL[wave][k - c0] = norm;
-                        }
-                    }
-                    wave_sync();
-                    FD_PROF_T(tr2);
-                    FD_PROF_ADD(10, tr1 - tr0);
-                    FD_PROF_ADD(11, tr2 - tr1);
-                    FD_PROF_ADD(12, 1);
-                }
-                // ---- the chunk's kernel values: one exp per level, lane == level (off the u_kernel_eval dependency chain)
-                if (lane < c1 - c0) khf[(c0 + lane) * 4 + wave] = (float)exp((double)m.negBasis * normL[wave][lane]);
-            }
-            FD_PROF_T(tc1);
-            __syncthreads();
-            FD_PROF_T(tc2);
-            // ---- hierarchical sums of the four windows: add the chunk's terms to every owned level >= c0; check the levels inside
-#pragma unroll
-            for (int ow = 0; ow < MAXOWN; ++ow) {
-                const int blk = wown + ow * 4;
-                if (blk * 64 >= NU || blk * 64 + 63 < c0) continue;   // nothing owned here / already decided
-                const int mm = blk * 64 + lane;
-                // two windows per instruction: packed fp32 multiply / add (v_pk_mul_f32, v_pk_add_f32) round each component exactly
-                // like the scalar forms and halve the instruction count of this VALU-dense loop
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-                f32x2 P01 = {P[ow][0], P[ow][1]}, P23 = {P[ow][2], P[ow][3]};
-                const f32x2* kh2 = reinterpret_cast<const f32x2*>(kh4);
-#define FD_HIER_TERM(W_, I_)                                  \
-    {                                                         \
-        const f32x2 w2 = {(W_), (W_)};                        \
-        const f32x2 ka = kh2[2 * (I_)], kb = kh2[2 * (I_) + 1]; \
-        const f32x2 ta = w2 * ka, tb = w2 * kb;               \
-        P01 = P01 + ta;                                       \
-        P23 = P23 + tb;                                       \
-    }
-                // terms in the reference's order; the aligned middle of the chunk takes four weights per load (16 terms in flight
-                // per wave with the unroll below: the loop is bound by the latency of its L2 hits, not by their bandwidth)
-                int i = c0;
-                for (; i < c1 && (i & 3); ++i) FD_HIER_TERM(m.wT[(size_t)i * F + mm], i)
-                const float4* wp4 = m.wP + (size_t)(i >> 2) * m.Fp + mm;
-#ifndef FD_HIER_UNROLL
-#define FD_HIER_UNROLL 4
-#endif
-#pragma unroll FD_HIER_UNROLL
-                for (; i + 4 <= c1; i += 4, wp4 += m.Fp) {
-                    const float4 w4 = *wp4;
-                    FD_HIER_TERM(w4.x, i)
-                    FD_HIER_TERM(w4.y, i + 1)
-                    FD_HIER_TERM(w4.z, i + 2)
-                    FD_HIER_TERM(w4.w, i + 3)
-                }
-                for (; i < c1; ++i) FD_HIER_TERM(m.wT[(size_t)i * F + mm], i)
-#undef FD_HIER_TERM
-                const float P0 = P01.x, P1 = P01.y, P2 = P23.x, P3 = P23.y;
-                P[ow][0] = P0; P[ow][1] = P1; P[ow][2] = P2; P[ow][3] = P3;
-                const bool mine = mm >= c0 && mm < c1;
-                const float thrm = mine ? m.thresholds[mm] : 0.f;
-                const bool last = !(mm + 1 < NU);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const float Pb = P[ow][b];
-                    const bool fail = mine && (!(Pb >= thrm) || last);
-                    const unsigned long long fm = __ballot(fail);
-                    if (fm) {
-                        const int e = __builtin_ctzll(fm);
-                        if (lane == e) atomicMin(&sExit[b], ((unsigned long long)(unsigned int)mm << 32) | (unsigned int)__float_as_int(Pb));
-                    }
-                }
-            }
-            FD_PROF_T(tc3);
-            __syncthreads();
-            FD_PROF_T(tc4);
-            FD_PROF_ADD(2, 1);
-            FD_PROF_ADD(3, tc1 - tc0);
-            FD_PROF_ADD(4, tc2 - tc1);
-            FD_PROF_ADD(5, tc3 - tc2);
-            FD_PROF_ADD(6, tc4 - tc3);
-            const unsigned long long ex = sExit[wave];
-            if (alive && ex != ~0ull) {
-                level = (int)(ex >> 32);
-                fout = __int_as_float((int)(unsigned int)ex);
-                alive = false;
-            }
-            bool allDone = true;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) allDone = allDone && (batch * 4 + b >= ndeep || sExit[b] != ~0ull);
-            if (allDone) break;
-        }
-        FD_PROF_T(te0);
-        // no barrier here: the next batch touches only per-wave state and the other sExit set before its first barrier, and the
-        // positives' stores / the counter atomic complete under its window preparation
-        if (valid) {
-            const bool positive = (level + 1 == m.numFilters) && (fout >= m.thresholds[level]);
-            if (lane == 0) {
-                if (o.all_level) o.all_level[wid] = level;
-                if (o.all_fout) o.all_fout[wid] = fout;
-            }
-            if (positive) {
-                if (lane == 0) {
-                    // an address the compiler cannot prove uniform: its atomic optimiser would otherwise wrap the add in a wave scan
-                    // that waits for the result on the spot
-                    unsigned int zero = 0;
-                    asm volatile("" : "+v"(zero));
-                    pendSlot = atomicAdd(o.pos_count + zero, 1u);
-                }
-                pend = true;
-                pendWid = wid; pendLevel = level; pendFout = fout;
-            }
-        }
-        FD_PROF_T(te1);
-        FD_PROF_ADD(7, te1 - te0);
-        FD_PROF_ADD(8, te1 - tp0);
-        FD_PROF_ADD(9, level + 1);
-        FD_PROF_FLUSH;
-    }
-    flushPending();
-    wvm_finalize(o);
-}
-
 // HistEq64 only (fd_histeq64_batch): same steps 1-3 on contiguous patches
 __global__ __launch_bounds__(256) void k_histeq64(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int64_t n, int pw,
                                                   int ph, float stretch) {
@@ -1720,95 +978,39 @@ template <int PW_, int PH_, bool RAW>
 void launch_sized(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* mh, const uint8_t* arena, const WinTable& wt,
                   const CascadeOut& o, bool skipA = false) {
     const WvmDev& dev = mh->dev;
-    // both stages are persistent grids: exactly as many workgroups as fit on the device at once (a partial second
-    // round of workgroups would run at a fraction of the occupancy)
-    static int perCuA = 0;
-    if (perCuA == 0) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuA, k_wvm_cascade<PW_, PH_, RAW>, 256, 0) != hipSuccess || perCuA < 1) perCuA = 4;
-        if (const char* e = getenv("FD_WVM_GRID_PER_CU")) if (atoi(e) > 0) perCuA = atoi(e);
-    }
-    static const bool single = getenv("FD_WVM_SINGLE") != nullptr;
-    bool launched = skipA;   // skipA: the dense pre-filter has filled the stage-B queue itself
-    if constexpr (PW_ > 0 && PW_ <= 32) {
-        static const bool pairOnly = getenv("FD_WVM_PAIR") != nullptr;
-        // four windows per wavefront where four integral images leave enough LDS for the occupancy of the fixed part (measured per
-        // kernel, pair -> quad: 20x20 -12 %, 16x24 -12 %, 24x24 -3 %, 32x16 0 %, 32x24 +19 %)
-        constexpr bool quadFits = PW_ * PH_ <= 576 && PW_ <= 24;
-        bool quadLaunched = false;
-        if constexpr (quadFits) {
-          if (dev.numPer <= 32 && !single && !pairOnly && dev.numUsed > WVM_LCAP && !skipA) {
+    // Exact stage A (every window, when per-window outputs are requested or the model has no dense pre-filter): persistent grids,
+    // exactly as many workgroups as fit on the device at once.  skipA: the dense pre-filter has filled the stage-B queue itself.
+    bool launched = skipA;
+    if constexpr (PW_ > 0 && PW_ <= 24 && PW_ * PH_ <= 576) {
+        // four windows per wavefront where four integral images leave enough LDS for the occupancy of the fixed part; only for
+        // cascades that continue in stage B (no window turns positive in the first WVM_LCAP filters)
+        if (!launched && dev.numPer <= 32 && dev.numUsed > WVM_LCAP) {
             static int perCu4q = 0;
-            if (perCu4q == 0) {
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu4q, k_wvm_cascade4<PW_, PH_, RAW>, 64 * WVM_QUAD_WAVES, 0) != hipSuccess || perCu4q < 1)
-                    perCu4q = 4;
-            }
-            // rounds of resident workgroups: 2 = (almost) persistent; more rounds retire workgroups more often, which lets the
-            // high-priority follow-up kernels of other detectors / frames in between (FD_WVM_ROUNDS)
-            static const int rounds = [] { const char* e = getenv("FD_WVM_ROUNDS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
-            const int grid4 = (int)std::min<int64_t>((total + 4 * WVM_QUAD_WAVES - 1) / (4 * WVM_QUAD_WAVES), (int64_t)ctx->num_cus * perCu4q * rounds);
+            if (perCu4q == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu4q, k_wvm_cascade4<PW_, PH_, RAW>, 64 * WVM_QUAD_WAVES, 0) != hipSuccess || perCu4q < 1))
+                perCu4q = 4;
+            const int grid4 = (int)std::min<int64_t>((total + 4 * WVM_QUAD_WAVES - 1) / (4 * WVM_QUAD_WAVES), (int64_t)ctx->num_cus * perCu4q * 2);
             hipLaunchKernelGGL((k_wvm_cascade4<PW_, PH_, RAW>), dim3(grid4), dim3(64 * WVM_QUAD_WAVES), 0, st, arena, wt, dev, o);
-            launched = quadLaunched = true;
-          }
-        }
-        if (!quadLaunched && dev.numPer <= 32 && !single && !skipA) {   // two windows per wavefront
-            static int perCu2 = 0;
-            if (perCu2 == 0) {
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu2, k_wvm_cascade2<PW_, PH_, RAW>, 256, 0) != hipSuccess || perCu2 < 1) perCu2 = 4;
-            }
-            static const int rounds2 = [] { const char* e = getenv("FD_WVM_ROUNDS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
-            const int grid2 = (int)std::min<int64_t>((total + 7) / 8, (int64_t)ctx->num_cus * perCu2 * rounds2);
-            hipLaunchKernelGGL((k_wvm_cascade2<PW_, PH_, RAW>), dim3(grid2), dim3(256), 0, st, arena, wt, dev, o);
             launched = true;
         }
     }
-    const int gridA = (int)std::min<int64_t>((total + 3) / 4, (int64_t)ctx->num_cus * perCuA * 2);   // two full rounds
-    if (!launched) hipLaunchKernelGGL((k_wvm_cascade<PW_, PH_, RAW>), dim3(gridA), dim3(256), 0, st, arena, wt, dev, o);
-    if (dev.numUsed <= WVM_LCAP) return;
-    // 8 waves per survivor: half the latency of 4 on small frames (45 vs 72 us at 640x480) and no worse in the
-    // throughput-bound cases (config 3: 48 vs 63 ms per frame); FD_WVM_DEEP_WAVES=4 selects the narrow variant
-    static int perCu4 = 0, perCu8 = 0;
-    if (perCu4 == 0) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu4, k_wvm_deep<PW_, PH_, RAW, 4>, 256, 0) != hipSuccess || perCu4 < 1) perCu4 = 2;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu8, k_wvm_deep<PW_, PH_, RAW, 8>, 512, 0) != hipSuccess || perCu8 < 1) perCu8 = 1;
+    if (!launched) {   // one window per wavefront: any patch size, any filters per level
+        static int perCuA = 0;
+        if (perCuA == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuA, k_wvm_cascade<PW_, PH_, RAW>, 256, 0) != hipSuccess || perCuA < 1)) perCuA = 4;
+        const int gridA = (int)std::min<int64_t>((total + 3) / 4, (int64_t)ctx->num_cus * perCuA * 2);   // two full rounds
+        hipLaunchKernelGGL((k_wvm_cascade<PW_, PH_, RAW>), dim3(gridA), dim3(256), 0, st, arena, wt, dev, o);
     }
-    static const char* nwEnv = getenv("FD_WVM_DEEP_WAVES");
-    static const bool deepOld = getenv("FD_WVM_DEEP_OLD") != nullptr;
-    static const bool deep4Env = getenv("FD_WVM_DEEP4") != nullptr;
-    // default: stage B as dense contractions (wvm_stageb.hpp); FD_WVM_STAGEB=old keeps the rect-lookup kernels below
+    if (dev.numUsed <= WVM_LCAP) return;
+    // stage B as dense contractions (wvm_stageb.hpp) -- every model whose rect counts fit the int8 operand
     if (mh->sbRun) {
         launch_stageb<PW_, PH_, RAW>(ctx, st, total, mh, arena, wt, o);
         return;
     }
-    if (dev.numPer <= 32 && !deepOld && !deep4Env && dev.genRec) {   // four windows per workgroup, one wave per window
-        if (dev.maxCnt <= 8) {
-            static int perCuB = 0;
-            if (perCuB == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuB, k_wvm_deepB<PW_, PH_, RAW, 8>, 256, 0) != hipSuccess || perCuB < 1)) perCuB = 2;
-            if (const char* e = getenv("FD_WVM_DEEPB_PER_CU")) if (atoi(e) > 0) perCuB = std::min(perCuB, atoi(e));
-            const int gridB = (int)std::min<int64_t>((total + 3) / 4, (int64_t)ctx->num_cus * perCuB);
-            hipLaunchKernelGGL((k_wvm_deepB<PW_, PH_, RAW, 8>), dim3(gridB), dim3(256), 0, st, arena, wt, dev, o);
-        } else {
-            static int perCuB = 0;
-            if (perCuB == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuB, k_wvm_deepB<PW_, PH_, RAW, WVM_MAX_VALS>, 256, 0) != hipSuccess || perCuB < 1)) perCuB = 2;
-            const int gridB = (int)std::min<int64_t>((total + 3) / 4, (int64_t)ctx->num_cus * perCuB);
-            hipLaunchKernelGGL((k_wvm_deepB<PW_, PH_, RAW, WVM_MAX_VALS>), dim3(gridB), dim3(256), 0, st, arena, wt, dev, o);
-        }
-        return;
-    }
-    if (dev.numPer <= 32 && !deepOld) {   // four filters per wavefront, four waves per surviving window
-        static int perCuQ = 0;
-        if (perCuQ == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuQ, k_wvm_deep4<PW_, PH_, RAW, 4>, 256, 0) != hipSuccess || perCuQ < 1)) perCuQ = 2;
-        const int gridB = (int)std::min<int64_t>(total, (int64_t)ctx->num_cus * perCuQ);
-        hipLaunchKernelGGL((k_wvm_deep4<PW_, PH_, RAW, 4>), dim3(gridB), dim3(256), 0, st, arena, wt, dev, o);
-        return;
-    }
-    const bool wide = nwEnv ? atoi(nwEnv) != 4 : true;
-    if (wide) {
-        const int gridB = (int)std::min<int64_t>(total, (int64_t)ctx->num_cus * perCu8);
-        hipLaunchKernelGGL((k_wvm_deep<PW_, PH_, RAW, 8>), dim3(gridB), dim3(512), 0, st, arena, wt, dev, o);
-    } else {
-        const int gridB = (int)std::min<int64_t>(total, (int64_t)ctx->num_cus * perCu4);
-        hipLaunchKernelGGL((k_wvm_deep<PW_, PH_, RAW, 4>), dim3(gridB), dim3(256), 0, st, arena, wt, dev, o);
-    }
+    // the rect-lookup stage B (k_wvm_deep: one workgroup of eight wavefronts per queued window): models the int8 operand cannot
+    // express (more than 127 rects of one grey value on a pixel), FD_WVM_STAGEB=old (the cross-check of the tests)
+    static int perCu8 = 0;
+    if (perCu8 == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu8, k_wvm_deep<PW_, PH_, RAW, 8>, 512, 0) != hipSuccess || perCu8 < 1)) perCu8 = 1;
+    const int gridB = (int)std::min<int64_t>(total, (int64_t)ctx->num_cus * perCu8);
+    hipLaunchKernelGGL((k_wvm_deep<PW_, PH_, RAW, 8>), dim3(gridB), dim3(512), 0, st, arena, wt, dev, o);
 }
 
 // patch sizes with compile-time geometry: the detectors of ffpDetectApp/*.cfg (20x20 faces, 24x24 lip / nose / eye
@@ -2325,16 +1527,19 @@ static bool wvm_launch_head(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const WinTab
     o.all_fout = want_all ? m->all_fout.as<float>() : nullptr;
     o.pos = ((zc && !m->tailRun) ? m->h_pos.as<PosRec>() : m->pos.as<PosRec>()) + 1;   // pinned host memory is device-accessible under the same address
     if (m->tailRun) {
-        if (!m->fstHdr.p) {
-            m->fstHdr.reserve(64);
+        // The tail's counters (FstHdr words, positives per frame) are cleared by k_fs_oe itself, so a run normally finds them zero.  A
+        // run whose cascade was queued but whose k_fs_oe never was (an error between the two) leaves k_wvb_exit's counts
+        // behind: fstDirty stays set from here until fst_launch has queued k_fs_oe, and a run that finds it set clears them first.
+        const bool fresh = !m->fstHdr.p || !m->fstFrameCount.p;
+        m->fstHdr.reserve(64);
+        m->fstFrameCount.reserve(sizeof(unsigned int) * FD_MAX_FRAMES);
+        if (fresh || m->fstDirty) {
             HIP_CHECK(hipMemsetAsync(m->fstHdr.p, 0, 64, st));
-        }
-        o.tail_count = m->fstHdr.as<unsigned int>() + 8;   // behind the FstHdr words
-        const int nimg = wt.nimg > 1 ? wt.nimg : 1;
-        if (!m->fstFrameCount.p) {
-            m->fstFrameCount.reserve(sizeof(unsigned int) * FD_MAX_FRAMES);
             HIP_CHECK(hipMemsetAsync(m->fstFrameCount.p, 0, sizeof(unsigned int) * FD_MAX_FRAMES, st));
         }
+        m->fstDirty = true;
+        o.tail_count = m->fstHdr.as<unsigned int>() + 8;   // behind the FstHdr words
+        const int nimg = wt.nimg > 1 ? wt.nimg : 1;
         m->fstFrameList.reserve(sizeof(uint32_t) * (size_t)FST_NMAX * nimg);
         o.frame_count = m->fstFrameCount.as<unsigned int>();
         o.frame_list = m->fstFrameList.as<uint32_t>();
@@ -2380,23 +1585,12 @@ static void wvm_launch_table(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm*
     bool skipA = false;
     // production path: the dense pre-filter drops every window the first cascade levels reject with a margin; the exact
     // cascade then only sees the queue (header word 2 = its length).  Per-window outputs need the exact path for all.
-    // Default: the pre-filter feeds stage B's queue directly (stage B evaluates a window from level 0 anyway; measured
-    // 1157 -> 1445 Mpatches/s on config 3 against running the stage-A kernel on the queue first); FD_WVM_DENSE_DIRECT=0
-    // inserts stage A between them.
-    static const bool direct = [] { const char* e = getenv("FD_WVM_DENSE_DIRECT"); return !(e && atoi(e) == 0); }();
+    // The pre-filter feeds stage B's queue directly (stage B evaluates a window from level 0 anyway).
     if (!want_all && m->denseL) {
-        if (direct) {
-            skipA = launch_prefilter(ctx, st, m, p->arena.as<uint8_t>(), wt, o.deep_q, o.deep_count);
-            if (skipA && time_kernel && ctx->kernel_timing_mode == 2) {   // bench hook: the pre-filter alone
-                HIP_CHECK(hipEventRecord(ctx->ev1, st));
-                time_kernel = false;
-            }
-        } else {
-            m->pre_q.reserve(sizeof(int64_t) * (size_t)wt.total);
-            if (launch_prefilter(ctx, st, m, p->arena.as<uint8_t>(), wt, m->pre_q.as<int64_t>(), m->pos.as<unsigned int>() + 2)) {
-                wtq.widq = m->pre_q.as<int64_t>();
-                wtq.widq_count = m->pos.as<unsigned int>() + 2;
-            }
+        skipA = launch_prefilter(ctx, st, m, p->arena.as<uint8_t>(), wt, o.deep_q, o.deep_count);
+        if (skipA && time_kernel && ctx->kernel_timing_mode == 2) {   // bench hook: the pre-filter alone
+            HIP_CHECK(hipEventRecord(ctx->ev1, st));
+            time_kernel = false;
         }
     }
     wvm_launch_tail(ctx, st, p, m, wt, wtq, L, skipA, time_kernel);
@@ -2603,64 +1797,6 @@ int fd_wvm_create(fd_ctx* ctx, const fd_wvm_model* md, fd_wvm** out) {
             up(m->lvlHdr, hdr.data(), sizeof(WvmLevelHdr) * hdr.size());
         }
         WvmDev& d = m->dev;
-        if (md->num_per_level >= 1 && md->num_per_level <= 32) {   // generation-major tables (k_wvm_deepB)
-            const int NP = md->num_per_level, G = (F + NP - 1) / NP;
-            std::vector<uint32_t> grec;
-            std::vector<int32_t> gbeg(G + 1), gmax(G, 1), cntg((size_t)G * 32, 0);
-            std::vector<double> ppg((size_t)G * 32, 0.0), valg((size_t)G * 16 * 32, 0.0);
-            for (int g = 0; g < G; ++g) {
-                gbeg[g] = (int32_t)(grec.size() / 2);
-                for (int n = 0; n < NP && g * NP + n < F; ++n) {
-                    const int k = g * NP + n;
-                    const int v0 = md->val_off[k], cntval = md->val_off[k + 1] - v0;
-                    gmax[g] = std::max(gmax[g], cntval);
-                    cntg[(size_t)g * 32 + n] = cntval;
-                    ppg[(size_t)g * 32 + n] = md->pp[k];
-                    for (int v = 0; v < cntval; ++v) valg[((size_t)g * 16 + v) * 32 + n] = md->val[v0 + v];
-                    for (int r = rectBegin[k]; r < rectBegin[k + 1]; ++r) {
-                        // the four corners of the rect in the zero-padded integral image (k_wvm_deepB), 12 bits each, + the tag
-                        const uint32_t rc = rects[r], W1 = (uint32_t)md->filter_w + 1;
-                        const uint32_t x1 = rc & 255, y1 = (rc >> 8) & 255, x2 = (rc >> 16) & 255, y2 = rc >> 24;
-                        const uint32_t A = (y2 + 1) * W1 + x2 + 1, B = (y2 + 1) * W1 + x1, C = y1 * W1 + x2 + 1, D = y1 * W1 + x1;
-                        const uint32_t tag = (uint32_t)(n * WVM_SVS + rectV[r]);
-                        grec.push_back(A | (B << 12) | ((tag & 255u) << 24));
-                        grec.push_back(C | (D << 12) | ((tag >> 8) << 24));
-                    }
-                }
-            }
-            gbeg[G] = (int32_t)(grec.size() / 2);
-            grec.resize(grec.size() + 2 * 64, 0u);   // the record prefetch runs one pass ahead
-            up(m->genRec, grec.data(), sizeof(uint32_t) * grec.size());
-            up(m->genBegin, gbeg.data(), sizeof(int32_t) * gbeg.size());
-            up(m->genMaxCnt, gmax.data(), sizeof(int32_t) * gmax.size());
-            up(m->cntG, cntg.data(), sizeof(int32_t) * cntg.size());
-            up(m->ppG, ppg.data(), sizeof(double) * ppg.size());
-            up(m->valG, valg.data(), sizeof(double) * valg.size());
-            d.genRec = m->genRec.as<uint2>(); d.genBegin = m->genBegin.as<int32_t>(); d.genMaxCnt = m->genMaxCnt.as<int32_t>();
-            d.cntG = m->cntG.as<int32_t>(); d.ppG = m->ppG.as<double>(); d.valG = m->valG.as<double>();
-            d.maxCnt = *std::max_element(gmax.begin(), gmax.end());
-            const int Fp = (F + 63) / 64 * 64 + 64;
-            std::vector<float> wp((size_t)((F + 3) / 4) * Fp * 4, 0.f);
-            for (int k = 0; k < F; ++k)
-                for (int pidx = 0; pidx <= k; ++pidx) wp[((size_t)(pidx >> 2) * Fp + k) * 4 + (pidx & 3)] = md->hk_weights[(size_t)k * F + pidx];
-            up(m->wP, wp.data(), sizeof(float) * wp.size());
-            d.wP = m->wP.as<float4>(); d.Fp = Fp;
-            {
-                bool sized = false;   // does this patch size have a compile-time kernel instance (FD_WVM_SIZES)?
-                const int fixed[][2] = {{20, 20}, {24, 24}, {16, 24}, {32, 16}, {32, 24}};
-                for (auto& f : fixed) sized = sized || (md->filter_w == f[0] && md->filter_h == f[1]);
-                const int cap = sized ? wvm_reccap_for(md->filter_w, md->filter_h) : wvm_reccap_for(0, 0);
-                const int gpc = std::max(1, 64 / NP);
-                std::vector<int32_t> plan((size_t)G * 4, 0);
-                for (int g = 0; g < G; ++g) {
-                    int gens = 0;
-                    while (gens < gpc && g + gens < G && gbeg[g + gens + 1] - gbeg[g] <= cap) ++gens;
-                    plan[4 * (size_t)g] = gens; plan[4 * (size_t)g + 1] = gbeg[g]; plan[4 * (size_t)g + 2] = gbeg[g + std::max(gens, 1)];
-                }
-                up(m->chunkPlan, plan.data(), sizeof(int32_t) * plan.size());
-                d.chunkPlan = m->chunkPlan.as<int4>();
-            }
-        }
         d.fw = md->filter_w; d.fh = md->filter_h; d.d = md->filter_w * md->filter_h;
         d.numFilters = F;
         d.numUsed = (md->num_used > F || md->num_used <= 0) ? F : md->num_used;  // WvmClassifier.cpp:151-158
@@ -2946,6 +2082,7 @@ static void fst_launch(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm* m, co
     io.hostHdr[0] = 0xffffffffu;
     hipLaunchKernelGGL(k_fs_oe, dim3((unsigned)nimg), dim3(256), 0, st, T, io);
     HIP_CHECK(hipGetLastError());
+    m->fstDirty = false;   // k_fs_oe is queued: it leaves the tail's counters clean for the next run
     // the SVM launch covers what the previous run kept, with a margin; a run that keeps more gets a second launch for the rest
     int64_t nmax = m->fstPrevKeep >= 0 ? m->fstPrevKeep * 2 + 256 : std::max<int64_t>(1024, run.total / 256);
     nmax = std::min<int64_t>(std::max<int64_t>(nmax, 256), m->pos_cap);
@@ -3395,8 +2532,6 @@ static void five_stage_batch_end(fd_ctx* ctx, fd_five_stage_batch& b) {
             jobs[i].count = counts[i];
         } catch (const FdError& e) { fail(i, e); }
     };
-    static const bool tailOnPool = getenv("FD_TAIL_ON_POOL") != nullptr;
-    static const bool inOrder = getenv("FD_BATCH_IN_ORDER") != nullptr;
     // Large batches (config 3: 15 detectors, thousands of WVM positives each) take ~1 ms of host work per detector -- more than
     // the GPU needs for its cascade since the dense pre-filter -- so the detectors are handed to a few host threads: each worker
     // claims a detector whose cascade has finished, reads its positives back, runs the overlap elimination, queues the SVM stage
@@ -3405,11 +2540,10 @@ static void five_stage_batch_end(fd_ctx* ctx, fd_five_stage_batch& b) {
     static const int nthreads = [] { const char* e = getenv("FD_BATCH_THREADS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
     int64_t totalWindows = 0;
     for (int i = 0; i < n; ++i) totalWindows += b.runs[i].total;
-    if (nthreads > 1 && !inOrder && (n >= 6 || totalWindows >= (int64_t)4 << 20) && n >= 2) {
+    if (nthreads > 1 && (n >= 6 || totalWindows >= (int64_t)4 << 20) && n >= 2) {
         if (!ctx->workers) ctx->workers.reset(new FdWorkerPool(nthreads - 1));
-        hipStream_t tailStream = tailOnPool ? nullptr : fd_tail_stream(ctx);
+        hipStream_t tailStream = fd_tail_stream(ctx);
         (void)fd_aux_stream(ctx);
-        for (int i = 0; tailOnPool && i < n; ++i) (void)fd_pool_stream(ctx, i);
         std::vector<std::atomic<char>> claimed((size_t)n);
         for (auto& c : claimed) c.store(0);
         std::mutex errMu;
@@ -3436,7 +2570,7 @@ static void five_stage_batch_end(fd_ctx* ctx, fd_five_stage_batch& b) {
                 try {
                     fd_wvm_finish(ctx, m, b.runs[pick]);
                     tails[pick].begin(ctx, j.pyramid, m, j.svm, b.runs[pick], j.oe_dist, j.oe_ratio, j.step_x, j.step_y, j.roi,
-                                      tailOnPool ? fd_pool_stream(ctx, pick) : tailStream, j.out, j.cap, &counts[pick], j.stage_counts);
+                                      tailStream, j.out, j.cap, &counts[pick], j.stage_counts);
                     tails[pick].end();
                     j.count = counts[pick];
                 } catch (const FdError& e) {
@@ -3472,13 +2606,8 @@ static void five_stage_batch_end(fd_ctx* ctx, fd_five_stage_batch& b) {
     };
     for (int nbegun = 0; nbegun < n;) {
         int pick = -1;
-        if (inOrder) {
-            for (int i = 0; i < n && pick < 0; ++i)
-                if (!begun[i]) pick = i;
-        } else {
-            for (int i = 0; i < n && pick < 0; ++i)
-                if (!begun[i] && cascadeReady(i)) pick = i;
-        }
+        for (int i = 0; i < n && pick < 0; ++i)
+            if (!begun[i] && cascadeReady(i)) pick = i;
         if (pick < 0) {   // nothing to start: use the time for the NMS of a detector whose SVM stage has arrived, else yield
             bool did = false;
             for (int k = 0; k < n && !did; ++k)
@@ -3500,7 +2629,7 @@ static void five_stage_batch_end(fd_ctx* ctx, fd_five_stage_batch& b) {
                 fprintf(stderr, "[fd batch] job %2d cascade wait + read-back %8.1f us (%zu positives)\n", i, us, b.runs[i].pos.size());
             }
             tails[i].begin(ctx, j.pyramid, m, j.svm, b.runs[i], j.oe_dist, j.oe_ratio, j.step_x, j.step_y, j.roi,
-                           tailOnPool ? fd_pool_stream(ctx, i) : fd_tail_stream(ctx), j.out, j.cap, &counts[i], j.stage_counts);
+                           fd_tail_stream(ctx), j.out, j.cap, &counts[i], j.stage_counts);
         } catch (const FdError& e) {
             tails[i].finished = true;
             fail(i, e);

@@ -115,181 +115,6 @@ __global__ __launch_bounds__(256) void k_wvb_prepare(const uint8_t* __restrict__
 // Per-level record of the chain (host-packed, 256 bytes = one dword per lane): [0] tile, [1] first row inside the tile, [2] grey-value
 // count, [4..5] pp, [8 + 2v..] val[v] (16 doubles), [40 + v] 128 * sum of row (row0 + v - 1) (v >= 1)
 constexpr int WVB_REC_DW = 64;
-constexpr int WVB_RECS = 16;   // level records a wavefront keeps in LDS at a time
-
-// LDS: [64 windows][dstride] equalised pixels of the tile; per wavefront [32 rows][64 windows] rect sums of the current tile; per
-// wavefront WVB_RECS level records.  Memory latency (~0.5-0.8 us per dependent round trip on this part) is what bounds a unit, so
-// every stage issues all its loads before it consumes the first: the tile, the records, the operand fragments of a rect-sum tile.
-// MAXV: compile-time bound of the grey values per filter (8 or 16, chosen by the model).
-template <int MAXV>
-__global__ __launch_bounds__(256, 2) void k_wvb_chain(WvbDev mv, WvbState s, int phase, const unsigned int* countPtr) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char wvb_lds[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned int n = wvb_count(countPtr, s);
-    const int ntiles = (int)((n + 63u) >> 6);
-    const int NP = mv.numPer, NU = mv.numUsed, KS = mv.KS, KSP = mv.KSP, DS = mv.dstride;
-    const int NQ = (NP + 3) >> 2;
-    const int set = phase & 1;
-    const int g0 = mv.phaseGen[phase], g1 = mv.phaseGen[phase + 1];
-    int* Sw = reinterpret_cast<int*>(wvb_lds + 64 * DS) + wave * (32 * 64);
-    int* Rw = reinterpret_cast<int*>(wvb_lds + 64 * DS) + 4 * (32 * 64) + wave * (WVB_RECS * WVB_REC_DW);
-    const int cpr = DS >> 4;   // 16-byte slots per row
-    WVB_DECL(8 * phase);
-    const WvbXcd X(ntiles);
-    for (int unit = X.wg; unit < X.ntl * NQ; unit += X.nwg) {
-        const int tl = unit / NQ, cq = unit - tl * NQ;   // neighbouring workgroups share the window tile (L2)
-        const int t = X.tile(tl);
-        WVB_T(tq0);
-        __syncthreads();   // the previous unit's MFMA operand reads are done
-        {
-            const uint4* xg = reinterpret_cast<const uint4*>(s.X[set] + (size_t)t * 64 * DS);
-            const int live = (int)min(64u, n - (unsigned int)t * 64u) * cpr;   // slots of the tile's real windows (rows are contiguous)
-            for (int c0 = threadIdx.x; c0 < 64 * cpr; c0 += 8 * 256) {
-                uint4 v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int c = c0 + i * 256;
-                    v[i] = make_uint4(0, 0, 0, 0);
-                    if (c < live) v[i] = xg[c];
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int c = c0 + i * 256;
-                    if (c < 64 * cpr) reinterpret_cast<uint4*>(wvb_lds)[c] = v[i];
-                }
-            }
-        }
-        const int cls = cq * 4 + wave;
-        const unsigned int pos = (unsigned int)t * 64u + (unsigned int)lane;
-        const bool valid = pos < n;
-        float u = 0.f;
-        int sx_total = 0;
-        float sxx = 0.f;
-        if (cls < NP && valid) {
-            const int2 ax = s.aux[set][pos];
-            sx_total = ax.x;
-            sxx = __int_as_float(ax.y);
-            if (phase > 0) u = s.U[set][((size_t)t * NP + cls) * 64 + lane];
-            if (cls == 0) s.exitKey[pos] = ~0ull;   // k_wvb_sums of this phase takes the minimum over the failed levels
-        }
-        __syncthreads();
-        WVB_T(tq1);
-        WVB_ADD(8 * phase + 0, 1);
-        WVB_ADD(8 * phase + 1, tq1 - tq0);
-        if (cls < NP) {
-            int curTile = -1, ringTile = -1;   // tile whose sums are in Sw; tile whose first eight fragments are in the ring
-            wvb_v4i an[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) an[q] = wvb_v4i{0, 0, 0, 0};
-            for (int gb = g0; gb < g1; gb += WVB_RECS) {
-                WVB_T(tq2);
-                // the level records of the next WVB_RECS levels of this class: one coalesced load each, all in flight together
-                const int rem = NU - 1 - cls - gb * NP;
-                if (rem < 0) break;
-                const int nl = min(min(WVB_RECS, g1 - gb), rem / NP + 1);   // levels of this batch (k < NU)
-                wave_sync();
-                {
-                    int rv[WVB_RECS];
-#pragma unroll
-                    for (int i = 0; i < WVB_RECS; ++i) rv[i] = mv.rec[(size_t)((gb + min(i, nl - 1)) * NP + cls) * WVB_REC_DW + lane];
-#pragma unroll
-                    for (int i = 0; i < WVB_RECS; ++i) Rw[i * WVB_REC_DW + lane] = rv[i];
-                }
-                wave_sync();
-                WVB_T(tq3);
-                WVB_ADD(8 * phase + 2, tq3 - tq2);
-                for (int i0 = 0; i0 < nl; i0 += 4) {
-                    WVB_T(tq4);
-                    // ---- four levels at a time: everything up to the u_kernel_eval dependency is independent between them
-                    double part[4], ppv[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int* rc = Rw + min(i0 + j, nl - 1) * WVB_REC_DW;   // past the end: the last level again (discarded)
-                        const int tile = __builtin_amdgcn_readfirstlane(rc[0]), row0 = __builtin_amdgcn_readfirstlane(rc[1]);
-                        const int cnt = __builtin_amdgcn_readfirstlane(rc[2]);
-                        if (tile != curTile) {
-                            // ---- rect sums of the tile's rows for the 64 windows: C[row][window] = sum_pixel M[row][pixel] * x[window][pixel]
-                            // The operand fragments stream from L2 through a ring of eight that runs one group ahead AND wraps into the next
-                            // tile of the class (tiles of a class are consecutive, KSP is a multiple of eight): when the levels of this tile
-                            // have been chained, the first eight fragments of the next one are already in registers.
-                            const wvb_v4i* Ap = mv.A + (size_t)tile * KSP * 64 + lane;
-                            if (tile != ringTile) {
-#pragma unroll
-                                for (int q = 0; q < 8; ++q) an[q] = Ap[q * 64];
-                            }
-                            curTile = tile;
-                            ringTile = tile + 1;
-                            wvb_v16i acc0 = {}, acc1 = {};
-                            const unsigned char* xb = wvb_lds + (lane & 31) * DS + (lane >> 5) * 16;
-                            for (int ks = 0; ks < KSP; ks += 8) {
-#pragma unroll
-                                for (int q = 0; q < 8; ++q) {
-                                    const wvb_v4i a = an[q];
-                                    an[q] = Ap[(ks + 8 + q) * 64];   // past this tile: the next tile's fragments (a zero tile ends the table)
-                                    if (ks + q < KS) {
-                                        const wvb_v4i b0 = *reinterpret_cast<const wvb_v4i*>(xb + (ks + q) * 32);
-                                        const wvb_v4i b1 = *reinterpret_cast<const wvb_v4i*>(xb + 32 * DS + (ks + q) * 32);
-                                        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b0, acc0, 0, 0, 0);
-                                        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1, acc1, 0, 0, 0);
-                                    }
-                                }
-                            }
-                            wave_sync();   // the reads of the previous tile's sums are done
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                                Sw[row * 64 + (lane & 31)] = acc0[r];
-                                Sw[row * 64 + 32 + (lane & 31)] = acc1[r];
-                            }
-                            wave_sync();
-                        }
-                        // the reference's sums in its order (WvmClassifier.cpp:277-309); grey values past cnt add an exact +0
-                        const double* valL = reinterpret_cast<const double*>(rc + 8);
-                        double sum_xp = 0.0;
-                        int sumv0 = sx_total;
-#pragma unroll
-                        for (int v = 1; v < MAXV; ++v) {
-                            int sv = Sw[min(row0 + v - 1, 31) * 64 + lane] + rc[40 + v];
-                            sv = v < cnt ? sv : 0;
-                            sumv0 -= sv;
-                            const double prod = (double)sv * valL[v];   // val[v] is stored as 0 for v >= cnt
-                            sum_xp = sum_xp + prod;
-                        }
-                        const double t0 = (double)sumv0 * valL[0];
-                        part[j] = sum_xp + t0;
-                        ppv[j] = *reinterpret_cast<const double*>(rc + 4);
-                    }
-                    // ---- the serial part: u_kernel_eval of the class from level to level (WvmClassifier.cpp:310-316)
-                    double arg[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        double sum_xp = part[j] + (double)u;
-                        if (i0 + j < nl) u = (float)sum_xp;
-                        double norm = (double)sxx;
-                        norm = norm - 2 * sum_xp;
-                        norm = norm + ppv[j];
-                        arg[j] = (double)mv.negBasis * norm;
-                    }
-                    // ---- the kernel values: independent again
-                    float Kk[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) Kk[j] = (float)exp(arg[j]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (i0 + j < nl && valid) s.K[set][((size_t)t * NU + (gb + i0 + j) * NP + cls) * 64 + lane] = Kk[j];
-                    WVB_T(tq6);
-                    WVB_ADD(8 * phase + 4, tq6 - tq4);
-                    WVB_ADD(8 * phase + 6, min(4, nl - i0));
-                }
-            }
-            if (valid && phase + 1 < mv.nphase) s.U[set][((size_t)t * NP + cls) * 64 + lane] = u;
-        }
-        WVB_T(tq7);
-        WVB_ADD(8 * phase + 5, tq7 - tq0);
-    }
-    WVB_FLUSH;
-}
 
 // Window operands of four k-steps (2 N-tiles each) from LDS with all eight ds_read_b128 in flight, and the wait that hands them to the
 // MFMAs.  Left to the compiler every read was waited for one MFMA ahead (register pressure): 26 exposed LDS round trips per tile,
@@ -885,15 +710,16 @@ static void launch_stageb(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* m,
     const int64_t ub = std::min<int64_t>(total, s.cap);   // upper bound of the windows in any phase
     if (ub <= 0) return;
     const int cus = ctx->num_cus;
-    static const bool chainOld = [] { const char* e = getenv("FD_WVB_CHAIN"); return e && !std::strcmp(e, "old"); }();
     const int lpt = mv.maxCnt <= 8 ? 4 : 2;
-    const int ldsBytes = chainOld ? 64 * mv.dstride + 4 * (32 * 64 + WVB_RECS * WVB_REC_DW) * (int)sizeof(int)
-                                  : 64 * mv.dstride + 4 * (2 * lpt * WVB_REC_DW) * (int)sizeof(int);
-    static uint64_t ldsDone8 = 0, ldsDone16 = 0;
-    const bool v8 = mv.maxCnt <= 8;
-    if (v8) fd_allow_lds(ctx, (const void*)k_wvb_chain<8>, 160 * 1024, ldsDone8);
-    else fd_allow_lds(ctx, (const void*)k_wvb_chain<WVM_MAX_VALS>, 160 * 1024, ldsDone16);
-    const int perCuC = chainOld ? std::max(1, std::min(8, (160 * 1024) / ldsBytes)) : 2;
+    const int ldsBytes = 64 * mv.dstride + 4 * (2 * lpt * WVB_REC_DW) * (int)sizeof(int);
+    const bool v8 = mv.maxCnt <= 8, r16 = mv.KSP == 16;
+    const int perCuC = 2;   // k_wvb_chain2: __launch_bounds__(256, 2)
+    void (*chainK)(WvbDev, WvbState, int, const unsigned int*) =
+        v8 ? (r16 ? k_wvb_chain2<8, 16> : k_wvb_chain2<8, 8>) : (r16 ? k_wvb_chain2<WVM_MAX_VALS, 16> : k_wvb_chain2<WVM_MAX_VALS, 8>);
+    if (ldsBytes > 64 * 1024) {   // run-time-sized patches of more than ~900 pixels: above the default dynamic LDS limit
+        static uint64_t ldsDone[4] = {};
+        fd_allow_lds(ctx, (const void*)chainK, 160 * 1024, ldsDone[(v8 ? 0 : 2) + (r16 ? 1 : 0)]);
+    }
     auto expect = [&](int ph) {   // windows expected at the start of phase ph, with a margin
         int64_t pred = ph == 0 ? m->sbDeep : m->sbCutAlive[m->sbPlanCut[ph - 1]];
         if (pred < 0) pred = m->sbDeep;
@@ -927,16 +753,7 @@ static void launch_stageb(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* m,
         const int nrb = (k1 - k0 + 7) / 8;
         const int64_t tiles = (expect(ph) + 63) / 64;
         const int gridC = wvb_grid8(std::min<int64_t>(tiles * NQ, (int64_t)cus * perCuC));
-        if (chainOld) {
-            if (v8) hipLaunchKernelGGL(k_wvb_chain<8>, dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
-            else hipLaunchKernelGGL(k_wvb_chain<WVM_MAX_VALS>, dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
-        } else {
-            const bool r16 = mv.KSP == 16;
-            if (v8 && r16) hipLaunchKernelGGL((k_wvb_chain2<8, 16>), dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
-            else if (v8) hipLaunchKernelGGL((k_wvb_chain2<8, 8>), dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
-            else if (r16) hipLaunchKernelGGL((k_wvb_chain2<WVM_MAX_VALS, 16>), dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
-            else hipLaunchKernelGGL((k_wvb_chain2<WVM_MAX_VALS, 8>), dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
-        }
+        hipLaunchKernelGGL(chainK, dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
         const int gridH = wvb_grid8(std::min<int64_t>((tiles + 3) / 4 * nrb, (int64_t)cus * 8));
         hipLaunchKernelGGL(k_wvb_sums, dim3(gridH), dim3(256), 0, st, mv, s, ph, countPtr);
         const int gridE = wvb_grid8(std::min<int64_t>(tiles, (int64_t)cus * 4));

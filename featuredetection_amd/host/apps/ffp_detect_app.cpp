@@ -87,6 +87,7 @@ static int launch_ranks(int gpus, int argc, char** argv, const std::vector<char*
     int rc = (int)kids.size() == gpus ? 0 : 1;
     size_t left = kids.size();
     bool killed = false;
+    std::chrono::steady_clock::time_point tKill;
     while (left > 0) {
         int st = 0;
         const pid_t k = waitpid(-1, &st, WNOHANG);
@@ -103,6 +104,20 @@ static int launch_ranks(int gpus, int argc, char** argv, const std::vector<char*
             if (late) { std::fprintf(stderr, "runtime error: the ranks did not finish within %.0f s\n", timeoutS); rc = 1; }
             for (pid_t p : kids) kill(p, SIGTERM);
             killed = true;
+            tKill = std::chrono::steady_clock::now();
+        } else if (killed && std::chrono::duration<double>(std::chrono::steady_clock::now() - tKill).count() > 5.0) {
+            // a rank blocked in a driver / RCCL call does not react to SIGTERM (the very hang this guards against): SIGKILL after a grace
+            // period of 5 s, then at most 5 s more for the kernel to reap them -- the launcher never waits forever
+            for (pid_t p : kids) kill(p, SIGKILL);
+            const auto tk = std::chrono::steady_clock::now();
+            while (left > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - tk).count() < 5.0) {
+                int st2 = 0;
+                const pid_t k2 = waitpid(-1, &st2, WNOHANG);
+                if (k2 > 0) --left;
+                else if (k2 < 0) break;
+                else usleep(2000);
+            }
+            break;
         }
     }
     unlink(path);
@@ -200,7 +215,7 @@ int main(int argc, char** argv) {
                 if (!f) throw std::runtime_error("cannot read the communicator id");
             }
             fd_dist* dist = nullptr;
-            fdhost::check(fd_dist_init(fdhost::context(), rank, world, id, &dist));
+            fdhost::check(fd_dist_init(fdhost::context(), rank, world, world > 1 ? id : nullptr, &dist));   // one rank: no communicator
             std::vector<cv::Mat> imgs;
             std::vector<int64_t> ids;
             const int nimg = argc - 2;

@@ -471,6 +471,8 @@ int fd_sdm_fit_batch_end(fd_ctx* ctx, fd_sdm_ticket* ticket, float* shapes_out, 
  * source); a maintainer binds these around that loop (ffp_detect_app --gpus N).
  *   fd_dist_unique_id   rank 0 creates the communicator id (ncclGetUniqueId, 128 bytes) and hands it to the other ranks by any means
  *   fd_dist_init        joins the communicator on the context's device (ncclCommInitRank); world 1 needs no id and no librccl
+ *                       (id == NULL: the rank gathers from itself; id != NULL with world 1: a real one-rank communicator, the gather
+ *                       goes through ncclAllGather -- what the one-GPU tests use to run librccl itself)
  *   fd_pack_records     fd_detection -> fixed-stride records {image, detector, cx, cy, w, h, score, probability} (all exact in fp64)
  *   fd_dist_gather_records  ONE ncclAllGather of a padded [cap_per_rank + 1] record buffer per rank (row 0 = count) on the context's
  *                       stream; every rank receives the records of all ranks ordered by (image, detector, original order).
@@ -480,7 +482,11 @@ int fd_sdm_fit_batch_end(fd_ctx* ctx, fd_sdm_ticket* ticket, float* shapes_out, 
  *                       records: with all == NULL the call returns the count, with all_cap too small FD_ERR_CAPACITY -- either way the
  *                       gathered records stay in the handle, and the next call with a large enough buffer delivers them WITHOUT another
  *                       collective (so a retry on some ranks only cannot deadlock).  local / n_local of such a follow-up call are ignored.
- *                       FD_RCCL_LIB names another library with the five nccl entry points (tests: tests/stub_rccl). */
+ *                       FD_RCCL_LIB names another library with the five nccl entry points (tests: tests/stub_rccl).
+ *   fd_dist_gather_discard  drops a gathered set the caller does not want to fetch (after a count-only call or FD_ERR_CAPACITY), so that
+ *                       the next fd_dist_gather_records is a new collective.  Every rank must drop or take a set: a rank that still
+ *                       holds one would answer the next call from its handle while the others enter ncclAllGather.
+ *   fd_dist_gather_pending  1 while the handle holds a gathered set that has not been delivered or dropped. */
 #define FD_DIST_ID_BYTES 128
 typedef struct fd_dist fd_dist;
 typedef struct fd_record {
@@ -495,6 +501,8 @@ int fd_dist_world(const fd_dist* d);
 int fd_pack_records(int64_t image_id, int32_t detector_id, const fd_detection* dets, int n, fd_record* out);
 int fd_dist_gather_records(fd_dist* d, const fd_record* local, int n_local, int cap_per_rank, fd_record* all, int64_t all_cap,
                            int64_t* n_all, int* truncated);
+void fd_dist_gather_discard(fd_dist* d);
+int fd_dist_gather_pending(const fd_dist* d);
 
 #ifdef __cplusplus
 }

@@ -202,7 +202,7 @@ def test_stage_b_state_grows_with_the_queue(oracle, capi, ctx, synth, small_mode
 
 
 def test_stage_b_dense_equals_rect_lookup_kernels(capi, ctx, synth, oracle, frame640):
-    """FD_WVM_STAGEB=old keeps the rect-lookup stage-B kernels (k_wvm_deepB): both must deliver the same positive records"""
+    """FD_WVM_STAGEB=old keeps the rect-lookup stage-B kernel (k_wvm_deep): both must deliver the same positive records"""
     import bench
     wvm_m, _ = bench.cascade_models()
     _, pg = _pyr_pair(oracle, capi, ctx, frame640, **FF)

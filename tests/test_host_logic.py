@@ -269,3 +269,39 @@ def test_prefilter_plan_covers_every_window_once(capi, seed):
     assert capi.wvd_plan([77, 45], [53, 29], 1, 1, 20, 3072)[0] == 1
     assert capi.wvd_plan([1901], [1061], 1, 1, 24, 3072)[0] >= 8
     assert capi.wvd_plan([1901], [1061], 64, 1, 24, 3072)[0] >= 12
+
+
+def test_probability_order_margin_of_the_device_overlap_elimination():
+    """k_fs_oe (csrc/fs_tail.hpp) orders a frame's positives by the fp32 cascade output and claims that this is the order of
+    the reference's double probabilities 1 / (1 + exp(A + B x)) whenever two sorted neighbours pass its gap test (relative distance of
+    the two 1 + e values > 1e-14); everything else goes back to the host.  The claim rests on the host's libm: sweep pairs of fp32
+    outputs -- adjacent floats and small multiples of an ulp apart, from the steep part of the logistic into its saturation -- and
+    check, with THIS host's exp, that every pair the kernel would accept has strictly ordered probabilities, and that the rule does
+    give up where the doubles collapse."""
+    import math
+    A, B = 0.00556, -2.95   # ProbabilisticWvmClassifier.hpp:36
+    accepted = rejected = collapsed_accepted = 0
+    for base in np.concatenate([np.linspace(-3.0, 14.0, 3001), np.linspace(11.0, 13.5, 2001)]).astype(np.float32):
+        for k in (1, 2, 3, 5, 9, 33, 1025):
+            x1 = np.float32(base)
+            x2 = x1
+            for _ in range(min(k, 40)):
+                x2 = np.nextafter(x2, np.float32(np.inf))
+            if k > 40:
+                x2 = np.float32(x1 + np.float32(k) * np.spacing(x1))
+            if x2 == x1:
+                continue
+            if x2 < x1:   # np.spacing carries the sign of its argument
+                x1, x2 = x2, x1
+            t1, t2 = A + B * float(x1), A + B * float(x2)
+            ex = math.exp(min(t1, t2))
+            gap = ex / (1.0 + ex) * abs(B) * abs(float(x1) - float(x2))
+            p1 = 1.0 / (1.0 + math.exp(t1))   # wvm_probability (csrc/wvm.hip) = ProbabilisticWvmClassifier.cpp:52, evaluated in double
+            p2 = 1.0 / (1.0 + math.exp(t2))
+            if gap > 1e-14:   # the kernel keeps the fp32 order: B < 0, so the larger output must have the larger probability
+                accepted += 1
+                assert p2 > p1, (float(x1), float(x2), p1, p2, gap)
+            else:
+                rejected += 1
+            collapsed_accepted += int(p1 == p2 and gap > 1e-14)
+    assert accepted > 10000 and rejected > 100 and collapsed_accepted == 0
