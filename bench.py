@@ -9,8 +9,10 @@ fd_detect_five_stage_batch; every frame's fd_detection records reach the host in
 The other BASELINE configs ride along as sub-records under "also" (same JSON line), each with its own ms_per_step, roofline and
 cpu_baseline:
   hog_svm  config 2: 640x480, 21-layer pyramid, 20x20 windows stride 2, HOG-324 + RBF-SVM 1024 SV   (fd_detect_hog_svm_begin/_end)
-  ffp15    config 3: the 15 detectors of ffpDetectApp/*.cfg on a 1920x1080 frame                    (fd_five_stage_batch_begin/_end)
+  ffp15    config 3: the 15 detectors of ffpDetectApp/*.cfg on 1920x1080 frames, 32 distinct ones    (fd_five_stage_batch_begin/_end)
   sdm      config 4: 256 face crops x 68 landmarks x 4 cascade steps                                 (fd_sdm_fit_batch)
+  config5  config 5: a 10,000-image 1920x1080 batch through the 15 detectors, image i -> rank i mod N, the detection records gathered
+           every 256 images (fd_dist_gather_records = ONE ncclAllGather); a FIXED job ("scaling": "strong"), steps = gathers
 Frames are resident in HBM before the timed region.  Multi-GPU (config 5): one process per GPU (torch.distributed, RCCL), image i
 -> rank i mod N, no data-path collective, ONE all_gather of the real detection records {image, detector, cx, cy, w, h, score,
 prob} every --gather-every steps.  `python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run.
@@ -41,6 +43,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense f32 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 PEAK_VALU_GINST = 256 * 4 * 2.4 / 4.0   # wave64 VALU instructions per ns: 1024 SIMD16 x 2.4 GHz / 4 cycles per wave64 instruction
+PEAK_I8_MFMA_TOPS = 3944.0     # MI355X dense int8 MFMA (MI355X_MICROARCH.md: ">= 3944 TOPS")
 
 
 # ---------------------------------------------------------------------------------------------------------------- helpers
@@ -64,8 +67,15 @@ def pmc_record(workload, kernel_substr):
     """Counter figures per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/r04_pmc.json, written by
     tools/pmc_summary.py from runs of this script; every entry names the command and the git head it was measured at)."""
     try:
-        path = next(p_ for p_ in (os.path.join(ROOT, "profiles", "r0%d_pmc.json" % r) for r in (4, 3, 2)) if os.path.exists(p_))
-        rec = json.load(open(path))
+        # the newest committed pass that holds this workload (a round only re-measures the workloads whose kernels it touched)
+        rec = None
+        for r in (5, 4, 3, 2):
+            p_ = os.path.join(ROOT, "profiles", "r0%d_pmc.json" % r)
+            if os.path.exists(p_):
+                cand = json.load(open(p_))
+                if workload in cand:
+                    rec = cand
+                    break
         ks = rec.get(workload, {}).get("kernels", {})
         agg = "k_all(%s)" % kernel_substr
         for k, v in ([(agg, ks[agg])] if agg in ks else []) + list(ks.items()):
@@ -122,6 +132,54 @@ def cpu_record(units_1t, dt_1t, phases, units_nt, dt_nt, nthreads, sample, unit)
     return rec
 
 
+def device_frames(ids, W, H, dev, seed0=20260927, scene_len=4, nbase=9):
+    """Synthetic BGR frames generated ON THE DEVICE ("generated on-device to avoid PCIe/host bias"): the recipe of
+    synth.make_frames_varied -- smooth noise fields drifting like a camera pan, per-frame fine noise, 0..10 high-contrast blobs moving
+    through short scenes whose busy-ness differs -- restated with torch ops (test data, not product code).  Frame `i` depends on
+    (seed0, i) only, so the content of image i is the same whatever the number of ranks.  Returns a list of H x W x 3 uint8 tensors."""
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed0)
+    k1 = {}
+    bases = []
+    for b in range(nbase):   # smooth base fields: Gaussian-blurred uniform noise (sigma 4 / 8 / 14), rescaled to 0..1
+        sigma = (4.0, 8.0, 14.0)[b % 3]
+        if sigma not in k1:
+            r = int(3 * sigma + 0.5)
+            k = torch.exp(-0.5 * (torch.arange(-r, r + 1, device=dev, dtype=torch.float32) / sigma) ** 2)
+            k1[sigma] = (k / k.sum(), r)
+        k, r = k1[sigma]
+        x = torch.rand((1, 1, H, W), generator=g, device=dev)
+        x = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (0, 0, r, r), mode="reflect"), k.view(1, 1, -1, 1))
+        x = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (r, r, 0, 0), mode="reflect"), k.view(1, 1, 1, -1))[0, 0]
+        bases.append((x - x.min()) / (x.max() - x.min()).clamp_min(1e-12))
+    yy, xx = torch.meshgrid(torch.arange(160, device=dev, dtype=torch.float32), torch.arange(160, device=dev, dtype=torch.float32), indexing="ij")
+    out, scenes = [], {}
+    for i in ids:
+        sc, t = int(i) // scene_len, int(i) % scene_len
+        if sc not in scenes:   # the scene's parameters: host RNG seeded by (seed0, scene)
+            rng = np.random.default_rng([seed0, sc])
+            busy = float(rng.random())
+            scenes = {sc: dict(fine=0.05 + 0.35 * rng.random(), gain=0.5 + 0.5 * rng.random(), idx=rng.integers(0, nbase, 3), vel=rng.integers(-3, 4, (3, 2)),
+                               blobs=[dict(s=int(rng.integers(48, 161)), y=float(rng.uniform(0, H - 161)), x=float(rng.uniform(0, W - 161)), vy=float(rng.uniform(-2, 2)),
+                                           vx=float(rng.uniform(-2, 2)), fy=float(rng.uniform(4, 12)), fx=float(rng.uniform(4, 12))) for _ in range(int(round(busy * 10)))])}
+        p_ = scenes[sc]
+        g.manual_seed(seed0 * 1000003 + int(i))
+        noise = torch.rand((H, W, 3), generator=g, device=dev)
+        img = torch.empty((H, W, 3), device=dev)
+        for c in range(3):
+            base = torch.roll(bases[int(p_["idx"][c])], (int(p_["vel"][c, 0]) * t, int(p_["vel"][c, 1]) * t), dims=(0, 1))
+            img[..., c] = (1.0 - p_["fine"]) * (0.5 + p_["gain"] * (base - 0.5)) + p_["fine"] * noise[..., c]
+        for bl in p_["blobs"]:
+            s_ = bl["s"]
+            y0 = int(min(max(bl["y"] + bl["vy"] * t, 0), H - s_ - 1))
+            x0 = int(min(max(bl["x"] + bl["vx"] * t, 0), W - s_ - 1))
+            blob = 0.5 + 0.5 * torch.sin(yy[:s_, :s_] / s_ * bl["fy"]) * torch.cos(xx[:s_, :s_] / s_ * bl["fx"])
+            img[y0:y0 + s_, x0:x0 + s_, :] = 0.15 * img[y0:y0 + s_, x0:x0 + s_, :] + 0.85 * blob[..., None]
+        out.append(torch.clamp(torch.round(img * 255), 0, 255).to(torch.uint8).contiguous())
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------- workloads
 class Workload:
     name = ""
@@ -130,6 +188,8 @@ class Workload:
     units_name = "windows"
     records_cap = 1 << 16     # rows of the padded all_gather buffer (multi-GPU)
     gather_every = None       # None: --gather-every
+    fixed_steps = None        # a workload that is ONE fixed job (config 5) sets its own number of steps
+    scaling = "weak"
 
     def step(self, i):
         """one step; returns (units, [(image_id, detector_id, detections)])"""
@@ -162,8 +222,7 @@ WVM_PROFILES = {
 def cascade_models(profile="default"):
     """FaceFrontal WVM (280 filters) + RBF-SVM (1024 SV) calibrated on the config-1 frame; identical on every rank"""
     from featuredetection_amd import synth
-    from oracle import pyoracle as O   # calibration patches only (bgr2gray of the calibration frame), untimed setup
-    gray = O.bgr2gray(synth.make_frame(640, 480, seed=20260927))
+    gray = synth.bgr2gray_np(synth.make_frame(640, 480, seed=20260927))   # calibration patches (untimed setup; no oracle involved)
     prof = WVM_PROFILES[profile]
     calib = synth.random_patches(gray[::4, ::4].copy(), 20, 20, prof["ncalib"], np.random.default_rng(1))
     wvm_m = synth.make_wvm(7, calib_patches=calib, **prof["kw"])
@@ -310,6 +369,8 @@ class Cascade(Workload):
         a call, the roofline entries, and the single-frame latency of the detector"""
         capi, ctx = self.capi, self.env.ctx
         nf = self.NB if self.multi else 1
+        if self.profile != "default" and self.multi:
+            return self.kernel_probe_stage_b()
         times = {}
         for mode in (2, 1):   # 2: k_wvm_prefilter alone; 1: every WVM kernel of the call (pre-filter + stage B)
             ctx.set_kernel_timing(mode)
@@ -344,6 +405,47 @@ class Cascade(Workload):
             extra["roofline_issue"] = issue_roofline(pm)
         if (self.W, self.H) == (640, 480) and self.profile == "default":
             extra["latency_us_single_frame"] = self.single_frame_latency()
+        return roof, extra
+
+    def kernel_probe_stage_b(self):
+        """The rejection-profile variants hand stage B a large share of the windows: their dominant kernel is k_wvb_chain2 (the rect sums
+        of every level as an int8 MFMA contraction + the reference's fp64 chain and exp per level), launched once per stage-B phase.
+        HIP events around each of its launches (fd_ctx_set_kernel_timing(3)), summed per call; algorithmic work from the phase plan of
+        the same calls: windows alive at a phase's start x its levels x (grey values - 1) x patch pixels x 2 int8 ops."""
+        capi, ctx = self.capi, self.env.ctx
+        nf = self.NB
+        sl = self.slots[0]
+        d = int(self.wvm_m["filter_w"]) * int(self.wvm_m["filter_h"])
+        nper, nused = int(self.wvm_m["num_per_level"]), int(self.wvm_m["num_used"])
+        vo = np.asarray(self.wvm_m["val_off"])
+        gv = float(np.mean(np.diff(vo[:nused + 1]) - 1))
+        times, ops, plans = {}, [], []
+        for mode in (3, 1):
+            ctx.set_kernel_timing(mode)
+            ms = []
+            for i in range(10):
+                sl["pyr"].update_frames(device_ptrs=[self.dptrs[(i * nf + j) % self.NFR] for j in range(nf)], w=self.W, h=self.H, ch=3)
+                capi.detect_five_stage_frames(ctx, sl["pyr"], sl["wvm"], sl["svm"], nf)
+                ms.append(ctx.last_kernel_ms()[1])
+                if mode == 3 and i >= 2:
+                    plan = sl["wvm"].last_stage_b_plan()
+                    plans.append(plan)
+                    ops.append(sum(max(a, 0) * (min(g1 * nper, nused) - min(g0 * nper, nused)) * gv * d * 2.0 for g0, g1, a in plan))
+            times[mode] = float(np.mean(ms[2:]))
+        ctx.set_kernel_timing(False)
+        kms = times[3]
+        ach = float(np.mean(ops)) / (kms * 1e-3) / 1e12
+        pmk = pmc_record(self.name, "k_wvb_chain2")
+        roof = dict(bound="mfma", kernel="k_wvb_chain2 (stage B: rect sums of every level of the queued windows as an int8 MFMA contraction + the reference's "
+                    "fp64 chain and exp per level; one launch per stage-B phase, %d per call here) -- the dominant kernel of this rejection profile" % len(plans[-1]),
+                    achieved=ach, peak=PEAK_I8_MFMA_TOPS, unit="TOP/s (int8)", frac=ach / PEAK_I8_MFMA_TOPS, traffic=pmk.get("hbm_bytes") if pmk else None,
+                    kernel_ms=kms, cascade_kernels_ms=times[1], stage_b_phases=[dict(generations=[g0, g1], windows=a) for g0, g1, a in plans[-1]],
+                    algorithmic="sum over the stage-B phases of a call: windows alive x levels of the phase x %.1f grey values x %d pixels x 2 ops (SURVEY 8(a) a8: "
+                                "S_v = rect sums of grey level v); the contraction is exact int8, the bound that matters for this kernel is its fp64 VALU chain "
+                                "(roofline_issue)" % (gv, d))
+        extra = {}
+        if pmk and pmk.get("valu_issue_frac"):
+            extra["roofline_issue"] = issue_roofline(pmk)
         return roof, extra
 
     def single_frame_latency(self, n=400):
@@ -555,8 +657,7 @@ class HogSvm(Workload):
 def ffp15_models(nsv=1024):
     """the 15 detectors of ffpDetectApp/*.cfg: (name, pyramid key, WVM, SVM, pw, ph); SURVEY 8(d) config 3: 1024 SVs each"""
     from featuredetection_amd import synth
-    from oracle import pyoracle as O   # calibration patches only, untimed setup
-    gray = O.bgr2gray(synth.make_frame(640, 480, seed=20260927))
+    gray = synth.bgr2gray_np(synth.make_frame(640, 480, seed=20260927))   # calibration patches (untimed setup; no oracle involved)
     models = []
     for di, (name, (inc, mn, mx, pw, ph, nper, nlev)) in enumerate(sorted(synth.DETECTOR_CFGS.items())):
         src = gray[::4, ::4] if mx < 0.3 else gray[::2, ::2]
@@ -569,17 +670,43 @@ def ffp15_models(nsv=1024):
 
 
 class Ffp15(Workload):
-    """config 3 (and the per-GPU work of config 5): 15 five-stage detectors on one 1920x1080 frame, 32.1 M windows"""
+    """config 3 (and the per-GPU work of config 5): 15 five-stage detectors on 1920x1080 frames, 32.1 M windows per frame"""
     name = "ffp15"
     dtype = "u8/i32/f32/f64"
+    content = "varied"        # "2frames": the content of rounds 1-4 (two alternating frames of synth.make_frame)
+    NDISTINCT = 32
+
+    def make_content(self, W, H):
+        """the frames this rank works on, resident in HBM: (list of device tensors, description)"""
+        import torch
+        from featuredetection_amd import synth
+        env = self.env
+        if self.content == "2frames":
+            fr = [torch.from_numpy(synth.make_frame(W, H, seed=20260927 + 1000 * env.rank + i)).to(env.dev) for i in range(2)]
+            return fr, "2 alternating frames (the content of rounds 1-4: stage B's launch plan, OE and the SVM see the same positives every other frame)"
+        # VERDICT r04 task 1a: >= 32 distinct frames per rank (199 MB of BGR in HBM), 8 scenes of 4 frames with different busy-ness,
+        # visited in an order reshuffled every pass -- so consecutive frames queue different numbers of windows and nothing repeats
+        ids = np.arange(self.NDISTINCT) + 100000 * (1 + env.rank)
+        return device_frames(ids, W, H, env.dev), ("%d distinct frames resident in HBM (device_frames: %d scenes of 4 with different busy-ness), order reshuffled every pass"
+                                                   % (self.NDISTINCT, self.NDISTINCT // 4))
+
+    def next_frame(self):
+        """device tensor of the next frame of the endless sequence"""
+        n = len(self.dframes)
+        pos = self.nfed % n
+        if pos == 0 and self.content == "varied":
+            sc = self.order_rng.permutation(n // 4)
+            self.order = (sc[:, None] * 4 + np.arange(4)[None, :]).ravel()
+        self.nfed += 1
+        return self.dframes[int(self.order[pos])]
 
     def __init__(self, env, W=1920, H=1080, frames_per_step=4):
-        import torch
-        from featuredetection_amd import capi, synth
+        import torch  # noqa: F401
+        from featuredetection_amd import capi, synth  # noqa: F401
         self.env, self.capi, self.W, self.H = env, capi, W, H
         self.FP = max(1, frames_per_step)
-        self.frames = [synth.make_frame(W, H, seed=20260927 + 1000 * env.rank + i) for i in range(2)]
-        self.dframes = [torch.from_numpy(f).to(env.dev) for f in self.frames]
+        self.dframes, content_note = self.make_content(W, H)
+        self.order, self.nfed, self.order_rng = np.arange(len(self.dframes)), 0, np.random.default_rng(78 + env.rank)
         self.models = ffp15_models()
         ctx = env.ctx
         # two frames in flight (FD_BENCH_FFP_SLOTS), each with its own pyramids and classifier handles: frame f + 1's pyramids and
@@ -595,33 +722,37 @@ class Ffp15(Workload):
             self.slots.append(dict(pyrs=pyrs, dets=dets, run=None, img=None))
         self.pyrs, self.dets = self.slots[0]["pyrs"], self.slots[0]["dets"]
         for pr in self.pyrs.values():
-            pr.update(self.frames[0])
+            pr.update_device(self.dframes[0].data_ptr(), W, H, 3)
         self.nwin = sum(pr.window_count(pw, ph, 1, 1) for _, pr, _, _, pw, ph in self.dets)
         self.ncalls = 0
         self.metric = "Mpatches/s (extract+WVM+SVM cascade, 15 detectors), %dx%d pyramid" % (W, H)
         self.config = dict(workload="config 3: the 15 detectors of ffpDetectApp/*.cfg (five-stage WVM -> OE -> RBF-SVM 1024 SV -> NMS each), full %dx%d "
                                     "frame, step 1: %d windows per frame; %d shared pyramids; fd_five_stage_batch_begin/_end, %d frames in flight" %
                                     (W, H, self.nwin, len(self.pyrs), nslots),
-                           frames_per_step=self.FP, parallelism="image-shard dp%d" % env.world)
+                           frames_per_step=self.FP, parallelism="image-shard dp%d" % env.world, content=content_note)
 
     def _collect(self, sl):
         res, sl["run"] = sl["run"].end(), None
         return [(sl["img"], di, d_) for di, (d_, _) in enumerate(res)]
 
+    def _feed(self, fr, image_id):
+        """queues one frame (device tensor) through the 15 detectors; returns the records of the call that had to be collected first"""
+        out = []
+        sl = self.slots[self.ncalls % len(self.slots)]
+        self.ncalls += 1
+        if sl["run"] is not None:
+            out.extend(self._collect(sl))
+        for pr in sl["pyrs"].values():
+            pr.update_device(fr.data_ptr(), self.W, self.H, 3)
+        sl["run"] = self.capi.FiveStageBatch(self.env.ctx, [(pr, wv, sv_) for _, pr, wv, sv_, _, _ in sl["dets"]], cap=4096)
+        sl["img"] = image_id
+        return out
+
     def step(self, i):
-        capi = self.capi
         out = []
         for j in range(self.FP):
             f = i * self.FP + j
-            sl = self.slots[self.ncalls % len(self.slots)]
-            self.ncalls += 1
-            if sl["run"] is not None:
-                out.extend(self._collect(sl))
-            fr = self.dframes[f % 2]
-            for pr in sl["pyrs"].values():
-                pr.update_device(fr.data_ptr(), self.W, self.H, 3)
-            sl["run"] = capi.FiveStageBatch(self.env.ctx, [(pr, wv, sv_) for _, pr, wv, sv_, _, _ in sl["dets"]], cap=4096)
-            sl["img"] = f * self.env.world + self.env.rank
+            out.extend(self._feed(self.next_frame(), f * self.env.world + self.env.rank))
         return self.nwin * self.FP, out
 
     def flush(self):
@@ -641,7 +772,7 @@ class Ffp15(Workload):
             ctx.set_kernel_timing(mode)
             ms = []
             for i in range(6):
-                pr.update_device(self.dframes[i % 2].data_ptr(), self.W, self.H, 3)
+                pr.update_device(self.dframes[i % len(self.dframes)].data_ptr(), self.W, self.H, 3)
                 capi.detect_five_stage(ctx, pr, wv, sv_, cap=1 << 14)
                 ms.append(ctx.last_kernel_ms()[1])
             times[mode] = float(np.mean(ms[1:]))
@@ -698,6 +829,72 @@ class Ffp15(Workload):
         return cpu_record(n1, dt1, dict(update=tu, extract=te, classify=tc, total=dt1), sum(r[0] for r in rs), max(r[1] for r in rs), nt,
                           "the 15 detectors on one %dx%d frame of the same recipe (%d windows, %.1f s; the reference rebuilds the pyramid per detector), "
                           "oracle -O2, 1 thread; n_thread: detectors spread over threads" % (SW, SH, n1, dt1), "Mpatches/s")
+
+
+class Ffp15Two(Ffp15):
+    """config 3 on the content of rounds 1-4 (two alternating frames per rank): kept as a second record for continuity"""
+    name = "ffp15_2frames"
+    content = "2frames"
+
+    def cpu_baseline(self):
+        return None
+
+
+class Config5(Ffp15):
+    """BASELINE config 5: a 10,000-image 1920x1080 batch through the 15 five-stage detectors, image i -> rank i mod N (fd_dist_owner),
+    models replicated, the detection records gathered every 256 images of the job.  A FIXED job: one step = one
+    gather interval (256 images job-wide, 256 / N per rank), steps = ceil(images / 256) whatever --steps says; value = all windows of
+    the job / wall time, `scaling` = "strong".  Every image is distinct and generated on the device from (seed, image index), so the
+    job's content -- and its detections -- do not depend on N."""
+    name = "config5"
+    gather_every = 1
+    scaling = "strong"
+    GATHER_IMAGES = 256
+    records_cap = 1 << 15     # records per rank and gather: 256 / N images x 15 detectors x a few detections
+
+    def make_content(self, W, H):
+        env = self.env
+        total = max(1, int(os.environ.get("FD_BENCH_CONFIG5_IMAGES", "10000")))
+        self.total_images = total
+        self.my_ids = np.arange(env.rank, total, env.world)          # image i belongs to rank i mod N
+        t0 = time.perf_counter()
+        fr = device_frames(self.my_ids, W, H, env.dev, seed0=20260928)
+        import torch
+        torch.cuda.synchronize()
+        self.gen_s = time.perf_counter() - t0
+        self.fixed_steps = (total + self.GATHER_IMAGES - 1) // self.GATHER_IMAGES
+        return fr, ("%d distinct %dx%d frames of the %d-image job resident in HBM on this rank (%.1f GB), generated on the device in %.1f s, each from "
+                    "(seed, image index)" % (len(fr), W, H, total, len(fr) * W * H * 3 / 1e9, self.gen_s))
+
+    def __init__(self, env, W=1920, H=1080, frames_per_step=0):
+        super().__init__(env, W, H, frames_per_step=1)
+        self.metric = "Mpatches/s (extract+WVM+SVM cascade, 15 detectors), %d-image %dx%d batch sharded over %d GPU(s)" % (self.total_images, W, H, env.world)
+        self.config["workload"] = ("config 5: %d images of %dx%d through the 15 detectors of ffpDetectApp/*.cfg (%d windows per image), image i -> rank i mod %d, "
+                                   "models replicated, ONE all-gather of the detection records (fd_dist_gather_records) every %d images; %s" %
+                                   (self.total_images, W, H, self.nwin, env.world, self.GATHER_IMAGES, self.config["workload"].split("; ", 1)[-1]))
+        self.config["images"] = self.total_images
+        self.config["gather_every_images"] = self.GATHER_IMAGES
+        self.config.pop("frames_per_step", None)
+
+    @staticmethod
+    def step_images(i, rank, world, total, gather=256):
+        """images of step i (the job's images [gather i, gather (i + 1))) that belong to `rank`: image j -> rank j mod world"""
+        lo, hi = i * gather, min((i + 1) * gather, total)
+        first = lo + ((rank - lo) % world)
+        return np.arange(first, hi, world)
+
+    def step(self, i):
+        out = []
+        ids = self.step_images(i, self.env.rank, self.env.world, self.total_images, self.GATHER_IMAGES)
+        for img in ids:
+            out.extend(self._feed(self.dframes[(int(img) - self.env.rank) // self.env.world], int(img)))
+        return self.nwin * len(ids), out
+
+    def kernel_probe(self):
+        return None
+
+    def cpu_baseline(self):
+        return None
 
 
 class Sdm(Workload):
@@ -788,10 +985,9 @@ class Rvm(Workload):
     def __init__(self, env, W=1920, H=1080):
         import torch
         from featuredetection_amd import capi, synth
-        from oracle import pyoracle as O  # calibration patches only
         self.env, self.capi, self.W, self.H = env, capi, W, H
         self.dframes = [torch.from_numpy(synth.make_frame(W, H, seed=20260927 + 1000 * env.rank + i)).to(env.dev) for i in range(4)]
-        gray = O.bgr2gray(synth.make_frame(640, 480, seed=20260927))
+        gray = synth.bgr2gray_np(synth.make_frame(640, 480, seed=20260927))
         calib = synth.histeq64_np(synth.random_patches(gray[::4, ::4].copy(), 20, 20, 6000, np.random.default_rng(1)))
         feats = calib.reshape(len(calib), -1).astype(np.float32) * np.float32(1.0 / 255.0)
         self.pyr = capi.Pyramid(env.ctx, inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16)))
@@ -853,6 +1049,8 @@ def measure(wl, env, steps, warmup, gather_every, want_cpu):
     recs_cap = wl.records_cap
     gather_every = wl.gather_every or gather_every
     truncated = False
+    if wl.fixed_steps:   # a fixed job (config 5): its own number of steps, one light warm-up step (the job's first 256 images, run again timed)
+        steps, warmup = wl.fixed_steps, min(warmup, 1)
 
     def barrier():
         wl.flush_out = wl.flush()
@@ -873,6 +1071,7 @@ def measure(wl, env, steps, warmup, gather_every, want_cpu):
     wl.flush()
     for i in range(warmup):
         wl.step(i)
+    wl.flush()
     gc.collect()
     gc.disable()   # a full gc pass over torch's object graph costs ~75 ms and would land on a random step
     barrier()
@@ -909,7 +1108,7 @@ def measure(wl, env, steps, warmup, gather_every, want_cpu):
         dist.all_reduce(uu, op=dist.ReduceOp.SUM)
     dt, total_units, total_det = float(tt.item()), float(uu[0].item()), int(uu[1].item())
     rec = dict(metric=wl.metric, value=total_units / dt / 1e6, unit=wl.unit, n_gpus=world, steps=steps, warmup=warmup,
-               ms_per_step=dt / steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype=wl.dtype, data="synthetic",
+               ms_per_step=dt / steps * 1e3, higher_is_better=True, scaling=wl.scaling, vs_baseline=None, dtype=wl.dtype, data="synthetic",
                config=wl.config, detections_delivered=total_det)
     if world > 1:
         rec["records_gathered"] = gathered
@@ -927,7 +1126,8 @@ def measure(wl, env, steps, warmup, gather_every, want_cpu):
     return rec
 
 
-WORKLOADS = dict(cascade=Cascade, cascade_8frames=Cascade8, cascade_late=CascadeLate, cascade_group=CascadeGroup, hog_svm=HogSvm, ffp15=Ffp15, sdm=Sdm, rvm=Rvm, aggregated=Aggregated)
+WORKLOADS = dict(cascade=Cascade, cascade_8frames=Cascade8, cascade_late=CascadeLate, cascade_group=CascadeGroup, hog_svm=HogSvm, ffp15=Ffp15, ffp15_2frames=Ffp15Two,
+                 config5=Config5, sdm=Sdm, rvm=Rvm, aggregated=Aggregated)
 
 
 def free_port():
@@ -944,8 +1144,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cascade", choices=sorted(WORKLOADS) + ["wvm"], help="headline workload (wvm = cascade)")
-    ap.add_argument("--also", default=None, help="comma-separated sub-records (default: hog_svm,ffp15,sdm,cascade_late,cascade_group,cascade_8frames when the headline is the "
-                                                 "default cascade; 'none' for none)")
+    ap.add_argument("--also", default=None, help="comma-separated sub-records (default: hog_svm,ffp15,sdm,cascade_late,cascade_group,cascade_8frames,ffp15_2frames,config5 "
+                                                 "when the headline is the default cascade; 'none' for none)")
+    ap.add_argument("--images", type=int, default=0, help="config5 workload: images of the job (default 10000; FD_BENCH_CONFIG5_IMAGES)")
     ap.add_argument("--gather-every", type=int, default=4)
     ap.add_argument("--size", default=None, help="frame size WxH of the headline workload (cascade, hog_svm, ffp15, rvm, aggregated)")
     ap.add_argument("--frames-per-step", type=int, default=0, help="frames (sdm: batches) per step of the headline workload; 0 = its default")
@@ -958,6 +1159,8 @@ def main():
     args = ap.parse_args()
     if args.workload == "wvm":
         args.workload = "cascade"
+    if args.images > 0:
+        os.environ["FD_BENCH_CONFIG5_IMAGES"] = str(args.images)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: start one rank per GPU ourselves (the same command the driver uses for the scaling runs)
@@ -1007,7 +1210,7 @@ def main():
             kw["W"], kw["H"] = [int(v) for v in args.size.split("x")]
         if headline and args.frames_per_step > 0:
             kw["batches_per_step" if name == "sdm" else "frames_per_step"] = args.frames_per_step
-            if name in ("rvm", "aggregated"):
+            if name in ("rvm", "aggregated", "config5"):
                 kw.pop("frames_per_step")
         if headline and args.frames_per_call > 0 and name == "cascade":
             kw["nb"] = args.frames_per_call
@@ -1018,7 +1221,7 @@ def main():
 
     also = args.also
     if also is None:
-        also = "hog_svm,ffp15,sdm,cascade_late,cascade_group,cascade_8frames" if (args.workload == "cascade" and not args.size) else "none"
+        also = "hog_svm,ffp15,sdm,cascade_late,cascade_group,cascade_8frames,ffp15_2frames,config5" if (args.workload == "cascade" and not args.size) else "none"
     also = [a for a in also.split(",") if a and a != "none"]
     want_cpu = not args.no_cpu_baseline
     env.no_probe = args.no_probe

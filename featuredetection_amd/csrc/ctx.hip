@@ -67,6 +67,7 @@ void fd_ctx_destroy(fd_ctx* ctx) {
     if (ctx->pinned.p) (void)hipHostFree(ctx->pinned.p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (hipEvent_t e : ctx->evx) if (e) (void)hipEventDestroy(e);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     if (ctx->tail) (void)hipStreamDestroy(ctx->tail);
     for (hipStream_t ps : ctx->pool) if (ps) (void)hipStreamDestroy(ps);
@@ -86,7 +87,7 @@ int fd_ctx_synchronize(fd_ctx* ctx) {
 int fd_ctx_set_kernel_timing(fd_ctx* ctx, int enable) {
     if (!ctx) return FD_ERR_INVALID_ARGUMENT;
     ctx->kernel_timing = enable != 0;
-    ctx->kernel_timing_mode = enable == 2 ? 2 : 1;
+    ctx->kernel_timing_mode = enable == 2 ? 2 : (enable == 3 ? 3 : 1);
     return FD_OK;
 }
 

@@ -156,7 +156,9 @@ struct fd_ctx {
     std::string error;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the dominant kernel of a detect call when kernel_timing is on (fd_hip_bench.h)
     bool kernel_timing = false;
-    int kernel_timing_mode = 1;      // WVM cascades: 1 = all cascade kernels of the call, 2 = the dense pre-filter only (fd_hip_bench.h)
+    int kernel_timing_mode = 1;      // WVM cascades: 1 = all cascade kernels of the call, 2 = the dense pre-filter only, 3 = stage B's chain kernels (fd_hip_bench.h)
+    hipEvent_t evx[8] = {};          // mode 3: one event pair per stage-B phase around its k_wvb_chain2 launch (created on first use)
+    int evxN = 0;                    // pairs recorded by the last timed launch
     const char* last_kernel = "";
     float last_kernel_ms = 0.f;
     int num_cus = 256;

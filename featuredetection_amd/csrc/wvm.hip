@@ -171,6 +171,7 @@ struct fd_wvm {
     int64_t sbDeep = -1, sbCutAlive[WVB_MAXPHASE] = {-1, -1, -1, -1};
     uint32_t sbCutMask = ~0u, sbRuns = 0;
     int sbPlanN = 0, sbPlanCut[WVB_MAXPHASE] = {};   // cuts of the run in flight
+    int sbLastN = 0, sbLastGen[WVB_MAXPHASE + 1] = {};   // phases of the last launch and their generation boundaries (fd_wvm_last_stage_b_plan)
     int64_t sbGrown = 0;             // capacity a queue overflow made the handle grow to
     std::shared_ptr<void> relaunch;   // WvbRelaunch: what fd_wvm_finish needs to run stage B again with a larger state (queue overflow)
     // five-stage tail on the device (fs_tail.hpp): overlap elimination + SVM queued behind the cascade
@@ -1596,6 +1597,23 @@ static void wvm_launch_table(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm*
     wvm_launch_tail(ctx, st, p, m, wt, wtq, L, skipA, time_kernel);
 }
 
+// bench hook: duration of the timed kernel(s) of a finished run (fd_hip_bench.h)
+static void wvm_read_timing(fd_ctx* ctx) {
+    if (ctx->kernel_timing_mode == 3 && ctx->evxN > 0) {
+        float sum = 0.f;
+        for (int ph = 0; ph < ctx->evxN; ++ph) {
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, ctx->evx[2 * ph], ctx->evx[2 * ph + 1]));
+            sum += ms;
+        }
+        ctx->last_kernel_ms = sum;
+        ctx->last_kernel = "k_wvb_chain2";
+        return;
+    }
+    HIP_CHECK(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev0, ctx->ev1));
+    ctx->last_kernel = "k_wvm_cascade";
+}
+
 // what a finished run's header tells the handle about the next one (idempotent)
 static void wvm_finish_header(fd_wvm* m, const PosRec* hraw) {
     if (m->zcRun) m->hdrClean = true;   // the last stage-B workgroup has cleared the device header
@@ -1621,10 +1639,7 @@ void fd_wvm_finish(fd_ctx* ctx, fd_wvm* m, WvmRun& run) {
     HIP_CHECK(hipEventSynchronize(m->done));
     PosRec* hraw = m->h_pos.as<PosRec>();
     const unsigned int cnt = hraw[0].wid_lo;
-    if (run.timed) {
-        HIP_CHECK(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev0, ctx->ev1));
-        ctx->last_kernel = "k_wvm_cascade";
-    }
+    if (run.timed) wvm_read_timing(ctx);
     if (m->zcRun && cnt == 0xffffffffu) FD_THROW(FD_ERR_HIP, "WVM stage B did not deliver its positive count");
     if (m->sbRun && (int64_t)hraw[0].wid_hi > m->deepCap && !wvb_cap_env() && m->relaunch) {
         // More windows reached stage B than its state holds (header word 1 = queue length; stage B took the first deepCap of them).
@@ -2103,10 +2118,7 @@ static bool fst_collect(fd_ctx* ctx, fd_wvm* m, const fd_svm* svm, const WvmRun&
     const PosRec* hraw = m->h_pos.as<PosRec>();
     const unsigned int cnt = hraw[0].wid_lo;
     if (cnt == 0xffffffffu) FD_THROW(FD_ERR_HIP, "WVM stage B did not deliver its positive count");
-    if (run.timed) {
-        HIP_CHECK(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev0, ctx->ev1));
-        ctx->last_kernel = "k_wvm_cascade";
-    }
+    if (run.timed) wvm_read_timing(ctx);
     m->fstLastState = 0x100;
     if ((int64_t)hraw[0].wid_hi > m->deepCap || (int64_t)cnt > m->pos_cap) return false;   // overflow: fd_wvm_finish grows / reports
     char* hb = m->h_fst.as<char>();
@@ -2784,6 +2796,17 @@ int fd_debug_wvd_prof(unsigned long long* out, int nwaves) {
 // Measurement hook (include/fd_hip_bench.h): windows the last finished run of this handle queued for stage B (-1: none yet)
 int64_t fd_wvm_last_queue_length(const fd_wvm* m) { return m ? m->sbDeep : -1; }
 int fd_wvm_last_tail_state(const fd_wvm* m) { return m ? m->fstLastState : -1; }
+int fd_wvm_last_stage_b_plan(const fd_wvm* m, int64_t* out) {
+    if (!m || !out) return FD_ERR_INVALID_ARGUMENT;
+    const int n = std::min(m->sbLastN, 3);
+    out[0] = n;
+    for (int ph = 0; ph < n; ++ph) {
+        out[1 + 3 * ph] = m->sbLastGen[ph];
+        out[2 + 3 * ph] = m->sbLastGen[ph + 1];
+        out[3 + 3 * ph] = ph == 0 ? m->sbDeep : (ph - 1 < m->sbPlanN ? m->sbCutAlive[m->sbPlanCut[ph - 1]] : -1);
+    }
+    return FD_OK;
+}
 #ifdef FD_FST_PROF
 int fd_debug_fst_prof(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(fd_fst_prof), 64) == hipSuccess ? 0 : -1; }
 #endif

@@ -147,6 +147,17 @@ __device__ __forceinline__ unsigned int wvd_load_u32(const uint8_t* p) {
     __builtin_memcpy(&v, p, 4);   // unaligned global_load_dword
     return v;
 }
+// A patch row of NW dwords from an arbitrary byte address with as few instructions as possible (dwordx4 / x2 / x1: unaligned vector
+// loads are legal on this part).  A lane that reads ITS OWN window (k_wvb_prepare_lanes) makes every load instruction touch 64 different
+// cache lines, so the number of instructions, not the bytes, is what the texture addresser is busy with.
+template <int NW>
+__device__ __forceinline__ void wvd_load_row(const uint8_t* p, unsigned int (&w)[NW]) {
+    int j = 0;
+#pragma unroll
+    for (; j + 4 <= NW; j += 4) { uint4 v; __builtin_memcpy(&v, p + 4 * j, 16); w[j] = v.x; w[j + 1] = v.y; w[j + 2] = v.z; w[j + 3] = v.w; }
+    if (j + 2 <= NW) { uint2 v; __builtin_memcpy(&v, p + 4 * j, 8); w[j] = v.x; w[j + 1] = v.y; j += 2; }
+    if (j < NW) w[j] = wvd_load_u32(p + 4 * j);
+}
 // the same with a wave-uniform base and a 32-bit lane offset: global_load_dword v, v_off, s[base] offset:imm -- no address arithmetic
 // on the vector unit (the uniform part of an address advances on the scalar unit)
 __device__ __forceinline__ unsigned int wvd_load_u32(const uint8_t* ubase, unsigned int voff) {
@@ -586,16 +597,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         __builtin_amdgcn_wave_barrier();
         {
             unsigned int wn[NW];
-#pragma unroll
-            for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(src + 4 * j);
+            wvd_load_row<NW>(src, wn);
 #pragma unroll 2
             for (int r = 0; r < PH_; ++r) {
                 unsigned int w4[NW];
 #pragma unroll
                 for (int j = 0; j < NW; ++j) w4[j] = wn[j];
-                const uint8_t* nsrc = src + (size_t)(r + 1 < PH_ ? r + 1 : r) * lw;
-#pragma unroll
-                for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(nsrc + 4 * j);
+                wvd_load_row<NW>(src + (size_t)(r + 1 < PH_ ? r + 1 : r) * lw, wn);
                 wvd_hist_row<NW, true>(w4, blkH4, laneOff32, inc);
             }
         }
@@ -607,29 +615,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         int8_t* xr = s.X[0] + (size_t)pos * mv.dstride;
         float sxx = 0.f;
         {
+            // G rows (G PW bytes = whole 16-byte slots, 16-byte aligned: the state's row stride and G PW are multiples of 16) are packed
+            // in registers and stored as uint4: every lane writes its own window's row, so a store instruction is 64 scattered
+            // segments whatever its width -- a quarter of the instructions (round 4 stored dword by dword: 100 per 20 x 20 window)
+            constexpr int G = (PW_ % 16 == 0) ? 1 : ((PW_ % 8 == 0) ? 2 : 4);   // rows per group: the fewest whose bytes are whole 16-byte slots
+            static_assert(PH_ % G == 0 && (G * PW_) % 16 == 0, "row groups of the state stores");
             unsigned int wn[NW];
+            wvd_load_row<NW>(src, wn);
+#pragma unroll 1
+            for (int r0 = 0; r0 < PH_; r0 += G) {
+                unsigned int grp[G * NW];
 #pragma unroll
-            for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(src + 4 * j);
-#pragma unroll 2
-            for (int r = 0; r < PH_; ++r) {
-                unsigned int w4[NW], pk[NW];
+                for (int rr = 0; rr < G; ++rr) {
+                    const int r = r0 + rr;
+                    unsigned int w4[NW], pk[NW];
 #pragma unroll
-                for (int j = 0; j < NW; ++j) w4[j] = wn[j];
-                const uint8_t* nsrc = src + (size_t)(r + 1 < PH_ ? r + 1 : r) * lw;
+                    for (int j = 0; j < NW; ++j) w4[j] = wn[j];
+                    wvd_load_row<NW>(src + (size_t)(r + 1 < PH_ ? r + 1 : r) * lw, wn);
+                    if constexpr (NW <= 5) wvd_equalise<NW>(w4, pk, lutWord, blkL4);
+                    else { wvd_equalise<NW / 2>(w4, pk, lutWord, blkL4); wvd_equalise<NW / 2>(w4 + NW / 2, pk + NW / 2, lutWord, blkL4); }
+                    unsigned int rowsq = 0;
 #pragma unroll
-                for (int j = 0; j < NW; ++j) wn[j] = wvd_load_u32(nsrc + 4 * j);
-                if constexpr (NW <= 5) wvd_equalise<NW>(w4, pk, lutWord, blkL4);
-                else { wvd_equalise<NW / 2>(w4, pk, lutWord, blkL4); wvd_equalise<NW / 2>(w4 + NW / 2, pk + NW / 2, lutWord, blkL4); }
-                unsigned int rowsq = 0;
-#pragma unroll
-                for (int j = 0; j < NW; ++j) {
-                    const unsigned int x4 = pk[j] ^ 0x80808080u;
-                    rowsq = __builtin_amdgcn_udot4(x4, x4, rowsq, false);
+                    for (int j = 0; j < NW; ++j) {
+                        const unsigned int x4 = pk[j] ^ 0x80808080u;
+                        rowsq = __builtin_amdgcn_udot4(x4, x4, rowsq, false);
+                        grp[rr * NW + j] = pk[j];
+                    }
+                    sxx = r == 0 ? (float)rowsq : sxx + (float)rowsq;
                 }
-                sxx = r == 0 ? (float)rowsq : sxx + (float)rowsq;
                 if (valid) {
+                    uint4* dst = reinterpret_cast<uint4*>(xr + r0 * PW_);
 #pragma unroll
-                    for (int j = 0; j < NW; ++j) *reinterpret_cast<unsigned int*>(xr + r * PW_ + 4 * j) = pk[j];
+                    for (int q4 = 0; q4 < G * NW / 4; ++q4) dst[q4] = make_uint4(grp[4 * q4], grp[4 * q4 + 1], grp[4 * q4 + 2], grp[4 * q4 + 3]);
                 }
             }
         }

@@ -149,8 +149,12 @@ __device__ __forceinline__ void wvb_wait8(wvb_v4i (&b)[8]) {
 // RING: operand fragments in flight per wavefront.  16 when a tile has 16 k-steps (patches of up to 512 pixels): the whole next tile is
 // requested while the current tile's levels are chained, so the contraction never waits for L2 (8: two L2 round trips per tile, 3 us
 // of a 4 us tile).  Two workgroups per CU: with a third (168 registers) the exp temporaries spilled and a level took 1 us instead of 0.27.
+// cqPer (round 5): class quarters a workgroup works through on ONE staged window tile.  1 = a unit per (tile, class quarter): the most
+// workgroups, what a short queue needs to reach all CUs.  NQ = a unit per tile: the 64 windows' pixels are staged once instead of once
+// per class quarter -- with long queues (the late-rejecting profiles hand stage B 300-700 K windows) staging was 2.5 of a unit's 5.7 us
+// in the short first phases.  Wavefronts move on to their next class without a workgroup barrier.
 template <int MAXV, int RING>
-__global__ __launch_bounds__(256, 2) void k_wvb_chain2(WvbDev mv, WvbState s, int phase, const unsigned int* countPtr) {
+__global__ __launch_bounds__(256, 2) void k_wvb_chain2(WvbDev mv, WvbState s, int phase, const unsigned int* countPtr, int cqPer) {
     constexpr int RPL = MAXV <= 8 ? 7 : 15;   // rows per level slot
     constexpr int LPT = 32 / RPL;             // level slots per tile: 4 or 2
     extern __shared__ __attribute__((aligned(16))) unsigned char wvb_lds[];
@@ -166,9 +170,12 @@ __global__ __launch_bounds__(256, 2) void k_wvb_chain2(WvbDev mv, WvbState s, in
     const int cpr = DS >> 4;   // 16-byte slots per row
     WVB_DECL(8 * phase);
     const WvbXcd X(ntiles);
-    for (int unit = X.wg; unit < X.ntl * NQ; unit += X.nwg) {
-        const int tl = unit / NQ, cq = unit - tl * NQ;   // neighbouring workgroups share the window tile (L2)
-        const int t = X.tile(tl);
+    const int NQU = (NQ + cqPer - 1) / cqPer;   // units per window tile
+    for (int unit = X.wg; unit < X.ntl * NQU; unit += X.nwg) {
+      const int tl = unit / NQU, cq0 = (unit - tl * NQU) * cqPer;   // neighbouring workgroups share the window tile (L2)
+      const int t = X.tile(tl);
+      for (int cq = cq0; cq < min(cq0 + cqPer, NQ); ++cq) {   // (wave-uniform bounds: the barriers below are reached by all or none)
+        const bool firstCq = cq == cq0;
         WVB_T(tq0);
         // Everything the unit needs from memory is requested at once -- the first tile's operand fragments, its level records, the
         // windows' pixels -- instead of three dependent round trips (pixels -> records -> the tile id in the record -> fragments):
@@ -205,8 +212,8 @@ __global__ __launch_bounds__(256, 2) void k_wvb_chain2(WvbDev mv, WvbState s, in
                 if (phase > 0) u = s.U[set][((size_t)t * NP + cls) * 64 + lane];
             }
         }
-        __syncthreads();   // the previous unit's MFMA operand reads are done
-        {
+        if (firstCq) {
+            __syncthreads();   // the previous unit's MFMA operand reads are done
             const uint4* xg = reinterpret_cast<const uint4*>(s.X[set] + (size_t)t * 64 * DS);
             const int live = (int)min(64u, n - (unsigned int)t * 64u) * cpr;   // slots of the tile's real windows (rows are contiguous)
             for (int c0 = threadIdx.x; c0 < 64 * cpr; c0 += 8 * 256) {
@@ -233,7 +240,8 @@ __global__ __launch_bounds__(256, 2) void k_wvb_chain2(WvbDev mv, WvbState s, in
 #pragma unroll
             for (int j = 0; j < LPT; ++j) Rw[((T & 1) * LPT + j) * WVB_REC_DW + lane] = rv[j];
         };
-        __syncthreads();
+        if (firstCq) __syncthreads();
+        else wave_sync();   // this wavefront's reads of its previous class's records are done before storeRecs overwrites them
         WVB_T(tq1);
         WVB_ADD(8 * phase + 0, 1);
         WVB_ADD(8 * phase + 1, tq1 - tq0);
@@ -314,10 +322,24 @@ __global__ __launch_bounds__(256, 2) void k_wvb_chain2(WvbDev mv, WvbState s, in
                 }
                 WVB_T(tq3);
                 WVB_ADD(8 * phase + 3, tq3 - tq2);
-                // ---- the tile's levels.  Everything up to the u_kernel_eval dependency is independent between them
+                // ---- the tile's levels.  Everything up to the u_kernel_eval dependency is independent between them.  A tile whose slots
+                // all belong to this phase takes the straight-line form (the four levels' chains and exps interleave); a tile that straddles a
+                // phase cut (phases [0, 2), [2, 6): half of every tile) skips its other slots -- their fp64 chain and exp were 45 % of the
+                // chain's arithmetic in the first two phases of the late-rejecting profiles
+                bool act[LPT];
+                bool allAct = true;
+#pragma unroll
+                for (int j = 0; j < LPT; ++j) {
+                    const int g = T * LPT + j;
+                    act[j] = g >= g0 && g < g1 && g <= gLast;
+                    allAct = allAct && act[j];
+                }
+                auto levels = [&](auto allTag) {
+                constexpr bool ALL = decltype(allTag)::value;
                 double part[LPT], ppv[LPT];
 #pragma unroll
                 for (int j = 0; j < LPT; ++j) {
+                    if (!ALL && !act[j]) { part[j] = 0.0; ppv[j] = 0.0; continue; }
                     const int* rc = Rt + j * WVB_REC_DW;
                     const double* valL = reinterpret_cast<const double*>(rc + 8);
                     // the reference's sums in its order (WvmClassifier.cpp:277-309); grey values the filter does not have add an exact +0
@@ -339,13 +361,11 @@ __global__ __launch_bounds__(256, 2) void k_wvb_chain2(WvbDev mv, WvbState s, in
                 }
                 // ---- the serial part: u_kernel_eval of the class from level to level (WvmClassifier.cpp:310-316)
                 double arg[LPT];
-                bool act[LPT];
 #pragma unroll
                 for (int j = 0; j < LPT; ++j) {
-                    const int g = T * LPT + j;
-                    act[j] = g >= g0 && g < g1 && g <= gLast;
+                    if (!ALL && !act[j]) { arg[j] = 0.0; continue; }
                     double sum_xp = part[j] + (double)u;
-                    if (act[j]) u = (float)sum_xp;
+                    u = (float)sum_xp;
                     double norm = (double)sxx;
                     norm = norm - 2 * sum_xp;
                     norm = norm + ppv[j];
@@ -354,9 +374,12 @@ __global__ __launch_bounds__(256, 2) void k_wvb_chain2(WvbDev mv, WvbState s, in
                 // ---- the kernel values: independent again
 #pragma unroll
                 for (int j = 0; j < LPT; ++j) {
+                    if (!ALL && !act[j]) continue;
                     kst[j] = (float)exp(arg[j]);
-                    kmask |= act[j] ? 1u << j : 0u;
+                    kmask |= 1u << j;
                 }
+                };
+                if (allAct) levels(std::true_type{}); else levels(std::false_type{});
                 kT = T;
                 WVB_T(tq4);
                 WVB_ADD(8 * phase + 4, tq4 - tq3);
@@ -372,17 +395,22 @@ __global__ __launch_bounds__(256, 2) void k_wvb_chain2(WvbDev mv, WvbState s, in
         }
         WVB_T(tq7);
         WVB_ADD(8 * phase + 5, tq7 - tq0);
+      }
     }
     WVB_FLUSH;
 }
 
 // res_k = -bias + sum_{p <= k} w[k][p] K_p for the rows of the phase and the cascade's exit rule on them (WvmClassifier.cpp:139-141).
-// A workgroup takes one block of 8 consecutive rows for four tiles of 64 windows (one per wavefront, lane == window): the block's
-// weights are staged in LDS once and read as broadcasts, every K_p load (256 B, coalesced) feeds 8 multiply-adds; the terms keep the
+// A workgroup takes one block of RB consecutive rows for four tiles of 64 windows (one per wavefront, lane == window): the block's
+// weights are staged in LDS once and read as broadcasts, every K_p load (256 B, coalesced) feeds RB multiply-adds; the terms keep the
 // reference's order.  The first failed row of a window inside the block goes into exitKey by a 64-bit minimum (level << 32 | fp32 bits).
+// RB = 8: the most units, what a short queue needs.  RB = 32 (round 5, long queues): a tile's K history is streamed once per 32 rows
+// instead of once per 8 -- the first phases of the late-rejecting profiles (28 / 56 rows, 300-700 K windows) read it 4-7 times and
+// spent their time in those loads and in the per-unit weight staging.
 constexpr int WVB_MAXF = 64 * WVM_PJ;
+template <int RB>
 __global__ __launch_bounds__(256) void k_wvb_sums(WvbDev mv, WvbState s, int phase, const unsigned int* countPtr) {
-    __shared__ __attribute__((aligned(16))) float wl[(WVB_MAXF + 8) * 8];
+    __shared__ __attribute__((aligned(16))) float wl[(WVB_MAXF + RB) * RB];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned int n = wvb_count(countPtr, s);
@@ -391,17 +419,18 @@ __global__ __launch_bounds__(256) void k_wvb_sums(WvbDev mv, WvbState s, int pha
     const int nquads = (X.ntl + 3) >> 2;
     const int NU = mv.numUsed, Fr = mv.Fr;
     const int k0 = min(mv.phaseGen[phase] * mv.numPer, NU), k1 = min(mv.phaseGen[phase + 1] * mv.numPer, NU);
-    const int nrb = (k1 - k0 + 7) >> 3;
+    const int nrb = (k1 - k0 + RB - 1) / RB;
     const int set = phase & 1;
     constexpr size_t ks = 64;   // K[tile][level][64 windows]: a tile's history is one contiguous block
     WVB_DECL(24 + 4 * phase);
     for (int unit = X.wg; unit < nquads * nrb; unit += X.nwg) {
         const int rb = nrb - 1 - unit / nquads, q = unit - (unit / nquads) * nquads;   // the longest rows first
-        const int kb = k0 + rb * 8;
-        const int kend = min(kb + 8, k1);   // terms p < kend
+        const int kb = k0 + rb * RB;
+        const int kend = min(kb + RB, k1);   // terms p < kend
         WVB_T(ts0);
         __syncthreads();   // the previous unit's weight reads are done
-        for (int i = threadIdx.x; i < kend * 8; i += 256) wl[i] = mv.wR[(size_t)(i >> 3) * Fr + kb + (i & 7)];
+        // wl[p][j] = w[kb + j][p]; a row of wR has Fr >= F + 8 entries: columns past it (rows j the block does not have) are clamped, never used
+        for (int i = threadIdx.x; i < kend * RB; i += 256) wl[i] = mv.wR[(size_t)(i / RB) * Fr + min(kb + (i % RB), Fr - 1)];
         __syncthreads();
         WVB_T(ts1);
         WVB_ADD(24 + 4 * phase + 0, 1);
@@ -411,9 +440,9 @@ __global__ __launch_bounds__(256) void k_wvb_sums(WvbDev mv, WvbState s, int pha
         const unsigned int pos = (unsigned int)t * 64u + (unsigned int)lane;
         const bool valid = pos < n;
         const float* Kp = s.K[set] + (size_t)t * NU * 64 + lane;
-        float acc[8];
+        float acc[RB];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = mv.negBias;
+        for (int j = 0; j < RB; ++j) acc[j] = mv.negBias;
         // terms every row of the block takes (p < kb): groups of 16 K loads, the next group in flight while one is consumed
         auto loadK = [&](float (&kv)[16], int p0) {
 #pragma unroll
@@ -422,10 +451,16 @@ __global__ __launch_bounds__(256) void k_wvb_sums(WvbDev mv, WvbState s, int pha
         auto useK = [&](const float (&kv)[16], int p0) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float4 wa = *reinterpret_cast<const float4*>(wl + (p0 + i) * 8), wb = *reinterpret_cast<const float4*>(wl + (p0 + i) * 8 + 4);
-                const float w8[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+                const float4* w4 = reinterpret_cast<const float4*>(wl + (p0 + i) * RB);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const float tt = w8[j] * kv[i]; acc[j] = acc[j] + tt; }
+                for (int j4 = 0; j4 < RB / 4; ++j4) {
+                    const float4 w = w4[j4];
+                    float tt;
+                    tt = w.x * kv[i]; acc[4 * j4] = acc[4 * j4] + tt;
+                    tt = w.y * kv[i]; acc[4 * j4 + 1] = acc[4 * j4 + 1] + tt;
+                    tt = w.z * kv[i]; acc[4 * j4 + 2] = acc[4 * j4 + 2] + tt;
+                    tt = w.w * kv[i]; acc[4 * j4 + 3] = acc[4 * j4 + 3] + tt;
+                }
             }
         };
         const int ngroups = kb >> 4;
@@ -449,23 +484,24 @@ __global__ __launch_bounds__(256) void k_wvb_sums(WvbDev mv, WvbState s, int pha
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 if (p + i < kb) {
-                    const float* w0 = wl + (p + i) * 8;
+                    const float* w0 = wl + (p + i) * RB;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { const float tt = w0[j] * kv[i]; acc[j] = acc[j] + tt; }
+                    for (int j = 0; j < RB; ++j) { const float tt = w0[j] * kv[i]; acc[j] = acc[j] + tt; }
                 }
             }
         }
         // the diagonal block: row kb + j ends with term p = kb + j
-        {
+#pragma unroll
+        for (int j0 = 0; j0 < RB; j0 += 8) {
             float kv[8];
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) kv[jj] = Kp[(size_t)min(kb + jj, k1 - 1) * ks];
+            for (int jj = 0; jj < 8; ++jj) kv[jj] = Kp[(size_t)min(kb + j0 + jj, k1 - 1) * ks];
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                if (kb + jj < k1) {
-                    const float* w0 = wl + (kb + jj) * 8;
+                if (kb + j0 + jj < k1) {
+                    const float* w0 = wl + (kb + j0 + jj) * RB;
 #pragma unroll
-                    for (int j = jj; j < 8; ++j) { const float tt = w0[j] * kv[jj]; acc[j] = acc[j] + tt; }
+                    for (int j = j0 + jj; j < RB; ++j) { const float tt = w0[j] * kv[jj]; acc[j] = acc[j] + tt; }
                 }
             }
         }
@@ -474,7 +510,7 @@ __global__ __launch_bounds__(256) void k_wvb_sums(WvbDev mv, WvbState s, int pha
             int fj = -1;
             float fv = 0.f;
 #pragma unroll
-            for (int j = 7; j >= 0; --j) {
+            for (int j = RB - 1; j >= 0; --j) {
                 const int k = kb + j;
                 if (k < k1 && (!(acc[j] >= mv.thr[k]) || k + 1 == NU)) { fj = k; fv = acc[j]; }
             }
@@ -714,7 +750,7 @@ static void launch_stageb(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* m,
     const int ldsBytes = 64 * mv.dstride + 4 * (2 * lpt * WVB_REC_DW) * (int)sizeof(int);
     const bool v8 = mv.maxCnt <= 8, r16 = mv.KSP == 16;
     const int perCuC = 2;   // k_wvb_chain2: __launch_bounds__(256, 2)
-    void (*chainK)(WvbDev, WvbState, int, const unsigned int*) =
+    void (*chainK)(WvbDev, WvbState, int, const unsigned int*, int) =
         v8 ? (r16 ? k_wvb_chain2<8, 16> : k_wvb_chain2<8, 8>) : (r16 ? k_wvb_chain2<WVM_MAX_VALS, 16> : k_wvb_chain2<WVM_MAX_VALS, 8>);
     if (ldsBytes > 64 * 1024) {   // run-time-sized patches of more than ~900 pixels: above the default dynamic LDS limit
         static uint64_t ldsDone[4] = {};
@@ -747,15 +783,35 @@ static void launch_stageb(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* m,
         }
     }
     const int NQ = (mv.numPer + 3) / 4;
+    const bool timeChain = ctx->kernel_timing && ctx->kernel_timing_mode == 3 && st == ctx->stream && mv.nphase <= 4;
+    ctx->evxN = timeChain ? mv.nphase : 0;
+    m->sbLastN = mv.nphase;
+    for (int i = 0; i <= mv.nphase; ++i) m->sbLastGen[i] = mv.phaseGen[i];
     for (int ph = 0; ph < mv.nphase; ++ph) {
         const unsigned int* countPtr = ph == 0 ? o.deep_count : s.cnt + ph;
         const int k0 = std::min(mv.phaseGen[ph] * mv.numPer, mv.numUsed), k1 = std::min(mv.phaseGen[ph + 1] * mv.numPer, mv.numUsed);
         const int nrb = (k1 - k0 + 7) / 8;
         const int64_t tiles = (expect(ph) + 63) / 64;
-        const int gridC = wvb_grid8(std::min<int64_t>(tiles * NQ, (int64_t)cus * perCuC));
-        hipLaunchKernelGGL(chainK, dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr);
-        const int gridH = wvb_grid8(std::min<int64_t>((tiles + 3) / 4 * nrb, (int64_t)cus * 8));
-        hipLaunchKernelGGL(k_wvb_sums, dim3(gridH), dim3(256), 0, st, mv, s, ph, countPtr);
+        // a unit per tile (all class quarters on one staged tile) once every resident workgroup gets at least two tiles that way
+        static const int cqMode = [] { const char* e = getenv("FD_WVB_CQ"); return e ? atoi(e) : 0; }();   // A/B: 1 = always per class quarter, 2 = always per tile
+        const int cqPer = (cqMode == 2 || (cqMode != 1 && tiles >= (int64_t)2 * cus * perCuC)) ? NQ : 1;
+        const int gridC = wvb_grid8(std::min<int64_t>(tiles * ((NQ + cqPer - 1) / cqPer), (int64_t)cus * perCuC));
+        if (timeChain) {   // bench hook (fd_ctx_set_kernel_timing(3)): the chain kernel of every phase between its own pair of events
+            for (int e = 2 * ph; e < 2 * ph + 2; ++e)
+                if (!ctx->evx[e]) HIP_CHECK(hipEventCreate(&ctx->evx[e]));
+            HIP_CHECK(hipEventRecord(ctx->evx[2 * ph], st));
+        }
+        hipLaunchKernelGGL(chainK, dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr, cqPer);
+        if (timeChain) HIP_CHECK(hipEventRecord(ctx->evx[2 * ph + 1], st));
+        // 16 rows per block once the queue fills every resident workgroup that way (A/B: FD_WVB_RB = 8 / 16 / 32)
+        static const int rbMode = [] { const char* e = getenv("FD_WVB_RB"); return e ? atoi(e) : 0; }();
+        const int64_t quads = (tiles + 3) / 4;
+        const int rb = (rbMode == 8 || rbMode == 16 || rbMode == 32) ? rbMode : (quads * ((k1 - k0 + 15) / 16) >= (int64_t)cus * 4 ? 16 : 8);
+        const int nrbX = (k1 - k0 + rb - 1) / rb;
+        (void)nrb;
+        if (rb == 32) hipLaunchKernelGGL(k_wvb_sums<32>, dim3(wvb_grid8(std::min<int64_t>(quads * nrbX, (int64_t)cus * 2))), dim3(256), 0, st, mv, s, ph, countPtr);
+        else if (rb == 16) hipLaunchKernelGGL(k_wvb_sums<16>, dim3(wvb_grid8(std::min<int64_t>(quads * nrbX, (int64_t)cus * 4))), dim3(256), 0, st, mv, s, ph, countPtr);
+        else hipLaunchKernelGGL(k_wvb_sums<8>, dim3(wvb_grid8(std::min<int64_t>(quads * nrbX, (int64_t)cus * 8))), dim3(256), 0, st, mv, s, ph, countPtr);
         const int gridE = wvb_grid8(std::min<int64_t>(tiles, (int64_t)cus * 4));
         hipLaunchKernelGGL(k_wvb_exit, dim3(gridE), dim3(256), 0, st, mv, s, o, ph, countPtr, s.cnt + ph + 1);
     }

@@ -101,6 +101,13 @@ def make_frames_varied(n, width=640, height=480, seed=20260927, scene_len=32, nb
     return frames, np.asarray(busy)
 
 
+def bgr2gray_np(img):
+    """cv::cvtColor(BGR2GRAY) on 8-bit images: (B * 1868 + G * 9617 + R * 4899 + 8192) >> 14 (SURVEY.md App. B); used to draw calibration
+    patches for the synthetic models (bench.py must not need the oracle to build them)"""
+    a = np.asarray(img, np.uint8).astype(np.uint32)
+    return ((a[..., 0] * 1868 + a[..., 1] * 9617 + a[..., 2] * 4899 + 8192) >> 14).astype(np.uint8)
+
+
 def histeq64_np(patches):
     """Vectorised HistEq64 used for threshold calibration / SV synthesis; tests/test_oracle_golden.py also checks the C++ oracle against it."""
     p = np.asarray(patches, np.uint8)

@@ -11,13 +11,17 @@ extern "C" {
 
 /* enable != 0: the detect entry points (fd_detect_five_stage, fd_detect_wvm, fd_detect_hog_svm[_begin/_end], fd_sdm_fit_batch)
  * bracket their dominant kernel(s) with two hipEvents on the context's stream. */
-int fd_ctx_set_kernel_timing(fd_ctx* ctx, int enable);   /* enable == 2: WVM cascades bracket the dense pre-filter kernel only */
+int fd_ctx_set_kernel_timing(fd_ctx* ctx, int enable);   /* enable == 2: WVM cascades bracket the dense pre-filter kernel only;
+                                                          * enable == 3: every k_wvb_chain2 launch of stage B (one per phase), summed */
 /* duration (ms) between those events for the last timed call on this context and the name of the bracketed kernel(s) */
 int fd_last_kernel_ms(fd_ctx* ctx, const char** kernel_name, float* ms);
 
 /* Windows the last finished cascade run of this handle handed to stage B (the pre-filter's queue; all frames of a multi-frame call
  * together); -1 before the first run.  bench.py reports the spread over the calls of a run. */
 int64_t fd_wvm_last_queue_length(const fd_wvm* wvm);
+/* The stage-B plan of the last finished run: out[0] = phases, then per phase {first generation, end generation, windows alive at its
+ * start} (10 int64 at most: 1 + 3 * 3); -1 where unknown.  bench.py derives the chain kernel's algorithmic work from it. */
+int fd_wvm_last_stage_b_plan(const fd_wvm* wvm, int64_t* out);
 /* How the last finished five-stage run of this handle did its overlap elimination: -1 on the host (no device tail was queued), 0 on
  * the device (csrc/fs_tail.hpp), > 0: the device kernel gave up and the host redid it -- 1 the order of the positives could not be
  * proven to be the reference's (tied or saturated probabilities), 2 more positives in a frame than the kernel holds, 4 window ids

@@ -158,3 +158,20 @@ def test_native_record_packing_equals_the_python_twin():
     for world in (1, 2, 4, 8):
         for r in range(world):
             assert parallel.shard_indices(37, r, world) == [i for i in range(37) if capi.lib().fd_dist_owner(i, world) == r]
+
+
+def test_config5_image_partition():
+    """bench.py's config-5 job: image j belongs to rank j mod N (fd_dist_owner), a step = the job's images [256 i, 256 (i + 1)); over
+    the ranks every image is fed exactly once, in its step, whatever N"""
+    import bench
+    for total in (10000, 24, 257, 1):
+        steps = (total + 255) // 256
+        for world in (1, 2, 3, 8):
+            seen = []
+            for i in range(steps):
+                per_rank = [bench.Config5.step_images(i, r, world, total) for r in range(world)]
+                for r, ids in enumerate(per_rank):
+                    assert all(j % world == r for j in ids)
+                    assert all(256 * i <= j < min(256 * (i + 1), total) for j in ids)
+                seen.extend(np.concatenate(per_rank).tolist())
+            assert sorted(seen) == list(range(total))

@@ -663,8 +663,36 @@ def test_bench_two_ranks_gather_through_fd_dist(tmp_path):
     assert rec["records_gathered"] == rec["detections_delivered"] > 0 and not rec["records_truncated"]
 
 
+def test_bench_config5_one_and_two_ranks(tmp_path):
+    """BASELINE config 5 as a bench workload (VERDICT r04 task 1b), scaled down to 24 images: `bench.py --workload config5` on one rank,
+    and on two ranks the way the driver launches it (both on device 0, gloo + the librccl stand-in).  The job is fixed -- every image
+    is generated from (seed, image index) -- so both runs deliver the same number of detections, rank 0 receives all of them through
+    fd_dist_gather_records, and the record says "strong"."""
+    import json
+    import subprocess
+    import sys
+    if not os.path.exists(STUB_RCCL):
+        pytest.fail("tests/stub_rccl/librccl_stub.so not built")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tail = [os.path.join(root, "bench.py"), "--workload", "config5", "--images", "24", "--also", "none", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-probe"]
+    r1 = subprocess.run([sys.executable] + tail, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    rec1 = json.loads(r1.stdout.strip().splitlines()[-1])
+    assert rec1["n_gpus"] == 1 and rec1["scaling"] == "strong" and rec1["steps"] == 1 and rec1["config"]["images"] == 24
+    assert rec1["detections_delivered"] > 0 and "config 5" in rec1["config"]["workload"]
+    env = dict(os.environ, FD_DIST_ONE_DEVICE="1", FD_BENCH_DIST_BACKEND="gloo", FD_RCCL_LIB=STUB_RCCL)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29573"] + tail + ["--gpus", "2"]
+    r2 = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    rec2 = json.loads(r2.stdout.strip().splitlines()[-1])
+    assert rec2["n_gpus"] == 2 and rec2["scaling"] == "strong" and rec2["steps"] == 1
+    assert rec2["detections_delivered"] == rec1["detections_delivered"]          # the same 24 images, whatever the sharding
+    assert rec2["records_gathered"] == rec2["detections_delivered"] and not rec2["records_truncated"]
+    assert abs(rec2["value"] * rec2["ms_per_step"] - rec1["value"] * rec1["ms_per_step"]) < 1e-6 * rec1["value"] * rec1["ms_per_step"]   # same windows
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload", ["cascade", "hog_svm", "ffp15", "sdm"])
+@pytest.mark.parametrize("workload", ["cascade", "cascade_group", "hog_svm", "ffp15", "sdm"])
 def test_bench_line_of_every_workload_with_its_probe(workload):
     """One short run of bench.py per workload WITH its kernel probe and roofline records (the multi-rank test above runs without them):
     the JSON line parses and carries the contract's fields.  (A NameError in one workload's probe once left the driver's default run
@@ -674,7 +702,7 @@ def test_bench_line_of_every_workload_with_its_probe(workload):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", workload, "--also", "none", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
-    if workload == "cascade":
+    if workload.startswith("cascade"):
         cmd += ["--frames-per-step", "128"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -683,3 +711,7 @@ def test_bench_line_of_every_workload_with_its_probe(workload):
         assert key in rec, key
     assert rec["value"] > 0 and rec["roofline"]["bound"] in ("hbm", "mfma") and 0 < rec["roofline"]["frac"] <= 1.0
     assert rec["roofline"]["achieved"] > 0 and rec["roofline"]["peak"] > 0 and "workload" in rec["config"]
+    if workload == "cascade_group":   # VERDICT r04 task 1c: the heavy-queue profiles name the kernel that dominates THEM
+        assert rec["roofline"]["kernel"].startswith("k_wvb_chain2") and rec["roofline"]["kernel_ms"] > 0.25 * rec["roofline"]["cascade_kernels_ms"]
+    if workload == "ffp15":
+        assert "32 distinct frames" in rec["config"]["content"]
