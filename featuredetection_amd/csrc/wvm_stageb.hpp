@@ -806,7 +806,9 @@ static void launch_stageb(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* m,
         // 16 rows per block once the queue fills every resident workgroup that way (A/B: FD_WVB_RB = 8 / 16 / 32)
         static const int rbMode = [] { const char* e = getenv("FD_WVB_RB"); return e ? atoi(e) : 0; }();
         const int64_t quads = (tiles + 3) / 4;
-        const int rb = (rbMode == 8 || rbMode == 16 || rbMode == 32) ? rbMode : (quads * ((k1 - k0 + 15) / 16) >= (int64_t)cus * 4 ? 16 : 8);
+        // (measured, cascade_group: 16-row blocks everywhere 513 vs 525 Mpatches/s, 32-row blocks 445: fewer re-reads of the K history, but
+        // half / a quarter of the wavefronts to hide them.)  116 / 132: the larger block only for phases that start at level 64 or deeper
+        const int rb = (rbMode == 8 || rbMode == 16 || rbMode == 32) ? rbMode : ((rbMode == 116 || rbMode == 132) && k0 >= 64 && quads * ((k1 - k0 + 15) / 16) >= (int64_t)cus * 4 ? rbMode - 100 : 8);
         const int nrbX = (k1 - k0 + rb - 1) / rb;
         (void)nrb;
         if (rb == 32) hipLaunchKernelGGL(k_wvb_sums<32>, dim3(wvb_grid8(std::min<int64_t>(quads * nrbX, (int64_t)cus * 2))), dim3(256), 0, st, mv, s, ph, countPtr);
