@@ -707,6 +707,7 @@ class Ffp15(Workload):
         self.FP = max(1, frames_per_step)
         self.dframes, content_note = self.make_content(W, H)
         self.order, self.nfed, self.order_rng = np.arange(len(self.dframes)), 0, np.random.default_rng(78 + env.rank)
+        self.stage_sum, self.stage_frames = np.zeros(4, np.int64), 0
         self.models = ffp15_models()
         ctx = env.ctx
         # two frames in flight (FD_BENCH_FFP_SLOTS), each with its own pyramids and classifier handles: frame f + 1's pyramids and
@@ -733,7 +734,18 @@ class Ffp15(Workload):
 
     def _collect(self, sl):
         res, sl["run"] = sl["run"].end(), None
+        self.stage_sum += np.sum([np.asarray(st_, np.int64)[:4] for _, st_ in res], axis=0)
+        self.stage_frames += 1
         return [(sl["img"], di, d_) for di, (d_, _) in enumerate(res)]
+
+    def extra_record(self):
+        """what the host stages of a frame see: WVM positives, survivors of the overlap elimination, SVM positives, detections -- summed
+        over the 15 detectors, mean per frame (the host stages scale with the first number)"""
+        if not self.stage_frames:
+            return {}
+        m = self.stage_sum / self.stage_frames
+        return dict(stage_counts_per_frame=dict(wvm_positives=float(m[0]), after_overlap_elimination=float(m[1]), svm_positives=float(m[2]), detections=float(m[3]),
+                                                frames=int(self.stage_frames)))
 
     def _feed(self, fr, image_id):
         """queues one frame (device tensor) through the 15 detectors; returns the records of the call that had to be collected first"""
@@ -1077,6 +1089,8 @@ def measure(wl, env, steps, warmup, gather_every, want_cpu):
     barrier()
     if hasattr(wl, "qlens"):
         wl.qlens = []
+    if hasattr(wl, "stage_frames"):
+        wl.stage_sum, wl.stage_frames = np.zeros(4, np.int64), 0
     t0 = time.perf_counter()
     units, ndet, pending, gathered = 0, 0, [], 0
     for i in range(steps):
@@ -1187,7 +1201,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # N ranks share one host: at most 8 host threads per rank (this thread + the library's queue threads + its batch workers)
         os.environ.setdefault("FD_ASYNC_THREADS", "2")
-        os.environ.setdefault("FD_BATCH_THREADS", "4")
+        os.environ.setdefault("FD_BATCH_THREADS", "8")
         os.environ.setdefault("FD_BENCH_SDM_THREADS", "1")
         backend = os.environ.get("FD_BENCH_DIST_BACKEND", "nccl")
         if backend == "nccl":

@@ -47,19 +47,6 @@ struct DownJobs {
     int tile0[MAXJ + 1];   // k_pyrdown_tiled: first tile of every job in the launch's flat tile list (exact grids: no empty workgroups)
     DownJob j[MAXJ];
 };
-// k_pyrdown_chain: up to three consecutive pyrDown generations of one chain in one launch (round 5)
-struct ChainJob {
-    int w0, h0;          // size of the job's source layer (level 0)
-    uint32_t off[4];     // arena offsets of the source layer and of the D destination layers (levels 1 .. D)
-    int D;               // pyrDown steps: 1 .. 3
-    int T;               // side of a tile at level D (16 / 32 / 64 for D = 3 / 2 / 1: the source box is at most 149 pixels wide)
-    int tilesX;
-};
-struct ChainJobs {
-    int n;
-    int tile0[MAXJ + 1];
-    ChainJob j[MAXJ];
-};
 struct FilterJob {
     int w, h;
     uint32_t src_off, dst_off;
@@ -609,109 +596,6 @@ __global__ __launch_bounds__(256) void k_pyrdown_tiled(uint8_t* __restrict__ are
     }
 }
 
-// ---- the deeper generations of a pyrDown chain in ONE kernel (ImagePyramid.cpp:183-192: `pyrDown(previous, current)` repeated) -----
-// Round 4 launched k_pyrdown_tiled once per generation: three or four latency-bound launches per pyramid update that each held the CUs
-// at a few per cent and re-read what the previous one had just written (counters: 3.6x the algorithmic bytes).  Here a workgroup owns a
-// T x T tile of the job's DEEPEST level and computes everything that tile depends on in LDS: the box of level l - 1 a box of level l
-// needs is [2 lo - 2, 2 hi + 1) (5 taps, stride 2), so a 16 x 16 tile three generations down reads a 149 x 149 box of the source layer
-// (35 % more source bytes than the layer has: the halo is recomputed instead of exchanged -- no grid barrier, no launch).
-// BORDER_REFLECT_101 without a test in the inner loop: a level's box is materialised over its UNCLAMPED coordinates, the entry at
-// coordinate c holding the level's pixel at reflect(c) -- exactly what cv::pyrDown's border extrapolation reads there -- so every
-// output, at the border or not, takes its 5 x 5 taps at 2 x - 2 .. 2 x + 2 relative to the box origin (k_pyrdown_tiled's arithmetic:
-// [1 4 6 4] . (s0..s3) + s4 per row as one byte dot product, then the column, (v + 128) >> 8).  A pixel of an intermediate level is
-// written to memory by the tile that owns it (coordinate >> (D - l) inside the tile), so every layer is written exactly once.
-constexpr int PC_P0 = 152, PC_N0 = 149, PC_P1 = 76, PC_N1 = 73, PC_P2 = 36, PC_N2 = 35;
-__global__ __launch_bounds__(256) void k_pyrdown_chain(uint8_t* __restrict__ arena, ChainJobs jobs, size_t imageStride) {
-    __shared__ __attribute__((aligned(16))) uint8_t V0[PC_P0 * PC_N0 + 8];
-    __shared__ __attribute__((aligned(16))) uint8_t V1[PC_P1 * PC_N1 + 8];
-    __shared__ __attribute__((aligned(16))) uint8_t V2[PC_P2 * PC_N2 + 8];
-    arena += (size_t)blockIdx.z * imageStride;   // blockIdx.z = frame of a multi-frame pyramid
-    const int tid = threadIdx.x;
-    for (int g = blockIdx.x; g < jobs.tile0[jobs.n]; g += gridDim.x) {
-        int ji = 0;
-        while (ji + 1 < jobs.n && g >= jobs.tile0[ji + 1]) ++ji;
-        const ChainJob jb = jobs.j[ji];
-        const int t = g - jobs.tile0[ji];
-        const int D = jb.D, T = jb.T;
-        const int ty = t / jb.tilesX, tx = t - ty * jb.tilesX;
-        int w[4], h[4], lox[4], hix[4], loy[4], hiy[4];
-        w[0] = jb.w0; h[0] = jb.h0;
-#pragma unroll
-        for (int l = 1; l < 4; ++l) { w[l] = (w[l - 1] + 1) >> 1; h[l] = (h[l - 1] + 1) >> 1; }
-#pragma unroll
-        for (int l = 3; l >= 1; --l) {
-            if (l > D) continue;
-            if (l == D) { lox[l] = tx * T; hix[l] = min(lox[l] + T, w[l]); loy[l] = ty * T; hiy[l] = min(loy[l] + T, h[l]); }
-            lox[l - 1] = 2 * lox[l] - 2; hix[l - 1] = 2 * hix[l] + 1;
-            loy[l - 1] = 2 * loy[l] - 2; hiy[l - 1] = 2 * hiy[l] + 1;
-        }
-        __syncthreads();   // the previous tile's readers are done
-        {   // ---- level 0: the source box, dword by dword; only dwords that hang over the layer's left / right edge are built from bytes
-            const uint8_t* src = arena + jb.off[0];
-            const int nx = hix[0] - lox[0], ny = hiy[0] - loy[0], nd = (nx + 3) >> 2;
-            const float inv = 1.0f / (float)nd;
-            const int sw = w[0], sh = h[0];
-            for (int i = tid; i < nd * ny; i += 256) {
-                const int r = (int)(((float)i + 0.5f) * inv), dq = i - r * nd;   // i / nd, exact for i < 2^15 (checked exhaustively)
-                const int xs = lox[0] + 4 * dq;
-                const uint8_t* row = src + (uint32_t)(reflect_cf(loy[0] + r, sh) * sw);
-                uint32_t v;
-                if (xs >= 0 && xs + 3 < sw) v = ld_u32_unaligned(row + xs);
-                else {
-                    v = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) v |= (uint32_t)row[reflect_cf(xs + b, sw)] << (8 * b);
-                }
-                *reinterpret_cast<uint32_t*>(&V0[r * PC_P0 + 4 * dq]) = v;
-            }
-        }
-        __syncthreads();
-        // one pyrDown output from a materialised box: base = top-left tap
-        auto pd = [](const uint8_t* B, int pitch) {
-            int hh[5];
-#pragma unroll
-            for (int r = 0; r < 5; ++r) {
-                const uint8_t* S = B + r * pitch;
-                const uint32_t p01 = *reinterpret_cast<const uint16_t*>(S), p23 = *reinterpret_cast<const uint16_t*>(S + 2);
-                hh[r] = (int)__builtin_amdgcn_udot4(p01 | (p23 << 16), 0x04060401u, (uint32_t)S[4], false);
-            }
-            const int v = hh[2] * 6 + (hh[1] + hh[3]) * 4 + hh[0] + hh[4];
-            return (uint8_t)((v + 128) >> 8);
-        };
-        // level l (1 <= l <= D) from the box of level l - 1.  Intermediate levels: every coordinate of the unclamped box (entry = the
-        // pixel at the reflected coordinate), stored to LDS, and to memory where the coordinate is a pixel this tile owns.  Level D: the
-        // tile's own pixels, to memory only.
-        auto level = [&](int l, const uint8_t* Vs, int ps, uint8_t* Vd, int pd_) {
-            const int nx = hix[l] - lox[l], ny = hiy[l] - loy[l];
-            const float inv = 1.0f / (float)nx;
-            const int wl = w[l], hl = h[l];
-            const int rx0 = max(lox[l], 0), rx1 = min(hix[l], wl) - 1, ry0 = max(loy[l], 0), ry1 = min(hiy[l], hl) - 1;
-            const int sh_ = D - l;
-            const int ox0 = (tx * T) << sh_, ox1 = ((tx + 1) * T) << sh_, oy0 = (ty * T) << sh_, oy1 = ((ty + 1) * T) << sh_;
-            uint8_t* dst = arena + jb.off[l];
-            for (int i = tid; i < nx * ny; i += 256) {
-                const int iy = (int)(((float)i + 0.5f) * inv), ix = i - iy * nx;
-                const int cx = lox[l] + ix, cy = loy[l] + iy;
-                const int rx = min(max(reflect_cf(cx, wl), rx0), rx1), ry = min(max(reflect_cf(cy, hl), ry0), ry1);
-                const uint8_t v = pd(Vs + (2 * ry - 2 - loy[l - 1]) * ps + (2 * rx - 2 - lox[l - 1]), ps);
-                if (Vd) Vd[iy * pd_ + ix] = v;
-                if (cx >= ox0 && cx < min(ox1, wl) && cy >= oy0 && cy < min(oy1, hl)) dst[(uint32_t)(cy * wl) + cx] = v;
-            }
-        };
-        if (D == 1) level(1, V0, PC_P0, nullptr, 0);
-        else {
-            level(1, V0, PC_P0, V1, PC_P1);
-            __syncthreads();
-            if (D == 2) level(2, V1, PC_P1, nullptr, 0);
-            else {
-                level(2, V1, PC_P1, V2, PC_P2);
-                __syncthreads();
-                level(3, V2, PC_P2, nullptr, 0);
-            }
-        }
-    }
-}
-
 // cv::Sobel derivatives of GradientFilter (GradientFilter.cpp:16-59; taps of getDerivKernels, see oracle/orc_image.cpp): ksize 1, 3
 // take the short forms; 5, 7 and CV_SCHARR (-1) the separable sums.  Returns the scale 1 / 2^(2 ksize - 3) (1/2, 1/32 for ksize 1 /
 // Scharr).  Everything is an exact integer; 127 + scale * g is exact in float.
@@ -1092,6 +976,12 @@ void build_layout(fd_pyramid* p, int W, int H) {
 int grid_for(int npix) { return std::max(1, std::min(1024, (npix + 255) / 256)); }
 int tile_grid_for(int ntiles) { return std::max(1, std::min(1024, ntiles)); }
 
+// (Measured and dropped in round 5: single-image updates replayed as a hipGraph -- captured with hipStreamBeginCapture around the launch
+// code below on the second update with the same layout, the image address patched into the k_bgr2gray node with
+// hipGraphExecKernelNodeSetParams.  Bit-exact and the call returned after 10 instead of 18 us, but a blocking 640x480 frame took
+// 153.5 us p50 against 146 with plain launches (ROCm 7.2: the graph's first node starts later than a plain kernel would), and the
+// 15-detector batch 5723 against 5871 Mpatches/s.  The rocprofv3 timeline that motivated it: k_bgr2gray 3.3 + k_resize_down 5.9 + 4 x
+// k_pyrdown_tiled ~4.5 us = 27 us of kernels spread over 48 us, the host's ~3.5 us per launch between them.)
 void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, int is_device, hipStream_t st, const uint8_t* const* frames = nullptr) {
     if (!image && !frames) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_update: image is NULL");
     if (p->nimg > 1 && !frames) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_pyramid_update: the pyramid holds %d frames, use fd_pyramid_update_frames", p->nimg);
@@ -1103,31 +993,8 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
     const size_t npix = (size_t)W * H;
     const int NI = frames ? p->nimg : 1;
     const size_t IS = p->image_stride;
-    if (frames) {   // one launch converts / copies all frames into their arenas
-        FramePtrs fp;
-        if (!is_device) {
-            p->input.reserve(npix * ch * (size_t)NI);
-            for (int f = 0; f < NI; ++f) {
-                HIP_CHECK(hipMemcpyAsync(p->input.as<uint8_t>() + (size_t)f * npix * ch, frames[f], npix * ch, hipMemcpyHostToDevice, st));
-                fp.p[f] = p->input.as<uint8_t>() + (size_t)f * npix * ch;
-            }
-        } else {
-            for (int f = 0; f < NI; ++f) fp.p[f] = frames[f];
-        }
-        hipLaunchKernelGGL(k_frames_to_gray, dim3(grid_for((int)(npix / 16 + 1)), NI), dim3(256), 0, st, fp, arena + p->gray_full_off, IS, (int)npix, ch);   // four quads per thread
-    } else {
-        const uint8_t* dimg = image;
-        if (!is_device) {
-            p->input.reserve(npix * ch);
-            HIP_CHECK(hipMemcpyAsync(p->input.p, image, npix * ch, hipMemcpyHostToDevice, st));
-            dimg = p->input.as<uint8_t>();
-        }
-        if (ch == 3) {
-            hipLaunchKernelGGL(k_bgr2gray, dim3(grid_for((int)npix)), dim3(256), 0, st, dimg, arena + p->gray_full_off, (int)npix);
-        } else {
-            HIP_CHECK(hipMemcpyAsync(arena + p->gray_full_off, dimg, npix, hipMemcpyDeviceToDevice, st));
-        }
-    }
+    // everything behind the gray image: the resizes, the pyrDown chains, the layer filters
+    auto enqueue_rest = [&]() {
     // depth 0: resize from the full-resolution gray image
     int maxDepth = 0;
     for (const HostLayer& L : p->all) maxDepth = std::max(maxDepth, L.depth);
@@ -1212,38 +1079,13 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
         }
         flush1();
     }
-    // Generations 2 .. of every chain: k_pyrdown_chain, three generations per launch (FD_PYR_CHAIN=0: one k_pyrdown_tiled launch per
-    // generation, the form of round 4).  (One workgroup walking all deeper generations of a chain TILE BY TILE was measured in round 3 and
-    // dropped -- 160 us per 64-frame call, 32 serial tiles per workgroup; the chain kernel recomputes halos instead and stays parallel.)
-    static const bool chainOn = [] { const char* e = getenv("FD_PYR_CHAIN"); return !(e && atoi(e) == 0); }();
-    for (int d0 = 2; chainOn && d0 <= maxDepth; d0 += 3) {
-        ChainJobs cj;
-        cj.n = 0;
-        cj.tile0[0] = 0;
-        auto flushC = [&]() {
-            if (!cj.n) return;
-            hipLaunchKernelGGL(k_pyrdown_chain, dim3(tile_grid_for(cj.tile0[cj.n]), 1, NI), dim3(256), 0, st, arena, cj, IS);
-            cj.n = 0;
-        };
-        for (size_t k = 0; k < p->all.size(); ++k) {
-            const HostLayer& L = p->all[k];
-            if (L.depth != d0) continue;
-            // the chain's layers of depth d0 - 1 (source), d0, d0 + 1, d0 + 2 are consecutive entries of p->all
-            int D = 1;
-            while (D < 3 && k + D < p->all.size() && p->all[k + D].chain == L.chain && p->all[k + D].depth == d0 + D) ++D;
-            ChainJob& j = cj.j[cj.n++];
-            const HostLayer& S = p->all[k - 1];
-            j.w0 = S.w; j.h0 = S.h; j.D = D; j.T = D == 3 ? 16 : (D == 2 ? 32 : 64);
-            j.off[0] = S.gray_off;
-            for (int l = 1; l <= 3; ++l) j.off[l] = l <= D ? p->all[k + l - 1].gray_off : 0u;
-            const HostLayer& E = p->all[k + D - 1];
-            j.tilesX = (E.w + j.T - 1) / j.T;
-            cj.tile0[cj.n] = cj.tile0[cj.n - 1] + j.tilesX * ((E.h + j.T - 1) / j.T);
-            if (cj.n == MAXJ) flushC();
-        }
-        flushC();
-    }
-    for (int d = 2; !chainOn && d <= maxDepth; ++d) {
+    // (Measured and dropped, twice.  Round 3: one workgroup walking all deeper generations of a chain tile by tile -- 160 us per 64-frame
+    // call against 57 us for the per-generation launches, 32 serial tiles per workgroup.  Round 5: k_pyrdown_chain, a workgroup owning a
+    // 16 x 16 tile of the deepest generation and computing the 35 / 73 / 149-pixel boxes above it in LDS (halo recomputed, reflected
+    // borders materialised; bit-exact on every pyramid test) -- ONE launch of 121 us instead of three of 11.4 us, headline 3270 -> 2690
+    // Mpatches/s: 1.8x the outputs (halo) at ~60 instructions each, against ~12 per output of the column walk below, which shares
+    // the row dot products between vertically adjacent outputs.  The per-generation launches are latency-bound but cheap.)
+    for (int d = 2; d <= maxDepth; ++d) {
         DownJobs jobs;
         jobs.n = 0;
         jobs.tile0[0] = 0;
@@ -1299,6 +1141,33 @@ void pyramid_update(fd_pyramid* p, const uint8_t* image, int W, int H, int ch, i
         }
         flush();
     }
+    };   // enqueue_rest
+    if (frames) {   // one launch converts / copies all frames into their arenas
+        FramePtrs fp;
+        if (!is_device) {
+            p->input.reserve(npix * ch * (size_t)NI);
+            for (int f = 0; f < NI; ++f) {
+                HIP_CHECK(hipMemcpyAsync(p->input.as<uint8_t>() + (size_t)f * npix * ch, frames[f], npix * ch, hipMemcpyHostToDevice, st));
+                fp.p[f] = p->input.as<uint8_t>() + (size_t)f * npix * ch;
+            }
+        } else {
+            for (int f = 0; f < NI; ++f) fp.p[f] = frames[f];
+        }
+        hipLaunchKernelGGL(k_frames_to_gray, dim3(grid_for((int)(npix / 16 + 1)), NI), dim3(256), 0, st, fp, arena + p->gray_full_off, IS, (int)npix, ch);   // four quads per thread
+    } else {
+        const uint8_t* dimg = image;
+        if (!is_device) {
+            p->input.reserve(npix * ch);
+            HIP_CHECK(hipMemcpyAsync(p->input.p, image, npix * ch, hipMemcpyHostToDevice, st));
+            dimg = p->input.as<uint8_t>();
+        }
+        if (ch == 3) {
+            hipLaunchKernelGGL(k_bgr2gray, dim3(grid_for((int)npix)), dim3(256), 0, st, dimg, arena + p->gray_full_off, (int)npix);
+        } else {
+            HIP_CHECK(hipMemcpyAsync(arena + p->gray_full_off, dimg, npix, hipMemcpyDeviceToDevice, st));
+        }
+    }
+    enqueue_rest();
     HIP_CHECK(hipGetLastError());
     if (!p->ready) HIP_CHECK(hipEventCreateWithFlags(&p->ready, hipEventDisableTiming));
     HIP_CHECK(hipEventRecord(p->ready, st));

@@ -2483,7 +2483,7 @@ static void five_stage_batch_begin(fd_ctx* ctx, fd_five_stage_job* jobs, int n, 
     // A frame costs ~15 runtime calls (pyramid kernels, cascade kernels, copies, events): with many small jobs the single host
     // thread issuing them is the bottleneck, so batches of >= 6 jobs are issued by the worker pool -- all pyramid updates first
     // (jobs may share a pyramid one of them updates), then all cascades.  Each job has its own stream, handles and buffers.
-    static const int nthreads = [] { const char* e = getenv("FD_BATCH_THREADS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+    static const int nthreads = [] { const char* e = getenv("FD_BATCH_THREADS"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
     if (nthreads > 1 && n >= 6) {
         if (!ctx->workers) ctx->workers.reset(new FdWorkerPool(nthreads - 1));
         std::mutex errMu;
@@ -2549,7 +2549,7 @@ static void five_stage_batch_end(fd_ctx* ctx, fd_five_stage_batch& b) {
     // claims a detector whose cascade has finished, reads its positives back, runs the overlap elimination, queues the SVM stage
     // on the shared high-priority stream, waits for it and finishes with the NMS.  Everything a worker touches belongs to its
     // job (WVM handle, pinned staging, events); the streams are created up front.  FD_BATCH_THREADS=1 keeps it on the caller.
-    static const int nthreads = [] { const char* e = getenv("FD_BATCH_THREADS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+    static const int nthreads = [] { const char* e = getenv("FD_BATCH_THREADS"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
     int64_t totalWindows = 0;
     for (int i = 0; i < n; ++i) totalWindows += b.runs[i].total;
     if (nthreads > 1 && (n >= 6 || totalWindows >= (int64_t)4 << 20) && n >= 2) {

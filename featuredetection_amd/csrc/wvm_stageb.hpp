@@ -404,13 +404,11 @@ __global__ __launch_bounds__(256, 2) void k_wvb_chain2(WvbDev mv, WvbState s, in
 // A workgroup takes one block of RB consecutive rows for four tiles of 64 windows (one per wavefront, lane == window): the block's
 // weights are staged in LDS once and read as broadcasts, every K_p load (256 B, coalesced) feeds RB multiply-adds; the terms keep the
 // reference's order.  The first failed row of a window inside the block goes into exitKey by a 64-bit minimum (level << 32 | fp32 bits).
-// RB = 8: the most units, what a short queue needs.  RB = 32 (round 5, long queues): a tile's K history is streamed once per 32 rows
-// instead of once per 8 -- the first phases of the late-rejecting profiles (28 / 56 rows, 300-700 K windows) read it 4-7 times and
-// spent their time in those loads and in the per-unit weight staging.
 constexpr int WVB_MAXF = 64 * WVM_PJ;
-template <int RB>
+constexpr int WVB_RB = 8;   // rows per block
 __global__ __launch_bounds__(256) void k_wvb_sums(WvbDev mv, WvbState s, int phase, const unsigned int* countPtr) {
-    __shared__ __attribute__((aligned(16))) float wl[(WVB_MAXF + RB) * RB];
+    __shared__ __attribute__((aligned(16))) float wl[(WVB_MAXF + WVB_RB) * WVB_RB];
+    constexpr int RB = WVB_RB;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned int n = wvb_count(countPtr, s);
@@ -793,8 +791,9 @@ static void launch_stageb(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* m,
         const int nrb = (k1 - k0 + 7) / 8;
         const int64_t tiles = (expect(ph) + 63) / 64;
         // a unit per tile (all class quarters on one staged tile) once every resident workgroup gets at least two tiles that way
-        static const int cqMode = [] { const char* e = getenv("FD_WVB_CQ"); return e ? atoi(e) : 0; }();   // A/B: 1 = always per class quarter, 2 = always per tile
-        const int cqPer = (cqMode == 2 || (cqMode != 1 && tiles >= (int64_t)2 * cus * perCuC)) ? NQ : 1;
+        // (measured on the heavy-queue profiles, round 5: cascade_group 525 -> 553, cascade_late 1304 -> 1403 Mpatches/s; k_wvb_chain2 of
+        // the first phase 780 -> 690 us)
+        const int cqPer = tiles >= (int64_t)2 * cus * perCuC ? NQ : 1;
         const int gridC = wvb_grid8(std::min<int64_t>(tiles * ((NQ + cqPer - 1) / cqPer), (int64_t)cus * perCuC));
         if (timeChain) {   // bench hook (fd_ctx_set_kernel_timing(3)): the chain kernel of every phase between its own pair of events
             for (int e = 2 * ph; e < 2 * ph + 2; ++e)
@@ -803,17 +802,10 @@ static void launch_stageb(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* m,
         }
         hipLaunchKernelGGL(chainK, dim3(gridC), dim3(256), ldsBytes, st, mv, s, ph, countPtr, cqPer);
         if (timeChain) HIP_CHECK(hipEventRecord(ctx->evx[2 * ph + 1], st));
-        // 16 rows per block once the queue fills every resident workgroup that way (A/B: FD_WVB_RB = 8 / 16 / 32)
-        static const int rbMode = [] { const char* e = getenv("FD_WVB_RB"); return e ? atoi(e) : 0; }();
-        const int64_t quads = (tiles + 3) / 4;
-        // (measured, cascade_group: 16-row blocks everywhere 513 vs 525 Mpatches/s, 32-row blocks 445: fewer re-reads of the K history, but
-        // half / a quarter of the wavefronts to hide them.)  116 / 132: the larger block only for phases that start at level 64 or deeper
-        const int rb = (rbMode == 8 || rbMode == 16 || rbMode == 32) ? rbMode : ((rbMode == 116 || rbMode == 132) && k0 >= 64 && quads * ((k1 - k0 + 15) / 16) >= (int64_t)cus * 4 ? rbMode - 100 : 8);
-        const int nrbX = (k1 - k0 + rb - 1) / rb;
-        (void)nrb;
-        if (rb == 32) hipLaunchKernelGGL(k_wvb_sums<32>, dim3(wvb_grid8(std::min<int64_t>(quads * nrbX, (int64_t)cus * 2))), dim3(256), 0, st, mv, s, ph, countPtr);
-        else if (rb == 16) hipLaunchKernelGGL(k_wvb_sums<16>, dim3(wvb_grid8(std::min<int64_t>(quads * nrbX, (int64_t)cus * 4))), dim3(256), 0, st, mv, s, ph, countPtr);
-        else hipLaunchKernelGGL(k_wvb_sums<8>, dim3(wvb_grid8(std::min<int64_t>(quads * nrbX, (int64_t)cus * 8))), dim3(256), 0, st, mv, s, ph, countPtr);
+        // (Larger row blocks -- 16 or 32 rows: the K history streamed half / a quarter as often -- were measured on the heavy-queue
+        // profiles and lost in every phase: cascade_group 513 / 445 against 525 Mpatches/s; per launch 260 -> 295 us with 16 rows: at 184 /
+        // 256 registers a SIMD holds two / one wavefronts instead of four, too few to hide the loads that remain.)
+        hipLaunchKernelGGL(k_wvb_sums, dim3(wvb_grid8(std::min<int64_t>((tiles + 3) / 4 * nrb, (int64_t)cus * 8))), dim3(256), 0, st, mv, s, ph, countPtr);
         const int gridE = wvb_grid8(std::min<int64_t>(tiles, (int64_t)cus * 4));
         hipLaunchKernelGGL(k_wvb_exit, dim3(gridE), dim3(256), 0, st, mv, s, o, ph, countPtr, s.cnt + ph + 1);
     }

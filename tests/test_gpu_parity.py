@@ -819,6 +819,35 @@ def test_sdm_real_regressors(oracle, capi, ctx, synth):
         capi.Sdm(ctx, bad)
 
 
+def test_pyramid_updated_again_and_again_is_bit_exact(oracle, capi, ctx, synth):
+    """One pyramid object updated twelve times -- host images and device-resident images at changing addresses, a change of the frame size
+    and back, a gray pyramid and one with gradient-bin layers: every update gives the oracle's layers bit for bit (nothing of an earlier
+    update survives in the arena or the tables).  (Written for round 5's hipGraph replay of the update, which was measured and dropped.)"""
+    import torch
+    for kw, filt in ((dict(inc=float(np.float32(0.92)), min_scale=float(np.float32(0.05)), max_scale=float(np.float32(0.16))), False),
+                     (dict(octave_layers=3, min_scale=0.25, max_scale=1.0), True)):
+        pg, po = capi.Pyramid(ctx, **kw), oracle.Pyramid(**kw)
+        if filt:
+            pg.set_layer_filter(kind=1, bins=9)
+            po.set_layer_filter(kind=1, bins=9)
+        sizes = [(640, 480)] * 5 + [(320, 240)] * 4 + [(640, 480)] * 3
+        keep = []
+        for i, (W, H) in enumerate(sizes):
+            fr = synth.make_frame(W, H, seed=900 + i)
+            if i % 2 == 0:
+                pg.update(fr)                                   # host image: staged in the pyramid's input buffer
+            else:
+                t = torch.from_numpy(fr).cuda()                 # device image at a new address every time
+                keep.append(t)
+                pg.update_device(t.data_ptr(), W, H, 3)
+            po.update(fr)
+            lg, lo = pg.layers(), po.layers()
+            assert len(lg) == len(lo) > 0
+            for k in range(len(lo)):
+                assert np.array_equal(pg.layer(k), po.layer(k)), (filt, i, k)   # (the filtered layer when the pyramid has a layer filter)
+        pg.close()
+
+
 def test_errors_are_reported_not_swallowed(capi, ctx):
     with pytest.raises(capi.FdError) as e:
         capi.Pyramid(ctx, octave_layers=0, min_scale=0.1, max_scale=1.0)
