@@ -438,28 +438,32 @@ __global__ __launch_bounds__(256) void k_wvb_sums(WvbDev mv, WvbState s, int pha
         const unsigned int pos = (unsigned int)t * 64u + (unsigned int)lane;
         const bool valid = pos < n;
         const float* Kp = s.K[set] + (size_t)t * NU * 64 + lane;
-        float acc[RB];
+        // The accumulators as pairs of rows: w * K and acc + t of two rows are ONE v_pk_mul_f32 / v_pk_add_f32 each (IEEE fp32 per
+        // component, the product rounded before the sum like the two scalar instructions of round 4) -- the sums are bound by VALU issue
+        // once a queue is long (2 instructions per term and row: 127 M wave-instructions for the last phase of cascade_group, 207 us
+        // of the chip's issue slots), and packed math halves them.
+        typedef float wvb_f2 __attribute__((ext_vector_type(2)));
+        wvb_f2 acc2[RB / 2];
 #pragma unroll
-        for (int j = 0; j < RB; ++j) acc[j] = mv.negBias;
+        for (int j = 0; j < RB / 2; ++j) acc2[j] = wvb_f2{mv.negBias, mv.negBias};
         // terms every row of the block takes (p < kb): groups of 16 K loads, the next group in flight while one is consumed
         auto loadK = [&](float (&kv)[16], int p0) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) kv[i] = Kp[(size_t)(p0 + i) * ks];
         };
+        auto term = [&](const float* w0, float kvv) {   // all RB rows take the term
+            const wvb_f2 k2 = wvb_f2{kvv, kvv};
+#pragma unroll
+            for (int j4 = 0; j4 < RB / 4; ++j4) {
+                const float4 w = reinterpret_cast<const float4*>(w0)[j4];
+                const wvb_f2 ta = wvb_f2{w.x, w.y} * k2, tb = wvb_f2{w.z, w.w} * k2;
+                acc2[2 * j4] = acc2[2 * j4] + ta;
+                acc2[2 * j4 + 1] = acc2[2 * j4 + 1] + tb;
+            }
+        };
         auto useK = [&](const float (&kv)[16], int p0) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float4* w4 = reinterpret_cast<const float4*>(wl + (p0 + i) * RB);
-#pragma unroll
-                for (int j4 = 0; j4 < RB / 4; ++j4) {
-                    const float4 w = w4[j4];
-                    float tt;
-                    tt = w.x * kv[i]; acc[4 * j4] = acc[4 * j4] + tt;
-                    tt = w.y * kv[i]; acc[4 * j4 + 1] = acc[4 * j4 + 1] + tt;
-                    tt = w.z * kv[i]; acc[4 * j4 + 2] = acc[4 * j4 + 2] + tt;
-                    tt = w.w * kv[i]; acc[4 * j4 + 3] = acc[4 * j4 + 3] + tt;
-                }
-            }
+            for (int i = 0; i < 16; ++i) term(wl + (p0 + i) * RB, kv[i]);
         };
         const int ngroups = kb >> 4;
         {
@@ -480,26 +484,24 @@ __global__ __launch_bounds__(256) void k_wvb_sums(WvbDev mv, WvbState s, int pha
 #pragma unroll
             for (int i = 0; i < 16; ++i) kv[i] = Kp[(size_t)min(p + i, kb) * ks];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (p + i < kb) {
-                    const float* w0 = wl + (p + i) * RB;
-#pragma unroll
-                    for (int j = 0; j < RB; ++j) { const float tt = w0[j] * kv[i]; acc[j] = acc[j] + tt; }
-                }
-            }
+            for (int i = 0; i < 16; ++i)
+                if (p + i < kb) term(wl + (p + i) * RB, kv[i]);
         }
-        // the diagonal block: row kb + j ends with term p = kb + j
+        // the diagonal block: row kb + j ends with term p = kb + j (component by component: a pair's lower row must not see the upper
+        // row's last term -- not even as + 0 * K: K may be inf)
+        float acc[RB];
 #pragma unroll
-        for (int j0 = 0; j0 < RB; j0 += 8) {
+        for (int j = 0; j < RB; ++j) acc[j] = (j & 1) ? acc2[j >> 1].y : acc2[j >> 1].x;
+        {
             float kv[8];
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) kv[jj] = Kp[(size_t)min(kb + j0 + jj, k1 - 1) * ks];
+            for (int jj = 0; jj < 8; ++jj) kv[jj] = Kp[(size_t)min(kb + jj, k1 - 1) * ks];
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                if (kb + j0 + jj < k1) {
-                    const float* w0 = wl + (kb + j0 + jj) * RB;
+                if (kb + jj < k1) {
+                    const float* w0 = wl + (kb + jj) * RB;
 #pragma unroll
-                    for (int j = j0 + jj; j < RB; ++j) { const float tt = w0[j] * kv[jj]; acc[j] = acc[j] + tt; }
+                    for (int j = jj; j < RB; ++j) { const float tt = w0[j] * kv[jj]; acc[j] = acc[j] + tt; }
                 }
             }
         }
@@ -805,6 +807,12 @@ static void launch_stageb(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* m,
         // (Larger row blocks -- 16 or 32 rows: the K history streamed half / a quarter as often -- were measured on the heavy-queue
         // profiles and lost in every phase: cascade_group 513 / 445 against 525 Mpatches/s; per launch 260 -> 295 us with 16 rows: at 184 /
         // 256 registers a SIMD holds two / one wavefronts instead of four, too few to hide the loads that remain.)
+        // (Also measured and dropped, round 5: a tile-owned form for long queues -- one workgroup per 64 windows with the tile's K history
+        // staged in LDS once, k1 x 384 bytes, its four wavefronts dealing the row blocks among themselves: the history is read once
+        // instead of 6-16 times, but 107 KB of LDS for a 280-row phase leaves ONE wavefront per SIMD, and nothing hides the LDS and weight
+        // latencies any more: 589 against 264 us per launch on cascade_group, 44 against 26 on cascade_late's short phases.  Packed
+        // multiplies / adds, which halve the kernel's VALU instructions, changed its time by nothing either: k_wvb_sums lives on the
+        // 5.8 TB/s at which 32 wavefronts per CU pull the history out of L2 / MALL.)
         hipLaunchKernelGGL(k_wvb_sums, dim3(wvb_grid8(std::min<int64_t>((tiles + 3) / 4 * nrb, (int64_t)cus * 8))), dim3(256), 0, st, mv, s, ph, countPtr);
         const int gridE = wvb_grid8(std::min<int64_t>(tiles, (int64_t)cus * 4));
         hipLaunchKernelGGL(k_wvb_exit, dim3(gridE), dim3(256), 0, st, mv, s, o, ph, countPtr, s.cnt + ph + 1);

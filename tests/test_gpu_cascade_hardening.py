@@ -201,6 +201,41 @@ def test_stage_b_state_grows_with_the_queue(oracle, capi, ctx, synth, small_mode
     wg.close(); sg.close(); single.close(); multi.close()
 
 
+@pytest.mark.parametrize("profile", ["group", "late"])
+def test_long_queue_kernels_of_stage_b_against_short_queue_kernels_and_the_oracle(oracle, capi, ctx, synth, profile):
+    """With hundreds of thousands of queued windows stage B switches kernels / forms -- k_wvb_prepare_lanes (from 32 K windows),
+    k_wvb_chain2 with all class quarters of a tile in one unit and the level slots outside the phase skipped (from 1024 tiles, round
+    5).  The bench's heavy-queue models (bench.cascade_models: 280 filters; 'group' rejects at the end of a level
+    group only, 'late' keeps rejecting through ~65 filters) on 32 frames in ONE call queue 200-330 K windows; every frame's stage
+    counts and detections must equal those of single-frame calls (short queues: the other kernels) and, for three frames, the
+    oracle's."""
+    import bench
+    wvm_m, svm_m = bench.cascade_models(profile)
+    frames, _ = synth.make_frames_varied(32, 640, 480, seed=4242, scene_len=8)
+    wg, sg = capi.Wvm(ctx, wvm_m), capi.Svm(ctx, svm_m)
+    multi = capi.Pyramid(ctx, **FF)
+    multi.set_frames(len(frames))
+    multi.update_frames(images=frames)
+    res = None
+    for _ in range(2):   # the first call may grow the state and settles the phase plan, the second runs on the settled plan
+        res = capi.detect_five_stage_frames(ctx, multi, wg, sg, len(frames), cap=2048)
+    assert wg.last_queue_length() > 150000, wg.last_queue_length()
+    single = capi.Pyramid(ctx, **FF)
+    w1 = capi.Wvm(ctx, wvm_m)   # its own handle: grids and phase plan of a short queue
+    for fi, f in enumerate(frames):
+        single.update(f)
+        d, st = capi.detect_five_stage(ctx, single, w1, sg, cap=2048)
+        assert np.array_equal(res[fi][1], st) and res[fi][0].tobytes() == d.tobytes(), fi
+    po, wo, so = oracle.Pyramid(**FF), oracle.Wvm(wvm_m), oracle.Svm(svm_m)
+    for fi in (0, 13, 31):
+        po.update(frames[fi])
+        do, sto = oracle.five_stage(po, wo, so)
+        assert np.array_equal(res[fi][1], sto), (fi, res[fi][1], sto)
+        for f in ("cx", "cy", "w", "h"):
+            assert np.array_equal(res[fi][0][f], do[f])
+    wg.close(); w1.close(); sg.close(); multi.close(); single.close()
+
+
 def test_stage_b_dense_equals_rect_lookup_kernels(capi, ctx, synth, oracle, frame640):
     """FD_WVM_STAGEB=old keeps the rect-lookup stage-B kernel (k_wvm_deep): both must deliver the same positive records"""
     import bench
