@@ -700,7 +700,7 @@ class Ffp15(Workload):
         self.nfed += 1
         return self.dframes[int(self.order[pos])]
 
-    def __init__(self, env, W=1920, H=1080, frames_per_step=4):
+    def __init__(self, env, W=1920, H=1080, frames_per_step=8):   # 20 steps = 160 frames = five whole passes over the 32 distinct frames
         import torch  # noqa: F401
         from featuredetection_amd import capi, synth  # noqa: F401
         self.env, self.capi, self.W, self.H = env, capi, W, H
@@ -1199,7 +1199,7 @@ def main():
         env.local_rank = 0
     if env.world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # N ranks share one host: at most 8 host threads per rank (this thread + the library's queue threads + its batch workers)
+        # N ranks share one host: at most 12 host threads per rank (this thread + the library's queue threads + its batch workers)
         os.environ.setdefault("FD_ASYNC_THREADS", "2")
         os.environ.setdefault("FD_BATCH_THREADS", "8")
         os.environ.setdefault("FD_BENCH_SDM_THREADS", "1")

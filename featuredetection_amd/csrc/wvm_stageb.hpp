@@ -812,7 +812,11 @@ static void launch_stageb(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* m,
         // instead of 6-16 times, but 107 KB of LDS for a 280-row phase leaves ONE wavefront per SIMD, and nothing hides the LDS and weight
         // latencies any more: 589 against 264 us per launch on cascade_group, 44 against 26 on cascade_late's short phases.  Packed
         // multiplies / adds, which halve the kernel's VALU instructions, changed its time by nothing either: k_wvb_sums lives on the
-        // 5.8 TB/s at which 32 wavefronts per CU pull the history out of L2 / MALL.)
+        // 5.8 TB/s at which 32 wavefronts per CU pull the history out of L2 / MALL.  Two more forms, same verdict: four consecutive row
+        // blocks per workgroup sharing the K rows through double-buffered LDS chunks -- a quarter of the 1.16 GB the counters see per
+        // launch -- took the same 265 us; the same with the weights as scalar operands (s_load_dwordx8 into SGPR pairs of the packed
+        // multiplies, no weight traffic through LDS at all) 311 us.  Bytes, VALU instructions and LDS traffic have each been cut by 2-4x
+        // without moving this kernel: what it waits for is the latency of its dependent loads at the occupancy it has.)
         hipLaunchKernelGGL(k_wvb_sums, dim3(wvb_grid8(std::min<int64_t>((tiles + 3) / 4 * nrb, (int64_t)cus * 8))), dim3(256), 0, st, mv, s, ph, countPtr);
         const int gridE = wvb_grid8(std::min<int64_t>(tiles, (int64_t)cus * 4));
         hipLaunchKernelGGL(k_wvb_exit, dim3(gridE), dim3(256), 0, st, mv, s, o, ph, countPtr, s.cnt + ph + 1);

@@ -1,6 +1,8 @@
 // sdm_fit_app -- the two calls every SDM caller of the reference makes (detect-landmarks.cpp:272-276,
 // sdmTracking.cpp:362,371): alignRigid + optimize, on the reference-shaped classes of this backend.
-// usage: sdm_fit_app <model.txt> <image.pgm> <x> <y> <w> <h> [landmarks.txt]   -> prints the 2L landmark coordinates;
+// usage: sdm_fit_app [--non-adaptive] <model.txt> <image.pgm> <x> <y> <w> <h> [landmarks.txt]   -> prints the 2L landmark coordinates;
+// --non-adaptive: the `else` branches of SdmLandmarkModelFitting::optimize (SdmLandmarkModel.hpp:236-238,246-248) -- the descriptor
+// parameters of the model file instead of the face-size adaptive ones (what the reference's shipped model needs);
 // with a seventh argument the landmarks also go through imageio::SimpleModelLandmarkSink ("name x y" per line)
 #include <cstdio>
 #include <cstdlib>
@@ -11,10 +13,12 @@
 using namespace superviseddescent;
 
 int main(int argc, char** argv) {
-    if (argc < 7) { std::fprintf(stderr, "usage: %s model.txt image.pgm x y w h\n", argv[0]); return 2; }
+    bool adaptive = true;
+    if (argc > 1 && std::string(argv[1]) == "--non-adaptive") { adaptive = false; --argc; ++argv; }
+    if (argc < 7) { std::fprintf(stderr, "usage: %s [--non-adaptive] model.txt image.pgm x y w h\n", argv[0]); return 2; }
     try {
         SdmLandmarkModel lmModel = SdmLandmarkModel::load(argv[1]);
-        SdmLandmarkModelFitting modelFitter(lmModel);
+        SdmLandmarkModelFitting modelFitter(lmModel, adaptive);
         std::ifstream f(argv[2], std::ios::binary);
         std::string magic; int w, h, maxv;
         f >> magic >> w >> h >> maxv; f.get();

@@ -376,7 +376,9 @@ def save_pnm(path, img):
 
 
 def save_sdm_text(path, m):
-    """Text format of SdmLandmarkModel::save (SdmLandmarkModel.cpp:98-128), adaptive vlhog-uoctti descriptors."""
+    """Text format of SdmLandmarkModel::save (SdmLandmarkModel.cpp:98-128): vlhog-uoctti descriptors, adaptive (empty parameter line) or
+    with `numCells n cellSize c numBins b` per step when the model carries desc_params (SdmLandmarkModel.cpp:188-204)."""
+    dp = None if m.get("desc_params") is None else np.asarray(m["desc_params"], np.int64).reshape(-1, 3)
     L = int(m["L"])
     with open(path, "w") as f:
         f.write("# synthetic SDM model\n")
@@ -390,6 +392,6 @@ def save_sdm_text(path, m):
             f.write("cascadeStep %d rows %d cols %d\n" % (s, R.shape[0], R.shape[1]))
             f.write("descriptorType vlhog-uoctti\n")
             f.write("descriptorPostprocessing none\n")
-            f.write("descriptorParameters \n")
+            f.write("descriptorParameters \n" if dp is None else "descriptorParameters numCells %d cellSize %d numBins %d\n" % tuple(dp[s]))
             for row in np.asarray(R, np.float32):
                 f.write(" ".join("%.9g" % v for v in row) + " \n")

@@ -15,7 +15,10 @@
 // this restatement: tests/test_oracle_golden.py holds SECOND restatements, written separately in
 // numpy / Python scalars from the reference's source, of cvtColor / resize / pyrDown, HistEq64,
 // the WVM cascade, the gradient / binning / HOG filter chain, OverlapElimination,
-// nonMaximaSuppression and the grey-world filter; the C++ code here must agree with them bit for bit.
+// nonMaximaSuppression and the grey-world filter; the C++ code here must agree with them bit for bit.  They are the same author's
+// second reading of the same sources: they catch transcription slips, they are NOT a pin by the reference.
+// Round 5 adds the reference's one trained model (detect-landmarks/share/models/SDM_Model_HOG_Zhenhua_11012014.txt) as committed
+// data with hog.c's outputs for the patches its regressors visit (tests/golden/make_sdm_real.py).
 #pragma once
 #include <cstdint>
 #include <cmath>
