@@ -673,6 +673,7 @@ class Ffp15(Workload):
     """config 3 (and the per-GPU work of config 5): 15 five-stage detectors on 1920x1080 frames, 32.1 M windows per frame"""
     name = "ffp15"
     dtype = "u8/i32/f32/f64"
+    records_cap = 1 << 18     # ~1,200 detections per frame over the 15 detectors, 32 frames of a rank between two gathers
     content = "varied"        # "2frames": the content of rounds 1-4 (two alternating frames of synth.make_frame)
     NDISTINCT = 32
 
@@ -862,7 +863,6 @@ class Config5(Ffp15):
     gather_every = 1
     scaling = "strong"
     GATHER_IMAGES = 256
-    records_cap = 1 << 15     # records per rank and gather: 256 / N images x 15 detectors x a few detections
 
     def make_content(self, W, H):
         env = self.env
@@ -886,6 +886,10 @@ class Config5(Ffp15):
                                    (self.total_images, W, H, self.nwin, env.world, self.GATHER_IMAGES, self.config["workload"].split("; ", 1)[-1]))
         self.config["images"] = self.total_images
         self.config["gather_every_images"] = self.GATHER_IMAGES
+        # rows of the padded gather buffer per rank (the same on every rank): ~1,200 detections per image over the 15 detectors on this
+        # content, 4096 allowed per image of a rank's share of a gather interval; a rank that had more is reported (`records_truncated`)
+        per_rank = (self.GATHER_IMAGES + env.world - 1) // env.world
+        self.records_cap = 1 << int(np.ceil(np.log2(max(1 << 15, per_rank * 4096))))
         self.config.pop("frames_per_step", None)
 
     @staticmethod
