@@ -888,7 +888,7 @@ class Config5(Ffp15):
         self.config["gather_every_images"] = self.GATHER_IMAGES
         # rows of the padded gather buffer per rank (the same on every rank): ~1,200 detections per image over the 15 detectors on this
         # content, 4096 allowed per image of a rank's share of a gather interval; a rank that had more is reported (`records_truncated`)
-        per_rank = (self.GATHER_IMAGES + env.world - 1) // env.world
+        per_rank = (min(self.GATHER_IMAGES, self.total_images) + env.world - 1) // env.world
         self.records_cap = 1 << int(np.ceil(np.log2(max(1 << 15, per_rank * 4096))))
         self.config.pop("frames_per_step", None)
 
