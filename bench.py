@@ -140,18 +140,19 @@ def device_frames(ids, W, H, dev, seed0=20260927, scene_len=4, nbase=9):
     import torch
     g = torch.Generator(device=dev)
     g.manual_seed(seed0)
-    k1 = {}
     bases = []
     for b in range(nbase):   # smooth base fields: Gaussian-blurred uniform noise (sigma 4 / 8 / 14), rescaled to 0..1
         sigma = (4.0, 8.0, 14.0)[b % 3]
-        if sigma not in k1:
-            r = int(3 * sigma + 0.5)
-            k = torch.exp(-0.5 * (torch.arange(-r, r + 1, device=dev, dtype=torch.float32) / sigma) ** 2)
-            k1[sigma] = (k / k.sum(), r)
-        k, r = k1[sigma]
+        r = int(3 * sigma + 0.5)
+        k = np.exp(-0.5 * (np.arange(-r, r + 1) / sigma) ** 2)
+        k = (k / k.sum()).astype(np.float32)
         x = torch.rand((1, 1, H, W), generator=g, device=dev)
-        x = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (0, 0, r, r), mode="reflect"), k.view(1, 1, -1, 1))
-        x = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (r, r, 0, 0), mode="reflect"), k.view(1, 1, 1, -1))[0, 0]
+        # separable blur as 2 r + 1 shifted multiply-adds per axis (plain elementwise kernels: no convolution library, nothing to
+        # compile or tune when eight ranks start at once)
+        p_ = torch.nn.functional.pad(x, (0, 0, r, r), mode="reflect")[0, 0]
+        x = sum(float(k[i]) * p_[i:i + H] for i in range(2 * r + 1))
+        p_ = torch.nn.functional.pad(x[None, None], (r, r, 0, 0), mode="reflect")[0, 0]
+        x = sum(float(k[i]) * p_[:, i:i + W] for i in range(2 * r + 1))
         bases.append((x - x.min()) / (x.max() - x.min()).clamp_min(1e-12))
     yy, xx = torch.meshgrid(torch.arange(160, device=dev, dtype=torch.float32), torch.arange(160, device=dev, dtype=torch.float32), indexing="ij")
     out, scenes = [], {}
