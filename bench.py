@@ -21,6 +21,7 @@ The cpu_baseline legs (rank 0, N=1 only) time the CPU oracle (oracle/, "port" of
 bounded sample of the same workload: 1 thread with the update / extract / classify split of BASELINE.md section 3, and an
 image-parallel (detector-parallel for ffp15) run on every host core."""
 import argparse
+import gc
 import json
 import os
 import socket
@@ -1246,13 +1247,22 @@ def main():
     env.no_probe = args.no_probe
 
     wl = build(args.workload, True)
+    def release(name):
+        # a workload's handles (pyramids, queues, record buffers) go back to the device before the next one is built
+        gc.collect()
+        if os.environ.get("FD_BENCH_MEMLOG"):
+            free, total = torch.cuda.mem_get_info()
+            print("[mem] rank %d after %s: %.2f GB in use of %.0f" % (env.rank, name, (total - free) / 1e9, total / 1e9), file=sys.stderr, flush=True)
+
     res = measure(wl, env, args.steps, args.warmup, args.gather_every, want_cpu)
     del wl
+    release(args.workload)
     subs = []
     for name in also:
         w2 = build(name, False)
         subs.append(measure(w2, env, args.steps, args.warmup, args.gather_every, want_cpu))
         del w2
+        release(name)
     if env.rank == 0:
         if subs:
             res["also"] = subs

@@ -390,9 +390,15 @@ class Pyramid:
         return out
 
     def close(self):
-        if self.h:
+        if getattr(self, "h", None):
             lib().fd_pyramid_destroy(self.h)
             self.h = C.c_void_p()
+
+    def __del__(self):   # a handle nobody holds any more gives its device memory back (hipFree waits for the device)
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _wvm_struct(m, cls):
@@ -440,9 +446,15 @@ class Wvm:
         return int(lib().fd_wvm_last_tail_state(self.h))
 
     def close(self):
-        if self.h:
+        if getattr(self, "h", None):
             lib().fd_wvm_destroy(self.h)
             self.h = C.c_void_p()
+
+    def __del__(self):   # a handle nobody holds any more gives its device memory back (hipFree waits for the device)
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def pack_records(image_id, detector_id, dets):
@@ -564,9 +576,15 @@ class Svm:
         return out
 
     def close(self):
-        if self.h:
+        if getattr(self, "h", None):
             lib().fd_svm_destroy(self.h)
             self.h = C.c_void_p()
+
+    def __del__(self):   # a handle nobody holds any more gives its device memory back (hipFree waits for the device)
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def hog_params(pw=20, ph=20, sx=2, sy=2, bins=9, cell=5, block=2, signed_and_unsigned=False):
@@ -647,6 +665,7 @@ class FiveStageFrames:
         if nframes != held:
             raise ValueError("FiveStageFrames: nframes=%d but the pyramid holds %d frames" % (nframes, held))
         self.ctx, self.nframes, self.cap = ctx, held, cap
+        self._keep = (pyr, wvm, svm)
         self.ticket = C.c_void_p()
         r = _c(roi, np.int32) if roi is not None else None
         ctx.check(lib().fd_detect_five_stage_frames_begin(ctx.h, pyr.h, wvm.h, svm.h, oe_dist, oe_ratio, sx, sy, _ptr(r), C.byref(self.ticket)))
@@ -713,6 +732,7 @@ class FiveStageBatch:
     end() runs the host stages and returns [(detections, stage_counts)].  Batches in flight must use different handles."""
     def __init__(self, ctx, detectors, oe_dist=5.0, oe_ratio=0.0, sx=1, sy=1, cap=4096, device_frames=None):
         self.ctx = ctx
+        self._keep = list(detectors)   # the handles in the jobs stay alive while the batch is in flight
         self.jobs, self.outs = _five_stage_jobs(detectors, oe_dist, oe_ratio, sx, sy, cap, device_frames)
         self.ticket = C.c_void_p()
         ctx.check(lib().fd_five_stage_batch_begin(ctx.h, self.jobs, len(detectors), C.byref(self.ticket)))
@@ -780,9 +800,15 @@ class Aggregated:
         return out[:n.value], (cand[:nc.value] if candidates else None)
 
     def close(self):
-        if self.h:
+        if getattr(self, "h", None):
             lib().fd_aggregated_destroy(self.h)
             self.h = None
+
+    def __del__(self):   # a handle nobody holds any more gives its device memory back (hipFree waits for the device)
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def nms_iou(boxes, overlap_threshold, maximum_type=0):
@@ -889,9 +915,15 @@ class Rvm:
         return lv, d
 
     def close(self):
-        if self.h:
+        if getattr(self, "h", None):
             lib().fd_rvm_destroy(self.h)
             self.h = None
+
+    def __del__(self):   # a handle nobody holds any more gives its device memory back (hipFree waits for the device)
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def detect_rvm(ctx, pyr, rvm, feature_space=FEATURE_HQ64, conv_scale=1.0, conv_shift=0.0, sx=1, sy=1, roi=None, want_all=True, cap=1 << 20):
@@ -1018,6 +1050,7 @@ class HogSvmRun:
 
     def __init__(self, ctx, pyr, svm, hp, cap=1 << 14):
         self.ctx, self.cap = ctx, cap
+        self._keep = (pyr, svm)
         self.ticket = C.c_void_p()
         ctx.check(lib().fd_detect_hog_svm_begin(ctx.h, pyr.h, svm.h, C.byref(hp), C.byref(self.ticket)))
 
@@ -1093,9 +1126,15 @@ class Sdm:
         return out, st
 
     def close(self):
-        if self.h:
+        if getattr(self, "h", None):
             lib().fd_sdm_destroy(self.h)
             self.h = C.c_void_p()
+
+    def __del__(self):   # a handle nobody holds any more gives its device memory back (hipFree waits for the device)
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def sdm_descriptors(ctx, gray, px, py, wsh, variant=1, num_cells=3, cell_size=10, num_bins=9):

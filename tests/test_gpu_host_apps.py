@@ -722,6 +722,34 @@ def test_bench_config5_one_and_two_ranks(tmp_path):
 
 
 @pytest.mark.gpu
+def test_bench_default_list_two_ranks_and_the_memory_it_leaves():
+    """The driver's N=2 command with bench.py's DEFAULT `also` list (two ranks on device 0, gloo + the librccl stand-in, config 5 cut to
+    32 images): every record arrives with n_gpus 2 and all its detections gathered on rank 0, and each finished workload gives its
+    device memory back -- capi's handles had no __del__ once, nine workloads left 160 GB behind and two ranks on one device ran out."""
+    import json
+    import re
+    import subprocess
+    import sys
+    if not os.path.exists(STUB_RCCL):
+        pytest.fail("tests/stub_rccl/librccl_stub.so not built")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FD_DIST_ONE_DEVICE="1", FD_BENCH_DIST_BACKEND="gloo", FD_RCCL_LIB=STUB_RCCL, FD_BENCH_CONFIG5_IMAGES="32", FD_BENCH_MEMLOG="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29577",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-probe"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    recs = [rec] + rec["also"]
+    assert len(recs) == 9 and set(rec["summary"]) >= {"cascade", "hog_svm", "ffp15", "sdm", "cascade_late", "cascade_group", "config5"}
+    for a in recs:
+        assert a["n_gpus"] == 2 and a["value"] > 0, a["config"]["workload"]
+        assert a["records_gathered"] == a["detections_delivered"] and not a["records_truncated"], a["config"]["workload"]
+    assert recs[-1]["scaling"] == "strong" and all(a["scaling"] == "weak" for a in recs[:-1])
+    used = [float(m) for m in re.findall(r"\[mem\] rank 0 after \w+: ([0-9.]+) GB", r.stderr)]
+    assert len(used) == 9 and max(used) < 24.0, used   # both ranks' share of one device; 160 GB per rank before the handles freed themselves
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("workload", ["cascade", "cascade_group", "hog_svm", "ffp15", "sdm"])
 def test_bench_line_of_every_workload_with_its_probe(workload):
     """One short run of bench.py per workload WITH its kernel probe and roofline records (the multi-rank test above runs without them):
