@@ -51,13 +51,12 @@ struct DescLds {   // per-wave views carved out of dynamic LDS
     unsigned long long* colmask;  // [hogW]: columns x contributing to cell column cx
     int* yrange;                  // [hogH][2]: first/last+1 row contributing to cell row cy
 };
-constexpr int SDM_SMALL_ITERS = 16;   // working images of up to 64 * 16 pixels keep their gradients in registers for one sync
+constexpr int SDM_SMALL_ITERS = 16;   // "small" working images: up to 64 * 16 pixels and at most 32 columns (32-bit orientation masks)
 #ifndef FD_SDM_REGGRAD
 #define FD_SDM_REGGRAD 1
 #endif
-// 1: small working images keep the gradient magnitudes in registers until every lane has read its neighbours and then overwrite the
-// image (3.6 KB of LDS less per wave, 16 instead of 12 waves per CU, but 32 registers and a 16-fold unrolled gradient loop);
-// 0: they go to their own LDS block through the plain loop
+// 1: small working images turn into their gradient magnitudes in place, one block of 64 pixels behind the block being computed (3.6 KB
+// of LDS less per wave: 18 instead of 12 waves per CU); 0: the magnitudes go to their own LDS block through the plain loop
 constexpr bool SDM_REGGRAD = FD_SDM_REGGRAD != 0;
 __host__ __device__ inline int align16i(int v) { return (v + 15) & ~15; }
 __host__ __device__ inline bool desc_small(int iw, int ih) { return iw * ih <= 64 * SDM_SMALL_ITERS && iw <= 32; }
@@ -148,8 +147,8 @@ extern "C" void fd_debug_sdm_prof(unsigned long long* out, int reset) {
 #endif
 
 // one wavefront per (face, landmark).  LDS per wave is what bounds the occupancy of this latency-bound kernel, so regions
-// are reused: the gradient magnitudes overwrite the working image (SMALL: they wait in registers until every lane has read
-// its neighbours), the features overwrite it once the votes are in, the block factors reuse the orientation masks.
+// are reused: the gradient magnitudes overwrite the working image (SMALL: in place, one 64-pixel block behind the
+// block being computed), the features overwrite it once the votes are in, the block factors reuse the orientation masks.
 #ifndef FD_SDM_WPE
 #define FD_SDM_WPE 4
 #endif
@@ -157,7 +156,7 @@ template <bool SMALL>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(FD_SDM_WPE, 8))) void k_sdm_descriptors(const uint8_t* __restrict__ images, const int32_t* __restrict__ origin,
                                                          DescParams p, int64_t nitems, float* __restrict__ out, int64_t out_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the per-wave LDS views below live in SGPRs
 #ifdef FD_SDM_PROF
     unsigned long long pacc[8] = {};
 #endif
@@ -402,23 +401,27 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(FD_SDM_WPE,
             return b0;
         };
         if (SMALL && SDM_REGGRAD) {
-            float gr[SDM_SMALL_ITERS];
-            int ob[SDM_SMALL_ITERS];
-#pragma unroll
-            for (int t = 0; t < SDM_SMALL_ITERS; ++t) {
-                const int i = lane + 64 * t;
-                gr[t] = 0.f;
-                ob[t] = i < npix ? gradient(i, gr[t]) : -2;
-                __builtin_amdgcn_sched_barrier(0);   // keep the unrolled iterations apart: 16 x (loads + temporaries) otherwise cost 235 VGPRs
-            }
-            wave_sync();   // every lane has read its neighbours: the magnitudes may overwrite the image
-#pragma unroll
-            for (int t = 0; t < SDM_SMALL_ITERS; ++t) {
-                const int i = lane + 64 * t;
-                if (ob[t] > -2) {
-                    S.grad[i] = gr[t];
-                    if (ob[t] >= 0) { const int y = divw(i); atomicOr(&masks[__mul24(ob[t], ih) + y], (mask_t)1 << (i - __mul24(y, iw))); }
+            // In place, one block of 64 pixels behind: the votes go to their orientation masks at once (a region of their own); a
+            // block's magnitudes wait in ONE register until the next block has been computed.  Pixel i reads i +- 1 and i +- iw with
+            // iw <= 32: block t reads nothing below 64 t - 32, so block t - 1 may be overwritten as soon as every lane has finished
+            // block t, and block t + 1 never looks at it.  -1 marks a border pixel (a magnitude is never negative).  (Round 5: the
+            // 16-fold unrolled form that kept all magnitudes and bins in registers spilled 53 VGPRs at the 128 of four wavefronts
+            // per SIMD -- 240 MB of scratch traffic per launch.)
+            float gprev = -1.f;
+#pragma unroll 1
+            for (int i = lane; i < npix + 64; i += 64) {
+                float g = -1.f;
+                if (i < npix) {
+                    float gg = 0.f;
+                    const int b0 = gradient(i, gg);
+                    if (b0 > -2) {
+                        g = gg;
+                        if (b0 >= 0) { const int y = divw(i); atomicOr(&masks[__mul24(b0, ih) + y], (mask_t)1 << (i - __mul24(y, iw))); }
+                    }
                 }
+                wave_sync();   // every lane has read its neighbours in the previous block
+                if (gprev >= 0.f) S.grad[i - 64] = gprev;
+                gprev = g;
             }
         } else {
             for (int i = lane; i < npix; i += 64) {
