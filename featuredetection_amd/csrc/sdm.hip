@@ -49,7 +49,6 @@ struct DescLds {   // per-wave views carved out of dynamic LDS
     float2* oxy;                  // [SDM_MAX_ORI] orientation unit vectors (a lane picks three of them by index)
     double *fac, *hc;             // block factors [ncell][4], clamped undirected terms [ncell*nori][4] (reuse the mask region)
     unsigned long long* colmask;  // [hogW]: columns x contributing to cell column cx
-    int* yrange;                  // [hogH][2]: first/last+1 row contributing to cell row cy
 };
 constexpr int SDM_SMALL_ITERS = 16;   // "small" working images: up to 64 * 16 pixels and at most 32 columns (32-bit orientation masks)
 #ifndef FD_SDM_REGGRAD
@@ -72,7 +71,7 @@ __host__ __device__ inline int desc_region_masks(int iw, int ih, int ncell, int 
 __host__ __device__ inline int desc_lds_bytes(int iw, int ih, int ncell, int nori, int dim, int hogMax) {
     const int m = iw > ih ? iw : ih;
     return desc_region_img(iw, ih, ncell, dim) + ((desc_small(iw, ih) && SDM_REGGRAD) ? 0 : align16i(iw * ih * 4)) + 3 * align16i(m * 4) +
-           align16i(ncell * nori * 2 * 4) + align16i(ncell * 4) + desc_region_masks(iw, ih, ncell, nori) + align16i(m * 8) + align16i(m * 2 * 4) +
+           align16i(ncell * nori * 2 * 4) + align16i(ncell * 4) + desc_region_masks(iw, ih, ncell, nori) + align16i(m * 8) +
            align16i(hogMax * m * 4) + align16i(SDM_MAX_ORI * 8);
 }
 
@@ -184,7 +183,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(FD_SDM_WPE,
         S.masks = (void*)b; S.fac = (double*)b; S.hc = (double*)(b + align16i(ncell * 4 * 8));
         b += desc_region_masks(iw, ih, ncell, nori);
         S.colmask = (unsigned long long*)b; b += align16i(m * 8);
-        S.yrange = (int*)b; b += align16i(m * 2 * 4);
         S.wsel = (float*)b; b += align16i((hogW > hogH ? hogW : hogH) * m * 4);
         S.oxy = (float2*)b;
     }
@@ -208,21 +206,21 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(FD_SDM_WPE,
         const int c = i / m_, p_ = i - c * m_;
         S.wsel[i] = S.binx[p_] == c ? S.wx1[p_] : S.wx2[p_];
     }
-    // per cell column: bit mask of the interior columns that vote into it; per cell row: row range
+    // per cell column: bit mask of the interior columns that vote into it
     for (int c = lane; c < hogW; c += 64) {
         unsigned long long mk = 0ull;
         for (int x = 1; x < iw - 1; ++x)
             if (S.binx[x] == c || S.binx[x] + 1 == c) mk |= 1ull << x;
         S.colmask[c] = mk;
     }
-    for (int c = lane; c < hogH; c += 64) {
-        int lo = ih, hi = 0;
-        for (int y = 1; y < ih - 1; ++y)
-            if (S.binx[y] == c || S.binx[y] + 1 == c) { lo = min(lo, y); hi = max(hi, y + 1); }
-        S.yrange[2 * c] = lo;
-        S.yrange[2 * c + 1] = hi;
-    }
     wave_sync();
+    // rows at which the cell row index moves on (bit y: binx[y] == binx[y - 1] + 1; it never moves by more), and binx[1]: scalars of the
+    // voting loop
+    unsigned long long rowStep = 0ull;
+    for (int y = 2; y < ih - 1; ++y)
+        if (S.binx[y] != S.binx[y - 1]) rowStep |= 1ull << y;
+    rowStep = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned int)(rowStep >> 32)) << 32) | (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned int)rowStep);
+    const int binx1 = __builtin_amdgcn_readfirstlane(S.binx[ih > 1 ? 1 : 0]);
     // XCD-aware item order: workgroup b runs on XCD b % 8 (round-robin dispatch), and every XCD has its own 4 MB L2.  With the
     // plain order every XCD touches every face image (256 x 64 KB = 16.8 MB: the crops stream through the L2s, 263 MB of fabric
     // traffic per launch by the FETCH_SIZE counter); here XCD x only works on the faces f = x (mod 8), whose images stay resident.
@@ -275,24 +273,57 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(FD_SDM_WPE,
             const int cropCap = desc_region_masks(iw, ih, ncell, nori) - 6 * m_ * 4;
             const bool staged = side * side <= cropCap;
             if (staged) {
-                const float invS = 1.0f / (float)side;
-                const int nsrc = side * side;
-                constexpr int CU = 8;
-                for (int q0 = lane; q0 < nsrc; q0 += 64 * CU) {
-                    float t[CU];
+                // four bytes per lane and load (a row of the crop is ceil(side / 4) dwords; rows keep their stride of `side` bytes, so a
+                // row's last dword is stored bytewise when side is not a multiple of four): a quarter of the load instructions and of
+                // the index arithmetic of the byte-per-lane form.  Dwords that touch the image border are put together from single bytes
+                // (zero outside, DescriptorExtractor.hpp:156-178)
+                const int ndw = (side + 3) >> 2, nd = __mul24(side, ndw);
+                const float invN = 1.0f / (float)ndw;
+                constexpr int CU = 4;
+                for (int d0 = lane; d0 < nd; d0 += 64 * CU) {
+                    unsigned int v[CU];
 #pragma unroll
                     for (int u = 0; u < CU; ++u) {
-                        const int q = min(q0 + 64 * u, nsrc - 1);
-                        const int r = (int)(((float)q + 0.5f) * invS), c = q - __mul24(r, side);
-                        t[u] = src_px(img, p.W, p.H, ox + c, oy + r);
+                        const int d = min(d0 + 64 * u, nd - 1);
+                        const int r = (int)(((float)d + 0.5f) * invN), c = (d - __mul24(r, ndw)) << 2;
+                        const int x = ox + c, y = oy + r;
+                        if ((unsigned)y < (unsigned)p.H && x >= 0 && x + 3 < p.W) {
+                            __builtin_memcpy(&v[u], img + (unsigned int)(__mul24(y, p.W) + x), 4);
+                        } else {
+                            auto px = [&](int xx) -> unsigned int { return ((unsigned)xx < (unsigned)p.W && (unsigned)y < (unsigned)p.H) ? (unsigned int)img[(unsigned int)(__mul24(y, p.W) + xx)] : 0u; };
+                            v[u] = px(x) | (px(x + 1) << 8) | (px(x + 2) << 16) | (px(x + 3) << 24);
+                        }
                     }
 #pragma unroll
-                    for (int u = 0; u < CU; ++u)
-                        if (q0 + 64 * u < nsrc) cropB[q0 + 64 * u] = (uint8_t)t[u];
+                    for (int u = 0; u < CU; ++u) {
+                        const int d = d0 + 64 * u;
+                        if (d < nd) {
+                            const int r = (int)(((float)d + 0.5f) * invN), c = (d - __mul24(r, ndw)) << 2;
+                            uint8_t* dstB = cropB + __mul24(r, side) + c;
+                            if (c + 4 <= side) __builtin_memcpy(dstB, &v[u], 4);
+                            else for (int k = 0; k < side - c; ++k) dstB[k] = (uint8_t)(v[u] >> (8 * k));
+                        }
+                    }
                 }
             }
             wave_sync();
-            if (staged) {
+            if (staged && SMALL) {
+                // lane = (row parity, column): a lane keeps its column's taps and weights in registers and walks every other row
+                const int half = lane >> 5, dx = lane & 31;
+                if (dx < iw) {
+                    const float fx = rfx[dx];
+                    const int sx = rsx[dx], sx1 = rsx1[dx];
+                    const float a0 = 1.f - fx, a1 = fx;
+                    for (int dy = half; dy < ih; dy += 2) {
+                        const float fy = rfy[dy];
+                        const int y0 = __mul24(ry0[dy], side), y1 = __mul24(ry1[dy], side);
+                        const float b0 = 1.f - fy, b1 = fy;
+                        const float r0 = (float)cropB[y0 + sx] * a0 + (float)cropB[y0 + sx1] * a1;
+                        const float r1 = (float)cropB[y1 + sx] * a0 + (float)cropB[y1 + sx1] * a1;
+                        S.img[__mul24(dy, iw) + dx] = r0 * b0 + r1 * b1;
+                    }
+                }
+            } else if (staged) {
                 for (int i = lane; i < npix; i += 64) {
                     const int dy = divw(i), dx = i - __mul24(dy, iw);
                     const float fx = rfx[dx], fy = rfy[dy];
@@ -435,41 +466,54 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(FD_SDM_WPE,
         }
         wave_sync();
         SDM_T(t2);
-        // ---- spatial voting: lane e = (orientation, cell) walks ITS contributing pixels (orientation bit
-        // masks) in the reference's scan order (y outer, x inner) with sequential fp32 adds
-        for (int e = lane; e < ncell * nori * 2; e += 64) {
-            const int o = e / ncell, c = e - o * ncell;
-            const int cy = c / hogW, cx = c - cy * hogW;
+        // ---- spatial voting (hog.c:697-721): lane e = (orientation, cell COLUMN) walks the interior rows once, in the reference's scan
+        // order (y outer, x inner), and carries the accumulators of the two cell rows a pixel row votes into: A = cell row binx[y]
+        // (weight wx1[y]), B = binx[y] + 1 (weight wx2[y]).  binx never decreases and grows by at most one per row, so when it moves
+        // on, A is complete (stored), B becomes A and a fresh B starts.  Every accumulator still receives exactly its own terms
+        // (g * wx) * wy in scan order with sequential fp32 adds -- bit-identical to hog.c -- but the rows are visited once by 2 * nori *
+        // hogW lanes (54 of 64 for the 3 x 3 x 18 descriptor: one pass) instead of three passes of (orientation, cell) lanes over 20
+        // rows each, the row loop is wave-uniform, and g * wx is shared by the two cell rows.  Accumulators of cell rows outside the
+        // descriptor (binx = -1, binx + 1 = hogH) collect terms nobody stores, like the reference's bounds checks drop them.
+        for (int e = lane; e < 2 * nori * hogW; e += 64) {
+            const int o = e / hogW, cx = e - o * hogW;
             const mask_t cm = (mask_t)S.colmask[cx];
-            const int ylo = S.yrange[2 * cy], yhi = S.yrange[2 * cy + 1];
             const float* __restrict__ wxs = S.wsel + cx * m_;
-            const float* __restrict__ wys = S.wsel + cy * m_;
-            float acc = 0.f;
             const int oih = __mul24(o, ih);
-            // software-pipelined: the next row's mask / weight and the next vote's two LDS operands are requested before the current
-            // vote is added (the loads do not depend on the running sum; issued in line they put one LDS round trip on every add)
-            mask_t mkN = ylo < yhi ? (mask_t)(masks[oih + ylo] & cm) : (mask_t)0;
-            float wyN = ylo < yhi ? wys[ylo] : 0.f;
-            for (int y = ylo; y < yhi; ++y) {
-                mask_t mk = mkN;
-                const float wy = wyN;
-                if (y + 1 < yhi) { mkN = masks[oih + y + 1] & cm; wyN = wys[y + 1]; }
+            float* __restrict__ hcol = S.hog + o * ncell + cx;   // + cy * hogW
+            float accA = 0.f, accB = 0.f;
+            int b = binx1;
+            mask_t mkN = ih > 2 ? masks[oih + 1] : (mask_t)0;
+            for (int y = 1; y < ih - 1; ++y) {
+                if (y > 1 && (rowStep >> y & 1ull)) {   // wave-uniform, scalar: binx[y] = binx[y - 1] + 1
+                    if (b >= 0 && b < hogH) hcol[b * hogW] = accA;
+                    accA = accB;
+                    accB = 0.f;
+                    ++b;
+                }
+                const float wyA = S.wx1[y], wyB = S.wx2[y];
+                mask_t mk = mkN & cm;
+                if (y + 1 < ih - 1) mkN = masks[oih + y + 1];   // the next row's mask is requested before this row's votes (and not looked at)
                 if (!mk) continue;
                 const float* __restrict__ grow = S.grad + __mul24(y, iw);
                 int x = (SMALL ? __ffs((int)mk) : __ffsll((long long)mk)) - 1;
                 mk &= mk - 1;
                 float g = grow[x], wx = wxs[x];
-                while (mk) {
+                while (mk) {   // the next vote's two LDS operands are requested before the current vote is added
                     x = (SMALL ? __ffs((int)mk) : __ffsll((long long)mk)) - 1;
                     mk &= mk - 1;
                     const float gn = grow[x], wxn = wxs[x];
-                    acc = acc + g * wx * wy;
+                    const float t = g * wx;
+                    accA = accA + t * wyA;
+                    accB = accB + t * wyB;
                     g = gn;
                     wx = wxn;
                 }
-                acc = acc + g * wx * wy;
+                const float t = g * wx;
+                accA = accA + t * wyA;
+                accB = accB + t * wyB;
             }
-            S.hog[e] = acc;  // layout hog[x + y*hogW + o*hogStride] == e
+            if (b >= 0 && b < hogH) hcol[b * hogW] = accA;
+            if (b + 1 >= 0 && b + 1 < hogH) hcol[(b + 1) * hogW] = accB;
         }
         wave_sync();
         SDM_T(t3);
