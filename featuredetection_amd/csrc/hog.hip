@@ -89,7 +89,7 @@ template <bool FRAG>
 __global__ __launch_bounds__(256) void k_hog_tile(const uint8_t* __restrict__ arena, HogWinTable wt, HogDev hp, HogTables tab,
                                                   int64_t npad, float* __restrict__ feat, float* __restrict__ xx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int B = hp.bins;
     const int C = hp.rows * hp.cols, nblocks = hp.brows * hp.bcols;
     const int WPW = 64 / C;                       // windows per wavefront pass
@@ -139,8 +139,8 @@ __global__ __launch_bounds__(256) void k_hog_tile(const uint8_t* __restrict__ ar
                 const unsigned short* rowp = src + (size_t)y * wl.lw;
                 for (int x = cc0; x < cc1; ++x) {
                     const unsigned int v = rowp[x];
-                    float* hp_ = &hist[(v & 255u) * 64 + lane];
-                    *hp_ = *hp_ + factor * (float)(v >> 8);
+float* hp_ = &hist[(v & 255u) * 64 + lane];
+                    *hp_ = *hp_ + factor * (float)(v >> 8);   // (ds_add_f32 instead of the read-add-write: bit-exact, but 131 against 168 Mpatches/s)
                 }
             }
         }
