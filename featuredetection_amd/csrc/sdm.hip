@@ -25,6 +25,10 @@ namespace {
 constexpr int SDM_IMG = 48;          // max working image side in LDS
 constexpr int SDM_MAX_CELLS = 12;    // per dimension
 constexpr int SDM_MAX_ORI = 16;
+// hog.c:630 tests the fp32 gradient magnitude as a double against 1e-10.  T = (float)1e-10 lies above 1e-10 and the float below it
+// below (T is the nearest float: |T - 1e-10| <= ulp / 2), so (double)g > 1e-10 exactly when g >= T: one fp32 compare
+constexpr float SDM_TINY = 1e-10f;
+static_assert((double)SDM_TINY > 1e-10, "the fp32 form of the 1e-10 test needs (float)1e-10 > 1e-10");
 
 struct DescParams {
     int32_t W, H;              // gray image size
@@ -149,7 +153,7 @@ extern "C" void fd_debug_sdm_prof(unsigned long long* out, int reset) {
 // are reused: the gradient magnitudes overwrite the working image (SMALL: in place, one 64-pixel block behind the
 // block being computed), the features overwrite it once the votes are in, the block factors reuse the orientation masks.
 #ifndef FD_SDM_WPE
-#define FD_SDM_WPE 4
+#define FD_SDM_WPE 5
 #endif
 template <bool SMALL>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(FD_SDM_WPE, 8))) void k_sdm_descriptors(const uint8_t* __restrict__ images, const int32_t* __restrict__ origin,
@@ -214,6 +218,18 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(FD_SDM_WPE,
         S.colmask[c] = mk;
     }
     wave_sync();
+    // where the transposing store (DescriptorExtractor.hpp:198-205) of output element lane + 64 t reads: geometry only, so the two
+    // integer divisions per element are done once per wavefront instead of once per item (descriptors of up to 64 * SDM_ST values)
+    constexpr int SDM_ST = 5;
+    int srcIdx[SDM_ST];
+    const bool stFast = p.dim * ncell <= 64 * SDM_ST;
+#pragma unroll
+    for (int t = 0; t < SDM_ST; ++t) {
+        const int i = lane + 64 * t;
+        const int j = i / ncell, rem = i - j * ncell;
+        const int cc = rem / hogH, r = rem - cc * hogH;
+        srcIdx[t] = i < p.dim * ncell ? j * ncell + r * hogW + cc : -1;
+    }
     // rows at which the cell row index moves on (bit y: binx[y] == binx[y - 1] + 1; it never moves by more), and binx[1]: scalars of the
     // voting loop
     unsigned long long rowStep = 0ull;
@@ -273,35 +289,40 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(FD_SDM_WPE,
             const int cropCap = desc_region_masks(iw, ih, ncell, nori) - 6 * m_ * 4;
             const bool staged = side * side <= cropCap;
             if (staged) {
-                // four bytes per lane and load (a row of the crop is ceil(side / 4) dwords; rows keep their stride of `side` bytes, so a
-                // row's last dword is stored bytewise when side is not a multiple of four): a quarter of the load instructions and of
-                // the index arithmetic of the byte-per-lane form.  Dwords that touch the image border are put together from single bytes
+                // four bytes per lane and load, lane = (row of a group of 64 / ndw rows, dword of the row): the column part of every address
+                // and test is fixed per lane, a load instruction fetches 64 / ndw crop rows (a row of the crop is ndw = ceil(side / 4)
+                // dwords; rows keep their stride of `side` bytes, so a row's last dword is stored bytewise when side is not a multiple of
+                // four): a quarter of the load instructions of the byte-per-lane form and a tenth of its index arithmetic.  Dwords that touch the image border are put together from single bytes
                 // (zero outside, DescriptorExtractor.hpp:156-178)
-                const int ndw = (side + 3) >> 2, nd = __mul24(side, ndw);
-                const float invN = 1.0f / (float)ndw;
+                const int ndw = (side + 3) >> 2;                 // dwords per crop row
+                const int rpi = 64 / ndw;                        // crop rows per load instruction
+                const int lr = (int)(((float)lane + 0.5f) * (1.0f / (float)ndw)), lc = (lane - __mul24(lr, ndw)) << 2;   // this lane's row in the group, byte column
+                const bool act = lr < rpi;
+                const int x = ox + lc;
+                const bool xin = x >= 0 && x + 3 < p.W, whole = lc + 4 <= side;
                 constexpr int CU = 4;
-                for (int d0 = lane; d0 < nd; d0 += 64 * CU) {
+                for (int r0 = lr; r0 < side; r0 += rpi * CU) {   // (lanes behind the last row group leave the loop early: no barrier inside)
                     unsigned int v[CU];
 #pragma unroll
                     for (int u = 0; u < CU; ++u) {
-                        const int d = min(d0 + 64 * u, nd - 1);
-                        const int r = (int)(((float)d + 0.5f) * invN), c = (d - __mul24(r, ndw)) << 2;
-                        const int x = ox + c, y = oy + r;
-                        if ((unsigned)y < (unsigned)p.H && x >= 0 && x + 3 < p.W) {
-                            __builtin_memcpy(&v[u], img + (unsigned int)(__mul24(y, p.W) + x), 4);
-                        } else {
-                            auto px = [&](int xx) -> unsigned int { return ((unsigned)xx < (unsigned)p.W && (unsigned)y < (unsigned)p.H) ? (unsigned int)img[(unsigned int)(__mul24(y, p.W) + xx)] : 0u; };
-                            v[u] = px(x) | (px(x + 1) << 8) | (px(x + 2) << 16) | (px(x + 3) << 24);
+                        const int r = r0 + u * rpi, y = oy + r;
+                        v[u] = 0u;
+                        if (act && r < side) {
+                            if (xin && (unsigned)y < (unsigned)p.H) {
+                                __builtin_memcpy(&v[u], img + (unsigned int)(__mul24(y, p.W) + x), 4);
+                            } else {
+                                auto px = [&](int xx) -> unsigned int { return ((unsigned)xx < (unsigned)p.W && (unsigned)y < (unsigned)p.H) ? (unsigned int)img[(unsigned int)(__mul24(y, p.W) + xx)] : 0u; };
+                                v[u] = px(x) | (px(x + 1) << 8) | (px(x + 2) << 16) | (px(x + 3) << 24);
+                            }
                         }
                     }
 #pragma unroll
                     for (int u = 0; u < CU; ++u) {
-                        const int d = d0 + 64 * u;
-                        if (d < nd) {
-                            const int r = (int)(((float)d + 0.5f) * invN), c = (d - __mul24(r, ndw)) << 2;
-                            uint8_t* dstB = cropB + __mul24(r, side) + c;
-                            if (c + 4 <= side) __builtin_memcpy(dstB, &v[u], 4);
-                            else for (int k = 0; k < side - c; ++k) dstB[k] = (uint8_t)(v[u] >> (8 * k));
+                        const int r = r0 + u * rpi;
+                        if (act && r < side) {
+                            uint8_t* dstB = cropB + __mul24(r, side) + lc;
+                            if (whole) __builtin_memcpy(dstB, &v[u], 4);
+                            else for (int k = 0; k < side - lc; ++k) dstB[k] = (uint8_t)(v[u] >> (8 * k));
                         }
                     }
                 }
@@ -377,7 +398,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(FD_SDM_WPE,
                 // that leads by more than 4e-6 of its score is the reference's winner.  Anything closer, a zero or a tiny gradient takes
                 // the exact path below (nine normalised scores in order, ties to the first): the two IEEE divisions and six of the nine
                 // evaluations are gone for all but a handful of pixels.
-                exact = !((double)grad > 1e-10);
+                exact = !(grad >= SDM_TINY);
                 if (grad2 > 0.f && !exact) {
                     const float ax = fabsf(gradx), ay = fabsf(grady);
                     const float d = ay * __builtin_amdgcn_rcpf(ax + ay);
@@ -397,7 +418,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(FD_SDM_WPE,
             }
             if (exact) {
                 b0 = -1;
-                if ((double)grad > 1e-10) {
+                if (grad >= SDM_TINY) {
                     // (float)((double)a / (double)b) == a / b for fp32 a, b: rounding the fp64 quotient (53 >= 2 * 24 + 2 bits) to
                     // fp32 cannot double-round, and the device's fp32 division is correctly rounded
                     gradx = gradx / grad;
@@ -576,6 +597,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(FD_SDM_WPE,
         wave_sync();
         SDM_T(t4);
         // ---- per-plane transpose and stack (DescriptorExtractor.hpp:198-205): out[j][c][r] = feat[j][r][c]
+        if (stFast) {
+#pragma unroll
+            for (int t = 0; t < SDM_ST; ++t)
+                if (srcIdx[t] >= 0) dst[lane + 64 * t] = S.feat[srcIdx[t]];
+        } else
         for (int i = lane; i < dim * ncell; i += 64) {
             const int j = i / ncell, rem = i - j * ncell;
             const int cc = rem / hogH, r = rem - cc * hogH;

@@ -28,8 +28,10 @@ if [ "$WHAT" = stats ] || [ "$WHAT" = all ]; then
   done
 fi
 if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
-  for wl in cascade cascade_late cascade_group; do
+  [ -f $O/r05_pmc.json ] || cp $R/profiles/r05_pmc.json $O/r05_pmc.json 2>/dev/null   # (a partial re-run keeps the other workloads' entries)
+  for wl in ${PMC_WLS:-cascade cascade_late cascade_group sdm}; do
     S=3; FP="--frames-per-step 64"
+    [ $wl = sdm ] && FP="--frames-per-step 4"
     CMD="$B --workload $wl --also none --steps $S --warmup 1 $FP --no-cpu-baseline --no-probe"
     i=0
     for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" \
@@ -39,6 +41,7 @@ if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
       timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc_${wl}_$i -- $CMD > /dev/null 2> $O/pmc_${wl}_$i.err
     done
     K=k_wv,k_resize,k_pyrdown,k_frames_to_gray,k_svm_u8,k_fs_oe
+    [ $wl = sdm ] && K=k_sdm_descriptors,k_sdm
     python $R/tools/pmc_summary.py $wl $O/r05_pmc.json $K "rocprofv3 --kernel-trace --pmc <group> (4 separate passes) -- python bench.py --workload $wl --also none --steps $S --warmup 1 $FP --no-cpu-baseline --no-probe; git head $HEAD" $O/pmc_${wl}_1 $O/pmc_${wl}_2 $O/pmc_${wl}_3 $O/pmc_${wl}_4 > $O/pmc_$wl.summary 2>&1
     rm -rf $O/pmc_${wl}_1 $O/pmc_${wl}_2 $O/pmc_${wl}_3 $O/pmc_${wl}_4
   done
