@@ -127,13 +127,15 @@ static int launch_ranks(int gpus, int argc, char** argv, const std::vector<char*
 
 int main(int argc, char** argv) {
     int gpus = 0;
+    string patchFile;   // --patches <file>: Detector::keepPatchData(true); every printed detection's patch (rows, cols, type as int32 + the pixels) is appended (one image)
     std::vector<char*> args;   // argv without --gpus N
     for (int a = 0; a < argc; ++a) {
         if (string(argv[a]) == "--gpus" && a + 1 < argc) { gpus = std::atoi(argv[++a]); continue; }
+        if (string(argv[a]) == "--patches" && a + 1 < argc) { patchFile = argv[++a]; continue; }
         args.push_back(argv[a]);
     }
     if ((int)args.size() < 3 || (gpus != 0 && (gpus < 1 || gpus > 64 || args.size() < 4))) {
-        std::fprintf(stderr, "usage: %s [--gpus N] <config.cfg> <image.ppm|pgm> [more images of a sequence ...]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s [--gpus N] [--patches <file>] <config.cfg> <image.ppm|pgm> [more images of a sequence ...]\n", argv[0]);
         return 2;
     }
     const char* rankEnv = std::getenv("FD_DIST_RANK");
@@ -272,12 +274,27 @@ int main(int argc, char** argv) {
             return 0;
         }
         cv::Mat img = read_pnm(argv[2]);
+        std::FILE* pf = nullptr;
+        if (!patchFile.empty()) {
+            pf = std::fopen(patchFile.c_str(), "wb");
+            if (!pf) throw std::invalid_argument("cannot write " + patchFile);
+            for (auto& d : faceDetectors) d.second->keepPatchData(true);
+            for (auto& d : featureDetectors) d.second->keepPatchData(true);
+        }
+        auto dumpPatch = [&](const ClassifiedPatch& p) {
+            if (!pf) return;
+            const cv::Mat& m = p.getPatch()->getData();
+            const int32_t hdr[3] = {m.rows, m.cols, m.type()};
+            std::fwrite(hdr, sizeof(hdr), 1, pf);
+            for (int r = 0; r < m.rows; ++r) std::fwrite(m.ptr<unsigned char>(r), m.elemSize(), (size_t)m.cols, pf);
+        };
         std::vector<shared_ptr<ClassifiedPatch>> facePatches;
         for (auto& d : faceDetectors) {
             facePatches = d.second->detect(img);
             for (const auto& p : facePatches) {
                 cv::Rect b = p->getPatch()->getBounds();
                 std::printf("%s %s %d %d %d %d %.17g\n", d.first.c_str(), d.second->landmark.c_str(), b.x, b.y, b.width, b.height, p->getProbability());
+                dumpPatch(*p);
             }
         }
         // the reference dereferences facePatches[0] unchecked (ffpDetectApp.cpp:591); here feature detectors are skipped without a face
@@ -288,9 +305,11 @@ int main(int argc, char** argv) {
                 for (const auto& p : res) {
                     cv::Rect b = p->getPatch()->getBounds();
                     std::printf("%s %s %d %d %d %d %.17g\n", d.first.c_str(), d.second->landmark.c_str(), b.x, b.y, b.width, b.height, p->getProbability());
+                    dumpPatch(*p);
                 }
             }
         }
+        if (pf) std::fclose(pf);
     } catch (const std::invalid_argument& e) {
         std::fprintf(stderr, "invalid argument: %s\n", e.what());
         return 1;

@@ -35,6 +35,15 @@ public:
     virtual std::vector<std::shared_ptr<ClassifiedPatch>> detect(const cv::Mat& image, const cv::Rect& roi) = 0;
     virtual std::vector<std::shared_ptr<ClassifiedPatch>> detect(std::shared_ptr<imageprocessing::VersionedImage> image) = 0;
     std::string landmark;
+    // Backend extension.  On the fused paths the patches' pixels never leave the GPU: a returned patch carries its geometry and
+    // probability, getPatch()->getData() is empty.  keepPatchData(true): every patch a detect() call RETURNS is extracted once more
+    // through the feature extractor's single-patch path (PyramidFeatureExtractor::extract(x, y, width, height): the layer comes to
+    // the host once per image, the patch filters run per Mat), so getData() holds what the reference's patch holds (Patch.hpp:28-243).
+    void keepPatchData(bool keep) { patchData = keep; }
+    bool keepsPatchData() const { return patchData; }
+protected:
+    void fillPatchData(const imageprocessing::PyramidFeatureExtractor& extractor, std::vector<std::shared_ptr<ClassifiedPatch>>& patches) const;
+    bool patchData = false;
 };
 
 // OverlapElimination.hpp:45-55 / OverlapElimination.cpp:44-105
@@ -103,6 +112,7 @@ public:
     int getStepSizeY() const { return stepSizeY; }
 private:
     std::vector<std::shared_ptr<ClassifiedPatch>> detect(const cv::Rect* roi) const;
+    std::vector<std::shared_ptr<ClassifiedPatch>> detectWindows(const cv::Rect* roi) const;
     std::shared_ptr<classification::ProbabilisticClassifier> classifier;
     std::shared_ptr<imageprocessing::PyramidFeatureExtractor> featureExtractor;
     int stepSizeX, stepSizeY;

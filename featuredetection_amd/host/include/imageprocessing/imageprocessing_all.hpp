@@ -408,6 +408,7 @@ private:
     std::shared_ptr<ConversionFilter> conversion;
     std::shared_ptr<ReshapingFilter> reshaping;
     int whiStage = 0;   // number of whi chain filters added so far (in order)
+    std::shared_ptr<ChainedFilter> chain = std::make_shared<ChainedFilter>();   // every patch filter in the order added: the per-Mat form of extract(x, y, w, h) / extract(layer, x, y)
 };
 
 // FilteringPyramidFeatureExtractor.hpp:20-90 -- applies additional patch filters to the patches of another pyramid feature

@@ -462,6 +462,7 @@ void DirectPyramidFeatureExtractor::addPatchFilter(shared_ptr<ImageFilter> filte
     if (auto rf = std::dynamic_pointer_cast<ReshapingFilter>(filter)) {   // the fused kernels work on flat vectors: nothing to do
         if (rf->rows != 1 || rf->channels > 1) throw std::logic_error("DirectPyramidFeatureExtractor: ReshapingFilter(1) (row vectors) is available in a fused chain");
         reshaping = rf;
+        chain->add(filter);
         return;
     }
     if (auto h = std::dynamic_pointer_cast<HistEq64Filter>(filter)) histeq = h;
@@ -475,6 +476,7 @@ void DirectPyramidFeatureExtractor::addPatchFilter(shared_ptr<ImageFilter> filte
     } else if (auto cf = std::dynamic_pointer_cast<ConversionFilter>(filter)) {
         if (whiStage == 0 && !hist && cf->type == CV_32F) {   // u8 feature space -> f32 (input of an RVM / f32 SVM)
             conversion = cf;
+            chain->add(filter);
             return;
         }
         if (whiStage != 2 || cf->type != CV_32F || cf->alpha != 1.0 / 127.5 || cf->beta != -1.0)
@@ -491,6 +493,7 @@ void DirectPyramidFeatureExtractor::addPatchFilter(shared_ptr<ImageFilter> filte
         // the tuned k_hog_tile path covers the square, non-interpolating HogFilter; everything else runs k_hist_features
         hog = (g && !g->interpolate && g->cellWidth == g->cellHeight && g->blockWidth == g->blockHeight) ? g : nullptr;
     } else throw std::logic_error("DirectPyramidFeatureExtractor: unsupported patch filter (HistEq64Filter and the HistogramFilter family are available)");
+    chain->add(filter);
 }
 vector<cv::Size> DirectPyramidFeatureExtractor::getPatchSizes() const {
     vector<cv::Size> sizes;
@@ -509,8 +512,7 @@ shared_ptr<Patch> DirectPyramidFeatureExtractor::extractFromLayer(const ImagePyr
     int ow = layer.getOriginal(b.width), oh = layer.getOriginal(b.height);
     int ox = layer.getOriginal(b.x) + ow / 2, oy = layer.getOriginal(b.y) + oh / 2;
     Mat data = Mat(image, b).clone();
-    if (histeq) data = histeq->applyTo(data);
-    if (hist) throw std::logic_error("DirectPyramidFeatureExtractor: single-patch extraction with a histogram filter is not available; use extract(stepX, stepY)");
+    if (hasPatchFilters()) data = chain->applyTo(data);   // per Mat, in the order the filters were added (DirectPyramidFeatureExtractor.cpp:75-123)
     return make_shared<Patch>(ox, oy, ow, oh, data);
 }
 shared_ptr<Patch> DirectPyramidFeatureExtractor::extract(int x, int y, int width, int height) const {
@@ -1175,7 +1177,20 @@ SlidingWindowDetector::SlidingWindowDetector(shared_ptr<classification::Probabil
                                              shared_ptr<imageprocessing::PyramidFeatureExtractor> featureExtractor, int sx, int sy)
     : classifier(classifier), featureExtractor(featureExtractor), stepSizeX(sx), stepSizeY(sy) {}
 
+void Detector::fillPatchData(const imageprocessing::PyramidFeatureExtractor& extractor, vector<shared_ptr<ClassifiedPatch>>& patches) const {
+    for (auto& cp : patches) {
+        auto p = cp->getPatch();
+        if (!p || !p->getData().empty()) continue;
+        auto q = extractor.extract(p->getX(), p->getY(), p->getWidth(), p->getHeight());
+        if (q) p->getData() = q->getData();
+    }
+}
 vector<shared_ptr<ClassifiedPatch>> SlidingWindowDetector::detect(const cv::Rect* roi) const {
+    auto out = detectWindows(roi);
+    if (patchData) fillPatchData(*featureExtractor, out);
+    return out;
+}
+vector<shared_ptr<ClassifiedPatch>> SlidingWindowDetector::detectWindows(const cv::Rect* roi) const {
     vector<shared_ptr<ClassifiedPatch>> out;
     auto direct = std::dynamic_pointer_cast<DirectPyramidFeatureExtractor>(featureExtractor);
     if (auto filtering = std::dynamic_pointer_cast<imageprocessing::FilteringPyramidFeatureExtractor>(featureExtractor))
@@ -1318,6 +1333,7 @@ vector<shared_ptr<ClassifiedPatch>> FiveStageSlidingWindowDetector::run(const Ma
     check(rc);
     vector<shared_ptr<ClassifiedPatch>> out;
     for (int i = 0; i < cnt; ++i) out.push_back(to_patch(dets[i]));
+    if (patchData) fillPatchData(*slidingWindowDetector->getPyramidFeatureExtractor(), out);   // the patches of the shared extractor (FiveStageSlidingWindowDetector.cpp:187-380)
     return out;
 }
 FiveStageSlidingWindowDetector::~FiveStageSlidingWindowDetector() { if (framesPyramid) fd_pyramid_destroy(framesPyramid); }
@@ -1336,7 +1352,8 @@ vector<vector<shared_ptr<ClassifiedPatch>>> FiveStageSlidingWindowDetector::dete
         while (j < images.size() && j - i < 64 && images[j].rows == images[i].rows && images[j].cols == images[i].cols && images[j].type() == images[i].type()) ++j;
         const int n = (int)(j - i);
         const int ch = images[i].channels();
-        bool fused = direct && pwvm && psvm && direct->hasHistEq64() && n > 1 && images[i].depth() == CV_8U && (ch == 1 || ch == 3);
+        // (keepPatchData: the patches are cut from the extractor's own pyramid, which the multi-frame path never fills: one image at a time)
+        bool fused = !patchData && direct && pwvm && psvm && direct->hasHistEq64() && n > 1 && images[i].depth() == CV_8U && (ch == 1 || ch == 3);
         if (fused && (!framesPyramid || framesCount != n)) {
             if (framesPyramid) { fd_pyramid_destroy(framesPyramid); framesPyramid = nullptr; }
             framesPyramid = direct->getPyramid()->createFramesPyramid(n);

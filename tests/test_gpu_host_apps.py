@@ -55,6 +55,20 @@ FACE_CFG = """detectors
 """
 
 
+def _read_patches(path):
+    """the file ffp_detect_app --patches writes: per printed detection rows, cols, type (int32) + the pixels of getPatch()->getData()"""
+    raw = open(path, "rb").read()
+    out, k = [], 0
+    while k < len(raw):
+        rows, cols, typ = np.frombuffer(raw, np.int32, 3, k)
+        k += 12
+        dt = {0: np.uint8, 5: np.float32}[int(typ) & 7]   # CV_8U / CV_32F, one channel
+        n = int(rows) * int(cols) * np.dtype(dt).itemsize
+        out.append(np.frombuffer(raw, dt, int(rows) * int(cols), k).reshape(int(rows), int(cols)).copy())
+        k += n
+    return out
+
+
 def test_ffp_detect_app_matches_oracle(tmp_path, oracle, synth, frame640, small_models):
     app = os.path.join(PKG, "ffp_detect_app")
     if not os.path.exists(app):
@@ -76,6 +90,15 @@ def test_ffp_detect_app_matches_oracle(tmp_path, oracle, synth, frame640, small_
         # Patch::getBounds (Patch.hpp:28-35)
         assert [int(v) for v in g[2:6]] == [d["cx"] - d["w"] // 2, d["cy"] - d["h"] // 2, d["w"], d["h"]]
         assert float(g[6]) == d["prob"]
+    # Detector::keepPatchData(true) (--patches): the same detections, and every returned patch carries the pixels the reference's patch
+    # carries -- the HistEq64-filtered 20x20 cut of its pyramid layer (Patch.hpp:28-243, DirectPyramidFeatureExtractor.cpp:75-123)
+    out2 = _run([app, "--patches", str(tmp_path / "patches.bin"), str(tmp_path / "face.cfg"), str(tmp_path / "frame.ppm")])
+    assert out2 == out
+    patches = _read_patches(str(tmp_path / "patches.bin"))
+    assert len(patches) == len(dets)
+    for pt, d in zip(patches, dets):
+        lp, lx, ly = oracle.extract_single(po, 20, 20, d["cx"], d["cy"], d["w"], d["h"])[:3]
+        assert pt.dtype == np.uint8 and np.array_equal(pt, oracle.histeq64(np.ascontiguousarray(po.layer(lp)[ly:ly + 20, lx:lx + 20])))
 
 
 
@@ -354,6 +377,16 @@ def test_ffp_detect_app_single_detector_feature_spaces(tmp_path, oracle, synth, 
         lp, lx, ly, cx, cy, ow, oh = [int(v) for v in wins[i]]
         assert [int(v) for v in g[2:6]] == [cx - ow // 2, cy - oh // 2, ow, oh]
         assert abs(float(g[6]) - so.probability(do[i])) <= 1e-6
+    # --patches: the patch of every detection after the feature space's filter chain, composed per Mat
+    out2 = _run([app, "--patches", str(tmp_path / "patches.bin"), str(tmp_path / "c.cfg"), str(tmp_path / "frame.ppm")])
+    assert out2 == out
+    patches = _read_patches(str(tmp_path / "patches.bin"))
+    assert len(patches) == len(pos)
+    for pt, i in zip(patches, pos):
+        if feature == "whi":
+            assert pt.dtype == np.float32 and np.allclose(pt.ravel(), feats[i], rtol=1e-6, atol=1e-9)
+        else:
+            assert pt.dtype == np.uint8 and np.array_equal(pt.ravel(), feats[i])
 
 def test_sdm_fit_app_matches_oracle(tmp_path, oracle, synth):
     app = os.path.join(PKG, "sdm_fit_app")
