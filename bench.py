@@ -936,7 +936,7 @@ class Sdm(Workload):
         self.sdm = capi.Sdm(env.ctx, self.model)
         # fd_sdm_fit_batch_begin / _end: ONE host thread keeps a few batches queued (each ticket has its own scratch set, consecutive
         # tickets alternate between two streams); FD_BENCH_SDM_INFLIGHT sets how many
-        self.inflight = max(1, int(os.environ.get("FD_BENCH_SDM_INFLIGHT", "3")))
+        self.inflight = max(1, int(os.environ.get("FD_BENCH_SDM_INFLIGHT", "4")))
         self.boxes = np.array([[48, 48, 160, 160]] * self.B, np.int32)
         self.metric = "SDM iters/s (x1e6): 68 landmarks, HOG at each point + linear regressor, 4 cascade steps, batch of 256 face crops"
         self.config = dict(workload="config 4: 256 gray 256x256 crops, 68 landmarks, 4 cascade steps, adaptive VlHog 3x3x31 per landmark + regressor "
