@@ -743,6 +743,24 @@ def test_sdm_descriptors_bit_exact(oracle, capi, ctx, synth):
     assert np.array_equal(dg, do)
 
 
+@pytest.mark.parametrize("geometry", [(4, 10, 9, 1), (6, 8, 5, 0), (2, 20, 9, 1), (5, 6, 16, 0), (1, 4, 9, 1), (3, 16, 9, 1)])
+def test_sdm_descriptors_of_every_working_image_shape(oracle, capi, ctx, synth, geometry):
+    """The extractor's own geometry (non-adaptive: VlHogDescriptorExtractor(numCells, cellSize, numBins), DescriptorExtractor.hpp:128-215)
+    on the shapes the adaptive 30x30 image never reaches: working images of 40 and 48 pixels (64-bit orientation masks, magnitudes in
+    their own LDS block, the generic resize-free path), cells of 20 pixels, 16 orientations, one cell -- the
+    voting by (orientation, cell column) lanes with sliding cell-row accumulators has to give hog.c's sums on all of them."""
+    nc, cs, nb, variant = geometry
+    gray = synth.make_frame(256, 256, seed=23, channels=1)
+    rng = np.random.default_rng(5)
+    half = nc * (cs // 2)
+    px = rng.uniform(half + 2, 253 - half, 24).astype(np.float32)
+    py = rng.uniform(half + 2, 253 - half, 24).astype(np.float32)
+    do = oracle.sdm_descriptors(gray, px, py, 0, variant=variant, num_cells=nc, cell_size=cs, num_bins=nb)
+    assert do is not None
+    dg = capi.sdm_descriptors(ctx, gray, px, py, 0, variant=variant, num_cells=nc, cell_size=cs, num_bins=nb)
+    assert dg.shape == do.shape and np.array_equal(dg, do), geometry
+
+
 def test_sdm_fit_batch(oracle, capi, ctx, synth):
     """68 landmarks, 4 cascade steps (BASELINE config 4 shape, reduced batch).  Landmarks within 1e-4 relative."""
     model = synth.make_sdm(9, L=68, S=4)
