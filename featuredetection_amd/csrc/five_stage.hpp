@@ -160,6 +160,10 @@ static bool fst_possible(const fd_wvm* m, const fd_svm* svm, int nimg) {
     if (mode == 0 || (mode != 1 && nimg < 2)) return false;
     return m->wvbOk && m->dev.numUsed > WVM_LCAP && fd_svm_u8_mfma_available(svm);
 }
+static bool spec_possible(const fd_wvm* m, const fd_svm* svm) {
+    static const bool off = [] { const char* e = getenv("FD_FS_SPEC"); return e && atoi(e) == 0; }();
+    return !off && m->wvbOk && m->dev.numUsed > WVM_LCAP && fd_svm_u8_mfma_available(svm);
+}
 static size_t fst_host_offsets(int nimg, int64_t cap, size_t& keepOff, size_t& distOff) {
     keepOff = (16 + sizeof(FstFrame) * (size_t)nimg + 15) & ~(size_t)15;
     distOff = (keepOff + sizeof(FstKeep) * (size_t)cap + 15) & ~(size_t)15;
@@ -274,7 +278,21 @@ int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const f
         // the device where the model allows (fs_tail.hpp): one wait instead of two round trips
         WvmRun run;
         m->tailWanted = fst_possible(m, svm, 1);
+        // One frame without the device tail: the SVM scores of ALL its WVM positives (~150) are queued straight behind the cascade -- the
+        // positive count stays on the device (CascadeOut::tail_count), the kernel covers twice the previous frame's count -- and the host
+        // waits ONCE, then eliminates overlaps and looks the survivors' scores up.  A patch's score does not depend on what else is in
+        // the launch, so the detections are the ones of the two-round-trip order (host elimination, then the survivors' SVM launch),
+        // which stays the path of a frame with more positives than the launch covered, of a stage-B rerun, and of FD_FS_SPEC=0.
+        m->specWanted = !m->tailWanted && spec_possible(m, svm);
         fd_wvm_launch(ctx, p, m, sx, sy, roi, false, run, ctx->kernel_timing);
+        if (m->specRun) {
+            int64_t nmax = m->specPrev >= 0 ? m->specPrev * 2 + 64 : 1024;
+            nmax = std::min<int64_t>(std::max<int64_t>(nmax, 64), m->pos_cap);
+            m->h_spec.reserve(sizeof(double) * (size_t)nmax);
+            m->specLaunched = nmax;
+            fd_svm_u8_mfma_launch_counted(ctx->stream, svm, m->pos_patches.p, nullptr, (int64_t)m->dev.d, nmax, m->specCnt.as<unsigned int>(), m->h_spec.as<double>());
+            HIP_CHECK(hipEventRecord(m->done, ctx->stream));   // fd_wvm_finish's wait now covers the scores too
+        }
         if (m->tailRun) {
             fst_launch(ctx, ctx->stream, p, m, svm, run, oe_dist, oe_ratio, sx, sy);
             FstResult R;
@@ -297,6 +315,29 @@ int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const f
             run.timed = false;   // read above
         }
         fd_wvm_finish(ctx, m, run);
+        if (m->specRun && (int64_t)run.pos.size() <= m->specLaunched) {
+            m->specPrev = (int64_t)run.pos.size();
+            std::vector<fd_detection> wvmPos, svmPos;
+            std::vector<int> keep;
+            fd_wvm_positives_to_detections(p, m, run, sx, sy, wvmPos);
+            if (stage_counts) stage_counts[0] = (int)wvmPos.size();
+            fd_host_overlap_elimination(wvmPos.data(), (int)wvmPos.size(), oe_dist, oe_ratio, keep);
+            if (stage_counts) stage_counts[1] = (int)keep.size();
+            const double* dist = m->h_spec.as<double>();
+            for (size_t i = 0; i < keep.size(); ++i) {
+                const double dv = dist[run.slots[keep[i]]];
+                if (dv >= (double)fd_svm_threshold(svm)) {   // strongClassifier->classify(): bool only
+                    fd_detection d = wvmPos[keep[i]];
+                    d.score = (float)dv;
+                    d.positive = 1;
+                    d.probability = 0.5;   // ClassifiedPatch(patch, bool) default probability (ClassifiedPatch.hpp:29-30)
+                    svmPos.push_back(d);
+                }
+            }
+            five_stage_nms(p, roi, svmPos, out, cap, count, stage_counts);
+            return;
+        }
+        if (m->specRun) m->specPrev = (int64_t)run.pos.size();
         five_stage_tail(ctx, p, m, svm, run, oe_dist, oe_ratio, sx, sy, roi, ctx->stream, out, cap, count, stage_counts);
     });
 }

@@ -184,6 +184,13 @@ struct fd_wvm {
     int64_t fstPrevKeep = -1;        // survivors of the previous run (sizes the next SVM launch)
     int fstFrames = 0;
     bool fstDirty = false;           // a cascade with the device tail was queued and k_fs_oe (which clears the tail's counters) not yet
+    // single-frame five-stage calls: the SVM scores of ALL WVM positives queued straight behind the cascade (five_stage.hpp, "spec")
+    bool specWanted = false;         // set by fd_detect_five_stage before the launch
+    bool specRun = false;            // the run in flight leaves its positive count on the device for the SVM launch behind it
+    DevBuf specCnt;                  // that count (written by the last stage-B workgroup: CascadeOut::tail_count)
+    HostBuf h_spec;                  // pinned: the distances, by positive slot
+    int64_t specLaunched = 0;        // slots the SVM launch of the run in flight covers
+    int64_t specPrev = -1;           // positives of the previous run (sizes the next launch)
     int fstLastState = -1;           // measurement / test hook: -1 no device tail in the last run, else the flags it ended with (0: its results were used)
     ~fd_wvm() { if (done) (void)hipEventDestroy(done); if (tailDone) (void)hipEventDestroy(tailDone); if (prep) (void)hipEventDestroy(prep); }
 };
@@ -1489,6 +1496,9 @@ static bool wvm_launch_head(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const WinTab
     const bool tailWanted = m->tailWanted;
     m->tailWanted = false;
     m->tailRun = false;
+    const bool specWanted = m->specWanted;
+    m->specWanted = false;
+    m->specRun = false;
     m->fstLastState = -1;
     if (wt.total == 0) return false;
     if (want_all) {
@@ -1548,6 +1558,11 @@ static bool wvm_launch_head(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const WinTab
         o.frame_n = (unsigned int)nimg;
         o.frame_per_image = (unsigned int)(wt.total / nimg);
         o.frame_magic = o.frame_per_image ? 0xffffffffu / o.frame_per_image : 0u;
+    }
+    m->specRun = specWanted && !m->tailRun && zc && m->wvbOk;
+    if (m->specRun) {   // no clearing: every run that ends in stage B writes the word before anything behind it on the stream reads it
+        m->specCnt.reserve(16);
+        o.tail_count = m->specCnt.as<unsigned int>();
     }
     o.pos_patches = m->pos_patches.as<uint8_t>();
     o.pos_count = m->pos.as<unsigned int>();        // header word 0
@@ -1648,6 +1663,7 @@ void fd_wvm_finish(fd_ctx* ctx, fd_wvm* m, WvmRun& run) {
         const int64_t deep = (int64_t)hraw[0].wid_hi;
         WvbRelaunch* R = static_cast<WvbRelaunch*>(m->relaunch.get());
         m->sbGrown = deep + deep / 8 + 64;
+        m->specRun = false;   // the scores queued behind the first run belong to its positives, not to the rerun's
         wvb_reserve(m, run.total, m->sbGrown);
         if (deep <= m->deepCap) {
             const uint32_t hdr[4] = {0u, (uint32_t)deep, 0u, 0u};   // positives 0, queue length, pre-filter queue, retired workgroups
