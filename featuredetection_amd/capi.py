@@ -227,6 +227,7 @@ _BENCH_SIGS = {
     "fd_debug_wvb_rect_sums": (C.c_int64, [C.POINTER(fd_wvm_model), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "fd_wvm_last_queue_length": (C.c_int64, [C.c_void_p]),
     "fd_wvm_last_tail_state": (C.c_int, [C.c_void_p]),
+    "fd_wvm_last_spec_state": (C.c_int, [C.c_void_p]),
     "fd_wvm_last_stage_b_plan": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fd_debug_wvd_plan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
@@ -440,6 +441,11 @@ class Wvm:
         out = np.full(10, -1, np.int64)
         lib().fd_wvm_last_stage_b_plan(self.h, _ptr(out))
         return [(int(out[1 + 3 * i]), int(out[2 + 3 * i]), int(out[3 + 3 * i])) for i in range(max(0, int(out[0])))]
+
+    def last_spec_state(self):
+        """test hook: -1 the survivors' SVM launch of its own, 0 the scores of all positives queued behind the cascade were used, 1 queued
+        but not usable: fell back (fd_hip_bench.h)"""
+        return int(lib().fd_wvm_last_spec_state(self.h))
 
     def last_tail_state(self):
         """test hook: -1 overlap elimination on the host, 0 on the device, > 0 the device kernel gave up (fd_hip_bench.h)"""

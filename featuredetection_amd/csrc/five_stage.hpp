@@ -161,7 +161,8 @@ static bool fst_possible(const fd_wvm* m, const fd_svm* svm, int nimg) {
     return m->wvbOk && m->dev.numUsed > WVM_LCAP && fd_svm_u8_mfma_available(svm);
 }
 static bool spec_possible(const fd_wvm* m, const fd_svm* svm) {
-    static const bool off = [] { const char* e = getenv("FD_FS_SPEC"); return e && atoi(e) == 0; }();
+    const char* e = getenv("FD_FS_SPEC");   // read per call: the tests compare both orders
+    const bool off = e && atoi(e) == 0;
     return !off && m->wvbOk && m->dev.numUsed > WVM_LCAP && fd_svm_u8_mfma_available(svm);
 }
 static size_t fst_host_offsets(int nimg, int64_t cap, size_t& keepOff, size_t& distOff) {
@@ -284,7 +285,9 @@ int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const f
         // the launch, so the detections are the ones of the two-round-trip order (host elimination, then the survivors' SVM launch),
         // which stays the path of a frame with more positives than the launch covered, of a stage-B rerun, and of FD_FS_SPEC=0.
         m->specWanted = !m->tailWanted && spec_possible(m, svm);
+        m->specLastState = -1;
         fd_wvm_launch(ctx, p, m, sx, sy, roi, false, run, ctx->kernel_timing);
+        const bool specQueued = m->specRun;
         if (m->specRun) {
             int64_t nmax = m->specPrev >= 0 ? m->specPrev * 2 + 64 : 1024;
             nmax = std::min<int64_t>(std::max<int64_t>(nmax, 64), m->pos_cap);
@@ -315,8 +318,10 @@ int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const f
             run.timed = false;   // read above
         }
         fd_wvm_finish(ctx, m, run);
+        if (specQueued) m->specLastState = 1;
         if (m->specRun && (int64_t)run.pos.size() <= m->specLaunched) {
             m->specPrev = (int64_t)run.pos.size();
+            m->specLastState = 0;
             std::vector<fd_detection> wvmPos, svmPos;
             std::vector<int> keep;
             fd_wvm_positives_to_detections(p, m, run, sx, sy, wvmPos);
@@ -337,7 +342,7 @@ int fd_detect_five_stage(fd_ctx* ctx, fd_pyramid* p, const fd_wvm* wvm_, const f
             five_stage_nms(p, roi, svmPos, out, cap, count, stage_counts);
             return;
         }
-        if (m->specRun) m->specPrev = (int64_t)run.pos.size();
+        if (specQueued) m->specPrev = (int64_t)run.pos.size();
         five_stage_tail(ctx, p, m, svm, run, oe_dist, oe_ratio, sx, sy, roi, ctx->stream, out, cap, count, stage_counts);
     });
 }

@@ -191,6 +191,7 @@ struct fd_wvm {
     HostBuf h_spec;                  // pinned: the distances, by positive slot
     int64_t specLaunched = 0;        // slots the SVM launch of the run in flight covers
     int64_t specPrev = -1;           // positives of the previous run (sizes the next launch)
+    int specLastState = -1;          // test hook (fd_wvm_last_spec_state)
     int fstLastState = -1;           // measurement / test hook: -1 no device tail in the last run, else the flags it ended with (0: its results were used)
     ~fd_wvm() { if (done) (void)hipEventDestroy(done); if (tailDone) (void)hipEventDestroy(tailDone); if (prep) (void)hipEventDestroy(prep); }
 };
@@ -2030,6 +2031,7 @@ int fd_debug_wvd_prof(unsigned long long* out, int nwaves) {
 // Measurement hook (include/fd_hip_bench.h): windows the last finished run of this handle queued for stage B (-1: none yet)
 int64_t fd_wvm_last_queue_length(const fd_wvm* m) { return m ? m->sbDeep : -1; }
 int fd_wvm_last_tail_state(const fd_wvm* m) { return m ? m->fstLastState : -1; }
+int fd_wvm_last_spec_state(const fd_wvm* m) { return m ? m->specLastState : -1; }
 int fd_wvm_last_stage_b_plan(const fd_wvm* m, int64_t* out) {
     if (!m || !out) return FD_ERR_INVALID_ARGUMENT;
     const int n = std::min(m->sbLastN, 3);

@@ -27,6 +27,11 @@ int fd_wvm_last_stage_b_plan(const fd_wvm* wvm, int64_t* out);
  * proven to be the reference's (tied or saturated probabilities), 2 more positives in a frame than the kernel holds, 4 window ids
  * beyond 32 bits, 0x100 stage-B queue / positive buffer overflow. */
 int fd_wvm_last_tail_state(const fd_wvm* wvm);
+/* How the last fd_detect_five_stage / fd_detect_five_stage_image call of this handle got its SVM scores: -1 the survivors of the host
+ * overlap elimination were scored in a launch of their own (two host round trips: FD_FS_SPEC=0, the device tail, models without the
+ * dense stage B or the u8 MFMA SVM), 0 the scores of all WVM positives were queued behind the cascade and used (one wait), 1 they were
+ * queued but the frame had more positives than the launch covered (or stage B was rerun): the call fell back to the two round trips. */
+int fd_wvm_last_spec_state(const fd_wvm* wvm);
 
 /* Test hook, needs no GPU: the rect sums (WvmClassifier.cpp:277-306) of every used level of `md` for n equalised patches, computed
  * from the tables of the dense stage B with the operand addressing of its MFMA kernel.  out[i * ncols + c]: c runs over the levels

@@ -293,6 +293,46 @@ def test_headline_workload_against_the_oracle(oracle, capi, ctx, synth):
     wg.close(); sg.close(); pm.close()
 
 
+def test_single_frame_scores_queued_behind_the_cascade(oracle, capi, ctx, synth, monkeypatch):
+    """fd_detect_five_stage on one frame: the SVM scores of ALL WVM positives are queued behind the cascade and the host waits once
+    (five_stage.hpp).  Byte-identical to the two-round-trip order (FD_FS_SPEC=0) on a sequence whose positive counts jump -- a blank
+    frame makes the next launch cover 64 slots only, so the busy frame behind it must fall back -- and equal to the oracle.  The hook
+    says which order produced each result."""
+    import bench
+    wvm_m, svm_m = bench.cascade_models()
+    frames, _ = synth.make_frames_varied(6, 640, 480, seed=977, scene_len=2)
+    blank = np.full((480, 640, 3), 128, np.uint8)
+    seq = [frames[0], frames[0], blank, frames[3], frames[3], frames[5], blank, blank, frames[1]]
+    pg, ph = capi.Pyramid(ctx, **FF), capi.Pyramid(ctx, **FF)
+    wg, wh, sg = capi.Wvm(ctx, wvm_m), capi.Wvm(ctx, wvm_m), capi.Svm(ctx, svm_m)
+    states, expect, prev = [], [], -1
+    for i, fr in enumerate(seq):
+        pg.update(fr)
+        dg, stg = capi.detect_five_stage(ctx, pg, wg, sg)
+        states.append(wg.last_spec_state())
+        covered = 1024 if prev < 0 else max(64, 2 * prev + 64)   # the launch covers twice the previous frame's positives (five_stage.hpp)
+        expect.append(0 if int(stg[0]) <= covered else 1)
+        prev = int(stg[0])
+        monkeypatch.setenv("FD_FS_SPEC", "0")
+        ph.update(fr)
+        dh, sth = capi.detect_five_stage(ctx, ph, wh, sg)
+        assert wh.last_spec_state() == -1
+        monkeypatch.delenv("FD_FS_SPEC")
+        assert dg.tobytes() == dh.tobytes() and np.array_equal(stg, sth), i
+        if i in (0, 3):
+            po = oracle.Pyramid(**FF)
+            po.update(fr)
+            do, sto = oracle.five_stage(po, oracle.Wvm(wvm_m), oracle.Svm(svm_m), 5.0, 0.0, 1, 1, None)
+            assert len(dg) == len(do) and list(stg) == list(sto), i
+            for fld in ("cx", "cy", "w", "h"):
+                assert np.array_equal(dg[fld], do[fld]), (i, fld)
+        if i == 3:
+            assert stg[0] > 64, "the busy frame behind the blank one must outgrow the 64-slot launch"
+    assert states == expect and states[3] == 1 and states[8] == 1 and states.count(0) >= 5, (states, expect)
+    for o_ in (wg, wh, sg, pg, ph):
+        o_.close()
+
+
 def test_device_overlap_elimination_equals_the_host_path(oracle, capi, ctx, synth, monkeypatch):
     """Stages 2-3 on the device (csrc/fs_tail.hpp: k_fs_oe + the counted SVM launch) against the host-driven tail (FD_FS_TAIL=0) and
     the oracle, on frames whose number of WVM positives differs ~7x (synth.make_frames_varied: the bench's headline content), through
