@@ -759,7 +759,12 @@ void fd_svm_u8_mfma_launch_counted(hipStream_t st, const fd_svm* m, const void* 
                                    const unsigned int* dcount, double* dout) {
     if (nmax <= 0) return;
     const size_t lb = (size_t)32 * (m->dev.KS * 32 + 16) + 384 + sizeof(double) * (size_t)(m->dev.nsv32 >> 5) * 32;
-    hipLaunchKernelGGL(k_svm_u8_rbf_mfma<8>, dim3((unsigned)((nmax + 31) / 32)), dim3(64 * 8), lb, st, m->dev, dfeat, didx, stride_bytes, nmax, dout, dcount);
+    // a frame's worth of vectors (a handful of workgroups: the launch is a chain of latencies) takes sixteen wavefronts per workgroup,
+    // half the support-vector tiles per wavefront and a tile's operands requested at once; the sums are the same (fixed pairwise order)
+    if (nmax <= 32 * 64)
+        hipLaunchKernelGGL(k_svm_u8_rbf_mfma<16>, dim3((unsigned)((nmax + 31) / 32)), dim3(64 * 16), lb, st, m->dev, dfeat, didx, stride_bytes, nmax, dout, dcount);
+    else
+        hipLaunchKernelGGL(k_svm_u8_rbf_mfma<8>, dim3((unsigned)((nmax + 31) / 32)), dim3(64 * 8), lb, st, m->dev, dfeat, didx, stride_bytes, nmax, dout, dcount);
     HIP_CHECK(hipGetLastError());
 }
 
