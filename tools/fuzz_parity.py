@@ -472,6 +472,28 @@ def case_whi(rng, ctx):
 def case_sdm(rng, ctx):
     gray = synth.make_frame(256, 256, seed=int(rng.integers(1 << 30)), channels=1)
     npts = int(rng.integers(1, 80))
+    if rng.random() < 0.4:
+        # the extractor's own geometry (non-adaptive): working images of 4..48 pixels, 3..16 orientations, both HOG variants
+        nc = int(rng.integers(1, 7))
+        cs = 2 * int(rng.integers(2, max(3, 48 // (2 * nc) + 1)))
+        nb, variant = int(rng.integers(3, 17)), int(rng.integers(0, 2))
+        half = nc * (cs // 2)
+        px = rng.uniform(half + 1, 254 - half, npts).astype(np.float32)
+        py = rng.uniform(half + 1, 254 - half, npts).astype(np.float32)
+        kw = dict(variant=variant, num_cells=nc, cell_size=cs, num_bins=nb)
+        do = O.sdm_descriptors(gray, px, py, 0, **kw)
+        if do is None:
+            return None
+        try:
+            dg = capi.sdm_descriptors(ctx, gray, px, py, 0, **kw)
+        except capi.FdError as e:
+            if "LDS budget" in str(e):   # a documented limit of the kernel (fd_hip.h), not a mismatch
+                return None
+            raise
+        STATS['features'] += int(do.size)
+        if dg.shape != do.shape or not np.array_equal(dg, do):
+            return "SDM descriptors differ (non-adaptive %d cells x %d px, %d bins, variant %d, %d points)" % (nc, cs, nb, variant, npts)
+        return None
     px = rng.uniform(2, 254, npts).astype(np.float32)
     py = rng.uniform(2, 254, npts).astype(np.float32)
     wsh = int(rng.integers(6, 40))
