@@ -70,12 +70,13 @@ def pmc_record(workload, kernel_substr):
     try:
         # the newest committed pass that holds this workload (a round only re-measures the workloads whose kernels it touched)
         rec = None
-        for r in (5, 4, 3, 2):
+        fname = None
+        for r in (6, 5, 4, 3, 2):
             p_ = os.path.join(ROOT, "profiles", "r0%d_pmc.json" % r)
             if os.path.exists(p_):
                 cand = json.load(open(p_))
                 if workload in cand:
-                    rec = cand
+                    rec, fname = cand, "profiles/r0%d_pmc.json" % r
                     break
         ks = rec.get(workload, {}).get("kernels", {})
         agg = "k_all(%s)" % kernel_substr
@@ -83,7 +84,11 @@ def pmc_record(workload, kernel_substr):
             if kernel_substr in k:
                 out = dict(v)
                 out["kernel"] = k
-                out["source"] = rec[workload].get("source", "")
+                # where the counters come from: the committed file and the git head of the pass (the command is in the file's own
+                # `source` field; a line the driver has to parse does not repeat it)
+                note = rec[workload].get("source", "")
+                hd = note.rsplit("git head ", 1)[-1].strip()[:12] if "git head " in note else "?"
+                out["source"] = "%s[%s] at git %s" % (fname, workload, hd)
                 return out
     except Exception:
         pass
@@ -626,34 +631,36 @@ class HogSvm(Workload):
                     algorithmic="2*324*1024 flop/window x %d windows/launch" % self.nwin), {}
 
     def cpu_baseline(self):
+        """the same inputs as the GPU leg -- one full 640x480 frame of the workload.  The whole
+        frame is 35 s of one core (278 K windows x 1024 support vectors x 324), so the 1-thread leg builds the full pyramid and evaluates
+        every SAMPLE-th window of it (a window's HOG + SVM cost does not depend on where it lies); the n-thread leg evaluates the WHOLE
+        frame, thread t taking windows t, t + T, ... (each thread builds the pyramid itself)."""
         from oracle import pyoracle as O
-        from featuredetection_amd import synth
-        model = self.model
-        SW, SH = 320, 240
+        model, frame, hp = self.model, self.frames[0], (20, 20, 2, 2, 9, 5, 2)
+        SAMPLE = 3
 
-        def run(t, split=False):
-            crop = synth.make_frame(SW, SH, seed=20260927 + t)
+        def run(first, step, split=False):
             p = O.Pyramid(octave_layers=5, min_scale=1 / 16, max_scale=1.0)
             p.set_layer_filter(1, bins=9)
             s = O.Svm(model)
             if split:
                 O.phase_timing(True)
             t0 = time.perf_counter()
-            p.update(crop)
+            p.update(frame)
             tu = time.perf_counter() - t0
-            _, dist, _ = O.sliding_hog_svm(p, s, 20, 20, 2, 2, 9, 5, 2)
+            nvis, _ = O.sliding_hog_svm_sample(p, s, *hp, first, step)
             dt = time.perf_counter() - t0
             ph = O.phase_times() if split else (0, 0)
             if split:
                 O.phase_timing(False)
-            return len(dist), dt, tu, ph
-        n1, dt1, tu, (te, tc) = run(0, True)
+            return nvis, dt, tu, ph
+        n1, dt1, tu, (te, tc) = run(0, SAMPLE, True)
         _, cores = host_info()
         nt = min(cores, 64)
-        rs = run_threads(run, nt)
+        rs = run_threads(lambda t: run(t, nt), nt)
         return cpu_record(n1, dt1, dict(update=tu, extract=te, classify=tc, total=dt1), sum(r[0] for r in rs), max(r[1] for r in rs), nt,
-                          "one %dx%d frame of the same recipe (%d windows, %.1f s), same pyramid / HOG / SVM parameters, oracle -O2, 1 thread; "
-                          "n_thread: one frame per thread" % (SW, SH, n1, dt1), "Mpatches/s")
+                          "one full %dx%d frame of the workload: its pyramid + every %d-rd of its %d windows (%d windows, %.1f s), oracle -O2, 1 thread; "
+                          "n_thread: the whole frame, windows dealt over the threads" % (self.W, self.H, SAMPLE, self.nwin, n1, dt1), "Mpatches/s")
 
 
 def ffp15_models(nsv=1024):
@@ -813,11 +820,13 @@ class Ffp15(Workload):
         return roof, extra
 
     def cpu_baseline(self):
+        """the same inputs as the GPU leg -- one full 1920x1080 frame of the workload.  All 15
+        detectors on it are ~60 s of one core, so the 1-thread leg runs every third detector (5 of the 15: 20x20, 24x24 and 32x16
+        patches among them) on the full frame; the n-thread leg runs all 15, one detector per thread."""
         from oracle import pyoracle as O
-        from featuredetection_amd import synth
-        SW, SH = 480, 270
-        frame = synth.make_frame(SW, SH, seed=20260927)
+        frame = self.dframes[0].cpu().numpy()
         models = self.models
+        W, H = self.W, self.H
 
         def run_dets(idx, split=False):
             if split:
@@ -837,13 +846,15 @@ class Ffp15(Workload):
             if split:
                 O.phase_timing(False)
             return n, dt, tu, ph_
-        n1, dt1, tu, (te, tc) = run_dets(range(len(models)), True)
+        sample = list(range(0, len(models), 3))
+        n1, dt1, tu, (te, tc) = run_dets(sample, True)
         _, cores = host_info()
         nt = min(cores, len(models))
         rs = run_threads(lambda t: run_dets(range(t, len(models), nt)), nt)
         return cpu_record(n1, dt1, dict(update=tu, extract=te, classify=tc, total=dt1), sum(r[0] for r in rs), max(r[1] for r in rs), nt,
-                          "the 15 detectors on one %dx%d frame of the same recipe (%d windows, %.1f s; the reference rebuilds the pyramid per detector), "
-                          "oracle -O2, 1 thread; n_thread: detectors spread over threads" % (SW, SH, n1, dt1), "Mpatches/s")
+                          "%d of the 15 detectors (%s) on one full %dx%d frame of the workload (%d windows, %.1f s; the reference rebuilds the pyramid per "
+                          "detector), oracle -O2, 1 thread; n_thread: all 15 detectors on the frame, one per thread" %
+                          (len(sample), ",".join(models[i][0] for i in sample), W, H, n1, dt1), "Mpatches/s")
 
 
 class Ffp15Two(Ffp15):
@@ -928,10 +939,15 @@ class Sdm(Workload):
         self.env, self.capi = env, capi
         self.B, self.W, self.H = 256, 256, 256
         self.FP = max(1, batches_per_step)
-        imgs = np.stack([synth.make_frame(self.W, self.H, seed=9000 + 1000 * env.rank + i, channels=1) for i in range(16)])
-        self.imgs16 = imgs
-        imgs = np.concatenate([imgs] * (self.B // 16))
-        self.dimgs = torch.from_numpy(imgs).to(env.dev)
+        # 256 DISTINCT crops per batch and NBATCH distinct batches cycled ("256 seeded crops");
+        # generated on the device (device_frames, scenes of 4 crops with different busy-ness), one gray plane per crop
+        self.NBATCH = 4
+        ids = np.arange(self.NBATCH * self.B) + 500000 * (1 + env.rank)
+        crops = device_frames(ids, self.W, self.H, env.dev, seed0=20260929)
+        self.dimgs = [torch.stack([c[..., 1] for c in crops[b * self.B:(b + 1) * self.B]]).contiguous() for b in range(self.NBATCH)]
+        self.imgs16 = self.dimgs[0][:16].cpu().numpy()
+        del crops
+        self.nfed = 0
         self.model = synth.make_sdm(9, L=68, S=4)
         self.sdm = capi.Sdm(env.ctx, self.model)
         # fd_sdm_fit_batch_begin / _end: ONE host thread keeps a few batches queued (each ticket has its own scratch set, consecutive
@@ -941,14 +957,16 @@ class Sdm(Workload):
         self.metric = "SDM iters/s (x1e6): 68 landmarks, HOG at each point + linear regressor, 4 cascade steps, batch of 256 face crops"
         self.config = dict(workload="config 4: 256 gray 256x256 crops, 68 landmarks, 4 cascade steps, adaptive VlHog 3x3x31 per landmark + regressor "
                                     "18973x136 (f64 MFMA); fd_sdm_fit_batch_begin/_end, shapes delivered per batch, one host thread, %d batches in flight" % self.inflight,
-                           batches_per_step=self.FP, parallelism="face-shard dp%d" % env.world)
+                           batches_per_step=self.FP, parallelism="face-shard dp%d" % env.world,
+                           content="%d distinct batches of %d distinct crops each resident in HBM (device_frames), cycled" % (self.NBATCH, self.B))
 
     def step(self, i):
         flying = []
         for _ in range(self.FP):
             if len(flying) == self.inflight:
                 self.sdm.fit_end(flying.pop(0))
-            flying.append(self.sdm.fit_device_begin(self.dimgs.data_ptr(), self.W, self.H, self.B, self.boxes))
+            flying.append(self.sdm.fit_device_begin(self.dimgs[self.nfed % self.NBATCH].data_ptr(), self.W, self.H, self.B, self.boxes))
+            self.nfed += 1
         for t in flying:
             self.sdm.fit_end(t)
         return self.B * 4 * self.FP, []
@@ -957,8 +975,8 @@ class Sdm(Workload):
         ctx = self.env.ctx
         ctx.set_kernel_timing(True)
         ms = []
-        for _ in range(8):
-            self.sdm.fit_device(self.dimgs.data_ptr(), self.W, self.H, self.B, self.boxes)
+        for i in range(8):
+            self.sdm.fit_device(self.dimgs[i % self.NBATCH].data_ptr(), self.W, self.H, self.B, self.boxes)
             ms.append(ctx.last_kernel_ms()[1])
         ctx.set_kernel_timing(False)
         kms = float(np.mean(ms[2:]))
@@ -1052,6 +1070,99 @@ class Aggregated(Workload):
         self.det.detect_device(self.dframes[i % 2].data_ptr(), self.W, self.H, 3)
         return self.nwin, []
 
+
+
+# ---------------------------------------------------------------------------------------------------------------- output
+LINE_LIMIT = 8000   # bytes of the ONE JSON line on stdout (the 22 KB line of round 5 was not parsed by the driver)
+
+
+def _r(v, nd=6):
+    """floats to nd significant digits (the line is for parsing, the side file keeps everything)"""
+    if isinstance(v, float):
+        return float("%.*g" % (nd, v))
+    if isinstance(v, dict):
+        return {k: _r(x, nd) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, nd) for x in v]
+    return v
+
+
+def _cut(s_, n):
+    s_ = str(s_)
+    return s_ if len(s_) <= n else s_[:n - 3] + "..."
+
+
+def compact_record(rec, text=160):
+    """the contract keys of a record + roofline / roofline_issue / cpu_baseline reduced to their numbers and short names"""
+    out = {k: rec[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                               "dtype", "data") if k in rec}
+    cfg = rec.get("config", {})
+    out["config"] = {k: (_cut(v, 2 * text) if k == "workload" else _cut(v, text) if isinstance(v, str) else v) for k, v in cfg.items()}
+    for k in ("detections_delivered", "records_gathered", "records_truncated"):
+        if k in rec:
+            out[k] = rec[k]
+    rf = rec.get("roofline")
+    if rf:
+        o = {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms") if k in rf}
+        o["kernel"] = _cut(rf.get("kernel", ""), 48).split(" (")[0]
+        o["algorithmic"] = _cut(rf.get("algorithmic", ""), text)
+        out["roofline"] = o
+    ri = rec.get("roofline_issue")
+    if ri:
+        out["roofline_issue"] = {k: ri[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "source", "wave_time_waitcnt") if k in ri}
+    cb = rec.get("cpu_baseline")
+    if cb:
+        o = {k: cb[k] for k in ("value", "unit", "cores", "kind", "cpu_model", "nproc") if k in cb}
+        o["sample"] = _cut(cb.get("sample", ""), text + 60)
+        if "phases_s" in cb:
+            o["phases_s"] = cb["phases_s"]
+        if "n_thread" in cb:
+            o["n_thread"] = {k: cb["n_thread"][k] for k in ("value", "cores") if k in cb["n_thread"]}
+        out["cpu_baseline"] = o
+    lat = rec.get("latency_us_single_frame")
+    if lat:
+        out["latency_us_single_frame"] = dict(p50=lat["p50"], p99=lat["p99"], frames=lat.get("frames"))
+    return out
+
+
+def emit(res, subs, names, full_out):
+    """ONE line <= LINE_LIMIT bytes on stdout: the headline record (contract keys, roofline, roofline_issue, cpu_baseline) and a `summary`
+    with value / ms_per_step / roofline fraction / CPU baseline of every workload of the run.  Everything else -- the complete
+    records of the headline and of the `also` workloads -- goes to the side file (`--full-out`, default bench_also.json beside bench.py;
+    tools/measure_r06.sh commits a copy as profiles/r06_bench_default.json)."""
+    full = dict(res)
+    if subs:
+        full["also"] = subs
+    try:
+        with open(full_out, "w") as f:
+            json.dump(full, f, indent=1)
+            f.write("\n")
+    except OSError as e:   # a read-only checkout must not cost the line
+        print("bench.py: side file %s not written: %s" % (full_out, e), file=sys.stderr)
+    line = compact_record(res)
+    if subs:
+        summ = {}
+        for nm, r2 in zip(names, [res] + subs):
+            e = dict(value=r2["value"], unit=r2["unit"], ms_per_step=r2["ms_per_step"])
+            if r2.get("roofline"):
+                e["roofline"] = dict(bound=r2["roofline"]["bound"], frac=r2["roofline"]["frac"], kernel=_cut(r2["roofline"].get("kernel", ""), 40).split(" (")[0].split(" of ")[0],
+                                     kernel_ms=r2["roofline"].get("kernel_ms"))
+            if r2.get("roofline_issue"):
+                e["valu_issue_frac"] = r2["roofline_issue"]["frac"]
+            if r2.get("cpu_baseline"):
+                e["cpu_1t"] = r2["cpu_baseline"]["value"]
+            summ[nm] = e
+        line["summary"] = summ
+    line["full_records"] = os.path.basename(full_out)
+    line = _r(line)
+    out = json.dumps(line, separators=(",", ":"))
+    # a line that still came out too long loses its free text first, then the summary's extras: the contract keys always survive
+    if len(out) > LINE_LIMIT:
+        line = _r(dict(compact_record(res, text=60), summary={k: dict(value=v["value"], unit=v["unit"]) for k, v in line.get("summary", {}).items()},
+                       full_records=os.path.basename(full_out)))
+        out = json.dumps(line, separators=(",", ":"))
+    print(out, flush=True)
+    return out
 
 # ---------------------------------------------------------------------------------------------------------------- driver
 class Env:
@@ -1174,6 +1285,8 @@ def main():
     ap.add_argument("--per-frame-launches", action="store_true", help="cascade workload: one pyramid + cascade per frame (fd_detect_five_stage_batch) "
                                                                       "instead of the multi-frame entry points")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-out", default=os.path.join(ROOT, "bench_also.json"), help="side file for the complete records of the headline and the "
+                                                                                       "`also` workloads (stdout carries one line of at most 8 KB)")
     ap.add_argument("--no-probe", action="store_true", help="skip kernel_probe (the HIP-event timing of the dominant kernel and the single-frame "
                                                             "latency loop): profiler runs want the timed steps' launches only")
     args = ap.parse_args()
@@ -1264,16 +1377,7 @@ def main():
         del w2
         release(name)
     if env.rank == 0:
-        if subs:
-            res["also"] = subs
-            # the line is long; whatever keeps only its tail still sees every record's value
-            summ = {args.workload: dict(value=res["value"], unit=res["unit"], ms_per_step=res["ms_per_step"])}
-            for w2, r2 in zip(also, subs):
-                summ[w2] = dict(value=r2["value"], unit=r2["unit"], ms_per_step=r2["ms_per_step"])
-            if "latency_us_single_frame" in res:
-                summ["latency_us_single_frame"] = {k: res["latency_us_single_frame"][k] for k in ("p50", "p99")}
-            res["summary"] = summ
-        print(json.dumps(res))
+        emit(res, subs, [args.workload] + also, args.full_out)
     if env.world > 1:
         env.dist.close()
         dist.destroy_process_group()

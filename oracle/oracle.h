@@ -162,6 +162,11 @@ void orc_phase_get(double* extract_s, double* classify_s);
 int64_t orc_sliding_hog_svm(const orc_pyramid* p, const orc_svm* svm, int pw, int ph, int stepX, int stepY,
                             int bins, int cell, int block, int interpolate, int signedAndUnsigned,
                             orc_det* out, int64_t cap, double* all_dist, float* feat_out, int64_t feat_cap_windows);
+/* bench.py cpu_baseline only: the same loop over windows first, first + step, ... (a bounded sample of one full-size frame) */
+int64_t orc_sliding_hog_svm_sample(const orc_pyramid* p, const orc_svm* svm, int pw, int ph, int stepX, int stepY,
+                                   int bins, int cell, int block, int interpolate, int signedAndUnsigned,
+                                   orc_det* out, int64_t cap, double* all_dist, float* feat_out, int64_t feat_cap_windows,
+                                   int64_t first, int64_t step, int64_t* visited);
 
 /* ---------------- SDM ---------------- */
 /* hog.c:174-…,596-721,858-1063 (VLFeat HOG), variant 0 DalalTriggs, 1 UoCTTI.  Returns dims; out = hw*hh*dim planar */

@@ -413,16 +413,22 @@ int orc_five_stage(const orc_pyramid* p, int imgW, int imgH, const orc_wvm* wvm,
 void orc_phase_timing(int enable) { g_phase.on = enable != 0; g_phase.extract = g_phase.classify = 0; }
 void orc_phase_get(double* extract_s, double* classify_s) { *extract_s = g_phase.extract; *classify_s = g_phase.classify; }
 
-int64_t orc_sliding_hog_svm(const orc_pyramid* p_, const orc_svm* svm_, int pw, int ph, int stepX, int stepY, int bins,
-                            int cell, int block, int interpolate, int signedAndUnsigned, orc_det* out, int64_t cap,
-                            double* all_dist, float* feat_out, int64_t feat_cap_windows) {
+// bench.py cpu_baseline only: the same loop over windows first, first + step, ... (a bounded sample of one full-size frame, or one
+// thread's share of it); *visited = windows evaluated.  all_dist / feat_out are indexed by window like the full run.
+int64_t orc_sliding_hog_svm_sample(const orc_pyramid* p_, const orc_svm* svm_, int pw, int ph, int stepX, int stepY, int bins,
+                                   int cell, int block, int interpolate, int signedAndUnsigned, orc_det* out, int64_t cap,
+                                   double* all_dist, float* feat_out, int64_t feat_cap_windows, int64_t first, int64_t step,
+                                   int64_t* visited) {
     const Pyramid& p = *(const Pyramid*)p_;
     const Svm* svm = (const Svm*)svm_;
     std::vector<Window> wins;
     enumerate_windows(p, pw, ph, stepX, stepY, nullptr, wins);
     std::vector<float> feat;
-    int64_t npos = 0;
-    for (size_t i = 0; i < wins.size(); ++i) {
+    int64_t npos = 0, nvis = 0;
+    if (step < 1) step = 1;
+    if (first < 0) first = 0;
+    for (size_t i = (size_t)first; i < wins.size(); i += (size_t)step) {
+        ++nvis;
         const Window& w = wins[i];
         const ImgU8& img = p.layers[w.layer].img;
         const uchar* src = img.d.data() + ((size_t)w.ly * img.w + w.lx) * img.ch;
@@ -444,6 +450,14 @@ int64_t orc_sliding_hog_svm(const orc_pyramid* p_, const orc_svm* svm_, int pw, 
             ++npos;
         }
     }
+    if (visited) *visited = nvis;
     return svm ? npos : (int64_t)wins.size();
+}
+
+int64_t orc_sliding_hog_svm(const orc_pyramid* p_, const orc_svm* svm_, int pw, int ph, int stepX, int stepY, int bins,
+                            int cell, int block, int interpolate, int signedAndUnsigned, orc_det* out, int64_t cap,
+                            double* all_dist, float* feat_out, int64_t feat_cap_windows) {
+    return orc_sliding_hog_svm_sample(p_, svm_, pw, ph, stepX, stepY, bins, cell, block, interpolate, signedAndUnsigned, out, cap, all_dist,
+                                      feat_out, feat_cap_windows, 0, 1, nullptr);
 }
 }

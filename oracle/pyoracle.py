@@ -78,6 +78,8 @@ def lib():
         l.orc_sliding_hog_svm.restype = C.c_int64
         l.orc_sliding_hog_svm.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                                                                    C.c_int64]
+        l.orc_sliding_hog_svm_sample.restype = C.c_int64
+        l.orc_sliding_hog_svm_sample.argtypes = l.orc_sliding_hog_svm.argtypes + [C.c_int64, C.c_int64, C.c_void_p]
         l.orc_hog_filter.argtypes = [C.c_void_p] + [C.c_int] * 11 + [C.c_void_p]
         l.orc_spatial_histogram.argtypes = [C.c_void_p] + [C.c_int] * 12 + [C.c_void_p]
         l.orc_pyramid_hog.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]
@@ -540,6 +542,16 @@ def sliding_hog_svm(pyr, svm, pw, ph, sx, sy, bins, cell, block, interpolate=Fal
     cnt = lib().orc_sliding_hog_svm(pyr.h, svm.h if svm else None, pw, ph, sx, sy, bins, cell, block, int(interpolate), int(sau),
                                     _p(out), len(out), _p(dist) if svm else None, _p(feats), len(feats) if feats is not None else 0)
     return (out[:cnt] if svm else None), (dist if svm else None), feats
+
+
+def sliding_hog_svm_sample(pyr, svm, pw, ph, sx, sy, bins, cell, block, first, step, interpolate=False, sau=False):
+    """bench.py cpu_baseline: sliding_hog_svm over the windows first, first + step, ... of the pyramid; returns (windows visited, positives)"""
+    n = len(pyr.windows(pw, ph, sx, sy))
+    out = np.zeros(max(n, 1), DET_DTYPE)
+    vis = C.c_int64(0)
+    cnt = lib().orc_sliding_hog_svm_sample(pyr.h, svm.h, pw, ph, sx, sy, bins, cell, block, int(interpolate), int(sau), _p(out), len(out), None,
+                                           None, 0, int(first), int(step), C.byref(vis))
+    return int(vis.value), int(cnt)
 
 
 def vlhog(img, cell, nori, variant):
