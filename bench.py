@@ -625,8 +625,9 @@ class HogSvm(Workload):
         kms = float(np.mean(ms[2:]))
         flops = 2.0 * 324 * 1024 * self.nwin
         ach = flops / (kms * 1e-3) / 1e12
-        pm = pmc_record("hog_svm", "k_svm_rbf_mfma") if (self.W, self.H) == (640, 480) else None
-        return dict(bound="mfma", kernel="k_svm_rbf_mfma_svs", achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F32_MFMA_TFLOPS,
+        kname = c_.last_kernel_ms()[0] or "k_hog_svm_fused"
+        pm = pmc_record("hog_svm", kname) if (self.W, self.H) == (640, 480) else None
+        return dict(bound="mfma", kernel=kname + (" (HOG vectors produced in the registers of the MFMA operand + RBF SVM: one kernel)" if "fused" in kname else ""), achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F32_MFMA_TFLOPS,
                     traffic=pm.get("hbm_bytes") if pm else None, traffic_source=pm.get("source") if pm else None, kernel_ms=kms,
                     algorithmic="2*324*1024 flop/window x %d windows/launch" % self.nwin), {}
 

@@ -297,6 +297,16 @@ static inline void fd_allow_lds(fd_ctx* ctx, const void* kernel, int bytes, uint
     done |= bit;
 }
 
+// what the fused HOG + SVM kernel (hog_svm_fused.hpp, launched from hog.hip) needs of an f32 RBF model (svm.hip)
+struct FdSvmFusedView {
+    const float* svFrag;   // fragment-major support vectors [nsv_pad][KP]
+    const float* ss;       // |s|^2, [nsv_pad]
+    const float* coeff;    // [nsv_pad], zero padded
+    int nsv_pad, KP;
+    float bias;
+    double gamma;
+};
+
 struct FdStreamSwap {   // temporarily redirects everything that launches on ctx->stream
     fd_ctx* c;
     hipStream_t keep;

@@ -46,6 +46,7 @@ bool fd_svm_is_u8(const fd_svm* m);
 double fd_svm_probability(const fd_svm* m, double d);
 void fd_svm_rbf_mfma_launch(fd_ctx* ctx, const fd_svm* m, const float* xFrag, const float* xx, int64_t npatches, double* out);
 void fd_svm_generic_launch(fd_ctx* ctx, const fd_svm* m, const void* dfeat, const uint32_t* didx, int64_t stride_bytes, int64_t n, double* dout);
+bool fd_svm_fused_view(const fd_svm* m, FdSvmFusedView* v);
 
 namespace {
 
@@ -226,8 +227,12 @@ __global__ void k_select_positives(const double* __restrict__ dist, int64_t n, f
     }
 }
 
+#include "hog_svm_fused.hpp"
+
 struct HogScratch {
-    DevBuf feat, xx, dist, pos, counter, tables, histTables, patchIn;
+    DevBuf feat, xx, dist, pos, counter, tables, histTables, patchIn, part;
+    DevBuf header;        // fused path: {positives, retired workgroups}, left zero by every run
+    bool headerClean = false;
     HostBuf hcount;       // pinned read-back slot
     HogDev tabFor;        // parameters the tables were built for
     bool tabValid = false;
@@ -352,8 +357,11 @@ void window_geometry(const fd_pyramid* p, const std::vector<WindowLayer>& wls, i
 }
 
 // features for all windows (fragment-major + |x|^2) then the MFMA SVM; returns window count
+// *selected: the positives are already in S.hcount (pinned: record 0 = their number) when the stream reaches this point -- the fused
+// path; otherwise the caller queues k_select_positives and the copy
 int64_t run_hog_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_hog_params* hp, std::vector<WindowLayer>& wls,
-                    HogScratch& S, bool time_kernel) {
+                    HogScratch& S, bool time_kernel, bool* selected = nullptr, unsigned int* pcapOut = nullptr) {
+    if (selected) *selected = false;
     if (!fd_svm_has_mfma_path(svm)) FD_THROW(FD_ERR_INVALID_ARGUMENT, "the HOG detector needs an RBF SVM on f32 feature vectors");
     HogDev hd = make_hogdev(hp, fd_svm_KP(svm));
     if (((hd.F + 7) & ~7) != hd.KP) FD_THROW(FD_ERR_INVALID_ARGUMENT, "SVM dimension does not match the HOG feature length %d", hd.F);
@@ -364,6 +372,54 @@ int64_t run_hog_svm(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const fd_hog_
     HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int64_t Npad = (N + 63) & ~(int64_t)63;
+    // config 2's shape (20 x 20 patches, 5-pixel cells, 2 x 2 blocks, 9 bins -> 324 elements) through ONE kernel: HOG vectors are
+    // produced in the registers of the MFMA operand, nothing but the distances is written (hog_svm_fused.hpp).  FD_HOG_FUSED=0:
+    // the two-kernel path below (any other shape takes it anyway; the tests compare the two).
+    FdSvmFusedView fv;
+    const char* fusedEnv = getenv("FD_HOG_FUSED");   // read per call: the tests switch between the two paths inside one process
+    const bool fusedOn = !(fusedEnv && atoi(fusedEnv) == 0);
+    if (fusedOn && hd.pw == 20 && hd.ph == 20 && hd.cell == 5 && hd.block == 2 && hd.bins == 9 && !hd.sau && hd.KP == 8 * HSF_Q &&
+        fd_svm_fused_view(svm, &fv) && fv.KP == hd.KP && fv.nsv_pad / 32 <= 64) {
+        HsfSvm hm;
+        hm.svFrag = fv.svFrag; hm.ss = fv.ss; hm.coeff = fv.coeff; hm.nsvt = fv.nsv_pad / 32; hm.bias = fv.bias; hm.negGamma = (float)(-fv.gamma);
+        const HsfPlan pl = hsf_plan(N, ctx->num_cus, hm.nsvt);
+        S.dist.reserve(sizeof(double) * (size_t)pl.npadRows);
+        if (pl.rem > 0) S.part.reserve(sizeof(double) * (size_t)pl.S * pl.npadRows);
+        const char* me = getenv("FD_HSF_SUBS");
+        const int subs = me ? atoi(me) : 1;
+        const size_t lds = hsf_lds_bytes(subs, hm.nsvt);
+        static uint64_t a0 = 0, a1 = 0, a2 = 0;
+        fd_allow_lds(ctx, (const void*)k_hog_svm_fused<0>, 160 * 1024, a0);
+        fd_allow_lds(ctx, (const void*)k_hog_svm_fused<1>, 160 * 1024, a1);
+        fd_allow_lds(ctx, (const void*)k_hog_svm_fused<2>, 160 * 1024, a2);
+        HsfOut o;
+        o.dist = S.dist.as<double>(); o.part = S.part.as<double>();
+        o.cap = (unsigned int)std::min<int64_t>(N, 1 << 22);
+        o.threshold = fd_svm_threshold(svm);
+        S.hcount.reserve(sizeof(HogPos) * ((size_t)o.cap + 1));
+        o.pos = S.hcount.as<HogPos>();          // pinned host memory is device-accessible under the same address
+        if (!S.header.p) { S.header.reserve(64); S.headerClean = false; }
+        if (!S.headerClean) HIP_CHECK(hipMemsetAsync(S.header.p, 0, 64, st));
+        S.headerClean = true;                   // k_hsf_finish leaves it zero
+        o.header = S.header.as<unsigned int>();
+        o.pos[0].wid_lo = 0xffffffffu;          // overwritten by the last workgroup of k_hsf_finish
+        const int grid = pl.R > 0 ? pl.G : pl.rem * pl.S;
+        if (time_kernel) HIP_CHECK(hipEventRecord(ctx->ev0, st));
+        if (subs == 0)
+            hipLaunchKernelGGL(k_hog_svm_fused<0>, dim3(grid), dim3(512), lds, st, p->arena.as<uint8_t>(), wt, hm, pl, o);
+        else if (subs == 2)
+            hipLaunchKernelGGL(k_hog_svm_fused<2>, dim3(grid), dim3(512), lds, st, p->arena.as<uint8_t>(), wt, hm, pl, o);
+        else
+            hipLaunchKernelGGL(k_hog_svm_fused<1>, dim3(grid), dim3(512), lds, st, p->arena.as<uint8_t>(), wt, hm, pl, o);
+        if (time_kernel) HIP_CHECK(hipEventRecord(ctx->ev1, st));
+        const int64_t first = pl.rem > 0 ? (int64_t)pl.R * pl.G * 256 : N;   // first window of the remainder round
+        hipLaunchKernelGGL(k_hsf_finish, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((N - first + 255) / 256, 1024))), dim3(256), 0, st,
+                           o, pl.S, pl.npadRows, first, N, hm.bias);
+        if (selected) *selected = true;
+        if (pcapOut) *pcapOut = o.cap;
+        HIP_CHECK(hipGetLastError());
+        return N;
+    }
     S.feat.reserve(sizeof(float) * (size_t)Npad * hd.KP);
     S.xx.reserve(sizeof(float) * (size_t)Npad);
     S.dist.reserve(sizeof(double) * (size_t)Npad);
@@ -415,6 +471,7 @@ struct fd_hog_svm_ticket {
     unsigned int pcap = 0;
     hipEvent_t done = nullptr;
     bool timed = false;
+    bool zerocopy = false;   // the fused path: the kernels wrote the positives into the pinned buffer themselves
     ~fd_hog_svm_ticket() { if (done) (void)hipEventDestroy(done); }
 };
 constexpr unsigned int HOG_FIRST_CHUNK = 4096;   // positives fetched together with the counter
@@ -423,19 +480,21 @@ static void hog_svm_begin(fd_ctx* ctx, fd_pyramid* p, const fd_svm* svm, const f
     HogScratch& S = scratch(ctx);
     t.p = p; t.svm = svm; t.hp = *hp;
     t.timed = ctx->kernel_timing;
-    t.N = run_hog_svm(ctx, p, svm, hp, t.wls, S, t.timed);
+    t.N = run_hog_svm(ctx, p, svm, hp, t.wls, S, t.timed, &t.zerocopy, &t.pcap);
     if (t.N == 0) return;
     hipStream_t st = ctx->stream;
-    t.pcap = (unsigned int)std::min<int64_t>(t.N, 1 << 22);
-    // record 0 of the positive buffer is the header (counter), so that counter + first positives come back in one copy
-    S.pos.reserve(sizeof(HogPos) * ((size_t)t.pcap + 1));
-    S.hcount.reserve(sizeof(HogPos) * ((size_t)t.pcap + 1));
-    HIP_CHECK(hipMemsetAsync(S.pos.p, 0, sizeof(HogPos), st));
-    hipLaunchKernelGGL(k_select_positives, dim3((unsigned)std::min<int64_t>((t.N + 255) / 256, 2048)), dim3(256), 0, st,
-                       S.dist.as<double>(), t.N, fd_svm_threshold(svm), S.pos.as<HogPos>() + 1, S.pos.as<unsigned int>(), t.pcap);
-    HIP_CHECK(hipGetLastError());
-    const size_t first = std::min<size_t>(t.pcap, HOG_FIRST_CHUNK);
-    HIP_CHECK(hipMemcpyAsync(S.hcount.p, S.pos.p, sizeof(HogPos) * (first + 1), hipMemcpyDeviceToHost, st));
+    if (!t.zerocopy) {
+        t.pcap = (unsigned int)std::min<int64_t>(t.N, 1 << 22);
+        // record 0 of the positive buffer is the header (counter), so that counter + first positives come back in one copy
+        S.pos.reserve(sizeof(HogPos) * ((size_t)t.pcap + 1));
+        S.hcount.reserve(sizeof(HogPos) * ((size_t)t.pcap + 1));
+        HIP_CHECK(hipMemsetAsync(S.pos.p, 0, sizeof(HogPos), st));
+        hipLaunchKernelGGL(k_select_positives, dim3((unsigned)std::min<int64_t>((t.N + 255) / 256, 2048)), dim3(256), 0, st,
+                           S.dist.as<double>(), t.N, fd_svm_threshold(svm), S.pos.as<HogPos>() + 1, S.pos.as<unsigned int>(), t.pcap);
+        HIP_CHECK(hipGetLastError());
+        const size_t first = std::min<size_t>(t.pcap, HOG_FIRST_CHUNK);
+        HIP_CHECK(hipMemcpyAsync(S.hcount.p, S.pos.p, sizeof(HogPos) * (first + 1), hipMemcpyDeviceToHost, st));
+    }
     if (!t.done) HIP_CHECK(hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
     HIP_CHECK(hipEventRecord(t.done, st));
 }
@@ -448,12 +507,12 @@ static void hog_svm_end(fd_ctx* ctx, fd_hog_svm_ticket& t, fd_detection* out, in
     HIP_CHECK(hipEventSynchronize(t.done));
     if (t.timed) {
         HIP_CHECK(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->ev0, ctx->ev1));
-        ctx->last_kernel = "k_svm_rbf_mfma";
+        ctx->last_kernel = t.zerocopy ? "k_hog_svm_fused" : "k_svm_rbf_mfma";
     }
     HogPos* h = S.hcount.as<HogPos>();
     const unsigned int cnt = h[0].wid_lo;
     if (cnt > t.pcap) FD_THROW(FD_ERR_DEVICE_CAPACITY, "fd_detect_hog_svm: %u positives exceed the device buffer", cnt);
-    const size_t first = std::min<size_t>(t.pcap, HOG_FIRST_CHUNK);
+    const size_t first = t.zerocopy ? (size_t)t.pcap : std::min<size_t>(t.pcap, HOG_FIRST_CHUNK);
     if (cnt > first) HIP_CHECK(hipMemcpyAsync(h + 1 + first, S.pos.as<HogPos>() + 1 + first, sizeof(HogPos) * (cnt - first), hipMemcpyDeviceToHost, st));
     if (all_distance) HIP_CHECK(hipMemcpyAsync(all_distance, S.dist.p, sizeof(double) * (size_t)t.N, hipMemcpyDeviceToHost, st));
     if (cnt > first || all_distance) HIP_CHECK(hipStreamSynchronize(st));

@@ -663,6 +663,13 @@ double fd_svm_probability(const fd_svm* m, double d) {  // ProbabilisticSvmClass
     return fABp >= 0 ? std::exp(-fABp) / (1.0 + std::exp(-fABp)) : 1.0 / (1.0 + std::exp(fABp));
 }
 
+bool fd_svm_fused_view(const fd_svm* m, FdSvmFusedView* v) {
+    if (!m->dev.svFrag || m->dev.kernel != FD_KERNEL_RBF) return false;
+    v->svFrag = m->dev.svFrag; v->ss = m->dev.ss_f32; v->coeff = m->dev.coeffPad;
+    v->nsv_pad = m->dev.nsv_pad; v->KP = m->dev.KP; v->bias = m->dev.bias; v->gamma = m->dev.p0;
+    return true;
+}
+
 size_t fd_svm_rbf_lds_bytes(int KP) { return (size_t)2 * (KP / 8) * 256 * 4 + 64 * 4 + 8 * 64 * 8; }
 
 // dense MFMA scoring of npatches feature vectors already on the device in fragment-major layout

@@ -724,6 +724,45 @@ def test_hog_rbf_svm_detector_config2(oracle, capi, ctx, synth):
     sg.close(); pg.close()
 
 
+@pytest.mark.parametrize("size,nsv", [((160, 120), 100), ((320, 240), 300), ((333, 251), 1024), ((640, 480), 64)])
+def test_hog_svm_fused_kernel_equals_the_two_kernel_path(oracle, capi, ctx, synth, size, nsv, monkeypatch):
+    """config 2's shape runs as ONE kernel (hog_svm_fused.hpp: HOG vectors produced in the registers of the MFMA operand, support
+    vectors streamed).  Against the two-kernel path (k_hog_tile -> features in HBM -> k_svm_rbf_mfma_svs, FD_HOG_FUSED=0) the HOG
+    values are the same bits; |x|^2 (fp32) and the fp64 sum over support vectors are added in another order: distances within 2e-7 of sum|coeff|,
+    the same positives away from the threshold.  The sizes cover a launch without a full round (the tail split over 2..32
+    support-vector parts), full rounds + a tail, window counts that are not multiples of 32, and 2 / 16 / 32 support-vector tiles."""
+    W, H = size
+    frame = synth.make_frame(W, H, seed=31)
+    kw = dict(octave_layers=5, min_scale=1 / 16, max_scale=1.0)
+    pg = capi.Pyramid(ctx, **kw)
+    pg.set_layer_filter(1, bins=9)
+    pg.update(synth.make_frame(W, H, seed=32))
+    feats2 = capi.extract_hog(ctx, pg, capi.hog_params())
+    m = synth.make_svm_f32(7, feats2[:: max(1, len(feats2) // 4000)], nsv=nsv, gamma=0.5, positive_fraction=0.05)
+    pg.update(frame)
+    sg = capi.Svm(ctx, m)
+    monkeypatch.setenv("FD_HOG_FUSED", "0")
+    dets_2, dist_2 = capi.detect_hog_svm(ctx, pg, sg, capi.hog_params())
+    monkeypatch.setenv("FD_HOG_FUSED", "1")
+    dets_f, dist_f = capi.detect_hog_svm(ctx, pg, sg, capi.hog_params())
+    dets_f2, dist_f2 = capi.detect_hog_svm(ctx, pg, sg, capi.hog_params())
+    assert np.array_equal(dist_f, dist_f2) and np.array_equal(dets_f, dets_f2)        # deterministic
+    assert len(dist_f) == len(dist_2) > 0
+    scale = np.abs(m["coeff"]).sum()
+    assert np.abs(dist_f - dist_2).max() <= 2e-7 * scale, np.abs(dist_f - dist_2).max()   # |x|^2 is an fp32 sum in another order
+    safe = np.abs(dist_2 - m["threshold"]) > 1e-6 * scale
+    pos_2, pos_f = np.nonzero(dist_2 >= m["threshold"])[0], np.nonzero(dist_f >= m["threshold"])[0]
+    assert np.array_equal(pos_2[safe[pos_2]], pos_f[safe[pos_f]])
+    # ... and against the oracle on a strided sample of the windows (the full-size comparison is test_gpu_fullsize's)
+    po = oracle.Pyramid(**kw)
+    po.set_layer_filter(1, bins=9)
+    po.update(frame)
+    if len(dist_f) <= 70000:
+        _, dist_o, _ = oracle.sliding_hog_svm(po, oracle.Svm(m), 20, 20, 2, 2, 9, 5, 2)
+        assert np.abs(dist_f - dist_o).max() <= 1e-5 * scale
+    sg.close(); pg.close()
+
+
 def test_sdm_descriptors_bit_exact(oracle, capi, ctx, synth):
     gray = synth.make_frame(256, 256, seed=21, channels=1)
     rng = np.random.default_rng(1)
