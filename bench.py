@@ -1211,6 +1211,7 @@ def measure(wl, env, steps, warmup, gather_every, want_cpu):
         wl.stage_sum, wl.stage_frames = np.zeros(4, np.int64), 0
     t0 = time.perf_counter()
     units, ndet, pending, gathered = 0, 0, [], 0
+    gather_open, gather_s, ngathers = False, 0.0, 0
     for i in range(steps):
         n, out = wl.step(i)
         units += n
@@ -1224,12 +1225,26 @@ def measure(wl, env, steps, warmup, gather_every, want_cpu):
             local = np.concatenate(recs) if recs else np.zeros((0, parallel.RECORD_FIELDS))
             ndet += len(local)
             if world > 1:
-                # the product's gather: fd_dist_gather_records = ONE ncclAllGather (librccl) of the padded record buffers on the
-                # context's stream (csrc/dist.hip); parallel.gather_records is its torch.distributed twin, used by the CPU tests
-                allr, tr = env.dist.gather(local, recs_cap)
-                gathered += len(allr)
-                truncated |= tr
+                # the product's gather (csrc/dist.hip): fd_dist_gather_begin = a 64-byte header exchange + ONE ncclAllGather (librccl) of
+                # max-count + 1 rows per rank, queued on the handle's own stream; the records of THIS interval travel while the next
+                # interval's images are processed, and are collected (fd_dist_gather_end) at the next gather point.
+                # parallel.gather_records is the torch.distributed twin, used by the CPU tests
+                tg0 = time.perf_counter()
+                if gather_open:
+                    allr, tr = env.dist.gather_end()
+                    gathered += len(allr)
+                    truncated |= tr
+                env.dist.gather_begin(local, recs_cap)
+                gather_open = True
+                gather_s += time.perf_counter() - tg0
+                ngathers += 1
             pending = []
+    if gather_open:   # the last interval's records
+        tg0 = time.perf_counter()
+        allr, tr = env.dist.gather_end()
+        gathered += len(allr)
+        truncated |= tr
+        gather_s += time.perf_counter() - tg0
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
@@ -1245,6 +1260,8 @@ def measure(wl, env, steps, warmup, gather_every, want_cpu):
     if world > 1:
         rec["records_gathered"] = gathered
         rec["records_truncated"] = bool(truncated)
+        # host time inside fd_dist_gather_begin / _end per gather interval (rank 0): what a gather costs the rank's pipeline
+        rec["gather_ms_per_interval"] = gather_s / max(1, ngathers) * 1e3
     if hasattr(wl, "extra_record") and env.rank == 0:
         rec.update(wl.extra_record())
     probe = wl.kernel_probe() if (env.rank == 0 and not getattr(env, "no_probe", False)) else None

@@ -146,6 +146,8 @@ _SIGS = {
     "fd_dist_world": (C.c_int, [C.c_void_p]),
     "fd_pack_records": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_int, C.c_void_p]),
     "fd_dist_gather_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "fd_dist_gather_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "fd_dist_gather_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "fd_dist_gather_discard": (None, [C.c_void_p]),
     "fd_dist_gather_pending": (C.c_int, [C.c_void_p]),
     "fd_pyramid_set_gradient_blur": (C.c_int, [C.c_void_p, C.c_int]),
@@ -222,6 +224,7 @@ _SIGS = {
 
 # include/fd_hip_bench.h: measurement hooks (not part of the drop-in boundary)
 _BENCH_SIGS = {
+    "fd_debug_svm_u8_both": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "fd_ctx_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "fd_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
     "fd_debug_wvb_rect_sums": (C.c_int64, [C.POINTER(fd_wvm_model), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -438,7 +441,7 @@ class Wvm:
 
     def last_stage_b_plan(self):
         """measurement hook: [(first generation, end generation, windows alive at its start)] per stage-B phase of the last finished run"""
-        out = np.full(10, -1, np.int64)
+        out = np.full(13, -1, np.int64)   # 1 + 3 * WVB_MAXPHASE
         lib().fd_wvm_last_stage_b_plan(self.h, _ptr(out))
         return [(int(out[1 + 3 * i]), int(out[2 + 3 * i]), int(out[3 + 3 * i])) for i in range(max(0, int(out[0])))]
 
@@ -498,6 +501,21 @@ class Dist:
         self.ctx.check(lib().fd_dist_gather_records(self.h, _ptr(local), len(local), cap, _ptr(out), len(out), C.byref(n), C.byref(tr)))
         return out[:n.value], bool(tr.value)
 
+    def gather_begin(self, local, cap):
+        """fd_dist_gather_begin: header exchange + the payload collective queued on the handle's own stream"""
+        local = np.ascontiguousarray(local, np.float64).reshape(-1, 8)
+        self._cap = cap
+        self.ctx.check(lib().fd_dist_gather_begin(self.h, _ptr(local), len(local), cap))
+
+    def gather_end(self):
+        """fd_dist_gather_end -> (records of all ranks, truncated)"""
+        world = lib().fd_dist_world(self.h)
+        n, tr = C.c_int64(), C.c_int()
+        self.ctx.check(lib().fd_dist_gather_end(self.h, None, 0, C.byref(n), C.byref(tr)))   # count first: the buffer follows the records
+        out = np.zeros((max(int(n.value), 1), 8), np.float64)
+        self.ctx.check(lib().fd_dist_gather_end(self.h, _ptr(out), len(out), C.byref(n), C.byref(tr)))
+        return out[:n.value], bool(tr.value)
+
     def discard(self):
         """fd_dist_gather_discard: drop the gathered set a count-only call / FD_ERR_CAPACITY left in the handle"""
         lib().fd_dist_gather_discard(self.h)
@@ -517,6 +535,14 @@ def dist_gather_count(dist, local, cap):
     n, tr = C.c_int64(), C.c_int()
     dist.ctx.check(lib().fd_dist_gather_records(dist.h, _ptr(local), len(local), cap, None, 0, C.byref(n), C.byref(tr)))
     return int(n.value)
+
+
+def svm_u8_both(ctx, svm, feats):
+    """Test hook: distances of u8 vectors through k_svm_u8_rbf_mfma<8> and <16> -> (out8, out16)"""
+    feats = _c(feats, np.uint8).reshape(-1, svm.dim)
+    o8, o16 = np.empty(len(feats), np.float64), np.empty(len(feats), np.float64)
+    ctx.check(lib().fd_debug_svm_u8_both(ctx.h, svm.h, _ptr(feats), len(feats), _ptr(o8), _ptr(o16)))
+    return o8, o16
 
 
 def wvd_plan(nx, ny, frames, sy, ph, slots):

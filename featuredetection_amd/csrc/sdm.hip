@@ -798,6 +798,10 @@ int fd_sdm_create(fd_ctx* ctx, const fd_sdm_model* md, fd_sdm** out) {
                 // the non-adaptive branch: the descriptor length follows from the step's own {numCells, cellSize, numBins}
                 const int32_t* dp = md->desc_params + 3 * s;
                 if (dp[0] < 1 || dp[1] < 1 || dp[2] < 1) FD_THROW(FD_ERR_LOGIC, "descriptorParameters must contain numCells, cellSize and numBins.");
+                //  bounds of what the descriptor kernel's LDS layout holds; also catches a struct that was not zero-initialised
+                if (dp[0] > 8 || dp[1] < 2 || dp[1] > 64 || dp[2] > 32)
+                    FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_sdm_model.desc_params of step %d out of range: numCells %d (1..8), cellSize %d (2..64), numBins %d (1..32)",
+                             s, dp[0], dp[1], dp[2]);
                 DescParams p;
                 fill_desc_params(p, 64, 64, m->L, false, m->variant, dp[0], dp[1], dp[2], 2 * (dp[0] * (dp[1] / 2)));
                 if (md->R_rows[s] != m->L * p.len + 1)

@@ -906,4 +906,31 @@ int fd_svm_distance_batch(fd_ctx* ctx, const fd_svm* m_, const void* features, i
     });
 }
 
+// Test hook (include/fd_hip_bench.h): the u8 RBF stage through BOTH instantiations of k_svm_u8_rbf_mfma for the same vectors -- <8>
+// (every launch of the survivors' SVM stage) and <16> (a single frame's launch over all its WVM positives; the launcher picks it
+// for up to 2048 vectors).  The five-stage entry points rely on the two giving identical bits (one partial per tile of 32 support
+// vectors, added in a fixed pairwise order).
+int fd_debug_svm_u8_both(fd_ctx* ctx, const fd_svm* m_, const uint8_t* features, int64_t n, double* out8, double* out16) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !m_ || n < 1 || !features || !out8 || !out16) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_debug_svm_u8_both: bad argument");
+        fd_svm* m = const_cast<fd_svm*>(m_);
+        if (!fd_svm_u8_mfma_available(m)) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_debug_svm_u8_both: the model has no u8 RBF MFMA path");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const size_t stride = (size_t)m->dev.dim;
+        m->feat.reserve(stride * (size_t)n + 16);
+        m->dist.reserve(sizeof(double) * (size_t)n * 2);
+        HIP_CHECK(hipMemcpyAsync(m->feat.p, features, stride * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        const size_t lb = (size_t)32 * (m->dev.KS * 32 + 16) + 384 + sizeof(double) * (size_t)(m->dev.nsv32 >> 5) * 32;
+        const unsigned grid = (unsigned)((n + 31) / 32);
+        hipLaunchKernelGGL(k_svm_u8_rbf_mfma<8>, dim3(grid), dim3(64 * 8), lb, ctx->stream, m->dev, m->feat.p, (const uint32_t*)nullptr, (int64_t)stride, n,
+                           m->dist.as<double>(), (const unsigned int*)nullptr);
+        hipLaunchKernelGGL(k_svm_u8_rbf_mfma<16>, dim3(grid), dim3(64 * 16), lb, ctx->stream, m->dev, m->feat.p, (const uint32_t*)nullptr, (int64_t)stride, n,
+                           m->dist.as<double>() + n, (const unsigned int*)nullptr);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(out8, m->dist.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(out16, m->dist.as<double>() + n, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
 }  // extern "C"

@@ -2034,7 +2034,7 @@ int fd_wvm_last_tail_state(const fd_wvm* m) { return m ? m->fstLastState : -1; }
 int fd_wvm_last_spec_state(const fd_wvm* m) { return m ? m->specLastState : -1; }
 int fd_wvm_last_stage_b_plan(const fd_wvm* m, int64_t* out) {
     if (!m || !out) return FD_ERR_INVALID_ARGUMENT;
-    const int n = std::min(m->sbLastN, 3);
+    const int n = std::min(m->sbLastN, WVB_MAXPHASE);   // out: 1 + 3 * WVB_MAXPHASE values (the hook reported 3 of up to 4 phases)
     out[0] = n;
     for (int ph = 0; ph < n; ++ph) {
         out[1 + 3 * ph] = m->sbLastGen[ph];

@@ -93,6 +93,7 @@ static int launch_ranks(int gpus, int argc, char** argv, const std::vector<char*
         const pid_t k = waitpid(-1, &st, WNOHANG);
         if (k > 0) {
             --left;
+            kids.erase(std::remove(kids.begin(), kids.end(), k), kids.end());   // reaped: its pid may belong to someone else by now, never signal it again
             if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = 1;
         } else if (k < 0) {
             break;
@@ -108,15 +109,13 @@ static int launch_ranks(int gpus, int argc, char** argv, const std::vector<char*
         } else if (killed && std::chrono::duration<double>(std::chrono::steady_clock::now() - tKill).count() > 5.0) {
             // a rank blocked in a driver / RCCL call does not react to SIGTERM (the very hang this guards against): SIGKILL after a grace
             // period of 5 s, then at most 5 s more for the kernel to reap them -- the launcher never waits forever
+            // (kids holds live children only: reaped ranks were removed above)
             for (pid_t p : kids) kill(p, SIGKILL);
-            const auto tk = std::chrono::steady_clock::now();
-            while (left > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - tk).count() < 5.0) {
+            for (pid_t p : kids) {   // SIGKILL cannot be ignored: a blocking wait per remaining child ends, and leaves no zombie
                 int st2 = 0;
-                const pid_t k2 = waitpid(-1, &st2, WNOHANG);
-                if (k2 > 0) --left;
-                else if (k2 < 0) break;
-                else usleep(2000);
+                if (waitpid(p, &st2, 0) == p) --left;
             }
+            kids.clear();
             break;
         }
     }

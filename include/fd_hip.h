@@ -435,7 +435,10 @@ typedef struct {
                                  * numBins) (SdmLandmarkModel.cpp:188-204), getDescriptors(image, points) with windowSizeHalf = 0 and
                                  * modelShape + deltaShape.t() without the face-size factor.  This is the only way the regressors of the
                                  * reference's shipped model (detect-landmarks/share/models/SDM_Model_HOG_Zhenhua_11012014.txt: 144 / 144 /
-                                 * 64 / 64 / 16 dimensions per landmark) can be applied at all. */
+                                 * 64 / 64 / 16 dimensions per landmark) can be applied at all.
+                                 * The struct MUST be zero-initialised before its fields are set (`fd_sdm_model md = {0};`): this trailing
+                                 * field was added in round 5, and a caller that fills the older fields one by one would otherwise hand
+                                 * in a wild pointer.  Values are validated (1 <= numCells <= 8, 2 <= cellSize <= 64, 1 <= numBins <= 32). */
 } fd_sdm_model;
 int fd_sdm_create(fd_ctx* ctx, const fd_sdm_model* model, fd_sdm** out);
 void fd_sdm_destroy(fd_sdm* m);
@@ -470,19 +473,24 @@ int fd_sdm_fit_batch_end(fd_ctx* ctx, fd_sdm_ticket* ticket, float* shapes_out, 
  * collective.  The reference has no counterpart (it is single-threaded, ffpDetectApp.cpp:548-659 loops over the images of a
  * source); a maintainer binds these around that loop (ffp_detect_app --gpus N).
  *   fd_dist_unique_id   rank 0 creates the communicator id (ncclGetUniqueId, 128 bytes) and hands it to the other ranks by any means
- *   fd_dist_init        joins the communicator on the context's device (ncclCommInitRank); world 1 needs no id and no librccl
- *                       (id == NULL: the rank gathers from itself; id != NULL with world 1: a real one-rank communicator, the gather
- *                       goes through ncclAllGather -- what the one-GPU tests use to run librccl itself)
+ *   fd_dist_init        joins the communicator on the context's device (ncclCommInitRank); world 1 needs no id and no librccl: the
+ *                       rank gathers from itself, whatever id holds.  (FD_DIST_FORCE_COMM=1 in the environment + an id: a real one-rank
+ *                       communicator, the gather goes through ncclAllGather -- what the one-GPU tests use to run librccl itself.)
  *   fd_pack_records     fd_detection -> fixed-stride records {image, detector, cx, cy, w, h, score, probability} (all exact in fp64)
- *   fd_dist_gather_records  ONE ncclAllGather of a padded [cap_per_rank + 1] record buffer per rank (row 0 = count) on the context's
- *                       stream; every rank receives the records of all ranks ordered by (image, detector, original order).
- *                       *truncated != 0: a rank had more than cap_per_rank records (the surplus was dropped).
+ *   fd_dist_gather_records  a 64-byte header exchange (every rank's count) and ONE ncclAllGather of max-count + 1 rows per rank, on the
+ *                       handle's own stream (nothing queued on the context's stream is waited for or held up); every rank receives the
+ *                       records of all ranks ordered by (image, detector, original order).  cap_per_rank: the most records a rank
+ *                       may contribute; *truncated != 0: a rank had more (the surplus was dropped).
  *                       COLLECTIVE: every rank of the communicator makes the call, with the same cap_per_rank (a rank that packed with
  *                       another stride is reported as FD_ERR_INVALID_ARGUMENT on all ranks).  The collective runs once per set of
  *                       records: with all == NULL the call returns the count, with all_cap too small FD_ERR_CAPACITY -- either way the
  *                       gathered records stay in the handle, and the next call with a large enough buffer delivers them WITHOUT another
  *                       collective (so a retry on some ranks only cannot deadlock).  local / n_local of such a follow-up call are ignored.
  *                       FD_RCCL_LIB names another library with the five nccl entry points (tests: tests/stub_rccl).
+ *   fd_dist_gather_begin / _end  the same gather in two halves: _begin exchanges the headers (a wait of tens of microseconds on the
+ *                       gather stream) and queues the payload collective, _end waits for it and delivers -- the records of one
+ *                       interval travel while the caller processes the next interval's images.  One gather in flight per handle; local
+ *                       may be reused as soon as _begin returns.  _end has fd_dist_gather_records' count-only / capacity-retry rules.
  *   fd_dist_gather_discard  drops a gathered set the caller does not want to fetch (after a count-only call or FD_ERR_CAPACITY), so that
  *                       the next fd_dist_gather_records is a new collective.  Every rank must drop or take a set: a rank that still
  *                       holds one would answer the next call from its handle while the others enter ncclAllGather.
@@ -501,6 +509,8 @@ int fd_dist_world(const fd_dist* d);
 int fd_pack_records(int64_t image_id, int32_t detector_id, const fd_detection* dets, int n, fd_record* out);
 int fd_dist_gather_records(fd_dist* d, const fd_record* local, int n_local, int cap_per_rank, fd_record* all, int64_t all_cap,
                            int64_t* n_all, int* truncated);
+int fd_dist_gather_begin(fd_dist* d, const fd_record* local, int n_local, int cap_per_rank);
+int fd_dist_gather_end(fd_dist* d, fd_record* all, int64_t all_cap, int64_t* n_all, int* truncated);
 void fd_dist_gather_discard(fd_dist* d);
 int fd_dist_gather_pending(const fd_dist* d);
 

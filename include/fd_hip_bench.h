@@ -20,7 +20,7 @@ int fd_last_kernel_ms(fd_ctx* ctx, const char** kernel_name, float* ms);
  * together); -1 before the first run.  bench.py reports the spread over the calls of a run. */
 int64_t fd_wvm_last_queue_length(const fd_wvm* wvm);
 /* The stage-B plan of the last finished run: out[0] = phases, then per phase {first generation, end generation, windows alive at its
- * start} (10 int64 at most: 1 + 3 * 3); -1 where unknown.  bench.py derives the chain kernel's algorithmic work from it. */
+ * start} (13 int64 at most: 1 + 3 * 4, the most phases a plan has); -1 where unknown.  bench.py derives the chain kernel's algorithmic work from it. */
 int fd_wvm_last_stage_b_plan(const fd_wvm* wvm, int64_t* out);
 /* How the last finished five-stage run of this handle did its overlap elimination: -1 on the host (no device tail was queued), 0 on
  * the device (csrc/fs_tail.hpp), > 0: the device kernel gave up and the host redid it -- 1 the order of the positives could not be
@@ -45,6 +45,12 @@ int64_t fd_debug_wvb_rect_sums(const fd_wvm_model* md, const uint8_t* patches, i
  * 64 tasks per tile.  Returns K (FD_WVD_K pins it); tile_first[i] = first tile of layer i inside a frame, tile_first[n_layers] = tiles
  * per frame. */
 int fd_debug_wvd_plan(const int32_t* nx, const int32_t* ny, int n_layers, int frames, int sy, int ph, int slots, int32_t* tile_first);
+
+/* Test hook: hyperplane distances of n u8 vectors through both instantiations of the u8 RBF MFMA kernel (8 and 16 wavefronts per
+ * workgroup).  fd_detect_five_stage scores one frame's positives with either, depending on how many the previous frame had, and
+ * relies on bit-identical sums; tests/test_gpu_cascade_hardening.py compares them.  (fd_detect_five_stage keeps per-call state in
+ * the fd_wvm handle: one handle must not be used from two threads at a time.) */
+int fd_debug_svm_u8_both(fd_ctx* ctx, const fd_svm* svm, const uint8_t* features, int64_t n, double* out8, double* out16);
 
 #ifdef __cplusplus
 }

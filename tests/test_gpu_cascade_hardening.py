@@ -432,3 +432,22 @@ def test_detect_image_equals_update_then_detect(oracle, capi, ctx, synth, small_
         assert np.array_equal(st1, sto)
     for h in (wg, sg, pg, pg2):
         h.close()
+
+
+@pytest.mark.parametrize("shape,nsv", [((20, 20), 1024), ((20, 20), 700), ((24, 32), 330), ((16, 24), 40)])
+def test_u8_svm_kernel_with_8_and_16_wavefronts_gives_the_same_bits(capi, ctx, synth, shape, nsv):
+    """a single frame's positives are scored by k_svm_u8_rbf_mfma<16> when the launch covers at most 2048 vectors and by <8>
+    otherwise or on the two-round-trip path -- the same frame may see either, so the two must give identical sums (one partial per tile
+    of 32 support vectors, added in a fixed pairwise order).  Compared directly on identical inputs: 32 / 22 / 11 / 2 support-vector
+    tiles (not multiples of 16) and 13 / 24 / 12 k-steps (24 > 16: vectors of 768 bytes), vector counts that are not multiples of 32."""
+    ph, pw = shape
+    rng = np.random.default_rng(nsv)
+    pool = rng.integers(0, 256, (nsv + 400, ph, pw), dtype=np.uint8)
+    m = synth.make_svm_u8(17, pool, nsv=nsv, calib=pool[nsv:])
+    s = capi.Svm(ctx, m)
+    for n in (1, 33, 777, 2048):
+        feats = rng.integers(0, 256, (n, ph * pw), dtype=np.uint8)
+        o8, o16 = capi.svm_u8_both(ctx, s, feats)
+        assert o8.tobytes() == o16.tobytes(), (shape, nsv, n)
+        assert np.array_equal(o8, s.distance(feats))   # ... and the production launcher's result
+    s.close()

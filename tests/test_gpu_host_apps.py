@@ -191,6 +191,15 @@ for n, cap in ((300, 512), (300, 100), (0, 16), (4096, 4096)):
 assert capi.dist_gather_count(real, local, 4096) == 4096 and real.pending()
 a, _ = real.gather(local[:3], 4096)
 assert len(a) == 4096
+# the two-halves form: the payload travels on the handle's own stream between _begin and _end
+real.gather_begin(local[:77], 4096)
+plain.gather_begin(local[:77], 4096)
+a, ta = real.gather_end()
+b, tb = plain.gather_end()
+assert len(a) == 77 and a.tobytes() == b.tobytes() and not ta and not tb
+real.gather_begin(np.zeros((0, 8)), 16)     # nobody has a record: the payload collective is skipped
+a, _ = real.gather_end()
+assert len(a) == 0
 real.close(); plain.close()
 print("REAL_RCCL_OK")
 """
@@ -202,7 +211,7 @@ def test_real_rccl_one_rank_communicator():
     the no-communicator path and the torch twin.  Proves symbol binding, sizeof(ncclUniqueId), the call signatures and the stream
     semantics; more than one physical GPU stays unmeasured here.  In a child process with a timeout: a communicator that cannot
     bootstrap must fail this test, not hang the suite."""
-    env = dict(os.environ)
+    env = dict(os.environ, FD_DIST_FORCE_COMM="1")   # a one-rank communicator is an explicit request (ADVICE r05)
     env.pop("FD_RCCL_LIB", None)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     try:
