@@ -160,6 +160,18 @@ static bool fst_possible(const fd_wvm* m, const fd_svm* svm, int nimg) {
     if (mode == 0 || (mode != 1 && nimg < 2)) return false;
     return m->wvbOk && m->dev.numUsed > WVM_LCAP && fd_svm_u8_mfma_available(svm);
 }
+// The jobs of a batch (one frame each, fd_detect_five_stage_batch / fd_five_stage_batch_begin): overlap elimination on the device by
+// k_fs_oe_big, whatever the number of positives (config 3 / 5: ~13 K per detector and frame, 0.9 ms of std::sort + painted map per job on a
+// host thread) with FD_FS_TAIL=1.  Unset / 0: the host stages on the context's worker threads -- the default, because what the device tail
+// buys depends on the HIP runtime's hardware queues (GPU_MAX_HW_QUEUES, read when the runtime starts): a job's tail is ~0.3 ms of ONE
+// compute unit on the job's stream, and with the default four queues the streams behind such a kernel stall (config 3: 4.8 G patches/s
+// against the host stages' 5.3 G on eight threads); with six queues the tails overlap and the device wins with a quarter of the host
+// threads (5.6 G on two threads).  The results are the same bytes either way.
+static bool fst_possible_batch(const fd_wvm* m, const fd_svm* svm) {
+    const char* e = getenv("FD_FS_TAIL");
+    if (!e || atoi(e) != 1) return false;
+    return m->wvbOk && m->dev.numUsed > WVM_LCAP && fd_svm_u8_mfma_available(svm);
+}
 static bool spec_possible(const fd_wvm* m, const fd_svm* svm) {
     const char* e = getenv("FD_FS_SPEC");   // read per call: the tests compare both orders
     const bool off = e && atoi(e) == 0;
@@ -171,8 +183,11 @@ static size_t fst_host_offsets(int nimg, int64_t cap, size_t& keepOff, size_t& d
     return distOff + sizeof(double) * (size_t)cap;
 }
 // queues k_fs_oe and the SVM stage behind the cascade of `run` (m->tailRun is set) and records m->tailDone
-static void fst_launch(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm* m, const fd_svm* svm, const WvmRun& run, float oe_dist, float oe_ratio, int sx, int sy) {
+// big: k_fs_oe_big (one frame, any number of positives, painted map in device memory) instead of k_fs_oe (<= 1024 positives per frame)
+static void fst_launch(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm* m, const fd_svm* svm, const WvmRun& run, float oe_dist, float oe_ratio, int sx, int sy,
+                       bool big = false) {
     const int nimg = p->nimg > 1 ? p->nimg : 1;
+    if (big && nimg != 1) FD_THROW(FD_ERR_LOGIC, "k_fs_oe_big takes one frame");
     FstTable T;
     std::memset(&T, 0, sizeof(T));
     T.sx = sx; T.sy = sy; T.nimg = nimg;
@@ -206,7 +221,24 @@ static void fst_launch(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm* m, co
     io.frames = reinterpret_cast<FstFrame*>(hb + 16);
     io.keep = reinterpret_cast<FstKeep*>(hb + keepOff);
     io.hostHdr[0] = 0xffffffffu;
-    hipLaunchKernelGGL(k_fs_oe, dim3((unsigned)nimg), dim3(256), 0, st, T, io);
+    if (big) {
+        FsbIO S;
+        S.cap = (unsigned int)m->pos_cap;
+        S.mapStride = (((p->img_w + 2 * FSB_PAD + 31) >> 5) + 3) & ~3;   // words per row, whole uint4 (the kernel zeroes the map 16 bytes at a time)
+        S.mapH = p->img_h + 2 * FSB_PAD;
+        m->fsbKeys.reserve(sizeof(unsigned long long) * 2 * (size_t)S.cap);
+        m->fsbGeo.reserve(sizeof(int2) * (size_t)S.cap);
+        m->fsbAcc.reserve(sizeof(unsigned int) * (size_t)S.cap);
+        m->fsbMap.reserve(sizeof(unsigned int) * (size_t)S.mapStride * S.mapH);
+        S.keyA = m->fsbKeys.as<unsigned long long>();
+        S.keyB = S.keyA + S.cap;
+        S.geo = m->fsbGeo.as<int2>();
+        S.acc = m->fsbAcc.as<unsigned int>();
+        S.map = m->fsbMap.as<unsigned int>();
+        hipLaunchKernelGGL(k_fs_oe_big, dim3(1), dim3(FSB_T), 0, st, T, io, S);
+    } else {
+        hipLaunchKernelGGL(k_fs_oe, dim3((unsigned)nimg), dim3(256), 0, st, T, io);
+    }
     HIP_CHECK(hipGetLastError());
     m->fstDirty = false;   // k_fs_oe is queued: it leaves the tail's counters clean for the next run
     // the SVM launch covers what the previous run kept, with a margin; a run that keeps more gets a second launch for the rest
@@ -596,6 +628,7 @@ struct fd_five_stage_batch {
     fd_five_stage_job* jobs = nullptr;
     int n = 0;
     std::vector<WvmRun> runs;
+    std::vector<char> tail;   // job i: overlap elimination + SVM were queued on the device behind its cascade (k_fs_oe_big)
 };
 
 static void five_stage_batch_begin(fd_ctx* ctx, fd_five_stage_job* jobs, int n, fd_five_stage_batch& b) {
@@ -604,6 +637,7 @@ static void five_stage_batch_begin(fd_ctx* ctx, fd_five_stage_job* jobs, int n, 
     b.jobs = jobs;
     b.n = n;
     b.runs.assign((size_t)n, WvmRun());
+    b.tail.assign((size_t)n, 0);
     for (int i = 0; i < n; ++i) {
         fd_five_stage_job& j = jobs[i];
         j.count = 0;
@@ -630,7 +664,19 @@ static void five_stage_batch_begin(fd_ctx* ctx, fd_five_stage_job* jobs, int n, 
     const int nunits = n;
     auto cascadeJob = [&](int i) {
         fd_five_stage_job& j = jobs[i];
-        fd_wvm_launch_on(ctx, fd_pool_stream(ctx, i), j.pyramid, const_cast<fd_wvm*>(j.wvm), j.step_x, j.step_y, j.roi, false, b.runs[i], false);
+        fd_wvm* m = const_cast<fd_wvm*>(j.wvm);
+        // stages 2-3 on the device where the model allows (fs_tail.hpp: k_fs_oe_big + the counted SVM launch behind the cascade, on the
+        // job's stream); everything here touches the job's own handles only (the jobs of a batch may be queued by different threads)
+        m->tailWanted = !j.roi && fst_possible_batch(m, j.svm);
+        fd_wvm_launch_on(ctx, fd_pool_stream(ctx, i), j.pyramid, m, j.step_x, j.step_y, j.roi, false, b.runs[i], false);
+        if (m->tailRun) {
+            // (on the job's own stream.  k_fs_oe_big is ONE workgroup working for ~0.3 ms per job, 4.7 ms per 15-detector frame: dedicated
+            // tail streams behind the cascades' events were measured and lost -- 1 / 2 / 4 of them: 3670 / 4426 / 4926 Mpatches/s against
+            // 5565 on the jobs' streams with six hardware queues -- the tails of a frame have to overlap each other)
+            hipStream_t ts = fd_pool_stream(ctx, i);
+            fst_launch(ctx, ts, j.pyramid, m, j.svm, b.runs[i], j.oe_dist, j.oe_ratio, j.step_x, j.step_y, true);
+            b.tail[i] = 1;
+        }
     };
     // A frame costs ~15 runtime calls (pyramid kernels, cascade kernels, copies, events): with many small jobs the single host
     // thread issuing them is the bottleneck, so batches of >= 6 jobs are issued by the worker pool -- all pyramid updates first
@@ -702,14 +748,59 @@ static void five_stage_batch_end(fd_ctx* ctx, fd_five_stage_batch& b) {
     // on the shared high-priority stream, waits for it and finishes with the NMS.  Everything a worker touches belongs to its
     // job (WVM handle, pinned staging, events); the streams are created up front.  FD_BATCH_THREADS=1 keeps it on the caller.
     static const int nthreads = [] { const char* e = getenv("FD_BATCH_THREADS"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+    // ---- jobs whose stages 2-3 ran on the device: the SVM's verdicts, then the block NMS (a few hundred elements per job: this thread).
+    // A job whose device tail gave up (overlapping ties, an overflow, parameters the painted map does not cover) or whose SVM positives
+    // hold two equal WVM outputs (fs_tail.hpp: the order of tied survivors is the reference's std::sort's) takes the host stages below.
+    std::vector<char> doneByTail((size_t)n, 0);
+    int ndone = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!b.tail[i]) continue;
+        fd_five_stage_job& j = jobs[i];
+        fd_wvm* m = const_cast<fd_wvm*>(j.wvm);
+        try {
+            FstResult R;
+            if (!fst_collect(ctx, m, j.svm, b.runs[i], R)) continue;
+            const FstFrame fr = R.frames[0];
+            std::vector<fd_detection> svmPos;
+            std::vector<uint32_t> bits;
+            for (uint32_t q = 0; q < fr.nkeep; ++q) {
+                const double dv = R.dist[fr.base + q];
+                if (dv >= (double)fd_svm_threshold(j.svm)) {
+                    const FstKeep& k = R.keep[fr.base + q];
+                    fd_detection d = fst_detection(j.pyramid, m, b.runs[i], j.step_x, j.step_y, k);
+                    d.score = (float)dv;
+                    d.probability = 0.5;   // ClassifiedPatch(patch, bool) default probability (ClassifiedPatch.hpp:29-30)
+                    svmPos.push_back(d);
+                    uint32_t fb;
+                    std::memcpy(&fb, &k.fout, 4);
+                    bits.push_back(fb);
+                }
+            }
+            std::sort(bits.begin(), bits.end());
+            if (std::adjacent_find(bits.begin(), bits.end()) != bits.end()) { m->fstLastState = 0x200; continue; }   // tied survivors among the SVM positives
+            if (j.stage_counts) { j.stage_counts[0] = (int)fr.npos; j.stage_counts[1] = (int)fr.nkeep; }
+            five_stage_nms(j.pyramid, j.roi, svmPos, j.out, j.cap, &counts[i], j.stage_counts);
+            j.count = counts[i];
+            doneByTail[i] = 1;
+            ++ndone;
+        } catch (const FdError& e) {
+            doneByTail[i] = 1;
+            ++ndone;
+            fail(i, e);
+        }
+    }
+    if (ndone == n) {
+        if (firstError != FD_OK) throw FdError{firstError, ctx->error};
+        return;
+    }
     int64_t totalWindows = 0;
     for (int i = 0; i < n; ++i) totalWindows += b.runs[i].total;
-    if (nthreads > 1 && (n >= 6 || totalWindows >= (int64_t)4 << 20) && n >= 2) {
+    if (nthreads > 1 && (n - ndone >= 6 || totalWindows >= (int64_t)4 << 20) && n - ndone >= 2) {
         if (!ctx->workers) ctx->workers.reset(new FdWorkerPool(nthreads - 1));
         hipStream_t tailStream = fd_tail_stream(ctx);
         (void)fd_aux_stream(ctx);
         std::vector<std::atomic<char>> claimed((size_t)n);
-        for (auto& c : claimed) c.store(0);
+        for (int i = 0; i < n; ++i) claimed[i].store(doneByTail[i]);
         std::mutex errMu;
         auto cascadeDone = [&](int i) {
             return b.runs[i].total == 0 || hipEventQuery(jobs[i].wvm->done) != hipErrorNotReady;
@@ -764,11 +855,14 @@ static void five_stage_batch_end(fd_ctx* ctx, fd_five_stage_batch& b) {
     // would push every host stage behind the last cascade.  While nothing is ready the host polls (events of the cascades, then of
     // the queued SVM stages).
     std::vector<char> begun((size_t)n, 0);
+    int nbegun0 = 0;
+    for (int i = 0; i < n; ++i)
+        if (doneByTail[i]) { begun[i] = 1; tails[i].finished = true; ++nbegun0; }
     auto cascadeReady = [&](int i) {
         const fd_wvm* m = jobs[i].wvm;
         return b.runs[i].total == 0 || hipEventQuery(m->done) != hipErrorNotReady;   // an error surfaces in fd_wvm_finish
     };
-    for (int nbegun = 0; nbegun < n;) {
+    for (int nbegun = nbegun0; nbegun < n;) {
         int pick = -1;
         for (int i = 0; i < n && pick < 0; ++i)
             if (!begun[i] && cascadeReady(i)) pick = i;

@@ -179,6 +179,7 @@ struct fd_wvm {
     bool tailRun = false;            // the run in flight keeps its positives on the device and is followed by k_fs_oe
     DevBuf fstHdr, fstSlots;         // FstHdr + the positive count stage B leaves; the SVM's slot list
     DevBuf fstFrameCount, fstFrameList;   // positives per frame and their slots (filled by k_wvb_exit, consumed and cleared by k_fs_oe)
+    DevBuf fsbKeys, fsbGeo, fsbAcc, fsbMap;   // k_fs_oe_big (one frame, any number of positives): sort buffers, centres, accepted list, painted map
     HostBuf h_fst;                   // pinned: [hostHdr 16 B | FstFrame x frames | FstKeep x pos_cap | double x pos_cap]
     int64_t fstLaunched = 0;         // vectors the SVM launch of the run in flight covers
     int64_t fstPrevKeep = -1;        // survivors of the previous run (sizes the next SVM launch)

@@ -451,3 +451,62 @@ def test_u8_svm_kernel_with_8_and_16_wavefronts_gives_the_same_bits(capi, ctx, s
         assert o8.tobytes() == o16.tobytes(), (shape, nsv, n)
         assert np.array_equal(o8, s.distance(feats))   # ... and the production launcher's result
     s.close()
+
+
+def _big_tail_models(synth, oracle):
+    """three detectors of different patch shapes with WVMs that leave thousands of positives per 960x540 frame"""
+    gray = oracle.bgr2gray(synth.make_frame(640, 480, seed=20260927))
+    out = []
+    for di, name in enumerate(("LeftEyeCenter", "NoseTip", "CenterLipUpperOuter")):
+        inc, mn, mx, pw, ph, nper, nlev = synth.DETECTOR_CFGS[name]
+        src = gray[::2, ::2]
+        calib = synth.random_patches(src.copy(), pw, ph, 6000, np.random.default_rng(100 + di))
+        wm = synth.make_wvm(70 + di, fw=pw, fh=ph, n_per=nper, n_levels=min(nlev, 3), calib_patches=calib, min_survivors=60)
+        eq = synth.histeq64_np(synth.random_patches(src.copy(), pw, ph, 456, np.random.default_rng(200 + di)))
+        sm = synth.make_svm_u8(300 + di, eq, nsv=256, calib=eq[256:])
+        out.append((name, (inc, mn, mx), wm, sm))
+    return out
+
+
+@pytest.mark.parametrize("content", ["plain", "tiled"])
+def test_batch_device_tail_equals_the_host_tail(oracle, capi, ctx, synth, monkeypatch, content):
+    """The jobs of a batch (fd_detect_five_stage_batch: config 3 / 5) run their overlap elimination on the device whatever the number of
+    positives (fs_tail.hpp: k_fs_oe_big -- radix sort, painted map in device memory, 256 candidates per step).  Against the host stages
+    (FD_FS_TAIL=0: std::sort + hostalgo.cpp) the detections must be the same BYTES, on frames with thousands of positives per job.
+    "tiled": the frame is two identical halves, so every positive has a twin with the same fp32 output far away -- ties that do not
+    overlap are harmless for the set of survivors and are handled on the device; a job whose SVM positives contain a tied pair, or whose
+    tied elements overlap, is handed to the host stages (the hook says which path produced a job's result); either way the bytes agree.
+    One job is also compared with the oracle."""
+    frame = synth.make_frame(960, 540, seed=3)
+    if content == "tiled":
+        frame = np.ascontiguousarray(np.concatenate([frame[:, :480], frame[:, :480]], axis=1))
+    models = _big_tail_models(synth, oracle)
+    pyr = capi.Pyramid(ctx, inc=float(np.float32(0.9)), min_scale=float(np.float32(0.5)), max_scale=float(np.float32(0.7)))
+    pyr.update(frame)
+    handles = [(capi.Wvm(ctx, wm), capi.Svm(ctx, sm)) for _, _, wm, sm in models]
+    jobs = [(pyr, w, s) for w, s in handles]
+    monkeypatch.setenv("FD_FS_TAIL", "0")
+    ref = capi.detect_five_stage_batch(ctx, jobs, cap=1 << 14)
+    assert all(w.last_tail_state() == -1 for w, _ in handles)
+    monkeypatch.setenv("FD_FS_TAIL", "1")
+    got = capi.detect_five_stage_batch(ctx, jobs, cap=1 << 14)
+    states = [w.last_tail_state() for w, _ in handles]
+    got2 = capi.detect_five_stage_batch(ctx, jobs, cap=1 << 14)   # second run: the SVM launch is sized from the first
+    for (name, *_), (dr, sr), (dg, sg), (dg2, sg2) in zip(models, ref, got, got2):
+        assert sr[0] > 1024, (name, sr)   # more positives than k_fs_oe's LDS arrays hold
+        assert np.array_equal(sg, sr) and dg.tobytes() == dr.tobytes(), (name, sg, sr)
+        assert np.array_equal(sg2, sr) and dg2.tobytes() == dr.tobytes(), name
+    assert all(st in (0, 1, 0x200) for st in states), states   # 0: the device's result; 1: overlapping ties; 0x200: tied SVM positives
+    if content == "plain":
+        assert 0 in states, states
+    # the oracle on one job
+    po = oracle.Pyramid(inc=float(np.float32(0.9)), min_scale=float(np.float32(0.5)), max_scale=float(np.float32(0.7)))
+    po.update(frame)
+    name, _, wm, sm = models[0]
+    do, so = oracle.five_stage(po, oracle.Wvm(wm), oracle.Svm(sm), cap=1 << 14)
+    assert np.array_equal(got[0][1], so), (got[0][1], so)
+    for fld in ("cx", "cy", "w", "h"):
+        assert np.array_equal(got[0][0][fld], do[fld]), fld
+    for w, s in handles:
+        w.close(); s.close()
+    pyr.close()

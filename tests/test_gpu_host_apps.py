@@ -760,7 +760,7 @@ def test_bench_config5_one_and_two_ranks(tmp_path):
     assert rec2["n_gpus"] == 2 and rec2["scaling"] == "strong" and rec2["steps"] == 1
     assert rec2["detections_delivered"] == rec1["detections_delivered"]          # the same 24 images, whatever the sharding
     assert rec2["records_gathered"] == rec2["detections_delivered"] and not rec2["records_truncated"]
-    assert abs(rec2["value"] * rec2["ms_per_step"] - rec1["value"] * rec1["ms_per_step"]) < 1e-6 * rec1["value"] * rec1["ms_per_step"]   # same windows
+    assert abs(rec2["value"] * rec2["ms_per_step"] - rec1["value"] * rec1["ms_per_step"]) < 1e-4 * rec1["value"] * rec1["ms_per_step"]   # same windows (the line carries 6 digits)
 
 
 @pytest.mark.gpu
