@@ -721,9 +721,9 @@ class Ffp15(Workload):
         self.stage_sum, self.stage_frames = np.zeros(4, np.int64), 0
         self.models = ffp15_models()
         ctx = env.ctx
-        # two frames in flight (FD_BENCH_FFP_SLOTS), each with its own pyramids and classifier handles: frame f + 1's pyramids and
+        # three frames in flight (FD_BENCH_FFP_SLOTS; round 6: 5309 against 5204-5224 Mpatches/s with two), each with its own pyramids and classifier handles: frame f + 1's pyramids and
         # cascades are queued before frame f's host stages (ordering, overlap elimination, SVM launches, NMS) are collected
-        nslots = max(1, int(os.environ.get("FD_BENCH_FFP_SLOTS", "2")))
+        nslots = max(1, int(os.environ.get("FD_BENCH_FFP_SLOTS", "3")))
         self.slots = []
         for k in range(nslots):
             pyrs, dets = {}, []
