@@ -942,7 +942,7 @@ class Sdm(Workload):
         self.FP = max(1, batches_per_step)
         # 256 DISTINCT crops per batch and NBATCH distinct batches cycled ("256 seeded crops");
         # generated on the device (device_frames, scenes of 4 crops with different busy-ness), one gray plane per crop
-        self.NBATCH = 4
+        self.NBATCH = max(1, int(os.environ.get("FD_BENCH_SDM_NBATCH", "4")))   # (1 for counter passes: rocprofv3 --pmc does not survive the generator's ~40 K tiny dispatches)
         ids = np.arange(self.NBATCH * self.B) + 500000 * (1 + env.rank)
         crops = device_frames(ids, self.W, self.H, env.dev, seed0=20260929)
         self.dimgs = [torch.stack([c[..., 1] for c in crops[b * self.B:(b + 1) * self.B]]).contiguous() for b in range(self.NBATCH)]

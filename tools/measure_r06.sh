@@ -35,7 +35,7 @@ if [ "$WHAT" = stats ] || [ "$WHAT" = all ]; then
   done
 fi
 if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
-  rm -f $O/r06_pmc.json
+  [ -z "$KEEP_PMC" ] && rm -f $O/r06_pmc.json   # KEEP_PMC=1 WLS=sdm: add one workload to an existing file
   for wl in $WLS; do
     S=3; FP="--frames-per-step 64"
     [ $wl = sdm ] && FP="--frames-per-step 4"
@@ -47,7 +47,8 @@ if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
                "SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES" \
                "FETCH_SIZE" "WRITE_SIZE"; do
       i=$((i+1))
-      timeout 400 $(iso_env $wl) rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc_${wl}_$i -- $CMD > /dev/null 2> $O/pmc_${wl}_$i.err
+      PX=""; [ $wl = sdm ] && PX="env FD_BENCH_SDM_NBATCH=1"   # (the crop generator's ~40 K tiny torch dispatches crash a counter pass)
+      timeout 400 $(iso_env $wl) $PX rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc_${wl}_$i -- $CMD > /dev/null 2> $O/pmc_${wl}_$i.err
     done
     case $wl in
       sdm)     K=k_sdm_descriptors,k_sdm;;
