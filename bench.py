@@ -944,7 +944,10 @@ class Sdm(Workload):
         # generated on the device (device_frames, scenes of 4 crops with different busy-ness), one gray plane per crop
         self.NBATCH = max(1, int(os.environ.get("FD_BENCH_SDM_NBATCH", "4")))   # (1 for counter passes: rocprofv3 --pmc does not survive the generator's ~40 K tiny dispatches)
         ids = np.arange(self.NBATCH * self.B) + 500000 * (1 + env.rank)
-        crops = device_frames(ids, self.W, self.H, env.dev, seed0=20260929)
+        if os.environ.get("FD_BENCH_SDM_HOSTGEN"):   # counter passes: rocprofv3 --pmc segfaults inside the torch generator at this size
+            crops = [torch.from_numpy(np.repeat(synth.make_frame(self.W, self.H, seed=int(i), channels=1)[..., None], 3, axis=2)).to(env.dev) for i in ids]
+        else:
+            crops = device_frames(ids, self.W, self.H, env.dev, seed0=20260929)
         self.dimgs = [torch.stack([c[..., 1] for c in crops[b * self.B:(b + 1) * self.B]]).contiguous() for b in range(self.NBATCH)]
         self.imgs16 = self.dimgs[0][:16].cpu().numpy()
         del crops

@@ -47,7 +47,7 @@ if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
                "SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES" \
                "FETCH_SIZE" "WRITE_SIZE"; do
       i=$((i+1))
-      PX=""; [ $wl = sdm ] && PX="env FD_BENCH_SDM_NBATCH=1"   # (the crop generator's ~40 K tiny torch dispatches crash a counter pass)
+      PX=""; [ $wl = sdm ] && PX="env FD_BENCH_SDM_NBATCH=1 FD_BENCH_SDM_HOSTGEN=1"   # (rocprofv3 --pmc segfaults inside the torch crop generator: host-made crops, one batch)
       timeout 400 $(iso_env $wl) $PX rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc_${wl}_$i -- $CMD > /dev/null 2> $O/pmc_${wl}_$i.err
     done
     case $wl in
