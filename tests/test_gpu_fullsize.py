@@ -347,3 +347,44 @@ def test_multi_frame_ticket_reports_errors_and_stays_usable(capi, ctx, synth, sm
     assert dets.tobytes() == b"".join(d.tobytes() for d, _ in ref)
     assert np.array_equal(stages, np.stack([s for _, s in ref]))
     w_.close(); s_.close(); p_.close()
+
+
+def test_config5_image_against_the_oracle(oracle, capi, ctx, synth):
+    """BASELINE config 5's content: images generated on the device from (seed, image index) (bench.device_frames, what `bench.py
+    --workload config5` shards over the ranks).  Image 7 of the job through the 15 detectors as one batch (the job's per-image call);
+    the three 20x20 face detectors and one 24x24 detector (2.7 M windows, the busiest kind on this content) are compared with the
+    complete oracle cascade on the full 1920x1080 frame: stage counts, boxes, order, scores."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    img = bench.device_frames(np.array([7]), 1920, 1080, dev, seed0=20260928)[0]   # config 5's seed
+    frame = img.cpu().numpy()
+    models = _models(synth, oracle, nsv=1024)
+    pyrs, dets = {}, []
+    for name, key, wm, sm, pw, ph in models:
+        if key not in pyrs:
+            pyrs[key] = capi.Pyramid(ctx, **_kw(key))
+            pyrs[key].update_device(img.data_ptr(), 1920, 1080, 3)
+        dets.append((name, key, pyrs[key], capi.Wvm(ctx, wm), capi.Svm(ctx, sm), wm, sm))
+    res = capi.detect_five_stage_batch(ctx, [(p, w, s) for _, _, p, w, s, _, _ in dets], cap=1 << 14)
+    assert sum(int(st[0]) for _, st in res) > 10000   # busy content: tens of thousands of WVM positives over the 15 detectors
+    opyr = {}
+    checked = 0
+    for i, (name, key, p, w, s, wm, sm) in enumerate(dets):
+        if not (name.startswith("Face") or name == "LeftLipCorner"):
+            continue
+        if key not in opyr:
+            opyr[key] = oracle.Pyramid(**_kw(key))
+            opyr[key].update(frame)
+        do, so = oracle.five_stage(opyr[key], oracle.Wvm(wm), oracle.Svm(sm), cap=1 << 14)
+        dg, sg = res[i]
+        assert np.array_equal(sg, so), (name, sg, so)
+        for f in ("cx", "cy", "w", "h", "layer", "lx", "ly", "level"):
+            assert np.array_equal(dg[f], do[f]), (name, f)
+        assert np.allclose(dg["score"], do["fout"], rtol=1e-4, atol=1e-6), name
+        checked += 1
+    assert checked == 4
+    for d_ in dets:
+        d_[3].close(); d_[4].close()
+    for p in pyrs.values():
+        p.close()

@@ -724,7 +724,7 @@ def test_hog_rbf_svm_detector_config2(oracle, capi, ctx, synth):
     sg.close(); pg.close()
 
 
-@pytest.mark.parametrize("size,nsv", [((160, 120), 100), ((320, 240), 300), ((333, 251), 1024), ((640, 480), 64)])
+@pytest.mark.parametrize("size,nsv", [((160, 120), 100), ((320, 240), 300), ((333, 251), 1024), ((640, 480), 64), ((45, 37), 33), ((97, 22), 256)])
 def test_hog_svm_fused_kernel_equals_the_two_kernel_path(oracle, capi, ctx, synth, size, nsv, monkeypatch):
     """config 2's shape runs as ONE kernel (hog_svm_fused.hpp: HOG vectors produced in the registers of the MFMA operand, support
     vectors streamed).  Against the two-kernel path (k_hog_tile -> features in HBM -> k_svm_rbf_mfma_svs, FD_HOG_FUSED=0) the HOG
@@ -738,6 +738,12 @@ def test_hog_svm_fused_kernel_equals_the_two_kernel_path(oracle, capi, ctx, synt
     pg.set_layer_filter(1, bins=9)
     pg.update(synth.make_frame(W, H, seed=32))
     feats2 = capi.extract_hog(ctx, pg, capi.hog_params())
+    if len(feats2) < nsv:   # tiny frames (a handful of windows, fewer than one tile of 32): support vectors from a larger frame's vectors
+        pb = capi.Pyramid(ctx, **kw)
+        pb.set_layer_filter(1, bins=9)
+        pb.update(synth.make_frame(320, 240, seed=33))
+        feats2 = capi.extract_hog(ctx, pb, capi.hog_params())
+        pb.close()
     m = synth.make_svm_f32(7, feats2[:: max(1, len(feats2) // 4000)], nsv=nsv, gamma=0.5, positive_fraction=0.05)
     pg.update(frame)
     sg = capi.Svm(ctx, m)
