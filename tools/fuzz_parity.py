@@ -511,8 +511,119 @@ def case_sdm(rng, ctx):
     return None
 
 
+def case_hog_fused(rng, ctx):
+    """config 2's shape (20x20 patches, 5-pixel cells, 2x2 blocks, 9 bins) through k_hog_svm_fused on random frames, pyramids, strides and
+    support-vector counts: against the oracle, and against the two-kernel path (FD_HOG_FUSED=0)"""
+    frame, frame2 = rand_frame(rng), rand_frame(rng)
+    kw = rand_pyr_kw(rng)
+    sx, sy = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    po = O.Pyramid(**kw); po.set_layer_filter(1, bins=9); po.update(frame2)
+    pg = capi.Pyramid(ctx, **kw); pg.set_layer_filter(1, bins=9)
+    keep = os.environ.get("FD_HOG_FUSED")
+    try:
+        _, _, feats2 = O.sliding_hog_svm(po, None, 20, 20, sx, sy, 9, 5, 2, want_feats=10 ** 9)
+        if feats2 is None or len(feats2) < 40:
+            return None
+        nsv = int(rng.choice([33, 64, 257, 700, 1024]))
+        m = synth.make_svm_f32(int(rng.integers(1 << 20)), feats2, nsv=min(nsv, len(feats2)), gamma=float(rng.choice([0.5, 2.0])), positive_fraction=0.05)
+        po.update(frame)
+        dets_o, dist_o, _ = O.sliding_hog_svm(po, O.Svm(m), 20, 20, sx, sy, 9, 5, 2)
+        if len(dist_o) == 0:
+            return None
+        pg.update(frame)
+        hp = capi.hog_params(pw=20, ph=20, sx=sx, sy=sy, bins=9, cell=5, block=2, signed_and_unsigned=False)
+        sg = capi.Svm(ctx, m)
+        try:
+            os.environ["FD_HOG_FUSED"] = "1"
+            dets_g, dist_g = capi.detect_hog_svm(ctx, pg, sg, hp)
+            os.environ["FD_HOG_FUSED"] = "0"
+            dets_2, dist_2 = capi.detect_hog_svm(ctx, pg, sg, hp)
+        finally:
+            sg.close()
+        STATS['windows'] += len(dist_o)
+        scale = np.abs(m["coeff"]).sum()
+        if len(dist_g) != len(dist_o):
+            return "window count %d vs %d" % (len(dist_g), len(dist_o))
+        err = np.abs(dist_g - dist_o)
+        if err.max() > 1e-5 * scale or err.max() > 1e-4 * max(1.0, np.abs(dist_o).max()):
+            return "fused HOG+SVM distances differ from the oracle: %g (scale %g, nsv %d, %d windows)" % (float(err.max()), float(scale), len(m["coeff"]), len(dist_o))
+        if np.abs(dist_g - dist_2).max() > 2e-7 * scale:
+            return "fused vs two-kernel path: %g (scale %g)" % (float(np.abs(dist_g - dist_2).max()), float(scale))
+        safe = np.abs(dist_o - m["threshold"]) > 1e-4
+        pos_o, pos_g = np.nonzero(dist_o >= m["threshold"])[0], np.nonzero(dist_g >= m["threshold"])[0]
+        if not np.array_equal(pos_o[safe[pos_o]], pos_g[safe[pos_g]]):
+            return "positives differ away from the threshold"
+        if np.array_equal(pos_o, pos_g):
+            e = same_geometry(dets_g, dets_o)
+            if e:
+                return "fused HOG+SVM " + e
+    finally:
+        if keep is None:
+            os.environ.pop("FD_HOG_FUSED", None)
+        else:
+            os.environ["FD_HOG_FUSED"] = keep
+        pg.close(); po.close()
+    return None
+
+
+def case_batch_tail(rng, ctx):
+    """the jobs of a batch with their overlap elimination on the device (k_fs_oe_big, FD_FS_TAIL=1) against the host stages (FD_FS_TAIL=0):
+    random frames, 1..4 detectors of random patch shapes on one pyramid, WVMs that leave hundreds to thousands of positives; one job
+    also against the oracle"""
+    frame = rand_frame(rng)
+    if rng.random() < 0.3:   # repeated content: ties with equal outputs far apart
+        half = frame[:, : frame.shape[1] // 2]
+        frame = np.ascontiguousarray(np.concatenate([half, half], axis=1))
+    gray = O.bgr2gray(frame)
+    kw = rand_pyr_kw(rng)
+    njobs = int(rng.integers(1, 5))
+    pg = capi.Pyramid(ctx, **kw); pg.update(frame)
+    po = O.Pyramid(**kw); po.update(frame)
+    handles, models = [], []
+    keep = os.environ.get("FD_FS_TAIL")
+    try:
+        for _ in range(njobs):
+            pw, ph = SIZES[int(rng.integers(5))]   # the sizes with a dense pre-filter (the device tail needs the production cascade)
+            src = np.ascontiguousarray(gray[::2, ::2])
+            if src.shape[0] <= ph + 2 or src.shape[1] <= pw + 2:
+                src = gray
+            calib = synth.random_patches(src, pw, ph, 1500, rng)
+            wvm = synth.make_wvm(int(rng.integers(1 << 20)), fw=pw, fh=ph, n_per=int(rng.choice([10, 14, 20])), n_levels=int(rng.integers(2, 4)), calib_patches=calib,
+                                 min_survivors=int(rng.integers(30, 400)))
+            eq = synth.histeq64_np(synth.random_patches(src, pw, ph, 260, rng))
+            svm = synth.make_svm_u8(int(rng.integers(1 << 20)), eq, nsv=int(rng.choice([33, 64, 100])), calib=eq[100:], positive_fraction=0.4)
+            models.append((wvm, svm))
+            handles.append((capi.Wvm(ctx, wvm), capi.Svm(ctx, svm)))
+        jobs = [(pg, w, s) for w, s in handles]
+        os.environ["FD_FS_TAIL"] = "0"
+        ref = capi.detect_five_stage_batch(ctx, jobs, cap=1 << 14)
+        os.environ["FD_FS_TAIL"] = "1"
+        got = capi.detect_five_stage_batch(ctx, jobs, cap=1 << 14)
+        states = [w.last_tail_state() for w, _ in handles]
+        for ji, ((dr, sr), (dg, sg)) in enumerate(zip(ref, got)):
+            STATS['detections'] += len(dr)
+            STATS['candidates'] += int(sr[0])
+            if not np.array_equal(sr, sg) or dr.tobytes() != dg.tobytes():
+                return "job %d of %d: device tail %s vs host stages %s (state %s, frame %s)" % (ji, njobs, sg.tolist(), sr.tolist(), states[ji], frame.shape)
+        do, so = O.five_stage(po, O.Wvm(models[0][0]), O.Svm(models[0][1]), cap=1 << 14)
+        if not np.array_equal(got[0][1], so):
+            return "stage counts %s vs the oracle's %s" % (got[0][1].tolist(), so.tolist())
+        e = same_geometry(got[0][0], do)
+        if e:
+            return "batch " + e
+    finally:
+        if keep is None:
+            os.environ.pop("FD_FS_TAIL", None)
+        else:
+            os.environ["FD_FS_TAIL"] = keep
+        for w, s in handles:
+            w.close(); s.close()
+        pg.close(); po.close()
+    return None
+
+
 CASES = dict(pyramid=case_pyramid, cascade=case_cascade, frames=case_frames, hist=case_hist, fhog=case_fhog, aggregated=case_aggregated, svm=case_svm,
-             hog_svm=case_hog_svm, rvm=case_rvm, whi=case_whi, sdm=case_sdm)
+             hog_svm=case_hog_svm, rvm=case_rvm, whi=case_whi, sdm=case_sdm, hog_fused=case_hog_fused, batch_tail=case_batch_tail)
 
 
 def main():
