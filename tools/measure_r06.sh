@@ -5,7 +5,7 @@
 # bench.py's roofline.kernel_ms can be recomputed from the CSV; (2) the --pmc passes (each counter group in its own run, kernel trace
 # only) behind roofline.traffic and roofline_issue; (3) the driver's command, whose line reads the fresh profiles/r06_pmc.json, and the
 # single-frame latency.  Outputs under gpurun_out/measure6/; tools/collect_profiles_r06.sh copies the summaries into profiles/.
-# usage: tools/measure_r06.sh [stats|pmc|bench|all]   (default all);  WLS="..." restricts the workloads
+# usage: tools/measure_r06.sh [stats|pmc|bench|all|tail]   (default all; tail: the host-stages / device-tail x hardware-queues table);  WLS="..." restricts the workloads
 R=$PWD
 O=$R/gpurun_out/measure6
 mkdir -p $O
@@ -63,6 +63,20 @@ fi
 if [ "$WHAT" = bench ] || [ "$WHAT" = all ]; then
   ( cd $R && timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 --full-out $O/bench_also.json > $O/bench_line.json 2> $O/bench_default.err )
   timeout 300 python $R/tools/latency_probe.py 1000 > $O/latency_single_frame.txt 2>&1
+fi
+if [ "$WHAT" = tail ]; then
+  # DESIGN.md section 6's table: the 15-detector batch with its stages 2-3 on the host / on the device (k_fs_oe_big) against the HIP
+  # runtime's hardware queues, and the headline beside it (one process has one GPU_MAX_HW_QUEUES)
+  T=$O/ffp15_tail_matrix.txt; : > $T
+  run() { wl=$1; shift; env "$@" $B --workload $wl --also none --steps 20 --warmup 3 --no-cpu-baseline --no-probe --full-out /tmp/tail_full.json | python3 -c "import sys,json; r=json.loads(sys.stdin.read()); print('%-8s %-95s %8.1f Mpatches/s %7.2f ms/step' % ('$wl', '$*', r['value'], r['ms_per_step']))" >> $T; }
+  for Q in 4 6 8; do
+    run cascade GPU_MAX_HW_QUEUES=$Q
+    run ffp15 GPU_MAX_HW_QUEUES=$Q FD_FS_TAIL=0 FD_BATCH_THREADS=8
+    run ffp15 GPU_MAX_HW_QUEUES=$Q FD_FS_TAIL=1 FD_BATCH_THREADS=1
+    run ffp15 GPU_MAX_HW_QUEUES=$Q FD_FS_TAIL=1 FD_BATCH_THREADS=2
+  done
+  echo "git head $HEAD" >> $T
+  cat $T
 fi
 ls $O | head -60
 wc -c $O/bench_line.json 2>/dev/null
