@@ -108,3 +108,12 @@ FdAsyncQueue& fd_async_queue() {
     }());
     return q;
 }
+
+FdAsyncQueue& fd_batch_queue() {
+    static FdAsyncQueue q([] {
+        const char* e = getenv("FD_BATCH_THREADS");
+        const int n = e ? atoi(e) : 8;
+        return n < 1 ? 1 : (n > 16 ? 16 : n);
+    }());
+    return q;
+}

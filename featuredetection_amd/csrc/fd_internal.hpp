@@ -148,6 +148,7 @@ struct FdAsyncQueue {
     }
 };
 FdAsyncQueue& fd_async_queue();   // ctx.hip
+FdAsyncQueue& fd_batch_queue();   // ctx.hip: the per-detector host stages of batches in flight (FD_BATCH_THREADS threads)
 
 struct fd_ctx {
     int device = 0;

@@ -629,7 +629,52 @@ struct fd_five_stage_batch {
     int n = 0;
     std::vector<WvmRun> runs;
     std::vector<char> tail;   // job i: overlap elimination + SVM were queued on the device behind its cascade (k_fs_oe_big)
+    // ticket entry points: the host stages of job i as a task of fd_batch_queue() (null: taken by fd_five_stage_batch_end itself)
+    std::vector<std::shared_ptr<FdAsyncTask>> tasks;
+    std::vector<FiveStageTail> tails;
+    std::vector<int> counts;
+    ~fd_five_stage_batch() {   // the tasks reference this object: never released while one is running
+        for (std::shared_ptr<FdAsyncTask>& t : tasks)
+            if (t) { try { t->wait(); } catch (...) {} }
+    }
 };
+
+// The host stages of the jobs of a batch in flight, one task per job on the process-wide batch queue: a worker waits for the job's
+// cascade, reads its positives back, runs the overlap elimination, queues the SVM stage on the shared high-priority stream, waits
+// for it and finishes with the NMS -- everything a task touches belongs to its job.  With the stages inside _end (the blocking entry
+// point) a frame's _end lasts as long as its heaviest detector's tail (config 3 on busy content: one detector with 70 K WVM positives,
+// ~5.5 ms of serial host work, while the other fourteen are done after ~2.5 ms and the GPU idles half of the time); as tasks the
+// tails of the frames in flight overlap each other and the host stages run at (sum of the work) / threads.  FD_BATCH_ASYNC=0 keeps them in _end.
+static void five_stage_batch_submit(fd_ctx* ctx, fd_five_stage_batch& b) {
+    if (const char* e = getenv("FD_BATCH_ASYNC")) if (atoi(e) == 0) return;
+    const int n = b.n;
+    if (n < 2) return;
+    for (int i = 0; i < n; ++i)
+        if (b.runs[(size_t)i].timed) return;
+    hipStream_t tailStream = fd_tail_stream(ctx);   // created here, on the caller's thread
+    (void)fd_aux_stream(ctx);
+    b.tasks.assign((size_t)n, nullptr);
+    b.tails.assign((size_t)n, FiveStageTail());
+    b.counts.assign((size_t)n, 0);
+    std::vector<int> order;
+    for (int i = 0; i < n; ++i)
+        if (!b.tail[(size_t)i]) order.push_back(i);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return b.jobs[a].wvm->prevPos > b.jobs[c].wvm->prevPos; });   // heaviest first
+    fd_five_stage_batch* bp = &b;
+    for (int i : order) {
+        b.tasks[(size_t)i] = fd_batch_queue().submit([ctx, bp, i, tailStream] {
+            HIP_CHECK(hipSetDevice(ctx->device));
+            fd_five_stage_job& j = bp->jobs[i];
+            fd_wvm* m = const_cast<fd_wvm*>(j.wvm);
+            fd_wvm_finish(ctx, m, bp->runs[(size_t)i]);
+            FiveStageTail& t = bp->tails[(size_t)i];
+            t.begin(ctx, j.pyramid, m, j.svm, bp->runs[(size_t)i], j.oe_dist, j.oe_ratio, j.step_x, j.step_y, j.roi, tailStream, j.out, j.cap,
+                    &bp->counts[(size_t)i], j.stage_counts);
+            t.end();
+            j.count = bp->counts[(size_t)i];
+        });
+    }
+}
 
 static void five_stage_batch_begin(fd_ctx* ctx, fd_five_stage_job* jobs, int n, fd_five_stage_batch& b) {
     if (!ctx || n < 0 || (n > 0 && !jobs)) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_detect_five_stage_batch: bad argument");
@@ -661,14 +706,31 @@ static void five_stage_batch_begin(fd_ctx* ctx, fd_five_stage_job* jobs, int n, 
         fd_five_stage_job& j = jobs[i];
         if (j.image) fd_pyramid_update_on(j.pyramid, j.image, j.image_w, j.image_h, j.image_channels, j.image_is_device, fd_pool_stream(ctx, i));
     };
-    const int nunits = n;
-    auto cascadeJob = [&](int i) {
+    // Detectors that scan the same windows -- one pyramid, one patch size, one stepping, no ROI -- share their dense pre-filter
+    // (k_wvm_prefilter_group: seven of ffpDetectApp's fifteen detectors are one such group, the ears and the profile faces two more).
+    // A unit is a group (or a single job), the largest groups first.
+    std::vector<std::vector<int>> units;
+    for (int i = 0; i < n; ++i) {
+        const fd_five_stage_job& j = jobs[i];
+        bool placed = false;
+        if (!j.roi && fd_wvm_groupable(j.wvm)) {
+            for (std::vector<int>& u : units) {
+                const fd_five_stage_job& h = jobs[u[0]];
+                if ((int)u.size() < WVD_GMAX && !h.roi && fd_wvm_groupable(h.wvm) && h.pyramid == j.pyramid && h.step_x == j.step_x && h.step_y == j.step_y &&
+                    h.wvm->dev.fw == j.wvm->dev.fw && h.wvm->dev.fh == j.wvm->dev.fh) {
+                    u.push_back(i);
+                    placed = true;
+                    break;
+                }
+            }
+        }
+        if (!placed) units.push_back(std::vector<int>(1, i));
+    }
+    std::stable_sort(units.begin(), units.end(), [](const std::vector<int>& a, const std::vector<int>& c) { return a.size() > c.size(); });
+    const int nunits = (int)units.size();
+    auto tailOf = [&](int i) {
         fd_five_stage_job& j = jobs[i];
         fd_wvm* m = const_cast<fd_wvm*>(j.wvm);
-        // stages 2-3 on the device where the model allows (fs_tail.hpp: k_fs_oe_big + the counted SVM launch behind the cascade, on the
-        // job's stream); everything here touches the job's own handles only (the jobs of a batch may be queued by different threads)
-        m->tailWanted = !j.roi && fst_possible_batch(m, j.svm);
-        fd_wvm_launch_on(ctx, fd_pool_stream(ctx, i), j.pyramid, m, j.step_x, j.step_y, j.roi, false, b.runs[i], false);
         if (m->tailRun) {
             // (on the job's own stream.  k_fs_oe_big is ONE workgroup working for ~0.3 ms per job, 4.7 ms per 15-detector frame: dedicated
             // tail streams behind the cascades' events were measured and lost -- 1 / 2 / 4 of them: 3670 / 4426 / 4926 Mpatches/s against
@@ -677,6 +739,32 @@ static void five_stage_batch_begin(fd_ctx* ctx, fd_five_stage_job* jobs, int n, 
             fst_launch(ctx, ts, j.pyramid, m, j.svm, b.runs[i], j.oe_dist, j.oe_ratio, j.step_x, j.step_y, true);
             b.tail[i] = 1;
         }
+    };
+    auto cascadeJob = [&](int ui) {
+        const std::vector<int>& u = units[(size_t)ui];
+        if (u.size() > 1) {
+            hipStream_t sts[WVD_GMAX];
+            fd_wvm* ms[WVD_GMAX];
+            WvmRun* rs[WVD_GMAX];
+            for (size_t q = 0; q < u.size(); ++q) {
+                fd_five_stage_job& j = jobs[u[q]];
+                ms[q] = const_cast<fd_wvm*>(j.wvm);
+                ms[q]->tailWanted = fst_possible_batch(ms[q], j.svm);
+                sts[q] = fd_pool_stream(ctx, u[q]);
+                rs[q] = &b.runs[u[q]];
+            }
+            fd_wvm_launch_group(ctx, sts, jobs[u[0]].pyramid, ms, (int)u.size(), jobs[u[0]].step_x, jobs[u[0]].step_y, rs);
+            for (int i : u) tailOf(i);
+            return;
+        }
+        const int i = u[0];
+        fd_five_stage_job& j = jobs[i];
+        fd_wvm* m = const_cast<fd_wvm*>(j.wvm);
+        // stages 2-3 on the device where the model allows (fs_tail.hpp: k_fs_oe_big + the counted SVM launch behind the cascade, on the
+        // job's stream); everything here touches the job's own handles only (the jobs of a batch may be queued by different threads)
+        m->tailWanted = !j.roi && fst_possible_batch(m, j.svm);
+        fd_wvm_launch_on(ctx, fd_pool_stream(ctx, i), j.pyramid, m, j.step_x, j.step_y, j.roi, false, b.runs[i], false);
+        tailOf(i);
     };
     // A frame costs ~15 runtime calls (pyramid kernels, cascade kernels, copies, events): with many small jobs the single host
     // thread issuing them is the bottleneck, so batches of >= 6 jobs are issued by the worker pool -- all pyramid updates first
@@ -753,6 +841,16 @@ static void five_stage_batch_end(fd_ctx* ctx, fd_five_stage_batch& b) {
     // hold two equal WVM outputs (fs_tail.hpp: the order of tied survivors is the reference's std::sort's) takes the host stages below.
     std::vector<char> doneByTail((size_t)n, 0);
     int ndone = 0;
+    if (!b.tasks.empty()) {   // host stages already running (or done) on the batch queue
+        for (int i = 0; i < n; ++i) {
+            if (!b.tasks[(size_t)i]) continue;
+            std::shared_ptr<FdAsyncTask> task = std::move(b.tasks[(size_t)i]);
+            try { task->wait(); } catch (const FdError& e) { fail(i, e); } catch (const std::exception& e) { fail(i, FdError{FD_ERR_RUNTIME, e.what()}); }
+            doneByTail[(size_t)i] = 1;
+            tails[(size_t)i].finished = true;
+            ++ndone;
+        }
+    }
     for (int i = 0; i < n; ++i) {
         if (!b.tail[i]) continue;
         fd_five_stage_job& j = jobs[i];
@@ -919,6 +1017,7 @@ int fd_five_stage_batch_begin(fd_ctx* ctx, fd_five_stage_job* jobs, int n, fd_fi
         if (!ticket) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_five_stage_batch_begin: NULL ticket");
         std::unique_ptr<fd_five_stage_batch> b(new fd_five_stage_batch());
         five_stage_batch_begin(ctx, jobs, n, *b);
+        five_stage_batch_submit(ctx, *b);
         *ticket = b.release();
     });
 }

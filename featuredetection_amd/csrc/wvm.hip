@@ -157,7 +157,8 @@ struct fd_wvm {
     hipEvent_t done = nullptr;   // recorded after the cascade kernels + first read-back of a run
     HostBuf h_tail;              // pinned staging of the SVM stage of a five-stage run: [slots | distances]
     hipEvent_t tailDone = nullptr;   // recorded after the SVM stage + its read-back
-    hipEvent_t prep = nullptr;       // grouped launches: header cleared (members) / shared pre-filter queued (leader)
+    hipEvent_t prep = nullptr;       // group launches (fd_wvm_launch_group): this member's header is cleared
+    hipEvent_t grp = nullptr;        // group launches: the leader's shared pre-filter has been queued up to here
     // stage B as dense contractions (wvm_stageb.hpp): model tables, and the per-run state of the queued windows
     WvbDev wvb;
     bool wvbOk = false;
@@ -173,6 +174,7 @@ struct fd_wvm {
     int sbPlanN = 0, sbPlanCut[WVB_MAXPHASE] = {};   // cuts of the run in flight
     int sbLastN = 0, sbLastGen[WVB_MAXPHASE + 1] = {};   // phases of the last launch and their generation boundaries (fd_wvm_last_stage_b_plan)
     int64_t sbGrown = 0;             // capacity a queue overflow made the handle grow to
+    int64_t prevPos = 0;             // positives of the handle's previous run (the batch entry points start the heaviest host tails first)
     std::shared_ptr<void> relaunch;   // WvbRelaunch: what fd_wvm_finish needs to run stage B again with a larger state (queue overflow)
     // five-stage tail on the device (fs_tail.hpp): overlap elimination + SVM queued behind the cascade
     bool tailWanted = false;         // set by the five-stage entry points before the launch
@@ -194,7 +196,7 @@ struct fd_wvm {
     int64_t specPrev = -1;           // positives of the previous run (sizes the next launch)
     int specLastState = -1;          // test hook (fd_wvm_last_spec_state)
     int fstLastState = -1;           // measurement / test hook: -1 no device tail in the last run, else the flags it ended with (0: its results were used)
-    ~fd_wvm() { if (done) (void)hipEventDestroy(done); if (tailDone) (void)hipEventDestroy(tailDone); if (prep) (void)hipEventDestroy(prep); }
+    ~fd_wvm() { if (done) (void)hipEventDestroy(done); if (tailDone) (void)hipEventDestroy(tailDone); if (prep) (void)hipEventDestroy(prep); if (grp) (void)hipEventDestroy(grp); }
 };
 
 namespace {
@@ -1040,6 +1042,7 @@ void launch_cascade(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* mh, cons
 }  // namespace
 
 #include "wvm_dense.hpp"
+#include "wvm_dense_group.hpp"
 #include "fs_tail.hpp"
 
 // ---- host side ---------------------------------------------------------------------------------
@@ -1048,6 +1051,7 @@ void launch_cascade(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* mh, cons
 // four balanced base-256 digits in the B-operand layout of v_mfma_i32_32x32x32_i8.  L = 0 (no dense stage) when the model does
 // not qualify: fewer than 17 used filters (the exact stage-A kernels would emit positives themselves), fewer than 4 filters per
 // level, a patch size without a compile-time kernel, or FD_WVM_DENSE=0.
+static void wvd_dev_from(const fd_wvm* m, int64_t* q, unsigned int* qcount, WvdDev& dv);
 static void wvm_build_dense(fd_wvm* m, const fd_wvm_model* md) {
     m->denseL = 0;
     static const bool off = [] { const char* e = getenv("FD_WVM_DENSE"); return e && atoi(e) == 0; }();
@@ -1091,7 +1095,7 @@ static void wvm_build_dense(fd_wvm* m, const fd_wvm_model* md) {
     m->denseScale = std::ldexp(1.0, -sh);
     // k-step ks, slot t = pixel 32 ks + t of the row-major patch (k_wvm_prefilter walks the patch as a flat run of dwords)
     const int KS = (d + 31) / 32;
-    std::vector<int8_t> B((size_t)KS * 2 * 64 * 16, 0);
+    std::vector<int8_t> B((size_t)((KS + 3) / 4 * 4) * 2 * 64 * 16, 0);   // zero k-steps up to a multiple of four: k_wvm_prefilter_group's fragment ring runs over whole rounds
     const double nb2 = (double)m->dev.negBasis * 1.4426950408889634;   // log2(e) * (-basis): K = 2^(nb2 * norm)
     for (int k = 0; k < WVD_L; ++k) C.thr[k] = -INFINITY;              // levels past L never reject
     for (int k = 0; k < L; ++k) {
@@ -1124,9 +1128,15 @@ static void wvm_build_dense(fd_wvm* m, const fd_wvm_model* md) {
     }
     m->denseB.reserve(B.size());
     HIP_CHECK(hipMemcpy(m->denseB.p, B.data(), B.size(), hipMemcpyHostToDevice));
+    m->denseL = L;
+    {   // the same values wvd_dev_from hands to k_wvm_prefilter as kernel arguments
+        WvdDev dv;
+        wvd_dev_from(m, nullptr, nullptr, dv);
+        C.sc.L = dv.L; C.sc.negBasis = dv.negBasis; C.sc.negBias = dv.negBias; C.sc.stretch = dv.stretch; C.sc.sxxSlack = dv.sxxSlack;
+        C.sc.scale = dv.scale; C.sc.nb2 = dv.nb2; C.sc.mXq = dv.mXq;
+    }
     m->denseC.reserve(sizeof(C));
     HIP_CHECK(hipMemcpy(m->denseC.p, &C, sizeof(C), hipMemcpyHostToDevice));
-    m->denseL = L;
 }
 
 // Tables of the dense stage B (wvm_stageb.hpp), pure host part.  Returns false (the rect-lookup stage-B kernels run instead) when
@@ -1412,6 +1422,42 @@ static bool launch_prefilter(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const uint8
     return false;
 }
 
+// the same for a group of detectors with one patch size on one window table (wvm_dense_group.hpp)
+template <int PW_, int PH_>
+static void launch_prefilter_group_sized(fd_ctx* ctx, hipStream_t st, const uint8_t* arena, WvdTable wt, const WvdGroup& g) {
+    static int perCu = 0;
+    if (perCu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wvm_prefilter_group<PW_, PH_>, 256, 0) != hipSuccess || perCu < 1)) perCu = 2;
+    const int slots = ctx->num_cus * perCu * 4;
+    const int64_t tiles = (int64_t)wvd_plan_sliding(wt, wvd_choose_k(wt, slots, PH_)) * wt.nimg;
+    static const int rounds = [] { const char* e = getenv("FD_WVD_ROUNDS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+    int grid = (int)std::min<int64_t>((tiles + 3) / 4, (int64_t)ctx->num_cus * perCu * rounds);
+    if (wt.nimg >= 8 && grid >= 64) grid &= ~7;
+    hipLaunchKernelGGL((k_wvm_prefilter_group<PW_, PH_>), dim3(grid), dim3(256), 0, st, arena, wt, g);
+}
+// patch sizes whose equalised patch fits a lane's registers (KS <= 18 k-steps)
+static bool wvd_group_size(int fw, int fh) { return (fw == 20 && fh == 20) || (fw == 24 && fh == 24) || (fw == 16 && fh == 24) || (fw == 32 && fh == 16); }
+static bool launch_prefilter_group(fd_ctx* ctx, hipStream_t st, fd_wvm* const* ms, int n, const uint8_t* arena, const WinTable& wt, const CascadeOut* os) {
+    if (n < 2 || n > WVD_GMAX) return false;
+    WvdTable t;
+    if (!wvd_table_from(wt, t)) return false;
+    WvdGroup g;
+    std::memset(&g, 0, sizeof(g));
+    g.n = n;
+    for (int i = 0; i < n; ++i) {
+        const fd_wvm* m = ms[i];
+        if (m->denseL == 0 || m->dev.fw != ms[0]->dev.fw || m->dev.fh != ms[0]->dev.fh) return false;
+        g.m[i].B = m->denseB.as<wvd_v4i>();
+        g.m[i].c = m->denseC.as<WvdConst>();
+        g.m[i].q = os[i].deep_q;
+        g.m[i].qcount = os[i].deep_count;
+    }
+#define FD_WVM_CASE(W, H) \
+    if (ms[0]->dev.fw == W && ms[0]->dev.fh == H) { launch_prefilter_group_sized<W, H>(ctx, st, arena, t, g); return true; }
+    FD_WVM_CASE(20, 20) FD_WVM_CASE(24, 24) FD_WVM_CASE(16, 24) FD_WVM_CASE(32, 16)
+#undef FD_WVM_CASE
+    return false;
+}
+
 void fd_wvm_build_table(const fd_pyramid* p, int pw, int ph, int sx, int sy, const int* roi, WinTable& wt,
                         std::vector<WindowLayer>& wls) {
     int64_t total;
@@ -1489,6 +1535,7 @@ struct WvmLaunch {
     CascadeOut o;
     bool zc = false;
     bool headerMemset = false;   // a memset of the device header was queued on the stream
+    bool queued = false;         // the head queued anything at all on the stream (header / counter clears)
 };
 static bool wvm_launch_head(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const WinTable& wt, bool want_all, WvmRun& run, bool time_kernel, WvmLaunch& L) {
     run.total = wt.total;
@@ -1529,6 +1576,7 @@ static bool wvm_launch_head(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const WinTab
     L.zc = zc;
     L.headerMemset = !(zc && m->hdrClean);
     if (L.headerMemset) HIP_CHECK(hipMemsetAsync(m->pos.p, 0, sizeof(PosRec), st));
+    L.queued = L.headerMemset;
     m->sbRun = m->wvbOk && m->dev.numUsed > WVM_LCAP;
     if (m->sbRun) {
         wvb_reserve(m, wt.total);
@@ -1549,6 +1597,7 @@ static bool wvm_launch_head(fd_ctx* ctx, hipStream_t st, fd_wvm* m, const WinTab
         if (fresh || m->fstDirty) {
             HIP_CHECK(hipMemsetAsync(m->fstHdr.p, 0, 64, st));
             HIP_CHECK(hipMemsetAsync(m->fstFrameCount.p, 0, sizeof(unsigned int) * FD_MAX_FRAMES, st));
+            L.queued = true;
         }
         m->fstDirty = true;
         o.tail_count = m->fstHdr.as<unsigned int>() + 8;   // behind the FstHdr words
@@ -1612,6 +1661,62 @@ static void wvm_launch_table(fd_ctx* ctx, hipStream_t st, fd_pyramid* p, fd_wvm*
         }
     }
     wvm_launch_tail(ctx, st, p, m, wt, wtq, L, skipA, time_kernel);
+}
+
+// A detector of a batch that may share its pre-filter with others on the same pyramid (five_stage_batch_begin groups them).
+// FD_WVM_GROUP=0: never (read per call: the tests compare both ways).
+bool fd_wvm_groupable(const fd_wvm* m) {
+    if (const char* e = getenv("FD_WVM_GROUP")) if (atoi(e) == 0) return false;
+    return m && m->denseL != 0 && m->wvbOk && m->dev.numUsed > WVM_LCAP && wvd_group_size(m->dev.fw, m->dev.fh);
+}
+
+// The cascades of n detectors with the same patch size on the same pyramid and window stepping (no ROI), each on its own stream:
+// every member's buffers and header as in fd_wvm_launch_on, ONE k_wvm_prefilter_group on the first member's stream that fills all
+// members' stage-B queues, then every member's stage B, read-back and completion event on its own stream behind the group's event.
+void fd_wvm_launch_group(fd_ctx* ctx, const hipStream_t* sts, fd_pyramid* p, fd_wvm* const* ms, int n, int sx, int sy, WvmRun* const* runs) {
+    if (n < 1 || n > WVD_GMAX) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_wvm_launch_group: %d members", n);
+    for (int i = 0; i < n; ++i)
+        if (p->ctx != ctx || ms[i]->ctx != ctx) FD_THROW(FD_ERR_INVALID_ARGUMENT, "objects belong to different contexts");
+    if (p->filter_kind != FD_LAYER_NONE) FD_THROW(FD_ERR_INVALID_ARGUMENT, "WVM detection needs a gray pyramid (no layer filter)");
+    if (p->all.empty()) FD_THROW(FD_ERR_RUNTIME, "pyramid has not been updated with an image");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    fd_pyramid_wait(p, sts[0]);
+    WinTable wt;
+    fd_wvm_build_table(p, ms[0]->dev.fw, ms[0]->dev.fh, sx, sy, nullptr, wt, runs[0]->wls);
+    for (int i = 1; i < n; ++i) runs[i]->wls = runs[0]->wls;
+    WvmLaunch L[WVD_GMAX];
+    CascadeOut os[WVD_GMAX];
+    bool any = false;
+    for (int i = 0; i < n; ++i) {
+        const bool ok = wvm_launch_head(ctx, sts[i], ms[i], wt, false, *runs[i], false, L[i]);
+        any = any || ok;
+        os[i] = L[i].o;
+        // A member's header / counter clears are queued on ITS stream: the shared kernel waits for them.  (Only then: a steady-state
+        // zero-copy run queues nothing in front of its kernels, and an unconditional join made every frame's group kernel wait for all
+        // pool streams to drain the previous frame -- and all of them for it.)
+        if (ok && L[i].queued && i > 0 && sts[i] != sts[0]) {
+            if (!ms[i]->prep) HIP_CHECK(hipEventCreateWithFlags(&ms[i]->prep, hipEventDisableTiming));
+            HIP_CHECK(hipEventRecord(ms[i]->prep, sts[i]));
+            HIP_CHECK(hipStreamWaitEvent(sts[0], ms[i]->prep, 0));
+        }
+    }
+    if (!any) return;   // no windows at all (every member sees the same table)
+    const uint8_t* arena = p->arena.as<uint8_t>();
+    const bool grouped = launch_prefilter_group(ctx, sts[0], ms, n, arena, wt, os);
+    if (grouped) {
+        if (!ms[0]->grp) HIP_CHECK(hipEventCreateWithFlags(&ms[0]->grp, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(ms[0]->grp, sts[0]));
+    }
+    for (int i = 0; i < n; ++i) {
+        bool skipA = grouped;
+        if (grouped) {
+            if (sts[i] != sts[0]) HIP_CHECK(hipStreamWaitEvent(sts[i], ms[0]->grp, 0));
+        } else {
+            if (i > 0 && sts[i] != sts[0]) fd_pyramid_wait(p, sts[i]);
+            skipA = ms[i]->denseL ? launch_prefilter(ctx, sts[i], ms[i], arena, wt, os[i].deep_q, os[i].deep_count) : false;
+        }
+        wvm_launch_tail(ctx, sts[i], p, ms[i], wt, wt, L[i], skipA, false);
+    }
 }
 
 // bench hook: duration of the timed kernel(s) of a finished run (fd_hip_bench.h)
@@ -1687,6 +1792,7 @@ void fd_wvm_finish(fd_ctx* ctx, fd_wvm* m, WvmRun& run) {
             return;
         }
     }
+    m->prevPos = (int64_t)cnt;
     if ((int64_t)cnt > m->pos_cap)
         FD_THROW(FD_ERR_DEVICE_CAPACITY, "WVM produced %u positives, device buffer holds %lld (set FD_WVM_POS_CAP)", cnt, (long long)m->pos_cap);
     wvm_finish_header(m, hraw);

@@ -50,10 +50,18 @@ struct WvdTable {
 };
 
 // per-level model constants of the dense stage (device memory, read through the scalar cache)
+// the scalars k_wvm_prefilter takes as kernel arguments (WvdDev), for k_wvm_prefilter_group, which reads them per detector
+struct WvdScal {
+    int32_t L;
+    float negBasis, negBias, stretch, sxxSlack;
+    int32_t pad;
+    double scale, nb2, mXq;
+};
 struct WvdConst {
     double cA[WVD_L];          // log2(e) * (-basis) * (pp_k - 2 * 2^-s * 128 * sum_i Q_k[i]): the window-independent part of level k's exponent
     float thr[WVD_L];          // -inf from level L on (those levels never reject)
     float w2[WVD_L][WVD_L][2]; // {hkWeights[k][p], |hkWeights[k][p]|}, p <= k: the level sum and its error bound as one packed fma
+    WvdScal sc;
 };
 
 struct WvdDev {

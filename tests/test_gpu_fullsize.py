@@ -108,6 +108,89 @@ def test_config3_all_detectors_full_size(oracle, capi, ctx, synth):
         p.close()
 
 
+def test_grouped_prefilter_equals_separate_launches(oracle, capi, ctx, synth, monkeypatch):
+    """Detectors of a batch that scan the same windows (one pyramid, one patch size: seven 24x24, two 16x24, two 20x20 of the
+    fifteen) share ONE dense pre-filter launch (k_wvm_prefilter_group, wvm_dense_group.hpp).  The batch with groups equals the batch
+    with FD_WVM_GROUP=0 (fifteen k_wvm_prefilter launches) byte for byte -- detections, order, scores, stage counts -- on two frames,
+    and a group of two with different cascade depths (L = 16 and L = 8 dense levels) equals its members' single calls."""
+    models = _models(synth, oracle, nsv=256)
+    pyrs, dets = {}, []
+    for name, key, wm, sm, pw, ph in models:
+        if key not in pyrs:
+            pyrs[key] = capi.Pyramid(ctx, **_kw(key))
+        dets.append((name, pyrs[key], capi.Wvm(ctx, wm), capi.Svm(ctx, sm)))
+    jobs = [(p, w, s) for _, p, w, s in dets]
+    for seed, (W, H) in ((5, (960, 540)), (6, (1280, 720))):
+        frame = synth.make_frame(W, H, seed=seed)
+        for p in pyrs.values():
+            p.update(frame)
+        monkeypatch.setenv("FD_WVM_GROUP", "0")
+        r0 = capi.detect_five_stage_batch(ctx, jobs, cap=1 << 14)
+        monkeypatch.delenv("FD_WVM_GROUP")
+        r1 = capi.detect_five_stage_batch(ctx, jobs, cap=1 << 14)
+        r2 = capi.detect_five_stage_batch(ctx, jobs, cap=1 << 14)
+        npos = 0
+        for (name, *_), (d0, s0), (d1, s1), (d2, s2) in zip(dets, r0, r1, r2):
+            assert np.array_equal(s0, s1) and np.array_equal(s1, s2), (name, s0, s1, s2)
+            assert d0.tobytes() == d1.tobytes() == d2.tobytes(), name
+            npos += int(s0[0])
+        assert npos > 200
+    # the ticket entry points run the per-detector host stages as tasks of the batch queue (three frames in flight) or, with
+    # FD_BATCH_ASYNC=0, inside _end: the same bytes as the blocking call either way
+    frames = [synth.make_frame(960, 540, seed=20 + k) for k in range(3)]
+    sets = []
+    for k in range(3):
+        ps, js = {}, []
+        for name, key, wm, sm, pw, ph in models:
+            if key not in ps:
+                ps[key] = capi.Pyramid(ctx, **_kw(key))
+            js.append((ps[key], capi.Wvm(ctx, wm), capi.Svm(ctx, sm)))
+        sets.append((ps, js))
+    want = []
+    for k in range(3):
+        for p in pyrs.values():
+            p.update(frames[k])
+        want.append(capi.detect_five_stage_batch(ctx, jobs, cap=1 << 14))
+    for mode in ("1", "0", "1"):
+        monkeypatch.setenv("FD_BATCH_ASYNC", mode)
+        tickets = []
+        for k in range(3):
+            for p in sets[k][0].values():
+                p.update(frames[k])
+            tickets.append(capi.FiveStageBatch(ctx, sets[k][1], cap=1 << 14))
+        for k in range(3):
+            got = tickets[k].end()
+            for (name, *_), (dw, sw), (dg, sg) in zip(dets, want[k], got):
+                assert np.array_equal(sw, sg) and dw.tobytes() == dg.tobytes(), (mode, k, name)
+    monkeypatch.delenv("FD_BATCH_ASYNC")
+    for ps, js in sets:
+        for _, w_, s_ in js:
+            w_.close(); s_.close()
+        for p in ps.values():
+            p.close()
+    # two 24x24 models of different depth in one group
+    gray = oracle.bgr2gray(synth.make_frame(640, 480, seed=20260927))
+    calib = synth.random_patches(gray[::2, ::2].copy(), 24, 24, 4000, np.random.default_rng(9))
+    wa = synth.make_wvm(71, fw=24, fh=24, n_per=20, n_levels=4, calib_patches=calib, min_survivors=24)
+    wb = synth.make_wvm(72, fw=24, fh=24, n_per=8, n_levels=6, calib_patches=calib, min_survivors=24)
+    eq = synth.histeq64_np(synth.random_patches(gray[::2, ::2].copy(), 24, 24, 456, np.random.default_rng(10)))
+    sm = synth.make_svm_u8(73, eq, nsv=256, calib=eq[256:])
+    p = capi.Pyramid(ctx, **_kw((0.9, 0.5, 0.7)))
+    p.update(synth.make_frame(800, 600, seed=11))
+    ha, hb, s1_, s2_ = capi.Wvm(ctx, wa), capi.Wvm(ctx, wb), capi.Svm(ctx, sm), capi.Svm(ctx, sm)
+    rb = capi.detect_five_stage_batch(ctx, [(p, ha, s1_), (p, hb, s2_)], cap=1 << 14)
+    for (w_, s_), (db, sb) in zip(((ha, s1_), (hb, s2_)), rb):
+        ds, ss = capi.detect_five_stage(ctx, p, w_, s_, cap=1 << 14)
+        assert ds.tobytes() == db.tobytes() and np.array_equal(ss, sb)
+    assert int(rb[0][1][0]) + int(rb[1][1][0]) > 0
+    for h in (ha, hb, s1_, s2_, p):
+        h.close()
+    for d_ in dets:
+        d_[2].close(); d_[3].close()
+    for p_ in pyrs.values():
+        p_.close()
+
+
 @pytest.mark.parametrize("step,roi", [(1, None), (2, None), (1, (200, 100, 700, 500)), (3, (-30, -20, 400, 300))])
 def test_wvm_production_path_equals_exact_path(oracle, capi, ctx, synth, step, roi):
     """fd_detect_wvm without per-window outputs takes the production path (dense pre-filter on the matrix pipe, exact cascade on
