@@ -68,6 +68,7 @@ void fd_ctx_destroy(fd_ctx* ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (hipEvent_t e : ctx->evx) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->evg) if (e) (void)hipEventDestroy(e);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     if (ctx->tail) (void)hipStreamDestroy(ctx->tail);
     for (hipStream_t ps : ctx->pool) if (ps) (void)hipStreamDestroy(ps);

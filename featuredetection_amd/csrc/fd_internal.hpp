@@ -160,6 +160,8 @@ struct fd_ctx {
     int kernel_timing_mode = 1;      // WVM cascades: 1 = all cascade kernels of the call, 2 = the dense pre-filter only, 3 = stage B's chain kernels (fd_hip_bench.h)
     hipEvent_t evx[8] = {};          // mode 3: one event pair per stage-B phase around its k_wvb_chain2 launch (created on first use)
     int evxN = 0;                    // pairs recorded by the last timed launch
+    hipEvent_t evg[2] = {};          // mode 2: around the last k_wvm_prefilter_group launch (fd_last_group_prefilter_ms)
+    int evgMembers = 0;              // its member count (0: none recorded)
     const char* last_kernel = "";
     float last_kernel_ms = 0.f;
     int num_cus = 256;

@@ -1702,7 +1702,17 @@ void fd_wvm_launch_group(fd_ctx* ctx, const hipStream_t* sts, fd_pyramid* p, fd_
     }
     if (!any) return;   // no windows at all (every member sees the same table)
     const uint8_t* arena = p->arena.as<uint8_t>();
+    const bool timeGroup = ctx->kernel_timing && ctx->kernel_timing_mode == 2;   // bench hook: one group launched alone (fd_last_group_prefilter_ms)
+    if (timeGroup) {
+        for (int e = 0; e < 2; ++e)
+            if (!ctx->evg[e]) HIP_CHECK(hipEventCreate(&ctx->evg[e]));
+        HIP_CHECK(hipEventRecord(ctx->evg[0], sts[0]));
+    }
     const bool grouped = launch_prefilter_group(ctx, sts[0], ms, n, arena, wt, os);
+    if (timeGroup) {
+        HIP_CHECK(hipEventRecord(ctx->evg[1], sts[0]));
+        ctx->evgMembers = grouped ? n : 0;
+    }
     if (grouped) {
         if (!ms[0]->grp) HIP_CHECK(hipEventCreateWithFlags(&ms[0]->grp, hipEventDisableTiming));
         HIP_CHECK(hipEventRecord(ms[0]->grp, sts[0]));
@@ -2136,6 +2146,16 @@ int fd_debug_wvd_prof(unsigned long long* out, int nwaves) {
 #endif
 
 // Measurement hook (include/fd_hip_bench.h): windows the last finished run of this handle queued for stage B (-1: none yet)
+int fd_last_group_prefilter_ms(fd_ctx* ctx, float* ms, int* members) {
+    return fd_guard(ctx, [&] {
+        if (!ctx || !ms) FD_THROW(FD_ERR_INVALID_ARGUMENT, "fd_last_group_prefilter_ms: NULL argument");
+        *ms = 0.f;
+        if (members) *members = ctx->evgMembers;
+        if (ctx->evgMembers <= 0) return;
+        HIP_CHECK(hipEventSynchronize(ctx->evg[1]));
+        HIP_CHECK(hipEventElapsedTime(ms, ctx->evg[0], ctx->evg[1]));
+    });
+}
 int64_t fd_wvm_last_queue_length(const fd_wvm* m) { return m ? m->sbDeep : -1; }
 int fd_wvm_last_tail_state(const fd_wvm* m) { return m ? m->fstLastState : -1; }
 int fd_wvm_last_spec_state(const fd_wvm* m) { return m ? m->specLastState : -1; }
