@@ -92,6 +92,11 @@ __device__ __forceinline__ unsigned int mad24(unsigned int a, unsigned int b, un
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+__device__ __forceinline__ unsigned int mulhi24_s(unsigned int a_uniform, unsigned int b) {   // (a * b) >> 32 of two 24-bit factors
+    unsigned int r;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "s"(a_uniform), "v"(b));
+    return r;
+}
 __device__ __forceinline__ uint32_t ld_u32_unaligned(const uint8_t* p) {
     uint32_t v;
     __builtin_memcpy(&v, p, 4);
@@ -404,6 +409,7 @@ __global__ __launch_bounds__(256) void k_resize_down(uint8_t* __restrict__ arena
     fused_issue(f, arena0 + (size_t)frame_of(item) * imageStride + src_off, sw, tabs, jobs.j[d.w], d);
     int itemN = item + nslot;
     int4 dN = desc_of(itemN);
+
 #ifdef FD_PYR_PROF
     unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0}, ptiles = 0;
 #endif
@@ -437,25 +443,31 @@ __global__ __launch_bounds__(256) void k_resize_down(uint8_t* __restrict__ arena
                 const uint8_t* sp = stage + (ex.x - X0);
                 const unsigned int a0 = ex.y & 0xffff, a1 = (unsigned int)ex.y >> 16;
                 uint8_t* gp = g0 + c;
+                // A row's record in ONE register (lane == row): stage row of y0 (7 bits), b0, b1 (12 bits each).  The lower tap's row is the
+                // next stage row -- the table builder only fuses layers where y1 == y0 + 1 or b1 == 0 (every down-scaling layer) -- so a row
+                // costs one v_readlane, a handful of scalar instructions and one address add (round 5: two v_readlane, nine scalar
+                // instructions and two address computations per row and wavefront: as many scalar as vector instructions).
+                const unsigned int rowRec = (unsigned int)((ey.x & 0xffff) - Y0) | (((unsigned int)ey.y & 0xfffu) << 7) | ((((unsigned int)ey.y >> 16) & 0xfffu) << 19);
                 // three rows at a time: their twelve byte loads first, then the arithmetic (one LDS round trip per three rows).  The 35 rows
                 // are dealt as 0..17 / 17..34: row 17 is computed by both halves (the same value, stored twice) and nothing is predicated
                 const int rBase = half * (G0_H - 18);
 #pragma unroll 2
                 for (int i = 0; i < 18; i += 3) {
-                    unsigned int s00[3], s01[3], s10[3], s11[3], e1[3];
+                    unsigned int s00[3], s01[3], s10[3], s11[3], b0s[3], b1s[3];
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         const int r = rBase + i + q;
-                        const unsigned int e0 = (unsigned int)__builtin_amdgcn_readlane(ey.x, r);
-                        e1[q] = (unsigned int)__builtin_amdgcn_readlane(ey.y, r);
-                        const int o0 = ((int)(e0 & 0xffff) - Y0) * FS_PITCH, o1 = ((int)(e0 >> 16) - Y0) * FS_PITCH;
-                        s00[q] = sp[o0]; s01[q] = sp[o0 + 1]; s10[q] = sp[o1]; s11[q] = sp[o1 + 1];
+                        const unsigned int e = (unsigned int)__builtin_amdgcn_readlane((int)rowRec, r);
+                        b0s[q] = ((e >> 7) & 0xfffu) << 12;   // b << 12 (<= 2^23): (b << 12) * (h & ~15) >> 32 == (b * (h >> 4)) >> 16
+                        b1s[q] = (e >> 19) << 12;
+                        const uint8_t* sr = sp + ((e & 127u) << 8);
+                        s00[q] = sr[0]; s01[q] = sr[1]; s10[q] = sr[FS_PITCH]; s11[q] = sr[FS_PITCH + 1];
                     }
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
-                        const unsigned int h0 = mad24(s01[q], a1, mul24(s00[q], a0)) >> 4;   // cv::resize's horizontal intermediate
-                        const unsigned int h1 = mad24(s11[q], a1, mul24(s10[q], a0)) >> 4;
-                        const unsigned int v = ((mul24_s(e1[q] & 0xffff, h0) >> 16) + (mul24_s(e1[q] >> 16, h1) >> 16) + 2) >> 2;
+                        const unsigned int h0 = mad24(s01[q], a1, mul24(s00[q], a0)) & ~15u;   // cv::resize's horizontal intermediate, times 16
+                        const unsigned int h1 = mad24(s11[q], a1, mul24(s10[q], a0)) & ~15u;
+                        const unsigned int v = (mulhi24_s(b0s[q], h0) + mulhi24_s(b1s[q], h1) + 2) >> 2;
                         gp[(rBase + i + q) * G0_PITCH] = (uint8_t)v;
                     }
                 }
@@ -870,6 +882,11 @@ void build_resize_tables(fd_pyramid* p, int W, int H) {
         }
         // every tile's source rectangle must fit the kernel's stage
         bool fits = true;
+        // the kernel reads a row's lower tap from the stage row behind its upper tap, and packs b0 / b1 into 12 bits each
+        for (int dy = 0; dy < L.h && fits; ++dy) {
+            const int y0 = yt[(size_t)dy].x & 0xffff, y1 = (int)((uint32_t)yt[(size_t)dy].x >> 16), b0 = yt[(size_t)dy].y & 0xffff, b1 = (int)((uint32_t)yt[(size_t)dy].y >> 16);
+            fits = (y1 == y0 + 1 || b1 == 0) && b0 >= 0 && b0 <= 2048 && b1 >= 0 && b1 <= 2048 && y1 >= y0;
+        }
         for (int x1 = 0; x1 < D.w && fits; x1 += FT_W1) {
             const int cLo = std::max(0, 2 * x1 - 2), cHi = std::min(L.w - 1, 2 * x1 - 2 + G0_W - 1);
             fits = std::min(W - 1, xt[(size_t)cHi].x + 1) - xt[(size_t)cLo].x + 1 <= FS_PITCH;
