@@ -781,6 +781,14 @@ class FiveStageBatch:
         self.ctx.check(lib().fd_five_stage_batch_end(self.ctx.h, t))
         return _five_stage_results(self.jobs, self.outs)
 
+    def __del__(self):   # the library's threads write to self.jobs / self.outs until the batch has been ended
+        t, self.ticket = getattr(self, "ticket", None), None
+        if t:
+            try:
+                lib().fd_five_stage_batch_end(self.ctx.h, t)
+            except Exception:
+                pass
+
 
 def fhog(ctx, gray=None, pyramid=None, layer=0, cell_size=8, unsigned_bins=9, interpolate_bins=False, interpolate_cells=True, alpha=0.2):
     """FhogFilter::applyTo on a host gray (h, w) / BGR (h, w, 3) image or on a layer of a gray pyramid:

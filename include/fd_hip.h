@@ -240,9 +240,11 @@ typedef struct {
 } fd_five_stage_job;
 int fd_detect_five_stage_batch(fd_ctx* ctx, fd_five_stage_job* jobs, int n);
 /* The same in two halves, for callers that keep more than one frame in flight: begin validates the jobs, queues the optional
- * pyramid updates and all cascades and returns at once; end runs the host stages (read-back, overlap elimination, the SVM stage,
- * NMS) and fills out / count / stage_counts / status of every job.  `jobs` (and the buffers it points to) must stay alive and
- * untouched until end returns; every batch that has begun must be ended (end also releases the ticket, whatever it returns).
+ * pyramid updates and all cascades and returns at once; the host stages (read-back, overlap elimination, the SVM stage, NMS) of
+ * every job follow on the library's own threads as its cascade completes (FD_BATCH_THREADS of them, shared by all batches in flight;
+ * FD_BATCH_ASYNC=0: inside end) and fill out / count / stage_counts of the job; end waits for them and sets every job's status.
+ * `jobs` (and the buffers it points to) must stay alive and untouched from begin until end returns -- the library writes to them in
+ * between; every batch that has begun must be ended (end also releases the ticket, whatever it returns).
  * Two batches in flight must not share pyramid or WVM handles: their scratch buffers belong to one run at a time. */
 typedef struct fd_five_stage_batch fd_five_stage_batch;
 int fd_five_stage_batch_begin(fd_ctx* ctx, fd_five_stage_job* jobs, int n, fd_five_stage_batch** ticket);
