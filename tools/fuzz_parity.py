@@ -622,8 +622,70 @@ def case_batch_tail(rng, ctx):
     return None
 
 
+def case_batch_group(rng, ctx):
+    """detectors of a batch that scan the same windows share one pre-filter launch (k_wvm_prefilter_group): 2..8 detectors of ONE random
+    patch shape (+ sometimes a detector of another shape) on one pyramid, random depths (4..16 dense levels), random frames -- the batch
+    with groups against FD_WVM_GROUP=0, the ticket entry points (host stages on the batch queue) against the blocking call, and one
+    member against the oracle"""
+    frame = rand_frame(rng)
+    gray = O.bgr2gray(frame)
+    kw = rand_pyr_kw(rng)
+    pw, ph = [(20, 20), (24, 24), (16, 24), (32, 16)][int(rng.integers(4))]   # the shapes with a group kernel
+    nmem = int(rng.integers(2, 9))
+    pg = capi.Pyramid(ctx, **kw); pg.update(frame)
+    po = O.Pyramid(**kw); po.update(frame)
+    handles, models = [], []
+    keep = {k: os.environ.get(k) for k in ("FD_WVM_GROUP", "FD_BATCH_ASYNC")}
+    try:
+        shapes = [(pw, ph)] * nmem + ([SIZES[int(rng.integers(5))]] if rng.random() < 0.4 else [])
+        for (w_, h_) in shapes:
+            src = np.ascontiguousarray(gray[::2, ::2])
+            if src.shape[0] <= h_ + 2 or src.shape[1] <= w_ + 2:
+                src = gray
+            calib = synth.random_patches(src, w_, h_, 1200, rng)
+            wvm = synth.make_wvm(int(rng.integers(1 << 20)), fw=w_, fh=h_, n_per=int(rng.choice([4, 8, 14, 20, 30])), n_levels=int(rng.integers(2, 5)),
+                                 calib_patches=calib, min_survivors=int(rng.integers(20, 200)))
+            eq = synth.histeq64_np(synth.random_patches(src, w_, h_, 200, rng))
+            svm = synth.make_svm_u8(int(rng.integers(1 << 20)), eq, nsv=int(rng.choice([33, 64])), calib=eq[64:], positive_fraction=0.4)
+            models.append((wvm, svm))
+            handles.append((capi.Wvm(ctx, wvm), capi.Svm(ctx, svm)))
+        jobs = [(pg, w, s) for w, s in handles]
+        if pg.window_count(pw, ph, 1, 1) < 512:
+            return "skip: fewer than 512 windows (no dense pre-filter)"
+        os.environ["FD_WVM_GROUP"] = "0"
+        ref = capi.detect_five_stage_batch(ctx, jobs, cap=1 << 14)
+        os.environ.pop("FD_WVM_GROUP")
+        got = capi.detect_five_stage_batch(ctx, jobs, cap=1 << 14)
+        os.environ["FD_BATCH_ASYNC"] = "1" if rng.random() < 0.7 else "0"
+        tick = capi.FiveStageBatch(ctx, jobs, cap=1 << 14).end()
+        for ji, ((dr, sr), (dg, sg), (dt, st_)) in enumerate(zip(ref, got, tick)):
+            STATS['detections'] += len(dr)
+            STATS['candidates'] += int(sr[0])
+            if not np.array_equal(sr, sg) or dr.tobytes() != dg.tobytes():
+                return "job %d of %d (%dx%d x %d): grouped %s vs separate %s" % (ji, len(jobs), pw, ph, nmem, sg.tolist(), sr.tolist())
+            if not np.array_equal(sr, st_) or dr.tobytes() != dt.tobytes():
+                return "job %d of %d: ticket %s vs blocking %s" % (ji, len(jobs), st_.tolist(), sr.tolist())
+        mi = int(rng.integers(nmem))
+        do, so = O.five_stage(po, O.Wvm(models[mi][0]), O.Svm(models[mi][1]), cap=1 << 14)
+        if not np.array_equal(got[mi][1], so):
+            return "member %d: stage counts %s vs the oracle's %s" % (mi, got[mi][1].tolist(), so.tolist())
+        e = same_geometry(got[mi][0], do)
+        if e:
+            return "group member " + e
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        for w, s in handles:
+            w.close(); s.close()
+        pg.close(); po.close()
+    return None
+
+
 CASES = dict(pyramid=case_pyramid, cascade=case_cascade, frames=case_frames, hist=case_hist, fhog=case_fhog, aggregated=case_aggregated, svm=case_svm,
-             hog_svm=case_hog_svm, rvm=case_rvm, whi=case_whi, sdm=case_sdm, hog_fused=case_hog_fused, batch_tail=case_batch_tail)
+             hog_svm=case_hog_svm, rvm=case_rvm, whi=case_whi, sdm=case_sdm, hog_fused=case_hog_fused, batch_tail=case_batch_tail, batch_group=case_batch_group)
 
 
 def main():
