@@ -405,7 +405,10 @@ __global__ __launch_bounds__(256, 2) void k_wvb_chain2(WvbDev mv, WvbState s, in
 // weights are staged in LDS once and read as broadcasts, every K_p load (256 B, coalesced) feeds RB multiply-adds; the terms keep the
 // reference's order.  The first failed row of a window inside the block goes into exitKey by a 64-bit minimum (level << 32 | fp32 bits).
 constexpr int WVB_MAXF = 64 * WVM_PJ;
-constexpr int WVB_RB = 8;   // rows per block
+#ifndef FD_WVB_RB
+#define FD_WVB_RB 8
+#endif
+constexpr int WVB_RB = FD_WVB_RB;   // rows per block
 __global__ __launch_bounds__(256) void k_wvb_sums(WvbDev mv, WvbState s, int phase, const unsigned int* countPtr) {
     __shared__ __attribute__((aligned(16))) float wl[(WVB_MAXF + WVB_RB) * WVB_RB];
     constexpr int RB = WVB_RB;
@@ -493,11 +496,11 @@ __global__ __launch_bounds__(256) void k_wvb_sums(WvbDev mv, WvbState s, int pha
 #pragma unroll
         for (int j = 0; j < RB; ++j) acc[j] = (j & 1) ? acc2[j >> 1].y : acc2[j >> 1].x;
         {
-            float kv[8];
+            float kv[RB];
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) kv[jj] = Kp[(size_t)min(kb + jj, k1 - 1) * ks];
+            for (int jj = 0; jj < RB; ++jj) kv[jj] = Kp[(size_t)min(kb + jj, k1 - 1) * ks];
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
+            for (int jj = 0; jj < RB; ++jj) {
                 if (kb + jj < k1) {
                     const float* w0 = wl + (kb + jj) * RB;
 #pragma unroll
@@ -790,7 +793,7 @@ static void launch_stageb(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* m,
     for (int ph = 0; ph < mv.nphase; ++ph) {
         const unsigned int* countPtr = ph == 0 ? o.deep_count : s.cnt + ph;
         const int k0 = std::min(mv.phaseGen[ph] * mv.numPer, mv.numUsed), k1 = std::min(mv.phaseGen[ph + 1] * mv.numPer, mv.numUsed);
-        const int nrb = (k1 - k0 + 7) / 8;
+        const int nrb = (k1 - k0 + WVB_RB - 1) / WVB_RB;
         const int64_t tiles = (expect(ph) + 63) / 64;
         // a unit per tile (all class quarters on one staged tile) once every resident workgroup gets at least two tiles that way
         // (measured on the heavy-queue profiles, round 5: cascade_group 525 -> 553, cascade_late 1304 -> 1403 Mpatches/s; k_wvb_chain2 of
