@@ -721,9 +721,10 @@ class Ffp15(Workload):
         self.stage_sum, self.stage_frames = np.zeros(4, np.int64), 0
         self.models = ffp15_models()
         ctx = env.ctx
-        # three frames in flight (FD_BENCH_FFP_SLOTS; round 6: 5309 against 5204-5224 Mpatches/s with two), each with its own pyramids and classifier handles: frame f + 1's pyramids and
-        # cascades are queued before frame f's host stages (ordering, overlap elimination, SVM launches, NMS) are collected
-        nslots = max(1, int(os.environ.get("FD_BENCH_FFP_SLOTS", "3")))
+        # four frames in flight (FD_BENCH_FFP_SLOTS; with the library's batch queue and eight batch streams: 9600 against 9280 Mpatches/s with
+        # three, 9430 with five), each with its own pyramids and classifier handles: the next frames' pyramids and cascades are queued while
+        # the library's queue threads run frame f's host stages (ordering, overlap elimination, SVM launches, NMS)
+        nslots = max(1, int(os.environ.get("FD_BENCH_FFP_SLOTS", "4")))
         self.slots = []
         for k in range(nslots):
             pyrs, dets = {}, []
