@@ -282,10 +282,12 @@ class Cascade(Workload):
         self.svm = capi.Svm(ctx, self.svm_m)
         self.slots, self.flying, self.ncalls = [], [], 0
         if self.multi:
-            # six calls in flight, each on its own context (stream), multi-frame pyramid and handles: the library runs the host
+            # eleven calls in flight, each on its own context (stream), multi-frame pyramid and handles: the library runs the host
             # stages of a call (overlap elimination, SVM launch, NMS) on its queue threads behind the cascade kernels, so this thread
             # only queues kernels and collects finished calls
-            for k in range(max(1, int(os.environ.get("FD_BENCH_SLOTS", "6")))):
+            # (eleven since the gather points stopped draining the pipeline: 3550-3670 Mpatches/s against 3420-3510 with six; on the
+            # runtime's four hardware queues the counts 7, 11, 15 beat their neighbours by 2-4 %)
+            for k in range(max(1, int(os.environ.get("FD_BENCH_SLOTS", "11")))):
                 c_ = ctx if k == 0 else capi.Context(env.local_rank)
                 mp = capi.Pyramid(c_, **kw)
                 mp.set_frames(self.NB)
@@ -300,7 +302,7 @@ class Cascade(Workload):
                                     "%s, detections delivered per frame" % (W, H, self.nlayers, self.nwin, "fd_pyramid_update_frames + "
                                     "fd_detect_five_stage_frames (the frames of a call share one pyramid arena, one cascade run and one SVM launch)"
                                     if self.multi else "fd_detect_five_stage_batch"),
-                           frames_per_step=self.FP, frames_per_call=self.NB, parallelism="image-shard dp%d" % env.world,
+                           frames_per_step=self.FP, frames_per_call=self.NB, calls_in_flight=max(1, len(self.slots)), parallelism="image-shard dp%d" % env.world,
                            content=("%d distinct frames resident in HBM, %d scenes of %d with different busy-ness, scene order reshuffled every pass"
                                     % (self.NFR, self.NFR // self.SCENE, self.SCENE)) if self.content == "varied" else
                                    "8 distinct frames, every call holds the same frames (the content of rounds 1-3)")
