@@ -409,9 +409,15 @@ constexpr int WVB_MAXF = 64 * WVM_PJ;
 #define FD_WVB_RB 8
 #endif
 constexpr int WVB_RB = FD_WVB_RB;   // rows per block
+// DEPTH: groups of 16 K rows in flight per wavefront.  2 for long queues (the launch lives on L2 bandwidth, registers are occupancy); 4 for
+// short ones (a single frame queues 3 tiles: its 27 workgroups waited one L2 round trip per group, 17 round trips for the last row block).
+// RB_: rows per block.  WVB_RB for long queues; 2 for short ones: a single frame's 3 tiles x 35 blocks of 8 rows were 27 wavefronts that each
+// issued ~3000 dependent-ish instructions alone on their SIMD (7 of the launch's 18 us); 140 blocks of 2 rows are four times the wavefronts.
+template <int RB_, int DEPTH>
 __global__ __launch_bounds__(256) void k_wvb_sums(WvbDev mv, WvbState s, int phase, const unsigned int* countPtr) {
-    __shared__ __attribute__((aligned(16))) float wl[(WVB_MAXF + WVB_RB) * WVB_RB];
-    constexpr int RB = WVB_RB;
+    __shared__ __attribute__((aligned(16))) float wl[(WVB_MAXF + RB_) * RB_];
+    constexpr int RB = RB_;
+    static_assert(RB == 2 || RB % 4 == 0, "rows per block");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned int n = wvb_count(countPtr, s);
@@ -456,6 +462,10 @@ __global__ __launch_bounds__(256) void k_wvb_sums(WvbDev mv, WvbState s, int pha
         };
         auto term = [&](const float* w0, float kvv) {   // all RB rows take the term
             const wvb_f2 k2 = wvb_f2{kvv, kvv};
+            if constexpr (RB == 2) {
+                const float2 w = *reinterpret_cast<const float2*>(w0);
+                acc2[0] = acc2[0] + wvb_f2{w.x, w.y} * k2;
+            }
 #pragma unroll
             for (int j4 = 0; j4 < RB / 4; ++j4) {
                 const float4 w = reinterpret_cast<const float4*>(w0)[j4];
@@ -469,7 +479,7 @@ __global__ __launch_bounds__(256) void k_wvb_sums(WvbDev mv, WvbState s, int pha
             for (int i = 0; i < 16; ++i) term(wl + (p0 + i) * RB, kv[i]);
         };
         const int ngroups = kb >> 4;
-        {
+        if constexpr (DEPTH == 2) {
             float ka[16], kc[16];
             if (ngroups > 0) loadK(ka, 0);
             for (int g = 0; g < ngroups; g += 2) {
@@ -478,6 +488,22 @@ __global__ __launch_bounds__(256) void k_wvb_sums(WvbDev mv, WvbState s, int pha
                 if (g + 1 < ngroups) {
                     if (g + 2 < ngroups) loadK(ka, (g + 2) * 16);
                     useK(kc, (g + 1) * 16);
+                }
+            }
+        } else {
+            // a ring of DEPTH groups; a group past the block's columns loads the last whole group again (valid rows, never used)
+            float kr[DEPTH][16];
+            const int gl = ngroups > 0 ? ngroups - 1 : 0;
+#pragma unroll
+            for (int d = 0; d < DEPTH - 1; ++d)
+                if (ngroups > 0) loadK(kr[d], min(d, gl) * 16);
+            for (int g = 0; g < ngroups; g += DEPTH) {
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) {
+                    if (g + d < ngroups) {   // wave-uniform
+                        loadK(kr[(d + DEPTH - 1) % DEPTH], min(g + d + DEPTH - 1, gl) * 16);
+                        useK(kr[d], (g + d) * 16);
+                    }
                 }
             }
         }
@@ -820,7 +846,15 @@ static void launch_stageb(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* m,
         // launch -- took the same 265 us; the same with the weights as scalar operands (s_load_dwordx8 into SGPR pairs of the packed
         // multiplies, no weight traffic through LDS at all) 311 us.  Bytes, VALU instructions and LDS traffic have each been cut by 2-4x
         // without moving this kernel: what it waits for is the latency of its dependent loads at the occupancy it has.)
-        hipLaunchKernelGGL(k_wvb_sums, dim3(wvb_grid8(std::min<int64_t>((tiles + 3) / 4 * nrb, (int64_t)cus * 8))), dim3(256), 0, st, mv, s, ph, countPtr);
+        {
+            const dim3 gridS(wvb_grid8(std::min<int64_t>((tiles + 3) / 4 * nrb, (int64_t)cus * 8)));
+            if (tiles <= 16) {   // a frame or two: more, smaller units (k_wvb_sums)
+                const dim3 gridQ(wvb_grid8(std::min<int64_t>((tiles + 3) / 4 * ((k1 - k0 + 1) / 2), (int64_t)cus * 8)));
+                hipLaunchKernelGGL((k_wvb_sums<2, 4>), gridQ, dim3(256), 0, st, mv, s, ph, countPtr);
+            } else {
+                hipLaunchKernelGGL((k_wvb_sums<WVB_RB, 2>), gridS, dim3(256), 0, st, mv, s, ph, countPtr);
+            }
+        }
         const int gridE = wvb_grid8(std::min<int64_t>(tiles, (int64_t)cus * 4));
         hipLaunchKernelGGL(k_wvb_exit, dim3(gridE), dim3(256), 0, st, mv, s, o, ph, countPtr, s.cnt + ph + 1);
     }
