@@ -1377,6 +1377,13 @@ def main():
     torch.cuda.set_device(env.local_rank)
     env.dev = torch.device("cuda", env.local_rank)
     env.ctx = capi.Context(env.local_rank, torch.cuda.current_stream().cuda_stream)
+    if os.environ.get("FD_BENCH_WARM_STREAMS", "1") == "1":
+        # The HIP runtime deals streams to its (four) hardware queues in creation order.  The context's ten lazily created streams (batch
+        # pool, tail, auxiliary) are created here, so that a workload finds the same mapping whatever ran before it in this process (the
+        # 15-detector batch: 8.4 G patches/s behind the headline and config 2, 9.7 G in every order with this), and FD_BENCH_PAD_STREAMS
+        # idle streams round their number up to a multiple of four (the headline's contexts then land as in a fresh process)
+        env.ctx.warm_streams()
+        env.pad_streams = [capi.Context(env.local_rank) for _ in range(max(0, int(os.environ.get("FD_BENCH_PAD_STREAMS", "2"))))]   # (a context owns one stream)
     env.dist = None
     if env.world > 1:
         # fd_dist_*: rank 0 makes the communicator id (ncclGetUniqueId of librccl), torch.distributed only carries its 128 bytes

@@ -228,6 +228,7 @@ _BENCH_SIGS = {
     "fd_ctx_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "fd_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
     "fd_last_group_prefilter_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "fd_ctx_warm_streams": (C.c_int, [C.c_void_p]),
     "fd_debug_wvb_rect_sums": (C.c_int64, [C.POINTER(fd_wvm_model), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "fd_wvm_last_queue_length": (C.c_int64, [C.c_void_p]),
     "fd_wvm_last_tail_state": (C.c_int, [C.c_void_p]),
@@ -288,6 +289,9 @@ class Context:
         ms = C.c_float()
         lib().fd_last_kernel_ms(self.h, C.byref(name), C.byref(ms))
         return (name.value or b"").decode(), float(ms.value)
+
+    def warm_streams(self):
+        self.check(lib().fd_ctx_warm_streams(self.h))
 
     def last_group_prefilter_ms(self):
         """(ms, members) of the last k_wvm_prefilter_group launch timed with set_kernel_timing(2); members == 0: none"""
