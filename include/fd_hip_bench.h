@@ -15,9 +15,6 @@ int fd_ctx_set_kernel_timing(fd_ctx* ctx, int enable);   /* enable == 2: WVM cas
                                                           * enable == 3: every k_wvb_chain2 launch of stage B (one per phase), summed */
 /* duration (ms) between those events for the last timed call on this context and the name of the bracketed kernel(s) */
 int fd_last_kernel_ms(fd_ctx* ctx, const char** kernel_name, float* ms);
-/* Creates the context's batch / tail / auxiliary streams now instead of on first use: the HIP runtime maps streams to hardware queues in
- * creation order, so a measurement that runs several workloads in one process pins the mapping this way. */
-int fd_ctx_warm_streams(fd_ctx* ctx);
 /* With fd_ctx_set_kernel_timing(ctx, 2): duration (ms) of the last k_wvm_prefilter_group launch of a batch entry point on this context
  * (HIP events on the stream it was launched on) and the number of detectors it served; members = 0: no group launch was timed.  Meant
  * for a batch that holds ONE group (several groups of a batch are queued by different host threads: the last writer wins). */
