@@ -111,6 +111,7 @@ FEATURE_GRAY, FEATURE_HQ64, FEATURE_HISTEQ = 0, 1, 2
 HIST_HOG, HIST_SPATIAL, HIST_PYRAMID_HOG, HIST_SPATIAL_PYRAMID = 0, 1, 2, 3
 
 _SIGS = {
+    "fd_ctx_warm_streams": (C.c_int, [C.c_void_p]),
     "fd_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "fd_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "fd_ctx_destroy": (None, [C.c_void_p]),
@@ -228,7 +229,6 @@ _BENCH_SIGS = {
     "fd_ctx_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "fd_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
     "fd_last_group_prefilter_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
-    "fd_ctx_warm_streams": (C.c_int, [C.c_void_p]),
     "fd_debug_wvb_rect_sums": (C.c_int64, [C.POINTER(fd_wvm_model), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "fd_wvm_last_queue_length": (C.c_int64, [C.c_void_p]),
     "fd_wvm_last_tail_state": (C.c_int, [C.c_void_p]),
