@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // Operand fragments (2 x 16 bytes per lane and k-step) are requested RD k-steps ahead of their MFMAs and wrap into the next detector's
     // table: with nothing but MFMAs between the requests an L2 round trip is ~4 k-steps of one wavefront; the SIMD's second wavefront
     // covers part of it.  (The equalised patch + the accumulators are 208 of the 256 registers two wavefronts per SIMD leave.)
-    constexpr int RD = WVD_GRP_RD;
+    constexpr int RD = KS <= 13 ? 4 : WVD_GRP_RD;   // (16 x 24 and 20 x 20 patches have the registers for four k-steps: 396 against 415, 106 against 113 us per 1080p frame)
     static_assert(RD == 1 || RD == 2 || RD == 4, "the digit tables are padded with zero k-steps to a multiple of four");
     constexpr int KSR = (KS + RD - 1) / RD * RD;   // k-steps contracted per detector: whole rounds of the ring (the pad steps add 0 x anything)
     wvd_v4i frag[RD][2];
