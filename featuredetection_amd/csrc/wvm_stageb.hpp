@@ -851,6 +851,9 @@ static void launch_stageb(fd_ctx* ctx, hipStream_t st, int64_t total, fd_wvm* m,
             if (tiles <= 16) {   // a frame or two: more, smaller units (k_wvb_sums)
                 const dim3 gridQ(wvb_grid8(std::min<int64_t>((tiles + 3) / 4 * ((k1 - k0 + 1) / 2), (int64_t)cus * 8)));
                 hipLaunchKernelGGL((k_wvb_sums<2, 4>), gridQ, dim3(256), 0, st, mv, s, ph, countPtr);
+            } else if (tiles >= 4096 && WVB_RB == 8) {   // a quarter of a million windows alive: the K history streamed half as often (cascade_group 593 against 568)
+                const dim3 gridL(wvb_grid8(std::min<int64_t>((tiles + 3) / 4 * ((k1 - k0 + 15) / 16), (int64_t)cus * 8)));
+                hipLaunchKernelGGL((k_wvb_sums<16, 2>), gridL, dim3(256), 0, st, mv, s, ph, countPtr);
             } else {
                 hipLaunchKernelGGL((k_wvb_sums<WVB_RB, 2>), gridS, dim3(256), 0, st, mv, s, ph, countPtr);
             }
