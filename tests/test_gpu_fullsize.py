@@ -191,6 +191,28 @@ def test_grouped_prefilter_equals_separate_launches(oracle, capi, ctx, synth, mo
         p_.close()
 
 
+def test_abandoned_batch_ticket_is_ended_and_handles_stay_usable(capi, ctx, synth, small_models):
+    """Between fd_five_stage_batch_begin and _end the library's queue threads write the jobs' outputs; a ticket that is dropped without
+    end() is ended by the binding (the job arrays stay alive until then), and the same handles run the next batch with the same result."""
+    wm, sm = small_models
+    frame = synth.make_frame(640, 480, seed=31)
+    p = capi.Pyramid(ctx, **FF_)
+    p.update(frame)
+    hs = [(capi.Wvm(ctx, wm), capi.Svm(ctx, sm)) for _ in range(3)]
+    jobs = [(p, w, s) for w, s in hs]
+    want = capi.detect_five_stage_batch(ctx, jobs, cap=4096)
+    t = capi.FiveStageBatch(ctx, jobs, cap=4096)
+    del t   # never ended by the caller
+    import gc
+    gc.collect()
+    got = capi.FiveStageBatch(ctx, jobs, cap=4096).end()
+    for (dw, sw), (dg, sg) in zip(want, got):
+        assert np.array_equal(sw, sg) and dw.tobytes() == dg.tobytes()
+    for w, s in hs:
+        w.close(); s.close()
+    p.close()
+
+
 @pytest.mark.parametrize("step,roi", [(1, None), (2, None), (1, (200, 100, 700, 500)), (3, (-30, -20, 400, 300))])
 def test_wvm_production_path_equals_exact_path(oracle, capi, ctx, synth, step, roi):
     """fd_detect_wvm without per-window outputs takes the production path (dense pre-filter on the matrix pipe, exact cascade on
