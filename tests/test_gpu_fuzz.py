@@ -17,7 +17,7 @@ def _fuzz():
     return mod
 
 
-@pytest.mark.parametrize("kind", ["pyramid", "cascade", "frames", "hist", "fhog", "aggregated", "svm", "hog_svm", "rvm", "whi", "sdm", "hog_fused", "batch_tail"])
+@pytest.mark.parametrize("kind", ["pyramid", "cascade", "frames", "hist", "fhog", "aggregated", "svm", "hog_svm", "rvm", "whi", "sdm", "hog_fused", "batch_tail", "batch_group"])
 def test_fuzzed_parity(capi, ctx, oracle, kind):
     fz = _fuzz()
     bad, ran = [], 0
